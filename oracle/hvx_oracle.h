@@ -1,0 +1,121 @@
+/*
+ * hvx_oracle.h -- CPU ORACLE for the HelixDB vector-search hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may link or call it.  The shipped library
+ * (helix-db_amd/csrc, libhelix_vec_gfx950.so) never includes, links or calls anything here.
+ *
+ * It is a plain-C restatement of the reference's algorithm (the Rust reference cannot be
+ * compiled in this environment: no cargo/rustc).  Every function
+ * cites the reference file:line it follows; paths are relative to
+ * /root/reference/crates/db/src/search/vector/ unless written out.
+ *
+ * Parity pin: tests/test_oracle_golden.py checks this oracle against every golden vector /
+ * known-answer test the reference's own tests hold for this path.
+ */
+#ifndef HVX_ORACLE_H
+#define HVX_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* distance metrics: mod.rs:283-290, distance/semantics.rs:31-56 */
+enum { ORC_COSINE = 0, ORC_L2SQ = 1, ORC_L1 = 2 };
+
+/* float kernel = which summation tree the reference takes on a given host
+ * (spaces/simple.rs:45-112).  AVX_FMA is what an x86-64 host with avx+fma runs. */
+enum {
+    ORC_KERNEL_SCALAR = 0,
+    ORC_KERNEL_SSE = 1,
+    ORC_KERNEL_AVX = 2,
+    ORC_KERNEL_AVX_FMA = 3,
+    ORC_KERNEL_NEON = 4
+};
+
+/* statuses mirror include/helix_vec.h (hvx_status) */
+enum {
+    ORC_OK = 0,
+    ORC_ERR_DIMENSION = 1,
+    ORC_ERR_NONFINITE = 2,
+    ORC_ERR_ZERO_NORM = 3,
+    ORC_ERR_MAGNITUDE = 4,
+    ORC_ERR_K_RANGE = 5,
+    ORC_ERR_CANDIDATE_LIMIT = 6,
+    ORC_ERR_DEVICE = 7,
+    ORC_ERR_INVARIANT = 8
+};
+
+/* ---- distance kernels (spaces/simple.rs, simple_avx.rs, simple_sse.rs, simple_neon.rs) ---- */
+float orc_euclidean(const float *a, const float *b, uint32_t n, int kernel);
+float orc_dot(const float *a, const float *b, uint32_t n, int kernel);
+float orc_manhattan(const float *a, const float *b, uint32_t n);
+/* hardware AVX2+FMA twin of ORC_KERNEL_AVX_FMA (used by the timed cpu_baseline and to prove the
+ * portable fmaf emulation equals the real instructions); returns NaN if not compiled in. */
+float orc_euclidean_avxfma_hw(const float *a, const float *b, uint32_t n);
+float orc_dot_avxfma_hw(const float *a, const float *b, uint32_t n);
+int orc_have_avxfma_hw(void);
+
+double orc_scaled_l2_norm(const float *v, uint32_t n);                 /* distance/cosine.rs:12-36 */
+float orc_header(int metric, const float *v, uint32_t n);              /* new_header            */
+float orc_distance(int metric, int kernel, const float *p, float p_hdr, const float *q, float q_hdr,
+                   uint32_t n);                                        /* Distance::distance    */
+
+/* ---- validation (domain.rs:18-157) ---- */
+float orc_component_limit(int metric, uint32_t dim);                   /* 0 => no limit (cosine) */
+int orc_validate_vector(int metric, const float *v, uint32_t n_actual, uint32_t dim, uint32_t *bad_index);
+/* DistanceScore::try_new (parameters.rs:243-274): 0 ok (normalises -0), else ORC_ERR_INVARIANT */
+int orc_distance_score(float *score);
+
+/* layer draw (mod.rs:769-796) */
+uint16_t orc_select_layer_from_uniform(float ml, float uniform);
+float orc_default_ml_for_m(uint32_t m);                                 /* mod.rs:705-708 */
+
+/* ---- index ---- */
+typedef struct orc_index orc_index;
+
+typedef struct {
+    uint32_t expansion_steps;
+    uint32_t neighbors_examined;
+    uint32_t vectors_loaded;
+    uint32_t distance_computations;
+} orc_stats;
+
+orc_index *orc_index_new(uint32_t dim, int metric, int kernel, uint32_t m, uint32_t m0,
+                         uint32_t ef_construction);
+void orc_index_free(orc_index *);
+/* insert one row (mutation.rs:642-780 + insert_hnsw :787-895); node ids may come in any order.
+ * level is the scripted layer (reference: with_scripted_layers / select_layer). */
+int orc_index_insert(orc_index *, uint64_t node_id, const float *vector, uint16_t level);
+/* seed a pre-built graph (scale_contracts.rs:95-155 style): rows given as CSR over node ids. */
+int orc_index_seed(orc_index *, uint64_t n, const uint64_t *node_ids, const float *vectors,
+                   const uint64_t *l0_offsets, const uint64_t *l0_neighbors,
+                   const uint16_t *level, const uint64_t *up_offsets, const uint64_t *up_neighbors,
+                   int has_entry, uint64_t entry_point, uint16_t max_layer);
+uint64_t orc_index_count(const orc_index *);
+int orc_index_entry(const orc_index *, uint64_t *entry_point, uint16_t *max_layer);
+/* export in the import layout of include/helix_vec.h (ids ascending).  Pass NULL to size. */
+uint64_t orc_index_export_sizes(const orc_index *, uint64_t *l0_edges, uint64_t *up_rows, uint64_t *up_edges);
+int orc_index_export(const orc_index *, uint64_t *node_ids, float *vectors, uint64_t *l0_offsets,
+                     uint64_t *l0_neighbors, uint16_t *level, uint64_t *up_offsets,
+                     uint64_t *up_neighbors);
+
+/* SearchSession::run, strict-exhaustive arm (search.rs:1101-1230, :169-224, :267-1067 STRICT). */
+int orc_search(const orc_index *, const float *query, uint32_t query_len, uint32_t k, uint32_t ef,
+               uint64_t *out_ids, float *out_scores, uint32_t *out_count, orc_stats *stats);
+/* exact scan over all rows or over an allowed id list (restricted.rs:753-835, :661-704). */
+int orc_flat_search(const orc_index *, const float *query, uint32_t query_len, uint32_t k,
+                    const uint64_t *allowed_ids, uint64_t n_allowed, uint64_t *out_ids,
+                    float *out_scores, uint32_t *out_count);
+/* exact scan over a bare matrix (no index object): rows [n][dim], ids = row numbers. */
+int orc_flat_search_matrix(int metric, int kernel, const float *rows, uint64_t n, uint32_t dim,
+                           const float *query, uint32_t k, uint64_t *out_ids, float *out_scores,
+                           uint32_t *out_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

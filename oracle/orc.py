@@ -1,0 +1,271 @@
+"""ctypes binding of the CPU oracle (oracle/hvx_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product library (helix-db_amd/) never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libhvx_oracle.so")
+
+COSINE, L2SQ, L1 = 0, 1, 2
+K_SCALAR, K_SSE, K_AVX, K_AVX_FMA, K_NEON = 0, 1, 2, 3, 4
+OK, ERR_DIMENSION, ERR_NONFINITE, ERR_ZERO_NORM, ERR_MAGNITUDE, ERR_K_RANGE, ERR_CANDIDATE_LIMIT, \
+    ERR_DEVICE, ERR_INVARIANT = range(9)
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+_lib = None
+
+f32p = C.POINTER(C.c_float)
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+u16p = C.POINTER(C.c_uint16)
+
+
+class Stats(C.Structure):
+    _fields_ = [("expansion_steps", C.c_uint32), ("neighbors_examined", C.c_uint32),
+                ("vectors_loaded", C.c_uint32), ("distance_computations", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    L = C.CDLL(build())
+    L.orc_euclidean.restype = C.c_float
+    L.orc_euclidean.argtypes = [f32p, f32p, C.c_uint32, C.c_int]
+    L.orc_dot.restype = C.c_float
+    L.orc_dot.argtypes = [f32p, f32p, C.c_uint32, C.c_int]
+    L.orc_manhattan.restype = C.c_float
+    L.orc_manhattan.argtypes = [f32p, f32p, C.c_uint32]
+    L.orc_euclidean_avxfma_hw.restype = C.c_float
+    L.orc_euclidean_avxfma_hw.argtypes = [f32p, f32p, C.c_uint32]
+    L.orc_dot_avxfma_hw.restype = C.c_float
+    L.orc_dot_avxfma_hw.argtypes = [f32p, f32p, C.c_uint32]
+    L.orc_have_avxfma_hw.restype = C.c_int
+    L.orc_scaled_l2_norm.restype = C.c_double
+    L.orc_scaled_l2_norm.argtypes = [f32p, C.c_uint32]
+    L.orc_header.restype = C.c_float
+    L.orc_header.argtypes = [C.c_int, f32p, C.c_uint32]
+    L.orc_distance.restype = C.c_float
+    L.orc_distance.argtypes = [C.c_int, C.c_int, f32p, C.c_float, f32p, C.c_float, C.c_uint32]
+    L.orc_component_limit.restype = C.c_float
+    L.orc_component_limit.argtypes = [C.c_int, C.c_uint32]
+    L.orc_validate_vector.restype = C.c_int
+    L.orc_validate_vector.argtypes = [C.c_int, f32p, C.c_uint32, C.c_uint32, u32p]
+    L.orc_distance_score.restype = C.c_int
+    L.orc_distance_score.argtypes = [f32p]
+    L.orc_select_layer_from_uniform.restype = C.c_uint16
+    L.orc_select_layer_from_uniform.argtypes = [C.c_float, C.c_float]
+    L.orc_default_ml_for_m.restype = C.c_float
+    L.orc_default_ml_for_m.argtypes = [C.c_uint32]
+    L.orc_index_new.restype = C.c_void_p
+    L.orc_index_new.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.orc_index_free.argtypes = [C.c_void_p]
+    L.orc_index_insert.restype = C.c_int
+    L.orc_index_insert.argtypes = [C.c_void_p, C.c_uint64, f32p, C.c_uint16]
+    L.orc_index_seed.restype = C.c_int
+    L.orc_index_seed.argtypes = [C.c_void_p, C.c_uint64, u64p, f32p, u64p, u64p, u16p, u64p, u64p,
+                                 C.c_int, C.c_uint64, C.c_uint16]
+    L.orc_index_count.restype = C.c_uint64
+    L.orc_index_count.argtypes = [C.c_void_p]
+    L.orc_index_entry.restype = C.c_int
+    L.orc_index_entry.argtypes = [C.c_void_p, u64p, u16p]
+    L.orc_index_export_sizes.restype = C.c_uint64
+    L.orc_index_export_sizes.argtypes = [C.c_void_p, u64p, u64p, u64p]
+    L.orc_index_export.restype = C.c_int
+    L.orc_index_export.argtypes = [C.c_void_p, u64p, f32p, u64p, u64p, u16p, u64p, u64p]
+    L.orc_search.restype = C.c_int
+    L.orc_search.argtypes = [C.c_void_p, f32p, C.c_uint32, C.c_uint32, C.c_uint32, u64p, f32p, u32p,
+                             C.POINTER(Stats)]
+    L.orc_flat_search.restype = C.c_int
+    L.orc_flat_search.argtypes = [C.c_void_p, f32p, C.c_uint32, C.c_uint32, u64p, C.c_uint64, u64p,
+                                  f32p, u32p]
+    L.orc_flat_search_matrix.restype = C.c_int
+    L.orc_flat_search_matrix.argtypes = [C.c_int, C.c_int, f32p, C.c_uint64, C.c_uint32, f32p,
+                                         C.c_uint32, u64p, f32p, u32p]
+    _extra_signatures(L)
+    _lib = L
+    return L
+
+
+def _extra_signatures(L):
+    """Signatures of the optional oracle translation units (simhash, restricted, traverse)."""
+    if hasattr(L, "orc_simhash_planes"):
+        L.orc_simhash_planes.restype = C.c_int
+        L.orc_simhash_planes.argtypes = [C.c_uint32, C.c_uint64, f32p]
+        L.orc_simhash_hash.restype = C.c_uint64
+        L.orc_simhash_hash.argtypes = [f32p, f32p, C.c_uint32]
+        L.orc_order_code.restype = C.c_uint64
+        L.orc_order_code.argtypes = [C.c_uint64]
+        L.orc_stdrng_u32.restype = None
+        L.orc_stdrng_u32.argtypes = [C.c_uint64, u32p, C.c_uint32]
+    if hasattr(L, "orc_traverse"):
+        L.orc_traverse.restype = C.c_int64
+    if hasattr(L, "orc_search_restricted"):
+        L.orc_search_restricted.restype = C.c_int
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(f32p)
+
+
+def euclidean(a, b, kernel=K_AVX_FMA):
+    a, pa = _f(a); b, pb = _f(b)
+    return np.float32(lib().orc_euclidean(pa, pb, a.size, kernel))
+
+
+def dot(a, b, kernel=K_AVX_FMA):
+    a, pa = _f(a); b, pb = _f(b)
+    return np.float32(lib().orc_dot(pa, pb, a.size, kernel))
+
+
+def manhattan(a, b):
+    a, pa = _f(a); b, pb = _f(b)
+    return np.float32(lib().orc_manhattan(pa, pb, a.size))
+
+
+def header(metric, v):
+    v, pv = _f(v)
+    return np.float32(lib().orc_header(metric, pv, v.size))
+
+
+def distance(metric, a, b, kernel=K_AVX_FMA):
+    a, pa = _f(a); b, pb = _f(b)
+    return np.float32(lib().orc_distance(metric, kernel, pa, header(metric, a), pb, header(metric, b), a.size))
+
+
+def validate(metric, v, dim):
+    v, pv = _f(v)
+    bad = C.c_uint32(0)
+    rc = lib().orc_validate_vector(metric, pv, v.size, dim, C.byref(bad))
+    return rc, int(bad.value)
+
+
+class Index:
+    """Oracle index: the reference's VectorIndex<D> restated over dense arrays."""
+
+    def __init__(self, dim, metric, kernel=K_AVX_FMA, m=16, m0=32, ef_construction=200):
+        self.dim, self.metric, self.kernel = dim, metric, kernel
+        self.m, self.m0, self.efc = m, m0, ef_construction
+        self._h = lib().orc_index_new(dim, metric, kernel, m, m0, ef_construction)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_index_free(self._h)
+            self._h = None
+
+    def insert(self, node_id, vector, level):
+        v, pv = _f(vector)
+        assert v.size == self.dim
+        return lib().orc_index_insert(self._h, int(node_id), pv, int(level))
+
+    def seed(self, node_ids, vectors, l0_offsets, l0_neighbors, level=None, up_offsets=None,
+             up_neighbors=None, entry_point=None, max_layer=0):
+        ids = np.ascontiguousarray(node_ids, dtype=np.uint64)
+        vec, pvec = _f(vectors)
+        o0 = np.ascontiguousarray(l0_offsets, dtype=np.uint64)
+        n0 = np.ascontiguousarray(l0_neighbors, dtype=np.uint64)
+        lv = None if level is None else np.ascontiguousarray(level, dtype=np.uint16)
+        uo = np.zeros(1, np.uint64) if up_offsets is None else np.ascontiguousarray(up_offsets, dtype=np.uint64)
+        un = np.zeros(1, np.uint64) if up_neighbors is None else np.ascontiguousarray(up_neighbors, dtype=np.uint64)
+        return lib().orc_index_seed(
+            self._h, ids.size, ids.ctypes.data_as(u64p), pvec, o0.ctypes.data_as(u64p),
+            n0.ctypes.data_as(u64p), None if lv is None else lv.ctypes.data_as(u16p),
+            uo.ctypes.data_as(u64p), un.ctypes.data_as(u64p), 0 if entry_point is None else 1,
+            0 if entry_point is None else int(entry_point), int(max_layer))
+
+    @property
+    def count(self):
+        return int(lib().orc_index_count(self._h))
+
+    def entry(self):
+        e, ml = C.c_uint64(0), C.c_uint16(0)
+        if not lib().orc_index_entry(self._h, C.byref(e), C.byref(ml)):
+            return None
+        return int(e.value), int(ml.value)
+
+    def export(self):
+        """Arrays in the hvx_index_import layout (ids ascending)."""
+        e0, ur, ue = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        n = int(lib().orc_index_export_sizes(self._h, C.byref(e0), C.byref(ur), C.byref(ue)))
+        out = dict(
+            node_ids=np.zeros(n, np.uint64), vectors=np.zeros((n, self.dim), np.float32),
+            l0_offsets=np.zeros(n + 1, np.uint64), l0_neighbors=np.zeros(max(e0.value, 1), np.uint64),
+            level=np.zeros(max(n, 1), np.uint16), up_offsets=np.zeros(ur.value + 1, np.uint64),
+            up_neighbors=np.zeros(max(ue.value, 1), np.uint64))
+        lib().orc_index_export(
+            self._h, out["node_ids"].ctypes.data_as(u64p), out["vectors"].ctypes.data_as(f32p),
+            out["l0_offsets"].ctypes.data_as(u64p), out["l0_neighbors"].ctypes.data_as(u64p),
+            out["level"].ctypes.data_as(u16p), out["up_offsets"].ctypes.data_as(u64p),
+            out["up_neighbors"].ctypes.data_as(u64p))
+        out["l0_neighbors"] = out["l0_neighbors"][: e0.value]
+        out["up_neighbors"] = out["up_neighbors"][: ue.value]
+        out["level"] = out["level"][:n]
+        ent = self.entry()
+        out["entry_point"], out["max_layer"] = (ent if ent else (None, 0))
+        return out
+
+    def search(self, query, k, ef, with_stats=False):
+        q, pq = _f(query)
+        ids = np.zeros(max(k, 1), np.uint64)
+        sc = np.zeros(max(k, 1), np.float32)
+        cnt = C.c_uint32(0)
+        st = Stats()
+        rc = lib().orc_search(self._h, pq, q.size, k, ef, ids.ctypes.data_as(u64p),
+                              sc.ctypes.data_as(f32p), C.byref(cnt), C.byref(st))
+        res = (rc, ids[: cnt.value].copy(), sc[: cnt.value].copy())
+        return res + (st.as_dict(),) if with_stats else res
+
+    def flat(self, query, k, allowed=None):
+        q, pq = _f(query)
+        ids = np.zeros(max(k, 1), np.uint64)
+        sc = np.zeros(max(k, 1), np.float32)
+        cnt = C.c_uint32(0)
+        if allowed is None:
+            pa, na = None, 0
+        else:
+            al = np.ascontiguousarray(allowed, dtype=np.uint64)
+            pa, na = al.ctypes.data_as(u64p), al.size
+        rc = lib().orc_flat_search(self._h, pq, q.size, k, pa, na, ids.ctypes.data_as(u64p),
+                                   sc.ctypes.data_as(f32p), C.byref(cnt))
+        return rc, ids[: cnt.value].copy(), sc[: cnt.value].copy()
+
+
+def flat_matrix(metric, rows, query, k, kernel=K_AVX_FMA):
+    rows = np.ascontiguousarray(rows, dtype=np.float32)
+    q, pq = _f(query)
+    ids = np.zeros(max(k, 1), np.uint64)
+    sc = np.zeros(max(k, 1), np.float32)
+    cnt = C.c_uint32(0)
+    rc = lib().orc_flat_search_matrix(metric, kernel, rows.ctypes.data_as(f32p), rows.shape[0],
+                                      rows.shape[1], pq, k, ids.ctypes.data_as(u64p),
+                                      sc.ctypes.data_as(f32p), C.byref(cnt))
+    return rc, ids[: cnt.value].copy(), sc[: cnt.value].copy()
+
+
+def select_layer(ml, uniform):
+    return int(lib().orc_select_layer_from_uniform(np.float32(ml), np.float32(uniform)))
+
+
+def default_ml(m):
+    return np.float32(lib().orc_default_ml_for_m(m))

@@ -1,0 +1,255 @@
+"""Pins the CPU oracle against the reference's own golden vectors / KATs.
+
+Reference paths are under /root/reference/crates/db/ ; nothing here reads that tree at run time.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import fixtures as fx
+
+F32_EPS = np.finfo(np.float32).eps
+F32_MAX = np.finfo(np.float32).max
+
+
+def bits(x):
+    return np.array(x, np.float32).view(np.uint32).tolist()
+
+
+# --- src/search/vector/distance/mod.rs:112-141, tests/production_support/vector/distance_neighbors.rs:82-123
+def test_metric_definitions(orc):
+    assert orc.distance(orc.COSINE, [1, 0], [0, 1]) == np.float32(0.5)
+    assert math.isnan(orc.distance(orc.COSINE, [1, 0], [0, 0]))
+    assert math.isnan(orc.distance(orc.COSINE, [0, 0], [0, 0]))
+    assert orc.header(orc.COSINE, [1, 0]) == np.float32(1.0)
+    assert orc.distance(orc.L2SQ, [1, 2], [4, 6]) == np.float32(25.0)
+    assert orc.distance(orc.L1, [1, -2, 3], [-1, 2, 1]) == np.float32(8.0)
+    # norm_no_header for euclidean/manhattan = sqrt(dot(v,v))
+    assert np.sqrt(orc.dot([4, 6], [4, 6])) == np.sqrt(np.float32(52.0))
+    assert np.sqrt(orc.dot([3, 4], [3, 4])) == np.float32(5.0)
+
+
+# --- src/search/vector/distance/cosine.rs:128-141
+def test_cosine_f32_extremes_stay_finite(orc):
+    huge = [F32_MAX, F32_MAX]
+    assert orc.header(orc.COSINE, huge) == F32_MAX
+    assert orc.distance(orc.COSINE, huge, huge) <= F32_EPS
+    tiny = np.array([1, 1], np.uint32).view(np.float32)
+    assert orc.header(orc.COSINE, tiny) > 0.0
+    assert orc.distance(orc.COSINE, tiny, tiny) <= F32_EPS
+
+
+# --- src/search/vector/spaces/simple_avx.rs:246-293 (70-element integer vectors: SIMD == scalar)
+def test_avx_tree_equals_scalar_on_reference_vectors(orc):
+    blk = [float(x) for x in range(10, 26)]
+    v1 = blk * 4 + [26., 27., 28., 29., 30., 31.]
+    v2 = [float(x) for x in range(40, 56)] + blk * 3 + [56., 57., 58., 59., 60., 61.]
+    for kern in (orc.K_AVX_FMA, orc.K_AVX, orc.K_SSE, orc.K_NEON):
+        assert orc.euclidean(v1, v2, kern) == orc.euclidean(v1, v2, orc.K_SCALAR)
+        assert orc.dot(v1, v2, kern) == orc.dot(v1, v2, orc.K_SCALAR)
+    assert orc.euclidean(v1, v2, orc.K_SCALAR) == np.float32(16 * 900 + 6 * 900)
+
+
+def test_portable_avxfma_emulation_equals_hardware_intrinsics(orc):
+    """The oracle's fmaf emulation of simple_avx.rs:128-238 must equal the real AVX2+FMA instructions."""
+    if not orc.lib().orc_have_avxfma_hw():
+        pytest.skip("oracle built without AVX2+FMA")
+    import ctypes as C
+    rng = np.random.default_rng(7)
+    for n in (32, 33, 63, 64, 70, 128, 768, 1000, 1536):
+        for _ in range(20):
+            a = rng.standard_normal(n).astype(np.float32)
+            b = rng.standard_normal(n).astype(np.float32)
+            pa = a.ctypes.data_as(C.POINTER(C.c_float)); pb = b.ctypes.data_as(C.POINTER(C.c_float))
+            hw_e = np.float32(orc.lib().orc_euclidean_avxfma_hw(pa, pb, n))
+            hw_d = np.float32(orc.lib().orc_dot_avxfma_hw(pa, pb, n))
+            assert bits(hw_e) == bits(orc.euclidean(a, b, orc.K_AVX_FMA))
+            assert bits(hw_d) == bits(orc.dot(a, b, orc.K_AVX_FMA))
+
+
+def test_kernel_dispatch_thresholds(orc):
+    """spaces/simple.rs:32,43,127-143: AVX needs n>=32, SSE/NEON n>=16, else scalar."""
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal(31).astype(np.float32); b = rng.standard_normal(31).astype(np.float32)
+    assert bits(orc.euclidean(a, b, orc.K_AVX_FMA)) == bits(orc.euclidean(a, b, orc.K_SCALAR))
+    a15, b15 = a[:15], b[:15]
+    assert bits(orc.euclidean(a15, b15, orc.K_SSE)) == bits(orc.euclidean(a15, b15, orc.K_SCALAR))
+
+
+# --- src/search/vector/model.rs:69-74, parameters.rs:243-274
+def test_candidate_score_validation(orc):
+    import ctypes as C
+    for bad in (float("nan"), float("inf"), -1.0):
+        v = C.c_float(bad)
+        assert orc.lib().orc_distance_score(C.byref(v)) == orc.ERR_INVARIANT
+    v = C.c_float(-0.0)
+    assert orc.lib().orc_distance_score(C.byref(v)) == orc.OK
+    assert bits(v.value) == bits(0.0)
+
+
+def test_candidate_tie_order_by_node_id(orc):
+    ix = orc.Index(2, orc.L2SQ, m=4, m0=8, ef_construction=16)
+    for nid, v in [(2, [1, 0]), (1, [1, 0]), (3, [-1, 0])]:
+        assert ix.insert(nid, v, 0) == orc.OK
+    rc, ids, sc = ix.flat([1, 0], 3)
+    assert rc == orc.OK and ids.tolist() == [1, 2, 3]
+
+
+# --- src/search/vector/domain.rs:26-157
+def test_validation_order_and_limits(orc):
+    assert orc.validate(orc.L2SQ, [1, 2, 3], 4)[0] == orc.ERR_DIMENSION
+    assert orc.validate(orc.L2SQ, [1, float("nan"), float("inf")], 3) == (orc.ERR_NONFINITE, 1)
+    assert orc.validate(orc.COSINE, [0, 0, 0], 3)[0] == orc.ERR_ZERO_NORM
+    assert orc.validate(orc.L2SQ, [0, 0, 0], 3)[0] == orc.OK
+    lim = orc.lib().orc_component_limit(orc.L2SQ, 768)
+    exact = math.sqrt(float(F32_MAX) / (768 * 8))
+    assert float(lim) <= exact < float(np.nextafter(np.float32(lim), np.float32(np.inf)))
+    assert orc.validate(orc.L2SQ, [lim] * 768, 768)[0] == orc.OK
+    over = np.nextafter(np.float32(lim), np.float32(np.inf))
+    v = np.zeros(768, np.float32); v[5] = -over
+    assert orc.validate(orc.L2SQ, v, 768) == (orc.ERR_MAGNITUDE, 5)
+    lim1 = orc.lib().orc_component_limit(orc.L1, 128)
+    assert float(lim1) <= float(F32_MAX) / (128 * 4)
+    assert orc.lib().orc_component_limit(orc.COSINE, 128) == 0.0
+
+
+# --- src/search/vector/mod.rs:776-796
+def test_select_layer(orc):
+    ml = orc.default_ml(16)
+    assert ml == np.float32(1.0) / np.log(np.float32(16.0))
+    assert orc.select_layer(ml, 0.999) == 0
+    assert orc.select_layer(ml, 0.0) == int(min(63, math.floor(-math.log(np.finfo(np.float32).tiny) * ml)))
+    assert orc.select_layer(ml, float("nan")) == orc.select_layer(ml, 0.5)
+    assert orc.select_layer(float("nan"), 0.001) == orc.select_layer(ml, 0.001)
+    lv = fx.draw_levels(4096, 16, seed=11)
+    for u_idx in range(0, 4096, 97):
+        rng = np.random.Generator(np.random.PCG64(11))
+        u = rng.random(4096, dtype=np.float32)
+        assert orc.select_layer(ml, u[u_idx]) == lv[u_idx]
+        break
+
+
+# --- src/search/vector/index.rs:2318-2412: full build + search pipeline incl. stats, as f32 bit patterns
+def test_phase0_public_result_and_io_baseline(orc):
+    ix = orc.Index(2, orc.COSINE, m=4, m0=8, ef_construction=16)
+    for (nid, v), lvl in zip([(1, [1, 0]), (2, [0, 1]), (3, [-1, 0]), (4, [0, -1])], [0, 1, 2, 0]):
+        assert ix.insert(nid, v, lvl) == orc.OK
+    assert ix.entry() == (3, 2)
+    rc, ids, sc, st = ix.search([1.0, 0.0], 4, 16, with_stats=True)
+    assert rc == orc.OK
+    assert list(zip(ids.tolist(), bits(sc))) == list(zip([1, 2, 4, 3], bits([0.0, 0.5, 0.5, 1.0])))
+    assert st == dict(expansion_steps=4, neighbors_examined=12, vectors_loaded=3, distance_computations=4)
+
+
+# --- src/index_lifecycle/vector/driver.rs:5132-5212: HNSW(ef=N) == brute force sorted (score,id)
+def test_driver_bruteforce_oracle_equivalence(orc):
+    vecs = [[0, 0, 0], [1, 0, 0], [0, 2, 0], [0, 0, 3], [4, 0, 0], [0, 5, 0], [0, 0, 6], [7, 7, 7]]
+    q = np.array([0.25, 0.5, 0.75], np.float32)
+    for levels in ([0] * 8, [0, 1, 0, 0, 2, 0, 1, 0]):
+        ix = orc.Index(3, orc.L2SQ, m=16, m0=32, ef_construction=200)
+        for i, v in enumerate(vecs):
+            assert ix.insert(i, v, levels[i]) == orc.OK
+        rc, ids, sc = ix.search(q, 8, 8)
+        exp = []
+        for i, v in enumerate(vecs):
+            s = np.float32(0.0)
+            for c, qq in zip(np.array(v, np.float32), q):
+                d = np.float32(c - qq)
+                s = np.float32(s + np.float32(d * d))
+            exp.append((s, i))
+        exp.sort()
+        assert rc == orc.OK
+        assert ids.tolist() == [i for _, i in exp]
+        assert bits(sc) == bits([s for s, _ in exp])
+
+
+# --- tests/production_support/vector/restricted.rs:710-787 exact restricted scan, all three metrics
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_exact_restricted_scan_tie_stable(orc, metric):
+    ix = orc.Index(2, metric)
+    ids = np.array([1, 2, 3], np.uint64)
+    vec = np.array([[1, 0], [1, 0], [-1, 0]], np.float32)
+    assert ix.seed(ids, vec, np.zeros(4, np.uint64), np.zeros(0, np.uint64), entry_point=1) == orc.OK
+    rc, got, _ = ix.flat([1.0, 0.0], 10, allowed=[3, 2, 1])
+    assert rc == orc.OK and got.tolist() == [1, 2, 3]
+    # :788-800 absent ids are omitted, not an error
+    rc, got, _ = ix.flat([1.0, 0.0], 10, allowed=[1, 9999])
+    assert rc == orc.OK and got.tolist() == [1]
+
+
+# --- src/search/vector/scale_contracts.rs:45-93,161-216,256-270: circle fixture recall gates
+def _circle_recall(orc, n):
+    ids, vec, offs, nbrs = fx.circle_index_arrays(n)
+    ix = orc.Index(2, orc.COSINE, m=32, m0=64, ef_construction=200)
+    assert ix.seed(ids, vec, offs, nbrs, entry_point=1, max_layer=0) == orc.OK
+    got, truth = [], []
+    for q in fx.circle_queries(n):
+        rc, g, _ = ix.search(q, 10, 64)
+        assert rc == orc.OK
+        rc, t, _ = ix.flat(q, 10)
+        got.append(g); truth.append(t)
+    return fx.recall_at_k(got, truth)
+
+
+def test_circle_fixture_smallest_is_exact(orc):
+    assert _circle_recall(orc, 24) == 1.0
+
+
+def test_circle_fixture_10k_recall_gate(orc):
+    assert _circle_recall(orc, 10_000) >= 0.995
+
+
+# --- tests/production_support/index_lifecycle_scale.rs:410-421,1332-1359: generator + top-1 of vector(0)
+def test_lifecycle_generator_and_flat_top1(orc):
+    m = fx.lifecycle_matrix(8000)
+    assert bits(m[17]) == bits(fx.lifecycle_vector(17))
+    assert np.all(np.abs(m) <= 1.0)
+    rc, ids, sc = orc.flat_matrix(orc.L2SQ, m, fx.lifecycle_vector(0), 1)
+    assert rc == orc.OK and ids.tolist() == [0] and sc[0] == 0.0
+    # the reference's flat oracle arithmetic is sequential f32 sum((c-q)^2): == K_SCALAR kernel
+    q = fx.lifecycle_vector(123) + np.float32(1e-3)
+    s = np.float32(0.0)
+    for c, qq in zip(m[5], q):
+        d = np.float32(c - qq)
+        s = np.float32(s + np.float32(d * d))
+    assert bits(orc.euclidean(m[5], q, orc.K_SCALAR)) == bits(s)
+
+
+def test_parameters_and_empty_index(orc):
+    ix = orc.Index(4, orc.L2SQ)
+    # query is validated before the empty-index early return (search.rs:1120-1128)
+    assert ix.search([1, 2, 3], 1, 1)[0] == orc.ERR_DIMENSION
+    rc, ids, _ = ix.search([1, 2, 3, 4], 5, 10)
+    assert rc == orc.OK and ids.size == 0
+    assert ix.search([1, 2, 3, 4], 5, 4)[0] == orc.ERR_K_RANGE  # ef >= k (parameters.rs:118-133)
+    assert ix.search([1, 2, 3, 4], 0, 4)[0] == orc.ERR_K_RANGE
+
+
+def test_built_graph_invariants_and_recall(orc):
+    """Build with the restated insert_hnsw; rows must be canonical (sorted, deduped, self-free,
+    degree-bounded, symmetric: mutation.rs:1498-1583, neighbor_set.rs:1-9) and search must recall."""
+    n, dim = 3000, 32
+    rng = np.random.default_rng(5)
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    lv = fx.draw_levels(n, 16, seed=7)
+    ix = orc.Index(dim, orc.L2SQ, m=16, m0=32, ef_construction=100)
+    for i in range(n):
+        assert ix.insert(i, data[i], lv[i]) == orc.OK
+    ex = ix.export()
+    off, nb = ex["l0_offsets"], ex["l0_neighbors"]
+    adj = [set(nb[off[i]:off[i + 1]].tolist()) for i in range(n)]
+    for i in range(n):
+        row = nb[off[i]:off[i + 1]]
+        assert len(row) <= 32 and i not in adj[i]
+        assert np.all(np.diff(row.astype(np.int64)) > 0)
+        for j in adj[i]:
+            assert i in adj[j]
+    assert ex["max_layer"] == int(lv.max())
+    got, truth = [], []
+    for qi in range(50):
+        q = rng.standard_normal(dim).astype(np.float32)
+        _, g, _ = ix.search(q, 10, 100)
+        _, t, _ = ix.flat(q, 10)
+        got.append(g); truth.append(t)
+    assert fx.recall_at_k(got, truth) >= 0.9

@@ -1,0 +1,566 @@
+// hvx_api.hip -- host side of the C ABI (include/helix_vec.h): index import, batched search entry
+// points, scratch management.  No torch types, no CPU compute fallback: every search runs on the
+// gfx950 kernels or fails with HVX_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "hvx_host.h"
+
+using namespace hvx;
+
+namespace {
+thread_local std::string g_err;
+}
+
+namespace hvx {
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+} // namespace hvx
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) return fail(HVX_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+extern "C" const char *hvx_last_error(void) { return g_err.c_str(); }
+extern "C" const char *hvx_version(void) { return "helix_vec_gfx950 0.1 (round 1)"; }
+
+// domain.rs:26-78 VectorComponentLimit::try_new
+float hvx::component_limit(uint32_t metric, uint32_t dim) {
+    if (metric == kCosine) return INFINITY;
+    const double factor = metric == kL2 ? 8.0 : 4.0;
+    const double divisor = (double)((uint64_t)dim * (uint64_t)factor);
+    const double fmax = 3.4028234663852886e+38;
+    const double exact = metric == kL2 ? std::sqrt(fmax / divisor) : fmax / divisor;
+    float rounded = (float)exact;
+    if ((double)rounded > exact) {
+        uint32_t bits;
+        memcpy(&bits, &rounded, 4);
+        bits -= 1;
+        memcpy(&rounded, &bits, 4);
+    }
+    return rounded;
+}
+
+template <typename F> static void parallel_for(uint64_t n, F f) {
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 4;
+    if (nt > 16) nt = 16;
+    if (n < 4096) nt = 1;
+    std::vector<std::thread> th;
+    const uint64_t per = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; ++t) {
+        uint64_t lo = t * per, hi = std::min(n, lo + per);
+        if (lo >= hi) break;
+        th.emplace_back([=] { f(lo, hi); });
+    }
+    for (auto &x : th) x.join();
+}
+
+static void free_index(hvx_index *ix) {
+    if (!ix) return;
+    hipSetDevice(ix->device);
+    for (void *p : ix->allocs) hipFree(p);
+    if (ix->ev0) hipEventDestroy(ix->ev0);
+    if (ix->ev1) hipEventDestroy(ix->ev1);
+    if (ix->stream) hipStreamDestroy(ix->stream);
+    delete ix;
+}
+
+extern "C" void hvx_index_free(hvx_index *ix) { free_index(ix); }
+
+extern "C" int hvx_index_sync(const hvx_index *ix) {
+    if (!ix) return fail(HVX_ERR_INVARIANT, "null index");
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    return HVX_OK;
+}
+
+extern "C" void *hvx_index_stream(const hvx_index *ix) { return ix ? (void *)ix->stream : nullptr; }
+
+int hvx_index::dalloc(void **p, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return fail(HVX_ERR_DEVICE, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    allocs.push_back(*p);
+    return HVX_OK;
+}
+
+static uint32_t round_up(uint32_t x, uint32_t m) { return (x + m - 1) / m * m; }
+
+extern "C" int hvx_index_import(const hvx_index_desc *desc, const uint64_t *node_ids, const float *vectors,
+                                const uint64_t *l0_offsets, const uint64_t *l0_neighbors,
+                                const uint16_t *level, const uint64_t *up_offsets,
+                                const uint64_t *up_neighbors, hvx_index **out) {
+    if (!desc || !out) return fail(HVX_ERR_INVARIANT, "null argument");
+    *out = nullptr;
+    if (desc->dim == 0) return fail(HVX_ERR_DIMENSION, "dimension must be non-zero");
+    if (desc->metric > HVX_MANHATTAN) return fail(HVX_ERR_UNSUPPORTED, "unknown metric %u", desc->metric);
+    if (desc->dtype != HVX_F32)
+        return fail(HVX_ERR_UNSUPPORTED, "device dtype %u not built yet (f32 is the reference's only active codec)",
+                    desc->dtype);
+    if (desc->float_kernel != HVX_KERNEL_SCALAR && desc->float_kernel != HVX_KERNEL_AVX &&
+        desc->float_kernel != HVX_KERNEL_AVX_FMA)
+        return fail(HVX_ERR_UNSUPPORTED, "float kernel %u not supported on device", desc->float_kernel);
+    if (desc->n >= (1ull << 31)) return fail(HVX_ERR_UNSUPPORTED, "shard too large (n < 2^31)");
+    const uint64_t n = desc->n;
+    if (n && (!node_ids || !vectors || !l0_offsets)) return fail(HVX_ERR_INVARIANT, "null array");
+
+    int dev = desc->device;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipSetDevice(dev));
+
+    hvx_index *ix = new hvx_index();
+    ix->device = dev;
+    ix->desc = *desc;
+    ix->limit = component_limit(desc->metric, desc->dim);
+    ix->max_batch = desc->max_batch ? desc->max_batch : 1024;
+    DevIndex &d = ix->dev;
+    memset(&d, 0, sizeof(d));
+    d.n = (uint32_t)n;
+    d.dim = desc->dim;
+    d.ld = round_up(desc->dim, 4);
+    d.metric = desc->metric;
+    d.fkernel = desc->float_kernel;
+    d.dim_main = (desc->float_kernel == HVX_KERNEL_SCALAR || desc->dim < 32) ? 0u : desc->dim - desc->dim % 32u;
+    d.max_layer = desc->max_layer;
+    d.has_entry = (desc->has_entry && n) ? 1u : 0u;
+    if (desc->max_layer > 63) { free_index(ix); return fail(HVX_ERR_INVARIANT, "max_layer > 63"); }
+
+    auto bail = [&](int code) { free_index(ix); return code; };
+    if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ix->ev0) != hipSuccess || hipEventCreate(&ix->ev1) != hipSuccess)
+        return bail(fail(HVX_ERR_DEVICE, "stream/event creation failed"));
+
+    // ---- ids: strictly ascending; contiguous ranges get an arithmetic id->index map ----
+    ix->ids.assign(node_ids, node_ids + n);
+    ix->contiguous = true;
+    for (uint64_t i = 1; i < n; ++i) {
+        if (node_ids[i] <= node_ids[i - 1]) return bail(fail(HVX_ERR_INVARIANT, "node_ids must be strictly ascending (row %llu)", (unsigned long long)i));
+        if (node_ids[i] != node_ids[0] + i) ix->contiguous = false;
+    }
+    if (d.has_entry) {
+        uint32_t e = ix->find(desc->entry_point);
+        if (e == kSentinel) return bail(fail(HVX_ERR_INVARIANT, "entry point %llu is not a row of this shard", (unsigned long long)desc->entry_point));
+        d.entry = e;
+    }
+
+    // ---- graph: CSR over external ids -> fixed-stride rows of internal ids ----
+    uint64_t max_deg = 0, up_rows = 0, max_up = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (l0_offsets[i + 1] < l0_offsets[i]) return bail(fail(HVX_ERR_INVARIANT, "l0_offsets not monotone"));
+        max_deg = std::max<uint64_t>(max_deg, l0_offsets[i + 1] - l0_offsets[i]);
+        if (level) up_rows += level[i];
+    }
+    if (level && up_rows && (!up_offsets || !up_neighbors)) return bail(fail(HVX_ERR_INVARIANT, "upper rows missing"));
+    for (uint64_t r = 0; r < up_rows; ++r) max_up = std::max<uint64_t>(max_up, up_offsets[r + 1] - up_offsets[r]);
+    d.s0 = round_up((uint32_t)std::max<uint64_t>(max_deg, 1), 32);
+    d.su = round_up((uint32_t)std::max<uint64_t>(max_up, 1), 16);
+    if (d.s0 > 128 || d.su > 128) return bail(fail(HVX_ERR_UNSUPPORTED, "neighbour rows longer than 128 are not supported (l0 %llu, upper %llu)", (unsigned long long)max_deg, (unsigned long long)max_up));
+
+    std::vector<uint32_t> h_l0((size_t)n * d.s0, kSentinel);
+    std::atomic<int> graph_err{0};
+    auto convert_row = [&](const uint64_t *src, uint64_t cnt, uint32_t *dst, uint64_t self) -> bool {
+        uint64_t prev = 0;
+        for (uint64_t t = 0; t < cnt; ++t) {
+            // rows are canonical: ascending, deduped, self-free (neighbor_set.rs:1-9, values/vectors.rs:97-111)
+            if (t && src[t] <= prev) return false;
+            prev = src[t];
+            uint32_t x = ix->find(src[t]);
+            if (x == kSentinel || x == self) return false;
+            dst[t] = x;
+        }
+        return true;
+    };
+    parallel_for(n, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t i = lo; i < hi; ++i)
+            if (!convert_row(l0_neighbors + l0_offsets[i], l0_offsets[i + 1] - l0_offsets[i], &h_l0[(size_t)i * d.s0], i))
+                graph_err = 1;
+    });
+    if (graph_err) return bail(fail(HVX_ERR_INVARIANT, "layer-0 row is not canonical (ascending, deduped, self-free, known ids)"));
+
+    std::vector<uint32_t> h_up((size_t)std::max<uint64_t>(up_rows, 1) * d.su, kSentinel);
+    std::vector<uint32_t> h_up_base(std::max<uint64_t>(n, 1), kSentinel);
+    std::vector<uint16_t> h_level(std::max<uint64_t>(n, 1), 0);
+    {
+        uint64_t r = 0;
+        for (uint64_t i = 0; i < n; ++i) {
+            uint16_t lv = level ? level[i] : 0;
+            if (lv > 63) return bail(fail(HVX_ERR_INVARIANT, "node level > 63"));
+            h_level[i] = lv;
+            if (lv) {
+                h_up_base[i] = (uint32_t)r;
+                for (uint16_t l = 0; l < lv; ++l, ++r)
+                    if (!convert_row(up_neighbors + up_offsets[r], up_offsets[r + 1] - up_offsets[r], &h_up[(size_t)r * d.su], i))
+                        return bail(fail(HVX_ERR_INVARIANT, "upper row of node %llu is not canonical", (unsigned long long)node_ids[i]));
+            }
+        }
+    }
+    if (d.has_entry && h_level[d.entry] < d.max_layer)
+        return bail(fail(HVX_ERR_INVARIANT, "entry point level %u below max_layer %u", h_level[d.entry], d.max_layer));
+
+    // ---- upload ----
+    void *p;
+    int rc;
+    const size_t vec_bytes = (size_t)n * d.ld * 4;
+    if ((rc = ix->dalloc(&p, vec_bytes))) return bail(rc);
+    d.vec = (const float *)p;
+    if (n) {
+        if (d.ld == d.dim) {
+            if (hipMemcpy(p, vectors, vec_bytes, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(HVX_ERR_DEVICE, "vector upload failed"));
+        } else {
+            if (hipMemset(p, 0, vec_bytes) != hipSuccess ||
+                hipMemcpy2D(p, (size_t)d.ld * 4, vectors, (size_t)d.dim * 4, (size_t)d.dim * 4, n, hipMemcpyHostToDevice) != hipSuccess)
+                return bail(fail(HVX_ERR_DEVICE, "vector upload failed"));
+        }
+    }
+    auto upload = [&](const void *src, size_t bytes, const void **dst) -> int {
+        void *q;
+        int r2 = ix->dalloc(&q, bytes);
+        if (r2) return r2;
+        if (bytes && hipMemcpy(q, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return fail(HVX_ERR_DEVICE, "upload failed");
+        *dst = q;
+        return HVX_OK;
+    };
+    if ((rc = upload(h_l0.data(), h_l0.size() * 4, (const void **)&d.l0))) return bail(rc);
+    if ((rc = upload(h_up.data(), h_up.size() * 4, (const void **)&d.up))) return bail(rc);
+    if ((rc = upload(h_up_base.data(), h_up_base.size() * 4, (const void **)&d.up_base))) return bail(rc);
+    if ((rc = upload(h_level.data(), h_level.size() * 2, (const void **)&d.level))) return bail(rc);
+    if ((rc = upload(ix->ids.data(), std::max<size_t>(ix->ids.size(), 1) * 8, (const void **)&d.ids))) return bail(rc);
+
+    // ---- validate rows + headers ONCE on the device (decode_item_borrowed does it per fetch:
+    //      mod.rs:889-949) ----
+    float *d_hdr;
+    uint32_t *d_rowstatus;
+    if ((rc = ix->dalloc((void **)&d_hdr, std::max<size_t>(n, 1) * 4))) return bail(rc);
+    d.hdr = d_hdr;
+    if (n) {
+        if (hipMalloc((void **)&d_rowstatus, n * 4) != hipSuccess) return bail(fail(HVX_ERR_DEVICE, "hipMalloc row status"));
+        // rows are laid out with stride ld; validate through a DevIndex view whose "dim" stride matches
+        DevIndex view = d;
+        hipError_t e = launch_validate_rows(view, (uint32_t)n, ix->limit, d_rowstatus, d_hdr, ix->stream);
+        std::vector<uint32_t> st(n);
+        if (e == hipSuccess) e = hipMemcpyAsync(st.data(), d_rowstatus, n * 4, hipMemcpyDeviceToHost, ix->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+        hipFree(d_rowstatus);
+        if (e != hipSuccess) return bail(fail(HVX_ERR_DEVICE, "row validation: %s", hipGetErrorString(e)));
+        for (uint64_t i = 0; i < n; ++i)
+            if (st[i]) return bail(fail((int)st[i], "stored vector of node %llu is invalid for this metric (status %u)", (unsigned long long)node_ids[i], st[i]));
+    }
+
+    // ---- per-batch scratch ----
+    const uint32_t mb = ix->max_batch;
+    ix->words_per_query = round_up((uint32_t)((n + 31) / 32), 4);
+    if (ix->words_per_query == 0) ix->words_per_query = 4;
+    if ((rc = ix->dalloc((void **)&ix->d_bitmap, (size_t)mb * ix->words_per_query * 4))) return bail(rc);
+    if ((rc = ix->dalloc((void **)&ix->d_qstatus, (size_t)mb * 4))) return bail(rc);
+    if ((rc = ix->dalloc((void **)&ix->d_qhdr, (size_t)mb * 4))) return bail(rc);
+    if ((rc = ix->dalloc((void **)&ix->d_tie, (size_t)mb * 4))) return bail(rc);
+    if ((rc = ix->dalloc((void **)&ix->d_qstats, (size_t)mb * sizeof(hvx_query_stats)))) return bail(rc);
+    *out = ix;
+    return HVX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// staging buffers of the host-pointer API (grown on demand, owned by the index)
+// ---------------------------------------------------------------------------------------------
+int hvx_index::stage(uint32_t b, uint32_t k) {
+    const size_t need_q = (size_t)b * dev.dim * 4, need_o = (size_t)b * k;
+    int rc;
+    if (need_q > cap_q) {
+        if ((rc = dalloc((void **)&s_queries, need_q))) return rc;
+        cap_q = need_q;
+    }
+    if (need_o > cap_o) {
+        if ((rc = dalloc((void **)&s_ids, need_o * 8))) return rc;
+        if ((rc = dalloc((void **)&s_scores, need_o * 4))) return rc;
+        cap_o = need_o;
+    }
+    if (b > cap_b) {
+        if ((rc = dalloc((void **)&s_counts, (size_t)b * 4))) return rc;
+        if ((rc = dalloc((void **)&s_status, (size_t)b * 4))) return rc;
+        cap_b = b;
+    }
+    return HVX_OK;
+}
+
+static int check_k_ef(uint32_t k, uint32_t ef) {
+    // ResultCount / SearchBeamWidth (parameters.rs:100-133)
+    if (k == 0) return fail(HVX_ERR_K_RANGE, "result count must be non-zero");
+    if (ef < k) return fail(HVX_ERR_K_RANGE, "search beam width %u is below the result count %u", ef, k);
+    if (ef + 32 > 1024) return fail(HVX_ERR_UNSUPPORTED, "ef %u exceeds the register-beam limit of 992", ef);
+    return HVX_OK;
+}
+
+static void add_stats(hvx_stats *stats, const std::vector<hvx_query_stats> &qs, const std::vector<uint32_t> &tie,
+                      float ms) {
+    stats->queries += qs.size();
+    for (size_t i = 0; i < qs.size(); ++i) {
+        stats->expansion_steps += qs[i].expansion_steps;
+        stats->neighbors_examined += qs[i].neighbors_examined;
+        stats->vectors_loaded += qs[i].vectors_loaded;
+        stats->distance_computations += qs[i].distance_computations;
+        if (i < tie.size() && tie[i]) stats->tie_overflow_queries += 1;
+    }
+    stats->device_ms += ms;
+}
+
+// enqueue validation + memset + search kernel for one chunk of <= max_batch queries
+static int enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t b, uint32_t k, uint32_t ef,
+                          uint64_t *d_ids, float *d_scores, uint32_t *d_counts, uint32_t *d_status,
+                          hvx_query_stats *d_qstats, bool timed) {
+    hvx_index *ix = const_cast<hvx_index *>(cix);
+    HIP_TRY(launch_validate_queries(ix->dev, d_queries, b, ix->limit, ix->d_qstatus, ix->d_qhdr, ix->stream));
+    if (timed) HIP_TRY(hipEventRecord(ix->ev0, ix->stream));
+    HIP_TRY(hipMemsetAsync(ix->d_bitmap, 0, (size_t)b * ix->words_per_query * 4, ix->stream));
+    HnswArgs a;
+    a.ix = ix->dev;
+    a.queries = d_queries;
+    a.qstatus = ix->d_qstatus;
+    a.qhdr = ix->d_qhdr;
+    a.bitmap = ix->d_bitmap;
+    a.words_per_query = ix->words_per_query;
+    a.k = k;
+    a.ef = ef;
+    a.out_ids = d_ids;
+    a.out_scores = d_scores;
+    a.out_counts = d_counts;
+    a.out_status = d_status;
+    a.qstats = d_qstats ? d_qstats : ix->d_qstats;
+    a.tie_flags = ix->d_tie;
+    HIP_TRY(launch_hnsw_search(a, b, ix->stream));
+    if (timed) HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
+    return HVX_OK;
+}
+
+static int collect_stats(hvx_index *ix, uint32_t b, const hvx_query_stats *d_qstats, hvx_stats *stats) {
+    std::vector<hvx_query_stats> qs(b);
+    std::vector<uint32_t> tie(b);
+    HIP_TRY(hipMemcpyAsync(qs.data(), d_qstats ? d_qstats : ix->d_qstats, (size_t)b * sizeof(hvx_query_stats), hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipMemcpyAsync(tie.data(), ix->d_tie, (size_t)b * 4, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
+    add_stats(stats, qs, tie, ms);
+    return HVX_OK;
+}
+
+extern "C" int hvx_search_batch_device(const hvx_index *cix, const float *d_queries, uint32_t b, uint32_t k,
+                                       uint32_t ef, uint64_t *d_out_ids, float *d_out_scores,
+                                       uint32_t *d_out_counts, uint32_t *d_out_status,
+                                       hvx_query_stats *d_query_stats, hvx_stats *stats) {
+    if (!cix) return fail(HVX_ERR_INVARIANT, "null index");
+    hvx_index *ix = const_cast<hvx_index *>(cix);
+    int rc = check_k_ef(k, ef);
+    if (rc) return rc;
+    if (b == 0) return HVX_OK;
+    if (b > ix->max_batch) return fail(HVX_ERR_UNSUPPORTED, "batch %u exceeds max_batch %u given at import", b, ix->max_batch);
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    rc = enqueue_search(ix, d_queries, b, k, ef, d_out_ids, d_out_scores, d_out_counts, d_out_status, d_query_stats, stats != nullptr);
+    if (rc) return rc;
+    if (stats) return collect_stats(ix, b, d_query_stats, stats);
+    return HVX_OK;
+}
+
+extern "C" int hvx_search_batch(const hvx_index *cix, const float *queries, uint32_t b, uint32_t k, uint32_t ef,
+                                uint64_t *out_ids, float *out_scores, uint32_t *out_counts,
+                                uint32_t *out_status, hvx_stats *stats) {
+    if (!cix) return fail(HVX_ERR_INVARIANT, "null index");
+    hvx_index *ix = const_cast<hvx_index *>(cix);
+    int rc = check_k_ef(k, ef);
+    if (rc) return rc;
+    if (b == 0) return HVX_OK;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    const uint32_t mb = ix->max_batch;
+    std::vector<uint32_t> status(b, 0);
+    for (uint32_t c0 = 0; c0 < b; c0 += mb) {
+        const uint32_t cb = std::min(mb, b - c0);
+        if ((rc = ix->stage(cb, k))) return rc;
+        HIP_TRY(hipMemcpyAsync(ix->s_queries, queries + (size_t)c0 * ix->dev.dim, (size_t)cb * ix->dev.dim * 4, hipMemcpyHostToDevice, ix->stream));
+        rc = enqueue_search(ix, ix->s_queries, cb, k, ef, ix->s_ids, ix->s_scores, ix->s_counts, ix->s_status, nullptr, stats != nullptr);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(out_ids + (size_t)c0 * k, ix->s_ids, (size_t)cb * k * 8, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipMemcpyAsync(out_scores + (size_t)c0 * k, ix->s_scores, (size_t)cb * k * 4, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipMemcpyAsync(out_counts + c0, ix->s_counts, (size_t)cb * 4, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipMemcpyAsync(status.data() + c0, ix->s_status, (size_t)cb * 4, hipMemcpyDeviceToHost, ix->stream));
+        if (stats) {
+            if ((rc = collect_stats(ix, cb, nullptr, stats))) return rc;
+        } else {
+            HIP_TRY(hipStreamSynchronize(ix->stream));
+        }
+    }
+    if (out_status) {
+        memcpy(out_status, status.data(), (size_t)b * 4);
+        return HVX_OK;
+    }
+    for (uint32_t i = 0; i < b; ++i)
+        if (status[i]) return fail((int)status[i], "query %u rejected with status %u", i, status[i]);
+    return HVX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// exact scans
+// ---------------------------------------------------------------------------------------------
+int hvx_index::flat_scratch(uint32_t b, uint32_t k, uint32_t chunk_rows) {
+    int rc;
+    const size_t need_d = (size_t)b * chunk_rows * 4;
+    if (need_d > cap_dist) {
+        if ((rc = dalloc((void **)&f_dist, need_d))) return rc;
+        cap_dist = need_d;
+    }
+    const size_t need_t = (size_t)b * k;
+    if (need_t > cap_top) {
+        if ((rc = dalloc((void **)&f_top_s, need_t * 4))) return rc;
+        if ((rc = dalloc((void **)&f_top_i, need_t * 4))) return rc;
+        cap_top = need_t;
+    }
+    if (b > cap_topc) {
+        if ((rc = dalloc((void **)&f_top_c, (size_t)b * 4))) return rc;
+        cap_topc = b;
+    }
+    return HVX_OK;
+}
+
+// scan `n_rows` rows (all rows, or d_subset internal ids) for b device-resident queries
+int hvx::flat_scan_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, const uint32_t *d_subset,
+                          uint32_t n_rows, uint64_t *d_ids, float *d_scores, uint32_t *d_counts,
+                          uint32_t *d_status, bool timed) {
+    if (k == 0) return fail(HVX_ERR_K_RANGE, "result count must be non-zero");
+    if (k > 1024) return fail(HVX_ERR_UNSUPPORTED, "flat scan supports k <= 1024");
+    // chunk the scan so the distance workspace stays <= 256 MiB
+    uint32_t chunk = 65536;
+    while ((size_t)chunk * b * 4 > (256u << 20) && chunk > 256) chunk >>= 1;
+    if (chunk > n_rows) chunk = std::max<uint32_t>(n_rows, 1);
+    chunk = (chunk + 3) & ~3u;
+    int rc = ix->flat_scratch(b, k, chunk);
+    if (rc) return rc;
+    HIP_TRY(launch_validate_queries(ix->dev, d_queries, b, ix->limit, ix->d_qstatus, ix->d_qhdr, ix->stream));
+    if (timed) HIP_TRY(hipEventRecord(ix->ev0, ix->stream));
+    HIP_TRY(hipMemsetAsync(ix->f_top_c, 0, (size_t)b * 4, ix->stream));
+    FlatArgs a;
+    a.ix = ix->dev;
+    a.queries = d_queries;
+    a.qstatus = ix->d_qstatus;
+    a.qhdr = ix->d_qhdr;
+    a.subset = d_subset;
+    a.n_rows = n_rows;
+    a.dist = ix->f_dist;
+    a.chunk_ld = chunk;
+    a.b = b;
+    a.k = k;
+    a.top_scores = ix->f_top_s;
+    a.top_ids = ix->f_top_i;
+    a.top_counts = ix->f_top_c;
+    for (uint32_t r0 = 0; r0 < n_rows; r0 += chunk) {
+        a.row0 = r0;
+        a.rows = std::min(chunk, n_rows - r0);
+        HIP_TRY(launch_flat_distances(a, ix->stream));
+        HIP_TRY(launch_flat_select(a, ix->stream));
+    }
+    a.row0 = 0;
+    a.rows = 0;
+    HIP_TRY(launch_flat_finish(a, d_ids, d_scores, d_counts, d_status, ix->stream));
+    if (timed) HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
+    return HVX_OK;
+}
+
+static int flat_stats(hvx_index *ix, uint32_t b, uint64_t rows, hvx_stats *stats) {
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
+    stats->queries += b;
+    stats->vectors_loaded += (uint64_t)b * rows;
+    stats->distance_computations += (uint64_t)b * rows;
+    stats->device_ms += ms;
+    return HVX_OK;
+}
+
+extern "C" int hvx_flat_search_batch_device(const hvx_index *cix, const float *d_queries, uint32_t b, uint32_t k,
+                                            uint64_t *d_out_ids, float *d_out_scores, uint32_t *d_out_counts,
+                                            uint32_t *d_out_status, hvx_stats *stats) {
+    if (!cix) return fail(HVX_ERR_INVARIANT, "null index");
+    hvx_index *ix = const_cast<hvx_index *>(cix);
+    if (b == 0) return HVX_OK;
+    if (b > ix->max_batch) return fail(HVX_ERR_UNSUPPORTED, "batch %u exceeds max_batch %u", b, ix->max_batch);
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    int rc = flat_scan_device(ix, d_queries, b, k, nullptr, ix->dev.n, d_out_ids, d_out_scores, d_out_counts, d_out_status, stats != nullptr);
+    if (rc) return rc;
+    if (stats) return flat_stats(ix, b, ix->dev.n, stats);
+    return HVX_OK;
+}
+
+int hvx::flat_scan_host(hvx_index *ix, const float *queries, uint32_t b, uint32_t k, const uint32_t *d_subset,
+                        uint32_t n_rows, uint64_t *out_ids, float *out_scores, uint32_t *out_counts,
+                        uint32_t *out_status, hvx_stats *stats) {
+    int rc;
+    const uint32_t mb = ix->max_batch;
+    std::vector<uint32_t> status(b, 0);
+    for (uint32_t c0 = 0; c0 < b; c0 += mb) {
+        const uint32_t cb = std::min(mb, b - c0);
+        if ((rc = ix->stage(cb, k))) return rc;
+        HIP_TRY(hipMemcpyAsync(ix->s_queries, queries + (size_t)c0 * ix->dev.dim, (size_t)cb * ix->dev.dim * 4, hipMemcpyHostToDevice, ix->stream));
+        rc = flat_scan_device(ix, ix->s_queries, cb, k, d_subset, n_rows, ix->s_ids, ix->s_scores, ix->s_counts, ix->s_status, stats != nullptr);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(out_ids + (size_t)c0 * k, ix->s_ids, (size_t)cb * k * 8, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipMemcpyAsync(out_scores + (size_t)c0 * k, ix->s_scores, (size_t)cb * k * 4, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipMemcpyAsync(out_counts + c0, ix->s_counts, (size_t)cb * 4, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipMemcpyAsync(status.data() + c0, ix->s_status, (size_t)cb * 4, hipMemcpyDeviceToHost, ix->stream));
+        if (stats) {
+            if ((rc = flat_stats(ix, cb, n_rows, stats))) return rc;
+        } else {
+            HIP_TRY(hipStreamSynchronize(ix->stream));
+        }
+    }
+    if (out_status) {
+        memcpy(out_status, status.data(), (size_t)b * 4);
+        return HVX_OK;
+    }
+    for (uint32_t i = 0; i < b; ++i)
+        if (status[i]) return fail((int)status[i], "query %u rejected with status %u", i, status[i]);
+    return HVX_OK;
+}
+
+extern "C" int hvx_flat_search_batch(const hvx_index *cix, const float *queries, uint32_t b, uint32_t k,
+                                     uint64_t *out_ids, float *out_scores, uint32_t *out_counts,
+                                     uint32_t *out_status, hvx_stats *stats) {
+    if (!cix) return fail(HVX_ERR_INVARIANT, "null index");
+    hvx_index *ix = const_cast<hvx_index *>(cix);
+    if (k == 0) return fail(HVX_ERR_K_RANGE, "result count must be non-zero");
+    if (b == 0) return HVX_OK;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    return flat_scan_host(ix, queries, b, k, nullptr, ix->dev.n, out_ids, out_scores, out_counts, out_status, stats);
+}
+
+extern "C" int hvx_merge_topk_device(const hvx_index *cix, uint32_t g, uint32_t b, uint32_t k, const uint64_t *d_ids,
+                                     const float *d_scores, const uint32_t *d_counts, uint64_t *d_out_ids,
+                                     float *d_out_scores, uint32_t *d_out_counts) {
+    if (!cix) return fail(HVX_ERR_INVARIANT, "null index");
+    hvx_index *ix = const_cast<hvx_index *>(cix);
+    if (k == 0 || g == 0) return fail(HVX_ERR_K_RANGE, "k and shard count must be non-zero");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(launch_merge_topk(g, b, k, d_ids, d_scores, d_counts, d_out_ids, d_out_scores, d_out_counts, ix->stream));
+    return HVX_OK;
+}

@@ -1,0 +1,234 @@
+// hvx_device.h -- device-side building blocks shared by the gfx950 kernels.
+//
+// The central piece is the bit-exact distance evaluator: HelixDB ranks by (f32 score, node id)
+// (crates/db/src/search/vector/model.rs:55-61) and the f32 score depends on the summation tree of
+// the host SIMD kernel that produced it (spaces/simple.rs:127-143).  The AVX kernels keep 4 x 8
+// lane accumulators = 32 "virtual lanes", virtual lane v summing elements v, v+32, v+64, ... in
+// order (spaces/simple_avx.rs:128-181).  On CDNA4 eight consecutive lanes of a wavefront (a "row
+// group") own one embedding row; lane j carries virtual lanes 4j..4j+3 in a float4 accumulator fed
+// by 16-byte global loads, so the per-virtual-lane FMA chain is reproduced exactly, and the final
+// (s1+s2)+(s3+s4) / hsum256 tree maps onto three DPP lane exchanges.  Scores therefore match the
+// reference CPU path bit for bit, not only in rank.
+//
+// Built with -ffp-contract=off: every fused multiply-add below is an explicit __builtin_fmaf.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hvx {
+
+constexpr uint32_t kSentinel = 0xFFFFFFFFu; // empty slot in a fixed-stride neighbour row
+constexpr uint32_t kExpandedBit = 0x80000000u;
+
+enum : uint32_t { kCosine = 0, kL2 = 1, kL1 = 2 };
+enum : uint32_t { kKernelScalar = 0, kKernelAvx = 2, kKernelAvxFma = 3 };
+
+// Read-only index image in HBM (see DESIGN.md "HBM layout").
+struct DevIndex {
+    const float *vec;         // [n][ld] row-major f32, rows 16-byte aligned, zero padded to ld
+    const float *hdr;         // [n] cosine norm header (distance/cosine.rs:73-75); 0 otherwise
+    const uint32_t *l0;       // [n][s0] layer-0 rows: internal ids ascending, kSentinel padded
+    const uint32_t *up;       // [up_rows][su] upper-layer rows, same format
+    const uint32_t *up_base;  // [n] first upper row (layer 1) of a node, kSentinel if level 0
+    const uint16_t *level;    // [n] top layer of the node
+    const uint64_t *ids;      // [n] external node ids, ascending
+    uint32_t n, dim, ld;      // ld = dim rounded up to 4 floats
+    uint32_t dim_main;        // elements covered by the 32-lane SIMD tree (0 in scalar mode / dim<32)
+    uint32_t s0, su;          // row strides of l0 / up (multiples of 32 / 16)
+    uint32_t metric, fkernel;
+    uint32_t entry, max_layer, has_entry;
+};
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+// Lane exchanges of the 8-lane row group as DPP modifiers (no LDS crossbar traffic):
+//   quad_perm [1,0,3,2] = lane^1, quad_perm [2,3,0,1] = lane^2, row_half_mirror = lane -> 7-lane.
+__device__ __forceinline__ float dpp_xor1(float v) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_xor2(float v) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_half_mirror(float v) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0x141, 0xF, 0xF, true));
+}
+
+// Which float4 of a 32-float chunk lane j of a row group owns.  AVX register r (sum256_{r+1}) covers
+// floats 8r..8r+7 = (lo128, hi128).  Lanes 0..3 hold s1lo,s1hi,s2lo,s2hi and lanes 4..7 hold
+// s4hi,s4lo,s3hi,s3lo, so that (s1+s2),(s3+s4) is a lane^2 exchange, (s12+s34) a half-row mirror
+// and hi128+lo128 a lane^1 exchange -- all three are DPP row operations.
+__device__ __forceinline__ int chunk_slot(int j) { return j < 4 ? j : 11 - j; }
+
+// (sum256_1+sum256_2)+(sum256_3+sum256_4), then hsum256_ps_avx (simple_avx.rs:7-12,59-63):
+// every lane of the group returns the same value.
+__device__ __forceinline__ float avx_tree_reduce(float4 acc) {
+    float4 p, t, u;
+    p.x = acc.x + dpp_xor2(acc.x); p.y = acc.y + dpp_xor2(acc.y);
+    p.z = acc.z + dpp_xor2(acc.z); p.w = acc.w + dpp_xor2(acc.w);
+    t.x = p.x + dpp_half_mirror(p.x); t.y = p.y + dpp_half_mirror(p.y);
+    t.z = p.z + dpp_half_mirror(p.z); t.w = p.w + dpp_half_mirror(p.w);
+    u.x = t.x + dpp_xor1(t.x); u.y = t.y + dpp_xor1(t.y);
+    u.z = t.z + dpp_xor1(t.z); u.w = t.w + dpp_xor1(t.w);
+    const float x64_0 = u.x + u.z;
+    const float x64_1 = u.y + u.w;
+    return x64_0 + x64_1;
+}
+
+__device__ __forceinline__ bool f32_is_normal(float x) {
+    uint32_t e = (__float_as_uint(x) >> 23) & 0xFFu;
+    return e != 0u && e != 0xFFu;
+}
+__device__ __forceinline__ bool f32_is_finite(float x) {
+    return ((__float_as_uint(x) >> 23) & 0xFFu) != 0xFFu;
+}
+
+// DistanceScore::try_new (parameters.rs:243-274): finite, non-negative, -0 -> +0.
+__device__ __forceinline__ bool score_valid(float &s) {
+    if (!f32_is_finite(s)) return false;
+    if (s < 0.0f) return false;
+    if (s == 0.0f) s = 0.0f;
+    return true;
+}
+
+// distance/cosine.rs:12-36 scaled_l2_norm, serial f64.  `at(i)` yields component i.
+template <typename F> __device__ inline double scaled_l2_norm(uint32_t n, F at) {
+    double scale = 0.0, scaled_sum = 1.0;
+    for (uint32_t i = 0; i < n; ++i) {
+        double mag = (double)fabsf(at(i));
+        if (mag == 0.0) continue;
+        if (scale < mag) {
+            double ratio = scale / mag;
+            scaled_sum = 1.0 + scaled_sum * ratio * ratio;
+            scale = mag;
+        } else {
+            double ratio = mag / scale;
+            scaled_sum += ratio * ratio;
+        }
+    }
+    if (scale == 0.0) return 0.0;
+    return scale * sqrt(scaled_sum);
+}
+
+// distance/cosine.rs:39-59 stable_half_cosine (f64 fallback; rare: extreme norms only)
+__device__ inline float stable_half_cosine(const float *p, const float *q, uint32_t n) {
+    double pn = scaled_l2_norm(n, [&](uint32_t i) { return p[i]; });
+    double qn = scaled_l2_norm(n, [&](uint32_t i) { return q[i]; });
+    if (pn == 0.0 || qn == 0.0) return __uint_as_float(0x7FC00000u);
+    double dot = 0.0;
+    for (uint32_t i = 0; i < n; ++i) dot += (double)p[i] * (double)q[i];
+    double c = dot / (pn * qn);
+    if (c < -1.0) c = -1.0;
+    if (c > 1.0) c = 1.0;
+    return (float)((1.0 - c) * 0.5);
+}
+
+// distance/cosine.rs:96-118: fast path on cached norms, else f64 fallback
+__device__ __forceinline__ float cosine_finish(float pq, float pn, float qn, const float *qv,
+                                               const float *row, uint32_t dim) {
+    float pnqn = pn * qn;
+    if (pn > 0.0f && qn > 0.0f && pn != 3.402823466e+38f && qn != 3.402823466e+38f &&
+        f32_is_normal(pnqn) && f32_is_finite(pq)) {
+        float c = __fdiv_rn(pq, pnqn);
+        if (c < -1.0f) c = -1.0f;
+        if (c > 1.0f) c = 1.0f;
+        return (1.0f - c) / 2.0f;
+    }
+    return stable_half_cosine(qv, row, dim);
+}
+
+// One embedding row scored by the 8 lanes of a row group (all 8 lanes return the same value).
+//   qv   : query vector in LDS (ld floats, zero padded)
+//   row  : embedding row in HBM
+//   j    : lane & 7
+// METRIC kL2 / kCosine use the AVX tree for the first dim_main elements and the reference's scalar
+// tail for the rest (simple_avx.rs:172-177); kL1 is sequential everywhere (simple.rs:186-202).
+template <uint32_t METRIC, bool FUSED>
+__device__ __forceinline__ float group_distance(const DevIndex &ix, const float *qv, float qhdr,
+                                                uint32_t node, int j) {
+    const float *row = ix.vec + (size_t)node * ix.ld;
+    float result;
+    uint32_t t0;
+    if (METRIC == kL1) {
+        result = 0.0f;
+        t0 = 0;
+    } else {
+        t0 = ix.dim_main;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const uint32_t nk = t0 >> 5;
+        const int slot = chunk_slot(j);
+        const float4 *rp = reinterpret_cast<const float4 *>(row) + slot;
+        const float4 *qp = reinterpret_cast<const float4 *>(qv) + slot;
+        uint32_t k = 0;
+        // 8 independent 16-byte loads in flight per lane (8 KiB per wavefront) before the first use
+        for (; k + 8 <= nk; k += 8) {
+            float4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = rp[(size_t)(k + u) * 8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float4 qq = qp[(k + u) * 8];
+                if (METRIC == kL2) {
+                    float d0 = qq.x - x[u].x, d1 = qq.y - x[u].y, d2 = qq.z - x[u].z, d3 = qq.w - x[u].w;
+                    if (FUSED) {
+                        acc.x = __builtin_fmaf(d0, d0, acc.x); acc.y = __builtin_fmaf(d1, d1, acc.y);
+                        acc.z = __builtin_fmaf(d2, d2, acc.z); acc.w = __builtin_fmaf(d3, d3, acc.w);
+                    } else {
+                        acc.x = d0 * d0 + acc.x; acc.y = d1 * d1 + acc.y;
+                        acc.z = d2 * d2 + acc.z; acc.w = d3 * d3 + acc.w;
+                    }
+                } else {
+                    if (FUSED) {
+                        acc.x = __builtin_fmaf(qq.x, x[u].x, acc.x); acc.y = __builtin_fmaf(qq.y, x[u].y, acc.y);
+                        acc.z = __builtin_fmaf(qq.z, x[u].z, acc.z); acc.w = __builtin_fmaf(qq.w, x[u].w, acc.w);
+                    } else {
+                        acc.x = qq.x * x[u].x + acc.x; acc.y = qq.y * x[u].y + acc.y;
+                        acc.z = qq.z * x[u].z + acc.z; acc.w = qq.w * x[u].w + acc.w;
+                    }
+                }
+            }
+        }
+        for (; k < nk; ++k) {
+            float4 x = rp[(size_t)k * 8];
+            float4 qq = qp[k * 8];
+            if (METRIC == kL2) {
+                float d0 = qq.x - x.x, d1 = qq.y - x.y, d2 = qq.z - x.z, d3 = qq.w - x.w;
+                if (FUSED) {
+                    acc.x = __builtin_fmaf(d0, d0, acc.x); acc.y = __builtin_fmaf(d1, d1, acc.y);
+                    acc.z = __builtin_fmaf(d2, d2, acc.z); acc.w = __builtin_fmaf(d3, d3, acc.w);
+                } else {
+                    acc.x = d0 * d0 + acc.x; acc.y = d1 * d1 + acc.y;
+                    acc.z = d2 * d2 + acc.z; acc.w = d3 * d3 + acc.w;
+                }
+            } else {
+                if (FUSED) {
+                    acc.x = __builtin_fmaf(qq.x, x.x, acc.x); acc.y = __builtin_fmaf(qq.y, x.y, acc.y);
+                    acc.z = __builtin_fmaf(qq.z, x.z, acc.z); acc.w = __builtin_fmaf(qq.w, x.w, acc.w);
+                } else {
+                    acc.x = qq.x * x.x + acc.x; acc.y = qq.y * x.y + acc.y;
+                    acc.z = qq.z * x.z + acc.z; acc.w = qq.w * x.w + acc.w;
+                }
+            }
+        }
+        result = nk ? avx_tree_reduce(acc) : 0.0f;
+    }
+    // sequential part: scalar tail of the SIMD kernels, the whole vector for dim<32 / scalar mode,
+    // and all of Manhattan.  Every lane of the group walks the same chain (addresses are
+    // group-uniform, so the loads coalesce to one request per row).
+    for (uint32_t t = t0; t < ix.dim; ++t) {
+        float a = qv[t], b = row[t];
+        if (METRIC == kL2) {
+            float d = a - b;
+            float pr = d * d;
+            result += pr;
+        } else if (METRIC == kCosine) {
+            float pr = a * b;
+            result += pr;
+        } else {
+            result += fabsf(a - b);
+        }
+    }
+    if (METRIC == kCosine) result = cosine_finish(result, qhdr, ix.hdr[node], qv, row, ix.dim);
+    return result;
+}
+
+} // namespace hvx

@@ -1,0 +1,383 @@
+// hvx_hnsw.hip -- batched HNSW search on gfx950: one 256-thread workgroup (4 wavefronts) per query.
+//
+// Restates SearchSession::run (crates/db/src/search/vector/search.rs:1101-1230): greedy descent of
+// the upper layers (search_layer_greedy, :169-224) then the strict-exhaustive layer-0 beam
+// (search_layer0_with_simhash<_, STRICT_EXHAUSTIVE=true>, :267-1067), step for
+// step, so results, scores AND the SearchStats counters equal the reference's CPU path.
+//
+// Mapping onto CDNA4:
+//   * query vector staged once in LDS; each expansion gathers the unvisited neighbour rows with
+//     16-byte coalesced loads, 8 lanes per row, 8 rows per wavefront, 32 rows per workgroup pass;
+//   * distances are produced in the host kernel's summation order (hvx_device.h) => bit-exact;
+//   * the reference's two BinaryHeaps (`candidates`, `w`) are ONE sorted beam held in registers,
+//     striped across the 64 lanes (entry e in register e/64, lane e%64), replicated in all four
+//     wavefronts so no broadcast is needed: W = first min(count,ef) entries, candidates = entries
+//     without the expanded bit.  Insert = ballot-popcount position + one DPP wave-shift;
+//   * visited set = one bit per node per query in HBM, test-and-set with atomicOr (exact for any
+//     shard size, sized for 288 GB: 125 KB/query at 1M rows).
+#include "hvx_device.h"
+#include "hvx_kernels.h"
+
+namespace hvx {
+
+constexpr int kMaxStride = 128;  // largest neighbour-row stride served
+constexpr int kClearCap = 1024;  // upper-layer visited ids remembered for targeted clearing
+
+// LDS carve (dynamic, 16-byte aligned): query | frontier ids x2 | frontier dist x2 | clear list | misc
+struct LdsView {
+    float *qv;
+    uint32_t *fr_id_base; // [2][kMaxStride]
+    float *fr_d_base;     // [2][kMaxStride]
+    uint32_t *clr;
+    uint32_t *misc; // [0..1] frontier sizes, [2] clr_n, [4] row degree
+    __device__ __forceinline__ uint32_t *fr_id(int p) const { return fr_id_base + p * kMaxStride; }
+    __device__ __forceinline__ float *fr_d(int p) const { return fr_d_base + p * kMaxStride; }
+};
+
+__device__ __forceinline__ LdsView carve(char *smem, uint32_t ld) {
+    LdsView v;
+    uint32_t qbytes = ((ld * 4u) + 15u) & ~15u;
+    v.qv = reinterpret_cast<float *>(smem);
+    char *p = smem + qbytes;
+    v.fr_id_base = reinterpret_cast<uint32_t *>(p); p += 2 * kMaxStride * 4;
+    v.fr_d_base = reinterpret_cast<float *>(p); p += 2 * kMaxStride * 4;
+    v.clr = reinterpret_cast<uint32_t *>(p); p += kClearCap * 4;
+    v.misc = reinterpret_cast<uint32_t *>(p);
+    return v;
+}
+
+size_t hnsw_lds_bytes(uint32_t ld) {
+    return (((size_t)ld * 4u + 15u) & ~(size_t)15u) + 4u * kMaxStride * 4u + kClearCap * 4u + 64u;
+}
+
+// wave-shift right by one lane; lane 0 receives `carry`
+__device__ __forceinline__ uint32_t shr1(uint32_t v, uint32_t carry) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)v, 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
+}
+
+// The beam: CAP = 64*R entries sorted by (score, id) ascending; id bit31 = already expanded.
+template <int R> struct Beam {
+    float sc[R];
+    uint32_t id[R];
+    uint32_t count;
+
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { sc[r] = 0.f; id[r] = 0u; }
+        count = 0;
+    }
+    __device__ __forceinline__ float score_at(uint32_t pos) const {
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if ((pos >> 6) == (uint32_t)r) v = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sc[r]), pos & 63u));
+        return v;
+    }
+    __device__ __forceinline__ uint32_t id_at(uint32_t pos) const {
+        uint32_t v = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if ((pos >> 6) == (uint32_t)r) v = __builtin_amdgcn_readlane(id[r], pos & 63u);
+        return v;
+    }
+    // first entry without the expanded bit; returns count if none
+    __device__ __forceinline__ uint32_t first_unexpanded(int lane) const {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            uint32_t e = (uint32_t)r * 64u + (uint32_t)lane;
+            unsigned long long m = __ballot(e < count && !(id[r] & kExpandedBit));
+            if (m) return (uint32_t)r * 64u + (uint32_t)__builtin_ctzll(m);
+        }
+        return count;
+    }
+    __device__ __forceinline__ void mark_expanded(uint32_t pos, int lane) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if ((pos >> 6) == (uint32_t)r && (pos & 63u) == (uint32_t)lane) id[r] |= kExpandedBit;
+    }
+    // sorted insert; returns true when an unexpanded entry fell off the end
+    __device__ __forceinline__ bool insert(float d, uint32_t nid, int lane, float &dropped_score) {
+        uint32_t p = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            uint32_t e = (uint32_t)r * 64u + (uint32_t)lane;
+            uint32_t eid = id[r] & ~kExpandedBit;
+            bool less = e < count && (sc[r] < d || (sc[r] == d && eid < nid));
+            p += (uint32_t)__builtin_popcountll(__ballot(less));
+        }
+        constexpr uint32_t CAP = 64u * R;
+        bool dropped = false;
+        if (count == CAP) {
+            uint32_t last = id_at(CAP - 1);
+            dropped_score = score_at(CAP - 1);
+            dropped = !(last & kExpandedBit);
+            if (p == CAP) return dropped_new_only(d, dropped_score);
+        }
+#pragma unroll
+        for (int r = R - 1; r >= 0; --r) {
+            uint32_t e = (uint32_t)r * 64u + (uint32_t)lane;
+            uint32_t cs = 0, ci = 0;
+            if (r > 0) {
+                cs = __builtin_amdgcn_readlane(__float_as_uint(sc[r - 1]), 63);
+                ci = __builtin_amdgcn_readlane(id[r - 1], 63);
+            }
+            uint32_t ss = shr1(__float_as_uint(sc[r]), cs);
+            uint32_t si = shr1(id[r], ci);
+            if (e == p) { sc[r] = d; id[r] = nid; }
+            else if (e > p) { sc[r] = __uint_as_float(ss); id[r] = si; }
+        }
+        if (count < CAP) ++count;
+        return dropped;
+    }
+    // the new entry itself would land past the end of a full beam
+    __device__ __forceinline__ bool dropped_new_only(float d, float &dropped_score) {
+        dropped_score = d;
+        return true;
+    }
+};
+
+// wavefront 0: test-and-set the visited bits of one neighbour row and compact the unvisited ids,
+// in row order (= ascending id), into fr[]; returns frontier size, *deg = valid ids in the row.
+__device__ __forceinline__ uint32_t frontier_from_row(const uint32_t *row, uint32_t stride, uint32_t *bm,
+                                                      uint32_t *fr, int lane, uint32_t *deg,
+                                                      uint32_t *clr, uint32_t *clr_n, bool record) {
+    uint32_t base = 0, d = 0;
+    for (uint32_t c = 0; c < stride; c += 64) {
+        uint32_t slot = c + (uint32_t)lane;
+        uint32_t nid = slot < stride ? row[slot] : kSentinel;
+        bool valid = nid != kSentinel;
+        bool unv = false;
+        if (valid) {
+            uint32_t bit = 1u << (nid & 31u);
+            uint32_t old = atomicOr(&bm[nid >> 5], bit);
+            unv = !(old & bit);
+        }
+        unsigned long long vm = __ballot(valid);
+        unsigned long long um = __ballot(unv);
+        d += (uint32_t)__builtin_popcountll(vm);
+        if (unv) {
+            uint32_t pos = base + (uint32_t)__builtin_popcountll(um & ((1ull << lane) - 1ull));
+            fr[pos] = nid;
+            if (record) {
+                uint32_t cp = *clr_n + pos;
+                if (cp < (uint32_t)kClearCap) clr[cp] = nid;
+            }
+        }
+        base += (uint32_t)__builtin_popcountll(um);
+        if (!vm) break; // rows are sentinel-padded at the end
+    }
+    if (record) *clr_n += base;
+    *deg = d;
+    return base;
+}
+
+template <uint32_t METRIC, bool FUSED, int R>
+__global__ __launch_bounds__(256) void hnsw_search_kernel(HnswArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const DevIndex &ix = a.ix;
+    const uint32_t q = blockIdx.x;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 3, j = lane & 7;
+    LdsView L = carve(smem, ix.ld);
+
+    const uint32_t status_in = a.qstatus ? a.qstatus[q] : 0u;
+    if (status_in != 0u || !ix.has_entry) {
+        if (tid == 0) {
+            a.out_counts[q] = 0;
+            if (a.out_status) a.out_status[q] = status_in;
+            if (a.qstats) a.qstats[q] = hvx_query_stats{0, 0, 0, 0};
+        }
+        return;
+    }
+    for (uint32_t i = (uint32_t)tid; i < ix.ld; i += 256) L.qv[i] = i < ix.dim ? a.queries[(size_t)q * ix.dim + i] : 0.f;
+    if (tid < 8) L.misc[tid] = 0;
+    const float qhdr = a.qhdr ? a.qhdr[q] : 0.f;
+    uint32_t *bm = a.bitmap + (size_t)q * a.words_per_query;
+    __syncthreads();
+
+    bool bad_score = false;
+    uint32_t cur = ix.entry;
+
+    // ---------------- upper layers: search_layer_greedy (search.rs:169-224) ----------------
+    for (uint32_t layer = ix.max_layer; layer >= 1; --layer) {
+        // fresh visited set per layer: bits set here are cleared again before the next layer
+        float cur_d = group_distance<METRIC, FUSED>(ix, L.qv, qhdr, cur, j);
+        if (!score_valid(cur_d)) bad_score = true;
+        if (tid == 0) {
+            atomicOr(&bm[cur >> 5], 1u << (cur & 31u));
+            L.clr[0] = cur;
+            L.misc[2] = 1;
+        }
+        int p = 0;
+        for (;;) {
+            __syncthreads();
+            if (wave == 0) {
+                uint32_t nf = 0, deg = 0;
+                uint32_t base_row = ix.up_base[cur];
+                uint32_t clr_n = L.misc[2];
+                if (base_row != kSentinel && ix.level[cur] >= layer) {
+                    const uint32_t *row = ix.up + (size_t)(base_row + layer - 1) * ix.su;
+                    nf = frontier_from_row(row, ix.su, bm, L.fr_id(p), lane, &deg, L.clr, &clr_n, true);
+                }
+                if (lane == 0) { L.misc[p] = nf; L.misc[2] = clr_n; }
+            }
+            __syncthreads();
+            const uint32_t nf = L.misc[p];
+            if (nf == 0) break;
+            for (uint32_t f = (uint32_t)(grp * 4 + wave); f < nf; f += 32) {
+                float d = group_distance<METRIC, FUSED>(ix, L.qv, qhdr, L.fr_id(p)[f], j);
+                if (j == 0) L.fr_d(p)[f] = d;
+            }
+            __syncthreads();
+            // sequential `if distance < current_dist` over the row == first minimum, if it improves
+            bool changed = false;
+            for (uint32_t c = 0; c < nf; c += 64) {
+                uint32_t f = c + (uint32_t)lane;
+                float d = f < nf ? L.fr_d(p)[f] : __uint_as_float(0x7F800000u);
+                bool ok = true;
+                if (f < nf) ok = score_valid(d);
+                if (__ballot(!ok)) bad_score = true;
+                float m = d;
+#pragma unroll
+                for (int s = 1; s < 64; s <<= 1) m = fminf(m, __shfl_xor(m, s, 64));
+                if (m < cur_d) {
+                    unsigned long long eq = __ballot(f < nf && d == m);
+                    uint32_t first = c + (uint32_t)__builtin_ctzll(eq);
+                    cur = L.fr_id(p)[first];
+                    cur_d = m;
+                    changed = true;
+                }
+            }
+            if (bad_score || !changed) break;
+            p ^= 1;
+        }
+        __syncthreads();
+        // clear this layer's visited bits
+        const uint32_t clr_n = L.misc[2];
+        if (clr_n > (uint32_t)kClearCap) {
+            for (uint32_t w = (uint32_t)tid; w < a.words_per_query; w += 256) bm[w] = 0u;
+        } else if (wave == 0) {
+            for (uint32_t i = (uint32_t)lane; i < clr_n; i += 64) {
+                uint32_t nid = L.clr[i];
+                atomicAnd(&bm[nid >> 5], ~(1u << (nid & 31u)));
+            }
+        }
+        __syncthreads();
+        if (bad_score) break;
+    }
+
+    // ---------------- layer 0: strict-exhaustive beam (search.rs:267-1067) ----------------
+    Beam<R> S;
+    S.init();
+    uint32_t st_exp = 0, st_nb = 0, st_vl = 0, st_dc = 0;
+    bool tie_overflow = false;
+    uint32_t dropped_unexpanded = 0;
+    const uint32_t ef = a.ef;
+    if (!bad_score) {
+        float d0 = group_distance<METRIC, FUSED>(ix, L.qv, qhdr, cur, j);
+        st_dc = 1;
+        if (!score_valid(d0)) bad_score = true;
+        if (tid == 0) atomicOr(&bm[cur >> 5], 1u << (cur & 31u));
+        float ds;
+        S.insert(d0, cur, lane, ds);
+    }
+    int p = 0;
+    while (!bad_score) {
+        uint32_t pos = S.first_unexpanded(lane);
+        if (pos >= S.count) {
+            // the reference would still pop an evicted candidate that we no longer hold, count the
+            // step and stop on `current_dist > w.peek()` (search.rs:549)
+            if (dropped_unexpanded) ++st_exp;
+            break;
+        }
+        ++st_exp;
+        const float dc = S.score_at(pos);
+        const uint32_t c = S.id_at(pos);
+        const uint32_t wlen = S.count < ef ? S.count : ef;
+        float wmax = S.score_at(wlen - 1);
+        if (wlen >= ef && dc > wmax) break;
+        S.mark_expanded(pos, lane);
+
+        if (wave == 0) {
+            uint32_t deg = 0, dummy = 0;
+            const uint32_t *row = ix.l0 + (size_t)c * ix.s0;
+            uint32_t nf = frontier_from_row(row, ix.s0, bm, L.fr_id(p), lane, &deg, L.clr, &dummy, false);
+            if (lane == 0) { L.misc[p] = nf; L.misc[4] = deg; }
+        }
+        __syncthreads();
+        const uint32_t nf = L.misc[p];
+        st_nb += L.misc[4];
+        if (nf == 0) { __syncthreads(); continue; }
+        st_vl += nf;
+        st_dc += nf;
+        for (uint32_t f = (uint32_t)(grp * 4 + wave); f < nf; f += 32) {
+            float d = group_distance<METRIC, FUSED>(ix, L.qv, qhdr, L.fr_id(p)[f], j);
+            if (j == 0) L.fr_d(p)[f] = d;
+        }
+        __syncthreads();
+        // admission in row order with the running bound (search.rs:928-952)
+        for (uint32_t f = 0; f < nf; ++f) {
+            float d = L.fr_d(p)[f];
+            if (!score_valid(d)) { bad_score = true; break; }
+            const uint32_t wl = S.count < ef ? S.count : ef;
+            if (d < wmax || wl < ef) {
+                float ds = 0.f;
+                bool drop = S.insert(d, L.fr_id(p)[f], lane, ds);
+                const uint32_t wl2 = S.count < ef ? S.count : ef;
+                wmax = S.score_at(wl2 - 1);
+                if (drop) {
+                    ++dropped_unexpanded;
+                    if (!(ds > wmax)) tie_overflow = true; // an equal-score candidate left the beam
+                }
+            }
+        }
+        p ^= 1;
+    }
+
+    // ---------------- results: w sorted by (score,id), take k (search.rs:995-1004,1229) ----------------
+    uint32_t outn = 0;
+    if (!bad_score) {
+        const uint32_t wl = S.count < ef ? S.count : ef;
+        outn = wl < a.k ? wl : a.k;
+        if (wave == 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                uint32_t e = (uint32_t)r * 64u + (uint32_t)lane;
+                if (e < outn) {
+                    a.out_ids[(size_t)q * a.k + e] = ix.ids[S.id[r] & ~kExpandedBit];
+                    a.out_scores[(size_t)q * a.k + e] = S.sc[r];
+                }
+            }
+        }
+    }
+    if (tid == 0) {
+        a.out_counts[q] = outn;
+        if (a.out_status) a.out_status[q] = bad_score ? 8u /*HVX_ERR_INVARIANT*/ : 0u;
+        if (a.qstats) a.qstats[q] = hvx_query_stats{st_exp, st_nb, st_vl, st_dc};
+        if (a.tie_flags) a.tie_flags[q] = tie_overflow ? 1u : 0u;
+    }
+}
+
+template <uint32_t METRIC, bool FUSED>
+static hipError_t launch_r(const HnswArgs &a, uint32_t b, hipStream_t s) {
+    const size_t lds = hnsw_lds_bytes(a.ix.ld);
+    // beam capacity 64*R must hold ef plus slack for equal-score evictions
+    const uint32_t need = a.ef + 32u;
+    if (need <= 128) hipLaunchKernelGGL((hnsw_search_kernel<METRIC, FUSED, 2>), dim3(b), dim3(256), lds, s, a);
+    else if (need <= 192) hipLaunchKernelGGL((hnsw_search_kernel<METRIC, FUSED, 3>), dim3(b), dim3(256), lds, s, a);
+    else if (need <= 256) hipLaunchKernelGGL((hnsw_search_kernel<METRIC, FUSED, 4>), dim3(b), dim3(256), lds, s, a);
+    else if (need <= 512) hipLaunchKernelGGL((hnsw_search_kernel<METRIC, FUSED, 8>), dim3(b), dim3(256), lds, s, a);
+    else if (need <= 1024) hipLaunchKernelGGL((hnsw_search_kernel<METRIC, FUSED, 16>), dim3(b), dim3(256), lds, s, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_hnsw_search(const HnswArgs &a, uint32_t b, hipStream_t s) {
+    const bool fused = a.ix.fkernel == kKernelAvxFma;
+    switch (a.ix.metric) {
+    case kCosine: return fused ? launch_r<kCosine, true>(a, b, s) : launch_r<kCosine, false>(a, b, s);
+    case kL2: return fused ? launch_r<kL2, true>(a, b, s) : launch_r<kL2, false>(a, b, s);
+    default: return launch_r<kL1, true>(a, b, s);
+    }
+}
+
+} // namespace hvx

@@ -1,0 +1,66 @@
+// hvx_host.h -- host-side state behind the opaque handles of include/helix_vec.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+#include "hvx_kernels.h"
+
+struct hvx_index {
+    int device = 0;
+    hvx_index_desc desc{};
+    hvx::DevIndex dev{};
+    float limit = 0.f;               // VectorComponentLimit (domain.rs:26-78); +inf for cosine
+    uint32_t max_batch = 1024;
+    uint32_t words_per_query = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::mutex mu;                   // calls on one index are serialised on its stream
+    std::vector<void *> allocs;
+    std::vector<uint64_t> ids;       // host copy of node ids (id -> internal index lookups)
+    bool contiguous = false;
+    // per-batch device scratch
+    uint32_t *d_bitmap = nullptr, *d_qstatus = nullptr, *d_tie = nullptr;
+    float *d_qhdr = nullptr;
+    hvx_query_stats *d_qstats = nullptr;
+    // staging of the host-pointer API
+    float *s_queries = nullptr;
+    uint64_t *s_ids = nullptr;
+    float *s_scores = nullptr;
+    uint32_t *s_counts = nullptr, *s_status = nullptr;
+    size_t cap_q = 0, cap_o = 0;
+    uint32_t cap_b = 0;
+    // exact-scan scratch
+    float *f_dist = nullptr, *f_top_s = nullptr;
+    uint32_t *f_top_i = nullptr, *f_top_c = nullptr, *f_subset = nullptr;
+    size_t cap_dist = 0, cap_top = 0, cap_subset = 0;
+    uint32_t cap_topc = 0;
+
+    int dalloc(void **p, size_t bytes);
+    int stage(uint32_t b, uint32_t k);
+    int flat_scratch(uint32_t b, uint32_t k, uint32_t chunk_rows);
+    // external id -> internal row, kSentinel when absent
+    uint32_t find(uint64_t id) const {
+        if (ids.empty()) return hvx::kSentinel;
+        if (contiguous) {
+            if (id < ids[0] || id - ids[0] >= ids.size()) return hvx::kSentinel;
+            return (uint32_t)(id - ids[0]);
+        }
+        auto it = std::lower_bound(ids.begin(), ids.end(), id);
+        if (it == ids.end() || *it != id) return hvx::kSentinel;
+        return (uint32_t)(it - ids.begin());
+    }
+};
+
+namespace hvx {
+int fail(int code, const char *fmt, ...);
+float component_limit(uint32_t metric, uint32_t dim);
+int flat_scan_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, const uint32_t *d_subset,
+                     uint32_t n_rows, uint64_t *d_ids, float *d_scores, uint32_t *d_counts, uint32_t *d_status,
+                     bool timed);
+int flat_scan_host(hvx_index *ix, const float *queries, uint32_t b, uint32_t k, const uint32_t *d_subset,
+                   uint32_t n_rows, uint64_t *out_ids, float *out_scores, uint32_t *out_counts,
+                   uint32_t *out_status, hvx_stats *stats);
+} // namespace hvx

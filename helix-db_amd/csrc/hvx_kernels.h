@@ -1,0 +1,63 @@
+// hvx_kernels.h -- host-visible launch interface of the gfx950 kernels (internal to the library).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/helix_vec.h"
+#include "hvx_device.h"
+
+namespace hvx {
+
+struct HnswArgs {
+    DevIndex ix;
+    const float *queries;      // [b][dim]
+    const uint32_t *qstatus;   // [b] validation status (0 = ok), nullable
+    const float *qhdr;         // [b] query cosine norm header, nullable (non-cosine)
+    uint32_t *bitmap;          // [b][words_per_query] visited bits, zeroed before launch
+    uint32_t words_per_query;
+    uint32_t k, ef;
+    uint64_t *out_ids;         // [b][k]
+    float *out_scores;         // [b][k]
+    uint32_t *out_counts;      // [b]
+    uint32_t *out_status;      // [b] nullable
+    hvx_query_stats *qstats;   // [b] nullable
+    uint32_t *tie_flags;       // [b] nullable
+};
+
+size_t hnsw_lds_bytes(uint32_t ld);
+hipError_t launch_hnsw_search(const HnswArgs &a, uint32_t b, hipStream_t s);
+
+// validate queries on the device (domain.rs:113-157) and compute the cosine header
+hipError_t launch_validate_queries(const DevIndex &ix, const float *d_queries, uint32_t b, float limit,
+                                   uint32_t *d_status, float *d_qhdr, hipStream_t s);
+
+hipError_t launch_validate_rows(const DevIndex &ix, uint32_t n, float limit, uint32_t *d_status, float *d_hdr,
+                                hipStream_t s);
+
+// exact distance matrix tile + exact top-k selection (flat scan / restricted exact scan)
+struct FlatArgs {
+    DevIndex ix;
+    const float *queries;     // [b][dim]
+    const uint32_t *qstatus;  // [b]
+    const float *qhdr;        // [b]
+    const uint32_t *subset;   // optional [n_rows] internal ids to scan (restricted); NULL = all rows
+    uint32_t n_rows;          // rows to scan (n or subset size)
+    uint32_t row0, rows;      // this chunk: rows [row0, row0+rows) of the scan order
+    float *dist;              // [b][chunk_ld] workspace
+    uint32_t chunk_ld;
+    uint32_t b, k;
+    // running top-k per query, kept sorted; merged with every chunk
+    float *top_scores;        // [b][k]
+    uint32_t *top_ids;        // [b][k] internal ids
+    uint32_t *top_counts;     // [b]
+};
+hipError_t launch_flat_distances(const FlatArgs &a, hipStream_t s);
+hipError_t launch_flat_select(const FlatArgs &a, hipStream_t s);
+hipError_t launch_flat_finish(const FlatArgs &a, uint64_t *out_ids, float *out_scores, uint32_t *out_counts,
+                              uint32_t *out_status, hipStream_t s);
+
+hipError_t launch_merge_topk(uint32_t g, uint32_t b, uint32_t k, const uint64_t *ids, const float *scores,
+                             const uint32_t *counts, uint64_t *out_ids, float *out_scores,
+                             uint32_t *out_counts, hipStream_t s);
+
+} // namespace hvx

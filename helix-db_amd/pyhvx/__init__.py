@@ -1,0 +1,316 @@
+"""ctypes binding of libhelix_vec_gfx950.so (include/helix_vec.h) for tests and bench.py.
+
+Names mirror the reference's Rust interface for this path (crates/db/src/search/vector/):
+SearchParams (mod.rs:410-516), RestrictedVectorCandidates (restricted.rs:345-371),
+ValidatedVectorReadIndex.search / .search_restricted (read_index.rs:83-102), SearchResult
+(result.rs:20-41), HelixDbError.  There is NO CPU fallback here: if the HIP library is missing or a
+call fails, HelixDbError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libhelix_vec_gfx950.so")
+
+COSINE, EUCLIDEAN, MANHATTAN = 0, 1, 2
+KERNEL_SCALAR, KERNEL_AVX, KERNEL_AVX_FMA = 0, 2, 3
+OK, ERR_DIMENSION, ERR_NONFINITE, ERR_ZERO_NORM, ERR_MAGNITUDE, ERR_K_RANGE, ERR_CANDIDATE_LIMIT, \
+    ERR_DEVICE, ERR_INVARIANT, ERR_UNSUPPORTED = range(10)
+DIR_OUT, DIR_IN, DIR_BOTH = 0, 1, 2
+
+_STATUS_NAMES = {
+    1: "InvalidDimension", 2: "InvalidVectorComponent", 3: "ZeroNormCosineVector",
+    4: "ComponentMagnitudeExceeded", 5: "Query(result count / beam width out of range)",
+    6: "Query(too many restricted candidates)", 7: "Device", 8: "InvariantViolation", 9: "Unsupported",
+}
+
+
+class HelixDbError(RuntimeError):
+    def __init__(self, status: int, message: str = ""):
+        self.status = status
+        super().__init__(f"{_STATUS_NAMES.get(status, status)}: {message}")
+
+    def is_invalid_vector_input(self) -> bool:  # crates/server/src/http.rs:143-145
+        return self.status in (ERR_DIMENSION, ERR_NONFINITE, ERR_ZERO_NORM, ERR_MAGNITUDE)
+
+
+class _Desc(C.Structure):
+    _fields_ = [("dim", C.c_uint32), ("metric", C.c_uint32), ("dtype", C.c_uint32),
+                ("float_kernel", C.c_uint32), ("n", C.c_uint64), ("m", C.c_uint32), ("m0", C.c_uint32),
+                ("has_entry", C.c_uint32), ("max_layer", C.c_uint32), ("entry_point", C.c_uint64),
+                ("shard_id_lo", C.c_uint64), ("shard_id_hi", C.c_uint64), ("device", C.c_int32),
+                ("max_batch", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("queries", C.c_uint64), ("expansion_steps", C.c_uint64),
+                ("neighbors_examined", C.c_uint64), ("vectors_loaded", C.c_uint64),
+                ("distance_computations", C.c_uint64), ("tie_overflow_queries", C.c_uint64),
+                ("device_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class QueryStats(C.Structure):
+    _fields_ = [("expansion_steps", C.c_uint32), ("neighbors_examined", C.c_uint32),
+                ("vectors_loaded", C.c_uint32), ("distance_computations", C.c_uint32)]
+
+
+_lib = None
+_vp = C.c_void_p
+
+
+def lib():
+    """Load the product library; raises HelixDbError(ERR_DEVICE) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HelixDbError(ERR_DEVICE, f"{LIB_PATH} is missing: run __graft_entry__.build() / make -C helix-db_amd/csrc")
+    L = C.CDLL(LIB_PATH)
+    L.hvx_last_error.restype = C.c_char_p
+    L.hvx_version.restype = C.c_char_p
+    L.hvx_index_import.restype = C.c_int
+    L.hvx_index_import.argtypes = [C.POINTER(_Desc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp)]
+    L.hvx_index_free.argtypes = [_vp]
+    L.hvx_index_sync.restype = C.c_int
+    L.hvx_index_sync.argtypes = [_vp]
+    L.hvx_index_stream.restype = _vp
+    L.hvx_index_stream.argtypes = [_vp]
+    L.hvx_search_batch.restype = C.c_int
+    L.hvx_search_batch.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, C.POINTER(Stats)]
+    L.hvx_search_batch_device.restype = C.c_int
+    L.hvx_search_batch_device.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp, C.POINTER(Stats)]
+    L.hvx_flat_search_batch.restype = C.c_int
+    L.hvx_flat_search_batch.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, C.POINTER(Stats)]
+    L.hvx_flat_search_batch_device.restype = C.c_int
+    L.hvx_flat_search_batch_device.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, C.POINTER(Stats)]
+    L.hvx_search_restricted_batch.restype = C.c_int
+    L.hvx_search_restricted_batch.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp, C.POINTER(Stats)]
+    L.hvx_merge_topk_device.restype = C.c_int
+    L.hvx_merge_topk_device.argtypes = [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.hvx_csr_import.restype = C.c_int
+    L.hvx_csr_import.argtypes = [C.c_uint64, C.c_uint64, _vp, _vp, _vp, C.c_int32, C.POINTER(_vp)]
+    L.hvx_csr_free.argtypes = [_vp]
+    L.hvx_traverse_filter.restype = C.c_int
+    L.hvx_traverse_filter.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp]
+    L.hvx_expand_filter.restype = C.c_int
+    L.hvx_expand_filter.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32, _vp]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != OK:
+        raise HelixDbError(rc, lib().hvx_last_error().decode())
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+@dataclass(frozen=True)
+class SearchResult:  # result.rs:20-41
+    entity_id: int
+    score: np.float32
+
+
+class SearchParams:
+    """mod.rs:482-516: SearchParams::new(k) => ef = max(k, 100); with_ef validates ef >= k."""
+
+    def __init__(self, k: int):
+        if k <= 0:
+            raise HelixDbError(ERR_K_RANGE, "result count must be non-zero")
+        self.k = int(k)
+        self.ef = max(self.k, 100)
+
+    def with_ef(self, ef: int) -> "SearchParams":
+        if ef <= 0 or ef < self.k:
+            raise HelixDbError(ERR_K_RANGE, f"search beam width {ef} is below the result count {self.k}")
+        self.ef = int(ef)
+        return self
+
+
+class RestrictedVectorCandidates:
+    """restricted.rs:345-371: dedupes ids, at most 1,000,000 unique candidates."""
+
+    def __init__(self, ids: np.ndarray):
+        self.ids = ids
+
+    @classmethod
+    def from_ids(cls, ids) -> "RestrictedVectorCandidates":
+        a = np.unique(np.asarray(list(ids) if not isinstance(ids, np.ndarray) else ids, dtype=np.uint64))
+        if a.size > 1_000_000:
+            raise HelixDbError(ERR_CANDIDATE_LIMIT, "restricted vector search accepts at most 1000000 unique candidates")
+        return cls(a)
+
+    @classmethod
+    def from_bitmap_words(cls, words: np.ndarray) -> "RestrictedVectorCandidates":
+        bits = np.unpackbits(np.ascontiguousarray(words, dtype="<u8").view(np.uint8), bitorder="little")
+        return cls.from_ids(np.nonzero(bits)[0].astype(np.uint64))
+
+    def __len__(self):
+        return int(self.ids.size)
+
+
+class ValidatedVectorReadIndex:
+    """Device-resident read index (read_index.rs:43-102 over VectorIndex<D>, index.rs:108-140)."""
+
+    def __init__(self, handle, dim, metric, n):
+        self._h = handle
+        self.dim, self.metric, self.n = dim, metric, n
+
+    @classmethod
+    def managed(cls, *, dim, metric, node_ids, vectors, l0_offsets, l0_neighbors, level=None,
+                up_offsets=None, up_neighbors=None, entry_point=None, max_layer=0, m=16, m0=32,
+                float_kernel=KERNEL_AVX_FMA, device=-1, max_batch=1024):
+        ids = np.ascontiguousarray(node_ids, dtype=np.uint64)
+        vec = np.ascontiguousarray(vectors, dtype=np.float32).reshape(ids.size, dim) if ids.size else np.zeros((0, dim), np.float32)
+        o0 = np.ascontiguousarray(l0_offsets, dtype=np.uint64)
+        n0 = np.ascontiguousarray(l0_neighbors, dtype=np.uint64)
+        lv = None if level is None else np.ascontiguousarray(level, dtype=np.uint16)
+        uo = None if up_offsets is None else np.ascontiguousarray(up_offsets, dtype=np.uint64)
+        un = None if up_neighbors is None else np.ascontiguousarray(up_neighbors, dtype=np.uint64)
+        d = _Desc(dim=dim, metric=metric, dtype=0, float_kernel=float_kernel, n=ids.size, m=m, m0=m0,
+                  has_entry=0 if entry_point is None else 1, max_layer=max_layer,
+                  entry_point=0 if entry_point is None else int(entry_point),
+                  shard_id_lo=int(ids[0]) if ids.size else 0, shard_id_hi=int(ids[-1]) if ids.size else 0,
+                  device=device, max_batch=max_batch)
+        h = _vp()
+        _check(lib().hvx_index_import(C.byref(d), _ptr(ids), _ptr(vec), _ptr(o0), _ptr(n0), _ptr(lv),
+                                      _ptr(uo), _ptr(un), C.byref(h)))
+        return cls(h, dim, metric, int(ids.size))
+
+    @classmethod
+    def from_export(cls, ex: dict, *, dim, metric, **kw):
+        """Build from the dict produced by the oracle's Index.export() (tests) or the GPU builder."""
+        return cls.managed(dim=dim, metric=metric, node_ids=ex["node_ids"], vectors=ex["vectors"],
+                           l0_offsets=ex["l0_offsets"], l0_neighbors=ex["l0_neighbors"], level=ex["level"],
+                           up_offsets=ex["up_offsets"], up_neighbors=ex["up_neighbors"],
+                           entry_point=ex["entry_point"], max_layer=ex["max_layer"], **kw)
+
+    def close(self):
+        if self._h:
+            lib().hvx_index_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- single-query surface, as the reference's operator calls it ----
+    def search(self, query, params: SearchParams):
+        ids, sc, cnt, _ = self.search_batch(np.asarray(query, np.float32).reshape(1, -1), params)
+        return [SearchResult(int(i), s) for i, s in zip(ids[0, :cnt[0]], sc[0, :cnt[0]])]
+
+    def search_restricted(self, query, params: SearchParams, candidates: RestrictedVectorCandidates):
+        ids, sc, cnt = self.search_restricted_batch(np.asarray(query, np.float32).reshape(1, -1), params, candidates)
+        return [SearchResult(int(i), s) for i, s in zip(ids[0, :cnt[0]], sc[0, :cnt[0]])]
+
+    # ---- batched surface ----
+    def _q(self, queries):
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise HelixDbError(ERR_DIMENSION, f"expected dimension {self.dim}, got {q.shape[-1] if q.ndim else 0}")
+        return q
+
+    def search_batch(self, queries, params: SearchParams, per_query_status=False):
+        q = self._q(queries)
+        b, k = q.shape[0], params.k
+        ids = np.zeros((b, k), np.uint64); sc = np.zeros((b, k), np.float32)
+        cnt = np.zeros(b, np.uint32); st = np.zeros(b, np.uint32)
+        stats = Stats()
+        _check(lib().hvx_search_batch(self._h, _ptr(q), b, k, params.ef, _ptr(ids), _ptr(sc), _ptr(cnt),
+                                      _ptr(st) if per_query_status else None, C.byref(stats)))
+        return (ids, sc, cnt, stats.as_dict()) if not per_query_status else (ids, sc, cnt, stats.as_dict(), st)
+
+    def flat_search_batch(self, queries, k, per_query_status=False):
+        q = self._q(queries)
+        b = q.shape[0]
+        ids = np.zeros((b, k), np.uint64); sc = np.zeros((b, k), np.float32)
+        cnt = np.zeros(b, np.uint32); st = np.zeros(b, np.uint32)
+        stats = Stats()
+        _check(lib().hvx_flat_search_batch(self._h, _ptr(q), b, k, _ptr(ids), _ptr(sc), _ptr(cnt),
+                                           _ptr(st) if per_query_status else None, C.byref(stats)))
+        return (ids, sc, cnt, stats.as_dict()) if not per_query_status else (ids, sc, cnt, stats.as_dict(), st)
+
+    def search_restricted_batch(self, queries, params: SearchParams, candidates, offsets=None):
+        q = self._q(queries)
+        b, k = q.shape[0], params.k
+        al = candidates.ids if isinstance(candidates, RestrictedVectorCandidates) else np.ascontiguousarray(candidates, dtype=np.uint64)
+        off = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.uint64)
+        ids = np.zeros((b, k), np.uint64); sc = np.zeros((b, k), np.float32); cnt = np.zeros(b, np.uint32)
+        _check(lib().hvx_search_restricted_batch(self._h, _ptr(q), b, k, params.ef, _ptr(al), _ptr(off), al.size,
+                                                 _ptr(ids), _ptr(sc), _ptr(cnt), None, None))
+        return ids, sc, cnt
+
+    # ---- device-resident surface (torch tensors on the index's GPU) ----
+    def search_batch_device(self, d_queries, k, ef, d_ids, d_scores, d_counts, d_status, d_qstats=None, want_stats=False):
+        stats = Stats()
+        _check(lib().hvx_search_batch_device(
+            self._h, d_queries.data_ptr(), d_queries.shape[0], k, ef, d_ids.data_ptr(), d_scores.data_ptr(),
+            d_counts.data_ptr(), d_status.data_ptr(), None if d_qstats is None else d_qstats.data_ptr(),
+            C.byref(stats) if want_stats else None))
+        return stats.as_dict() if want_stats else None
+
+    def flat_search_batch_device(self, d_queries, k, d_ids, d_scores, d_counts, d_status, want_stats=False):
+        stats = Stats()
+        _check(lib().hvx_flat_search_batch_device(
+            self._h, d_queries.data_ptr(), d_queries.shape[0], k, d_ids.data_ptr(), d_scores.data_ptr(),
+            d_counts.data_ptr(), d_status.data_ptr(), C.byref(stats) if want_stats else None))
+        return stats.as_dict() if want_stats else None
+
+    def merge_topk_device(self, g, b, k, d_ids, d_scores, d_counts, d_out_ids, d_out_scores, d_out_counts):
+        _check(lib().hvx_merge_topk_device(self._h, g, b, k, d_ids.data_ptr(), d_scores.data_ptr(), d_counts.data_ptr(),
+                                           d_out_ids.data_ptr(), d_out_scores.data_ptr(), d_out_counts.data_ptr()))
+
+    def sync(self):
+        _check(lib().hvx_index_sync(self._h))
+
+
+class Graph:
+    """Device CSR for the graph prefilter (crates/graph-algorithms Graph::traverse; interpreter expand)."""
+
+    def __init__(self, n_nodes, out_offsets, out_targets, edge_labels=None, device=-1):
+        off = np.ascontiguousarray(out_offsets, dtype=np.uint64)
+        tgt = np.ascontiguousarray(out_targets, dtype=np.uint64)
+        lab = None if edge_labels is None else np.ascontiguousarray(edge_labels, dtype=np.uint32)
+        self.n = int(n_nodes)
+        h = _vp()
+        _check(lib().hvx_csr_import(self.n, tgt.size, _ptr(off), _ptr(tgt), _ptr(lab), device, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h:
+            lib().hvx_csr_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def traverse(self, seeds, max_depth, direction=DIR_BOTH, allowed_labels=(), hub_degree=0, include_seeds=True):
+        s = np.ascontiguousarray(seeds, dtype=np.uint64)
+        lab = np.ascontiguousarray(list(allowed_labels), dtype=np.uint32)
+        words = np.zeros((self.n + 63) // 64, np.uint64)
+        depth = np.zeros(max(self.n, 1), np.uint32)
+        _check(lib().hvx_traverse_filter(self._h, _ptr(s), s.size, max_depth, direction, _ptr(lab), lab.size,
+                                         hub_degree, 1 if include_seeds else 0, _ptr(words), _ptr(depth)))
+        return words, depth[: self.n]
+
+    def expand(self, rows, direction=DIR_OUT, allowed_labels=()):
+        s = np.ascontiguousarray(rows, dtype=np.uint64)
+        lab = np.ascontiguousarray(list(allowed_labels), dtype=np.uint32)
+        words = np.zeros((self.n + 63) // 64, np.uint64)
+        _check(lib().hvx_expand_filter(self._h, _ptr(s), s.size, direction, _ptr(lab), lab.size, _ptr(words)))
+        return words

@@ -1,0 +1,180 @@
+/*
+ * helix_vec.h -- C ABI of libhelix_vec_gfx950.so, the MI355X-native vector-search executor that
+ * sits behind HelixDB's vector index facade.
+ *
+ * The reference has no FFI for this path; these are the entry points a Rust
+ * `extern "C"` shim at the B2 seam would bind.  Every entry point cites the reference interface
+ * it replaces (paths relative to /root/reference/).  Conventions follow the project's UniFFI
+ * style: POD buffers in, caller-owned out-buffers, integer status, thread-local error string.
+ *
+ * All host-pointer entry points are re-entrant on an immutable index; calls on ONE index are
+ * serialised on that index's HIP stream.  *_device entry points take device pointers, enqueue on
+ * the index's stream and return without synchronising (use hvx_index_sync).
+ */
+#ifndef HELIX_VEC_H
+#define HELIX_VEC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hvx_index hvx_index; /* opaque, device-resident, immutable after import */
+typedef struct hvx_csr hvx_csr;     /* opaque device-resident CSR graph for traverse/prefilter */
+
+/* crates/db/src/search/vector/mod.rs:283-290, distance/semantics.rs:31-56 */
+enum hvx_metric { HVX_COSINE_HALF = 0, HVX_L2_SQUARED = 1, HVX_MANHATTAN = 2 };
+/* only F32 is an active codec in the reference (distance/mod.rs:17-41); BF16/FP8 are new */
+enum hvx_dtype { HVX_F32 = 0, HVX_BF16 = 1, HVX_FP8_E4M3 = 2 };
+/* which host summation tree scores must be bit-identical to (spaces/simple.rs:45-112):
+ * the reference's result depends on the CPU it runs on; the device reproduces the chosen tree. */
+enum hvx_float_kernel { HVX_KERNEL_SCALAR = 0, HVX_KERNEL_AVX = 2, HVX_KERNEL_AVX_FMA = 3 };
+
+/* HelixDbError variants of the path (crates/db/src/error.rs via search.rs:1101-1230,
+ * restricted.rs:196-260,356-371) */
+enum hvx_status {
+    HVX_OK = 0,
+    HVX_ERR_DIMENSION = 1,       /* InvalidDimension                       domain.rs:118-123 */
+    HVX_ERR_NONFINITE = 2,       /* InvalidVectorComponent{index}          domain.rs:124-128 */
+    HVX_ERR_ZERO_NORM = 3,       /* ZeroNormCosineVector                   domain.rs:129-131 */
+    HVX_ERR_MAGNITUDE = 4,       /* ComponentMagnitudeExceeded             domain.rs:132-146 */
+    HVX_ERR_K_RANGE = 5,         /* k==0, ef<k (parameters.rs:100-133), restricted k>800 (restricted.rs:55) */
+    HVX_ERR_CANDIDATE_LIMIT = 6, /* >1,000,000 restricted candidates       restricted.rs:40,356-371 */
+    HVX_ERR_DEVICE = 7,          /* HIP failure / extension unavailable */
+    HVX_ERR_INVARIANT = 8,       /* InvariantViolation (bad graph row, invalid score, ...) */
+    HVX_ERR_UNSUPPORTED = 9      /* configuration outside what this build implements */
+};
+
+enum hvx_direction { HVX_DIR_OUT = 0, HVX_DIR_IN = 1, HVX_DIR_BOTH = 2 };
+
+/* VectorIndexMetadata + config subset (values/vectors/metadata.rs:22-62) needed by search */
+typedef struct hvx_index_desc {
+    uint32_t dim;
+    uint32_t metric;       /* hvx_metric */
+    uint32_t dtype;        /* hvx_dtype (storage on device; import source is always f32) */
+    uint32_t float_kernel; /* hvx_float_kernel */
+    uint64_t n;            /* rows in this shard */
+    uint32_t m, m0;        /* degree limits (upper layers / layer 0) */
+    uint32_t has_entry;    /* 0 => VectorIndexState::Empty */
+    uint32_t max_layer;
+    uint64_t entry_point;  /* external node id */
+    uint64_t shard_id_lo, shard_id_hi; /* informational: id range held by this shard */
+    int32_t device;        /* HIP device ordinal, -1 = current */
+    uint32_t max_batch;    /* largest query batch the index must serve (sizes scratch); 0 => 1024 */
+} hvx_index_desc;
+
+/* SearchStats subset (mod.rs:629-700) -- exactly the algorithmic-bytes numerators,
+ * summed over the batch, plus device timing of the call. */
+typedef struct hvx_stats {
+    uint64_t queries;
+    uint64_t expansion_steps;
+    uint64_t neighbors_examined;
+    uint64_t vectors_loaded;
+    uint64_t distance_computations;
+    uint64_t tie_overflow_queries; /* queries whose beam had > slack equal-score entries (exactness not proven) */
+    double device_ms;              /* HIP-event time of the search kernels of this call */
+} hvx_stats;
+
+/* per-query counters, same order as the reference's golden test (index.rs:2396-2399) */
+typedef struct hvx_query_stats {
+    uint32_t expansion_steps, neighbors_examined, vectors_loaded, distance_computations;
+} hvx_query_stats;
+
+/*
+ * Import a read-only index image (replaces VectorMemoryStore hydration, memory_store.rs:97-105,
+ * and every row read under VectorIndex::search: storage.rs:1713-2066).
+ *   node_ids      [n] external ids, strictly ascending
+ *   vectors       [n][dim] row-major f32, host memory; validated like decode_item_borrowed
+ *                 (mod.rs:889-949) ONCE here instead of on every fetch
+ *   l0_offsets    [n+1], l0_neighbors: CSR of layer-0 rows over external ids (ids sorted per row:
+ *                 values/vectors.rs:97-111)
+ *   level         [n] top layer of each node (0 = layer 0 only); may be NULL when max_layer==0
+ *   up_offsets    [rows+1], up_neighbors: CSR of upper rows; rows ordered by node, then layer 1..level
+ */
+int hvx_index_import(const hvx_index_desc *desc, const uint64_t *node_ids, const float *vectors,
+                     const uint64_t *l0_offsets, const uint64_t *l0_neighbors, const uint16_t *level,
+                     const uint64_t *up_offsets, const uint64_t *up_neighbors, hvx_index **out);
+void hvx_index_free(hvx_index *);
+int hvx_index_sync(const hvx_index *);
+/* the HIP stream (hipStream_t) search kernels are enqueued on */
+void *hvx_index_stream(const hvx_index *);
+
+/*
+ * ValidatedVectorReadIndex::search (read_index.rs:83-92) -> VectorIndex::search (index.rs:1578-1587)
+ * -> SearchSession::run (search.rs:1101-1230), strict-exhaustive arm, for b queries at once.
+ * Results per query sorted (score asc, id asc), count <= min(k, population).
+ * out_status: per-query hvx_status, nullable; when NULL the first failing query's status is returned
+ * and no results are written.
+ */
+int hvx_search_batch(const hvx_index *, const float *queries /*[b][dim]*/, uint32_t b, uint32_t k,
+                     uint32_t ef, uint64_t *out_ids /*[b][k]*/, float *out_scores /*[b][k]*/,
+                     uint32_t *out_counts /*[b]*/, uint32_t *out_status /*[b] nullable*/,
+                     hvx_stats *stats /*nullable*/);
+/* same, queries/outputs already in HBM; d_query_stats nullable; validation runs on the device */
+int hvx_search_batch_device(const hvx_index *, const float *d_queries, uint32_t b, uint32_t k,
+                            uint32_t ef, uint64_t *d_out_ids, float *d_out_scores,
+                            uint32_t *d_out_counts, uint32_t *d_out_status,
+                            hvx_query_stats *d_query_stats, hvx_stats *stats);
+
+/*
+ * Exact scan over all rows -- the reference has no general flat operator; semantics are
+ * restricted_exact_scan (restricted.rs:753-835) with allowed = every id and no 256-id admission cap.
+ */
+int hvx_flat_search_batch(const hvx_index *, const float *queries, uint32_t b, uint32_t k,
+                          uint64_t *out_ids, float *out_scores, uint32_t *out_counts,
+                          uint32_t *out_status, hvx_stats *stats);
+int hvx_flat_search_batch_device(const hvx_index *, const float *d_queries, uint32_t b, uint32_t k,
+                                 uint64_t *d_out_ids, float *d_out_scores, uint32_t *d_out_counts,
+                                 uint32_t *d_out_status, hvx_stats *stats);
+
+/*
+ * ValidatedVectorReadIndex::search_restricted (read_index.rs:93-102) -> restricted.rs:466-613.
+ * allowed_ids/allowed_offsets: per-query candidate id lists (RestrictedVectorCandidates::from_ids,
+ * restricted.rs:356-371: deduped, <= 1,000,000).  allowed_offsets==NULL => one list of n_allowed ids
+ * shared by all queries.
+ */
+int hvx_search_restricted_batch(const hvx_index *, const float *queries, uint32_t b, uint32_t k,
+                                uint32_t ef, const uint64_t *allowed_ids,
+                                const uint64_t *allowed_offsets /*[b+1] or NULL*/, uint64_t n_allowed,
+                                uint64_t *out_ids, float *out_scores, uint32_t *out_counts,
+                                uint32_t *out_status, hvx_stats *stats);
+
+/* k-way merge of per-shard results by Candidate order (model.rs:55-61); inputs in HBM, laid out
+ * [g][b][k] as an all-gather over shards delivers them. */
+int hvx_merge_topk_device(const hvx_index *, uint32_t g, uint32_t b, uint32_t k, const uint64_t *d_ids,
+                          const float *d_scores, const uint32_t *d_counts, uint64_t *d_out_ids,
+                          float *d_out_scores, uint32_t *d_out_counts);
+
+/*
+ * Graph prefilter (crates/graph-algorithms/src/model.rs:370-417 Csr; algorithms/traversal.rs:197-318
+ * breadth_first; crates/db/src/execution/interpreter/access/expand.rs:16-80 one-hop expand).
+ */
+int hvx_csr_import(uint64_t n_nodes, uint64_t n_edges, const uint64_t *out_offsets /*[n+1]*/,
+                   const uint64_t *out_targets /*[e]*/, const uint32_t *edge_labels /*[e] or NULL*/,
+                   int32_t device, hvx_csr **out);
+void hvx_csr_free(hvx_csr *);
+/* Graph::traverse, BreadthFirst (traversal.rs:216-261): multi-seed BFS with depth cap, direction,
+ * edge-label allow-set (n_labels==0 => every label) and hub policy (hub_degree>0 => non-seed nodes
+ * whose total degree >= hub_degree are emitted but not expanded, :311-318).  Writes a bitmap (1 bit
+ * per node, n_nodes bits rounded up to 64) of every visited node (seeds included iff
+ * include_seeds!=0) and, when out_depth!=NULL, each node's BFS depth (UINT32_MAX = unreached).
+ * Unknown seeds => HVX_ERR_INVARIANT (GraphError::UnknownNode). */
+int hvx_traverse_filter(const hvx_csr *, const uint64_t *seeds, uint32_t n_seeds, uint32_t max_depth,
+                        uint32_t direction, const uint32_t *allowed_label_ids, uint32_t n_labels,
+                        uint32_t hub_degree, uint32_t include_seeds, uint64_t *out_bitmap_words,
+                        uint32_t *out_depth);
+/* One interpreter `expand` hop (crates/db/src/execution/interpreter/access/expand.rs:16-80): the
+ * union of the neighbours of every input row (an input row that is itself a neighbour of another
+ * input row IS included) as the candidate bitmap handed to the restricted vector search. */
+int hvx_expand_filter(const hvx_csr *, const uint64_t *rows, uint32_t n_rows, uint32_t direction,
+                      const uint32_t *allowed_label_ids, uint32_t n_labels, uint64_t *out_bitmap_words);
+
+const char *hvx_last_error(void); /* thread-local */
+const char *hvx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,325 @@
+"""Parity of the gfx950 path (through the C ABI) against the CPU oracle: ids, f32 score BITS and the
+SearchStats counters must be identical.  Run with `-m gpu` on an MI355X."""
+import numpy as np
+import pytest
+
+import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hv():
+    import pyhvx
+    pyhvx.lib()  # fails loudly if the HIP extension is missing
+    return pyhvx
+
+
+def bits(x):
+    return np.ascontiguousarray(x, np.float32).view(np.uint32)
+
+
+def build_oracle(orc, data, metric, levels, m=16, m0=32, efc=100, kernel=None, ids=None):
+    ix = orc.Index(data.shape[1], metric, kernel=orc.K_AVX_FMA if kernel is None else kernel, m=m, m0=m0,
+                   ef_construction=efc)
+    for i in range(data.shape[0]):
+        nid = i if ids is None else int(ids[i])
+        assert ix.insert(nid, data[i], int(levels[i])) == orc.OK
+    return ix
+
+
+def assert_hnsw_equal(orc, hv, oix, gix, queries, k, ef):
+    ids, sc, cnt, stats = gix.search_batch(queries, hv.SearchParams(k).with_ef(ef))
+    tot = dict(expansion_steps=0, neighbors_examined=0, vectors_loaded=0, distance_computations=0)
+    for qi in range(queries.shape[0]):
+        rc, oid, osc, ost = oix.search(queries[qi], k, ef, with_stats=True)
+        assert rc == orc.OK
+        assert cnt[qi] == oid.size, f"query {qi}: count {cnt[qi]} vs oracle {oid.size}"
+        assert ids[qi, :cnt[qi]].tolist() == oid.tolist(), f"query {qi}: ids differ"
+        assert bits(sc[qi, :cnt[qi]]).tolist() == bits(osc).tolist(), f"query {qi}: score bits differ"
+        for key in tot:
+            tot[key] += ost[key]
+    for key in tot:
+        assert stats[key] == tot[key], f"{key}: device {stats[key]} vs oracle {tot[key]}"
+    assert stats["tie_overflow_queries"] == 0
+
+
+# --- reference golden: src/search/vector/index.rs:2318-2412 ---
+def test_phase0_golden_on_device(orc, hv):
+    oix = orc.Index(2, orc.COSINE, m=4, m0=8, ef_construction=16)
+    for (nid, v), lvl in zip([(1, [1, 0]), (2, [0, 1]), (3, [-1, 0]), (4, [0, -1])], [0, 1, 2, 0]):
+        oix.insert(nid, v, lvl)
+    gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=2, metric=hv.COSINE, m=4, m0=8)
+    ids, sc, cnt, st = gix.search_batch(np.array([[1.0, 0.0]], np.float32), hv.SearchParams(4).with_ef(16))
+    assert cnt[0] == 4 and ids[0].tolist() == [1, 2, 4, 3]
+    assert bits(sc[0]).tolist() == bits([0.0, 0.5, 0.5, 1.0]).tolist()
+    assert (st["expansion_steps"], st["neighbors_examined"], st["vectors_loaded"], st["distance_computations"]) == (4, 12, 3, 4)
+    # single-query operator surface
+    res = gix.search([1.0, 0.0], hv.SearchParams(4).with_ef(16))
+    assert [r.entity_id for r in res] == [1, 2, 4, 3]
+
+
+# --- reference golden: src/index_lifecycle/vector/driver.rs:5132-5212 ---
+def test_driver_bruteforce_equivalence_on_device(orc, hv):
+    vecs = np.array([[0, 0, 0], [1, 0, 0], [0, 2, 0], [0, 0, 3], [4, 0, 0], [0, 5, 0], [0, 0, 6], [7, 7, 7]], np.float32)
+    q = np.array([[0.25, 0.5, 0.75]], np.float32)
+    oix = build_oracle(orc, vecs, orc.L2SQ, [0, 1, 0, 0, 2, 0, 1, 0], efc=200)
+    gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=3, metric=hv.EUCLIDEAN)
+    assert_hnsw_equal(orc, hv, oix, gix, q, 8, 8)
+    fid, fsc, fcnt, _ = gix.flat_search_batch(q, 8)
+    hid, hsc, hcnt, _ = gix.search_batch(q, hv.SearchParams(8).with_ef(8))
+    assert fid.tolist() == hid.tolist() and bits(fsc).tolist() == bits(hsc).tolist()
+
+
+# --- reference golden: tests/production_support/vector/restricted.rs:710-800 ---
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_exact_restricted_scan_on_device(orc, hv, metric):
+    ids = np.array([1, 2, 3], np.uint64)
+    vec = np.array([[1, 0], [1, 0], [-1, 0]], np.float32)
+    gix = hv.ValidatedVectorReadIndex.managed(dim=2, metric=metric, node_ids=ids, vectors=vec,
+                                              l0_offsets=np.zeros(4, np.uint64), l0_neighbors=np.zeros(0, np.uint64),
+                                              entry_point=1)
+    res = gix.search_restricted([1.0, 0.0], hv.SearchParams(10), hv.RestrictedVectorCandidates.from_ids([3, 2, 1]))
+    assert [r.entity_id for r in res] == [1, 2, 3]
+    res = gix.search_restricted([1.0, 0.0], hv.SearchParams(10), hv.RestrictedVectorCandidates.from_ids([1, 9999]))
+    assert [r.entity_id for r in res] == [1]
+    assert gix.search_restricted([1.0, 0.0], hv.SearchParams(10), hv.RestrictedVectorCandidates.from_ids([])) == []
+
+
+# --- reference fixture: src/search/vector/scale_contracts.rs (hand-made graph, degree up to 34, M0=64) ---
+@pytest.mark.parametrize("n", [24, 10_000])
+def test_circle_fixture_on_device(orc, hv, n):
+    ids, vec, offs, nbrs = fx.circle_index_arrays(n)
+    oix = orc.Index(2, orc.COSINE, m=32, m0=64, ef_construction=200)
+    assert oix.seed(ids, vec, offs, nbrs, entry_point=1, max_layer=0) == orc.OK
+    gix = hv.ValidatedVectorReadIndex.managed(dim=2, metric=hv.COSINE, node_ids=ids, vectors=vec, l0_offsets=offs,
+                                              l0_neighbors=nbrs, entry_point=1, max_layer=0, m=32, m0=64)
+    q = np.stack(fx.circle_queries(n))
+    assert_hnsw_equal(orc, hv, oix, gix, q, 10, 64)
+    gid, _, _, _ = gix.search_batch(q, hv.SearchParams(10).with_ef(64))
+    tid, _, _, _ = gix.flat_search_batch(q, 10)
+    assert fx.recall_at_k(gid, tid) >= 0.995
+
+
+CASES = [
+    # (n, dim, metric, m, m0, efc, ef, k, nq)
+    (2000, 32, 1, 16, 32, 100, 64, 10, 64),
+    (2000, 100, 1, 16, 32, 100, 128, 10, 64),    # 100 = 3*32 + 4: scalar tail
+    (1500, 128, 0, 16, 32, 100, 128, 10, 64),    # cosine
+    (1200, 48, 2, 8, 16, 60, 100, 5, 32),        # manhattan (sequential order)
+    (1500, 768, 1, 16, 32, 80, 128, 10, 48),     # the bench shape
+    (1500, 20, 1, 16, 32, 80, 200, 20, 32),      # dim < 32: scalar path, R=4 beam
+    (1500, 64, 0, 16, 32, 80, 400, 50, 16),      # R=8 beam
+]
+
+
+@pytest.mark.parametrize("n,dim,metric,m,m0,efc,ef,k,nq", CASES)
+def test_hnsw_bit_exact_vs_oracle(orc, hv, n, dim, metric, m, m0, efc, ef, k, nq):
+    rng = np.random.default_rng(1000 + dim + metric)
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    lv = fx.draw_levels(n, m, seed=dim)
+    ids = np.arange(n, dtype=np.uint64) * 3 + 7  # non-contiguous external ids
+    oix = build_oracle(orc, data, metric, lv, m=m, m0=m0, efc=efc, ids=ids)
+    gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=dim, metric=metric, m=m, m0=m0)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    assert_hnsw_equal(orc, hv, oix, gix, q, k, ef)
+
+
+@pytest.mark.parametrize("kernel", ["avx", "scalar"])
+def test_other_float_kernels(orc, hv, kernel):
+    n, dim = 1000, 96
+    rng = np.random.default_rng(5)
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    lv = fx.draw_levels(n, 16, seed=3)
+    ok, hk = (orc.K_AVX, hv.KERNEL_AVX) if kernel == "avx" else (orc.K_SCALAR, hv.KERNEL_SCALAR)
+    oix = build_oracle(orc, data, orc.L2SQ, lv, kernel=ok)
+    gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=dim, metric=hv.EUCLIDEAN, float_kernel=hk)
+    q = rng.standard_normal((16, dim)).astype(np.float32)
+    assert_hnsw_equal(orc, hv, oix, gix, q, 10, 64)
+
+
+# --- BASELINE config #1: 10k x 128 f32 from the reference generator, flat k=10 ---
+def test_flat_scan_config1_bit_exact(orc, hv):
+    n = 10_000
+    m = fx.lifecycle_matrix(n)
+    ids = np.arange(n, dtype=np.uint64)
+    gix = hv.ValidatedVectorReadIndex.managed(dim=128, metric=hv.EUCLIDEAN, node_ids=ids, vectors=m,
+                                              l0_offsets=np.zeros(n + 1, np.uint64), l0_neighbors=np.zeros(0, np.uint64))
+    qs = [fx.lifecycle_vector(0)]
+    for j in range(1, 64):
+        v = fx.lifecycle_vector((1_000_003 * j) % n).copy()
+        v[j] += np.float32(1e-3)
+        qs.append(v)
+    q = np.stack(qs)
+    gid, gsc, gcnt, _ = gix.flat_search_batch(q, 10)
+    one_id, one_sc, _, _ = gix.flat_search_batch(q[:1], 10)       # single query (the config as quoted)
+    assert one_id[0].tolist() == gid[0].tolist() and one_id[0, 0] == 0 and one_sc[0, 0] == 0.0
+    for qi in range(q.shape[0]):
+        rc, oid, osc = orc.flat_matrix(orc.L2SQ, m, q[qi], 10)
+        assert rc == orc.OK and gcnt[qi] == 10
+        assert gid[qi].tolist() == oid.tolist()
+        assert bits(gsc[qi]).tolist() == bits(osc).tolist()
+
+
+@pytest.mark.parametrize("metric,dim,n,k", [(0, 128, 3000, 10), (2, 40, 3000, 7), (1, 768, 5000, 100), (1, 7, 300, 400)])
+def test_flat_scan_metrics_and_k(orc, hv, metric, dim, n, k):
+    rng = np.random.default_rng(dim)
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    data[7] = data[3]  # exact duplicate row: tie broken by id
+    ids = np.arange(n, dtype=np.uint64) + 100
+    gix = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=metric, node_ids=ids, vectors=data,
+                                              l0_offsets=np.zeros(n + 1, np.uint64), l0_neighbors=np.zeros(0, np.uint64))
+    q = rng.standard_normal((9, dim)).astype(np.float32)
+    q[0] = data[3]
+    gid, gsc, gcnt, _ = gix.flat_search_batch(q, k)
+    for qi in range(q.shape[0]):
+        rc, oid, osc = orc.flat_matrix(metric, data, q[qi], k)
+        assert gcnt[qi] == oid.size == min(k, n)
+        assert (gid[qi, :gcnt[qi]] - 100).tolist() == oid.tolist()
+        assert bits(gsc[qi, :gcnt[qi]]).tolist() == bits(osc).tolist()
+    assert gid[0, :2].tolist() == [103, 107]
+
+
+def test_cosine_extremes_take_f64_fallback(orc, hv):
+    """distance/cosine.rs:128-141: f32::MAX and subnormal rows stay finite through the f64 path."""
+    fmax = np.finfo(np.float32).max
+    tiny = np.array([1], np.uint32).view(np.float32)[0]
+    data = np.array([[fmax, fmax], [tiny, tiny], [1.0, 0.0], [-1.0, 0.5]], np.float32)
+    ids = np.arange(4, dtype=np.uint64)
+    gix = hv.ValidatedVectorReadIndex.managed(dim=2, metric=hv.COSINE, node_ids=ids, vectors=data,
+                                              l0_offsets=np.zeros(5, np.uint64), l0_neighbors=np.zeros(0, np.uint64))
+    q = np.array([[fmax, fmax], [tiny, tiny], [0.3, -0.2]], np.float32)
+    gid, gsc, gcnt, _ = gix.flat_search_batch(q, 4)
+    for qi in range(3):
+        rc, oid, osc = orc.flat_matrix(orc.COSINE, data, q[qi], 4)
+        assert gid[qi].tolist() == oid.tolist()
+        assert bits(gsc[qi]).tolist() == bits(osc).tolist()
+    assert gsc[0, 0] <= np.finfo(np.float32).eps
+
+
+def test_query_validation_statuses(orc, hv):
+    n, dim = 64, 8
+    rng = np.random.default_rng(0)
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    ids = np.arange(n, dtype=np.uint64)
+    zeros = dict(l0_offsets=np.zeros(n + 1, np.uint64), l0_neighbors=np.zeros(0, np.uint64), entry_point=0)
+    l2 = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=hv.EUCLIDEAN, node_ids=ids, vectors=data, **zeros)
+    cs = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=hv.COSINE, node_ids=ids, vectors=data, **zeros)
+    q = rng.standard_normal((4, dim)).astype(np.float32)
+    q[1, 3] = np.nan
+    q[2, :] = 0.0
+    q[3, 0] = np.float32(orc.lib().orc_component_limit(orc.L2SQ, dim)) * np.float32(2)
+    *_, st = l2.search_batch(q, hv.SearchParams(3), per_query_status=True)
+    assert st.tolist() == [hv.OK, hv.ERR_NONFINITE, hv.OK, hv.ERR_MAGNITUDE]
+    ids_c, _, cnt_c, _, st = cs.search_batch(q, hv.SearchParams(3), per_query_status=True)
+    assert st.tolist() == [hv.OK, hv.ERR_NONFINITE, hv.ERR_ZERO_NORM, hv.OK]
+    assert cnt_c[1] == 0 and cnt_c[2] == 0
+    with pytest.raises(hv.HelixDbError) as e:
+        cs.search_batch(q, hv.SearchParams(3))
+    assert e.value.status == hv.ERR_NONFINITE and e.value.is_invalid_vector_input()
+    with pytest.raises(hv.HelixDbError) as e:
+        l2.search_batch(q[:, :4], hv.SearchParams(3))
+    assert e.value.status == hv.ERR_DIMENSION
+    with pytest.raises(hv.HelixDbError) as e:
+        hv.SearchParams(5).with_ef(4)
+    assert e.value.status == hv.ERR_K_RANGE
+    # stored rows are validated at import (decode_item_borrowed, mod.rs:889-949)
+    bad = data.copy(); bad[5, 2] = np.inf
+    with pytest.raises(hv.HelixDbError) as e:
+        hv.ValidatedVectorReadIndex.managed(dim=dim, metric=hv.EUCLIDEAN, node_ids=ids, vectors=bad, **zeros)
+    assert e.value.status == hv.ERR_NONFINITE
+    # empty index: no results, not an error (search.rs:1128)
+    empty = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=hv.EUCLIDEAN, node_ids=np.zeros(0, np.uint64),
+                                                vectors=np.zeros((0, dim), np.float32), l0_offsets=np.zeros(1, np.uint64),
+                                                l0_neighbors=np.zeros(0, np.uint64))
+    assert empty.search(q[0], hv.SearchParams(3)) == []
+
+
+def test_restricted_wide_set_matches_flat_oracle(orc, hv):
+    """Candidate sets above the reference's 256-id exact threshold: the device scans them exactly;
+    result must equal the oracle's exact scan over the same allowed ids (recall 1.0 >= the
+    reference's 0.95 gate, tests/production_support/vector/restricted.rs:1226-1285)."""
+    n, dim = 4000, 64
+    rng = np.random.default_rng(9)
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    lv = np.zeros(n, np.uint16)
+    oix = orc.Index(dim, orc.L2SQ)
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    assert oix.seed(ids, data, np.zeros(n + 1, np.uint64), np.zeros(0, np.uint64), entry_point=1) == orc.OK
+    gix = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=hv.EUCLIDEAN, node_ids=ids, vectors=data,
+                                              l0_offsets=np.zeros(n + 1, np.uint64), l0_neighbors=np.zeros(0, np.uint64),
+                                              entry_point=1)
+    allowed = np.array([i for i in range(1, n + 1) if i % 3 != 0] + [10, 10, 99999], np.uint64)
+    q = rng.standard_normal((6, dim)).astype(np.float32)
+    gid, gsc, gcnt = gix.search_restricted_batch(q, hv.SearchParams(10).with_ef(64), hv.RestrictedVectorCandidates.from_ids(allowed))
+    for qi in range(6):
+        rc, oid, osc = oix.flat(q[qi], 10, allowed=allowed)
+        assert gid[qi, :gcnt[qi]].tolist() == oid.tolist()
+        assert bits(gsc[qi, :gcnt[qi]]).tolist() == bits(osc).tolist()
+    # per-query candidate lists
+    offs = np.array([0, 3, 3, 10], np.uint64)
+    al = np.array([5, 9, 2, 100, 101, 102, 103, 104, 105, 106], np.uint64)
+    gid, _, gcnt = gix.search_restricted_batch(q[:3], hv.SearchParams(10), al, offsets=offs)
+    assert gcnt.tolist() == [3, 0, 7]
+    assert sorted(gid[0, :3].tolist()) == [2, 5, 9]
+    with pytest.raises(hv.HelixDbError) as e:
+        gix.search_restricted_batch(q[:1], hv.SearchParams(900).with_ef(900), np.arange(1, 2001, dtype=np.uint64))
+    assert e.value.status == hv.ERR_K_RANGE
+
+
+def _py_bfs(n, off, tgt, lab, seeds, max_depth, direction, allowed, hub):
+    out = [[] for _ in range(n)]; inc = [[] for _ in range(n)]
+    for u in range(n):
+        for a in range(off[u], off[u + 1]):
+            out[u].append((int(tgt[a]), None if lab is None else int(lab[a])))
+            inc[int(tgt[a])].append((u, None if lab is None else int(lab[a])))
+    depth = {}
+    from collections import deque
+    dq = deque()
+    sset = []
+    for s in seeds:
+        if s not in depth:
+            depth[s] = 0; dq.append(s); sset.append(s)
+    while dq:
+        u = dq.popleft()
+        if depth[u] >= max_depth:
+            continue
+        if u not in sset and hub and len(out[u]) + len(inc[u]) >= hub:
+            continue
+        arcs = (out[u] if direction in (0, 2) else []) + (inc[u] if direction in (1, 2) else [])
+        for v, l in arcs:
+            if allowed and l not in allowed:
+                continue
+            if v not in depth:
+                depth[v] = depth[u] + 1; dq.append(v)
+    return depth
+
+
+def test_traverse_and_expand_match_reference_semantics(hv):
+    """crates/graph-algorithms/src/algorithms/traversal.rs:216-318 (visited set + BFS depth are
+    order-independent) and interpreter expand (access/expand.rs:16-80)."""
+    rng = np.random.default_rng(4)
+    n, e = 500, 3000
+    src = np.sort(rng.integers(0, n, e)); tgt = rng.integers(0, n, e).astype(np.uint64)
+    off = np.zeros(n + 1, np.uint64); np.add.at(off, src + 1, 1); off = np.cumsum(off).astype(np.uint64)
+    lab = rng.integers(0, 4, e).astype(np.uint32)
+    g = hv.Graph(n, off, tgt, lab)
+    for seeds, md, direction, allowed, hub in [([3], 2, 0, [], 0), ([3, 77, 3], 3, 2, [1, 2], 0), ([10, 11], 4, 1, [], 12),
+                                               ([0], 0, 2, [], 0), ([5, 6, 7], 50, 0, [0], 0)]:
+        words, depth = g.traverse(seeds, md, direction, allowed, hub, include_seeds=True)
+        ref = _py_bfs(n, off.astype(np.int64), tgt, lab, seeds, md, direction, set(allowed), hub)
+        got = set(np.nonzero(np.unpackbits(words.view(np.uint8), bitorder="little"))[0].tolist())
+        assert got == set(ref.keys())
+        for v, d in ref.items():
+            assert depth[v] == d
+        words2, _ = g.traverse(seeds, md, direction, allowed, hub, include_seeds=False)
+        got2 = set(np.nonzero(np.unpackbits(words2.view(np.uint8), bitorder="little"))[0].tolist())
+        assert got2 == set(ref.keys()) - set(seeds)
+    rows = [3, 4, 5]
+    w = g.expand(rows, hv.DIR_OUT)
+    exp = set()
+    for u in rows:
+        exp |= set(int(x) for x in tgt[int(off[u]):int(off[u + 1])])
+    assert set(np.nonzero(np.unpackbits(w.view(np.uint8), bitorder="little"))[0].tolist()) == exp
+    with pytest.raises(hv.HelixDbError):
+        g.traverse([n + 5], 1)

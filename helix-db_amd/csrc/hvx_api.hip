@@ -77,11 +77,11 @@ template <typename F> static void parallel_for(uint64_t n, F f) {
 
 static void free_index(hvx_index *ix) {
     if (!ix) return;
-    hipSetDevice(ix->device);
-    for (void *p : ix->allocs) hipFree(p);
-    if (ix->ev0) hipEventDestroy(ix->ev0);
-    if (ix->ev1) hipEventDestroy(ix->ev1);
-    if (ix->stream) hipStreamDestroy(ix->stream);
+    (void)hipSetDevice(ix->device);
+    for (void *p : ix->allocs) (void)hipFree(p);
+    if (ix->ev0) (void)hipEventDestroy(ix->ev0);
+    if (ix->ev1) (void)hipEventDestroy(ix->ev1);
+    if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
     delete ix;
 }
 
@@ -95,6 +95,15 @@ extern "C" int hvx_index_sync(const hvx_index *ix) {
 }
 
 extern "C" void *hvx_index_stream(const hvx_index *ix) { return ix ? (void *)ix->stream : nullptr; }
+
+extern "C" int hvx_index_set_stream(hvx_index *ix, void *hip_stream) {
+    if (!ix) return fail(HVX_ERR_INVARIANT, "null index");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    ix->stream = hip_stream ? (hipStream_t)hip_stream : ix->own_stream;
+    return HVX_OK;
+}
 
 int hvx_index::dalloc(void **p, size_t bytes) {
     if (bytes == 0) bytes = 16;
@@ -146,9 +155,10 @@ extern "C" int hvx_index_import(const hvx_index_desc *desc, const uint64_t *node
     if (desc->max_layer > 63) { free_index(ix); return fail(HVX_ERR_INVARIANT, "max_layer > 63"); }
 
     auto bail = [&](int code) { free_index(ix); return code; };
-    if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess ||
+    if (hipStreamCreateWithFlags(&ix->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ix->ev0) != hipSuccess || hipEventCreate(&ix->ev1) != hipSuccess)
         return bail(fail(HVX_ERR_DEVICE, "stream/event creation failed"));
+    ix->stream = ix->own_stream;
 
     // ---- ids: strictly ascending; contiguous ranges get an arithmetic id->index map ----
     ix->ids.assign(node_ids, node_ids + n);
@@ -244,7 +254,7 @@ extern "C" int hvx_index_import(const hvx_index_desc *desc, const uint64_t *node
     if ((rc = upload(h_up.data(), h_up.size() * 4, (const void **)&d.up))) return bail(rc);
     if ((rc = upload(h_up_base.data(), h_up_base.size() * 4, (const void **)&d.up_base))) return bail(rc);
     if ((rc = upload(h_level.data(), h_level.size() * 2, (const void **)&d.level))) return bail(rc);
-    if ((rc = upload(ix->ids.data(), std::max<size_t>(ix->ids.size(), 1) * 8, (const void **)&d.ids))) return bail(rc);
+    if ((rc = upload(ix->ids.data(), ix->ids.size() * 8, (const void **)&d.ids))) return bail(rc);
 
     // ---- validate rows + headers ONCE on the device (decode_item_borrowed does it per fetch:
     //      mod.rs:889-949) ----
@@ -260,7 +270,7 @@ extern "C" int hvx_index_import(const hvx_index_desc *desc, const uint64_t *node
         std::vector<uint32_t> st(n);
         if (e == hipSuccess) e = hipMemcpyAsync(st.data(), d_rowstatus, n * 4, hipMemcpyDeviceToHost, ix->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
-        hipFree(d_rowstatus);
+        (void)hipFree(d_rowstatus);
         if (e != hipSuccess) return bail(fail(HVX_ERR_DEVICE, "row validation: %s", hipGetErrorString(e)));
         for (uint64_t i = 0; i < n; ++i)
             if (st[i]) return bail(fail((int)st[i], "stored vector of node %llu is invalid for this metric (status %u)", (unsigned long long)node_ids[i], st[i]));
@@ -329,7 +339,6 @@ static int enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t
                           hvx_query_stats *d_qstats, bool timed) {
     hvx_index *ix = const_cast<hvx_index *>(cix);
     HIP_TRY(launch_validate_queries(ix->dev, d_queries, b, ix->limit, ix->d_qstatus, ix->d_qhdr, ix->stream));
-    if (timed) HIP_TRY(hipEventRecord(ix->ev0, ix->stream));
     HIP_TRY(hipMemsetAsync(ix->d_bitmap, 0, (size_t)b * ix->words_per_query * 4, ix->stream));
     HnswArgs a;
     a.ix = ix->dev;
@@ -346,6 +355,7 @@ static int enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t
     a.out_status = d_status;
     a.qstats = d_qstats ? d_qstats : ix->d_qstats;
     a.tie_flags = ix->d_tie;
+    if (timed) HIP_TRY(hipEventRecord(ix->ev0, ix->stream)); // device_ms = the search kernel alone
     HIP_TRY(launch_hnsw_search(a, b, ix->stream));
     if (timed) HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
     return HVX_OK;

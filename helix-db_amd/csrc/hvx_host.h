@@ -15,7 +15,8 @@ struct hvx_index {
     float limit = 0.f;               // VectorComponentLimit (domain.rs:26-78); +inf for cosine
     uint32_t max_batch = 1024;
     uint32_t words_per_query = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // stream in use
+    hipStream_t own_stream = nullptr;  // created at import
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::mutex mu;                   // calls on one index are serialised on its stream
     std::vector<void *> allocs;

@@ -83,6 +83,8 @@ def lib():
     L.hvx_index_sync.argtypes = [_vp]
     L.hvx_index_stream.restype = _vp
     L.hvx_index_stream.argtypes = [_vp]
+    L.hvx_index_set_stream.restype = C.c_int
+    L.hvx_index_set_stream.argtypes = [_vp, _vp]
     L.hvx_search_batch.restype = C.c_int
     L.hvx_search_batch.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, C.POINTER(Stats)]
     L.hvx_search_batch_device.restype = C.c_int
@@ -274,6 +276,10 @@ class ValidatedVectorReadIndex:
 
     def sync(self):
         _check(lib().hvx_index_sync(self._h))
+
+    def set_stream(self, hip_stream):
+        """Enqueue on a caller-owned hipStream_t (int handle, e.g. torch.cuda.current_stream().cuda_stream)."""
+        _check(lib().hvx_index_set_stream(self._h, _vp(hip_stream) if hip_stream else None))
 
 
 class Graph:

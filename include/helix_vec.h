@@ -74,7 +74,8 @@ typedef struct hvx_stats {
     uint64_t vectors_loaded;
     uint64_t distance_computations;
     uint64_t tie_overflow_queries; /* queries whose beam had > slack equal-score entries (exactness not proven) */
-    double device_ms;              /* HIP-event time of the search kernels of this call */
+    double device_ms;              /* HIP-event time of the search kernel(s) of this call (HNSW: the beam-search
+                                      kernel alone; flat: distance+select+finish kernels) */
 } hvx_stats;
 
 /* per-query counters, same order as the reference's golden test (index.rs:2396-2399) */
@@ -100,6 +101,9 @@ void hvx_index_free(hvx_index *);
 int hvx_index_sync(const hvx_index *);
 /* the HIP stream (hipStream_t) search kernels are enqueued on */
 void *hvx_index_stream(const hvx_index *);
+/* enqueue on a caller-owned stream instead (e.g. the host runtime's current stream, so that
+ * collectives and searches order without host synchronisation); NULL restores the index's own. */
+int hvx_index_set_stream(hvx_index *, void *hip_stream);
 
 /*
  * ValidatedVectorReadIndex::search (read_index.rs:83-92) -> VectorIndex::search (index.rs:1578-1587)

@@ -125,6 +125,10 @@ static float simd_tree(const float *a, const float *b, uint32_t n, int width, in
 /* spaces/simple.rs:120-144 euclidean_distance (dispatch incl. MIN_DIM_SIZE_AVX=32 / _SIMD=16) */
 float orc_euclidean(const float *a, const float *b, uint32_t n, int kernel) {
     switch (kernel) {
+    case ORC_KERNEL_AVX_FMA_HW:
+        if (orc_have_avxfma_hw()) return orc_euclidean_avxfma_hw(a, b, n);
+        if (n >= 32) return simd_tree(a, b, n, 8, 1, 1, 0);
+        break;
     case ORC_KERNEL_AVX_FMA:
         if (n >= 32) return simd_tree(a, b, n, 8, 1, 1, 0);
         break;
@@ -146,6 +150,10 @@ float orc_euclidean(const float *a, const float *b, uint32_t n, int kernel) {
 /* spaces/simple.rs:155-178 dot_product */
 float orc_dot(const float *a, const float *b, uint32_t n, int kernel) {
     switch (kernel) {
+    case ORC_KERNEL_AVX_FMA_HW:
+        if (orc_have_avxfma_hw()) return orc_dot_avxfma_hw(a, b, n);
+        if (n >= 32) return simd_tree(a, b, n, 8, 1, 0, 0);
+        break;
     case ORC_KERNEL_AVX_FMA:
         if (n >= 32) return simd_tree(a, b, n, 8, 1, 0, 0);
         break;
@@ -718,6 +726,51 @@ int orc_search(const orc_index *ix, const float *query, uint32_t qlen, uint32_t 
     *out_count = cnt;
     free(w);
     return ORC_OK;
+}
+
+/* BASELINE.md CPU-baseline plan (ii): one query per thread at a time, static interleaved split */
+#include <pthread.h>
+typedef struct {
+    const orc_index *ix;
+    const float *queries;
+    uint32_t nq, k, ef, tid, nthreads;
+    uint64_t *ids;
+    float *scores;
+    uint32_t *counts;
+    orc_stats *stats;
+    int rc;
+} mt_job;
+static void *mt_worker(void *arg) {
+    mt_job *j = (mt_job *)arg;
+    for (uint32_t q = j->tid; q < j->nq; q += j->nthreads) {
+        orc_stats st;
+        int rc = orc_search(j->ix, j->queries + (size_t)q * j->ix->dim, j->ix->dim, j->k, j->ef,
+                            j->ids + (size_t)q * j->k, j->scores + (size_t)q * j->k, j->counts + q, &st);
+        if (j->stats) j->stats[q] = st;
+        if (rc && !j->rc) j->rc = rc;
+    }
+    return NULL;
+}
+int orc_search_batch_mt(const orc_index *ix, const float *queries, uint32_t nq, uint32_t k, uint32_t ef,
+                        uint32_t threads, uint64_t *out_ids, float *out_scores, uint32_t *out_counts,
+                        orc_stats *stats) {
+    if (threads == 0) threads = 1;
+    if (threads > nq) threads = nq ? nq : 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads);
+    mt_job *jobs = (mt_job *)malloc(sizeof(mt_job) * threads);
+    for (uint32_t t = 0; t < threads; ++t) {
+        mt_job j = {ix, queries, nq, k, ef, t, threads, out_ids, out_scores, out_counts, stats, 0};
+        jobs[t] = j;
+        pthread_create(&th[t], NULL, mt_worker, &jobs[t]);
+    }
+    int rc = 0;
+    for (uint32_t t = 0; t < threads; ++t) {
+        pthread_join(th[t], NULL);
+        if (jobs[t].rc && !rc) rc = jobs[t].rc;
+    }
+    free(th);
+    free(jobs);
+    return rc;
 }
 
 /* restricted.rs:753-835 restricted_exact_scan (+ :661-704): bounded max-heap of k, final sort */

@@ -33,7 +33,11 @@ enum {
     ORC_KERNEL_SSE = 1,
     ORC_KERNEL_AVX = 2,
     ORC_KERNEL_AVX_FMA = 3,
-    ORC_KERNEL_NEON = 4
+    ORC_KERNEL_NEON = 4,
+    /* same summation tree as ORC_KERNEL_AVX_FMA executed with the real AVX2+FMA instructions
+     * (bit-identical, proven by tests/test_oracle_golden.py); this is what the timed cpu_baseline
+     * uses.  Falls back to the portable emulation when the host lacks AVX2+FMA. */
+    ORC_KERNEL_AVX_FMA_HW = 5
 };
 
 /* statuses mirror include/helix_vec.h (hvx_status) */
@@ -106,6 +110,12 @@ int orc_index_export(const orc_index *, uint64_t *node_ids, float *vectors, uint
 /* SearchSession::run, strict-exhaustive arm (search.rs:1101-1230, :169-224, :267-1067 STRICT). */
 int orc_search(const orc_index *, const float *query, uint32_t query_len, uint32_t k, uint32_t ef,
                uint64_t *out_ids, float *out_scores, uint32_t *out_count, orc_stats *stats);
+/* nq independent orc_search calls spread over `threads` pthreads (one query per thread at a time:
+ * BASELINE.md "CPU-baseline plan" (ii)); outputs are [nq][k]; per-query stats optional.
+ * Returns the first non-OK status, 0 otherwise. */
+int orc_search_batch_mt(const orc_index *, const float *queries, uint32_t nq, uint32_t k, uint32_t ef,
+                        uint32_t threads, uint64_t *out_ids, float *out_scores, uint32_t *out_counts,
+                        orc_stats *stats);
 /* exact scan over all rows or over an allowed id list (restricted.rs:753-835, :661-704). */
 int orc_flat_search(const orc_index *, const float *query, uint32_t query_len, uint32_t k,
                     const uint64_t *allowed_ids, uint64_t n_allowed, uint64_t *out_ids,

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libhvx_oracle.so")
 
 COSINE, L2SQ, L1 = 0, 1, 2
-K_SCALAR, K_SSE, K_AVX, K_AVX_FMA, K_NEON = 0, 1, 2, 3, 4
+K_SCALAR, K_SSE, K_AVX, K_AVX_FMA, K_NEON, K_AVX_FMA_HW = 0, 1, 2, 3, 4, 5
 OK, ERR_DIMENSION, ERR_NONFINITE, ERR_ZERO_NORM, ERR_MAGNITUDE, ERR_K_RANGE, ERR_CANDIDATE_LIMIT, \
     ERR_DEVICE, ERR_INVARIANT = range(9)
 
@@ -96,6 +96,9 @@ def lib():
     L.orc_search.restype = C.c_int
     L.orc_search.argtypes = [C.c_void_p, f32p, C.c_uint32, C.c_uint32, C.c_uint32, u64p, f32p, u32p,
                              C.POINTER(Stats)]
+    L.orc_search_batch_mt.restype = C.c_int
+    L.orc_search_batch_mt.argtypes = [C.c_void_p, f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                      u64p, f32p, u32p, C.POINTER(Stats)]
     L.orc_flat_search.restype = C.c_int
     L.orc_flat_search.argtypes = [C.c_void_p, f32p, C.c_uint32, C.c_uint32, u64p, C.c_uint64, u64p,
                                   f32p, u32p]
@@ -235,6 +238,17 @@ class Index:
                               sc.ctypes.data_as(f32p), C.byref(cnt), C.byref(st))
         res = (rc, ids[: cnt.value].copy(), sc[: cnt.value].copy())
         return res + (st.as_dict(),) if with_stats else res
+
+    def search_batch(self, queries, k, ef, threads=1):
+        """nq independent searches on `threads` pthreads; returns (rc, ids[nq,k], scores, counts, stats list)."""
+        q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, self.dim)
+        nq = q.shape[0]
+        ids = np.zeros((nq, k), np.uint64); sc = np.zeros((nq, k), np.float32)
+        cnt = np.zeros(nq, np.uint32); st = (Stats * nq)()
+        rc = lib().orc_search_batch_mt(self._h, q.ctypes.data_as(f32p), nq, k, ef, threads,
+                                       ids.ctypes.data_as(u64p), sc.ctypes.data_as(f32p),
+                                       cnt.ctypes.data_as(u32p), st)
+        return rc, ids, sc, cnt, [s.as_dict() for s in st]
 
     def flat(self, query, k, allowed=None):
         q, pq = _f(query)

@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores (capped at 64)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle bit-exactness check")
+    ap.add_argument("--graph-cache", default="", help="npz path: reuse the built graph across invocations on one box")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "traffic_latest.json"))
     return ap.parse_args()
 
@@ -94,7 +95,18 @@ def main():
     log(f"corpus {n_total}x{dim} f32 generated in {time.time() - t0:.1f}s; shard rows [{id_lo},{id_lo + n})")
 
     t0 = time.time()
-    g = synth.build_hnsw_graph(x, m=args.m, m0=2 * args.m, level_seed=7 + rank)
+    cache = f"{args.graph_cache}.r{rank}.npz" if args.graph_cache else ""
+    cache_key = f"{args.dataset}-{n}-{dim}-{args.m}-{args.seed}-{args.latent}-{args.clusters}-{world}"
+    g = None
+    if cache and os.path.exists(cache):
+        z = np.load(cache, allow_pickle=False)
+        if str(z["key"]) == cache_key:
+            g = {kk: z[kk] for kk in z.files if kk != "key"}
+            g["entry_point"], g["max_layer"] = int(g["entry_point"]), int(g["max_layer"])
+    if g is None:
+        g = synth.build_hnsw_graph(x, m=args.m, m0=2 * args.m, level_seed=7 + rank)
+        if cache:
+            np.savez(cache, key=np.array(cache_key), **g)
     torch.cuda.synchronize()
     deg = np.diff(g["l0_offsets"].astype(np.int64))
     log(f"graph built in {time.time() - t0:.1f}s: layer-0 degree mean {deg.mean():.1f} max {deg.max()}, max_layer {g['max_layer']}")
@@ -194,7 +206,7 @@ def main():
             traffic = json.load(open(args.traffic_file)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "hnsw_search_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+    roofline = {"bound": "hbm", "kernel": "hnsw_search_kernel" if os.environ.get("HVX_HNSW_GENERAL") else "hnsw_wave_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": round(k_ms, 4),
                 "distance_computations_per_query": round(dist_comp / b, 1),

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -281,6 +282,7 @@ extern "C" int hvx_index_import(const hvx_index_desc *desc, const uint64_t *node
     ix->words_per_query = round_up((uint32_t)((n + 31) / 32), 4);
     if (ix->words_per_query == 0) ix->words_per_query = 4;
     if ((rc = ix->dalloc((void **)&ix->d_bitmap, (size_t)mb * ix->words_per_query * 4))) return bail(rc);
+    if (hipMemset(ix->d_bitmap, 0, (size_t)mb * ix->words_per_query * 4) != hipSuccess) return bail(fail(HVX_ERR_DEVICE, "bitmap clear failed"));
     if ((rc = ix->dalloc((void **)&ix->d_qstatus, (size_t)mb * 4))) return bail(rc);
     if ((rc = ix->dalloc((void **)&ix->d_qhdr, (size_t)mb * 4))) return bail(rc);
     if ((rc = ix->dalloc((void **)&ix->d_tie, (size_t)mb * 4))) return bail(rc);
@@ -339,7 +341,6 @@ static int enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t
                           hvx_query_stats *d_qstats, bool timed) {
     hvx_index *ix = const_cast<hvx_index *>(cix);
     HIP_TRY(launch_validate_queries(ix->dev, d_queries, b, ix->limit, ix->d_qstatus, ix->d_qhdr, ix->stream));
-    HIP_TRY(hipMemsetAsync(ix->d_bitmap, 0, (size_t)b * ix->words_per_query * 4, ix->stream));
     HnswArgs a;
     a.ix = ix->dev;
     a.queries = d_queries;
@@ -355,8 +356,38 @@ static int enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t
     a.out_status = d_status;
     a.qstats = d_qstats ? d_qstats : ix->d_qstats;
     a.tie_flags = ix->d_tie;
+    a.prof = nullptr;
+    const bool prof = getenv("HVX_WAVE_PROF") != nullptr; // tuning hook: phase-timing kernel + stderr report
+    if (prof) {
+        if (!ix->d_prof && ix->dalloc((void **)&ix->d_prof, (size_t)ix->max_batch * 64)) return HVX_ERR_DEVICE;
+        a.prof = ix->d_prof;
+    }
+    // the HBM visited bitmap is all-zero at import; the general kernel dirties it, the wave kernel
+    // (LDS visited set, bitmap only as overflow) hands it back zeroed
+    const bool force_general = getenv("HVX_HNSW_GENERAL") != nullptr; // test hook
+    const bool wave = !force_general && hnsw_wave_supported(a);
+    if (ix->bitmap_dirty) {
+        HIP_TRY(hipMemsetAsync(ix->d_bitmap, 0, (size_t)ix->max_batch * ix->words_per_query * 4, ix->stream));
+        ix->bitmap_dirty = false;
+    }
     if (timed) HIP_TRY(hipEventRecord(ix->ev0, ix->stream)); // device_ms = the search kernel alone
-    HIP_TRY(launch_hnsw_search(a, b, ix->stream));
+    if (wave) {
+        HIP_TRY(launch_hnsw_wave(a, b, ix->stream));
+        if (prof) {
+            std::vector<unsigned long long> h((size_t)b * 8);
+            HIP_TRY(hipMemcpyAsync(h.data(), ix->d_prof, h.size() * 8, hipMemcpyDeviceToHost, ix->stream));
+            HIP_TRY(hipStreamSynchronize(ix->stream));
+            double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (uint32_t i = 0; i < b; ++i)
+                for (int j = 0; j < 8; ++j) acc[j] += (double)h[(size_t)i * 8 + j];
+            fprintf(stderr, "[hvx prof] per query: row-wait %.0f  visited %.0f  gather+fma %.0f  predict %.0f  admit %.0f cycles;"
+                            " inserts %.1f  prefetch-hits %.1f  upper-layers %.0f cycles\n",
+                    acc[0] / b, acc[1] / b, acc[2] / b, acc[3] / b, acc[4] / b, acc[5] / b, acc[6] / b, acc[7] / b);
+        }
+    } else {
+        HIP_TRY(launch_hnsw_search(a, b, ix->stream));
+        ix->bitmap_dirty = true;
+    }
     if (timed) HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
     return HVX_OK;
 }

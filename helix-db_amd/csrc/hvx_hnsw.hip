@@ -15,6 +15,9 @@
 //     without the expanded bit.  Insert = ballot-popcount position + one DPP wave-shift;
 //   * visited set = one bit per node per query in HBM, test-and-set with atomicOr (exact for any
 //     shard size, sized for 288 GB: 125 KB/query at 1M rows).
+#include <cstdlib>
+
+#include "hvx_beam.h"
 #include "hvx_device.h"
 #include "hvx_kernels.h"
 
@@ -49,92 +52,6 @@ __device__ __forceinline__ LdsView carve(char *smem, uint32_t ld) {
 size_t hnsw_lds_bytes(uint32_t ld) {
     return (((size_t)ld * 4u + 15u) & ~(size_t)15u) + 4u * kMaxStride * 4u + kClearCap * 4u + 64u;
 }
-
-// wave-shift right by one lane; lane 0 receives `carry`
-__device__ __forceinline__ uint32_t shr1(uint32_t v, uint32_t carry) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)v, 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
-}
-
-// The beam: CAP = 64*R entries sorted by (score, id) ascending; id bit31 = already expanded.
-template <int R> struct Beam {
-    float sc[R];
-    uint32_t id[R];
-    uint32_t count;
-
-    __device__ __forceinline__ void init() {
-#pragma unroll
-        for (int r = 0; r < R; ++r) { sc[r] = 0.f; id[r] = 0u; }
-        count = 0;
-    }
-    __device__ __forceinline__ float score_at(uint32_t pos) const {
-        float v = 0.f;
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            if ((pos >> 6) == (uint32_t)r) v = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sc[r]), pos & 63u));
-        return v;
-    }
-    __device__ __forceinline__ uint32_t id_at(uint32_t pos) const {
-        uint32_t v = 0;
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            if ((pos >> 6) == (uint32_t)r) v = __builtin_amdgcn_readlane(id[r], pos & 63u);
-        return v;
-    }
-    // first entry without the expanded bit; returns count if none
-    __device__ __forceinline__ uint32_t first_unexpanded(int lane) const {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            uint32_t e = (uint32_t)r * 64u + (uint32_t)lane;
-            unsigned long long m = __ballot(e < count && !(id[r] & kExpandedBit));
-            if (m) return (uint32_t)r * 64u + (uint32_t)__builtin_ctzll(m);
-        }
-        return count;
-    }
-    __device__ __forceinline__ void mark_expanded(uint32_t pos, int lane) {
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            if ((pos >> 6) == (uint32_t)r && (pos & 63u) == (uint32_t)lane) id[r] |= kExpandedBit;
-    }
-    // sorted insert; returns true when an unexpanded entry fell off the end
-    __device__ __forceinline__ bool insert(float d, uint32_t nid, int lane, float &dropped_score) {
-        uint32_t p = 0;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            uint32_t e = (uint32_t)r * 64u + (uint32_t)lane;
-            uint32_t eid = id[r] & ~kExpandedBit;
-            bool less = e < count && (sc[r] < d || (sc[r] == d && eid < nid));
-            p += (uint32_t)__builtin_popcountll(__ballot(less));
-        }
-        constexpr uint32_t CAP = 64u * R;
-        bool dropped = false;
-        if (count == CAP) {
-            uint32_t last = id_at(CAP - 1);
-            dropped_score = score_at(CAP - 1);
-            dropped = !(last & kExpandedBit);
-            if (p == CAP) return dropped_new_only(d, dropped_score);
-        }
-#pragma unroll
-        for (int r = R - 1; r >= 0; --r) {
-            uint32_t e = (uint32_t)r * 64u + (uint32_t)lane;
-            uint32_t cs = 0, ci = 0;
-            if (r > 0) {
-                cs = __builtin_amdgcn_readlane(__float_as_uint(sc[r - 1]), 63);
-                ci = __builtin_amdgcn_readlane(id[r - 1], 63);
-            }
-            uint32_t ss = shr1(__float_as_uint(sc[r]), cs);
-            uint32_t si = shr1(id[r], ci);
-            if (e == p) { sc[r] = d; id[r] = nid; }
-            else if (e > p) { sc[r] = __uint_as_float(ss); id[r] = si; }
-        }
-        if (count < CAP) ++count;
-        return dropped;
-    }
-    // the new entry itself would land past the end of a full beam
-    __device__ __forceinline__ bool dropped_new_only(float d, float &dropped_score) {
-        dropped_score = d;
-        return true;
-    }
-};
 
 // wavefront 0: test-and-set the visited bits of one neighbour row and compact the unvisited ids,
 // in row order (= ascending id), into fr[]; returns frontier size, *deg = valid ids in the row.
@@ -378,6 +295,41 @@ hipError_t launch_hnsw_search(const HnswArgs &a, uint32_t b, hipStream_t s) {
     case kL2: return fused ? launch_r<kL2, true>(a, b, s) : launch_r<kL2, false>(a, b, s);
     default: return launch_r<kL1, true>(a, b, s);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dispatch to the one-wavefront-per-query kernel (hvx_hnsw_wave.h)
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_hnsw_wave_l2(const HnswArgs &a, uint32_t b, uint32_t log2cap, size_t lds, hipStream_t s);
+hipError_t launch_hnsw_wave_cos(const HnswArgs &a, uint32_t b, uint32_t log2cap, size_t lds, hipStream_t s);
+hipError_t launch_hnsw_wave_prof(const HnswArgs &a, uint32_t b, uint32_t log2cap, size_t lds, hipStream_t s);
+
+bool hnsw_wave_supported(const HnswArgs &a) {
+    const DevIndex &ix = a.ix;
+    if (ix.metric != kL2 && ix.metric != kCosine) return false;
+    if (ix.fkernel != kKernelAvxFma) return false;
+    if (ix.dim % 32u != 0u || ix.dim_main != ix.dim || ix.ld != ix.dim) return false;
+    const uint32_t nk = ix.dim >> 5;
+    if (nk != 4 && nk != 8 && nk != 16 && nk != 24 && nk != 32 && nk != 48) return false;
+    if (ix.s0 > 64 || ix.su > 64) return false;
+    if (a.ef + 32u > 384u) return false;
+    return true;
+}
+
+hipError_t launch_hnsw_wave(const HnswArgs &a, uint32_t b, hipStream_t s) {
+    // visited hash: >= 64 slots per beam entry keeps the load factor under ~0.3 at the measured
+    // ~10 distance evaluations per expansion; the kernel spills to the HBM bitmap beyond half full
+    uint32_t log2cap = 11;
+    while ((1u << log2cap) < 64u * a.ef && log2cap < 15) ++log2cap;
+    if (const char *e = getenv("HVX_WAVE_LOG2CAP")) { // test hook: force a small table to exercise the spill path
+        const int v = atoi(e);
+        if (v >= 7 && v <= 15) log2cap = (uint32_t)v;
+    }
+    size_t lds = ((size_t)4 << log2cap) + 512 + (size_t)a.ix.dim * 4;
+    // exactly four resident wavefronts per CU (one per SIMD, 512 VGPRs each): 160 KiB / 4
+    if (lds < 40 * 1024) lds = 40 * 1024;
+    if (a.prof) return launch_hnsw_wave_prof(a, b, log2cap, lds, s);
+    return a.ix.metric == kL2 ? launch_hnsw_wave_l2(a, b, log2cap, lds, s) : launch_hnsw_wave_cos(a, b, log2cap, lds, s);
 }
 
 } // namespace hvx

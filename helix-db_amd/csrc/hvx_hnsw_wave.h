@@ -1,0 +1,441 @@
+// hvx_hnsw_wave.h -- the fast HNSW search kernel: ONE wavefront per query, no workgroup barriers.
+//
+// Same algorithm, same results, same counters as hvx_hnsw.hip (SearchSession::run,
+// crates/db/src/search/vector/search.rs:1101-1230; greedy upper layers :169-224; strict-exhaustive
+// layer-0 beam :267-1067) -- restructured around what bounded the first kernel
+// on MI355X (profiles/r01a: 11.6 us per expansion, three dependent HBM round trips + barriers):
+//
+//   * 1024 queries = 1024 wavefronts = one wave per SIMD on all 256 CUs: each wave owns a whole
+//     SIMD's register file, so a full
+//     pass of P x 8 neighbour rows (P*NK 16-byte loads per lane, 8 lanes per row, rows coalesced
+//     128 B per load) is in flight before the first FMA -- one HBM latency per expansion, not three;
+//   * the visited set is an open-addressing hash table in LDS (ds_cmpst, ~100 cycles) instead of an
+//     HBM bitmap (atomicOr round trip); it spills to the exact HBM bitmap if it ever fills;
+//   * the next candidate's neighbour row is predicted from the fresh distances and its load is issued
+//     before the sequential admission loop, so the row fetch overlaps the beam inserts;
+//   * distances keep the host SIMD summation order (hvx_device.h) => scores are bit-identical to the
+//     reference CPU path; the beam (hvx_beam.h) is exact.
+//
+// Served shapes: metric L2 / cosine, AVX+FMA summation tree, dim = 32*NK with NK in
+// {4,8,16,24,32,48}, neighbour rows <= 64 ids, ef + 32 <= 384.  Everything else runs on the general
+// kernel in hvx_hnsw.hip.
+#pragma once
+#include "hvx_beam.h"
+#include "hvx_device.h"
+#include "hvx_kernels.h"
+
+namespace hvx {
+
+constexpr uint32_t kTabEmpty = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint32_t umin_dpp_row(uint32_t v) {
+    // butterfly inside each 16-lane DPP row: xor1, xor2, half-mirror (7-l), mirror (15-l)
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); v = v < t ? v : t;
+    t = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true); v = v < t ? v : t;
+    t = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true); v = v < t ? v : t;
+    t = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, true); v = v < t ? v : t;
+    return v;
+}
+// wave-wide unsigned minimum, result uniform
+__device__ __forceinline__ uint32_t wave_umin(uint32_t v) {
+    v = umin_dpp_row(v);
+    uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    uint32_t c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    a = a < b ? a : b;
+    c = c < d ? c : d;
+    return a < c ? a : c;
+}
+
+// Visited set of one query: LDS hash table, exact; falls back to the HBM bitmap when half full.
+struct Visited {
+    uint32_t *tab;      // LDS [cap]
+    uint32_t *bm;       // HBM bitmap of this query (zeroed by the host before the launch)
+    uint32_t mask, shift, cap, words;
+    uint32_t count;     // uniform: ids inserted into the table since the last clear
+    bool spilled;       // uniform: bitmap mode
+
+    __device__ __forceinline__ void clear(int lane) {
+        if (spilled) {
+            for (uint32_t w = (uint32_t)lane; w < words; w += 64) bm[w] = 0u;
+            spilled = false;
+        }
+        for (uint32_t i = (uint32_t)lane; i < cap; i += 64) tab[i] = kTabEmpty;
+        count = 0;
+        __syncthreads();
+    }
+    __device__ __forceinline__ void spill(int lane) {
+        for (uint32_t i = (uint32_t)lane; i < cap; i += 64) {
+            uint32_t v = tab[i];
+            if (v != kTabEmpty) atomicOr(&bm[v >> 5], 1u << (v & 31u));
+        }
+        spilled = true;
+        __threadfence_block();
+    }
+    // test-and-set for the lanes with valid==true (ids distinct across lanes); true = newly inserted
+    __device__ __forceinline__ bool insert(uint32_t id, bool valid, int lane) {
+        if (!spilled && count + 64u > (cap >> 1)) spill(lane);
+        bool isnew = false;
+        if (spilled) {
+            if (valid) {
+                uint32_t bit = 1u << (id & 31u);
+                uint32_t old = atomicOr(&bm[id >> 5], bit);
+                isnew = !(old & bit);
+            }
+            return isnew;
+        }
+        bool pending = valid;
+        uint32_t slot = (id * 2654435761u) >> shift;
+        while (__ballot(pending)) {
+            if (pending) {
+                uint32_t old = atomicCAS(&tab[slot], kTabEmpty, id);
+                if (old == kTabEmpty) { isnew = true; pending = false; }
+                else if (old == id) { pending = false; }
+                else slot = (slot + 1u) & mask;
+            }
+        }
+        count += (uint32_t)__builtin_popcountll(__ballot(isnew));
+        return isnew;
+    }
+};
+
+// Score P rows (one per 8-lane group per p) against the query staged in LDS.  Straight-line: all
+// P*NK 16-byte row loads are issued before the first FMA (one HBM latency per pass); the query
+// float4s are re-read from LDS chunk by chunk (conflict-free: the 8 lanes of a group read 128
+// contiguous bytes, the 8 groups broadcast) so that the P*NK*4 destination VGPRs fit under the
+// 256-VGPR architectural limit.  Groups without a row of their own are pointed at another group's
+// row by the caller (identical addresses coalesce inside the load instruction): no divergence, and
+// nothing for the compiler to sink behind a branch.
+template <uint32_t METRIC, int NK, int P>
+__device__ __forceinline__ void score_rows(const DevIndex &ix, const float *qs, const uint32_t (&node)[P],
+                                           int slot, float qhdr, const float *qglobal, float (&out)[P]) {
+    float4 x[P][NK];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const float4 *rp = reinterpret_cast<const float4 *>(ix.vec + (size_t)node[p] * ix.ld) + slot;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) x[p][k] = rp[k * 8];
+    }
+    __builtin_amdgcn_sched_barrier(0); // every row load is issued before the first FMA is scheduled
+    float4 acc[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 *qp = reinterpret_cast<const float4 *>(qs) + slot;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const float4 qq = qp[k * 8];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            if (METRIC == kL2) {
+                const float d0 = qq.x - x[p][k].x, d1 = qq.y - x[p][k].y;
+                const float d2 = qq.z - x[p][k].z, d3 = qq.w - x[p][k].w;
+                acc[p].x = __builtin_fmaf(d0, d0, acc[p].x); acc[p].y = __builtin_fmaf(d1, d1, acc[p].y);
+                acc[p].z = __builtin_fmaf(d2, d2, acc[p].z); acc[p].w = __builtin_fmaf(d3, d3, acc[p].w);
+            } else {
+                acc[p].x = __builtin_fmaf(qq.x, x[p][k].x, acc[p].x); acc[p].y = __builtin_fmaf(qq.y, x[p][k].y, acc[p].y);
+                acc[p].z = __builtin_fmaf(qq.z, x[p][k].z, acc[p].z); acc[p].w = __builtin_fmaf(qq.w, x[p][k].w, acc[p].w);
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        float r = avx_tree_reduce(acc[p]);
+        if (METRIC == kCosine)
+            r = cosine_finish(r, qhdr, ix.hdr[node[p]], qglobal, ix.vec + (size_t)node[p] * ix.ld, ix.dim);
+        out[p] = r;
+    }
+}
+
+// PROF=true builds the phase-timing variant (s_memtime around each phase of a layer-0 expansion,
+// hard waits at the phase boundaries); it is only launched when HVX_WAVE_PROF is set.
+template <uint32_t METRIC, int R, int NK, bool PROF = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void hnsw_wave_kernel(HnswArgs a, uint32_t log2cap) {
+    constexpr int P = NK <= 8 ? 4 : (NK <= 16 ? 3 : (NK <= 24 ? 2 : 1)); // P*NK <= 48 float4 in flight per lane
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const DevIndex &ix = a.ix;
+    const uint32_t q = blockIdx.x;
+    const int lane = (int)threadIdx.x, grp = lane >> 3, j = lane & 7;
+    const int slot = chunk_slot(j);
+
+    Visited V;
+    V.tab = reinterpret_cast<uint32_t *>(smem);
+    V.cap = 1u << log2cap;
+    V.mask = V.cap - 1u;
+    V.shift = 32u - log2cap;
+    V.words = a.words_per_query;
+    V.bm = a.bitmap + (size_t)q * a.words_per_query;
+    V.count = 0;
+    V.spilled = false;
+    uint32_t *fr_id = V.tab + V.cap;                      // [64]
+    float *fr_d = reinterpret_cast<float *>(fr_id + 64);   // [64]
+    float *qs = fr_d + 64;                                 // [dim] query, 16-byte aligned
+
+    const uint32_t status_in = a.qstatus ? a.qstatus[q] : 0u;
+    if (status_in != 0u || !ix.has_entry) {
+        if (lane == 0) {
+            a.out_counts[q] = 0;
+            if (a.out_status) a.out_status[q] = status_in;
+            if (a.qstats) a.qstats[q] = hvx_query_stats{0, 0, 0, 0};
+            if (a.tie_flags) a.tie_flags[q] = 0u;
+        }
+        return;
+    }
+    const float *qglobal = a.queries + (size_t)q * ix.dim;
+    for (uint32_t i = (uint32_t)lane; i < (uint32_t)NK * 8u; i += 64)
+        reinterpret_cast<float4 *>(qs)[i] = reinterpret_cast<const float4 *>(qglobal)[i];
+    __syncthreads();
+    const float qhdr = a.qhdr ? a.qhdr[q] : 0.f;
+    const float inf = __uint_as_float(0x7F800000u);
+
+    // distance of ONE node, uniform result
+    auto score_one = [&](uint32_t node) -> float {
+        uint32_t nd[1] = {node};
+        float o[1];
+        score_rows<METRIC, NK, 1>(ix, qs, nd, slot, qhdr, qglobal, o);
+        return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(o[0]), 0));
+    };
+    // distances of fr_id[0..nf) -> fr_d[0..nf)
+    auto score_frontier = [&](uint32_t nf) {
+        for (uint32_t f0 = 0; f0 < nf; f0 += 8u * P) {
+            uint32_t nd[P];
+            bool ac[P];
+            float o[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const uint32_t f = f0 + (uint32_t)(p * 8 + grp);
+                ac[p] = f < nf;
+                nd[p] = fr_id[ac[p] ? f : f0]; // idle groups shadow the pass's first row
+            }
+            score_rows<METRIC, NK, P>(ix, qs, nd, slot, qhdr, qglobal, o);
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                if (ac[p] && j == 0) fr_d[f0 + (uint32_t)(p * 8 + grp)] = o[p];
+        }
+        __syncthreads();
+    };
+    // visited test-and-set + in-order compaction of one neighbour row held one id per lane
+    auto frontier_from = [&](uint32_t nid, uint32_t &deg) -> uint32_t {
+        const bool valid = nid != kSentinel;
+        const bool isnew = V.insert(nid, valid, lane);
+        const unsigned long long um = __ballot(isnew);
+        deg = (uint32_t)__builtin_popcountll(__ballot(valid));
+        if (isnew) fr_id[__builtin_popcountll(um & ((1ull << lane) - 1ull))] = nid;
+        __syncthreads();
+        return (uint32_t)__builtin_popcountll(um);
+    };
+
+    bool bad_score = false;
+    uint32_t cur = ix.entry;
+
+    // ---------------- upper layers: search_layer_greedy (search.rs:169-224) ----------------
+    for (uint32_t layer = ix.max_layer; layer >= 1; --layer) {
+        V.clear(lane); // fresh visited set per layer
+        float cur_d = score_one(cur);
+        if (!score_valid(cur_d)) bad_score = true;
+        V.insert(cur, lane == 0, lane);
+        while (!bad_score) {
+            uint32_t nid = kSentinel;
+            const uint32_t base_row = ix.up_base[cur];
+            if (base_row != kSentinel && ix.level[cur] >= layer && (uint32_t)lane < ix.su)
+                nid = ix.up[(size_t)(base_row + layer - 1) * ix.su + (uint32_t)lane];
+            uint32_t deg;
+            const uint32_t nf = frontier_from(nid, deg);
+            if (nf == 0) break;
+            score_frontier(nf);
+            // sequential `if distance < current_dist` over the row == first minimum, if it improves
+            float d = (uint32_t)lane < nf ? fr_d[lane] : inf;
+            bool ok = true;
+            if ((uint32_t)lane < nf) ok = score_valid(d);
+            if (__ballot(!ok)) { bad_score = true; break; }
+            const uint32_t m = wave_umin(__float_as_uint(d)); // scores are >= 0: bit order == value order
+            const float mf = __uint_as_float(m);
+            if (!(mf < cur_d)) break;
+            const unsigned long long eq = __ballot((uint32_t)lane < nf && d == mf);
+            cur = fr_id[__builtin_ctzll(eq)];
+            cur_d = mf;
+            __syncthreads();
+        }
+        if (bad_score) break;
+    }
+
+    // ---------------- layer 0: strict-exhaustive beam (search.rs:267-1067) ----------------
+    Beam<R> S;
+    S.init();
+    uint32_t st_exp = 0, st_nb = 0, st_vl = 0, st_dc = 0;
+    bool tie_overflow = false;
+    uint32_t dropped_unexpanded = 0;
+    const uint32_t ef = a.ef;
+    uint32_t pf_id = kSentinel, pf_row = kSentinel; // predicted next candidate and its prefetched row
+    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0; // PROF only
+    auto tick = [&](int phase) {
+        if (PROF) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            t1 = __builtin_readcyclecounter();
+            pt[phase] += t1 - t0;
+            t0 = t1;
+        }
+    };
+    const unsigned long long t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
+    if (!bad_score) {
+        V.clear(lane);
+        float d0 = score_one(cur);
+        st_dc = 1;
+        if (!score_valid(d0)) bad_score = true;
+        V.insert(cur, lane == 0, lane);
+        float ds;
+        S.insert(d0, cur, lane, ds);
+    }
+    if (PROF) { pt[7] = __builtin_readcyclecounter() - t_begin; t0 = __builtin_readcyclecounter(); }
+    while (!bad_score) {
+        const uint32_t pos = S.first_unexpanded(lane);
+        if (pos >= S.count) {
+            // the reference would still pop an evicted candidate that we no longer hold, count the
+            // step and stop on `current_dist > w.peek()` (search.rs:549)
+            if (dropped_unexpanded) ++st_exp;
+            break;
+        }
+        ++st_exp;
+        const float dc = S.score_at(pos);
+        const uint32_t c = S.id_at(pos);
+        const uint32_t wlen = S.count < ef ? S.count : ef;
+        float wmax = S.score_at(wlen - 1);
+        if (wlen >= ef && dc > wmax) break;
+        S.mark_expanded(pos, lane);
+
+        uint32_t nid;
+        if (c == pf_id) { nid = pf_row; if (PROF) pt[6] += 1; }
+        else nid = (uint32_t)lane < ix.s0 ? ix.l0[(size_t)c * ix.s0 + (uint32_t)lane] : kSentinel;
+        tick(0); // pop + neighbour row available
+        uint32_t deg;
+        const uint32_t nf = frontier_from(nid, deg);
+        st_nb += deg;
+        tick(1); // visited test-and-set + compaction
+        if (nf == 0) continue;
+        st_vl += nf;
+        st_dc += nf;
+        score_frontier(nf);
+        tick(2); // row gathers + FMAs
+        const float d_l = (uint32_t)lane < nf ? fr_d[lane] : inf;
+        const uint32_t id_l = (uint32_t)lane < nf ? fr_id[lane] : kSentinel;
+        __syncthreads();
+        {
+            // predict the next pop: best admissible fresh candidate vs best unexpanded beam entry
+            const uint32_t wl0 = S.count < ef ? S.count : ef;
+            const bool adm = ((uint32_t)lane < nf) & ((d_l < wmax) | (wl0 < ef)) & (d_l >= 0.f) & (d_l < inf);
+            const uint32_t key = adm ? __float_as_uint(d_l) : 0xFFFFFFFFu;
+            const uint32_t kmin = wave_umin(key);
+            const uint32_t p2 = S.first_unexpanded(lane);
+            uint32_t pred = kSentinel;
+            float s2 = inf;
+            if (p2 < S.count) { pred = S.id_at(p2); s2 = S.score_at(p2); }
+            if (kmin != 0xFFFFFFFFu && __uint_as_float(kmin) < s2) {
+                const unsigned long long eq = __ballot(key == kmin);
+                pred = __builtin_amdgcn_readlane(id_l, (uint32_t)__builtin_ctzll(eq));
+            }
+            pf_id = pred;
+            if (pred != kSentinel)
+                pf_row = (uint32_t)lane < ix.s0 ? ix.l0[(size_t)pred * ix.s0 + (uint32_t)lane] : kSentinel;
+        }
+        if (PROF) { t1 = __builtin_readcyclecounter(); pt[3] += t1 - t0; t0 = t1; } // prediction (no wait: prefetch in flight)
+        // admission in row order with the running bound (search.rs:928-952).  Once W is full the
+        // bound only ever tightens, so a candidate that fails it at entry fails it at its turn: only
+        // the lanes passing the entry bound are visited (in row order), each re-checked against the
+        // running bound.  (While W is still filling its max can grow, so nothing is skipped then.)
+        // Invalid scores fail the whole query wherever they sit.
+        {
+            float dv = d_l;
+            const bool okv = (uint32_t)lane >= nf || score_valid(dv);
+            if (__ballot(!okv)) { bad_score = true; break; }
+            const uint32_t wl_in = S.count < ef ? S.count : ef;
+            unsigned long long todo = __ballot(((uint32_t)lane < nf) & ((dv < wmax) | (wl_in < ef)));
+            while (todo) {
+                const uint32_t f = (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const float d = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dv), f));
+                const uint32_t wl = S.count < ef ? S.count : ef;
+                if (d < wmax || wl < ef) {
+                    float ds = 0.f;
+                    const bool drop = S.insert(d, __builtin_amdgcn_readlane(id_l, f), lane, ds);
+                    const uint32_t wl2 = S.count < ef ? S.count : ef;
+                    wmax = S.score_at(wl2 - 1);
+                    if (drop) {
+                        ++dropped_unexpanded;
+                        if (!(ds > wmax)) tie_overflow = true; // an equal-score candidate left the beam
+                    }
+                    if (PROF) pt[5] += 1;
+                }
+            }
+        }
+        if (PROF) { t1 = __builtin_readcyclecounter(); pt[4] += t1 - t0; t0 = t1; } // admission loop
+    }
+    if (PROF && a.prof && lane == 0) {
+        // [0] row wait [1] visited [2] gather+FMA [3] predict [4] admit (cycles); [5] inserts [6] prefetch hits [7] upper layers
+        for (int i = 0; i < 8; ++i) a.prof[(size_t)q * 8 + i] = pt[i];
+    }
+
+    // ---------------- results: w sorted by (score,id), take k (search.rs:995-1004,1229) ----------------
+    uint32_t outn = 0;
+    if (!bad_score) {
+        const uint32_t wl = S.count < ef ? S.count : ef;
+        outn = wl < a.k ? wl : a.k;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t e = (uint32_t)r * 64u + (uint32_t)lane;
+            if (e < outn) {
+                a.out_ids[(size_t)q * a.k + e] = ix.ids[S.id[r] & ~kExpandedBit];
+                a.out_scores[(size_t)q * a.k + e] = S.sc[r];
+            }
+        }
+    }
+    if (V.spilled) { // leave the HBM bitmap zeroed for the next launch
+        for (uint32_t w = (uint32_t)lane; w < V.words; w += 64) V.bm[w] = 0u;
+    }
+    if (lane == 0) {
+        a.out_counts[q] = outn;
+        if (a.out_status) a.out_status[q] = bad_score ? 8u /*HVX_ERR_INVARIANT*/ : 0u;
+        if (a.qstats) a.qstats[q] = hvx_query_stats{st_exp, st_nb, st_vl, st_dc};
+        if (a.tie_flags) a.tie_flags[q] = tie_overflow ? 1u : 0u;
+    }
+}
+
+// per-metric launchers, defined in hvx_hnsw_wave_l2.hip / hvx_hnsw_wave_cos.hip
+hipError_t launch_hnsw_wave_l2(const HnswArgs &a, uint32_t b, uint32_t log2cap, size_t lds, hipStream_t s);
+hipError_t launch_hnsw_wave_prof(const HnswArgs &a, uint32_t b, uint32_t log2cap, size_t lds, hipStream_t s);
+hipError_t launch_hnsw_wave_cos(const HnswArgs &a, uint32_t b, uint32_t log2cap, size_t lds, hipStream_t s);
+
+template <uint32_t METRIC, int R>
+static hipError_t launch_wave_nk(const HnswArgs &a, uint32_t b, uint32_t log2cap, size_t lds, hipStream_t s) {
+    const uint32_t nk = a.ix.dim >> 5;
+#define HVX_WAVE_CASE(N)                                                                                       \
+    case N: {                                                                                                  \
+        auto kern = hnsw_wave_kernel<METRIC, R, N>;                                                            \
+        if (lds > 48 * 1024) {                                                                                 \
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                               (int)lds);                                                      \
+            if (e != hipSuccess) return e;                                                                     \
+        }                                                                                                      \
+        hipLaunchKernelGGL(kern, dim3(b), dim3(64), lds, s, a, log2cap);                                       \
+        break;                                                                                                 \
+    }
+    switch (nk) {
+        HVX_WAVE_CASE(4)
+        HVX_WAVE_CASE(8)
+        HVX_WAVE_CASE(16)
+        HVX_WAVE_CASE(24)
+        HVX_WAVE_CASE(32)
+        HVX_WAVE_CASE(48)
+    default: return hipErrorInvalidValue;
+    }
+#undef HVX_WAVE_CASE
+    return hipGetLastError();
+}
+
+template <uint32_t METRIC>
+static hipError_t launch_wave_r(const HnswArgs &a, uint32_t b, uint32_t log2cap, size_t lds, hipStream_t s) {
+    const uint32_t need = a.ef + 32u; // beam capacity 64*R must hold ef plus slack for equal-score evictions
+    if (need <= 192) return launch_wave_nk<METRIC, 3>(a, b, log2cap, lds, s);
+    if (need <= 384) return launch_wave_nk<METRIC, 6>(a, b, log2cap, lds, s);
+    return hipErrorInvalidValue;
+}
+
+} // namespace hvx

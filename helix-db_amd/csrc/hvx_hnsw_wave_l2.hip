@@ -1,0 +1,8 @@
+// hvx_hnsw_wave_l2.hip -- squared-Euclidean instantiations of the one-wavefront-per-query HNSW kernel.
+#include "hvx_hnsw_wave.h"
+
+namespace hvx {
+hipError_t launch_hnsw_wave_l2(const HnswArgs &a, uint32_t b, uint32_t log2cap, size_t lds, hipStream_t s) {
+    return launch_wave_r<kL2>(a, b, log2cap, lds, s);
+}
+} // namespace hvx

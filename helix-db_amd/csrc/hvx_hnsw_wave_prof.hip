@@ -1,0 +1,11 @@
+// hvx_hnsw_wave_prof.hip -- phase-timing build of the wave kernel (L2, R=3, dim 768 only); launched
+// instead of the production kernel when HVX_WAVE_PROF is set, for kernel tuning.
+#include "hvx_hnsw_wave.h"
+
+namespace hvx {
+hipError_t launch_hnsw_wave_prof(const HnswArgs &a, uint32_t b, uint32_t log2cap, size_t lds, hipStream_t s) {
+    if (a.ix.metric != kL2 || (a.ix.dim >> 5) != 24 || a.ef + 32u > 192u) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((hnsw_wave_kernel<kL2, 3, 24, true>), dim3(b), dim3(64), lds, s, a, log2cap);
+    return hipGetLastError();
+}
+} // namespace hvx

@@ -15,6 +15,7 @@ struct hvx_index {
     float limit = 0.f;               // VectorComponentLimit (domain.rs:26-78); +inf for cosine
     uint32_t max_batch = 1024;
     uint32_t words_per_query = 0;
+    bool bitmap_dirty = false;       // d_bitmap holds stale visited bits (general kernel ran last)
     hipStream_t stream = nullptr;      // stream in use
     hipStream_t own_stream = nullptr;  // created at import
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -26,6 +27,7 @@ struct hvx_index {
     uint32_t *d_bitmap = nullptr, *d_qstatus = nullptr, *d_tie = nullptr;
     float *d_qhdr = nullptr;
     hvx_query_stats *d_qstats = nullptr;
+    unsigned long long *d_prof = nullptr; // HVX_WAVE_PROF tuning buffer
     // staging of the host-pointer API
     float *s_queries = nullptr;
     uint64_t *s_ids = nullptr;

@@ -22,10 +22,15 @@ struct HnswArgs {
     uint32_t *out_status;      // [b] nullable
     hvx_query_stats *qstats;   // [b] nullable
     uint32_t *tie_flags;       // [b] nullable
+    unsigned long long *prof;  // [b][8] phase cycle counters of the PROF kernel variant, nullable
 };
 
 size_t hnsw_lds_bytes(uint32_t ld);
+// general kernel (4 wavefronts per query, any metric/dim/summation tree); dirties the HBM bitmap
 hipError_t launch_hnsw_search(const HnswArgs &a, uint32_t b, hipStream_t s);
+// fast kernel (1 wavefront per query, hvx_hnsw_wave.h); leaves the HBM bitmap zeroed
+bool hnsw_wave_supported(const HnswArgs &a);
+hipError_t launch_hnsw_wave(const HnswArgs &a, uint32_t b, hipStream_t s);
 
 // validate queries on the device (domain.rs:113-157) and compute the cosine header
 hipError_t launch_validate_queries(const DevIndex &ix, const float *d_queries, uint32_t b, float limit,

@@ -117,9 +117,9 @@ int csr_alloc(hvx_csr *g, void **p, size_t bytes) {
 
 void csr_free(hvx_csr *g) {
     if (!g) return;
-    hipSetDevice(g->device);
-    for (void *p : g->allocs) hipFree(p);
-    if (g->stream) hipStreamDestroy(g->stream);
+    (void)hipSetDevice(g->device);
+    for (void *p : g->allocs) (void)hipFree(p);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
     delete g;
 }
 

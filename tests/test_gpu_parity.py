@@ -125,6 +125,38 @@ def test_hnsw_bit_exact_vs_oracle(orc, hv, n, dim, metric, m, m0, efc, ef, k, nq
     assert_hnsw_equal(orc, hv, oix, gix, q, k, ef)
 
 
+WAVE_CASES = [
+    # (n, dim, metric, m, m0, efc, ef, k, nq) -- shapes served by the one-wavefront-per-query kernel
+    (1500, 128, 1, 16, 32, 80, 128, 10, 48),
+    (1200, 256, 0, 16, 32, 80, 100, 10, 32),
+    (1200, 512, 1, 16, 32, 60, 128, 10, 32),
+    (1500, 768, 0, 16, 32, 80, 128, 10, 32),
+    (1000, 1024, 1, 8, 16, 60, 64, 10, 24),
+    (1000, 1536, 1, 16, 32, 60, 100, 10, 24),
+    (2500, 128, 1, 16, 32, 80, 300, 50, 24),     # R=6 beam
+    (3000, 128, 1, 32, 64, 100, 160, 10, 24),    # 64-id rows
+]
+
+
+@pytest.mark.parametrize("n,dim,metric,m,m0,efc,ef,k,nq", WAVE_CASES)
+@pytest.mark.parametrize("path", ["wave", "general", "wave-spill"])
+def test_hnsw_kernels_agree_with_oracle(orc, hv, monkeypatch, path, n, dim, metric, m, m0, efc, ef, k, nq):
+    """Both HNSW kernels (hvx_hnsw_wave.h and the general hvx_hnsw.hip) and the wave kernel's
+    LDS-table -> HBM-bitmap spill path give the oracle's ids, score bits and counters."""
+    if path == "general":
+        monkeypatch.setenv("HVX_HNSW_GENERAL", "1")
+    if path == "wave-spill":
+        monkeypatch.setenv("HVX_WAVE_LOG2CAP", "8")  # 256-slot table: spills after ~64 visited ids
+    rng = np.random.default_rng(77 + dim + metric)
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    lv = fx.draw_levels(n, m, seed=dim + 1)
+    oix = build_oracle(orc, data, metric, lv, m=m, m0=m0, efc=efc)
+    gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=dim, metric=metric, m=m, m0=m0)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    assert_hnsw_equal(orc, hv, oix, gix, q, k, ef)
+    assert_hnsw_equal(orc, hv, oix, gix, q[: nq // 2], k, ef)  # second launch: visited state handed back clean
+
+
 @pytest.mark.parametrize("kernel", ["avx", "scalar"])
 def test_other_float_kernels(orc, hv, kernel):
     n, dim = 1000, 96

@@ -210,7 +210,11 @@ def main():
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": round(k_ms, 4),
                 "distance_computations_per_query": round(dist_comp / b, 1),
-                "expansion_steps_per_query": round(exp_steps / b, 1)}
+                "expansion_steps_per_query": round(exp_steps / b, 1),
+                "per_query_distance_computations": {"p50": int(np.percentile(qst[:, 3], 50)), "p99": int(np.percentile(qst[:, 3], 99)),
+                                                    "max": int(qst[:, 3].max())},
+                "per_query_expansion_steps": {"p50": int(np.percentile(qst[:, 0], 50)), "p99": int(np.percentile(qst[:, 0], 99)),
+                                              "max": int(qst[:, 0].max())}}
 
     out = {
         "metric": "QPS @ recall@10>=0.95, 1Mx768 fp32; achieved HBM GB/s vs roofline", "value": round(qps, 1),

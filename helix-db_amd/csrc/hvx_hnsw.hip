@@ -300,9 +300,13 @@ hipError_t launch_hnsw_search(const HnswArgs &a, uint32_t b, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 // dispatch to the one-wavefront-per-query kernel (hvx_hnsw_wave.h)
 // ---------------------------------------------------------------------------------------------
-hipError_t launch_hnsw_wave_l2(const HnswArgs &a, uint32_t b, uint32_t log2cap, size_t lds, hipStream_t s);
-hipError_t launch_hnsw_wave_cos(const HnswArgs &a, uint32_t b, uint32_t log2cap, size_t lds, hipStream_t s);
-hipError_t launch_hnsw_wave_prof(const HnswArgs &a, uint32_t b, uint32_t log2cap, size_t lds, hipStream_t s);
+struct WaveGeom {
+    uint32_t log2cap;
+    size_t lds;
+};
+hipError_t launch_hnsw_wave_l2(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_cos(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_prof(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 
 bool hnsw_wave_supported(const HnswArgs &a) {
     const DevIndex &ix = a.ix;
@@ -316,20 +320,26 @@ bool hnsw_wave_supported(const HnswArgs &a) {
     return true;
 }
 
+static int env_int(const char *name, int lo, int hi, int fallback) {
+    const char *e = getenv(name);
+    if (!e) return fallback;
+    const int v = atoi(e);
+    return (v >= lo && v <= hi) ? v : fallback;
+}
+
 hipError_t launch_hnsw_wave(const HnswArgs &a, uint32_t b, hipStream_t s) {
-    // visited hash: >= 64 slots per beam entry keeps the load factor under ~0.3 at the measured
-    // ~10 distance evaluations per expansion; the kernel spills to the HBM bitmap beyond half full
-    uint32_t log2cap = 11;
-    while ((1u << log2cap) < 64u * a.ef && log2cap < 15) ++log2cap;
-    if (const char *e = getenv("HVX_WAVE_LOG2CAP")) { // test hook: force a small table to exercise the spill path
-        const int v = atoi(e);
-        if (v >= 7 && v <= 15) log2cap = (uint32_t)v;
-    }
-    size_t lds = ((size_t)4 << log2cap) + 512 + (size_t)a.ix.dim * 4;
-    // exactly four resident wavefronts per CU (one per SIMD, 512 VGPRs each): 160 KiB / 4
-    if (lds < 40 * 1024) lds = 40 * 1024;
-    if (a.prof) return launch_hnsw_wave_prof(a, b, log2cap, lds, s);
-    return a.ix.metric == kL2 ? launch_hnsw_wave_l2(a, b, log2cap, lds, s) : launch_hnsw_wave_cos(a, b, log2cap, lds, s);
+    WaveGeom g;
+    // visited hash: 64 slots per beam entry (load factor ~0.15-0.3 at the measured ~10 distance evaluations
+    // per expansion); the kernel spills to the exact HBM bitmap beyond 3/4 full
+    g.log2cap = 11;
+    while ((1u << g.log2cap) < 64u * a.ef && g.log2cap < 15) ++g.log2cap;
+    g.log2cap = (uint32_t)env_int("HVX_WAVE_LOG2CAP", 7, 15, (int)g.log2cap); // test hook: tiny table => spill path
+    // 160 KiB / 4: exactly four resident wavefronts per CU, one per SIMD, each with the SIMD's whole register file
+    const size_t budget = 40 * 1024;
+    const size_t need = ((size_t)4 << g.log2cap) + 512 + (size_t)a.ix.dim * 4;
+    g.lds = need < budget ? budget : need;
+    if (a.prof) return launch_hnsw_wave_prof(a, b, g, s);
+    return a.ix.metric == kL2 ? launch_hnsw_wave_l2(a, b, g, s) : launch_hnsw_wave_cos(a, b, g, s);
 }
 
 } // namespace hvx

@@ -5,21 +5,26 @@
 // layer-0 beam :267-1067) -- restructured around what bounded the first kernel
 // on MI355X (profiles/r01a: 11.6 us per expansion, three dependent HBM round trips + barriers):
 //
-//   * 1024 queries = 1024 wavefronts = one wave per SIMD on all 256 CUs: each wave owns a whole
-//     SIMD's register file, so a full
-//     pass of P x 8 neighbour rows (P*NK 16-byte loads per lane, 8 lanes per row, rows coalesced
-//     128 B per load) is in flight before the first FMA -- one HBM latency per expansion, not three;
+//   * 1024 queries = 1024 wavefronts = one wave per SIMD on all 256 CUs: each wave owns a whole SIMD's
+//     register file, so a full pass of P x 8 neighbour rows (P*NK 16-byte loads per lane, 8 lanes per
+//     row, 128 B coalesced per load) is in flight before the first FMA;
 //   * the visited set is an open-addressing hash table in LDS (ds_cmpst, ~100 cycles) instead of an
 //     HBM bitmap (atomicOr round trip); it spills to the exact HBM bitmap if it ever fills;
-//   * the next candidate's neighbour row is predicted from the fresh distances and its load is issued
-//     before the sequential admission loop, so the row fetch overlaps the beam inserts;
+//   * the next pop is predicted right after the distances of an expansion are known (best fresh
+//     candidate vs best unexpanded beam entry; right 97.7 % of the time on the 1M x 768 workload) and
+//     its neighbour row is fetched underneath the sequential admission loop;
+//   * a frontier of up to 8, 16 or 32 rows is gathered with ONE latency: the pass width is chosen per
+//     expansion (P, 2P or 4P rows per 8-lane group in flight), because the kernel ends with its
+//     slowest query and the slow queries are the ones with large frontiers (profiles/r01c);
 //   * distances keep the host SIMD summation order (hvx_device.h) => scores are bit-identical to the
 //     reference CPU path; the beam (hvx_beam.h) is exact.
 //
 // Served shapes: metric L2 / cosine, AVX+FMA summation tree, dim = 32*NK with NK in
-// {4,8,16,24,32,48}, neighbour rows <= 64 ids, ef + 32 <= 384.  Everything else runs on the general
+// {4,8,16,24,32,48} (dim 128 ... 1536), neighbour rows <= 64 ids, ef + 32 <= 384.  Everything else runs on the general
 // kernel in hvx_hnsw.hip.
 #pragma once
+#include <type_traits>
+
 #include "hvx_beam.h"
 #include "hvx_device.h"
 #include "hvx_kernels.h"
@@ -47,10 +52,10 @@ __device__ __forceinline__ uint32_t wave_umin(uint32_t v) {
     return a < c ? a : c;
 }
 
-// Visited set of one query: LDS hash table, exact; falls back to the HBM bitmap when half full.
+// Visited set of one query: LDS hash table, exact; falls back to the HBM bitmap when 3/4 full.
 struct Visited {
     uint32_t *tab;      // LDS [cap]
-    uint32_t *bm;       // HBM bitmap of this query (zeroed by the host before the launch)
+    uint32_t *bm;       // HBM bitmap of this query (all-zero on entry, handed back all-zero)
     uint32_t mask, shift, cap, words;
     uint32_t count;     // uniform: ids inserted into the table since the last clear
     bool spilled;       // uniform: bitmap mode
@@ -74,7 +79,7 @@ struct Visited {
     }
     // test-and-set for the lanes with valid==true (ids distinct across lanes); true = newly inserted
     __device__ __forceinline__ bool insert(uint32_t id, bool valid, int lane) {
-        if (!spilled && count + 64u > (cap >> 1)) spill(lane);
+        if (!spilled && count + 64u > cap - (cap >> 2)) spill(lane);
         bool isnew = false;
         if (spilled) {
             if (valid) {
@@ -99,24 +104,31 @@ struct Visited {
     }
 };
 
-// Score P rows (one per 8-lane group per p) against the query staged in LDS.  Straight-line: all
-// P*NK 16-byte row loads are issued before the first FMA (one HBM latency per pass); the query
-// float4s are re-read from LDS chunk by chunk (conflict-free: the 8 lanes of a group read 128
-// contiguous bytes, the 8 groups broadcast) so that the P*NK*4 destination VGPRs fit under the
-// 256-VGPR architectural limit.  Groups without a row of their own are pointed at another group's
-// row by the caller (identical addresses coalesce inside the load instruction): no divergence, and
-// nothing for the compiler to sink behind a branch.
-template <uint32_t METRIC, int NK, int P>
-__device__ __forceinline__ void score_rows(const DevIndex &ix, const float *qs, const uint32_t (&node)[P],
-                                           int slot, float qhdr, const float *qglobal, float (&out)[P]) {
+// One gather pass in flight: P rows per 8-lane group, P*NK float4 per lane.
+template <int NK, int P> struct Gather {
     float4 x[P][NK];
+};
+
+// Straight-line issue of every load of a pass.  Groups without a row of their own are pointed at
+// another group's row by the caller (identical addresses coalesce inside the load instruction): no
+// divergence, nothing for the compiler to sink behind a branch.
+template <int NK, int P>
+__device__ __forceinline__ void gather_issue(const DevIndex &ix, const uint32_t (&node)[P], int slot, Gather<NK, P> &g) {
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         const float4 *rp = reinterpret_cast<const float4 *>(ix.vec + (size_t)node[p] * ix.ld) + slot;
 #pragma unroll
-        for (int k = 0; k < NK; ++k) x[p][k] = rp[k * 8];
+        for (int k = 0; k < NK; ++k) g.x[p][k] = rp[k * 8];
     }
-    __builtin_amdgcn_sched_barrier(0); // every row load is issued before the first FMA is scheduled
+    __builtin_amdgcn_sched_barrier(0); // every load is issued before anything that follows is scheduled
+}
+
+// FMAs in the host SIMD order against the query staged in LDS (conflict-free: the 8 lanes of a group
+// read 128 contiguous bytes, the 8 groups broadcast), then the AVX reduction tree.
+template <uint32_t METRIC, int NK, int P>
+__device__ __forceinline__ void gather_consume(const DevIndex &ix, const float *qs, const Gather<NK, P> &g,
+                                               const uint32_t (&node)[P], int slot, float qhdr,
+                                               const float *qglobal, float (&out)[P]) {
     float4 acc[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -126,14 +138,14 @@ __device__ __forceinline__ void score_rows(const DevIndex &ix, const float *qs, 
         const float4 qq = qp[k * 8];
 #pragma unroll
         for (int p = 0; p < P; ++p) {
+            const float4 xv = g.x[p][k];
             if (METRIC == kL2) {
-                const float d0 = qq.x - x[p][k].x, d1 = qq.y - x[p][k].y;
-                const float d2 = qq.z - x[p][k].z, d3 = qq.w - x[p][k].w;
+                const float d0 = qq.x - xv.x, d1 = qq.y - xv.y, d2 = qq.z - xv.z, d3 = qq.w - xv.w;
                 acc[p].x = __builtin_fmaf(d0, d0, acc[p].x); acc[p].y = __builtin_fmaf(d1, d1, acc[p].y);
                 acc[p].z = __builtin_fmaf(d2, d2, acc[p].z); acc[p].w = __builtin_fmaf(d3, d3, acc[p].w);
             } else {
-                acc[p].x = __builtin_fmaf(qq.x, x[p][k].x, acc[p].x); acc[p].y = __builtin_fmaf(qq.y, x[p][k].y, acc[p].y);
-                acc[p].z = __builtin_fmaf(qq.z, x[p][k].z, acc[p].z); acc[p].w = __builtin_fmaf(qq.w, x[p][k].w, acc[p].w);
+                acc[p].x = __builtin_fmaf(qq.x, xv.x, acc[p].x); acc[p].y = __builtin_fmaf(qq.y, xv.y, acc[p].y);
+                acc[p].z = __builtin_fmaf(qq.z, xv.z, acc[p].z); acc[p].w = __builtin_fmaf(qq.w, xv.w, acc[p].w);
             }
         }
     }
@@ -150,7 +162,10 @@ __device__ __forceinline__ void score_rows(const DevIndex &ix, const float *qs, 
 // hard waits at the phase boundaries); it is only launched when HVX_WAVE_PROF is set.
 template <uint32_t METRIC, int R, int NK, bool PROF = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void hnsw_wave_kernel(HnswArgs a, uint32_t log2cap) {
-    constexpr int P = NK <= 8 ? 4 : (NK <= 16 ? 3 : (NK <= 24 ? 2 : 1)); // P*NK <= 48 float4 in flight per lane
+    // rows per 8-lane group in flight: P*NK <= 24 float4 per lane for a narrow pass, x2 and x4 for wider
+    // frontiers (4P*NK <= 96 float4 = 384 registers, VGPR+AGPR file of one wave per SIMD)
+    constexpr int P = NK <= 8 ? 2 : 1;
+    constexpr bool kWide4 = 4 * P * NK <= 96;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const DevIndex &ix = a.ix;
     const uint32_t q = blockIdx.x;
@@ -166,8 +181,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     V.bm = a.bitmap + (size_t)q * a.words_per_query;
     V.count = 0;
     V.spilled = false;
-    uint32_t *fr_id = V.tab + V.cap;                      // [64]
-    float *fr_d = reinterpret_cast<float *>(fr_id + 64);   // [64]
+    uint32_t *fr_id = V.tab + V.cap;                      // [64] frontier ids, row order
+    float *fr_d = reinterpret_cast<float *>(fr_id + 64);   // [64] their distances
     float *qs = fr_d + 64;                                 // [dim] query, 16-byte aligned
 
     const uint32_t status_in = a.qstatus ? a.qstatus[q] : 0u;
@@ -187,34 +202,47 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const float qhdr = a.qhdr ? a.qhdr[q] : 0.f;
     const float inf = __uint_as_float(0x7F800000u);
 
-    // distance of ONE node, uniform result
-    auto score_one = [&](uint32_t node) -> float {
-        uint32_t nd[1] = {node};
-        float o[1];
-        score_rows<METRIC, NK, 1>(ix, qs, nd, slot, qhdr, qglobal, o);
-        return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(o[0]), 0));
+    // one pass of W rows per group over fr_id[f0..nf): issue everything, then FMA, then publish
+    auto pass = [&](auto width, uint32_t f0, uint32_t nf) __attribute__((always_inline)) {
+        constexpr int W = decltype(width)::value;
+        uint32_t nd[W];
+        float o[W];
+        Gather<NK, W> g;
+#pragma unroll
+        for (int p = 0; p < W; ++p) {
+            const uint32_t f = f0 + (uint32_t)(p * 8 + grp);
+            nd[p] = fr_id[f < nf ? f : f0]; // idle groups shadow the pass's first row
+        }
+        gather_issue<NK, W>(ix, nd, slot, g);
+        gather_consume<METRIC, NK, W>(ix, qs, g, nd, slot, qhdr, qglobal, o);
+#pragma unroll
+        for (int p = 0; p < W; ++p) {
+            const uint32_t f = f0 + (uint32_t)(p * 8 + grp);
+            if (f < nf && j == 0) fr_d[f] = o[p];
+        }
     };
-    // distances of fr_id[0..nf) -> fr_d[0..nf)
-    auto score_frontier = [&](uint32_t nf) {
-        for (uint32_t f0 = 0; f0 < nf; f0 += 8u * P) {
-            uint32_t nd[P];
-            bool ac[P];
-            float o[P];
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                const uint32_t f = f0 + (uint32_t)(p * 8 + grp);
-                ac[p] = f < nf;
-                nd[p] = fr_id[ac[p] ? f : f0]; // idle groups shadow the pass's first row
-            }
-            score_rows<METRIC, NK, P>(ix, qs, nd, slot, qhdr, qglobal, o);
-#pragma unroll
-            for (int p = 0; p < P; ++p)
-                if (ac[p] && j == 0) fr_d[f0 + (uint32_t)(p * 8 + grp)] = o[p];
+    // distances of fr_id[0..nf) -> fr_d, widest pass that the remaining rows fill
+    auto score_frontier = [&](uint32_t nf) __attribute__((always_inline)) {
+        uint32_t f0 = 0;
+        while (f0 < nf) {
+            const uint32_t rem = nf - f0;
+            if (kWide4 && rem > 16u * P) { pass(std::integral_constant<int, kWide4 ? 4 * P : P>{}, f0, nf); f0 += 32u * P; }
+            else if (rem > 8u * P) { pass(std::integral_constant<int, 2 * P>{}, f0, nf); f0 += 16u * P; }
+            else { pass(std::integral_constant<int, P>{}, f0, nf); f0 += 8u * P; }
         }
         __syncthreads();
     };
+    // distance of ONE node, uniform result
+    auto score_one = [&](uint32_t node) __attribute__((always_inline)) -> float {
+        uint32_t nd[1] = {node};
+        float o[1];
+        Gather<NK, 1> g;
+        gather_issue<NK, 1>(ix, nd, slot, g);
+        gather_consume<METRIC, NK, 1>(ix, qs, g, nd, slot, qhdr, qglobal, o);
+        return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(o[0]), 0));
+    };
     // visited test-and-set + in-order compaction of one neighbour row held one id per lane
-    auto frontier_from = [&](uint32_t nid, uint32_t &deg) -> uint32_t {
+    auto frontier_from = [&](uint32_t nid, uint32_t &deg) __attribute__((always_inline)) -> uint32_t {
         const bool valid = nid != kSentinel;
         const bool isnew = V.insert(nid, valid, lane);
         const unsigned long long um = __ballot(isnew);
@@ -267,15 +295,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const uint32_t ef = a.ef;
     uint32_t pf_id = kSentinel, pf_row = kSentinel; // predicted next candidate and its prefetched row
     unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0; // PROF only
-    auto tick = [&](int phase) {
+    auto tick = [&](int phase, bool wait) __attribute__((always_inline)) {
         if (PROF) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (wait) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             t1 = __builtin_readcyclecounter();
             pt[phase] += t1 - t0;
             t0 = t1;
         }
     };
-    const unsigned long long t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
     if (!bad_score) {
         V.clear(lane);
         float d0 = score_one(cur);
@@ -285,7 +312,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         float ds;
         S.insert(d0, cur, lane, ds);
     }
-    if (PROF) { pt[7] = __builtin_readcyclecounter() - t_begin; t0 = __builtin_readcyclecounter(); }
+    const unsigned long long t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
+    if (PROF) t0 = t_begin;
     while (!bad_score) {
         const uint32_t pos = S.first_unexpanded(lane);
         if (pos >= S.count) {
@@ -305,21 +333,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         uint32_t nid;
         if (c == pf_id) { nid = pf_row; if (PROF) pt[6] += 1; }
         else nid = (uint32_t)lane < ix.s0 ? ix.l0[(size_t)c * ix.s0 + (uint32_t)lane] : kSentinel;
-        tick(0); // pop + neighbour row available
+        tick(0, true); // pop + neighbour row available
         uint32_t deg;
         const uint32_t nf = frontier_from(nid, deg);
         st_nb += deg;
-        tick(1); // visited test-and-set + compaction
+        tick(1, true); // visited test-and-set + compaction
         if (nf == 0) continue;
         st_vl += nf;
         st_dc += nf;
         score_frontier(nf);
-        tick(2); // row gathers + FMAs
+        tick(2, true); // row gathers + FMAs
+        if (PROF) pt[5] += nf > 16u * P ? 1 : 0;
         const float d_l = (uint32_t)lane < nf ? fr_d[lane] : inf;
         const uint32_t id_l = (uint32_t)lane < nf ? fr_id[lane] : kSentinel;
         __syncthreads();
         {
-            // predict the next pop: best admissible fresh candidate vs best unexpanded beam entry
+            // predict the next pop (best admissible fresh candidate vs best unexpanded beam entry) and
+            // fetch its neighbour row underneath the admission loop
             const uint32_t wl0 = S.count < ef ? S.count : ef;
             const bool adm = ((uint32_t)lane < nf) & ((d_l < wmax) | (wl0 < ef)) & (d_l >= 0.f) & (d_l < inf);
             const uint32_t key = adm ? __float_as_uint(d_l) : 0xFFFFFFFFu;
@@ -328,15 +358,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             uint32_t pred = kSentinel;
             float s2 = inf;
             if (p2 < S.count) { pred = S.id_at(p2); s2 = S.score_at(p2); }
-            if (kmin != 0xFFFFFFFFu && __uint_as_float(kmin) < s2) {
-                const unsigned long long eq = __ballot(key == kmin);
-                pred = __builtin_amdgcn_readlane(id_l, (uint32_t)__builtin_ctzll(eq));
-            }
+            if (kmin != 0xFFFFFFFFu && __uint_as_float(kmin) < s2)
+                pred = __builtin_amdgcn_readlane(id_l, (uint32_t)__builtin_ctzll(__ballot(key == kmin)));
             pf_id = pred;
             if (pred != kSentinel)
                 pf_row = (uint32_t)lane < ix.s0 ? ix.l0[(size_t)pred * ix.s0 + (uint32_t)lane] : kSentinel;
         }
-        if (PROF) { t1 = __builtin_readcyclecounter(); pt[3] += t1 - t0; t0 = t1; } // prediction (no wait: prefetch in flight)
+        tick(3, false); // prediction (the row load stays in flight)
         // admission in row order with the running bound (search.rs:928-952).  Once W is full the
         // bound only ever tightens, so a candidate that fails it at entry fails it at its turn: only
         // the lanes passing the entry bound are visited (in row order), each re-checked against the
@@ -362,14 +390,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                         ++dropped_unexpanded;
                         if (!(ds > wmax)) tie_overflow = true; // an equal-score candidate left the beam
                     }
-                    if (PROF) pt[5] += 1;
                 }
             }
         }
         if (PROF) { t1 = __builtin_readcyclecounter(); pt[4] += t1 - t0; t0 = t1; } // admission loop
     }
     if (PROF && a.prof && lane == 0) {
-        // [0] row wait [1] visited [2] gather+FMA [3] predict [4] admit (cycles); [5] inserts [6] prefetch hits [7] upper layers
+        // cycles: [0] pop+row wait [1] visited [2] gather wait+FMA [3] predict [4] admit [7] whole layer-0 loop;
+        // counts: [5] expansions with more than 16P fresh rows [6] row-prefetch hits
+        pt[7] = __builtin_readcyclecounter() - t_begin;
         for (int i = 0; i < 8; ++i) a.prof[(size_t)q * 8 + i] = pt[i];
     }
 
@@ -398,43 +427,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
 }
 
-// per-metric launchers, defined in hvx_hnsw_wave_l2.hip / hvx_hnsw_wave_cos.hip
-hipError_t launch_hnsw_wave_l2(const HnswArgs &a, uint32_t b, uint32_t log2cap, size_t lds, hipStream_t s);
-hipError_t launch_hnsw_wave_prof(const HnswArgs &a, uint32_t b, uint32_t log2cap, size_t lds, hipStream_t s);
-hipError_t launch_hnsw_wave_cos(const HnswArgs &a, uint32_t b, uint32_t log2cap, size_t lds, hipStream_t s);
+// launch geometry shared by the per-metric translation units
+struct WaveGeom {
+    uint32_t log2cap;
+    size_t lds;
+};
 
-template <uint32_t METRIC, int R>
-static hipError_t launch_wave_nk(const HnswArgs &a, uint32_t b, uint32_t log2cap, size_t lds, hipStream_t s) {
-    const uint32_t nk = a.ix.dim >> 5;
-#define HVX_WAVE_CASE(N)                                                                                       \
-    case N: {                                                                                                  \
-        auto kern = hnsw_wave_kernel<METRIC, R, N>;                                                            \
-        if (lds > 48 * 1024) {                                                                                 \
-            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                               (int)lds);                                                      \
-            if (e != hipSuccess) return e;                                                                     \
-        }                                                                                                      \
-        hipLaunchKernelGGL(kern, dim3(b), dim3(64), lds, s, a, log2cap);                                       \
-        break;                                                                                                 \
+// per-metric launchers, defined in hvx_hnsw_wave_l2.hip / hvx_hnsw_wave_cos.hip / hvx_hnsw_wave_prof.hip
+hipError_t launch_hnsw_wave_l2(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_cos(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_prof(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+
+template <typename K> static hipError_t launch_wave_kernel(K kern, const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
+    if (g.lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
+        if (e != hipSuccess) return e;
     }
-    switch (nk) {
-        HVX_WAVE_CASE(4)
-        HVX_WAVE_CASE(8)
-        HVX_WAVE_CASE(16)
-        HVX_WAVE_CASE(24)
-        HVX_WAVE_CASE(32)
-        HVX_WAVE_CASE(48)
-    default: return hipErrorInvalidValue;
-    }
-#undef HVX_WAVE_CASE
+    hipLaunchKernelGGL(kern, dim3(b), dim3(64), g.lds, s, a, g.log2cap);
     return hipGetLastError();
 }
 
+template <uint32_t METRIC, int R>
+static hipError_t launch_wave_nk(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
+    switch (a.ix.dim >> 5) {
+    case 4: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 4>, a, b, g, s);
+    case 8: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 8>, a, b, g, s);
+    case 16: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 16>, a, b, g, s);
+    case 24: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 24>, a, b, g, s);
+    case 32: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 32>, a, b, g, s);
+    case 48: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 48>, a, b, g, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
 template <uint32_t METRIC>
-static hipError_t launch_wave_r(const HnswArgs &a, uint32_t b, uint32_t log2cap, size_t lds, hipStream_t s) {
+static hipError_t launch_wave_r(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
     const uint32_t need = a.ef + 32u; // beam capacity 64*R must hold ef plus slack for equal-score evictions
-    if (need <= 192) return launch_wave_nk<METRIC, 3>(a, b, log2cap, lds, s);
-    if (need <= 384) return launch_wave_nk<METRIC, 6>(a, b, log2cap, lds, s);
+    if (need <= 192) return launch_wave_nk<METRIC, 3>(a, b, g, s);
+    if (need <= 384) return launch_wave_nk<METRIC, 6>(a, b, g, s);
     return hipErrorInvalidValue;
 }
 

@@ -2,7 +2,7 @@
 #include "hvx_hnsw_wave.h"
 
 namespace hvx {
-hipError_t launch_hnsw_wave_cos(const HnswArgs &a, uint32_t b, uint32_t log2cap, size_t lds, hipStream_t s) {
-    return launch_wave_r<kCosine>(a, b, log2cap, lds, s);
+hipError_t launch_hnsw_wave_cos(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
+    return launch_wave_r<kCosine>(a, b, g, s);
 }
 } // namespace hvx

@@ -3,9 +3,8 @@
 #include "hvx_hnsw_wave.h"
 
 namespace hvx {
-hipError_t launch_hnsw_wave_prof(const HnswArgs &a, uint32_t b, uint32_t log2cap, size_t lds, hipStream_t s) {
+hipError_t launch_hnsw_wave_prof(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
     if (a.ix.metric != kL2 || (a.ix.dim >> 5) != 24 || a.ef + 32u > 192u) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((hnsw_wave_kernel<kL2, 3, 24, true>), dim3(b), dim3(64), lds, s, a, log2cap);
-    return hipGetLastError();
+    return launch_wave_kernel(hnsw_wave_kernel<kL2, 3, 24, true>, a, b, g, s);
 }
 } // namespace hvx

@@ -146,7 +146,7 @@ def test_hnsw_kernels_agree_with_oracle(orc, hv, monkeypatch, path, n, dim, metr
     if path == "general":
         monkeypatch.setenv("HVX_HNSW_GENERAL", "1")
     if path == "wave-spill":
-        monkeypatch.setenv("HVX_WAVE_LOG2CAP", "8")  # 256-slot table: spills after ~64 visited ids
+        monkeypatch.setenv("HVX_WAVE_LOG2CAP", "8")  # 256-slot table: spills after ~128 visited ids
     rng = np.random.default_rng(77 + dim + metric)
     data = rng.standard_normal((n, dim)).astype(np.float32)
     lv = fx.draw_levels(n, m, seed=dim + 1)

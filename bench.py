@@ -8,7 +8,8 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JS
 N > 1 (launched by torch.distributed.run, one rank per GPU): the corpus is sharded by vector-id range,
 every rank searches the whole query batch on its shard, per-shard top-k are exchanged with ONE
 RCCL all-gather per result array and merged on the device by Candidate order
-(hvx_merge_topk_device).  `--shard-rows` fixes rows per GPU (weak scaling, default) .
+(hvx_merge_topk_device).  `--rows` is rows PER GPU: the corpus grows with N (weak scaling), every query
+is answered over all N x rows vectors; `value` stays the number of fully answered queries per second.
 
 The CPU oracle (oracle/) is used here ONLY as (a) the `cpu_baseline` leg and (b) a bit-exact
 checker of the GPU results; the timed product path is the HIP library through its C ABI.
@@ -77,7 +78,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
     import pyhvx as hv
-    from pyhvx import synth
+    from pyhvx import shard, synth
     hv.lib()
 
     n, dim, b, k, ef = args.rows, args.dim, args.batch, args.k, args.ef
@@ -130,20 +131,10 @@ def main():
     d_cnt = torch.zeros(b, dtype=torch.int32, device=dev)
     d_st = torch.zeros(b, dtype=torch.int32, device=dev)
     d_qst = torch.zeros(b, 4, dtype=torch.int32, device=dev)
-    if world > 1:
-        g_ids = torch.zeros(world, b, k, dtype=torch.int64, device=dev)
-        g_sc = torch.zeros(world, b, k, dtype=torch.float32, device=dev)
-        g_cnt = torch.zeros(world, b, dtype=torch.int32, device=dev)
-        m_ids = torch.zeros(b, k, dtype=torch.int64, device=dev)
-        m_sc = torch.zeros(b, k, dtype=torch.float32, device=dev)
-        m_cnt = torch.zeros(b, dtype=torch.int32, device=dev)
+    sharded = shard.ShardedSearcher(ix, world, b, k, dev) if world > 1 else None
 
     def exchange_and_merge(ids_t, sc_t, cnt_t):
-        dist.all_gather_into_tensor(g_ids, ids_t)
-        dist.all_gather_into_tensor(g_sc, sc_t)
-        dist.all_gather_into_tensor(g_cnt, cnt_t)
-        ix.merge_topk_device(world, b, k, g_ids, g_sc, g_cnt, m_ids, m_sc, m_cnt)
-        return m_ids, m_sc, m_cnt
+        return sharded.merge(ids_t, sc_t, cnt_t)
 
     kernel_ms = []
 
@@ -226,6 +217,7 @@ def main():
                    "dataset": args.dataset, "rows_per_gpu": n, "rows_total": n_total, "dim": dim, "batch": b, "k": k,
                    "ef_search": ef, "parallelism": f"id-range shards x{world} + all-gather top-k merge" if world > 1 else "1 GPU"},
         "recall_at_10": round(recall, 4),
+        "shard_searches_per_s": round(qps * world, 1),
         "roofline": roofline,
         "flat_scan_ms": round(flat_stats["device_ms"], 3),
     }

@@ -13,8 +13,8 @@
 //   * the next pop is predicted right after the distances of an expansion are known (best fresh
 //     candidate vs best unexpanded beam entry; right 97.7 % of the time on the 1M x 768 workload) and
 //     its neighbour row is fetched underneath the sequential admission loop;
-//   * a frontier of up to 8, 16 or 32 rows is gathered with ONE latency: the pass width is chosen per
-//     expansion (P, 2P or 4P rows per 8-lane group in flight), because the kernel ends with its
+//   * a frontier of up to 8, 16, 24 or 32 rows is gathered with ONE latency: the pass width is chosen per
+//     expansion (1, 2, 3 or 4 x P rows per 8-lane group in flight), because the kernel ends with its
 //     slowest query and the slow queries are the ones with large frontiers (profiles/r01c);
 //   * distances keep the host SIMD summation order (hvx_device.h) => scores are bit-identical to the
 //     reference CPU path; the beam (hvx_beam.h) is exact.
@@ -226,7 +226,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         uint32_t f0 = 0;
         while (f0 < nf) {
             const uint32_t rem = nf - f0;
-            if (kWide4 && rem > 16u * P) { pass(std::integral_constant<int, kWide4 ? 4 * P : P>{}, f0, nf); f0 += 32u * P; }
+            if (kWide4 && rem > 24u * P) { pass(std::integral_constant<int, kWide4 ? 4 * P : P>{}, f0, nf); f0 += 32u * P; }
+            else if (kWide4 && rem > 16u * P) { pass(std::integral_constant<int, kWide4 ? 3 * P : P>{}, f0, nf); f0 += 24u * P; }
             else if (rem > 8u * P) { pass(std::integral_constant<int, 2 * P>{}, f0, nf); f0 += 16u * P; }
             else { pass(std::integral_constant<int, P>{}, f0, nf); f0 += 8u * P; }
         }

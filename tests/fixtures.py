@@ -99,3 +99,28 @@ def recall_at_k(got_ids, true_ids) -> float:
         hit += sum(1 for x in g if int(x) in ts)
         tot += len(t)
     return hit / max(tot, 1)
+
+
+def merge_topk_reference(ids, scores, counts, k):
+    """Checker for the multi-shard merge: per query, the k smallest of the gathered per-shard lists by
+    the reference's Candidate order (score asc, then id asc; model.rs:55-61).
+    ids/scores [g,b,k'], counts [g,b] -> (ids [b,k] u64, scores [b,k] f32, counts [b])."""
+    ids = np.asarray(ids).astype(np.uint64)
+    scores = np.asarray(scores, np.float32)
+    counts = np.asarray(counts).astype(np.int64)
+    g, b, _ = ids.shape
+    out_i = np.zeros((b, k), np.uint64)
+    out_s = np.zeros((b, k), np.float32)
+    out_c = np.zeros(b, np.uint32)
+    for q in range(b):
+        cand = []
+        for s in range(g):
+            for t in range(int(counts[s, q])):
+                cand.append((float(scores[s, q, t]), int(ids[s, q, t])))
+        cand.sort()
+        cand = cand[:k]
+        out_c[q] = len(cand)
+        for t, (sc, i) in enumerate(cand):
+            out_i[q, t] = i
+            out_s[q, t] = np.float32(sc)
+    return out_i, out_s, out_c

@@ -355,3 +355,34 @@ def test_traverse_and_expand_match_reference_semantics(hv):
     assert set(np.nonzero(np.unpackbits(w.view(np.uint8), bitorder="little"))[0].tolist()) == exp
     with pytest.raises(hv.HelixDbError):
         g.traverse([n + 5], 1)
+
+
+def test_merge_topk_device_matches_candidate_order(orc, hv):
+    """hvx_merge_topk_device (the N>1 merge after the all-gather) vs the Candidate-order checker,
+    including equal scores on different shards, short lists and empty shards."""
+    import torch
+    rng = np.random.default_rng(3)
+    g, b, k = 5, 33, 10
+    gix = hv.ValidatedVectorReadIndex.managed(dim=4, metric=hv.EUCLIDEAN, node_ids=np.arange(4, dtype=np.uint64),
+                                              vectors=np.zeros((4, 4), np.float32), l0_offsets=np.zeros(5, np.uint64),
+                                              l0_neighbors=np.zeros(0, np.uint64))
+    ids = np.zeros((g, b, k), np.uint64); sc = np.zeros((g, b, k), np.float32); cnt = np.zeros((g, b), np.int32)
+    for s_ in range(g):
+        for q in range(b):
+            c = int(rng.integers(0, k + 1)) if (s_ + q) % 7 else 0
+            vals = np.sort(rng.integers(0, 6, c).astype(np.float32) * np.float32(0.25))  # many ties
+            idv = rng.choice(1000, c, replace=False).astype(np.uint64) * g + s_            # unique across shards
+            order = np.lexsort((idv, vals))
+            sc[s_, q, :c] = vals[order]; ids[s_, q, :c] = idv[order]; cnt[s_, q] = c
+    dev = torch.device("cuda")
+    t = lambda a, dt: torch.from_numpy(a.view(dt) if a.dtype == np.uint64 else a).to(dev)
+    o_ids = torch.zeros(b, k, dtype=torch.int64, device=dev); o_sc = torch.zeros(b, k, dtype=torch.float32, device=dev)
+    o_cnt = torch.zeros(b, dtype=torch.int32, device=dev)
+    gix.merge_topk_device(g, b, k, t(ids, np.int64), t(sc, None), t(cnt, None), o_ids, o_sc, o_cnt)
+    gix.sync()
+    r_ids, r_sc, r_cnt = fx.merge_topk_reference(ids, sc, cnt, k)
+    got_i, got_s, got_c = o_ids.cpu().numpy().view(np.uint64), o_sc.cpu().numpy(), o_cnt.cpu().numpy()
+    assert got_c.tolist() == r_cnt.tolist()
+    for q in range(b):
+        assert got_i[q, :r_cnt[q]].tolist() == r_ids[q, :r_cnt[q]].tolist()
+        assert bits(got_s[q, :r_cnt[q]]).tolist() == bits(r_sc[q, :r_cnt[q]]).tolist()

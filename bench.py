@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--ef", type=int, default=128)
     ap.add_argument("--m", type=int, default=16)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="row storage on the device (bf16 = config #4)")
     ap.add_argument("--dataset", default="embedding", choices=["embedding", "gaussian"])
     ap.add_argument("--latent", type=int, default=16)
     ap.add_argument("--clusters", type=int, default=1024)
@@ -113,15 +114,25 @@ def main():
     log(f"graph built in {time.time() - t0:.1f}s: layer-0 degree mean {deg.mean():.1f} max {deg.max()}, max_layer {g['max_layer']}")
 
     t0 = time.time()
+    bf16 = args.dtype == "bf16"
+    if bf16:  # the index holds the rounded values; graph and oracle see exactly those
+        x = x.to(torch.bfloat16).to(torch.float32)
     x_host = x.cpu().numpy()
     ids = g["node_ids"] + np.uint64(id_lo)
     ix = hv.ValidatedVectorReadIndex.managed(
         dim=dim, metric=hv.EUCLIDEAN, node_ids=ids, vectors=x_host, l0_offsets=g["l0_offsets"],
         l0_neighbors=g["l0_neighbors"] + np.uint64(id_lo), level=g["level"], up_offsets=g["up_offsets"],
         up_neighbors=g["up_neighbors"] + np.uint64(id_lo), entry_point=g["entry_point"] + id_lo,
-        max_layer=g["max_layer"], m=args.m, m0=2 * args.m, device=local_rank, max_batch=b)
+        max_layer=g["max_layer"], m=args.m, m0=2 * args.m, device=local_rank, max_batch=b,
+        dtype=hv.BF16 if bf16 else hv.F32)
     stream = torch.cuda.current_stream(dev)
     ix.set_stream(stream.cuda_stream)
+    ix_truth = ix
+    if bf16:  # exact-scan ground truth over the same rounded rows (the exact scan reads f32 rows)
+        ix_truth = hv.ValidatedVectorReadIndex.managed(
+            dim=dim, metric=hv.EUCLIDEAN, node_ids=ids, vectors=x_host, l0_offsets=np.zeros(n + 1, np.uint64),
+            l0_neighbors=np.zeros(0, np.uint64), device=local_rank, max_batch=b)
+        ix_truth.set_stream(stream.cuda_stream)
     log(f"index imported in {time.time() - t0:.1f}s")
     del x
 
@@ -172,7 +183,7 @@ def main():
     f_sc = torch.zeros(b, k, dtype=torch.float32, device=dev)
     f_cnt = torch.zeros(b, dtype=torch.int32, device=dev)
     f_st = torch.zeros(b, dtype=torch.int32, device=dev)
-    flat_stats = ix.flat_search_batch_device(q, k, f_ids, f_sc, f_cnt, f_st, want_stats=True)
+    flat_stats = ix_truth.flat_search_batch_device(q, k, f_ids, f_sc, f_cnt, f_st, want_stats=True)
     if world > 1:
         truth = exchange_and_merge(f_ids, f_sc, f_cnt)[0].clone()
         got = exchange_and_merge(d_ids, d_sc, d_cnt)[0].clone()
@@ -188,7 +199,8 @@ def main():
     qst = d_qst.cpu().numpy().astype(np.int64)
     exp_steps, nb_exam, vec_loaded, dist_comp = (int(qst[:, i].sum()) for i in range(4))
     avg_deg = nb_exam / max(exp_steps, 1)
-    alg_bytes = dist_comp * dim * 4 + exp_steps * avg_deg * 4 + b * dim * 4
+    elem = 2 if bf16 else 4
+    alg_bytes = dist_comp * dim * elem + exp_steps * avg_deg * 4 + b * dim * 4
     k_ms = float(np.mean(kernel_ms))
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     traffic = None
@@ -211,8 +223,8 @@ def main():
         "metric": "QPS @ recall@10>=0.95, 1Mx768 fp32; achieved HBM GB/s vs roofline", "value": round(qps, 1),
         "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"configs[1]: {n}x{dim} f32 per GPU, HNSW M={args.m}/M0={2 * args.m} ef_search={ef} k={k}, "
+        "dtype": "f32" if not bf16 else "f32 arithmetic on bf16 rows", "data": "synthetic",
+        "config": {"workload": f"configs[1]: {n}x{dim} {args.dtype} per GPU, HNSW M={args.m}/M0={2 * args.m} ef_search={ef} k={k}, "
                                f"batch={b} queries, squared-L2, strict-exhaustive beam (bit-exact vs reference CPU path)",
                    "dataset": args.dataset, "rows_per_gpu": n, "rows_total": n_total, "dim": dim, "batch": b, "k": k,
                    "ef_search": ef, "parallelism": f"id-range shards x{world} + all-gather top-k merge" if world > 1 else "1 GPU"},

@@ -124,9 +124,11 @@ extern "C" int hvx_index_import(const hvx_index_desc *desc, const uint64_t *node
     *out = nullptr;
     if (desc->dim == 0) return fail(HVX_ERR_DIMENSION, "dimension must be non-zero");
     if (desc->metric > HVX_MANHATTAN) return fail(HVX_ERR_UNSUPPORTED, "unknown metric %u", desc->metric);
-    if (desc->dtype != HVX_F32)
-        return fail(HVX_ERR_UNSUPPORTED, "device dtype %u not built yet (f32 is the reference's only active codec)",
+    if (desc->dtype != HVX_F32 && desc->dtype != HVX_BF16)
+        return fail(HVX_ERR_UNSUPPORTED, "device dtype %u not built yet (f32 is the reference's only active codec; bf16 is served)",
                     desc->dtype);
+    if (desc->dtype == HVX_BF16 && (desc->dim % 64u != 0u || desc->float_kernel != HVX_KERNEL_AVX_FMA || desc->metric == HVX_MANHATTAN))
+        return fail(HVX_ERR_UNSUPPORTED, "bf16 rows need dim %% 64 == 0, the AVX+FMA summation tree and an L2/cosine metric");
     if (desc->float_kernel != HVX_KERNEL_SCALAR && desc->float_kernel != HVX_KERNEL_AVX &&
         desc->float_kernel != HVX_KERNEL_AVX_FMA)
         return fail(HVX_ERR_UNSUPPORTED, "float kernel %u not supported on device", desc->float_kernel);
@@ -153,6 +155,7 @@ extern "C" int hvx_index_import(const hvx_index_desc *desc, const uint64_t *node
     d.dim_main = (desc->float_kernel == HVX_KERNEL_SCALAR || desc->dim < 32) ? 0u : desc->dim - desc->dim % 32u;
     d.max_layer = desc->max_layer;
     d.has_entry = (desc->has_entry && n) ? 1u : 0u;
+    d.dtype = desc->dtype;
     if (desc->max_layer > 63) { free_index(ix); return fail(HVX_ERR_INVARIANT, "max_layer > 63"); }
 
     auto bail = [&](int code) { free_index(ix); return code; };
@@ -232,16 +235,25 @@ extern "C" int hvx_index_import(const hvx_index_desc *desc, const uint64_t *node
     void *p;
     int rc;
     const size_t vec_bytes = (size_t)n * d.ld * 4;
-    if ((rc = ix->dalloc(&p, vec_bytes))) return bail(rc);
+    const bool bf16 = desc->dtype == HVX_BF16;
+    float *staging = nullptr; // bf16: temporary f32 copy, rounded in place, validated, packed, freed
+    if (bf16) {
+        if (hipMalloc((void **)&staging, std::max<size_t>(vec_bytes, 16)) != hipSuccess) return bail(fail(HVX_ERR_DEVICE, "hipMalloc(%zu) staging", vec_bytes));
+        p = staging;
+    } else if ((rc = ix->dalloc(&p, vec_bytes))) return bail(rc);
     d.vec = (const float *)p;
+    auto bail_free = [&](int code) { if (staging) (void)hipFree(staging); return bail(code); };
     if (n) {
         if (d.ld == d.dim) {
-            if (hipMemcpy(p, vectors, vec_bytes, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(HVX_ERR_DEVICE, "vector upload failed"));
+            if (hipMemcpy(p, vectors, vec_bytes, hipMemcpyHostToDevice) != hipSuccess) return bail_free(fail(HVX_ERR_DEVICE, "vector upload failed"));
         } else {
             if (hipMemset(p, 0, vec_bytes) != hipSuccess ||
                 hipMemcpy2D(p, (size_t)d.ld * 4, vectors, (size_t)d.dim * 4, (size_t)d.dim * 4, n, hipMemcpyHostToDevice) != hipSuccess)
-                return bail(fail(HVX_ERR_DEVICE, "vector upload failed"));
+                return bail_free(fail(HVX_ERR_DEVICE, "vector upload failed"));
         }
+        // bf16: the index IS the rounded vectors -- validation and cosine headers see the rounded values
+        if (bf16 && launch_round_bf16_inplace(staging, (size_t)n * d.ld, ix->stream) != hipSuccess)
+            return bail_free(fail(HVX_ERR_DEVICE, "bf16 rounding failed"));
     }
     auto upload = [&](const void *src, size_t bytes, const void **dst) -> int {
         void *q;
@@ -251,20 +263,20 @@ extern "C" int hvx_index_import(const hvx_index_desc *desc, const uint64_t *node
         *dst = q;
         return HVX_OK;
     };
-    if ((rc = upload(h_l0.data(), h_l0.size() * 4, (const void **)&d.l0))) return bail(rc);
-    if ((rc = upload(h_up.data(), h_up.size() * 4, (const void **)&d.up))) return bail(rc);
-    if ((rc = upload(h_up_base.data(), h_up_base.size() * 4, (const void **)&d.up_base))) return bail(rc);
-    if ((rc = upload(h_level.data(), h_level.size() * 2, (const void **)&d.level))) return bail(rc);
-    if ((rc = upload(ix->ids.data(), ix->ids.size() * 8, (const void **)&d.ids))) return bail(rc);
+    if ((rc = upload(h_l0.data(), h_l0.size() * 4, (const void **)&d.l0))) return bail_free(rc);
+    if ((rc = upload(h_up.data(), h_up.size() * 4, (const void **)&d.up))) return bail_free(rc);
+    if ((rc = upload(h_up_base.data(), h_up_base.size() * 4, (const void **)&d.up_base))) return bail_free(rc);
+    if ((rc = upload(h_level.data(), h_level.size() * 2, (const void **)&d.level))) return bail_free(rc);
+    if ((rc = upload(ix->ids.data(), ix->ids.size() * 8, (const void **)&d.ids))) return bail_free(rc);
 
     // ---- validate rows + headers ONCE on the device (decode_item_borrowed does it per fetch:
     //      mod.rs:889-949) ----
     float *d_hdr;
     uint32_t *d_rowstatus;
-    if ((rc = ix->dalloc((void **)&d_hdr, std::max<size_t>(n, 1) * 4))) return bail(rc);
+    if ((rc = ix->dalloc((void **)&d_hdr, std::max<size_t>(n, 1) * 4))) return bail_free(rc);
     d.hdr = d_hdr;
     if (n) {
-        if (hipMalloc((void **)&d_rowstatus, n * 4) != hipSuccess) return bail(fail(HVX_ERR_DEVICE, "hipMalloc row status"));
+        if (hipMalloc((void **)&d_rowstatus, n * 4) != hipSuccess) return bail_free(fail(HVX_ERR_DEVICE, "hipMalloc row status"));
         // rows are laid out with stride ld; validate through a DevIndex view whose "dim" stride matches
         DevIndex view = d;
         hipError_t e = launch_validate_rows(view, (uint32_t)n, ix->limit, d_rowstatus, d_hdr, ix->stream);
@@ -272,9 +284,20 @@ extern "C" int hvx_index_import(const hvx_index_desc *desc, const uint64_t *node
         if (e == hipSuccess) e = hipMemcpyAsync(st.data(), d_rowstatus, n * 4, hipMemcpyDeviceToHost, ix->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
         (void)hipFree(d_rowstatus);
-        if (e != hipSuccess) return bail(fail(HVX_ERR_DEVICE, "row validation: %s", hipGetErrorString(e)));
+        if (e != hipSuccess) return bail_free(fail(HVX_ERR_DEVICE, "row validation: %s", hipGetErrorString(e)));
         for (uint64_t i = 0; i < n; ++i)
-            if (st[i]) return bail(fail((int)st[i], "stored vector of node %llu is invalid for this metric (status %u)", (unsigned long long)node_ids[i], st[i]));
+            if (st[i]) return bail_free(fail((int)st[i], "stored vector of node %llu is invalid for this metric (status %u)", (unsigned long long)node_ids[i], st[i]));
+    }
+    if (bf16) {
+        void *pb;
+        if ((rc = ix->dalloc(&pb, (size_t)n * d.dim * 2))) return bail_free(rc);
+        hipError_t e = launch_pack_bf16(staging, (uint16_t *)pb, (uint32_t)n, d.dim, ix->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+        (void)hipFree(staging);
+        staging = nullptr;
+        if (e != hipSuccess) return bail(fail(HVX_ERR_DEVICE, "bf16 packing: %s", hipGetErrorString(e)));
+        d.vecb = (const uint16_t *)pb;
+        d.vec = nullptr;
     }
 
     // ---- per-batch scratch ----
@@ -365,7 +388,9 @@ static int enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t
     // the HBM visited bitmap is all-zero at import; the general kernel dirties it, the wave kernel
     // (LDS visited set, bitmap only as overflow) hands it back zeroed
     const bool force_general = getenv("HVX_HNSW_GENERAL") != nullptr; // test hook
-    const bool wave = !force_general && hnsw_wave_supported(a);
+    const bool wave = !(force_general && ix->dev.dtype == HVX_F32) && hnsw_wave_supported(a);
+    if (!wave && ix->dev.dtype != HVX_F32)
+        return fail(HVX_ERR_UNSUPPORTED, "bf16 rows are served by the one-wavefront-per-query kernel only (dim in {128,256,512,768,1024,1536}, rows <= 64 ids, ef <= 352)");
     if (ix->bitmap_dirty) {
         HIP_TRY(hipMemsetAsync(ix->d_bitmap, 0, (size_t)ix->max_batch * ix->words_per_query * 4, ix->stream));
         ix->bitmap_dirty = false;
@@ -488,6 +513,7 @@ int hvx::flat_scan_device(hvx_index *ix, const float *d_queries, uint32_t b, uin
                           uint32_t *d_status, bool timed) {
     if (k == 0) return fail(HVX_ERR_K_RANGE, "result count must be non-zero");
     if (k > 1024) return fail(HVX_ERR_UNSUPPORTED, "flat scan supports k <= 1024");
+    if (ix->dev.dtype != HVX_F32) return fail(HVX_ERR_UNSUPPORTED, "exact scan over bf16 rows is not built yet");
     // chunk the scan so the distance workspace stays <= 256 MiB
     uint32_t chunk = 65536;
     while ((size_t)chunk * b * 4 > (256u << 20) && chunk > 256) chunk >>= 1;

@@ -25,7 +25,8 @@ enum : uint32_t { kKernelScalar = 0, kKernelAvx = 2, kKernelAvxFma = 3 };
 
 // Read-only index image in HBM (see DESIGN.md "HBM layout").
 struct DevIndex {
-    const float *vec;         // [n][ld] row-major f32, rows 16-byte aligned, zero padded to ld
+    const float *vec;         // [n][ld] row-major f32, rows 16-byte aligned, zero padded to ld (dtype f32)
+    const uint16_t *vecb;     // [n][dim] bf16 rows in the interleaved device layout below (dtype bf16)
     const float *hdr;         // [n] cosine norm header (distance/cosine.rs:73-75); 0 otherwise
     const uint32_t *l0;       // [n][s0] layer-0 rows: internal ids ascending, kSentinel padded
     const uint32_t *up;       // [up_rows][su] upper-layer rows, same format
@@ -37,7 +38,30 @@ struct DevIndex {
     uint32_t s0, su;          // row strides of l0 / up (multiples of 32 / 16)
     uint32_t metric, fkernel;
     uint32_t entry, max_layer, has_entry;
+    uint32_t dtype;           // hvx_dtype of the stored rows
 };
+
+// bf16 device layout (dim % 64 == 0): element i = 32*chunk + 4*slot + e is stored at
+// 64*(chunk/2) + 8*slot + 4*(chunk%2) + e, so that the 16 bytes a lane of a row group owns hold its
+// four AVX "virtual lanes" of TWO consecutive 32-float chunks: one dwordx4 load per chunk pair, the
+// eight lanes of a group still read 128 contiguous bytes.  Dot products (MFMA flat scan) are
+// indifferent to the permutation as long as the query operand uses the same one.
+__host__ __device__ __forceinline__ uint32_t bf16_slot_of(uint32_t i) {
+    const uint32_t k = i >> 5, s = (i >> 2) & 7u, e = i & 3u;
+    return (k >> 1) * 64u + s * 8u + (k & 1u) * 4u + e;
+}
+// round-to-nearest-even f32 -> bf16 bits (finite inputs; NaN/inf are rejected before)
+__host__ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+    union { float f; uint32_t u; } v;
+    v.f = f;
+    const uint32_t lsb = (v.u >> 16) & 1u;
+    return (uint16_t)((v.u + 0x7FFFu + lsb) >> 16);
+}
+__host__ __device__ __forceinline__ float bf16_to_f32(uint16_t h) {
+    union { float f; uint32_t u; } v;
+    v.u = (uint32_t)h << 16;
+    return v.f;
+}
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
@@ -122,9 +146,21 @@ __device__ inline float stable_half_cosine(const float *p, const float *q, uint3
     return (float)((1.0 - c) * 0.5);
 }
 
-// distance/cosine.rs:96-118: fast path on cached norms, else f64 fallback
-__device__ __forceinline__ float cosine_finish(float pq, float pn, float qn, const float *qv,
-                                               const float *row, uint32_t dim) {
+// distance/cosine.rs:39-59 over arbitrary component accessors (bf16 rows are dequantised on the fly)
+template <typename FP, typename FQ> __device__ inline float stable_half_cosine_fn(uint32_t n, FP pat, FQ qat) {
+    double pn = scaled_l2_norm(n, pat);
+    double qn = scaled_l2_norm(n, qat);
+    if (pn == 0.0 || qn == 0.0) return __uint_as_float(0x7FC00000u);
+    double dot = 0.0;
+    for (uint32_t i = 0; i < n; ++i) dot += (double)pat(i) * (double)qat(i);
+    double c = dot / (pn * qn);
+    if (c < -1.0) c = -1.0;
+    if (c > 1.0) c = 1.0;
+    return (float)((1.0 - c) * 0.5);
+}
+
+// distance/cosine.rs:96-118: fast path on cached norms, else the f64 fallback `slow()`
+template <typename F> __device__ __forceinline__ float cosine_finish_fn(float pq, float pn, float qn, F slow) {
     float pnqn = pn * qn;
     if (pn > 0.0f && qn > 0.0f && pn != 3.402823466e+38f && qn != 3.402823466e+38f &&
         f32_is_normal(pnqn) && f32_is_finite(pq)) {
@@ -133,7 +169,11 @@ __device__ __forceinline__ float cosine_finish(float pq, float pn, float qn, con
         if (c > 1.0f) c = 1.0f;
         return (1.0f - c) / 2.0f;
     }
-    return stable_half_cosine(qv, row, dim);
+    return slow();
+}
+__device__ __forceinline__ float cosine_finish(float pq, float pn, float qn, const float *qv,
+                                               const float *row, uint32_t dim) {
+    return cosine_finish_fn(pq, pn, qn, [&]() { return stable_half_cosine(qv, row, dim); });
 }
 
 // One embedding row scored by the 8 lanes of a row group (all 8 lanes return the same value).

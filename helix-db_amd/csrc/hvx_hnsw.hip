@@ -307,12 +307,15 @@ struct WaveGeom {
 hipError_t launch_hnsw_wave_l2(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_cos(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_prof(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_l2_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_cos_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 
 bool hnsw_wave_supported(const HnswArgs &a) {
     const DevIndex &ix = a.ix;
     if (ix.metric != kL2 && ix.metric != kCosine) return false;
     if (ix.fkernel != kKernelAvxFma) return false;
     if (ix.dim % 32u != 0u || ix.dim_main != ix.dim || ix.ld != ix.dim) return false;
+    if (ix.dtype != HVX_F32 && ix.dtype != HVX_BF16) return false;
     const uint32_t nk = ix.dim >> 5;
     if (nk != 4 && nk != 8 && nk != 16 && nk != 24 && nk != 32 && nk != 48) return false;
     if (ix.s0 > 64 || ix.su > 64) return false;
@@ -339,6 +342,7 @@ hipError_t launch_hnsw_wave(const HnswArgs &a, uint32_t b, hipStream_t s) {
     const size_t need = ((size_t)4 << g.log2cap) + 512 + (size_t)a.ix.dim * 4;
     g.lds = need < budget ? budget : need;
     if (a.prof) return launch_hnsw_wave_prof(a, b, g, s);
+    if (a.ix.dtype == HVX_BF16) return a.ix.metric == kL2 ? launch_hnsw_wave_l2_bf16(a, b, g, s) : launch_hnsw_wave_cos_bf16(a, b, g, s);
     return a.ix.metric == kL2 ? launch_hnsw_wave_l2(a, b, g, s) : launch_hnsw_wave_cos(a, b, g, s);
 }
 

@@ -19,7 +19,7 @@
 //   * distances keep the host SIMD summation order (hvx_device.h) => scores are bit-identical to the
 //     reference CPU path; the beam (hvx_beam.h) is exact.
 //
-// Served shapes: metric L2 / cosine, AVX+FMA summation tree, dim = 32*NK with NK in
+// Served shapes: f32 or bf16 rows, metric L2 / cosine, AVX+FMA summation tree, dim = 32*NK with NK in
 // {4,8,16,24,32,48} (dim 128 ... 1536), neighbour rows <= 64 ids, ef + 32 <= 384.  Everything else runs on the general
 // kernel in hvx_hnsw.hip.
 #pragma once
@@ -104,68 +104,105 @@ struct Visited {
     }
 };
 
-// One gather pass in flight: P rows per 8-lane group, P*NK float4 per lane.
-template <int NK, int P> struct Gather {
-    float4 x[P][NK];
+// One gather pass in flight: P rows per 8-lane group.  f32 rows: NK 16-byte loads per lane and row;
+// bf16 rows (interleaved layout, hvx_device.h): NK/2 loads, each carrying the lane's virtual lanes of
+// two consecutive chunks.
+template <int NK, int P, bool BF> struct Gather {
+    float4 x[P][BF ? NK / 2 : NK];
 };
 
 // Straight-line issue of every load of a pass.  Groups without a row of their own are pointed at
 // another group's row by the caller (identical addresses coalesce inside the load instruction): no
 // divergence, nothing for the compiler to sink behind a branch.
-template <int NK, int P>
-__device__ __forceinline__ void gather_issue(const DevIndex &ix, const uint32_t (&node)[P], int slot, Gather<NK, P> &g) {
+template <int NK, int P, bool BF>
+__device__ __forceinline__ void gather_issue(const DevIndex &ix, const uint32_t (&node)[P], int slot, Gather<NK, P, BF> &g) {
+    constexpr int NL = BF ? NK / 2 : NK;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        const float4 *rp = reinterpret_cast<const float4 *>(ix.vec + (size_t)node[p] * ix.ld) + slot;
+        const float4 *rp = BF ? reinterpret_cast<const float4 *>(ix.vecb + (size_t)node[p] * ix.dim) + slot
+                              : reinterpret_cast<const float4 *>(ix.vec + (size_t)node[p] * ix.ld) + slot;
 #pragma unroll
-        for (int k = 0; k < NK; ++k) g.x[p][k] = rp[k * 8];
+        for (int k = 0; k < NL; ++k) g.x[p][k] = rp[k * 8];
     }
     __builtin_amdgcn_sched_barrier(0); // every load is issued before anything that follows is scheduled
 }
 
+template <uint32_t METRIC> __device__ __forceinline__ void fma_chunk(float4 &acc, const float4 qq, const float4 xv) {
+    if (METRIC == kL2) {
+        const float d0 = qq.x - xv.x, d1 = qq.y - xv.y, d2 = qq.z - xv.z, d3 = qq.w - xv.w;
+        acc.x = __builtin_fmaf(d0, d0, acc.x); acc.y = __builtin_fmaf(d1, d1, acc.y);
+        acc.z = __builtin_fmaf(d2, d2, acc.z); acc.w = __builtin_fmaf(d3, d3, acc.w);
+    } else {
+        acc.x = __builtin_fmaf(qq.x, xv.x, acc.x); acc.y = __builtin_fmaf(qq.y, xv.y, acc.y);
+        acc.z = __builtin_fmaf(qq.z, xv.z, acc.z); acc.w = __builtin_fmaf(qq.w, xv.w, acc.w);
+    }
+}
+
 // FMAs in the host SIMD order against the query staged in LDS (conflict-free: the 8 lanes of a group
 // read 128 contiguous bytes, the 8 groups broadcast), then the AVX reduction tree.
-template <uint32_t METRIC, int NK, int P>
-__device__ __forceinline__ void gather_consume(const DevIndex &ix, const float *qs, const Gather<NK, P> &g,
+template <uint32_t METRIC, int NK, int P, bool BF>
+__device__ __forceinline__ void gather_consume(const DevIndex &ix, const float *qs, const Gather<NK, P, BF> &g,
                                                const uint32_t (&node)[P], int slot, float qhdr,
                                                const float *qglobal, float (&out)[P]) {
     float4 acc[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 *qp = reinterpret_cast<const float4 *>(qs) + slot;
+    if (!BF) {
 #pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        const float4 qq = qp[k * 8];
+        for (int k = 0; k < NK; ++k) {
+            const float4 qq = qp[k * 8];
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            const float4 xv = g.x[p][k];
-            if (METRIC == kL2) {
-                const float d0 = qq.x - xv.x, d1 = qq.y - xv.y, d2 = qq.z - xv.z, d3 = qq.w - xv.w;
-                acc[p].x = __builtin_fmaf(d0, d0, acc[p].x); acc[p].y = __builtin_fmaf(d1, d1, acc[p].y);
-                acc[p].z = __builtin_fmaf(d2, d2, acc[p].z); acc[p].w = __builtin_fmaf(d3, d3, acc[p].w);
-            } else {
-                acc[p].x = __builtin_fmaf(qq.x, xv.x, acc[p].x); acc[p].y = __builtin_fmaf(qq.y, xv.y, acc[p].y);
-                acc[p].z = __builtin_fmaf(qq.z, xv.z, acc[p].z); acc[p].w = __builtin_fmaf(qq.w, xv.w, acc[p].w);
+            for (int p = 0; p < P; ++p) fma_chunk<METRIC>(acc[p], qq, g.x[p][k]);
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < NK / 2; ++m) {
+            const float4 q0 = qp[(2 * m) * 8], q1 = qp[(2 * m + 1) * 8];
+#pragma unroll
+            for (int p = 0; p < P; ++p) { // bf16 -> f32 is exact: the halfword becomes the high half of the word
+                const uint32_t w0 = __float_as_uint(g.x[p][BF ? m : 0].x), w1 = __float_as_uint(g.x[p][BF ? m : 0].y);
+                const float4 x0 = make_float4(__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xFFFF0000u),
+                                              __uint_as_float(w1 << 16), __uint_as_float(w1 & 0xFFFF0000u));
+                fma_chunk<METRIC>(acc[p], q0, x0);
+            }
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const uint32_t w2 = __float_as_uint(g.x[p][BF ? m : 0].z), w3 = __float_as_uint(g.x[p][BF ? m : 0].w);
+                const float4 x1 = make_float4(__uint_as_float(w2 << 16), __uint_as_float(w2 & 0xFFFF0000u),
+                                              __uint_as_float(w3 << 16), __uint_as_float(w3 & 0xFFFF0000u));
+                fma_chunk<METRIC>(acc[p], q1, x1);
             }
         }
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         float r = avx_tree_reduce(acc[p]);
-        if (METRIC == kCosine)
-            r = cosine_finish(r, qhdr, ix.hdr[node[p]], qglobal, ix.vec + (size_t)node[p] * ix.ld, ix.dim);
+        if (METRIC == kCosine) {
+            const uint32_t nd = node[p];
+            r = cosine_finish_fn(r, qhdr, ix.hdr[nd], [&]() {
+                if (BF) {
+                    const uint16_t *rb = ix.vecb + (size_t)nd * ix.dim;
+                    return stable_half_cosine_fn(ix.dim, [&](uint32_t i) { return qglobal[i]; },
+                                                 [&](uint32_t i) { return bf16_to_f32(rb[bf16_slot_of(i)]); });
+                }
+                const float *rf = ix.vec + (size_t)nd * ix.ld;
+                return stable_half_cosine_fn(ix.dim, [&](uint32_t i) { return qglobal[i]; }, [&](uint32_t i) { return rf[i]; });
+            });
+        }
         out[p] = r;
     }
 }
 
 // PROF=true builds the phase-timing variant (s_memtime around each phase of a layer-0 expansion,
 // hard waits at the phase boundaries); it is only launched when HVX_WAVE_PROF is set.
-template <uint32_t METRIC, int R, int NK, bool PROF = false>
+template <uint32_t METRIC, int R, int NK, bool BF, bool PROF = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void hnsw_wave_kernel(HnswArgs a, uint32_t log2cap) {
     // rows per 8-lane group in flight: P*NK <= 24 float4 per lane for a narrow pass, x2 and x4 for wider
     // frontiers (4P*NK <= 96 float4 = 384 registers, VGPR+AGPR file of one wave per SIMD)
-    constexpr int P = NK <= 8 ? 2 : 1;
-    constexpr bool kWide4 = 4 * P * NK <= 96;
+    constexpr int NL = BF ? NK / 2 : NK;        // 16-byte loads per lane and row
+    constexpr int P = NL <= 8 ? 2 : 1;
+    constexpr bool kWide4 = 4 * P * NL <= 96;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const DevIndex &ix = a.ix;
     const uint32_t q = blockIdx.x;
@@ -207,14 +244,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         constexpr int W = decltype(width)::value;
         uint32_t nd[W];
         float o[W];
-        Gather<NK, W> g;
+        Gather<NK, W, BF> g;
 #pragma unroll
         for (int p = 0; p < W; ++p) {
             const uint32_t f = f0 + (uint32_t)(p * 8 + grp);
             nd[p] = fr_id[f < nf ? f : f0]; // idle groups shadow the pass's first row
         }
-        gather_issue<NK, W>(ix, nd, slot, g);
-        gather_consume<METRIC, NK, W>(ix, qs, g, nd, slot, qhdr, qglobal, o);
+        gather_issue<NK, W, BF>(ix, nd, slot, g);
+        gather_consume<METRIC, NK, W, BF>(ix, qs, g, nd, slot, qhdr, qglobal, o);
 #pragma unroll
         for (int p = 0; p < W; ++p) {
             const uint32_t f = f0 + (uint32_t)(p * 8 + grp);
@@ -237,9 +274,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     auto score_one = [&](uint32_t node) __attribute__((always_inline)) -> float {
         uint32_t nd[1] = {node};
         float o[1];
-        Gather<NK, 1> g;
-        gather_issue<NK, 1>(ix, nd, slot, g);
-        gather_consume<METRIC, NK, 1>(ix, qs, g, nd, slot, qhdr, qglobal, o);
+        Gather<NK, 1, BF> g;
+        gather_issue<NK, 1, BF>(ix, nd, slot, g);
+        gather_consume<METRIC, NK, 1, BF>(ix, qs, g, nd, slot, qhdr, qglobal, o);
         return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(o[0]), 0));
     };
     // visited test-and-set + in-order compaction of one neighbour row held one id per lane
@@ -437,6 +474,8 @@ struct WaveGeom {
 // per-metric launchers, defined in hvx_hnsw_wave_l2.hip / hvx_hnsw_wave_cos.hip / hvx_hnsw_wave_prof.hip
 hipError_t launch_hnsw_wave_l2(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_cos(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_l2_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_cos_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_prof(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 
 template <typename K> static hipError_t launch_wave_kernel(K kern, const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
@@ -448,24 +487,24 @@ template <typename K> static hipError_t launch_wave_kernel(K kern, const HnswArg
     return hipGetLastError();
 }
 
-template <uint32_t METRIC, int R>
+template <uint32_t METRIC, int R, bool BF>
 static hipError_t launch_wave_nk(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
     switch (a.ix.dim >> 5) {
-    case 4: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 4>, a, b, g, s);
-    case 8: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 8>, a, b, g, s);
-    case 16: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 16>, a, b, g, s);
-    case 24: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 24>, a, b, g, s);
-    case 32: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 32>, a, b, g, s);
-    case 48: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 48>, a, b, g, s);
+    case 4: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 4, BF>, a, b, g, s);
+    case 8: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 8, BF>, a, b, g, s);
+    case 16: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 16, BF>, a, b, g, s);
+    case 24: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 24, BF>, a, b, g, s);
+    case 32: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 32, BF>, a, b, g, s);
+    case 48: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 48, BF>, a, b, g, s);
     default: return hipErrorInvalidValue;
     }
 }
 
-template <uint32_t METRIC>
+template <uint32_t METRIC, bool BF>
 static hipError_t launch_wave_r(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
     const uint32_t need = a.ef + 32u; // beam capacity 64*R must hold ef plus slack for equal-score evictions
-    if (need <= 192) return launch_wave_nk<METRIC, 3>(a, b, g, s);
-    if (need <= 384) return launch_wave_nk<METRIC, 6>(a, b, g, s);
+    if (need <= 192) return launch_wave_nk<METRIC, 3, BF>(a, b, g, s);
+    if (need <= 384) return launch_wave_nk<METRIC, 6, BF>(a, b, g, s);
     return hipErrorInvalidValue;
 }
 

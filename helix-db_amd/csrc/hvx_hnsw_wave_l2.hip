@@ -1,8 +1,8 @@
-// hvx_hnsw_wave_l2.hip -- squared-Euclidean instantiations of the one-wavefront-per-query HNSW kernel.
+// hvx_hnsw_wave_l2.hip -- squared-Euclidean, f32 rows: instantiations of the one-wavefront-per-query HNSW kernel.
 #include "hvx_hnsw_wave.h"
 
 namespace hvx {
 hipError_t launch_hnsw_wave_l2(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
-    return launch_wave_r<kL2>(a, b, g, s);
+    return launch_wave_r<kL2, false>(a, b, g, s);
 }
 } // namespace hvx

@@ -4,7 +4,7 @@
 
 namespace hvx {
 hipError_t launch_hnsw_wave_prof(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
-    if (a.ix.metric != kL2 || (a.ix.dim >> 5) != 24 || a.ef + 32u > 192u) return hipErrorInvalidValue;
-    return launch_wave_kernel(hnsw_wave_kernel<kL2, 3, 24, true>, a, b, g, s);
+    if (a.ix.dtype != HVX_F32 || a.ix.metric != kL2 || (a.ix.dim >> 5) != 24 || a.ef + 32u > 192u) return hipErrorInvalidValue;
+    return launch_wave_kernel(hnsw_wave_kernel<kL2, 3, 24, false, true>, a, b, g, s);
 }
 } // namespace hvx

@@ -39,6 +39,10 @@ hipError_t launch_validate_queries(const DevIndex &ix, const float *d_queries, u
 hipError_t launch_validate_rows(const DevIndex &ix, uint32_t n, float limit, uint32_t *d_status, float *d_hdr,
                                 hipStream_t s);
 
+// bf16 row storage (hvx_dtype.hip): round an f32 staging copy in place, then pack it interleaved
+hipError_t launch_round_bf16_inplace(float *v, size_t count, hipStream_t s);
+hipError_t launch_pack_bf16(const float *staging, uint16_t *dst, uint32_t n, uint32_t dim, hipStream_t s);
+
 // exact distance matrix tile + exact top-k selection (flat scan / restricted exact scan)
 struct FlatArgs {
     DevIndex ix;

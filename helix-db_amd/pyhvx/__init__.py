@@ -18,6 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libhelix_vec_gfx950.so")
 
 COSINE, EUCLIDEAN, MANHATTAN = 0, 1, 2
+F32, BF16, FP8_E4M3 = 0, 1, 2
 KERNEL_SCALAR, KERNEL_AVX, KERNEL_AVX_FMA = 0, 2, 3
 OK, ERR_DIMENSION, ERR_NONFINITE, ERR_ZERO_NORM, ERR_MAGNITUDE, ERR_K_RANGE, ERR_CANDIDATE_LIMIT, \
     ERR_DEVICE, ERR_INVARIANT, ERR_UNSUPPORTED = range(10)
@@ -171,7 +172,7 @@ class ValidatedVectorReadIndex:
     @classmethod
     def managed(cls, *, dim, metric, node_ids, vectors, l0_offsets, l0_neighbors, level=None,
                 up_offsets=None, up_neighbors=None, entry_point=None, max_layer=0, m=16, m0=32,
-                float_kernel=KERNEL_AVX_FMA, device=-1, max_batch=1024):
+                float_kernel=KERNEL_AVX_FMA, device=-1, max_batch=1024, dtype=F32):
         ids = np.ascontiguousarray(node_ids, dtype=np.uint64)
         vec = np.ascontiguousarray(vectors, dtype=np.float32).reshape(ids.size, dim) if ids.size else np.zeros((0, dim), np.float32)
         o0 = np.ascontiguousarray(l0_offsets, dtype=np.uint64)
@@ -179,7 +180,7 @@ class ValidatedVectorReadIndex:
         lv = None if level is None else np.ascontiguousarray(level, dtype=np.uint16)
         uo = None if up_offsets is None else np.ascontiguousarray(up_offsets, dtype=np.uint64)
         un = None if up_neighbors is None else np.ascontiguousarray(up_neighbors, dtype=np.uint64)
-        d = _Desc(dim=dim, metric=metric, dtype=0, float_kernel=float_kernel, n=ids.size, m=m, m0=m0,
+        d = _Desc(dim=dim, metric=metric, dtype=dtype, float_kernel=float_kernel, n=ids.size, m=m, m0=m0,
                   has_entry=0 if entry_point is None else 1, max_layer=max_layer,
                   entry_point=0 if entry_point is None else int(entry_point),
                   shard_id_lo=int(ids[0]) if ids.size else 0, shard_id_hi=int(ids[-1]) if ids.size else 0,

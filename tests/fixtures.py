@@ -124,3 +124,11 @@ def merge_topk_reference(ids, scores, counts, k):
             out_i[q, t] = i
             out_s[q, t] = np.float32(sc)
     return out_i, out_s, out_c
+
+
+def round_bf16(x: np.ndarray) -> np.ndarray:
+    """f32 -> nearest bf16 (ties to even) -> f32: the values a bf16-stored index holds."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    lsb = (u >> np.uint64(16)) & np.uint64(1)
+    r = ((u + np.uint64(0x7FFF) + lsb) >> np.uint64(16)) << np.uint64(16)
+    return (r & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.float32).reshape(np.shape(x))

@@ -386,3 +386,26 @@ def test_merge_topk_device_matches_candidate_order(orc, hv):
     for q in range(b):
         assert got_i[q, :r_cnt[q]].tolist() == r_ids[q, :r_cnt[q]].tolist()
         assert bits(got_s[q, :r_cnt[q]]).tolist() == bits(r_sc[q, :r_cnt[q]]).tolist()
+
+
+@pytest.mark.parametrize("n,dim,metric,ef,k", [(1500, 128, 1, 128, 10), (1200, 768, 1, 128, 10), (1200, 256, 0, 100, 10),
+                                               (2000, 128, 1, 300, 20)])
+def test_hnsw_bf16_rows_bit_exact_vs_oracle_on_rounded_vectors(orc, hv, n, dim, metric, ef, k):
+    """BASELINE config #4 storage: rows rounded to bf16 once at import; distances in f32 on the rounded
+    values in the reference's summation order == the oracle run on the rounded vectors, bit for bit."""
+    rng = np.random.default_rng(500 + dim)
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    rounded = fx.round_bf16(data)
+    assert not np.array_equal(rounded, data)
+    lv = fx.draw_levels(n, 16, seed=dim + 5)
+    oix = build_oracle(orc, rounded, metric, lv, efc=80)
+    ex = oix.export()
+    ex["vectors"] = data  # the device does the rounding
+    gix = hv.ValidatedVectorReadIndex.from_export(ex, dim=dim, metric=metric, dtype=hv.BF16)
+    q = rng.standard_normal((24, dim)).astype(np.float32)  # queries stay f32
+    assert_hnsw_equal(orc, hv, oix, gix, q, k, ef)
+    with pytest.raises(hv.HelixDbError) as e:  # shapes the bf16 kernel does not serve fail loudly
+        hv.ValidatedVectorReadIndex.managed(dim=40, metric=metric, node_ids=np.arange(4, dtype=np.uint64),
+                                            vectors=np.ones((4, 40), np.float32), l0_offsets=np.zeros(5, np.uint64),
+                                            l0_neighbors=np.zeros(0, np.uint64), dtype=hv.BF16)
+    assert e.value.status == hv.ERR_UNSUPPORTED

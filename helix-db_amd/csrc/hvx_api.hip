@@ -406,7 +406,7 @@ static int enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t
             for (uint32_t i = 0; i < b; ++i)
                 for (int j = 0; j < 8; ++j) acc[j] += (double)h[(size_t)i * 8 + j];
             fprintf(stderr, "[hvx prof] per query: row-wait %.0f  visited %.0f  gather+fma %.0f  predict %.0f  admit %.0f  (layer-0 loop %.0f) cycles;"
-                            " wide-frontier expansions %.1f  row-prefetch hits %.1f\n",
+                            " fresh-candidate predictions %.1f  row-prefetch hits %.1f\n",
                     acc[0] / b, acc[1] / b, acc[2] / b, acc[3] / b, acc[4] / b, acc[7] / b, acc[5] / b, acc[6] / b);
         }
     } else {

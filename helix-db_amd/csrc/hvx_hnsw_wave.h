@@ -114,8 +114,8 @@ template <int NK, int P, bool BF> struct Gather {
 // Straight-line issue of every load of a pass.  Groups without a row of their own are pointed at
 // another group's row by the caller (identical addresses coalesce inside the load instruction): no
 // divergence, nothing for the compiler to sink behind a branch.
-template <int NK, int P, bool BF>
-__device__ __forceinline__ void gather_issue(const DevIndex &ix, const uint32_t (&node)[P], int slot, Gather<NK, P, BF> &g) {
+template <int NK, int P, bool BF, int PMAX = P>
+__device__ __forceinline__ void gather_issue(const DevIndex &ix, const uint32_t (&node)[P], int slot, Gather<NK, PMAX, BF> &g) {
     constexpr int NL = BF ? NK / 2 : NK;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -140,8 +140,8 @@ template <uint32_t METRIC> __device__ __forceinline__ void fma_chunk(float4 &acc
 
 // FMAs in the host SIMD order against the query staged in LDS (conflict-free: the 8 lanes of a group
 // read 128 contiguous bytes, the 8 groups broadcast), then the AVX reduction tree.
-template <uint32_t METRIC, int NK, int P, bool BF>
-__device__ __forceinline__ void gather_consume(const DevIndex &ix, const float *qs, const Gather<NK, P, BF> &g,
+template <uint32_t METRIC, int NK, int P, bool BF, int PMAX = P>
+__device__ __forceinline__ void gather_consume(const DevIndex &ix, const float *qs, const Gather<NK, PMAX, BF> &g,
                                                const uint32_t (&node)[P], int slot, float qhdr,
                                                const float *qglobal, float (&out)[P]) {
     float4 acc[P];
@@ -381,7 +381,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         st_dc += nf;
         score_frontier(nf);
         tick(2, true); // row gathers + FMAs
-        if (PROF) pt[5] += nf > 16u * P ? 1 : 0;
         const float d_l = (uint32_t)lane < nf ? fr_d[lane] : inf;
         const uint32_t id_l = (uint32_t)lane < nf ? fr_id[lane] : kSentinel;
         __syncthreads();
@@ -396,8 +395,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             uint32_t pred = kSentinel;
             float s2 = inf;
             if (p2 < S.count) { pred = S.id_at(p2); s2 = S.score_at(p2); }
-            if (kmin != 0xFFFFFFFFu && __uint_as_float(kmin) < s2)
+            if (kmin != 0xFFFFFFFFu && __uint_as_float(kmin) < s2) {
                 pred = __builtin_amdgcn_readlane(id_l, (uint32_t)__builtin_ctzll(__ballot(key == kmin)));
+                if (PROF) pt[5] += 1; // the predicted next pop is a candidate discovered by THIS expansion
+            }
             pf_id = pred;
             if (pred != kSentinel)
                 pf_row = (uint32_t)lane < ix.s0 ? ix.l0[(size_t)pred * ix.s0 + (uint32_t)lane] : kSentinel;
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
     if (PROF && a.prof && lane == 0) {
         // cycles: [0] pop+row wait [1] visited [2] gather wait+FMA [3] predict [4] admit [7] whole layer-0 loop;
-        // counts: [5] expansions with more than 16P fresh rows [6] row-prefetch hits
+        // counts: [5] predictions that chose a fresh candidate [6] row-prefetch hits
         pt[7] = __builtin_readcyclecounter() - t_begin;
         for (int i = 0; i < 8; ++i) a.prof[(size_t)q * 8 + i] = pt[i];
     }

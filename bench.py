@@ -184,6 +184,14 @@ def main():
     f_cnt = torch.zeros(b, dtype=torch.int32, device=dev)
     f_st = torch.zeros(b, dtype=torch.int32, device=dev)
     flat_stats = ix_truth.flat_search_batch_device(q, k, f_ids, f_sc, f_cnt, f_st, want_stats=True)
+    mfma_flat_ms = None
+    if bf16:  # the bf16 index's own exact scan (matrix cores + re-rank + certificate) must give the same answer
+        g_ids2 = torch.zeros_like(f_ids); g_sc2 = torch.zeros_like(f_sc); g_cnt2 = torch.zeros_like(f_cnt); g_st2 = torch.zeros_like(f_st)
+        st2 = ix.flat_search_batch_device(q, k, g_ids2, g_sc2, g_cnt2, g_st2, want_stats=True)
+        torch.cuda.synchronize()
+        assert bool((g_ids2 == f_ids).all()) and bool((g_sc2.view(torch.int32) == f_sc.view(torch.int32)).all()), \
+            "bf16 MFMA exact scan differs from the f32-kernel exact scan over the rounded rows"
+        mfma_flat_ms = round(st2["device_ms"], 3)
     if world > 1:
         truth = exchange_and_merge(f_ids, f_sc, f_cnt)[0].clone()
         got = exchange_and_merge(d_ids, d_sc, d_cnt)[0].clone()
@@ -232,6 +240,7 @@ def main():
         "shard_searches_per_s": round(qps * world, 1),
         "roofline": roofline,
         "flat_scan_ms": round(flat_stats["device_ms"], 3),
+        "flat_scan_mfma_bf16_ms": mfma_flat_ms,
     }
 
     # ---- CPU baseline + bit-exact verification (rank 0, N=1 only) ----

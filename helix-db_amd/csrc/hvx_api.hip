@@ -298,6 +298,16 @@ extern "C" int hvx_index_import(const hvx_index_desc *desc, const uint64_t *node
         if (e != hipSuccess) return bail(fail(HVX_ERR_DEVICE, "bf16 packing: %s", hipGetErrorString(e)));
         d.vecb = (const uint16_t *)pb;
         d.vec = nullptr;
+        // |x|^2 per row and its maximum: score term and error bound of the MFMA exact scan
+        if ((rc = ix->dalloc((void **)&ix->m_rowterm, std::max<size_t>(n, 1) * 4))) return bail(rc);
+        if (n) {
+            std::vector<float> h_n2(n);
+            e = launch_bf16_row_norm2(d.vecb, (uint32_t)n, d.dim, ix->m_rowterm, ix->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(h_n2.data(), ix->m_rowterm, n * 4, hipMemcpyDeviceToHost, ix->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+            if (e != hipSuccess) return bail(fail(HVX_ERR_DEVICE, "row norms: %s", hipGetErrorString(e)));
+            for (float v : h_n2) ix->m_xmax2 = std::max(ix->m_xmax2, v);
+        }
     }
 
     // ---- per-batch scratch ----
@@ -513,7 +523,10 @@ int hvx::flat_scan_device(hvx_index *ix, const float *d_queries, uint32_t b, uin
                           uint32_t *d_status, bool timed) {
     if (k == 0) return fail(HVX_ERR_K_RANGE, "result count must be non-zero");
     if (k > 1024) return fail(HVX_ERR_UNSUPPORTED, "flat scan supports k <= 1024");
-    if (ix->dev.dtype != HVX_F32) return fail(HVX_ERR_UNSUPPORTED, "exact scan over bf16 rows is not built yet");
+    if (ix->dev.dtype == HVX_BF16) {
+        if (d_subset) return fail(HVX_ERR_UNSUPPORTED, "restricted scans over bf16 rows are not built yet");
+        return flat_mfma_device(ix, d_queries, b, k, d_ids, d_scores, d_counts, d_status, timed);
+    }
     // chunk the scan so the distance workspace stays <= 256 MiB
     uint32_t chunk = 65536;
     while ((size_t)chunk * b * 4 > (256u << 20) && chunk > 256) chunk >>= 1;

@@ -1,0 +1,377 @@
+// hvx_flat_mfma.hip -- exact scan over bf16 rows as a dense batched-query x corpus contraction on the
+// matrix cores (BASELINE configs #4/#5: "MFMA GEMM path only for the brute-force flat scan").
+//
+// Semantics are still restricted_exact_scan (crates/db/src/search/vector/restricted.rs:753-835): the k
+// smallest (score, id) pairs, scores produced by D::distance in the host kernel's summation order.  An
+// MFMA sums in a different order, so the pipeline is candidate generation + exact re-rank + certificate:
+//   1. queries are split into bf16 hi + lo parts (residual <= 2^-18 |q|) in the rows' interleaved layout
+//      (a dot product does not care about the permutation as long as both operands use it);
+//   2. `flat_mfma_bf16_kernel`: 128 queries x 128 rows per workgroup, v_mfma_f32_32x32x16_bf16,
+//      acc += q_hi.x + q_lo.x, epilogue turns the dot product into the metric's score and writes one
+//      chunk of the [b][rows] score matrix;
+//   3. the exact top-(m+1) by approximate score per query is kept (flat_select_kernel, m = max(64, 2k));
+//   4. `rerank_kernel`: one wavefront per query re-scores those candidates with the reference's
+//      summation order (the same gather/FMA code as the HNSW kernel), sorts by (score, id), keeps k;
+//   5. certificate: every row that was NOT re-scored has approximate score >= t (the (m+1)-th), hence a
+//      reference-order score >= t - E; if the k-th exact score is < t - E the answer is provably the
+//      exact scan's.  E bounds the bf16 split residual plus the f32 accumulation error of both orders.
+//      Queries that fail are re-run with m = 1023; if that fails too they are reported, never guessed.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "hvx_hnsw_wave.h"
+#include "hvx_host.h"
+
+using namespace hvx;
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) return fail(HVX_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+namespace hvx {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// ---- per-row term of the approximate score: |x|^2 for L2 (cosine uses the norm header) ----
+__global__ __launch_bounds__(64) void bf16_row_norm2_kernel(const uint16_t *rows, uint32_t n, uint32_t dim, float *out) {
+    const uint32_t r = blockIdx.x;
+    if (r >= n) return;
+    const uint16_t *p = rows + (size_t)r * dim;
+    double acc = 0.0;
+    for (uint32_t i = threadIdx.x; i < dim; i += 64) {
+        const double v = (double)bf16_to_f32(p[i]);
+        acc += v * v;
+    }
+    for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s, 64);
+    if (threadIdx.x == 0) out[r] = (float)acc;
+}
+
+// ---- queries: f32 -> bf16 hi + lo in the interleaved layout, padded with zero rows; |q|^2 ----
+__global__ __launch_bounds__(64) void split_queries_kernel(const float *q, uint32_t b, uint32_t bpad, uint32_t dim,
+                                                           uint16_t *qhi, uint16_t *qlo, float *qn2) {
+    const uint32_t r = blockIdx.x;
+    if (r >= bpad) return;
+    double acc = 0.0;
+    for (uint32_t i = threadIdx.x; i < dim; i += 64) {
+        float v = r < b ? q[(size_t)r * dim + i] : 0.f;
+        if (!f32_is_finite(v)) v = 0.f; // rejected queries are masked by their status; keep the GEMM finite
+        const uint16_t h = f32_to_bf16_rne(v);
+        const float res = v - bf16_to_f32(h);
+        const uint32_t s = bf16_slot_of(i);
+        qhi[(size_t)r * dim + s] = h;
+        qlo[(size_t)r * dim + s] = f32_to_bf16_rne(res);
+        acc += (double)v * (double)v;
+    }
+    for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s, 64);
+    if (threadIdx.x == 0 && r < b) qn2[r] = (float)acc;
+}
+
+// ---- the contraction ----
+constexpr int kBM = 128, kBN = 128, kBK = 32; // queries x rows x depth per stage
+constexpr int kLdsStride = kBK * 2 + 16;      // bytes per tile row: 64 B of data + 16 B pad => conflict-free ds_read_b128
+
+struct MfmaArgs {
+    const uint16_t *qhi, *qlo; // [bpad][dim]
+    const uint16_t *rows;      // [n][dim]
+    const float *rowterm;      // [n]: |x|^2 (L2) or |x| (cosine)
+    const float *qn2;          // [b]
+    uint32_t dim, b, row0, nrows, metric;
+    float *dist;               // [b][chunk_ld]
+    uint32_t chunk_ld;
+};
+
+__global__ __launch_bounds__(256) void flat_mfma_bf16_kernel(MfmaArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * kBM * kLdsStride]; // A_hi | A_lo | B
+    unsigned char *sAh = lds, *sAl = lds + kBM * kLdsStride, *sB = lds + 2 * kBM * kLdsStride;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1; // 64x64 sub-tile of the wave
+    const uint32_t q0 = blockIdx.y * kBM, r0 = blockIdx.x * kBN;
+    // staging: thread owns 16 bytes (8 bf16) of tile rows sr and sr+64, depth chunk sc
+    const int sr = tid >> 2, sc = tid & 3;
+    const uint32_t rowA0 = q0 + sr, rowA1 = q0 + sr + 64; // queries are padded to a multiple of 128
+    uint32_t rowB0 = r0 + sr, rowB1 = r0 + sr + 64;
+    if (rowB0 >= a.nrows) rowB0 = a.nrows - 1; // clamp: duplicates are masked in the epilogue
+    if (rowB1 >= a.nrows) rowB1 = a.nrows - 1;
+    const uint16_t *gAh0 = a.qhi + (size_t)rowA0 * a.dim + sc * 8, *gAh1 = a.qhi + (size_t)rowA1 * a.dim + sc * 8;
+    const uint16_t *gAl0 = a.qlo + (size_t)rowA0 * a.dim + sc * 8, *gAl1 = a.qlo + (size_t)rowA1 * a.dim + sc * 8;
+    const uint16_t *gB0 = a.rows + ((size_t)a.row0 + rowB0) * a.dim + sc * 8, *gB1 = a.rows + ((size_t)a.row0 + rowB1) * a.dim + sc * 8;
+    const int so0 = sr * kLdsStride + sc * 16, so1 = (sr + 64) * kLdsStride + sc * 16;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
+
+    // fragment addresses: lane holds 8 consecutive depth values of tile row (lane & 31), depth group lane >> 5
+    const int fr = lane & 31, fk = (lane >> 5) * 16; // byte offset of the lane's 8 bf16 inside a 16-deep step
+    uint4 pAh0 = *reinterpret_cast<const uint4 *>(gAh0), pAh1 = *reinterpret_cast<const uint4 *>(gAh1);
+    uint4 pAl0 = *reinterpret_cast<const uint4 *>(gAl0), pAl1 = *reinterpret_cast<const uint4 *>(gAl1);
+    uint4 pB0 = *reinterpret_cast<const uint4 *>(gB0), pB1 = *reinterpret_cast<const uint4 *>(gB1);
+    for (uint32_t k0 = 0; k0 < a.dim; k0 += kBK) {
+        __syncthreads(); // previous stage fully consumed
+        *reinterpret_cast<uint4 *>(sAh + so0) = pAh0; *reinterpret_cast<uint4 *>(sAh + so1) = pAh1;
+        *reinterpret_cast<uint4 *>(sAl + so0) = pAl0; *reinterpret_cast<uint4 *>(sAl + so1) = pAl1;
+        *reinterpret_cast<uint4 *>(sB + so0) = pB0; *reinterpret_cast<uint4 *>(sB + so1) = pB1;
+        __syncthreads();
+        if (k0 + kBK < a.dim) { // next stage's global loads fly under this stage's MFMAs
+            const uint32_t kn = k0 + kBK;
+            pAh0 = *reinterpret_cast<const uint4 *>(gAh0 + kn); pAh1 = *reinterpret_cast<const uint4 *>(gAh1 + kn);
+            pAl0 = *reinterpret_cast<const uint4 *>(gAl0 + kn); pAl1 = *reinterpret_cast<const uint4 *>(gAl1 + kn);
+            pB0 = *reinterpret_cast<const uint4 *>(gB0 + kn); pB1 = *reinterpret_cast<const uint4 *>(gB1 + kn);
+        }
+#pragma unroll
+        for (int kk = 0; kk < kBK / 16; ++kk) {
+            bf16x8 fah[2], fal[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int off = (wm * 64 + i * 32 + fr) * kLdsStride + kk * 32 + fk;
+                fah[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sAh + off));
+                fal[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sAl + off));
+            }
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+                const int off = (wn * 64 + jn * 32 + fr) * kLdsStride + kk * 32 + fk;
+                fb[jn] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sB + off));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) {
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fb[jn], acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fb[jn], acc[i][jn], 0, 0, 0);
+                }
+        }
+    }
+    // epilogue: C[m = query][n = row]; lane holds n = lane & 31, m = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) {
+        const uint32_t rloc = r0 + wn * 64 + jn * 32 + (lane & 31);
+        if (rloc >= a.nrows) continue;
+        const float term = a.rowterm[(size_t)a.row0 + rloc];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t qq = q0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (qq >= a.b) continue;
+                const float dot = acc[i][jn][e];
+                float s;
+                if (a.metric == kL2) {
+                    s = (a.qn2[qq] + term) - 2.0f * dot;
+                    s = s < 0.f ? 0.f : s;
+                } else {
+                    const float den = sqrtf(a.qn2[qq]) * term;
+                    float c = den > 0.f ? dot / den : 0.f;
+                    c = c < -1.f ? -1.f : (c > 1.f ? 1.f : c);
+                    s = (1.0f - c) * 0.5f;
+                }
+                a.dist[(size_t)qq * a.chunk_ld + rloc] = s;
+            }
+    }
+}
+
+// ---- exact re-rank: one wavefront per query, candidates scored in the reference's summation order ----
+struct RerankArgs {
+    DevIndex ix;
+    const float *queries;     // [b][dim] f32
+    const uint32_t *qstatus;  // [b]
+    const float *qhdr;        // [b]
+    const float *qn2;         // [b]
+    const float *cand_scores; // [b][kc] approximate scores, ascending
+    const uint32_t *cand_ids; // [b][kc] internal ids
+    const uint32_t *cand_counts; // [b]
+    uint32_t kc, k, m;        // kc = m + 1 slots; results k
+    float xmax2;              // max |x|^2 over the rows
+    uint64_t *out_ids;
+    float *out_scores;
+    uint32_t *out_counts, *out_status;
+    uint32_t *cert;           // [b] 1 = proven exact, 0 = needs a wider candidate set
+};
+
+template <uint32_t METRIC, int NK>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void rerank_bf16_kernel(RerankArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int P = 2; // 16 rows per pass
+    const DevIndex &ix = a.ix;
+    const uint32_t q = blockIdx.x;
+    const int lane = (int)threadIdx.x, grp = lane >> 3, j = lane & 7, slot = chunk_slot(j);
+    float *qs = reinterpret_cast<float *>(smem);                     // [dim]
+    float *ss = qs + (size_t)NK * 32;                                // [1024] exact scores
+    uint32_t *si = reinterpret_cast<uint32_t *>(ss + 1024);          // [1024] ids
+    const uint32_t st = a.qstatus[q];
+    if (st != 0u) {
+        if (lane == 0) { a.out_counts[q] = 0; if (a.out_status) a.out_status[q] = st; a.cert[q] = 1u; }
+        return;
+    }
+    const float *qglobal = a.queries + (size_t)q * ix.dim;
+    for (uint32_t i = (uint32_t)lane; i < (uint32_t)NK * 8u; i += 64)
+        reinterpret_cast<float4 *>(qs)[i] = reinterpret_cast<const float4 *>(qglobal)[i];
+    const uint32_t nc = a.cand_counts[q];
+    const float inf = __uint_as_float(0x7F800000u);
+    for (uint32_t i = (uint32_t)lane; i < 1024u; i += 64) {
+        ss[i] = inf;
+        si[i] = i < nc ? a.cand_ids[(size_t)q * a.kc + i] : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    const float qhdr = a.qhdr[q];
+    bool bad = false;
+    for (uint32_t f0 = 0; f0 < nc; f0 += 8u * P) {
+        uint32_t nd[P];
+        float o[P];
+        Gather<NK, P, true> g;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const uint32_t f = f0 + (uint32_t)(p * 8 + grp);
+            nd[p] = si[f < nc ? f : f0];
+        }
+        gather_issue<NK, P, true>(ix, nd, slot, g);
+        gather_consume<METRIC, NK, P, true>(ix, qs, g, nd, slot, qhdr, qglobal, o);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const uint32_t f = f0 + (uint32_t)(p * 8 + grp);
+            float d = o[p];
+            if (f < nc) {
+                if (!score_valid(d)) bad = true;
+                if (j == 0) ss[f] = d;
+            }
+        }
+    }
+    if (__ballot(bad)) { // Candidate::try_new rejects the score (model.rs:21-29)
+        if (lane == 0) { a.out_counts[q] = 0; if (a.out_status) a.out_status[q] = 8u; a.cert[q] = 1u; }
+        return;
+    }
+    __syncthreads();
+    // bitonic sort of 1024 (score, id) pairs by one wavefront
+    for (int size = 2; size <= 1024; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = lane; t < 512; t += 64) {
+                const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const float sl = ss[lo], sh = ss[hi];
+                const uint32_t il = si[lo], ih = si[hi];
+                const bool lt = sh < sl || (sh == sl && ih < il); // hi before lo
+                const bool gt = sl < sh || (sl == sh && il < ih);
+                if (up ? lt : gt) { ss[lo] = sh; ss[hi] = sl; si[lo] = ih; si[hi] = il; }
+            }
+            __syncthreads();
+        }
+    const uint32_t outn = nc < a.k ? nc : a.k;
+    for (uint32_t t = (uint32_t)lane; t < outn; t += 64) {
+        a.out_ids[(size_t)q * a.k + t] = ix.ids[si[t]];
+        a.out_scores[(size_t)q * a.k + t] = ss[t];
+    }
+    if (lane == 0) {
+        a.out_counts[q] = outn;
+        if (a.out_status) a.out_status[q] = 0u;
+        // certificate (see the file header).  nc <= m: every row of the scan was re-scored.
+        uint32_t ok = 1u;
+        if (nc > a.m) {
+            const float t = a.cand_scores[(size_t)q * a.kc + (nc - 1)];
+            const float e = METRIC == kL2 ? 1.0e-3f * 0.5f * (a.qn2[q] + a.xmax2) : 1.0e-3f;
+            const float kth = outn ? ss[outn - 1] : inf;
+            ok = (outn == a.k && kth < t - e) ? 1u : 0u;
+        }
+        a.cert[q] = ok;
+    }
+}
+
+template <uint32_t METRIC>
+static hipError_t launch_rerank(const RerankArgs &a, uint32_t b, hipStream_t s) {
+    const size_t lds = (size_t)a.ix.dim * 4 + 8192;
+    switch (a.ix.dim >> 5) {
+#define HVX_RR(N) case N: hipLaunchKernelGGL((rerank_bf16_kernel<METRIC, N>), dim3(b), dim3(64), lds, s, a); break;
+        HVX_RR(4) HVX_RR(8) HVX_RR(16) HVX_RR(24) HVX_RR(32) HVX_RR(48)
+#undef HVX_RR
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_bf16_row_norm2(const uint16_t *rows, uint32_t n, uint32_t dim, float *out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(bf16_row_norm2_kernel, dim3(n), dim3(64), 0, s, rows, n, dim, out);
+    return hipGetLastError();
+}
+
+// scan all rows of a bf16 index for b device-resident queries (see the file header)
+int flat_mfma_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, uint64_t *d_ids, float *d_scores,
+                     uint32_t *d_counts, uint32_t *d_status, bool timed) {
+    const DevIndex &d = ix->dev;
+    const uint32_t n = d.n;
+    if (k == 0) return fail(HVX_ERR_K_RANGE, "result count must be non-zero");
+    if (k > 511) return fail(HVX_ERR_UNSUPPORTED, "bf16 exact scan supports k <= 511");
+    const uint32_t nk = d.dim >> 5;
+    if (nk != 4 && nk != 8 && nk != 16 && nk != 24 && nk != 32 && nk != 48)
+        return fail(HVX_ERR_UNSUPPORTED, "bf16 exact scan serves dim in {128,256,512,768,1024,1536}");
+    HIP_TRY(launch_validate_queries(d, d_queries, b, ix->limit, ix->d_qstatus, ix->d_qhdr, ix->stream));
+    if (n == 0) {
+        HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)b * 4, ix->stream));
+        if (d_status) HIP_TRY(hipMemcpyAsync(d_status, ix->d_qstatus, (size_t)b * 4, hipMemcpyDeviceToDevice, ix->stream));
+        return HVX_OK;
+    }
+    const uint32_t bpad = (b + kBM - 1) / kBM * kBM;
+    int rc;
+    if ((size_t)bpad * d.dim > ix->cap_qsplit) {
+        if ((rc = ix->dalloc((void **)&ix->m_qhi, (size_t)bpad * d.dim * 2))) return rc;
+        if ((rc = ix->dalloc((void **)&ix->m_qlo, (size_t)bpad * d.dim * 2))) return rc;
+        if ((rc = ix->dalloc((void **)&ix->m_qn2, (size_t)bpad * 4))) return rc;
+        if ((rc = ix->dalloc((void **)&ix->m_cert, (size_t)bpad * 4))) return rc;
+        ix->cap_qsplit = (size_t)bpad * d.dim;
+    }
+    hipLaunchKernelGGL(split_queries_kernel, dim3(bpad), dim3(64), 0, ix->stream, d_queries, b, bpad, d.dim, ix->m_qhi, ix->m_qlo, ix->m_qn2);
+    HIP_TRY(hipGetLastError());
+    if (timed) HIP_TRY(hipEventRecord(ix->ev0, ix->stream));
+    uint32_t m = std::max<uint32_t>(64u, 2u * k);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const uint32_t kc = m + 1;
+        uint32_t chunk = 65536;
+        while ((size_t)chunk * b * 4 > (512u << 20) && chunk > 1024) chunk >>= 1;
+        if (chunk > n) chunk = (n + 3u) & ~3u;
+        if ((rc = ix->flat_scratch(b, kc, chunk))) return rc;
+        HIP_TRY(hipMemsetAsync(ix->f_top_c, 0, (size_t)b * 4, ix->stream));
+        FlatArgs fa;
+        fa.ix = d; fa.queries = d_queries; fa.qstatus = ix->d_qstatus; fa.qhdr = ix->d_qhdr; fa.subset = nullptr;
+        fa.n_rows = n; fa.dist = ix->f_dist; fa.chunk_ld = chunk; fa.b = b; fa.k = kc;
+        fa.top_scores = ix->f_top_s; fa.top_ids = ix->f_top_i; fa.top_counts = ix->f_top_c;
+        MfmaArgs ma;
+        ma.qhi = ix->m_qhi; ma.qlo = ix->m_qlo; ma.rows = d.vecb; ma.rowterm = d.metric == kL2 ? ix->m_rowterm : d.hdr;
+        ma.qn2 = ix->m_qn2; ma.dim = d.dim; ma.b = b; ma.metric = d.metric; ma.dist = ix->f_dist; ma.chunk_ld = chunk;
+        for (uint32_t r0 = 0; r0 < n; r0 += chunk) {
+            const uint32_t rows = std::min(chunk, n - r0);
+            ma.row0 = r0; ma.nrows = rows;
+            hipLaunchKernelGGL(flat_mfma_bf16_kernel, dim3((rows + kBN - 1) / kBN, bpad / kBM), dim3(256), 0, ix->stream, ma);
+            HIP_TRY(hipGetLastError());
+            fa.row0 = r0; fa.rows = rows;
+            HIP_TRY(launch_flat_select(fa, ix->stream));
+        }
+        RerankArgs ra;
+        ra.ix = d; ra.queries = d_queries; ra.qstatus = ix->d_qstatus; ra.qhdr = ix->d_qhdr; ra.qn2 = ix->m_qn2;
+        ra.cand_scores = ix->f_top_s; ra.cand_ids = ix->f_top_i; ra.cand_counts = ix->f_top_c; ra.kc = kc; ra.k = k; ra.m = m;
+        ra.xmax2 = ix->m_xmax2; ra.out_ids = d_ids; ra.out_scores = d_scores; ra.out_counts = d_counts; ra.out_status = d_status;
+        ra.cert = ix->m_cert;
+        HIP_TRY(d.metric == kL2 ? launch_rerank<kL2>(ra, b, ix->stream) : launch_rerank<kCosine>(ra, b, ix->stream));
+        if (timed && attempt == 0) HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
+        std::vector<uint32_t> cert(b);
+        HIP_TRY(hipMemcpyAsync(cert.data(), ix->m_cert, (size_t)b * 4, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipStreamSynchronize(ix->stream));
+        uint32_t failed = 0, first = 0;
+        for (uint32_t i = 0; i < b; ++i)
+            if (!cert[i]) { if (!failed) first = i; ++failed; }
+        if (!failed) return HVX_OK;
+        if (m >= 1023u)
+            return fail(HVX_ERR_INVARIANT, "exact-scan certificate failed for %u queries (first %u): more than 1023 rows within the "
+                        "error bound of the k-th score", failed, first);
+        m = 1023u; // widen: the select pool holds 2048 entries
+    }
+    return fail(HVX_ERR_INVARIANT, "exact-scan certificate failed after widening");
+}
+
+} // namespace hvx

@@ -40,6 +40,12 @@ struct hvx_index {
     uint32_t *f_top_i = nullptr, *f_top_c = nullptr, *f_subset = nullptr;
     size_t cap_dist = 0, cap_top = 0, cap_subset = 0;
     uint32_t cap_topc = 0;
+    // bf16 exact scan on the matrix cores (hvx_flat_mfma.hip)
+    uint16_t *m_qhi = nullptr, *m_qlo = nullptr;
+    float *m_qn2 = nullptr, *m_rowterm = nullptr; // |q|^2 per query; |x|^2 per row
+    uint32_t *m_cert = nullptr;
+    size_t cap_qsplit = 0;
+    float m_xmax2 = 0.f;
 
     int dalloc(void **p, size_t bytes);
     int stage(uint32_t b, uint32_t k);
@@ -63,6 +69,9 @@ float component_limit(uint32_t metric, uint32_t dim);
 int flat_scan_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, const uint32_t *d_subset,
                      uint32_t n_rows, uint64_t *d_ids, float *d_scores, uint32_t *d_counts, uint32_t *d_status,
                      bool timed);
+int flat_mfma_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, uint64_t *d_ids, float *d_scores,
+                     uint32_t *d_counts, uint32_t *d_status, bool timed);
+hipError_t launch_bf16_row_norm2(const uint16_t *rows, uint32_t n, uint32_t dim, float *out, hipStream_t s);
 int flat_scan_host(hvx_index *ix, const float *queries, uint32_t b, uint32_t k, const uint32_t *d_subset,
                    uint32_t n_rows, uint64_t *out_ids, float *out_scores, uint32_t *out_counts,
                    uint32_t *out_status, hvx_stats *stats);

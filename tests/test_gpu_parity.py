@@ -409,3 +409,49 @@ def test_hnsw_bf16_rows_bit_exact_vs_oracle_on_rounded_vectors(orc, hv, n, dim, 
                                             vectors=np.ones((4, 40), np.float32), l0_offsets=np.zeros(5, np.uint64),
                                             l0_neighbors=np.zeros(0, np.uint64), dtype=hv.BF16)
     assert e.value.status == hv.ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("n,dim,metric,k,b", [(5000, 128, 1, 10, 9), (3000, 256, 0, 7, 5), (20000, 768, 1, 100, 130),
+                                              (50, 128, 1, 10, 3), (4000, 512, 0, 10, 17)])
+def test_bf16_exact_scan_on_matrix_cores_is_bit_exact(orc, hv, n, dim, metric, k, b):
+    """Exact scan over bf16 rows = MFMA candidate generation + reference-order re-rank + certificate
+    (hvx_flat_mfma.hip): ids and score bits equal the oracle's exact scan over the rounded vectors."""
+    rng = np.random.default_rng(900 + dim + n)
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    data[7] = data[3]  # exact duplicate row: tie broken by id
+    rounded = fx.round_bf16(data)
+    ids = np.arange(n, dtype=np.uint64) + 11
+    gix = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=metric, node_ids=ids, vectors=data, dtype=hv.BF16,
+                                              l0_offsets=np.zeros(n + 1, np.uint64), l0_neighbors=np.zeros(0, np.uint64),
+                                              max_batch=max(b, 16))
+    q = rng.standard_normal((b, dim)).astype(np.float32)
+    q[0] = data[3]
+    gid, gsc, gcnt, st = gix.flat_search_batch(q, k)
+    for qi in range(b):
+        rc, oid, osc = orc.flat_matrix(metric, rounded, q[qi], k)
+        assert gcnt[qi] == oid.size == min(k, n)
+        assert (gid[qi, :gcnt[qi]] - 11).tolist() == oid.tolist(), f"query {qi}"
+        assert bits(gsc[qi, :gcnt[qi]]).tolist() == bits(osc).tolist()
+    assert gid[0, :2].tolist() == [14, 18]
+
+
+def test_bf16_exact_scan_never_guesses_on_dense_near_ties(orc, hv):
+    """2000 rows within the error bound of each other: the certificate cannot be issued with 64
+    candidates; the widened pass (1023) or a loud error are the only acceptable outcomes."""
+    n, dim = 3000, 128
+    rng = np.random.default_rng(5)
+    base = rng.standard_normal(dim).astype(np.float32)
+    data = np.tile(base, (n, 1)) + rng.standard_normal((n, dim)).astype(np.float32) * np.float32(1e-3)
+    data[2000:] = rng.standard_normal((n - 2000, dim)).astype(np.float32)
+    rounded = fx.round_bf16(data)
+    ids = np.arange(n, dtype=np.uint64)
+    gix = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=hv.EUCLIDEAN, node_ids=ids, vectors=data, dtype=hv.BF16,
+                                              l0_offsets=np.zeros(n + 1, np.uint64), l0_neighbors=np.zeros(0, np.uint64))
+    q = (base + np.float32(0.01)).reshape(1, dim).astype(np.float32)
+    try:
+        gid, gsc, gcnt, _ = gix.flat_search_batch(q, 10)
+    except hv.HelixDbError as e:
+        assert e.status == hv.ERR_INVARIANT and "certificate" in str(e)
+        return
+    rc, oid, osc = orc.flat_matrix(orc.L2SQ, rounded, q[0], 10)
+    assert gid[0].tolist() == oid.tolist() and bits(gsc[0]).tolist() == bits(osc).tolist()

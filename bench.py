@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--ef", type=int, default=128)
     ap.add_argument("--m", type=int, default=16)
+    ap.add_argument("--mode", default="shard", choices=["shard", "replica"],
+                    help="N>1: 'shard' = id-range shards + all-gather top-k merge (north star); 'replica' = every GPU holds "
+                         "the whole index and answers its own batch (no collective)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="row storage on the device (bf16 = config #4)")
     ap.add_argument("--dataset", default="embedding", choices=["embedding", "gaussian"])
     ap.add_argument("--latent", type=int, default=16)
@@ -85,12 +88,16 @@ def main():
     n, dim, b, k, ef = args.rows, args.dim, args.batch, args.k, args.ef
     t0 = time.time()
     # every rank draws the same global corpus from the same seed and keeps its id-range shard
-    n_total = n * world
+    replica = args.mode == "replica" and world > 1
+    n_total = n if replica else n * world
+    nq_total = b * world if replica else b
     if args.dataset == "embedding":
-        xg, q = synth.embedding_like(n_total, dim, b, args.seed, dev, latent=args.latent, clusters=args.clusters)
+        xg, q = synth.embedding_like(n_total, dim, nq_total, args.seed, dev, latent=args.latent, clusters=args.clusters)
     else:
-        xg, q = synth.gaussian_sphere(n_total, dim, b, args.seed, dev)
-    id_lo = rank * n
+        xg, q = synth.gaussian_sphere(n_total, dim, nq_total, args.seed, dev)
+    id_lo = 0 if replica else rank * n
+    if replica:  # every rank answers its own batch of held-out queries
+        q = q[rank * b:(rank + 1) * b].contiguous()
     x = xg[id_lo:id_lo + n].contiguous()
     del xg
     torch.cuda.synchronize()
@@ -142,7 +149,7 @@ def main():
     d_cnt = torch.zeros(b, dtype=torch.int32, device=dev)
     d_st = torch.zeros(b, dtype=torch.int32, device=dev)
     d_qst = torch.zeros(b, 4, dtype=torch.int32, device=dev)
-    sharded = shard.ShardedSearcher(ix, world, b, k, dev) if world > 1 else None
+    sharded = shard.ShardedSearcher(ix, world, b, k, dev) if (world > 1 and not replica) else None
 
     def exchange_and_merge(ids_t, sc_t, cnt_t):
         return sharded.merge(ids_t, sc_t, cnt_t)
@@ -153,7 +160,7 @@ def main():
         st = ix.search_batch_device(q, k, ef, d_ids, d_sc, d_cnt, d_st, d_qst, want_stats=True)
         if timed:
             kernel_ms.append(st["device_ms"])
-        if world > 1:
+        if sharded is not None:
             exchange_and_merge(d_ids, d_sc, d_cnt)
         return st
 
@@ -176,7 +183,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed * 1e3 / args.steps
-    qps = b * args.steps / elapsed
+    qps = b * args.steps / elapsed * (world if replica else 1)
 
     # ---- recall@k against the exact scan (bit-exact vs the oracle's flat scan, tests/test_gpu_parity.py) ----
     f_ids = torch.zeros(b, k, dtype=torch.int64, device=dev)
@@ -192,7 +199,7 @@ def main():
         assert bool((g_ids2 == f_ids).all()) and bool((g_sc2.view(torch.int32) == f_sc.view(torch.int32)).all()), \
             "bf16 MFMA exact scan differs from the f32-kernel exact scan over the rounded rows"
         mfma_flat_ms = round(st2["device_ms"], 3)
-    if world > 1:
+    if sharded is not None:
         truth = exchange_and_merge(f_ids, f_sc, f_cnt)[0].clone()
         got = exchange_and_merge(d_ids, d_sc, d_cnt)[0].clone()
     else:
@@ -235,9 +242,10 @@ def main():
         "config": {"workload": f"configs[1]: {n}x{dim} {args.dtype} per GPU, HNSW M={args.m}/M0={2 * args.m} ef_search={ef} k={k}, "
                                f"batch={b} queries, squared-L2, strict-exhaustive beam (bit-exact vs reference CPU path)",
                    "dataset": args.dataset, "rows_per_gpu": n, "rows_total": n_total, "dim": dim, "batch": b, "k": k,
-                   "ef_search": ef, "parallelism": f"id-range shards x{world} + all-gather top-k merge" if world > 1 else "1 GPU"},
+                   "ef_search": ef, "parallelism": ("1 GPU" if world == 1 else f"{world} replicas, one query batch each" if replica
+                                   else f"id-range shards x{world} + all-gather top-k merge")},
         "recall_at_10": round(recall, 4),
-        "shard_searches_per_s": round(qps * world, 1),
+        "shard_searches_per_s": round(qps * (1 if replica else world), 1),
         "roofline": roofline,
         "flat_scan_ms": round(flat_stats["device_ms"], 3),
         "flat_scan_mfma_bf16_ms": mfma_flat_ms,

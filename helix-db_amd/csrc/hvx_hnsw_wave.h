@@ -10,9 +10,9 @@
 //     row, 128 B coalesced per load) is in flight before the first FMA;
 //   * the visited set is an open-addressing hash table in LDS (ds_cmpst, ~100 cycles) instead of an
 //     HBM bitmap (atomicOr round trip); it spills to the exact HBM bitmap if it ever fills;
-//   * the next pop is predicted right after the distances of an expansion are known (best fresh
-//     candidate vs best unexpanded beam entry; right 97.7 % of the time on the 1M x 768 workload) and
-//     its neighbour row is fetched underneath the sequential admission loop;
+//   * the next pop is predicted (right 97.7 % of the time on the 1M x 768 workload): 93 % of pops are the
+//     next unexpanded entry already in the beam, whose neighbour row is requested AHEAD of the expansion's
+//     gathers; if a fresh candidate beats it, that one's row is fetched underneath the admission loop;
 //   * a frontier of up to 8, 16, 24 or 32 rows is gathered with ONE latency: the pass width is chosen per
 //     expansion (1, 2, 3 or 4 x P rows per 8-lane group in flight), because the kernel ends with its
 //     slowest query and the slow queries are the ones with large frontiers (profiles/r01c);
@@ -376,6 +376,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         const uint32_t nf = frontier_from(nid, deg);
         st_nb += deg;
         tick(1, true); // visited test-and-set + compaction
+        // 93 % of the time the next pop is simply the next unexpanded entry already in the beam: its
+        // neighbour row goes out AHEAD of this expansion's gathers and is back together with them
+        const uint32_t p2 = S.first_unexpanded(lane);
+        uint32_t e2 = kSentinel, row2 = kSentinel;
+        float s2 = inf;
+        if (p2 < S.count) {
+            e2 = S.id_at(p2);
+            s2 = S.score_at(p2);
+            row2 = (uint32_t)lane < ix.s0 ? ix.l0[(size_t)e2 * ix.s0 + (uint32_t)lane] : kSentinel;
+        }
+        pf_id = e2;
+        pf_row = row2;
         if (nf == 0) continue;
         st_vl += nf;
         st_dc += nf;
@@ -385,23 +397,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         const uint32_t id_l = (uint32_t)lane < nf ? fr_id[lane] : kSentinel;
         __syncthreads();
         {
-            // predict the next pop (best admissible fresh candidate vs best unexpanded beam entry) and
-            // fetch its neighbour row underneath the admission loop
+            // a fresh candidate of this expansion that beats that entry becomes the prediction instead;
+            // its row is fetched underneath the admission loop
             const uint32_t wl0 = S.count < ef ? S.count : ef;
             const bool adm = ((uint32_t)lane < nf) & ((d_l < wmax) | (wl0 < ef)) & (d_l >= 0.f) & (d_l < inf);
             const uint32_t key = adm ? __float_as_uint(d_l) : 0xFFFFFFFFu;
             const uint32_t kmin = wave_umin(key);
-            const uint32_t p2 = S.first_unexpanded(lane);
-            uint32_t pred = kSentinel;
-            float s2 = inf;
-            if (p2 < S.count) { pred = S.id_at(p2); s2 = S.score_at(p2); }
             if (kmin != 0xFFFFFFFFu && __uint_as_float(kmin) < s2) {
-                pred = __builtin_amdgcn_readlane(id_l, (uint32_t)__builtin_ctzll(__ballot(key == kmin)));
+                const uint32_t pred = __builtin_amdgcn_readlane(id_l, (uint32_t)__builtin_ctzll(__ballot(key == kmin)));
+                pf_id = pred;
+                pf_row = (uint32_t)lane < ix.s0 ? ix.l0[(size_t)pred * ix.s0 + (uint32_t)lane] : kSentinel;
                 if (PROF) pt[5] += 1; // the predicted next pop is a candidate discovered by THIS expansion
             }
-            pf_id = pred;
-            if (pred != kSentinel)
-                pf_row = (uint32_t)lane < ix.s0 ? ix.l0[(size_t)pred * ix.s0 + (uint32_t)lane] : kSentinel;
         }
         tick(3, false); // prediction (the row load stays in flight)
         // admission in row order with the running bound (search.rs:928-952).  Once W is full the

@@ -124,9 +124,10 @@ extern "C" int hvx_index_import(const hvx_index_desc *desc, const uint64_t *node
     *out = nullptr;
     if (desc->dim == 0) return fail(HVX_ERR_DIMENSION, "dimension must be non-zero");
     if (desc->metric > HVX_MANHATTAN) return fail(HVX_ERR_UNSUPPORTED, "unknown metric %u", desc->metric);
-    if (desc->dtype != HVX_F32 && desc->dtype != HVX_BF16)
-        return fail(HVX_ERR_UNSUPPORTED, "device dtype %u not built yet (f32 is the reference's only active codec; bf16 is served)",
-                    desc->dtype);
+    if (desc->dtype != HVX_F32 && desc->dtype != HVX_BF16 && desc->dtype != HVX_FP8_E4M3)
+        return fail(HVX_ERR_UNSUPPORTED, "unknown device dtype %u", desc->dtype);
+    if (desc->dtype == HVX_FP8_E4M3 && (desc->dim % 128u != 0u || desc->float_kernel != HVX_KERNEL_AVX_FMA || desc->metric == HVX_MANHATTAN))
+        return fail(HVX_ERR_UNSUPPORTED, "fp8 rows need dim %% 128 == 0, the AVX+FMA summation tree and an L2/cosine metric");
     if (desc->dtype == HVX_BF16 && (desc->dim % 64u != 0u || desc->float_kernel != HVX_KERNEL_AVX_FMA || desc->metric == HVX_MANHATTAN))
         return fail(HVX_ERR_UNSUPPORTED, "bf16 rows need dim %% 64 == 0, the AVX+FMA summation tree and an L2/cosine metric");
     if (desc->float_kernel != HVX_KERNEL_SCALAR && desc->float_kernel != HVX_KERNEL_AVX &&
@@ -235,9 +236,11 @@ extern "C" int hvx_index_import(const hvx_index_desc *desc, const uint64_t *node
     void *p;
     int rc;
     const size_t vec_bytes = (size_t)n * d.ld * 4;
-    const bool bf16 = desc->dtype == HVX_BF16;
-    float *staging = nullptr; // bf16: temporary f32 copy, rounded in place, validated, packed, freed
-    if (bf16) {
+    const bool bf16 = desc->dtype == HVX_BF16, fp8 = desc->dtype == HVX_FP8_E4M3;
+    float *staging = nullptr; // bf16 / fp8: temporary f32 copy, quantised in place, validated, packed, freed
+    void *fp8_codes = nullptr;
+    float *fp8_scale = nullptr;
+    if (bf16 || fp8) {
         if (hipMalloc((void **)&staging, std::max<size_t>(vec_bytes, 16)) != hipSuccess) return bail(fail(HVX_ERR_DEVICE, "hipMalloc(%zu) staging", vec_bytes));
         p = staging;
     } else if ((rc = ix->dalloc(&p, vec_bytes))) return bail(rc);
@@ -245,15 +248,22 @@ extern "C" int hvx_index_import(const hvx_index_desc *desc, const uint64_t *node
     auto bail_free = [&](int code) { if (staging) (void)hipFree(staging); return bail(code); };
     if (n) {
         if (d.ld == d.dim) {
-            if (hipMemcpy(p, vectors, vec_bytes, hipMemcpyHostToDevice) != hipSuccess) return bail_free(fail(HVX_ERR_DEVICE, "vector upload failed"));
+            // hipMemcpyDefault: `vectors` may be host memory or memory already resident on a device
+            if (hipMemcpy(p, vectors, vec_bytes, hipMemcpyDefault) != hipSuccess) return bail_free(fail(HVX_ERR_DEVICE, "vector upload failed"));
         } else {
             if (hipMemset(p, 0, vec_bytes) != hipSuccess ||
-                hipMemcpy2D(p, (size_t)d.ld * 4, vectors, (size_t)d.dim * 4, (size_t)d.dim * 4, n, hipMemcpyHostToDevice) != hipSuccess)
+                hipMemcpy2D(p, (size_t)d.ld * 4, vectors, (size_t)d.dim * 4, (size_t)d.dim * 4, n, hipMemcpyDefault) != hipSuccess)
                 return bail_free(fail(HVX_ERR_DEVICE, "vector upload failed"));
         }
         // bf16: the index IS the rounded vectors -- validation and cosine headers see the rounded values
         if (bf16 && launch_round_bf16_inplace(staging, (size_t)n * d.ld, ix->stream) != hipSuccess)
             return bail_free(fail(HVX_ERR_DEVICE, "bf16 rounding failed"));
+    }
+    if (fp8) { // quantise now: validation and headers below see the dequantised rows
+        if ((rc = ix->dalloc(&fp8_codes, std::max<size_t>((size_t)n * d.dim, 16)))) return bail_free(rc);
+        if ((rc = ix->dalloc((void **)&fp8_scale, std::max<size_t>(n, 1) * 4))) return bail_free(rc);
+        if (launch_quantize_fp8(staging, (uint8_t *)fp8_codes, fp8_scale, (uint32_t)n, d.dim, ix->stream) != hipSuccess)
+            return bail_free(fail(HVX_ERR_DEVICE, "fp8 quantisation failed"));
     }
     auto upload = [&](const void *src, size_t bytes, const void **dst) -> int {
         void *q;
@@ -308,6 +318,23 @@ extern "C" int hvx_index_import(const hvx_index_desc *desc, const uint64_t *node
             if (e != hipSuccess) return bail(fail(HVX_ERR_DEVICE, "row norms: %s", hipGetErrorString(e)));
             for (float v : h_n2) ix->m_xmax2 = std::max(ix->m_xmax2, v);
         }
+    }
+    if (fp8) {
+        if ((rc = ix->dalloc((void **)&ix->m_rowterm, std::max<size_t>(n, 1) * 4))) return bail_free(rc);
+        hipError_t e = hipSuccess;
+        std::vector<float> h_n2(n);
+        if (n) {
+            e = launch_f32_row_norm2(staging, (uint32_t)n, d.ld, d.dim, ix->m_rowterm, ix->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(h_n2.data(), ix->m_rowterm, n * 4, hipMemcpyDeviceToHost, ix->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+        }
+        (void)hipFree(staging);
+        staging = nullptr;
+        if (e != hipSuccess) return bail(fail(HVX_ERR_DEVICE, "fp8 row norms: %s", hipGetErrorString(e)));
+        for (float v : h_n2) ix->m_xmax2 = std::max(ix->m_xmax2, v);
+        d.vec8 = (const uint8_t *)fp8_codes;
+        d.rowscale = fp8_scale;
+        d.vec = nullptr;
     }
 
     // ---- per-batch scratch ----
@@ -400,7 +427,8 @@ static int enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t
     const bool force_general = getenv("HVX_HNSW_GENERAL") != nullptr; // test hook
     const bool wave = !(force_general && ix->dev.dtype == HVX_F32) && hnsw_wave_supported(a);
     if (!wave && ix->dev.dtype != HVX_F32)
-        return fail(HVX_ERR_UNSUPPORTED, "bf16 rows are served by the one-wavefront-per-query kernel only (dim in {128,256,512,768,1024,1536}, rows <= 64 ids, ef <= 352)");
+        return fail(HVX_ERR_UNSUPPORTED, ix->dev.dtype == HVX_FP8_E4M3 ? "fp8 rows serve the exact scan only (HNSW over fp8 rows is not built)"
+                    : "bf16 rows are served by the one-wavefront-per-query kernel only (dim in {128,256,512,768,1024,1536}, rows <= 64 ids, ef <= 352)");
     if (ix->bitmap_dirty) {
         HIP_TRY(hipMemsetAsync(ix->d_bitmap, 0, (size_t)ix->max_batch * ix->words_per_query * 4, ix->stream));
         ix->bitmap_dirty = false;
@@ -523,8 +551,8 @@ int hvx::flat_scan_device(hvx_index *ix, const float *d_queries, uint32_t b, uin
                           uint32_t *d_status, bool timed) {
     if (k == 0) return fail(HVX_ERR_K_RANGE, "result count must be non-zero");
     if (k > 1024) return fail(HVX_ERR_UNSUPPORTED, "flat scan supports k <= 1024");
-    if (ix->dev.dtype == HVX_BF16) {
-        if (d_subset) return fail(HVX_ERR_UNSUPPORTED, "restricted scans over bf16 rows are not built yet");
+    if (ix->dev.dtype != HVX_F32) {
+        if (d_subset) return fail(HVX_ERR_UNSUPPORTED, "restricted scans over bf16 / fp8 rows are not built yet");
         return flat_mfma_device(ix, d_queries, b, k, d_ids, d_scores, d_counts, d_status, timed);
     }
     // chunk the scan so the distance workspace stays <= 256 MiB

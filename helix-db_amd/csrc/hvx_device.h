@@ -27,6 +27,8 @@ enum : uint32_t { kKernelScalar = 0, kKernelAvx = 2, kKernelAvxFma = 3 };
 struct DevIndex {
     const float *vec;         // [n][ld] row-major f32, rows 16-byte aligned, zero padded to ld (dtype f32)
     const uint16_t *vecb;     // [n][dim] bf16 rows in the interleaved device layout below (dtype bf16)
+    const uint8_t *vec8;      // [n][dim] fp8 e4m3fn codes, interleaved (dtype fp8); value = rowscale[row] * decode(code)
+    const float *rowscale;    // [n] per-row scale of fp8 rows
     const float *hdr;         // [n] cosine norm header (distance/cosine.rs:73-75); 0 otherwise
     const uint32_t *l0;       // [n][s0] layer-0 rows: internal ids ascending, kSentinel padded
     const uint32_t *up;       // [up_rows][su] upper-layer rows, same format
@@ -50,6 +52,42 @@ __host__ __device__ __forceinline__ uint32_t bf16_slot_of(uint32_t i) {
     const uint32_t k = i >> 5, s = (i >> 2) & 7u, e = i & 3u;
     return (k >> 1) * 64u + s * 8u + (k & 1u) * 4u + e;
 }
+// fp8 device layout (dim % 128 == 0): element i = 32*chunk + 4*slot + e is stored at
+// 128*(chunk/4) + 16*slot + 4*(chunk%4) + e: a lane's 16 bytes hold its four virtual lanes of FOUR chunks.
+__host__ __device__ __forceinline__ uint32_t fp8_slot_of(uint32_t i) {
+    const uint32_t k = i >> 5, s = (i >> 2) & 7u, e = i & 3u;
+    return (k >> 2) * 128u + s * 16u + (k & 3u) * 4u + e;
+}
+// OCP e4m3fn: 1 sign, 4 exponent (bias 7), 3 mantissa bits; max finite 448; no infinities.
+__host__ __device__ __forceinline__ float fp8_e4m3_decode(uint8_t c) {
+    const uint32_t m = c & 7u, e = (c >> 3) & 15u;
+    float v = e == 0u ? (float)m * 0.001953125f /* m/8 * 2^-6 */ : (1.0f + (float)m * 0.125f) * __builtin_ldexpf(1.0f, (int)e - 7);
+    return (c & 0x80u) ? -v : v;
+}
+// round-to-nearest-even of y (|y| <= 448) to e4m3fn
+__host__ __device__ __forceinline__ uint8_t fp8_e4m3_encode(float y) {
+    const uint8_t sign = y < 0.0f ? 0x80u : 0u;
+    float a = __builtin_fabsf(y);
+    if (!(a < 464.0f)) a = 448.0f; // beyond the midpoint to the next (non-existent) step: saturate
+    int ex;
+    (void)__builtin_frexpf(a, &ex); // a = f * 2^ex, f in [0.5, 1)
+    int e = ex - 1;                 // floor(log2(a)) for a > 0
+    if (a == 0.0f || e < -6) e = -6; // subnormal range shares the exponent of the smallest normal
+    const float step = __builtin_ldexpf(1.0f, e - 3);
+    float qv = __builtin_rintf(a / step); // exact division by a power of two; ties to even
+    float v = qv * step;
+    if (v > 448.0f) v = 448.0f;
+    // encode the (exactly representable) value
+    if (v == 0.0f) return sign;
+    int ex2;
+    (void)__builtin_frexpf(v, &ex2);
+    int e2 = ex2 - 1;
+    uint32_t code;
+    if (e2 < -6) code = (uint32_t)(v * 512.0f); // subnormal: m = v / 2^-9
+    else code = ((uint32_t)(e2 + 7) << 3) | ((uint32_t)(v * __builtin_ldexpf(1.0f, 3 - e2)) - 8u);
+    return (uint8_t)(sign | code);
+}
+
 // round-to-nearest-even f32 -> bf16 bits (finite inputs; NaN/inf are rejected before)
 __host__ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
     union { float f; uint32_t u; } v;

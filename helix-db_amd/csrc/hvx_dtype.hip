@@ -22,6 +22,59 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float *staging, ui
     }
 }
 
+// fp8 e4m3fn rows with one f32 scale per row (BASELINE config #5): code = RNE(x / scale), scale = max|x| / 448.
+// The staging row is overwritten with the dequantised values fl32(scale * decode(code)) -- these ARE the index:
+// validation, cosine headers and every distance see exactly them.  Rows holding a non-finite value are left
+// untouched so that validation reports them.
+__global__ __launch_bounds__(64) void quantize_fp8_kernel(float *staging, uint8_t *dst, float *rowscale, uint32_t n, uint32_t dim) {
+    const uint32_t r = blockIdx.x;
+    if (r >= n) return;
+    float *row = staging + (size_t)r * dim;
+    float amax = 0.f;
+    bool finite = true;
+    for (uint32_t i = threadIdx.x; i < dim; i += 64) {
+        const float v = row[i];
+        if (!f32_is_finite(v)) finite = false;
+        amax = fmaxf(amax, fabsf(v));
+    }
+    for (int s = 32; s > 0; s >>= 1) amax = fmaxf(amax, __shfl_xor(amax, s, 64));
+    if (__ballot(!finite)) {
+        if (threadIdx.x == 0) rowscale[r] = 1.0f;
+        return;
+    }
+    const float scale = amax > 0.f ? __fdiv_rn(amax, 448.0f) : 1.0f;
+    if (threadIdx.x == 0) rowscale[r] = scale;
+    for (uint32_t i = threadIdx.x; i < dim; i += 64) {
+        const uint8_t c = fp8_e4m3_encode(__fdiv_rn(row[i], scale));
+        dst[(size_t)r * dim + fp8_slot_of(i)] = c;
+        row[i] = scale * fp8_e4m3_decode(c);
+    }
+}
+
+__global__ __launch_bounds__(64) void f32_row_norm2_kernel(const float *rows, uint32_t n, uint32_t ld, uint32_t dim, float *out) {
+    const uint32_t r = blockIdx.x;
+    if (r >= n) return;
+    double acc = 0.0;
+    for (uint32_t i = threadIdx.x; i < dim; i += 64) {
+        const double v = (double)rows[(size_t)r * ld + i];
+        acc += v * v;
+    }
+    for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s, 64);
+    if (threadIdx.x == 0) out[r] = (float)acc;
+}
+
+hipError_t launch_quantize_fp8(float *staging, uint8_t *dst, float *rowscale, uint32_t n, uint32_t dim, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(quantize_fp8_kernel, dim3(n), dim3(64), 0, s, staging, dst, rowscale, n, dim);
+    return hipGetLastError();
+}
+
+hipError_t launch_f32_row_norm2(const float *rows, uint32_t n, uint32_t ld, uint32_t dim, float *out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(f32_row_norm2_kernel, dim3(n), dim3(64), 0, s, rows, n, ld, dim, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_round_bf16_inplace(float *v, size_t count, hipStream_t s) {
     if (count == 0) return hipSuccess;
     hipLaunchKernelGGL(round_bf16_inplace_kernel, dim3(4096), dim3(256), 0, s, v, count);

@@ -1,4 +1,4 @@
-// hvx_flat_mfma.hip -- exact scan over bf16 rows as a dense batched-query x corpus contraction on the
+// hvx_flat_mfma.hip -- exact scan over bf16 / fp8 rows as a dense batched-query x corpus contraction on the
 // matrix cores (BASELINE configs #4/#5: "MFMA GEMM path only for the brute-force flat scan").
 //
 // Semantics are still restricted_exact_scan (crates/db/src/search/vector/restricted.rs:753-835): the k
@@ -8,7 +8,8 @@
 //      (a dot product does not care about the permutation as long as both operands use it);
 //   2. `flat_mfma_bf16_kernel`: 128 queries x 128 rows per workgroup, v_mfma_f32_32x32x16_bf16,
 //      acc += q_hi.x + q_lo.x, epilogue turns the dot product into the metric's score and writes one
-//      chunk of the [b][rows] score matrix;
+//      chunk of the [b][rows] score matrix (fp8 rows: codes widened to bf16 -- exactly -- on the way into
+//      LDS, the row scale applied in the epilogue);
 //   3. the exact top-(m+1) by approximate score per query is kept (flat_select_kernel, m = max(64, 2k));
 //   4. `rerank_kernel`: one wavefront per query re-scores those candidates with the reference's
 //      summation order (the same gather/FMA code as the HNSW kernel), sorts by (score, id), keeps k;
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(64) void bf16_row_norm2_kernel(const uint16_t *rows
 
 // ---- queries: f32 -> bf16 hi + lo in the interleaved layout, padded with zero rows; |q|^2 ----
 __global__ __launch_bounds__(64) void split_queries_kernel(const float *q, uint32_t b, uint32_t bpad, uint32_t dim,
-                                                           uint16_t *qhi, uint16_t *qlo, float *qn2) {
+                                                           uint16_t *qhi, uint16_t *qlo, float *qn2, uint32_t fp8_layout) {
     const uint32_t r = blockIdx.x;
     if (r >= bpad) return;
     double acc = 0.0;
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(64) void split_queries_kernel(const float *q, uint3
         if (!f32_is_finite(v)) v = 0.f; // rejected queries are masked by their status; keep the GEMM finite
         const uint16_t h = f32_to_bf16_rne(v);
         const float res = v - bf16_to_f32(h);
-        const uint32_t s = bf16_slot_of(i);
+        const uint32_t s = fp8_layout ? fp8_slot_of(i) : bf16_slot_of(i);
         qhi[(size_t)r * dim + s] = h;
         qlo[(size_t)r * dim + s] = f32_to_bf16_rne(res);
         acc += (double)v * (double)v;
@@ -77,7 +78,8 @@ constexpr int kLdsStride = kBK * 2 + 16;      // bytes per tile row: 64 B of dat
 
 struct MfmaArgs {
     const uint16_t *qhi, *qlo; // [bpad][dim]
-    const uint16_t *rows;      // [n][dim]
+    const void *rows;          // [n][dim] bf16, or fp8 codes
+    const float *rowscale;     // [n] fp8 only
     const float *rowterm;      // [n]: |x|^2 (L2) or |x| (cosine)
     const float *qn2;          // [b]
     uint32_t dim, b, row0, nrows, metric;
@@ -85,6 +87,7 @@ struct MfmaArgs {
     uint32_t chunk_ld;
 };
 
+template <bool FP8>
 __global__ __launch_bounds__(256) void flat_mfma_bf16_kernel(MfmaArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * kBM * kLdsStride]; // A_hi | A_lo | B
     unsigned char *sAh = lds, *sAl = lds + kBM * kLdsStride, *sB = lds + 2 * kBM * kLdsStride;
@@ -99,8 +102,21 @@ __global__ __launch_bounds__(256) void flat_mfma_bf16_kernel(MfmaArgs a) {
     if (rowB1 >= a.nrows) rowB1 = a.nrows - 1;
     const uint16_t *gAh0 = a.qhi + (size_t)rowA0 * a.dim + sc * 8, *gAh1 = a.qhi + (size_t)rowA1 * a.dim + sc * 8;
     const uint16_t *gAl0 = a.qlo + (size_t)rowA0 * a.dim + sc * 8, *gAl1 = a.qlo + (size_t)rowA1 * a.dim + sc * 8;
-    const uint16_t *gB0 = a.rows + ((size_t)a.row0 + rowB0) * a.dim + sc * 8, *gB1 = a.rows + ((size_t)a.row0 + rowB1) * a.dim + sc * 8;
+    const uint16_t *gB0 = reinterpret_cast<const uint16_t *>(a.rows) + ((size_t)a.row0 + rowB0) * a.dim + sc * 8;
+    const uint16_t *gB1 = reinterpret_cast<const uint16_t *>(a.rows) + ((size_t)a.row0 + rowB1) * a.dim + sc * 8;
     const int so0 = sr * kLdsStride + sc * 16, so1 = (sr + 64) * kLdsStride + sc * 16;
+    // fp8 rows: ONE 16-byte load per thread and stage = 16 codes of tile row tid/2, depth half tid&1,
+    // widened to bf16 (exact) on the way into LDS
+    uint32_t rowF = r0 + (uint32_t)(tid >> 1);
+    if (rowF >= a.nrows) rowF = a.nrows - 1;
+    const uint8_t *gF = reinterpret_cast<const uint8_t *>(a.rows) + ((size_t)a.row0 + rowF) * a.dim + (tid & 1) * 16;
+    const int soF = (tid >> 1) * kLdsStride + (tid & 1) * 32;
+    auto widen = [](uint32_t w, uint32_t &lo, uint32_t &hi) { // 4 fp8 -> 4 bf16 (two words)
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 a01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false), a23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);
+        lo = (__float_as_uint(a01[1]) & 0xFFFF0000u) | (__float_as_uint(a01[0]) >> 16);
+        hi = (__float_as_uint(a23[1]) & 0xFFFF0000u) | (__float_as_uint(a23[0]) >> 16);
+    };
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -114,18 +130,27 @@ __global__ __launch_bounds__(256) void flat_mfma_bf16_kernel(MfmaArgs a) {
     const int fr = lane & 31, fk = (lane >> 5) * 16; // byte offset of the lane's 8 bf16 inside a 16-deep step
     uint4 pAh0 = *reinterpret_cast<const uint4 *>(gAh0), pAh1 = *reinterpret_cast<const uint4 *>(gAh1);
     uint4 pAl0 = *reinterpret_cast<const uint4 *>(gAl0), pAl1 = *reinterpret_cast<const uint4 *>(gAl1);
-    uint4 pB0 = *reinterpret_cast<const uint4 *>(gB0), pB1 = *reinterpret_cast<const uint4 *>(gB1);
+    uint4 pB0, pB1;
+    if (FP8) { pB0 = *reinterpret_cast<const uint4 *>(gF); pB1 = pB0; }
+    else { pB0 = *reinterpret_cast<const uint4 *>(gB0); pB1 = *reinterpret_cast<const uint4 *>(gB1); }
     for (uint32_t k0 = 0; k0 < a.dim; k0 += kBK) {
         __syncthreads(); // previous stage fully consumed
         *reinterpret_cast<uint4 *>(sAh + so0) = pAh0; *reinterpret_cast<uint4 *>(sAh + so1) = pAh1;
         *reinterpret_cast<uint4 *>(sAl + so0) = pAl0; *reinterpret_cast<uint4 *>(sAl + so1) = pAl1;
-        *reinterpret_cast<uint4 *>(sB + so0) = pB0; *reinterpret_cast<uint4 *>(sB + so1) = pB1;
+        if (FP8) {
+            uint4 w0, w1;
+            widen(pB0.x, w0.x, w0.y); widen(pB0.y, w0.z, w0.w); widen(pB0.z, w1.x, w1.y); widen(pB0.w, w1.z, w1.w);
+            *reinterpret_cast<uint4 *>(sB + soF) = w0; *reinterpret_cast<uint4 *>(sB + soF + 16) = w1;
+        } else {
+            *reinterpret_cast<uint4 *>(sB + so0) = pB0; *reinterpret_cast<uint4 *>(sB + so1) = pB1;
+        }
         __syncthreads();
         if (k0 + kBK < a.dim) { // next stage's global loads fly under this stage's MFMAs
             const uint32_t kn = k0 + kBK;
             pAh0 = *reinterpret_cast<const uint4 *>(gAh0 + kn); pAh1 = *reinterpret_cast<const uint4 *>(gAh1 + kn);
             pAl0 = *reinterpret_cast<const uint4 *>(gAl0 + kn); pAl1 = *reinterpret_cast<const uint4 *>(gAl1 + kn);
-            pB0 = *reinterpret_cast<const uint4 *>(gB0 + kn); pB1 = *reinterpret_cast<const uint4 *>(gB1 + kn);
+            if (FP8) pB0 = *reinterpret_cast<const uint4 *>(gF + kn);
+            else { pB0 = *reinterpret_cast<const uint4 *>(gB0 + kn); pB1 = *reinterpret_cast<const uint4 *>(gB1 + kn); }
         }
 #pragma unroll
         for (int kk = 0; kk < kBK / 16; ++kk) {
@@ -156,13 +181,14 @@ __global__ __launch_bounds__(256) void flat_mfma_bf16_kernel(MfmaArgs a) {
         const uint32_t rloc = r0 + wn * 64 + jn * 32 + (lane & 31);
         if (rloc >= a.nrows) continue;
         const float term = a.rowterm[(size_t)a.row0 + rloc];
+        const float rsc = FP8 ? a.rowscale[(size_t)a.row0 + rloc] : 1.0f;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const uint32_t qq = q0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                 if (qq >= a.b) continue;
-                const float dot = acc[i][jn][e];
+                const float dot = FP8 ? acc[i][jn][e] * rsc : acc[i][jn][e];
                 float s;
                 if (a.metric == kL2) {
                     s = (a.qn2[qq] + term) - 2.0f * dot;
@@ -196,7 +222,57 @@ struct RerankArgs {
     uint32_t *cert;           // [b] 1 = proven exact, 0 = needs a wider candidate set
 };
 
-template <uint32_t METRIC, int NK>
+// P fp8 rows per 8-lane group scored in the reference's summation order: NK/4 16-byte loads per lane and row
+// (the lane's four virtual lanes of four consecutive chunks), codes widened by v_cvt_pk_f32_fp8 and scaled by
+// the row's f32 scale -- exactly the dequantised value the import validated.
+template <uint32_t METRIC, int NK, int P>
+__device__ __forceinline__ void score_rows_fp8(const DevIndex &ix, const float *qs, const uint32_t (&node)[P], int slot,
+                                               float qhdr, const float *qglobal, float (&out)[P]) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    constexpr int NL = NK / 4;
+    uint4 x[P][NL];
+    float sc[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const uint4 *rp = reinterpret_cast<const uint4 *>(ix.vec8 + (size_t)node[p] * ix.dim) + slot;
+#pragma unroll
+        for (int m = 0; m < NL; ++m) x[p][m] = rp[m * 8];
+        sc[p] = ix.rowscale[node[p]];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float4 acc[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 *qp = reinterpret_cast<const float4 *>(qs) + slot;
+#pragma unroll
+    for (int m = 0; m < NL; ++m)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 qq = qp[(4 * m + c) * 8];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const uint32_t w = c == 0 ? x[p][m].x : (c == 1 ? x[p][m].y : (c == 2 ? x[p][m].z : x[p][m].w));
+                const f2 a01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false), a23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);
+                fma_chunk<METRIC>(acc[p], qq, make_float4(sc[p] * a01[0], sc[p] * a01[1], sc[p] * a23[0], sc[p] * a23[1]));
+            }
+        }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        float r = avx_tree_reduce(acc[p]);
+        if (METRIC == kCosine) {
+            const uint32_t nd = node[p];
+            r = cosine_finish_fn(r, qhdr, ix.hdr[nd], [&]() {
+                const uint8_t *rb = ix.vec8 + (size_t)nd * ix.dim;
+                const float s = ix.rowscale[nd];
+                return stable_half_cosine_fn(ix.dim, [&](uint32_t i) { return qglobal[i]; },
+                                             [&](uint32_t i) { return s * fp8_e4m3_decode(rb[fp8_slot_of(i)]); });
+            });
+        }
+        out[p] = r;
+    }
+}
+
+template <uint32_t METRIC, int NK, bool FP8>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void rerank_bf16_kernel(RerankArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int P = 2; // 16 rows per pass
@@ -226,14 +302,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     for (uint32_t f0 = 0; f0 < nc; f0 += 8u * P) {
         uint32_t nd[P];
         float o[P];
-        Gather<NK, P, true> g;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const uint32_t f = f0 + (uint32_t)(p * 8 + grp);
             nd[p] = si[f < nc ? f : f0];
         }
-        gather_issue<NK, P, true>(ix, nd, slot, g);
-        gather_consume<METRIC, NK, P, true>(ix, qs, g, nd, slot, qhdr, qglobal, o);
+        if (FP8) {
+            score_rows_fp8<METRIC, NK, P>(ix, qs, nd, slot, qhdr, qglobal, o);
+        } else {
+            Gather<NK, P, true> g;
+            gather_issue<NK, P, true>(ix, nd, slot, g);
+            gather_consume<METRIC, NK, P, true>(ix, qs, g, nd, slot, qhdr, qglobal, o);
+        }
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const uint32_t f = f0 + (uint32_t)(p * 8 + grp);
@@ -287,7 +367,11 @@ template <uint32_t METRIC>
 static hipError_t launch_rerank(const RerankArgs &a, uint32_t b, hipStream_t s) {
     const size_t lds = (size_t)a.ix.dim * 4 + 8192;
     switch (a.ix.dim >> 5) {
-#define HVX_RR(N) case N: hipLaunchKernelGGL((rerank_bf16_kernel<METRIC, N>), dim3(b), dim3(64), lds, s, a); break;
+#define HVX_RR(N)                                                                                                   \
+    case N:                                                                                                         \
+        if (a.ix.dtype == HVX_FP8_E4M3) hipLaunchKernelGGL((rerank_bf16_kernel<METRIC, N, true>), dim3(b), dim3(64), lds, s, a); \
+        else hipLaunchKernelGGL((rerank_bf16_kernel<METRIC, N, false>), dim3(b), dim3(64), lds, s, a);             \
+        break;
         HVX_RR(4) HVX_RR(8) HVX_RR(16) HVX_RR(24) HVX_RR(32) HVX_RR(48)
 #undef HVX_RR
     default: return hipErrorInvalidValue;
@@ -310,7 +394,7 @@ int flat_mfma_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t
     if (k > 511) return fail(HVX_ERR_UNSUPPORTED, "bf16 exact scan supports k <= 511");
     const uint32_t nk = d.dim >> 5;
     if (nk != 4 && nk != 8 && nk != 16 && nk != 24 && nk != 32 && nk != 48)
-        return fail(HVX_ERR_UNSUPPORTED, "bf16 exact scan serves dim in {128,256,512,768,1024,1536}");
+        return fail(HVX_ERR_UNSUPPORTED, "bf16 / fp8 exact scan serves dim in {128,256,512,768,1024,1536}");
     HIP_TRY(launch_validate_queries(d, d_queries, b, ix->limit, ix->d_qstatus, ix->d_qhdr, ix->stream));
     if (n == 0) {
         HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)b * 4, ix->stream));
@@ -326,7 +410,9 @@ int flat_mfma_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t
         if ((rc = ix->dalloc((void **)&ix->m_cert, (size_t)bpad * 4))) return rc;
         ix->cap_qsplit = (size_t)bpad * d.dim;
     }
-    hipLaunchKernelGGL(split_queries_kernel, dim3(bpad), dim3(64), 0, ix->stream, d_queries, b, bpad, d.dim, ix->m_qhi, ix->m_qlo, ix->m_qn2);
+    const bool fp8 = d.dtype == HVX_FP8_E4M3;
+    hipLaunchKernelGGL(split_queries_kernel, dim3(bpad), dim3(64), 0, ix->stream, d_queries, b, bpad, d.dim, ix->m_qhi, ix->m_qlo, ix->m_qn2,
+                       fp8 ? 1u : 0u);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ix->ev0, ix->stream));
     uint32_t m = std::max<uint32_t>(64u, 2u * k);
@@ -342,12 +428,14 @@ int flat_mfma_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t
         fa.n_rows = n; fa.dist = ix->f_dist; fa.chunk_ld = chunk; fa.b = b; fa.k = kc;
         fa.top_scores = ix->f_top_s; fa.top_ids = ix->f_top_i; fa.top_counts = ix->f_top_c;
         MfmaArgs ma;
-        ma.qhi = ix->m_qhi; ma.qlo = ix->m_qlo; ma.rows = d.vecb; ma.rowterm = d.metric == kL2 ? ix->m_rowterm : d.hdr;
+        ma.qhi = ix->m_qhi; ma.qlo = ix->m_qlo; ma.rows = fp8 ? (const void *)d.vec8 : (const void *)d.vecb; ma.rowscale = d.rowscale;
+        ma.rowterm = d.metric == kL2 ? ix->m_rowterm : d.hdr;
         ma.qn2 = ix->m_qn2; ma.dim = d.dim; ma.b = b; ma.metric = d.metric; ma.dist = ix->f_dist; ma.chunk_ld = chunk;
         for (uint32_t r0 = 0; r0 < n; r0 += chunk) {
             const uint32_t rows = std::min(chunk, n - r0);
             ma.row0 = r0; ma.nrows = rows;
-            hipLaunchKernelGGL(flat_mfma_bf16_kernel, dim3((rows + kBN - 1) / kBN, bpad / kBM), dim3(256), 0, ix->stream, ma);
+            if (fp8) hipLaunchKernelGGL(flat_mfma_bf16_kernel<true>, dim3((rows + kBN - 1) / kBN, bpad / kBM), dim3(256), 0, ix->stream, ma);
+            else hipLaunchKernelGGL(flat_mfma_bf16_kernel<false>, dim3((rows + kBN - 1) / kBN, bpad / kBM), dim3(256), 0, ix->stream, ma);
             HIP_TRY(hipGetLastError());
             fa.row0 = r0; fa.rows = rows;
             HIP_TRY(launch_flat_select(fa, ix->stream));

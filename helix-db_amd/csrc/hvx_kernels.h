@@ -42,6 +42,9 @@ hipError_t launch_validate_rows(const DevIndex &ix, uint32_t n, float limit, uin
 // bf16 row storage (hvx_dtype.hip): round an f32 staging copy in place, then pack it interleaved
 hipError_t launch_round_bf16_inplace(float *v, size_t count, hipStream_t s);
 hipError_t launch_pack_bf16(const float *staging, uint16_t *dst, uint32_t n, uint32_t dim, hipStream_t s);
+// fp8 row storage: quantise rows (staging is overwritten with the dequantised values), |x|^2 of f32 rows
+hipError_t launch_quantize_fp8(float *staging, uint8_t *dst, float *rowscale, uint32_t n, uint32_t dim, hipStream_t s);
+hipError_t launch_f32_row_norm2(const float *rows, uint32_t n, uint32_t ld, uint32_t dim, float *out, hipStream_t s);
 
 // exact distance matrix tile + exact top-k selection (flat scan / restricted exact scan)
 struct FlatArgs {

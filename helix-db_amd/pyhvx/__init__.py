@@ -174,7 +174,12 @@ class ValidatedVectorReadIndex:
                 up_offsets=None, up_neighbors=None, entry_point=None, max_layer=0, m=16, m0=32,
                 float_kernel=KERNEL_AVX_FMA, device=-1, max_batch=1024, dtype=F32):
         ids = np.ascontiguousarray(node_ids, dtype=np.uint64)
-        vec = np.ascontiguousarray(vectors, dtype=np.float32).reshape(ids.size, dim) if ids.size else np.zeros((0, dim), np.float32)
+        dev_rows = hasattr(vectors, "data_ptr")  # a torch tensor already resident on the device
+        if dev_rows:
+            assert vectors.is_contiguous() and vectors.dtype.is_floating_point and vectors.element_size() == 4 and vectors.numel() == ids.size * dim
+            vec = None
+        else:
+            vec = np.ascontiguousarray(vectors, dtype=np.float32).reshape(ids.size, dim) if ids.size else np.zeros((0, dim), np.float32)
         o0 = np.ascontiguousarray(l0_offsets, dtype=np.uint64)
         n0 = np.ascontiguousarray(l0_neighbors, dtype=np.uint64)
         lv = None if level is None else np.ascontiguousarray(level, dtype=np.uint16)
@@ -186,7 +191,7 @@ class ValidatedVectorReadIndex:
                   shard_id_lo=int(ids[0]) if ids.size else 0, shard_id_hi=int(ids[-1]) if ids.size else 0,
                   device=device, max_batch=max_batch)
         h = _vp()
-        _check(lib().hvx_index_import(C.byref(d), _ptr(ids), _ptr(vec), _ptr(o0), _ptr(n0), _ptr(lv),
+        _check(lib().hvx_index_import(C.byref(d), _ptr(ids), _vp(vectors.data_ptr()) if dev_rows else _ptr(vec), _ptr(o0), _ptr(n0), _ptr(lv),
                                       _ptr(uo), _ptr(un), C.byref(h)))
         return cls(h, dim, metric, int(ids.size))
 

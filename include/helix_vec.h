@@ -87,7 +87,7 @@ typedef struct hvx_query_stats {
  * Import a read-only index image (replaces VectorMemoryStore hydration, memory_store.rs:97-105,
  * and every row read under VectorIndex::search: storage.rs:1713-2066).
  *   node_ids      [n] external ids, strictly ascending
- *   vectors       [n][dim] row-major f32, host memory; validated like decode_item_borrowed
+ *   vectors       [n][dim] row-major f32, host memory (or memory already on a device); validated like decode_item_borrowed
  *                 (mod.rs:889-949) ONCE here instead of on every fetch
  *   l0_offsets    [n+1], l0_neighbors: CSR of layer-0 rows over external ids (ids sorted per row:
  *                 values/vectors.rs:97-111)

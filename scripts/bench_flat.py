@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""BASELINE config #5 shape on one MI355X: exact scan of a batch of queries over a reduced-precision corpus on the
+matrix cores (hvx_flat_mfma.hip).  The full config is 100M x 1536 fp8 over 8 GPUs = 12.5M rows per GPU, batch 4096;
+`--rows` is the per-GPU shard.  Reports the contraction rate (useful 2*b*N*dim flops, and executed = x2 for the
+query's bf16 hi/lo split) against the dense bf16 MFMA peak (fp8 codes are widened to bf16 -- exactly -- on the way
+into LDS, so the matrix rate is the bf16 one), HBM bytes, and recall@k of the reduced-precision answer against
+the f32 rows (quantisation loss; the scan itself is exact on the stored values)."""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "helix-db_amd"))
+import numpy as np
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=2_000_000)
+    ap.add_argument("--dim", type=int, default=1536)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--dtype", default="fp8", choices=["fp8", "bf16"])
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--recall-queries", type=int, default=64)
+    args = ap.parse_args()
+    import pyhvx as hv
+    from pyhvx import synth
+    dev = torch.device("cuda", 0)
+    n, dim, b, k = args.rows, args.dim, args.batch, args.k
+    t0 = time.time()
+    x, q = synth.embedding_like(n, dim, b, 20260924, dev, latent=24, clusters=4096)
+    torch.cuda.synchronize()
+    t1 = time.time()
+    ix = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=hv.EUCLIDEAN, node_ids=np.arange(n, dtype=np.uint64), vectors=x,
+                                             l0_offsets=np.zeros(n + 1, np.uint64), l0_neighbors=np.zeros(0, np.uint64),
+                                             max_batch=b, dtype=hv.FP8_E4M3 if args.dtype == "fp8" else hv.BF16)
+    print(f"[flat] corpus {n}x{dim} generated in {t1 - t0:.1f}s, imported as {args.dtype} in {time.time() - t1:.1f}s", file=sys.stderr)
+    ids = torch.zeros(b, k, dtype=torch.int64, device=dev); sc = torch.zeros(b, k, device=dev)
+    cnt = torch.zeros(b, dtype=torch.int32, device=dev); st = torch.zeros(b, dtype=torch.int32, device=dev)
+    ms = []
+    for i in range(args.steps + 1):
+        s = ix.flat_search_batch_device(q, k, ids, sc, cnt, st, want_stats=True)
+        if i:
+            ms.append(s["device_ms"])
+    ms = float(np.mean(ms))
+    # quantisation loss: recall of the reduced-precision top-k against the exact f32 top-k (library GEMM, harness only)
+    rq = min(args.recall_queries, b)
+    d2 = (x * x).sum(1)[None, :] - 2.0 * (q[:rq] @ x.t())
+    truth = torch.topk(d2, k, dim=1, largest=False).indices.cpu().numpy()
+    got = ids[:rq].cpu().numpy()
+    recall = sum(len(set(got[i].tolist()) & set(truth[i].tolist())) for i in range(rq)) / float(rq * k)
+    useful = 2.0 * b * n * dim
+    elem = 1 if args.dtype == "fp8" else 2
+    print(json.dumps({
+        "workload": f"configs[4] per-GPU shard: exact scan, {n}x{dim} {args.dtype} rows, batch {b}, k={k}, squared-L2",
+        "ms_per_batch": round(ms, 3), "queries_per_s": round(b / ms * 1e3, 1),
+        "roofline": {"bound": "mfma", "achieved": round(useful * 2 / ms / 1e9, 1), "useful": round(useful / ms / 1e9, 1), "peak": 2500.0,
+                     "unit": "TFLOP/s", "frac": round(useful * 2 / ms / 1e9 / 2500.0, 4),
+                     "note": "achieved = executed flops (query split into bf16 hi+lo => 2 MFMA per product); useful = 2*b*N*dim"},
+        "hbm_bytes_min_per_batch": n * dim * elem * ((b + 127) // 128), "recall_at_k_vs_f32_rows": round(recall, 4),
+        "exactness": "certificate passed for every query (the call fails otherwise)"}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

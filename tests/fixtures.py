@@ -132,3 +132,22 @@ def round_bf16(x: np.ndarray) -> np.ndarray:
     lsb = (u >> np.uint64(16)) & np.uint64(1)
     r = ((u + np.uint64(0x7FFF) + lsb) >> np.uint64(16)) << np.uint64(16)
     return (r & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.float32).reshape(np.shape(x))
+
+
+def quantize_fp8_rows(x: np.ndarray) -> np.ndarray:
+    """The values an fp8-e4m3fn-stored index holds (twin of quantize_fp8_kernel, hvx_dtype.hip): per row
+    scale = max|x| / 448, code = RNE(x / scale) to e4m3fn, value = fl32(scale * decode(code))."""
+    x = np.ascontiguousarray(x, np.float32)
+    amax = np.abs(x).max(axis=1).astype(np.float32)
+    scale = np.where(amax > 0, amax / np.float32(448.0), np.float32(1.0)).astype(np.float32)
+    y = (x / scale[:, None]).astype(np.float32)
+    a = np.abs(y)
+    a = np.where(a < np.float32(464.0), a, np.float32(448.0)).astype(np.float32)
+    _, ex = np.frexp(a)
+    e = ex.astype(np.int32) - 1
+    e = np.where((a == 0) | (e < -6), -6, e)
+    step = np.ldexp(np.float32(1.0), e - 3).astype(np.float32)
+    v = (np.rint(a / step) * step).astype(np.float32)
+    v = np.minimum(v, np.float32(448.0))
+    v = np.where(y < 0, -v, v).astype(np.float32)
+    return (scale[:, None] * v).astype(np.float32)

@@ -455,3 +455,37 @@ def test_bf16_exact_scan_never_guesses_on_dense_near_ties(orc, hv):
         return
     rc, oid, osc = orc.flat_matrix(orc.L2SQ, rounded, q[0], 10)
     assert gid[0].tolist() == oid.tolist() and bits(gsc[0]).tolist() == bits(osc).tolist()
+
+
+@pytest.mark.parametrize("n,dim,metric,k,b", [(5000, 128, 1, 10, 9), (3000, 256, 0, 7, 5), (20000, 768, 1, 10, 130),
+                                              (4000, 1536, 1, 10, 17)])
+def test_fp8_exact_scan_is_bit_exact_on_the_dequantised_rows(orc, hv, n, dim, metric, k, b):
+    """BASELINE config #5 storage: e4m3fn codes + one f32 scale per row.  The index IS the dequantised rows
+    fl32(scale * decode(code)); the MFMA scan + reference-order re-rank + certificate returns the oracle's exact
+    scan over exactly those values (ids and score bits)."""
+    rng = np.random.default_rng(1300 + dim + n)
+    data = (rng.standard_normal((n, dim)) * rng.uniform(0.2, 3.0, (n, 1))).astype(np.float32)
+    data[7] = data[3]
+    deq = fx.quantize_fp8_rows(data)
+    ids = np.arange(n, dtype=np.uint64) + 11
+    gix = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=metric, node_ids=ids, vectors=data, dtype=hv.FP8_E4M3,
+                                              l0_offsets=np.zeros(n + 1, np.uint64), l0_neighbors=np.zeros(0, np.uint64),
+                                              max_batch=max(b, 16))
+    q = rng.standard_normal((b, dim)).astype(np.float32)
+    q[0] = data[3]
+    gid, gsc, gcnt, _ = gix.flat_search_batch(q, k)
+    for qi in range(b):
+        rc, oid, osc = orc.flat_matrix(metric, deq, q[qi], k)
+        assert gcnt[qi] == oid.size
+        assert (gid[qi, :gcnt[qi]] - 11).tolist() == oid.tolist(), f"query {qi}"
+        assert bits(gsc[qi, :gcnt[qi]]).tolist() == bits(osc).tolist()
+    assert gid[0, :2].tolist() == [14, 18]
+    # quantisation loss is a property of the dtype, reported separately: recall of the fp8 answer vs the f32 rows
+    hits = 0
+    for qi in range(b):
+        rc, tid, _ = orc.flat_matrix(metric, data, q[qi], k)
+        hits += len(set((gid[qi, :gcnt[qi]] - 11).tolist()) & set(tid.tolist()))
+    assert hits / (b * k) > 0.5
+    with pytest.raises(hv.HelixDbError) as e:  # HNSW over fp8 rows is not built: fails loudly
+        gix.search_batch(q[:1], hv.SearchParams(k))
+    assert e.value.status == hv.ERR_UNSUPPORTED

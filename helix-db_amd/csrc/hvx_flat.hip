@@ -235,22 +235,39 @@ __global__ __launch_bounds__(256) void flat_select_kernel(FlatArgs a, uint32_t *
     float thr_s = have >= k ? ps[k - 1] : inf;
     uint32_t thr_i = have >= k ? pi[k - 1] : 0xFFFFFFFFu;
     const float *dq = a.dist + (size_t)q * a.chunk_ld;
-    for (uint32_t base = 0; base < a.rows; base += 256) {
-        const uint32_t i = base + (uint32_t)tid;
-        if (i < a.rows) {
-            float d = dq[i];
-            const uint32_t scan = a.row0 + i;
-            const uint32_t node = a.subset ? a.subset[scan] : scan;
-            if (!score_valid(d)) {
-                bad = 1; // Candidate::try_new rejects the score (model.rs:21-29)
-            } else if (pair_less(d, node, thr_s, thr_i)) {
-                uint32_t slot = atomicAdd(&cnt, 1u);
-                ps[slot] = d;
-                pi[slot] = node;
+    // segments of 1024 scores: one 16-byte load per thread, pushes through an LDS counter, ONE barrier
+    // per segment; the pool (2048) is re-sorted and cut back to k whenever it is more than half full,
+    // so a segment can never overflow it
+    const bool vec_ok = (a.chunk_ld & 3u) == 0u;
+    for (uint32_t base = 0; base < a.rows; base += 1024) {
+        const uint32_t i0 = base + (uint32_t)tid * 4u;
+        float d4[4] = {inf, inf, inf, inf};
+        if (vec_ok && i0 + 3 < a.rows) {
+            const float4 v = *reinterpret_cast<const float4 *>(dq + i0);
+            d4[0] = v.x; d4[1] = v.y; d4[2] = v.z; d4[3] = v.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (i0 + e < a.rows) d4[e] = dq[i0 + e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t i = i0 + (uint32_t)e;
+            if (i < a.rows) {
+                float d = d4[e];
+                const uint32_t scan = a.row0 + i;
+                const uint32_t node = a.subset ? a.subset[scan] : scan;
+                if (!score_valid(d)) {
+                    bad = 1; // Candidate::try_new rejects the score (model.rs:21-29)
+                } else if (pair_less(d, node, thr_s, thr_i)) {
+                    uint32_t slot = atomicAdd(&cnt, 1u);
+                    ps[slot] = d;
+                    pi[slot] = node;
+                }
             }
         }
         __syncthreads();
-        if (cnt > (uint32_t)(kPool - 256)) {
+        if (cnt > (uint32_t)(kPool / 2)) {
             bitonic_sort_pool(ps, pi, tid);
             const uint32_t keep = cnt < k ? cnt : k;
             for (int t = tid; t < kPool; t += 256)

@@ -98,6 +98,13 @@ def lib():
     L.hvx_search_restricted_batch.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp, C.POINTER(Stats)]
     L.hvx_merge_topk_device.restype = C.c_int
     L.hvx_merge_topk_device.argtypes = [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.hvx_simhasher_new.restype = C.c_int
+    L.hvx_simhasher_new.argtypes = [C.c_uint32, C.c_uint64, C.c_int32, C.POINTER(_vp)]
+    L.hvx_simhasher_free.argtypes = [_vp]
+    L.hvx_simhash_batch.restype = C.c_int
+    L.hvx_simhash_batch.argtypes = [_vp, _vp, C.c_uint64, _vp]
+    L.hvx_order_code_from_simhash_bits.restype = C.c_uint64
+    L.hvx_order_code_from_simhash_bits.argtypes = [C.c_uint64]
     L.hvx_csr_import.restype = C.c_int
     L.hvx_csr_import.argtypes = [C.c_uint64, C.c_uint64, _vp, _vp, _vp, C.c_int32, C.POINTER(_vp)]
     L.hvx_csr_free.argtypes = [_vp]
@@ -326,3 +333,37 @@ class Graph:
         words = np.zeros((self.n + 63) // 64, np.uint64)
         _check(lib().hvx_expand_filter(self._h, _ptr(s), s.size, direction, _ptr(lab), lab.size, _ptr(words)))
         return words
+
+
+class SimHasher:
+    """unaligned_vector/simhash.rs SimHasher::new_with_seed / hash_from_slice, batched on the device."""
+
+    def __init__(self, dim, seed=42, device=-1):
+        self.dim = int(dim)
+        h = _vp()
+        _check(lib().hvx_simhasher_new(self.dim, int(seed), device, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h:
+            lib().hvx_simhasher_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def hash_batch(self, vectors) -> np.ndarray:
+        v = np.ascontiguousarray(vectors, dtype=np.float32).reshape(-1, self.dim)
+        out = np.zeros(v.shape[0], np.uint64)
+        _check(lib().hvx_simhash_batch(self._h, _ptr(v), v.shape[0], _ptr(out)))
+        return out
+
+    def hash(self, vector) -> int:
+        return int(self.hash_batch(np.asarray(vector, np.float32).reshape(1, -1))[0])
+
+
+def order_code_from_simhash_bits(bits: int) -> int:
+    return int(lib().hvx_order_code_from_simhash_bits(int(bits)))

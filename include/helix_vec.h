@@ -175,6 +175,17 @@ int hvx_traverse_filter(const hvx_csr *, const uint64_t *seeds, uint32_t n_seeds
 int hvx_expand_filter(const hvx_csr *, const uint64_t *rows, uint32_t n_rows, uint32_t direction,
                       const uint32_t *allowed_label_ids, uint32_t n_labels, uint64_t *out_bitmap_words);
 
+/*
+ * SimHash projections (crates/db/src/search/vector/unaligned_vector/simhash.rs:123-178 SimHasher::new_with_seed,
+ * :263-291 hash_from_slice; simhash.rs:44-59 order_code_from_simhash_bits, which keys the canonical vector rows
+ * `[0xF1][index_id][0x02][order_code][node_id]`).  `vectors` is [n][dim] f32 in host or device memory.
+ */
+typedef struct hvx_simhasher hvx_simhasher;
+int hvx_simhasher_new(uint32_t dim, uint64_t seed, int32_t device, hvx_simhasher **out);
+void hvx_simhasher_free(hvx_simhasher *);
+int hvx_simhash_batch(const hvx_simhasher *, const float *vectors, uint64_t n, uint64_t *out_bits /*[n] host*/);
+uint64_t hvx_order_code_from_simhash_bits(uint64_t bits);
+
 const char *hvx_last_error(void); /* thread-local */
 const char *hvx_version(void);
 

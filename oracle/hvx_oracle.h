@@ -125,6 +125,14 @@ int orc_flat_search_matrix(int metric, int kernel, const float *rows, uint64_t n
                            const float *query, uint32_t k, uint64_t *out_ids, float *out_scores,
                            uint32_t *out_count);
 
+/* ---- SimHash projections (hvx_oracle_simhash.c): unaligned_vector/simhash.rs, simhash.rs:44-59 ---- */
+void orc_stdrng_u32(uint64_t seed, uint32_t *out, uint32_t n);            /* rand 0.10 StdRng stream (pinned by KAT) */
+int orc_simhash_planes(uint32_t dim, uint64_t seed, float *planes /*[64][dim]*/);
+uint64_t orc_simhash_hash(const float *planes, const float *vec, uint32_t dim);
+uint64_t orc_order_code(uint64_t bits);
+uint32_t orc_simhash_collisions(uint64_t a, uint64_t b);
+uint64_t orc_query_seed(uint64_t query_simhash, uint64_t entry_point, uint64_t ef);
+
 #ifdef __cplusplus
 }
 #endif

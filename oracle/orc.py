@@ -121,6 +121,10 @@ def _extra_signatures(L):
         L.orc_order_code.argtypes = [C.c_uint64]
         L.orc_stdrng_u32.restype = None
         L.orc_stdrng_u32.argtypes = [C.c_uint64, u32p, C.c_uint32]
+        L.orc_simhash_collisions.restype = C.c_uint32
+        L.orc_simhash_collisions.argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_query_seed.restype = C.c_uint64
+        L.orc_query_seed.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
     if hasattr(L, "orc_traverse"):
         L.orc_traverse.restype = C.c_int64
     if hasattr(L, "orc_search_restricted"):
@@ -283,3 +287,22 @@ def select_layer(ml, uniform):
 
 def default_ml(m):
     return np.float32(lib().orc_default_ml_for_m(m))
+
+
+class SimHasher:
+    """unaligned_vector/simhash.rs SimHasher::new_with_seed + hash_from_slice."""
+
+    def __init__(self, dim, seed=42):
+        self.dim = dim
+        self.planes = np.zeros((64, dim), np.float32)
+        rc = lib().orc_simhash_planes(dim, seed, self.planes.ctypes.data_as(f32p))
+        assert rc == OK
+
+    def hash(self, vec):
+        v, pv = _f(vec)
+        assert v.size == self.dim
+        return int(lib().orc_simhash_hash(self.planes.ctypes.data_as(f32p), pv, self.dim))
+
+
+def order_code(bits):
+    return int(lib().orc_order_code(bits))

@@ -489,3 +489,19 @@ def test_fp8_exact_scan_is_bit_exact_on_the_dequantised_rows(orc, hv, n, dim, me
     with pytest.raises(hv.HelixDbError) as e:  # HNSW over fp8 rows is not built: fails loudly
         gix.search_batch(q[:1], hv.SearchParams(k))
     assert e.value.status == hv.ERR_UNSUPPORTED
+
+
+def test_simhash_on_device_matches_reference_known_answer_and_oracle(orc, hv):
+    """a16: the device SimHasher reproduces the reference KAT (simhash_registry.rs:344-362) and the oracle on
+    random vectors (incl. a dimension that is not a multiple of anything), and the order code (simhash.rs:314-329)."""
+    assert hv.SimHasher(3, 42).hash([1.0, 2.0, 3.0]) == 0x6D91_A757_8862_6786
+    rng = np.random.default_rng(8)
+    for dim, seed in [(3, 42), (128, 42), (768, 7), (100, 123456789)]:
+        dh, oh = hv.SimHasher(dim, seed), orc.SimHasher(dim, seed)
+        v = rng.standard_normal((257, dim)).astype(np.float32)
+        v[5] = 0.0  # all dots are 0 -> no bit set
+        got = dh.hash_batch(v)
+        assert got.tolist() == [oh.hash(v[i]) for i in range(v.shape[0])]
+        assert got[5] == 0
+    for bits in (0, (1 << 64) - 1, 1 << 63, 1 << 47, 1 << 31, 1 << 15, 0x6D91_A757_8862_6786):
+        assert hv.order_code_from_simhash_bits(bits) == orc.order_code(bits)

@@ -253,3 +253,30 @@ def test_built_graph_invariants_and_recall(orc):
         _, t, _ = ix.flat(q, 10)
         got.append(g); truth.append(t)
     assert fx.recall_at_k(got, truth) >= 0.9
+
+
+# --- src/search/vector/simhash_registry.rs:344-362: pins the third-party RNG (rand 0.10 StdRng = ChaCha12
+#     keyed through seed_from_u64's PCG32 expansion) and the whole projection pipeline ---
+def test_simhash_known_answer_pins_stdrng_and_projections(orc):
+    assert orc.SimHasher(3, 42).hash([1.0, 2.0, 3.0]) == 0x6D91_A757_8862_6786
+    h = orc.SimHasher(3, 42)
+    assert np.allclose(np.linalg.norm(h.planes.astype(np.float64), axis=1), 1.0, atol=1e-6)  # unit hyperplanes
+    assert orc.SimHasher(3, 43).hash([1.0, 2.0, 3.0]) != 0x6D91_A757_8862_6786
+
+
+# --- src/search/vector/simhash.rs:314-329 ---
+def test_order_code_from_simhash_bits(orc):
+    assert orc.order_code(0) == 0 and orc.order_code((1 << 64) - 1) == (1 << 64) - 1
+    assert orc.order_code(1 << 63) == 1 << 63
+    assert orc.order_code(1 << 47) == 1 << 62
+    assert orc.order_code(1 << 31) == 1 << 61
+    assert orc.order_code(1 << 15) == 1 << 60
+
+
+# --- src/search/vector/randomness.rs:194-207, unaligned_vector/simhash.rs:36-55 ---
+def test_query_seed_and_collision_count(orc):
+    bits, entry, ef = 0x0123_4567_89AB_CDEF, 42, 128
+    rotl = lambda v, n: ((v << n) | (v >> (64 - n))) & ((1 << 64) - 1)
+    assert orc.lib().orc_query_seed(bits, entry, ef) == bits ^ rotl(entry, 17) ^ rotl(ef, 7)
+    assert orc.lib().orc_simhash_collisions(0, 0) == 64 and orc.lib().orc_simhash_collisions(0, (1 << 64) - 1) == 0
+    assert orc.lib().orc_simhash_collisions(0b1011, 0b0001) == 62

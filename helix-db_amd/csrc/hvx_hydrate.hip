@@ -1,0 +1,239 @@
+// hvx_hydrate.hip -- hydrating a device index from HelixDB's persisted vector rows.
+//
+// Host-only code: the value codecs of the rows the search path reads, and a hydrator that collects decoded
+// rows and hands the dense image to hvx_index_import (the role VectorMemoryStore hydration plays for the
+// reference's resident cache, memory_store.rs:97-105).  Formats restated from the reference
+// (paths under crates/db/src/encoding/v1/):
+//   layer-0 neighbours  values/vectors.rs:29-44,97-210   [0x12][count u32 BE][id u64 BE ...]  |
+//                                                        [0x13][flags][count u32 BE][simhash u64 LE if flags&1][ids ...] | empty
+//   upper neighbours    values/vectors/neighbors.rs:57-110  [count u32 BE][id u64 BE ...] (exact length)
+//   vector item         values/vectors/item.rs:34-60 + distance/{cosine,euclidean}.rs headers:
+//                       [header f32 native-endian][dim x f32 native-endian]
+//   keys                keys/vectors.rs:23-50: [0xF1][index_id u64 BE][0x02][order_code u64 BE][node_id u64 BE] (item),
+//                       [0xF0][index_id][0x16][node_id] (layer 0), [0xF0][index_id][0x11][layer u16 BE][node_id] (upper)
+// The rkyv-archived VectorIndexMetadata row is not decoded here: the host passes entry point / max layer.
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "hvx_host.h"
+
+using namespace hvx;
+
+namespace {
+
+inline uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+inline uint64_t be64(const uint8_t *p) { return ((uint64_t)be32(p) << 32) | be32(p + 4); }
+inline uint64_t le64(const uint8_t *p) {
+    uint64_t v;
+    memcpy(&v, p, 8); // little-endian host
+    return v;
+}
+
+int decode_ids(const uint8_t *p, size_t len, uint64_t count, std::vector<uint64_t> &out) {
+    if (count > (SIZE_MAX - 16) / 8 || len != count * 8) return fail(HVX_ERR_INVARIANT, "neighbour row length %zu does not match its count %llu", len, (unsigned long long)count);
+    out.resize(count);
+    for (uint64_t i = 0; i < count; ++i) out[i] = be64(p + 8 * i);
+    return HVX_OK;
+}
+
+// decode_layer0_neighbors_and_simhash (values/vectors.rs:187-210)
+int decode_layer0(const uint8_t *v, size_t len, std::vector<uint64_t> &ids, bool &has_sh, uint64_t &sh) {
+    ids.clear();
+    has_sh = false;
+    sh = 0;
+    if (len == 0) return HVX_OK; // empty compatibility value
+    if (v[0] == 0x12) {
+        if (len < 5) return fail(HVX_ERR_INVARIANT, "layer-0 row shorter than its header");
+        return decode_ids(v + 5, len - 5, be32(v + 1), ids);
+    }
+    if (v[0] == 0x13) {
+        if (len < 6) return fail(HVX_ERR_INVARIANT, "layer-0 record shorter than its header");
+        const uint8_t flags = v[1];
+        if (flags & ~1u) return fail(HVX_ERR_INVARIANT, "invalid layer-0 record flags: 0x%02x", flags);
+        size_t off = 6;
+        if (flags & 1u) {
+            if (len < off + 8) return fail(HVX_ERR_INVARIANT, "layer-0 record truncated inside its SimHash");
+            sh = le64(v + off);
+            has_sh = true;
+            off += 8;
+        }
+        return decode_ids(v + off, len - off, be32(v + 2), ids);
+    }
+    return fail(HVX_ERR_INVARIANT, "invalid layer-0 encoding type 0x%02x", v[0]);
+}
+
+} // namespace
+
+struct hvx_hydrator {
+    uint32_t dim = 0, metric = 0;
+    struct Node {
+        std::vector<float> vec;
+        float header = 0.f;
+        bool has_vec = false, has_l0 = false;
+        std::vector<uint64_t> l0;
+        std::map<uint16_t, std::vector<uint64_t>> upper;
+    };
+    std::map<uint64_t, Node> nodes; // ordered by node id
+    bool has_entry = false;
+    uint64_t entry = 0;
+    uint32_t max_layer = 0;
+};
+
+extern "C" int hvx_decode_layer0_row(const uint8_t *value, size_t len, uint64_t *out_ids, uint32_t cap, uint32_t *out_count,
+                                     uint64_t *out_simhash, uint32_t *out_has_simhash) {
+    std::vector<uint64_t> ids;
+    bool has;
+    uint64_t sh;
+    int rc = decode_layer0(value, len, ids, has, sh);
+    if (rc) return rc;
+    if (out_count) *out_count = (uint32_t)ids.size();
+    if (out_has_simhash) *out_has_simhash = has ? 1u : 0u;
+    if (out_simhash) *out_simhash = sh;
+    if (ids.size() > cap) return fail(HVX_ERR_INVARIANT, "layer-0 row holds %zu ids, buffer %u", ids.size(), cap);
+    if (out_ids && !ids.empty()) memcpy(out_ids, ids.data(), ids.size() * 8);
+    return HVX_OK;
+}
+
+// decode_upper_neighbors (values/vectors/neighbors.rs:79-110)
+extern "C" int hvx_decode_upper_row(const uint8_t *value, size_t len, uint64_t *out_ids, uint32_t cap, uint32_t *out_count) {
+    if (len < 4) return fail(HVX_ERR_INVARIANT, "upper-layer row shorter than its count");
+    std::vector<uint64_t> ids;
+    int rc = decode_ids(value + 4, len - 4, be32(value), ids);
+    if (rc) return rc;
+    if (out_count) *out_count = (uint32_t)ids.size();
+    if (ids.size() > cap) return fail(HVX_ERR_INVARIANT, "upper row holds %zu ids, buffer %u", ids.size(), cap);
+    if (out_ids && !ids.empty()) memcpy(out_ids, ids.data(), ids.size() * 8);
+    return HVX_OK;
+}
+
+// keys/vectors.rs: returns the key kind (0x02 item, 0x16 layer 0, 0x11 upper) or 0 when the key is none of them
+extern "C" uint32_t hvx_parse_vector_key(const uint8_t *key, size_t len, uint64_t *index_id, uint64_t *node_id, uint64_t *order_code,
+                                         uint32_t *layer) {
+    if (len < 10) return 0;
+    const uint8_t ks = key[0], kind = key[9];
+    if (index_id) *index_id = be64(key + 1);
+    if (ks == 0xF1 && kind == 0x02 && len == 26) {
+        if (order_code) *order_code = be64(key + 10);
+        if (node_id) *node_id = be64(key + 18);
+        return 0x02;
+    }
+    if (ks == 0xF0 && kind == 0x16 && len == 18) {
+        if (node_id) *node_id = be64(key + 10);
+        return 0x16;
+    }
+    if (ks == 0xF0 && kind == 0x11 && len == 20) {
+        if (layer) *layer = ((uint32_t)key[10] << 8) | key[11];
+        if (node_id) *node_id = be64(key + 12);
+        return 0x11;
+    }
+    return 0;
+}
+
+extern "C" int hvx_hydrator_new(uint32_t dim, uint32_t metric, hvx_hydrator **out) {
+    if (!out) return fail(HVX_ERR_INVARIANT, "null argument");
+    *out = nullptr;
+    if (dim == 0) return fail(HVX_ERR_DIMENSION, "dimension must be non-zero");
+    if (metric > HVX_MANHATTAN) return fail(HVX_ERR_UNSUPPORTED, "unknown metric %u", metric);
+    hvx_hydrator *h = new hvx_hydrator();
+    h->dim = dim;
+    h->metric = metric;
+    *out = h;
+    return HVX_OK;
+}
+
+extern "C" void hvx_hydrator_free(hvx_hydrator *h) { delete h; }
+
+// item row = [header: f32][dim x f32], native-endian (values/vectors/item.rs:34-60; mod.rs:873-877)
+extern "C" int hvx_hydrator_add_item(hvx_hydrator *h, uint64_t node_id, const uint8_t *value, size_t len) {
+    if (!h || !value) return fail(HVX_ERR_INVARIANT, "null argument");
+    if (len != 4 + (size_t)h->dim * 4) return fail(HVX_ERR_DIMENSION, "vector row of node %llu has %zu bytes, expected %zu", (unsigned long long)node_id, len, 4 + (size_t)h->dim * 4);
+    auto &n = h->nodes[node_id];
+    memcpy(&n.header, value, 4);
+    n.vec.resize(h->dim);
+    memcpy(n.vec.data(), value + 4, (size_t)h->dim * 4);
+    n.has_vec = true;
+    return HVX_OK;
+}
+
+extern "C" int hvx_hydrator_add_layer0_row(hvx_hydrator *h, uint64_t node_id, const uint8_t *value, size_t len) {
+    if (!h) return fail(HVX_ERR_INVARIANT, "null argument");
+    std::vector<uint64_t> ids;
+    bool has;
+    uint64_t sh;
+    int rc = decode_layer0(value, len, ids, has, sh);
+    if (rc) return rc;
+    // runtime canonicalisation (neighbor_set.rs:1-9): ascending, deduped, self-free
+    std::sort(ids.begin(), ids.end());
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    ids.erase(std::remove(ids.begin(), ids.end(), node_id), ids.end());
+    auto &n = h->nodes[node_id];
+    n.l0 = std::move(ids);
+    n.has_l0 = true;
+    return HVX_OK;
+}
+
+extern "C" int hvx_hydrator_add_upper_row(hvx_hydrator *h, uint64_t node_id, uint32_t layer, const uint8_t *value, size_t len) {
+    if (!h) return fail(HVX_ERR_INVARIANT, "null argument");
+    if (layer == 0 || layer > 63) return fail(HVX_ERR_INVARIANT, "upper row with layer %u", layer);
+    if (len < 4) return fail(HVX_ERR_INVARIANT, "upper-layer row shorter than its count");
+    std::vector<uint64_t> ids;
+    int rc = decode_ids(value + 4, len - 4, be32(value), ids);
+    if (rc) return rc;
+    std::sort(ids.begin(), ids.end()); // historical rows may be distance-ordered; the runtime re-sorts
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    ids.erase(std::remove(ids.begin(), ids.end(), node_id), ids.end());
+    h->nodes[node_id].upper[(uint16_t)layer] = std::move(ids);
+    return HVX_OK;
+}
+
+extern "C" int hvx_hydrator_set_entry(hvx_hydrator *h, uint64_t entry_point, uint32_t max_layer) {
+    if (!h) return fail(HVX_ERR_INVARIANT, "null argument");
+    h->has_entry = true;
+    h->entry = entry_point;
+    h->max_layer = max_layer;
+    return HVX_OK;
+}
+
+extern "C" int hvx_hydrator_finish(const hvx_hydrator *h, const hvx_index_desc *tmpl, hvx_index **out) {
+    if (!h || !tmpl || !out) return fail(HVX_ERR_INVARIANT, "null argument");
+    // every node must have its canonical vector row; neighbour ids without a vector row are dangling and
+    // dropped (the reference skips missing rows silently: search.rs:848-914)
+    std::vector<uint64_t> ids;
+    for (auto &kv : h->nodes)
+        if (kv.second.has_vec) ids.push_back(kv.first);
+    const uint64_t n = ids.size();
+    std::vector<float> vecs((size_t)n * h->dim);
+    std::vector<uint64_t> l0_off(n + 1, 0), l0_nb, up_off(1, 0), up_nb;
+    std::vector<uint16_t> level(n, 0);
+    auto known = [&](uint64_t id) { return std::binary_search(ids.begin(), ids.end(), id); };
+    for (uint64_t i = 0; i < n; ++i) {
+        const auto &nd = h->nodes.at(ids[i]);
+        memcpy(&vecs[(size_t)i * h->dim], nd.vec.data(), (size_t)h->dim * 4);
+        for (uint64_t x : nd.l0)
+            if (known(x)) l0_nb.push_back(x);
+        l0_off[i + 1] = l0_nb.size();
+        uint16_t top = 0;
+        for (auto &u : nd.upper) top = std::max(top, u.first);
+        level[i] = top;
+        for (uint16_t l = 1; l <= top; ++l) {
+            auto it = nd.upper.find(l);
+            if (it != nd.upper.end())
+                for (uint64_t x : it->second)
+                    if (known(x)) up_nb.push_back(x);
+            up_off.push_back(up_nb.size());
+        }
+    }
+    hvx_index_desc d = *tmpl;
+    d.dim = h->dim;
+    d.metric = h->metric;
+    d.n = n;
+    d.has_entry = (h->has_entry && n) ? 1u : 0u;
+    d.entry_point = h->entry;
+    d.max_layer = h->max_layer;
+    if (n) { d.shard_id_lo = ids.front(); d.shard_id_hi = ids.back(); }
+    if (l0_nb.empty()) l0_nb.push_back(0);
+    if (up_nb.empty()) up_nb.push_back(0);
+    return hvx_index_import(&d, ids.data(), vecs.data(), l0_off.data(), l0_nb.data(), level.data(), up_off.data(), up_nb.data(), out);
+}

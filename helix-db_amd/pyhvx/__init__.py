@@ -105,6 +105,25 @@ def lib():
     L.hvx_simhash_batch.argtypes = [_vp, _vp, C.c_uint64, _vp]
     L.hvx_order_code_from_simhash_bits.restype = C.c_uint64
     L.hvx_order_code_from_simhash_bits.argtypes = [C.c_uint64]
+    L.hvx_decode_layer0_row.restype = C.c_int
+    L.hvx_decode_layer0_row.argtypes = [C.c_char_p, C.c_size_t, _vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    L.hvx_decode_upper_row.restype = C.c_int
+    L.hvx_decode_upper_row.argtypes = [C.c_char_p, C.c_size_t, _vp, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.hvx_parse_vector_key.restype = C.c_uint32
+    L.hvx_parse_vector_key.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    L.hvx_hydrator_new.restype = C.c_int
+    L.hvx_hydrator_new.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(_vp)]
+    L.hvx_hydrator_free.argtypes = [_vp]
+    L.hvx_hydrator_add_item.restype = C.c_int
+    L.hvx_hydrator_add_item.argtypes = [_vp, C.c_uint64, C.c_char_p, C.c_size_t]
+    L.hvx_hydrator_add_layer0_row.restype = C.c_int
+    L.hvx_hydrator_add_layer0_row.argtypes = [_vp, C.c_uint64, C.c_char_p, C.c_size_t]
+    L.hvx_hydrator_add_upper_row.restype = C.c_int
+    L.hvx_hydrator_add_upper_row.argtypes = [_vp, C.c_uint64, C.c_uint32, C.c_char_p, C.c_size_t]
+    L.hvx_hydrator_set_entry.restype = C.c_int
+    L.hvx_hydrator_set_entry.argtypes = [_vp, C.c_uint64, C.c_uint32]
+    L.hvx_hydrator_finish.restype = C.c_int
+    L.hvx_hydrator_finish.argtypes = [_vp, C.POINTER(_Desc), C.POINTER(_vp)]
     L.hvx_csr_import.restype = C.c_int
     L.hvx_csr_import.argtypes = [C.c_uint64, C.c_uint64, _vp, _vp, _vp, C.c_int32, C.POINTER(_vp)]
     L.hvx_csr_free.argtypes = [_vp]
@@ -367,3 +386,62 @@ class SimHasher:
 
 def order_code_from_simhash_bits(bits: int) -> int:
     return int(lib().hvx_order_code_from_simhash_bits(int(bits)))
+
+
+def decode_layer0_row(value: bytes):
+    """values/vectors.rs:187-210 decode_layer0_neighbors_and_simhash -> (ids, simhash or None)."""
+    ids = np.zeros(max(len(value) // 8 + 1, 1), np.uint64)
+    cnt, sh, has = C.c_uint32(0), C.c_uint64(0), C.c_uint32(0)
+    _check(lib().hvx_decode_layer0_row(value, len(value), _ptr(ids), ids.size, C.byref(cnt), C.byref(sh), C.byref(has)))
+    return ids[: cnt.value].tolist(), (int(sh.value) if has.value else None)
+
+
+def decode_upper_row(value: bytes):
+    """values/vectors/neighbors.rs:79-110 decode_upper_neighbors."""
+    ids = np.zeros(max(len(value) // 8 + 1, 1), np.uint64)
+    cnt = C.c_uint32(0)
+    _check(lib().hvx_decode_upper_row(value, len(value), _ptr(ids), ids.size, C.byref(cnt)))
+    return ids[: cnt.value].tolist()
+
+
+def parse_vector_key(key: bytes):
+    """keys/vectors.rs: -> dict(kind, index_id, node_id, order_code, layer) or None."""
+    ix, nd, oc, ly = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
+    kind = lib().hvx_parse_vector_key(key, len(key), C.byref(ix), C.byref(nd), C.byref(oc), C.byref(ly))
+    if not kind:
+        return None
+    return dict(kind=int(kind), index_id=int(ix.value), node_id=int(nd.value), order_code=int(oc.value), layer=int(ly.value))
+
+
+class Hydrator:
+    """Collects persisted rows (value bytes as stored by HelixDB) and imports them as a device index."""
+
+    def __init__(self, dim, metric):
+        self.dim, self.metric = dim, metric
+        h = _vp()
+        _check(lib().hvx_hydrator_new(dim, metric, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().hvx_hydrator_free(self._h)
+            self._h = None
+
+    def add_item(self, node_id, value: bytes):
+        _check(lib().hvx_hydrator_add_item(self._h, int(node_id), value, len(value)))
+
+    def add_layer0_row(self, node_id, value: bytes):
+        _check(lib().hvx_hydrator_add_layer0_row(self._h, int(node_id), value, len(value)))
+
+    def add_upper_row(self, node_id, layer, value: bytes):
+        _check(lib().hvx_hydrator_add_upper_row(self._h, int(node_id), int(layer), value, len(value)))
+
+    def set_entry(self, entry_point, max_layer):
+        _check(lib().hvx_hydrator_set_entry(self._h, int(entry_point), int(max_layer)))
+
+    def finish(self, *, m=16, m0=32, float_kernel=KERNEL_AVX_FMA, device=-1, max_batch=1024, dtype=F32):
+        d = _Desc(dim=self.dim, metric=self.metric, dtype=dtype, float_kernel=float_kernel, n=0, m=m, m0=m0, has_entry=0,
+                  max_layer=0, entry_point=0, shard_id_lo=0, shard_id_hi=0, device=device, max_batch=max_batch)
+        h = _vp()
+        _check(lib().hvx_hydrator_finish(self._h, C.byref(d), C.byref(h)))
+        return ValidatedVectorReadIndex(h, self.dim, self.metric, -1)

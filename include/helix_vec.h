@@ -186,6 +186,28 @@ void hvx_simhasher_free(hvx_simhasher *);
 int hvx_simhash_batch(const hvx_simhasher *, const float *vectors, uint64_t n, uint64_t *out_bits /*[n] host*/);
 uint64_t hvx_order_code_from_simhash_bits(uint64_t bits);
 
+/*
+ * Hydration from HelixDB's persisted rows (replaces VectorMemoryStore hydration, memory_store.rs:97-105).
+ * Value codecs restated from crates/db/src/encoding/v1/values/vectors.rs:97-210 (layer-0 rows, tags 0x12 / 0x13, empty),
+ * values/vectors/neighbors.rs:57-110 (upper rows), values/vectors/item.rs:34-60 (header f32 + dim f32, native-endian);
+ * keys from keys/vectors.rs:23-50.  The rkyv metadata row is not decoded: pass entry point / max layer explicitly.
+ */
+typedef struct hvx_hydrator hvx_hydrator;
+int hvx_decode_layer0_row(const uint8_t *value, size_t len, uint64_t *out_ids, uint32_t cap, uint32_t *out_count,
+                          uint64_t *out_simhash, uint32_t *out_has_simhash);
+int hvx_decode_upper_row(const uint8_t *value, size_t len, uint64_t *out_ids, uint32_t cap, uint32_t *out_count);
+/* returns the key kind (0x02 canonical vector, 0x16 layer-0 neighbours, 0x11 upper neighbours) or 0 */
+uint32_t hvx_parse_vector_key(const uint8_t *key, size_t len, uint64_t *index_id, uint64_t *node_id, uint64_t *order_code,
+                              uint32_t *layer);
+int hvx_hydrator_new(uint32_t dim, uint32_t metric, hvx_hydrator **out);
+void hvx_hydrator_free(hvx_hydrator *);
+int hvx_hydrator_add_item(hvx_hydrator *, uint64_t node_id, const uint8_t *value, size_t len);
+int hvx_hydrator_add_layer0_row(hvx_hydrator *, uint64_t node_id, const uint8_t *value, size_t len);
+int hvx_hydrator_add_upper_row(hvx_hydrator *, uint64_t node_id, uint32_t layer, const uint8_t *value, size_t len);
+int hvx_hydrator_set_entry(hvx_hydrator *, uint64_t entry_point, uint32_t max_layer);
+/* `tmpl` supplies dtype, float_kernel, m, m0, device, max_batch; the rest comes from the collected rows */
+int hvx_hydrator_finish(const hvx_hydrator *, const hvx_index_desc *tmpl, hvx_index **out);
+
 const char *hvx_last_error(void); /* thread-local */
 const char *hvx_version(void);
 

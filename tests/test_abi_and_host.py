@@ -77,3 +77,44 @@ def test_no_product_code_references_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "hvx_oracle" not in txt and "import orc" not in txt and "oracle/" not in txt, f
+
+
+# --- persisted row codecs: the reference's own wire-layout tests (encoding/v1/values/vectors.rs:214-330,
+#     values/vectors/neighbors.rs) restated byte for byte ---
+def _be64(*ids):
+    return b"".join(int(i).to_bytes(8, "big") for i in ids)
+
+
+def test_layer0_row_codec_matches_reference_wire_layouts():
+    import pyhvx as hv
+    assert hv.decode_layer0_row(bytes([0x12, 0, 0, 0, 0])) == ([], None)              # zero neighbours, exact layout
+    assert hv.decode_layer0_row(bytes([0x12, 0, 0, 0, 2]) + _be64(3, 7)) == ([3, 7], None)
+    rec = bytes([0x13, 0x01, 0, 0, 0, 2]) + (0x0102_0304_0506_0708).to_bytes(8, "little") + _be64(1, 9)
+    assert hv.decode_layer0_row(rec) == ([1, 9], 0x0102_0304_0506_0708)
+    assert hv.decode_layer0_row(bytes([0x13, 0, 0, 0, 0, 2]) + _be64(1, 9)) == ([1, 9], None)
+    assert hv.decode_layer0_row(b"") == ([], None)                                    # empty compatibility value
+    assert hv.decode_layer0_row(bytes([0x12, 0, 0, 0, 2]) + _be64(0, (1 << 64) - 1)) == ([0, (1 << 64) - 1], None)
+    for bad in (bytes([0x14, 0, 0, 0, 0]),                       # InvalidEncodingType
+                bytes([0x13, 0x02, 0, 0, 0, 0]),                 # invalid flags
+                bytes([0x12, 0, 0, 0, 2]) + _be64(3),            # count says 2, one id present
+                bytes([0x12, 0, 0, 0, 1]) + _be64(3) + b"x",     # trailing byte
+                bytes([0x13, 0x01, 0, 0, 0, 0, 1, 2, 3])):       # truncated SimHash
+        with pytest.raises(hv.HelixDbError):
+            hv.decode_layer0_row(bad)
+
+
+def test_upper_row_codec_and_keys():
+    import pyhvx as hv
+    assert hv.decode_upper_row((2).to_bytes(4, "big") + _be64(9, 1)) == [9, 1]      # order preserved by the codec
+    assert hv.decode_upper_row((0).to_bytes(4, "big")) == []
+    for bad in (b"\x00\x00", (2).to_bytes(4, "big") + _be64(9), (1).to_bytes(4, "big") + _be64(9) + b"z"):
+        with pytest.raises(hv.HelixDbError):
+            hv.decode_upper_row(bad)
+    ix = (77).to_bytes(8, "big")
+    k = hv.parse_vector_key(bytes([0xF1]) + ix + bytes([0x02]) + (0xABCD).to_bytes(8, "big") + (5).to_bytes(8, "big"))
+    assert k == dict(kind=0x02, index_id=77, node_id=5, order_code=0xABCD, layer=0)
+    k = hv.parse_vector_key(bytes([0xF0]) + ix + bytes([0x16]) + (5).to_bytes(8, "big"))
+    assert k["kind"] == 0x16 and k["node_id"] == 5
+    k = hv.parse_vector_key(bytes([0xF0]) + ix + bytes([0x11]) + (3).to_bytes(2, "big") + (5).to_bytes(8, "big"))
+    assert k["kind"] == 0x11 and k["layer"] == 3 and k["node_id"] == 5
+    assert hv.parse_vector_key(bytes([0xF0]) + ix + bytes([0x12]) + (5).to_bytes(8, "big")) is None  # SimHash row: not a search row

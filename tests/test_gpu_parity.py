@@ -505,3 +505,37 @@ def test_simhash_on_device_matches_reference_known_answer_and_oracle(orc, hv):
         assert got[5] == 0
     for bits in (0, (1 << 64) - 1, 1 << 63, 1 << 47, 1 << 31, 1 << 15, 0x6D91_A757_8862_6786):
         assert hv.order_code_from_simhash_bits(bits) == orc.order_code(bits)
+
+
+def test_hydration_from_persisted_rows_equals_direct_import(orc, hv):
+    """an index hydrated from HelixDB's persisted value bytes (item rows, layer-0 rows in both tagged
+    formats, upper rows in historical distance order, a dangling neighbour) searches exactly like the oracle."""
+    n, dim = 600, 128
+    rng = np.random.default_rng(21)
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    lv = fx.draw_levels(n, 16, seed=9)
+    ids = np.arange(n, dtype=np.uint64) * 5 + 3
+    oix = build_oracle(orc, data, orc.L2SQ, lv, efc=60, ids=ids)
+    ex = oix.export()
+    hy = hv.Hydrator(dim, hv.EUCLIDEAN)
+    be = lambda xs: b"".join(int(x).to_bytes(8, "big") for x in xs)
+    up_row = 0
+    for i in range(n):
+        nid = int(ex["node_ids"][i])
+        hy.add_item(nid, np.float32(0).tobytes() + ex["vectors"][i].tobytes())     # Euclidean header = bias 0.0
+        nb = ex["l0_neighbors"][int(ex["l0_offsets"][i]):int(ex["l0_offsets"][i + 1])].tolist()
+        if i % 3 == 0:
+            row = bytes([0x13, 0x01]) + len(nb).to_bytes(4, "big") + (0x1234 + i).to_bytes(8, "little") + be(nb)
+        elif i % 3 == 1:
+            row = bytes([0x12]) + (len(nb) + 1).to_bytes(4, "big") + be(nb + [999_999_999])  # dangling id: no vector row
+        else:
+            row = bytes([0x12]) + len(nb).to_bytes(4, "big") + be(nb)
+        hy.add_layer0_row(nid, row)
+        for layer in range(1, int(ex["level"][i]) + 1):
+            unb = ex["up_neighbors"][int(ex["up_offsets"][up_row]):int(ex["up_offsets"][up_row + 1])].tolist()
+            hy.add_upper_row(nid, layer, len(unb).to_bytes(4, "big") + be(unb[::-1]))  # historical (unsorted) order
+            up_row += 1
+    hy.set_entry(ex["entry_point"], ex["max_layer"])
+    gix = hy.finish()
+    q = rng.standard_normal((16, dim)).astype(np.float32)
+    assert_hnsw_equal(orc, hv, oix, gix, q, 10, 64)

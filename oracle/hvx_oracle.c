@@ -399,6 +399,11 @@ struct orc_index {
     uint64_t map_cap;
     uint64_t *map_key;
     uint32_t *map_val;
+    /* per-node SimHash rows + the hasher's hyperplanes (orc_index_set_simhash) */
+    uint64_t *simhash;
+    float *planes;
+    uint64_t simhash_seed;
+    int has_simhash;
 };
 
 #define NO_ROW UINT64_MAX
@@ -455,6 +460,7 @@ void orc_index_free(orc_index *ix) {
     if (!ix) return;
     free(ix->ids); free(ix->vec); free(ix->hdr); free(ix->level); free(ix->l0); free(ix->l0_deg);
     free(ix->up_base); free(ix->up); free(ix->up_deg); free(ix->map_key); free(ix->map_val);
+    free(ix->simhash); free(ix->planes);
     free(ix);
 }
 
@@ -1174,3 +1180,6 @@ int orc_index_export(const orc_index *ix, uint64_t *node_ids, float *vectors, ui
     free(ord);
     return ORC_OK;
 }
+
+/* non-strict layer-0 arms (SimHash filter, sampling, adaptive bypass) */
+#include "hvx_oracle_adaptive.inc"

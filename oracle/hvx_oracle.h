@@ -126,12 +126,113 @@ int orc_flat_search_matrix(int metric, int kernel, const float *rows, uint64_t n
                            uint32_t *out_count);
 
 /* ---- SimHash projections (hvx_oracle_simhash.c): unaligned_vector/simhash.rs, simhash.rs:44-59 ---- */
+void orc_stdrng_key(uint64_t seed, uint32_t key[8]);                       /* seed_from_u64 -> ChaCha key */
+void orc_chacha12_block(const uint32_t key[8], uint64_t counter, uint32_t out[16]);
 void orc_stdrng_u32(uint64_t seed, uint32_t *out, uint32_t n);            /* rand 0.10 StdRng stream (pinned by KAT) */
 int orc_simhash_planes(uint32_t dim, uint64_t seed, float *planes /*[64][dim]*/);
 uint64_t orc_simhash_hash(const float *planes, const float *vec, uint32_t dim);
 uint64_t orc_order_code(uint64_t bits);
 uint32_t orc_simhash_collisions(uint64_t a, uint64_t b);
 uint64_t orc_query_seed(uint64_t query_simhash, uint64_t entry_point, uint64_t ef);
+
+/* ---- non-strict layer-0 arms (hvx_oracle_adaptive.inc): policy.rs, search.rs:595-829, randomness.rs ---- */
+enum { ORC_SIMHASH_ALWAYS = 0, ORC_SIMHASH_ADAPTIVE = 1, ORC_SIMHASH_OFF = 2 };          /* mod.rs SimHashMode */
+enum { ORC_SAMPLING_EXHAUSTIVE = 0, ORC_SAMPLING_FIXED = 1, ORC_SAMPLING_ADAPTIVE = 2 }; /* policy.rs SamplingDecision */
+enum { ORC_BYPASS_READY = 0, ORC_BYPASS_BYPASSING = 1, ORC_BYPASS_COOLING = 2 };         /* policy.rs AdaptiveBypassState */
+enum { ORC_TRIGGER_NONE = 0, ORC_TRIGGER_READ_BUDGET = 1, ORC_TRIGGER_LOW_YIELD = 2, ORC_TRIGGER_BOTH = 3 };
+
+/* SearchParams (mod.rs:410-621) resolved against the index-level VectorConfig knobs
+ * (metadata.rs:38-44; defaults 43 / 0.8 / true / 0.1, mod.rs:313-329).  Overrides: < 0 means None. */
+typedef struct {
+    uint32_t k, ef;
+    uint32_t simhash_mode;
+    float pre_simhash_sampling_ratio_override;
+    uint32_t bypass_min_frontier, bypass_window_expansions;
+    float bypass_min_filter_rate;
+    uint32_t read_budget_multiplier;
+    float simhash_sampling_ratio_override;
+    float simhash_failure_prob_override;
+    /* index configuration */
+    uint32_t simhash_threshold;
+    float sampling_ratio;
+    uint32_t adaptive_enabled;
+    float adaptive_failure_prob;
+    /* 1: SimHash rows come from the resident snapshot (memory_store.rs:329-335: not counted as reads);
+     * 0: Uncached handle, every first-seen row is one stable-view read (memory_store.rs:338-347). */
+    uint32_t resident_simhash;
+    /* SearchRandomness::Seeded (test only, randomness.rs:94-96); 0 = QueryDerived */
+    uint32_t use_fixed_seed;
+    uint64_t fixed_seed;
+} orc_search_params;
+void orc_search_params_default(orc_search_params *p, uint32_t k); /* SearchParams::new(k) + default config */
+
+typedef struct {   /* SearchStats (mod.rs:629-700), the fields the traversal itself determines */
+    uint32_t expansion_steps, neighbors_examined, vectors_loaded, distance_computations;
+    uint32_t simhash_filtered, simhash_examined, simhash_missing_hash;
+    uint32_t simhash_passed_before_sampling, simhash_passed_after_sampling;
+    uint32_t pre_simhash_sample_kept, pre_simhash_sample_dropped;
+    uint32_t simhash_bypass_expansions, simhash_skipped_candidates;
+    uint32_t simhash_bypass_trigger_budget, simhash_bypass_trigger_low_yield;
+    uint32_t txn_get_simhash_filter;
+    uint32_t active_simhash_threshold_sum, active_simhash_threshold_samples;
+    uint32_t effective_beam_len_sum, effective_beam_len_samples;
+    uint32_t active_sampling_ratio_samples;
+    uint32_t rng_words;                 /* u32 outputs drawn from the query RNG (not a reference field) */
+    double active_sampling_ratio_sum;
+} orc_adaptive_stats;
+
+/* Layer0Policy::from_deployed(..).with_adaptive_bypass(..).decide(ctx) as one pure call (policy.rs:54-183). */
+typedef struct {
+    uint32_t metric, simhash_mode, configured_threshold;
+    float sampling_ratio, pre_sampling_override /* <0 None */;
+    uint32_t adaptive_enabled;
+    float failure;
+    uint32_t bypass_from_deployed;      /* 0: AdaptiveBypassPolicy::Disabled (from_deployed default) */
+    uint32_t bypass_ef, bypass_min_frontier, bypass_window_expansions;
+    float bypass_min_filter_rate;
+    uint32_t bypass_read_budget_multiplier;
+    /* SimHashContext */
+    uint32_t topk_ready, ef, search_frontier_len, candidate_frontier_len;
+    float current, delta;
+    uint32_t state, state_remaining;
+    uint64_t simhash_filter_reads, window_examined, window_filtered, window_expansions;
+} orc_policy_input;
+typedef struct {
+    uint32_t fetch_missing, filter_cached, has_threshold, threshold;
+    uint32_t pre_sampling_kind; float pre_sampling_probability;
+    uint32_t sampling_kind; float sampling_probability;
+    float base_sampling_probability;
+    uint32_t bypassed, next_state, next_state_remaining, trigger;
+} orc_policy_decision;
+void orc_policy_decide(const orc_policy_input *in, orc_policy_decision *out);
+float orc_candidate_probability(uint32_t kind, float probability, uint32_t similarity_bits, int has_threshold,
+                                uint32_t threshold);                        /* policy.rs:417-433 */
+uint32_t orc_pre_sampling_decision(float base_ratio, uint32_t frontier, uint32_t ef, float *probability); /* :540-557 */
+float orc_adaptive_sampling_ratio(float base, uint32_t search_frontier_len, uint32_t ef, float current, float delta);
+uint32_t orc_adaptive_threshold(uint32_t topk_ready, float delta, uint32_t configured, float failure);   /* :577-599 */
+
+/* query RNG session (randomness.rs:127-164).  should_sample is pinned through the SimHasher KAT (same
+ * generator, same random::<f32>()); choose_index restates rand's `random_range(0..n)` from its published
+ * algorithm (widening multiply with one bias-correction draw) and has NO reference known answer:
+ * PARITY UNPINNED for the two fallback sites that call it (search.rs:667,818). */
+typedef struct { uint64_t seed; uint32_t key[8]; uint32_t buf[16]; uint64_t block; uint32_t pos; int ready; uint32_t words; } orc_rng;
+void orc_rng_seed(orc_rng *r, uint64_t seed);
+int orc_rng_should_sample(orc_rng *r, float ratio);
+int64_t orc_rng_choose_index(orc_rng *r, uint64_t n);   /* -1 when n == 0 */
+
+/* per-node SimHash rows: either given (e.g. decoded from the persisted keys) or computed with
+ * SimHasher(dim, seed) (unaligned_vector/simhash.rs).  Required by orc_search_params(). */
+int orc_index_set_simhash(orc_index *, uint64_t seed, const uint64_t *node_hashes /* NULL: compute */);
+int orc_index_get_simhash(const orc_index *, uint64_t *node_hashes /* export order = ascending ids */);
+uint64_t orc_index_query_simhash(const orc_index *, const float *query);
+
+/* SearchSession::run with full SearchParams: strict-exhaustive parameters take the STRICT arm,
+ * everything else search_layer0_with_simhash::<_, false> (search.rs:267-1067). */
+int orc_search_params_run(const orc_index *, const float *query, uint32_t query_len, const orc_search_params *p,
+                          uint64_t *out_ids, float *out_scores, uint32_t *out_count, orc_adaptive_stats *stats);
+int orc_search_params_batch_mt(const orc_index *, const float *queries, uint32_t nq, const orc_search_params *p,
+                               uint32_t threads, uint64_t *out_ids, float *out_scores, uint32_t *out_counts,
+                               orc_adaptive_stats *stats);
 
 #ifdef __cplusplus
 }

@@ -51,6 +51,10 @@ static void chacha12_block(const uint32_t key[8], uint64_t counter, uint32_t out
     for (int i = 0; i < 16; ++i) out[i] = x[i] + st[i];
 }
 
+/* exported for the query RNG session in hvx_oracle_adaptive.inc */
+void orc_stdrng_key(uint64_t seed, uint32_t key[8]) { seed_from_u64(seed, key); }
+void orc_chacha12_block(const uint32_t key[8], uint64_t counter, uint32_t out[16]) { chacha12_block(key, counter, out); }
+
 /* the first n outputs of StdRng::seed_from_u64(seed).next_u32() */
 void orc_stdrng_u32(uint64_t seed, uint32_t *out, uint32_t n) {
     uint32_t key[8], blk[16];

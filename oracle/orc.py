@@ -21,7 +21,7 @@ OK, ERR_DIMENSION, ERR_NONFINITE, ERR_ZERO_NORM, ERR_MAGNITUDE, ERR_K_RANGE, ERR
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h", ".inc"))]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
     if force or stale:
@@ -43,6 +43,124 @@ class Stats(C.Structure):
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+SIMHASH_ALWAYS, SIMHASH_ADAPTIVE, SIMHASH_OFF = 0, 1, 2
+SAMPLING_EXHAUSTIVE, SAMPLING_FIXED, SAMPLING_ADAPTIVE = 0, 1, 2
+BYPASS_READY, BYPASS_BYPASSING, BYPASS_COOLING = 0, 1, 2
+TRIGGER_NONE, TRIGGER_READ_BUDGET, TRIGGER_LOW_YIELD, TRIGGER_BOTH = 0, 1, 2, 3
+
+
+class _Rec(C.Structure):
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class SearchParams(_Rec):
+    """orc_search_params: SearchParams (mod.rs:410-621) + the index-level config it resolves against."""
+    _fields_ = [("k", C.c_uint32), ("ef", C.c_uint32), ("simhash_mode", C.c_uint32),
+                ("pre_simhash_sampling_ratio_override", C.c_float),
+                ("bypass_min_frontier", C.c_uint32), ("bypass_window_expansions", C.c_uint32),
+                ("bypass_min_filter_rate", C.c_float), ("read_budget_multiplier", C.c_uint32),
+                ("simhash_sampling_ratio_override", C.c_float), ("simhash_failure_prob_override", C.c_float),
+                ("simhash_threshold", C.c_uint32), ("sampling_ratio", C.c_float),
+                ("adaptive_enabled", C.c_uint32), ("adaptive_failure_prob", C.c_float),
+                ("resident_simhash", C.c_uint32), ("use_fixed_seed", C.c_uint32), ("fixed_seed", C.c_uint64)]
+
+    @classmethod
+    def new(cls, k, **over):
+        p = cls()
+        lib().orc_search_params_default(C.byref(p), k)
+        for key, v in over.items():
+            assert hasattr(p, key), key
+            setattr(p, key, v)
+        return p
+
+
+class AdaptiveStats(_Rec):
+    _fields_ = [(n, C.c_uint32) for n in (
+        "expansion_steps", "neighbors_examined", "vectors_loaded", "distance_computations",
+        "simhash_filtered", "simhash_examined", "simhash_missing_hash",
+        "simhash_passed_before_sampling", "simhash_passed_after_sampling",
+        "pre_simhash_sample_kept", "pre_simhash_sample_dropped",
+        "simhash_bypass_expansions", "simhash_skipped_candidates",
+        "simhash_bypass_trigger_budget", "simhash_bypass_trigger_low_yield",
+        "txn_get_simhash_filter", "active_simhash_threshold_sum", "active_simhash_threshold_samples",
+        "effective_beam_len_sum", "effective_beam_len_samples", "active_sampling_ratio_samples",
+        "rng_words")] + [("active_sampling_ratio_sum", C.c_double)]
+
+
+class PolicyInput(_Rec):
+    _fields_ = [("metric", C.c_uint32), ("simhash_mode", C.c_uint32), ("configured_threshold", C.c_uint32),
+                ("sampling_ratio", C.c_float), ("pre_sampling_override", C.c_float),
+                ("adaptive_enabled", C.c_uint32), ("failure", C.c_float),
+                ("bypass_from_deployed", C.c_uint32), ("bypass_ef", C.c_uint32),
+                ("bypass_min_frontier", C.c_uint32), ("bypass_window_expansions", C.c_uint32),
+                ("bypass_min_filter_rate", C.c_float), ("bypass_read_budget_multiplier", C.c_uint32),
+                ("topk_ready", C.c_uint32), ("ef", C.c_uint32), ("search_frontier_len", C.c_uint32),
+                ("candidate_frontier_len", C.c_uint32), ("current", C.c_float), ("delta", C.c_float),
+                ("state", C.c_uint32), ("state_remaining", C.c_uint32),
+                ("simhash_filter_reads", C.c_uint64), ("window_examined", C.c_uint64),
+                ("window_filtered", C.c_uint64), ("window_expansions", C.c_uint64)]
+
+
+class PolicyDecision(_Rec):
+    _fields_ = [("fetch_missing", C.c_uint32), ("filter_cached", C.c_uint32), ("has_threshold", C.c_uint32),
+                ("threshold", C.c_uint32), ("pre_sampling_kind", C.c_uint32),
+                ("pre_sampling_probability", C.c_float), ("sampling_kind", C.c_uint32),
+                ("sampling_probability", C.c_float), ("base_sampling_probability", C.c_float),
+                ("bypassed", C.c_uint32), ("next_state", C.c_uint32), ("next_state_remaining", C.c_uint32),
+                ("trigger", C.c_uint32)]
+
+
+class Rng(_Rec):
+    _fields_ = [("seed", C.c_uint64), ("key", C.c_uint32 * 8), ("buf", C.c_uint32 * 16), ("block", C.c_uint64),
+                ("pos", C.c_uint32), ("ready", C.c_int), ("words", C.c_uint32)]
+
+    @classmethod
+    def seeded(cls, seed):
+        r = cls()
+        lib().orc_rng_seed(C.byref(r), seed)
+        return r
+
+    def should_sample(self, ratio):
+        return bool(lib().orc_rng_should_sample(C.byref(self), np.float32(ratio)))
+
+    def choose_index(self, n):
+        v = int(lib().orc_rng_choose_index(C.byref(self), n))
+        return None if v < 0 else v
+
+
+def policy_decide(**kw):
+    """Layer0Policy::from_deployed(..)[.with_adaptive_bypass(..)].decide(context) -- see PolicyInput."""
+    inp = PolicyInput()
+    inp.pre_sampling_override = -1.0
+    for key, v in kw.items():
+        assert hasattr(inp, key), key
+        setattr(inp, key, v)
+    out = PolicyDecision()
+    lib().orc_policy_decide(C.byref(inp), C.byref(out))
+    return out
+
+
+def candidate_probability(kind, probability, similarity_bits, threshold=None):
+    return np.float32(lib().orc_candidate_probability(kind, np.float32(probability), similarity_bits,
+                                                      0 if threshold is None else 1, threshold or 0))
+
+
+def pre_sampling_decision(base_ratio, frontier, ef):
+    p = C.c_float(0)
+    kind = lib().orc_pre_sampling_decision(np.float32(base_ratio), frontier, ef, C.byref(p))
+    return int(kind), np.float32(p.value)
+
+
+def adaptive_sampling_ratio(base, search_frontier_len, ef, current, delta):
+    return np.float32(lib().orc_adaptive_sampling_ratio(np.float32(base), search_frontier_len, ef,
+                                                        np.float32(current), np.float32(delta)))
+
+
+def adaptive_threshold(topk_ready, delta, configured, failure):
+    return int(lib().orc_adaptive_threshold(int(topk_ready), np.float32(delta), configured, np.float32(failure)))
 
 
 def lib():
@@ -125,6 +243,37 @@ def _extra_signatures(L):
         L.orc_simhash_collisions.argtypes = [C.c_uint64, C.c_uint64]
         L.orc_query_seed.restype = C.c_uint64
         L.orc_query_seed.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+    if hasattr(L, "orc_policy_decide"):
+        L.orc_search_params_default.restype = None
+        L.orc_search_params_default.argtypes = [C.POINTER(SearchParams), C.c_uint32]
+        L.orc_policy_decide.restype = None
+        L.orc_policy_decide.argtypes = [C.POINTER(PolicyInput), C.POINTER(PolicyDecision)]
+        L.orc_candidate_probability.restype = C.c_float
+        L.orc_candidate_probability.argtypes = [C.c_uint32, C.c_float, C.c_uint32, C.c_int, C.c_uint32]
+        L.orc_pre_sampling_decision.restype = C.c_uint32
+        L.orc_pre_sampling_decision.argtypes = [C.c_float, C.c_uint32, C.c_uint32, f32p]
+        L.orc_adaptive_sampling_ratio.restype = C.c_float
+        L.orc_adaptive_sampling_ratio.argtypes = [C.c_float, C.c_uint32, C.c_uint32, C.c_float, C.c_float]
+        L.orc_adaptive_threshold.restype = C.c_uint32
+        L.orc_adaptive_threshold.argtypes = [C.c_uint32, C.c_float, C.c_uint32, C.c_float]
+        L.orc_rng_seed.restype = None
+        L.orc_rng_seed.argtypes = [C.POINTER(Rng), C.c_uint64]
+        L.orc_rng_should_sample.restype = C.c_int
+        L.orc_rng_should_sample.argtypes = [C.POINTER(Rng), C.c_float]
+        L.orc_rng_choose_index.restype = C.c_int64
+        L.orc_rng_choose_index.argtypes = [C.POINTER(Rng), C.c_uint64]
+        L.orc_index_set_simhash.restype = C.c_int
+        L.orc_index_set_simhash.argtypes = [C.c_void_p, C.c_uint64, u64p]
+        L.orc_index_get_simhash.restype = C.c_int
+        L.orc_index_get_simhash.argtypes = [C.c_void_p, u64p]
+        L.orc_index_query_simhash.restype = C.c_uint64
+        L.orc_index_query_simhash.argtypes = [C.c_void_p, f32p]
+        L.orc_search_params_run.restype = C.c_int
+        L.orc_search_params_run.argtypes = [C.c_void_p, f32p, C.c_uint32, C.POINTER(SearchParams), u64p, f32p, u32p,
+                                            C.POINTER(AdaptiveStats)]
+        L.orc_search_params_batch_mt.restype = C.c_int
+        L.orc_search_params_batch_mt.argtypes = [C.c_void_p, f32p, C.c_uint32, C.POINTER(SearchParams), C.c_uint32,
+                                                 u64p, f32p, u32p, C.POINTER(AdaptiveStats)]
     if hasattr(L, "orc_traverse"):
         L.orc_traverse.restype = C.c_int64
     if hasattr(L, "orc_search_restricted"):
@@ -252,6 +401,47 @@ class Index:
         rc = lib().orc_search_batch_mt(self._h, q.ctypes.data_as(f32p), nq, k, ef, threads,
                                        ids.ctypes.data_as(u64p), sc.ctypes.data_as(f32p),
                                        cnt.ctypes.data_as(u32p), st)
+        return rc, ids, sc, cnt, [s.as_dict() for s in st]
+
+    def set_simhash(self, seed=42, node_hashes=None):
+        """Per-node SimHash rows: computed with SimHasher(dim, seed) or given in ascending-id order."""
+        ph = None
+        if node_hashes is not None:
+            h = np.ascontiguousarray(node_hashes, dtype=np.uint64)
+            assert h.size == self.count
+            ph = h.ctypes.data_as(u64p)
+        rc = lib().orc_index_set_simhash(self._h, seed, ph)
+        assert rc == OK, rc
+
+    def get_simhash(self):
+        out = np.zeros(self.count, np.uint64)
+        rc = lib().orc_index_get_simhash(self._h, out.ctypes.data_as(u64p))
+        assert rc == OK, rc
+        return out
+
+    def query_simhash(self, query):
+        q, pq = _f(query)
+        return int(lib().orc_index_query_simhash(self._h, pq))
+
+    def search_params(self, query, params, with_stats=False):
+        """SearchSession::run with full SearchParams (strict or non-strict arm as the params dictate)."""
+        q, pq = _f(query)
+        k = max(int(params.k), 1)
+        ids = np.zeros(k, np.uint64); sc = np.zeros(k, np.float32)
+        cnt = C.c_uint32(0); st = AdaptiveStats()
+        rc = lib().orc_search_params_run(self._h, pq, q.size, C.byref(params), ids.ctypes.data_as(u64p),
+                                         sc.ctypes.data_as(f32p), C.byref(cnt), C.byref(st))
+        res = (rc, ids[: cnt.value].copy(), sc[: cnt.value].copy())
+        return res + (st.as_dict(),) if with_stats else res
+
+    def search_params_batch(self, queries, params, threads=1):
+        q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, self.dim)
+        nq, k = q.shape[0], int(params.k)
+        ids = np.zeros((nq, k), np.uint64); sc = np.zeros((nq, k), np.float32)
+        cnt = np.zeros(nq, np.uint32); st = (AdaptiveStats * nq)()
+        rc = lib().orc_search_params_batch_mt(self._h, q.ctypes.data_as(f32p), nq, C.byref(params), threads,
+                                              ids.ctypes.data_as(u64p), sc.ctypes.data_as(f32p),
+                                              cnt.ctypes.data_as(u32p), st)
         return rc, ids, sc, cnt, [s.as_dict() for s in st]
 
     def flat(self, query, k, allowed=None):

@@ -374,7 +374,7 @@ int hvx_index::stage(uint32_t b, uint32_t k) {
     return HVX_OK;
 }
 
-static int check_k_ef(uint32_t k, uint32_t ef) {
+int hvx::check_k_ef(uint32_t k, uint32_t ef) {
     // ResultCount / SearchBeamWidth (parameters.rs:100-133)
     if (k == 0) return fail(HVX_ERR_K_RANGE, "result count must be non-zero");
     if (ef < k) return fail(HVX_ERR_K_RANGE, "search beam width %u is below the result count %u", ef, k);
@@ -396,9 +396,9 @@ static void add_stats(hvx_stats *stats, const std::vector<hvx_query_stats> &qs, 
 }
 
 // enqueue validation + memset + search kernel for one chunk of <= max_batch queries
-static int enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t b, uint32_t k, uint32_t ef,
-                          uint64_t *d_ids, float *d_scores, uint32_t *d_counts, uint32_t *d_status,
-                          hvx_query_stats *d_qstats, bool timed) {
+int hvx::enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t b, uint32_t k, uint32_t ef,
+                        uint64_t *d_ids, float *d_scores, uint32_t *d_counts, uint32_t *d_status,
+                        hvx_query_stats *d_qstats, bool timed, const AdaptArgs *ad) {
     hvx_index *ix = const_cast<hvx_index *>(cix);
     HIP_TRY(launch_validate_queries(ix->dev, d_queries, b, ix->limit, ix->d_qstatus, ix->d_qhdr, ix->stream));
     HnswArgs a;
@@ -417,6 +417,21 @@ static int enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t
     a.qstats = d_qstats ? d_qstats : ix->d_qstats;
     a.tie_flags = ix->d_tie;
     a.prof = nullptr;
+    a.adaptive = ad ? 1u : 0u;
+    a.ad = ad ? *ad : AdaptArgs{};
+    if (ad) {
+        if (!hnsw_wave_adaptive_supported(a))
+            return fail(HVX_ERR_UNSUPPORTED, "the non-strict search arms are served by the one-wavefront-per-query kernel only "
+                        "(f32 rows, cosine / Euclidean, dim in {128,256,512,768,1024,1536}, rows <= 64 ids, ef <= 352)");
+        if (ix->bitmap_dirty) {
+            HIP_TRY(hipMemsetAsync(ix->d_bitmap, 0, (size_t)ix->max_batch * ix->words_per_query * 4, ix->stream));
+            ix->bitmap_dirty = false;
+        }
+        if (timed) HIP_TRY(hipEventRecord(ix->ev0, ix->stream));
+        HIP_TRY(launch_hnsw_wave(a, b, ix->stream));
+        if (timed) HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
+        return HVX_OK;
+    }
     const bool prof = getenv("HVX_WAVE_PROF") != nullptr; // tuning hook: phase-timing kernel + stderr report
     if (prof) {
         if (!ix->d_prof && ix->dalloc((void **)&ix->d_prof, (size_t)ix->max_batch * 64)) return HVX_ERR_DEVICE;
@@ -455,7 +470,7 @@ static int enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t
     return HVX_OK;
 }
 
-static int collect_stats(hvx_index *ix, uint32_t b, const hvx_query_stats *d_qstats, hvx_stats *stats) {
+int hvx::collect_stats(hvx_index *ix, uint32_t b, const hvx_query_stats *d_qstats, hvx_stats *stats) {
     std::vector<hvx_query_stats> qs(b);
     std::vector<uint32_t> tie(b);
     HIP_TRY(hipMemcpyAsync(qs.data(), d_qstats ? d_qstats : ix->d_qstats, (size_t)b * sizeof(hvx_query_stats), hipMemcpyDeviceToHost, ix->stream));

@@ -309,6 +309,9 @@ hipError_t launch_hnsw_wave_cos(const HnswArgs &a, uint32_t b, const WaveGeom &g
 hipError_t launch_hnsw_wave_prof(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_l2_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_cos_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_l2_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_cos_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+constexpr uint32_t kRngWords = 1024; // LDS window of the query RNG (hvx_hnsw_wave.h)
 
 bool hnsw_wave_supported(const HnswArgs &a) {
     const DevIndex &ix = a.ix;
@@ -322,6 +325,8 @@ bool hnsw_wave_supported(const HnswArgs &a) {
     if (a.ef + 32u > 384u) return false;
     return true;
 }
+
+bool hnsw_wave_adaptive_supported(const HnswArgs &a) { return hnsw_wave_supported(a) && a.ix.dtype == HVX_F32; }
 
 static int env_int(const char *name, int lo, int hi, int fallback) {
     const char *e = getenv(name);
@@ -339,8 +344,9 @@ hipError_t launch_hnsw_wave(const HnswArgs &a, uint32_t b, hipStream_t s) {
     g.log2cap = (uint32_t)env_int("HVX_WAVE_LOG2CAP", 7, 15, (int)g.log2cap); // test hook: tiny table => spill path
     // 160 KiB / 4: exactly four resident wavefronts per CU, one per SIMD, each with the SIMD's whole register file
     const size_t budget = 40 * 1024;
-    const size_t need = ((size_t)4 << g.log2cap) + 512 + (size_t)a.ix.dim * 4;
+    const size_t need = ((size_t)4 << g.log2cap) + 512 + (size_t)a.ix.dim * 4 + (a.adaptive ? kRngWords * 4 : 0);
     g.lds = need < budget ? budget : need;
+    if (a.adaptive) return a.ix.metric == kL2 ? launch_hnsw_wave_l2_ad(a, b, g, s) : launch_hnsw_wave_cos_ad(a, b, g, s);
     if (a.prof) return launch_hnsw_wave_prof(a, b, g, s);
     if (a.ix.dtype == HVX_BF16) return a.ix.metric == kL2 ? launch_hnsw_wave_l2_bf16(a, b, g, s) : launch_hnsw_wave_cos_bf16(a, b, g, s);
     return a.ix.metric == kL2 ? launch_hnsw_wave_l2(a, b, g, s) : launch_hnsw_wave_cos(a, b, g, s);

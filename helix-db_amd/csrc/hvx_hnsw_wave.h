@@ -77,6 +77,25 @@ struct Visited {
         spilled = true;
         __threadfence_block();
     }
+    // membership test only (non-strict arms: a neighbour is marked visited later, when it is filtered or admitted)
+    __device__ __forceinline__ bool contains(uint32_t id, bool valid) const {
+        if (spilled) {
+            bool hit = false;
+            if (valid) hit = (__hip_atomic_load(&bm[id >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (id & 31u)) & 1u;
+            return hit;
+        }
+        bool pending = valid, found = false;
+        uint32_t slot = (id * 2654435761u) >> shift;
+        while (__ballot(pending)) {
+            if (pending) {
+                const uint32_t v = tab[slot];
+                if (v == id) { found = true; pending = false; }
+                else if (v == kTabEmpty) pending = false;
+                else slot = (slot + 1u) & mask;
+            }
+        }
+        return found;
+    }
     // test-and-set for the lanes with valid==true (ids distinct across lanes); true = newly inserted
     __device__ __forceinline__ bool insert(uint32_t id, bool valid, int lane) {
         if (!spilled && count + 64u > cap - (cap >> 2)) spill(lane);
@@ -194,9 +213,199 @@ __device__ __forceinline__ void gather_consume(const DevIndex &ix, const float *
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Non-strict layer-0 arms (search.rs:595-829, policy.rs, randomness.rs)
+// ------------------------------------------------------------------------------------------------------------
+
+// The query-local generator of SearchSession (randomness.rs:127-164): rand 0.10 StdRng = ChaCha12 keyed by
+// seed_from_u64's PCG32 expansion (pinned by the SimHasher known answer, hvx_simhash.hip).  The stream is consumed
+// strictly in order, but the NUMBER of draws of a sampling stage is known before the stage runs, so the words are
+// produced 64 blocks (1 024 words) at a time -- lane L computes block base/16 + L -- and parked in LDS, and a stage
+// hands word (pos + rank) to the lane whose candidate is the rank-th one to draw.
+constexpr uint32_t kRngWords = 1024;
+struct QueryRng {
+    uint32_t *buf;   // LDS [kRngWords], word w of the window at buf[(w % 16) * 64 + w / 16] (conflict-free fill)
+    uint32_t key[8]; // uniform
+    uint32_t base;   // stream index of the window's first word
+    uint32_t pos;    // words consumed so far (uniform)
+    bool ready;
+
+    __device__ __forceinline__ void seed(uint64_t state) { // rand_core SeedableRng::seed_from_u64
+        const uint64_t MUL = 6364136223846793005ULL, INC = 11634580027462260723ULL;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            state = state * MUL + INC;
+            const uint32_t xs = (uint32_t)(((state >> 18) ^ state) >> 27), rot = (uint32_t)(state >> 59);
+            key[i] = (xs >> rot) | (xs << ((32u - rot) & 31u));
+        }
+        base = 0;
+        pos = 0;
+        ready = false; // SearchSession::seeded: nothing is generated until the first draw
+    }
+    // make words [pos, pos + 66) readable (a stage draws <= 64 words, choose_index <= 2)
+    __device__ __forceinline__ void ensure(int lane) {
+        if (ready && pos + 66u <= base + kRngWords) return;
+        base = pos & ~15u;
+        const uint32_t ctr = (base >> 4) + (uint32_t)lane; // block counter (64-bit in ChaCha; < 2^32 here)
+        uint32_t st[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3],
+                           key[4], key[5], key[6], key[7], ctr, 0u, 0u, 0u};
+        uint32_t x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = st[i];
+#define HVX_QR(a, b, c, d)                                                                                   \
+    x[a] += x[b]; x[d] = __builtin_rotateleft32(x[d] ^ x[a], 16); x[c] += x[d]; x[b] = __builtin_rotateleft32(x[b] ^ x[c], 12); \
+    x[a] += x[b]; x[d] = __builtin_rotateleft32(x[d] ^ x[a], 8);  x[c] += x[d]; x[b] = __builtin_rotateleft32(x[b] ^ x[c], 7)
+#pragma unroll 1
+        for (int r = 0; r < 6; ++r) { // 12 rounds
+            HVX_QR(0, 4, 8, 12); HVX_QR(1, 5, 9, 13); HVX_QR(2, 6, 10, 14); HVX_QR(3, 7, 11, 15);
+            HVX_QR(0, 5, 10, 15); HVX_QR(1, 6, 11, 12); HVX_QR(2, 7, 8, 13); HVX_QR(3, 4, 9, 14);
+        }
+#undef HVX_QR
+        __syncthreads(); // every reader of the previous window is done
+#pragma unroll
+        for (int i = 0; i < 16; ++i) buf[i * 64 + lane] = x[i] + st[i];
+        ready = true;
+        __syncthreads();
+    }
+    __device__ __forceinline__ uint32_t word(uint32_t idx) const {
+        const uint32_t r = idx - base;
+        return buf[(r & 15u) * 64u + (r >> 4)];
+    }
+    // random::<f32>() < ratio for stream word idx
+    __device__ __forceinline__ bool below(uint32_t idx, float ratio) const {
+        return (float)(word(idx) >> 8) * (1.0f / 16777216.0f) < ratio;
+    }
+    // SearchSession::choose_index (randomness.rs:162-164) -> rand `random_range(0..n)`, n <= 64: high word of
+    // x*n with one bias-correction draw (restated; the reference holds no known answer for it).  Uniform.
+    __device__ __forceinline__ uint32_t choose_index(uint32_t n, int lane) {
+        ensure(lane);
+        const unsigned long long m = (unsigned long long)word(pos) * n;
+        ++pos;
+        uint32_t hi = (uint32_t)(m >> 32);
+        const uint32_t lo = (uint32_t)m;
+        if (lo > 0u - n) {
+            const uint32_t nhi = (uint32_t)(((unsigned long long)word(pos) * n) >> 32);
+            ++pos;
+            hi += (lo + nhi < lo) ? 1u : 0u;
+        }
+        return hi;
+    }
+};
+
+__device__ __forceinline__ float rs_clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); } // f32::clamp
+
+// one decision epoch (Layer0Policy::decide, policy.rs:119-183); everything uniform
+struct AdaptDecision {
+    bool filter;          // fetch_missing == filter_cached
+    uint32_t threshold;   // active collision threshold (0 when not filtering)
+    uint32_t pre_kind;    // SamplingDecision of the pre-sampling stage: 0 Exhaustive, 1 Fixed
+    float pre_p;
+    uint32_t samp_kind;   // 0 Exhaustive, 1 Fixed, 2 Adaptive (after activation)
+    float samp_p;         // probability() of that decision (1.0 for Exhaustive)
+    float base_p;
+    bool bypassed;
+    uint32_t trigger;
+};
+
+// per-query state of the non-strict arms (uniform) + SearchStats counters
+struct AdaptState {
+    uint32_t fill;                        // simhash_fill_slots (search.rs:532)
+    uint32_t win_ex, win_filt, win_exp;   // rolling yield window (search.rs:790-801)
+    uint32_t bstate, bremain;             // AdaptiveBypassState: 0 Ready, 1 Bypassing, 2 CoolingDown
+    hvx_adaptive_stats st;
+};
+
+__device__ __forceinline__ float adaptive_sampling_ratio_fn(float base, uint32_t wlen, uint32_t ef, float current, float delta) {
+    if (base >= 1.0f) return base;                                   // policy.rs:559-575
+    const uint32_t lim = ef / 3u > 8u ? ef / 3u : 8u;
+    if (wlen < lim) return 1.0f;
+    if (delta <= 1e-6f) return base;
+    const float rq = rs_clampf(1.0f - rs_clampf(current / delta, 0.0f, 1.0f), 0.0f, 1.0f);
+    const float u = (1.0f - base) * rq;
+    const float v = rs_clampf(base + u, base, 1.0f);
+    return __builtin_fminf(v, __builtin_fmaxf(0.90f, base));
+}
+
+__device__ __forceinline__ AdaptDecision adapt_decide(const AdaptArgs &p, AdaptState &s, uint32_t ef, bool topk_ready, uint32_t wlen,
+                                                      uint32_t frontier, float current, float delta, float brk_lane) {
+    AdaptDecision d;
+    // AdaptiveBypassPolicy::decide (policy.rs:228-296); the device index is the resident snapshot: 0 SimHash reads
+    bool bypassed = false;
+    uint32_t trigger = 0, nstate = 0, nremain = 0;
+    if (p.bypass_windowed) {
+        if (s.bstate == 1u) {
+            bypassed = true;
+            nstate = s.bremain - 1u ? 1u : 2u;
+            nremain = s.bremain - 1u ? s.bremain - 1u : p.window_expansions;
+        } else if (s.bstate == 2u && s.bremain > 1u) {
+            nstate = 2u;
+            nremain = s.bremain - 1u;
+        } else {
+            const float rate = s.win_ex == 0u ? 1.0f : (float)s.win_filt / (float)s.win_ex;
+            const bool low_yield = (s.win_exp >= p.window_expansions) & (rate < p.min_filter_rate);
+            if (frontier >= p.min_frontier && low_yield) {
+                bypassed = true;
+                trigger = 2u; // LowYield
+                nstate = p.window_expansions - 1u ? 1u : 2u;
+                nremain = p.window_expansions - 1u ? p.window_expansions - 1u : p.window_expansions;
+            }
+        }
+    }
+    s.bstate = nstate;
+    s.bremain = nremain;
+    // sampling (policy.rs:123-138, 526-557)
+    float base_p = 1.0f;
+    uint32_t kind = p.sampling;
+    if (kind == 1u) base_p = p.ratio;
+    else if (kind == 2u) base_p = adaptive_sampling_ratio_fn(p.ratio, wlen, ef, current, delta);
+    const uint32_t lim = ef / 4u > 8u ? ef / 4u : 8u;
+    d.base_p = base_p;
+    d.samp_kind = kind;
+    d.samp_p = base_p;
+    if (!(base_p <= 0.0f || base_p >= 1.0f || frontier > lim)) { d.samp_kind = 0u; d.samp_p = 1.0f; }
+    if (kind == 0u) d.samp_p = 1.0f;
+    const float pre_base = p.pre_override >= 0.0f ? p.pre_override : base_p;
+    if (pre_base >= 1.0f || frontier <= lim) {
+        d.pre_kind = 0u;
+        d.pre_p = 1.0f;
+    } else {
+        float r = rs_clampf(pre_base * 0.65f, 0.25f, 0.9f);
+        const uint32_t wide = ef * 2u > 32u ? ef * 2u : 32u;
+        if (pre_base <= 0.0f) r = 0.0f;
+        else if (frontier > wide) r = __builtin_fmaxf(r * 0.8f, 0.20f);
+        d.pre_kind = 1u;
+        d.pre_p = r;
+    }
+    d.bypassed = bypassed;
+    d.trigger = trigger;
+    d.filter = !bypassed && p.filtering != 0u;
+    d.threshold = 0u;
+    if (d.filter) {
+        if (p.filtering == 1u) d.threshold = p.configured;
+        else if (p.configured == 0u) d.threshold = 0u;
+        else if (!topk_ready) d.threshold = 1u;
+        else d.threshold = (uint32_t)__builtin_popcountll(__ballot(delta <= brk_lane)); // adaptive_threshold as a table
+    }
+    return d;
+}
+
+// SamplingDecision::candidate_probability (policy.rs:417-433), per lane
+__device__ __forceinline__ float candidate_probability_fn(uint32_t kind, float base, uint32_t sim_bits, bool has_thr, uint32_t thr) {
+    if (kind != 2u) return base;
+    if (base <= 0.0f || base >= 1.0f) return base;
+    const float sr = (float)(sim_bits < 64u ? sim_bits : 64u) / 64.0f;
+    const float tr = has_thr ? (float)thr / 64.0f : 0.0f;
+    const float t = __builtin_fmaxf(sr - tr, 0.0f);
+    const float u = (1.0f - base) * t;
+    return rs_clampf(base + u, base, 1.0f);
+}
+
 // PROF=true builds the phase-timing variant (s_memtime around each phase of a layer-0 expansion,
 // hard waits at the phase boundaries); it is only launched when HVX_WAVE_PROF is set.
-template <uint32_t METRIC, int R, int NK, bool BF, bool PROF = false>
+// AD=true builds the non-strict layer-0 arms (SimHash filter, pre/post sampling, adaptive bypass) into the same
+// beam search; AD=false is the strict-exhaustive arm and compiles to exactly the code it was before.
+template <uint32_t METRIC, int R, int NK, bool BF, bool PROF = false, bool AD = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void hnsw_wave_kernel(HnswArgs a, uint32_t log2cap) {
     // rows per 8-lane group in flight: P*NK <= 24 float4 per lane for a narrow pass, x2 and x4 for wider
     // frontiers (4P*NK <= 96 float4 = 384 registers, VGPR+AGPR file of one wave per SIMD)
@@ -221,6 +430,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     uint32_t *fr_id = V.tab + V.cap;                      // [64] frontier ids, row order
     float *fr_d = reinterpret_cast<float *>(fr_id + 64);   // [64] their distances
     float *qs = fr_d + 64;                                 // [dim] query, 16-byte aligned
+    uint32_t *rng_buf = reinterpret_cast<uint32_t *>(qs + NK * 32); // [kRngWords] (AD only)
 
     const uint32_t status_in = a.qstatus ? a.qstatus[q] : 0u;
     if (status_in != 0u || !ix.has_entry) {
@@ -229,6 +439,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             if (a.out_status) a.out_status[q] = status_in;
             if (a.qstats) a.qstats[q] = hvx_query_stats{0, 0, 0, 0};
             if (a.tie_flags) a.tie_flags[q] = 0u;
+            if (AD && a.ad.stats) a.ad.stats[q] = hvx_adaptive_stats{};
         }
         return;
     }
@@ -290,6 +501,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         return (uint32_t)__builtin_popcountll(um);
     };
 
+    // non-strict arms: visited TEST only; the unvisited neighbours land in fr_id in row order
+    auto frontier_probe = [&](uint32_t nid, uint32_t &deg) __attribute__((always_inline)) -> uint32_t {
+        const bool valid = nid != kSentinel;
+        const bool unseen = valid & !V.contains(nid, valid);
+        const unsigned long long um = __ballot(unseen);
+        deg = (uint32_t)__builtin_popcountll(__ballot(valid));
+        if (unseen) fr_id[__builtin_popcountll(um & ((1ull << lane) - 1ull))] = nid;
+        __syncthreads();
+        return (uint32_t)__builtin_popcountll(um);
+    };
+
     bool bad_score = false;
     uint32_t cur = ix.entry;
 
@@ -341,6 +563,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             t0 = t1;
         }
     };
+    AdaptState A;
+    QueryRng G;
+    uint64_t qh = 0;
+    float brk_lane = -1.0f;
+    if (AD) {
+        A.fill = A.win_ex = A.win_filt = A.win_exp = A.bstate = A.bremain = 0u;
+        A.st = hvx_adaptive_stats{};
+        qh = a.ad.qhash[q];
+        brk_lane = a.ad.thr_break[lane];
+        G.buf = rng_buf;
+        // SearchRandomness::QueryDerived (randomness.rs:104-120): the LAYER-0 entry after the descent, external id
+        const uint64_t ep = ix.ids[cur], efw = (uint64_t)a.ef;
+        G.seed(qh ^ ((ep << 17) | (ep >> 47)) ^ ((efw << 7) | (efw >> 57)));
+    }
     if (!bad_score) {
         V.clear(lane);
         float d0 = score_one(cur);
@@ -357,7 +593,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if (pos >= S.count) {
             // the reference would still pop an evicted candidate that we no longer hold, count the
             // step and stop on `current_dist > w.peek()` (search.rs:549)
-            if (dropped_unexpanded) ++st_exp;
+            if (dropped_unexpanded) {
+                ++st_exp;
+                if (AD) { A.st.effective_beam_len_sum += (S.count < ef ? S.count : ef) + A.fill; A.st.effective_beam_len_samples += 1u; }
+            }
             break;
         }
         ++st_exp;
@@ -365,7 +604,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         const uint32_t c = S.id_at(pos);
         const uint32_t wlen = S.count < ef ? S.count : ef;
         float wmax = S.score_at(wlen - 1);
-        if (wlen >= ef && dc > wmax) break;
+        if (AD) { A.st.effective_beam_len_sum += wlen + A.fill; A.st.effective_beam_len_samples += 1u; }
+        if (wlen + (AD ? A.fill : 0u) >= ef && dc > wmax) break; // effective_len counts the virtual fill slots
         S.mark_expanded(pos, lane);
 
         uint32_t nid;
@@ -373,7 +613,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         else nid = (uint32_t)lane < ix.s0 ? ix.l0[(size_t)c * ix.s0 + (uint32_t)lane] : kSentinel;
         tick(0, true); // pop + neighbour row available
         uint32_t deg;
-        const uint32_t nf = frontier_from(nid, deg);
+        uint32_t nf = AD ? frontier_probe(nid, deg) : frontier_from(nid, deg);
         st_nb += deg;
         tick(1, true); // visited test-and-set + compaction
         // 93 % of the time the next pop is simply the next unexpanded entry already in the beam: its
@@ -389,6 +629,95 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         pf_id = e2;
         pf_row = row2;
         if (nf == 0) continue;
+        if (AD) {
+            // ---- one decision epoch + candidate selection (search.rs:595-829) ----
+            const AdaptArgs &P = a.ad;
+            const uint32_t nf0 = nf;
+            const uint32_t node = (uint32_t)lane < nf0 ? fr_id[lane] : kSentinel;
+            __syncthreads();
+            const uint32_t kt = a.k > 1u ? a.k : 1u;              // topk_target
+            const float delta = S.score_at((kt < wlen ? kt : wlen) - 1u); // topk == the first min(k,|W|) of W
+            const AdaptDecision D = adapt_decide(P, A, ef, wlen >= kt, wlen, nf0, dc, delta, brk_lane);
+            A.st.simhash_bypass_trigger_low_yield += D.trigger == 2u ? 1u : 0u;
+            A.st.active_sampling_ratio_sum += (double)D.base_p;
+            A.st.active_sampling_ratio_samples += 1u;
+            if (D.filter) { A.st.active_simhash_threshold_sum += D.threshold; A.st.active_simhash_threshold_samples += 1u; }
+            // stage 0: pre-sampling, one draw per frontier neighbour in row order (search.rs:651-679)
+            bool keep = (uint32_t)lane < nf0;
+            const bool pre_enabled = D.pre_kind != 0u;
+            if (pre_enabled) {
+                if (D.pre_p <= 0.0f) keep = false;
+                else if (D.pre_p < 1.0f) {
+                    G.ensure(lane);
+                    keep = keep && G.below(G.pos + (uint32_t)lane, D.pre_p);
+                    G.pos += nf0;
+                }
+                uint32_t nk = (uint32_t)__builtin_popcountll(__ballot(keep));
+                A.st.pre_simhash_sample_dropped += nf0 - nk;
+                if (nk == 0u) { keep = (uint32_t)lane == G.choose_index(nf0, lane); nk = 1u; }
+                A.st.pre_simhash_sample_kept += nk;
+            }
+            const uint32_t ns = (uint32_t)__builtin_popcountll(__ballot(keep));
+            if (D.bypassed) { A.st.simhash_bypass_expansions += 1u; A.st.simhash_skipped_candidates += ns; }
+            // threshold screening (search.rs:708-757): filtered rows are marked visited and, while the beam is
+            // still filling, consume a virtual fill slot
+            uint32_t sim = 32u;
+            bool pass = keep;
+            if (D.filter) {
+                const uint64_t h = keep ? P.node_hash[node] : 0ull;
+                sim = 64u - (uint32_t)__builtin_popcountll(h ^ qh); // collision_count == 64 - hamming_distance
+                const bool failed = keep & !(sim >= D.threshold);
+                const uint32_t nfail = (uint32_t)__builtin_popcountll(__ballot(failed));
+                A.st.simhash_examined += ns;
+                A.st.simhash_filtered += nfail;
+                const bool fresh = V.insert(node, failed, lane);
+                const uint32_t nfresh = (uint32_t)__builtin_popcountll(__ballot(fresh));
+                const uint32_t eff = wlen + A.fill;
+                const uint32_t room = eff < ef ? ef - eff : 0u;
+                A.fill += nfresh < room ? nfresh : room;
+                pass = keep & !failed;
+                if (ns > 0u) { // rolling yield window (search.rs:790-801)
+                    A.win_ex += ns;
+                    A.win_filt += nfail;
+                    A.win_exp += 1u;
+                    if (A.win_exp > P.window_expansions) { A.win_ex >>= 1; A.win_filt >>= 1; A.win_exp = P.window_expansions >> 1; }
+                }
+            }
+            A.st.simhash_passed_before_sampling += (uint32_t)__builtin_popcountll(__ballot(pass));
+            // proximity-aware probabilistic expansion (search.rs:759-788): draws only for 0 < p < 1, in row order
+            bool sampled = pass, deferred = false;
+            const bool should_sample = !pre_enabled & (D.samp_kind != 0u) & (D.samp_p > 0.0f);
+            if (should_sample) {
+                const float pr = candidate_probability_fn(D.samp_kind, D.samp_p, sim, D.filter, D.threshold);
+                const bool draws = pass & (pr > 0.0f) & (pr < 1.0f);
+                const unsigned long long dm = __ballot(draws);
+                G.ensure(lane);
+                bool hit = pr >= 1.0f;
+                if (draws) hit = G.below(G.pos + (uint32_t)__builtin_popcountll(dm & ((1ull << lane) - 1ull)), pr);
+                G.pos += (uint32_t)__builtin_popcountll(dm);
+                sampled = pass & hit;
+                deferred = pass & !hit;
+            } else if (D.samp_p <= 0.0f) {
+                sampled = false;
+                deferred = pass;
+            }
+            // avoid getting stuck on sparse frontier expansions (search.rs:803-823)
+            if (D.samp_p > 0.0f && !__ballot(sampled) && __ballot(deferred)) {
+                const uint32_t best = 64u - wave_umin(deferred ? 64u - sim : 0xFFFFFFFFu);
+                unsigned long long bm = __ballot(deferred & (sim == best));
+                uint32_t idx = G.choose_index((uint32_t)__builtin_popcountll(bm), lane);
+                while (idx--) bm &= bm - 1ull;
+                sampled = (uint32_t)lane == (uint32_t)__builtin_ctzll(bm);
+            }
+            // mark_sampled_neighbors_visited (search.rs:89-97): only admitted rows become visited
+            const bool acc = V.insert(node, sampled, lane);
+            const unsigned long long am = __ballot(acc);
+            A.st.simhash_passed_after_sampling += (uint32_t)__builtin_popcountll(__ballot(sampled));
+            if (acc) fr_id[__builtin_popcountll(am & ((1ull << lane) - 1ull))] = node;
+            __syncthreads();
+            nf = (uint32_t)__builtin_popcountll(am);
+            if (nf == 0) continue;
+        }
         st_vl += nf;
         st_dc += nf;
         score_frontier(nf);
@@ -399,7 +728,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         {
             // a fresh candidate of this expansion that beats that entry becomes the prediction instead;
             // its row is fetched underneath the admission loop
-            const uint32_t wl0 = S.count < ef ? S.count : ef;
+            const uint32_t wl0 = (S.count < ef ? S.count : ef) + (AD ? A.fill : 0u);
             const bool adm = ((uint32_t)lane < nf) & ((d_l < wmax) | (wl0 < ef)) & (d_l >= 0.f) & (d_l < inf);
             const uint32_t key = adm ? __float_as_uint(d_l) : 0xFFFFFFFFu;
             const uint32_t kmin = wave_umin(key);
@@ -420,14 +749,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             float dv = d_l;
             const bool okv = (uint32_t)lane >= nf || score_valid(dv);
             if (__ballot(!okv)) { bad_score = true; break; }
-            const uint32_t wl_in = S.count < ef ? S.count : ef;
+            const uint32_t wl_in = (S.count < ef ? S.count : ef) + (AD ? A.fill : 0u);
             unsigned long long todo = __ballot(((uint32_t)lane < nf) & ((dv < wmax) | (wl_in < ef)));
             while (todo) {
                 const uint32_t f = (uint32_t)__builtin_ctzll(todo);
                 todo &= todo - 1ull;
                 const float d = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dv), f));
-                const uint32_t wl = S.count < ef ? S.count : ef;
+                const uint32_t wl = (S.count < ef ? S.count : ef) + (AD ? A.fill : 0u); // effective_len (search.rs:927)
                 if (d < wmax || wl < ef) {
+                    // a real candidate replaces a virtual fill slot before anything is trimmed (search.rs:943-950)
+                    if (AD) A.fill -= (wl >= ef && A.fill > 0u) ? 1u : 0u;
                     float ds = 0.f;
                     const bool drop = S.insert(d, __builtin_amdgcn_readlane(id_l, f), lane, ds);
                     const uint32_t wl2 = S.count < ef ? S.count : ef;
@@ -470,6 +801,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if (a.out_status) a.out_status[q] = bad_score ? 8u /*HVX_ERR_INVARIANT*/ : 0u;
         if (a.qstats) a.qstats[q] = hvx_query_stats{st_exp, st_nb, st_vl, st_dc};
         if (a.tie_flags) a.tie_flags[q] = tie_overflow ? 1u : 0u;
+        if (AD && a.ad.stats) {
+            A.st.rng_words = G.pos;
+            a.ad.stats[q] = A.st;
+        }
     }
 }
 
@@ -485,6 +820,9 @@ hipError_t launch_hnsw_wave_cos(const HnswArgs &a, uint32_t b, const WaveGeom &g
 hipError_t launch_hnsw_wave_l2_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_cos_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_prof(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+// non-strict arms (AD instantiations), hvx_hnsw_wave_l2_ad.hip / hvx_hnsw_wave_cos_ad.hip
+hipError_t launch_hnsw_wave_l2_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_cos_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 
 template <typename K> static hipError_t launch_wave_kernel(K kern, const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
     if (g.lds > 48 * 1024) {
@@ -495,24 +833,24 @@ template <typename K> static hipError_t launch_wave_kernel(K kern, const HnswArg
     return hipGetLastError();
 }
 
-template <uint32_t METRIC, int R, bool BF>
+template <uint32_t METRIC, int R, bool BF, bool AD = false>
 static hipError_t launch_wave_nk(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
     switch (a.ix.dim >> 5) {
-    case 4: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 4, BF>, a, b, g, s);
-    case 8: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 8, BF>, a, b, g, s);
-    case 16: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 16, BF>, a, b, g, s);
-    case 24: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 24, BF>, a, b, g, s);
-    case 32: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 32, BF>, a, b, g, s);
-    case 48: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 48, BF>, a, b, g, s);
+    case 4: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 4, BF, false, AD>, a, b, g, s);
+    case 8: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 8, BF, false, AD>, a, b, g, s);
+    case 16: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 16, BF, false, AD>, a, b, g, s);
+    case 24: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 24, BF, false, AD>, a, b, g, s);
+    case 32: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 32, BF, false, AD>, a, b, g, s);
+    case 48: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 48, BF, false, AD>, a, b, g, s);
     default: return hipErrorInvalidValue;
     }
 }
 
-template <uint32_t METRIC, bool BF>
+template <uint32_t METRIC, bool BF, bool AD = false>
 static hipError_t launch_wave_r(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
     const uint32_t need = a.ef + 32u; // beam capacity 64*R must hold ef plus slack for equal-score evictions
-    if (need <= 192) return launch_wave_nk<METRIC, 3, BF>(a, b, g, s);
-    if (need <= 384) return launch_wave_nk<METRIC, 6, BF>(a, b, g, s);
+    if (need <= 192) return launch_wave_nk<METRIC, 3, BF, AD>(a, b, g, s);
+    if (need <= 384) return launch_wave_nk<METRIC, 6, BF, AD>(a, b, g, s);
     return hipErrorInvalidValue;
 }
 

@@ -46,6 +46,14 @@ struct hvx_index {
     uint32_t *m_cert = nullptr;
     size_t cap_qsplit = 0;
     float m_xmax2 = 0.f;
+    // non-strict search arms (hvx_params.hip): per-node SimHash rows, the hasher, per-batch fingerprints
+    bool has_simhash = false;
+    hvx_simhash_config sh_cfg{};
+    uint64_t *d_node_hash = nullptr, *d_qhash = nullptr;
+    float *d_planes_t = nullptr, *d_thr_break = nullptr;
+    hvx_adaptive_stats *d_astats = nullptr;
+    uint32_t thr_configured = 0xFFFFFFFFu; // what d_thr_break was built for
+    float thr_failure = -1.f;
 
     int dalloc(void **p, size_t bytes);
     int stage(uint32_t b, uint32_t k);
@@ -65,6 +73,13 @@ struct hvx_index {
 
 namespace hvx {
 int fail(int code, const char *fmt, ...);
+int check_k_ef(uint32_t k, uint32_t ef);
+// enqueue validation + the search kernel for one chunk of <= max_batch device-resident queries;
+// ad != NULL selects the non-strict arms
+int enqueue_search(const hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, uint32_t ef, uint64_t *d_ids,
+                   float *d_scores, uint32_t *d_counts, uint32_t *d_status, hvx_query_stats *d_qstats, bool timed,
+                   const AdaptArgs *ad = nullptr);
+int collect_stats(hvx_index *ix, uint32_t b, const hvx_query_stats *d_qstats, hvx_stats *stats);
 float component_limit(uint32_t metric, uint32_t dim);
 int flat_scan_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, const uint32_t *d_subset,
                      uint32_t n_rows, uint64_t *d_ids, float *d_scores, uint32_t *d_counts, uint32_t *d_status,

@@ -8,6 +8,25 @@
 
 namespace hvx {
 
+// Non-strict layer-0 arms: the per-launch projection of SearchParams + VectorIndexConfig
+// (Layer0Policy::from_deployed / AdaptiveBypassPolicy::from_deployed, policy.rs:54-110,203-226) and the per-query
+// fingerprints.  Only read by the AD instantiations of the wave kernel.
+struct AdaptArgs {
+    const uint64_t *node_hash;  // [n] SimHash row of every node, internal order
+    const uint64_t *qhash;      // [b] query SimHash
+    const float *thr_break;     // [64] adaptive_threshold as a table: brk[t-1] = largest delta with threshold(delta) >= t,
+                                //      -1 when no delta reaches t (policy.rs:577-599 evaluated with the HOST libm)
+    hvx_adaptive_stats *stats;  // [b] nullable
+    uint32_t filtering;         // SimHashFilteringPolicy: 0 Disabled, 1 Fixed, 2 Adaptive
+    uint32_t configured;        // configured collision threshold
+    uint32_t sampling;          // FrontierSamplingPolicy: 0 Exhaustive, 1 Fixed, 2 Adaptive
+    float ratio;                // base sampling ratio (override or index sampling_ratio)
+    float pre_override;         // pre-sampling override, < 0 = None
+    uint32_t bypass_windowed;   // AdaptiveBypassPolicy::Windowed
+    uint32_t min_frontier, window_expansions;
+    float min_filter_rate;
+};
+
 struct HnswArgs {
     DevIndex ix;
     const float *queries;      // [b][dim]
@@ -23,6 +42,8 @@ struct HnswArgs {
     hvx_query_stats *qstats;   // [b] nullable
     uint32_t *tie_flags;       // [b] nullable
     unsigned long long *prof;  // [b][8] phase cycle counters of the PROF kernel variant, nullable
+    uint32_t adaptive;         // 0 = strict-exhaustive search; 1 = non-strict arms, policy in `ad`
+    AdaptArgs ad;
 };
 
 size_t hnsw_lds_bytes(uint32_t ld);
@@ -30,6 +51,13 @@ size_t hnsw_lds_bytes(uint32_t ld);
 hipError_t launch_hnsw_search(const HnswArgs &a, uint32_t b, hipStream_t s);
 // fast kernel (1 wavefront per query, hvx_hnsw_wave.h); leaves the HBM bitmap zeroed
 bool hnsw_wave_supported(const HnswArgs &a);
+// non-strict arms: the AD instantiations of the wave kernel (f32 rows only)
+bool hnsw_wave_adaptive_supported(const HnswArgs &a);
+// SimHash of n device-resident f32 rows (row stride ld) against transposed hyperplanes [dim][64]
+hipError_t launch_simhash_rows(const float *planes_t, const float *rows, uint32_t dim, uint32_t ld, uint64_t n, uint64_t *out,
+                               hipStream_t s);
+// host: the 64 unit hyperplanes of SimHasher(dim, seed), transposed to [dim][64]
+void simhash_planes_transposed(uint32_t dim, uint64_t seed, float *planes_t);
 hipError_t launch_hnsw_wave(const HnswArgs &a, uint32_t b, hipStream_t s);
 
 // validate queries on the device (domain.rs:113-157) and compute the cosine header

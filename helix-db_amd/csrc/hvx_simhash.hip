@@ -67,11 +67,11 @@ void chacha12_block(const uint32_t key[8], uint64_t counter, uint32_t out[16]) {
     for (int i = 0; i < 16; ++i) out[i] = x[i] + st[i];
 }
 
-__global__ __launch_bounds__(64) void simhash_kernel(const float *planes_t, const float *vectors, uint32_t dim, uint64_t n,
-                                                     uint64_t *out) {
+__global__ __launch_bounds__(64) void simhash_kernel(const float *planes_t, const float *vectors, uint32_t dim, uint32_t ld,
+                                                     uint64_t n, uint64_t *out) {
     const uint64_t r = blockIdx.x;
     if (r >= n) return;
-    const float *v = vectors + r * dim;
+    const float *v = vectors + r * ld;
     const int lane = (int)threadIdx.x;
     float dot = 0.0f;
     for (uint32_t d = 0; d < dim; ++d) {
@@ -83,6 +83,38 @@ __global__ __launch_bounds__(64) void simhash_kernel(const float *planes_t, cons
 }
 
 } // namespace
+
+namespace hvx {
+hipError_t launch_simhash_rows(const float *planes_t, const float *rows, uint32_t dim, uint32_t ld, uint64_t n, uint64_t *out,
+                               hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(simhash_kernel, dim3((uint32_t)n), dim3(64), 0, s, planes_t, rows, dim, ld, n, out);
+    return hipGetLastError();
+}
+
+// 64 hyperplanes, plane-major draws; component = u*2-1 with u = (next_u32 >> 8) * 2^-24; normalised in f32
+void simhash_planes_transposed(uint32_t dim, uint64_t seed, float *planes_t) {
+    std::vector<float> planes((size_t)64 * dim);
+    uint32_t key[8], blk[16];
+    seed_from_u64(seed, key);
+    uint64_t ctr = 0;
+    size_t have = 16, total = (size_t)64 * dim;
+    for (size_t i = 0; i < total; ++i) {
+        if (have == 16) { chacha12_block(key, ctr++, blk); have = 0; }
+        const float value = (float)(blk[have++] >> 8) * (1.0f / 16777216.0f);
+        planes[i] = value * 2.0f - 1.0f;
+    }
+    for (uint32_t p = 0; p < 64; ++p) {
+        float *pl = planes.data() + (size_t)p * dim;
+        float s = 0.0f;
+        for (uint32_t d = 0; d < dim; ++d) { const float t = pl[d] * pl[d]; s += t; }
+        const float norm = std::sqrt(s);
+        if (norm > 1e-10f)
+            for (uint32_t d = 0; d < dim; ++d) pl[d] /= norm;
+        for (uint32_t d = 0; d < dim; ++d) planes_t[(size_t)d * 64 + p] = pl[d];
+    }
+}
+} // namespace hvx
 
 extern "C" uint64_t hvx_order_code_from_simhash_bits(uint64_t bits) {
     const uint16_t b0 = (uint16_t)(bits >> 48), b1 = (uint16_t)(bits >> 32), b2 = (uint16_t)(bits >> 16), b3 = (uint16_t)bits;
@@ -114,26 +146,9 @@ extern "C" int hvx_simhasher_new(uint32_t dim, uint64_t seed, int32_t device, hv
     int dev = device;
     if (dev < 0) HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipSetDevice(dev));
-    // 64 hyperplanes, plane-major draws; component = u*2-1 with u = (next_u32 >> 8) * 2^-24; normalised in f32
-    std::vector<float> planes((size_t)64 * dim), planes_t((size_t)64 * dim);
-    uint32_t key[8], blk[16];
-    seed_from_u64(seed, key);
-    uint64_t ctr = 0;
-    size_t have = 16, total = (size_t)64 * dim;
-    for (size_t i = 0; i < total; ++i) {
-        if (have == 16) { chacha12_block(key, ctr++, blk); have = 0; }
-        const float value = (float)(blk[have++] >> 8) * (1.0f / 16777216.0f);
-        planes[i] = value * 2.0f - 1.0f;
-    }
-    for (uint32_t p = 0; p < 64; ++p) {
-        float *pl = planes.data() + (size_t)p * dim;
-        float s = 0.0f;
-        for (uint32_t d = 0; d < dim; ++d) { const float t = pl[d] * pl[d]; s += t; }
-        const float norm = std::sqrt(s);
-        if (norm > 1e-10f)
-            for (uint32_t d = 0; d < dim; ++d) pl[d] /= norm;
-        for (uint32_t d = 0; d < dim; ++d) planes_t[(size_t)d * 64 + p] = pl[d];
-    }
+    const size_t total = (size_t)64 * dim;
+    std::vector<float> planes_t(total);
+    simhash_planes_transposed(dim, seed, planes_t.data());
     hvx_simhasher *h = new hvx_simhasher();
     h->device = dev;
     h->dim = dim;
@@ -164,8 +179,7 @@ extern "C" int hvx_simhash_batch(const hvx_simhasher *ch, const float *vectors, 
             h->cap_rows = rows;
         }
         HIP_TRY(hipMemcpyAsync(h->d_stage, vectors + r0 * h->dim, rows * h->dim * 4, hipMemcpyDefault, h->stream));
-        hipLaunchKernelGGL(simhash_kernel, dim3((uint32_t)rows), dim3(64), 0, h->stream, h->d_planes_t, h->d_stage, h->dim, rows, h->d_bits);
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(launch_simhash_rows(h->d_planes_t, h->d_stage, h->dim, h->dim, rows, h->d_bits, h->stream));
         HIP_TRY(hipMemcpyAsync(out_bits + r0, h->d_bits, rows * 8, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     }

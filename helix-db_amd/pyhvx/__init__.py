@@ -63,6 +63,44 @@ class QueryStats(C.Structure):
                 ("vectors_loaded", C.c_uint32), ("distance_computations", C.c_uint32)]
 
 
+SIMHASH_ALWAYS, SIMHASH_ADAPTIVE, SIMHASH_OFF = 0, 1, 2
+
+
+class _Params(C.Structure):  # hvx_search_params
+    _fields_ = [("k", C.c_uint32), ("ef", C.c_uint32), ("simhash_mode", C.c_uint32),
+                ("pre_simhash_sampling_ratio_override", C.c_float),
+                ("bypass_min_frontier", C.c_uint32), ("bypass_window_expansions", C.c_uint32),
+                ("bypass_min_filter_rate", C.c_float), ("read_budget_multiplier", C.c_uint32),
+                ("simhash_sampling_ratio_override", C.c_float), ("simhash_failure_prob_override", C.c_float)]
+
+
+class SimHashConfig(C.Structure):  # hvx_simhash_config: the index-level VectorIndexConfig knobs
+    _fields_ = [("seed", C.c_uint64), ("simhash_threshold", C.c_uint32), ("sampling_ratio", C.c_float),
+                ("adaptive_enabled", C.c_uint32), ("adaptive_failure_prob", C.c_float)]
+
+    @classmethod
+    def default(cls, **over):
+        c = cls()
+        lib().hvx_simhash_config_default(C.byref(c))
+        for key, v in over.items():
+            assert hasattr(c, key), key
+            setattr(c, key, v)
+        return c
+
+
+class AdaptiveStats(C.Structure):  # hvx_adaptive_stats
+    _fields_ = [(n, C.c_uint32) for n in (
+        "simhash_filtered", "simhash_examined", "simhash_passed_before_sampling", "simhash_passed_after_sampling",
+        "pre_simhash_sample_kept", "pre_simhash_sample_dropped", "simhash_bypass_expansions",
+        "simhash_skipped_candidates", "simhash_bypass_trigger_budget", "simhash_bypass_trigger_low_yield",
+        "active_simhash_threshold_sum", "active_simhash_threshold_samples", "effective_beam_len_sum",
+        "effective_beam_len_samples", "active_sampling_ratio_samples", "rng_words")] + \
+        [("active_sampling_ratio_sum", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 _lib = None
 _vp = C.c_void_p
 
@@ -90,6 +128,18 @@ def lib():
     L.hvx_search_batch.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, C.POINTER(Stats)]
     L.hvx_search_batch_device.restype = C.c_int
     L.hvx_search_batch_device.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp, C.POINTER(Stats)]
+    L.hvx_search_params_default.restype = None
+    L.hvx_search_params_default.argtypes = [C.POINTER(_Params), C.c_uint32]
+    L.hvx_simhash_config_default.restype = None
+    L.hvx_simhash_config_default.argtypes = [C.POINTER(SimHashConfig)]
+    L.hvx_index_set_simhash.restype = C.c_int
+    L.hvx_index_set_simhash.argtypes = [_vp, C.POINTER(SimHashConfig), _vp]
+    L.hvx_index_get_simhash.restype = C.c_int
+    L.hvx_index_get_simhash.argtypes = [_vp, _vp]
+    L.hvx_search_batch_params.restype = C.c_int
+    L.hvx_search_batch_params.argtypes = [_vp, _vp, C.c_uint32, C.POINTER(_Params), _vp, _vp, _vp, _vp, C.POINTER(Stats), _vp, _vp]
+    L.hvx_search_batch_params_device.restype = C.c_int
+    L.hvx_search_batch_params_device.argtypes = [_vp, _vp, C.c_uint32, C.POINTER(_Params), _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(Stats)]
     L.hvx_flat_search_batch.restype = C.c_int
     L.hvx_flat_search_batch.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, C.POINTER(Stats)]
     L.hvx_flat_search_batch_device.restype = C.c_int
@@ -151,19 +201,89 @@ class SearchResult:  # result.rs:20-41
 
 
 class SearchParams:
-    """mod.rs:482-516: SearchParams::new(k) => ef = max(k, 100); with_ef validates ef >= k."""
+    """mod.rs:410-621 SearchParams.
 
-    def __init__(self, k: int):
+    `SearchParams.new(k)` is the reference's `SearchParams::new(k)`: ef = max(k, 100), SimHashMode::Adaptive, bypass
+    tuning (24, 4, 0.12, 3) -- what the query path runs (access/search/storage.rs:140-141).  `SearchParams(k)` is the
+    strict-exhaustive baseline the reference's golden tests and benches use:
+    `SearchParams::new(k).with_simhash_mode(Off).with_pre_simhash_sampling_ratio(1.0)` (index.rs:2335-2342).
+    """
+
+    def __init__(self, k: int, *, _strict: bool = True):
         if k <= 0:
             raise HelixDbError(ERR_K_RANGE, "result count must be non-zero")
         self.k = int(k)
         self.ef = max(self.k, 100)
+        self.simhash_mode = SIMHASH_OFF if _strict else SIMHASH_ADAPTIVE
+        self.pre_simhash_sampling_ratio_override = 1.0 if _strict else None
+        self.simhash_bypass_min_frontier, self.simhash_bypass_window_expansions = 24, 4
+        self.simhash_bypass_min_filter_rate, self.simhash_read_budget_multiplier = 0.12, 3
+        self.simhash_sampling_ratio_override = None
+        self.simhash_failure_prob_override = None
+
+    @classmethod
+    def new(cls, k: int) -> "SearchParams":
+        return cls(k, _strict=False)
+
+    @classmethod
+    def throughput_profile_floor_92(cls, k: int) -> "SearchParams":  # mod.rs:614-620
+        return cls.new(k).with_ef(max(k, 48)).with_simhash_mode(SIMHASH_ADAPTIVE) \
+            .with_pre_simhash_sampling_ratio(0.20).with_simhash_bypass_tuning(24, 4, 0.12, 3)
 
     def with_ef(self, ef: int) -> "SearchParams":
         if ef <= 0 or ef < self.k:
             raise HelixDbError(ERR_K_RANGE, f"search beam width {ef} is below the result count {self.k}")
         self.ef = int(ef)
         return self
+
+    def with_simhash_mode(self, mode: int) -> "SearchParams":
+        self.simhash_mode = int(mode)
+        return self
+
+    @staticmethod
+    def _unit(value, what):  # parameters.rs:170-184
+        v = float(value)
+        if not np.isfinite(v) or not 0.0 <= v <= 1.0:
+            raise HelixDbError(ERR_K_RANGE, f"{what} outside the closed unit interval")
+        return v
+
+    def with_pre_simhash_sampling_ratio(self, ratio: float) -> "SearchParams":
+        self.pre_simhash_sampling_ratio_override = self._unit(ratio, "pre-sampling ratio")
+        return self
+
+    def clear_pre_simhash_sampling_ratio_override(self) -> "SearchParams":
+        self.pre_simhash_sampling_ratio_override = None
+        return self
+
+    def with_simhash_bypass_tuning(self, min_frontier, window_expansions, min_filter_rate, read_budget_multiplier):
+        if min(min_frontier, window_expansions, read_budget_multiplier) <= 0:
+            raise HelixDbError(ERR_K_RANGE, "SimHash bypass tuning parameters must be non-zero")
+        self.simhash_bypass_min_frontier, self.simhash_bypass_window_expansions = int(min_frontier), int(window_expansions)
+        self.simhash_bypass_min_filter_rate = self._unit(min_filter_rate, "bypass filter rate")
+        self.simhash_read_budget_multiplier = int(read_budget_multiplier)
+        return self
+
+    def with_simhash_sampling_ratio(self, ratio: float) -> "SearchParams":
+        self.simhash_sampling_ratio_override = self._unit(ratio, "sampling ratio")
+        return self
+
+    def with_simhash_failure_prob(self, p: float) -> "SearchParams":
+        p = float(p)
+        if not np.isfinite(p) or not 0.0 < p < 1.0:  # parameters.rs:196-210
+            raise HelixDbError(ERR_K_RANGE, "failure probability outside the open unit interval")
+        self.simhash_failure_prob_override = p
+        return self
+
+    def requires_query_simhash(self) -> bool:  # mod.rs:546-552
+        pre = self.pre_simhash_sampling_ratio_override
+        return self.simhash_mode != SIMHASH_OFF or (pre is not None and pre < 1.0)
+
+    def _c(self) -> "_Params":
+        none = lambda v: -1.0 if v is None else float(v)
+        return _Params(self.k, self.ef, self.simhash_mode, none(self.pre_simhash_sampling_ratio_override),
+                       self.simhash_bypass_min_frontier, self.simhash_bypass_window_expansions,
+                       self.simhash_bypass_min_filter_rate, self.simhash_read_budget_multiplier,
+                       none(self.simhash_sampling_ratio_override), none(self.simhash_failure_prob_override))
 
 
 class RestrictedVectorCandidates:
@@ -262,9 +382,53 @@ class ValidatedVectorReadIndex:
         ids = np.zeros((b, k), np.uint64); sc = np.zeros((b, k), np.float32)
         cnt = np.zeros(b, np.uint32); st = np.zeros(b, np.uint32)
         stats = Stats()
-        _check(lib().hvx_search_batch(self._h, _ptr(q), b, k, params.ef, _ptr(ids), _ptr(sc), _ptr(cnt),
-                                      _ptr(st) if per_query_status else None, C.byref(stats)))
+        if params.requires_query_simhash():
+            _check(lib().hvx_search_batch_params(self._h, _ptr(q), b, C.byref(params._c()), _ptr(ids), _ptr(sc), _ptr(cnt),
+                                                 _ptr(st) if per_query_status else None, C.byref(stats), None, None))
+        else:
+            _check(lib().hvx_search_batch(self._h, _ptr(q), b, k, params.ef, _ptr(ids), _ptr(sc), _ptr(cnt),
+                                          _ptr(st) if per_query_status else None, C.byref(stats)))
         return (ids, sc, cnt, stats.as_dict()) if not per_query_status else (ids, sc, cnt, stats.as_dict(), st)
+
+    def search_batch_with_stats(self, queries, params: SearchParams):
+        """search_with_stats (index.rs:1589-1611) for a batch: results + per-query SearchStats counters of both arms."""
+        q = self._q(queries)
+        b, k = q.shape[0], params.k
+        ids = np.zeros((b, k), np.uint64); sc = np.zeros((b, k), np.float32)
+        cnt = np.zeros(b, np.uint32); st = np.zeros(b, np.uint32)
+        qs = (QueryStats * b)(); ad = (AdaptiveStats * b)()
+        stats = Stats()
+        _check(lib().hvx_search_batch_params(self._h, _ptr(q), b, C.byref(params._c()), _ptr(ids), _ptr(sc), _ptr(cnt), _ptr(st),
+                                             C.byref(stats), C.cast(qs, _vp), C.cast(ad, _vp)))
+        per_query = []
+        for i in range(b):
+            d = {f: int(getattr(qs[i], f)) for f, _ in QueryStats._fields_}
+            d.update(ad[i].as_dict())
+            per_query.append(d)
+        return ids, sc, cnt, st, per_query, stats.as_dict()
+
+    def set_simhash(self, config: "SimHashConfig" = None, node_hashes=None):
+        """Attach the per-node SimHash rows (computed on the device from the f32 rows when node_hashes is None)."""
+        cfg = config if config is not None else SimHashConfig.default()
+        h = None if node_hashes is None else np.ascontiguousarray(node_hashes, dtype=np.uint64)
+        if h is not None and h.size != self.n:
+            raise HelixDbError(ERR_INVARIANT, "one SimHash row per node expected")
+        _check(lib().hvx_index_set_simhash(self._h, C.byref(cfg), _ptr(h)))
+        return self
+
+    def get_simhash(self) -> np.ndarray:
+        out = np.zeros(self.n, np.uint64)
+        _check(lib().hvx_index_get_simhash(self._h, _ptr(out)))
+        return out
+
+    def search_batch_params_device(self, d_queries, params: SearchParams, d_ids, d_scores, d_counts, d_status, d_qstats=None,
+                                   d_astats=None, want_stats=False):
+        stats = Stats()
+        _check(lib().hvx_search_batch_params_device(
+            self._h, d_queries.data_ptr(), d_queries.shape[0], C.byref(params._c()), d_ids.data_ptr(), d_scores.data_ptr(),
+            d_counts.data_ptr(), d_status.data_ptr(), None if d_qstats is None else d_qstats.data_ptr(),
+            None if d_astats is None else d_astats.data_ptr(), C.byref(stats) if want_stats else None))
+        return stats.as_dict() if want_stats else None
 
     def flat_search_batch(self, queries, k, per_query_status=False):
         q = self._q(queries)

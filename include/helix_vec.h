@@ -123,6 +123,79 @@ int hvx_search_batch_device(const hvx_index *, const float *d_queries, uint32_t 
                             hvx_query_stats *d_query_stats, hvx_stats *stats);
 
 /*
+ * Full SearchParams (mod.rs:410-621): the NON-strict arms of the layer-0 search -- SimHash threshold filter,
+ * pre / post sampling, adaptive bypass (search.rs:595-829, policy.rs, randomness.rs).
+ * `SearchParams::new(k)` -- what the query path runs (access/search/storage.rs:140-141) -- is
+ * hvx_search_params_default(): ef = max(k, 100), SimHashMode::Adaptive, bypass tuning (24, 4, 0.12, 3).
+ */
+typedef enum hvx_simhash_mode { HVX_SIMHASH_ALWAYS = 0, HVX_SIMHASH_ADAPTIVE = 1, HVX_SIMHASH_OFF = 2 } hvx_simhash_mode;
+
+typedef struct hvx_search_params {
+    uint32_t k, ef;                              /* ResultCount, SearchBeamWidth (ef >= k) */
+    uint32_t simhash_mode;                       /* hvx_simhash_mode */
+    float pre_simhash_sampling_ratio_override;   /* [0,1]; < 0 = None */
+    uint32_t bypass_min_frontier;                /* with_simhash_bypass_tuning (mod.rs:555-583), all non-zero */
+    uint32_t bypass_window_expansions;
+    float bypass_min_filter_rate;
+    uint32_t read_budget_multiplier;
+    float simhash_sampling_ratio_override;       /* [0,1]; < 0 = None */
+    float simhash_failure_prob_override;         /* (0,1); < 0 = None */
+} hvx_search_params;
+void hvx_search_params_default(hvx_search_params *, uint32_t k);
+
+/* index-level knobs of VectorIndexConfig the params resolve against (values/vectors/metadata.rs:38-44;
+ * defaults 43 / 0.8 / true / 0.1, SimHasher seed 42: mod.rs:313-329, generation.rs:25) */
+typedef struct hvx_simhash_config {
+    uint64_t seed;
+    uint32_t simhash_threshold;                  /* <= 64 */
+    float sampling_ratio;                        /* [0,1] */
+    uint32_t adaptive_enabled;
+    float adaptive_failure_prob;                 /* (0,1) */
+} hvx_simhash_config;
+void hvx_simhash_config_default(hvx_simhash_config *);
+
+/* Attach the per-node SimHash rows ([0xF0][index_id][0x13] rows / order codes of the vector keys) to an imported
+ * index: node_hashes [n] in node-id order (host memory), or NULL to compute them on the device with
+ * SimHasher(dim, cfg->seed) from the imported f32 rows (unaligned_vector/simhash.rs:263-291).  Required before
+ * a search whose params need the query fingerprint (SearchParams::requires_query_simhash, mod.rs:546-552). */
+int hvx_index_set_simhash(hvx_index *, const hvx_simhash_config *cfg, const uint64_t *node_hashes);
+int hvx_index_get_simhash(const hvx_index *, uint64_t *out_node_hashes /*[n] host*/);
+
+/* SearchStats fields of the non-strict arms (mod.rs:629-700), per query.  The device index plays the resident
+ * snapshot (memory_store.rs:329-335): SimHash lookups are not stable-view reads, txn_get_simhash_filter stays 0
+ * and the read-budget bypass trigger cannot fire -- exactly as for the reference with a Ready resident store. */
+typedef struct hvx_adaptive_stats {
+    uint32_t simhash_filtered, simhash_examined;
+    uint32_t simhash_passed_before_sampling, simhash_passed_after_sampling;
+    uint32_t pre_simhash_sample_kept, pre_simhash_sample_dropped;
+    uint32_t simhash_bypass_expansions, simhash_skipped_candidates;
+    uint32_t simhash_bypass_trigger_budget, simhash_bypass_trigger_low_yield;
+    uint32_t active_simhash_threshold_sum, active_simhash_threshold_samples; /* avg_active_simhash_threshold */
+    uint32_t effective_beam_len_sum, effective_beam_len_samples;             /* avg_effective_beam_len */
+    uint32_t active_sampling_ratio_samples;                                  /* avg_active_sampling_ratio */
+    uint32_t rng_words;                          /* u32 outputs drawn from the query's StdRng (not a reference field) */
+    double active_sampling_ratio_sum;
+} hvx_adaptive_stats;
+
+/*
+ * SearchSession::run (search.rs:1101-1230) under full SearchParams, b queries at once.  Strict-exhaustive
+ * params (mode Off, no pre-sampling below 1.0) take the same kernel as hvx_search_batch.  Otherwise the query
+ * SimHash is computed on the device, the query RNG is rand's StdRng seeded with
+ * simhash ^ rotl(entry,17) ^ rotl(ef,7) (randomness.rs:104-120), and every decision epoch follows policy.rs.
+ * Results, SearchStats counters and the number of RNG words drawn equal the reference CPU path's for the same
+ * (index, query, params) -- with one caveat: the two `choose_index` fallback sites (search.rs:667,818) use
+ * rand's `random_range`, for which the reference holds no known answer (restated, parity unpinned).
+ * query_stats / adaptive_stats: per query, host (…_device: device) memory, nullable.
+ */
+int hvx_search_batch_params(const hvx_index *, const float *queries, uint32_t b, const hvx_search_params *params,
+                            uint64_t *out_ids, float *out_scores, uint32_t *out_counts, uint32_t *out_status,
+                            hvx_stats *stats, hvx_query_stats *query_stats, hvx_adaptive_stats *adaptive_stats);
+int hvx_search_batch_params_device(const hvx_index *, const float *d_queries, uint32_t b, const hvx_search_params *params,
+                                   uint64_t *d_out_ids, float *d_out_scores, uint32_t *d_out_counts,
+                                   uint32_t *d_out_status, hvx_query_stats *d_query_stats,
+                                   hvx_adaptive_stats *d_adaptive_stats, hvx_stats *stats);
+
+/*
  * Exact scan over all rows -- the reference has no general flat operator; semantics are
  * restricted_exact_scan (restricted.rs:753-835) with allowed = every id and no 256-id admission cap.
  */

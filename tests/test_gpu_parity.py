@@ -539,3 +539,192 @@ def test_hydration_from_persisted_rows_equals_direct_import(orc, hv):
     gix = hy.finish()
     q = rng.standard_normal((16, dim)).astype(np.float32)
     assert_hnsw_equal(orc, hv, oix, gix, q, 10, 64)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Non-strict layer-0 arms: SimHash filter, pre/post sampling, adaptive bypass, query RNG.
+# Oracle: oracle/hvx_oracle_adaptive.inc (pinned by the reference's policy / search-mode tests, tests/test_oracle_adaptive.py).
+# ---------------------------------------------------------------------------------------------------------------
+def _oracle_params(orc, p, cfg):
+    none = lambda v: -1.0 if v is None else float(v)
+    return orc.SearchParams.new(
+        p.k, ef=p.ef, simhash_mode=p.simhash_mode,
+        pre_simhash_sampling_ratio_override=none(p.pre_simhash_sampling_ratio_override),
+        bypass_min_frontier=p.simhash_bypass_min_frontier, bypass_window_expansions=p.simhash_bypass_window_expansions,
+        bypass_min_filter_rate=p.simhash_bypass_min_filter_rate, read_budget_multiplier=p.simhash_read_budget_multiplier,
+        simhash_sampling_ratio_override=none(p.simhash_sampling_ratio_override),
+        simhash_failure_prob_override=none(p.simhash_failure_prob_override),
+        simhash_threshold=cfg.simhash_threshold, sampling_ratio=cfg.sampling_ratio,
+        adaptive_enabled=cfg.adaptive_enabled, adaptive_failure_prob=cfg.adaptive_failure_prob,
+        resident_simhash=1)  # the device index plays the resident snapshot (memory_store.rs:329-335)
+
+
+ADAPTIVE_STAT_KEYS = ("expansion_steps", "neighbors_examined", "vectors_loaded", "distance_computations",
+                      "simhash_filtered", "simhash_examined", "simhash_passed_before_sampling",
+                      "simhash_passed_after_sampling", "pre_simhash_sample_kept", "pre_simhash_sample_dropped",
+                      "simhash_bypass_expansions", "simhash_skipped_candidates", "simhash_bypass_trigger_budget",
+                      "simhash_bypass_trigger_low_yield", "active_simhash_threshold_sum",
+                      "active_simhash_threshold_samples", "effective_beam_len_sum", "effective_beam_len_samples",
+                      "active_sampling_ratio_samples", "rng_words", "active_sampling_ratio_sum")
+
+
+def assert_params_equal(orc, hv, oix, gix, queries, p, cfg):
+    ids, sc, cnt, st, per_query, stats = gix.search_batch_with_stats(queries, p)
+    op = _oracle_params(orc, p, cfg)
+    agg = {}
+    for qi in range(queries.shape[0]):
+        rc, oid, osc, ost = oix.search_params(queries[qi], op, with_stats=True)
+        assert rc == orc.OK and st[qi] == 0
+        assert ids[qi, :cnt[qi]].tolist() == oid.tolist(), f"query {qi}: ids differ"
+        assert bits(sc[qi, :cnt[qi]]).tolist() == bits(osc).tolist(), f"query {qi}: score bits differ"
+        for key in ADAPTIVE_STAT_KEYS:
+            assert per_query[qi][key] == ost[key], f"query {qi}: {key} device {per_query[qi][key]} vs oracle {ost[key]}"
+            agg[key] = agg.get(key, 0) + ost[key]
+    assert stats["tie_overflow_queries"] == 0
+    return agg
+
+
+def _default(hv):
+    return hv.SearchParams.new(10)
+
+
+def _always_post_sampling(hv):   # fixed threshold, explicit pre 1.0 => the post-filter Bernoulli stage draws
+    return hv.SearchParams.new(10).with_ef(64).with_simhash_mode(hv.SIMHASH_ALWAYS).with_pre_simhash_sampling_ratio(1.0) \
+        .with_simhash_sampling_ratio(0.5)
+
+
+def _adaptive_post_sampling(hv):  # candidate_probability weighting by similarity bits
+    return hv.SearchParams.new(10).with_ef(48).with_pre_simhash_sampling_ratio(1.0).with_simhash_sampling_ratio(0.35)
+
+
+def _throughput(hv):
+    return hv.SearchParams.throughput_profile_floor_92(10)
+
+
+def _bypass_happy(hv):            # index.rs:2515-2530: every filtering epoch re-triggers the low-yield bypass
+    return hv.SearchParams.new(5).with_ef(16).with_pre_simhash_sampling_ratio(0.25).with_simhash_sampling_ratio(0.5) \
+        .with_simhash_failure_prob(0.5).with_simhash_bypass_tuning(1, 1, 1.0, 1)
+
+
+def _defer_all(hv):               # ratio 0 defers every neighbour and disables the fallback: the entry is the result
+    return hv.SearchParams.new(10).with_ef(32).with_simhash_mode(hv.SIMHASH_ALWAYS).with_pre_simhash_sampling_ratio(1.0) \
+        .with_simhash_sampling_ratio(0.0)
+
+
+def _fallback(hv):                # ratio 0.03: most wide frontiers sample nobody and take the choose_index fallback
+    return hv.SearchParams.new(10).with_ef(32).with_simhash_mode(hv.SIMHASH_ALWAYS).with_pre_simhash_sampling_ratio(1.0) \
+        .with_simhash_sampling_ratio(0.03)
+
+
+def _pre_zero(hv):                # pre-sampling ratio 0: the pre-stage fallback picks one neighbour per wide frontier
+    return hv.SearchParams.new(10).with_ef(24).with_pre_simhash_sampling_ratio(0.0)
+
+
+def _wide_beam(hv):
+    return hv.SearchParams.new(50).with_ef(200)
+
+
+ADAPTIVE_CASES = [
+    # (name, metric, n, dim, m, m0, params, config overrides)
+    ("default-cos", 0, 3000, 128, 16, 32, _default, {}),
+    ("default-l2", 1, 3000, 128, 16, 32, _default, {}),
+    ("default-cos-768", 0, 1500, 768, 16, 32, _default, {}),
+    ("always-post", 0, 2500, 256, 16, 32, _always_post_sampling, {"simhash_threshold": 30}),
+    ("adaptive-post", 0, 2500, 128, 32, 64, _adaptive_post_sampling, {"sampling_ratio": 0.35}),
+    ("throughput-l2", 1, 2500, 128, 32, 64, _throughput, {}),
+    ("throughput-cos", 0, 2500, 128, 32, 64, _throughput, {}),
+    ("bypass", 0, 2000, 128, 16, 32, _bypass_happy, {"simhash_threshold": 20, "sampling_ratio": 0.5}),
+    ("defer-all", 0, 2000, 128, 16, 32, _defer_all, {"simhash_threshold": 28}),
+    ("fallback", 0, 2000, 128, 16, 32, _fallback, {"simhash_threshold": 28}),
+    ("fallback-l2", 1, 2000, 128, 32, 64, _fallback, {}),
+    ("pre-zero", 1, 2000, 128, 32, 64, _pre_zero, {}),
+    ("fixed-not-adaptive", 0, 2000, 128, 16, 32, _default, {"adaptive_enabled": 0, "simhash_threshold": 34}),
+    ("wide-beam", 0, 3000, 128, 16, 32, _wide_beam, {}),
+    ("threshold-0", 0, 2000, 128, 16, 32, _default, {"simhash_threshold": 0}),
+]
+
+
+@pytest.mark.parametrize("name,metric,n,dim,m,m0,mk,over", ADAPTIVE_CASES, ids=[c[0] for c in ADAPTIVE_CASES])
+def test_non_strict_arms_match_oracle(orc, hv, name, metric, n, dim, m, m0, mk, over):
+    """Production-default (`SearchParams::new(k)`) and every other non-strict configuration: ids, score bits, all
+    SearchStats counters of the filter / sampling / bypass stages and the number of RNG words drawn equal the oracle's."""
+    rng = np.random.default_rng(1000 + n + dim + metric)
+    centers = rng.standard_normal((24, dim)).astype(np.float32)
+    data = (centers[rng.integers(0, 24, n)] + 0.7 * rng.standard_normal((n, dim))).astype(np.float32)
+    lv = fx.draw_levels(n, m, seed=dim + 3)
+    oix = build_oracle(orc, data, metric, lv, m=m, m0=m0, efc=80)
+    cfg = hv.SimHashConfig.default(**over)
+    oix.set_simhash(int(cfg.seed))
+    gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=dim, metric=metric, m=m, m0=m0)
+    gix.set_simhash(cfg)
+    assert gix.get_simhash().tolist() == oix.get_simhash().tolist()      # device SimHasher == oracle, every row
+    q = (centers[rng.integers(0, 24, 40)] + 0.7 * rng.standard_normal((40, dim))).astype(np.float32)
+    p = mk(hv)
+    agg = assert_params_equal(orc, hv, oix, gix, q, p, cfg)
+    assert_params_equal(orc, hv, oix, gix, q[:7], p, cfg)               # second launch: clean visited state
+    # the case exercises what its name says
+    if name in ("default-cos", "default-cos-768", "throughput-cos", "wide-beam", "fixed-not-adaptive"):
+        assert agg["simhash_examined"] > 0 and agg["simhash_filtered"] > 0
+    if metric == 1:
+        assert agg["simhash_examined"] == 0
+    if name in ("always-post", "adaptive-post"):
+        assert agg["pre_simhash_sample_kept"] == 0 and agg["rng_words"] > 0
+        assert agg["simhash_passed_after_sampling"] < agg["simhash_passed_before_sampling"]
+    if name.startswith("throughput") or name.startswith("default"):
+        assert agg["pre_simhash_sample_dropped"] > 0
+    if name == "bypass":
+        assert agg["simhash_bypass_expansions"] > 0 and agg["simhash_bypass_trigger_low_yield"] > 0
+    if name == "defer-all":
+        assert agg["simhash_passed_after_sampling"] == 0 and agg["rng_words"] == 0 and agg["distance_computations"] == 40
+    if name.startswith("fallback"):
+        assert agg["simhash_passed_after_sampling"] > 0 and agg["rng_words"] > agg["simhash_passed_before_sampling"] // 2
+    if name == "pre-zero":
+        assert agg["pre_simhash_sample_dropped"] > 0 and agg["pre_simhash_sample_kept"] > 0
+
+
+def test_non_strict_arms_spill_path_and_given_hashes(orc, hv, monkeypatch):
+    """LDS visited table -> HBM bitmap spill inside the non-strict arms (visited TEST and late insert both take the
+    bitmap), with the SimHash rows handed over by the host instead of recomputed."""
+    monkeypatch.setenv("HVX_WAVE_LOG2CAP", "8")
+    rng = np.random.default_rng(4242)
+    n, dim = 2500, 128
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    lv = fx.draw_levels(n, 16, seed=8)
+    oix = build_oracle(orc, data, 0, lv, efc=80)
+    oix.set_simhash(42)
+    cfg = hv.SimHashConfig.default()
+    gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=dim, metric=0)
+    gix.set_simhash(cfg, node_hashes=oix.get_simhash())
+    q = rng.standard_normal((24, dim)).astype(np.float32)
+    agg = assert_params_equal(orc, hv, oix, gix, q, hv.SearchParams.new(10), cfg)
+    assert agg["distance_computations"] > 24 * 128  # far more visited ids than the 256-slot table holds
+
+
+def test_strict_params_route_to_the_strict_kernel_and_validation(orc, hv):
+    rng = np.random.default_rng(99)
+    n, dim = 1500, 128
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    oix = build_oracle(orc, data, 1, fx.draw_levels(n, 16, seed=1), efc=60)
+    gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=dim, metric=1)
+    q = rng.standard_normal((8, dim)).astype(np.float32)
+    # Off + pre 1.0 through the params entry point == hvx_search_batch (no SimHash rows needed)
+    strict = hv.SearchParams(10).with_ef(64)
+    ids, sc, cnt, st, per_query, _ = gix.search_batch_with_stats(q, strict)
+    ids2, sc2, cnt2, _ = gix.search_batch(q, strict)
+    assert ids.tolist() == ids2.tolist() and bits(sc).tolist() == bits(sc2).tolist()
+    assert all(d["rng_words"] == 0 and d["effective_beam_len_samples"] == 0 for d in per_query)
+    # "layer-zero filtering or sampling requires a query fingerprint" (search.rs:289-295)
+    with pytest.raises(hv.HelixDbError) as e:
+        gix.search_batch(q, hv.SearchParams.new(10))
+    assert e.value.status == hv.ERR_INVARIANT
+    gix.set_simhash()
+    bad = hv.SearchParams.new(10)
+    bad.simhash_bypass_window_expansions = 0
+    with pytest.raises(hv.HelixDbError) as e:
+        gix.search_batch(q, bad)
+    assert e.value.status == hv.ERR_K_RANGE
+    # invalid queries keep their per-query status in the non-strict arms too
+    q2 = q.copy()
+    q2[3, 5] = np.nan
+    ids, sc, cnt, stats, st = gix.search_batch(q2, hv.SearchParams.new(10), per_query_status=True)
+    assert st.tolist() == [0, 0, 0, hv.ERR_NONFINITE, 0, 0, 0, 0] and cnt[3] == 0

@@ -17,6 +17,7 @@ checker of the GPU results; the timed product path is the HIP library through it
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -60,6 +61,10 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores (capped at 64)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle bit-exactness check")
+    ap.add_argument("--metric", default="l2", choices=["l2", "cosine"],
+                    help="l2 = BASELINE config #2; cosine (rows normalised) additionally exercises the SimHash filter of the production default")
+    ap.add_argument("--no-production-default", action="store_true",
+                    help="skip the extra `SearchParams::new(k)` (SimHashMode::Adaptive, ef=max(k,100)) measurement")
     ap.add_argument("--graph-cache", default="", help="npz path: reuse the built graph across invocations on one box")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "traffic_latest.json"))
     return ap.parse_args()
@@ -95,6 +100,11 @@ def main():
         xg, q = synth.embedding_like(n_total, dim, nq_total, args.seed, dev, latent=args.latent, clusters=args.clusters)
     else:
         xg, q = synth.gaussian_sphere(n_total, dim, nq_total, args.seed, dev)
+    cosine = args.metric == "cosine"
+    if cosine:  # unit rows: the L2-built graph is the cosine graph (same neighbour order)
+        xg = torch.nn.functional.normalize(xg, dim=1)
+        q = torch.nn.functional.normalize(q, dim=1)
+    hv_metric = hv.COSINE if cosine else hv.EUCLIDEAN
     id_lo = 0 if replica else rank * n
     if replica:  # every rank answers its own batch of held-out queries
         q = q[rank * b:(rank + 1) * b].contiguous()
@@ -127,7 +137,7 @@ def main():
     x_host = x.cpu().numpy()
     ids = g["node_ids"] + np.uint64(id_lo)
     ix = hv.ValidatedVectorReadIndex.managed(
-        dim=dim, metric=hv.EUCLIDEAN, node_ids=ids, vectors=x_host, l0_offsets=g["l0_offsets"],
+        dim=dim, metric=hv_metric, node_ids=ids, vectors=x_host, l0_offsets=g["l0_offsets"],
         l0_neighbors=g["l0_neighbors"] + np.uint64(id_lo), level=g["level"], up_offsets=g["up_offsets"],
         up_neighbors=g["up_neighbors"] + np.uint64(id_lo), entry_point=g["entry_point"] + id_lo,
         max_layer=g["max_layer"], m=args.m, m0=2 * args.m, device=local_rank, max_batch=b,
@@ -137,7 +147,7 @@ def main():
     ix_truth = ix
     if bf16:  # exact-scan ground truth over the same rounded rows (the exact scan reads f32 rows)
         ix_truth = hv.ValidatedVectorReadIndex.managed(
-            dim=dim, metric=hv.EUCLIDEAN, node_ids=ids, vectors=x_host, l0_offsets=np.zeros(n + 1, np.uint64),
+            dim=dim, metric=hv_metric, node_ids=ids, vectors=x_host, l0_offsets=np.zeros(n + 1, np.uint64),
             l0_neighbors=np.zeros(0, np.uint64), device=local_rank, max_batch=b)
         ix_truth.set_stream(stream.cuda_stream)
     log(f"index imported in {time.time() - t0:.1f}s")
@@ -210,6 +220,48 @@ def main():
     recall = hits / float(b * k)
     assert int(d_st.abs().sum().item()) == 0, "a query was rejected"
 
+    # ---- what the reference's query path actually runs: SearchParams::new(k) = ef max(k,100), SimHashMode::Adaptive
+    #      (access/search/storage.rs:140-141), next to the strict arm at the same beam width ----
+    prod = None
+    p_ids = p_sc = None
+    if world == 1 and not bf16 and not args.no_production_default:
+        t0 = time.time()
+        ix.set_simhash()  # per-node SimHash rows, computed on the device with SimHasher(dim, seed 42)
+        log(f"SimHash rows attached in {time.time() - t0:.1f}s")
+        pp = hv.SearchParams.new(k)
+        p_ids = torch.zeros_like(d_ids); p_sc = torch.zeros_like(d_sc); p_cnt = torch.zeros_like(d_cnt); p_st = torch.zeros_like(d_st)
+        p_qst = torch.zeros_like(d_qst)
+        p_ast = torch.zeros(b, C.sizeof(hv.AdaptiveStats), dtype=torch.uint8, device=dev)
+
+        def run(params, ids_t, sc_t, qst_t, ast_t):
+            ms = []
+            for it in range(args.warmup + args.steps):
+                st = ix.search_batch_params_device(q, params, ids_t, sc_t, p_cnt, p_st, qst_t, ast_t, want_stats=True)
+                if it >= args.warmup:
+                    ms.append(st["device_ms"])
+            torch.cuda.synchronize()
+            got = ids_t.cpu().numpy()
+            rec = sum(len(set(got[i].tolist()) & set(truth_h[i].tolist())) for i in range(b)) / float(b * k)
+            qs = qst_t.cpu().numpy().astype(np.int64)
+            return float(np.mean(ms)), rec, qs
+
+        s_ids = torch.zeros_like(d_ids); s_sc = torch.zeros_like(d_sc); s_qst = torch.zeros_like(d_qst)
+        strict_ms, strict_rec, strict_qs = run(hv.SearchParams(k).with_ef(pp.ef), s_ids, s_sc, s_qst, None)
+        prod_ms, prod_rec, prod_qs = run(pp, p_ids, p_sc, p_qst, p_ast)
+        ast = np.frombuffer(p_ast.cpu().numpy().tobytes(), dtype=np.dtype(hv.AdaptiveStats))
+        prod = {
+            "params": f"SearchParams::new({k}): ef={pp.ef}, SimHashMode::Adaptive, index config threshold 43 / sampling 0.8 / adaptive",
+            "kernel_ms": round(prod_ms, 4), "qps_kernel": round(b / (prod_ms * 1e-3), 1), "recall_at_10": round(prod_rec, 4),
+            "distance_computations_per_query": round(float(prod_qs[:, 3].mean()), 1),
+            "simhash_examined_per_query": round(float(ast["simhash_examined"].mean()), 1),
+            "simhash_filtered_per_query": round(float(ast["simhash_filtered"].mean()), 1),
+            "pre_sample_dropped_per_query": round(float(ast["pre_simhash_sample_dropped"].mean()), 1),
+            "bypass_expansions_per_query": round(float(ast["simhash_bypass_expansions"].mean()), 2),
+            "rng_words_per_query": round(float(ast["rng_words"].mean()), 1),
+            "strict_same_ef": {"kernel_ms": round(strict_ms, 4), "qps_kernel": round(b / (strict_ms * 1e-3), 1),
+                               "recall_at_10": round(strict_rec, 4),
+                               "distance_computations_per_query": round(float(strict_qs[:, 3].mean()), 1)}}
+
     # ---- roofline of the dominant kernel (hnsw_search_kernel): algorithmic bytes / launch ----
     qst = d_qst.cpu().numpy().astype(np.int64)
     exp_steps, nb_exam, vec_loaded, dist_comp = (int(qst[:, i].sum()) for i in range(4))
@@ -240,7 +292,7 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if not bf16 else "f32 arithmetic on bf16 rows", "data": "synthetic",
         "config": {"workload": f"configs[1]: {n}x{dim} {args.dtype} per GPU, HNSW M={args.m}/M0={2 * args.m} ef_search={ef} k={k}, "
-                               f"batch={b} queries, squared-L2, strict-exhaustive beam (bit-exact vs reference CPU path)",
+                               f"batch={b} queries, {'cosine' if cosine else 'squared-L2'}, strict-exhaustive beam (bit-exact vs reference CPU path)",
                    "dataset": args.dataset, "rows_per_gpu": n, "rows_total": n_total, "dim": dim, "batch": b, "k": k,
                    "ef_search": ef, "parallelism": ("1 GPU" if world == 1 else f"{world} replicas, one query batch each" if replica
                                    else f"id-range shards x{world} + all-gather top-k merge")},
@@ -249,6 +301,7 @@ def main():
         "roofline": roofline,
         "flat_scan_ms": round(flat_stats["device_ms"], 3),
         "flat_scan_mfma_bf16_ms": mfma_flat_ms,
+        "production_default": prod,
     }
 
     # ---- CPU baseline + bit-exact verification (rank 0, N=1 only) ----
@@ -256,7 +309,7 @@ def main():
         import orc
         threads = args.cpu_threads or min(os.cpu_count() or 1, 64)
         t0 = time.time()
-        oix = orc.Index(dim, orc.L2SQ, kernel=orc.K_AVX_FMA_HW, m=args.m, m0=2 * args.m)
+        oix = orc.Index(dim, orc.COSINE if cosine else orc.L2SQ, kernel=orc.K_AVX_FMA_HW, m=args.m, m0=2 * args.m)
         rc = oix.seed(ids, x_host, g["l0_offsets"], g["l0_neighbors"] + np.uint64(id_lo), g["level"], g["up_offsets"],
                       g["up_neighbors"] + np.uint64(id_lo), entry_point=g["entry_point"] + id_lo, max_layer=g["max_layer"])
         assert rc == orc.OK, f"oracle seed failed: {rc}"
@@ -289,6 +342,18 @@ def main():
             out["parity"] = {"queries": b, "ids_equal_oracle": same_ids, "score_bits_equal_oracle": same_bits,
                              "distance_computations_equal": bool(o_dc == dist_comp)}
             assert same_ids and same_bits, "GPU HNSW results differ from the CPU oracle"
+            if prod is not None:  # the non-strict arms against the oracle's restatement, same SimHash rows
+                oix.set_simhash(42, node_hashes=ix.get_simhash())
+                t1 = time.perf_counter()
+                rc, a_ids, a_sc, a_cnt, a_st = oix.search_params_batch(q_host, orc.SearchParams.new(k), threads=threads)
+                cpu_s = time.perf_counter() - t1
+                assert rc == orc.OK
+                pa = bool((p_ids.cpu().numpy().astype(np.uint64) == a_ids).all())
+                pb = bool((p_sc.cpu().numpy().view(np.uint32) == a_sc.view(np.uint32)).all())
+                pc = bool(sum(s_["rng_words"] for s_ in a_st) == int(ast["rng_words"].sum()))
+                prod["parity"] = {"queries": b, "ids_equal_oracle": pa, "score_bits_equal_oracle": pb, "rng_words_equal": pc}
+                prod["cpu_oracle_qps"] = round(b / cpu_s, 1)
+                assert pa and pb and pc, "GPU non-strict search differs from the CPU oracle"
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

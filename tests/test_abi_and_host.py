@@ -118,3 +118,37 @@ def test_upper_row_codec_and_keys():
     k = hv.parse_vector_key(bytes([0xF0]) + ix + bytes([0x11]) + (3).to_bytes(2, "big") + (5).to_bytes(8, "big"))
     assert k["kind"] == 0x11 and k["layer"] == 3 and k["node_id"] == 5
     assert hv.parse_vector_key(bytes([0xF0]) + ix + bytes([0x12]) + (5).to_bytes(8, "big")) is None  # SimHash row: not a search row
+
+
+def test_full_search_params_mirror_the_reference():
+    """mod.rs:482-500 SearchParams::new, :546-552 requires_query_simhash, :555-583 bypass tuning validation,
+    :614-620 throughput_profile_floor_92; hvx_search_params_default / hvx_simhash_config_default (mod.rs:313-329)."""
+    import ctypes as C
+    import pyhvx as hv
+    p = hv.SearchParams.new(7)
+    c = p._c()
+    d = hv._Params()
+    hv.lib().hvx_search_params_default(C.byref(d), 7)
+    for f, _ in hv._Params._fields_:
+        assert getattr(c, f) == getattr(d, f), f
+    assert (d.k, d.ef, d.simhash_mode) == (7, 100, hv.SIMHASH_ADAPTIVE)
+    assert (d.bypass_min_frontier, d.bypass_window_expansions, d.read_budget_multiplier) == (24, 4, 3)
+    assert d.bypass_min_filter_rate == np.float32(0.12) and d.pre_simhash_sampling_ratio_override < 0
+    assert hv.SearchParams.new(250)._c().ef == 250
+    assert p.requires_query_simhash()
+    assert not hv.SearchParams.new(5).with_simhash_mode(hv.SIMHASH_OFF).requires_query_simhash()
+    assert hv.SearchParams.new(5).with_simhash_mode(hv.SIMHASH_OFF).with_pre_simhash_sampling_ratio(0.5).requires_query_simhash()
+    assert not hv.SearchParams(5).requires_query_simhash()      # the strict baseline: Off + pre 1.0
+    t = hv.SearchParams.throughput_profile_floor_92(10)._c()
+    assert (t.ef, t.simhash_mode) == (48, hv.SIMHASH_ADAPTIVE) and t.pre_simhash_sampling_ratio_override == np.float32(0.20)
+    assert hv.SearchParams.throughput_profile_floor_92(60)._c().ef == 60
+    for bad in (lambda: p.with_simhash_bypass_tuning(0, 4, 0.1, 3), lambda: p.with_simhash_bypass_tuning(24, 4, 1.5, 3),
+                lambda: p.with_pre_simhash_sampling_ratio(-0.1), lambda: p.with_simhash_sampling_ratio(float("nan")),
+                lambda: p.with_simhash_failure_prob(0.0), lambda: p.with_simhash_failure_prob(1.0)):
+        with pytest.raises(hv.HelixDbError) as e:
+            bad()
+        assert e.value.status == hv.ERR_K_RANGE
+    cfg = hv.SimHashConfig.default()
+    assert (cfg.seed, cfg.simhash_threshold, cfg.adaptive_enabled) == (42, 43, 1)
+    assert cfg.sampling_ratio == np.float32(0.8) and cfg.adaptive_failure_prob == np.float32(0.1)
+    assert C.sizeof(hv.AdaptiveStats) == 72

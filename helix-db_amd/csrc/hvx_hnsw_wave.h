@@ -128,14 +128,19 @@ struct Visited {
 // two consecutive chunks.
 template <int NK, int P, bool BF> struct Gather {
     float4 x[P][BF ? NK / 2 : NK];
+    float h[P]; // cosine: the row's cached norm header, requested together with the row
 };
 
 // Straight-line issue of every load of a pass.  Groups without a row of their own are pointed at
 // another group's row by the caller (identical addresses coalesce inside the load instruction): no
 // divergence, nothing for the compiler to sink behind a branch.
-template <int NK, int P, bool BF, int PMAX = P>
+template <int NK, int P, bool BF, int PMAX = P, bool HDR = false>
 __device__ __forceinline__ void gather_issue(const DevIndex &ix, const uint32_t (&node)[P], int slot, Gather<NK, PMAX, BF> &g) {
     constexpr int NL = BF ? NK / 2 : NK;
+    if (HDR) { // ahead of the rows: returns in order, so it is there when the reduction tree ends
+#pragma unroll
+        for (int p = 0; p < P; ++p) g.h[p] = ix.hdr[node[p]];
+    }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         const float4 *rp = BF ? reinterpret_cast<const float4 *>(ix.vecb + (size_t)node[p] * ix.dim) + slot
@@ -199,7 +204,7 @@ __device__ __forceinline__ void gather_consume(const DevIndex &ix, const float *
         float r = avx_tree_reduce(acc[p]);
         if (METRIC == kCosine) {
             const uint32_t nd = node[p];
-            r = cosine_finish_fn(r, qhdr, ix.hdr[nd], [&]() {
+            r = cosine_finish_fn(r, qhdr, g.h[p], [&]() {
                 if (BF) {
                     const uint16_t *rb = ix.vecb + (size_t)nd * ix.dim;
                     return stable_half_cosine_fn(ix.dim, [&](uint32_t i) { return qglobal[i]; },
@@ -461,7 +466,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             const uint32_t f = f0 + (uint32_t)(p * 8 + grp);
             nd[p] = fr_id[f < nf ? f : f0]; // idle groups shadow the pass's first row
         }
-        gather_issue<NK, W, BF>(ix, nd, slot, g);
+        gather_issue<NK, W, BF, W, METRIC == kCosine>(ix, nd, slot, g);
         gather_consume<METRIC, NK, W, BF>(ix, qs, g, nd, slot, qhdr, qglobal, o);
 #pragma unroll
         for (int p = 0; p < W; ++p) {
@@ -486,7 +491,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         uint32_t nd[1] = {node};
         float o[1];
         Gather<NK, 1, BF> g;
-        gather_issue<NK, 1, BF>(ix, nd, slot, g);
+        gather_issue<NK, 1, BF, 1, METRIC == kCosine>(ix, nd, slot, g);
         gather_consume<METRIC, NK, 1, BF>(ix, qs, g, nd, slot, qhdr, qglobal, o);
         return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(o[0]), 0));
     };

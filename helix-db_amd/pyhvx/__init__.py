@@ -548,6 +548,38 @@ class SimHasher:
         return int(self.hash_batch(np.asarray(vector, np.float32).reshape(1, -1))[0])
 
 
+def unique_restricted_rows(rows, element_type: str = "node"):
+    """interpreter/access/restricted_vector.rs:14-38: first row wins per element id; rows keyed in id order.
+
+    `rows` are dicts with "current" = ("node" | "edge", id).  Raises Query errors exactly where the reference does."""
+    rows_by_id = {}
+    for row in rows:
+        current = row.get("current")
+        if current is None:
+            raise HelixDbError(ERR_K_RANGE, "vector_search expected rows with a current graph element")
+        kind, eid = current
+        if kind != element_type:
+            raise HelixDbError(ERR_K_RANGE, "vector_search index kind does not match the input stream")
+        rows_by_id.setdefault(int(eid), row)
+    return dict(sorted(rows_by_id.items()))  # BTreeMap iteration order
+
+
+def materialize_restricted_results(rows_by_id: dict, results):
+    """restricted_vector.rs:40-65: re-attach the upstream rows in RANK order and add `$distance` = score as F64."""
+    ranked = []
+    pending = dict(rows_by_id)
+    for r in results:
+        row = pending.pop(int(r.entity_id), None)
+        if row is None:
+            raise HelixDbError(ERR_INVARIANT, "restricted vector search returned an ID outside its exact bitmap")
+        row = dict(row)
+        vp = dict(row.get("virtual_properties", {}))
+        vp["$distance"] = float(np.float64(np.float32(r.score)))
+        row["virtual_properties"] = vp
+        ranked.append(row)
+    return ranked
+
+
 def order_code_from_simhash_bits(bits: int) -> int:
     return int(lib().hvx_order_code_from_simhash_bits(int(bits)))
 

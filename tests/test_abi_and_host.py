@@ -152,3 +152,22 @@ def test_full_search_params_mirror_the_reference():
     assert (cfg.seed, cfg.simhash_threshold, cfg.adaptive_enabled) == (42, 43, 1)
     assert cfg.sampling_ratio == np.float32(0.8) and cfg.adaptive_failure_prob == np.float32(0.1)
     assert C.sizeof(hv.AdaptiveStats) == 72
+
+
+def test_restricted_row_dedupe_and_materialisation_follow_the_interpreter():
+    """interpreter/access/restricted_vector.rs:14-65: first row wins, rank order, `$distance` as F64."""
+    import pyhvx as hv
+    rows = [{"current": ("node", 9), "tag": "a"}, {"current": ("node", 4), "tag": "b"}, {"current": ("node", 9), "tag": "dup"}]
+    by_id = hv.unique_restricted_rows(rows, "node")
+    assert list(by_id) == [4, 9] and by_id[9]["tag"] == "a"
+    with pytest.raises(hv.HelixDbError):
+        hv.unique_restricted_rows([{"current": ("edge", 1)}], "node")
+    with pytest.raises(hv.HelixDbError):
+        hv.unique_restricted_rows([{"current": None}], "node")
+    res = [hv.SearchResult(9, np.float32(0.1)), hv.SearchResult(4, np.float32(0.25))]
+    out = hv.materialize_restricted_results(by_id, res)
+    assert [r["tag"] for r in out] == ["a", "b"]
+    assert out[0]["virtual_properties"]["$distance"] == float(np.float32(0.1)) and isinstance(out[0]["virtual_properties"]["$distance"], float)
+    with pytest.raises(hv.HelixDbError) as e:
+        hv.materialize_restricted_results(by_id, [hv.SearchResult(5, np.float32(0.0))])
+    assert e.value.status == hv.ERR_INVARIANT

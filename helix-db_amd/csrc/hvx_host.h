@@ -39,6 +39,8 @@ struct hvx_index {
     float *f_dist = nullptr, *f_top_s = nullptr;
     uint32_t *f_top_i = nullptr, *f_top_c = nullptr, *f_subset = nullptr;
     size_t cap_dist = 0, cap_top = 0, cap_subset = 0;
+    uint32_t *pf_blocks = nullptr;   // fused prefilter: per-block candidate counts / scan
+    uint32_t cap_pf_blocks = 0;
     uint32_t cap_topc = 0;
     // bf16 exact scan on the matrix cores (hvx_flat_mfma.hip)
     uint16_t *m_qhi = nullptr, *m_qlo = nullptr;

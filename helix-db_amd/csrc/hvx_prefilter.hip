@@ -204,12 +204,12 @@ static int upload_labels(hvx_csr *g, const uint32_t *labels, uint32_t n) {
     return HVX_OK;
 }
 
-static int run_bfs(hvx_csr *g, const uint64_t *seeds, uint32_t n_seeds, uint32_t max_depth, uint32_t direction,
-                   const uint32_t *labels, uint32_t n_labels, uint32_t hub_degree, uint32_t include_seeds,
-                   bool expand_only, uint64_t *out_bitmap, uint32_t *out_depth) {
+// caller holds g->mu; the visited bitmap stays in g->visited (device) whether or not it is copied out
+static int run_bfs_locked(hvx_csr *g, const uint64_t *seeds, uint32_t n_seeds, uint32_t max_depth, uint32_t direction,
+                          const uint32_t *labels, uint32_t n_labels, uint32_t hub_degree, uint32_t include_seeds,
+                          bool expand_only, uint64_t *out_bitmap, uint32_t *out_depth) {
     if (direction > HVX_DIR_BOTH) return fail(HVX_ERR_INVARIANT, "bad direction");
     if (n_seeds == 0) return fail(HVX_ERR_INVARIANT, "traversal requires at least one seed"); // traversal.rs:198-202
-    std::lock_guard<std::mutex> lock(g->mu);
     HIP_TRY(hipSetDevice(g->device));
     // dedupe seeds preserving first occurrence (traversal.rs:203-210); unknown node => error
     std::vector<uint32_t> s32;
@@ -257,6 +257,14 @@ static int run_bfs(hvx_csr *g, const uint64_t *seeds, uint32_t n_seeds, uint32_t
     if (out_depth && g->n) HIP_TRY(hipMemcpyAsync(out_depth, g->depth, (size_t)g->n * 4, hipMemcpyDeviceToHost, g->stream));
     HIP_TRY(hipStreamSynchronize(g->stream));
     return HVX_OK;
+}
+
+static int run_bfs(hvx_csr *g, const uint64_t *seeds, uint32_t n_seeds, uint32_t max_depth, uint32_t direction,
+                   const uint32_t *labels, uint32_t n_labels, uint32_t hub_degree, uint32_t include_seeds,
+                   bool expand_only, uint64_t *out_bitmap, uint32_t *out_depth) {
+    std::lock_guard<std::mutex> lock(g->mu);
+    return run_bfs_locked(g, seeds, n_seeds, max_depth, direction, labels, n_labels, hub_degree, include_seeds, expand_only,
+                          out_bitmap, out_depth);
 }
 
 extern "C" int hvx_traverse_filter(const hvx_csr *cg, const uint64_t *seeds, uint32_t n_seeds, uint32_t max_depth,
@@ -358,6 +366,170 @@ extern "C" int hvx_search_restricted_batch(const hvx_index *cix, const float *qu
                                 out_ids + (size_t)q * k, out_scores + (size_t)q * k, out_counts + q,
                                 out_status ? out_status + q : nullptr, stats);
         if (rc) return rc;
+    }
+    return HVX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused prefilter + restricted kNN: the candidate bitmap never leaves the device.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// external node id -> internal row of the index (ids ascending), kSentinel when the node holds no vector
+__device__ __forceinline__ uint32_t find_row(const uint64_t *ids, uint32_t n, uint64_t id, bool contiguous) {
+    if (n == 0) return kSentinel;
+    if (contiguous) return (id >= ids[0] && id - ids[0] < n) ? (uint32_t)(id - ids[0]) : kSentinel;
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (ids[mid] < id) lo = mid + 1;
+        else hi = mid;
+    }
+    return (lo < n && ids[lo] == id) ? lo : kSentinel;
+}
+
+// pass 1: per 256-word block, how many set bits map to an indexed row (restricted.rs:615-659: ids that are not
+// indexed are omitted) and how many bits are set at all (the RestrictedVectorCandidates population, :356-371)
+__global__ __launch_bounds__(256) void bitmap_count_kernel(const uint32_t *bitmap, uint32_t n_words, const uint64_t *ids, uint32_t n,
+                                                           uint32_t contiguous, uint32_t *block_rows, uint32_t *total_bits) {
+    __shared__ uint32_t s_rows, s_bits;
+    if (threadIdx.x == 0) { s_rows = 0; s_bits = 0; }
+    __syncthreads();
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    uint32_t word = w < n_words ? bitmap[w] : 0u, rows = 0;
+    const uint32_t bits = (uint32_t)__builtin_popcount(word);
+    while (word) {
+        const uint32_t b = (uint32_t)__builtin_ctz(word);
+        word &= word - 1u;
+        rows += find_row(ids, n, (uint64_t)w * 32u + b, contiguous != 0u) != kSentinel ? 1u : 0u;
+    }
+    if (rows) atomicAdd(&s_rows, rows);
+    if (bits) atomicAdd(&s_bits, bits);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        block_rows[blockIdx.x] = s_rows;
+        if (s_bits) atomicAdd(total_bits, s_bits);
+    }
+}
+
+// exclusive scan of the block counts (one block; n_blocks <= a few thousand), total into block_rows[n_blocks]
+__global__ __launch_bounds__(1024) void block_scan_kernel(uint32_t *block_rows, uint32_t n_blocks) {
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (n_blocks + 1023u) / 1024u, t = threadIdx.x;
+    uint32_t sum = 0;
+    for (uint32_t i = t * per; i < (t + 1) * per && i < n_blocks; ++i) sum += block_rows[i];
+    part[t] = sum;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t run = 0;
+        for (uint32_t i = 0; i < 1024; ++i) { const uint32_t v = part[i]; part[i] = run; run += v; }
+        block_rows[n_blocks] = run;
+    }
+    __syncthreads();
+    uint32_t run = part[t];
+    for (uint32_t i = t * per; i < (t + 1) * per && i < n_blocks; ++i) { const uint32_t v = block_rows[i]; block_rows[i] = run; run += v; }
+}
+
+// pass 2: rows of the set bits, ascending id order (thread order inside a block by an LDS scan of the per-word counts)
+__global__ __launch_bounds__(256) void bitmap_compact_kernel(const uint32_t *bitmap, uint32_t n_words, const uint64_t *ids, uint32_t n,
+                                                             uint32_t contiguous, const uint32_t *block_base, uint32_t *subset) {
+    __shared__ uint32_t cnt[256];
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t word0 = w < n_words ? bitmap[w] : 0u;
+    uint32_t word = word0, rows = 0;
+    while (word) {
+        const uint32_t b = (uint32_t)__builtin_ctz(word);
+        word &= word - 1u;
+        rows += find_row(ids, n, (uint64_t)w * 32u + b, contiguous != 0u) != kSentinel ? 1u : 0u;
+    }
+    cnt[threadIdx.x] = rows;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) { // Hillis-Steele inclusive scan
+        const uint32_t v = threadIdx.x >= off ? cnt[threadIdx.x - off] : 0u;
+        __syncthreads();
+        cnt[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t out = block_base[blockIdx.x] + cnt[threadIdx.x] - rows;
+    word = word0;
+    while (word) {
+        const uint32_t b = (uint32_t)__builtin_ctz(word);
+        word &= word - 1u;
+        const uint32_t r = find_row(ids, n, (uint64_t)w * 32u + b, contiguous != 0u);
+        if (r != kSentinel) subset[out++] = r;
+    }
+}
+
+} // namespace
+
+extern "C" int hvx_prefilter_search_batch(const hvx_index *cix, const hvx_csr *cg, const float *queries, uint32_t b, uint32_t k,
+                                          uint32_t ef, uint32_t mode, const uint64_t *seeds, uint32_t n_seeds, uint32_t max_depth,
+                                          uint32_t direction, const uint32_t *allowed_label_ids, uint32_t n_labels,
+                                          uint32_t hub_degree, uint32_t include_seeds, uint64_t *out_ids, float *out_scores,
+                                          uint32_t *out_counts, uint32_t *out_status, uint64_t *out_candidates, hvx_stats *stats) {
+    if (!cix || !cg) return fail(HVX_ERR_INVARIANT, "null argument");
+    hvx_index *ix = const_cast<hvx_index *>(cix);
+    hvx_csr *g = const_cast<hvx_csr *>(cg);
+    if (k == 0) return fail(HVX_ERR_K_RANGE, "result count must be non-zero");
+    if (ef < k) return fail(HVX_ERR_K_RANGE, "search beam width %u is below the result count %u", ef, k);
+    if (mode > HVX_PREFILTER_TRAVERSE) return fail(HVX_ERR_INVARIANT, "bad prefilter mode");
+    if (ix->device != g->device) return fail(HVX_ERR_INVARIANT, "index and graph live on different devices");
+    if (out_candidates) *out_candidates = 0;
+    for (uint32_t q = 0; q < b; ++q) {
+        out_counts[q] = 0;
+        if (out_status) out_status[q] = HVX_OK;
+    }
+    if (b == 0) return HVX_OK;
+    if (mode == HVX_PREFILTER_EXPAND && n_seeds == 0) return HVX_OK; // an empty stream expands to nothing
+    std::lock_guard<std::mutex> glock(g->mu);
+    std::lock_guard<std::mutex> lock(ix->mu);
+    int rc = run_bfs_locked(g, seeds, n_seeds, mode == HVX_PREFILTER_EXPAND ? 1u : max_depth, direction, allowed_label_ids, n_labels,
+                            mode == HVX_PREFILTER_EXPAND ? 0u : hub_degree, mode == HVX_PREFILTER_EXPAND ? 0u : include_seeds,
+                            mode == HVX_PREFILTER_EXPAND, nullptr, nullptr);
+    if (rc) return rc; // (run_bfs_locked ends with a stream synchronise: the bitmap is complete)
+    const uint32_t n_words = ((g->n + 63u) / 64u) * 2u, n_blocks = (n_words + 255u) / 256u;
+    if (n_blocks + 2 > ix->cap_pf_blocks) {
+        if ((rc = ix->dalloc((void **)&ix->pf_blocks, (size_t)(n_blocks + 2) * 4))) return rc;
+        ix->cap_pf_blocks = n_blocks + 2;
+    }
+    uint32_t *d_total_bits = ix->pf_blocks + n_blocks + 1;
+    HIP_TRY(hipMemsetAsync(d_total_bits, 0, 4, ix->stream));
+    hipLaunchKernelGGL(bitmap_count_kernel, dim3(n_blocks), dim3(256), 0, ix->stream, g->visited, n_words, ix->dev.ids, ix->dev.n,
+                       ix->contiguous ? 1u : 0u, ix->pf_blocks, d_total_bits);
+    hipLaunchKernelGGL(block_scan_kernel, dim3(1), dim3(1024), 0, ix->stream, ix->pf_blocks, n_blocks);
+    HIP_TRY(hipGetLastError());
+    uint32_t totals[2] = {0, 0}; // rows to scan, candidate population
+    HIP_TRY(hipMemcpyAsync(totals, ix->pf_blocks + n_blocks, 8, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    const uint32_t n_rows = totals[0], population = totals[1];
+    if (out_candidates) *out_candidates = population;
+    // RestrictedVectorCandidates::from_ids (restricted.rs:356-371) / RestrictedResultCount::try_new (:200-213)
+    if (population > 1000000) return fail(HVX_ERR_CANDIDATE_LIMIT, "restricted vector search accepts at most 1000000 unique candidates");
+    if (population == 0) return HVX_OK;
+    const uint32_t kk = std::min<uint32_t>(k, population);
+    if (kk > 800) return fail(HVX_ERR_K_RANGE, "restricted vector search result count %u is above the maximum 800", kk);
+    if (n_rows > ix->cap_subset) {
+        if ((rc = ix->dalloc((void **)&ix->f_subset, (size_t)n_rows * 4))) return rc;
+        ix->cap_subset = n_rows;
+    }
+    if (n_rows)
+        hipLaunchKernelGGL(bitmap_compact_kernel, dim3(n_blocks), dim3(256), 0, ix->stream, g->visited, n_words, ix->dev.ids, ix->dev.n,
+                           ix->contiguous ? 1u : 0u, ix->pf_blocks, ix->f_subset);
+    HIP_TRY(hipGetLastError());
+    std::vector<uint64_t> t_ids((size_t)b * kk);
+    std::vector<float> t_sc((size_t)b * kk);
+    std::vector<uint32_t> t_cnt(b), t_st(b);
+    rc = flat_scan_host(ix, queries, b, kk, ix->f_subset, n_rows, t_ids.data(), t_sc.data(), t_cnt.data(), t_st.data(), stats);
+    if (rc) return rc;
+    for (uint32_t q = 0; q < b; ++q) {
+        if (t_st[q]) {
+            if (!out_status) return fail((int)t_st[q], "query %u rejected with status %u", q, t_st[q]);
+            out_status[q] = t_st[q];
+            continue;
+        }
+        out_counts[q] = t_cnt[q];
+        memcpy(out_ids + (size_t)q * k, t_ids.data() + (size_t)q * kk, (size_t)t_cnt[q] * 8);
+        memcpy(out_scores + (size_t)q * k, t_sc.data() + (size_t)q * kk, (size_t)t_cnt[q] * 4);
     }
     return HVX_OK;
 }

@@ -174,6 +174,10 @@ def lib():
     L.hvx_hydrator_set_entry.argtypes = [_vp, C.c_uint64, C.c_uint32]
     L.hvx_hydrator_finish.restype = C.c_int
     L.hvx_hydrator_finish.argtypes = [_vp, C.POINTER(_Desc), C.POINTER(_vp)]
+    L.hvx_prefilter_search_batch.restype = C.c_int
+    L.hvx_prefilter_search_batch.argtypes = [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint32,
+                                             C.c_uint32, C.c_uint32, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp,
+                                             C.POINTER(C.c_uint64), C.POINTER(Stats)]
     L.hvx_csr_import.restype = C.c_int
     L.hvx_csr_import.argtypes = [C.c_uint64, C.c_uint64, _vp, _vp, _vp, C.c_int32, C.POINTER(_vp)]
     L.hvx_csr_free.argtypes = [_vp]
@@ -449,6 +453,23 @@ class ValidatedVectorReadIndex:
         _check(lib().hvx_search_restricted_batch(self._h, _ptr(q), b, k, params.ef, _ptr(al), _ptr(off), al.size,
                                                  _ptr(ids), _ptr(sc), _ptr(cnt), None, None))
         return ids, sc, cnt
+
+    def prefilter_search_batch(self, graph: "Graph", queries, params: SearchParams, seeds, *, traverse=False, max_depth=1,
+                               direction=DIR_OUT, allowed_labels=(), hub_degree=0, include_seeds=True):
+        """`where_()` / traversal filter + vector_search in ONE call: the hop's candidate bitmap stays on the device
+        (hvx_prefilter_search_batch).  Returns (ids, scores, counts, n_candidates, stats)."""
+        q = self._q(queries)
+        b, k = q.shape[0], params.k
+        s = np.ascontiguousarray(seeds, dtype=np.uint64)
+        lab = np.ascontiguousarray(allowed_labels, dtype=np.uint32)
+        ids = np.zeros((b, k), np.uint64); sc = np.zeros((b, k), np.float32); cnt = np.zeros(b, np.uint32)
+        ncand = C.c_uint64(0)
+        stats = Stats()
+        _check(lib().hvx_prefilter_search_batch(self._h, graph._h, _ptr(q), b, k, params.ef, 1 if traverse else 0, _ptr(s), s.size,
+                                                max_depth, direction, _ptr(lab) if lab.size else None, lab.size, hub_degree,
+                                                1 if include_seeds else 0, _ptr(ids), _ptr(sc), _ptr(cnt), None,
+                                                C.byref(ncand), C.byref(stats)))
+        return ids, sc, cnt, int(ncand.value), stats.as_dict()
 
     # ---- device-resident surface (torch tensors on the index's GPU) ----
     def search_batch_device(self, d_queries, k, ef, d_ids, d_scores, d_counts, d_status, d_qstats=None, want_stats=False):

@@ -249,6 +249,22 @@ int hvx_expand_filter(const hvx_csr *, const uint64_t *rows, uint32_t n_rows, ui
                       const uint32_t *allowed_label_ids, uint32_t n_labels, uint64_t *out_bitmap_words);
 
 /*
+ * Fused graph prefilter + restricted kNN (BASELINE config #3: `where_()` / traversal filter, then vector_search):
+ * hvx_expand_filter or hvx_traverse_filter followed by hvx_search_restricted_batch with the candidate bitmap kept ON
+ * THE DEVICE -- the hop's bitmap is compacted into the scan's row list by two small kernels (ids without a vector are
+ * omitted, restricted.rs:615-659), no candidate list crosses PCIe.  The CSR's node numbers are the index's node ids.
+ * mode: HVX_PREFILTER_EXPAND (one hop from `seeds`, expand.rs:16-80; max_depth / hub_degree / include_seeds ignored)
+ * or HVX_PREFILTER_TRAVERSE (Graph::traverse, traversal.rs:197-261).  Same limits and statuses as the two-call form
+ * (<= 1 000 000 candidates, k <= 800); out_candidates receives the candidate population.
+ */
+enum { HVX_PREFILTER_EXPAND = 0, HVX_PREFILTER_TRAVERSE = 1 };
+int hvx_prefilter_search_batch(const hvx_index *, const hvx_csr *, const float *queries, uint32_t b, uint32_t k, uint32_t ef,
+                               uint32_t mode, const uint64_t *seeds, uint32_t n_seeds, uint32_t max_depth, uint32_t direction,
+                               const uint32_t *allowed_label_ids, uint32_t n_labels, uint32_t hub_degree,
+                               uint32_t include_seeds, uint64_t *out_ids, float *out_scores, uint32_t *out_counts,
+                               uint32_t *out_status /*nullable*/, uint64_t *out_candidates /*nullable*/, hvx_stats *stats);
+
+/*
  * SimHash projections (crates/db/src/search/vector/unaligned_vector/simhash.rs:123-178 SimHasher::new_with_seed,
  * :263-291 hash_from_slice; simhash.rs:44-59 order_code_from_simhash_bits, which keys the canonical vector rows
  * `[0xF1][index_id][0x02][order_code][node_id]`).  `vectors` is [n][dim] f32 in host or device memory.

@@ -728,3 +728,46 @@ def test_strict_params_route_to_the_strict_kernel_and_validation(orc, hv):
     q2[3, 5] = np.nan
     ids, sc, cnt, stats, st = gix.search_batch(q2, hv.SearchParams.new(10), per_query_status=True)
     assert st.tolist() == [0, 0, 0, hv.ERR_NONFINITE, 0, 0, 0, 0] and cnt[3] == 0
+
+
+@pytest.mark.parametrize("contiguous", [True, False])
+def test_fused_prefilter_search_equals_the_two_call_form_and_the_oracle(orc, hv, contiguous):
+    """hvx_prefilter_search_batch (hop -> device bitmap -> device row list -> exact restricted scan) against
+    hvx_expand_filter / hvx_traverse_filter + hvx_search_restricted_batch and the oracle's exact scan over the allowed
+    ids (restricted.rs:753-835); vectors exist only for part of the graph's nodes (ids without a vector are omitted)."""
+    rng = np.random.default_rng(31)
+    n_nodes, e, dim = 4000, 20000, 64
+    src = np.sort(rng.integers(0, n_nodes, e)); tgt = rng.integers(0, n_nodes, e).astype(np.uint64)
+    off = np.zeros(n_nodes + 1, np.uint64); np.add.at(off, src + 1, 1); off = np.cumsum(off).astype(np.uint64)
+    lab = rng.integers(0, 3, e).astype(np.uint32)
+    g = hv.Graph(n_nodes, off, tgt, lab)
+    # vectors on a subset of the nodes: a contiguous id range, or every third id (binary-search id map on the device)
+    vec_ids = np.arange(500, 3500, dtype=np.uint64) if contiguous else np.arange(0, n_nodes, 3, dtype=np.uint64)
+    data = rng.standard_normal((vec_ids.size, dim)).astype(np.float32)
+    oix = orc.Index(dim, orc.L2SQ)
+    assert oix.seed(vec_ids, data, np.zeros(vec_ids.size + 1, np.uint64), np.zeros(0, np.uint64)) == orc.OK
+    gix = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=hv.EUCLIDEAN, node_ids=vec_ids, vectors=data,
+                                              l0_offsets=np.zeros(vec_ids.size + 1, np.uint64),
+                                              l0_neighbors=np.zeros(0, np.uint64), max_batch=16)
+    q = rng.standard_normal((9, dim)).astype(np.float32)
+    p = hv.SearchParams(10)
+    for seeds, kw in [(np.arange(40, 90), dict()),                                           # one-hop expand
+                      (np.arange(0, 400), dict(allowed_labels=[1], direction=hv.DIR_BOTH)),
+                      ([7, 8, 9], dict(traverse=True, max_depth=3, direction=hv.DIR_OUT)),   # BFS, seeds included
+                      ([7, 8, 9], dict(traverse=True, max_depth=2, direction=hv.DIR_BOTH, include_seeds=False, hub_degree=14))]:
+        ids, sc, cnt, ncand, _ = gix.prefilter_search_batch(g, q, p, seeds, **kw)
+        if kw.get("traverse"):
+            words, _ = g.traverse(seeds, kw["max_depth"], kw["direction"], kw.get("allowed_labels", ()), kw.get("hub_degree", 0),
+                                  include_seeds=kw.get("include_seeds", True))
+        else:
+            words = g.expand(seeds, kw.get("direction", hv.DIR_OUT), kw.get("allowed_labels", ()))
+        cand = hv.RestrictedVectorCandidates.from_bitmap_words(words)
+        assert ncand == len(cand) and ncand > 10
+        ids2, sc2, cnt2 = gix.search_restricted_batch(q, p, cand)
+        assert cnt.tolist() == cnt2.tolist() and ids.tolist() == ids2.tolist() and bits(sc).tolist() == bits(sc2).tolist()
+        for qi in range(q.shape[0]):
+            rc, oid, osc = oix.flat(q[qi], 10, allowed=cand.ids)
+            assert rc == orc.OK and ids[qi, :cnt[qi]].tolist() == oid.tolist() and bits(sc[qi, :cnt[qi]]).tolist() == bits(osc).tolist()
+    # an empty stream expands to nothing; a hop that reaches only vector-less nodes returns no rows
+    ids, sc, cnt, ncand, _ = gix.prefilter_search_batch(g, q, p, [])
+    assert ncand == 0 and cnt.sum() == 0

@@ -82,6 +82,7 @@ static void free_index(hvx_index *ix) {
     for (void *p : ix->allocs) (void)hipFree(p);
     if (ix->ev0) (void)hipEventDestroy(ix->ev0);
     if (ix->ev1) (void)hipEventDestroy(ix->ev1);
+    for (hipEvent_t e : ix->ring) (void)hipEventDestroy(e);
     if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
     delete ix;
 }
@@ -396,6 +397,16 @@ static void add_stats(hvx_stats *stats, const std::vector<hvx_query_stats> &qs, 
 }
 
 // enqueue validation + memset + search kernel for one chunk of <= max_batch queries
+// the event pair a search kernel is bracketed with: the synchronous stats pair, else the next slot of the timing ring
+static void pick_events(hvx_index *ix, bool timed, hipEvent_t *e0, hipEvent_t *e1) {
+    if (timed) { *e0 = ix->ev0; *e1 = ix->ev1; return; }
+    if (ix->ring_n < ix->ring_cap) {
+        *e0 = ix->ring[2 * ix->ring_n];
+        *e1 = ix->ring[2 * ix->ring_n + 1];
+        ix->ring_n += 1;
+    }
+}
+
 int hvx::enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t b, uint32_t k, uint32_t ef,
                         uint64_t *d_ids, float *d_scores, uint32_t *d_counts, uint32_t *d_status,
                         hvx_query_stats *d_qstats, bool timed, const AdaptArgs *ad) {
@@ -427,9 +438,11 @@ int hvx::enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t b
             HIP_TRY(hipMemsetAsync(ix->d_bitmap, 0, (size_t)ix->max_batch * ix->words_per_query * 4, ix->stream));
             ix->bitmap_dirty = false;
         }
-        if (timed) HIP_TRY(hipEventRecord(ix->ev0, ix->stream));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        pick_events(ix, timed, &e0, &e1);
+        if (e0) HIP_TRY(hipEventRecord(e0, ix->stream));
         HIP_TRY(launch_hnsw_wave(a, b, ix->stream));
-        if (timed) HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
+        if (e1) HIP_TRY(hipEventRecord(e1, ix->stream));
         return HVX_OK;
     }
     const bool prof = getenv("HVX_WAVE_PROF") != nullptr; // tuning hook: phase-timing kernel + stderr report
@@ -448,7 +461,9 @@ int hvx::enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t b
         HIP_TRY(hipMemsetAsync(ix->d_bitmap, 0, (size_t)ix->max_batch * ix->words_per_query * 4, ix->stream));
         ix->bitmap_dirty = false;
     }
-    if (timed) HIP_TRY(hipEventRecord(ix->ev0, ix->stream)); // device_ms = the search kernel alone
+    hipEvent_t e0 = nullptr, e1 = nullptr; // device_ms = the search kernel alone
+    pick_events(ix, timed, &e0, &e1);
+    if (e0) HIP_TRY(hipEventRecord(e0, ix->stream));
     if (wave) {
         HIP_TRY(launch_hnsw_wave(a, b, ix->stream));
         if (prof) {
@@ -466,7 +481,35 @@ int hvx::enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t b
         HIP_TRY(launch_hnsw_search(a, b, ix->stream));
         ix->bitmap_dirty = true;
     }
-    if (timed) HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
+    if (e1) HIP_TRY(hipEventRecord(e1, ix->stream));
+    return HVX_OK;
+}
+
+// ---- asynchronous kernel timing (hvx_index_timing_begin / _collect) ----
+extern "C" int hvx_index_timing_begin(hvx_index *ix, uint32_t capacity) {
+    if (!ix) return fail(HVX_ERR_INVARIANT, "null index");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    while (ix->ring.size() < (size_t)capacity * 2) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        ix->ring.push_back(e);
+    }
+    ix->ring_cap = capacity;
+    ix->ring_n = 0;
+    return HVX_OK;
+}
+
+extern "C" int hvx_index_timing_collect(hvx_index *ix, float *out_ms, uint32_t cap, uint32_t *out_n) {
+    if (!ix || !out_n) return fail(HVX_ERR_INVARIANT, "null argument");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    const uint32_t n = std::min(ix->ring_n, cap);
+    for (uint32_t i = 0; i < n; ++i) HIP_TRY(hipEventElapsedTime(&out_ms[i], ix->ring[2 * i], ix->ring[2 * i + 1]));
+    *out_n = n;
+    ix->ring_cap = 0;
+    ix->ring_n = 0;
     return HVX_OK;
 }
 

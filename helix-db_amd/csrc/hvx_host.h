@@ -19,6 +19,8 @@ struct hvx_index {
     hipStream_t stream = nullptr;      // stream in use
     hipStream_t own_stream = nullptr;  // created at import
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> ring;    // asynchronous timing: event pairs of the searches since hvx_index_timing_begin
+    uint32_t ring_cap = 0, ring_n = 0;
     std::mutex mu;                   // calls on one index are serialised on its stream
     std::vector<void *> allocs;
     std::vector<uint64_t> ids;       // host copy of node ids (id -> internal index lookups)

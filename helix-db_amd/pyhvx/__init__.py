@@ -124,6 +124,10 @@ def lib():
     L.hvx_index_stream.argtypes = [_vp]
     L.hvx_index_set_stream.restype = C.c_int
     L.hvx_index_set_stream.argtypes = [_vp, _vp]
+    L.hvx_index_timing_begin.restype = C.c_int
+    L.hvx_index_timing_begin.argtypes = [_vp, C.c_uint32]
+    L.hvx_index_timing_collect.restype = C.c_int
+    L.hvx_index_timing_collect.argtypes = [_vp, _vp, C.c_uint32, C.POINTER(C.c_uint32)]
     L.hvx_search_batch.restype = C.c_int
     L.hvx_search_batch.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, C.POINTER(Stats)]
     L.hvx_search_batch_device.restype = C.c_int
@@ -490,6 +494,16 @@ class ValidatedVectorReadIndex:
     def merge_topk_device(self, g, b, k, d_ids, d_scores, d_counts, d_out_ids, d_out_scores, d_out_counts):
         _check(lib().hvx_merge_topk_device(self._h, g, b, k, d_ids.data_ptr(), d_scores.data_ptr(), d_counts.data_ptr(),
                                            d_out_ids.data_ptr(), d_out_scores.data_ptr(), d_out_counts.data_ptr()))
+
+    def timing_begin(self, capacity: int):
+        _check(lib().hvx_index_timing_begin(self._h, capacity))
+
+    def timing_collect(self, capacity: int) -> np.ndarray:
+        """kernel durations (ms) of the un-synchronised search calls since timing_begin, in call order"""
+        ms = np.zeros(capacity, np.float32)
+        n = C.c_uint32(0)
+        _check(lib().hvx_index_timing_collect(self._h, _ptr(ms), capacity, C.byref(n)))
+        return ms[: n.value].copy()
 
     def sync(self):
         _check(lib().hvx_index_sync(self._h))

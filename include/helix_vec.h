@@ -104,6 +104,11 @@ void *hvx_index_stream(const hvx_index *);
 /* enqueue on a caller-owned stream instead (e.g. the host runtime's current stream, so that
  * collectives and searches order without host synchronisation); NULL restores the index's own. */
 int hvx_index_set_stream(hvx_index *, void *hip_stream);
+/* Asynchronous kernel timing for pipelined callers: after _begin(capacity), every HNSW search call that is NOT asked
+ * for hvx_stats brackets its search kernel with the next HIP-event pair of a ring instead of synchronising;
+ * _collect waits for the stream once and returns the per-call kernel durations (ms) in call order, then disarms. */
+int hvx_index_timing_begin(hvx_index *, uint32_t capacity);
+int hvx_index_timing_collect(hvx_index *, float *out_ms, uint32_t cap, uint32_t *out_n);
 
 /*
  * ValidatedVectorReadIndex::search (read_index.rs:83-92) -> VectorIndex::search (index.rs:1578-1587)

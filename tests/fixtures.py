@@ -6,7 +6,11 @@ from __future__ import annotations
 
 import math
 
+import os
+
 import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 MASK64 = (1 << 64) - 1
 

@@ -771,3 +771,40 @@ def test_fused_prefilter_search_equals_the_two_call_form_and_the_oracle(orc, hv,
     # an empty stream expands to nothing; a hop that reaches only vector-less nodes returns no rows
     ids, sc, cnt, ncand, _ = gix.prefilter_search_batch(g, q, p, [])
     assert ncand == 0 and cnt.sum() == 0
+
+
+def test_async_kernel_timing_ring():
+    """hvx_index_timing_begin / _collect: un-synchronised device-pointer searches bracketed by a ring of HIP-event pairs.
+    Runs in a child process because torch (device buffers) must initialise its HIP runtime before the library does."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+torch.cuda.init()
+sys.path[:0] = [%r, %r, %r]
+import pyhvx as hv, orc, fixtures as fx
+rng = np.random.default_rng(3)
+n, dim = 1200, 128
+data = rng.standard_normal((n, dim)).astype(np.float32)
+oix = orc.Index(dim, orc.L2SQ, ef_construction=60)
+lv = fx.draw_levels(n, 16, seed=2)
+for i in range(n):
+    assert oix.insert(i, data[i], int(lv[i])) == orc.OK
+gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=dim, metric=1, max_batch=16)
+dev = torch.device("cuda", 0)
+q = torch.from_numpy(rng.standard_normal((16, dim)).astype(np.float32)).to(dev)
+d_ids = torch.zeros(16, 10, dtype=torch.int64, device=dev); d_sc = torch.zeros(16, 10, dtype=torch.float32, device=dev)
+d_cnt = torch.zeros(16, dtype=torch.int32, device=dev); d_st = torch.zeros(16, dtype=torch.int32, device=dev)
+gix.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+gix.timing_begin(5)
+for _ in range(7):  # two more calls than slots: the surplus is simply not timed
+    gix.search_batch_device(q, 10, 64, d_ids, d_sc, d_cnt, d_st)
+ms = gix.timing_collect(8)
+assert ms.size == 5 and (ms > 0).all() and (ms < 50).all(), ms
+assert gix.timing_collect(8).size == 0  # disarmed
+rc, oid, _ = oix.search(q[3].cpu().numpy(), 10, 64)
+assert d_ids[3].cpu().numpy().astype(np.uint64)[: oid.size].tolist() == oid.tolist()
+print("TIMING-OK")
+''' % tuple(__import__("os").path.join(fx.ROOT, d) for d in ("helix-db_amd", "oracle", "tests"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "TIMING-OK" in out.stdout, out.stdout + out.stderr

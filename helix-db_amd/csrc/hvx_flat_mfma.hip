@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             score_rows_fp8<METRIC, NK, P>(ix, qs, nd, slot, qhdr, qglobal, o);
         } else {
             Gather<NK, P, true> g;
-            gather_issue<NK, P, true>(ix, nd, slot, g);
+            gather_issue<NK, P, true, P, METRIC == kCosine>(ix, nd, slot, g);
             gather_consume<METRIC, NK, P, true>(ix, qs, g, nd, slot, qhdr, qglobal, o);
         }
 #pragma unroll

@@ -182,6 +182,13 @@ def lib():
     L.hvx_prefilter_search_batch.argtypes = [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint32,
                                              C.c_uint32, C.c_uint32, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp,
                                              C.POINTER(C.c_uint64), C.POINTER(Stats)]
+    L.hvx_batcher_new.restype = C.c_int
+    L.hvx_batcher_new.argtypes = [_vp, C.POINTER(_Params), C.c_uint32, C.c_uint32, C.POINTER(_vp)]
+    L.hvx_batcher_free.argtypes = [_vp]
+    L.hvx_batcher_search.restype = C.c_int
+    L.hvx_batcher_search.argtypes = [_vp, _vp, _vp, _vp, C.POINTER(C.c_uint32)]
+    L.hvx_batcher_stats.restype = C.c_int
+    L.hvx_batcher_stats.argtypes = [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.hvx_csr_import.restype = C.c_int
     L.hvx_csr_import.argtypes = [C.c_uint64, C.c_uint64, _vp, _vp, _vp, C.c_int32, C.POINTER(_vp)]
     L.hvx_csr_free.argtypes = [_vp]
@@ -511,6 +518,42 @@ class ValidatedVectorReadIndex:
     def set_stream(self, hip_stream):
         """Enqueue on a caller-owned hipStream_t (int handle, e.g. torch.cuda.current_stream().cuda_stream)."""
         _check(lib().hvx_index_set_stream(self._h, _vp(hip_stream) if hip_stream else None))
+
+
+class Batcher:
+    """hvx_batcher: coalesces concurrent single-query `search` calls (one per operator invocation in the reference,
+    access/search/storage.rs:140-163) into batched launches.  `search` may be called from many threads."""
+
+    def __init__(self, index: "ValidatedVectorReadIndex", params: SearchParams, max_batch: int = 0, max_wait_us: int = 200):
+        self._index = index  # keeps the index alive
+        self.k = params.k
+        h = _vp()
+        _check(lib().hvx_batcher_new(index._h, C.byref(params._c()), max_batch, max_wait_us, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().hvx_batcher_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def search(self, query):
+        q = np.ascontiguousarray(query, dtype=np.float32).reshape(-1)
+        if q.size != self._index.dim:
+            raise HelixDbError(ERR_DIMENSION, f"expected dimension {self._index.dim}, got {q.size}")
+        ids = np.zeros(self.k, np.uint64); sc = np.zeros(self.k, np.float32); cnt = C.c_uint32(0)
+        _check(lib().hvx_batcher_search(self._h, _ptr(q), _ptr(ids), _ptr(sc), C.byref(cnt)))
+        return [SearchResult(int(i), s) for i, s in zip(ids[: cnt.value], sc[: cnt.value])]
+
+    def stats(self):
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _check(lib().hvx_batcher_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"batches": int(a.value), "queries": int(b.value), "full_batches": int(c.value)}
 
 
 class Graph:

@@ -270,6 +270,20 @@ int hvx_prefilter_search_batch(const hvx_index *, const hvx_csr *, const float *
                                uint32_t *out_status /*nullable*/, uint64_t *out_candidates /*nullable*/, hvx_stats *stats);
 
 /*
+ * Batching operator: the reference calls ValidatedVectorReadIndex::search once per operator invocation
+ * from many tokio tasks (access/search/storage.rs:140-163).  Concurrent single-query callers are coalesced into ONE
+ * hvx_search_batch_params launch: a caller blocks in hvx_batcher_search until its rows are ready; a dispatcher thread
+ * launches when max_batch (0 = the index's max_batch) queries wait or the oldest has waited max_wait_us.  All callers of
+ * one batcher share `params`.  Thread-safe; results equal a direct batch call's.  A rejected query fails alone.
+ */
+typedef struct hvx_batcher hvx_batcher;
+int hvx_batcher_new(hvx_index *, const hvx_search_params *params, uint32_t max_batch, uint32_t max_wait_us, hvx_batcher **out);
+void hvx_batcher_free(hvx_batcher *);
+int hvx_batcher_search(hvx_batcher *, const float *query /*[dim]*/, uint64_t *out_ids /*[k]*/, float *out_scores /*[k]*/,
+                       uint32_t *out_count);
+int hvx_batcher_stats(const hvx_batcher *, uint64_t *batches, uint64_t *queries, uint64_t *full_batches);
+
+/*
  * SimHash projections (crates/db/src/search/vector/unaligned_vector/simhash.rs:123-178 SimHasher::new_with_seed,
  * :263-291 hash_from_slice; simhash.rs:44-59 order_code_from_simhash_bits, which keys the canonical vector rows
  * `[0xF1][index_id][0x02][order_code][node_id]`).  `vectors` is [n][dim] f32 in host or device memory.

@@ -1,0 +1,115 @@
+// bench_batcher.cpp -- concurrent single-query callers (the reference's calling pattern: one
+// ValidatedVectorReadIndex::search per operator invocation, many tokio tasks) with and without the batching operator.
+//
+//   g++ -O2 -std=c++17 -I include scripts/bench_batcher.cpp -o scripts/_bin/bench_batcher \
+//       -L helix-db_amd -lhelix_vec_gfx950 -Wl,-rpath,$PWD/helix-db_amd -lpthread
+//   scripts/_bin/bench_batcher <dir with the arrays written by scripts/bench_batcher.py> <threads> <queries per thread>
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "helix_vec.h"
+
+template <typename T> static std::vector<T> load(const std::string &path) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) { fprintf(stderr, "cannot open %s\n", path.c_str()); exit(2); }
+    fseek(f, 0, SEEK_END);
+    const long bytes = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<T> v((size_t)bytes / sizeof(T));
+    if (fread(v.data(), 1, (size_t)bytes, f) != (size_t)bytes) exit(2);
+    fclose(f);
+    return v;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 4) { fprintf(stderr, "usage: %s <dir> <threads> <queries per thread> [strict]\n", argv[0]); return 2; }
+    const std::string dir = argv[1];
+    const int threads = atoi(argv[2]), per = atoi(argv[3]);
+    const bool strict = argc > 4 && !strcmp(argv[4], "strict");
+    auto meta = load<uint64_t>(dir + "/meta.u64"); // n, dim, m, entry, max_layer
+    const uint64_t n = meta[0];
+    const uint32_t dim = (uint32_t)meta[1], m = (uint32_t)meta[2];
+    auto ids = load<uint64_t>(dir + "/ids.u64");
+    auto vec = load<float>(dir + "/vectors.f32");
+    auto l0o = load<uint64_t>(dir + "/l0_offsets.u64");
+    auto l0n = load<uint64_t>(dir + "/l0_neighbors.u64");
+    auto lvl = load<uint16_t>(dir + "/level.u16");
+    auto upo = load<uint64_t>(dir + "/up_offsets.u64");
+    auto upn = load<uint64_t>(dir + "/up_neighbors.u64");
+    auto qs = load<float>(dir + "/queries.f32");
+    const uint32_t nq = (uint32_t)(qs.size() / dim);
+    hvx_index_desc d;
+    memset(&d, 0, sizeof(d));
+    d.dim = dim; d.metric = HVX_L2_SQUARED; d.dtype = HVX_F32; d.float_kernel = HVX_KERNEL_AVX_FMA;
+    d.n = n; d.m = m; d.m0 = 2 * m; d.has_entry = 1; d.max_layer = (uint32_t)meta[4]; d.entry_point = meta[3];
+    d.device = -1; d.max_batch = 1024;
+    hvx_index *ix = nullptr;
+    if (hvx_index_import(&d, ids.data(), vec.data(), l0o.data(), l0n.data(), lvl.data(), upo.data(), upn.data(), &ix)) {
+        fprintf(stderr, "import failed: %s\n", hvx_last_error());
+        return 1;
+    }
+    hvx_search_params p;
+    hvx_search_params_default(&p, 10);
+    if (strict) { p.simhash_mode = HVX_SIMHASH_OFF; p.pre_simhash_sampling_ratio_override = 1.0f; }
+    else {
+        hvx_simhash_config c;
+        hvx_simhash_config_default(&c);
+        if (hvx_index_set_simhash(ix, &c, nullptr)) { fprintf(stderr, "%s\n", hvx_last_error()); return 1; }
+    }
+    const uint32_t k = p.k;
+    auto run = [&](hvx_batcher *bt, double *qps, double *mean_us, double *p99_us) {
+        std::vector<std::vector<double>> lat(threads);
+        std::atomic<int> failures{0};
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<std::thread> th;
+        for (int t = 0; t < threads; ++t)
+            th.emplace_back([&, t] {
+                std::vector<uint64_t> oi(k);
+                std::vector<float> os(k);
+                uint32_t cnt = 0, st = 0;
+                for (int i = 0; i < per; ++i) {
+                    const float *q = qs.data() + (size_t)((t * per + i) % nq) * dim;
+                    const auto a = std::chrono::steady_clock::now();
+                    int rc = bt ? hvx_batcher_search(bt, q, oi.data(), os.data(), &cnt)
+                                : hvx_search_batch_params(ix, q, 1, &p, oi.data(), os.data(), &cnt, &st, nullptr, nullptr, nullptr);
+                    if (rc || cnt != k) failures++;
+                    lat[t].push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count());
+                }
+            });
+        for (auto &x : th) x.join();
+        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::vector<double> all;
+        for (auto &v : lat) all.insert(all.end(), v.begin(), v.end());
+        std::sort(all.begin(), all.end());
+        double sum = 0;
+        for (double x : all) sum += x;
+        *qps = all.size() / secs;
+        *mean_us = sum / all.size();
+        *p99_us = all[(size_t)(all.size() * 0.99)];
+        if (failures) fprintf(stderr, "%d failed calls\n", failures.load());
+    };
+    double q0, m0, p0, q1, m1, p1;
+    run(nullptr, &q0, &m0, &p0); // warm-up + direct
+    run(nullptr, &q0, &m0, &p0);
+    hvx_batcher *bt = nullptr;
+    if (hvx_batcher_new(ix, &p, 1024, 100, &bt)) { fprintf(stderr, "%s\n", hvx_last_error()); return 1; }
+    run(bt, &q1, &m1, &p1);
+    run(bt, &q1, &m1, &p1);
+    uint64_t nb = 0, nqs = 0, nf = 0;
+    hvx_batcher_stats(bt, &nb, &nqs, &nf);
+    printf("{\"workload\": \"%llu x %u f32, %s, k=10, %d caller threads x %d single-query calls\", "
+           "\"direct_calls\": {\"qps\": %.0f, \"mean_us\": %.1f, \"p99_us\": %.1f}, "
+           "\"batcher\": {\"qps\": %.0f, \"mean_us\": %.1f, \"p99_us\": %.1f, \"mean_batch\": %.1f, \"max_wait_us\": 100}}\n",
+           (unsigned long long)n, dim, strict ? "strict ef=100" : "SearchParams::new(10)", threads, per, q0, m0, p0, q1, m1, p1,
+           nb ? (double)nqs / nb : 0.0);
+    hvx_batcher_free(bt);
+    hvx_index_free(ix);
+    return 0;
+}

@@ -808,3 +808,45 @@ print("TIMING-OK")
 ''' % tuple(__import__("os").path.join(fx.ROOT, d) for d in ("helix-db_amd", "oracle", "tests"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert "TIMING-OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_batcher_coalesces_concurrent_single_query_callers(orc, hv):
+    """hvx_batcher: 48 threads issue single-query searches; every caller gets exactly the rows a direct
+    batch call returns (strict and production-default params), launches are shared, a rejected query fails alone."""
+    import threading
+    rng = np.random.default_rng(17)
+    n, dim = 2000, 128
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    oix = build_oracle(orc, data, 0, fx.draw_levels(n, 16, seed=4), efc=60)
+    gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=dim, metric=0, max_batch=64)
+    gix.set_simhash()
+    q = rng.standard_normal((480, dim)).astype(np.float32)
+    for params in (hv.SearchParams(10).with_ef(64), hv.SearchParams.new(10)):
+        want_ids, want_sc, want_cnt, _ = gix.search_batch(q, params)
+        bt = hv.Batcher(gix, params, max_batch=32, max_wait_us=2000)
+        got = [None] * q.shape[0]
+        errors = []
+
+        def worker(t):
+            try:
+                for i in range(t, q.shape[0], 48):
+                    got[i] = bt.search(q[i])
+            except Exception as e:  # pragma: no cover
+                errors.append(e)
+
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(48)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errors, errors
+        for i in range(q.shape[0]):
+            assert [r.entity_id for r in got[i]] == want_ids[i, :want_cnt[i]].tolist()
+            assert bits([r.score for r in got[i]]).tolist() == bits(want_sc[i, :want_cnt[i]]).tolist()
+        st = bt.stats()
+        assert st["queries"] == q.shape[0] and st["batches"] < q.shape[0] // 4, st
+        bad = q[0].copy()
+        bad[5] = np.inf
+        with pytest.raises(hv.HelixDbError) as e:
+            bt.search(bad)
+        assert e.value.status == hv.ERR_NONFINITE
+        assert [r.entity_id for r in bt.search(q[1])] == want_ids[1, :want_cnt[1]].tolist()
+        bt.close()

@@ -311,6 +311,8 @@ hipError_t launch_hnsw_wave_l2_bf16(const HnswArgs &a, uint32_t b, const WaveGeo
 hipError_t launch_hnsw_wave_cos_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_l2_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_cos_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_l2_bf16_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_cos_bf16_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 constexpr uint32_t kRngWords = 1024; // LDS window of the query RNG (hvx_hnsw_wave.h)
 
 bool hnsw_wave_supported(const HnswArgs &a) {
@@ -326,7 +328,7 @@ bool hnsw_wave_supported(const HnswArgs &a) {
     return true;
 }
 
-bool hnsw_wave_adaptive_supported(const HnswArgs &a) { return hnsw_wave_supported(a) && a.ix.dtype == HVX_F32; }
+bool hnsw_wave_adaptive_supported(const HnswArgs &a) { return hnsw_wave_supported(a); }
 
 static int env_int(const char *name, int lo, int hi, int fallback) {
     const char *e = getenv(name);
@@ -346,7 +348,10 @@ hipError_t launch_hnsw_wave(const HnswArgs &a, uint32_t b, hipStream_t s) {
     const size_t budget = 40 * 1024;
     const size_t need = ((size_t)4 << g.log2cap) + 512 + (size_t)a.ix.dim * 4 + (a.adaptive ? kRngWords * 4 : 0);
     g.lds = need < budget ? budget : need;
-    if (a.adaptive) return a.ix.metric == kL2 ? launch_hnsw_wave_l2_ad(a, b, g, s) : launch_hnsw_wave_cos_ad(a, b, g, s);
+    if (a.adaptive) {
+        if (a.ix.dtype == HVX_BF16) return a.ix.metric == kL2 ? launch_hnsw_wave_l2_bf16_ad(a, b, g, s) : launch_hnsw_wave_cos_bf16_ad(a, b, g, s);
+        return a.ix.metric == kL2 ? launch_hnsw_wave_l2_ad(a, b, g, s) : launch_hnsw_wave_cos_ad(a, b, g, s);
+    }
     if (a.prof) return launch_hnsw_wave_prof(a, b, g, s);
     if (a.ix.dtype == HVX_BF16) return a.ix.metric == kL2 ? launch_hnsw_wave_l2_bf16(a, b, g, s) : launch_hnsw_wave_cos_bf16(a, b, g, s);
     return a.ix.metric == kL2 ? launch_hnsw_wave_l2(a, b, g, s) : launch_hnsw_wave_cos(a, b, g, s);

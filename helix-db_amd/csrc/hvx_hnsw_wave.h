@@ -828,6 +828,8 @@ hipError_t launch_hnsw_wave_prof(const HnswArgs &a, uint32_t b, const WaveGeom &
 // non-strict arms (AD instantiations), hvx_hnsw_wave_l2_ad.hip / hvx_hnsw_wave_cos_ad.hip
 hipError_t launch_hnsw_wave_l2_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_cos_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_l2_bf16_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_cos_bf16_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 
 template <typename K> static hipError_t launch_wave_kernel(K kern, const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
     if (g.lds > 48 * 1024) {

@@ -56,6 +56,8 @@ bool hnsw_wave_adaptive_supported(const HnswArgs &a);
 // SimHash of n device-resident f32 rows (row stride ld) against transposed hyperplanes [dim][64]
 hipError_t launch_simhash_rows(const float *planes_t, const float *rows, uint32_t dim, uint32_t ld, uint64_t n, uint64_t *out,
                                hipStream_t s);
+hipError_t launch_simhash_rows_bf16(const float *planes_t, const uint16_t *rows, uint32_t dim, uint64_t n, uint64_t *out,
+                                    hipStream_t s);
 // host: the 64 unit hyperplanes of SimHasher(dim, seed), transposed to [dim][64]
 void simhash_planes_transposed(uint32_t dim, uint64_t seed, float *planes_t);
 hipError_t launch_hnsw_wave(const HnswArgs &a, uint32_t b, hipStream_t s);

@@ -68,9 +68,12 @@ extern "C" int hvx_index_set_simhash(hvx_index *ix, const hvx_simhash_config *cf
     if (node_hashes) {
         HIP_TRY(hipMemcpy(ix->d_node_hash, node_hashes, (size_t)n * 8, hipMemcpyDefault));
     } else {
-        if (ix->dev.dtype != HVX_F32)
-            return fail(HVX_ERR_UNSUPPORTED, "SimHash rows can only be recomputed from f32 rows; pass node_hashes for bf16 / fp8 storage");
-        HIP_TRY(launch_simhash_rows(ix->d_planes_t, ix->dev.vec, dim, ix->dev.ld, n, ix->d_node_hash, ix->stream));
+        if (ix->dev.dtype == HVX_FP8_E4M3)
+            return fail(HVX_ERR_UNSUPPORTED, "SimHash rows are not recomputed from fp8 storage; pass node_hashes");
+        if (ix->dev.dtype == HVX_BF16) // the stored (rounded) values are the vectors of this index
+            HIP_TRY(launch_simhash_rows_bf16(ix->d_planes_t, ix->dev.vecb, dim, n, ix->d_node_hash, ix->stream));
+        else
+            HIP_TRY(launch_simhash_rows(ix->d_planes_t, ix->dev.vec, dim, ix->dev.ld, n, ix->d_node_hash, ix->stream));
         HIP_TRY(hipStreamSynchronize(ix->stream));
     }
     ix->sh_cfg = *cfg;

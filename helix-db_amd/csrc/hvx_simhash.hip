@@ -84,7 +84,32 @@ __global__ __launch_bounds__(64) void simhash_kernel(const float *planes_t, cons
 
 } // namespace
 
+namespace {
+// the same projection over bf16 rows in the interleaved device layout (hvx_device.h): element d sits at bf16_slot_of(d)
+__global__ __launch_bounds__(64) void simhash_bf16_kernel(const float *planes_t, const uint16_t *rows, uint32_t dim, uint64_t n,
+                                                          uint64_t *out) {
+    const uint64_t r = blockIdx.x;
+    if (r >= n) return;
+    const uint16_t *v = rows + r * dim;
+    const int lane = (int)threadIdx.x;
+    float dot = 0.0f;
+    for (uint32_t d = 0; d < dim; ++d) {
+        const float t = bf16_to_f32(v[bf16_slot_of(d)]) * planes_t[(size_t)d * 64 + lane];
+        dot += t;
+    }
+    const unsigned long long bits = __ballot(dot > 0.0f);
+    if (lane == 0) out[r] = bits;
+}
+} // namespace
+
 namespace hvx {
+hipError_t launch_simhash_rows_bf16(const float *planes_t, const uint16_t *rows, uint32_t dim, uint64_t n, uint64_t *out,
+                                    hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(simhash_bf16_kernel, dim3((uint32_t)n), dim3(64), 0, s, planes_t, rows, dim, n, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_simhash_rows(const float *planes_t, const float *rows, uint32_t dim, uint32_t ld, uint64_t n, uint64_t *out,
                                hipStream_t s) {
     if (n == 0) return hipSuccess;

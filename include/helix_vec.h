@@ -161,7 +161,7 @@ void hvx_simhash_config_default(hvx_simhash_config *);
 
 /* Attach the per-node SimHash rows ([0xF0][index_id][0x13] rows / order codes of the vector keys) to an imported
  * index: node_hashes [n] in node-id order (host memory), or NULL to compute them on the device with
- * SimHasher(dim, cfg->seed) from the imported f32 rows (unaligned_vector/simhash.rs:263-291).  Required before
+ * SimHasher(dim, cfg->seed) from the stored f32 / bf16 rows (unaligned_vector/simhash.rs:263-291).  Required before
  * a search whose params need the query fingerprint (SearchParams::requires_query_simhash, mod.rs:546-552). */
 int hvx_index_set_simhash(hvx_index *, const hvx_simhash_config *cfg, const uint64_t *node_hashes);
 int hvx_index_get_simhash(const hvx_index *, uint64_t *out_node_hashes /*[n] host*/);

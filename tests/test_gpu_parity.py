@@ -682,6 +682,29 @@ def test_non_strict_arms_match_oracle(orc, hv, name, metric, n, dim, m, m0, mk, 
         assert agg["pre_simhash_sample_dropped"] > 0 and agg["pre_simhash_sample_kept"] > 0
 
 
+@pytest.mark.parametrize("metric,dim", [(0, 256), (1, 128)])
+def test_non_strict_arms_over_bf16_rows(orc, hv, metric, dim):
+    """Config #4 storage under the production-default params: the oracle runs on the rounded vectors (its SimHash rows
+    are those of the rounded vectors too, as the device computes them from the stored bf16 values)."""
+    rng = np.random.default_rng(77 + dim)
+    n = 2500
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    rounded = fx.round_bf16(data)
+    lv = fx.draw_levels(n, 16, seed=dim + 9)
+    oix = build_oracle(orc, rounded, metric, lv, efc=80)
+    oix.set_simhash(42)
+    ex = oix.export()
+    ex["vectors"] = data  # the device does the rounding
+    gix = hv.ValidatedVectorReadIndex.from_export(ex, dim=dim, metric=metric, dtype=hv.BF16)
+    cfg = hv.SimHashConfig.default()
+    gix.set_simhash(cfg)
+    assert gix.get_simhash().tolist() == oix.get_simhash().tolist()
+    q = rng.standard_normal((32, dim)).astype(np.float32)
+    agg = assert_params_equal(orc, hv, oix, gix, q, hv.SearchParams.new(10), cfg)
+    assert agg["pre_simhash_sample_dropped"] > 0 and (metric == 1 or agg["simhash_filtered"] > 0)
+    assert_params_equal(orc, hv, oix, gix, q, hv.SearchParams.throughput_profile_floor_92(10), cfg)
+
+
 def test_non_strict_arms_spill_path_and_given_hashes(orc, hv, monkeypatch):
     """LDS visited table -> HBM bitmap spill inside the non-strict arms (visited TEST and late insert both take the
     bitmap), with the SimHash rows handed over by the host instead of recomputed."""

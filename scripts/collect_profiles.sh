@@ -11,14 +11,20 @@ cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 BENCH="python bench.py --steps 20 --warmup 3 --graph-cache /tmp/g"
 $BENCH 2> $out/bench.log | tail -1 > $out/bench_line.json
 rm -rf /tmp/prof_$tag
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o $tag -- $BENCH --cpu-seconds 0 --no-verify > /tmp/prof_$tag.log 2>&1
+# the headline kernel alone (no production-default leg: its strict ef=100 launches share the R=3 instantiation's name)
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o $tag -- $BENCH --cpu-seconds 0 --no-verify --no-production-default > /tmp/prof_$tag.log 2>&1
 grep '^{' /tmp/prof_$tag.log | tail -1 > $out/bench_line_profiled.json
 cp /tmp/prof_$tag/${tag}_kernel_stats.csv $out/kernel_stats_full.csv
 (head -1 $out/kernel_stats_full.csv; grep "hvx::" $out/kernel_stats_full.csv) > $out/kernel_stats_hvx.csv
+# the same with the production-default leg: the AD instantiation (..., false, true>) only runs SearchParams::new(k) launches
+rm -rf /tmp/prof_${tag}p
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${tag}p -o ${tag}p -- $BENCH --cpu-seconds 0 --no-verify > /tmp/prof_${tag}p.log 2>&1
+grep '^{' /tmp/prof_${tag}p.log | tail -1 > $out/bench_line_profiled_production_default.json
+(head -1 /tmp/prof_${tag}p/${tag}p_kernel_stats.csv; grep "hvx::" /tmp/prof_${tag}p/${tag}p_kernel_stats.csv) > $out/kernel_stats_hvx_production_default.csv
 pmc() {
   name=$1; shift
   rm -rf /tmp/pmc_$name
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$name -o $name -- $BENCH --steps 5 --warmup 2 --cpu-seconds 0 --no-verify > /tmp/pmc_$name.log 2>&1
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$name -o $name -- $BENCH --steps 5 --warmup 2 --cpu-seconds 0 --no-verify --no-production-default > /tmp/pmc_$name.log 2>&1
   f=$(ls /tmp/pmc_$name/*counter_collection.csv | head -1)
   (head -1 "$f"; grep -E "hnsw_(wave|search)_kernel" "$f") > $out/pmc_$name.csv
 }

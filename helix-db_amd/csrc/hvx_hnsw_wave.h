@@ -32,6 +32,7 @@
 namespace hvx {
 
 constexpr uint32_t kTabEmpty = 0xFFFFFFFFu;
+constexpr uint32_t kTentativeBit = 0x80000000u; // visited-table entry claimed by the non-strict arms, not (yet) visited
 
 __device__ __forceinline__ uint32_t umin_dpp_row(uint32_t v) {
     // butterfly inside each 16-lane DPP row: xor1, xor2, half-mirror (7-l), mirror (15-l)
@@ -72,12 +73,41 @@ struct Visited {
     __device__ __forceinline__ void spill(int lane) {
         for (uint32_t i = (uint32_t)lane; i < cap; i += 64) {
             uint32_t v = tab[i];
-            if (v != kTabEmpty) atomicOr(&bm[v >> 5], 1u << (v & 31u));
+            if (v != kTabEmpty && !(v & kTentativeBit)) atomicOr(&bm[v >> 5], 1u << (v & 31u));
         }
         spilled = true;
         __threadfence_block();
     }
-    // membership test only (non-strict arms: a neighbour is marked visited later, when it is filtered or admitted)
+    // Non-strict arms: a neighbour becomes visited only when it is filtered or admitted, later in the expansion.
+    // claim() probes ONCE: an unknown id takes an empty slot as TENTATIVE (bit 31; tentative ids count as unseen, also for
+    // later expansions, and keep their slot), commit() turns the remembered slot into a visited entry with one plain
+    // store -- one LDS probe loop per expansion instead of a test loop plus an insert loop.  In bitmap mode claim() is
+    // a bit test and commit() the atomicOr.  Returns true for unseen ids; ids must be < 2^31 - 1.
+    __device__ __forceinline__ bool claim(uint32_t id, bool valid, int lane, uint32_t &slot_out) {
+        if (!spilled && count + 64u > cap - (cap >> 2)) spill(lane);
+        if (spilled) return !contains(id, valid) & valid;
+        bool pending = valid, unseen = false, taken = false;
+        uint32_t slot = (id * 2654435761u) >> shift;
+        while (__ballot(pending)) {
+            if (pending) {
+                const uint32_t old = atomicCAS(&tab[slot], kTabEmpty, id | kTentativeBit);
+                if (old == kTabEmpty) { unseen = true; taken = true; pending = false; }
+                else if ((old & ~kTentativeBit) == id) { unseen = (old & kTentativeBit) != 0u; pending = false; }
+                else slot = (slot + 1u) & mask;
+            }
+        }
+        slot_out = slot;
+        count += (uint32_t)__builtin_popcountll(__ballot(taken));
+        return unseen;
+    }
+    __device__ __forceinline__ void commit(uint32_t id, bool doit, uint32_t slot) {
+        if (spilled) {
+            if (doit) atomicOr(&bm[id >> 5], 1u << (id & 31u));
+        } else if (doit) {
+            tab[slot] = id;
+        }
+    }
+    // membership test only
     __device__ __forceinline__ bool contains(uint32_t id, bool valid) const {
         if (spilled) {
             bool hit = false;
@@ -410,7 +440,9 @@ __device__ __forceinline__ float candidate_probability_fn(uint32_t kind, float b
 // hard waits at the phase boundaries); it is only launched when HVX_WAVE_PROF is set.
 // AD=true builds the non-strict layer-0 arms (SimHash filter, pre/post sampling, adaptive bypass) into the same
 // beam search; AD=false is the strict-exhaustive arm and compiles to exactly the code it was before.
-template <uint32_t METRIC, int R, int NK, bool BF, bool PROF = false, bool AD = false>
+// ST=false drops the SearchStats counters of the non-strict stages (the reference's COLLECT_DIAGNOSTICS=false
+// specialisation, search.rs:267-270): seventeen fewer live scalars, which is what keeps the AD kernels out of SGPR spills.
+template <uint32_t METRIC, int R, int NK, bool BF, bool PROF = false, bool AD = false, bool ST = true>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void hnsw_wave_kernel(HnswArgs a, uint32_t log2cap) {
     // rows per 8-lane group in flight: P*NK <= 24 float4 per lane for a narrow pass, x2 and x4 for wider
     // frontiers (4P*NK <= 96 float4 = 384 registers, VGPR+AGPR file of one wave per SIMD)
@@ -507,13 +539,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     };
 
     // non-strict arms: visited TEST only; the unvisited neighbours land in fr_id in row order
-    auto frontier_probe = [&](uint32_t nid, uint32_t &deg) __attribute__((always_inline)) -> uint32_t {
+    // non-strict arms: ONE probe of the visited table claims the unseen neighbours tentatively (Visited::claim); the
+    // selection stages then work in row-lane space (lane = position in the neighbour row = frontier order)
+    uint32_t vslot = 0;
+    auto frontier_claim = [&](uint32_t nid, uint32_t &deg, unsigned long long &um) __attribute__((always_inline)) -> uint32_t {
         const bool valid = nid != kSentinel;
-        const bool unseen = valid & !V.contains(nid, valid);
-        const unsigned long long um = __ballot(unseen);
+        const bool unseen = V.claim(nid, valid, lane, vslot);
+        um = __ballot(unseen);
         deg = (uint32_t)__builtin_popcountll(__ballot(valid));
-        if (unseen) fr_id[__builtin_popcountll(um & ((1ull << lane) - 1ull))] = nid;
-        __syncthreads();
         return (uint32_t)__builtin_popcountll(um);
     };
 
@@ -559,6 +592,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     uint32_t dropped_unexpanded = 0;
     const uint32_t ef = a.ef;
     uint32_t pf_id = kSentinel, pf_row = kSentinel; // predicted next candidate and its prefetched row
+    // non-strict arms with a SimHash filter: the SimHash rows of the prefetched neighbour row are requested underneath
+    // the admission loop, so the filter of the next expansion does not wait for an 8-byte gather of its own
+    uint32_t pf_hash_for = kSentinel;
+    unsigned long long pf_hash = 0ull;
+    const bool want_hash = AD && a.ad.filtering != 0u;
+    auto prefetch_hash = [&]() __attribute__((always_inline)) {
+        if (AD && want_hash && pf_id != kSentinel && pf_hash_for != pf_id) {
+            pf_hash = pf_row != kSentinel ? a.ad.node_hash[pf_row] : 0ull;
+            pf_hash_for = pf_id;
+        }
+    };
     unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0; // PROF only
     auto tick = [&](int phase, bool wait) __attribute__((always_inline)) {
         if (PROF) {
@@ -600,7 +644,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             // step and stop on `current_dist > w.peek()` (search.rs:549)
             if (dropped_unexpanded) {
                 ++st_exp;
-                if (AD) { A.st.effective_beam_len_sum += (S.count < ef ? S.count : ef) + A.fill; A.st.effective_beam_len_samples += 1u; }
+                if (AD && ST) { A.st.effective_beam_len_sum += (S.count < ef ? S.count : ef) + A.fill; A.st.effective_beam_len_samples += 1u; }
             }
             break;
         }
@@ -609,7 +653,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         const uint32_t c = S.id_at(pos);
         const uint32_t wlen = S.count < ef ? S.count : ef;
         float wmax = S.score_at(wlen - 1);
-        if (AD) { A.st.effective_beam_len_sum += wlen + A.fill; A.st.effective_beam_len_samples += 1u; }
+        if (AD && ST) { A.st.effective_beam_len_sum += wlen + A.fill; A.st.effective_beam_len_samples += 1u; }
         if (wlen + (AD ? A.fill : 0u) >= ef && dc > wmax) break; // effective_len counts the virtual fill slots
         S.mark_expanded(pos, lane);
 
@@ -617,8 +661,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if (c == pf_id) { nid = pf_row; if (PROF) pt[6] += 1; }
         else nid = (uint32_t)lane < ix.s0 ? ix.l0[(size_t)c * ix.s0 + (uint32_t)lane] : kSentinel;
         tick(0, true); // pop + neighbour row available
+        unsigned long long nh = 0ull;
+        if (AD && want_hash) nh = c == pf_hash_for ? pf_hash : (nid != kSentinel ? a.ad.node_hash[nid] : 0ull);
         uint32_t deg;
-        uint32_t nf = AD ? frontier_probe(nid, deg) : frontier_from(nid, deg);
+        unsigned long long um = 0ull; // AD: lanes (row positions) of the unseen neighbours
+        uint32_t nf = AD ? frontier_claim(nid, deg, um) : frontier_from(nid, deg);
         st_nb += deg;
         tick(1, true); // visited test-and-set + compaction
         // 93 % of the time the next pop is simply the next unexpanded entry already in the beam: its
@@ -633,50 +680,54 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         }
         pf_id = e2;
         pf_row = row2;
-        if (nf == 0) continue;
+        if (nf == 0) { prefetch_hash(); continue; }
         if (AD) {
             // ---- one decision epoch + candidate selection (search.rs:595-829) ----
             const AdaptArgs &P = a.ad;
             const uint32_t nf0 = nf;
-            const uint32_t node = (uint32_t)lane < nf0 ? fr_id[lane] : kSentinel;
-            __syncthreads();
+            const uint32_t node = nid;
+            const unsigned long long node_h = nh;
+            const bool unseen = (um >> lane) & 1ull;
+            const uint32_t frank = (uint32_t)__builtin_popcountll(um & ((1ull << lane) - 1ull)); // index in the frontier
             const uint32_t kt = a.k > 1u ? a.k : 1u;              // topk_target
             const float delta = S.score_at((kt < wlen ? kt : wlen) - 1u); // topk == the first min(k,|W|) of W
             const AdaptDecision D = adapt_decide(P, A, ef, wlen >= kt, wlen, nf0, dc, delta, brk_lane);
-            A.st.simhash_bypass_trigger_low_yield += D.trigger == 2u ? 1u : 0u;
-            A.st.active_sampling_ratio_sum += (double)D.base_p;
-            A.st.active_sampling_ratio_samples += 1u;
-            if (D.filter) { A.st.active_simhash_threshold_sum += D.threshold; A.st.active_simhash_threshold_samples += 1u; }
+            if (ST) A.st.simhash_bypass_trigger_low_yield += D.trigger == 2u ? 1u : 0u;
+            if (ST) A.st.active_sampling_ratio_sum += (double)D.base_p;
+            if (ST) A.st.active_sampling_ratio_samples += 1u;
+            if (ST && D.filter) { A.st.active_simhash_threshold_sum += D.threshold; A.st.active_simhash_threshold_samples += 1u; }
             // stage 0: pre-sampling, one draw per frontier neighbour in row order (search.rs:651-679)
-            bool keep = (uint32_t)lane < nf0;
+            bool keep = unseen;
             const bool pre_enabled = D.pre_kind != 0u;
             if (pre_enabled) {
                 if (D.pre_p <= 0.0f) keep = false;
                 else if (D.pre_p < 1.0f) {
                     G.ensure(lane);
-                    keep = keep && G.below(G.pos + (uint32_t)lane, D.pre_p);
+                    keep = keep && G.below(G.pos + frank, D.pre_p);
                     G.pos += nf0;
                 }
                 uint32_t nk = (uint32_t)__builtin_popcountll(__ballot(keep));
-                A.st.pre_simhash_sample_dropped += nf0 - nk;
-                if (nk == 0u) { keep = (uint32_t)lane == G.choose_index(nf0, lane); nk = 1u; }
-                A.st.pre_simhash_sample_kept += nk;
+                if (ST) A.st.pre_simhash_sample_dropped += nf0 - nk;
+                if (nk == 0u) { keep = unseen & (frank == G.choose_index(nf0, lane)); nk = 1u; }
+                if (ST) A.st.pre_simhash_sample_kept += nk;
             }
             const uint32_t ns = (uint32_t)__builtin_popcountll(__ballot(keep));
-            if (D.bypassed) { A.st.simhash_bypass_expansions += 1u; A.st.simhash_skipped_candidates += ns; }
+            if (ST && D.bypassed) { A.st.simhash_bypass_expansions += 1u; A.st.simhash_skipped_candidates += ns; }
             // threshold screening (search.rs:708-757): filtered rows are marked visited and, while the beam is
             // still filling, consume a virtual fill slot
             uint32_t sim = 32u;
-            bool pass = keep;
+            bool pass = keep, vfail = false;
             if (D.filter) {
-                const uint64_t h = keep ? P.node_hash[node] : 0ull;
+                const uint64_t h = keep ? node_h : 0ull;
                 sim = 64u - (uint32_t)__builtin_popcountll(h ^ qh); // collision_count == 64 - hamming_distance
                 const bool failed = keep & !(sim >= D.threshold);
                 const uint32_t nfail = (uint32_t)__builtin_popcountll(__ballot(failed));
-                A.st.simhash_examined += ns;
-                A.st.simhash_filtered += nfail;
-                const bool fresh = V.insert(node, failed, lane);
-                const uint32_t nfresh = (uint32_t)__builtin_popcountll(__ballot(fresh));
+                if (ST) A.st.simhash_examined += ns;
+                if (ST) A.st.simhash_filtered += nfail;
+                // rows are canonical (deduped) and these neighbours were unseen a moment ago: every filtered row is a
+                // fresh `visited.insert`; the insertion itself happens once, together with the admitted rows below
+                vfail = failed;
+                const uint32_t nfresh = nfail;
                 const uint32_t eff = wlen + A.fill;
                 const uint32_t room = eff < ef ? ef - eff : 0u;
                 A.fill += nfresh < room ? nfresh : room;
@@ -688,7 +739,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     if (A.win_exp > P.window_expansions) { A.win_ex >>= 1; A.win_filt >>= 1; A.win_exp = P.window_expansions >> 1; }
                 }
             }
-            A.st.simhash_passed_before_sampling += (uint32_t)__builtin_popcountll(__ballot(pass));
+            if (ST) A.st.simhash_passed_before_sampling += (uint32_t)__builtin_popcountll(__ballot(pass));
             // proximity-aware probabilistic expansion (search.rs:759-788): draws only for 0 < p < 1, in row order
             bool sampled = pass, deferred = false;
             const bool should_sample = !pre_enabled & (D.samp_kind != 0u) & (D.samp_p > 0.0f);
@@ -715,17 +766,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 sampled = (uint32_t)lane == (uint32_t)__builtin_ctzll(bm);
             }
             // mark_sampled_neighbors_visited (search.rs:89-97): only admitted rows become visited
-            const bool acc = V.insert(node, sampled, lane);
+            // ... and so do the rows the filter rejected (search.rs:739-748): ONE pass over the visited table for both
+            V.commit(node, sampled | vfail, vslot);
+            const bool acc = sampled;
             const unsigned long long am = __ballot(acc);
-            A.st.simhash_passed_after_sampling += (uint32_t)__builtin_popcountll(__ballot(sampled));
+            if (ST) A.st.simhash_passed_after_sampling += (uint32_t)__builtin_popcountll(__ballot(sampled));
             if (acc) fr_id[__builtin_popcountll(am & ((1ull << lane) - 1ull))] = node;
             __syncthreads();
             nf = (uint32_t)__builtin_popcountll(am);
-            if (nf == 0) continue;
+            if (nf == 0) { prefetch_hash(); continue; }
         }
         st_vl += nf;
         st_dc += nf;
         score_frontier(nf);
+        prefetch_hash(); // the prefetched row came back with the gathers: its SimHash rows go out under the admission loop
         tick(2, true); // row gathers + FMAs
         const float d_l = (uint32_t)lane < nf ? fr_d[lane] : inf;
         const uint32_t id_l = (uint32_t)lane < nf ? fr_id[lane] : kSentinel;
@@ -775,6 +829,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 }
             }
         }
+        prefetch_hash(); // a fresh-candidate prediction replaced the prefetched row during this expansion
         if (PROF) { t1 = __builtin_readcyclecounter(); pt[4] += t1 - t0; t0 = t1; } // admission loop
     }
     if (PROF && a.prof && lane == 0) {
@@ -806,7 +861,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if (a.out_status) a.out_status[q] = bad_score ? 8u /*HVX_ERR_INVARIANT*/ : 0u;
         if (a.qstats) a.qstats[q] = hvx_query_stats{st_exp, st_nb, st_vl, st_dc};
         if (a.tie_flags) a.tie_flags[q] = tie_overflow ? 1u : 0u;
-        if (AD && a.ad.stats) {
+        if (AD && ST && a.ad.stats) {
             A.st.rng_words = G.pos;
             a.ad.stats[q] = A.st;
         }
@@ -840,25 +895,31 @@ template <typename K> static hipError_t launch_wave_kernel(K kern, const HnswArg
     return hipGetLastError();
 }
 
-template <uint32_t METRIC, int R, bool BF, bool AD = false>
+template <uint32_t METRIC, int R, bool BF, bool AD = false, bool ST = true>
 static hipError_t launch_wave_nk(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
     switch (a.ix.dim >> 5) {
-    case 4: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 4, BF, false, AD>, a, b, g, s);
-    case 8: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 8, BF, false, AD>, a, b, g, s);
-    case 16: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 16, BF, false, AD>, a, b, g, s);
-    case 24: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 24, BF, false, AD>, a, b, g, s);
-    case 32: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 32, BF, false, AD>, a, b, g, s);
-    case 48: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 48, BF, false, AD>, a, b, g, s);
+    case 4: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 4, BF, false, AD, ST>, a, b, g, s);
+    case 8: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 8, BF, false, AD, ST>, a, b, g, s);
+    case 16: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 16, BF, false, AD, ST>, a, b, g, s);
+    case 24: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 24, BF, false, AD, ST>, a, b, g, s);
+    case 32: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 32, BF, false, AD, ST>, a, b, g, s);
+    case 48: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 48, BF, false, AD, ST>, a, b, g, s);
     default: return hipErrorInvalidValue;
     }
 }
 
-template <uint32_t METRIC, bool BF, bool AD = false>
+template <uint32_t METRIC, bool BF, bool AD = false, bool ST = true>
 static hipError_t launch_wave_r(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
     const uint32_t need = a.ef + 32u; // beam capacity 64*R must hold ef plus slack for equal-score evictions
-    if (need <= 192) return launch_wave_nk<METRIC, 3, BF, AD>(a, b, g, s);
-    if (need <= 384) return launch_wave_nk<METRIC, 6, BF, AD>(a, b, g, s);
+    if (need <= 192) return launch_wave_nk<METRIC, 3, BF, AD, ST>(a, b, g, s);
+    if (need <= 384) return launch_wave_nk<METRIC, 6, BF, AD, ST>(a, b, g, s);
     return hipErrorInvalidValue;
+}
+// non-strict arms: with the per-query SearchStats of the filter / sampling stages when the caller asked for them,
+// else the diagnostics-free build
+template <uint32_t METRIC, bool BF>
+static hipError_t launch_wave_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
+    return a.ad.stats ? launch_wave_r<METRIC, BF, true, true>(a, b, g, s) : launch_wave_r<METRIC, BF, true, false>(a, b, g, s);
 }
 
 } // namespace hvx

@@ -4,6 +4,6 @@
 
 namespace hvx {
 hipError_t launch_hnsw_wave_cos_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
-    return launch_wave_r<kCosine, false, true>(a, b, g, s);
+    return launch_wave_ad<kCosine, false>(a, b, g, s);
 }
 } // namespace hvx

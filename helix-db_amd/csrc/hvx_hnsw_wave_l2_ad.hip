@@ -4,6 +4,6 @@
 
 namespace hvx {
 hipError_t launch_hnsw_wave_l2_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
-    return launch_wave_r<kL2, false, true>(a, b, g, s);
+    return launch_wave_ad<kL2, false>(a, b, g, s);
 }
 } // namespace hvx

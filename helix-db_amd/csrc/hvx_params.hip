@@ -162,7 +162,7 @@ static int project_params(hvx_index *ix, const hvx_search_params *p, AdaptArgs *
     ad->node_hash = ix->d_node_hash;
     ad->qhash = ix->d_qhash;
     ad->thr_break = ix->d_thr_break;
-    ad->stats = ix->d_astats;
+    ad->stats = nullptr; // set per call: the diagnostics-free kernel build runs when the caller wants no SearchStats
     ad->configured = c.simhash_threshold;
     ad->ratio = has_sr ? p->simhash_sampling_ratio_override : c.sampling_ratio;
     ad->pre_override = has_pre ? p->pre_simhash_sampling_ratio_override : -1.0f;
@@ -197,7 +197,7 @@ static int enqueue_params(hvx_index *ix, const float *d_queries, uint32_t b, con
         return enqueue_search(ix, d_queries, b, p->k, p->ef, d_ids, d_scores, d_counts, d_status, d_qstats, timed);
     }
     AdaptArgs a = *ad;
-    if (d_astats) a.stats = d_astats;
+    a.stats = d_astats;
     // query fingerprints (search.rs:1143-1154); invalid queries are rejected by the search kernel's status check
     HIP_TRY(launch_simhash_rows(ix->d_planes_t, d_queries, ix->dev.dim, ix->dev.dim, b, ix->d_qhash, ix->stream));
     return enqueue_search(ix, d_queries, b, p->k, p->ef, d_ids, d_scores, d_counts, d_status, d_qstats, timed, &a);

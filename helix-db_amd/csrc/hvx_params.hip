@@ -137,6 +137,18 @@ static int build_threshold_table(uint32_t configured, float failure, float brk[6
     return HVX_OK;
 }
 
+// host-only utility (no device work): the table the kernels evaluate adaptive_threshold with, for inspection and tests
+extern "C" int hvx_adaptive_threshold_table(uint32_t configured, float failure, float *out_brk /*[64]*/) {
+    if (!out_brk) return fail(HVX_ERR_INVARIANT, "null argument");
+    if (configured > 64) return fail(HVX_ERR_K_RANGE, "collision threshold %u exceeds the 64-bit SimHash width", configured);
+    if (!open_unit(failure)) return fail(HVX_ERR_K_RANGE, "failure probability outside the open unit interval");
+    if (configured == 0) { // threshold is 0 whatever delta is (policy.rs:582-583): no step reaches 1
+        for (int t = 0; t < 64; ++t) out_brk[t] = -1.0f;
+        return HVX_OK;
+    }
+    return build_threshold_table(configured, failure, out_brk);
+}
+
 // validate + project; strict = the params describe the strict-exhaustive arm (no fingerprint, no RNG)
 static int project_params(hvx_index *ix, const hvx_search_params *p, AdaptArgs *ad, bool *strict) {
     int rc = check_k_ef(p->k, p->ef);

@@ -144,6 +144,8 @@ def lib():
     L.hvx_search_batch_params.argtypes = [_vp, _vp, C.c_uint32, C.POINTER(_Params), _vp, _vp, _vp, _vp, C.POINTER(Stats), _vp, _vp]
     L.hvx_search_batch_params_device.restype = C.c_int
     L.hvx_search_batch_params_device.argtypes = [_vp, _vp, C.c_uint32, C.POINTER(_Params), _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(Stats)]
+    L.hvx_adaptive_threshold_table.restype = C.c_int
+    L.hvx_adaptive_threshold_table.argtypes = [C.c_uint32, C.c_float, _vp]
     L.hvx_flat_search_batch.restype = C.c_int
     L.hvx_flat_search_batch.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, C.POINTER(Stats)]
     L.hvx_flat_search_batch_device.restype = C.c_int
@@ -624,6 +626,13 @@ class SimHasher:
 
     def hash(self, vector) -> int:
         return int(self.hash_batch(np.asarray(vector, np.float32).reshape(1, -1))[0])
+
+
+def adaptive_threshold_table(configured: int, failure: float) -> np.ndarray:
+    """The 64-step table the kernels evaluate policy.rs:577-599 with (threshold(delta) = #{t : delta <= brk[t-1]})."""
+    brk = np.zeros(64, np.float32)
+    _check(lib().hvx_adaptive_threshold_table(configured, np.float32(failure), _ptr(brk)))
+    return brk
 
 
 def unique_restricted_rows(rows, element_type: str = "node"):

@@ -166,6 +166,10 @@ void hvx_simhash_config_default(hvx_simhash_config *);
 int hvx_index_set_simhash(hvx_index *, const hvx_simhash_config *cfg, const uint64_t *node_hashes);
 int hvx_index_get_simhash(const hvx_index *, uint64_t *out_node_hashes /*[n] host*/);
 
+/* Host-only: the step table the kernels evaluate `adaptive_threshold` (policy.rs:577-599) with -- out_brk[t-1] = the largest
+ * f32 delta whose threshold is >= t (-1: none), built with THIS host's libm; threshold(delta) = #{t : delta <= out_brk[t-1]}. */
+int hvx_adaptive_threshold_table(uint32_t configured, float failure, float *out_brk /*[64]*/);
+
 /* SearchStats fields of the non-strict arms (mod.rs:629-700), per query.  The device index plays the resident
  * snapshot (memory_store.rs:329-335): SimHash lookups are not stable-view reads, txn_get_simhash_filter stays 0
  * and the read-budget bypass trigger cannot fire -- exactly as for the reference with a Ready resident store. */

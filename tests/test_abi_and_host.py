@@ -171,3 +171,27 @@ def test_restricted_row_dedupe_and_materialisation_follow_the_interpreter():
     with pytest.raises(hv.HelixDbError) as e:
         hv.materialize_restricted_results(by_id, [hv.SearchResult(5, np.float32(0.0))])
     assert e.value.status == hv.ERR_INVARIANT
+
+
+@pytest.mark.parametrize("configured,failure", [(43, 0.1), (64, 0.5), (20, 0.01), (1, 0.3), (0, 0.1), (37, 0.9)])
+def test_adaptive_threshold_step_table_equals_the_formula(orc, configured, failure):
+    """The device never evaluates acos/ln: hvx_params.hip turns policy.rs:577-599 into a 64-step table with the host's
+    libm.  Table lookup == the oracle's direct evaluation for random deltas and for every f32 around every step."""
+    import pyhvx as hv
+    brk = hv.adaptive_threshold_table(configured, failure)
+    assert all(brk[i] >= brk[i + 1] for i in range(63))          # nested steps
+
+    def lookup(delta):
+        return int(np.count_nonzero(np.float32(delta) <= brk))
+
+    rng = np.random.default_rng(configured * 7 + 1)
+    deltas = np.concatenate([rng.random(4000, dtype=np.float32), np.float32([0.0, 1.0, 0.5, 2.0, 1e-7, 1e30]),
+                             np.abs(rng.standard_normal(500).astype(np.float32)) * np.float32(1e-3)])
+    for d in deltas:
+        assert lookup(d) == orc.adaptive_threshold(1, d, configured, failure), float(d)
+    for b in brk[brk >= 0]:
+        bits = int(np.float32(b).view(np.uint32))
+        for off in range(-3, 4):
+            if 0 <= bits + off <= 0x7F7FFFFF:
+                d = np.uint32(bits + off).view(np.float32)
+                assert lookup(d) == orc.adaptive_threshold(1, d, configured, failure), (float(b), off)

@@ -13,8 +13,9 @@
  * scales by 2^-24.  This restatement is PINNED by the reference's own known-answer test
  *   SimHasher(dim = 3, seed = 42).hash([1, 2, 3]) == 0x6d91_a757_8862_6786   (simhash_registry.rs:344-362)
  * which consumes 192 consecutive outputs of the stream (tests/test_oracle_golden.py).
- * `random_range` (the query-time sampling of the non-strict search arms) is NOT restated: the reference
- * holds no known answer for it.
+ * The query-time sampler of the non-strict search arms (`random::<f32>() < p`, hvx_oracle_adaptive.inc) draws from this
+ * same pinned generator; `random_range` (their two choose_index fallback sites) is restated there from rand's
+ * published algorithm but has no known answer in the reference: parity unpinned for those two sites.
  */
 #include "hvx_oracle.h"
 

@@ -873,3 +873,23 @@ def test_batcher_coalesces_concurrent_single_query_callers(orc, hv):
         assert e.value.status == hv.ERR_NONFINITE
         assert [r.entity_id for r in bt.search(q[1])] == want_ids[1, :want_cnt[1]].tolist()
         bt.close()
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_duplicate_vectors_ties_are_broken_by_id_in_both_arms(orc, hv, metric):
+    """20 exact copies of each of 120 vectors: every score occurs 20 times, so the (score, id) order (model.rs:55-61)
+    decides pops, evictions and the k cut everywhere; strict arm and production-default params against the oracle."""
+    rng = np.random.default_rng(2024 + metric)
+    base = rng.standard_normal((120, 128)).astype(np.float32)
+    data = np.repeat(base, 20, axis=0)[rng.permutation(2400)]
+    n = data.shape[0]
+    oix = build_oracle(orc, data, metric, fx.draw_levels(n, 16, seed=6), efc=80)
+    oix.set_simhash(42)
+    gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=128, metric=metric)
+    cfg = hv.SimHashConfig.default()
+    gix.set_simhash(cfg)
+    q = np.concatenate([base[:12] + np.float32(0.05) * rng.standard_normal((12, 128)).astype(np.float32), base[12:20]])
+    assert_hnsw_equal(orc, hv, oix, gix, q, 25, 64)     # k cuts through a group of equal scores
+    assert_hnsw_equal(orc, hv, oix, gix, q, 10, 100)
+    assert_params_equal(orc, hv, oix, gix, q, hv.SearchParams.new(10), cfg)
+    assert_params_equal(orc, hv, oix, gix, q, hv.SearchParams.new(25).with_ef(48), cfg)

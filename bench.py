@@ -160,6 +160,8 @@ def main():
     d_st = torch.zeros(b, dtype=torch.int32, device=dev)
     d_qst = torch.zeros(b, 4, dtype=torch.int32, device=dev)
     sharded = shard.ShardedSearcher(ix, world, b, k, dev) if (world > 1 and not replica) else None
+    if sharded is not None:  # the search writes straight into this rank's payload of the packed exchange buffer
+        d_ids, d_sc, d_cnt = sharded.outputs()
 
     def exchange_and_merge(ids_t, sc_t, cnt_t):
         return sharded.merge(ids_t, sc_t, cnt_t)
@@ -211,8 +213,8 @@ def main():
             "bf16 MFMA exact scan differs from the f32-kernel exact scan over the rounded rows"
         mfma_flat_ms = round(st2["device_ms"], 3)
     if sharded is not None:
-        truth = exchange_and_merge(f_ids, f_sc, f_cnt)[0].clone()
-        got = exchange_and_merge(d_ids, d_sc, d_cnt)[0].clone()
+        got = exchange_and_merge(d_ids, d_sc, d_cnt)[0].clone()    # d_* ARE the payload views: merge them first,
+        truth = exchange_and_merge(f_ids, f_sc, f_cnt)[0].clone()  # then let the exact-scan lists overwrite the payload
     else:
         truth, got = f_ids, d_ids
     torch.cuda.synchronize()

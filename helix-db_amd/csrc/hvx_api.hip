@@ -730,3 +730,26 @@ extern "C" int hvx_merge_topk_device(const hvx_index *cix, uint32_t g, uint32_t 
     HIP_TRY(launch_merge_topk(g, b, k, d_ids, d_scores, d_counts, d_out_ids, d_out_scores, d_out_counts, ix->stream));
     return HVX_OK;
 }
+
+// One rank's payload of the packed exchange buffer: ids [b][k] u64, then scores [b][k] f32, then counts [b] u32,
+// padded to a multiple of 8 bytes -- so that ONE all-gather carries everything a merge needs.
+extern "C" size_t hvx_topk_payload_bytes(uint32_t b, uint32_t k) {
+    const size_t raw = (size_t)b * k * 12 + (size_t)b * 4;
+    return (raw + 7) & ~(size_t)7;
+}
+
+extern "C" int hvx_merge_topk_packed_device(const hvx_index *cix, uint32_t g, uint32_t b, uint32_t k, const void *d_packed,
+                                            uint64_t *d_out_ids, float *d_out_scores, uint32_t *d_out_counts) {
+    if (!cix || !d_packed) return fail(HVX_ERR_INVARIANT, "null argument");
+    hvx_index *ix = const_cast<hvx_index *>(cix);
+    if (k == 0 || g == 0) return fail(HVX_ERR_K_RANGE, "k and shard count must be non-zero");
+    const size_t payload = hvx_topk_payload_bytes(b, k);
+    const char *base = static_cast<const char *>(d_packed);
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(launch_merge_topk_strided(g, b, k, reinterpret_cast<const uint64_t *>(base),
+                                      reinterpret_cast<const float *>(base + (size_t)b * k * 8),
+                                      reinterpret_cast<const uint32_t *>(base + (size_t)b * k * 12), payload / 8, payload / 4, payload / 4,
+                                      d_out_ids, d_out_scores, d_out_counts, ix->stream));
+    return HVX_OK;
+}

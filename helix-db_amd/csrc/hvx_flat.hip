@@ -326,24 +326,27 @@ hipError_t launch_flat_finish(const FlatArgs &a, uint64_t *out_ids, float *out_s
 // Rank-by-counting: entry x goes to position #{y : y < x}; ids are unique across shards.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void merge_topk_kernel(uint32_t g, uint32_t b, uint32_t k, const uint64_t *ids,
-                                                         const float *scores, const uint32_t *counts,
-                                                         uint64_t *out_ids, float *out_scores, uint32_t *out_counts) {
+                                                         const float *scores, const uint32_t *counts, size_t ids_stride,
+                                                         size_t scores_stride, size_t counts_stride, uint64_t *out_ids,
+                                                         float *out_scores, uint32_t *out_counts) {
+    // list s of query q: ids + s*ids_stride + q*k (strides in elements: b*k / b*k / b for three dense arrays, or the
+    // per-rank payload size for the packed exchange buffer of pyhvx/shard.py)
     const uint32_t q = blockIdx.x;
     uint32_t total = 0;
-    for (uint32_t s = 0; s < g; ++s) total += counts[(size_t)s * b + q];
+    for (uint32_t s = 0; s < g; ++s) total += counts[(size_t)s * counts_stride + q];
     const uint32_t outn = total < k ? total : k;
     for (uint32_t e = threadIdx.x; e < g * k; e += blockDim.x) {
         const uint32_t s = e / k, i = e % k;
-        if (i >= counts[(size_t)s * b + q]) continue;
-        const float sc = scores[((size_t)s * b + q) * k + i];
-        const uint64_t id = ids[((size_t)s * b + q) * k + i];
+        if (i >= counts[(size_t)s * counts_stride + q]) continue;
+        const float sc = scores[(size_t)s * scores_stride + (size_t)q * k + i];
+        const uint64_t id = ids[(size_t)s * ids_stride + (size_t)q * k + i];
         // rank = (entries before it in its own list) + for every other list, a binary search
         uint32_t rank = i;
         for (uint32_t s2 = 0; s2 < g; ++s2) {
             if (s2 == s) continue;
-            const uint32_t c2 = counts[(size_t)s2 * b + q];
-            const float *sp = scores + ((size_t)s2 * b + q) * k;
-            const uint64_t *ip = ids + ((size_t)s2 * b + q) * k;
+            const uint32_t c2 = counts[(size_t)s2 * counts_stride + q];
+            const float *sp = scores + (size_t)s2 * scores_stride + (size_t)q * k;
+            const uint64_t *ip = ids + (size_t)s2 * ids_stride + (size_t)q * k;
             uint32_t lo = 0, hi = c2;
             while (lo < hi) {
                 uint32_t mid = (lo + hi) >> 1;
@@ -363,9 +366,15 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(uint32_t g, uint32_t b,
 hipError_t launch_merge_topk(uint32_t g, uint32_t b, uint32_t k, const uint64_t *ids, const float *scores,
                              const uint32_t *counts, uint64_t *out_ids, float *out_scores,
                              uint32_t *out_counts, hipStream_t s) {
+    return launch_merge_topk_strided(g, b, k, ids, scores, counts, (size_t)b * k, (size_t)b * k, b, out_ids, out_scores, out_counts, s);
+}
+
+hipError_t launch_merge_topk_strided(uint32_t g, uint32_t b, uint32_t k, const uint64_t *ids, const float *scores,
+                                     const uint32_t *counts, size_t ids_stride, size_t scores_stride, size_t counts_stride,
+                                     uint64_t *out_ids, float *out_scores, uint32_t *out_counts, hipStream_t s) {
     if (b == 0) return hipSuccess;
-    hipLaunchKernelGGL(merge_topk_kernel, dim3(b), dim3(256), 0, s, g, b, k, ids, scores, counts, out_ids,
-                       out_scores, out_counts);
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(b), dim3(256), 0, s, g, b, k, ids, scores, counts, ids_stride, scores_stride,
+                       counts_stride, out_ids, out_scores, out_counts);
     return hipGetLastError();
 }
 

@@ -102,4 +102,8 @@ hipError_t launch_merge_topk(uint32_t g, uint32_t b, uint32_t k, const uint64_t 
                              const uint32_t *counts, uint64_t *out_ids, float *out_scores,
                              uint32_t *out_counts, hipStream_t s);
 
+hipError_t launch_merge_topk_strided(uint32_t g, uint32_t b, uint32_t k, const uint64_t *ids, const float *scores,
+                                     const uint32_t *counts, size_t ids_stride, size_t scores_stride, size_t counts_stride,
+                                     uint64_t *out_ids, float *out_scores, uint32_t *out_counts, hipStream_t s);
+
 } // namespace hvx

@@ -154,6 +154,10 @@ def lib():
     L.hvx_search_restricted_batch.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp, C.POINTER(Stats)]
     L.hvx_merge_topk_device.restype = C.c_int
     L.hvx_merge_topk_device.argtypes = [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]
+    L.hvx_topk_payload_bytes.restype = C.c_size_t
+    L.hvx_topk_payload_bytes.argtypes = [C.c_uint32, C.c_uint32]
+    L.hvx_merge_topk_packed_device.restype = C.c_int
+    L.hvx_merge_topk_packed_device.argtypes = [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]
     L.hvx_simhasher_new.restype = C.c_int
     L.hvx_simhasher_new.argtypes = [C.c_uint32, C.c_uint64, C.c_int32, C.POINTER(_vp)]
     L.hvx_simhasher_free.argtypes = [_vp]
@@ -503,6 +507,10 @@ class ValidatedVectorReadIndex:
     def merge_topk_device(self, g, b, k, d_ids, d_scores, d_counts, d_out_ids, d_out_scores, d_out_counts):
         _check(lib().hvx_merge_topk_device(self._h, g, b, k, d_ids.data_ptr(), d_scores.data_ptr(), d_counts.data_ptr(),
                                            d_out_ids.data_ptr(), d_out_scores.data_ptr(), d_out_counts.data_ptr()))
+
+    def merge_topk_packed_device(self, g, b, k, d_packed, d_out_ids, d_out_scores, d_out_counts):
+        _check(lib().hvx_merge_topk_packed_device(self._h, g, b, k, d_packed.data_ptr(), d_out_ids.data_ptr(),
+                                                  d_out_scores.data_ptr(), d_out_counts.data_ptr()))
 
     def timing_begin(self, capacity: int):
         _check(lib().hvx_index_timing_begin(self._h, capacity))

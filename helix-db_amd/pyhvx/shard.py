@@ -2,10 +2,10 @@
 
 One process per GPU.  Rank r owns the contiguous id range `plan_shards(n, world)[r]`, holds only
 those rows and an HNSW graph built over them, and searches the WHOLE query batch on its shard.  The
-only data-path exchange is the all-gather of the per-shard top-k (`b x k x (u64 id, f32 score)` +
-`b` counts -- 120 KB per rank for b=1024, k=10), after which every rank merges the `world` sorted
+only data-path exchange is ONE all-gather of the per-shard top-k, packed (`b x k x (u64 id, f32 score)` +
+`b` counts = 124 KB per rank for b=1024, k=10), after which every rank merges the `world` sorted
 lists by the reference's Candidate order (score asc, then id asc:
-crates/db/src/search/vector/model.rs:55-61) on its own device (hvx_merge_topk_device).
+crates/db/src/search/vector/model.rs:55-61) on its own device (hvx_merge_topk_packed_device).
 
 `exchange_topk` is backend-agnostic (`nccl` = RCCL over xGMI on the GPU box, `gloo` in the CPU
 tests); the merge itself has no CPU implementation in the product -- tests bring their own checker.
@@ -38,25 +38,48 @@ def owner_of(node_id: int, n_rows: int, world: int) -> int:
     return extra + (node_id - cut) // max(base, 1)
 
 
+def payload_bytes(b: int, k: int) -> int:
+    """One rank's share of the packed exchange buffer (== hvx_topk_payload_bytes): ids [b][k] u64, scores [b][k] f32,
+    counts [b] u32, padded to 8 bytes."""
+    return (b * k * 12 + b * 4 + 7) & ~7
+
+
 class TopkExchange:
-    """Pre-allocated all-gather of per-shard top-k lists: [world][b][k] ids / scores, [world][b] counts."""
+    """ONE all-gather per step: every rank contributes one packed payload (ids, scores, counts) and receives
+    [world][payload].  `ids` / `scores` / `counts` are views INTO the local payload, so a search that is handed them as
+    its output buffers has nothing to copy before the exchange."""
 
     def __init__(self, world: int, b: int, k: int, device, group=None):
         self.world, self.b, self.k, self.group = world, b, k, group
-        self.ids = torch.zeros(world, b, k, dtype=torch.int64, device=device)      # u64 bit patterns
-        self.scores = torch.zeros(world, b, k, dtype=torch.float32, device=device)
-        self.counts = torch.zeros(world, b, dtype=torch.int32, device=device)
+        self.payload = payload_bytes(b, k)
+        self.send = torch.zeros(self.payload, dtype=torch.uint8, device=device)
+        self.recv = torch.zeros(world * self.payload, dtype=torch.uint8, device=device)
+        self.ids, self.scores, self.counts = self.views(self.send, 0)
 
-    def gather(self, ids: torch.Tensor, scores: torch.Tensor, counts: torch.Tensor):
-        """ids [b,k] int64, scores [b,k] f32, counts [b] int32 of THIS rank -> the gathered tensors."""
+    def views(self, buf: torch.Tensor, rank: int):
+        """(ids [b][k] int64, scores [b][k] f32, counts [b] int32) of one rank's payload inside `buf`."""
+        b, k, o = self.b, self.k, rank * self.payload
+        ids = buf[o: o + b * k * 8].view(torch.int64).view(b, k)
+        scores = buf[o + b * k * 8: o + b * k * 12].view(torch.float32).view(b, k)
+        counts = buf[o + b * k * 12: o + b * k * 12 + b * 4].view(torch.int32)
+        return ids, scores, counts
+
+    def gather(self, ids: torch.Tensor = None, scores: torch.Tensor = None, counts: torch.Tensor = None):
+        """All-gather the local payload (after copying the given tensors into it, unless they ARE its views);
+        returns the packed [world][payload] buffer."""
+        for src, dst in ((ids, self.ids), (scores, self.scores), (counts, self.counts)):
+            if src is not None and src.data_ptr() != dst.data_ptr():
+                dst.copy_(src)
         if self.world == 1:
-            self.ids[0].copy_(ids); self.scores[0].copy_(scores); self.counts[0].copy_(counts)
+            self.recv.copy_(self.send)
         else:
-            w, b, k = self.world, self.b, self.k  # concatenation along dim 0 == the [world][b][k] layout
-            dist.all_gather_into_tensor(self.ids.view(w * b, k), ids.contiguous(), group=self.group)
-            dist.all_gather_into_tensor(self.scores.view(w * b, k), scores.contiguous(), group=self.group)
-            dist.all_gather_into_tensor(self.counts.view(w * b), counts.contiguous(), group=self.group)
-        return self.ids, self.scores, self.counts
+            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+        return self.recv
+
+    def gathered(self):
+        """The received lists as dense tensors [world][b][k] / [world][b] (copies; for checkers and tests)."""
+        parts = [self.views(self.recv, r) for r in range(self.world)]
+        return (torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]), torch.stack([p[2] for p in parts]))
 
 
 class ShardedSearcher:
@@ -69,8 +92,12 @@ class ShardedSearcher:
         self.m_scores = torch.zeros(b, k, dtype=torch.float32, device=device)
         self.m_counts = torch.zeros(b, dtype=torch.int32, device=device)
 
-    def merge(self, ids, scores, counts):
-        """All-gather this rank's lists and merge the `world` lists per query; returns merged tensors."""
-        g_ids, g_sc, g_cnt = self.ex.gather(ids, scores, counts)
-        self.ix.merge_topk_device(self.world, self.b, self.k, g_ids, g_sc, g_cnt, self.m_ids, self.m_scores, self.m_counts)
+    def outputs(self):
+        """Output buffers for this rank's search: views into the exchange payload (no copy before the all-gather)."""
+        return self.ex.ids, self.ex.scores, self.ex.counts
+
+    def merge(self, ids=None, scores=None, counts=None):
+        """One all-gather of this rank's lists, then the per-query merge of the `world` lists on the device."""
+        packed = self.ex.gather(ids, scores, counts)
+        self.ix.merge_topk_packed_device(self.world, self.b, self.k, packed, self.m_ids, self.m_scores, self.m_counts)
         return self.m_ids, self.m_scores, self.m_counts

@@ -232,6 +232,12 @@ int hvx_search_restricted_batch(const hvx_index *, const float *queries, uint32_
 int hvx_merge_topk_device(const hvx_index *, uint32_t g, uint32_t b, uint32_t k, const uint64_t *d_ids,
                           const float *d_scores, const uint32_t *d_counts, uint64_t *d_out_ids,
                           float *d_out_scores, uint32_t *d_out_counts);
+/* The same merge over ONE packed exchange buffer (one all-gather per step instead of three): rank r's payload starts at
+ * r * hvx_topk_payload_bytes(b, k) and holds ids [b][k] u64, scores [b][k] f32, counts [b] u32 in that order.  A search
+ * can write its outputs straight into the local payload (the three sub-arrays are ordinary device pointers). */
+size_t hvx_topk_payload_bytes(uint32_t b, uint32_t k);
+int hvx_merge_topk_packed_device(const hvx_index *, uint32_t g, uint32_t b, uint32_t k, const void *d_packed /*[g][payload]*/,
+                                 uint64_t *d_out_ids, float *d_out_scores, uint32_t *d_out_counts);
 
 /*
  * Graph prefilter (crates/graph-algorithms/src/model.rs:370-417 Csr; algorithms/traversal.rs:197-318

@@ -386,6 +386,23 @@ def test_merge_topk_device_matches_candidate_order(orc, hv):
     for q in range(b):
         assert got_i[q, :r_cnt[q]].tolist() == r_ids[q, :r_cnt[q]].tolist()
         assert bits(got_s[q, :r_cnt[q]]).tolist() == bits(r_sc[q, :r_cnt[q]]).tolist()
+    # the same lists as ONE packed exchange buffer (what pyhvx/shard.py all-gathers): [g][ids | scores | counts | pad]
+    from pyhvx import shard
+    payload = shard.payload_bytes(b, k)
+    assert payload == hv.lib().hvx_topk_payload_bytes(b, k) and payload % 8 == 0
+    packed = np.zeros((g, payload), np.uint8)
+    for s_ in range(g):
+        packed[s_, : b * k * 8] = ids[s_].view(np.uint8).reshape(-1)
+        packed[s_, b * k * 8: b * k * 12] = sc[s_].view(np.uint8).reshape(-1)
+        packed[s_, b * k * 12: b * k * 12 + b * 4] = cnt[s_].view(np.uint8).reshape(-1)
+    o_ids.zero_(); o_sc.zero_(); o_cnt.zero_()
+    gix.merge_topk_packed_device(g, b, k, torch.from_numpy(packed).to(dev), o_ids, o_sc, o_cnt)
+    gix.sync()
+    got_i, got_s, got_c = o_ids.cpu().numpy().view(np.uint64), o_sc.cpu().numpy(), o_cnt.cpu().numpy()
+    assert got_c.tolist() == r_cnt.tolist()
+    for q in range(b):
+        assert got_i[q, :r_cnt[q]].tolist() == r_ids[q, :r_cnt[q]].tolist()
+        assert bits(got_s[q, :r_cnt[q]]).tolist() == bits(r_sc[q, :r_cnt[q]]).tolist()
 
 
 @pytest.mark.parametrize("n,dim,metric,ef,k", [(1500, 128, 1, 128, 10), (1200, 768, 1, 128, 10), (1200, 256, 0, 100, 10),

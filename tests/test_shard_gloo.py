@@ -51,7 +51,14 @@ def _worker(rank, world, port, out_dir, n, dim, k, b):
         assert rc == orc.OK
         l_ids[qi, :oid.size] = oid.astype(np.int64); l_sc[qi, :oid.size] = osc; l_cnt[qi] = oid.size
     ex = shard.TopkExchange(world, b, k, "cpu")
-    g_ids, g_sc, g_cnt = ex.gather(torch.from_numpy(l_ids), torch.from_numpy(l_sc), torch.from_numpy(l_cnt))
+    assert ex.payload == shard.payload_bytes(b, k) and ex.payload % 8 == 0
+    if rank % 2:   # one rank writes its results straight into the payload views (what the GPU search does) ...
+        ex.ids.copy_(torch.from_numpy(l_ids)); ex.scores.copy_(torch.from_numpy(l_sc)); ex.counts.copy_(torch.from_numpy(l_cnt))
+        packed = ex.gather()
+    else:          # ... the other hands tensors over
+        packed = ex.gather(torch.from_numpy(l_ids), torch.from_numpy(l_sc), torch.from_numpy(l_cnt))
+    assert packed.numel() == world * ex.payload            # ONE all-gather carried ids, scores and counts
+    g_ids, g_sc, g_cnt = ex.gathered()
     m_ids, m_sc, m_cnt = fx.merge_topk_reference(g_ids.numpy().view(np.uint64), g_sc.numpy(), g_cnt.numpy(), k)
     ok = True
     for qi in range(b):

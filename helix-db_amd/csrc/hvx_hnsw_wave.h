@@ -554,19 +554,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     uint32_t cur = ix.entry;
 
     // ---------------- upper layers: search_layer_greedy (search.rs:169-224) ----------------
+    // The reference recomputes distance(query, current) when it enters a layer (search.rs:177-181): same inputs, same
+    // value, so it is computed once and carried down.  The upper-row pointer and the level of every candidate of a hop
+    // are requested together with the candidates' rows: the next hop's neighbour row is one round trip away instead of two.
+    float cur_d = 0.f;
+    bool have_d = false;
+    uint32_t cur_base = kSentinel, cur_level = 0;
+    if (ix.max_layer >= 1) {
+        cur_base = ix.up_base[cur];
+        cur_level = ix.level[cur];
+    }
     for (uint32_t layer = ix.max_layer; layer >= 1; --layer) {
         V.clear(lane); // fresh visited set per layer
-        float cur_d = score_one(cur);
-        if (!score_valid(cur_d)) bad_score = true;
+        if (!have_d) {
+            cur_d = score_one(cur);
+            have_d = true;
+            if (!score_valid(cur_d)) bad_score = true;
+        }
         V.insert(cur, lane == 0, lane);
         while (!bad_score) {
             uint32_t nid = kSentinel;
-            const uint32_t base_row = ix.up_base[cur];
-            if (base_row != kSentinel && ix.level[cur] >= layer && (uint32_t)lane < ix.su)
-                nid = ix.up[(size_t)(base_row + layer - 1) * ix.su + (uint32_t)lane];
+            if (cur_base != kSentinel && cur_level >= layer && (uint32_t)lane < ix.su)
+                nid = ix.up[(size_t)(cur_base + layer - 1) * ix.su + (uint32_t)lane];
             uint32_t deg;
             const uint32_t nf = frontier_from(nid, deg);
             if (nf == 0) break;
+            const uint32_t fnode = (uint32_t)lane < nf ? fr_id[lane] : cur;
+            const uint32_t f_base = ix.up_base[fnode];
+            const uint32_t f_level = ix.level[fnode];
             score_frontier(nf);
             // sequential `if distance < current_dist` over the row == first minimum, if it improves
             float d = (uint32_t)lane < nf ? fr_d[lane] : inf;
@@ -576,8 +591,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             const uint32_t m = wave_umin(__float_as_uint(d)); // scores are >= 0: bit order == value order
             const float mf = __uint_as_float(m);
             if (!(mf < cur_d)) break;
-            const unsigned long long eq = __ballot((uint32_t)lane < nf && d == mf);
-            cur = fr_id[__builtin_ctzll(eq)];
+            const uint32_t w = (uint32_t)__builtin_ctzll(__ballot((uint32_t)lane < nf && d == mf));
+            cur = __builtin_amdgcn_readlane(fnode, w);
+            cur_base = __builtin_amdgcn_readlane(f_base, w);
+            cur_level = __builtin_amdgcn_readlane(f_level, w);
             cur_d = mf;
             __syncthreads();
         }
@@ -628,7 +645,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
     if (!bad_score) {
         V.clear(lane);
-        float d0 = score_one(cur);
+        float d0 = have_d ? cur_d : score_one(cur); // search.rs:500-512: the same distance once more
         st_dc = 1;
         if (!score_valid(d0)) bad_score = true;
         V.insert(cur, lane == 0, lane);

@@ -613,6 +613,19 @@ int hvx::flat_scan_device(hvx_index *ix, const float *d_queries, uint32_t b, uin
         if (d_subset) return fail(HVX_ERR_UNSUPPORTED, "restricted scans over bf16 / fp8 rows are not built yet");
         return flat_mfma_device(ix, d_queries, b, k, d_ids, d_scores, d_counts, d_status, timed);
     }
+    // f32 rows, whole-corpus scan, dim >= 256 (below that the top-(m+1) selection over the score matrix outweighs the
+    // contraction) and enough work (b x rows x dim >= 2^33 MACs) to amortise the extra passes: candidates on MFMA (rows split into bf16 hi + lo on
+    // the fly), exact re-rank, certificate; any query whose certificate is not reached sends the batch to the exact VALU scan
+    {
+        const DevIndex &d = ix->dev;
+        const uint32_t nk = d.dim >> 5;
+        const bool shape = d.dim % 32u == 0u && d.ld == d.dim && d.dim_main == d.dim && d.fkernel == kKernelAvxFma &&
+                           (nk == 4 || nk == 8 || nk == 16 || nk == 24 || nk == 32 || nk == 48) && (d.metric == kL2 || d.metric == kCosine);
+        if (!d_subset && shape && d.dim >= 256 && k <= 511 && (uint64_t)b * n_rows * d.dim >= (1ull << 33) && !getenv("HVX_FLAT_VALU")) {
+            const int rc = flat_mfma_device(ix, d_queries, b, k, d_ids, d_scores, d_counts, d_status, timed);
+            if (rc != -1) return rc;
+        }
+    }
     // chunk the scan so the distance workspace stays <= 256 MiB
     uint32_t chunk = 65536;
     while ((size_t)chunk * b * 4 > (256u << 20) && chunk > 256) chunk >>= 1;

@@ -15,7 +15,8 @@
 //      summation order (the same gather/FMA code as the HNSW kernel), sorts by (score, id), keeps k;
 //   5. certificate: every row that was NOT re-scored has approximate score >= t (the (m+1)-th), hence a
 //      reference-order score >= t - E; if the k-th exact score is < t - E the answer is provably the
-//      exact scan's.  E bounds the bf16 split residual plus the f32 accumulation error of both orders.
+//      exact scan's.  E bounds the bf16 split residual plus the f32 accumulation error of both orders
+//      (2e-5 + 12 dim 2^-24, relative to (|q|^2 + max|x|^2)/2 for L2, absolute for cosine).
 //      Queries that fail are re-run with m = 1023; if that fails too they are reported, never guessed.
 #include <hip/hip_runtime.h>
 
@@ -34,6 +35,8 @@ using namespace hvx;
     } while (0)
 
 namespace hvx {
+
+constexpr int HVX_MFMA_FALLBACK = -1; // flat_mfma_device over f32 rows: certificate not reached, run the exact VALU scan
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(64) void split_queries_kernel(const float *q, uint3
         if (!f32_is_finite(v)) v = 0.f; // rejected queries are masked by their status; keep the GEMM finite
         const uint16_t h = f32_to_bf16_rne(v);
         const float res = v - bf16_to_f32(h);
-        const uint32_t s = fp8_layout ? fp8_slot_of(i) : bf16_slot_of(i);
+        const uint32_t s = fp8_layout == 2u ? i : (fp8_layout ? fp8_slot_of(i) : bf16_slot_of(i)); // 2: f32 rows, plain order
         qhi[(size_t)r * dim + s] = h;
         qlo[(size_t)r * dim + s] = f32_to_bf16_rne(res);
         acc += (double)v * (double)v;
@@ -87,10 +90,14 @@ struct MfmaArgs {
     uint32_t chunk_ld;
 };
 
-template <bool FP8>
+// KIND: 0 = bf16 rows, 1 = fp8 rows, 2 = f32 rows (split into bf16 hi + lo on the way into LDS: acc += q_hi.x_hi +
+// q_lo.x_hi + q_hi.x_lo; the dropped q_lo.x_lo term is <= 2^-16 |q||x| and is covered by the certificate's bound)
+template <int KIND>
 __global__ __launch_bounds__(256) void flat_mfma_bf16_kernel(MfmaArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * kBM * kLdsStride]; // A_hi | A_lo | B
+    constexpr bool FP8 = KIND == 1, F32 = KIND == 2;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[(F32 ? 4 : 3) * kBM * kLdsStride]; // A_hi | A_lo | B (| B_lo)
     unsigned char *sAh = lds, *sAl = lds + kBM * kLdsStride, *sB = lds + 2 * kBM * kLdsStride;
+    unsigned char *sBl = lds + (F32 ? 3 : 2) * kBM * kLdsStride;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1; // 64x64 sub-tile of the wave
     const uint32_t q0 = blockIdx.y * kBM, r0 = blockIdx.x * kBN;
@@ -111,6 +118,22 @@ __global__ __launch_bounds__(256) void flat_mfma_bf16_kernel(MfmaArgs a) {
     if (rowF >= a.nrows) rowF = a.nrows - 1;
     const uint8_t *gF = reinterpret_cast<const uint8_t *>(a.rows) + ((size_t)a.row0 + rowF) * a.dim + (tid & 1) * 16;
     const int soF = (tid >> 1) * kLdsStride + (tid & 1) * 32;
+    // f32 rows: 8 consecutive floats (two 16-byte loads) of tile rows sr and sr+64 per thread and stage
+    const float *gX0 = reinterpret_cast<const float *>(a.rows) + ((size_t)a.row0 + rowB0) * a.dim + sc * 8;
+    const float *gX1 = reinterpret_cast<const float *>(a.rows) + ((size_t)a.row0 + rowB1) * a.dim + sc * 8;
+    auto split8 = [](const float4 &u, const float4 &v, uint4 &hi, uint4 &lo) { // 8 f32 -> 8 bf16 hi + 8 bf16 residuals
+        const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+        uint32_t h[8], l[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint16_t hb = f32_to_bf16_rne(x[i]);
+            h[i] = hb;
+            l[i] = f32_to_bf16_rne(x[i] - bf16_to_f32(hb));
+        }
+        hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+        lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+    };
+    float4 pX0a, pX0b, pX1a, pX1b;
     auto widen = [](uint32_t w, uint32_t &lo, uint32_t &hi) { // 4 fp8 -> 4 bf16 (two words)
         typedef float f2 __attribute__((ext_vector_type(2)));
         const f2 a01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false), a23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);
@@ -130,14 +153,23 @@ __global__ __launch_bounds__(256) void flat_mfma_bf16_kernel(MfmaArgs a) {
     const int fr = lane & 31, fk = (lane >> 5) * 16; // byte offset of the lane's 8 bf16 inside a 16-deep step
     uint4 pAh0 = *reinterpret_cast<const uint4 *>(gAh0), pAh1 = *reinterpret_cast<const uint4 *>(gAh1);
     uint4 pAl0 = *reinterpret_cast<const uint4 *>(gAl0), pAl1 = *reinterpret_cast<const uint4 *>(gAl1);
-    uint4 pB0, pB1;
-    if (FP8) { pB0 = *reinterpret_cast<const uint4 *>(gF); pB1 = pB0; }
+    uint4 pB0 = make_uint4(0, 0, 0, 0), pB1 = pB0;
+    if (F32) {
+        pX0a = *reinterpret_cast<const float4 *>(gX0); pX0b = *reinterpret_cast<const float4 *>(gX0 + 4);
+        pX1a = *reinterpret_cast<const float4 *>(gX1); pX1b = *reinterpret_cast<const float4 *>(gX1 + 4);
+    } else if (FP8) { pB0 = *reinterpret_cast<const uint4 *>(gF); pB1 = pB0; }
     else { pB0 = *reinterpret_cast<const uint4 *>(gB0); pB1 = *reinterpret_cast<const uint4 *>(gB1); }
     for (uint32_t k0 = 0; k0 < a.dim; k0 += kBK) {
         __syncthreads(); // previous stage fully consumed
         *reinterpret_cast<uint4 *>(sAh + so0) = pAh0; *reinterpret_cast<uint4 *>(sAh + so1) = pAh1;
         *reinterpret_cast<uint4 *>(sAl + so0) = pAl0; *reinterpret_cast<uint4 *>(sAl + so1) = pAl1;
-        if (FP8) {
+        if (F32) {
+            uint4 h0, l0, h1, l1;
+            split8(pX0a, pX0b, h0, l0);
+            split8(pX1a, pX1b, h1, l1);
+            *reinterpret_cast<uint4 *>(sB + so0) = h0; *reinterpret_cast<uint4 *>(sB + so1) = h1;
+            *reinterpret_cast<uint4 *>(sBl + so0) = l0; *reinterpret_cast<uint4 *>(sBl + so1) = l1;
+        } else if (FP8) {
             uint4 w0, w1;
             widen(pB0.x, w0.x, w0.y); widen(pB0.y, w0.z, w0.w); widen(pB0.z, w1.x, w1.y); widen(pB0.w, w1.z, w1.w);
             *reinterpret_cast<uint4 *>(sB + soF) = w0; *reinterpret_cast<uint4 *>(sB + soF + 16) = w1;
@@ -149,12 +181,15 @@ __global__ __launch_bounds__(256) void flat_mfma_bf16_kernel(MfmaArgs a) {
             const uint32_t kn = k0 + kBK;
             pAh0 = *reinterpret_cast<const uint4 *>(gAh0 + kn); pAh1 = *reinterpret_cast<const uint4 *>(gAh1 + kn);
             pAl0 = *reinterpret_cast<const uint4 *>(gAl0 + kn); pAl1 = *reinterpret_cast<const uint4 *>(gAl1 + kn);
-            if (FP8) pB0 = *reinterpret_cast<const uint4 *>(gF + kn);
+            if (F32) {
+                pX0a = *reinterpret_cast<const float4 *>(gX0 + kn); pX0b = *reinterpret_cast<const float4 *>(gX0 + kn + 4);
+                pX1a = *reinterpret_cast<const float4 *>(gX1 + kn); pX1b = *reinterpret_cast<const float4 *>(gX1 + kn + 4);
+            } else if (FP8) pB0 = *reinterpret_cast<const uint4 *>(gF + kn);
             else { pB0 = *reinterpret_cast<const uint4 *>(gB0 + kn); pB1 = *reinterpret_cast<const uint4 *>(gB1 + kn); }
         }
 #pragma unroll
         for (int kk = 0; kk < kBK / 16; ++kk) {
-            bf16x8 fah[2], fal[2], fb[2];
+            bf16x8 fah[2], fal[2], fb[2], fbl[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int off = (wm * 64 + i * 32 + fr) * kLdsStride + kk * 32 + fk;
@@ -165,6 +200,7 @@ __global__ __launch_bounds__(256) void flat_mfma_bf16_kernel(MfmaArgs a) {
             for (int jn = 0; jn < 2; ++jn) {
                 const int off = (wn * 64 + jn * 32 + fr) * kLdsStride + kk * 32 + fk;
                 fb[jn] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sB + off));
+                if (F32) fbl[jn] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sBl + off));
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -172,6 +208,7 @@ __global__ __launch_bounds__(256) void flat_mfma_bf16_kernel(MfmaArgs a) {
                 for (int jn = 0; jn < 2; ++jn) {
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fb[jn], acc[i][jn], 0, 0, 0);
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fb[jn], acc[i][jn], 0, 0, 0);
+                    if (F32) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbl[jn], acc[i][jn], 0, 0, 0);
                 }
         }
     }
@@ -272,8 +309,9 @@ __device__ __forceinline__ void score_rows_fp8(const DevIndex &ix, const float *
     }
 }
 
-template <uint32_t METRIC, int NK, bool FP8>
+template <uint32_t METRIC, int NK, int KIND> // KIND as in flat_mfma_bf16_kernel: 0 bf16, 1 fp8, 2 f32 rows
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void rerank_bf16_kernel(RerankArgs a) {
+    constexpr bool FP8 = KIND == 1, BFR = KIND != 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int P = 2; // 16 rows per pass
     const DevIndex &ix = a.ix;
@@ -310,9 +348,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if (FP8) {
             score_rows_fp8<METRIC, NK, P>(ix, qs, nd, slot, qhdr, qglobal, o);
         } else {
-            Gather<NK, P, true> g;
-            gather_issue<NK, P, true, P, METRIC == kCosine>(ix, nd, slot, g);
-            gather_consume<METRIC, NK, P, true>(ix, qs, g, nd, slot, qhdr, qglobal, o);
+            Gather<NK, P, BFR> g;
+            gather_issue<NK, P, BFR, P, METRIC == kCosine>(ix, nd, slot, g);
+            gather_consume<METRIC, NK, P, BFR>(ix, qs, g, nd, slot, qhdr, qglobal, o);
         }
 #pragma unroll
         for (int p = 0; p < P; ++p) {
@@ -355,7 +393,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         uint32_t ok = 1u;
         if (nc > a.m) {
             const float t = a.cand_scores[(size_t)q * a.kc + (nc - 1)];
-            const float e = METRIC == kL2 ? 1.0e-3f * 0.5f * (a.qn2[q] + a.xmax2) : 1.0e-3f;
+            // worst-case |approximate - reference-order score| relative to (|q|^2 + |x|^2)/2 (L2) resp. absolute (cosine):
+            // hi/lo split residuals (<= 2^-17 each way, the dropped lo.lo term and the f32 roundings of the norms:
+            // 2e-5 in all) + f32 accumulation over K = dim terms in BOTH summation orders (6 K 2^-24 worst case),
+            // the latter doubled for whatever order the matrix core accumulates in.  K = 1536 -> 1.1e-3, K = 128 -> 1.1e-4.
+            const float erel = 2.0e-5f + 12.0f * (float)(NK * 32) * 5.9604645e-8f;
+            const float e = METRIC == kL2 ? erel * 0.5f * (a.qn2[q] + a.xmax2) : erel;
             const float kth = outn ? ss[outn - 1] : inf;
             ok = (outn == a.k && kth < t - e) ? 1u : 0u;
         }
@@ -369,8 +412,9 @@ static hipError_t launch_rerank(const RerankArgs &a, uint32_t b, hipStream_t s) 
     switch (a.ix.dim >> 5) {
 #define HVX_RR(N)                                                                                                   \
     case N:                                                                                                         \
-        if (a.ix.dtype == HVX_FP8_E4M3) hipLaunchKernelGGL((rerank_bf16_kernel<METRIC, N, true>), dim3(b), dim3(64), lds, s, a); \
-        else hipLaunchKernelGGL((rerank_bf16_kernel<METRIC, N, false>), dim3(b), dim3(64), lds, s, a);             \
+        if (a.ix.dtype == HVX_FP8_E4M3) hipLaunchKernelGGL((rerank_bf16_kernel<METRIC, N, 1>), dim3(b), dim3(64), lds, s, a); \
+        else if (a.ix.dtype == HVX_F32) hipLaunchKernelGGL((rerank_bf16_kernel<METRIC, N, 2>), dim3(b), dim3(64), lds, s, a);  \
+        else hipLaunchKernelGGL((rerank_bf16_kernel<METRIC, N, 0>), dim3(b), dim3(64), lds, s, a);                  \
         break;
         HVX_RR(4) HVX_RR(8) HVX_RR(16) HVX_RR(24) HVX_RR(32) HVX_RR(48)
 #undef HVX_RR
@@ -410,9 +454,18 @@ int flat_mfma_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t
         if ((rc = ix->dalloc((void **)&ix->m_cert, (size_t)bpad * 4))) return rc;
         ix->cap_qsplit = (size_t)bpad * d.dim;
     }
-    const bool fp8 = d.dtype == HVX_FP8_E4M3;
+    const bool fp8 = d.dtype == HVX_FP8_E4M3, f32 = d.dtype == HVX_F32;
+    if (f32 && !ix->m_rowterm) { // |x|^2 per row and its maximum: once per index, on first use
+        if ((rc = ix->dalloc((void **)&ix->m_rowterm, std::max<size_t>(n, 1) * 4))) return rc;
+        std::vector<float> h_n2(n);
+        HIP_TRY(launch_f32_row_norm2(d.vec, n, d.ld, d.dim, ix->m_rowterm, ix->stream));
+        HIP_TRY(hipMemcpyAsync(h_n2.data(), ix->m_rowterm, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipStreamSynchronize(ix->stream));
+        ix->m_xmax2 = 0.f;
+        for (float v : h_n2) ix->m_xmax2 = std::max(ix->m_xmax2, v);
+    }
     hipLaunchKernelGGL(split_queries_kernel, dim3(bpad), dim3(64), 0, ix->stream, d_queries, b, bpad, d.dim, ix->m_qhi, ix->m_qlo, ix->m_qn2,
-                       fp8 ? 1u : 0u);
+                       f32 ? 2u : (fp8 ? 1u : 0u));
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ix->ev0, ix->stream));
     uint32_t m = std::max<uint32_t>(64u, 2u * k);
@@ -428,14 +481,17 @@ int flat_mfma_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t
         fa.n_rows = n; fa.dist = ix->f_dist; fa.chunk_ld = chunk; fa.b = b; fa.k = kc;
         fa.top_scores = ix->f_top_s; fa.top_ids = ix->f_top_i; fa.top_counts = ix->f_top_c;
         MfmaArgs ma;
-        ma.qhi = ix->m_qhi; ma.qlo = ix->m_qlo; ma.rows = fp8 ? (const void *)d.vec8 : (const void *)d.vecb; ma.rowscale = d.rowscale;
+        ma.qhi = ix->m_qhi; ma.qlo = ix->m_qlo;
+        ma.rows = f32 ? (const void *)d.vec : (fp8 ? (const void *)d.vec8 : (const void *)d.vecb);
+        ma.rowscale = d.rowscale;
         ma.rowterm = d.metric == kL2 ? ix->m_rowterm : d.hdr;
         ma.qn2 = ix->m_qn2; ma.dim = d.dim; ma.b = b; ma.metric = d.metric; ma.dist = ix->f_dist; ma.chunk_ld = chunk;
         for (uint32_t r0 = 0; r0 < n; r0 += chunk) {
             const uint32_t rows = std::min(chunk, n - r0);
             ma.row0 = r0; ma.nrows = rows;
-            if (fp8) hipLaunchKernelGGL(flat_mfma_bf16_kernel<true>, dim3((rows + kBN - 1) / kBN, bpad / kBM), dim3(256), 0, ix->stream, ma);
-            else hipLaunchKernelGGL(flat_mfma_bf16_kernel<false>, dim3((rows + kBN - 1) / kBN, bpad / kBM), dim3(256), 0, ix->stream, ma);
+            if (f32) hipLaunchKernelGGL(flat_mfma_bf16_kernel<2>, dim3((rows + kBN - 1) / kBN, bpad / kBM), dim3(256), 0, ix->stream, ma);
+            else if (fp8) hipLaunchKernelGGL(flat_mfma_bf16_kernel<1>, dim3((rows + kBN - 1) / kBN, bpad / kBM), dim3(256), 0, ix->stream, ma);
+            else hipLaunchKernelGGL(flat_mfma_bf16_kernel<0>, dim3((rows + kBN - 1) / kBN, bpad / kBM), dim3(256), 0, ix->stream, ma);
             HIP_TRY(hipGetLastError());
             fa.row0 = r0; fa.rows = rows;
             HIP_TRY(launch_flat_select(fa, ix->stream));
@@ -454,6 +510,7 @@ int flat_mfma_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t
         for (uint32_t i = 0; i < b; ++i)
             if (!cert[i]) { if (!failed) first = i; ++failed; }
         if (!failed) return HVX_OK;
+        if (f32) return HVX_MFMA_FALLBACK; // f32 rows have an exact VALU scan to fall back to: never widen, never guess
         if (m >= 1023u)
             return fail(HVX_ERR_INVARIANT, "exact-scan certificate failed for %u queries (first %u): more than 1023 rows within the "
                         "error bound of the k-th score", failed, first);

@@ -910,3 +910,50 @@ def test_duplicate_vectors_ties_are_broken_by_id_in_both_arms(orc, hv, metric):
     assert_hnsw_equal(orc, hv, oix, gix, q, 10, 100)
     assert_params_equal(orc, hv, oix, gix, q, hv.SearchParams.new(10), cfg)
     assert_params_equal(orc, hv, oix, gix, q, hv.SearchParams.new(25).with_ef(48), cfg)
+
+
+@pytest.mark.parametrize("metric,dim,n,k,b", [(1, 512, 40000, 10, 512), (0, 256, 80000, 25, 512), (1, 768, 60000, 100, 500)])
+def test_f32_exact_scan_on_matrix_cores_is_bit_exact(orc, hv, monkeypatch, metric, dim, n, k, b):
+    """Whole-corpus exact scans over f32 rows (dim >= 256) with enough work (b x n x dim >= 2^33) generate their candidates on the matrix
+    cores (rows split into bf16 hi + lo on the fly), re-rank them in the reference's summation order and certify the
+    result; it must equal the oracle's exact scan -- and the VALU exact-scan kernel -- bit for bit."""
+    rng = np.random.default_rng(dim + n)
+    centers = rng.standard_normal((32, dim)).astype(np.float32)
+    data = (centers[rng.integers(0, 32, n)] + 0.5 * rng.standard_normal((n, dim))).astype(np.float32)
+    data[7] = data[3]  # exact duplicate row: tie broken by id
+    ids = np.arange(n, dtype=np.uint64) + 11
+    gix = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=metric, node_ids=ids, vectors=data,
+                                              l0_offsets=np.zeros(n + 1, np.uint64), l0_neighbors=np.zeros(0, np.uint64),
+                                              max_batch=512)
+    q = (centers[rng.integers(0, 32, b)] + 0.5 * rng.standard_normal((b, dim))).astype(np.float32)
+    q[0] = data[3]
+    gid, gsc, gcnt, stats = gix.flat_search_batch(q, k)
+    monkeypatch.setenv("HVX_FLAT_VALU", "1")
+    vid, vsc, vcnt, vstats = gix.flat_search_batch(q, k)
+    monkeypatch.delenv("HVX_FLAT_VALU")
+    assert gid.tolist() == vid.tolist() and bits(gsc).tolist() == bits(vsc).tolist() and gcnt.tolist() == vcnt.tolist()
+    print(f"f32 exact scan {b} x {n} x {dim}: MFMA path {stats['device_ms']:.3f} ms, VALU kernel {vstats['device_ms']:.3f} ms")
+    if dim == 768:
+        assert stats["device_ms"] < vstats["device_ms"]      # and that is the point of it
+    for qi in range(0, b, max(1, b // 24)):
+        rc, oid, osc = orc.flat_matrix(metric, data, q[qi], k, kernel=orc.K_AVX_FMA_HW)
+        assert rc == orc.OK and (gid[qi, :gcnt[qi]] - 11).tolist() == oid.tolist(), f"query {qi}"
+        assert bits(gsc[qi, :gcnt[qi]]).tolist() == bits(osc).tolist()
+
+
+def test_f32_exact_scan_falls_back_to_the_valu_kernel_on_dense_near_ties(orc, hv):
+    """5 000 rows within a few ulps of each other: no certificate can separate the k-th score from the rest, so the
+    batch must be answered by the exact VALU scan -- never by a guess, never by an error."""
+    rng = np.random.default_rng(8)
+    n, dim, b, k = 20000, 512, 1024, 10           # b x n x dim = 2^33.3: takes the matrix-core path first
+    base = rng.standard_normal(dim).astype(np.float32)
+    data = np.tile(base, (n, 1))
+    data[:, 0] += (np.arange(n) % 7).astype(np.float32) * np.float32(1e-6)
+    gix = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=hv.EUCLIDEAN, node_ids=np.arange(n, dtype=np.uint64),
+                                              vectors=data, l0_offsets=np.zeros(n + 1, np.uint64),
+                                              l0_neighbors=np.zeros(0, np.uint64), max_batch=b)
+    q = rng.standard_normal((b, dim)).astype(np.float32)
+    gid, gsc, gcnt, _ = gix.flat_search_batch(q, k)
+    for qi in (0, 17, 500, 1023):
+        rc, oid, osc = orc.flat_matrix(orc.L2SQ, data, q[qi], k, kernel=orc.K_AVX_FMA_HW)
+        assert gid[qi].tolist() == oid.tolist() and bits(gsc[qi]).tolist() == bits(osc).tolist()

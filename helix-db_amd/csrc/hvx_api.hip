@@ -61,6 +61,20 @@ float hvx::component_limit(uint32_t metric, uint32_t dim) {
     return rounded;
 }
 
+// rows of `words` 32-bit words: gather (dst[i] = src[idx[i]]) or scatter (dst[idx[i]] = src[i])
+__global__ void move_rows_kernel(const uint32_t *src, const uint32_t *idx, uint32_t *dst, uint32_t words, uint32_t n, uint32_t gather) {
+    const uint32_t i = blockIdx.x;
+    if (i >= n) return;
+    const size_t s0 = (size_t)(gather ? idx[i] : i) * words, d0 = (size_t)(gather ? i : idx[i]) * words;
+    for (uint32_t w = threadIdx.x; w < words; w += blockDim.x) dst[d0 + w] = src[s0 + w];
+}
+static hipError_t launch_move_rows(const uint32_t *src, const uint32_t *idx, uint32_t *dst, uint32_t words, uint32_t n, bool gather,
+                                   hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(move_rows_kernel, dim3(n), dim3(128), 0, s, src, idx, dst, words, n, gather ? 1u : 0u);
+    return hipGetLastError();
+}
+
 template <typename F> static void parallel_for(uint64_t n, F f) {
     unsigned nt = std::thread::hardware_concurrency();
     if (nt == 0) nt = 4;
@@ -624,8 +638,45 @@ int hvx::flat_scan_device(hvx_index *ix, const float *d_queries, uint32_t b, uin
         if (!d_subset && shape && d.dim >= 256 && k <= 511 && (uint64_t)b * n_rows * d.dim >= (1ull << 33) && !getenv("HVX_FLAT_VALU")) {
             const int rc = flat_mfma_device(ix, d_queries, b, k, d_ids, d_scores, d_counts, d_status, timed);
             if (rc != -1) return rc;
+            // certificate not reached for some queries: those -- and only those, unless they are many -- are answered
+            // by the exact VALU scan below; the rest of the batch keeps its certified rows
+            const std::vector<uint32_t> failed = ix->m_failed;
+            const uint32_t nf = (uint32_t)failed.size();
+            if (getenv("HVX_FLAT_DEBUG"))
+                fprintf(stderr, "[hvx flat] certificate not reached for %u of %u queries: exact VALU scan for %s\n", nf, b,
+                        nf * 4u <= b ? "those queries only" : "the whole batch");
+            if (nf * 4u <= b) {
+                const size_t dim = d.dim;
+                int r2;
+                if (nf > ix->cap_fb) {
+                    if ((r2 = ix->dalloc((void **)&ix->fb_idx, (size_t)nf * 4))) return r2;
+                    if ((r2 = ix->dalloc((void **)&ix->fb_q, (size_t)nf * dim * 4))) return r2;
+                    if ((r2 = ix->dalloc((void **)&ix->fb_ids, (size_t)nf * 1024 * 8))) return r2;
+                    if ((r2 = ix->dalloc((void **)&ix->fb_sc, (size_t)nf * 1024 * 4))) return r2;
+                    if ((r2 = ix->dalloc((void **)&ix->fb_cnt, (size_t)nf * 4))) return r2;
+                    if ((r2 = ix->dalloc((void **)&ix->fb_st, (size_t)nf * 4))) return r2;
+                    ix->cap_fb = nf;
+                }
+                HIP_TRY(hipMemcpyAsync(ix->fb_idx, failed.data(), (size_t)nf * 4, hipMemcpyHostToDevice, ix->stream));
+                HIP_TRY(hipStreamSynchronize(ix->stream)); // `failed` lives on this stack frame
+                HIP_TRY(launch_move_rows(reinterpret_cast<const uint32_t *>(d_queries), ix->fb_idx, reinterpret_cast<uint32_t *>(ix->fb_q),
+                                         (uint32_t)dim, nf, true, ix->stream));
+                if ((r2 = flat_scan_valu(ix, ix->fb_q, nf, k, nullptr, n_rows, ix->fb_ids, ix->fb_sc, ix->fb_cnt, ix->fb_st, timed, false))) return r2;
+                HIP_TRY(launch_move_rows(reinterpret_cast<const uint32_t *>(ix->fb_ids), ix->fb_idx, reinterpret_cast<uint32_t *>(d_ids), 2 * k, nf, false, ix->stream));
+                HIP_TRY(launch_move_rows(reinterpret_cast<const uint32_t *>(ix->fb_sc), ix->fb_idx, reinterpret_cast<uint32_t *>(d_scores), k, nf, false, ix->stream));
+                HIP_TRY(launch_move_rows(ix->fb_cnt, ix->fb_idx, d_counts, 1, nf, false, ix->stream));
+                if (d_status) HIP_TRY(launch_move_rows(ix->fb_st, ix->fb_idx, d_status, 1, nf, false, ix->stream));
+                if (timed) HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
+                return HVX_OK;
+            }
         }
     }
+    return flat_scan_valu(ix, d_queries, b, k, d_subset, n_rows, d_ids, d_scores, d_counts, d_status, timed, true);
+}
+
+// the exact VALU scan (flat_distance_kernel + flat_select_kernel + finish); record_begin=false keeps an earlier ev0
+int hvx::flat_scan_valu(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, const uint32_t *d_subset, uint32_t n_rows,
+                        uint64_t *d_ids, float *d_scores, uint32_t *d_counts, uint32_t *d_status, bool timed, bool record_begin) {
     // chunk the scan so the distance workspace stays <= 256 MiB
     uint32_t chunk = 65536;
     while ((size_t)chunk * b * 4 > (256u << 20) && chunk > 256) chunk >>= 1;
@@ -634,7 +685,7 @@ int hvx::flat_scan_device(hvx_index *ix, const float *d_queries, uint32_t b, uin
     int rc = ix->flat_scratch(b, k, chunk);
     if (rc) return rc;
     HIP_TRY(launch_validate_queries(ix->dev, d_queries, b, ix->limit, ix->d_qstatus, ix->d_qhdr, ix->stream));
-    if (timed) HIP_TRY(hipEventRecord(ix->ev0, ix->stream));
+    if (timed && record_begin) HIP_TRY(hipEventRecord(ix->ev0, ix->stream));
     HIP_TRY(hipMemsetAsync(ix->f_top_c, 0, (size_t)b * 4, ix->stream));
     FlatArgs a;
     a.ix = ix->dev;

@@ -510,7 +510,12 @@ int flat_mfma_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t
         for (uint32_t i = 0; i < b; ++i)
             if (!cert[i]) { if (!failed) first = i; ++failed; }
         if (!failed) return HVX_OK;
-        if (f32) return HVX_MFMA_FALLBACK; // f32 rows have an exact VALU scan to fall back to: never widen, never guess
+        if (f32) { // f32 rows have an exact VALU scan to fall back to: never widen, never guess
+            ix->m_failed.clear();
+            for (uint32_t i = 0; i < b; ++i)
+                if (!cert[i]) ix->m_failed.push_back(i);
+            return HVX_MFMA_FALLBACK;
+        }
         if (m >= 1023u)
             return fail(HVX_ERR_INVARIANT, "exact-scan certificate failed for %u queries (first %u): more than 1023 rows within the "
                         "error bound of the k-th score", failed, first);

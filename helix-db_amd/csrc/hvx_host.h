@@ -41,6 +41,12 @@ struct hvx_index {
     float *f_dist = nullptr, *f_top_s = nullptr;
     uint32_t *f_top_i = nullptr, *f_top_c = nullptr, *f_subset = nullptr;
     size_t cap_dist = 0, cap_top = 0, cap_subset = 0;
+    // per-query fallback of the f32 matrix-core exact scan (queries whose certificate was not reached)
+    std::vector<uint32_t> m_failed;
+    uint32_t *fb_idx = nullptr, *fb_cnt = nullptr, *fb_st = nullptr;
+    float *fb_q = nullptr, *fb_sc = nullptr;
+    uint64_t *fb_ids = nullptr;
+    uint32_t cap_fb = 0;
     uint32_t *pf_blocks = nullptr;   // fused prefilter: per-block candidate counts / scan
     uint32_t cap_pf_blocks = 0;
     uint32_t cap_topc = 0;
@@ -88,6 +94,8 @@ float component_limit(uint32_t metric, uint32_t dim);
 int flat_scan_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, const uint32_t *d_subset,
                      uint32_t n_rows, uint64_t *d_ids, float *d_scores, uint32_t *d_counts, uint32_t *d_status,
                      bool timed);
+int flat_scan_valu(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, const uint32_t *d_subset, uint32_t n_rows,
+                   uint64_t *d_ids, float *d_scores, uint32_t *d_counts, uint32_t *d_status, bool timed, bool record_begin);
 int flat_mfma_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, uint64_t *d_ids, float *d_scores,
                      uint32_t *d_counts, uint32_t *d_status, bool timed);
 hipError_t launch_bf16_row_norm2(const uint16_t *rows, uint32_t n, uint32_t dim, float *out, hipStream_t s);

@@ -957,3 +957,31 @@ def test_f32_exact_scan_falls_back_to_the_valu_kernel_on_dense_near_ties(orc, hv
     for qi in (0, 17, 500, 1023):
         rc, oid, osc = orc.flat_matrix(orc.L2SQ, data, q[qi], k, kernel=orc.K_AVX_FMA_HW)
         assert gid[qi].tolist() == oid.tolist() and bits(gsc[qi]).tolist() == bits(osc).tolist()
+
+
+def test_f32_exact_scan_answers_only_the_uncertified_queries_with_the_valu_kernel(orc, hv, monkeypatch, capfd):
+    """A corpus with one blob of 3 000 near-identical rows: queries that land in the blob cannot be certified and are
+    re-answered (alone) by the exact VALU scan, the other ~1 000 queries of the batch keep their matrix-core result."""
+    rng = np.random.default_rng(21)
+    n, dim, b, k = 20000, 512, 1024, 10
+    centers = rng.standard_normal((16, dim)).astype(np.float32)
+    data = (centers[rng.integers(0, 16, n)] + 0.5 * rng.standard_normal((n, dim))).astype(np.float32)
+    blob = rng.standard_normal(dim).astype(np.float32) * np.float32(3.0)
+    data[5000:8000] = blob
+    data[5000:8000, 0] += (np.arange(3000) % 11).astype(np.float32) * np.float32(1e-6)
+    gix = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=hv.EUCLIDEAN, node_ids=np.arange(n, dtype=np.uint64),
+                                              vectors=data, l0_offsets=np.zeros(n + 1, np.uint64),
+                                              l0_neighbors=np.zeros(0, np.uint64), max_batch=b)
+    q = (centers[rng.integers(0, 16, b)] + 0.5 * rng.standard_normal((b, dim))).astype(np.float32)
+    hard = [3, 100, 511, 512, 777, 1023]
+    for i in hard:
+        q[i] = blob + np.float32(0.01) * rng.standard_normal(dim).astype(np.float32)
+    monkeypatch.setenv("HVX_FLAT_DEBUG", "1")
+    gid, gsc, gcnt, _ = gix.flat_search_batch(q, k)
+    err = capfd.readouterr().err
+    assert "certificate not reached for 6 of 1024 queries: exact VALU scan for those queries only" in err, err
+    for qi in hard + [0, 1, 99, 640, 1022]:
+        rc, oid, osc = orc.flat_matrix(orc.L2SQ, data, q[qi], k, kernel=orc.K_AVX_FMA_HW)
+        assert gcnt[qi] == k and gid[qi].tolist() == oid.tolist(), f"query {qi}"
+        assert bits(gsc[qi]).tolist() == bits(osc).tolist()
+    assert all(5000 <= int(x) < 8000 for x in gid[3])

@@ -623,10 +623,8 @@ int hvx::flat_scan_device(hvx_index *ix, const float *d_queries, uint32_t b, uin
                           uint32_t *d_status, bool timed) {
     if (k == 0) return fail(HVX_ERR_K_RANGE, "result count must be non-zero");
     if (k > 1024) return fail(HVX_ERR_UNSUPPORTED, "flat scan supports k <= 1024");
-    if (ix->dev.dtype != HVX_F32) {
-        if (d_subset) return fail(HVX_ERR_UNSUPPORTED, "restricted scans over bf16 / fp8 rows are not built yet");
-        return flat_mfma_device(ix, d_queries, b, k, d_ids, d_scores, d_counts, d_status, timed);
-    }
+    if (ix->dev.dtype != HVX_F32) // bf16 / fp8 rows: the matrix-core pipeline, over all rows or over the restricted row list
+        return flat_mfma_device(ix, d_queries, b, k, d_subset, n_rows, d_ids, d_scores, d_counts, d_status, timed);
     // f32 rows, whole-corpus scan, dim >= 256 (below that the top-(m+1) selection over the score matrix outweighs the
     // contraction) and enough work (b x rows x dim >= 2^33 MACs) to amortise the extra passes: candidates on MFMA (rows split into bf16 hi + lo on
     // the fly), exact re-rank, certificate; any query whose certificate is not reached sends the batch to the exact VALU scan
@@ -635,8 +633,8 @@ int hvx::flat_scan_device(hvx_index *ix, const float *d_queries, uint32_t b, uin
         const uint32_t nk = d.dim >> 5;
         const bool shape = d.dim % 32u == 0u && d.ld == d.dim && d.dim_main == d.dim && d.fkernel == kKernelAvxFma &&
                            (nk == 4 || nk == 8 || nk == 16 || nk == 24 || nk == 32 || nk == 48) && (d.metric == kL2 || d.metric == kCosine);
-        if (!d_subset && shape && d.dim >= 256 && k <= 511 && (uint64_t)b * n_rows * d.dim >= (1ull << 33) && !getenv("HVX_FLAT_VALU")) {
-            const int rc = flat_mfma_device(ix, d_queries, b, k, d_ids, d_scores, d_counts, d_status, timed);
+        if (shape && d.dim >= 256 && k <= 511 && (uint64_t)b * n_rows * d.dim >= (1ull << 33) && !getenv("HVX_FLAT_VALU")) {
+            const int rc = flat_mfma_device(ix, d_queries, b, k, d_subset, n_rows, d_ids, d_scores, d_counts, d_status, timed);
             if (rc != -1) return rc;
             // certificate not reached for some queries: those -- and only those, unless they are many -- are answered
             // by the exact VALU scan below; the rest of the batch keeps its certified rows
@@ -661,7 +659,7 @@ int hvx::flat_scan_device(hvx_index *ix, const float *d_queries, uint32_t b, uin
                 HIP_TRY(hipStreamSynchronize(ix->stream)); // `failed` lives on this stack frame
                 HIP_TRY(launch_move_rows(reinterpret_cast<const uint32_t *>(d_queries), ix->fb_idx, reinterpret_cast<uint32_t *>(ix->fb_q),
                                          (uint32_t)dim, nf, true, ix->stream));
-                if ((r2 = flat_scan_valu(ix, ix->fb_q, nf, k, nullptr, n_rows, ix->fb_ids, ix->fb_sc, ix->fb_cnt, ix->fb_st, timed, false))) return r2;
+                if ((r2 = flat_scan_valu(ix, ix->fb_q, nf, k, d_subset, n_rows, ix->fb_ids, ix->fb_sc, ix->fb_cnt, ix->fb_st, timed, false))) return r2;
                 HIP_TRY(launch_move_rows(reinterpret_cast<const uint32_t *>(ix->fb_ids), ix->fb_idx, reinterpret_cast<uint32_t *>(d_ids), 2 * k, nf, false, ix->stream));
                 HIP_TRY(launch_move_rows(reinterpret_cast<const uint32_t *>(ix->fb_sc), ix->fb_idx, reinterpret_cast<uint32_t *>(d_scores), k, nf, false, ix->stream));
                 HIP_TRY(launch_move_rows(ix->fb_cnt, ix->fb_idx, d_counts, 1, nf, false, ix->stream));

@@ -81,6 +81,7 @@ constexpr int kLdsStride = kBK * 2 + 16;      // bytes per tile row: 64 B of dat
 
 struct MfmaArgs {
     const uint16_t *qhi, *qlo; // [bpad][dim]
+    const uint32_t *subset;    // optional: scan position -> row (restricted scans); NULL = the rows themselves
     const void *rows;          // [n][dim] bf16, or fp8 codes
     const float *rowscale;     // [n] fp8 only
     const float *rowterm;      // [n]: |x|^2 (L2) or |x| (cosine)
@@ -109,18 +110,21 @@ __global__ __launch_bounds__(256) void flat_mfma_bf16_kernel(MfmaArgs a) {
     if (rowB1 >= a.nrows) rowB1 = a.nrows - 1;
     const uint16_t *gAh0 = a.qhi + (size_t)rowA0 * a.dim + sc * 8, *gAh1 = a.qhi + (size_t)rowA1 * a.dim + sc * 8;
     const uint16_t *gAl0 = a.qlo + (size_t)rowA0 * a.dim + sc * 8, *gAl1 = a.qlo + (size_t)rowA1 * a.dim + sc * 8;
-    const uint16_t *gB0 = reinterpret_cast<const uint16_t *>(a.rows) + ((size_t)a.row0 + rowB0) * a.dim + sc * 8;
-    const uint16_t *gB1 = reinterpret_cast<const uint16_t *>(a.rows) + ((size_t)a.row0 + rowB1) * a.dim + sc * 8;
+    // restricted scans walk a row list: the tile's rows are gathered through it
+    const size_t nodeB0 = a.subset ? a.subset[a.row0 + rowB0] : a.row0 + rowB0, nodeB1 = a.subset ? a.subset[a.row0 + rowB1] : a.row0 + rowB1;
+    const uint16_t *gB0 = reinterpret_cast<const uint16_t *>(a.rows) + nodeB0 * a.dim + sc * 8;
+    const uint16_t *gB1 = reinterpret_cast<const uint16_t *>(a.rows) + nodeB1 * a.dim + sc * 8;
     const int so0 = sr * kLdsStride + sc * 16, so1 = (sr + 64) * kLdsStride + sc * 16;
     // fp8 rows: ONE 16-byte load per thread and stage = 16 codes of tile row tid/2, depth half tid&1,
     // widened to bf16 (exact) on the way into LDS
     uint32_t rowF = r0 + (uint32_t)(tid >> 1);
     if (rowF >= a.nrows) rowF = a.nrows - 1;
-    const uint8_t *gF = reinterpret_cast<const uint8_t *>(a.rows) + ((size_t)a.row0 + rowF) * a.dim + (tid & 1) * 16;
+    const size_t nodeF = a.subset ? a.subset[a.row0 + rowF] : a.row0 + rowF;
+    const uint8_t *gF = reinterpret_cast<const uint8_t *>(a.rows) + nodeF * a.dim + (tid & 1) * 16;
     const int soF = (tid >> 1) * kLdsStride + (tid & 1) * 32;
     // f32 rows: 8 consecutive floats (two 16-byte loads) of tile rows sr and sr+64 per thread and stage
-    const float *gX0 = reinterpret_cast<const float *>(a.rows) + ((size_t)a.row0 + rowB0) * a.dim + sc * 8;
-    const float *gX1 = reinterpret_cast<const float *>(a.rows) + ((size_t)a.row0 + rowB1) * a.dim + sc * 8;
+    const float *gX0 = reinterpret_cast<const float *>(a.rows) + nodeB0 * a.dim + sc * 8;
+    const float *gX1 = reinterpret_cast<const float *>(a.rows) + nodeB1 * a.dim + sc * 8;
     auto split8 = [](const float4 &u, const float4 &v, uint4 &hi, uint4 &lo) { // 8 f32 -> 8 bf16 hi + 8 bf16 residuals
         const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
         uint32_t h[8], l[8];
@@ -217,8 +221,9 @@ __global__ __launch_bounds__(256) void flat_mfma_bf16_kernel(MfmaArgs a) {
     for (int jn = 0; jn < 2; ++jn) {
         const uint32_t rloc = r0 + wn * 64 + jn * 32 + (lane & 31);
         if (rloc >= a.nrows) continue;
-        const float term = a.rowterm[(size_t)a.row0 + rloc];
-        const float rsc = FP8 ? a.rowscale[(size_t)a.row0 + rloc] : 1.0f;
+        const size_t node = a.subset ? a.subset[a.row0 + rloc] : a.row0 + rloc;
+        const float term = a.rowterm[node];
+        const float rsc = FP8 ? a.rowscale[node] : 1.0f;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -430,10 +435,10 @@ hipError_t launch_bf16_row_norm2(const uint16_t *rows, uint32_t n, uint32_t dim,
 }
 
 // scan all rows of a bf16 index for b device-resident queries (see the file header)
-int flat_mfma_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, uint64_t *d_ids, float *d_scores,
-                     uint32_t *d_counts, uint32_t *d_status, bool timed) {
+int flat_mfma_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, const uint32_t *d_subset, uint32_t n_rows,
+                     uint64_t *d_ids, float *d_scores, uint32_t *d_counts, uint32_t *d_status, bool timed) {
     const DevIndex &d = ix->dev;
-    const uint32_t n = d.n;
+    const uint32_t n = n_rows; // rows of the scan: the whole index, or the restricted row list
     if (k == 0) return fail(HVX_ERR_K_RANGE, "result count must be non-zero");
     if (k > 511) return fail(HVX_ERR_UNSUPPORTED, "bf16 exact scan supports k <= 511");
     const uint32_t nk = d.dim >> 5;
@@ -456,10 +461,10 @@ int flat_mfma_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t
     }
     const bool fp8 = d.dtype == HVX_FP8_E4M3, f32 = d.dtype == HVX_F32;
     if (f32 && !ix->m_rowterm) { // |x|^2 per row and its maximum: once per index, on first use
-        if ((rc = ix->dalloc((void **)&ix->m_rowterm, std::max<size_t>(n, 1) * 4))) return rc;
-        std::vector<float> h_n2(n);
-        HIP_TRY(launch_f32_row_norm2(d.vec, n, d.ld, d.dim, ix->m_rowterm, ix->stream));
-        HIP_TRY(hipMemcpyAsync(h_n2.data(), ix->m_rowterm, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
+        if ((rc = ix->dalloc((void **)&ix->m_rowterm, std::max<size_t>(d.n, 1) * 4))) return rc;
+        std::vector<float> h_n2(d.n);
+        HIP_TRY(launch_f32_row_norm2(d.vec, d.n, d.ld, d.dim, ix->m_rowterm, ix->stream));
+        HIP_TRY(hipMemcpyAsync(h_n2.data(), ix->m_rowterm, (size_t)d.n * 4, hipMemcpyDeviceToHost, ix->stream));
         HIP_TRY(hipStreamSynchronize(ix->stream));
         ix->m_xmax2 = 0.f;
         for (float v : h_n2) ix->m_xmax2 = std::max(ix->m_xmax2, v);
@@ -477,11 +482,11 @@ int flat_mfma_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t
         if ((rc = ix->flat_scratch(b, kc, chunk))) return rc;
         HIP_TRY(hipMemsetAsync(ix->f_top_c, 0, (size_t)b * 4, ix->stream));
         FlatArgs fa;
-        fa.ix = d; fa.queries = d_queries; fa.qstatus = ix->d_qstatus; fa.qhdr = ix->d_qhdr; fa.subset = nullptr;
+        fa.ix = d; fa.queries = d_queries; fa.qstatus = ix->d_qstatus; fa.qhdr = ix->d_qhdr; fa.subset = d_subset;
         fa.n_rows = n; fa.dist = ix->f_dist; fa.chunk_ld = chunk; fa.b = b; fa.k = kc;
         fa.top_scores = ix->f_top_s; fa.top_ids = ix->f_top_i; fa.top_counts = ix->f_top_c;
         MfmaArgs ma;
-        ma.qhi = ix->m_qhi; ma.qlo = ix->m_qlo;
+        ma.qhi = ix->m_qhi; ma.qlo = ix->m_qlo; ma.subset = d_subset;
         ma.rows = f32 ? (const void *)d.vec : (fp8 ? (const void *)d.vec8 : (const void *)d.vecb);
         ma.rowscale = d.rowscale;
         ma.rowterm = d.metric == kL2 ? ix->m_rowterm : d.hdr;

@@ -96,8 +96,8 @@ int flat_scan_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t
                      bool timed);
 int flat_scan_valu(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, const uint32_t *d_subset, uint32_t n_rows,
                    uint64_t *d_ids, float *d_scores, uint32_t *d_counts, uint32_t *d_status, bool timed, bool record_begin);
-int flat_mfma_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, uint64_t *d_ids, float *d_scores,
-                     uint32_t *d_counts, uint32_t *d_status, bool timed);
+int flat_mfma_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, const uint32_t *d_subset, uint32_t n_rows,
+                     uint64_t *d_ids, float *d_scores, uint32_t *d_counts, uint32_t *d_status, bool timed);
 hipError_t launch_bf16_row_norm2(const uint16_t *rows, uint32_t n, uint32_t dim, float *out, hipStream_t s);
 int flat_scan_host(hvx_index *ix, const float *queries, uint32_t b, uint32_t k, const uint32_t *d_subset,
                    uint32_t n_rows, uint64_t *out_ids, float *out_scores, uint32_t *out_counts,

@@ -985,3 +985,51 @@ def test_f32_exact_scan_answers_only_the_uncertified_queries_with_the_valu_kerne
         assert gcnt[qi] == k and gid[qi].tolist() == oid.tolist(), f"query {qi}"
         assert bits(gsc[qi]).tolist() == bits(osc).tolist()
     assert all(5000 <= int(x) < 8000 for x in gid[3])
+
+
+@pytest.mark.parametrize("dtype_name,metric,dim", [("bf16", 1, 128), ("bf16", 0, 256), ("fp8", 1, 128)])
+def test_restricted_scan_over_bf16_and_fp8_rows(orc, hv, dtype_name, metric, dim):
+    """search_restricted (restricted.rs:753-835) over quantised storage: the matrix-core pipeline gathers the tile's rows
+    through the candidate row list; results equal the oracle's exact scan over the allowed ids on the stored values."""
+    rng = np.random.default_rng(900 + dim + metric)
+    n, k, b = 6000, 10, 9
+    data = (rng.standard_normal((n, dim)) * rng.uniform(0.5, 2.0, (n, 1))).astype(np.float32)
+    stored = fx.round_bf16(data) if dtype_name == "bf16" else fx.quantize_fp8_rows(data)
+    ids = np.arange(n, dtype=np.uint64) * 2 + 5                       # non-contiguous external ids
+    gix = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=metric, node_ids=ids, vectors=data,
+                                              dtype=hv.BF16 if dtype_name == "bf16" else hv.FP8_E4M3,
+                                              l0_offsets=np.zeros(n + 1, np.uint64), l0_neighbors=np.zeros(0, np.uint64), max_batch=16)
+    oix = orc.Index(dim, metric)
+    assert oix.seed(ids, stored, np.zeros(n + 1, np.uint64), np.zeros(0, np.uint64)) == orc.OK
+    q = rng.standard_normal((b, dim)).astype(np.float32)
+    for size in (37, 900):
+        allowed = np.concatenate([rng.choice(ids, size, replace=False), np.array([4, 10**9], np.uint64)])  # + ids without a vector
+        cand = hv.RestrictedVectorCandidates.from_ids(allowed)
+        gid, gsc, gcnt = gix.search_restricted_batch(q, hv.SearchParams(k), cand)
+        for qi in range(b):
+            rc, oid, osc = oix.flat(q[qi], k, allowed=allowed)
+            assert rc == orc.OK and gcnt[qi] == oid.size == k
+            assert gid[qi, :k].tolist() == oid.tolist(), f"{size} candidates, query {qi}"
+            assert bits(gsc[qi, :k]).tolist() == bits(osc).tolist()
+
+
+def test_large_restricted_scan_over_f32_rows_takes_the_matrix_cores(orc, hv, monkeypatch):
+    """A 30 000-candidate restricted scan x 512 queries x 768 dims is above the work threshold: row-list gather on the
+    matrix-core pipeline, equal to the VALU kernel and the oracle bit for bit."""
+    rng = np.random.default_rng(33)
+    n, dim, b, k = 60000, 768, 512, 10
+    centers = rng.standard_normal((24, dim)).astype(np.float32)
+    data = (centers[rng.integers(0, 24, n)] + 0.5 * rng.standard_normal((n, dim))).astype(np.float32)
+    gix = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=hv.EUCLIDEAN, node_ids=np.arange(n, dtype=np.uint64), vectors=data,
+                                              l0_offsets=np.zeros(n + 1, np.uint64), l0_neighbors=np.zeros(0, np.uint64), max_batch=b)
+    q = (centers[rng.integers(0, 24, b)] + 0.5 * rng.standard_normal((b, dim))).astype(np.float32)
+    allowed = np.sort(rng.choice(n, 30000, replace=False)).astype(np.uint64)
+    cand = hv.RestrictedVectorCandidates.from_ids(allowed)
+    gid, gsc, gcnt = gix.search_restricted_batch(q, hv.SearchParams(k), cand)
+    monkeypatch.setenv("HVX_FLAT_VALU", "1")
+    vid, vsc, vcnt = gix.search_restricted_batch(q, hv.SearchParams(k), cand)
+    assert gid.tolist() == vid.tolist() and bits(gsc).tolist() == bits(vsc).tolist() and gcnt.tolist() == vcnt.tolist()
+    sub = data[allowed.astype(np.int64)]
+    for qi in (0, 100, 511):
+        rc, oid, osc = orc.flat_matrix(orc.L2SQ, sub, q[qi], k, kernel=orc.K_AVX_FMA_HW)
+        assert allowed[oid.astype(np.int64)].tolist() == gid[qi].tolist() and bits(osc).tolist() == bits(gsc[qi]).tolist()

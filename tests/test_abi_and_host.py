@@ -195,3 +195,16 @@ def test_adaptive_threshold_step_table_equals_the_formula(orc, configured, failu
             if 0 <= bits + off <= 0x7F7FFFFF:
                 d = np.uint32(bits + off).view(np.float32)
                 assert lookup(d) == orc.adaptive_threshold(1, d, configured, failure), (float(b), off)
+
+
+def test_header_is_plain_c_and_the_c_example_links(tmp_path):
+    """include/helix_vec.h must be usable from C (cgo / Rust bindgen / JNI): the example compiles as pedantic C99 and
+    links against the product library (running it needs a GPU)."""
+    import subprocess
+    exe = tmp_path / "c_abi_example"
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "c_abi_example.c"), "-L", os.path.join(ROOT, "helix-db_amd"), "-lhelix_vec_gfx950",
+           f"-Wl,-rpath,{os.path.join(ROOT, 'helix-db_amd')}", "-o", str(exe)]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert exe.exists()

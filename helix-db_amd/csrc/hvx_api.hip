@@ -432,6 +432,7 @@ int hvx::enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t b
     a.qstatus = ix->d_qstatus;
     a.qhdr = ix->d_qhdr;
     a.bitmap = ix->d_bitmap;
+    a.bitmap2 = (ad && ad->count_reads) ? ix->d_bitmap2 : nullptr;
     a.words_per_query = ix->words_per_query;
     a.k = k;
     a.ef = ef;

@@ -33,6 +33,7 @@ namespace hvx {
 
 constexpr uint32_t kTabEmpty = 0xFFFFFFFFu;
 constexpr uint32_t kTentativeBit = 0x80000000u; // visited-table entry claimed by the non-strict arms, not (yet) visited
+constexpr uint32_t kHashedBit = 0x40000000u;    // ... whose SimHash row is already in the query-local cache (uncached-handle read accounting)
 
 __device__ __forceinline__ uint32_t umin_dpp_row(uint32_t v) {
     // butterfly inside each 16-lane DPP row: xor1, xor2, half-mirror (7-l), mirror (15-l)
@@ -57,13 +58,14 @@ __device__ __forceinline__ uint32_t wave_umin(uint32_t v) {
 struct Visited {
     uint32_t *tab;      // LDS [cap]
     uint32_t *bm;       // HBM bitmap of this query (all-zero on entry, handed back all-zero)
+    uint32_t *bm2;      // second bitmap: SimHash-row-cached ids in bitmap mode (uncached-handle read accounting only; may be NULL)
     uint32_t mask, shift, cap, words;
     uint32_t count;     // uniform: ids inserted into the table since the last clear
     bool spilled;       // uniform: bitmap mode
 
     __device__ __forceinline__ void clear(int lane) {
         if (spilled) {
-            for (uint32_t w = (uint32_t)lane; w < words; w += 64) bm[w] = 0u;
+            for (uint32_t w = (uint32_t)lane; w < words; w += 64) { bm[w] = 0u; if (bm2) bm2[w] = 0u; }
             spilled = false;
         }
         for (uint32_t i = (uint32_t)lane; i < cap; i += 64) tab[i] = kTabEmpty;
@@ -73,7 +75,10 @@ struct Visited {
     __device__ __forceinline__ void spill(int lane) {
         for (uint32_t i = (uint32_t)lane; i < cap; i += 64) {
             uint32_t v = tab[i];
-            if (v != kTabEmpty && !(v & kTentativeBit)) atomicOr(&bm[v >> 5], 1u << (v & 31u));
+            if (v == kTabEmpty) continue;
+            const uint32_t vid = v & ~(kTentativeBit | kHashedBit);
+            if (!(v & kTentativeBit)) atomicOr(&bm[vid >> 5], 1u << (vid & 31u));
+            else if ((v & kHashedBit) && bm2) atomicOr(&bm2[vid >> 5], 1u << (vid & 31u));
         }
         spilled = true;
         __threadfence_block();
@@ -83,16 +88,24 @@ struct Visited {
     // later expansions, and keep their slot), commit() turns the remembered slot into a visited entry with one plain
     // store -- one LDS probe loop per expansion instead of a test loop plus an insert loop.  In bitmap mode claim() is
     // a bit test and commit() the atomicOr.  Returns true for unseen ids; ids must be < 2^31 - 1.
-    __device__ __forceinline__ bool claim(uint32_t id, bool valid, int lane, uint32_t &slot_out) {
+    __device__ __forceinline__ bool claim(uint32_t id, bool valid, int lane, uint32_t &slot_out, bool &hashed_out) {
         if (!spilled && count + 64u > cap - (cap >> 2)) spill(lane);
-        if (spilled) return !contains(id, valid) & valid;
+        hashed_out = false;
+        if (spilled) {
+            if (valid && bm2) hashed_out = (__hip_atomic_load(&bm2[id >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (id & 31u)) & 1u;
+            return !contains(id, valid) & valid;
+        }
         bool pending = valid, unseen = false, taken = false;
         uint32_t slot = (id * 2654435761u) >> shift;
         while (__ballot(pending)) {
             if (pending) {
                 const uint32_t old = atomicCAS(&tab[slot], kTabEmpty, id | kTentativeBit);
                 if (old == kTabEmpty) { unseen = true; taken = true; pending = false; }
-                else if ((old & ~kTentativeBit) == id) { unseen = (old & kTentativeBit) != 0u; pending = false; }
+                else if ((old & ~(kTentativeBit | kHashedBit)) == id) {
+                    unseen = (old & kTentativeBit) != 0u;
+                    hashed_out = (old & kHashedBit) != 0u;
+                    pending = false;
+                }
                 else slot = (slot + 1u) & mask;
             }
         }
@@ -105,6 +118,14 @@ struct Visited {
             if (doit) atomicOr(&bm[id >> 5], 1u << (id & 31u));
         } else if (doit) {
             tab[slot] = id;
+        }
+    }
+    // the id's SimHash row entered the query-local cache (it stays a tentative, unseen id)
+    __device__ __forceinline__ void mark_hashed(uint32_t id, bool doit, uint32_t slot) {
+        if (spilled) {
+            if (doit && bm2) atomicOr(&bm2[id >> 5], 1u << (id & 31u));
+        } else if (doit) {
+            tab[slot] = id | kTentativeBit | kHashedBit;
         }
     }
     // membership test only
@@ -348,6 +369,7 @@ struct AdaptState {
     uint32_t fill;                        // simhash_fill_slots (search.rs:532)
     uint32_t win_ex, win_filt, win_exp;   // rolling yield window (search.rs:790-801)
     uint32_t bstate, bremain;             // AdaptiveBypassState: 0 Ready, 1 Bypassing, 2 CoolingDown
+    uint32_t reads;                       // _txn_get_simhash_filter: stable-view SimHash reads (uncached handle only)
     hvx_adaptive_stats st;
 };
 
@@ -379,9 +401,10 @@ __device__ __forceinline__ AdaptDecision adapt_decide(const AdaptArgs &p, AdaptS
         } else {
             const float rate = s.win_ex == 0u ? 1.0f : (float)s.win_filt / (float)s.win_ex;
             const bool low_yield = (s.win_exp >= p.window_expansions) & (rate < p.min_filter_rate);
-            if (frontier >= p.min_frontier && low_yield) {
+            const bool budget = (p.count_reads != 0u) & (s.reads >= p.read_budget); // a resident snapshot reads nothing
+            if (frontier >= p.min_frontier && (low_yield | budget)) {
                 bypassed = true;
-                trigger = 2u; // LowYield
+                trigger = (budget ? 1u : 0u) | (low_yield ? 2u : 0u); // ReadBudget / LowYield / both
                 nstate = p.window_expansions - 1u ? 1u : 2u;
                 nremain = p.window_expansions - 1u ? p.window_expansions - 1u : p.window_expansions;
             }
@@ -462,6 +485,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     V.shift = 32u - log2cap;
     V.words = a.words_per_query;
     V.bm = a.bitmap + (size_t)q * a.words_per_query;
+    V.bm2 = (AD && a.bitmap2) ? a.bitmap2 + (size_t)q * a.words_per_query : nullptr;
     V.count = 0;
     V.spilled = false;
     uint32_t *fr_id = V.tab + V.cap;                      // [64] frontier ids, row order
@@ -542,9 +566,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // non-strict arms: ONE probe of the visited table claims the unseen neighbours tentatively (Visited::claim); the
     // selection stages then work in row-lane space (lane = position in the neighbour row = frontier order)
     uint32_t vslot = 0;
+    bool vhashed = false;
     auto frontier_claim = [&](uint32_t nid, uint32_t &deg, unsigned long long &um) __attribute__((always_inline)) -> uint32_t {
         const bool valid = nid != kSentinel;
-        const bool unseen = V.claim(nid, valid, lane, vslot);
+        const bool unseen = V.claim(nid, valid, lane, vslot, vhashed);
         um = __ballot(unseen);
         deg = (uint32_t)__builtin_popcountll(__ballot(valid));
         return (uint32_t)__builtin_popcountll(um);
@@ -634,7 +659,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     uint64_t qh = 0;
     float brk_lane = -1.0f;
     if (AD) {
-        A.fill = A.win_ex = A.win_filt = A.win_exp = A.bstate = A.bremain = 0u;
+        A.fill = A.win_ex = A.win_filt = A.win_exp = A.bstate = A.bremain = A.reads = 0u;
         A.st = hvx_adaptive_stats{};
         qh = a.ad.qhash[q];
         brk_lane = a.ad.thr_break[lane];
@@ -709,7 +734,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             const uint32_t kt = a.k > 1u ? a.k : 1u;              // topk_target
             const float delta = S.score_at((kt < wlen ? kt : wlen) - 1u); // topk == the first min(k,|W|) of W
             const AdaptDecision D = adapt_decide(P, A, ef, wlen >= kt, wlen, nf0, dc, delta, brk_lane);
-            if (ST) A.st.simhash_bypass_trigger_low_yield += D.trigger == 2u ? 1u : 0u;
+            if (ST) A.st.simhash_bypass_trigger_low_yield += (D.trigger & 2u) ? 1u : 0u;
+            if (ST) A.st.simhash_bypass_trigger_budget += (D.trigger & 1u) ? 1u : 0u;
             if (ST) A.st.active_sampling_ratio_sum += (double)D.base_p;
             if (ST) A.st.active_sampling_ratio_samples += 1u;
             if (ST && D.filter) { A.st.active_simhash_threshold_sum += D.threshold; A.st.active_simhash_threshold_samples += 1u; }
@@ -735,6 +761,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             uint32_t sim = 32u;
             bool pass = keep, vfail = false;
             if (D.filter) {
+                if (P.count_reads) { // fill_simhash_cache (memory_store.rs:314-372): every row not yet in the query-local cache is one read
+                    const bool fresh_row = keep & !vhashed;
+                    A.reads += (uint32_t)__builtin_popcountll(__ballot(fresh_row));
+                    V.mark_hashed(node, fresh_row, vslot);
+                }
                 const uint64_t h = keep ? node_h : 0ull;
                 sim = 64u - (uint32_t)__builtin_popcountll(h ^ qh); // collision_count == 64 - hamming_distance
                 const bool failed = keep & !(sim >= D.threshold);
@@ -870,8 +901,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             }
         }
     }
-    if (V.spilled) { // leave the HBM bitmap zeroed for the next launch
-        for (uint32_t w = (uint32_t)lane; w < V.words; w += 64) V.bm[w] = 0u;
+    if (V.spilled) { // leave the HBM bitmap(s) zeroed for the next launch
+        for (uint32_t w = (uint32_t)lane; w < V.words; w += 64) { V.bm[w] = 0u; if (V.bm2) V.bm2[w] = 0u; }
     }
     if (lane == 0) {
         a.out_counts[q] = outn;
@@ -880,6 +911,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if (a.tie_flags) a.tie_flags[q] = tie_overflow ? 1u : 0u;
         if (AD && ST && a.ad.stats) {
             A.st.rng_words = G.pos;
+            A.st.txn_get_simhash_filter = A.reads;
             a.ad.stats[q] = A.st;
         }
     }

@@ -60,6 +60,7 @@ struct hvx_index {
     bool has_simhash = false;
     hvx_simhash_config sh_cfg{};
     uint64_t *d_node_hash = nullptr, *d_qhash = nullptr;
+    uint32_t *d_bitmap2 = nullptr;   // SimHash-cached ids of the bitmap (spill) mode, uncached-handle accounting only
     float *d_planes_t = nullptr, *d_thr_break = nullptr;
     hvx_adaptive_stats *d_astats = nullptr;
     uint32_t thr_configured = 0xFFFFFFFFu; // what d_thr_break was built for

@@ -22,6 +22,8 @@ struct AdaptArgs {
     uint32_t sampling;          // FrontierSamplingPolicy: 0 Exhaustive, 1 Fixed, 2 Adaptive
     float ratio;                // base sampling ratio (override or index sampling_ratio)
     float pre_override;         // pre-sampling override, < 0 = None
+    uint32_t count_reads;       // 1: uncached handle -- SimHash rows are stable-view reads (memory_store.rs:338-347), budget trigger live
+    uint32_t read_budget;       // max(ef * multiplier, min_frontier) (policy.rs:214-218)
     uint32_t bypass_windowed;   // AdaptiveBypassPolicy::Windowed
     uint32_t min_frontier, window_expansions;
     float min_filter_rate;
@@ -33,6 +35,7 @@ struct HnswArgs {
     const uint32_t *qstatus;   // [b] validation status (0 = ok), nullable
     const float *qhdr;         // [b] query cosine norm header, nullable (non-cosine)
     uint32_t *bitmap;          // [b][words_per_query] visited bits, zeroed before launch
+    uint32_t *bitmap2;         // same shape, SimHash-cached ids in bitmap mode (non-strict arms with read accounting), nullable
     uint32_t words_per_query;
     uint32_t k, ef;
     uint64_t *out_ids;         // [b][k]

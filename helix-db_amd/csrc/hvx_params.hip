@@ -40,6 +40,7 @@ extern "C" void hvx_simhash_config_default(hvx_simhash_config *c) { // mod.rs:31
     c->sampling_ratio = 0.8f;
     c->adaptive_enabled = 1;
     c->adaptive_failure_prob = 0.1f;
+    c->resident_snapshot = 1;
 }
 
 static bool unit_interval(float v) { return std::isfinite(v) && v >= 0.0f && v <= 1.0f; }      // parameters.rs:170-184
@@ -75,6 +76,11 @@ extern "C" int hvx_index_set_simhash(hvx_index *ix, const hvx_simhash_config *cf
         else
             HIP_TRY(launch_simhash_rows(ix->d_planes_t, ix->dev.vec, dim, ix->dev.ld, n, ix->d_node_hash, ix->stream));
         HIP_TRY(hipStreamSynchronize(ix->stream));
+    }
+    if (!cfg->resident_snapshot && !ix->d_bitmap2) { // second spill bitmap, all-zero between launches like the first
+        const size_t bytes = (size_t)ix->max_batch * ix->words_per_query * 4;
+        if ((rc = ix->dalloc((void **)&ix->d_bitmap2, bytes))) return rc;
+        HIP_TRY(hipMemset(ix->d_bitmap2, 0, bytes));
     }
     ix->sh_cfg = *cfg;
     ix->has_simhash = true;
@@ -185,8 +191,13 @@ static int project_params(hvx_index *ix, const hvx_search_params *p, AdaptArgs *
     if (mode == HVX_SIMHASH_OFF) ad->sampling = 0;
     else if (mode == HVX_SIMHASH_ALWAYS) ad->sampling = 1;
     else ad->sampling = c.adaptive_enabled ? 2 : 1;
-    // AdaptiveBypassPolicy::from_deployed (policy.rs:203-226); the read budget is moot for a resident snapshot
+    // AdaptiveBypassPolicy::from_deployed (policy.rs:203-226); the read budget only ever fills for an uncached handle
     ad->bypass_windowed = mode == HVX_SIMHASH_ADAPTIVE ? 1 : 0;
+    ad->count_reads = c.resident_snapshot ? 0u : 1u;
+    {
+        const uint64_t budget = (uint64_t)p->ef * p->read_budget_multiplier;
+        ad->read_budget = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(budget, p->bypass_min_frontier), 0xFFFFFFFFull);
+    }
     ad->min_frontier = p->bypass_min_frontier;
     ad->window_expansions = p->bypass_window_expansions;
     ad->min_filter_rate = p->bypass_min_filter_rate;

@@ -76,7 +76,7 @@ class _Params(C.Structure):  # hvx_search_params
 
 class SimHashConfig(C.Structure):  # hvx_simhash_config: the index-level VectorIndexConfig knobs
     _fields_ = [("seed", C.c_uint64), ("simhash_threshold", C.c_uint32), ("sampling_ratio", C.c_float),
-                ("adaptive_enabled", C.c_uint32), ("adaptive_failure_prob", C.c_float)]
+                ("adaptive_enabled", C.c_uint32), ("adaptive_failure_prob", C.c_float), ("resident_snapshot", C.c_uint32)]
 
     @classmethod
     def default(cls, **over):
@@ -94,7 +94,7 @@ class AdaptiveStats(C.Structure):  # hvx_adaptive_stats
         "pre_simhash_sample_kept", "pre_simhash_sample_dropped", "simhash_bypass_expansions",
         "simhash_skipped_candidates", "simhash_bypass_trigger_budget", "simhash_bypass_trigger_low_yield",
         "active_simhash_threshold_sum", "active_simhash_threshold_samples", "effective_beam_len_sum",
-        "effective_beam_len_samples", "active_sampling_ratio_samples", "rng_words")] + \
+        "effective_beam_len_samples", "active_sampling_ratio_samples", "rng_words", "txn_get_simhash_filter")] + \
         [("active_sampling_ratio_sum", C.c_double)]
 
     def as_dict(self):

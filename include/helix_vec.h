@@ -156,6 +156,10 @@ typedef struct hvx_simhash_config {
     float sampling_ratio;                        /* [0,1] */
     uint32_t adaptive_enabled;
     float adaptive_failure_prob;                 /* (0,1) */
+    uint32_t resident_snapshot;                  /* 1 (default): the index stands in for a Ready resident store -- SimHash
+                                                    lookups are not stable-view reads (memory_store.rs:329-335);
+                                                    0: an uncached handle -- every row first seen by a query is one read
+                                                    (memory_store.rs:338-347) and the read-budget bypass trigger is live */
 } hvx_simhash_config;
 void hvx_simhash_config_default(hvx_simhash_config *);
 
@@ -170,9 +174,9 @@ int hvx_index_get_simhash(const hvx_index *, uint64_t *out_node_hashes /*[n] hos
  * f32 delta whose threshold is >= t (-1: none), built with THIS host's libm; threshold(delta) = #{t : delta <= out_brk[t-1]}. */
 int hvx_adaptive_threshold_table(uint32_t configured, float failure, float *out_brk /*[64]*/);
 
-/* SearchStats fields of the non-strict arms (mod.rs:629-700), per query.  The device index plays the resident
- * snapshot (memory_store.rs:329-335): SimHash lookups are not stable-view reads, txn_get_simhash_filter stays 0
- * and the read-budget bypass trigger cannot fire -- exactly as for the reference with a Ready resident store. */
+/* SearchStats fields of the non-strict arms (mod.rs:629-700), per query.  With hvx_simhash_config.resident_snapshot = 1
+ * (default) SimHash lookups are not stable-view reads: txn_get_simhash_filter stays 0 and the read-budget bypass trigger
+ * cannot fire -- exactly as for the reference with a Ready resident store; with 0 both follow the uncached handle. */
 typedef struct hvx_adaptive_stats {
     uint32_t simhash_filtered, simhash_examined;
     uint32_t simhash_passed_before_sampling, simhash_passed_after_sampling;
@@ -183,6 +187,7 @@ typedef struct hvx_adaptive_stats {
     uint32_t effective_beam_len_sum, effective_beam_len_samples;             /* avg_effective_beam_len */
     uint32_t active_sampling_ratio_samples;                                  /* avg_active_sampling_ratio */
     uint32_t rng_words;                          /* u32 outputs drawn from the query's StdRng (not a reference field) */
+    uint32_t txn_get_simhash_filter;             /* SimHash rows read for filtering (uncached accounting; 0 for a resident snapshot) */
     double active_sampling_ratio_sum;
 } hvx_adaptive_stats;
 

@@ -151,7 +151,7 @@ def test_full_search_params_mirror_the_reference():
     cfg = hv.SimHashConfig.default()
     assert (cfg.seed, cfg.simhash_threshold, cfg.adaptive_enabled) == (42, 43, 1)
     assert cfg.sampling_ratio == np.float32(0.8) and cfg.adaptive_failure_prob == np.float32(0.1)
-    assert C.sizeof(hv.AdaptiveStats) == 72
+    assert C.sizeof(hv.AdaptiveStats) == 80 and cfg.resident_snapshot == 1
 
 
 def test_restricted_row_dedupe_and_materialisation_follow_the_interpreter():

@@ -573,7 +573,7 @@ def _oracle_params(orc, p, cfg):
         simhash_failure_prob_override=none(p.simhash_failure_prob_override),
         simhash_threshold=cfg.simhash_threshold, sampling_ratio=cfg.sampling_ratio,
         adaptive_enabled=cfg.adaptive_enabled, adaptive_failure_prob=cfg.adaptive_failure_prob,
-        resident_simhash=1)  # the device index plays the resident snapshot (memory_store.rs:329-335)
+        resident_simhash=int(cfg.resident_snapshot))  # resident snapshot (memory_store.rs:329-335) or uncached handle
 
 
 ADAPTIVE_STAT_KEYS = ("expansion_steps", "neighbors_examined", "vectors_loaded", "distance_computations",
@@ -582,7 +582,7 @@ ADAPTIVE_STAT_KEYS = ("expansion_steps", "neighbors_examined", "vectors_loaded",
                       "simhash_bypass_expansions", "simhash_skipped_candidates", "simhash_bypass_trigger_budget",
                       "simhash_bypass_trigger_low_yield", "active_simhash_threshold_sum",
                       "active_simhash_threshold_samples", "effective_beam_len_sum", "effective_beam_len_samples",
-                      "active_sampling_ratio_samples", "rng_words", "active_sampling_ratio_sum")
+                      "active_sampling_ratio_samples", "rng_words", "txn_get_simhash_filter", "active_sampling_ratio_sum")
 
 
 def assert_params_equal(orc, hv, oix, gix, queries, p, cfg):
@@ -720,6 +720,36 @@ def test_non_strict_arms_over_bf16_rows(orc, hv, metric, dim):
     agg = assert_params_equal(orc, hv, oix, gix, q, hv.SearchParams.new(10), cfg)
     assert agg["pre_simhash_sample_dropped"] > 0 and (metric == 1 or agg["simhash_filtered"] > 0)
     assert_params_equal(orc, hv, oix, gix, q, hv.SearchParams.throughput_profile_floor_92(10), cfg)
+
+
+@pytest.mark.parametrize("spill", [False, True])
+@pytest.mark.parametrize("mult,ef", [(1, 100), (3, 100), (1, 24)])
+def test_uncached_handle_read_accounting_and_budget_bypass(orc, hv, monkeypatch, spill, mult, ef):
+    """hvx_simhash_config.resident_snapshot = 0: every SimHash row a query sees for the first time in a filtering epoch is
+    one stable-view read (memory_store.rs:338-347); once ef x multiplier reads are spent the read-budget trigger
+    (policy.rs:266) opens bypass windows.  Reads, triggers, results equal the oracle's uncached accounting -- also when
+    the visited table has spilled to the HBM bitmaps."""
+    if spill:
+        monkeypatch.setenv("HVX_WAVE_LOG2CAP", "8")
+    rng = np.random.default_rng(606 + mult + ef)
+    n, dim = 2500, 128
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    oix = build_oracle(orc, data, 0, fx.draw_levels(n, 16, seed=12), efc=80)
+    oix.set_simhash(42)
+    gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=dim, metric=0)
+    cfg = hv.SimHashConfig.default(resident_snapshot=0, simhash_threshold=30)
+    gix.set_simhash(cfg)
+    q = rng.standard_normal((32, dim)).astype(np.float32)
+    p = hv.SearchParams.new(10).with_ef(ef).with_simhash_bypass_tuning(8, 3, 0.05, mult)
+    agg = assert_params_equal(orc, hv, oix, gix, q, p, cfg)
+    assert agg["txn_get_simhash_filter"] > 0
+    if mult == 1:
+        assert agg["simhash_bypass_trigger_budget"] > 0 and agg["simhash_bypass_expansions"] > 0
+    # the same index with resident accounting answers differently once the budget has fired
+    cfg_r = hv.SimHashConfig.default(resident_snapshot=1, simhash_threshold=30)
+    gix.set_simhash(cfg_r)
+    agg_r = assert_params_equal(orc, hv, oix, gix, q, p, cfg_r)
+    assert agg_r["txn_get_simhash_filter"] == 0 and agg_r["simhash_bypass_trigger_budget"] == 0
 
 
 def test_non_strict_arms_spill_path_and_given_hashes(orc, hv, monkeypatch):

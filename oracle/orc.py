@@ -496,3 +496,42 @@ class SimHasher:
 
 def order_code(bits):
     return int(lib().orc_order_code(bits))
+
+
+def breadth_first_depths(n, out_offsets, out_targets, labels, seeds, max_depth, direction=2, allowed_labels=(), hub_degree=0):
+    """crates/graph-algorithms/src/algorithms/traversal.rs:216-261 `breadth_first` + :311-318 `suppresses_hub`, restated
+    for what the device returns: the visited set with its minimum depths (both are independent of the arc order, so the
+    id-ordered merge of `ArcIter::Both`, model.rs:680-725, does not matter here).  direction: 0 Out, 1 In, 2 Both;
+    hub_degree 0 = HubExpansionPolicy::ExpandAll; degree = out + in arcs (traversal.rs:347-356).  Small cases only."""
+    from collections import deque
+    out = [[] for _ in range(n)]
+    inc = [[] for _ in range(n)]
+    for u in range(n):
+        for a in range(int(out_offsets[u]), int(out_offsets[u + 1])):
+            lab = None if labels is None else int(labels[a])
+            out[u].append((int(out_targets[a]), lab))
+            inc[int(out_targets[a])].append((u, lab))
+    depth, seed_list, queue = {}, [], deque()
+    for s in seeds:                                    # duplicates collapse, first occurrence wins (traversal.rs:203-210)
+        s = int(s)
+        if not 0 <= s < n:
+            raise KeyError(f"unknown node {s}")
+        if s not in depth:
+            depth[s] = 0
+            queue.append(s)
+            seed_list.append(s)
+    allowed = set(int(x) for x in allowed_labels)
+    while queue:
+        u = queue.popleft()
+        if depth[u] >= max_depth:
+            continue
+        if u not in seed_list and hub_degree and len(out[u]) + len(inc[u]) >= hub_degree:
+            continue                                   # emitted, never expanded
+        arcs = (out[u] if direction in (0, 2) else []) + (inc[u] if direction in (1, 2) else [])
+        for v, lab in arcs:
+            if allowed and lab not in allowed:
+                continue
+            if v not in depth:
+                depth[v] = depth[u] + 1
+                queue.append(v)
+    return depth

@@ -299,35 +299,7 @@ def test_restricted_wide_set_matches_flat_oracle(orc, hv):
     assert e.value.status == hv.ERR_K_RANGE
 
 
-def _py_bfs(n, off, tgt, lab, seeds, max_depth, direction, allowed, hub):
-    out = [[] for _ in range(n)]; inc = [[] for _ in range(n)]
-    for u in range(n):
-        for a in range(off[u], off[u + 1]):
-            out[u].append((int(tgt[a]), None if lab is None else int(lab[a])))
-            inc[int(tgt[a])].append((u, None if lab is None else int(lab[a])))
-    depth = {}
-    from collections import deque
-    dq = deque()
-    sset = []
-    for s in seeds:
-        if s not in depth:
-            depth[s] = 0; dq.append(s); sset.append(s)
-    while dq:
-        u = dq.popleft()
-        if depth[u] >= max_depth:
-            continue
-        if u not in sset and hub and len(out[u]) + len(inc[u]) >= hub:
-            continue
-        arcs = (out[u] if direction in (0, 2) else []) + (inc[u] if direction in (1, 2) else [])
-        for v, l in arcs:
-            if allowed and l not in allowed:
-                continue
-            if v not in depth:
-                depth[v] = depth[u] + 1; dq.append(v)
-    return depth
-
-
-def test_traverse_and_expand_match_reference_semantics(hv):
+def test_traverse_and_expand_match_reference_semantics(orc, hv):
     """crates/graph-algorithms/src/algorithms/traversal.rs:216-318 (visited set + BFS depth are
     order-independent) and interpreter expand (access/expand.rs:16-80)."""
     rng = np.random.default_rng(4)
@@ -339,7 +311,7 @@ def test_traverse_and_expand_match_reference_semantics(hv):
     for seeds, md, direction, allowed, hub in [([3], 2, 0, [], 0), ([3, 77, 3], 3, 2, [1, 2], 0), ([10, 11], 4, 1, [], 12),
                                                ([0], 0, 2, [], 0), ([5, 6, 7], 50, 0, [0], 0)]:
         words, depth = g.traverse(seeds, md, direction, allowed, hub, include_seeds=True)
-        ref = _py_bfs(n, off.astype(np.int64), tgt, lab, seeds, md, direction, set(allowed), hub)
+        ref = orc.breadth_first_depths(n, off.astype(np.int64), tgt, lab, seeds, md, direction, allowed, hub)
         got = set(np.nonzero(np.unpackbits(words.view(np.uint8), bitorder="little"))[0].tolist())
         assert got == set(ref.keys())
         for v, d in ref.items():

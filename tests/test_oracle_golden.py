@@ -280,3 +280,40 @@ def test_query_seed_and_collision_count(orc):
     assert orc.lib().orc_query_seed(bits, entry, ef) == bits ^ rotl(entry, 17) ^ rotl(ef, 7)
     assert orc.lib().orc_simhash_collisions(0, 0) == 64 and orc.lib().orc_simhash_collisions(0, (1 << 64) - 1) == 0
     assert orc.lib().orc_simhash_collisions(0b1011, 0b0001) == 62
+
+
+# --- crates/graph-algorithms/src/algorithms/traversal.rs:576-630 (the tests' own graph): a-b, b-c, b-hub, hub-leaf{,2,3}
+def _reference_traversal_graph():
+    names = ["a", "b", "c", "hub", "leaf", "leaf2", "leaf3"]
+    idx = {nm: i for i, nm in enumerate(names)}
+    edges = [("a", "b"), ("b", "c"), ("b", "hub"), ("hub", "leaf"), ("hub", "leaf2"), ("hub", "leaf3")]
+    n = len(names)
+    rows = [[] for _ in range(n)]
+    for s, t in edges:
+        rows[idx[s]].append(idx[t])
+    off = np.zeros(n + 1, np.int64)
+    tgt = []
+    for u in range(n):
+        tgt += rows[u]
+        off[u + 1] = len(tgt)
+    return names, idx, n, off, np.array(tgt, np.uint64)
+
+
+def test_breadth_first_returns_depth_order(orc):
+    names, idx, n, off, tgt = _reference_traversal_graph()
+    # GraphKind::Graph is undirected: every traversal runs in direction Both (model.rs:640-645)
+    d = orc.breadth_first_depths(n, off, tgt, None, [idx["a"]], 2, direction=2)
+    assert {names[v]: dep for v, dep in d.items()} == {"a": 0, "b": 1, "c": 2, "hub": 2}
+    assert len(d) - 1 == 3                                   # three discovery edges
+
+
+def test_traversal_includes_but_does_not_expand_non_seed_hubs(orc):
+    names, idx, n, off, tgt = _reference_traversal_graph()
+    d = orc.breadth_first_depths(n, off, tgt, None, [idx["a"]], 4, direction=2, hub_degree=4)
+    got = {names[v] for v in d}
+    assert "hub" in got and "leaf" not in got
+    # a seed is expanded whatever its degree (traversal.rs:238-240)
+    d = orc.breadth_first_depths(n, off, tgt, None, [idx["hub"]], 1, direction=2, hub_degree=4)
+    assert {names[v] for v in d} == {"hub", "b", "leaf", "leaf2", "leaf3"}
+    # max_depth 0 emits only the seeds; duplicate seeds collapse
+    assert orc.breadth_first_depths(n, off, tgt, None, [idx["b"], idx["b"]], 0) == {idx["b"]: 0}

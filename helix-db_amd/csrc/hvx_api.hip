@@ -129,6 +129,16 @@ int hvx_index::dalloc(void **p, size_t bytes) {
     return HVX_OK;
 }
 
+// scratch that is re-sized: the previous buffer is released first (hipFree waits for the device, so nothing in flight reads it)
+int hvx_index::regrow(void **p, size_t bytes) {
+    if (*p) {
+        (void)hipFree(*p);
+        allocs.erase(std::remove(allocs.begin(), allocs.end(), *p), allocs.end());
+        *p = nullptr;
+    }
+    return dalloc(p, bytes);
+}
+
 static uint32_t round_up(uint32_t x, uint32_t m) { return (x + m - 1) / m * m; }
 
 extern "C" int hvx_index_import(const hvx_index_desc *desc, const uint64_t *node_ids, const float *vectors,
@@ -373,17 +383,17 @@ int hvx_index::stage(uint32_t b, uint32_t k) {
     const size_t need_q = (size_t)b * dev.dim * 4, need_o = (size_t)b * k;
     int rc;
     if (need_q > cap_q) {
-        if ((rc = dalloc((void **)&s_queries, need_q))) return rc;
+        if ((rc = regrow((void **)&s_queries, need_q))) return rc;
         cap_q = need_q;
     }
     if (need_o > cap_o) {
-        if ((rc = dalloc((void **)&s_ids, need_o * 8))) return rc;
-        if ((rc = dalloc((void **)&s_scores, need_o * 4))) return rc;
+        if ((rc = regrow((void **)&s_ids, need_o * 8))) return rc;
+        if ((rc = regrow((void **)&s_scores, need_o * 4))) return rc;
         cap_o = need_o;
     }
     if (b > cap_b) {
-        if ((rc = dalloc((void **)&s_counts, (size_t)b * 4))) return rc;
-        if ((rc = dalloc((void **)&s_status, (size_t)b * 4))) return rc;
+        if ((rc = regrow((void **)&s_counts, (size_t)b * 4))) return rc;
+        if ((rc = regrow((void **)&s_status, (size_t)b * 4))) return rc;
         cap_b = b;
     }
     return HVX_OK;
@@ -602,17 +612,17 @@ int hvx_index::flat_scratch(uint32_t b, uint32_t k, uint32_t chunk_rows) {
     int rc;
     const size_t need_d = (size_t)b * chunk_rows * 4;
     if (need_d > cap_dist) {
-        if ((rc = dalloc((void **)&f_dist, need_d))) return rc;
+        if ((rc = regrow((void **)&f_dist, need_d))) return rc;
         cap_dist = need_d;
     }
     const size_t need_t = (size_t)b * k;
     if (need_t > cap_top) {
-        if ((rc = dalloc((void **)&f_top_s, need_t * 4))) return rc;
-        if ((rc = dalloc((void **)&f_top_i, need_t * 4))) return rc;
+        if ((rc = regrow((void **)&f_top_s, need_t * 4))) return rc;
+        if ((rc = regrow((void **)&f_top_i, need_t * 4))) return rc;
         cap_top = need_t;
     }
     if (b > cap_topc) {
-        if ((rc = dalloc((void **)&f_top_c, (size_t)b * 4))) return rc;
+        if ((rc = regrow((void **)&f_top_c, (size_t)b * 4))) return rc;
         cap_topc = b;
     }
     return HVX_OK;
@@ -648,12 +658,12 @@ int hvx::flat_scan_device(hvx_index *ix, const float *d_queries, uint32_t b, uin
                 const size_t dim = d.dim;
                 int r2;
                 if (nf > ix->cap_fb) {
-                    if ((r2 = ix->dalloc((void **)&ix->fb_idx, (size_t)nf * 4))) return r2;
-                    if ((r2 = ix->dalloc((void **)&ix->fb_q, (size_t)nf * dim * 4))) return r2;
-                    if ((r2 = ix->dalloc((void **)&ix->fb_ids, (size_t)nf * 1024 * 8))) return r2;
-                    if ((r2 = ix->dalloc((void **)&ix->fb_sc, (size_t)nf * 1024 * 4))) return r2;
-                    if ((r2 = ix->dalloc((void **)&ix->fb_cnt, (size_t)nf * 4))) return r2;
-                    if ((r2 = ix->dalloc((void **)&ix->fb_st, (size_t)nf * 4))) return r2;
+                    if ((r2 = ix->regrow((void **)&ix->fb_idx, (size_t)nf * 4))) return r2;
+                    if ((r2 = ix->regrow((void **)&ix->fb_q, (size_t)nf * dim * 4))) return r2;
+                    if ((r2 = ix->regrow((void **)&ix->fb_ids, (size_t)nf * 1024 * 8))) return r2;
+                    if ((r2 = ix->regrow((void **)&ix->fb_sc, (size_t)nf * 1024 * 4))) return r2;
+                    if ((r2 = ix->regrow((void **)&ix->fb_cnt, (size_t)nf * 4))) return r2;
+                    if ((r2 = ix->regrow((void **)&ix->fb_st, (size_t)nf * 4))) return r2;
                     ix->cap_fb = nf;
                 }
                 HIP_TRY(hipMemcpyAsync(ix->fb_idx, failed.data(), (size_t)nf * 4, hipMemcpyHostToDevice, ix->stream));

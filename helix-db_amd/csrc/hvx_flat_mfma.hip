@@ -453,10 +453,10 @@ int flat_mfma_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t
     const uint32_t bpad = (b + kBM - 1) / kBM * kBM;
     int rc;
     if ((size_t)bpad * d.dim > ix->cap_qsplit) {
-        if ((rc = ix->dalloc((void **)&ix->m_qhi, (size_t)bpad * d.dim * 2))) return rc;
-        if ((rc = ix->dalloc((void **)&ix->m_qlo, (size_t)bpad * d.dim * 2))) return rc;
-        if ((rc = ix->dalloc((void **)&ix->m_qn2, (size_t)bpad * 4))) return rc;
-        if ((rc = ix->dalloc((void **)&ix->m_cert, (size_t)bpad * 4))) return rc;
+        if ((rc = ix->regrow((void **)&ix->m_qhi, (size_t)bpad * d.dim * 2))) return rc;
+        if ((rc = ix->regrow((void **)&ix->m_qlo, (size_t)bpad * d.dim * 2))) return rc;
+        if ((rc = ix->regrow((void **)&ix->m_qn2, (size_t)bpad * 4))) return rc;
+        if ((rc = ix->regrow((void **)&ix->m_cert, (size_t)bpad * 4))) return rc;
         ix->cap_qsplit = (size_t)bpad * d.dim;
     }
     const bool fp8 = d.dtype == HVX_FP8_E4M3, f32 = d.dtype == HVX_F32;

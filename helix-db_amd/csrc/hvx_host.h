@@ -67,6 +67,7 @@ struct hvx_index {
     float thr_failure = -1.f;
 
     int dalloc(void **p, size_t bytes);
+    int regrow(void **p, size_t bytes);   // dalloc after releasing *p (scratch buffers that grow)
     int stage(uint32_t b, uint32_t k);
     int flat_scratch(uint32_t b, uint32_t k, uint32_t chunk_rows);
     // external id -> internal row, kSentinel when absent

@@ -323,7 +323,7 @@ static int restricted_one(hvx_index *ix, const float *queries, uint32_t b, uint3
     // query validation happens before the empty-index / empty-subset outcome (restricted.rs:556-567)
     int rc;
     if (subset.size() > ix->cap_subset) {
-        if ((rc = ix->dalloc((void **)&ix->f_subset, subset.size() * 4))) return rc;
+        if ((rc = ix->regrow((void **)&ix->f_subset, subset.size() * 4))) return rc;
         ix->cap_subset = subset.size();
     }
     if (!subset.empty())
@@ -489,7 +489,7 @@ extern "C" int hvx_prefilter_search_batch(const hvx_index *cix, const hvx_csr *c
     if (rc) return rc; // (run_bfs_locked ends with a stream synchronise: the bitmap is complete)
     const uint32_t n_words = ((g->n + 63u) / 64u) * 2u, n_blocks = (n_words + 255u) / 256u;
     if (n_blocks + 2 > ix->cap_pf_blocks) {
-        if ((rc = ix->dalloc((void **)&ix->pf_blocks, (size_t)(n_blocks + 2) * 4))) return rc;
+        if ((rc = ix->regrow((void **)&ix->pf_blocks, (size_t)(n_blocks + 2) * 4))) return rc;
         ix->cap_pf_blocks = n_blocks + 2;
     }
     uint32_t *d_total_bits = ix->pf_blocks + n_blocks + 1;
@@ -509,7 +509,7 @@ extern "C" int hvx_prefilter_search_batch(const hvx_index *cix, const hvx_csr *c
     const uint32_t kk = std::min<uint32_t>(k, population);
     if (kk > 800) return fail(HVX_ERR_K_RANGE, "restricted vector search result count %u is above the maximum 800", kk);
     if (n_rows > ix->cap_subset) {
-        if ((rc = ix->dalloc((void **)&ix->f_subset, (size_t)n_rows * 4))) return rc;
+        if ((rc = ix->regrow((void **)&ix->f_subset, (size_t)n_rows * 4))) return rc;
         ix->cap_subset = n_rows;
     }
     if (n_rows)

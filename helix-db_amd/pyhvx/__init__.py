@@ -636,6 +636,63 @@ class SimHasher:
         return int(self.hash_batch(np.asarray(vector, np.float32).reshape(1, -1))[0])
 
 
+# ---- what the reference's restricted planner would do (restricted.rs:40-56,196-260,426-453,321-342) --------------------
+# The device answers every restricted search with the exact scan; these mirrors exist so that a host can see (and log) the
+# plan the CPU path would have taken for the same request, and so that the planning rules stay pinned by the reference's tests.
+MAX_RESTRICTED_CANDIDATES = 1_000_000
+EXACT_CARDINALITY_THRESHOLD = 256
+EXACT_VECTOR_BYTES_THRESHOLD = 4 * 1024 * 1024
+FILTERED_BEAM_PERCENT = 150
+FILTERED_SAMPLED_SEEDS = 64
+FILTERED_DIRECTORY_SEEDS = 256
+MAX_RESTRICTED_RESULT_COUNT = 800
+FILTERED_VECTOR_PAYLOAD_LIMIT = MAX_RESTRICTED_RESULT_COUNT
+
+
+def restricted_result_count(requested: int, candidate_count: int) -> int:
+    """RestrictedResultCount::try_new (restricted.rs:200-213): clamp to the population FIRST, then enforce the 800 limit."""
+    count = min(int(requested), int(candidate_count))
+    if count <= 0:
+        raise HelixDbError(ERR_K_RANGE, "result count must be non-zero")
+    if count > MAX_RESTRICTED_RESULT_COUNT:
+        raise HelixDbError(ERR_K_RANGE, f"restricted vector search result count {count} is above the maximum {MAX_RESTRICTED_RESULT_COUNT}")
+    return count
+
+
+def restricted_execution_plan(candidate_count: int, dimension: int, params: SearchParams, beam_percent: int = FILTERED_BEAM_PERCENT):
+    """restricted_execution_plan_with_beam_percent (restricted.rs:426-453) + FilteredGraphBudgets::with_beam_percent (:230-259).
+    Returns {"plan": "exact" | "filtered_graph", "k": .., and for the filtered plan the row / payload / seed budgets}."""
+    n = int(candidate_count)
+    if n <= 0:
+        raise HelixDbError(ERR_INVARIANT, "an empty candidate set never reaches planning")
+    if n > MAX_RESTRICTED_CANDIDATES:
+        raise HelixDbError(ERR_CANDIDATE_LIMIT, f"restricted vector search accepts at most {MAX_RESTRICTED_CANDIDATES} unique candidates")
+    k = restricted_result_count(params.k, n)
+    if n <= EXACT_CARDINALITY_THRESHOLD and n * int(dimension) * 4 <= EXACT_VECTOR_BYTES_THRESHOLD:
+        return {"plan": "exact", "k": k}
+    if beam_percent <= 0:
+        raise ValueError("filtered beam percent is nonzero")
+    ef_filtered = min(max(params.ef * beam_percent // 100, k * 4), n)
+    vector_payloads = min(FILTERED_VECTOR_PAYLOAD_LIMIT, n)
+    assert vector_payloads >= k
+    return {"plan": "filtered_graph", "k": k, "ef_filtered": ef_filtered, "routing_rows": ef_filtered * 16,
+            "bridge_rows": ef_filtered * 8, "vector_payloads": vector_payloads,
+            "sampled_seeds": min(FILTERED_SAMPLED_SEEDS, n), "directory_seeds": min(FILTERED_DIRECTORY_SEEDS, n)}
+
+
+def deterministic_sample_ids(sorted_ids, limit: int):
+    """NonEmptyCandidateSet::deterministic_sample_ids (restricted.rs:321-342): evenly spaced ranks of the ascending id list."""
+    ids = np.asarray(sorted_ids, dtype=np.uint64)
+    n = ids.size
+    count = min(int(limit), n)
+    if count == n:
+        return ids.tolist()
+    if count == 1:
+        return [int(ids[0])]
+    last = n - 1
+    return [int(ids[(s * last) // (count - 1)]) for s in range(count)]
+
+
 def adaptive_threshold_table(configured: int, failure: float) -> np.ndarray:
     """The 64-step table the kernels evaluate policy.rs:577-599 with (threshold(delta) = #{t : delta <= brk[t-1]})."""
     brk = np.zeros(64, np.float32)

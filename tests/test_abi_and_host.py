@@ -246,3 +246,35 @@ def test_row_codecs_and_key_parser_survive_arbitrary_bytes():
         h.add_layer0_row(1, bytes([0x12, 0, 0, 0, 2]) + _be64(3))
     with pytest.raises(hv.HelixDbError):
         h.add_item(1, b"\x00\x01\x02")                           # not header || dim x f32
+
+
+def test_restricted_planner_mirror_follows_the_reference():
+    """tests/production_support/vector/restricted.rs:459-590: admission by cardinality OR bytes, the DBpedia budgets,
+    beam-percent scaling, deterministic seed sampling, clamp-before-limit of the result count."""
+    import pyhvx as hv
+    p = hv.SearchParams.new(10)
+    assert hv.restricted_execution_plan(256, 1536, p)["plan"] == "exact"
+    assert hv.restricted_execution_plan(256, 5000, p)["plan"] == "filtered_graph"        # 256 x 5000 x 4 B > 4 MiB
+    assert hv.restricted_execution_plan(257, 2, p)["plan"] == "filtered_graph"           # one id too many
+    assert p.ef == 100
+    b = hv.restricted_execution_plan(1000, 1536, p)
+    assert (b["plan"], b["ef_filtered"], b["sampled_seeds"], b["directory_seeds"], b["vector_payloads"]) == \
+        ("filtered_graph", 150, hv.FILTERED_SAMPLED_SEEDS, hv.FILTERED_DIRECTORY_SEEDS, hv.FILTERED_VECTOR_PAYLOAD_LIMIT)
+    assert (b["routing_rows"], b["bridge_rows"]) == (2400, 1200)                          # SURVEY row a11
+    for percent, want in [(100, 100), (150, 150), (200, 200), (400, 400)]:
+        assert hv.restricted_execution_plan(1000, 1536, p, beam_percent=percent)["ef_filtered"] == want
+    ids = np.arange(1, 100_001, dtype=np.uint64)
+    sample = hv.deterministic_sample_ids(ids, 256)
+    assert len(sample) == 256 and all(a < b_ for a, b_ in zip(sample, sample[1:])) and sample[0] == 1 and sample[-1] == 100_000
+    assert hv.deterministic_sample_ids([7], 1) == [7]
+    assert hv.deterministic_sample_ids([3, 7], 1) == [3] and hv.deterministic_sample_ids([3, 7], 8) == [3, 7]
+    assert hv.restricted_result_count(800, 1000) == 800
+    assert hv.restricted_result_count(1000, 800) == 800                                   # clamped before the limit applies
+    with pytest.raises(hv.HelixDbError) as e:
+        hv.restricted_result_count(801, 1000)
+    assert e.value.status == hv.ERR_K_RANGE
+    big = hv.restricted_execution_plan(1000, 1536, hv.SearchParams.new(800))
+    assert big["k"] == 800 and big["vector_payloads"] == 800
+    with pytest.raises(hv.HelixDbError) as e:
+        hv.restricted_execution_plan(1_000_001, 8, p)
+    assert e.value.status == hv.ERR_CANDIDATE_LIMIT

@@ -90,7 +90,8 @@ def main():
         se = float(np.median([b for _, b in lat])) * 1e3
         print(json.dumps({
             "workload": f"configs[2] stand-in: {n}x{dim} f32, one-hop expand of an equality group of {size} nodes -> restricted kNN k={k}, {nq} queries",
-            "candidates": size, "strategy": "exact device scan (reference: Exact iff <= 256 candidates, filtered graph walk above)",
+            "candidates": size, "strategy": "exact device scan",
+            "reference_plan": hv.restricted_execution_plan(size, dim, hv.SearchParams.new(k)),
             "expand_ms": round(ex, 3), "restricted_search_ms_per_batch": round(se, 3),
             "end_to_end_us_per_query": round((ex + se) * 1e3 / nq, 1),
             "fused_call_ms_per_batch": round(fu, 3), "fused_us_per_query": round(fu * 1e3 / nq, 1),

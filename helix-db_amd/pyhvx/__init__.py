@@ -700,6 +700,22 @@ def adaptive_threshold_table(configured: int, failure: float) -> np.ndarray:
     return brk
 
 
+CURRENT_SCORE, METRIC_DISTANCE = 0, 1  # result.rs:69-81 DistanceOutputVersion
+_UNITS = {COSINE: "HalfCosineScore", EUCLIDEAN: "SquaredEuclideanScore", MANHATTAN: "ManhattanDistance"}
+
+
+def materialize_distance(score, metric: int, version: int = CURRENT_SCORE):
+    """TypedVectorSearchResult::materialize_distance (result.rs:143-176): (value f32, unit label).  Existing responses use
+    CURRENT_SCORE; METRIC_DISTANCE takes exactly one square root of the squared-Euclidean score and never doubles the
+    half-cosine."""
+    s = np.float32(score)
+    if not np.isfinite(s) or s < 0:  # DistanceScore::try_new (parameters.rs:243-274)
+        raise HelixDbError(ERR_INVARIANT, "distance score must be finite and non-negative")
+    if metric == EUCLIDEAN and version == METRIC_DISTANCE:
+        return np.float32(np.sqrt(s)), "EuclideanDistance"
+    return s, _UNITS[metric]
+
+
 def unique_restricted_rows(rows, element_type: str = "node"):
     """interpreter/access/restricted_vector.rs:14-38: first row wins per element id; rows keyed in id order.
 

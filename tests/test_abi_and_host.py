@@ -278,3 +278,17 @@ def test_restricted_planner_mirror_follows_the_reference():
     with pytest.raises(hv.HelixDbError) as e:
         hv.restricted_execution_plan(1_000_001, 8, p)
     assert e.value.status == hv.ERR_CANDIDATE_LIMIT
+
+
+def test_distance_materialisation_follows_result_rs():
+    """result.rs:186-257: current numbers are preserved, squared Euclidean is converted exactly once on request, the
+    half-cosine is labelled and never doubled, invalid scores cannot form a result."""
+    import pyhvx as hv
+    assert hv.materialize_distance(25.0, hv.EUCLIDEAN, hv.CURRENT_SCORE) == (np.float32(25.0), "SquaredEuclideanScore")
+    assert hv.materialize_distance(25.0, hv.EUCLIDEAN, hv.METRIC_DISTANCE) == (np.float32(5.0), "EuclideanDistance")
+    for version in (hv.CURRENT_SCORE, hv.METRIC_DISTANCE):
+        assert hv.materialize_distance(0.25, hv.COSINE, version) == (np.float32(0.25), "HalfCosineScore")
+        assert hv.materialize_distance(3.0, hv.MANHATTAN, version) == (np.float32(3.0), "ManhattanDistance")
+    for invalid in (float("nan"), float("inf"), -1.0):
+        with pytest.raises(hv.HelixDbError):
+            hv.materialize_distance(invalid, hv.EUCLIDEAN)

@@ -317,3 +317,21 @@ def test_traversal_includes_but_does_not_expand_non_seed_hubs(orc):
     assert {names[v] for v in d} == {"hub", "b", "leaf", "leaf2", "leaf3"}
     # max_depth 0 emits only the seeds; duplicate seeds collapse
     assert orc.breadth_first_depths(n, off, tgt, None, [idx["b"], idx["b"]], 0) == {idx["b"]: 0}
+
+
+# --- unaligned_vector/simhash.rs tests: collision_count / hamming_distance / passes_threshold, hasher behaviour
+def test_simhash_ops_and_hasher_behaviour(orc):
+    cc = lambda a, b: int(orc.lib().orc_simhash_collisions(a, b))
+    a = 0xAAAA_AAAA_AAAA_AAAA
+    assert cc(a, a) == 64 and cc(a, 0x5555_5555_5555_5555) == 0 and cc(a, 0xAAAA_AAAA_0000_0000) == 48
+    f = 0xFFFF_FFFF_FFFF_FFFF
+    assert 64 - cc(f, f) == 0 and 64 - cc(f, 0) == 64 and 64 - cc(f, 0xFFFF_FFFF_FFFF_FFFE) == 1   # hamming distance
+    low4 = 0xFFFF_FFFF_FFFF_FFF0
+    assert cc(f, low4) >= 60 and not cc(f, low4) >= 61 and cc(f, low4) >= 50                       # passes_threshold
+    h1, h2 = orc.SimHasher(128, 42), orc.SimHasher(128, 42)                                          # reproducibility
+    ones = np.ones(128, np.float32)
+    assert h1.hash(ones) == h2.hash(ones)
+    near = ones.copy()
+    near[:13] = -1.0                                                                                # 10 % of the components flipped
+    assert cc(h1.hash(ones), h1.hash(near)) > 40
+    assert cc(h1.hash(ones), h1.hash(-ones)) < 20

@@ -288,6 +288,14 @@ class SearchParams:
         self.simhash_sampling_ratio_override = self._unit(ratio, "sampling ratio")
         return self
 
+    def clear_simhash_sampling_ratio_override(self) -> "SearchParams":
+        self.simhash_sampling_ratio_override = None
+        return self
+
+    def clear_simhash_failure_prob_override(self) -> "SearchParams":
+        self.simhash_failure_prob_override = None
+        return self
+
     def with_simhash_failure_prob(self, p: float) -> "SearchParams":
         p = float(p)
         if not np.isfinite(p) or not 0.0 < p < 1.0:  # parameters.rs:196-210

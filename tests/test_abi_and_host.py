@@ -292,3 +292,32 @@ def test_distance_materialisation_follows_result_rs():
     for invalid in (float("nan"), float("inf"), -1.0):
         with pytest.raises(hv.HelixDbError):
             hv.materialize_distance(invalid, hv.EUCLIDEAN)
+
+
+def test_search_params_replay_of_the_reference_unit_test():
+    """mod.rs:1186-1268 test_search_params, line by line, against the host mirror."""
+    import pyhvx as hv
+    P = hv.SearchParams
+    params = P.new(10).with_ef(100)
+    assert (params.k, params.ef) == (10, 100)
+    for bad in (lambda: P.new(0), lambda: P.new(100).with_ef(50), lambda: P.new(10).with_pre_simhash_sampling_ratio(2.0),
+                lambda: P.new(10).with_simhash_bypass_tuning(0, 4, 0.12, 3), lambda: P.new(10).with_simhash_bypass_tuning(24, 0, 0.12, 3),
+                lambda: P.new(10).with_simhash_bypass_tuning(24, 4, 0.12, 0), lambda: P.new(10).with_simhash_sampling_ratio(float("nan")),
+                lambda: P.new(10).with_simhash_failure_prob(1.0)):
+        with pytest.raises(hv.HelixDbError):
+            bad()
+    tuned = P.new(10).with_simhash_mode(hv.SIMHASH_OFF).with_pre_simhash_sampling_ratio(0.75) \
+        .with_simhash_bypass_tuning(2, 3, 0.25, 4).with_simhash_sampling_ratio(0.5).with_simhash_failure_prob(0.2)
+    assert tuned.simhash_mode == hv.SIMHASH_OFF and tuned.pre_simhash_sampling_ratio_override == 0.75
+    assert (tuned.simhash_bypass_min_frontier, tuned.simhash_bypass_window_expansions) == (2, 3)
+    assert (tuned.simhash_bypass_min_filter_rate, tuned.simhash_read_budget_multiplier) == (0.25, 4)
+    assert tuned.simhash_sampling_ratio_override == 0.5 and tuned.simhash_failure_prob_override == 0.2
+    c = tuned._c()
+    assert (c.simhash_mode, c.bypass_min_frontier, c.bypass_window_expansions, c.read_budget_multiplier) == (2, 2, 3, 4)
+    assert c.pre_simhash_sampling_ratio_override == np.float32(0.75) and c.simhash_failure_prob_override == np.float32(0.2)
+    cleared = tuned.clear_pre_simhash_sampling_ratio_override().clear_simhash_sampling_ratio_override() \
+        .clear_simhash_failure_prob_override()
+    assert cleared.pre_simhash_sampling_ratio_override is None and cleared.simhash_sampling_ratio_override is None
+    assert cleared.simhash_failure_prob_override is None and cleared._c().simhash_sampling_ratio_override < 0
+    profile = P.throughput_profile_floor_92(10)
+    assert profile.ef == 48 and profile.simhash_mode == hv.SIMHASH_ADAPTIVE and profile.pre_simhash_sampling_ratio_override == 0.2

@@ -13,6 +13,7 @@
 //                       [0xF0][index_id][0x16][node_id] (layer 0), [0xF0][index_id][0x11][layer u16 BE][node_id] (upper)
 // The rkyv-archived VectorIndexMetadata row is not decoded here: the host passes entry point / max layer.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <vector>
@@ -148,11 +149,40 @@ extern "C" void hvx_hydrator_free(hvx_hydrator *h) { delete h; }
 // item row = [header: f32][dim x f32], native-endian (values/vectors/item.rs:34-60; mod.rs:873-877)
 extern "C" int hvx_hydrator_add_item(hvx_hydrator *h, uint64_t node_id, const uint8_t *value, size_t len) {
     if (!h || !value) return fail(HVX_ERR_INVARIANT, "null argument");
-    if (len != 4 + (size_t)h->dim * 4) return fail(HVX_ERR_DIMENSION, "vector row of node %llu has %zu bytes, expected %zu", (unsigned long long)node_id, len, 4 + (size_t)h->dim * 4);
+    // decode_item_borrowed (mod.rs:889-949): payload length -> dimension, finiteness, then the header recomputed from the
+    // payload must equal the persisted header byte for byte (VectorItemDecodeError::{DimensionMismatch, NonFiniteComponent,
+    // HeaderMismatch}); the metric's domain rules (zero norm, magnitude) are applied by the import
+    if (len < 4 || (len - 4) % 4 != 0 || (len - 4) / 4 != h->dim)
+        return fail(HVX_ERR_DIMENSION, "vector row of node %llu: expected dimension %u, found %zu (%zu bytes)", (unsigned long long)node_id,
+                    h->dim, len >= 4 ? (len - 4) / 4 : (size_t)0, len);
+    std::vector<float> vec(h->dim);
+    memcpy(vec.data(), value + 4, (size_t)h->dim * 4);
+    for (uint32_t i = 0; i < h->dim; ++i)
+        if (!std::isfinite(vec[i])) return fail(HVX_ERR_NONFINITE, "vector row of node %llu: non-finite component %u", (unsigned long long)node_id, i);
+    float expect = 0.0f; // Euclidean / Manhattan headers are a zero bias (distance/euclidean.rs:42-44, manhattan.rs:41-43)
+    if (h->metric == HVX_COSINE_HALF) { // NodeHeaderCosine { norm } (distance/cosine.rs:89-93): scaled serial f64 norm, saturated, as f32
+        double scale = 0.0, scaled_sum = 1.0;
+        for (uint32_t i = 0; i < h->dim; ++i) {
+            const double mag = (double)std::fabs(vec[i]);
+            if (mag == 0.0) continue;
+            if (scale < mag) {
+                const double ratio = scale / mag;
+                scaled_sum = 1.0 + scaled_sum * ratio * ratio;
+                scale = mag;
+            } else {
+                const double ratio = mag / scale;
+                scaled_sum += ratio * ratio;
+            }
+        }
+        double norm = scale == 0.0 ? 0.0 : scale * std::sqrt(scaled_sum);
+        if (norm > 3.4028234663852886e+38) norm = 3.4028234663852886e+38;
+        expect = (float)norm;
+    }
+    if (memcmp(&expect, value, 4) != 0)
+        return fail(HVX_ERR_INVARIANT, "vector row of node %llu: persisted header does not match the payload (HeaderMismatch)", (unsigned long long)node_id);
     auto &n = h->nodes[node_id];
-    memcpy(&n.header, value, 4);
-    n.vec.resize(h->dim);
-    memcpy(n.vec.data(), value + 4, (size_t)h->dim * 4);
+    n.header = expect;
+    n.vec = std::move(vec);
     n.has_vec = true;
     return HVX_OK;
 }

@@ -321,3 +321,35 @@ def test_search_params_replay_of_the_reference_unit_test():
     assert cleared.simhash_failure_prob_override is None and cleared._c().simhash_sampling_ratio_override < 0
     profile = P.throughput_profile_floor_92(10)
     assert profile.ef == 48 and profile.simhash_mode == hv.SIMHASH_ADAPTIVE and profile.pre_simhash_sampling_ratio_override == 0.2
+
+
+def test_item_rows_are_decoded_like_decode_item(orc):
+    """mod.rs:1349-1391 item_decoder_rejects_dimension_finiteness_header_and_trailing_payload_corruption, against the
+    hydrator's item-row entry point (`[header f32][dim x f32]`, native-endian: values/vectors/item.rs:34-60)."""
+    import pyhvx as hv
+    v = np.array([1.0, 2.0, 3.0], np.float32)
+    encoded = np.float32(orc.header(orc.COSINE, v)).tobytes() + v.tobytes()       # encode_item: Cosine::new_header || payload
+    hv.Hydrator(3, hv.COSINE).add_item(1, encoded)                                  # the row itself decodes
+    with pytest.raises(hv.HelixDbError) as e:                                       # DimensionMismatch { expected: 2, actual: 3 }
+        hv.Hydrator(2, hv.COSINE).add_item(1, encoded)
+    assert e.value.status == hv.ERR_DIMENSION
+    with pytest.raises(hv.HelixDbError) as e:                                       # trailing 4.0: DimensionMismatch { 3, 4 }
+        hv.Hydrator(3, hv.COSINE).add_item(1, encoded + np.float32(4.0).tobytes())
+    assert e.value.status == hv.ERR_DIMENSION
+    non_finite = bytearray(encoded)
+    non_finite[4:8] = np.float32(np.nan).tobytes()
+    with pytest.raises(hv.HelixDbError) as e:                                       # NonFiniteComponent { index: 0 }
+        hv.Hydrator(3, hv.COSINE).add_item(1, bytes(non_finite))
+    assert e.value.status == hv.ERR_NONFINITE
+    wrong_header = bytearray(encoded)
+    wrong_header[0] ^= 1
+    with pytest.raises(hv.HelixDbError) as e:                                       # HeaderMismatch
+        hv.Hydrator(3, hv.COSINE).add_item(1, bytes(wrong_header))
+    assert e.value.status == hv.ERR_INVARIANT and "HeaderMismatch" in str(e.value)
+    # Euclidean / Manhattan rows carry a zero bias
+    hv.Hydrator(3, hv.EUCLIDEAN).add_item(1, np.float32(0).tobytes() + v.tobytes())
+    with pytest.raises(hv.HelixDbError):
+        hv.Hydrator(3, hv.EUCLIDEAN).add_item(1, np.float32(1).tobytes() + v.tobytes())
+    # f32 extremes: the persisted cosine header of a huge vector is the saturated norm (cosine.rs:128-141)
+    huge = np.array([np.finfo(np.float32).max] * 2, np.float32)
+    hv.Hydrator(2, hv.COSINE).add_item(2, np.float32(orc.header(orc.COSINE, huge)).tobytes() + huge.tobytes())

@@ -353,3 +353,40 @@ def test_item_rows_are_decoded_like_decode_item(orc):
     # f32 extremes: the persisted cosine header of a huge vector is the saturated norm (cosine.rs:128-141)
     huge = np.array([np.finfo(np.float32).max] * 2, np.float32)
     hv.Hydrator(2, hv.COSINE).add_item(2, np.float32(orc.header(orc.COSINE, huge)).tobytes() + huge.tobytes())
+
+
+def test_device_index_registry_attaches_only_exact_generation_and_sequence():
+    """tests/production_support/vector/read_index.rs:60-140: exact generation + snapshot sequence attach the resident
+    copy; stale / newer / unavailable visibility, other identities and unfinished hydrations fall back to storage; a
+    different distance is a MetricMismatch; guards fence retirement."""
+    import pyhvx as hv
+    from pyhvx import registry as rg
+
+    class FakeIndex:
+        closed = False
+
+        def close(self):
+            self.closed = True
+
+    reg = rg.DeviceIndexRegistry()
+    ident = rg.VectorCacheIdentity("legacy-unscoped", 4, 1, 40, 1)
+    assert reg.entry_for(ident, hv.COSINE) is True            # this caller owns the hydration
+    assert reg.entry_for(ident, hv.COSINE) is False           # nobody else does
+    assert reg.attach(ident, hv.COSINE, 9) is None            # still hydrating: storage fallback
+    ix = FakeIndex()
+    assert reg.finish_hydration(ident, ix, 9) is True
+    exact = reg.attach(ident, hv.COSINE, 9)
+    assert exact is not None and exact.index is ix
+    assert reg.attach(ident, hv.COSINE, 10) is None           # stale for a newer snapshot
+    assert reg.attach(ident, hv.COSINE, 8) is None            # newer than an older snapshot
+    assert reg.attach(ident, hv.COSINE, None) is None         # VectorReadVisibility::Unavailable
+    with pytest.raises(rg.MetricMismatch):
+        reg.attach(ident, hv.EUCLIDEAN, 9)
+    other = rg.VectorCacheIdentity("legacy-unscoped", 4, 2, 40, 1)   # next generation of the same index
+    assert reg.attach(other, hv.COSINE, 9) is None
+    reg.retire(ident)                                         # replaced: no new guards, memory kept while `exact` lives
+    assert reg.state(ident) == rg.RETIRING and not ix.closed and reg.attach(ident, hv.COSINE, 9) is None
+    exact.release()
+    assert ix.closed and reg.state(ident) == rg.CLOSED
+    assert reg.entry_for(ident, hv.COSINE) is True            # a closed entry can be hydrated again
+    assert reg.finish_hydration(other, FakeIndex(), 9) is False      # never registered: the caller keeps its index

@@ -4,7 +4,7 @@ set -e
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 rm -rf /tmp/pmc_$tag
-rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$tag -o $tag -- python bench.py --steps 5 --warmup 2 --cpu-seconds 0 --no-verify --graph-cache /tmp/g > /tmp/pmc_$tag.log 2>&1 || { tail -5 /tmp/pmc_$tag.log; exit 1; }
+rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$tag -o $tag -- python bench.py --steps 5 --warmup 2 --cpu-seconds 0 --no-verify --no-production-default --graph-cache /tmp/g > /tmp/pmc_$tag.log 2>&1 || { tail -5 /tmp/pmc_$tag.log; exit 1; }
 mkdir -p gpurun_out/pmc
 f=$(ls /tmp/pmc_$tag/*counter_collection.csv | head -1)
 head -1 "$f" > gpurun_out/pmc/${tag}_hnsw.csv

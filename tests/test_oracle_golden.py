@@ -200,6 +200,10 @@ def test_circle_fixture_10k_recall_gate(orc):
     assert _circle_recall(orc, 10_000) >= 0.995
 
 
+def test_circle_fixture_100k_recall_gate(orc):   # scale_contracts.rs:219-270, the largest of the reference's three sizes
+    assert _circle_recall(orc, 100_000) >= 0.995
+
+
 # --- tests/production_support/index_lifecycle_scale.rs:410-421,1332-1359: generator + top-1 of vector(0)
 def test_lifecycle_generator_and_flat_top1(orc):
     m = fx.lifecycle_matrix(8000)

@@ -390,3 +390,12 @@ def test_device_index_registry_attaches_only_exact_generation_and_sequence():
     assert ix.closed and reg.state(ident) == rg.CLOSED
     assert reg.entry_for(ident, hv.COSINE) is True            # a closed entry can be hydrated again
     assert reg.finish_hydration(other, FakeIndex(), 9) is False      # never registered: the caller keeps its index
+
+
+def test_topk_payload_layout_is_shared_by_library_and_host():
+    """hvx_topk_payload_bytes == pyhvx.shard.payload_bytes for every (b, k): ids | scores | counts, padded to 8 bytes."""
+    import pyhvx as hv
+    from pyhvx import shard
+    for b, k in [(1, 1), (7, 10), (33, 10), (1024, 10), (1024, 100), (5, 3), (4096, 7)]:
+        n = hv.lib().hvx_topk_payload_bytes(b, k)
+        assert n == shard.payload_bytes(b, k) and n % 8 == 0 and n >= b * k * 12 + b * 4

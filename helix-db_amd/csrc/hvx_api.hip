@@ -93,7 +93,10 @@ template <typename F> static void parallel_for(uint64_t n, F f) {
 static void free_index(hvx_index *ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
-    for (void *p : ix->allocs) (void)hipFree(p);
+    if (ix->stream) (void)hipStreamSynchronize(ix->stream); // nothing in flight reads the scratch released below
+    ix->allocs->device = ix->device;
+    ix->allocs.reset(); // own scratch (and, for the root handle, its reference on the index image)
+    ix->image.clear();
     if (ix->ev0) (void)hipEventDestroy(ix->ev0);
     if (ix->ev1) (void)hipEventDestroy(ix->ev1);
     for (hipEvent_t e : ix->ring) (void)hipEventDestroy(e);
@@ -107,6 +110,14 @@ extern "C" int hvx_index_sync(const hvx_index *ix) {
     if (!ix) return fail(HVX_ERR_INVARIANT, "null index");
     HIP_TRY(hipSetDevice(ix->device));
     HIP_TRY(hipStreamSynchronize(ix->stream));
+    return HVX_OK;
+}
+
+extern "C" int hvx_index_set_occupancy(hvx_index *ix, uint32_t queries_per_simd) {
+    if (!ix) return fail(HVX_ERR_INVARIANT, "null index");
+    if (queries_per_simd != 1 && queries_per_simd != 2) return fail(HVX_ERR_K_RANGE, "occupancy must be 1 or 2 queries per SIMD");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    ix->occupancy = queries_per_simd;
     return HVX_OK;
 }
 
@@ -125,7 +136,8 @@ int hvx_index::dalloc(void **p, size_t bytes) {
     if (bytes == 0) bytes = 16;
     hipError_t e = hipMalloc(p, bytes);
     if (e != hipSuccess) return fail(HVX_ERR_DEVICE, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
-    allocs.push_back(*p);
+    allocs->device = device;
+    allocs->v.push_back(*p);
     return HVX_OK;
 }
 
@@ -133,7 +145,7 @@ int hvx_index::dalloc(void **p, size_t bytes) {
 int hvx_index::regrow(void **p, size_t bytes) {
     if (*p) {
         (void)hipFree(*p);
-        allocs.erase(std::remove(allocs.begin(), allocs.end(), *p), allocs.end());
+        allocs->v.erase(std::remove(allocs->v.begin(), allocs->v.end(), *p), allocs->v.end());
         *p = nullptr;
     }
     return dalloc(p, bytes);
@@ -191,7 +203,7 @@ extern "C" int hvx_index_import(const hvx_index_desc *desc, const uint64_t *node
     ix->stream = ix->own_stream;
 
     // ---- ids: strictly ascending; contiguous ranges get an arithmetic id->index map ----
-    ix->ids.assign(node_ids, node_ids + n);
+    ix->ids_p = std::make_shared<std::vector<uint64_t>>(node_ids, node_ids + n);
     ix->contiguous = true;
     for (uint64_t i = 1; i < n; ++i) {
         if (node_ids[i] <= node_ids[i - 1]) return bail(fail(HVX_ERR_INVARIANT, "node_ids must be strictly ascending (row %llu)", (unsigned long long)i));
@@ -302,7 +314,7 @@ extern "C" int hvx_index_import(const hvx_index_desc *desc, const uint64_t *node
     if ((rc = upload(h_up.data(), h_up.size() * 4, (const void **)&d.up))) return bail_free(rc);
     if ((rc = upload(h_up_base.data(), h_up_base.size() * 4, (const void **)&d.up_base))) return bail_free(rc);
     if ((rc = upload(h_level.data(), h_level.size() * 2, (const void **)&d.level))) return bail_free(rc);
-    if ((rc = upload(ix->ids.data(), ix->ids.size() * 8, (const void **)&d.ids))) return bail_free(rc);
+    if ((rc = upload(ix->ids_ref().data(), ix->ids_ref().size() * 8, (const void **)&d.ids))) return bail_free(rc);
 
     // ---- validate rows + headers ONCE on the device (decode_item_borrowed does it per fetch:
     //      mod.rs:889-949) ----
@@ -372,6 +384,60 @@ extern "C" int hvx_index_import(const hvx_index_desc *desc, const uint64_t *node
     if ((rc = ix->dalloc((void **)&ix->d_qhdr, (size_t)mb * 4))) return bail(rc);
     if ((rc = ix->dalloc((void **)&ix->d_tie, (size_t)mb * 4))) return bail(rc);
     if ((rc = ix->dalloc((void **)&ix->d_qstats, (size_t)mb * sizeof(hvx_query_stats)))) return bail(rc);
+    *out = ix;
+    return HVX_OK;
+}
+
+// An execution lane on the same index image: own stream, events, per-batch scratch and mutex; rows, graph, ids, headers
+// and SimHash rows are shared with (and kept alive by) the handle it was forked from.
+extern "C" int hvx_index_fork(const hvx_index *parent, hvx_index **out) {
+    if (!parent || !out) return fail(HVX_ERR_INVARIANT, "null argument");
+    *out = nullptr;
+    hvx_index *src = const_cast<hvx_index *>(parent);
+    std::lock_guard<std::mutex> lock(src->mu);
+    HIP_TRY(hipSetDevice(src->device));
+    hvx_index *ix = new hvx_index();
+    ix->device = src->device;
+    ix->desc = src->desc;
+    ix->dev = src->dev;
+    ix->limit = src->limit;
+    ix->max_batch = src->max_batch;
+    ix->words_per_query = src->words_per_query;
+    ix->ids_p = src->ids_p;
+    ix->contiguous = src->contiguous;
+    ix->occupancy = src->occupancy;
+    ix->is_fork = true;
+    ix->image = src->image;
+    ix->image.push_back(src->allocs);
+    ix->m_rowterm = src->m_rowterm;
+    ix->m_xmax2 = src->m_xmax2;
+    ix->has_simhash = src->has_simhash;
+    ix->sh_cfg = src->sh_cfg;
+    ix->d_node_hash = src->d_node_hash;
+    ix->d_planes_t = src->d_planes_t;
+    auto bail = [&](int code) { free_index(ix); return code; };
+    if (hipStreamCreateWithFlags(&ix->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ix->ev0) != hipSuccess || hipEventCreate(&ix->ev1) != hipSuccess)
+        return bail(fail(HVX_ERR_DEVICE, "stream/event creation failed"));
+    ix->stream = ix->own_stream;
+    int rc;
+    const uint32_t mb = ix->max_batch;
+    const size_t bm_bytes = (size_t)mb * ix->words_per_query * 4;
+    if ((rc = ix->dalloc((void **)&ix->d_bitmap, bm_bytes))) return bail(rc);
+    if (hipMemset(ix->d_bitmap, 0, bm_bytes) != hipSuccess) return bail(fail(HVX_ERR_DEVICE, "bitmap clear failed"));
+    if ((rc = ix->dalloc((void **)&ix->d_qstatus, (size_t)mb * 4))) return bail(rc);
+    if ((rc = ix->dalloc((void **)&ix->d_qhdr, (size_t)mb * 4))) return bail(rc);
+    if ((rc = ix->dalloc((void **)&ix->d_tie, (size_t)mb * 4))) return bail(rc);
+    if ((rc = ix->dalloc((void **)&ix->d_qstats, (size_t)mb * sizeof(hvx_query_stats)))) return bail(rc);
+    if (ix->has_simhash) { // per-batch state of the non-strict arms (hvx_params.hip)
+        if ((rc = ix->dalloc((void **)&ix->d_qhash, (size_t)mb * 8))) return bail(rc);
+        if ((rc = ix->dalloc((void **)&ix->d_thr_break, 64 * 4))) return bail(rc);
+        if ((rc = ix->dalloc((void **)&ix->d_astats, (size_t)mb * sizeof(hvx_adaptive_stats)))) return bail(rc);
+        if (!ix->sh_cfg.resident_snapshot) {
+            if ((rc = ix->dalloc((void **)&ix->d_bitmap2, bm_bytes))) return bail(rc);
+            if (hipMemset(ix->d_bitmap2, 0, bm_bytes) != hipSuccess) return bail(fail(HVX_ERR_DEVICE, "bitmap clear failed"));
+        }
+    }
     *out = ix;
     return HVX_OK;
 }
@@ -455,6 +521,8 @@ int hvx::enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t b
     a.prof = nullptr;
     a.adaptive = ad ? 1u : 0u;
     a.ad = ad ? *ad : AdaptArgs{};
+    a.occupancy = ix->occupancy;
+    if (const char *e = getenv("HVX_WAVE_OCC")) a.occupancy = (uint32_t)atoi(e); // tuning hook
     if (ad) {
         if (!hnsw_wave_adaptive_supported(a))
             return fail(HVX_ERR_UNSUPPORTED, "the non-strict search arms are served by the one-wavefront-per-query kernel only "

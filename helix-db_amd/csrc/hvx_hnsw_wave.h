@@ -60,6 +60,7 @@ struct Visited {
     uint32_t *bm;       // HBM bitmap of this query (all-zero on entry, handed back all-zero)
     uint32_t *bm2;      // second bitmap: SimHash-row-cached ids in bitmap mode (uncached-handle read accounting only; may be NULL)
     uint32_t mask, shift, cap, words;
+    uint32_t limit;     // uniform: spill to the bitmap once count + 64 would exceed this many table entries
     uint32_t count;     // uniform: ids inserted into the table since the last clear
     bool spilled;       // uniform: bitmap mode
 
@@ -89,7 +90,7 @@ struct Visited {
     // store -- one LDS probe loop per expansion instead of a test loop plus an insert loop.  In bitmap mode claim() is
     // a bit test and commit() the atomicOr.  Returns true for unseen ids; ids must be < 2^31 - 1.
     __device__ __forceinline__ bool claim(uint32_t id, bool valid, int lane, uint32_t &slot_out, bool &hashed_out) {
-        if (!spilled && count + 64u > cap - (cap >> 2)) spill(lane);
+        if (!spilled && count + 64u > limit) spill(lane);
         hashed_out = false;
         if (spilled) {
             if (valid && bm2) hashed_out = (__hip_atomic_load(&bm2[id >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (id & 31u)) & 1u;
@@ -149,7 +150,7 @@ struct Visited {
     }
     // test-and-set for the lanes with valid==true (ids distinct across lanes); true = newly inserted
     __device__ __forceinline__ bool insert(uint32_t id, bool valid, int lane) {
-        if (!spilled && count + 64u > cap - (cap >> 2)) spill(lane);
+        if (!spilled && count + 64u > limit) spill(lane);
         bool isnew = false;
         if (spilled) {
             if (valid) {
@@ -465,13 +466,18 @@ __device__ __forceinline__ float candidate_probability_fn(uint32_t kind, float b
 // beam search; AD=false is the strict-exhaustive arm and compiles to exactly the code it was before.
 // ST=false drops the SearchStats counters of the non-strict stages (the reference's COLLECT_DIAGNOSTICS=false
 // specialisation, search.rs:267-270): seventeen fewer live scalars, which is what keeps the AD kernels out of SGPR spills.
-template <uint32_t METRIC, int R, int NK, bool BF, bool PROF = false, bool AD = false, bool ST = true>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void hnsw_wave_kernel(HnswArgs a, uint32_t log2cap) {
+// OCC = wavefronts per SIMD the build is register-budgeted for: 1 = one query owns the SIMD's whole 512-register file
+// (passes of up to 32 rows in flight), 2 = two queries share a SIMD (256 registers each, passes of up to 16 rows, half the
+// LDS): the row gathers of one query run underneath the beam bookkeeping of the other -- the build for callers that keep
+// >= 2 batches in flight (execution lanes, hvx_index_fork).
+template <uint32_t METRIC, int R, int NK, bool BF, bool PROF = false, bool AD = false, bool ST = true, int OCC = 1>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void hnsw_wave_kernel(HnswArgs a, uint32_t log2cap) {
     // rows per 8-lane group in flight: P*NK <= 24 float4 per lane for a narrow pass, x2 and x4 for wider
     // frontiers (4P*NK <= 96 float4 = 384 registers, VGPR+AGPR file of one wave per SIMD)
     constexpr int NL = BF ? NK / 2 : NK;        // 16-byte loads per lane and row
     constexpr int P = NL <= 8 ? 2 : 1;
-    constexpr bool kWide4 = 4 * P * NL <= 96;
+    constexpr bool kWide4 = OCC == 1 && 4 * P * NL <= 96;
+    constexpr bool kWide2 = OCC == 1 || 2 * P * NL <= 48; // 192 of the 256 registers of a half-SIMD wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const DevIndex &ix = a.ix;
     const uint32_t q = blockIdx.x;
@@ -483,6 +489,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     V.cap = 1u << log2cap;
     V.mask = V.cap - 1u;
     V.shift = 32u - log2cap;
+    V.limit = OCC == 1 ? V.cap - (V.cap >> 2) : V.cap - (V.cap >> 3); // 3/4 full; 7/8 for the half-LDS build
     V.words = a.words_per_query;
     V.bm = a.bitmap + (size_t)q * a.words_per_query;
     V.bm2 = (AD && a.bitmap2) ? a.bitmap2 + (size_t)q * a.words_per_query : nullptr;
@@ -537,7 +544,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             const uint32_t rem = nf - f0;
             if (kWide4 && rem > 24u * P) { pass(std::integral_constant<int, kWide4 ? 4 * P : P>{}, f0, nf); f0 += 32u * P; }
             else if (kWide4 && rem > 16u * P) { pass(std::integral_constant<int, kWide4 ? 3 * P : P>{}, f0, nf); f0 += 24u * P; }
-            else if (rem > 8u * P) { pass(std::integral_constant<int, 2 * P>{}, f0, nf); f0 += 16u * P; }
+            else if (kWide2 && rem > 8u * P) { pass(std::integral_constant<int, kWide2 ? 2 * P : P>{}, f0, nf); f0 += 16u * P; }
             else { pass(std::integral_constant<int, P>{}, f0, nf); f0 += 8u * P; }
         }
         __syncthreads();
@@ -921,6 +928,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 struct WaveGeom {
     uint32_t log2cap;
     size_t lds;
+    uint32_t occ; // wavefronts per SIMD the launch is budgeted for (1 or 2)
 };
 
 // per-metric launchers, defined in hvx_hnsw_wave_l2.hip / hvx_hnsw_wave_cos.hip / hvx_hnsw_wave_prof.hip
@@ -929,6 +937,8 @@ hipError_t launch_hnsw_wave_cos(const HnswArgs &a, uint32_t b, const WaveGeom &g
 hipError_t launch_hnsw_wave_l2_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_cos_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_prof(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+// two queries per SIMD (OCC = 2 builds), hvx_hnsw_wave_occ2.hip
+hipError_t launch_hnsw_wave_occ2(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 // non-strict arms (AD instantiations), hvx_hnsw_wave_l2_ad.hip / hvx_hnsw_wave_cos_ad.hip
 hipError_t launch_hnsw_wave_l2_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_cos_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
@@ -944,24 +954,24 @@ template <typename K> static hipError_t launch_wave_kernel(K kern, const HnswArg
     return hipGetLastError();
 }
 
-template <uint32_t METRIC, int R, bool BF, bool AD = false, bool ST = true>
+template <uint32_t METRIC, int R, bool BF, bool AD = false, bool ST = true, int OCC = 1>
 static hipError_t launch_wave_nk(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
     switch (a.ix.dim >> 5) {
-    case 4: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 4, BF, false, AD, ST>, a, b, g, s);
-    case 8: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 8, BF, false, AD, ST>, a, b, g, s);
-    case 16: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 16, BF, false, AD, ST>, a, b, g, s);
-    case 24: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 24, BF, false, AD, ST>, a, b, g, s);
-    case 32: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 32, BF, false, AD, ST>, a, b, g, s);
-    case 48: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 48, BF, false, AD, ST>, a, b, g, s);
+    case 4: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 4, BF, false, AD, ST, OCC>, a, b, g, s);
+    case 8: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 8, BF, false, AD, ST, OCC>, a, b, g, s);
+    case 16: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 16, BF, false, AD, ST, OCC>, a, b, g, s);
+    case 24: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 24, BF, false, AD, ST, OCC>, a, b, g, s);
+    case 32: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 32, BF, false, AD, ST, OCC>, a, b, g, s);
+    case 48: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 48, BF, false, AD, ST, OCC>, a, b, g, s);
     default: return hipErrorInvalidValue;
     }
 }
 
-template <uint32_t METRIC, bool BF, bool AD = false, bool ST = true>
+template <uint32_t METRIC, bool BF, bool AD = false, bool ST = true, int OCC = 1>
 static hipError_t launch_wave_r(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
     const uint32_t need = a.ef + 32u; // beam capacity 64*R must hold ef plus slack for equal-score evictions
-    if (need <= 192) return launch_wave_nk<METRIC, 3, BF, AD, ST>(a, b, g, s);
-    if (need <= 384) return launch_wave_nk<METRIC, 6, BF, AD, ST>(a, b, g, s);
+    if (need <= 192) return launch_wave_nk<METRIC, 3, BF, AD, ST, OCC>(a, b, g, s);
+    if (need <= 384) return launch_wave_nk<METRIC, 6, BF, AD, ST, OCC>(a, b, g, s);
     return hipErrorInvalidValue;
 }
 // non-strict arms: with the per-query SearchStats of the filter / sampling stages when the caller asked for them,

@@ -3,10 +3,23 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <memory>
 #include <mutex>
 #include <vector>
 
 #include "hvx_kernels.h"
+
+// Device allocations of one handle.  A fork (hvx_index_fork) keeps its parent's holder alive: the immutable index image
+// (rows, graph, ids, headers, SimHash rows) is freed when the last handle that references it is gone.
+struct hvx_allocs {
+    int device = 0;
+    std::vector<void *> v;
+    ~hvx_allocs() {
+        if (v.empty()) return;
+        (void)hipSetDevice(device);
+        for (void *p : v) (void)hipFree(p);
+    }
+};
 
 struct hvx_index {
     int device = 0;
@@ -15,6 +28,7 @@ struct hvx_index {
     float limit = 0.f;               // VectorComponentLimit (domain.rs:26-78); +inf for cosine
     uint32_t max_batch = 1024;
     uint32_t words_per_query = 0;
+    uint32_t occupancy = 1;          // wave kernel build: queries per SIMD (hvx_index_set_occupancy)
     bool bitmap_dirty = false;       // d_bitmap holds stale visited bits (general kernel ran last)
     hipStream_t stream = nullptr;      // stream in use
     hipStream_t own_stream = nullptr;  // created at import
@@ -22,8 +36,11 @@ struct hvx_index {
     std::vector<hipEvent_t> ring;    // asynchronous timing: event pairs of the searches since hvx_index_timing_begin
     uint32_t ring_cap = 0, ring_n = 0;
     std::mutex mu;                   // calls on one index are serialised on its stream
-    std::vector<void *> allocs;
-    std::vector<uint64_t> ids;       // host copy of node ids (id -> internal index lookups)
+    std::shared_ptr<hvx_allocs> allocs = std::make_shared<hvx_allocs>();
+    std::vector<std::shared_ptr<hvx_allocs>> image; // fork: the allocations of the handles it descends from (the image it aliases)
+    bool is_fork = false;
+    std::shared_ptr<const std::vector<uint64_t>> ids_p = std::make_shared<std::vector<uint64_t>>(); // host copy of node ids
+    const std::vector<uint64_t> &ids_ref() const { return *ids_p; }
     bool contiguous = false;
     // per-batch device scratch
     uint32_t *d_bitmap = nullptr, *d_qstatus = nullptr, *d_tie = nullptr;
@@ -72,6 +89,7 @@ struct hvx_index {
     int flat_scratch(uint32_t b, uint32_t k, uint32_t chunk_rows);
     // external id -> internal row, kSentinel when absent
     uint32_t find(uint64_t id) const {
+        const std::vector<uint64_t> &ids = *ids_p;
         if (ids.empty()) return hvx::kSentinel;
         if (contiguous) {
             if (id < ids[0] || id - ids[0] >= ids.size()) return hvx::kSentinel;

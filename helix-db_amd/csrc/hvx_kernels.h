@@ -46,6 +46,7 @@ struct HnswArgs {
     uint32_t *tie_flags;       // [b] nullable
     unsigned long long *prof;  // [b][8] phase cycle counters of the PROF kernel variant, nullable
     uint32_t adaptive;         // 0 = strict-exhaustive search; 1 = non-strict arms, policy in `ad`
+    uint32_t occupancy;        // wave kernel: 2 = the two-queries-per-SIMD build (callers with >= 2 batches in flight), else 1
     AdaptArgs ad;
 };
 

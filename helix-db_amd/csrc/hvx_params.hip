@@ -52,6 +52,7 @@ extern "C" int hvx_index_set_simhash(hvx_index *ix, const hvx_simhash_config *cf
     if (cfg->simhash_threshold > 64) return fail(HVX_ERR_K_RANGE, "collision threshold %u exceeds the 64-bit SimHash width", cfg->simhash_threshold);
     if (!unit_interval(cfg->sampling_ratio)) return fail(HVX_ERR_K_RANGE, "sampling ratio outside the closed unit interval");
     if (!open_unit(cfg->adaptive_failure_prob)) return fail(HVX_ERR_K_RANGE, "failure probability outside the open unit interval");
+    if (ix->is_fork) return fail(HVX_ERR_INVARIANT, "SimHash rows belong to the index image: attach them to the handle returned by import, then fork");
     std::lock_guard<std::mutex> lock(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));
     const uint32_t n = ix->dev.n, dim = ix->dev.dim;

@@ -124,6 +124,10 @@ def lib():
     L.hvx_index_stream.argtypes = [_vp]
     L.hvx_index_set_stream.restype = C.c_int
     L.hvx_index_set_stream.argtypes = [_vp, _vp]
+    L.hvx_index_fork.restype = C.c_int
+    L.hvx_index_fork.argtypes = [_vp, C.POINTER(_vp)]
+    L.hvx_index_set_occupancy.restype = C.c_int
+    L.hvx_index_set_occupancy.argtypes = [_vp, C.c_uint32]
     L.hvx_index_timing_begin.restype = C.c_int
     L.hvx_index_timing_begin.argtypes = [_vp, C.c_uint32]
     L.hvx_index_timing_collect.restype = C.c_int
@@ -532,6 +536,18 @@ class ValidatedVectorReadIndex:
 
     def sync(self):
         _check(lib().hvx_index_sync(self._h))
+
+    def fork(self) -> "ValidatedVectorReadIndex":
+        """Another execution lane on the same device image (own stream + scratch); see hvx_index_fork."""
+        h = _vp()
+        _check(lib().hvx_index_fork(self._h, C.byref(h)))
+        return type(self)(h, self.dim, self.metric, self.n)
+
+    def set_occupancy(self, queries_per_simd: int):
+        _check(lib().hvx_index_set_occupancy(self._h, queries_per_simd))
+
+    def stream(self) -> int:
+        return int(lib().hvx_index_stream(self._h) or 0)
 
     def set_stream(self, hip_stream):
         """Enqueue on a caller-owned hipStream_t (int handle, e.g. torch.cuda.current_stream().cuda_stream)."""

@@ -64,6 +64,40 @@ def gaussian_sphere(n: int, dim: int, n_queries: int, seed: int, device):
     return x / x.norm(dim=1, keepdim=True), q / q.norm(dim=1, keepdim=True)
 
 
+def clustered(n: int, dim: int, n_queries: int, seed: int, device, centres: int = 1024, sigma: float = 0.15, chunk: int = 1 << 18):
+    """SURVEY.md 8(d) C2, the clustered variant: `centres` Gaussian centres drawn N(0, I) in the native `dim`-d space,
+    rows = centre + sigma * N(0, I), L2-normalised like the i.i.d. corpus (so cosine and L2 rank identically);
+    queries are held-out draws of the same mixture.  No low-dimensional latent structure: inside a cluster the rows are
+    again i.i.d. Gaussian in `dim` dimensions."""
+    dev = torch.device(device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    c = torch.randn(centres, dim, generator=g, device=dev)
+
+    def draw(count):
+        out = torch.empty(count, dim, device=dev, dtype=torch.float32)
+        for s in range(0, count, chunk):
+            m = min(chunk, count - s)
+            which = torch.randint(0, centres, (m,), generator=g, device=dev)
+            x = c[which] + sigma * torch.randn(m, dim, generator=g, device=dev)
+            out[s:s + m] = x / x.norm(dim=1, keepdim=True)
+        return out
+
+    return draw(n), draw(n_queries)
+
+
+def corpus(name: str, n: int, dim: int, n_queries: int, seed: int, device, **kw):
+    """The benchmark corpora by name: 'gaussian' (SURVEY 8d as literally written), 'clustered' (its stated clustered
+    variant), 'embedding' (low intrinsic dimension, what learned embeddings look like)."""
+    if name == "gaussian":
+        return gaussian_sphere(n, dim, n_queries, seed, device)
+    if name == "clustered":
+        return clustered(n, dim, n_queries, seed, device, **kw)
+    if name == "embedding":
+        return embedding_like(n, dim, n_queries, seed, device, **kw)
+    raise ValueError(f"unknown corpus {name!r}")
+
+
 def draw_levels(n: int, m: int, seed: int) -> np.ndarray:
     """select_layer_from_uniform (mod.rs:776-796): floor(-ln(U) * ml), U clamped to
     [MIN_POSITIVE, 1-eps], capped at 63; ml = 1/ln(max(m,2)) (mod.rs:705-708)."""

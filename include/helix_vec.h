@@ -104,6 +104,19 @@ void *hvx_index_stream(const hvx_index *);
 /* enqueue on a caller-owned stream instead (e.g. the host runtime's current stream, so that
  * collectives and searches order without host synchronisation); NULL restores the index's own. */
 int hvx_index_set_stream(hvx_index *, void *hip_stream);
+/*
+ * Execution lanes.  The reference's facade is called concurrently from many tokio tasks on one immutable index
+ * (read_index.rs:83-102, access/search/storage.rs:140-163).  hvx_index_fork returns another handle on the SAME device image
+ * (rows, graph, ids, headers, SimHash rows are shared, not copied) with its own HIP stream, events, per-batch scratch and
+ * lock: calls on different handles of one image run concurrently on the device -- a host thread (or a pipelined caller
+ * that keeps several batches in flight) uses one handle per lane.  The image lives until the last handle referencing it
+ * is freed, in any order.  Attach SimHash rows (hvx_index_set_simhash) to the imported handle BEFORE forking.
+ */
+int hvx_index_fork(const hvx_index *, hvx_index **out);
+/* HNSW kernel build used by this handle: 1 (default) = one query per SIMD with the SIMD's whole register file (lowest
+ * latency of a lone batch); 2 = two queries per SIMD, half the registers / LDS each -- higher throughput when >= 2 batches
+ * are in flight on the device (lanes).  Results are identical.  Shapes without a 2-per-SIMD build run the default. */
+int hvx_index_set_occupancy(hvx_index *, uint32_t queries_per_simd);
 /* Asynchronous kernel timing for pipelined callers: after _begin(capacity), every HNSW search call that is NOT asked
  * for hvx_stats brackets its search kernel with the next HIP-event pair of a ring instead of synchronising;
  * _collect waits for the stream once and returns the per-call kernel durations (ms) in call order, then disarms. */

@@ -488,11 +488,12 @@ static void add_stats(hvx_stats *stats, const std::vector<hvx_query_stats> &qs, 
 
 // enqueue validation + memset + search kernel for one chunk of <= max_batch queries
 // the event pair a search kernel is bracketed with: the synchronous stats pair, else the next slot of the timing ring
-static void pick_events(hvx_index *ix, bool timed, hipEvent_t *e0, hipEvent_t *e1) {
+static void pick_events(hvx_index *ix, bool timed, hipEvent_t *e0, hipEvent_t *e1, unsigned long long **wclk = nullptr) {
     if (timed) { *e0 = ix->ev0; *e1 = ix->ev1; return; }
     if (ix->ring_n < ix->ring_cap) {
         *e0 = ix->ring[2 * ix->ring_n];
         *e1 = ix->ring[2 * ix->ring_n + 1];
+        if (wclk && ix->d_wclk && ix->ring_n < ix->wclk_cap) *wclk = ix->d_wclk + (size_t)ix->ring_n * ix->max_batch * 2;
         ix->ring_n += 1;
     }
 }
@@ -519,6 +520,7 @@ int hvx::enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t b
     a.qstats = d_qstats ? d_qstats : ix->d_qstats;
     a.tie_flags = ix->d_tie;
     a.prof = nullptr;
+    a.wave_clock = nullptr;
     a.adaptive = ad ? 1u : 0u;
     a.ad = ad ? *ad : AdaptArgs{};
     a.occupancy = ix->occupancy;
@@ -532,7 +534,7 @@ int hvx::enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t b
             ix->bitmap_dirty = false;
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        pick_events(ix, timed, &e0, &e1);
+        pick_events(ix, timed, &e0, &e1, &a.wave_clock);
         if (e0) HIP_TRY(hipEventRecord(e0, ix->stream));
         HIP_TRY(launch_hnsw_wave(a, b, ix->stream));
         if (e1) HIP_TRY(hipEventRecord(e1, ix->stream));
@@ -555,7 +557,7 @@ int hvx::enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t b
         ix->bitmap_dirty = false;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr; // device_ms = the search kernel alone
-    pick_events(ix, timed, &e0, &e1);
+    pick_events(ix, timed, &e0, &e1, &a.wave_clock);
     if (e0) HIP_TRY(hipEventRecord(e0, ix->stream));
     if (wave) {
         HIP_TRY(launch_hnsw_wave(a, b, ix->stream));
@@ -588,8 +590,25 @@ extern "C" int hvx_index_timing_begin(hvx_index *ix, uint32_t capacity) {
         HIP_TRY(hipEventCreate(&e));
         ix->ring.push_back(e);
     }
+    if (capacity > ix->wclk_cap) { // per-wavefront start / end clocks of the same launches (hvx_index_wave_clocks)
+        int rc = ix->regrow((void **)&ix->d_wclk, (size_t)capacity * ix->max_batch * 2 * sizeof(unsigned long long));
+        if (rc) return rc;
+        ix->wclk_cap = capacity;
+    }
+    if (ix->d_wclk) HIP_TRY(hipMemsetAsync(ix->d_wclk, 0, (size_t)ix->wclk_cap * ix->max_batch * 2 * sizeof(unsigned long long), ix->stream));
     ix->ring_cap = capacity;
     ix->ring_n = 0;
+    return HVX_OK;
+}
+
+extern "C" int hvx_index_wave_clocks(hvx_index *ix, uint64_t *out, uint32_t cap_launches, uint32_t *out_n) {
+    if (!ix || !out || !out_n) return fail(HVX_ERR_INVARIANT, "null argument");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    const uint32_t n = std::min(std::min(ix->ring_n, ix->wclk_cap), cap_launches);
+    if (n) HIP_TRY(hipMemcpy(out, ix->d_wclk, (size_t)n * ix->max_batch * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    *out_n = n;
     return HVX_OK;
 }
 

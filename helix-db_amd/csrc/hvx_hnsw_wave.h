@@ -500,9 +500,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
     float *qs = fr_d + 64;                                 // [dim] query, 16-byte aligned
     uint32_t *rng_buf = reinterpret_cast<uint32_t *>(qs + NK * 32); // [kRngWords] (AD only)
 
+    const unsigned long long wclk0 = a.wave_clock ? wall_clock64() : 0ull;
     const uint32_t status_in = a.qstatus ? a.qstatus[q] : 0u;
     if (status_in != 0u || !ix.has_entry) {
         if (lane == 0) {
+            if (a.wave_clock) { a.wave_clock[2 * (size_t)q] = wclk0; a.wave_clock[2 * (size_t)q + 1] = wclk0; }
             a.out_counts[q] = 0;
             if (a.out_status) a.out_status[q] = status_in;
             if (a.qstats) a.qstats[q] = hvx_query_stats{0, 0, 0, 0};
@@ -912,6 +914,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
         for (uint32_t w = (uint32_t)lane; w < V.words; w += 64) { V.bm[w] = 0u; if (V.bm2) V.bm2[w] = 0u; }
     }
     if (lane == 0) {
+        if (a.wave_clock) { a.wave_clock[2 * (size_t)q] = wclk0; a.wave_clock[2 * (size_t)q + 1] = wall_clock64(); }
         a.out_counts[q] = outn;
         if (a.out_status) a.out_status[q] = bad_score ? 8u /*HVX_ERR_INVARIANT*/ : 0u;
         if (a.qstats) a.qstats[q] = hvx_query_stats{st_exp, st_nb, st_vl, st_dc};
@@ -939,6 +942,7 @@ hipError_t launch_hnsw_wave_cos_bf16(const HnswArgs &a, uint32_t b, const WaveGe
 hipError_t launch_hnsw_wave_prof(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 // two queries per SIMD (OCC = 2 builds), hvx_hnsw_wave_occ2.hip
 hipError_t launch_hnsw_wave_occ2(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_occ2_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 // non-strict arms (AD instantiations), hvx_hnsw_wave_l2_ad.hip / hvx_hnsw_wave_cos_ad.hip
 hipError_t launch_hnsw_wave_l2_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_cos_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);

@@ -35,6 +35,8 @@ struct hvx_index {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> ring;    // asynchronous timing: event pairs of the searches since hvx_index_timing_begin
     uint32_t ring_cap = 0, ring_n = 0;
+    unsigned long long *d_wclk = nullptr; // [ring_cap][max_batch][2] wave start/end clocks of the searches since timing_begin
+    uint32_t wclk_cap = 0;
     std::mutex mu;                   // calls on one index are serialised on its stream
     std::shared_ptr<hvx_allocs> allocs = std::make_shared<hvx_allocs>();
     std::vector<std::shared_ptr<hvx_allocs>> image; // fork: the allocations of the handles it descends from (the image it aliases)

@@ -45,6 +45,7 @@ struct HnswArgs {
     hvx_query_stats *qstats;   // [b] nullable
     uint32_t *tie_flags;       // [b] nullable
     unsigned long long *prof;  // [b][8] phase cycle counters of the PROF kernel variant, nullable
+    unsigned long long *wave_clock; // [b][2] constant-rate (100 MHz) clock at the start / end of every query's wavefront, nullable
     uint32_t adaptive;         // 0 = strict-exhaustive search; 1 = non-strict arms, policy in `ad`
     uint32_t occupancy;        // wave kernel: 2 = the two-queries-per-SIMD build (callers with >= 2 batches in flight), else 1
     AdaptArgs ad;

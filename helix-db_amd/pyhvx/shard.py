@@ -49,8 +49,9 @@ class TopkExchange:
     [world][payload].  `ids` / `scores` / `counts` are views INTO the local payload, so a search that is handed them as
     its output buffers has nothing to copy before the exchange."""
 
-    def __init__(self, world: int, b: int, k: int, device, group=None):
+    def __init__(self, world: int, b: int, k: int, device, group=None, stage_through_host: bool = False):
         self.world, self.b, self.k, self.group = world, b, k, group
+        self.stage_through_host = stage_through_host  # a backend without device collectives (gloo): plumbing checks only
         self.payload = payload_bytes(b, k)
         self.send = torch.zeros(self.payload, dtype=torch.uint8, device=device)
         self.recv = torch.zeros(world * self.payload, dtype=torch.uint8, device=device)
@@ -72,6 +73,11 @@ class TopkExchange:
                 dst.copy_(src)
         if self.world == 1:
             self.recv.copy_(self.send)
+        elif self.stage_through_host and self.send.is_cuda:
+            torch.cuda.current_stream(self.send.device).synchronize()
+            parts = [torch.zeros(self.payload, dtype=torch.uint8) for _ in range(self.world)]
+            dist.all_gather(parts, self.send.cpu(), group=self.group)
+            self.recv.copy_(torch.cat(parts))
         else:
             dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
         return self.recv
@@ -85,9 +91,9 @@ class TopkExchange:
 class ShardedSearcher:
     """Search a query batch over every shard and merge on the device (the N>1 step of bench.py)."""
 
-    def __init__(self, index, world: int, b: int, k: int, device, group=None):
+    def __init__(self, index, world: int, b: int, k: int, device, group=None, stage_through_host: bool = False):
         self.ix, self.world, self.b, self.k = index, world, b, k
-        self.ex = TopkExchange(world, b, k, device, group)
+        self.ex = TopkExchange(world, b, k, device, group, stage_through_host)
         self.m_ids = torch.zeros(b, k, dtype=torch.int64, device=device)
         self.m_scores = torch.zeros(b, k, dtype=torch.float32, device=device)
         self.m_counts = torch.zeros(b, dtype=torch.int32, device=device)

@@ -86,6 +86,44 @@ def clustered(n: int, dim: int, n_queries: int, seed: int, device, centres: int 
     return draw(n), draw(n_queries)
 
 
+def embedding_like_np(n: int, dim: int, n_queries: int, seed: int, latent: int = 16, clusters: int = 1024, spread: float = 0.6,
+                      noise: float = 0.02):
+    """numpy (PCG64) twin of `embedding_like`: the same distribution from a generator that gives identical rows on every
+    machine with or without a GPU -- used where a CPU-side fixture and a GPU-side run must see the same corpus
+    (bench.py `graph_equivalence`, tests/golden/make_graph_equivalence_ref.py)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    w = (rng.standard_normal((latent, dim)) / math.sqrt(latent)).astype(np.float32)
+    centres = rng.standard_normal((clusters, latent)).astype(np.float32)
+
+    def draw(count):
+        which = rng.integers(0, clusters, count)
+        z = centres[which] + np.float32(spread) * rng.standard_normal((count, latent)).astype(np.float32)
+        x = z @ w + np.float32(noise) * rng.standard_normal((count, dim)).astype(np.float32)
+        return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+
+    return draw(n), draw(n_queries)
+
+
+def quantize_fp8_rows(x: np.ndarray) -> np.ndarray:
+    """The values an fp8-e4m3fn-stored index holds (numpy twin of quantize_fp8_kernel, csrc/hvx_dtype.hip): per row
+    scale = max|x| / 448, code = RNE(x / scale) to e4m3fn, value = fl32(scale * decode(code)).  Harness code: lets a
+    checker score the stored values of an fp8 index on the host."""
+    x = np.ascontiguousarray(x, np.float32)
+    amax = np.abs(x).max(axis=1).astype(np.float32)
+    scale = np.where(amax > 0, amax / np.float32(448.0), np.float32(1.0)).astype(np.float32)
+    y = (x / scale[:, None]).astype(np.float32)
+    a = np.abs(y)
+    a = np.where(a < np.float32(464.0), a, np.float32(448.0)).astype(np.float32)
+    _, ex = np.frexp(a)
+    e = ex.astype(np.int32) - 1
+    e = np.where((a == 0) | (e < -6), -6, e)
+    step = np.ldexp(np.float32(1.0), e - 3).astype(np.float32)
+    v = (np.rint(a / step) * step).astype(np.float32)
+    v = np.minimum(v, np.float32(448.0))
+    v = np.where(y < 0, -v, v).astype(np.float32)
+    return (scale[:, None] * v).astype(np.float32)
+
+
 def corpus(name: str, n: int, dim: int, n_queries: int, seed: int, device, **kw):
     """The benchmark corpora by name: 'gaussian' (SURVEY 8d as literally written), 'clustered' (its stated clustered
     variant), 'embedding' (low intrinsic dimension, what learned embeddings look like)."""

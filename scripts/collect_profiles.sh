@@ -1,30 +1,48 @@
 #!/bin/bash
 # usage (on the GPU box): scripts/collect_profiles.sh <tag>
-# 1. un-profiled bench (with cpu_baseline + oracle parity)   -> gpurun_out/prof_<tag>/bench_line.json
-# 2. rocprofv3 --kernel-trace --stats of the same command    -> kernel_stats_{full,hvx}.csv + bench_line_profiled.json
-# 3. rocprofv3 --pmc passes (own runs, kernel-trace only)    -> pmc_*.csv, traffic.json (FETCH_SIZE x2, gfx950 correction)
+# 1. un-profiled bench (all legs, cpu_baseline + oracle parity) -> gpurun_out/prof_<tag>/bench_line.json
+# 2. rocprofv3 --kernel-trace --stats of the headline leg        -> kernel_stats_{full,hvx}.csv, bench_line_profiled.json,
+#    kernel_span.json (overlapped span of the timed hnsw_wave_kernel dispatches / their count, from the kernel trace)
+# 3. the same with --lanes 1 --occupancy 1 (one lone batch at a time: AverageNs == roofline.lone_batch.kernel_ms)
+# 4. rocprofv3 --pmc passes (own runs, kernel-trace only; counter collection serialises the dispatches)
+#    -> pmc_*.csv, traffic.json (FETCH_SIZE x2, gfx950 correction)
 set -e
 tag=$1
 out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-BENCH="python bench.py --steps 20 --warmup 3 --graph-cache /tmp/g"
-$BENCH 2> $out/bench.log | tail -1 > $out/bench_line.json
+EXTRA="--skip production,datasets,config3,config4,config5,graph_equivalence --cpu-seconds 0 --no-verify"
+BENCH="python bench.py --steps 60 --warmup 6"
+if [ -z "$SKIP_FULL" ]; then $BENCH 2> $out/bench.log | tail -1 > $out/bench_line.json; fi
 rm -rf /tmp/prof_$tag
-# the headline kernel alone (no production-default leg: its strict ef=100 launches share the R=3 instantiation's name)
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o $tag -- $BENCH --cpu-seconds 0 --no-verify --no-production-default > /tmp/prof_$tag.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o $tag -- $BENCH $EXTRA > /tmp/prof_$tag.log 2>&1
 grep '^{' /tmp/prof_$tag.log | tail -1 > $out/bench_line_profiled.json
 cp /tmp/prof_$tag/${tag}_kernel_stats.csv $out/kernel_stats_full.csv
 (head -1 $out/kernel_stats_full.csv; grep "hvx::" $out/kernel_stats_full.csv) > $out/kernel_stats_hvx.csv
-# the same with the production-default leg: the AD instantiation (..., false, true>) only runs SearchParams::new(k) launches
-rm -rf /tmp/prof_${tag}p
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${tag}p -o ${tag}p -- $BENCH --cpu-seconds 0 --no-verify > /tmp/prof_${tag}p.log 2>&1
-grep '^{' /tmp/prof_${tag}p.log | tail -1 > $out/bench_line_profiled_production_default.json
-(head -1 /tmp/prof_${tag}p/${tag}p_kernel_stats.csv; grep "hvx::" /tmp/prof_${tag}p/${tag}p_kernel_stats.csv) > $out/kernel_stats_hvx_production_default.csv
+python - /tmp/prof_$tag/${tag}_kernel_trace.csv $out/kernel_span.json <<'PY'
+import csv, json, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "hnsw_wave_kernel" in r["Kernel_Name"]]
+by = {}
+for r in rows:
+    by.setdefault(r["Kernel_Name"], []).append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+out = {}
+for name, v in by.items():
+    v.sort()
+    timed = v[-60:] if len(v) >= 60 else v       # the timed region = the last 60 dispatches of the two-per-SIMD build
+    span = max(e for _, e in timed) - min(s for s, _ in timed)
+    out[name] = {"dispatches": len(v), "timed_dispatches": len(timed), "average_ns_each": sum(e - s for s, e in timed) / len(timed),
+                 "overlapped_span_ns": span, "span_per_dispatch_ns": span / len(timed)}
+json.dump(out, open(sys.argv[2], "w"), indent=1)
+print(json.dumps(out))
+PY
+rm -rf /tmp/prof_${tag}l
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${tag}l -o ${tag}l -- $BENCH $EXTRA --lanes 1 --occupancy 1 > /tmp/prof_${tag}l.log 2>&1
+grep '^{' /tmp/prof_${tag}l.log | tail -1 > $out/bench_line_profiled_lone_batch.json
+(head -1 /tmp/prof_${tag}l/${tag}l_kernel_stats.csv; grep "hvx::" /tmp/prof_${tag}l/${tag}l_kernel_stats.csv) > $out/kernel_stats_hvx_lone_batch.csv
 pmc() {
   name=$1; shift
   rm -rf /tmp/pmc_$name
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$name -o $name -- $BENCH --steps 5 --warmup 2 --cpu-seconds 0 --no-verify --no-production-default > /tmp/pmc_$name.log 2>&1
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$name -o $name -- python bench.py --steps 6 --warmup 3 $EXTRA > /tmp/pmc_$name.log 2>&1
   f=$(ls /tmp/pmc_$name/*counter_collection.csv | head -1)
   (head -1 "$f"; grep -E "hnsw_(wave|search)_kernel" "$f") > $out/pmc_$name.csv
 }
@@ -38,6 +56,8 @@ summary = {}
 for name in ("mem", "l2", "sq"):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f"{out}/pmc_{name}.csv")):
+        if ", 2>" not in r["Kernel_Name"].replace("2>(", "2>") and "Li2EE" not in r["Kernel_Name"]:
+            pass
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         summary[k] = {"dispatches": len(v), "mean_per_launch": sum(v) / len(v)}
@@ -46,7 +66,8 @@ rd = summary["TCC_EA0_RDREQ_sum"]["mean_per_launch"]
 traffic = {
     "kernel": "hnsw_wave_kernel",
     "hbm_bytes_per_launch": int(fetch_kb * 1024 * 2),
-    "how": "rocprofv3 --pmc FETCH_SIZE (own pass, --kernel-trace only), mean over the hnsw_wave_kernel dispatches of bench.py; "
+    "how": "rocprofv3 --pmc FETCH_SIZE (own pass, --kernel-trace only), mean over the hnsw_wave_kernel dispatches of bench.py "
+           "(counter collection serialises the dispatches: per-launch traffic is unaffected, overlap is not visible here); "
            "FETCH_SIZE is KiB and on gfx950 reports 1/2 of a wide coalesced read (MI355X_MICROARCH.md, HBM section) => x1024 x2; "
            "cross-check: TCC_EA0_RDREQ_sum x 128 B",
     "fetch_size_kib_raw": fetch_kb,

@@ -1037,3 +1037,75 @@ def test_large_restricted_scan_over_f32_rows_takes_the_matrix_cores(orc, hv, mon
     for qi in (0, 100, 511):
         rc, oid, osc = orc.flat_matrix(orc.L2SQ, sub, q[qi], k, kernel=orc.K_AVX_FMA_HW)
         assert allowed[oid.astype(np.int64)].tolist() == gid[qi].tolist() and bits(osc).tolist() == bits(gsc[qi]).tolist()
+
+
+# --- execution lanes (hvx_index_fork) and the two-queries-per-SIMD build of the wave kernel ---
+@pytest.mark.parametrize("n,dim,metric,m,m0,efc,ef,k,nq", WAVE_CASES)
+def test_two_queries_per_simd_build_equals_oracle(orc, hv, n, dim, metric, m, m0, efc, ef, k, nq):
+    """hvx_index_set_occupancy(2): same ids, score bits and SearchStats counters as the oracle on every wave-kernel shape."""
+    rng = np.random.default_rng(4000 + dim + metric)
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    lv = fx.draw_levels(n, m, seed=dim + 1)
+    oix = build_oracle(orc, data, metric, lv, m=m, m0=m0, efc=efc)
+    gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=dim, metric=metric, m=m, m0=m0)
+    gix.set_occupancy(2)
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    assert_hnsw_equal(orc, hv, oix, gix, q, k, ef)
+
+
+def test_two_queries_per_simd_build_spill_path(orc, hv, monkeypatch):
+    """The half-LDS build spills to the HBM bitmap at 7/8 of its (smaller) table: forced with a 256-slot table."""
+    monkeypatch.setenv("HVX_WAVE_LOG2CAP", "8")
+    rng = np.random.default_rng(77)
+    n, dim = 2500, 128
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    oix = build_oracle(orc, data, orc.L2SQ, fx.draw_levels(n, 16, seed=5), efc=80)
+    gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=dim, metric=hv.EUCLIDEAN)
+    gix.set_occupancy(2)
+    q = rng.standard_normal((32, dim)).astype(np.float32)
+    assert_hnsw_equal(orc, hv, oix, gix, q, 10, 128)
+    assert_hnsw_equal(orc, hv, oix, gix, q, 10, 128)  # the bitmap was handed back zeroed
+
+
+def test_forked_lanes_share_the_image_and_outlive_their_parent(orc, hv):
+    import threading
+    rng = np.random.default_rng(91)
+    n, dim = 3000, 128
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    oix = build_oracle(orc, data, orc.COSINE, fx.draw_levels(n, 16, seed=9), efc=80)
+    oix.set_simhash(42)
+    root = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=dim, metric=hv.COSINE)
+    root.set_simhash()
+    lanes = [root.fork() for _ in range(3)]
+    lanes[1].set_occupancy(2)
+    with pytest.raises(hv.HelixDbError):
+        lanes[0].set_simhash()  # the SimHash rows belong to the image: root handle only
+    q = rng.standard_normal((96, dim)).astype(np.float32)
+    want = root.search_batch(q, hv.SearchParams(10).with_ef(128))
+    want_p = root.search_batch(q, hv.SearchParams.new(10))
+    want_f = root.flat_search_batch(q, 10)
+    root.close()  # lanes keep the image alive
+    out = [None] * len(lanes)
+
+    def work(i):
+        res = []
+        for _ in range(5):
+            a = lanes[i].search_batch(q, hv.SearchParams(10).with_ef(128))
+            b = lanes[i].search_batch(q, hv.SearchParams.new(10))
+            c = lanes[i].flat_search_batch(q, 10)
+            res.append((a, b, c))
+        out[i] = res
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(lanes))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for res in out:
+        for a, b, c in res:
+            for got, exp in ((a, want), (b, want_p), (c, want_f)):
+                assert got[0].tolist() == exp[0].tolist() and bits(got[1]).tolist() == bits(exp[1]).tolist()
+                assert got[2].tolist() == exp[2].tolist()
+    for qi in range(0, 96, 7):  # and the lanes agree with the oracle
+        rc, oid, osc = oix.search(q[qi], 10, 128)
+        assert out[1][0][0][0][qi, :len(oid)].tolist() == oid.tolist()
+    for ln in lanes:
+        ln.close()

@@ -284,14 +284,19 @@ extern "C" int hvx_index_import(const hvx_index_desc *desc, const uint64_t *node
     d.vec = (const float *)p;
     auto bail_free = [&](int code) { if (staging) (void)hipFree(staging); return bail(code); };
     if (n) {
+        // hipMemcpyDefault: `vectors` may be host memory or memory already resident on a device.  A device-to-device
+        // hipMemcpy does not wait for the copy on the host, and the index's stream is non-blocking: the copy is ordered
+        // on that stream and waited for, so that the kernels below (rounding, validation, packing) see every row
+        hipError_t ce;
         if (d.ld == d.dim) {
-            // hipMemcpyDefault: `vectors` may be host memory or memory already resident on a device
-            if (hipMemcpy(p, vectors, vec_bytes, hipMemcpyDefault) != hipSuccess) return bail_free(fail(HVX_ERR_DEVICE, "vector upload failed"));
+            ce = hipMemcpyAsync(p, vectors, vec_bytes, hipMemcpyDefault, ix->stream);
         } else {
-            if (hipMemset(p, 0, vec_bytes) != hipSuccess ||
-                hipMemcpy2D(p, (size_t)d.ld * 4, vectors, (size_t)d.dim * 4, (size_t)d.dim * 4, n, hipMemcpyDefault) != hipSuccess)
-                return bail_free(fail(HVX_ERR_DEVICE, "vector upload failed"));
+            ce = hipMemsetAsync(p, 0, vec_bytes, ix->stream);
+            if (ce == hipSuccess)
+                ce = hipMemcpy2DAsync(p, (size_t)d.ld * 4, vectors, (size_t)d.dim * 4, (size_t)d.dim * 4, n, hipMemcpyDefault, ix->stream);
         }
+        if (ce == hipSuccess) ce = hipStreamSynchronize(ix->stream);
+        if (ce != hipSuccess) return bail_free(fail(HVX_ERR_DEVICE, "vector upload failed: %s", hipGetErrorString(ce)));
         // bf16: the index IS the rounded vectors -- validation and cosine headers see the rounded values
         if (bf16 && launch_round_bf16_inplace(staging, (size_t)n * d.ld, ix->stream) != hipSuccess)
             return bail_free(fail(HVX_ERR_DEVICE, "bf16 rounding failed"));

@@ -68,7 +68,8 @@ extern "C" int hvx_index_set_simhash(hvx_index *ix, const hvx_simhash_config *cf
     if (!ix->d_thr_break && (rc = ix->dalloc((void **)&ix->d_thr_break, 64 * 4))) return rc;
     if (!ix->d_astats && (rc = ix->dalloc((void **)&ix->d_astats, (size_t)ix->max_batch * sizeof(hvx_adaptive_stats)))) return rc;
     if (node_hashes) {
-        HIP_TRY(hipMemcpy(ix->d_node_hash, node_hashes, (size_t)n * 8, hipMemcpyDefault));
+        HIP_TRY(hipMemcpyAsync(ix->d_node_hash, node_hashes, (size_t)n * 8, hipMemcpyDefault, ix->stream)); // host or device source
+        HIP_TRY(hipStreamSynchronize(ix->stream));
     } else {
         if (ix->dev.dtype == HVX_FP8_E4M3)
             return fail(HVX_ERR_UNSUPPORTED, "SimHash rows are not recomputed from fp8 storage; pass node_hashes");

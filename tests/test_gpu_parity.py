@@ -379,7 +379,8 @@ def test_merge_topk_device_matches_candidate_order(orc, hv):
 
 @pytest.mark.parametrize("n,dim,metric,ef,k", [(1500, 128, 1, 128, 10), (1200, 768, 1, 128, 10), (1200, 256, 0, 100, 10),
                                                (2000, 128, 1, 300, 20)])
-def test_hnsw_bf16_rows_bit_exact_vs_oracle_on_rounded_vectors(orc, hv, n, dim, metric, ef, k):
+@pytest.mark.parametrize("occupancy", [1, 2])
+def test_hnsw_bf16_rows_bit_exact_vs_oracle_on_rounded_vectors(orc, hv, n, dim, metric, ef, k, occupancy):
     """BASELINE config #4 storage: rows rounded to bf16 once at import; distances in f32 on the rounded
     values in the reference's summation order == the oracle run on the rounded vectors, bit for bit."""
     rng = np.random.default_rng(500 + dim)
@@ -391,6 +392,7 @@ def test_hnsw_bf16_rows_bit_exact_vs_oracle_on_rounded_vectors(orc, hv, n, dim, 
     ex = oix.export()
     ex["vectors"] = data  # the device does the rounding
     gix = hv.ValidatedVectorReadIndex.from_export(ex, dim=dim, metric=metric, dtype=hv.BF16)
+    gix.set_occupancy(occupancy)
     q = rng.standard_normal((24, dim)).astype(np.float32)  # queries stay f32
     assert_hnsw_equal(orc, hv, oix, gix, q, k, ef)
     with pytest.raises(hv.HelixDbError) as e:  # shapes the bf16 kernel does not serve fail loudly
@@ -1109,3 +1111,26 @@ def test_forked_lanes_share_the_image_and_outlive_their_parent(orc, hv):
         assert out[1][0][0][0][qi, :len(oid)].tolist() == oid.tolist()
     for ln in lanes:
         ln.close()
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16", "fp8"])
+def test_import_from_device_memory_equals_import_from_host(hv, dtype_name):
+    """hvx_index_import accepts rows already resident on a device; the copy is ordered before the import's own kernels
+    (rounding / quantisation, validation, packing), so the image equals the one built from host rows -- sized so that
+    the copy is still in flight when the first kernel would otherwise start."""
+    import torch
+    rng = np.random.default_rng(123)
+    n, dim = 400_000, 256
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    dt = {"f32": hv.F32, "bf16": hv.BF16, "fp8": hv.FP8_E4M3}[dtype_name]
+    kw = dict(dim=dim, metric=hv.EUCLIDEAN, node_ids=np.arange(n, dtype=np.uint64), l0_offsets=np.zeros(n + 1, np.uint64),
+              l0_neighbors=np.zeros(0, np.uint64), dtype=dt, max_batch=64)
+    host = hv.ValidatedVectorReadIndex.managed(vectors=data, **kw)
+    xd = torch.from_numpy(data).to("cuda:0")
+    torch.cuda.synchronize()
+    devi = hv.ValidatedVectorReadIndex.managed(vectors=xd, **kw)
+    q = data[n - 64:] + np.float32(0.01)  # nearest rows sit at the END of the array: the last bytes a copy delivers
+    a = host.flat_search_batch(q, 10)
+    b = devi.flat_search_batch(q, 10)
+    assert a[0].tolist() == b[0].tolist() and bits(a[1]).tolist() == bits(b[1]).tolist()
+    assert all(int(a[0][i, 0]) == n - 64 + i for i in range(64))

@@ -157,6 +157,14 @@ extern "C" int hvx_index_import(const hvx_index_desc *desc, const uint64_t *node
                                 const uint64_t *l0_offsets, const uint64_t *l0_neighbors,
                                 const uint16_t *level, const uint64_t *up_offsets,
                                 const uint64_t *up_neighbors, hvx_index **out) {
+    return hvx::import_index(desc, node_ids, vectors, l0_offsets, l0_neighbors, level, up_offsets, up_neighbors, 0, 0, out);
+}
+
+// min_s0 / min_su: lower bounds of the row strides (the device builder imports an empty graph and fills rows of up to
+// m0 / m ids afterwards)
+int hvx::import_index(const hvx_index_desc *desc, const uint64_t *node_ids, const float *vectors, const uint64_t *l0_offsets,
+                      const uint64_t *l0_neighbors, const uint16_t *level, const uint64_t *up_offsets, const uint64_t *up_neighbors,
+                      uint32_t min_s0, uint32_t min_su, hvx_index **out) {
     if (!desc || !out) return fail(HVX_ERR_INVARIANT, "null argument");
     *out = nullptr;
     if (desc->dim == 0) return fail(HVX_ERR_DIMENSION, "dimension must be non-zero");
@@ -223,9 +231,14 @@ extern "C" int hvx_index_import(const hvx_index_desc *desc, const uint64_t *node
         if (level) up_rows += level[i];
     }
     if (level && up_rows && (!up_offsets || !up_neighbors)) return bail(fail(HVX_ERR_INVARIANT, "upper rows missing"));
-    for (uint64_t r = 0; r < up_rows; ++r) max_up = std::max<uint64_t>(max_up, up_offsets[r + 1] - up_offsets[r]);
-    d.s0 = round_up((uint32_t)std::max<uint64_t>(max_deg, 1), 32);
-    d.su = round_up((uint32_t)std::max<uint64_t>(max_up, 1), 16);
+    for (uint64_t r = 0; r < up_rows; ++r) {
+        if (up_offsets[r + 1] < up_offsets[r]) return bail(fail(HVX_ERR_INVARIANT, "up_offsets not monotone"));
+        max_up = std::max<uint64_t>(max_up, up_offsets[r + 1] - up_offsets[r]);
+    }
+    if (max_deg > 128 || max_up > 128) // before any narrowing: a huge row length must not wrap into a small stride
+        return bail(fail(HVX_ERR_UNSUPPORTED, "neighbour rows longer than 128 are not supported (l0 %llu, upper %llu)", (unsigned long long)max_deg, (unsigned long long)max_up));
+    d.s0 = round_up((uint32_t)std::max<uint64_t>(std::max<uint64_t>(max_deg, min_s0), 1), 32);
+    d.su = round_up((uint32_t)std::max<uint64_t>(std::max<uint64_t>(max_up, min_su), 1), 16);
     if (d.s0 > 128 || d.su > 128) return bail(fail(HVX_ERR_UNSUPPORTED, "neighbour rows longer than 128 are not supported (l0 %llu, upper %llu)", (unsigned long long)max_deg, (unsigned long long)max_up));
 
     std::vector<uint32_t> h_l0((size_t)n * d.s0, kSentinel);
@@ -528,6 +541,8 @@ int hvx::enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t b
     a.wave_clock = nullptr;
     a.adaptive = ad ? 1u : 0u;
     a.ad = ad ? *ad : AdaptArgs{};
+    a.build_nodes = nullptr;
+    a.build_ef_upper = 0;
     a.occupancy = ix->occupancy;
     if (const char *e = getenv("HVX_WAVE_OCC")) a.occupancy = (uint32_t)atoi(e); // tuning hook
     if (ad) {

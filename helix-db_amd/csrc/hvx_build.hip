@@ -1,0 +1,525 @@
+// hvx_build.hip -- GPU-assisted HNSW build: the reference's insert path
+// (crates/db/src/search/vector/mutation.rs:642-895 insert_with_mutation_cache / insert_hnsw) for BATCHES of nodes on
+// the device, over an index image whose rows are already resident in HBM.
+//
+// Per batch of B new nodes (consecutive ids; every node of a batch sees the graph as of the batch start):
+//   1. search   hnsw_wave_kernel<BUILD> -- greedy descent above min(level, max_layer), search_layer_beam
+//               (mutation.rs:904-1005) on every layer from there to 0; per layer the first 2*Mmax entries of W
+//   2. select   build_select_kernel    -- select_neighbors_heuristic (mutation.rs:1072-1097) = select_diverse
+//               (mod.rs:809-856) over those hydrated candidates, backfill; writes the new node's canonical row
+//   3. link     build_link_kernel      -- add_bidirectional_link (mutation.rs:1498-1583) for every selected neighbour IN
+//               SELECTION ORDER: append, and when the row exceeds Mmax rank its neighbours by distance to the row's owner,
+//               select_diverse + backfill, canonical row (neighbor_set.rs:1-9), remove the reverse edge of every dropped
+//               neighbour (mutation.rs:1890-1908).  One wavefront per new node; a row is changed under its owner's lock.
+// With B = 1 this IS the reference's sequential insertion: rows equal the oracle's row for row (tests).  With B > 1 the
+// nodes of one batch do not see each other and the order in which concurrent links reach a shared neighbour is not
+// defined; the result is a valid (symmetric, degree-bounded, canonical) HNSW graph whose recall / work match the
+// sequential one (bench.py graph_equivalence).  A node whose level exceeds the current top layer always forms its own
+// batch (it becomes the entry point, mutation.rs:769-772).
+//
+// Every distance is the reference-order f32 distance of hvx_device.h (group_distance), so `dist(c,s) < dist(c,q)` decisions
+// are the CPU path's.  Served shapes: those of the one-wavefront-per-query kernel (f32 rows, L2 / cosine, AVX+FMA tree,
+// dim in {128,...,1536}), m0 <= 32, ef_construction <= 352.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "hvx_host.h"
+
+using namespace hvx;
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) return fail(HVX_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+namespace hvx {
+
+constexpr uint32_t kCand = 64; // candidates kept per layer and node (2 * Mmax <= 64)
+
+struct BuildArgs {
+    DevIndex ix;
+    uint32_t *l0, *up;          // the same rows as ix.l0 / ix.up, writable
+    uint32_t *locks;            // [n] one lock per row owner (all its layers)
+    const uint32_t *nodes;      // [b] internal ids of the batch
+    uint32_t b, layers;         // layers = old max_layer + 1
+    const uint64_t *cand_ids;   // [layers][b][kCand] internal ids (search output)
+    const float *cand_sc;       // [layers][b][kCand]
+    const uint32_t *cand_cnt;   // [layers][b]
+    uint32_t *sel;              // [layers][b][32] selected neighbours in selection order
+    uint32_t *sel_cnt;          // [layers][b]
+    uint32_t m, m0;             // degree limits: upper layers / layer 0 (m0 = max(m0, 2m), mutation.rs:178-196)
+    uint32_t *err;              // [1] set when a row would overflow its stride (invariant violation)
+};
+
+__device__ __forceinline__ uint32_t ld_row(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_row(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ void lock_row(uint32_t *locks, uint32_t node, int lane) {
+    if (lane == 0) {
+        while (__hip_atomic_exchange(&locks[node], 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) __builtin_amdgcn_s_sleep(2);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+}
+__device__ __forceinline__ void unlock_row(uint32_t *locks, uint32_t node, int lane) {
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) __hip_atomic_store(&locks[node], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// row of `node` on `layer`, and its stride
+__device__ __forceinline__ uint32_t *row_ptr(const BuildArgs &a, uint32_t node, uint32_t layer, uint32_t &stride) {
+    if (layer == 0u) { stride = a.ix.s0; return a.l0 + (size_t)node * a.ix.s0; }
+    stride = a.ix.su;
+    return a.up + (size_t)(a.ix.up_base[node] + layer - 1u) * a.ix.su;
+}
+
+// LDS of one wavefront: the "query" row of the distance evaluator + small id / score lists
+struct BuildLds {
+    float *qv;       // [ld]
+    uint32_t *kept;  // [64]
+    uint32_t *cid;   // [64] candidates sorted by (score, id)
+    float *csc;      // [64]
+    float *dtmp;     // [64]
+};
+__device__ __forceinline__ BuildLds carve_build(char *smem, uint32_t ld) {
+    BuildLds L;
+    L.qv = reinterpret_cast<float *>(smem);
+    char *p = smem + (((size_t)ld * 4u + 15u) & ~(size_t)15u);
+    L.kept = reinterpret_cast<uint32_t *>(p); p += 256;
+    L.cid = reinterpret_cast<uint32_t *>(p); p += 256;
+    L.csc = reinterpret_cast<float *>(p); p += 256;
+    L.dtmp = reinterpret_cast<float *>(p);
+    return L;
+}
+static size_t build_lds_bytes(uint32_t ld) { return (((size_t)ld * 4u + 15u) & ~(size_t)15u) + 4 * 256; }
+
+__device__ __forceinline__ void stage_row(const DevIndex &ix, float *qv, uint32_t node, int lane) {
+    __syncthreads();
+    const float *r = ix.vec + (size_t)node * ix.ld;
+    for (uint32_t t = (uint32_t)lane; t < ix.ld; t += 64) qv[t] = r[t];
+    __syncthreads();
+}
+
+// mod.rs:809-856 select_diverse over L.cid/L.csc[0..hyd) (sorted closest first, all hydrated), at most m kept, then the
+// backfill with the closest remaining candidates (:845-854).  L.kept[0..ns) = the selection in selection order.
+template <uint32_t METRIC, bool FUSED>
+__device__ __forceinline__ uint32_t select_diverse_dev(const DevIndex &ix, const BuildLds &L, uint32_t hyd, uint32_t m, int lane) {
+    const int grp = lane >> 3, j = lane & 7;
+    uint32_t ns = 0;
+    for (uint32_t i = 0; i < hyd && ns < m; ++i) {
+        const uint32_t ci = L.cid[i];
+        const float si = L.csc[i];
+        bool diverse = true;
+        if (ns) {
+            stage_row(ix, L.qv, ci, lane);
+            const float chdr = ix.hdr[ci];
+            for (uint32_t p0 = 0; p0 < ns; p0 += 8) {
+                const uint32_t g = p0 + (uint32_t)grp;
+                const uint32_t other = L.kept[g < ns ? g : ns - 1u];
+                const float pd = group_distance<METRIC, FUSED>(ix, L.qv, chdr, other, j);
+                if (__ballot(g < ns && pd < si)) { diverse = false; break; } // strict < rejects (mod.rs:832)
+            }
+        }
+        if (diverse) {
+            __syncthreads();
+            if (lane == 0) L.kept[ns] = ci;
+            ++ns;
+            __syncthreads();
+        }
+    }
+    if (ns < m) { // backfill, closest first
+        const bool have = (uint32_t)lane < hyd;
+        const uint32_t mine = have ? L.cid[lane] : kSentinel;
+        bool in = false;
+        for (uint32_t s = 0; s < ns; ++s) in |= L.kept[s] == mine;
+        const unsigned long long free_m = __ballot(have && !in);
+        const uint32_t rank = (uint32_t)__builtin_popcountll(free_m & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (have && !in && ns + rank < m) L.kept[ns + rank] = mine;
+        const uint32_t add = (uint32_t)__builtin_popcountll(free_m);
+        ns = ns + add < m ? ns + add : m;
+        __syncthreads();
+    }
+    return ns;
+}
+
+// canonical row (ascending id, sentinel padded) of the ids in L.kept[0..ns)
+__device__ __forceinline__ void store_canonical(uint32_t *row, uint32_t stride, const uint32_t *ids_lds, uint32_t ns, int lane, bool coherent) {
+    const uint32_t mine = (uint32_t)lane < ns ? ids_lds[lane] : kSentinel;
+    uint32_t rank = 0;
+    for (uint32_t s = 0; s < ns; ++s) rank += ids_lds[s] < mine ? 1u : 0u;
+    __syncthreads();
+    for (uint32_t t = (uint32_t)lane; t < stride; t += 64)
+        if (t >= ns) { if (coherent) st_row(row + t, kSentinel); else row[t] = kSentinel; }
+    if ((uint32_t)lane < ns) { if (coherent) st_row(row + rank, mine); else row[rank] = mine; }
+}
+
+// ---- step 2: the new node's own neighbour lists ----
+template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(64) void build_select_kernel(BuildArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const DevIndex &ix = a.ix;
+    const uint32_t q = blockIdx.x, layer = blockIdx.y;
+    const int lane = (int)threadIdx.x;
+    const uint32_t node = a.nodes[q];
+    const uint32_t lv = ix.level[node];
+    const uint32_t top = lv < a.layers - 1u ? lv : a.layers - 1u; // min(node level, old max_layer)
+    if (layer > top) return; // layers above the old top stay empty rows (mutation.rs:883-894)
+    BuildLds L = carve_build(smem, ix.ld);
+    const uint32_t maxn = layer == 0u ? a.m0 : a.m;
+    const size_t slot = (size_t)layer * a.b + q;
+    const uint32_t cnt = a.cand_cnt[slot];
+    const uint32_t hyd = cnt < 2u * maxn ? cnt : 2u * maxn; // select_neighbors_heuristic hydrates the first 2*Mmax only
+    if ((uint32_t)lane < hyd) {
+        L.cid[lane] = (uint32_t)a.cand_ids[slot * kCand + lane];
+        L.csc[lane] = a.cand_sc[slot * kCand + lane];
+    }
+    __syncthreads();
+    const uint32_t ns = select_diverse_dev<METRIC, FUSED>(ix, L, hyd, maxn, lane);
+    if ((uint32_t)lane < ns) a.sel[slot * 32u + lane] = L.kept[lane];
+    if (lane == 0) a.sel_cnt[slot] = ns;
+    uint32_t stride;
+    uint32_t *row = row_ptr(a, node, layer, stride);
+    store_canonical(row, stride, L.kept, ns, lane, false); // nobody else can reach this row before the link step
+}
+
+// remove `victim` from the row of `owner` on `layer` (mutation.rs:1890-1908), under owner's lock
+__device__ __forceinline__ void remove_edge_dev(const BuildArgs &a, uint32_t layer, uint32_t owner, uint32_t victim, int lane) {
+    lock_row(a.locks, owner, lane);
+    uint32_t stride;
+    uint32_t *row = row_ptr(a, owner, layer, stride);
+    const uint32_t v = (uint32_t)lane < stride ? ld_row(row + lane) : kSentinel;
+    const bool keep = v != kSentinel && v != victim;
+    const unsigned long long km = __ballot(keep);
+    const uint32_t pos = (uint32_t)__builtin_popcountll(km & ((1ull << lane) - 1ull));
+    const uint32_t nk = (uint32_t)__builtin_popcountll(km);
+    __syncthreads();
+    if (keep) st_row(row + pos, v);
+    if ((uint32_t)lane >= nk && (uint32_t)lane < stride) st_row(row + lane, kSentinel);
+    unlock_row(a.locks, owner, lane);
+}
+
+// ---- step 3: bidirectional links of the new node, in selection order, top layer first ----
+template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(64) void build_link_kernel(BuildArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const DevIndex &ix = a.ix;
+    const uint32_t q = blockIdx.x;
+    const int lane = (int)threadIdx.x, grp = lane >> 3, j = lane & 7;
+    const uint32_t me = a.nodes[q];
+    const uint32_t lv = ix.level[me];
+    const uint32_t top = lv < a.layers - 1u ? lv : a.layers - 1u;
+    BuildLds L = carve_build(smem, ix.ld);
+    for (int32_t layer = (int32_t)top; layer >= 0; --layer) {
+        const uint32_t maxn = layer == 0 ? a.m0 : a.m;
+        const size_t slot = (size_t)layer * a.b + q;
+        const uint32_t ns = a.sel_cnt[slot];
+        for (uint32_t s = 0; s < ns; ++s) {
+            const uint32_t to = a.sel[slot * 32u + s];
+            // add_bidirectional_link(from = me, to) (mutation.rs:1498-1583)
+            lock_row(a.locks, to, lane);
+            uint32_t stride;
+            uint32_t *row = row_ptr(a, to, (uint32_t)layer, stride);
+            uint32_t v = (uint32_t)lane < stride ? ld_row(row + lane) : kSentinel;
+            uint32_t deg = (uint32_t)__builtin_popcountll(__ballot(v != kSentinel));
+            const bool present = __ballot(v == me) != 0ull;
+            if (!present) {
+                if (deg >= 64u) { if (lane == 0) *a.err = 1u; unlock_row(a.locks, to, lane); continue; }
+                if ((uint32_t)lane == deg) v = me; // rows are canonical: the valid ids occupy lanes 0..deg-1
+                ++deg;
+            }
+            const uint32_t nc = deg;
+            uint32_t dropped_id = kSentinel; // per lane: a candidate this prune removed
+            if (nc > maxn) {
+                // rank the row's neighbours by distance to its owner, select_diverse with the owner as the reference point
+                stage_row(ix, L.qv, to, lane);
+                const float thdr = ix.hdr[to];
+                __syncthreads();
+                if ((uint32_t)lane < nc) L.kept[lane] = v; // scratch: unsorted candidate ids
+                __syncthreads();
+                for (uint32_t p0 = 0; p0 < nc; p0 += 8) {
+                    const uint32_t g = p0 + (uint32_t)grp;
+                    const uint32_t other = L.kept[g < nc ? g : nc - 1u];
+                    const float d = group_distance<METRIC, FUSED>(ix, L.qv, thdr, other, j);
+                    if (g < nc && j == 0) L.dtmp[g] = d;
+                }
+                __syncthreads();
+                const float dmine = (uint32_t)lane < nc ? L.dtmp[lane] : 0.f;
+                uint32_t rank = 0;
+                for (uint32_t t = 0; t < nc; ++t) { // Candidate order: score, then id (model.rs:55-61)
+                    const float dt = L.dtmp[t];
+                    const uint32_t it = L.kept[t];
+                    rank += (dt < dmine || (dt == dmine && it < v)) ? 1u : 0u;
+                }
+                __syncthreads();
+                if ((uint32_t)lane < nc) { L.cid[rank] = v; L.csc[rank] = dmine; }
+                __syncthreads();
+                const uint32_t keepn = select_diverse_dev<METRIC, FUSED>(ix, L, nc, maxn, lane);
+                bool kept_mine = false;
+                for (uint32_t t = 0; t < keepn; ++t) kept_mine |= L.kept[t] == v;
+                if ((uint32_t)lane < nc && !kept_mine) dropped_id = v;
+                store_canonical(row, stride, L.kept, keepn, lane, true);
+            } else if (!present) {
+                __syncthreads();
+                if ((uint32_t)lane < nc) L.kept[lane] = v;
+                __syncthreads();
+                store_canonical(row, stride, L.kept, nc, lane, true);
+            }
+            unlock_row(a.locks, to, lane);
+            // every neighbour dropped by the prune loses its edge to `to` as well: the graph stays symmetric
+            unsigned long long dm = __ballot(dropped_id != kSentinel);
+            while (dm) {
+                const uint32_t src = (uint32_t)__builtin_ctzll(dm);
+                dm &= dm - 1ull;
+                const uint32_t x = __builtin_amdgcn_readlane(dropped_id, src);
+                remove_edge_dev(a, (uint32_t)layer, x, to, lane);
+            }
+        }
+    }
+}
+
+template <typename K> static hipError_t launch_build(K kern, dim3 grid, const BuildArgs &a, hipStream_t s) {
+    const size_t lds = build_lds_bytes(a.ix.ld);
+    hipLaunchKernelGGL(kern, grid, dim3(64), lds, s, a);
+    return hipGetLastError();
+}
+
+__global__ void iota_kernel(uint32_t *p, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+
+} // namespace hvx
+
+extern "C" void hvx_build_params_default(hvx_build_params *p) {
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->ef_construction = 200; // DEFAULT_EF_CONSTRUCTION (mod.rs:702-708)
+    p->max_batch = 2048;
+    p->batch_divisor = 32;
+}
+
+extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_ids, const float *vectors, const uint16_t *levels,
+                               const hvx_build_params *params, hvx_index **out, hvx_build_stats *stats) {
+    if (!desc || !out || !params) return fail(HVX_ERR_INVARIANT, "null argument");
+    *out = nullptr;
+    const uint64_t n = desc->n;
+    if (n && (!node_ids || !vectors)) return fail(HVX_ERR_INVARIANT, "null array");
+    const uint32_t m = desc->m ? desc->m : 16u;
+    const uint32_t m0 = std::max(desc->m0 ? desc->m0 : 2u * m, 2u * m); // MutationDegreeLimits (mutation.rs:178-196)
+    const uint32_t efc = params->ef_construction ? params->ef_construction : 200u;
+    if (desc->dtype != HVX_F32) return fail(HVX_ERR_UNSUPPORTED, "the device build reads f32 rows (import the built graph with a reduced-precision dtype afterwards)");
+    if (m0 > 32u || m > 32u) return fail(HVX_ERR_UNSUPPORTED, "device build serves m0 <= 32");
+    if (std::max(efc, m0) + 32u > 384u) return fail(HVX_ERR_UNSUPPORTED, "device build serves ef_construction <= 352");
+    const uint32_t ef0 = std::max(efc, m0), efu = std::max(efc, 2u * m);
+
+    // ---- the image: rows + EMPTY graph with rows sized for m0 / m ----
+    hvx_index_desc d0 = *desc;
+    d0.m = m;
+    d0.m0 = m0;
+    d0.has_entry = 0;
+    d0.max_layer = 0;
+    uint32_t bmax = params->max_batch ? params->max_batch : 2048u;
+    if (d0.max_batch == 0) d0.max_batch = 1024;
+    if (bmax > d0.max_batch) bmax = d0.max_batch; // per-batch scratch of the search kernel is sized by max_batch
+    uint64_t up_rows = 0;
+    uint32_t top_level = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint16_t lv = levels ? levels[i] : 0;
+        if (lv > 63) return fail(HVX_ERR_INVARIANT, "node level > 63");
+        up_rows += lv;
+        top_level = std::max<uint32_t>(top_level, lv);
+    }
+    std::vector<uint64_t> zeros0(n + 1, 0), zerosu(up_rows + 1, 0);
+    uint64_t dummy = 0;
+    hvx_index *ix = nullptr;
+    int rc = import_index(&d0, node_ids, vectors, zeros0.data(), &dummy, levels, zerosu.data(), &dummy, m0, m, &ix);
+    if (rc) return rc;
+    auto bail = [&](int code) { hvx_index_free(ix); return code; };
+    HnswArgs probe{};
+    probe.ix = ix->dev;
+    probe.ef = ef0;
+    if (n && !hnsw_wave_supported(probe))
+        return bail(fail(HVX_ERR_UNSUPPORTED, "device build serves the one-wavefront-per-query kernel's shapes: f32 rows, L2 / cosine, "
+                         "AVX+FMA summation tree, dim in {128,256,512,768,1024,1536}"));
+    if (n == 0) { *out = ix; return HVX_OK; }
+    HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t s = ix->stream; // the handle is private to this call until it is returned: no lock
+    const uint32_t layers_max = top_level + 1u;
+    uint32_t *d_iota, *d_locks, *d_cnt, *d_sel, *d_selcnt, *d_status, *d_err;
+    uint64_t *d_cids;
+    float *d_csc;
+    // scratch is released with the build (hipFree below); the image keeps only rows + graph
+    std::vector<void *> scratch;
+    auto salloc = [&](void **p, size_t bytes) -> int {
+        if (hipMalloc(p, std::max<size_t>(bytes, 16)) != hipSuccess) return fail(HVX_ERR_DEVICE, "hipMalloc(%zu) build scratch", bytes);
+        scratch.push_back(*p);
+        return HVX_OK;
+    };
+    auto release = [&]() { for (void *p : scratch) (void)hipFree(p); scratch.clear(); };
+    auto sbail = [&](int code) { (void)hipStreamSynchronize(s); release(); return bail(code); };
+    if ((rc = salloc((void **)&d_iota, n * 4)) || (rc = salloc((void **)&d_locks, n * 4)) ||
+        (rc = salloc((void **)&d_cids, (size_t)layers_max * bmax * kCand * 8)) || (rc = salloc((void **)&d_csc, (size_t)layers_max * bmax * kCand * 4)) ||
+        (rc = salloc((void **)&d_cnt, (size_t)layers_max * bmax * 4)) || (rc = salloc((void **)&d_sel, (size_t)layers_max * bmax * 32 * 4)) ||
+        (rc = salloc((void **)&d_selcnt, (size_t)layers_max * bmax * 4)) || (rc = salloc((void **)&d_status, (size_t)bmax * 4)) ||
+        (rc = salloc((void **)&d_err, 4)))
+        return sbail(rc);
+    hipLaunchKernelGGL(iota_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, d_iota, (uint32_t)n);
+    if (hipMemsetAsync(d_locks, 0, n * 4, s) != hipSuccess || hipMemsetAsync(d_err, 0, 4, s) != hipSuccess) return sbail(fail(HVX_ERR_DEVICE, "memset"));
+
+    DevIndex &d = ix->dev;
+    uint32_t *l0w = const_cast<uint32_t *>(d.l0), *upw = const_cast<uint32_t *>(d.up);
+    const bool l2 = d.metric == kL2;
+    // first node: the entry point with empty rows on its layers (mutation.rs:706-739)
+    d.has_entry = 1;
+    d.entry = 0;
+    d.max_layer = levels ? levels[0] : 0;
+    uint64_t done = 1, batches = 0, singles = 1;
+    const uint32_t divisor = params->batch_divisor ? params->batch_divisor : 32u;
+    while (done < n) {
+        // batch = consecutive nodes; a node above the current top layer is inserted alone and becomes the entry point
+        uint32_t bsz = 1;
+        const uint16_t lv0 = levels ? levels[done] : 0;
+        const bool promotes = lv0 > d.max_layer;
+        if (!promotes && !params->sequential) {
+            uint64_t want = std::min<uint64_t>(std::max<uint64_t>(done / divisor, 1), bmax);
+            want = std::min<uint64_t>(want, n - done);
+            while (bsz < want && !((levels ? levels[done + bsz] : 0) > d.max_layer)) ++bsz;
+        }
+        const uint32_t layers = d.max_layer + 1u; // old max_layer + 1
+        HnswArgs a{};
+        a.ix = d;
+        a.bitmap = ix->d_bitmap;
+        a.words_per_query = ix->words_per_query;
+        a.k = kCand;
+        a.ef = ef0;
+        a.build_ef_upper = efu;
+        a.out_ids = d_cids;
+        a.out_scores = d_csc;
+        a.out_counts = d_cnt;
+        a.out_status = d_status;
+        a.tie_flags = ix->d_tie;
+        a.build_nodes = d_iota + done;
+        a.occupancy = 1;
+        if (launch_hnsw_wave(a, bsz, s) != hipSuccess) return sbail(fail(HVX_ERR_DEVICE, "build search launch failed: %s", hipGetErrorString(hipGetLastError())));
+        BuildArgs ba{};
+        ba.ix = d;
+        ba.l0 = l0w;
+        ba.up = upw;
+        ba.locks = d_locks;
+        ba.nodes = d_iota + done;
+        ba.b = bsz;
+        ba.layers = layers;
+        ba.cand_ids = d_cids;
+        ba.cand_sc = d_csc;
+        ba.cand_cnt = d_cnt;
+        ba.sel = d_sel;
+        ba.sel_cnt = d_selcnt;
+        ba.m = m;
+        ba.m0 = m0;
+        ba.err = d_err;
+        hipError_t e = l2 ? launch_build(build_select_kernel<kL2, true>, dim3(bsz, layers), ba, s)
+                          : launch_build(build_select_kernel<kCosine, true>, dim3(bsz, layers), ba, s);
+        if (e == hipSuccess)
+            e = l2 ? launch_build(build_link_kernel<kL2, true>, dim3(bsz), ba, s) : launch_build(build_link_kernel<kCosine, true>, dim3(bsz), ba, s);
+        if (e != hipSuccess) return sbail(fail(HVX_ERR_DEVICE, "build launch failed: %s", hipGetErrorString(e)));
+        if (promotes) { // mutation.rs:769-772
+            d.entry = (uint32_t)done;
+            d.max_layer = lv0;
+        }
+        done += bsz;
+        batches += 1;
+        singles += bsz == 1 ? 1 : 0;
+        if ((batches & 63u) == 0u && hipStreamSynchronize(s) != hipSuccess) // bound the launch queue
+            return sbail(fail(HVX_ERR_DEVICE, "build kernels failed: %s", hipGetErrorString(hipGetLastError())));
+    }
+    uint32_t err = 0;
+    if (hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        return sbail(fail(HVX_ERR_DEVICE, "build did not complete: %s", hipGetErrorString(hipGetLastError())));
+    release();
+    if (err) return bail(fail(HVX_ERR_INVARIANT, "a neighbour row overflowed its stride during the build"));
+    ix->desc.has_entry = 1;
+    ix->desc.entry_point = node_ids[d.entry];
+    ix->desc.max_layer = d.max_layer;
+    if (stats) {
+        stats->batches = batches;
+        stats->single_node_batches = singles;
+        stats->nodes = n;
+    }
+    *out = ix;
+    return HVX_OK;
+}
+
+// ---- graph read-back: what the host persists (values/vectors.rs rows) and what tests compare with the oracle ----
+extern "C" int hvx_index_graph_sizes(const hvx_index *cix, uint64_t *l0_edges, uint64_t *up_rows, uint64_t *up_edges,
+                                     uint64_t *entry_point, uint32_t *max_layer, uint32_t *has_entry) {
+    if (!cix) return fail(HVX_ERR_INVARIANT, "null index");
+    hvx_index *ix = const_cast<hvx_index *>(cix);
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    const DevIndex &d = ix->dev;
+    std::vector<uint32_t> h((size_t)d.n * d.s0);
+    if (d.n) HIP_TRY(hipMemcpy(h.data(), d.l0, h.size() * 4, hipMemcpyDeviceToHost));
+    uint64_t e0 = 0;
+    for (uint32_t v : h) e0 += v != kSentinel;
+    std::vector<uint16_t> lv(d.n);
+    if (d.n) HIP_TRY(hipMemcpy(lv.data(), d.level, (size_t)d.n * 2, hipMemcpyDeviceToHost));
+    uint64_t ur = 0;
+    for (uint16_t v : lv) ur += v;
+    std::vector<uint32_t> hu((size_t)ur * d.su);
+    if (ur) HIP_TRY(hipMemcpy(hu.data(), d.up, hu.size() * 4, hipMemcpyDeviceToHost));
+    uint64_t eu = 0;
+    for (uint32_t v : hu) eu += v != kSentinel;
+    if (l0_edges) *l0_edges = e0;
+    if (up_rows) *up_rows = ur;
+    if (up_edges) *up_edges = eu;
+    if (entry_point) *entry_point = d.has_entry ? ix->ids_ref()[d.entry] : 0;
+    if (max_layer) *max_layer = d.max_layer;
+    if (has_entry) *has_entry = d.has_entry;
+    return HVX_OK;
+}
+
+extern "C" int hvx_index_export_graph(const hvx_index *cix, uint64_t *l0_offsets, uint64_t *l0_neighbors, uint16_t *level,
+                                      uint64_t *up_offsets, uint64_t *up_neighbors) {
+    if (!cix || !l0_offsets || !l0_neighbors) return fail(HVX_ERR_INVARIANT, "null argument");
+    hvx_index *ix = const_cast<hvx_index *>(cix);
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    const DevIndex &d = ix->dev;
+    const std::vector<uint64_t> &ids = ix->ids_ref();
+    std::vector<uint32_t> h((size_t)d.n * d.s0);
+    if (d.n) HIP_TRY(hipMemcpy(h.data(), d.l0, h.size() * 4, hipMemcpyDeviceToHost));
+    uint64_t w = 0;
+    for (uint32_t i = 0; i < d.n; ++i) {
+        l0_offsets[i] = w;
+        for (uint32_t t = 0; t < d.s0; ++t) {
+            const uint32_t v = h[(size_t)i * d.s0 + t];
+            if (v != kSentinel) l0_neighbors[w++] = ids[v];
+        }
+    }
+    l0_offsets[d.n] = w;
+    std::vector<uint16_t> lv(d.n);
+    if (d.n) HIP_TRY(hipMemcpy(lv.data(), d.level, (size_t)d.n * 2, hipMemcpyDeviceToHost));
+    if (level) memcpy(level, lv.data(), (size_t)d.n * 2);
+    uint64_t ur = 0;
+    for (uint16_t v : lv) ur += v;
+    if (up_offsets && up_neighbors) {
+        std::vector<uint32_t> hu((size_t)ur * d.su);
+        if (ur) HIP_TRY(hipMemcpy(hu.data(), d.up, hu.size() * 4, hipMemcpyDeviceToHost));
+        uint64_t wu = 0;
+        for (uint64_t r = 0; r < ur; ++r) {
+            up_offsets[r] = wu;
+            for (uint32_t t = 0; t < d.su; ++t) {
+                const uint32_t v = hu[(size_t)r * d.su + t];
+                if (v != kSentinel) up_neighbors[wu++] = ids[v];
+            }
+        }
+        up_offsets[ur] = wu;
+    }
+    return HVX_OK;
+}

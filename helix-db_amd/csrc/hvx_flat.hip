@@ -224,6 +224,12 @@ __global__ __launch_bounds__(256) void flat_select_kernel(FlatArgs a, uint32_t *
     const int tid = (int)threadIdx.x;
     const uint32_t k = a.k;
     const float inf = __uint_as_float(0x7F800000u);
+    // a query rejected by validation (NaN / zero-norm / magnitude: domain.rs:113-157) keeps its status and gets no rows:
+    // its scores would be NaN and must not be reported as an invariant violation
+    if (status && status[q] != 0u) {
+        if (tid == 0) a.top_counts[q] = 0u;
+        return;
+    }
     const uint32_t have = a.top_counts[q];
     for (int i = tid; i < kPool; i += 256) {
         bool in = (uint32_t)i < have;
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(256) void flat_select_kernel(FlatArgs a, uint32_t *
     }
     if (tid == 0) {
         a.top_counts[q] = keep;
-        if (bad && status) status[q] = 8u; // HVX_ERR_INVARIANT
+        if (bad && status && status[q] == 0u) status[q] = 8u; // HVX_ERR_INVARIANT
     }
 }
 

@@ -446,6 +446,10 @@ int flat_mfma_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t
         return fail(HVX_ERR_UNSUPPORTED, "bf16 / fp8 exact scan serves dim in {128,256,512,768,1024,1536}");
     HIP_TRY(launch_validate_queries(d, d_queries, b, ix->limit, ix->d_qstatus, ix->d_qhdr, ix->stream));
     if (n == 0) {
+        if (timed) { // the caller reads ev0 -> ev1: an empty scan is a zero-length interval, not a stale one
+            HIP_TRY(hipEventRecord(ix->ev0, ix->stream));
+            HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
+        }
         HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)b * 4, ix->stream));
         if (d_status) HIP_TRY(hipMemcpyAsync(d_status, ix->d_qstatus, (size_t)b * 4, hipMemcpyDeviceToDevice, ix->stream));
         return HVX_OK;

@@ -307,6 +307,7 @@ struct WaveGeom {
 };
 hipError_t launch_hnsw_wave_occ2(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_occ2_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_build(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_l2(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_cos(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_prof(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
@@ -346,10 +347,11 @@ hipError_t launch_hnsw_wave(const HnswArgs &a, uint32_t b, hipStream_t s) {
     // per expansion); the kernel spills to the exact HBM bitmap beyond 3/4 full
     g.log2cap = 11;
     while ((1u << g.log2cap) < 64u * a.ef && g.log2cap < 15) ++g.log2cap;
+    if (a.build_nodes && g.log2cap > 13) g.log2cap = 13; // build searches (ef_construction ~200): keep four workgroups per CU
     g.log2cap = (uint32_t)env_int("HVX_WAVE_LOG2CAP", 7, 15, (int)g.log2cap); // test hook: tiny table => spill path
     // 160 KiB / 4: exactly four resident wavefronts per CU, one per SIMD, each with the SIMD's whole register file.
     // occ = 2 (a.occupancy): eight per CU, two per SIMD -- the table shrinks until query + frontier + table fit 20 KiB
-    g.occ = (a.occupancy == 2 && !a.adaptive && !a.prof) ? 2u : 1u;
+    g.occ = (a.occupancy == 2 && !a.adaptive && !a.prof && !a.build_nodes) ? 2u : 1u;
     const size_t fixed = 512 + (size_t)a.ix.dim * 4 + (a.adaptive ? kRngWords * 4 : 0);
     if (g.occ == 2) {
         while (g.log2cap > 9 && ((size_t)4 << g.log2cap) + fixed > 20 * 1024) --g.log2cap;
@@ -359,6 +361,7 @@ hipError_t launch_hnsw_wave(const HnswArgs &a, uint32_t b, hipStream_t s) {
     const size_t need = ((size_t)4 << g.log2cap) + fixed;
     g.lds = need < budget ? budget : need;
     if (g.occ == 2) return a.ix.dtype == HVX_BF16 ? launch_hnsw_wave_occ2_bf16(a, b, g, s) : launch_hnsw_wave_occ2(a, b, g, s);
+    if (a.build_nodes) return launch_hnsw_wave_build(a, b, g, s);
     if (a.adaptive) {
         if (a.ix.dtype == HVX_BF16) return a.ix.metric == kL2 ? launch_hnsw_wave_l2_bf16_ad(a, b, g, s) : launch_hnsw_wave_cos_bf16_ad(a, b, g, s);
         return a.ix.metric == kL2 ? launch_hnsw_wave_l2_ad(a, b, g, s) : launch_hnsw_wave_cos_ad(a, b, g, s);

@@ -470,7 +470,11 @@ __device__ __forceinline__ float candidate_probability_fn(uint32_t kind, float b
 // (passes of up to 32 rows in flight), 2 = two queries share a SIMD (256 registers each, passes of up to 16 rows, half the
 // LDS): the row gathers of one query run underneath the beam bookkeeping of the other -- the build for callers that keep
 // >= 2 batches in flight (execution lanes, hvx_index_fork).
-template <uint32_t METRIC, int R, int NK, bool BF, bool PROF = false, bool AD = false, bool ST = true, int OCC = 1>
+// BUILD = the search side of a batched insert_hnsw (mutation.rs:787-895; hvx_build.hip): the "query" of wavefront q is the
+// stored row of node build_nodes[q], the descent is greedy above min(level, max_layer) and a full beam
+// (search_layer_beam, mutation.rs:904-1005 -- the same algorithm as the strict layer-0 search) on every layer from
+// there down to 0; the first k entries of every layer's W (internal ids, scores) are written per layer.
+template <uint32_t METRIC, int R, int NK, bool BF, bool PROF = false, bool AD = false, bool ST = true, int OCC = 1, bool BUILD = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void hnsw_wave_kernel(HnswArgs a, uint32_t log2cap) {
     // rows per 8-lane group in flight: P*NK <= 24 float4 per lane for a narrow pass, x2 and x4 for wider
     // frontiers (4P*NK <= 96 float4 = 384 registers, VGPR+AGPR file of one wave per SIMD)
@@ -501,7 +505,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
     uint32_t *rng_buf = reinterpret_cast<uint32_t *>(qs + NK * 32); // [kRngWords] (AD only)
 
     const unsigned long long wclk0 = a.wave_clock ? wall_clock64() : 0ull;
-    const uint32_t status_in = a.qstatus ? a.qstatus[q] : 0u;
+    const uint32_t status_in = BUILD ? 0u : (a.qstatus ? a.qstatus[q] : 0u);
     if (status_in != 0u || !ix.has_entry) {
         if (lane == 0) {
             if (a.wave_clock) { a.wave_clock[2 * (size_t)q] = wclk0; a.wave_clock[2 * (size_t)q + 1] = wclk0; }
@@ -513,11 +517,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
         }
         return;
     }
-    const float *qglobal = a.queries + (size_t)q * ix.dim;
+    const uint32_t bnode = BUILD ? a.build_nodes[q] : 0u;
+    const float *qglobal = BUILD ? ix.vec + (size_t)bnode * ix.ld : a.queries + (size_t)q * ix.dim;
     for (uint32_t i = (uint32_t)lane; i < (uint32_t)NK * 8u; i += 64)
         reinterpret_cast<float4 *>(qs)[i] = reinterpret_cast<const float4 *>(qglobal)[i];
     __syncthreads();
-    const float qhdr = a.qhdr ? a.qhdr[q] : 0.f;
+    const float qhdr = BUILD ? ix.hdr[bnode] : (a.qhdr ? a.qhdr[q] : 0.f);
     const float inf = __uint_as_float(0x7F800000u);
 
     // one pass of W rows per group over fr_id[f0..nf): issue everything, then FMA, then publish
@@ -598,7 +603,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
         cur_base = ix.up_base[cur];
         cur_level = ix.level[cur];
     }
-    for (uint32_t layer = ix.max_layer; layer >= 1; --layer) {
+    uint32_t beam_top = 0; // BUILD: the beam runs on every layer from min(node level, max_layer) down to 0
+    if (BUILD) {
+        const uint32_t lv = ix.level[bnode];
+        beam_top = lv < ix.max_layer ? lv : ix.max_layer;
+    }
+    for (uint32_t layer = ix.max_layer; layer >= 1 && layer > beam_top; --layer) {
         V.clear(lane); // fresh visited set per layer
         if (!have_d) {
             cur_d = score_one(cur);
@@ -637,11 +647,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
 
     // ---------------- layer 0: strict-exhaustive beam (search.rs:267-1067) ----------------
     Beam<R> S;
-    S.init();
     uint32_t st_exp = 0, st_nb = 0, st_vl = 0, st_dc = 0;
     bool tie_overflow = false;
+    uint32_t bl = beam_top; // the layer the beam runs on (always 0 outside BUILD)
+    // neighbour row of node c on the beam's layer, one id per lane
+    auto load_row = [&](uint32_t c) __attribute__((always_inline)) -> uint32_t {
+        if (!BUILD || bl == 0u) return (uint32_t)lane < ix.s0 ? ix.l0[(size_t)c * ix.s0 + (uint32_t)lane] : kSentinel;
+        const uint32_t base = ix.up_base[c]; // every node reached on layer bl >= 1 lives there: its row exists
+        return (uint32_t)lane < ix.su ? ix.up[(size_t)(base + bl - 1u) * ix.su + (uint32_t)lane] : kSentinel;
+    };
     uint32_t dropped_unexpanded = 0;
-    const uint32_t ef = a.ef;
+    uint32_t ef = a.ef;
     uint32_t pf_id = kSentinel, pf_row = kSentinel; // predicted next candidate and its prefetched row
     // non-strict arms with a SimHash filter: the SimHash rows of the prefetched neighbour row are requested underneath
     // the admission loop, so the filter of the next expansion does not wait for an 8-byte gather of its own
@@ -654,7 +670,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
             pf_hash_for = pf_id;
         }
     };
-    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0; // PROF only
+    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0, t_begin = 0; // PROF only
     auto tick = [&](int phase, bool wait) __attribute__((always_inline)) {
         if (PROF) {
             if (wait) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -677,6 +693,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
         const uint64_t ep = ix.ids[cur], efw = (uint64_t)a.ef;
         G.seed(qh ^ ((ep << 17) | (ep >> 47)) ^ ((efw << 7) | (efw >> 57)));
     }
+  for (;;) { // one pass outside BUILD; BUILD: one beam per layer, bl = beam_top .. 0
+    S.init();
+    dropped_unexpanded = 0;
+    ef = (BUILD && bl > 0u) ? a.build_ef_upper : a.ef;
+    pf_id = kSentinel;
+    pf_row = kSentinel;
     if (!bad_score) {
         V.clear(lane);
         float d0 = have_d ? cur_d : score_one(cur); // search.rs:500-512: the same distance once more
@@ -686,7 +708,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
         float ds;
         S.insert(d0, cur, lane, ds);
     }
-    const unsigned long long t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
+    t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
     if (PROF) t0 = t_begin;
     while (!bad_score) {
         const uint32_t pos = S.first_unexpanded(lane);
@@ -710,7 +732,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
 
         uint32_t nid;
         if (c == pf_id) { nid = pf_row; if (PROF) pt[6] += 1; }
-        else nid = (uint32_t)lane < ix.s0 ? ix.l0[(size_t)c * ix.s0 + (uint32_t)lane] : kSentinel;
+        else nid = load_row(c);
         tick(0, true); // pop + neighbour row available
         unsigned long long nh = 0ull;
         if (AD && want_hash) nh = c == pf_hash_for ? pf_hash : (nid != kSentinel ? a.ad.node_hash[nid] : 0ull);
@@ -727,7 +749,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
         if (p2 < S.count) {
             e2 = S.id_at(p2);
             s2 = S.score_at(p2);
-            row2 = (uint32_t)lane < ix.s0 ? ix.l0[(size_t)e2 * ix.s0 + (uint32_t)lane] : kSentinel;
+            row2 = load_row(e2);
         }
         pf_id = e2;
         pf_row = row2;
@@ -851,7 +873,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
             if (kmin != 0xFFFFFFFFu && __uint_as_float(kmin) < s2) {
                 const uint32_t pred = __builtin_amdgcn_readlane(id_l, (uint32_t)__builtin_ctzll(__ballot(key == kmin)));
                 pf_id = pred;
-                pf_row = (uint32_t)lane < ix.s0 ? ix.l0[(size_t)pred * ix.s0 + (uint32_t)lane] : kSentinel;
+                pf_row = load_row(pred);
                 if (PROF) pt[5] += 1; // the predicted next pop is a candidate discovered by THIS expansion
             }
         }
@@ -889,6 +911,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
         prefetch_hash(); // a fresh-candidate prediction replaced the prefetched row during this expansion
         if (PROF) { t1 = __builtin_readcyclecounter(); pt[4] += t1 - t0; t0 = t1; } // admission loop
     }
+    if (!BUILD) break;
+    // ---- BUILD: this layer's candidates (W sorted by (score, id), first k) -> [layer][b][k]; next layer starts at the best ----
+    {
+        const uint32_t wl = bad_score ? 0u : (S.count < ef ? S.count : ef);
+        const uint32_t outn = wl < a.k ? wl : a.k;
+        const size_t slot0 = ((size_t)bl * gridDim.x + q) * a.k;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t e = (uint32_t)r * 64u + (uint32_t)lane;
+            if (e < outn) {
+                a.out_ids[slot0 + e] = (uint64_t)(S.id[r] & ~kExpandedBit);
+                a.out_scores[slot0 + e] = S.sc[r];
+            }
+        }
+        if (lane == 0) a.out_counts[(size_t)bl * gridDim.x + q] = outn;
+        if (bad_score || bl == 0u) break;
+        cur = S.id_at(0) & ~kExpandedBit; // mutation.rs:876-878: the closest candidate enters the next layer
+        cur_d = S.score_at(0);
+        have_d = true;
+        --bl;
+    }
+  }
     if (PROF && a.prof && lane == 0) {
         // cycles: [0] pop+row wait [1] visited [2] gather wait+FMA [3] predict [4] admit [7] whole layer-0 loop;
         // counts: [5] predictions that chose a fresh candidate [6] row-prefetch hits
@@ -898,7 +942,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
 
     // ---------------- results: w sorted by (score,id), take k (search.rs:995-1004,1229) ----------------
     uint32_t outn = 0;
-    if (!bad_score) {
+    if (!BUILD && !bad_score) {
+        const uint32_t ef = a.ef;
         const uint32_t wl = S.count < ef ? S.count : ef;
         outn = wl < a.k ? wl : a.k;
 #pragma unroll
@@ -915,7 +960,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
     }
     if (lane == 0) {
         if (a.wave_clock) { a.wave_clock[2 * (size_t)q] = wclk0; a.wave_clock[2 * (size_t)q + 1] = wall_clock64(); }
-        a.out_counts[q] = outn;
+        if (!BUILD) a.out_counts[q] = outn;
         if (a.out_status) a.out_status[q] = bad_score ? 8u /*HVX_ERR_INVARIANT*/ : 0u;
         if (a.qstats) a.qstats[q] = hvx_query_stats{st_exp, st_nb, st_vl, st_dc};
         if (a.tie_flags) a.tie_flags[q] = tie_overflow ? 1u : 0u;
@@ -943,6 +988,8 @@ hipError_t launch_hnsw_wave_prof(const HnswArgs &a, uint32_t b, const WaveGeom &
 // two queries per SIMD (OCC = 2 builds), hvx_hnsw_wave_occ2.hip
 hipError_t launch_hnsw_wave_occ2(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_occ2_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+// search side of the device HNSW build (BUILD instantiations), hvx_hnsw_wave_build.hip
+hipError_t launch_hnsw_wave_build(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 // non-strict arms (AD instantiations), hvx_hnsw_wave_l2_ad.hip / hvx_hnsw_wave_cos_ad.hip
 hipError_t launch_hnsw_wave_l2_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_cos_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
@@ -958,15 +1005,15 @@ template <typename K> static hipError_t launch_wave_kernel(K kern, const HnswArg
     return hipGetLastError();
 }
 
-template <uint32_t METRIC, int R, bool BF, bool AD = false, bool ST = true, int OCC = 1>
+template <uint32_t METRIC, int R, bool BF, bool AD = false, bool ST = true, int OCC = 1, bool BUILD = false>
 static hipError_t launch_wave_nk(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
     switch (a.ix.dim >> 5) {
-    case 4: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 4, BF, false, AD, ST, OCC>, a, b, g, s);
-    case 8: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 8, BF, false, AD, ST, OCC>, a, b, g, s);
-    case 16: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 16, BF, false, AD, ST, OCC>, a, b, g, s);
-    case 24: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 24, BF, false, AD, ST, OCC>, a, b, g, s);
-    case 32: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 32, BF, false, AD, ST, OCC>, a, b, g, s);
-    case 48: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 48, BF, false, AD, ST, OCC>, a, b, g, s);
+    case 4: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 4, BF, false, AD, ST, OCC, BUILD>, a, b, g, s);
+    case 8: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 8, BF, false, AD, ST, OCC, BUILD>, a, b, g, s);
+    case 16: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 16, BF, false, AD, ST, OCC, BUILD>, a, b, g, s);
+    case 24: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 24, BF, false, AD, ST, OCC, BUILD>, a, b, g, s);
+    case 32: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 32, BF, false, AD, ST, OCC, BUILD>, a, b, g, s);
+    case 48: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 48, BF, false, AD, ST, OCC, BUILD>, a, b, g, s);
     default: return hipErrorInvalidValue;
     }
 }

@@ -105,6 +105,9 @@ struct hvx_index {
 
 namespace hvx {
 int fail(int code, const char *fmt, ...);
+int import_index(const hvx_index_desc *desc, const uint64_t *node_ids, const float *vectors, const uint64_t *l0_offsets,
+                 const uint64_t *l0_neighbors, const uint16_t *level, const uint64_t *up_offsets, const uint64_t *up_neighbors,
+                 uint32_t min_s0, uint32_t min_su, hvx_index **out);
 int check_k_ef(uint32_t k, uint32_t ef);
 // enqueue validation + the search kernel for one chunk of <= max_batch device-resident queries;
 // ad != NULL selects the non-strict arms

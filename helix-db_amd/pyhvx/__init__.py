@@ -88,6 +88,14 @@ class SimHashConfig(C.Structure):  # hvx_simhash_config: the index-level VectorI
         return c
 
 
+class BuildParams(C.Structure):  # hvx_build_params
+    _fields_ = [("ef_construction", C.c_uint32), ("max_batch", C.c_uint32), ("batch_divisor", C.c_uint32), ("sequential", C.c_uint32)]
+
+
+class BuildStats(C.Structure):  # hvx_build_stats
+    _fields_ = [("nodes", C.c_uint64), ("batches", C.c_uint64), ("single_node_batches", C.c_uint64)]
+
+
 class AdaptiveStats(C.Structure):  # hvx_adaptive_stats
     _fields_ = [(n, C.c_uint32) for n in (
         "simhash_filtered", "simhash_examined", "simhash_passed_before_sampling", "simhash_passed_after_sampling",
@@ -124,6 +132,15 @@ def lib():
     L.hvx_index_stream.argtypes = [_vp]
     L.hvx_index_set_stream.restype = C.c_int
     L.hvx_index_set_stream.argtypes = [_vp, _vp]
+    L.hvx_build_params_default.restype = None
+    L.hvx_build_params_default.argtypes = [C.POINTER(BuildParams)]
+    L.hvx_index_build.restype = C.c_int
+    L.hvx_index_build.argtypes = [C.POINTER(_Desc), _vp, _vp, _vp, C.POINTER(BuildParams), C.POINTER(_vp), C.POINTER(BuildStats)]
+    L.hvx_index_graph_sizes.restype = C.c_int
+    L.hvx_index_graph_sizes.argtypes = [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.hvx_index_export_graph.restype = C.c_int
+    L.hvx_index_export_graph.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp]
     L.hvx_index_fork.restype = C.c_int
     L.hvx_index_fork.argtypes = [_vp, C.POINTER(_vp)]
     L.hvx_index_set_occupancy.restype = C.c_int
@@ -375,6 +392,37 @@ class ValidatedVectorReadIndex:
         _check(lib().hvx_index_import(C.byref(d), _ptr(ids), _vp(vectors.data_ptr()) if dev_rows else _ptr(vec), _ptr(o0), _ptr(n0), _ptr(lv),
                                       _ptr(uo), _ptr(un), C.byref(h)))
         return cls(h, dim, metric, int(ids.size))
+
+    @classmethod
+    def build(cls, *, dim, metric, node_ids, vectors, levels=None, m=16, m0=32, ef_construction=200, max_batch=2048,
+              batch_divisor=32, sequential=False, device=-1, search_max_batch=None, float_kernel=KERNEL_AVX_FMA):
+        """GPU-assisted HNSW build (hvx_index_build): the reference's insert_hnsw for batches of nodes on the device.
+        Returns (index, stats dict).  `vectors` may be a host array or a torch tensor resident on the device."""
+        ids = np.ascontiguousarray(node_ids, dtype=np.uint64)
+        dev_rows = hasattr(vectors, "data_ptr")
+        vec = None if dev_rows else (np.ascontiguousarray(vectors, dtype=np.float32).reshape(ids.size, dim) if ids.size else np.zeros((0, dim), np.float32))
+        lv = None if levels is None else np.ascontiguousarray(levels, dtype=np.uint16)
+        d = _Desc(dim=dim, metric=metric, dtype=F32, float_kernel=float_kernel, n=ids.size, m=m, m0=m0, has_entry=0, max_layer=0,
+                  entry_point=0, shard_id_lo=int(ids[0]) if ids.size else 0, shard_id_hi=int(ids[-1]) if ids.size else 0,
+                  device=device, max_batch=max(max_batch, search_max_batch or 1024))
+        bp = BuildParams(ef_construction=ef_construction, max_batch=max_batch, batch_divisor=batch_divisor, sequential=1 if sequential else 0)
+        st = BuildStats()
+        h = _vp()
+        _check(lib().hvx_index_build(C.byref(d), _ptr(ids), _vp(vectors.data_ptr()) if dev_rows else _ptr(vec), _ptr(lv), C.byref(bp),
+                                     C.byref(h), C.byref(st)))
+        return cls(h, dim, metric, int(ids.size)), {"nodes": st.nodes, "batches": st.batches, "single_node_batches": st.single_node_batches}
+
+    def export_graph(self) -> dict:
+        """The index's graph in hvx_index_import's CSR layout (external ids): what the host persists / tests compare."""
+        e0, ur, eu, ep = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        ml, he = C.c_uint32(0), C.c_uint32(0)
+        _check(lib().hvx_index_graph_sizes(self._h, C.byref(e0), C.byref(ur), C.byref(eu), C.byref(ep), C.byref(ml), C.byref(he)))
+        l0o = np.zeros(self.n + 1, np.uint64); l0n = np.zeros(max(e0.value, 1), np.uint64)
+        lv = np.zeros(max(self.n, 1), np.uint16)
+        uo = np.zeros(ur.value + 1, np.uint64); un = np.zeros(max(eu.value, 1), np.uint64)
+        _check(lib().hvx_index_export_graph(self._h, _ptr(l0o), _ptr(l0n), _ptr(lv), _ptr(uo), _ptr(un)))
+        return {"l0_offsets": l0o, "l0_neighbors": l0n[: e0.value], "level": lv[: self.n], "up_offsets": uo, "up_neighbors": un[: eu.value],
+                "entry_point": int(ep.value) if he.value else None, "max_layer": int(ml.value)}
 
     @classmethod
     def from_export(cls, ex: dict, *, dim, metric, **kw):

@@ -131,8 +131,12 @@ int hvx_index_wave_clocks(hvx_index *, uint64_t *out, uint32_t cap_launches, uin
  * ValidatedVectorReadIndex::search (read_index.rs:83-92) -> VectorIndex::search (index.rs:1578-1587)
  * -> SearchSession::run (search.rs:1101-1230), strict-exhaustive arm, for b queries at once.
  * Results per query sorted (score asc, id asc), count <= min(k, population).
- * out_status: per-query hvx_status, nullable; when NULL the first failing query's status is returned
- * and no results are written.
+ * out_status: per-query hvx_status, nullable; when NULL the first failing query's status is returned (the rows of
+ * the queries that did succeed have been written by then; a rejected query's row is left untouched, count 0).
+ * Limits of this build: ef <= 992; the one-wavefront-per-query kernel serves dim in {128,256,512,768,1024,1536} with
+ * rows <= 64 ids and ef <= 352, the general kernel everything else (any dim / metric, rows <= 128 ids).
+ * A query whose beam evicted equal-score candidates beyond the 32-entry slack is re-run with a wider beam; only if
+ * that is not possible is it counted in hvx_stats.tie_overflow_queries.
  */
 int hvx_search_batch(const hvx_index *, const float *queries /*[b][dim]*/, uint32_t b, uint32_t k,
                      uint32_t ef, uint64_t *out_ids /*[b][k]*/, float *out_scores /*[b][k]*/,
@@ -347,6 +351,39 @@ int hvx_hydrator_add_upper_row(hvx_hydrator *, uint64_t node_id, uint32_t layer,
 int hvx_hydrator_set_entry(hvx_hydrator *, uint64_t entry_point, uint32_t max_layer);
 /* `tmpl` supplies dtype, float_kernel, m, m0, device, max_batch; the rest comes from the collected rows */
 int hvx_hydrator_finish(const hvx_hydrator *, const hvx_index_desc *tmpl, hvx_index **out);
+
+/*
+ * GPU-assisted HNSW build: the reference's insert path (mutation.rs:642-895 insert_with_mutation_cache /
+ * insert_hnsw: greedy descent, search_layer_beam per layer :904-1005, select_neighbors_heuristic :1072-1097 = select_diverse
+ * mod.rs:809-856, add_bidirectional_link with prune + reverse-edge removal :1498-1583,1890-1908) over rows resident in HBM,
+ * for batches of consecutive nodes.  `levels[i]` = the node's top layer (drawn by the host with select_layer_from_uniform,
+ * mod.rs:776-796 -- the reference's draw is intentionally non-deterministic, randomness.rs:41-46).  Nodes are inserted in
+ * node-id order.  With params->sequential != 0 every batch holds ONE node and the graph equals the reference's sequential
+ * insertion row for row; otherwise a batch holds up to min(max_batch, inserted / batch_divisor) nodes that do not see each
+ * other (a node above the current top layer is always inserted alone and becomes the entry point).  The result is an
+ * ordinary searchable hvx_index; hvx_index_export_graph hands the rows back for the host to persist (values/vectors.rs).
+ * Served shapes: f32 rows, cosine / Euclidean, AVX+FMA summation tree, dim in {128,256,512,768,1024,1536}, m0 <= 32,
+ * ef_construction <= 352; desc->max_batch bounds the batch size.
+ */
+typedef struct hvx_build_params {
+    uint32_t ef_construction; /* 0 => 200 (mod.rs:702-708) */
+    uint32_t max_batch;       /* 0 => 2048 */
+    uint32_t batch_divisor;   /* 0 => 32: batch <= nodes already inserted / divisor */
+    uint32_t sequential;      /* 1 => one node per batch: the reference's insertion order exactly */
+} hvx_build_params;
+typedef struct hvx_build_stats {
+    uint64_t nodes, batches, single_node_batches;
+} hvx_build_stats;
+void hvx_build_params_default(hvx_build_params *);
+int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_ids, const float *vectors /*host or device*/,
+                    const uint16_t *levels /*[n] or NULL = all layer 0*/, const hvx_build_params *params, hvx_index **out,
+                    hvx_build_stats *stats /*nullable*/);
+/* Read the graph of an index back in hvx_index_import's CSR layout (external ids, rows ascending): sizes first, then the arrays
+ * (l0_offsets [n+1], l0_neighbors [l0_edges], level [n] nullable, up_offsets [up_rows+1] / up_neighbors [up_edges] nullable). */
+int hvx_index_graph_sizes(const hvx_index *, uint64_t *l0_edges, uint64_t *up_rows, uint64_t *up_edges, uint64_t *entry_point,
+                          uint32_t *max_layer, uint32_t *has_entry);
+int hvx_index_export_graph(const hvx_index *, uint64_t *l0_offsets, uint64_t *l0_neighbors, uint16_t *level, uint64_t *up_offsets,
+                           uint64_t *up_neighbors);
 
 const char *hvx_last_error(void); /* thread-local */
 const char *hvx_version(void);

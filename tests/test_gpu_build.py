@@ -1,0 +1,108 @@
+"""GPU-assisted HNSW build (hvx_index_build, csrc/hvx_build.hip) against the oracle's restatement of the
+reference's sequential insertion (orc_index_insert == mutation.rs:642-895)."""
+import numpy as np
+import pytest
+
+import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hv():
+    import pyhvx
+    pyhvx.lib()
+    return pyhvx
+
+
+def oracle_build(orc, data, metric, levels, m, m0, efc, ids):
+    oix = orc.Index(data.shape[1], metric, kernel=orc.K_AVX_FMA, m=m, m0=m0, ef_construction=efc)
+    for i in range(data.shape[0]):
+        assert oix.insert(int(ids[i]), data[i], int(levels[i])) == orc.OK
+    return oix
+
+
+def rows_of(g, n):
+    l0 = [g["l0_neighbors"][int(g["l0_offsets"][i]):int(g["l0_offsets"][i + 1])].tolist() for i in range(n)]
+    up = [g["up_neighbors"][int(g["up_offsets"][r]):int(g["up_offsets"][r + 1])].tolist() for r in range(len(g["up_offsets"]) - 1)]
+    return l0, up
+
+
+@pytest.mark.parametrize("n,dim,metric,m,m0,efc", [(5000, 128, 1, 16, 32, 100), (2500, 128, 0, 16, 32, 200), (1500, 768, 1, 8, 16, 64),
+                                                   (1200, 256, 1, 16, 32, 40)])
+def test_sequential_device_build_equals_the_oracles_insertion_row_for_row(orc, hv, n, dim, metric, m, m0, efc):
+    """sequential=True: one node per batch == insert_hnsw in node-id order: every layer-0 row, every upper row, the entry
+    point and the top layer equal the oracle's (levels scripted, as the reference's tests do)."""
+    rng = np.random.default_rng(7000 + dim + metric + n)
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    lv = fx.draw_levels(n, m, seed=n)
+    ids = np.arange(n, dtype=np.uint64) * 2 + 11
+    oix = oracle_build(orc, data, metric, lv, m, m0, efc, ids)
+    ex = oix.export()
+    gix, st = hv.ValidatedVectorReadIndex.build(dim=dim, metric=metric, node_ids=ids, vectors=data, levels=lv, m=m, m0=m0,
+                                                ef_construction=efc, sequential=True)
+    assert st["nodes"] == n and st["batches"] == n - 1
+    g = gix.export_graph()
+    assert g["entry_point"] == ex["entry_point"] and g["max_layer"] == ex["max_layer"]
+    assert g["level"].tolist() == ex["level"].tolist()
+    gl0, gup = rows_of(g, n)
+    ol0, oup = rows_of(ex, n)
+    bad = [i for i in range(n) if gl0[i] != ol0[i]]
+    assert not bad, f"{len(bad)} layer-0 rows differ, first {bad[:5]}: device {gl0[bad[0]]} oracle {ol0[bad[0]]}"
+    assert gup == oup
+    # and the built index searches like the oracle's
+    q = rng.standard_normal((16, dim)).astype(np.float32)
+    gid, gsc, gcnt, _ = gix.search_batch(q, hv.SearchParams(10).with_ef(64))
+    for qi in range(16):
+        rc, oid, osc = oix.search(q[qi], 10, 64)
+        assert gid[qi, :gcnt[qi]].tolist() == oid.tolist()
+        assert gsc[qi, :gcnt[qi]].view(np.uint32).tolist() == osc.view(np.uint32).tolist()
+
+
+@pytest.mark.parametrize("n,dim,metric", [(20000, 128, 1), (12000, 256, 0)])
+def test_batched_device_build_invariants_and_recall(orc, hv, n, dim, metric):
+    """Batched insertion: rows canonical (ascending, deduped, self-free), degree-bounded, symmetric on every layer
+    (the reference keeps the persisted graph symmetric: mutation.rs:1498-1583,1890-1908), entry on the top layer, and the
+    graph searches as well as the sequentially built one."""
+    rng = np.random.default_rng(8000 + dim)
+    centres = rng.standard_normal((64, dim)).astype(np.float32)
+    data = (centres[rng.integers(0, 64, n)] + 0.5 * rng.standard_normal((n, dim))).astype(np.float32)
+    m, m0, efc = 16, 32, 100
+    lv = fx.draw_levels(n, m, seed=3)
+    ids = np.arange(n, dtype=np.uint64)
+    gix, st = hv.ValidatedVectorReadIndex.build(dim=dim, metric=metric, node_ids=ids, vectors=data, levels=lv, m=m, m0=m0,
+                                                ef_construction=efc, max_batch=512, batch_divisor=16)
+    assert st["batches"] < n // 4
+    g = gix.export_graph()
+    top = int(lv.max())
+    assert g["max_layer"] == top and lv[g["entry_point"]] == top
+    l0, up = rows_of(g, n)
+    edges = [set() for _ in range(top + 1)]
+    for i in range(n):
+        r = l0[i]
+        assert r == sorted(set(r)) and i not in r and len(r) <= m0
+        edges[0].update((i, t) for t in r)
+    r_idx = 0
+    for i in range(n):
+        for layer in range(1, int(lv[i]) + 1):
+            r = up[r_idx]
+            r_idx += 1
+            assert r == sorted(set(r)) and i not in r and len(r) <= m
+            assert all(lv[t] >= layer for t in r)
+            edges[layer].update((i, t) for t in r)
+    for layer, es in enumerate(edges):
+        asym = [(a, b) for (a, b) in es if (b, a) not in es]
+        assert not asym, f"layer {layer}: {len(asym)} one-directional edges, e.g. {asym[:3]}"
+    deg = np.array([len(r) for r in l0])
+    assert deg.min() >= 1 and deg.mean() > m0 * 0.6
+    q = (centres[rng.integers(0, 64, 200)] + 0.5 * rng.standard_normal((200, dim))).astype(np.float32)
+    gid, _, _, _ = gix.search_batch(q, hv.SearchParams(10).with_ef(100))
+    tid, _, _, _ = gix.flat_search_batch(q, 10)
+    rec = fx.recall_at_k(gid, tid)
+    # the oracle's sequential build of the same rows, searched by the oracle
+    oix = oracle_build(orc, data, metric, lv, m, m0, efc, ids)
+    hits = 0
+    for qi in range(200):
+        rc, oid, _ = oix.search(q[qi], 10, 100)
+        hits += len(set(oid.tolist()) & set(tid[qi].tolist()))
+    assert rec >= hits / 2000.0 - 0.01 and rec >= 0.95, (rec, hits / 2000.0)

@@ -249,6 +249,18 @@ def test_query_validation_statuses(orc, hv):
     with pytest.raises(hv.HelixDbError) as e:
         cs.search_batch(q, hv.SearchParams(3))
     assert e.value.status == hv.ERR_NONFINITE and e.value.is_invalid_vector_input()
+    # rejected queries keep their validation status through the exact-scan entry points too (flat, restricted, fused
+    # prefilter): their NaN scores are not an invariant violation (flat_select_kernel clobbered the status)
+    *_, st = cs.flat_search_batch(q, 3, per_query_status=True)
+    assert st.tolist() == [hv.OK, hv.ERR_NONFINITE, hv.ERR_ZERO_NORM, hv.OK]
+    *_, st = l2.flat_search_batch(q, 3, per_query_status=True)
+    assert st.tolist() == [hv.OK, hv.ERR_NONFINITE, hv.OK, hv.ERR_MAGNITUDE]
+    with pytest.raises(hv.HelixDbError) as e:
+        cs.flat_search_batch(q, 3)
+    assert e.value.status == hv.ERR_NONFINITE and e.value.is_invalid_vector_input()
+    with pytest.raises(hv.HelixDbError) as e:
+        cs.search_restricted_batch(q[2:3], hv.SearchParams(3), hv.RestrictedVectorCandidates.from_ids(np.arange(20)))
+    assert e.value.status == hv.ERR_ZERO_NORM and e.value.is_invalid_vector_input()
     with pytest.raises(hv.HelixDbError) as e:
         l2.search_batch(q[:, :4], hv.SearchParams(3))
     assert e.value.status == hv.ERR_DIMENSION

@@ -73,6 +73,8 @@ def parse():
     ap.add_argument("--skip", default="", help="comma list of extra legs to skip: production,datasets,config3,config4,config5,graph_equivalence")
     ap.add_argument("--c5-rows", type=int, default=12_500_000, help="config #5 per-GPU shard (100M / 8)")
     ap.add_argument("--c4-rows", type=int, default=1_250_000, help="config #4 per-GPU shard (10M / 8)")
+    ap.add_argument("--builder", default="device", choices=["device", "bulk"], help="how the benchmark graph is built")
+    ap.add_argument("--build-batch", type=int, default=2048, help="largest insertion batch of the device build")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "traffic_latest.json"))
     return ap.parse_args()
 
@@ -80,13 +82,51 @@ def parse():
 # ------------------------------------------------------------------------------------------------------------
 # helpers
 # ------------------------------------------------------------------------------------------------------------
-def import_index(hv, x, g, metric, dtype, id_lo, b, device):
-    ids = g["node_ids"] + np.uint64(id_lo)
+def import_index(hv, x, g, metric, dtype, b, device):
+    """g: graph in hvx_index_import's layout, EXTERNAL node ids throughout"""
     return hv.ValidatedVectorReadIndex.managed(
-        dim=x.shape[1], metric=metric, node_ids=ids, vectors=x, l0_offsets=g["l0_offsets"],
-        l0_neighbors=g["l0_neighbors"] + np.uint64(id_lo), level=g["level"], up_offsets=g["up_offsets"],
-        up_neighbors=g["up_neighbors"] + np.uint64(id_lo), entry_point=g["entry_point"] + id_lo,
+        dim=x.shape[1], metric=metric, node_ids=g["node_ids"], vectors=x, l0_offsets=g["l0_offsets"],
+        l0_neighbors=g["l0_neighbors"], level=g["level"], up_offsets=g["up_offsets"],
+        up_neighbors=g["up_neighbors"], entry_point=g["entry_point"],
         max_layer=g["max_layer"], m=g.get("m", 16), m0=2 * g.get("m", 16), device=device, max_batch=b, dtype=dtype)
+
+
+def build_graph(hv, synth, args, x, metric, id_lo, b, device, level_seed, keep_index=False):
+    """The benchmark graph.  'device' (default): hvx_index_build -- the reference's insert_hnsw for batches of nodes on the
+    GPU (csrc/hvx_build.hip), M / M0 = 2M / ef_construction 200, levels from the reference's layer rule; 'bulk': the
+    round-1 harness builder (pyhvx/synth.py: exact kNN + select_diverse).  Returns (graph dict with external ids, info,
+    the built f32 index or None)."""
+    n = x.shape[0]
+    ids = np.arange(n, dtype=np.uint64) + np.uint64(id_lo)
+    t0 = time.time()
+    if args.builder == "bulk":
+        g = synth.build_hnsw_graph(x, m=args.m, m0=2 * args.m, level_seed=level_seed)
+        g["node_ids"] = ids
+        for kk in ("l0_neighbors", "up_neighbors"):
+            g[kk] = g[kk] + np.uint64(id_lo)
+        g["entry_point"] = g["entry_point"] + id_lo
+        torch.cuda.synchronize()
+        info = {"builder": "pyhvx.synth.build_hnsw_graph (bulk: exact kNN candidates -> select_diverse -> reverse edges)",
+                "seconds": round(time.time() - t0, 2)}
+        bix = None
+    else:
+        lv = synth.draw_levels(n, args.m, level_seed)
+        bix, st = hv.ValidatedVectorReadIndex.build(dim=x.shape[1], metric=metric, node_ids=ids, vectors=x, levels=lv, m=args.m, m0=2 * args.m,
+                                                    ef_construction=200, max_batch=args.build_batch, batch_divisor=32, device=device,
+                                                    search_max_batch=b)
+        bix.sync()
+        secs = time.time() - t0
+        g = bix.export_graph()
+        g["node_ids"] = ids
+        info = {"builder": "hvx_index_build: insert_hnsw (mutation.rs:787-895) for batches of nodes on the device, M=%d M0=%d efC=200" % (args.m, 2 * args.m),
+                "seconds": round(secs, 2), "inserts_per_s": round(n / secs, 1), "batches": int(st["batches"]), "max_batch": args.build_batch}
+        if not keep_index:
+            bix.close()
+            bix = None
+    g["m"] = args.m
+    deg = np.diff(g["l0_offsets"].astype(np.int64))
+    info.update({"rows": n, "degree_mean": round(float(deg.mean()), 2), "degree_max": int(deg.max()), "max_layer": int(g["max_layer"])})
+    return g, info, bix
 
 
 def out_buffers(b, k, dev):
@@ -192,11 +232,9 @@ def hnsw_leg(hv, synth, args, dev, dataset, n, dim, b, k, ef, dtype_name="f32", 
     bf16 = dtype_name == "bf16"
     if bf16:  # the index holds the rounded values; graph, truth and oracle see exactly those
         x = x.to(torch.bfloat16).to(torch.float32)
-    g = synth.build_hnsw_graph(x, m=args.m, m0=2 * args.m, level_seed=7)
-    g["m"] = args.m
-    torch.cuda.synchronize()
+    g, ginfo, bix = build_graph(hv, synth, args, x, hv.EUCLIDEAN, 0, b, dev.index, 7, keep_index=not bf16)
     t_build = time.time() - t0
-    ix = import_index(hv, x, g, hv.EUCLIDEAN, hv.BF16 if bf16 else hv.F32, 0, b, dev.index)
+    ix = bix if bix is not None else import_index(hv, x, g, hv.EUCLIDEAN, hv.BF16 if bf16 else hv.F32, b, dev.index)
     ix_truth = ix
     if bf16:  # exact-scan ground truth over the same rounded rows through the f32 scan
         ix_truth = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=hv.EUCLIDEAN, node_ids=g["node_ids"], vectors=x,
@@ -222,7 +260,7 @@ def hnsw_leg(hv, synth, args, dev, dataset, n, dim, b, k, ef, dtype_name="f32", 
            "roofline": {"bound": "hbm", "achieved": round(alg / (per_step * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(alg / (per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": alg,
                         "kernel_ms_overlapped": round(per_step, 4), "kernel_ms_each": round(float(kms.mean()), 4)},
-           "corpus_and_graph_seconds": round(t_build, 1), "graph_degree_mean": round(float(np.diff(g["l0_offsets"].astype(np.int64)).mean()), 2)}
+           "corpus_and_graph_seconds": round(t_build, 1), "graph": ginfo}
     if keep:
         return res, dict(ix=ix, ix_truth=ix_truth, ls=ls, x=x, q=q, g=g, truth=f, qst=qst)
     ls.close_forks()
@@ -373,14 +411,26 @@ def leg_graph_equivalence(hv, synth, args, dev):
     xh, qh = synth.embedding_like_np(n, dim, nq, 20260925)
     lv = synth.draw_levels(n, args.m, 11)
     x = torch.from_numpy(xh).to(dev)
-    g = synth.build_hnsw_graph(x, m=args.m, m0=2 * args.m, levels=lv)
-    g["m"] = args.m
-    ix = import_index(hv, x, g, hv.EUCLIDEAN, hv.F32, 0, nq, dev.index)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    if args.builder == "bulk":
+        g = synth.build_hnsw_graph(x, m=args.m, m0=2 * args.m, levels=lv)
+        g["m"] = args.m
+        ix = import_index(hv, x, g, hv.EUCLIDEAN, hv.F32, nq, dev.index)
+        bname = "pyhvx.synth.build_hnsw_graph (exact kNN candidates -> select_diverse -> reverse edges, degree cap)"
+    else:
+        ix, _ = hv.ValidatedVectorReadIndex.build(dim=dim, metric=hv.EUCLIDEAN, node_ids=np.arange(n, dtype=np.uint64), vectors=x, levels=lv,
+                                                  m=args.m, m0=2 * args.m, ef_construction=200, max_batch=args.build_batch, batch_divisor=32,
+                                                  device=dev.index, search_max_batch=nq)
+        ix.sync()
+        g = ix.export_graph()
+        bname = f"hvx_index_build (device insert_hnsw, batches <= {args.build_batch}, same levels as the reference side)"
+    build_s = time.time() - t0
     ids, sc, cnt, st = ix.search_batch(qh, hv.SearchParams(k).with_ef(ef))
     tid, _, _, _ = ix.flat_search_batch(qh, k)
     rec = sum(len(set(ids[i].tolist()) & set(tid[i].tolist())) for i in range(nq)) / float(nq * k)
     deg = np.diff(g["l0_offsets"].astype(np.int64))
-    mine = {"builder": "pyhvx.synth.build_hnsw_graph (exact kNN candidates -> select_diverse -> reverse edges, degree cap)",
+    mine = {"builder": bname, "build_seconds": round(build_s, 2),
             "recall_at_10": round(rec, 4), "distance_computations_per_query": round(st["distance_computations"] / nq, 1),
             "expansion_steps_per_query": round(st["expansion_steps"] / nq, 1), "degree_mean": round(float(deg.mean()), 2),
             "degree_histogram": np.bincount(deg, minlength=2 * args.m + 1).tolist()}
@@ -450,18 +500,14 @@ def main():
             x = x.to(torch.bfloat16).to(torch.float32)
         torch.cuda.synchronize()
         log(f"[{label}] corpus {n_total}x{dim} generated in {time.time() - t0:.1f}s; shard rows [{id_lo},{id_lo + n})")
+        g, ginfo, bix = build_graph(hv, synth, args, x, hv_metric, id_lo, b, local_rank, 7 + rank, keep_index=not bf16)
+        log(f"[{label}] graph: {ginfo}")
         t0 = time.time()
-        g = synth.build_hnsw_graph(x, m=args.m, m0=2 * args.m, level_seed=7 + rank)
-        g["m"] = args.m
-        torch.cuda.synchronize()
-        deg = np.diff(g["l0_offsets"].astype(np.int64))
-        log(f"[{label}] graph built in {time.time() - t0:.1f}s: layer-0 degree mean {deg.mean():.1f} max {deg.max()}, max_layer {g['max_layer']}")
-        t0 = time.time()
-        ix = import_index(hv, x, g, hv_metric, hv.BF16 if bf16 else hv.F32, id_lo, b, local_rank)
+        ix = bix if bix is not None else import_index(hv, x, g, hv_metric, hv.BF16 if bf16 else hv.F32, b, local_rank)
         ix_truth = ix
         if bf16:
             ix_truth = hv.ValidatedVectorReadIndex.managed(
-                dim=dim, metric=hv_metric, node_ids=g["node_ids"] + np.uint64(id_lo), vectors=x, l0_offsets=np.zeros(n + 1, np.uint64),
+                dim=dim, metric=hv_metric, node_ids=g["node_ids"], vectors=x, l0_offsets=np.zeros(n + 1, np.uint64),
                 l0_neighbors=np.zeros(0, np.uint64), device=local_rank, max_batch=b)
         log(f"[{label}] index imported in {time.time() - t0:.1f}s")
         sharded = world > 1 and not replica
@@ -495,7 +541,7 @@ def main():
         alg = hnsw_alg_bytes(qst, dim, 2 if bf16 else 4, b)
         per_step = span / args.steps
         res = dict(qps=qps, ms_per_step=elapsed * 1e3 / args.steps, recall=recall, alg=alg, per_step=per_step, kms=kms, qst=qst, n=n,
-                   n_total=n_total, flat_ms=flat_stats["device_ms"])
+                   n_total=n_total, flat_ms=flat_stats["device_ms"], graph=ginfo)
         state = dict(ix=ix, ix_truth=ix_truth, ls=ls, x=x, q=q, g=g, truth=f, id_lo=id_lo)
         return res, state
 
@@ -558,6 +604,7 @@ def main():
         "shard_searches_per_s": round(res["qps"] * (1 if replica else world), 1),
         "roofline": roofline,
         "flat_scan_ms": round(res["flat_ms"], 3),
+        "graph_build": res["graph"],
     }
 
     # ---- N > 1: the north star's own curve -- the SAME 1M corpus split over the GPUs (strong scaling) ----
@@ -597,7 +644,7 @@ def main():
                 if (mname == "cosine") == cosine:
                     pix = ix
                 else:  # the rows are unit-norm: the same graph serves both metrics
-                    pix = import_index(hv, x, g, pm, hv.F32, 0, b, local_rank)
+                    pix = import_index(hv, x, g, pm, hv.F32, b, local_rank)
                 t0 = time.time()
                 pix.set_simhash()  # per-node SimHash rows, computed on the device with SimHasher(dim, seed 42)
                 log(f"[production default, {mname}] SimHash rows attached in {time.time() - t0:.1f}s")

@@ -6,7 +6,8 @@
  * Builds a toy index (8 nodes on a line, dim 128 -- the smallest dimension the one-wavefront-per-query kernel serves),
  * then runs the three calls a HelixDB host makes: the strict search of the reference's golden tests, the production
  * default `SearchParams::new(k)` through hvx_search_batch_params, and a restricted search over an id list.
- * Needs an MI355X to RUN; tests/test_abi_and_host.py only compiles and links it.
+ * Needs an MI355X to RUN: tests/test_abi_and_host.py compiles and links it (CPU), tests/test_gpu_parity.py runs it and checks its
+ * output against the oracle (-m gpu).
  */
 #include <stdio.h>
 #include <stdlib.h>

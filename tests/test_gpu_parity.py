@@ -1146,3 +1146,45 @@ def test_import_from_device_memory_equals_import_from_host(hv, dtype_name):
     b = devi.flat_search_batch(q, 10)
     assert a[0].tolist() == b[0].tolist() and bits(a[1]).tolist() == bits(b[1]).tolist()
     assert all(int(a[0][i, 0]) == n - 64 + i for i in range(64))
+
+
+def test_c_abi_example_runs_and_agrees_with_the_oracle(orc, tmp_path):
+    """examples/c_abi_example.c, compiled as C99 against include/helix_vec.h, RUN on the device: its three answers (strict
+    search with distance-computation count, production-default params with RNG word count, restricted search) equal the
+    oracle's on the same 8-node index."""
+    import os, re, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "c_abi_example"
+    cmd = ["gcc", "-std=c99", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "c_abi_example.c"), "-L",
+           os.path.join(root, "helix-db_amd"), "-lhelix_vec_gfx950", f"-Wl,-rpath,{os.path.join(root, 'helix-db_amd')}", "-o", str(exe)]
+    assert subprocess.run(cmd, capture_output=True, text=True).returncode == 0
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stderr
+    out = run.stdout
+    n, dim, k = 8, 128, 3
+    vec = np.zeros((n, dim), np.float32)
+    vec[:, 0] = np.arange(n)
+    ids = np.arange(n, dtype=np.uint64) + 100
+    offs, nbrs = [0], []
+    for i in range(n):
+        if i > 0:
+            nbrs.append(100 + i - 1)
+        if i + 1 < n:
+            nbrs.append(100 + i + 1)
+        offs.append(len(nbrs))
+    oix = orc.Index(dim, orc.L2SQ, m=16, m0=32)
+    assert oix.seed(ids, vec, np.array(offs, np.uint64), np.array(nbrs, np.uint64), entry_point=100, max_layer=0) == orc.OK
+    q = np.zeros(dim, np.float32)
+    q[0] = np.float32(5.2)
+    rc, oid, osc, ost = oix.search(q, k, 16, with_stats=True)
+    m = re.search(r"strict : (\d+) results, nearest id (\d+) score (\S+), (\d+) distance computations", out)
+    assert m, out
+    assert (int(m.group(1)), int(m.group(2)), int(m.group(4))) == (len(oid), int(oid[0]), ost["distance_computations"])
+    assert np.float32(float(m.group(3))) == np.float32(float("%g" % osc[0]))
+    oix.set_simhash(42)
+    rc, pid, psc, pst = oix.search_params(q, orc.SearchParams.new(k), with_stats=True)
+    m = re.search(r"default: (\d+) results, nearest id (\d+), (\d+) RNG words drawn", out)
+    assert m and (int(m.group(1)), int(m.group(2)), int(m.group(3))) == (len(pid), int(pid[0]), pst["rng_words"]), out
+    rc, rid, rsc = oix.flat(q, k, allowed=np.array([100, 103, 107], np.uint64))
+    m = re.search(r"restricted: (\d+) results, nearest allowed id (\d+)", out)
+    assert m and (int(m.group(1)), int(m.group(2))) == (len(rid), int(rid[0])), out

@@ -621,13 +621,17 @@ extern "C" int hvx_index_timing_begin(hvx_index *ix, uint32_t capacity) {
     return HVX_OK;
 }
 
-extern "C" int hvx_index_wave_clocks(hvx_index *ix, uint64_t *out, uint32_t cap_launches, uint32_t *out_n) {
+extern "C" int hvx_index_wave_clocks(hvx_index *ix, uint64_t *out, uint32_t cap_launches, uint32_t rows_per_launch, uint32_t *out_n) {
     if (!ix || !out || !out_n) return fail(HVX_ERR_INVARIANT, "null argument");
     std::lock_guard<std::mutex> lock(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));
     HIP_TRY(hipStreamSynchronize(ix->stream));
     const uint32_t n = std::min(std::min(ix->ring_n, ix->wclk_cap), cap_launches);
-    if (n) HIP_TRY(hipMemcpy(out, ix->d_wclk, (size_t)n * ix->max_batch * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    const uint32_t rows = std::min(rows_per_launch, ix->max_batch);
+    const size_t rb = 2 * sizeof(unsigned long long);
+    // device layout [launch][max_batch][2]; the caller's [launch][rows_per_launch][2]
+    if (n && rows)
+        HIP_TRY(hipMemcpy2D(out, (size_t)rows_per_launch * rb, ix->d_wclk, (size_t)ix->max_batch * rb, (size_t)rows * rb, n, hipMemcpyDeviceToHost));
     *out_n = n;
     return HVX_OK;
 }

@@ -148,7 +148,7 @@ def lib():
     L.hvx_index_timing_begin.restype = C.c_int
     L.hvx_index_timing_begin.argtypes = [_vp, C.c_uint32]
     L.hvx_index_wave_clocks.restype = C.c_int
-    L.hvx_index_wave_clocks.argtypes = [_vp, _vp, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.hvx_index_wave_clocks.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
     L.hvx_index_timing_collect.restype = C.c_int
     L.hvx_index_timing_collect.argtypes = [_vp, _vp, C.c_uint32, C.POINTER(C.c_uint32)]
     L.hvx_search_batch.restype = C.c_int
@@ -581,7 +581,7 @@ class ValidatedVectorReadIndex:
         """[launch][query][2] start / end of every query's wavefront (100 MHz device clock) since timing_begin"""
         out = np.zeros((capacity, max_batch, 2), np.uint64)
         n = C.c_uint32(0)
-        _check(lib().hvx_index_wave_clocks(self._h, _ptr(out), capacity, C.byref(n)))
+        _check(lib().hvx_index_wave_clocks(self._h, _ptr(out), capacity, max_batch, C.byref(n)))
         return out[: n.value].copy()
 
     def timing_collect(self, capacity: int) -> np.ndarray:

@@ -122,10 +122,10 @@ int hvx_index_set_occupancy(hvx_index *, uint32_t queries_per_simd);
  * _collect waits for the stream once and returns the per-call kernel durations (ms) in call order, then disarms. */
 int hvx_index_timing_begin(hvx_index *, uint32_t capacity);
 int hvx_index_timing_collect(hvx_index *, float *out_ms, uint32_t cap, uint32_t *out_n);
-/* Wave-slot residency evidence for the same launches (call before _collect): out[launch][query][2] = the device's
- * constant-rate 100 MHz clock when the query's wavefront started / finished (max_batch rows per launch; untouched
- * rows are 0).  Only the one-wavefront-per-query HNSW kernel writes them. */
-int hvx_index_wave_clocks(hvx_index *, uint64_t *out, uint32_t cap_launches, uint32_t *out_n);
+/* Wave-slot residency evidence for the same launches (call before _collect): out[launch][rows_per_launch][2] = the device's
+ * constant-rate 100 MHz clock when the query's wavefront started / finished (rows beyond a launch's batch are 0).  Only the
+ * one-wavefront-per-query HNSW kernel writes them. */
+int hvx_index_wave_clocks(hvx_index *, uint64_t *out, uint32_t cap_launches, uint32_t rows_per_launch, uint32_t *out_n);
 
 /*
  * ValidatedVectorReadIndex::search (read_index.rs:83-92) -> VectorIndex::search (index.rs:1578-1587)

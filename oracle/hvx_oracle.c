@@ -1183,3 +1183,4 @@ int orc_index_export(const orc_index *ix, uint64_t *node_ids, float *vectors, ui
 
 /* non-strict layer-0 arms (SimHash filter, sampling, adaptive bypass) */
 #include "hvx_oracle_adaptive.inc"
+#include "hvx_oracle_restricted.inc"

@@ -234,6 +234,33 @@ int orc_search_params_batch_mt(const orc_index *, const float *queries, uint32_t
                                uint32_t threads, uint64_t *out_ids, float *out_scores, uint32_t *out_counts,
                                orc_adaptive_stats *stats);
 
+/* ---- restricted search: planner + filter-aware walk (hvx_oracle_restricted.inc; restricted.rs:196-260,303-462,528-1148) ---- */
+enum { ORC_RESTRICTED_NONE = 0, ORC_RESTRICTED_EXACT = 1, ORC_RESTRICTED_FILTERED = 2 };              /* RestrictedSearchStrategy */
+enum { ORC_TERM_NONE = 0, ORC_TERM_EXHAUSTED = 1, ORC_TERM_BEAM_COMPLETE = 2, ORC_TERM_ROUTING_BUDGET = 3,
+       ORC_TERM_BRIDGE_BUDGET = 4, ORC_TERM_VECTOR_BUDGET = 5 };                                        /* RestrictedSearchTermination */
+typedef struct {   /* RestrictedExecutionPlan + FilteredGraphBudgets (restricted.rs:216-281) */
+    uint32_t strategy, k;
+    uint64_t ef_filtered, routing_rows, bridge_rows, vector_payloads, sampled_seeds, directory_seeds;
+} orc_restricted_plan_t;
+typedef struct {   /* RestrictedSearchStats (restricted.rs:147-166) */
+    uint32_t strategy, termination;
+    uint64_t ef_filtered, directory_scan_calls, directory_rows, directory_decoded_bytes, directory_hits, simhash_row_requests,
+        companion_row_requests, routing_rows, bridge_rows, bridge_frontier_pushes, neighbor_multi_get_calls,
+        vector_payload_requests, vector_bytes, distance_computations;
+} orc_restricted_stats;
+/* beam_percent 0 = FILTERED_BEAM_PERCENT (150) */
+void orc_restricted_plan(uint64_t candidates, uint32_t dim, uint32_t k, uint32_t ef, uint32_t beam_percent, orc_restricted_plan_t *out);
+uint64_t orc_deterministic_sample_ranks(uint64_t candidates, uint64_t limit, uint64_t *out_ranks); /* restricted.rs:321-342 */
+/* restricted_filter_aware_search with explicit budgets (plan->k, ->ef_filtered, ... as the reference's tests pass them) */
+int orc_restricted_filter_aware_search(const orc_index *, const float *query, uint32_t query_len, const uint64_t *allowed_ids,
+                                       uint64_t n_allowed, const orc_restricted_plan_t *plan, int directory_enabled,
+                                       uint64_t *out_ids, float *out_scores, uint32_t *out_count, orc_restricted_stats *stats);
+/* VectorIndex::search_restricted (restricted.rs:466-613).  directory_enabled = VectorIndex::with_simhash_directory().
+ * The filtered walk needs the per-node SimHash rows (orc_index_set_simhash). */
+int orc_search_restricted(const orc_index *, const float *query, uint32_t query_len, uint32_t k, uint32_t ef,
+                          const uint64_t *allowed_ids, uint64_t n_allowed, uint32_t beam_percent, int directory_enabled,
+                          uint64_t *out_ids, float *out_scores, uint32_t *out_count, orc_restricted_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

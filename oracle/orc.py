@@ -90,6 +90,22 @@ class AdaptiveStats(_Rec):
         "rng_words")] + [("active_sampling_ratio_sum", C.c_double)]
 
 
+RESTRICTED_EXACT, RESTRICTED_FILTERED = 1, 2
+TERM_EXHAUSTED, TERM_BEAM_COMPLETE, TERM_ROUTING_BUDGET, TERM_BRIDGE_BUDGET, TERM_VECTOR_BUDGET = 1, 2, 3, 4, 5
+
+
+class RestrictedPlan(_Rec):  # orc_restricted_plan_t: RestrictedExecutionPlan + FilteredGraphBudgets (restricted.rs:216-281)
+    _fields_ = [("strategy", C.c_uint32), ("k", C.c_uint32), ("ef_filtered", C.c_uint64), ("routing_rows", C.c_uint64),
+                ("bridge_rows", C.c_uint64), ("vector_payloads", C.c_uint64), ("sampled_seeds", C.c_uint64), ("directory_seeds", C.c_uint64)]
+
+
+class RestrictedStats(_Rec):  # orc_restricted_stats: RestrictedSearchStats (restricted.rs:147-166)
+    _fields_ = [("strategy", C.c_uint32), ("termination", C.c_uint32)] + [(n, C.c_uint64) for n in (
+        "ef_filtered", "directory_scan_calls", "directory_rows", "directory_decoded_bytes", "directory_hits", "simhash_row_requests",
+        "companion_row_requests", "routing_rows", "bridge_rows", "bridge_frontier_pushes", "neighbor_multi_get_calls",
+        "vector_payload_requests", "vector_bytes", "distance_computations")]
+
+
 class PolicyInput(_Rec):
     _fields_ = [("metric", C.c_uint32), ("simhash_mode", C.c_uint32), ("configured_threshold", C.c_uint32),
                 ("sampling_ratio", C.c_float), ("pre_sampling_override", C.c_float),
@@ -278,6 +294,15 @@ def _extra_signatures(L):
         L.orc_traverse.restype = C.c_int64
     if hasattr(L, "orc_search_restricted"):
         L.orc_search_restricted.restype = C.c_int
+        L.orc_search_restricted.argtypes = [C.c_void_p, f32p, C.c_uint32, C.c_uint32, C.c_uint32, u64p, C.c_uint64, C.c_uint32, C.c_int,
+                                            u64p, f32p, u32p, C.POINTER(RestrictedStats)]
+        L.orc_restricted_filter_aware_search.restype = C.c_int
+        L.orc_restricted_filter_aware_search.argtypes = [C.c_void_p, f32p, C.c_uint32, u64p, C.c_uint64, C.POINTER(RestrictedPlan), C.c_int,
+                                                         u64p, f32p, u32p, C.POINTER(RestrictedStats)]
+        L.orc_restricted_plan.restype = None
+        L.orc_restricted_plan.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(RestrictedPlan)]
+        L.orc_deterministic_sample_ranks.restype = C.c_uint64
+        L.orc_deterministic_sample_ranks.argtypes = [C.c_uint64, C.c_uint64, u64p]
 
 
 def _f(a):
@@ -444,6 +469,30 @@ class Index:
                                               cnt.ctypes.data_as(u32p), st)
         return rc, ids, sc, cnt, [s.as_dict() for s in st]
 
+    def search_restricted(self, query, k, ef, allowed, beam_percent=0, directory=True):
+        """VectorIndex::search_restricted (restricted.rs:466-613): Exact below 256 ids / 4 MiB, else the filter-aware walk.
+        Returns (rc, ids, scores, stats dict)."""
+        q, pq = _f(query)
+        al = np.ascontiguousarray(allowed, dtype=np.uint64)
+        ids = np.zeros(max(k, 1), np.uint64); sc = np.zeros(max(k, 1), np.float32)
+        cnt = C.c_uint32(0); st = RestrictedStats()
+        rc = lib().orc_search_restricted(self._h, pq, q.size, k, ef, al.ctypes.data_as(u64p), al.size, beam_percent, 1 if directory else 0,
+                                         ids.ctypes.data_as(u64p), sc.ctypes.data_as(f32p), C.byref(cnt), C.byref(st))
+        return rc, ids[: cnt.value].copy(), sc[: cnt.value].copy(), st.as_dict()
+
+    def restricted_filter_aware_search(self, query, allowed, *, k, ef_filtered, routing_rows, bridge_rows, vector_payloads, sampled_seeds,
+                                       directory_seeds, directory=False):
+        """restricted_filter_aware_search with explicit FilteredGraphBudgets, as the reference's tests call it."""
+        q, pq = _f(query)
+        al = np.ascontiguousarray(allowed, dtype=np.uint64)
+        plan = RestrictedPlan(strategy=RESTRICTED_FILTERED, k=k, ef_filtered=ef_filtered, routing_rows=routing_rows, bridge_rows=bridge_rows,
+                              vector_payloads=vector_payloads, sampled_seeds=sampled_seeds, directory_seeds=directory_seeds)
+        ids = np.zeros(max(k, 1), np.uint64); sc = np.zeros(max(k, 1), np.float32)
+        cnt = C.c_uint32(0); st = RestrictedStats()
+        rc = lib().orc_restricted_filter_aware_search(self._h, pq, q.size, al.ctypes.data_as(u64p), al.size, C.byref(plan), 1 if directory else 0,
+                                                      ids.ctypes.data_as(u64p), sc.ctypes.data_as(f32p), C.byref(cnt), C.byref(st))
+        return rc, ids[: cnt.value].copy(), sc[: cnt.value].copy(), st.as_dict()
+
     def flat(self, query, k, allowed=None):
         q, pq = _f(query)
         ids = np.zeros(max(k, 1), np.uint64)
@@ -469,6 +518,19 @@ def flat_matrix(metric, rows, query, k, kernel=K_AVX_FMA):
                                       rows.shape[1], pq, k, ids.ctypes.data_as(u64p),
                                       sc.ctypes.data_as(f32p), C.byref(cnt))
     return rc, ids[: cnt.value].copy(), sc[: cnt.value].copy()
+
+
+def restricted_plan(candidates, dim, k, ef, beam_percent=0):
+    """restricted_execution_plan_with_beam_percent (restricted.rs:426-453) -> dict"""
+    p = RestrictedPlan()
+    lib().orc_restricted_plan(candidates, dim, k, ef, beam_percent, C.byref(p))
+    return p.as_dict()
+
+
+def deterministic_sample_ranks(candidates, limit):
+    out = np.zeros(max(min(candidates, limit), 1), np.uint64)
+    n = lib().orc_deterministic_sample_ranks(candidates, limit, out.ctypes.data_as(u64p))
+    return out[:n].tolist()
 
 
 def select_layer(ml, uniform):

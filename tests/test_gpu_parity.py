@@ -1188,3 +1188,43 @@ def test_c_abi_example_runs_and_agrees_with_the_oracle(orc, tmp_path):
     rc, rid, rsc = oix.flat(q, k, allowed=np.array([100, 103, 107], np.uint64))
     m = re.search(r"restricted: (\d+) results, nearest allowed id (\d+)", out)
     assert m and (int(m.group(1)), int(m.group(2))) == (len(rid), int(rid[0])), out
+
+
+def test_restricted_device_scan_dominates_the_reference_filter_aware_walk(orc, hv):
+    """Row a11: above 256 candidates the reference answers with an ACORN-style walk (restricted.rs:837-1148, recall gate 0.95);
+    the device scans the allowed rows exactly.  On the reference's own fixture (tests/production_support/vector/restricted.rs:
+    1226-1285: 512 x 8-D circle, ef 64, k 10, allowed = ids not divisible by 3) the device's answer IS the exact top-k, so its
+    recall is 1.0 >= the walk's (restated in the oracle, pinned by tests/test_oracle_restricted.py) >= 0.95."""
+    import math
+    n, dim, k = 512, 8, 10
+
+    def vec(i):
+        v = np.zeros(dim, np.float32)
+        a = math.tau * i / n
+        v[0], v[1] = np.float32(math.cos(a)), np.float32(math.sin(a))
+        return v
+
+    ids = np.arange(1, n + 1, dtype=np.uint64)
+    data = np.stack([vec(i) for i in range(1, n + 1)])
+    offs, nbrs = [0], []
+    for i in range(1, n + 1):
+        nbrs.extend(fx.skip_neighbors(i, n))
+        offs.append(len(nbrs))
+    offs, nbrs = np.array(offs, np.uint64), np.array(nbrs, np.uint64)
+    oix = orc.Index(dim, orc.COSINE, m=32, m0=64)
+    assert oix.seed(ids, data, offs, nbrs, entry_point=1, max_layer=0) == orc.OK
+    oix.set_simhash(42)
+    gix = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=hv.COSINE, node_ids=ids, vectors=data, l0_offsets=offs, l0_neighbors=nbrs,
+                                              entry_point=1, max_layer=0, m=32, m0=64)
+    allowed = np.array([i for i in range(1, n + 1) if i % 3 != 0], np.uint64)
+    q = np.stack([vec(i) for i in (1, 43, 87, 129, 211, 307, 401, 509)])
+    gid, gsc, gcnt = gix.search_restricted_batch(q, hv.SearchParams(k).with_ef(64), hv.RestrictedVectorCandidates.from_ids(allowed))
+    walk_hits = dev_hits = 0
+    for qi in range(q.shape[0]):
+        rc, exact, esc = oix.flat(q[qi], k, allowed=allowed)
+        assert gid[qi, :gcnt[qi]].tolist() == exact.tolist() and bits(gsc[qi, :gcnt[qi]]).tolist() == bits(esc).tolist()
+        rc, wid, _, st = oix.search_restricted(q[qi], k, 64, allowed)
+        assert rc == orc.OK and st["strategy"] == orc.RESTRICTED_FILTERED
+        walk_hits += len(set(wid.tolist()) & set(exact.tolist()))
+        dev_hits += len(set(gid[qi, :gcnt[qi]].tolist()) & set(exact.tolist()))
+    assert dev_hits == 8 * k and dev_hits >= walk_hits and walk_hits / (8.0 * k) >= 0.95

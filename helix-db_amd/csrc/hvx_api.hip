@@ -547,8 +547,8 @@ int hvx::enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t b
     if (const char *e = getenv("HVX_WAVE_OCC")) a.occupancy = (uint32_t)atoi(e); // tuning hook
     if (ad) {
         if (!hnsw_wave_adaptive_supported(a))
-            return fail(HVX_ERR_UNSUPPORTED, "the non-strict search arms are served by the one-wavefront-per-query kernel only "
-                        "(f32 / bf16 rows, cosine / Euclidean, dim in {128,256,512,768,1024,1536}, rows <= 64 ids, ef <= 352)");
+            return fail(HVX_ERR_UNSUPPORTED, "the non-strict search arms serve f32 rows of any dimension / metric (bf16 rows: dim in "
+                        "{128,256,512,768,1024,1536}, cosine / Euclidean), neighbour rows <= 64 ids, ef <= 800");
         if (ix->bitmap_dirty) {
             HIP_TRY(hipMemsetAsync(ix->d_bitmap, 0, (size_t)ix->max_batch * ix->words_per_query * 4, ix->stream));
             ix->bitmap_dirty = false;

@@ -308,6 +308,9 @@ struct WaveGeom {
 hipError_t launch_hnsw_wave_occ2(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_occ2_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_build(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_gen_cos(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_gen_l2(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_gen_l1(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_l2(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_cos(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_prof(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
@@ -332,7 +335,16 @@ bool hnsw_wave_supported(const HnswArgs &a) {
     return true;
 }
 
-bool hnsw_wave_adaptive_supported(const HnswArgs &a) { return hnsw_wave_supported(a); }
+// the GENERIC builds of the non-strict arms: any dimension, metric and summation tree over f32 rows; one id per lane still
+// bounds the neighbour rows at 64 ids, the register beam bounds ef at 800 (the restricted path's k limit)
+static bool hnsw_wave_generic_supported(const HnswArgs &a) {
+    const DevIndex &ix = a.ix;
+    if (ix.dtype != HVX_F32) return false;
+    if (ix.s0 > 64 || ix.su > 64) return false;
+    if (a.ef + 32u > 832u) return false;
+    return true;
+}
+bool hnsw_wave_adaptive_supported(const HnswArgs &a) { return hnsw_wave_supported(a) || hnsw_wave_generic_supported(a); }
 
 static int env_int(const char *name, int lo, int hi, int fallback) {
     const char *e = getenv(name);
@@ -347,12 +359,14 @@ hipError_t launch_hnsw_wave(const HnswArgs &a, uint32_t b, hipStream_t s) {
     // per expansion); the kernel spills to the exact HBM bitmap beyond 3/4 full
     g.log2cap = 11;
     while ((1u << g.log2cap) < 64u * a.ef && g.log2cap < 15) ++g.log2cap;
+    const bool generic = a.adaptive && !hnsw_wave_supported(a);
+    if (generic && g.log2cap > 14) g.log2cap = 14; // 64 KiB table (two workgroups per CU); larger visited sets spill to the bitmap
     if (a.build_nodes && g.log2cap > 13) g.log2cap = 13; // build searches (ef_construction ~200): keep four workgroups per CU
     g.log2cap = (uint32_t)env_int("HVX_WAVE_LOG2CAP", 7, 15, (int)g.log2cap); // test hook: tiny table => spill path
     // 160 KiB / 4: exactly four resident wavefronts per CU, one per SIMD, each with the SIMD's whole register file.
     // occ = 2 (a.occupancy): eight per CU, two per SIMD -- the table shrinks until query + frontier + table fit 20 KiB
     g.occ = (a.occupancy == 2 && !a.adaptive && !a.prof && !a.build_nodes) ? 2u : 1u;
-    const size_t fixed = 512 + (size_t)a.ix.dim * 4 + (a.adaptive ? kRngWords * 4 : 0);
+    const size_t fixed = 512 + (size_t)a.ix.ld * 4 + (a.adaptive ? kRngWords * 4 : 0);
     if (g.occ == 2) {
         while (g.log2cap > 9 && ((size_t)4 << g.log2cap) + fixed > 20 * 1024) --g.log2cap;
         if (((size_t)4 << g.log2cap) + fixed > 20 * 1024) g.occ = 1;
@@ -362,6 +376,13 @@ hipError_t launch_hnsw_wave(const HnswArgs &a, uint32_t b, hipStream_t s) {
     g.lds = need < budget ? budget : need;
     if (g.occ == 2) return a.ix.dtype == HVX_BF16 ? launch_hnsw_wave_occ2_bf16(a, b, g, s) : launch_hnsw_wave_occ2(a, b, g, s);
     if (a.build_nodes) return launch_hnsw_wave_build(a, b, g, s);
+    if (generic) {
+        switch (a.ix.metric) {
+        case kCosine: return launch_hnsw_wave_gen_cos(a, b, g, s);
+        case kL2: return launch_hnsw_wave_gen_l2(a, b, g, s);
+        default: return launch_hnsw_wave_gen_l1(a, b, g, s);
+        }
+    }
     if (a.adaptive) {
         if (a.ix.dtype == HVX_BF16) return a.ix.metric == kL2 ? launch_hnsw_wave_l2_bf16_ad(a, b, g, s) : launch_hnsw_wave_cos_bf16_ad(a, b, g, s);
         return a.ix.metric == kL2 ? launch_hnsw_wave_l2_ad(a, b, g, s) : launch_hnsw_wave_cos_ad(a, b, g, s);

@@ -478,7 +478,11 @@ template <uint32_t METRIC, int R, int NK, bool BF, bool PROF = false, bool AD = 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void hnsw_wave_kernel(HnswArgs a, uint32_t log2cap) {
     // rows per 8-lane group in flight: P*NK <= 24 float4 per lane for a narrow pass, x2 and x4 for wider
     // frontiers (4P*NK <= 96 float4 = 384 registers, VGPR+AGPR file of one wave per SIMD)
-    constexpr int NL = BF ? NK / 2 : NK;        // 16-byte loads per lane and row
+    // NK == 0: the GENERIC build -- any dimension (scalar tail, simple_avx.rs:172-177), any metric (Manhattan's sequential
+    // order, simple.rs:186-202), the AVX / AVX+FMA / scalar summation trees: rows are scored one per 8-lane group with
+    // hvx_device.h's group_distance instead of the unrolled register passes.  Same beam, visited set and non-strict arms.
+    constexpr bool GEN = NK == 0;
+    constexpr int NL = GEN ? 1 : (BF ? NK / 2 : NK);        // 16-byte loads per lane and row
     constexpr int P = NL <= 8 ? 2 : 1;
     constexpr bool kWide4 = OCC == 1 && 4 * P * NL <= 96;
     constexpr bool kWide2 = OCC == 1 || 2 * P * NL <= 48; // 192 of the 256 registers of a half-SIMD wave
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
     uint32_t *fr_id = V.tab + V.cap;                      // [64] frontier ids, row order
     float *fr_d = reinterpret_cast<float *>(fr_id + 64);   // [64] their distances
     float *qs = fr_d + 64;                                 // [dim] query, 16-byte aligned
-    uint32_t *rng_buf = reinterpret_cast<uint32_t *>(qs + NK * 32); // [kRngWords] (AD only)
+    uint32_t *rng_buf = reinterpret_cast<uint32_t *>(qs + (GEN ? ix.ld : (uint32_t)NK * 32u)); // [kRngWords] (AD only)
 
     const unsigned long long wclk0 = a.wave_clock ? wall_clock64() : 0ull;
     const uint32_t status_in = BUILD ? 0u : (a.qstatus ? a.qstatus[q] : 0u);
@@ -519,25 +523,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
     }
     const uint32_t bnode = BUILD ? a.build_nodes[q] : 0u;
     const float *qglobal = BUILD ? ix.vec + (size_t)bnode * ix.ld : a.queries + (size_t)q * ix.dim;
-    for (uint32_t i = (uint32_t)lane; i < (uint32_t)NK * 8u; i += 64)
-        reinterpret_cast<float4 *>(qs)[i] = reinterpret_cast<const float4 *>(qglobal)[i];
+    if (GEN) { // zero padded to ld floats, as group_distance reads it
+        for (uint32_t i = (uint32_t)lane; i < ix.ld; i += 64) qs[i] = i < ix.dim ? qglobal[i] : 0.f;
+    } else {
+        for (uint32_t i = (uint32_t)lane; i < (uint32_t)NK * 8u; i += 64)
+            reinterpret_cast<float4 *>(qs)[i] = reinterpret_cast<const float4 *>(qglobal)[i];
+    }
     __syncthreads();
     const float qhdr = BUILD ? ix.hdr[bnode] : (a.qhdr ? a.qhdr[q] : 0.f);
     const float inf = __uint_as_float(0x7F800000u);
 
     // one pass of W rows per group over fr_id[f0..nf): issue everything, then FMA, then publish
+    // GENERIC build: one row per 8-lane group and step, the general distance evaluator
+    auto generic_distance = [&](uint32_t node) __attribute__((always_inline)) -> float {
+        if (ix.fkernel == kKernelAvxFma) return group_distance<METRIC, true>(ix, qs, qhdr, node, j);
+        return group_distance<METRIC, false>(ix, qs, qhdr, node, j);
+    };
     auto pass = [&](auto width, uint32_t f0, uint32_t nf) __attribute__((always_inline)) {
         constexpr int W = decltype(width)::value;
         uint32_t nd[W];
         float o[W];
-        Gather<NK, W, BF> g;
+        Gather<GEN ? 1 : NK, W, BF> g;
 #pragma unroll
         for (int p = 0; p < W; ++p) {
             const uint32_t f = f0 + (uint32_t)(p * 8 + grp);
             nd[p] = fr_id[f < nf ? f : f0]; // idle groups shadow the pass's first row
         }
-        gather_issue<NK, W, BF, W, METRIC == kCosine>(ix, nd, slot, g);
-        gather_consume<METRIC, NK, W, BF>(ix, qs, g, nd, slot, qhdr, qglobal, o);
+        if constexpr (!GEN) {
+            gather_issue<NK, W, BF, W, METRIC == kCosine>(ix, nd, slot, g);
+            gather_consume<METRIC, NK, W, BF>(ix, qs, g, nd, slot, qhdr, qglobal, o);
+        }
 #pragma unroll
         for (int p = 0; p < W; ++p) {
             const uint32_t f = f0 + (uint32_t)(p * 8 + grp);
@@ -547,6 +562,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
     // distances of fr_id[0..nf) -> fr_d, widest pass that the remaining rows fill
     auto score_frontier = [&](uint32_t nf) __attribute__((always_inline)) {
         uint32_t f0 = 0;
+        if constexpr (GEN) {
+            for (; f0 < nf; f0 += 8) {
+                const uint32_t f = f0 + (uint32_t)grp;
+                const float d = generic_distance(fr_id[f < nf ? f : f0]);
+                if (f < nf && j == 0) fr_d[f] = d;
+            }
+            __syncthreads();
+            return;
+        }
         while (f0 < nf) {
             const uint32_t rem = nf - f0;
             if (kWide4 && rem > 24u * P) { pass(std::integral_constant<int, kWide4 ? 4 * P : P>{}, f0, nf); f0 += 32u * P; }
@@ -558,12 +582,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
     };
     // distance of ONE node, uniform result
     auto score_one = [&](uint32_t node) __attribute__((always_inline)) -> float {
-        uint32_t nd[1] = {node};
-        float o[1];
-        Gather<NK, 1, BF> g;
-        gather_issue<NK, 1, BF, 1, METRIC == kCosine>(ix, nd, slot, g);
-        gather_consume<METRIC, NK, 1, BF>(ix, qs, g, nd, slot, qhdr, qglobal, o);
-        return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(o[0]), 0));
+        if constexpr (GEN) {
+            return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(generic_distance(node)), 0));
+        } else {
+            uint32_t nd[1] = {node};
+            float o[1];
+            Gather<NK, 1, BF> g;
+            gather_issue<NK, 1, BF, 1, METRIC == kCosine>(ix, nd, slot, g);
+            gather_consume<METRIC, NK, 1, BF>(ix, qs, g, nd, slot, qhdr, qglobal, o);
+            return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(o[0]), 0));
+        }
     };
     // visited test-and-set + in-order compaction of one neighbour row held one id per lane
     auto frontier_from = [&](uint32_t nid, uint32_t &deg) __attribute__((always_inline)) -> uint32_t {
@@ -990,6 +1018,10 @@ hipError_t launch_hnsw_wave_occ2(const HnswArgs &a, uint32_t b, const WaveGeom &
 hipError_t launch_hnsw_wave_occ2_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 // search side of the device HNSW build (BUILD instantiations), hvx_hnsw_wave_build.hip
 hipError_t launch_hnsw_wave_build(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+// GENERIC builds (NK = 0) of the non-strict arms: any dim / metric / summation tree, ef <= 800; hvx_hnsw_wave_gen_*.hip
+hipError_t launch_hnsw_wave_gen_cos(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_gen_l2(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_gen_l1(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 // non-strict arms (AD instantiations), hvx_hnsw_wave_l2_ad.hip / hvx_hnsw_wave_cos_ad.hip
 hipError_t launch_hnsw_wave_l2_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_cos_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
@@ -1024,6 +1056,17 @@ static hipError_t launch_wave_r(const HnswArgs &a, uint32_t b, const WaveGeom &g
     if (need <= 192) return launch_wave_nk<METRIC, 3, BF, AD, ST, OCC>(a, b, g, s);
     if (need <= 384) return launch_wave_nk<METRIC, 6, BF, AD, ST, OCC>(a, b, g, s);
     return hipErrorInvalidValue;
+}
+// GENERIC build of the non-strict arms: beam of 64*R >= ef + 32 entries
+template <uint32_t METRIC, bool ST> static hipError_t launch_wave_gen_r(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
+    const uint32_t need = a.ef + 32u;
+    if (need <= 192) return launch_wave_kernel(hnsw_wave_kernel<METRIC, 3, 0, false, false, true, ST>, a, b, g, s);
+    if (need <= 448) return launch_wave_kernel(hnsw_wave_kernel<METRIC, 7, 0, false, false, true, ST>, a, b, g, s);
+    if (need <= 832) return launch_wave_kernel(hnsw_wave_kernel<METRIC, 13, 0, false, false, true, ST>, a, b, g, s);
+    return hipErrorInvalidValue;
+}
+template <uint32_t METRIC> static hipError_t launch_wave_gen(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
+    return a.ad.stats ? launch_wave_gen_r<METRIC, true>(a, b, g, s) : launch_wave_gen_r<METRIC, false>(a, b, g, s);
 }
 // non-strict arms: with the per-query SearchStats of the filter / sampling stages when the caller asked for them,
 // else the diagnostics-free build

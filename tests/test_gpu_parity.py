@@ -627,6 +627,14 @@ def _wide_beam(hv):
     return hv.SearchParams.new(50).with_ef(200)
 
 
+def _ef400(hv):
+    return hv.SearchParams.new(100).with_ef(400)
+
+
+def _ef800(hv):
+    return hv.SearchParams.new(400).with_ef(800)
+
+
 ADAPTIVE_CASES = [
     # (name, metric, n, dim, m, m0, params, config overrides)
     ("default-cos", 0, 3000, 128, 16, 32, _default, {}),
@@ -644,6 +652,16 @@ ADAPTIVE_CASES = [
     ("fixed-not-adaptive", 0, 2000, 128, 16, 32, _default, {"adaptive_enabled": 0, "simhash_threshold": 34}),
     ("wide-beam", 0, 3000, 128, 16, 32, _wide_beam, {}),
     ("threshold-0", 0, 2000, 128, 16, 32, _default, {"simhash_threshold": 0}),
+    # shapes served by the GENERIC build of the non-strict arms (any dimension / metric / summation tree, ef <= 800)
+    ("gen-dim100-l2", 1, 2500, 100, 16, 32, _default, {}),            # 3 chunks + a 4-element scalar tail
+    ("gen-dim100-cos", 0, 2500, 100, 16, 32, _default, {}),
+    ("gen-dim384-cos", 0, 2000, 384, 16, 32, _default, {}),           # NK = 12: no unrolled build
+    ("gen-dim20-cos", 0, 2000, 20, 16, 32, _default, {}),             # dim < 32: the scalar kernel
+    ("gen-manhattan", 2, 2500, 96, 16, 32, _default, {}),             # sampling stays live for Manhattan (policy.rs:89-101)
+    ("gen-manhattan-throughput", 2, 2500, 40, 32, 64, _throughput, {}),
+    ("gen-ef400-cos", 0, 4000, 128, 16, 32, _ef400, {}),              # R = 7 beam on a shape the unrolled builds stop at 352
+    ("gen-ef800-l2", 1, 4000, 64, 16, 32, _ef800, {}),                # R = 13 beam, the restricted path's k limit
+    ("gen-always-post-dim100", 0, 2500, 100, 16, 32, _always_post_sampling, {"simhash_threshold": 30}),
 ]
 
 
@@ -668,7 +686,7 @@ def test_non_strict_arms_match_oracle(orc, hv, name, metric, n, dim, m, m0, mk, 
     # the case exercises what its name says
     if name in ("default-cos", "default-cos-768", "throughput-cos", "wide-beam", "fixed-not-adaptive"):
         assert agg["simhash_examined"] > 0 and agg["simhash_filtered"] > 0
-    if metric == 1:
+    if metric != 0:  # the SimHash filter is cosine-only (policy.rs:67-91); sampling stays live
         assert agg["simhash_examined"] == 0
     if name in ("always-post", "adaptive-post"):
         assert agg["pre_simhash_sample_kept"] == 0 and agg["rng_words"] > 0

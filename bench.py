@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--mode", default="shard", choices=["shard", "replica"],
                     help="N>1: 'shard' = id-range shards + all-gather top-k merge (north star); 'replica' = every GPU holds "
                          "the whole index and answers its own batch (no collective)")
+    ap.add_argument("--exchange", default="capi", choices=["capi", "torch"],
+                    help="N>1: 'capi' = hvx_shard_group_* (ncclAllGather inside the library), 'torch' = torch.distributed all-gather + device merge")
     ap.add_argument("--scaling", default="both", choices=["weak", "strong", "both"], help="N>1 shard mode: which corpus sizing to measure")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="row storage on the device (bf16 = config #4)")
     ap.add_argument("--dataset", default="embedding", choices=["embedding", "clustered", "gaussian"])
@@ -155,9 +157,27 @@ class LaneSet:
             for l, s in enumerate(self.sharded):
                 self.bufs[l][0], self.bufs[l][1], self.bufs[l][2] = s.outputs()
         self.b, self.k, self.dev, self.occ, self.residency = b, k, dev, occ, None
+        self.groups = None   # C-ABI shard groups (in-library RCCL exchange), one per lane
+        self.merged = None
+
+    def use_shard_groups(self, hv, dist, rank, world):
+        """One hvx_shard_group (own RCCL communicator) per lane; the 128-byte unique ids travel over torch.distributed."""
+        ids = []
+        for _ in self.handles:
+            t = torch.zeros(128, dtype=torch.uint8, device=self.dev)
+            if rank == 0:
+                t.copy_(torch.frombuffer(bytearray(hv.ShardGroup.unique_id()), dtype=torch.uint8))
+            dist.broadcast(t, 0)
+            ids.append(bytes(t.cpu().numpy().tobytes()))
+        self.groups = [hv.ShardGroup(h, uid, rank, world, self.b, self.k) for h, uid in zip(self.handles, ids)]
+        self.merged = [out_buffers(self.b, self.k, self.dev) for _ in self.handles]
 
     def step(self, i, q, ef):
         l = i % len(self.handles)
+        if self.groups:  # search -> ncclAllGather -> merge inside the library, one C-ABI call (hvx_shard_group_*)
+            m = self.merged[l]
+            self.groups[l].search_batch_device(q, self.k, ef, m[0], m[1], m[2])
+            return
         ids, sc, cnt, st, qst = self.bufs[l]
         self.handles[l].search_batch_device(q, self.k, ef, ids, sc, cnt, st, qst, want_stats=False)
         if self.sharded:
@@ -170,6 +190,10 @@ class LaneSet:
         torch.cuda.synchronize()
 
     def close_forks(self):
+        if self.groups:
+            for g in self.groups:
+                g.close()
+            self.groups = None
         for h in self.handles[1:]:
             h.close()
 
@@ -517,6 +541,23 @@ def main():
             return shard.ShardedSearcher(h, world, b, k, dev, group, stage_through_host=SHARED_GPU)
 
         ls = LaneSet(ix, lanes, occ, b, k, dev, factory if sharded else None)
+        exchange = "single GPU"
+        if sharded:
+            exchange = "torch.distributed all_gather_into_tensor + hvx_merge_topk_packed_device"
+            if not SHARED_GPU and args.exchange == "capi":
+                try:
+                    ls.use_shard_groups(hv, dist, rank, world)
+                    exchange = "hvx_shard_group_search_batch_device: in-library ncclAllGather (RCCL) + merge, one C-ABI call per step"
+                except Exception as e:  # RCCL could not be bootstrapped from inside the library: the torch.distributed exchange still works
+                    log(f"[{label}] hvx_shard_group_init failed ({e}); falling back to the torch.distributed exchange")
+                    ls.groups = None
+            ok = torch.tensor([1 if ls.groups else 0], dtype=torch.int32, device="cpu" if SHARED_GPU else dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank must take the same path
+            if int(ok.item()) == 0 and ls.groups:
+                for gq in ls.groups:
+                    gq.close()
+                ls.groups = None
+                exchange = "torch.distributed all_gather_into_tensor + hvx_merge_topk_packed_device"
         elapsed, span, kms = timed_steps(ls, q, ef, args.steps, args.warmup, barrier)
         if world > 1:
             t = torch.tensor([elapsed, span], dtype=torch.float64, device="cpu" if SHARED_GPU else dev)
@@ -528,7 +569,14 @@ def main():
         ix_truth.flat_search_batch_device(q, k, *f[:4])  # first use loads the scan's code objects: not timed
         flat_stats = ix_truth.flat_search_batch_device(q, k, *f[:4], want_stats=True)
         got = ls.bufs[0]
-        if sharded:
+        if sharded and ls.groups:
+            ls.sync()
+            got_ids = ls.merged[0][0].clone()
+            truth_ids = ls.sharded[0].merge(f[0], f[1], f[2])[0].clone()
+            # per-shard counters of the last step: one more local search into the lane's own buffers
+            ix.search_batch_device(q, k, ef, *got, want_stats=False)
+            ix.sync()
+        elif sharded:
             ix.sync()
             got_ids = ls.sharded[0].merge(got[0], got[1], got[2])[0].clone()   # the lane's buffers ARE the payload views: merge them first,
             truth_ids = ls.sharded[0].merge(f[0], f[1], f[2])[0].clone()       # then let the exact-scan lists overwrite the payload
@@ -541,7 +589,7 @@ def main():
         alg = hnsw_alg_bytes(qst, dim, 2 if bf16 else 4, b)
         per_step = span / args.steps
         res = dict(qps=qps, ms_per_step=elapsed * 1e3 / args.steps, recall=recall, alg=alg, per_step=per_step, kms=kms, qst=qst, n=n,
-                   n_total=n_total, flat_ms=flat_stats["device_ms"], graph=ginfo)
+                   n_total=n_total, flat_ms=flat_stats["device_ms"], graph=ginfo, exchange=exchange)
         state = dict(ix=ix, ix_truth=ix_truth, ls=ls, x=x, q=q, g=g, truth=f, id_lo=id_lo)
         return res, state
 
@@ -598,6 +646,7 @@ def main():
                                f"steps issued round-robin on {lanes} execution lanes",
                    "dataset": args.dataset, "rows_per_gpu": n, "rows_total": res["n_total"], "dim": dim, "batch": b, "k": k,
                    "ef_search": ef, "lanes": lanes,
+                   "exchange": res["exchange"],
                    "parallelism": ("1 GPU" if world == 1 else f"{world} replicas, one query batch each" if replica
                                    else f"id-range shards x{world} + all-gather top-k merge")},
         "recall_at_10": round(res["recall"], 4),

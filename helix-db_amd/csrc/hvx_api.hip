@@ -543,6 +543,7 @@ int hvx::enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t b
     a.ad = ad ? *ad : AdaptArgs{};
     a.build_nodes = nullptr;
     a.build_ef_upper = 0;
+    a.only_flagged = 0;
     a.occupancy = ix->occupancy;
     if (const char *e = getenv("HVX_WAVE_OCC")) a.occupancy = (uint32_t)atoi(e); // tuning hook
     if (ad) {

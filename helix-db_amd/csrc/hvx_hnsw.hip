@@ -353,7 +353,7 @@ static int env_int(const char *name, int lo, int hi, int fallback) {
     return (v >= lo && v <= hi) ? v : fallback;
 }
 
-hipError_t launch_hnsw_wave(const HnswArgs &a, uint32_t b, hipStream_t s) {
+static hipError_t launch_hnsw_wave_once(const HnswArgs &a, uint32_t b, hipStream_t s) {
     WaveGeom g;
     // visited hash: 64 slots per beam entry (load factor ~0.15-0.3 at the measured ~10 distance evaluations
     // per expansion); the kernel spills to the exact HBM bitmap beyond 3/4 full
@@ -390,6 +390,23 @@ hipError_t launch_hnsw_wave(const HnswArgs &a, uint32_t b, hipStream_t s) {
     if (a.prof) return launch_hnsw_wave_prof(a, b, g, s);
     if (a.ix.dtype == HVX_BF16) return a.ix.metric == kL2 ? launch_hnsw_wave_l2_bf16(a, b, g, s) : launch_hnsw_wave_cos_bf16(a, b, g, s);
     return a.ix.metric == kL2 ? launch_hnsw_wave_l2(a, b, g, s) : launch_hnsw_wave_cos(a, b, g, s);
+}
+
+// The search launch + its re-run: a beam of 64*R entries holds ef + >= 32 of slack; a query that evicted an EQUAL-score
+// candidate past that slack (many duplicate vectors) may differ from the reference, so the kernel flags it and a second
+// launch -- whose wavefronts leave at once unless their query is flagged -- repeats it with the next beam size.  Queries that
+// overflow even that stay flagged (hvx_stats.tie_overflow_queries).
+hipError_t launch_hnsw_wave(const HnswArgs &a, uint32_t b, hipStream_t s) {
+    hipError_t e = launch_hnsw_wave_once(a, b, s);
+    if (e != hipSuccess || a.prof || a.build_nodes || !a.tie_flags) return e;
+    const bool generic = a.adaptive && !hnsw_wave_supported(a);
+    const uint32_t need = a.ef + 32u;
+    const bool wider = generic ? need <= 448u : need <= 192u; // a wider instantiation exists
+    if (!wider) return e;
+    HnswArgs r = a;
+    r.only_flagged = 1;
+    r.occupancy = 1; // the wide-beam builds are budgeted for one query per SIMD
+    return launch_hnsw_wave_once(r, b, s);
 }
 
 } // namespace hvx

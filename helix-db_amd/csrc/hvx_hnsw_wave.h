@@ -508,7 +508,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
     float *qs = fr_d + 64;                                 // [dim] query, 16-byte aligned
     uint32_t *rng_buf = reinterpret_cast<uint32_t *>(qs + (GEN ? ix.ld : (uint32_t)NK * 32u)); // [kRngWords] (AD only)
 
-    const unsigned long long wclk0 = a.wave_clock ? wall_clock64() : 0ull;
+    // re-run launch (launch_hnsw_wave): a query whose beam evicted equal-score candidates beyond its slack is searched
+    // again from scratch with a beam twice as wide; everybody else leaves at once
+    if (!BUILD && a.only_flagged && a.tie_flags[blockIdx.x] == 0u) return;
+    const unsigned long long wclk0 = (a.wave_clock && !a.only_flagged) ? wall_clock64() : 0ull;
     const uint32_t status_in = BUILD ? 0u : (a.qstatus ? a.qstatus[q] : 0u);
     if (status_in != 0u || !ix.has_entry) {
         if (lane == 0) {
@@ -987,7 +990,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
         for (uint32_t w = (uint32_t)lane; w < V.words; w += 64) { V.bm[w] = 0u; if (V.bm2) V.bm2[w] = 0u; }
     }
     if (lane == 0) {
-        if (a.wave_clock) { a.wave_clock[2 * (size_t)q] = wclk0; a.wave_clock[2 * (size_t)q + 1] = wall_clock64(); }
+        if (a.wave_clock && !a.only_flagged) { a.wave_clock[2 * (size_t)q] = wclk0; a.wave_clock[2 * (size_t)q + 1] = wall_clock64(); }
         if (!BUILD) a.out_counts[q] = outn;
         if (a.out_status) a.out_status[q] = bad_score ? 8u /*HVX_ERR_INVARIANT*/ : 0u;
         if (a.qstats) a.qstats[q] = hvx_query_stats{st_exp, st_nb, st_vl, st_dc};
@@ -1053,15 +1056,15 @@ static hipError_t launch_wave_nk(const HnswArgs &a, uint32_t b, const WaveGeom &
 template <uint32_t METRIC, bool BF, bool AD = false, bool ST = true, int OCC = 1>
 static hipError_t launch_wave_r(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
     const uint32_t need = a.ef + 32u; // beam capacity 64*R must hold ef plus slack for equal-score evictions
-    if (need <= 192) return launch_wave_nk<METRIC, 3, BF, AD, ST, OCC>(a, b, g, s);
-    if (need <= 384) return launch_wave_nk<METRIC, 6, BF, AD, ST, OCC>(a, b, g, s);
+    if (need <= 192 && !a.only_flagged) return launch_wave_nk<METRIC, 3, BF, AD, ST, OCC>(a, b, g, s);
+    if (need <= 384) return launch_wave_nk<METRIC, 6, BF, AD, ST, OCC>(a, b, g, s); // also the re-run of an R = 3 launch: slack 32 -> 224+
     return hipErrorInvalidValue;
 }
 // GENERIC build of the non-strict arms: beam of 64*R >= ef + 32 entries
 template <uint32_t METRIC, bool ST> static hipError_t launch_wave_gen_r(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
     const uint32_t need = a.ef + 32u;
-    if (need <= 192) return launch_wave_kernel(hnsw_wave_kernel<METRIC, 3, 0, false, false, true, ST>, a, b, g, s);
-    if (need <= 448) return launch_wave_kernel(hnsw_wave_kernel<METRIC, 7, 0, false, false, true, ST>, a, b, g, s);
+    if (need <= 192 && !a.only_flagged) return launch_wave_kernel(hnsw_wave_kernel<METRIC, 3, 0, false, false, true, ST>, a, b, g, s);
+    if (need <= 448 && !(a.only_flagged && need > 192)) return launch_wave_kernel(hnsw_wave_kernel<METRIC, 7, 0, false, false, true, ST>, a, b, g, s);
     if (need <= 832) return launch_wave_kernel(hnsw_wave_kernel<METRIC, 13, 0, false, false, true, ST>, a, b, g, s);
     return hipErrorInvalidValue;
 }

@@ -49,6 +49,7 @@ struct HnswArgs {
     uint32_t adaptive;         // 0 = strict-exhaustive search; 1 = non-strict arms, policy in `ad`
     const uint32_t *build_nodes; // BUILD instantiations (hvx_build.hip): [b] internal ids of the nodes being inserted (their rows are the queries)
     uint32_t build_ef_upper;   // ... beam width on the layers above 0 (ef is layer 0's)
+    uint32_t only_flagged;     // wave kernel: 1 = the re-run launch -- only queries whose tie flag is set do anything (with a wider beam)
     uint32_t occupancy;        // wave kernel: 2 = the two-queries-per-SIMD build (callers with >= 2 batches in flight), else 1
     AdaptArgs ad;
 };

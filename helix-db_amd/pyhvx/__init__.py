@@ -141,6 +141,13 @@ def lib():
                                         C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.hvx_index_export_graph.restype = C.c_int
     L.hvx_index_export_graph.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp]
+    L.hvx_shard_group_unique_id.restype = C.c_int
+    L.hvx_shard_group_unique_id.argtypes = [_vp]
+    L.hvx_shard_group_init.restype = C.c_int
+    L.hvx_shard_group_init.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_vp)]
+    L.hvx_shard_group_search_batch_device.restype = C.c_int
+    L.hvx_shard_group_search_batch_device.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp]
+    L.hvx_shard_group_free.argtypes = [_vp]
     L.hvx_index_fork.restype = C.c_int
     L.hvx_index_fork.argtypes = [_vp, C.POINTER(_vp)]
     L.hvx_index_set_occupancy.restype = C.c_int
@@ -609,6 +616,39 @@ class ValidatedVectorReadIndex:
     def set_stream(self, hip_stream):
         """Enqueue on a caller-owned hipStream_t (int handle, e.g. torch.cuda.current_stream().cuda_stream)."""
         _check(lib().hvx_index_set_stream(self._h, _vp(hip_stream) if hip_stream else None))
+
+
+class ShardGroup:
+    """hvx_shard_group: local search -> RCCL all-gather of the packed per-shard top-k -> merge, enqueued on the shard's stream
+    by ONE C-ABI call.  `unique_id` = 128 bytes from ShardGroup.unique_id() on rank 0, handed to every rank by
+    the host (bench.py uses a torch.distributed broadcast); world == 1 with an id still runs the collective (tests)."""
+
+    def __init__(self, index: "ValidatedVectorReadIndex", unique_id, rank: int, world: int, max_batch: int, max_k: int):
+        self._ix = index  # keeps the shard handle alive
+        self._g = _vp()
+        uid = None if unique_id is None else np.frombuffer(bytes(unique_id), np.uint8).copy()
+        _check(lib().hvx_shard_group_init(index._h, _ptr(uid), rank, world, max_batch, max_k, C.byref(self._g)))
+
+    @staticmethod
+    def unique_id() -> bytes:
+        out = np.zeros(128, np.uint8)
+        _check(lib().hvx_shard_group_unique_id(_ptr(out)))
+        return out.tobytes()
+
+    def search_batch_device(self, d_queries, k, ef, d_ids, d_scores, d_counts):
+        _check(lib().hvx_shard_group_search_batch_device(self._g, d_queries.data_ptr(), d_queries.shape[0], k, ef, d_ids.data_ptr(),
+                                                         d_scores.data_ptr(), d_counts.data_ptr()))
+
+    def close(self):
+        if self._g:
+            lib().hvx_shard_group_free(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Batcher:

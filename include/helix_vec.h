@@ -266,6 +266,24 @@ int hvx_merge_topk_packed_device(const hvx_index *, uint32_t g, uint32_t b, uint
                                  uint64_t *d_out_ids, float *d_out_scores, uint32_t *d_out_counts);
 
 /*
+ * The sharded search step in ONE call: every rank of a node holds one id-range shard and runs
+ *     local search -> ncclAllGather of the packed per-shard top-k (RCCL over xGMI) -> merge by Candidate order
+ * on its shard's stream, without host synchronisation.  Bootstrap as NCCL does: rank 0 obtains a 128-byte unique id
+ * (hvx_shard_group_unique_id), the host distributes it (any transport), every rank calls hvx_shard_group_init with the
+ * same id; then all ranks call hvx_shard_group_search_batch_device in the same order with the same (b, k).  Every rank
+ * receives the merged top-k of the whole corpus.  RCCL is loaded at run time (librccl.so.1); a group of one rank needs
+ * none.  The group borrows the shard handle (use one handle -- e.g. one hvx_index_fork lane -- per group).
+ */
+#define HVX_SHARD_UNIQUE_ID_BYTES 128
+typedef struct hvx_shard_group hvx_shard_group;
+int hvx_shard_group_unique_id(uint8_t *out /*[HVX_SHARD_UNIQUE_ID_BYTES]*/);
+int hvx_shard_group_init(hvx_index *local_shard, const uint8_t *unique_id, uint32_t rank, uint32_t world, uint32_t max_batch, uint32_t max_k,
+                         hvx_shard_group **out);
+int hvx_shard_group_search_batch_device(hvx_shard_group *, const float *d_queries, uint32_t b, uint32_t k, uint32_t ef,
+                                        uint64_t *d_out_ids /*[b][k]*/, float *d_out_scores, uint32_t *d_out_counts);
+void hvx_shard_group_free(hvx_shard_group *);
+
+/*
  * Graph prefilter (crates/graph-algorithms/src/model.rs:370-417 Csr; algorithms/traversal.rs:197-318
  * breadth_first; crates/db/src/execution/interpreter/access/expand.rs:16-80 one-hop expand).
  */

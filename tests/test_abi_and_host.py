@@ -399,3 +399,15 @@ def test_topk_payload_layout_is_shared_by_library_and_host():
     for b, k in [(1, 1), (7, 10), (33, 10), (1024, 10), (1024, 100), (5, 3), (4096, 7)]:
         n = hv.lib().hvx_topk_payload_bytes(b, k)
         assert n == shard.payload_bytes(b, k) and n % 8 == 0 and n >= b * k * 12 + b * 4
+
+
+def test_shard_group_argument_checks_need_no_device():
+    """hvx_shard_group_init validates its plan before touching a device or RCCL (no GPU here)."""
+    import ctypes as C
+    import pyhvx as hv
+    L = hv.lib()
+    out = C.c_void_p()
+    assert L.hvx_shard_group_init(None, None, 0, 1, 16, 10, C.byref(out)) == hv.ERR_INVARIANT
+    assert L.hvx_shard_group_unique_id(None) == hv.ERR_INVARIANT
+    assert L.hvx_shard_group_search_batch_device(None, None, 1, 1, 1, None, None, None) == hv.ERR_INVARIANT
+    L.hvx_shard_group_free(None)

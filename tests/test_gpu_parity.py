@@ -946,6 +946,27 @@ def test_duplicate_vectors_ties_are_broken_by_id_in_both_arms(orc, hv, metric):
     assert_params_equal(orc, hv, oix, gix, q, hv.SearchParams.new(25).with_ef(48), cfg)
 
 
+@pytest.mark.parametrize("occupancy", [1, 2])
+def test_ties_beyond_the_beam_slack_are_rerun_with_a_wider_beam(orc, hv, occupancy):
+    """70 exact copies of each of 40 vectors: a beam of ef = 128 entries (+ 64 of slack in the R = 3 build) evicts equal-score
+    candidates it may still have to expand, so the kernel flags those queries and the re-run launch repeats them with the
+    R = 6 beam; results, score bits and counters then equal the oracle's and no query stays flagged."""
+    rng = np.random.default_rng(99)
+    base = rng.standard_normal((40, 128)).astype(np.float32)
+    data = np.repeat(base, 70, axis=0)[rng.permutation(2800)]
+    n = data.shape[0]
+    oix = build_oracle(orc, data, orc.L2SQ, fx.draw_levels(n, 16, seed=2), efc=80)
+    gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=128, metric=hv.EUCLIDEAN)
+    gix.set_occupancy(occupancy)
+    q = np.concatenate([base[:16], base[16:24] + np.float32(0.01) * rng.standard_normal((8, 128)).astype(np.float32)])
+    assert_hnsw_equal(orc, hv, oix, gix, q, 10, 128)   # asserts tie_overflow_queries == 0
+    assert_hnsw_equal(orc, hv, oix, gix, q, 100, 128)
+    oix.set_simhash(42)
+    cfg = hv.SimHashConfig.default()
+    gix.set_simhash(cfg)
+    assert_params_equal(orc, hv, oix, gix, q, hv.SearchParams.new(10).with_ef(128), cfg)
+
+
 @pytest.mark.parametrize("metric,dim,n,k,b", [(1, 512, 40000, 10, 512), (0, 256, 80000, 25, 512), (1, 768, 60000, 100, 500)])
 def test_f32_exact_scan_on_matrix_cores_is_bit_exact(orc, hv, monkeypatch, metric, dim, n, k, b):
     """Whole-corpus exact scans over f32 rows (dim >= 256) with enough work (b x n x dim >= 2^33) generate their candidates on the matrix
@@ -1246,3 +1267,34 @@ def test_restricted_device_scan_dominates_the_reference_filter_aware_walk(orc, h
         walk_hits += len(set(wid.tolist()) & set(exact.tolist()))
         dev_hits += len(set(gid[qi, :gcnt[qi]].tolist()) & set(exact.tolist()))
     assert dev_hits == 8 * k and dev_hits >= walk_hits and walk_hits / (8.0 * k) >= 0.95
+
+
+def test_shard_group_runs_search_allgather_merge_in_one_call(orc, hv):
+    """hvx_shard_group_*: a group of ONE rank with a real RCCL communicator (ncclCommInitRank + ncclAllGather on this GPU):
+    the one-call step returns exactly what a direct search returns, for strict search, repeated calls and smaller batches."""
+    import torch
+    rng = np.random.default_rng(321)
+    n, dim, b, k, ef = 4000, 128, 96, 10, 64
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    oix = build_oracle(orc, data, orc.L2SQ, fx.draw_levels(n, 16, seed=4), efc=80)
+    gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=dim, metric=hv.EUCLIDEAN, max_batch=128)
+    lane = gix.fork()
+    grp = hv.ShardGroup(lane, hv.ShardGroup.unique_id(), 0, 1, 128, 16)
+    dev = torch.device("cuda", 0)
+    q = rng.standard_normal((b, dim)).astype(np.float32)
+    dq = torch.from_numpy(q).to(dev)
+    ids = torch.zeros(b, k, dtype=torch.int64, device=dev); sc = torch.zeros(b, k, dtype=torch.float32, device=dev)
+    cnt = torch.zeros(b, dtype=torch.int32, device=dev)
+    want = gix.search_batch(q, hv.SearchParams(k).with_ef(ef))
+    for _ in range(3):
+        grp.search_batch_device(dq, k, ef, ids, sc, cnt)
+    lane.sync()
+    assert ids.cpu().numpy().astype(np.uint64).tolist() == want[0].tolist()
+    assert bits(sc.cpu().numpy()).tolist() == bits(want[1]).tolist() and cnt.cpu().numpy().tolist() == want[2].tolist()
+    grp.search_batch_device(dq[:7], k, ef, ids, sc, cnt)  # a smaller batch: another payload geometry
+    lane.sync()
+    assert ids[:7].cpu().numpy().astype(np.uint64).tolist() == want[0][:7].tolist()
+    with pytest.raises(hv.HelixDbError):
+        grp.search_batch_device(dq, 17, 64, ids, sc, cnt)  # k beyond the group's max_k
+    grp.close()
+    lane.close()

@@ -332,6 +332,10 @@ int hvx_prefilter_search_batch(const hvx_index *, const hvx_csr *, const float *
  */
 typedef struct hvx_batcher hvx_batcher;
 int hvx_batcher_new(hvx_index *, const hvx_search_params *params, uint32_t max_batch, uint32_t max_wait_us, hvx_batcher **out);
+/* the same with an explicit number of dispatcher lanes (1..8; 0 = 2): every lane is an hvx_index_fork of the index with its own
+ * dispatcher thread, so batch i+1 is collected and launched while batch i runs.  Attach SimHash rows before creating it. */
+int hvx_batcher_new_lanes(hvx_index *, const hvx_search_params *params, uint32_t max_batch, uint32_t max_wait_us, uint32_t lanes,
+                          hvx_batcher **out);
 void hvx_batcher_free(hvx_batcher *);
 int hvx_batcher_search(hvx_batcher *, const float *query /*[dim]*/, uint64_t *out_ids /*[k]*/, float *out_scores /*[k]*/,
                        uint32_t *out_count);

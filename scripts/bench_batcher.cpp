@@ -29,10 +29,11 @@ template <typename T> static std::vector<T> load(const std::string &path) {
 }
 
 int main(int argc, char **argv) {
-    if (argc < 4) { fprintf(stderr, "usage: %s <dir> <threads> <queries per thread> [strict]\n", argv[0]); return 2; }
+    if (argc < 4) { fprintf(stderr, "usage: %s <dir> <threads> <queries per thread> [strict|default] [lanes]\n", argv[0]); return 2; }
     const std::string dir = argv[1];
     const int threads = atoi(argv[2]), per = atoi(argv[3]);
     const bool strict = argc > 4 && !strcmp(argv[4], "strict");
+    const uint32_t lanes = argc > 5 ? (uint32_t)atoi(argv[5]) : 2u;
     auto meta = load<uint64_t>(dir + "/meta.u64"); // n, dim, m, entry, max_layer
     const uint64_t n = meta[0];
     const uint32_t dim = (uint32_t)meta[1], m = (uint32_t)meta[2];
@@ -96,18 +97,17 @@ int main(int argc, char **argv) {
         if (failures) fprintf(stderr, "%d failed calls\n", failures.load());
     };
     double q0, m0, p0, q1, m1, p1;
-    run(nullptr, &q0, &m0, &p0); // warm-up + direct
-    run(nullptr, &q0, &m0, &p0);
+    run(nullptr, &q0, &m0, &p0); // direct one-query calls on one handle: every call is a launch + two PCIe copies
     hvx_batcher *bt = nullptr;
-    if (hvx_batcher_new(ix, &p, 1024, 100, &bt)) { fprintf(stderr, "%s\n", hvx_last_error()); return 1; }
+    if (hvx_batcher_new_lanes(ix, &p, 1024, 100, lanes, &bt)) { fprintf(stderr, "%s\n", hvx_last_error()); return 1; }
     run(bt, &q1, &m1, &p1);
     run(bt, &q1, &m1, &p1);
     uint64_t nb = 0, nqs = 0, nf = 0;
     hvx_batcher_stats(bt, &nb, &nqs, &nf);
     printf("{\"workload\": \"%llu x %u f32, %s, k=10, %d caller threads x %d single-query calls\", "
            "\"direct_calls\": {\"qps\": %.0f, \"mean_us\": %.1f, \"p99_us\": %.1f}, "
-           "\"batcher\": {\"qps\": %.0f, \"mean_us\": %.1f, \"p99_us\": %.1f, \"mean_batch\": %.1f, \"max_wait_us\": 100}}\n",
-           (unsigned long long)n, dim, strict ? "strict ef=100" : "SearchParams::new(10)", threads, per, q0, m0, p0, q1, m1, p1,
+           "\"batcher\": {\"lanes\": %u, \"qps\": %.0f, \"mean_us\": %.1f, \"p99_us\": %.1f, \"mean_batch\": %.1f, \"max_wait_us\": 100}}\n",
+           (unsigned long long)n, dim, strict ? "strict ef=100" : "SearchParams::new(10)", threads, per, q0, m0, p0, lanes, q1, m1, p1,
            nb ? (double)nqs / nb : 0.0);
     hvx_batcher_free(bt);
     hvx_index_free(ix);

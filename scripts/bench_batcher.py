@@ -17,8 +17,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=768)
-    ap.add_argument("--threads", type=int, default=256)
-    ap.add_argument("--per-thread", type=int, default=200)
+    ap.add_argument("--threads", type=int, default=1024)
+    ap.add_argument("--per-thread", type=int, default=100)
+    ap.add_argument("--lanes", default="2,3")
     ap.add_argument("--dir", default="/tmp/hvx_batcher")
     args = ap.parse_args()
     from pyhvx import synth
@@ -41,7 +42,8 @@ def main():
                            "-o", exe, "-L", os.path.join(ROOT, "helix-db_amd"), "-lhelix_vec_gfx950",
                            f"-Wl,-rpath,{os.path.join(ROOT, 'helix-db_amd')}", "-lpthread"])
     for mode in ("strict", "default"):
-        subprocess.check_call([exe, args.dir, str(args.threads), str(args.per_thread)] + (["strict"] if mode == "strict" else []))
+        for lanes in args.lanes.split(","):
+            subprocess.check_call([exe, args.dir, str(args.threads), str(args.per_thread), mode, lanes])
 
 
 if __name__ == "__main__":

@@ -89,16 +89,25 @@ struct MfmaArgs {
     uint32_t dim, b, row0, nrows, metric;
     float *dist;               // [b][chunk_ld]
     uint32_t chunk_ld;
+    // FILT launches: only scores below the query's running threshold leave the tile, as (score, row) pairs
+    const float *thr;          // [b] approximate score of the (m+1)-th candidate so far (+inf while fewer are known)
+    float *cand_sc;            // [b][cand_cap]
+    uint32_t *cand_id;         // [b][cand_cap] internal ids
+    uint32_t *cand_cnt;        // [b] pairs appended (may exceed cand_cap: overflow, detected by the merge)
+    uint32_t cand_cap;
 };
 
 // KIND: 0 = bf16 rows, 1 = fp8 rows, 2 = f32 rows (split into bf16 hi + lo on the way into LDS: acc += q_hi.x_hi +
-// q_lo.x_hi + q_hi.x_lo; the dropped q_lo.x_lo term is <= 2^-16 |q||x| and is covered by the certificate's bound)
-template <int KIND>
+// q_lo.x_hi + q_hi.x_lo; the dropped q_lo.x_lo term is <= 2^-16 |q||x| and is covered by the certificate's bound).
+// FULL = false: the ONE-pass build -- only q_hi.x_hi; the dropped residual terms (<= 2^-9 |q||x| per rounded operand) are
+// added to the certificate's bound instead (RerankArgs::extra_rel), queries that then fail it are repeated with FULL.
+// FILT = true: the score matrix is not written; a score leaves the tile only if it is below the query's running threshold.
+template <int KIND, bool FULL, bool FILT>
 __global__ __launch_bounds__(256) void flat_mfma_bf16_kernel(MfmaArgs a) {
-    constexpr bool FP8 = KIND == 1, F32 = KIND == 2;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[(F32 ? 4 : 3) * kBM * kLdsStride]; // A_hi | A_lo | B (| B_lo)
-    unsigned char *sAh = lds, *sAl = lds + kBM * kLdsStride, *sB = lds + 2 * kBM * kLdsStride;
-    unsigned char *sBl = lds + (F32 ? 3 : 2) * kBM * kLdsStride;
+    constexpr bool FP8 = KIND == 1, F32 = KIND == 2, LOB = F32 && FULL;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[(2 + (FULL ? 1 : 0) + (LOB ? 1 : 0)) * kBM * kLdsStride]; // A_hi | B (| A_lo) (| B_lo)
+    unsigned char *sAh = lds, *sB = lds + kBM * kLdsStride, *sAl = lds + 2 * kBM * kLdsStride;
+    unsigned char *sBl = lds + 3 * kBM * kLdsStride;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1; // 64x64 sub-tile of the wave
     const uint32_t q0 = blockIdx.y * kBM, r0 = blockIdx.x * kBN;
@@ -156,7 +165,8 @@ __global__ __launch_bounds__(256) void flat_mfma_bf16_kernel(MfmaArgs a) {
     // fragment addresses: lane holds 8 consecutive depth values of tile row (lane & 31), depth group lane >> 5
     const int fr = lane & 31, fk = (lane >> 5) * 16; // byte offset of the lane's 8 bf16 inside a 16-deep step
     uint4 pAh0 = *reinterpret_cast<const uint4 *>(gAh0), pAh1 = *reinterpret_cast<const uint4 *>(gAh1);
-    uint4 pAl0 = *reinterpret_cast<const uint4 *>(gAl0), pAl1 = *reinterpret_cast<const uint4 *>(gAl1);
+    uint4 pAl0 = make_uint4(0, 0, 0, 0), pAl1 = pAl0;
+    if (FULL) { pAl0 = *reinterpret_cast<const uint4 *>(gAl0); pAl1 = *reinterpret_cast<const uint4 *>(gAl1); }
     uint4 pB0 = make_uint4(0, 0, 0, 0), pB1 = pB0;
     if (F32) {
         pX0a = *reinterpret_cast<const float4 *>(gX0); pX0b = *reinterpret_cast<const float4 *>(gX0 + 4);
@@ -166,13 +176,13 @@ __global__ __launch_bounds__(256) void flat_mfma_bf16_kernel(MfmaArgs a) {
     for (uint32_t k0 = 0; k0 < a.dim; k0 += kBK) {
         __syncthreads(); // previous stage fully consumed
         *reinterpret_cast<uint4 *>(sAh + so0) = pAh0; *reinterpret_cast<uint4 *>(sAh + so1) = pAh1;
-        *reinterpret_cast<uint4 *>(sAl + so0) = pAl0; *reinterpret_cast<uint4 *>(sAl + so1) = pAl1;
+        if (FULL) { *reinterpret_cast<uint4 *>(sAl + so0) = pAl0; *reinterpret_cast<uint4 *>(sAl + so1) = pAl1; }
         if (F32) {
             uint4 h0, l0, h1, l1;
             split8(pX0a, pX0b, h0, l0);
             split8(pX1a, pX1b, h1, l1);
             *reinterpret_cast<uint4 *>(sB + so0) = h0; *reinterpret_cast<uint4 *>(sB + so1) = h1;
-            *reinterpret_cast<uint4 *>(sBl + so0) = l0; *reinterpret_cast<uint4 *>(sBl + so1) = l1;
+            if (LOB) { *reinterpret_cast<uint4 *>(sBl + so0) = l0; *reinterpret_cast<uint4 *>(sBl + so1) = l1; }
         } else if (FP8) {
             uint4 w0, w1;
             widen(pB0.x, w0.x, w0.y); widen(pB0.y, w0.z, w0.w); widen(pB0.z, w1.x, w1.y); widen(pB0.w, w1.z, w1.w);
@@ -184,7 +194,7 @@ __global__ __launch_bounds__(256) void flat_mfma_bf16_kernel(MfmaArgs a) {
         if (k0 + kBK < a.dim) { // next stage's global loads fly under this stage's MFMAs
             const uint32_t kn = k0 + kBK;
             pAh0 = *reinterpret_cast<const uint4 *>(gAh0 + kn); pAh1 = *reinterpret_cast<const uint4 *>(gAh1 + kn);
-            pAl0 = *reinterpret_cast<const uint4 *>(gAl0 + kn); pAl1 = *reinterpret_cast<const uint4 *>(gAl1 + kn);
+            if (FULL) { pAl0 = *reinterpret_cast<const uint4 *>(gAl0 + kn); pAl1 = *reinterpret_cast<const uint4 *>(gAl1 + kn); }
             if (F32) {
                 pX0a = *reinterpret_cast<const float4 *>(gX0 + kn); pX0b = *reinterpret_cast<const float4 *>(gX0 + kn + 4);
                 pX1a = *reinterpret_cast<const float4 *>(gX1 + kn); pX1b = *reinterpret_cast<const float4 *>(gX1 + kn + 4);
@@ -198,25 +208,35 @@ __global__ __launch_bounds__(256) void flat_mfma_bf16_kernel(MfmaArgs a) {
             for (int i = 0; i < 2; ++i) {
                 const int off = (wm * 64 + i * 32 + fr) * kLdsStride + kk * 32 + fk;
                 fah[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sAh + off));
-                fal[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sAl + off));
+                if (FULL) fal[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sAl + off));
             }
 #pragma unroll
             for (int jn = 0; jn < 2; ++jn) {
                 const int off = (wn * 64 + jn * 32 + fr) * kLdsStride + kk * 32 + fk;
                 fb[jn] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sB + off));
-                if (F32) fbl[jn] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sBl + off));
+                if (LOB) fbl[jn] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sBl + off));
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int jn = 0; jn < 2; ++jn) {
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fb[jn], acc[i][jn], 0, 0, 0);
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fb[jn], acc[i][jn], 0, 0, 0);
-                    if (F32) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbl[jn], acc[i][jn], 0, 0, 0);
+                    if (FULL) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fb[jn], acc[i][jn], 0, 0, 0);
+                    if (LOB) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbl[jn], acc[i][jn], 0, 0, 0);
                 }
         }
     }
     // epilogue: C[m = query][n = row]; lane holds n = lane & 31, m = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    float thr_r[2][16]; // FILT: the running thresholds of this lane's 32 queries
+    if (FILT) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t qq = q0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                thr_r[i][e] = qq < a.b ? a.thr[qq] : 0.f;
+            }
+    }
 #pragma unroll
     for (int jn = 0; jn < 2; ++jn) {
         const uint32_t rloc = r0 + wn * 64 + jn * 32 + (lane & 31);
@@ -241,8 +261,78 @@ __global__ __launch_bounds__(256) void flat_mfma_bf16_kernel(MfmaArgs a) {
                     c = c < -1.f ? -1.f : (c > 1.f ? 1.f : c);
                     s = (1.0f - c) * 0.5f;
                 }
-                a.dist[(size_t)qq * a.chunk_ld + rloc] = s;
+                if (FILT) {
+                    if (s < thr_r[i][e]) { // rare once the threshold has settled: ~ (m+1) / rows-seen per row
+                        const uint32_t pos = atomicAdd(&a.cand_cnt[qq], 1u);
+                        if (pos < a.cand_cap) {
+                            a.cand_sc[(size_t)qq * a.cand_cap + pos] = s;
+                            a.cand_id[(size_t)qq * a.cand_cap + pos] = (uint32_t)node;
+                        }
+                    }
+                } else {
+                    a.dist[(size_t)qq * a.chunk_ld + rloc] = s;
+                }
             }
+    }
+}
+
+// ---- FILT pipeline: merge the (score, row) pairs a filtered launch produced into the query's running top-kc list ----
+constexpr int kPairPool = 2048;
+struct PairMergeArgs {
+    float *top_scores;        // [b][kc] ascending by (score, id)
+    uint32_t *top_ids;        // [b][kc]
+    uint32_t *top_counts;     // [b]
+    float *cand_sc;           // [b][cap]
+    uint32_t *cand_id;
+    uint32_t *cand_cnt;       // [b], reset to 0 here
+    float *thr;               // [b] out: score of the kc-th entry, +inf while the list is shorter
+    uint32_t *overflow;       // [1] set when a query produced more pairs than cap
+    const uint32_t *qstatus;  // [b]
+    uint32_t kc, cap;
+};
+__global__ __launch_bounds__(256) void flat_merge_pairs_kernel(PairMergeArgs a) {
+    __shared__ float ps[kPairPool];
+    __shared__ uint32_t pi[kPairPool];
+    const uint32_t q = blockIdx.x;
+    const int tid = (int)threadIdx.x;
+    const float inf = __uint_as_float(0x7F800000u);
+    const uint32_t have = a.top_counts[q];
+    uint32_t nc = a.cand_cnt[q];
+    if (nc > a.cap) { if (tid == 0) *a.overflow = 1u; nc = a.cap; }
+    if (a.qstatus[q] != 0u) nc = 0;
+    for (int i = tid; i < kPairPool; i += 256) {
+        float sv = inf;
+        uint32_t iv = 0xFFFFFFFFu;
+        if ((uint32_t)i < have) { sv = a.top_scores[(size_t)q * a.kc + i]; iv = a.top_ids[(size_t)q * a.kc + i]; }
+        else if ((uint32_t)i - have < nc) { sv = a.cand_sc[(size_t)q * a.cap + (i - have)]; iv = a.cand_id[(size_t)q * a.cap + (i - have)]; }
+        ps[i] = sv;
+        pi[i] = iv;
+    }
+    // bitonic sort of the pool by (score, id)
+    for (int size = 2; size <= kPairPool; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = tid; t < kPairPool / 2; t += 256) {
+                const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const float sl = ps[lo], sh = ps[hi];
+                const uint32_t il = pi[lo], ih = pi[hi];
+                const bool lt = sh < sl || (sh == sl && ih < il), gt = sl < sh || (sl == sh && il < ih);
+                if (up ? lt : gt) { ps[lo] = sh; ps[hi] = sl; pi[lo] = ih; pi[hi] = il; }
+            }
+        }
+    __syncthreads();
+    const uint32_t tot = have + nc;
+    const uint32_t keep = tot < a.kc ? tot : a.kc;
+    for (uint32_t t = (uint32_t)tid; t < keep; t += 256) {
+        a.top_scores[(size_t)q * a.kc + t] = ps[t];
+        a.top_ids[(size_t)q * a.kc + t] = pi[t];
+    }
+    if (tid == 0) {
+        a.top_counts[q] = keep;
+        a.cand_cnt[q] = 0u;
+        // a rejected query lets nothing through (its scores are not reported: domain.rs:113-157 failed it before any index work)
+        a.thr[q] = a.qstatus[q] != 0u ? 0.f : (keep >= a.kc ? ps[a.kc - 1] : inf);
     }
 }
 
@@ -258,6 +348,7 @@ struct RerankArgs {
     const uint32_t *cand_counts; // [b]
     uint32_t kc, k, m;        // kc = m + 1 slots; results k
     float xmax2;              // max |x|^2 over the rows
+    float extra_rel;          // added to the certificate's relative bound: the residual terms a one-pass contraction dropped
     uint64_t *out_ids;
     float *out_scores;
     uint32_t *out_counts, *out_status;
@@ -402,7 +493,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             // hi/lo split residuals (<= 2^-17 each way, the dropped lo.lo term and the f32 roundings of the norms:
             // 2e-5 in all) + f32 accumulation over K = dim terms in BOTH summation orders (6 K 2^-24 worst case),
             // the latter doubled for whatever order the matrix core accumulates in.  K = 1536 -> 1.1e-3, K = 128 -> 1.1e-4.
-            const float erel = 2.0e-5f + 12.0f * (float)(NK * 32) * 5.9604645e-8f;
+            const float erel = 2.0e-5f + 12.0f * (float)(NK * 32) * 5.9604645e-8f + a.extra_rel;
             const float e = METRIC == kL2 ? erel * 0.5f * (a.qn2[q] + a.xmax2) : erel;
             const float kth = outn ? ss[outn - 1] : inf;
             ok = (outn == a.k && kth < t - e) ? 1u : 0u;
@@ -434,9 +525,17 @@ hipError_t launch_bf16_row_norm2(const uint16_t *rows, uint32_t n, uint32_t dim,
     return hipGetLastError();
 }
 
+static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, const uint32_t *d_subset, uint32_t n_rows,
+                          uint64_t *d_ids, float *d_scores, uint32_t *d_counts, uint32_t *d_status, bool timed, bool allow_filter);
+
 // scan all rows of a bf16 index for b device-resident queries (see the file header)
 int flat_mfma_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, const uint32_t *d_subset, uint32_t n_rows,
                      uint64_t *d_ids, float *d_scores, uint32_t *d_counts, uint32_t *d_status, bool timed) {
+    return flat_mfma_impl(ix, d_queries, b, k, d_subset, n_rows, d_ids, d_scores, d_counts, d_status, timed, true);
+}
+
+static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, const uint32_t *d_subset, uint32_t n_rows,
+                          uint64_t *d_ids, float *d_scores, uint32_t *d_counts, uint32_t *d_status, bool timed, bool allow_filter) {
     const DevIndex &d = ix->dev;
     const uint32_t n = n_rows; // rows of the scan: the whole index, or the restricted row list
     if (k == 0) return fail(HVX_ERR_K_RANGE, "result count must be non-zero");
@@ -477,14 +576,35 @@ int flat_mfma_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t
                        f32 ? 2u : (fp8 ? 1u : 0u));
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ix->ev0, ix->stream));
-    uint32_t m = std::max<uint32_t>(64u, 2u * k);
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    // Attempts, cheapest first; a query whose certificate is not reached sends the batch to the next one:
+    //   0. ONE-pass contraction (q_hi.x_hi only; the dropped residual terms widen the certificate's bound), m = max(64, 2k)
+    //   1. the full split (bf16 / fp8 rows: + q_lo.x; f32 rows: + q_lo.x_hi + q_hi.x_lo), same m
+    //   2. the full split with m = 1023 (f32 rows: the exact VALU scan for the failing queries instead)
+    // With m + 1 <= 256 only the first chunk writes its score matrix; every later launch covers a geometrically growing
+    // slice of the rows and lets a score out of the tile only below the query's running threshold (FILT).
+    const uint32_t m0 = std::max<uint32_t>(64u, 2u * k);
+    const bool debug = getenv("HVX_FLAT_DEBUG") != nullptr;
+    const bool allow_fast = getenv("HVX_FLAT_NO_FAST") == nullptr;
+    constexpr uint32_t kCandCap = 1024;
+    for (int attempt = allow_fast ? 0 : 1; attempt < 3; ++attempt) {
+        const bool full = attempt >= 1;
+        const uint32_t m = attempt == 2 ? 1023u : m0;
+        if (attempt == 2 && m0 >= 1023u) break;
         const uint32_t kc = m + 1;
         uint32_t chunk = 65536;
         while ((size_t)chunk * b * 4 > (512u << 20) && chunk > 1024) chunk >>= 1;
         if (chunk > n) chunk = (n + 3u) & ~3u;
         if ((rc = ix->flat_scratch(b, kc, chunk))) return rc;
+        const bool filt = allow_filter && kc <= 256u && n > chunk && getenv("HVX_FLAT_NO_FILTER") == nullptr;
+        if (filt && ix->cap_cand < (size_t)bpad) {
+            if ((rc = ix->regrow((void **)&ix->m_thr, (size_t)bpad * 4))) return rc;
+            if ((rc = ix->regrow((void **)&ix->m_csc, (size_t)bpad * kCandCap * 4))) return rc;
+            if ((rc = ix->regrow((void **)&ix->m_cid, (size_t)bpad * kCandCap * 4))) return rc;
+            if ((rc = ix->regrow((void **)&ix->m_ccnt, (size_t)bpad * 4 + 4))) return rc;
+            ix->cap_cand = bpad;
+        }
         HIP_TRY(hipMemsetAsync(ix->f_top_c, 0, (size_t)b * 4, ix->stream));
+        if (filt) HIP_TRY(hipMemsetAsync(ix->m_ccnt, 0, (size_t)bpad * 4 + 4, ix->stream));
         FlatArgs fa;
         fa.ix = d; fa.queries = d_queries; fa.qstatus = ix->d_qstatus; fa.qhdr = ix->d_qhdr; fa.subset = d_subset;
         fa.n_rows = n; fa.dist = ix->f_dist; fa.chunk_ld = chunk; fa.b = b; fa.k = kc;
@@ -495,40 +615,80 @@ int flat_mfma_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t
         ma.rowscale = d.rowscale;
         ma.rowterm = d.metric == kL2 ? ix->m_rowterm : d.hdr;
         ma.qn2 = ix->m_qn2; ma.dim = d.dim; ma.b = b; ma.metric = d.metric; ma.dist = ix->f_dist; ma.chunk_ld = chunk;
-        for (uint32_t r0 = 0; r0 < n; r0 += chunk) {
-            const uint32_t rows = std::min(chunk, n - r0);
+        ma.thr = ix->m_thr; ma.cand_sc = ix->m_csc; ma.cand_id = ix->m_cid; ma.cand_cnt = ix->m_ccnt; ma.cand_cap = kCandCap;
+        auto contraction = [&](uint32_t r0, uint32_t rows, bool filtered) -> hipError_t {
             ma.row0 = r0; ma.nrows = rows;
-            if (f32) hipLaunchKernelGGL(flat_mfma_bf16_kernel<2>, dim3((rows + kBN - 1) / kBN, bpad / kBM), dim3(256), 0, ix->stream, ma);
-            else if (fp8) hipLaunchKernelGGL(flat_mfma_bf16_kernel<1>, dim3((rows + kBN - 1) / kBN, bpad / kBM), dim3(256), 0, ix->stream, ma);
-            else hipLaunchKernelGGL(flat_mfma_bf16_kernel<0>, dim3((rows + kBN - 1) / kBN, bpad / kBM), dim3(256), 0, ix->stream, ma);
-            HIP_TRY(hipGetLastError());
-            fa.row0 = r0; fa.rows = rows;
-            HIP_TRY(launch_flat_select(fa, ix->stream));
+            const dim3 grid((rows + kBN - 1) / kBN, bpad / kBM);
+#define HVX_FM(KIND)                                                                                                              \
+    do {                                                                                                                          \
+        if (full) { if (filtered) hipLaunchKernelGGL((flat_mfma_bf16_kernel<KIND, true, true>), grid, dim3(256), 0, ix->stream, ma);   \
+                    else hipLaunchKernelGGL((flat_mfma_bf16_kernel<KIND, true, false>), grid, dim3(256), 0, ix->stream, ma); }          \
+        else { if (filtered) hipLaunchKernelGGL((flat_mfma_bf16_kernel<KIND, false, true>), grid, dim3(256), 0, ix->stream, ma);        \
+               else hipLaunchKernelGGL((flat_mfma_bf16_kernel<KIND, false, false>), grid, dim3(256), 0, ix->stream, ma); }              \
+    } while (0)
+            if (f32) HVX_FM(2); else if (fp8) HVX_FM(1); else HVX_FM(0);
+#undef HVX_FM
+            return hipGetLastError();
+        };
+        PairMergeArgs pm;
+        pm.top_scores = ix->f_top_s; pm.top_ids = ix->f_top_i; pm.top_counts = ix->f_top_c; pm.cand_sc = ix->m_csc; pm.cand_id = ix->m_cid;
+        pm.cand_cnt = ix->m_ccnt; pm.thr = ix->m_thr; pm.overflow = ix->m_ccnt ? ix->m_ccnt + bpad : nullptr; pm.qstatus = ix->d_qstatus;
+        pm.kc = kc; pm.cap = kCandCap;
+        uint32_t r0 = 0;
+        while (r0 < n) {
+            if (filt && r0 > 0) {
+                // thresholds are those of the rows seen so far: a slice three times that long lets ~3 (m + 1) pairs per query through
+                const uint32_t rows = (uint32_t)std::min<uint64_t>((uint64_t)n - r0, (uint64_t)r0 * 3u);
+                HIP_TRY(contraction(r0, rows, true));
+                hipLaunchKernelGGL(flat_merge_pairs_kernel, dim3(b), dim3(256), 0, ix->stream, pm);
+                HIP_TRY(hipGetLastError());
+                r0 += rows;
+            } else {
+                const uint32_t rows = std::min(chunk, n - r0);
+                HIP_TRY(contraction(r0, rows, false));
+                fa.row0 = r0; fa.rows = rows;
+                HIP_TRY(launch_flat_select(fa, ix->stream));
+                r0 += rows;
+                if (filt) { // thresholds out of the first chunk's top list (no pairs yet)
+                    hipLaunchKernelGGL(flat_merge_pairs_kernel, dim3(b), dim3(256), 0, ix->stream, pm);
+                    HIP_TRY(hipGetLastError());
+                }
+            }
         }
         RerankArgs ra;
         ra.ix = d; ra.queries = d_queries; ra.qstatus = ix->d_qstatus; ra.qhdr = ix->d_qhdr; ra.qn2 = ix->m_qn2;
         ra.cand_scores = ix->f_top_s; ra.cand_ids = ix->f_top_i; ra.cand_counts = ix->f_top_c; ra.kc = kc; ra.k = k; ra.m = m;
         ra.xmax2 = ix->m_xmax2; ra.out_ids = d_ids; ra.out_scores = d_scores; ra.out_counts = d_counts; ra.out_status = d_status;
         ra.cert = ix->m_cert;
+        // one rounded operand drops a term <= 2^-9 |q||x| of the dot product = 2^-8 of (|q|^2 + |x|^2)/2 in the L2 score
+        // (cosine: <= 2^-10 absolute); f32 rows round BOTH operands in the one-pass build
+        ra.extra_rel = full ? 0.f : (f32 ? 0.0078125f : 0.00390625f);
         HIP_TRY(d.metric == kL2 ? launch_rerank<kL2>(ra, b, ix->stream) : launch_rerank<kCosine>(ra, b, ix->stream));
-        if (timed && attempt == 0) HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
+        if (timed) HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
         std::vector<uint32_t> cert(b);
+        uint32_t overflow = 0;
         HIP_TRY(hipMemcpyAsync(cert.data(), ix->m_cert, (size_t)b * 4, hipMemcpyDeviceToHost, ix->stream));
+        if (filt) HIP_TRY(hipMemcpyAsync(&overflow, ix->m_ccnt + bpad, 4, hipMemcpyDeviceToHost, ix->stream));
         HIP_TRY(hipStreamSynchronize(ix->stream));
         uint32_t failed = 0, first = 0;
         for (uint32_t i = 0; i < b; ++i)
             if (!cert[i]) { if (!failed) first = i; ++failed; }
+        if (debug)
+            fprintf(stderr, "[hvx flat] attempt %d (%s contraction, m = %u%s): %u of %u certificates missing%s\n", attempt,
+                    full ? "full" : "one-pass", m, filt ? ", filtered epilogue" : "", failed, b, overflow ? ", PAIR OVERFLOW" : "");
+        if (overflow) { // a query produced more pairs than the buffer holds: its list is incomplete -- never guess
+            return flat_mfma_impl(ix, d_queries, b, k, d_subset, n_rows, d_ids, d_scores, d_counts, d_status, timed, false);
+        }
         if (!failed) return HVX_OK;
-        if (f32) { // f32 rows have an exact VALU scan to fall back to: never widen, never guess
+        if (f32 && full) { // f32 rows have an exact VALU scan to fall back to: never widen, never guess
             ix->m_failed.clear();
             for (uint32_t i = 0; i < b; ++i)
                 if (!cert[i]) ix->m_failed.push_back(i);
             return HVX_MFMA_FALLBACK;
         }
-        if (m >= 1023u)
+        if (attempt == 2 || (attempt == 1 && m0 >= 1023u))
             return fail(HVX_ERR_INVARIANT, "exact-scan certificate failed for %u queries (first %u): more than 1023 rows within the "
                         "error bound of the k-th score", failed, first);
-        m = 1023u; // widen: the select pool holds 2048 entries
     }
     return fail(HVX_ERR_INVARIANT, "exact-scan certificate failed after widening");
 }

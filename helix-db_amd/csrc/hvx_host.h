@@ -73,6 +73,10 @@ struct hvx_index {
     uint16_t *m_qhi = nullptr, *m_qlo = nullptr;
     float *m_qn2 = nullptr, *m_rowterm = nullptr; // |q|^2 per query; |x|^2 per row
     uint32_t *m_cert = nullptr;
+    // filtered-epilogue pipeline: running thresholds and the (score, row) pairs a filtered launch lets through
+    float *m_thr = nullptr, *m_csc = nullptr;
+    uint32_t *m_cid = nullptr, *m_ccnt = nullptr;
+    size_t cap_cand = 0;
     size_t cap_qsplit = 0;
     float m_xmax2 = 0.f;
     // non-strict search arms (hvx_params.hip): per-node SimHash rows, the hasher, per-batch fingerprints

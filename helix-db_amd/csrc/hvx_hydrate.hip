@@ -109,11 +109,32 @@ extern "C" int hvx_decode_upper_row(const uint8_t *value, size_t len, uint64_t *
     return HVX_OK;
 }
 
-// keys/vectors.rs: returns the key kind (0x02 item, 0x16 layer 0, 0x11 upper) or 0 when the key is none of them
+// keys/tenant.rs:13-15,69-95: a tenant-scoped key is [0xFD][tenant_id: u128 BE] ++ the logical key; the legacy namespace has
+// no envelope.  Returns the envelope length (0 or 17) and the tenant id halves.
+extern "C" uint32_t hvx_strip_tenant_envelope(const uint8_t *key, size_t len, uint64_t *tenant_hi, uint64_t *tenant_lo) {
+    if (!key || len < 17 || key[0] != 0xFD) return 0;
+    if (tenant_hi) *tenant_hi = be64(key + 1);
+    if (tenant_lo) *tenant_lo = be64(key + 9);
+    return 17;
+}
+
+// keys/vectors.rs: returns the key kind (0x02 item, 0x16 layer 0, 0x11 upper) or 0 when the key is none of them;
+// a tenant envelope (keys/tenant.rs:69-95) in front of the logical key is skipped
 extern "C" uint32_t hvx_parse_vector_key(const uint8_t *key, size_t len, uint64_t *index_id, uint64_t *node_id, uint64_t *order_code,
                                          uint32_t *layer) {
+    if (!key) return 0;
+    const uint32_t env = hvx_strip_tenant_envelope(key, len, nullptr, nullptr);
+    key += env;
+    len -= env;
     if (len < 10) return 0;
     const uint8_t ks = key[0], kind = key[9];
+    if (ks == 0x03) { // index metadata row: [0x03][0x03][index_id: 8][0x01] (keys/vectors.rs:23-38)
+        if (len == 11 && key[1] == 0x03 && key[10] == 0x01) {
+            if (index_id) *index_id = be64(key + 2);
+            return 0x01;
+        }
+        return 0;
+    }
     if (index_id) *index_id = be64(key + 1);
     if (ks == 0xF1 && kind == 0x02 && len == 26) {
         if (order_code) *order_code = be64(key + 10);
@@ -130,6 +151,85 @@ extern "C" uint32_t hvx_parse_vector_key(const uint8_t *key, size_t len, uint64_
         return 0x11;
     }
     return 0;
+}
+
+// ---- the index metadata row: rkyv 0.8 archive of VectorIndexMetadata (values/vectors/metadata.rs:22-62) ----
+// rkyv is a third-party dependency (Cargo.lock: rkyv 0.8.17, default format: little-endian, aligned, 32-bit relative
+// pointers) that is not under /root/reference, and the reference holds no byte fixture of this row (its tests round-trip
+// through rkyv itself): the layout below restates rkyv 0.8's published format and is PARITY UNPINNED until a real store's row
+// is available.  Archived structs are repr(C) in field order; usize -> u32; bool -> u8; Option<u64> -> { tag: u8, [pad 7],
+// value: u64 }; String -> 8 bytes: inline (<= 8 bytes, padded with 0xFF) or out of line { len: u32 with 0b10 in bits 7..6 of
+// the first byte (len = (v & 0x3F) | ((v & ~0xFF) >> 2)), offset: i32 relative to the string's own position }.  The root
+// object is the LAST 88 bytes of the value:
+//   config  @0 : index_name 8 | property_name 8 | dimension, m, m0, ef_construction u32 | ml f32 | simhash_threshold u32 |
+//                sampling_ratio f32 | adaptive_enabled u8 + 3 pad | adaptive_failure_prob f32                       (52 bytes)
+//   @56 entry_point: tag u8, value u64 @64 | @72 max_layer u16 | @80 count u64
+static uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+static uint64_t rk_le64(const uint8_t *p) { return (uint64_t)le32(p) | ((uint64_t)le32(p + 4) << 32); }
+static float lef32(const uint8_t *p) { const uint32_t u = le32(p); float f; memcpy(&f, &u, 4); return f; }
+
+static bool archived_string(const uint8_t *base, size_t len, size_t pos, char *out, size_t cap) {
+    const uint8_t *r = base + pos;
+    if ((r[0] & 0xC0) != 0x80) { // inline
+        size_t n = 0;
+        while (n < 8 && r[n] != 0xFF) ++n;
+        if (n + 1 > cap) return false;
+        memcpy(out, r, n);
+        out[n] = 0;
+        return true;
+    }
+    const uint32_t v = le32(r);
+    const size_t n = (size_t)((v & 0x3Fu) | ((v & ~0xFFu) >> 2));
+    const int64_t off = (int32_t)le32(r + 4);
+    const int64_t at = (int64_t)pos + off;
+    if (at < 0 || (uint64_t)at + n > len || n + 1 > cap) return false;
+    memcpy(out, base + at, n);
+    out[n] = 0;
+    return true;
+}
+
+extern "C" int hvx_decode_index_metadata(const uint8_t *value, size_t len, hvx_index_metadata *out) {
+    if (!out) return fail(HVX_ERR_INVARIANT, "null argument");
+    memset(out, 0, sizeof(*out));
+    if (!value || len == 0) return fail(HVX_ERR_INVARIANT, "Empty metadata data"); // metadata.rs:132-134
+    constexpr size_t kRoot = 88;
+    if (len < kRoot || (len - kRoot) % 8 != 0) return fail(HVX_ERR_INVARIANT, "Failed to access archived metadata: %zu bytes cannot hold an aligned root", len);
+    const size_t root = len - kRoot;
+    const uint8_t *c = value + root;
+    if (!archived_string(value, len, root, out->index_name, sizeof(out->index_name)) ||
+        !archived_string(value, len, root + 8, out->property_name, sizeof(out->property_name)))
+        return fail(HVX_ERR_INVARIANT, "Failed to access archived metadata: string out of bounds");
+    out->dimension = le32(c + 16);
+    out->m = le32(c + 20);
+    out->m0 = le32(c + 24);
+    out->ef_construction = le32(c + 28);
+    out->ml = lef32(c + 32);
+    out->simhash_threshold = le32(c + 36);
+    out->sampling_ratio = lef32(c + 40);
+    if (c[44] > 1) return fail(HVX_ERR_INVARIANT, "Failed to access archived metadata: invalid bool");
+    out->adaptive_enabled = c[44];
+    out->adaptive_failure_prob = lef32(c + 48);
+    if (c[56] > 1) return fail(HVX_ERR_INVARIANT, "Failed to access archived metadata: invalid Option tag");
+    out->has_entry_point = c[56];
+    out->entry_point = c[56] ? rk_le64(c + 64) : 0;
+    out->max_layer = (uint32_t)c[72] | ((uint32_t)c[73] << 8);
+    out->count = rk_le64(c + 80);
+    return HVX_OK;
+}
+
+// VectorIndexMetadata::validated_state + the config checks the search path relies on (mod.rs:331-375): the row supplies entry
+// point and top layer, and must agree with the hydrator's dimension
+extern "C" int hvx_hydrator_set_metadata(hvx_hydrator *h, const uint8_t *value, size_t len) {
+    if (!h) return fail(HVX_ERR_INVARIANT, "null argument");
+    hvx_index_metadata md;
+    const int rc = hvx_decode_index_metadata(value, len, &md);
+    if (rc) return rc;
+    if (md.dimension != h->dim) return fail(HVX_ERR_DIMENSION, "metadata dimension %llu differs from the hydrator's %u", (unsigned long long)md.dimension, h->dim);
+    if (md.simhash_threshold > 64) return fail(HVX_ERR_INVARIANT, "metadata: SimHash threshold above 64");
+    if (md.max_layer > 63) return fail(HVX_ERR_INVARIANT, "metadata: max_layer above 63");
+    if (!md.has_entry_point && md.max_layer != 0) return fail(HVX_ERR_INVARIANT, "metadata: empty index with a non-zero top layer");
+    if (md.has_entry_point) return hvx_hydrator_set_entry(h, md.entry_point, md.max_layer);
+    return HVX_OK;
 }
 
 extern "C" int hvx_hydrator_new(uint32_t dim, uint32_t metric, hvx_hydrator **out) {

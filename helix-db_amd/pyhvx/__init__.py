@@ -88,6 +88,23 @@ class SimHashConfig(C.Structure):  # hvx_simhash_config: the index-level VectorI
         return c
 
 
+class IndexMetadata(C.Structure):  # hvx_index_metadata: VectorIndexMetadata (values/vectors/metadata.rs:22-62)
+    _fields_ = [("index_name", C.c_char * 256), ("property_name", C.c_char * 256), ("dimension", C.c_uint64), ("m", C.c_uint64),
+                ("m0", C.c_uint64), ("ef_construction", C.c_uint64), ("simhash_threshold", C.c_uint64), ("ml", C.c_float),
+                ("sampling_ratio", C.c_float), ("adaptive_failure_prob", C.c_float), ("adaptive_enabled", C.c_uint32),
+                ("has_entry_point", C.c_uint32), ("max_layer", C.c_uint32), ("entry_point", C.c_uint64), ("count", C.c_uint64)]
+
+
+def decode_index_metadata(value: bytes) -> dict:
+    """hvx_decode_index_metadata: the rkyv-archived VectorIndexMetadata row (layout restated, parity unpinned)."""
+    md = IndexMetadata()
+    _check(lib().hvx_decode_index_metadata(value, len(value), C.byref(md)))
+    out = {k: getattr(md, k) for k, _ in md._fields_}
+    out["index_name"], out["property_name"] = md.index_name.decode(), md.property_name.decode()
+    out["entry_point"] = md.entry_point if md.has_entry_point else None
+    return out
+
+
 class BuildParams(C.Structure):  # hvx_build_params
     _fields_ = [("ef_construction", C.c_uint32), ("max_batch", C.c_uint32), ("batch_divisor", C.c_uint32), ("sequential", C.c_uint32)]
 
@@ -201,6 +218,12 @@ def lib():
     L.hvx_decode_upper_row.argtypes = [C.c_char_p, C.c_size_t, _vp, C.c_uint32, C.POINTER(C.c_uint32)]
     L.hvx_parse_vector_key.restype = C.c_uint32
     L.hvx_parse_vector_key.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    L.hvx_strip_tenant_envelope.restype = C.c_uint32
+    L.hvx_strip_tenant_envelope.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.hvx_decode_index_metadata.restype = C.c_int
+    L.hvx_decode_index_metadata.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(IndexMetadata)]
+    L.hvx_hydrator_set_metadata.restype = C.c_int
+    L.hvx_hydrator_set_metadata.argtypes = [_vp, C.c_char_p, C.c_size_t]
     L.hvx_hydrator_new.restype = C.c_int
     L.hvx_hydrator_new.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(_vp)]
     L.hvx_hydrator_free.argtypes = [_vp]
@@ -920,6 +943,10 @@ class Hydrator:
 
     def add_upper_row(self, node_id, layer, value: bytes):
         _check(lib().hvx_hydrator_add_upper_row(self._h, int(node_id), int(layer), value, len(value)))
+
+    def set_metadata(self, value: bytes):
+        """entry point / top layer from the index metadata row (rkyv VectorIndexMetadata), checked against the dimension"""
+        _check(lib().hvx_hydrator_set_metadata(self._h, value, len(value)))
 
     def set_entry(self, entry_point, max_layer):
         _check(lib().hvx_hydrator_set_entry(self._h, int(entry_point), int(max_layer)))

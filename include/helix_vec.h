@@ -356,13 +356,28 @@ uint64_t hvx_order_code_from_simhash_bits(uint64_t bits);
  * Hydration from HelixDB's persisted rows (replaces VectorMemoryStore hydration, memory_store.rs:97-105).
  * Value codecs restated from crates/db/src/encoding/v1/values/vectors.rs:97-210 (layer-0 rows, tags 0x12 / 0x13, empty),
  * values/vectors/neighbors.rs:57-110 (upper rows), values/vectors/item.rs:34-60 (header f32 + dim f32, native-endian);
- * keys from keys/vectors.rs:23-50.  The rkyv metadata row is not decoded: pass entry point / max layer explicitly.
+ * keys from keys/vectors.rs:23-50 (legacy or tenant-scoped, keys/tenant.rs:69-95); the rkyv metadata row through
+ * hvx_decode_index_metadata / hvx_hydrator_set_metadata.
  */
 typedef struct hvx_hydrator hvx_hydrator;
 int hvx_decode_layer0_row(const uint8_t *value, size_t len, uint64_t *out_ids, uint32_t cap, uint32_t *out_count,
                           uint64_t *out_simhash, uint32_t *out_has_simhash);
 int hvx_decode_upper_row(const uint8_t *value, size_t len, uint64_t *out_ids, uint32_t cap, uint32_t *out_count);
-/* returns the key kind (0x02 canonical vector, 0x16 layer-0 neighbours, 0x11 upper neighbours) or 0 */
+/* keys/tenant.rs:69-95: length of the tenant envelope in front of a key (17 = [0xFD][tenant_id u128 BE], 0 = legacy namespace) */
+uint32_t hvx_strip_tenant_envelope(const uint8_t *key, size_t len, uint64_t *tenant_hi, uint64_t *tenant_lo);
+/* The index metadata row [0x03][0x03][index_id][0x01] (keys/vectors.rs:23-38): rkyv 0.8 archive of VectorIndexMetadata
+ * (values/vectors/metadata.rs:22-62).  rkyv is not vendored in the reference and the reference holds no byte fixture of the row:
+ * the layout is restated from rkyv 0.8's published format -- PARITY UNPINNED (csrc/hvx_hydrate.hip has the layout). */
+typedef struct hvx_index_metadata {
+    char index_name[256], property_name[256];
+    uint64_t dimension, m, m0, ef_construction, simhash_threshold;
+    float ml, sampling_ratio, adaptive_failure_prob;
+    uint32_t adaptive_enabled, has_entry_point, max_layer;
+    uint64_t entry_point, count;
+} hvx_index_metadata;
+int hvx_decode_index_metadata(const uint8_t *value, size_t len, hvx_index_metadata *out);
+/* returns the key kind (0x01 index metadata, 0x02 canonical vector, 0x16 layer-0 neighbours, 0x11 upper neighbours) or 0;
+ * tenant-scoped keys (a 17-byte envelope in front) are accepted */
 uint32_t hvx_parse_vector_key(const uint8_t *key, size_t len, uint64_t *index_id, uint64_t *node_id, uint64_t *order_code,
                               uint32_t *layer);
 int hvx_hydrator_new(uint32_t dim, uint32_t metric, hvx_hydrator **out);
@@ -371,6 +386,8 @@ int hvx_hydrator_add_item(hvx_hydrator *, uint64_t node_id, const uint8_t *value
 int hvx_hydrator_add_layer0_row(hvx_hydrator *, uint64_t node_id, const uint8_t *value, size_t len);
 int hvx_hydrator_add_upper_row(hvx_hydrator *, uint64_t node_id, uint32_t layer, const uint8_t *value, size_t len);
 int hvx_hydrator_set_entry(hvx_hydrator *, uint64_t entry_point, uint32_t max_layer);
+/* entry point / top layer from the metadata row instead (checked against the hydrator's dimension) */
+int hvx_hydrator_set_metadata(hvx_hydrator *, const uint8_t *value, size_t len);
 /* `tmpl` supplies dtype, float_kernel, m, m0, device, max_batch; the rest comes from the collected rows */
 int hvx_hydrator_finish(const hvx_hydrator *, const hvx_index_desc *tmpl, hvx_index **out);
 

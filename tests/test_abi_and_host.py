@@ -411,3 +411,87 @@ def test_shard_group_argument_checks_need_no_device():
     assert L.hvx_shard_group_unique_id(None) == hv.ERR_INVARIANT
     assert L.hvx_shard_group_search_batch_device(None, None, 1, 1, 1, None, None, None) == hv.ERR_INVARIANT
     L.hvx_shard_group_free(None)
+
+
+def _rkyv_string(buf: bytearray, s: bytes):
+    """rkyv 0.8 ArchivedString, 32-bit pointers, little-endian: returns a function writing the 8-byte repr at a given position"""
+    if len(s) <= 8:
+        return lambda pos: bytes(s) + b"\xff" * (8 - len(s))
+    at = len(buf)
+    buf.extend(s)  # out-of-line bytes are serialised before the object that points at them
+    n = len(s)
+    v = (n & 0x3F) | 0x80 | ((n & ~0x3F) << 2)
+    return lambda pos: v.to_bytes(4, "little") + (at - pos).to_bytes(4, "little", signed=True)
+
+
+def rkyv_metadata(index_name, property_name, dimension, m, m0, efc, ml, threshold, ratio, adaptive, failure, entry_point, max_layer, count):
+    """Python twin of rkyv::to_bytes(&VectorIndexMetadata) per rkyv 0.8's published format (values/vectors/metadata.rs:22-62):
+    out-of-line string bytes first, the 88-byte repr(C) root last, 8-aligned."""
+    import struct
+    buf = bytearray()
+    w_name = _rkyv_string(buf, index_name.encode())
+    w_prop = _rkyv_string(buf, property_name.encode())
+    while len(buf) % 8:
+        buf.append(0)
+    root = len(buf)
+    body = w_name(root) + w_prop(root + 8)
+    body += struct.pack("<IIIIfIfB3xf", dimension, m, m0, efc, ml, threshold, ratio, 1 if adaptive else 0, failure)
+    body += b"\x00" * 4                                                      # config is 52 bytes; Option<u64> aligns to 8
+    body += struct.pack("<B7xQ", 0 if entry_point is None else 1, 0 if entry_point is None else entry_point)
+    body += struct.pack("<H6xQ", max_layer, count)
+    assert len(body) == 88
+    return bytes(buf) + body
+
+
+def test_tenant_scoped_keys_and_the_metadata_row():
+    """keys/tenant.rs:69-95 envelopes in front of every vector key; keys/vectors.rs:23-38 metadata key; the rkyv metadata row
+    (values/vectors/metadata.rs) -- its layout is restated from rkyv 0.8's published format: parity UNPINNED (no byte fixture
+    exists in the reference), so this test pins self-consistency, the reference's own decode tests (empty / malformed values are
+    rejected, metadata.rs:311-314; the field values of :286-309) and memory safety on arbitrary bytes."""
+    import ctypes as C
+    import pyhvx as hv
+    L = hv.lib()
+    tenant = (0x0123456789ABCDEF_0FEDCBA987654321).to_bytes(16, "big")
+    logical = bytes([0xF1]) + (77).to_bytes(8, "big") + bytes([0x02]) + (0xAABB).to_bytes(8, "big") + (5).to_bytes(8, "big")
+    hi, lo = C.c_uint64(0), C.c_uint64(0)
+    assert L.hvx_strip_tenant_envelope(logical, len(logical), C.byref(hi), C.byref(lo)) == 0
+    scoped = bytes([0xFD]) + tenant + logical
+    assert L.hvx_strip_tenant_envelope(scoped, len(scoped), C.byref(hi), C.byref(lo)) == 17
+    assert (hi.value, lo.value) == (0x0123456789ABCDEF, 0x0FEDCBA987654321)
+    for key in (logical, scoped):
+        ix, node, order, layer = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
+        assert L.hvx_parse_vector_key(key, len(key), C.byref(ix), C.byref(node), C.byref(order), C.byref(layer)) == 0x02
+        assert (ix.value, node.value, order.value) == (77, 5, 0xAABB)
+    mkey = bytes([0x03, 0x03]) + (77).to_bytes(8, "big") + bytes([0x01])
+    for key in (mkey, bytes([0xFD]) + tenant + mkey):
+        ix = C.c_uint64(0)
+        assert L.hvx_parse_vector_key(key, len(key), C.byref(ix), None, None, None) == 0x01 and ix.value == 77
+    assert L.hvx_parse_vector_key(scoped[:20], 20, None, None, None, None) == 0
+    # the metadata row: the values of the reference's codec test (metadata.rs:286-309), then one with an entry point
+    v = rkyv_metadata("metadata-codec", "embedding", 3, 16, 32, 200, 0.5, 43, 0.8, True, 0.1, None, 0, 0)
+    md = hv.decode_index_metadata(v)
+    assert (md["index_name"], md["property_name"], md["dimension"], md["m"], md["m0"], md["ef_construction"]) == ("metadata-codec", "embedding", 3, 16, 32, 200)
+    assert md["ml"] == 0.5 and md["simhash_threshold"] == 43 and abs(md["sampling_ratio"] - 0.8) < 1e-7 and md["adaptive_enabled"] == 1
+    assert md["entry_point"] is None and md["max_layer"] == 0 and md["count"] == 0
+    v2 = rkyv_metadata("idx", "embedding-with-a-long-property-name", 768, 16, 32, 200, 0.36, 43, 0.8, False, 0.1, 123456789012, 5, 1_000_000)
+    md2 = hv.decode_index_metadata(v2)
+    assert (md2["index_name"], md2["property_name"]) == ("idx", "embedding-with-a-long-property-name")          # inline + out-of-line strings
+    assert (md2["dimension"], md2["entry_point"], md2["max_layer"], md2["count"], md2["adaptive_enabled"]) == (768, 123456789012, 5, 1_000_000, 0)
+    for bad in (b"", b"malformed"):                                           # metadata.rs:311-314
+        with pytest.raises(hv.HelixDbError):
+            hv.decode_index_metadata(bad)
+    rng = np.random.default_rng(5)
+    for _ in range(3000):                                                     # arbitrary / mutated bytes: a status, never a wild read
+        m = bytearray(v2 if rng.random() < 0.7 else bytes(rng.integers(0, 256, int(rng.integers(0, 200)), dtype=np.uint8)))
+        for _ in range(int(rng.integers(0, 4))):
+            if m:
+                m[int(rng.integers(0, len(m)))] = int(rng.integers(0, 256))
+        cut = bytes(m[: int(rng.integers(0, len(m) + 1))]) if rng.random() < 0.3 else bytes(m)
+        out = hv.IndexMetadata()
+        assert L.hvx_decode_index_metadata(cut, len(cut), C.byref(out)) in (hv.OK, hv.ERR_INVARIANT)
+    # the hydrator takes entry point / top layer from the row and checks the dimension
+    h = hv.Hydrator(768, hv.EUCLIDEAN)
+    h.set_metadata(v2)
+    with pytest.raises(hv.HelixDbError) as e:
+        hv.Hydrator(3, hv.EUCLIDEAN).set_metadata(v2)
+    assert e.value.status == hv.ERR_DIMENSION

@@ -95,6 +95,10 @@ struct MfmaArgs {
     uint32_t *cand_id;         // [b][cand_cap] internal ids
     uint32_t *cand_cnt;        // [b] pairs appended (may exceed cand_cap: overflow, detected by the merge)
     uint32_t cand_cap;
+    // 1-D launch: workgroup id -> (row tile, query tile).  Rows are walked in groups of `group_tiles` row tiles (~64 MB of
+    // rows: they stay in the Infinity Cache), inside a group the QUERY tile is the outer loop: a query tile's 128 x dim
+    // operand stays in L2 while the group's row tiles stream past it, and the group's rows come from HBM once.
+    uint32_t nq_tiles, nr_tiles, group_tiles;
 };
 
 // KIND: 0 = bf16 rows, 1 = fp8 rows, 2 = f32 rows (split into bf16 hi + lo on the way into LDS: acc += q_hi.x_hi +
@@ -110,7 +114,16 @@ __global__ __launch_bounds__(256) void flat_mfma_bf16_kernel(MfmaArgs a) {
     unsigned char *sBl = lds + 3 * kBM * kLdsStride;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1; // 64x64 sub-tile of the wave
-    const uint32_t q0 = blockIdx.y * kBM, r0 = blockIdx.x * kBN;
+    uint32_t qt, rt;
+    {
+        const uint32_t per_group = a.group_tiles * a.nq_tiles;
+        const uint32_t grp = blockIdx.x / per_group, rem = blockIdx.x % per_group;
+        const uint32_t in_group = a.nr_tiles - grp * a.group_tiles < a.group_tiles ? a.nr_tiles - grp * a.group_tiles : a.group_tiles;
+        qt = rem / in_group;
+        rt = grp * a.group_tiles + rem % in_group;
+        if (qt >= a.nq_tiles) return; // the last (short) group leaves workgroup ids over
+    }
+    const uint32_t q0 = qt * kBM, r0 = rt * kBN;
     // staging: thread owns 16 bytes (8 bf16) of tile rows sr and sr+64, depth chunk sc
     const int sr = tid >> 2, sc = tid & 3;
     const uint32_t rowA0 = q0 + sr, rowA1 = q0 + sr + 64; // queries are padded to a multiple of 128
@@ -618,7 +631,12 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
         ma.thr = ix->m_thr; ma.cand_sc = ix->m_csc; ma.cand_id = ix->m_cid; ma.cand_cnt = ix->m_ccnt; ma.cand_cap = kCandCap;
         auto contraction = [&](uint32_t r0, uint32_t rows, bool filtered) -> hipError_t {
             ma.row0 = r0; ma.nrows = rows;
-            const dim3 grid((rows + kBN - 1) / kBN, bpad / kBM);
+            ma.nq_tiles = bpad / kBM;
+            ma.nr_tiles = (rows + kBN - 1) / kBN;
+            const size_t row_bytes = (size_t)d.dim * (f32 ? 4 : (fp8 ? 1 : 2));
+            ma.group_tiles = (uint32_t)std::max<size_t>(1, std::min<size_t>(ma.nr_tiles, (64u << 20) / ((size_t)kBN * row_bytes)));
+            const uint32_t groups = (ma.nr_tiles + ma.group_tiles - 1) / ma.group_tiles;
+            const dim3 grid(groups * ma.group_tiles * ma.nq_tiles);
 #define HVX_FM(KIND)                                                                                                              \
     do {                                                                                                                          \
         if (full) { if (filtered) hipLaunchKernelGGL((flat_mfma_bf16_kernel<KIND, true, true>), grid, dim3(256), 0, ix->stream, ma);   \

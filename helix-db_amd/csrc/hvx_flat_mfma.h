@@ -1,0 +1,47 @@
+// hvx_flat_mfma.h -- launch interface shared by the two contraction kernels of the matrix-core exact scan
+// (hvx_flat_mfma.hip: 128 x 128 tiles, writes the score matrix or filters; hvx_flat_tile.hip: 256 x 256 tiles, filters only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hvx {
+
+struct MfmaArgs {
+    const uint16_t *qhi, *qlo; // [bpad][dim]
+    const uint32_t *subset;    // optional: scan position -> row (restricted scans); NULL = the rows themselves
+    const void *rows;          // [n][dim] bf16, or fp8 codes
+    const float *rowscale;     // [n] fp8 only
+    const float *rowterm;      // [n]: |x|^2 (L2) or |x| (cosine)
+    const float *qn2;          // [b]
+    uint32_t dim, b, row0, nrows, metric;
+    float *dist;               // [b][chunk_ld]
+    uint32_t chunk_ld;
+    // FILT launches: only scores below the query's running threshold leave the tile, as (score, row) pairs
+    const float *thr;          // [b] approximate score of the (m+1)-th candidate so far (+inf while fewer are known)
+    float *cand_sc;            // [b][cand_cap]
+    uint32_t *cand_id;         // [b][cand_cap] internal ids
+    uint32_t *cand_cnt;        // [b] pairs appended (may exceed cand_cap: overflow, detected by the merge)
+    uint32_t cand_cap;
+    // 1-D launch: workgroup id -> (row tile, query tile).  Rows are walked in groups of `group_tiles` row tiles (~64 MB of
+    // rows: they stay in the Infinity Cache), inside a group the QUERY tile is the outer loop: a query tile's 128 x dim
+    // operand stays in L2 while the group's row tiles stream past it, and the group's rows come from HBM once.
+    uint32_t nq_tiles, nr_tiles, group_tiles;
+    // 256 x 256 kernel: XCD-aware super-tiles (hvx_flat_tile.hip)
+    uint32_t sup_q, sup_r, sup_qblocks;
+};
+
+// 256 x 256 filtered contraction (hvx_flat_tile.hip).  kind: 0 = bf16 rows (a bf16 index, or the bf16 shadow of an f32
+// index; a.rows in the order a.qhi uses), 1 = fp8 codes (a.qhi in tile order, see tile_slot_fp8).  a.dim % 64 == 0.
+// `wg_overflow` is set when a workgroup's pair list overflowed (the caller repeats the scan unfiltered).
+hipError_t launch_flat_tile256(const MfmaArgs &a, int kind, uint32_t bpad, float xmax2, uint32_t *wg_overflow, hipStream_t s);
+
+// position of stored code `slot` (its index in the fp8 row) in the query operand of the 256 x 256 fp8 kernel: inside a
+// 64-code stage, MFMA step kk (0..3), lane half h, element e read code (2 (kk >> 1) + h) * 16 + (kk & 1) * 8 + e, so one
+// ds_read_b128 of the code tile feeds two steps.
+__host__ __device__ inline uint32_t tile_slot_fp8(uint32_t slot) {
+    const uint32_t c = slot & 63u, u = c >> 4, sb = (c >> 3) & 1u, e = c & 7u;
+    const uint32_t kk = (u >> 1) * 2u + sb, h = u & 1u;
+    return (slot & ~63u) + kk * 16u + h * 8u + e;
+}
+
+} // namespace hvx

@@ -25,6 +25,7 @@
 
 #include "hvx_hnsw_wave.h"
 #include "hvx_host.h"
+#include "hvx_flat_mfma.h"
 
 using namespace hvx;
 
@@ -55,9 +56,19 @@ __global__ __launch_bounds__(64) void bf16_row_norm2_kernel(const uint16_t *rows
     if (threadIdx.x == 0) out[r] = (float)acc;
 }
 
+// ---- bf16 shadow of f32 rows (plain element order): what the 256 x 256 kernel streams instead of the f32 rows ----
+__global__ __launch_bounds__(256) void bf16_shadow_kernel(const float *rows, size_t count4, uint16_t *out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count4; i += (size_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4 *>(rows)[i];
+        const uint32_t a = f32_to_bf16_rne(v.x), b = f32_to_bf16_rne(v.y), c = f32_to_bf16_rne(v.z), d = f32_to_bf16_rne(v.w);
+        reinterpret_cast<uint2 *>(out)[i] = make_uint2(a | (b << 16), c | (d << 16));
+    }
+}
+
 // ---- queries: f32 -> bf16 hi + lo in the interleaved layout, padded with zero rows; |q|^2 ----
 __global__ __launch_bounds__(64) void split_queries_kernel(const float *q, uint32_t b, uint32_t bpad, uint32_t dim,
-                                                           uint16_t *qhi, uint16_t *qlo, float *qn2, uint32_t fp8_layout) {
+                                                           uint16_t *qhi, uint16_t *qlo, float *qn2, uint32_t fp8_layout,
+                                                           uint16_t *qhi_tile8) {
     const uint32_t r = blockIdx.x;
     if (r >= bpad) return;
     double acc = 0.0;
@@ -69,6 +80,7 @@ __global__ __launch_bounds__(64) void split_queries_kernel(const float *q, uint3
         const uint32_t s = fp8_layout == 2u ? i : (fp8_layout ? fp8_slot_of(i) : bf16_slot_of(i)); // 2: f32 rows, plain order
         qhi[(size_t)r * dim + s] = h;
         qlo[(size_t)r * dim + s] = f32_to_bf16_rne(res);
+        if (qhi_tile8) qhi_tile8[(size_t)r * dim + tile_slot_fp8(s)] = h; // operand order of the 256 x 256 fp8 kernel
         acc += (double)v * (double)v;
     }
     for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s, 64);
@@ -79,27 +91,6 @@ __global__ __launch_bounds__(64) void split_queries_kernel(const float *q, uint3
 constexpr int kBM = 128, kBN = 128, kBK = 32; // queries x rows x depth per stage
 constexpr int kLdsStride = kBK * 2 + 16;      // bytes per tile row: 64 B of data + 16 B pad => conflict-free ds_read_b128
 
-struct MfmaArgs {
-    const uint16_t *qhi, *qlo; // [bpad][dim]
-    const uint32_t *subset;    // optional: scan position -> row (restricted scans); NULL = the rows themselves
-    const void *rows;          // [n][dim] bf16, or fp8 codes
-    const float *rowscale;     // [n] fp8 only
-    const float *rowterm;      // [n]: |x|^2 (L2) or |x| (cosine)
-    const float *qn2;          // [b]
-    uint32_t dim, b, row0, nrows, metric;
-    float *dist;               // [b][chunk_ld]
-    uint32_t chunk_ld;
-    // FILT launches: only scores below the query's running threshold leave the tile, as (score, row) pairs
-    const float *thr;          // [b] approximate score of the (m+1)-th candidate so far (+inf while fewer are known)
-    float *cand_sc;            // [b][cand_cap]
-    uint32_t *cand_id;         // [b][cand_cap] internal ids
-    uint32_t *cand_cnt;        // [b] pairs appended (may exceed cand_cap: overflow, detected by the merge)
-    uint32_t cand_cap;
-    // 1-D launch: workgroup id -> (row tile, query tile).  Rows are walked in groups of `group_tiles` row tiles (~64 MB of
-    // rows: they stay in the Infinity Cache), inside a group the QUERY tile is the outer loop: a query tile's 128 x dim
-    // operand stays in L2 while the group's row tiles stream past it, and the group's rows come from HBM once.
-    uint32_t nq_tiles, nr_tiles, group_tiles;
-};
 
 // KIND: 0 = bf16 rows, 1 = fp8 rows, 2 = f32 rows (split into bf16 hi + lo on the way into LDS: acc += q_hi.x_hi +
 // q_lo.x_hi + q_hi.x_lo; the dropped q_lo.x_lo term is <= 2^-16 |q||x| and is covered by the certificate's bound).
@@ -547,6 +538,25 @@ int flat_mfma_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t
     return flat_mfma_impl(ix, d_queries, b, k, d_subset, n_rows, d_ids, d_scores, d_counts, d_status, timed, true);
 }
 
+// bf16 shadow of an f32 index's rows (plain order, RNE: the values the one-pass contraction rounds to anyway): built once per
+// index by the first scan that reaches a filtered slice; +50 % of the row bytes, so an index that cannot afford it stays on
+// the 128 x 128 kernel (which splits the f32 rows on the fly)
+static int ensure_shadow(hvx_index *ix) {
+    const DevIndex &d = ix->dev;
+    if (ix->m_shadow || ix->m_shadow_failed) return HVX_OK;
+    void *p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>((size_t)d.n * d.dim * 2, 16)) != hipSuccess) {
+        (void)hipGetLastError();
+        ix->m_shadow_failed = true;
+        return HVX_OK;
+    }
+    ix->allocs->v.push_back(p);
+    ix->m_shadow = reinterpret_cast<uint16_t *>(p);
+    hipLaunchKernelGGL(bf16_shadow_kernel, dim3(2048), dim3(256), 0, ix->stream, d.vec, (size_t)d.n * d.dim / 4, ix->m_shadow);
+    HIP_TRY(hipGetLastError());
+    return HVX_OK;
+}
+
 static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, const uint32_t *d_subset, uint32_t n_rows,
                           uint64_t *d_ids, float *d_scores, uint32_t *d_counts, uint32_t *d_status, bool timed, bool allow_filter) {
     const DevIndex &d = ix->dev;
@@ -566,16 +576,19 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
         if (d_status) HIP_TRY(hipMemcpyAsync(d_status, ix->d_qstatus, (size_t)b * 4, hipMemcpyDeviceToDevice, ix->stream));
         return HVX_OK;
     }
-    const uint32_t bpad = (b + kBM - 1) / kBM * kBM;
+    const uint32_t bpad = (b + 255u) / 256u * 256u; // a multiple of both kernels' query tiles (128 and 256)
     int rc;
+    const bool fp8 = d.dtype == HVX_FP8_E4M3, f32 = d.dtype == HVX_F32;
     if ((size_t)bpad * d.dim > ix->cap_qsplit) {
         if ((rc = ix->regrow((void **)&ix->m_qhi, (size_t)bpad * d.dim * 2))) return rc;
         if ((rc = ix->regrow((void **)&ix->m_qlo, (size_t)bpad * d.dim * 2))) return rc;
+        if (fp8 && (rc = ix->regrow((void **)&ix->m_qhi8, (size_t)bpad * d.dim * 2))) return rc;
         if ((rc = ix->regrow((void **)&ix->m_qn2, (size_t)bpad * 4))) return rc;
         if ((rc = ix->regrow((void **)&ix->m_cert, (size_t)bpad * 4))) return rc;
         ix->cap_qsplit = (size_t)bpad * d.dim;
     }
-    const bool fp8 = d.dtype == HVX_FP8_E4M3, f32 = d.dtype == HVX_F32;
+    // the 256 x 256 filtered contraction (hvx_flat_tile.hip) serves the one-pass attempt of scans with dim % 64 == 0
+    const bool tile_ok = d.dim % 64u == 0u && getenv("HVX_FLAT_NO_TILE") == nullptr;
     if (f32 && !ix->m_rowterm) { // |x|^2 per row and its maximum: once per index, on first use
         if ((rc = ix->dalloc((void **)&ix->m_rowterm, std::max<size_t>(d.n, 1) * 4))) return rc;
         std::vector<float> h_n2(d.n);
@@ -586,7 +599,7 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
         for (float v : h_n2) ix->m_xmax2 = std::max(ix->m_xmax2, v);
     }
     hipLaunchKernelGGL(split_queries_kernel, dim3(bpad), dim3(64), 0, ix->stream, d_queries, b, bpad, d.dim, ix->m_qhi, ix->m_qlo, ix->m_qn2,
-                       f32 ? 2u : (fp8 ? 1u : 0u));
+                       f32 ? 2u : (fp8 ? 1u : 0u), fp8 && tile_ok ? ix->m_qhi8 : nullptr);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ix->ev0, ix->stream));
     // Attempts, cheapest first; a query whose certificate is not reached sends the batch to the next one:
@@ -605,6 +618,7 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
         if (attempt == 2 && m0 >= 1023u) break;
         const uint32_t kc = m + 1;
         uint32_t chunk = 65536;
+        if (const char *e = getenv("HVX_FLAT_CHUNK")) chunk = std::max<uint32_t>(1024u, (uint32_t)atoi(e) / 1024u * 1024u); // tests: small first chunks
         while ((size_t)chunk * b * 4 > (512u << 20) && chunk > 1024) chunk >>= 1;
         if (chunk > n) chunk = (n + 3u) & ~3u;
         if ((rc = ix->flat_scratch(b, kc, chunk))) return rc;
@@ -653,11 +667,21 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
         pm.cand_cnt = ix->m_ccnt; pm.thr = ix->m_thr; pm.overflow = ix->m_ccnt ? ix->m_ccnt + bpad : nullptr; pm.qstatus = ix->d_qstatus;
         pm.kc = kc; pm.cap = kCandCap;
         uint32_t r0 = 0;
+        bool used_tile = false;
         while (r0 < n) {
             if (filt && r0 > 0) {
                 // thresholds are those of the rows seen so far: a slice three times that long lets ~3 (m + 1) pairs per query through
                 const uint32_t rows = (uint32_t)std::min<uint64_t>((uint64_t)n - r0, (uint64_t)r0 * 3u);
-                HIP_TRY(contraction(r0, rows, true));
+                if (!full && tile_ok && f32 && (rc = ensure_shadow(ix))) return rc;
+                if (!full && tile_ok && (!f32 || ix->m_shadow)) { // one-pass attempt: the 256 x 256 kernel
+                    MfmaArgs ta = ma;
+                    ta.row0 = r0; ta.nrows = rows;
+                    if (f32) ta.rows = ix->m_shadow;
+                    if (fp8) ta.qhi = ix->m_qhi8;
+                    HIP_TRY(launch_flat_tile256(ta, fp8 ? 1 : 0, bpad, ix->m_xmax2, pm.overflow, ix->stream));
+                    used_tile = true;
+                } else
+                    HIP_TRY(contraction(r0, rows, true));
                 hipLaunchKernelGGL(flat_merge_pairs_kernel, dim3(b), dim3(256), 0, ix->stream, pm);
                 HIP_TRY(hipGetLastError());
                 r0 += rows;
@@ -692,8 +716,9 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
         for (uint32_t i = 0; i < b; ++i)
             if (!cert[i]) { if (!failed) first = i; ++failed; }
         if (debug)
-            fprintf(stderr, "[hvx flat] attempt %d (%s contraction, m = %u%s): %u of %u certificates missing%s\n", attempt,
-                    full ? "full" : "one-pass", m, filt ? ", filtered epilogue" : "", failed, b, overflow ? ", PAIR OVERFLOW" : "");
+            fprintf(stderr, "[hvx flat] attempt %d (%s contraction, m = %u%s%s): %u of %u certificates missing%s\n", attempt,
+                    full ? "full" : "one-pass", m, filt ? ", filtered epilogue" : "", used_tile ? ", 256 x 256 tiles" : "", failed, b,
+                    overflow ? ", PAIR OVERFLOW" : "");
         if (overflow) { // a query produced more pairs than the buffer holds: its list is incomplete -- never guess
             return flat_mfma_impl(ix, d_queries, b, k, d_subset, n_rows, d_ids, d_scores, d_counts, d_status, timed, false);
         }

@@ -1,0 +1,284 @@
+// hvx_flat_tile.hip -- the 256 x 256 contraction kernel of the matrix-core exact scan (BASELINE configs #4 / #5 and the
+// f32 exact scan): candidate generation for restricted_exact_scan (crates/db/src/search/vector/restricted.rs:753-835), see
+// the pipeline description at the top of hvx_flat_mfma.hip.  This kernel only FILTERS: a score leaves the tile when it is
+// below the query's running threshold, as a (score, row) pair; the first chunk of a scan (which has no threshold yet) and
+// the repeat passes stay on the 128 x 128 kernel.
+//
+// Structure (gfx950): 512 threads = 8 wavefronts as 2 (queries) x 4 (rows), each wavefront owns 128 queries x 64 rows =
+// 4 x 2 accumulators of v_mfma_f32_32x32x16_bf16 (128 registers).  A stage is 64 deep: 256 x 128 B of query values (bf16)
+// + 256 x 128 B of bf16 rows (or 256 x 64 B of fp8 codes), copied HBM/L2 -> LDS by global_load_lds_dwordx4 (no registers,
+// no ds_write pass), two LDS buffers, one barrier per stage: stage s+1 lands while stage s is multiplied.  The LDS image
+// is lane-linear per wave instruction (1 KB = 8 tile rows x 128 B, or 16 x 64 B), so the XOR swizzle that makes the
+// fragment reads (ds_read_b128, lane = tile row) conflict-free is applied to the SOURCE address and again to the read
+// address: 128-B rows: 16-B slot ^ ((row >> 1) & 7); 64-B rows: slot ^ ((row >> 2) & 3).
+// fp8 codes are widened to bf16 (exactly) in registers between the ds_read and the MFMA: v_cvt_pk_f32_fp8 + v_perm.
+//
+// Epilogue: score < threshold is tested in the accumulator's own units -- fma(acc, alpha_row, -beta_row) > h_query with a
+// conservative margin -- 2 VALU operations per score; the rare survivors are pushed to a workgroup list in LDS and
+// finished (exact score formula, exact `s < thr` test of the 128 x 128 kernel, global append) by the first threads.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "hvx_device.h"
+#include "hvx_flat_mfma.h"
+
+namespace hvx {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+constexpr int kTM = 256, kTN = 256;      // queries x rows per workgroup
+constexpr int kAStage = kTM * 128;       // bytes of query values per stage (64 bf16 per tile row)
+constexpr int kWgList = 2048;            // survivors a workgroup can hold
+
+#define HVX_GLDS16(gptr, lptr)                                                                                       \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),                          \
+                                     (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
+
+// KIND 0: bf16 rows, 1: fp8 codes.  PIPE: pin the fragment reads of step kk + 1 ahead of the MFMAs of step kk (the
+// compiler otherwise sinks them next to their use and waits for every read pair).
+template <int KIND, bool PIPE>
+__global__ __launch_bounds__(512) void flat_tile256_kernel(MfmaArgs a, float xmax2, uint32_t *wg_overflow) {
+    constexpr bool FP8 = KIND == 1;
+    constexpr int ROWB = FP8 ? 64 : 128;            // bytes of one row per stage
+    constexpr int BSTAGE = kTN * ROWB;
+    constexpr int STAGE = kAStage + BSTAGE;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    // workgroup -> tile, XCD-aware (workgroup b runs on XCD b % 8, every XCD has its own 4 MB L2): the 32 workgroups an XCD
+    // runs at a time form a super-tile of sup_r row tiles x sup_q query tiles, so each operand tile is fetched into that L2
+    // once per super-tile and shared; the query blocks of one row block follow each other (the rows come from HBM once).
+    uint32_t qt, rt;
+    {
+        const uint32_t x = blockIdx.x & 7u, l = blockIdx.x >> 3;
+        const uint32_t rq = a.sup_r * a.sup_q, per_rblock = a.sup_qblocks * rq;
+        const uint32_t rblock = l / per_rblock, rem = l % per_rblock;
+        const uint32_t qblock = rem / rq, rem2 = rem % rq;
+        rt = (rblock * a.sup_r + rem2 / a.sup_q) * 8u + x;
+        qt = qblock * a.sup_q + rem2 % a.sup_q;
+        if (rt >= a.nr_tiles || qt >= a.nq_tiles) return;
+    }
+    const uint32_t q0 = qt * kTM, r0 = rt * kTN;
+
+    // ---- staging addresses.  Query values: wave w copies tile rows 32 w .. 32 w + 31 as four 1-KB pieces (8 rows each);
+    // lane l of piece t lands on row 32 w + 8 t + (l >> 3), physical 16-B slot l & 7, and fetches the logical slot
+    // (l & 7) ^ ((row >> 1) & 7) of that row.
+    const unsigned char *gA[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const uint32_t row = (uint32_t)(32 * wave + 8 * t + (lane >> 3));
+        const uint32_t slot = (uint32_t)(lane & 7) ^ ((row >> 1) & 7u);
+        gA[t] = reinterpret_cast<const unsigned char *>(a.qhi) + (size_t)(q0 + row) * a.dim * 2 + slot * 16; // queries are padded to 256
+    }
+    constexpr int NB = FP8 ? 2 : 4; // 1-KB pieces of the row tile per wave and stage
+    const unsigned char *gB[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+        uint32_t row, slot;
+        if (FP8) { // 16 rows x 64 B per piece
+            row = (uint32_t)(32 * wave + 16 * t + (lane >> 2));
+            slot = (uint32_t)(lane & 3) ^ ((row >> 2) & 3u);
+        } else {
+            row = (uint32_t)(32 * wave + 8 * t + (lane >> 3));
+            slot = (uint32_t)(lane & 7) ^ ((row >> 1) & 7u);
+        }
+        uint32_t rloc = r0 + row;
+        if (rloc >= a.nrows) rloc = a.nrows - 1; // clamp: the duplicate is masked in the epilogue
+        const size_t node = a.subset ? a.subset[a.row0 + rloc] : (size_t)a.row0 + rloc;
+        gB[t] = reinterpret_cast<const unsigned char *>(a.rows) + node * a.dim * (FP8 ? 1 : 2) + slot * 16;
+    }
+    auto issue_stage = [&](uint32_t kbyteA, uint32_t kbyteB, int buf) {
+        unsigned char *sA = lds + buf * STAGE + wave * 4096;          // 32 rows x 128 B of this wave
+        unsigned char *sB = lds + buf * STAGE + kAStage + wave * (32 * ROWB);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) HVX_GLDS16(gA[t] + kbyteA, sA + t * 1024);
+#pragma unroll
+        for (int t = 0; t < NB; ++t) HVX_GLDS16(gB[t] + kbyteB, sB + t * 1024);
+    };
+
+    // ---- fragment read offsets: lane = tile row fr of the 32-row block, depth half h
+    const int fr = lane & 31, h = lane >> 5;
+    int offA[4]; // per step kk: 16-B slot (2 kk + h) ^ ((fr >> 1) & 7) of row fr (the row's block offset is added as an immediate)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) offA[kk] = fr * 128 + (((2 * kk + h) ^ ((fr >> 1) & 7)) << 4);
+    int offB8[2]; // fp8: per step pair: slot (2 jj + h) ^ ((fr >> 2) & 3) of the 64-B row
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) offB8[jj] = fr * 64 + (((2 * jj + h) ^ ((fr >> 2) & 3)) << 4);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const uint32_t nstage = a.dim >> 6;
+    issue_stage(0, 0, 0);
+    for (uint32_t s = 0; s < nstage; ++s) {
+        const int buf = (int)(s & 1u);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces of stage s have landed ...
+        __syncthreads();                                  // ... everyone's have, and buffer buf ^ 1 is no longer being read
+        if (s + 1 < nstage) issue_stage((s + 1) * 128u, (s + 1) * (uint32_t)ROWB, buf ^ 1);
+        const unsigned char *sA = lds + buf * STAGE + wm * (128 * 128);
+        const unsigned char *sB = lds + buf * STAGE + kAStage + wn * (64 * ROWB);
+        // fragments of step kk + 1 are read (fp8: and widened) while the matrix core works on step kk
+        uint4 c8[2]; // fp8: the codes of both steps of a pair
+        auto load_frags = [&](int kk, bf16x8 (&fa)[4], bf16x8 (&fb)[2]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sA + i * 4096 + offA[kk]));
+            if (FP8) {
+                if ((kk & 1) == 0) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) c8[j] = *reinterpret_cast<const uint4 *>(sB + j * (32 * 64) + offB8[kk >> 1]);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const uint32_t w0 = (kk & 1) ? c8[j].z : c8[j].x, w1 = (kk & 1) ? c8[j].w : c8[j].y;
+                    // 4 codes -> 4 f32 (exact) -> their high halves = 4 bf16 (exact)
+                    const f32x2 a01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w0, false), a23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w0, true);
+                    const f32x2 b01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w1, false), b23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w1, true);
+                    uint4 wv;
+                    wv.x = __builtin_amdgcn_perm(__float_as_uint(a01[1]), __float_as_uint(a01[0]), 0x07060302u);
+                    wv.y = __builtin_amdgcn_perm(__float_as_uint(a23[1]), __float_as_uint(a23[0]), 0x07060302u);
+                    wv.z = __builtin_amdgcn_perm(__float_as_uint(b01[1]), __float_as_uint(b01[0]), 0x07060302u);
+                    wv.w = __builtin_amdgcn_perm(__float_as_uint(b23[1]), __float_as_uint(b23[0]), 0x07060302u);
+                    fb[j] = __builtin_bit_cast(bf16x8, wv);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sB + j * 4096 + offA[kk]));
+            }
+        };
+        bf16x8 fa0[4], fb0[2], fa1[4], fb1[2];
+        load_frags(0, fa0, fb0);
+#pragma unroll
+        for (int kk = 0; kk < 4; kk += 2) {
+            load_frags(kk + 1, fa1, fb1);
+            if (PIPE) __builtin_amdgcn_sched_barrier(0); // keep the reads of the next step ahead of this step's MFMAs
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[i], fb0[j], acc[i][j], 0, 0, 0);
+            if (PIPE) __builtin_amdgcn_sched_barrier(0);
+            if (kk + 2 < 4) load_frags(kk + 2, fa0, fb0);
+            if (PIPE) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[i], fb1[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue.  C[m = query][n = row]: lane holds n = lane & 31, m = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+    __syncthreads(); // the stage buffers are free
+    float *sH = reinterpret_cast<float *>(lds);                      // [256] per-query pass level
+    uint32_t *sCnt = reinterpret_cast<uint32_t *>(lds + 1024);       // [1] survivors of this workgroup
+    float *sLv = reinterpret_cast<float *>(lds + 2048);              // [kWgList] accumulator value
+    uint32_t *sLc = reinterpret_cast<uint32_t *>(lds + 2048 + kWgList * 4); // [kWgList] (query << 8) | row, tile-local
+    const float inf = __uint_as_float(0x7F800000u);
+    if (tid < kTM) {
+        const uint32_t qq = q0 + (uint32_t)tid;
+        float hq = inf; // padded query rows let nothing through
+        if (qq < a.b) {
+            const float t = a.thr[qq], n2 = a.qn2[qq];
+            // s < t  <=>  dot - |x|^2/2 > (|q|^2 - t)/2 (L2)   resp.   dot / |x| > (1 - 2t) |q| (cosine), up to the rounding of
+            // the two evaluation orders: the margin lets a few more in, the exact test below decides
+            if (a.metric == kL2) hq = 0.5f * (n2 - t) - 4e-6f * (n2 + xmax2);
+            else { const float qn = sqrtf(n2); hq = (1.0f - 2.0f * t) * qn - 8e-6f * qn; }
+        }
+        sH[tid] = hq;
+    }
+    if (tid == 0) *sCnt = 0u;
+    float alpha[2], nbeta[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint32_t rloc = r0 + (uint32_t)(wn * 64 + j * 32 + fr);
+        alpha[j] = 0.f;
+        nbeta[j] = -inf; // rows past the end of the scan never pass
+        if (rloc < a.nrows) {
+            const size_t node = a.subset ? a.subset[a.row0 + rloc] : (size_t)a.row0 + rloc;
+            const float term = a.rowterm[node];
+            const float rsc = FP8 ? a.rowscale[node] : 1.0f;
+            if (a.metric == kL2) { alpha[j] = rsc; nbeta[j] = -0.5f * term; }
+            else { alpha[j] = term > 0.f ? rsc / term : 0.f; nbeta[j] = 0.f; }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h; // tile-local query
+            const float hq = sH[m];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (__builtin_fmaf(acc[i][j][e], alpha[j], nbeta[j]) > hq) {
+                    const uint32_t pos = atomicAdd(sCnt, 1u);
+                    if (pos < (uint32_t)kWgList) {
+                        sLv[pos] = acc[i][j][e];
+                        sLc[pos] = ((uint32_t)m << 8) | (uint32_t)(wn * 64 + j * 32 + fr);
+                    }
+                }
+            }
+        }
+    __syncthreads();
+    uint32_t cnt = *sCnt;
+    if (cnt > (uint32_t)kWgList) { // more survivors than the list holds: the scan is repeated unfiltered, never guessed
+        if (tid == 0) atomicOr(wg_overflow, 1u);
+        cnt = kWgList;
+    }
+    for (uint32_t t = (uint32_t)tid; t < cnt; t += 512u) {
+        const uint32_t code = sLc[t];
+        const uint32_t qq = q0 + (code >> 8), rloc = r0 + (code & 255u);
+        if (qq >= a.b || rloc >= a.nrows) continue;
+        const size_t node = a.subset ? a.subset[a.row0 + rloc] : (size_t)a.row0 + rloc;
+        const float term = a.rowterm[node];
+        const float dot = FP8 ? sLv[t] * a.rowscale[node] : sLv[t];
+        float sc;
+        if (a.metric == kL2) {
+            sc = (a.qn2[qq] + term) - 2.0f * dot;
+            sc = sc < 0.f ? 0.f : sc;
+        } else {
+            const float den = sqrtf(a.qn2[qq]) * term;
+            float c = den > 0.f ? dot / den : 0.f;
+            c = c < -1.f ? -1.f : (c > 1.f ? 1.f : c);
+            sc = (1.0f - c) * 0.5f;
+        }
+        if (sc < a.thr[qq]) {
+            const uint32_t pos = atomicAdd(&a.cand_cnt[qq], 1u);
+            if (pos < a.cand_cap) {
+                a.cand_sc[(size_t)qq * a.cand_cap + pos] = sc;
+                a.cand_id[(size_t)qq * a.cand_cap + pos] = (uint32_t)node;
+            }
+        }
+    }
+}
+
+hipError_t launch_flat_tile256(const MfmaArgs &a, int kind, uint32_t bpad, float xmax2, uint32_t *wg_overflow, hipStream_t s) {
+    if (a.nrows == 0) return hipSuccess;
+    if (a.dim % 64u != 0u || bpad % (uint32_t)kTM != 0u) return hipErrorInvalidValue;
+    MfmaArgs t = a;
+    t.nq_tiles = bpad / kTM;
+    t.nr_tiles = (a.nrows + kTN - 1) / kTN;
+    t.sup_q = std::min<uint32_t>(t.nq_tiles, 8u);
+    t.sup_r = 32u / t.sup_q;
+    t.sup_qblocks = (t.nq_tiles + t.sup_q - 1) / t.sup_q;
+    const uint32_t rblocks = (t.nr_tiles + 8u * t.sup_r - 1) / (8u * t.sup_r);
+    const dim3 grid(8u * rblocks * t.sup_qblocks * t.sup_r * t.sup_q);
+    static const bool pipe = [] { const char *e = getenv("HVX_FLAT_TILE_PIPE"); return !e || e[0] != '0'; }();
+    if (kind == 1) {
+        if (pipe) hipLaunchKernelGGL((flat_tile256_kernel<1, true>), grid, dim3(512), 0, s, t, xmax2, wg_overflow);
+        else hipLaunchKernelGGL((flat_tile256_kernel<1, false>), grid, dim3(512), 0, s, t, xmax2, wg_overflow);
+    } else {
+        if (pipe) hipLaunchKernelGGL((flat_tile256_kernel<0, true>), grid, dim3(512), 0, s, t, xmax2, wg_overflow);
+        else hipLaunchKernelGGL((flat_tile256_kernel<0, false>), grid, dim3(512), 0, s, t, xmax2, wg_overflow);
+    }
+    return hipGetLastError();
+}
+
+} // namespace hvx

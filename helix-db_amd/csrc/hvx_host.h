@@ -71,6 +71,9 @@ struct hvx_index {
     uint32_t cap_topc = 0;
     // bf16 exact scan on the matrix cores (hvx_flat_mfma.hip)
     uint16_t *m_qhi = nullptr, *m_qlo = nullptr;
+    uint16_t *m_qhi8 = nullptr;      // fp8 rows: the hi parts again, in the operand order of the 256 x 256 kernel (hvx_flat_tile.hip)
+    uint16_t *m_shadow = nullptr;    // f32 rows: bf16 (RNE) shadow of the rows for the 256 x 256 kernel, built on first use
+    bool m_shadow_failed = false;    // ... no memory for it: stay on the 128 x 128 kernel
     float *m_qn2 = nullptr, *m_rowterm = nullptr; // |q|^2 per query; |x|^2 per row
     uint32_t *m_cert = nullptr;
     // filtered-epilogue pipeline: running thresholds and the (score, row) pairs a filtered launch lets through

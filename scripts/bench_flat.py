@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--dim", type=int, default=1536)
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--dtype", default="fp8", choices=["fp8", "bf16"])
+    ap.add_argument("--dtype", default="fp8", choices=["fp8", "bf16", "f32"])
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--recall-queries", type=int, default=64)
     args = ap.parse_args()
@@ -32,7 +32,7 @@ def main():
     t1 = time.time()
     ix = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=hv.EUCLIDEAN, node_ids=np.arange(n, dtype=np.uint64), vectors=x,
                                              l0_offsets=np.zeros(n + 1, np.uint64), l0_neighbors=np.zeros(0, np.uint64),
-                                             max_batch=b, dtype=hv.FP8_E4M3 if args.dtype == "fp8" else hv.BF16)
+                                             max_batch=b, dtype={"fp8": hv.FP8_E4M3, "bf16": hv.BF16, "f32": hv.F32}[args.dtype])
     print(f"[flat] corpus {n}x{dim} generated in {t1 - t0:.1f}s, imported as {args.dtype} in {time.time() - t1:.1f}s", file=sys.stderr)
     ids = torch.zeros(b, k, dtype=torch.int64, device=dev); sc = torch.zeros(b, k, device=dev)
     cnt = torch.zeros(b, dtype=torch.int32, device=dev); st = torch.zeros(b, dtype=torch.int32, device=dev)
@@ -49,7 +49,7 @@ def main():
     got = ids[:rq].cpu().numpy()
     recall = sum(len(set(got[i].tolist()) & set(truth[i].tolist())) for i in range(rq)) / float(rq * k)
     useful = 2.0 * b * n * dim
-    elem = 1 if args.dtype == "fp8" else 2
+    elem = {"fp8": 1, "bf16": 2, "f32": 4}[args.dtype]
     print(json.dumps({
         "workload": f"configs[4] per-GPU shard: exact scan, {n}x{dim} {args.dtype} rows, batch {b}, k={k}, squared-L2",
         "ms_per_batch": round(ms, 3), "queries_per_s": round(b / ms * 1e3, 1),

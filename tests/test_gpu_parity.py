@@ -1092,6 +1092,74 @@ def test_large_restricted_scan_over_f32_rows_takes_the_matrix_cores(orc, hv, mon
         assert allowed[oid.astype(np.int64)].tolist() == gid[qi].tolist() and bits(osc).tolist() == bits(gsc[qi]).tolist()
 
 
+# --- the 256 x 256 filtered contraction kernel (hvx_flat_tile.hip) ---
+TILE_CASES = [("bf16", 1, 768, 30000, 10, 300), ("bf16", 0, 256, 20001, 25, 70), ("fp8", 1, 1536, 12000, 10, 130),
+              ("fp8", 0, 128, 20000, 10, 257), ("f32", 1, 512, 40000, 10, 512), ("f32", 0, 768, 30000, 100, 400)]
+
+
+@pytest.mark.parametrize("dtype_name,metric,dim,n,k,b", TILE_CASES)
+def test_exact_scan_through_the_256_tile_kernel(orc, hv, monkeypatch, capfd, dtype_name, metric, dim, n, k, b):
+    """Every slice after the first chunk of an exact scan runs on the 256 x 256 filtered kernel (global_load_lds staging,
+    swizzled LDS image, fp8 codes widened in registers, f32 rows through their bf16 shadow).  With 2 048-row first chunks
+    a small corpus takes several slices (ragged last row tile, padded query tile); the answer must equal the 128 x 128
+    kernel's and the oracle's exact scan over the stored values, ids and score bits."""
+    rng = np.random.default_rng(7000 + dim + n)
+    centers = rng.standard_normal((32, dim)).astype(np.float32)
+    data = (centers[rng.integers(0, 32, n)] + 0.5 * rng.standard_normal((n, dim))).astype(np.float32)
+    if dtype_name == "fp8":
+        data *= rng.uniform(0.2, 3.0, (n, 1)).astype(np.float32)
+    data[n - 5] = data[3]                                             # a duplicate in the last (ragged) row tile
+    stored = {"bf16": fx.round_bf16, "fp8": fx.quantize_fp8_rows, "f32": lambda x: x}[dtype_name](data)
+    dt = {"bf16": hv.BF16, "fp8": hv.FP8_E4M3, "f32": hv.F32}[dtype_name]
+    ids = np.arange(n, dtype=np.uint64) + 11
+    gix = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=metric, node_ids=ids, vectors=data, dtype=dt,
+                                              l0_offsets=np.zeros(n + 1, np.uint64), l0_neighbors=np.zeros(0, np.uint64), max_batch=b)
+    q = (centers[rng.integers(0, 32, b)] + 0.5 * rng.standard_normal((b, dim))).astype(np.float32)
+    q[0] = data[3]
+    q[b - 1, 5] = np.nan                                              # a rejected query in the padded query tile
+    monkeypatch.setenv("HVX_FLAT_CHUNK", "2048")
+    monkeypatch.setenv("HVX_FLAT_DEBUG", "1")
+    capfd.readouterr()
+    gid, gsc, gcnt, _ = gix.flat_search_batch(q, k)
+    err = capfd.readouterr().err
+    assert "256 x 256 tiles" in err, err                              # the kernel ran
+    monkeypatch.setenv("HVX_FLAT_NO_TILE", "1")
+    oid_, osc_, ocnt_, _ = gix.flat_search_batch(q, k)
+    assert "256 x 256" not in capfd.readouterr().err
+    assert gid.tolist() == oid_.tolist() and bits(gsc).tolist() == bits(osc_).tolist() and gcnt.tolist() == ocnt_.tolist()
+    assert gcnt[b - 1] == 0 and gcnt[0] == k
+    kern = orc.K_AVX_FMA_HW if dtype_name == "f32" else None
+    for qi in list(range(0, b - 1, max(1, b // 16))) + [b - 2]:
+        rc, oid, osc = orc.flat_matrix(metric, stored, q[qi], k, **({"kernel": kern} if kern is not None else {}))
+        assert rc == orc.OK and (gid[qi, :gcnt[qi]] - 11).tolist() == oid.tolist(), f"query {qi}"
+        assert bits(gsc[qi, :gcnt[qi]]).tolist() == bits(osc).tolist()
+    assert sorted((gid[0, :2] - 11).tolist()) == [3, n - 5]
+
+
+def test_restricted_scan_through_the_256_tile_kernel(orc, hv, monkeypatch, capfd):
+    """The 256 x 256 kernel gathers its row tile through the candidate row list (restricted scans over bf16 rows)."""
+    rng = np.random.default_rng(71)
+    n, dim, b, k = 40000, 256, 100, 10
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    stored = fx.round_bf16(data)
+    ids = np.arange(n, dtype=np.uint64) * 3 + 1
+    gix = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=hv.EUCLIDEAN, node_ids=ids, vectors=data, dtype=hv.BF16,
+                                              l0_offsets=np.zeros(n + 1, np.uint64), l0_neighbors=np.zeros(0, np.uint64), max_batch=b)
+    oix = orc.Index(dim, orc.L2SQ)
+    assert oix.seed(ids, stored, np.zeros(n + 1, np.uint64), np.zeros(0, np.uint64)) == orc.OK
+    q = rng.standard_normal((b, dim)).astype(np.float32)
+    allowed = rng.choice(ids, 9001, replace=False)
+    cand = hv.RestrictedVectorCandidates.from_ids(allowed)
+    monkeypatch.setenv("HVX_FLAT_CHUNK", "1024")
+    monkeypatch.setenv("HVX_FLAT_DEBUG", "1")
+    capfd.readouterr()
+    gid, gsc, gcnt = gix.search_restricted_batch(q, hv.SearchParams(k), cand)
+    assert "256 x 256 tiles" in capfd.readouterr().err
+    for qi in range(0, b, 7):
+        rc, oid, osc = oix.flat(q[qi], k, allowed=allowed)
+        assert rc == orc.OK and gid[qi, :k].tolist() == oid.tolist() and bits(gsc[qi, :k]).tolist() == bits(osc).tolist()
+
+
 # --- execution lanes (hvx_index_fork) and the two-queries-per-SIMD build of the wave kernel ---
 @pytest.mark.parametrize("n,dim,metric,m,m0,efc,ef,k,nq", WAVE_CASES)
 def test_two_queries_per_simd_build_equals_oracle(orc, hv, n, dim, metric, m, m0, efc, ef, k, nq):

@@ -38,6 +38,109 @@ constexpr int kWgList = 2048;            // survivors a workgroup can hold
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),                          \
                                      (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
 
+// workgroup -> tile, XCD-aware (workgroup b runs on XCD b % 8, every XCD has its own 4 MB L2): the 32 workgroups an XCD
+// runs at a time form a super-tile of sup_r row tiles x sup_q query tiles, so each operand tile is fetched into that L2
+// once per super-tile and shared; the query blocks of one row block follow each other (the rows come from HBM once).
+__device__ __forceinline__ bool tile_coords(const MfmaArgs &a, uint32_t &qt, uint32_t &rt) {
+    const uint32_t x = blockIdx.x & 7u, l = blockIdx.x >> 3;
+    const uint32_t rq = a.sup_r * a.sup_q, per_rblock = a.sup_qblocks * rq;
+    const uint32_t rblock = l / per_rblock, rem = l % per_rblock;
+    const uint32_t qblock = rem / rq, rem2 = rem % rq;
+    rt = (rblock * a.sup_r + rem2 / a.sup_q) * 8u + x;
+    qt = qblock * a.sup_q + rem2 % a.sup_q;
+    return rt < a.nr_tiles && qt < a.nq_tiles;
+}
+
+// ---- epilogue shared by both builds of the kernel.  acc = C[m = query][n = row] of this wavefront's 128 x 64 block.
+template <bool FP8>
+__device__ __forceinline__ void tile_epilogue(const MfmaArgs &a, f32x16 (&acc)[4][2], unsigned char *lds, uint32_t q0, uint32_t r0, int wm,
+                                              int wn, int tid, float xmax2, uint32_t *wg_overflow) {
+    const int lane = tid & 63, fr = lane & 31, h = lane >> 5;
+    // ---- epilogue.  C[m = query][n = row]: lane holds n = lane & 31, m = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+    __syncthreads(); // the stage buffers are free
+    float *sH = reinterpret_cast<float *>(lds);                      // [256] per-query pass level
+    uint32_t *sCnt = reinterpret_cast<uint32_t *>(lds + 1024);       // [1] survivors of this workgroup
+    float *sLv = reinterpret_cast<float *>(lds + 2048);              // [kWgList] accumulator value
+    uint32_t *sLc = reinterpret_cast<uint32_t *>(lds + 2048 + kWgList * 4); // [kWgList] (query << 8) | row, tile-local
+    const float inf = __uint_as_float(0x7F800000u);
+    if (tid < kTM) {
+        const uint32_t qq = q0 + (uint32_t)tid;
+        float hq = inf; // padded query rows let nothing through
+        if (qq < a.b) {
+            const float t = a.thr[qq], n2 = a.qn2[qq];
+            // s < t  <=>  dot - |x|^2/2 > (|q|^2 - t)/2 (L2)   resp.   dot / |x| > (1 - 2t) |q| (cosine), up to the rounding of
+            // the two evaluation orders: the margin lets a few more in, the exact test below decides
+            if (a.metric == kL2) hq = 0.5f * (n2 - t) - 4e-6f * (n2 + xmax2);
+            else { const float qn = sqrtf(n2); hq = (1.0f - 2.0f * t) * qn - 8e-6f * qn; }
+        }
+        sH[tid] = hq;
+    }
+    if (tid == 0) *sCnt = 0u;
+    float alpha[2], nbeta[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint32_t rloc = r0 + (uint32_t)(wn * 64 + j * 32 + fr);
+        alpha[j] = 0.f;
+        nbeta[j] = -inf; // rows past the end of the scan never pass
+        if (rloc < a.nrows) {
+            const size_t node = a.subset ? a.subset[a.row0 + rloc] : (size_t)a.row0 + rloc;
+            const float term = a.rowterm[node];
+            const float rsc = FP8 ? a.rowscale[node] : 1.0f;
+            if (a.metric == kL2) { alpha[j] = rsc; nbeta[j] = -0.5f * term; }
+            else { alpha[j] = term > 0.f ? rsc / term : 0.f; nbeta[j] = 0.f; }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h; // tile-local query
+            const float hq = sH[m];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (__builtin_fmaf(acc[i][j][e], alpha[j], nbeta[j]) > hq) {
+                    const uint32_t pos = atomicAdd(sCnt, 1u);
+                    if (pos < (uint32_t)kWgList) {
+                        sLv[pos] = acc[i][j][e];
+                        sLc[pos] = ((uint32_t)m << 8) | (uint32_t)(wn * 64 + j * 32 + fr);
+                    }
+                }
+            }
+        }
+    __syncthreads();
+    uint32_t cnt = *sCnt;
+    if (cnt > (uint32_t)kWgList) { // more survivors than the list holds: the scan is repeated unfiltered, never guessed
+        if (tid == 0) atomicOr(wg_overflow, 1u);
+        cnt = kWgList;
+    }
+    for (uint32_t t = (uint32_t)tid; t < cnt; t += 512u) {
+        const uint32_t code = sLc[t];
+        const uint32_t qq = q0 + (code >> 8), rloc = r0 + (code & 255u);
+        if (qq >= a.b || rloc >= a.nrows) continue;
+        const size_t node = a.subset ? a.subset[a.row0 + rloc] : (size_t)a.row0 + rloc;
+        const float term = a.rowterm[node];
+        const float dot = FP8 ? sLv[t] * a.rowscale[node] : sLv[t];
+        float sc;
+        if (a.metric == kL2) {
+            sc = (a.qn2[qq] + term) - 2.0f * dot;
+            sc = sc < 0.f ? 0.f : sc;
+        } else {
+            const float den = sqrtf(a.qn2[qq]) * term;
+            float c = den > 0.f ? dot / den : 0.f;
+            c = c < -1.f ? -1.f : (c > 1.f ? 1.f : c);
+            sc = (1.0f - c) * 0.5f;
+        }
+        if (sc < a.thr[qq]) {
+            const uint32_t pos = atomicAdd(&a.cand_cnt[qq], 1u);
+            if (pos < a.cand_cap) {
+                a.cand_sc[(size_t)qq * a.cand_cap + pos] = sc;
+                a.cand_id[(size_t)qq * a.cand_cap + pos] = (uint32_t)node;
+            }
+        }
+    }
+}
+
 // KIND 0: bf16 rows, 1: fp8 codes.  PIPE: pin the fragment reads of step kk + 1 ahead of the MFMAs of step kk (the
 // compiler otherwise sinks them next to their use and waits for every read pair).
 template <int KIND, bool PIPE>
@@ -49,19 +152,8 @@ __global__ __launch_bounds__(512) void flat_tile256_kernel(MfmaArgs a, float xma
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
-    // workgroup -> tile, XCD-aware (workgroup b runs on XCD b % 8, every XCD has its own 4 MB L2): the 32 workgroups an XCD
-    // runs at a time form a super-tile of sup_r row tiles x sup_q query tiles, so each operand tile is fetched into that L2
-    // once per super-tile and shared; the query blocks of one row block follow each other (the rows come from HBM once).
     uint32_t qt, rt;
-    {
-        const uint32_t x = blockIdx.x & 7u, l = blockIdx.x >> 3;
-        const uint32_t rq = a.sup_r * a.sup_q, per_rblock = a.sup_qblocks * rq;
-        const uint32_t rblock = l / per_rblock, rem = l % per_rblock;
-        const uint32_t qblock = rem / rq, rem2 = rem % rq;
-        rt = (rblock * a.sup_r + rem2 / a.sup_q) * 8u + x;
-        qt = qblock * a.sup_q + rem2 % a.sup_q;
-        if (rt >= a.nr_tiles || qt >= a.nq_tiles) return;
-    }
+    if (!tile_coords(a, qt, rt)) return;
     const uint32_t q0 = qt * kTM, r0 = rt * kTN;
 
     // ---- staging addresses.  Query values: wave w copies tile rows 32 w .. 32 w + 31 as four 1-KB pieces (8 rows each);
@@ -173,90 +265,153 @@ __global__ __launch_bounds__(512) void flat_tile256_kernel(MfmaArgs a, float xma
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[i], fb1[j], acc[i][j], 0, 0, 0);
         }
     }
+    tile_epilogue<FP8>(a, acc, lds, q0, r0, wm, wn, tid, xmax2, wg_overflow);
+}
 
-    // ---- epilogue.  C[m = query][n = row]: lane holds n = lane & 31, m = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
-    __syncthreads(); // the stage buffers are free
-    float *sH = reinterpret_cast<float *>(lds);                      // [256] per-query pass level
-    uint32_t *sCnt = reinterpret_cast<uint32_t *>(lds + 1024);       // [1] survivors of this workgroup
-    float *sLv = reinterpret_cast<float *>(lds + 2048);              // [kWgList] accumulator value
-    uint32_t *sLc = reinterpret_cast<uint32_t *>(lds + 2048 + kWgList * 4); // [kWgList] (query << 8) | row, tile-local
-    const float inf = __uint_as_float(0x7F800000u);
-    if (tid < kTM) {
-        const uint32_t qq = q0 + (uint32_t)tid;
-        float hq = inf; // padded query rows let nothing through
-        if (qq < a.b) {
-            const float t = a.thr[qq], n2 = a.qn2[qq];
-            // s < t  <=>  dot - |x|^2/2 > (|q|^2 - t)/2 (L2)   resp.   dot / |x| > (1 - 2t) |q| (cosine), up to the rounding of
-            // the two evaluation orders: the margin lets a few more in, the exact test below decides
-            if (a.metric == kL2) hq = 0.5f * (n2 - t) - 4e-6f * (n2 + xmax2);
-            else { const float qn = sqrtf(n2); hq = (1.0f - 2.0f * t) * qn - 8e-6f * qn; }
-        }
-        sH[tid] = hq;
-    }
-    if (tid == 0) *sCnt = 0u;
-    float alpha[2], nbeta[2];
+// ---- the ring build: the same tile with the operand copies running several stages ahead of the matrix core.  With two LDS
+// buffers a stage's copy has one stage of MFMA time (~0.9 us) to land, and under load an HBM / L2 -> LDS copy takes longer
+// than that: the 2-buffer build measured 0.35-0.39 of the bf16 peak, waiting on vmcnt(0) at every barrier.  Here the LDS is a
+// ring of NBUF buffers -- bf16 rows: 4 x (256 x 64 B + 256 x 64 B), 32 deep; fp8 codes: 3 x (256 x 128 B + 256 x 64 B), 64 deep
+// -- stage t + NBUF - 1 is issued right after the barrier of stage t (into the buffer stage t - 1 was read from), the wait
+// before the barrier is a COUNTED one (vmcnt = copies of the NBUF - 2 younger stages) and the barrier is the raw s_barrier
+// (__syncthreads() would drain the copy queue: an LDS-DMA is a pending LDS write).
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int KIND>
+__global__ __launch_bounds__(512) void flat_tile256_ring_kernel(MfmaArgs a, float xmax2, uint32_t *wg_overflow) {
+    constexpr bool FP8 = KIND == 1;
+    constexpr int KS = FP8 ? 64 : 32;               // depth of a stage
+    constexpr int AROWB = KS * 2, BROWB = FP8 ? KS : KS * 2; // bytes per tile row and stage: 64 / 64 (bf16), 128 / 64 (fp8)
+    constexpr int ASTAGE = kTM * AROWB, STAGE = ASTAGE + kTN * BROWB;
+    constexpr int NBUF = FP8 ? 3 : 4;
+    constexpr int GA = AROWB / 32, GB = BROWB / 32, G = GA + GB; // 1-KB copies per wave and stage
+    static_assert(BROWB == 64, "row tiles are staged as 64-byte rows");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NBUF * STAGE];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    uint32_t qt, rt;
+    if (!tile_coords(a, qt, rt)) return;
+    const uint32_t q0 = qt * kTM, r0 = rt * kTN;
+
+    // staging: wave w copies tile rows 32 w .. 32 w + 31 of both operands.  64-byte rows: a 1-KB copy covers 16 rows, lane l
+    // lands on row +(l >> 2), physical 16-B slot l & 3 and fetches logical slot (l & 3) ^ ((row >> 2) & 3); 128-byte rows:
+    // 8 rows, slot (l & 7) ^ ((row >> 1) & 7).
+    const unsigned char *gA[GA], *gB[GB];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const uint32_t rloc = r0 + (uint32_t)(wn * 64 + j * 32 + fr);
-        alpha[j] = 0.f;
-        nbeta[j] = -inf; // rows past the end of the scan never pass
-        if (rloc < a.nrows) {
-            const size_t node = a.subset ? a.subset[a.row0 + rloc] : (size_t)a.row0 + rloc;
-            const float term = a.rowterm[node];
-            const float rsc = FP8 ? a.rowscale[node] : 1.0f;
-            if (a.metric == kL2) { alpha[j] = rsc; nbeta[j] = -0.5f * term; }
-            else { alpha[j] = term > 0.f ? rsc / term : 0.f; nbeta[j] = 0.f; }
-        }
+    for (int t = 0; t < GA; ++t) {
+        uint32_t row, slot;
+        if (AROWB == 64) { row = (uint32_t)(32 * wave + 16 * t + (lane >> 2)); slot = (uint32_t)(lane & 3) ^ ((row >> 2) & 3u); }
+        else { row = (uint32_t)(32 * wave + 8 * t + (lane >> 3)); slot = (uint32_t)(lane & 7) ^ ((row >> 1) & 7u); }
+        gA[t] = reinterpret_cast<const unsigned char *>(a.qhi) + (size_t)(q0 + row) * a.dim * 2 + slot * 16; // queries are padded to 256
     }
-    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < GB; ++t) {
+        const uint32_t row = (uint32_t)(32 * wave + 16 * t + (lane >> 2));
+        const uint32_t slot = (uint32_t)(lane & 3) ^ ((row >> 2) & 3u);
+        uint32_t rloc = r0 + row;
+        if (rloc >= a.nrows) rloc = a.nrows - 1; // clamp: the duplicate is masked in the epilogue
+        const size_t node = a.subset ? a.subset[a.row0 + rloc] : (size_t)a.row0 + rloc;
+        gB[t] = reinterpret_cast<const unsigned char *>(a.rows) + node * a.dim * (FP8 ? 1 : 2) + slot * 16;
+    }
+    auto issue_stage = [&](uint32_t s) {
+        unsigned char *sA = lds + (s % NBUF) * STAGE + wave * (32 * AROWB);
+        unsigned char *sB = lds + (s % NBUF) * STAGE + ASTAGE + wave * (32 * BROWB);
+#pragma unroll
+        for (int t = 0; t < GA; ++t) HVX_GLDS16(gA[t] + s * (uint32_t)AROWB, sA + t * 1024);
+#pragma unroll
+        for (int t = 0; t < GB; ++t) HVX_GLDS16(gB[t] + s * (uint32_t)BROWB, sB + t * 1024);
+    };
+
+    // fragment read offsets: lane = tile row fr of a 32-row block, depth half h
+    const int fr = lane & 31, h = lane >> 5;
+    int off128[4], off64[2];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) off128[kk] = fr * 128 + (((2 * kk + h) ^ ((fr >> 1) & 7)) << 4);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) off64[jj] = fr * 64 + (((2 * jj + h) ^ ((fr >> 2) & 3)) << 4);
+
+    f32x16 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int m = wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h; // tile-local query
-            const float hq = sH[m];
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (__builtin_fmaf(acc[i][j][e], alpha[j], nbeta[j]) > hq) {
-                    const uint32_t pos = atomicAdd(sCnt, 1u);
-                    if (pos < (uint32_t)kWgList) {
-                        sLv[pos] = acc[i][j][e];
-                        sLc[pos] = ((uint32_t)m << 8) | (uint32_t)(wn * 64 + j * 32 + fr);
-                    }
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const uint32_t nstage = a.dim / (uint32_t)KS;
+#pragma unroll
+    for (int s = 0; s < NBUF - 1; ++s)
+        if ((uint32_t)s < nstage) issue_stage((uint32_t)s);
+    for (uint32_t s = 0; s < nstage; ++s) {
+        // stage s has landed when at most the copies of the younger stages in flight are outstanding
+        const uint32_t younger = nstage - 1u - s < (uint32_t)(NBUF - 2) ? nstage - 1u - s : (uint32_t)(NBUF - 2);
+        if (younger >= 2u) wait_vmcnt<2 * G>();
+        else if (younger == 1u) wait_vmcnt<G>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier(); // everyone's copies of stage s are in LDS; nobody still reads the buffer of stage s - 1
+        if (s + (uint32_t)(NBUF - 1) < nstage) issue_stage(s + (uint32_t)(NBUF - 1));
+        const unsigned char *sA = lds + (s % NBUF) * STAGE + wm * (128 * AROWB);
+        const unsigned char *sB = lds + (s % NBUF) * STAGE + ASTAGE + wn * (64 * BROWB);
+        if (FP8) {
+            uint4 c8[2];
+            auto load_frags = [&](int kk, bf16x8 (&fa)[4], bf16x8 (&fb)[2]) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sA + i * (32 * 128) + off128[kk]));
+                if ((kk & 1) == 0) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) c8[j] = *reinterpret_cast<const uint4 *>(sB + j * (32 * 64) + off64[kk >> 1]);
                 }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const uint32_t w0 = (kk & 1) ? c8[j].z : c8[j].x, w1 = (kk & 1) ? c8[j].w : c8[j].y;
+                    const f32x2 a01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w0, false), a23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w0, true);
+                    const f32x2 b01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w1, false), b23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w1, true);
+                    uint4 wv;
+                    wv.x = __builtin_amdgcn_perm(__float_as_uint(a01[1]), __float_as_uint(a01[0]), 0x07060302u);
+                    wv.y = __builtin_amdgcn_perm(__float_as_uint(a23[1]), __float_as_uint(a23[0]), 0x07060302u);
+                    wv.z = __builtin_amdgcn_perm(__float_as_uint(b01[1]), __float_as_uint(b01[0]), 0x07060302u);
+                    wv.w = __builtin_amdgcn_perm(__float_as_uint(b23[1]), __float_as_uint(b23[0]), 0x07060302u);
+                    fb[j] = __builtin_bit_cast(bf16x8, wv);
+                }
+            };
+            bf16x8 fa0[4], fb0[2], fa1[4], fb1[2];
+            load_frags(0, fa0, fb0);
+#pragma unroll
+            for (int kk = 0; kk < 4; kk += 2) {
+                load_frags(kk + 1, fa1, fb1);
+                __builtin_amdgcn_sched_barrier(0); // keep the reads of the next step ahead of this step's MFMAs
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[i], fb0[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 2 < 4) load_frags(kk + 2, fa0, fb0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[i], fb1[j], acc[i][j], 0, 0, 0);
             }
-        }
-    __syncthreads();
-    uint32_t cnt = *sCnt;
-    if (cnt > (uint32_t)kWgList) { // more survivors than the list holds: the scan is repeated unfiltered, never guessed
-        if (tid == 0) atomicOr(wg_overflow, 1u);
-        cnt = kWgList;
-    }
-    for (uint32_t t = (uint32_t)tid; t < cnt; t += 512u) {
-        const uint32_t code = sLc[t];
-        const uint32_t qq = q0 + (code >> 8), rloc = r0 + (code & 255u);
-        if (qq >= a.b || rloc >= a.nrows) continue;
-        const size_t node = a.subset ? a.subset[a.row0 + rloc] : (size_t)a.row0 + rloc;
-        const float term = a.rowterm[node];
-        const float dot = FP8 ? sLv[t] * a.rowscale[node] : sLv[t];
-        float sc;
-        if (a.metric == kL2) {
-            sc = (a.qn2[qq] + term) - 2.0f * dot;
-            sc = sc < 0.f ? 0.f : sc;
         } else {
-            const float den = sqrtf(a.qn2[qq]) * term;
-            float c = den > 0.f ? dot / den : 0.f;
-            c = c < -1.f ? -1.f : (c > 1.f ? 1.f : c);
-            sc = (1.0f - c) * 0.5f;
-        }
-        if (sc < a.thr[qq]) {
-            const uint32_t pos = atomicAdd(&a.cand_cnt[qq], 1u);
-            if (pos < a.cand_cap) {
-                a.cand_sc[(size_t)qq * a.cand_cap + pos] = sc;
-                a.cand_id[(size_t)qq * a.cand_cap + pos] = (uint32_t)node;
+            bf16x8 fa[2][4], fb[2][2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[kk][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sA + i * (32 * 64) + off64[kk]));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[kk][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sB + j * (32 * 64) + off64[kk]));
             }
+            __builtin_amdgcn_sched_barrier(0); // all twelve reads of the stage ahead of its sixteen MFMAs
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
         }
     }
+    tile_epilogue<FP8>(a, acc, lds, q0, r0, wm, wn, tid, xmax2, wg_overflow);
 }
 
 hipError_t launch_flat_tile256(const MfmaArgs &a, int kind, uint32_t bpad, float xmax2, uint32_t *wg_overflow, hipStream_t s) {
@@ -270,6 +425,12 @@ hipError_t launch_flat_tile256(const MfmaArgs &a, int kind, uint32_t bpad, float
     t.sup_qblocks = (t.nq_tiles + t.sup_q - 1) / t.sup_q;
     const uint32_t rblocks = (t.nr_tiles + 8u * t.sup_r - 1) / (8u * t.sup_r);
     const dim3 grid(8u * rblocks * t.sup_qblocks * t.sup_r * t.sup_q);
+    static const bool ring = [] { const char *e = getenv("HVX_FLAT_TILE_RING"); return !e || e[0] != '0'; }();
+    if (ring) {
+        if (kind == 1) hipLaunchKernelGGL((flat_tile256_ring_kernel<1>), grid, dim3(512), 0, s, t, xmax2, wg_overflow);
+        else hipLaunchKernelGGL((flat_tile256_ring_kernel<0>), grid, dim3(512), 0, s, t, xmax2, wg_overflow);
+        return hipGetLastError();
+    }
     static const bool pipe = [] { const char *e = getenv("HVX_FLAT_TILE_PIPE"); return !e || e[0] != '0'; }();
     if (kind == 1) {
         if (pipe) hipLaunchKernelGGL((flat_tile256_kernel<1, true>), grid, dim3(512), 0, s, t, xmax2, wg_overflow);

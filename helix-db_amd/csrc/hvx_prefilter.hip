@@ -38,6 +38,14 @@ struct hvx_csr {
     uint32_t *counter = nullptr;                    // [2] next-frontier size
     uint32_t *labels = nullptr;                     // allowed-label scratch
     uint32_t labels_cap = 0;
+    // ordered traversal (hvx_traverse_ordered)
+    bool rows_sorted = true;                        // every outgoing row ascends by target (the reference's rows do: model.rs:656-666)
+    uint32_t *in_arc = nullptr;                     // [e] incoming slot -> index of the stored edge in the outgoing arrays (e < 2^32)
+    uint32_t *owner = nullptr;                      // [n] frontier position that claimed the node at its level
+    uint32_t *pc_out = nullptr, *pc_in = nullptr;   // [e] per arc: bit 31 = discovery arc, low bits = discovery arcs before it in its row
+    uint32_t *cnt = nullptr;                        // [n + 1] per frontier position: discovery arcs (then their exclusive scan)
+    uint32_t *ord_node = nullptr, *ord_parent = nullptr, *ord_arc = nullptr; // [n] visits in discovery order
+    uint32_t *lvl = nullptr;                        // [4] level start, level size, next level size
 };
 
 namespace {
@@ -55,6 +63,11 @@ __device__ __forceinline__ bool label_ok(uint32_t lab, const uint32_t *allowed, 
     return false;
 }
 
+__device__ __forceinline__ void bfs_expand_node(const CsrView &g, uint32_t node, int lane, uint32_t *next, uint32_t *next_n,
+                                                uint32_t *visited, uint32_t *depth, uint32_t next_depth, uint32_t direction,
+                                                const uint32_t *allowed, uint32_t n_allowed, uint32_t hub_degree,
+                                                uint32_t is_seed_level, uint32_t expand_only);
+
 // One BFS level: one wavefront per frontier node, lanes stride over its arcs (out, then in).
 // mark_visited=false gives the `expand` union (no visited exclusion, bitmap only).
 __global__ __launch_bounds__(256) void bfs_level_kernel(CsrView g, const uint32_t *frontier, uint32_t n_front,
@@ -62,11 +75,21 @@ __global__ __launch_bounds__(256) void bfs_level_kernel(CsrView g, const uint32_
                                                         uint32_t *depth, uint32_t next_depth, uint32_t direction,
                                                         const uint32_t *allowed, uint32_t n_allowed,
                                                         uint32_t hub_degree, uint32_t is_seed_level,
-                                                        uint32_t expand_only) {
-    const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+                                                        uint32_t expand_only, const uint32_t *n_front_dev) {
+    // n_front_dev != NULL: the frontier size is whatever the previous level's launch counted (no host round trip between
+    // levels); the grid is then a fixed one and the wavefronts stride over the frontier
+    if (n_front_dev) n_front = *n_front_dev;
     const int lane = (int)(threadIdx.x & 63u);
-    if (w >= n_front) return;
-    const uint32_t node = frontier[w];
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n_front; w += n_waves)
+        bfs_expand_node(g, frontier[w], lane, next, next_n, visited, depth, next_depth, direction, allowed, n_allowed, hub_degree,
+                        is_seed_level, expand_only);
+}
+
+__device__ __forceinline__ void bfs_expand_node(const CsrView &g, uint32_t node, int lane, uint32_t *next, uint32_t *next_n,
+                                                uint32_t *visited, uint32_t *depth, uint32_t next_depth, uint32_t direction,
+                                                const uint32_t *allowed, uint32_t n_allowed, uint32_t hub_degree,
+                                                uint32_t is_seed_level, uint32_t expand_only) {
     const uint64_t o0 = g.out_off[node], o1 = g.out_off[node + 1];
     const uint64_t i0 = g.in_off[node], i1 = g.in_off[node + 1];
     // suppresses_hub (traversal.rs:311-318): non-seed nodes at/above the total-degree threshold are
@@ -143,12 +166,14 @@ extern "C" int hvx_csr_import(uint64_t n_nodes, uint64_t n_edges, const uint64_t
     // incoming CSR by counting sort (stable: incoming arcs keep source order)
     std::vector<uint64_t> in_off(n_nodes + 1, 0);
     std::vector<uint32_t> tgt32(std::max<uint64_t>(n_edges, 1)), in_tgt(std::max<uint64_t>(n_edges, 1)),
-        in_lab(edge_labels ? std::max<uint64_t>(n_edges, 1) : 0);
+        in_lab(edge_labels ? std::max<uint64_t>(n_edges, 1) : 0), in_arc(n_edges < (1ull << 32) ? std::max<uint64_t>(n_edges, 1) : 0);
+    bool rows_sorted = true;
     for (uint64_t u = 0; u < n_nodes; ++u) {
         if (out_offsets[u + 1] < out_offsets[u]) return fail(HVX_ERR_INVARIANT, "offsets not monotone");
         for (uint64_t a = out_offsets[u]; a < out_offsets[u + 1]; ++a) {
             if (out_targets[a] >= n_nodes) return fail(HVX_ERR_INVARIANT, "edge target out of range");
             tgt32[a] = (uint32_t)out_targets[a];
+            if (a > out_offsets[u] && out_targets[a] < out_targets[a - 1]) rows_sorted = false;
             in_off[out_targets[a] + 1]++;
         }
     }
@@ -159,6 +184,7 @@ extern "C" int hvx_csr_import(uint64_t n_nodes, uint64_t n_edges, const uint64_t
             for (uint64_t a = out_offsets[u]; a < out_offsets[u + 1]; ++a) {
                 uint64_t slot = cur[out_targets[a]]++;
                 in_tgt[slot] = (uint32_t)u;
+                if (n_edges < (1ull << 32)) in_arc[slot] = (uint32_t)a;
                 if (edge_labels) in_lab[slot] = edge_labels[a];
             }
     }
@@ -180,6 +206,8 @@ extern "C" int hvx_csr_import(uint64_t n_nodes, uint64_t n_edges, const uint64_t
     if ((rc = up(in_off.data(), (n_nodes + 1) * 8, (void **)&g->in_off))) return bail(rc);
     if ((rc = up(tgt32.data(), n_edges * 4, (void **)&g->out_tgt))) return bail(rc);
     if ((rc = up(in_tgt.data(), n_edges * 4, (void **)&g->in_tgt))) return bail(rc);
+    g->rows_sorted = rows_sorted;
+    if (!in_arc.empty() && (rc = up(in_arc.data(), n_edges * 4, (void **)&g->in_arc))) return bail(rc);
     if (edge_labels) {
         if ((rc = up(edge_labels, n_edges * 4, (void **)&g->out_lab))) return bail(rc);
         if ((rc = up(in_lab.data(), n_edges * 4, (void **)&g->in_lab))) return bail(rc);
@@ -234,18 +262,30 @@ static int run_bfs_locked(hvx_csr *g, const uint64_t *seeds, uint32_t n_seeds, u
     CsrView v{g->out_off, g->in_off, g->out_tgt, g->in_tgt, g->out_lab, g->in_lab, g->n};
     int cur = 0;
     const uint32_t levels = expand_only ? 1u : max_depth;
-    for (uint32_t d = 0; d < levels && nf; ++d) {
-        HIP_TRY(hipMemsetAsync(g->counter, 0, 4, g->stream));
-        const uint32_t blocks = (uint32_t)(((uint64_t)nf * 64 + 255) / 256);
-        hipLaunchKernelGGL(bfs_level_kernel, dim3(blocks), dim3(256), 0, g->stream, v, g->front[cur], nf,
-                           g->front[cur ^ 1], g->counter, g->visited, g->depth, d + 1, direction, g->labels,
-                           n_labels, hub_degree, d == 0 ? 1u : 0u, expand_only ? 1u : 0u);
-        HIP_TRY(hipGetLastError());
-        uint32_t next_n = 0;
-        HIP_TRY(hipMemcpyAsync(&next_n, g->counter, 4, hipMemcpyDeviceToHost, g->stream));
-        HIP_TRY(hipStreamSynchronize(g->stream));
-        nf = next_n;
-        cur ^= 1;
+    // Level 0 is sized by the host (it knows the seeds); every later level reads its frontier size from the counter the
+    // level before it incremented -- the levels are enqueued back to back, the host looks at the counter only every
+    // kLevelsPerSync levels (to stop an unbounded traversal whose frontier has emptied).
+    constexpr uint32_t kLevelsPerSync = 8;
+    HIP_TRY(hipMemsetAsync(g->counter, 0, 8, g->stream));
+    for (uint32_t d = 0; d < levels && nf;) {
+        const uint32_t until = std::min<uint64_t>(levels, (uint64_t)d + kLevelsPerSync);
+        for (; d < until; ++d) {
+            uint32_t *cnt_next = g->counter + ((d + 1) & 1u);
+            HIP_TRY(hipMemsetAsync(cnt_next, 0, 4, g->stream));
+            const uint32_t blocks = d == 0 ? (uint32_t)(((uint64_t)nf * 64 + 255) / 256) : 1024u;
+            hipLaunchKernelGGL(bfs_level_kernel, dim3(blocks), dim3(256), 0, g->stream, v, g->front[cur], nf,
+                               g->front[cur ^ 1], cnt_next, g->visited, g->depth, d + 1, direction, g->labels,
+                               n_labels, hub_degree, d == 0 ? 1u : 0u, expand_only ? 1u : 0u,
+                               d == 0 ? (const uint32_t *)nullptr : (const uint32_t *)(g->counter + (d & 1u)));
+            HIP_TRY(hipGetLastError());
+            cur ^= 1;
+        }
+        if (d < levels) { // more levels wanted: is there a frontier left?
+            uint32_t next_n = 0;
+            HIP_TRY(hipMemcpyAsync(&next_n, g->counter + (d & 1u), 4, hipMemcpyDeviceToHost, g->stream));
+            HIP_TRY(hipStreamSynchronize(g->stream));
+            nf = next_n;
+        }
     }
     if (!expand_only && !include_seeds) {
         // seeds were inserted into front[0]; re-upload (front[0] may have been reused) and clear
@@ -286,6 +326,307 @@ extern "C" int hvx_expand_filter(const hvx_csr *cg, const uint64_t *rows, uint32
     }
     return run_bfs(const_cast<hvx_csr *>(cg), rows, n_rows, 1, direction, allowed_label_ids, n_labels, 0, 0, true,
                    out_bitmap_words, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ordered traversal: Graph::traverse (BreadthFirst) with its visit ORDER and discovery edges
+// (traversal.rs:216-261).  The reference's FIFO order is: by the discovery position of the node that reached you, then
+// by the arc order of that node (model.rs:635-725: rows sorted by neighbour, direction Both merges the two rows by
+// neighbour, outgoing first on equal neighbours, incoming self-loops skipped).  Level-synchronous form of exactly that
+// order, four launches per level, no host round trip between levels:
+//   claim  -- every frontier position i offers itself to the unvisited nodes its allowed arcs reach: owner[v] = min i;
+//   count  -- wave i walks its rows: an arc is v's discovery arc iff owner[v] == i and it is the first allowed arc to v
+//             in the merged arc order; per arc it stores (flag, discovery arcs before it in its row), per position the total;
+//   scan   -- exclusive prefix sum of the totals (one workgroup);
+//   emit   -- a discovery arc's rank among its node's = (those before it in its own row) + (those of the other row with
+//             a smaller neighbour: one binary search); visit slot = level start + scan[i] + rank.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+constexpr uint32_t kUnset = 0xFFFFFFFFu;
+
+struct OrdArgs {
+    CsrView g;
+    const uint32_t *in_arc;
+    uint32_t *owner, *pc_out, *pc_in, *cnt, *depth;
+    uint32_t *ord_node, *ord_parent, *ord_arc;
+    uint32_t *lvl;               // [0] start of the current level in ord_*, [1] its size, [2] size of the next one
+    const uint32_t *allowed;
+    uint32_t n_allowed, direction, hub_degree, cur_depth;
+};
+
+__device__ __forceinline__ bool ord_expands(const OrdArgs &a, uint32_t node) {
+    if (!a.hub_degree || a.cur_depth == 0) return true; // seeds are expanded whatever their degree
+    return (a.g.out_off[node + 1] - a.g.out_off[node]) + (a.g.in_off[node + 1] - a.g.in_off[node]) < a.hub_degree;
+}
+__device__ __forceinline__ bool ord_allowed(const uint32_t *lab, uint64_t a, const OrdArgs &o) {
+    return !lab || label_ok(lab[a], o.allowed, o.n_allowed);
+}
+
+__global__ __launch_bounds__(256) void ord_claim_kernel(OrdArgs a) {
+    const uint32_t start = a.lvl[0], nf = a.lvl[1];
+    const int lane = (int)(threadIdx.x & 63u);
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < nf; i += n_waves) {
+        const uint32_t node = a.ord_node[start + i];
+        if (!ord_expands(a, node)) continue;
+        for (int pass = 0; pass < 2; ++pass) {
+            const bool use_out = pass == 0;
+            if (use_out ? a.direction == 1u : a.direction == 0u) continue;
+            const uint64_t a0 = use_out ? a.g.out_off[node] : a.g.in_off[node], a1 = use_out ? a.g.out_off[node + 1] : a.g.in_off[node + 1];
+            const uint32_t *tgt = use_out ? a.g.out_tgt : a.g.in_tgt;
+            const uint32_t *lab = use_out ? a.g.out_lab : a.g.in_lab;
+            for (uint64_t e = a0 + (uint64_t)lane; e < a1; e += 64) {
+                if (!ord_allowed(lab, e, a)) continue;
+                const uint32_t v = tgt[e];
+                if (a.depth[v] == kUnset) atomicMin(&a.owner[v], i);
+            }
+        }
+    }
+}
+
+// is arc e (a row of `tgt`, starting at row0) the first ALLOWED arc to its neighbour in its row?  (rows ascend by neighbour)
+__device__ __forceinline__ bool ord_first_in_row(const uint32_t *tgt, const uint32_t *lab, uint64_t row0, uint64_t e, const OrdArgs &o) {
+    const uint32_t v = tgt[e];
+    for (uint64_t p = e; p > row0 && tgt[p - 1] == v; --p)
+        if (ord_allowed(lab, p - 1, o)) return false;
+    return true;
+}
+// does the outgoing row [o0, o1) hold an allowed arc to v?
+__device__ __forceinline__ bool ord_out_reaches(const OrdArgs &o, uint64_t o0, uint64_t o1, uint32_t v) {
+    uint64_t lo = o0, hi = o1;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (o.g.out_tgt[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    for (; lo < o1 && o.g.out_tgt[lo] == v; ++lo)
+        if (ord_allowed(o.g.out_lab, lo, o)) return true;
+    return false;
+}
+
+__global__ __launch_bounds__(256) void ord_count_kernel(OrdArgs a) {
+    const uint32_t start = a.lvl[0], nf = a.lvl[1];
+    const int lane = (int)(threadIdx.x & 63u);
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < nf; i += n_waves) {
+        const uint32_t node = a.ord_node[start + i];
+        uint32_t total = 0;
+        if (ord_expands(a, node)) {
+            const uint64_t o0 = a.g.out_off[node], o1 = a.g.out_off[node + 1];
+            for (int pass = 0; pass < 2; ++pass) {
+                const bool use_out = pass == 0;
+                if (use_out ? a.direction == 1u : a.direction == 0u) continue;
+                const uint64_t a0 = use_out ? o0 : a.g.in_off[node], a1 = use_out ? o1 : a.g.in_off[node + 1];
+                const uint32_t *tgt = use_out ? a.g.out_tgt : a.g.in_tgt;
+                const uint32_t *lab = use_out ? a.g.out_lab : a.g.in_lab;
+                uint32_t *pc = use_out ? a.pc_out : a.pc_in;
+                uint32_t row_count = 0;
+                for (uint64_t base = a0; base < a1; base += 64) {
+                    const uint64_t e = base + (uint64_t)lane;
+                    bool flag = false;
+                    if (e < a1 && ord_allowed(lab, e, a)) {
+                        const uint32_t v = tgt[e];
+                        flag = a.depth[v] == kUnset && a.owner[v] == i && ord_first_in_row(tgt, lab, a0, e, a) &&
+                               (use_out || a.direction != 2u || !ord_out_reaches(a, o0, o1, v));
+                    }
+                    const unsigned long long m = __ballot(flag);
+                    if (e < a1) pc[e] = (flag ? 0x80000000u : 0u) | (row_count + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
+                    row_count += (uint32_t)__popcll(m);
+                }
+                total += row_count;
+            }
+        }
+        if (lane == 0) a.cnt[i] = total;
+    }
+}
+
+// exclusive scan of cnt[0 .. lvl[1]) in place; lvl[2] = the total (the next level's size)
+__global__ __launch_bounds__(1024) void ord_scan_kernel(uint32_t *cnt, uint32_t *lvl) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t carry_s;
+    const uint32_t nf = lvl[1];
+    const int tid = (int)threadIdx.x;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nf; base += 1024) {
+        const uint32_t idx = base + (uint32_t)tid;
+        const uint32_t v = idx < nf ? cnt[idx] : 0u;
+        part[tid] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan
+            const uint32_t t = tid >= off ? part[tid - off] : 0u;
+            __syncthreads();
+            part[tid] += t;
+            __syncthreads();
+        }
+        const uint32_t carry = carry_s;
+        if (idx < nf) cnt[idx] = carry + part[tid] - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + part[1023];
+        __syncthreads();
+    }
+    if (tid == 0) lvl[2] = carry_s;
+}
+
+__global__ __launch_bounds__(256) void ord_emit_kernel(OrdArgs a) {
+    const uint32_t start = a.lvl[0], nf = a.lvl[1];
+    const uint32_t next_start = start + nf;
+    const int lane = (int)(threadIdx.x & 63u);
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < nf; i += n_waves) {
+        const uint32_t node = a.ord_node[start + i];
+        if (!ord_expands(a, node)) continue;
+        const uint32_t base = a.cnt[i];
+        const uint64_t o0 = a.g.out_off[node], o1 = a.g.out_off[node + 1], i0 = a.g.in_off[node], i1 = a.g.in_off[node + 1];
+        const bool both = a.direction == 2u;
+        if (a.direction != 1u)
+            for (uint64_t e = o0 + (uint64_t)lane; e < o1; e += 64) {
+                const uint32_t p = a.pc_out[e];
+                if (!(p & 0x80000000u)) continue;
+                const uint32_t v = a.g.out_tgt[e];
+                uint32_t rank = p & 0x7FFFFFFFu;
+                if (both) { // + discovery arcs of the incoming row with a smaller neighbour
+                    uint64_t lo = i0, hi = i1;
+                    while (lo < hi) {
+                        const uint64_t mid = (lo + hi) >> 1;
+                        if (a.g.in_tgt[mid] < v) lo = mid + 1; else hi = mid;
+                    }
+                    // pc_in[lo] counts the flags before slot lo; past the row's end: every flag of the row
+                    if (lo < i1) rank += a.pc_in[lo] & 0x7FFFFFFFu;
+                    else if (i1 > i0) rank += (a.pc_in[i1 - 1] & 0x7FFFFFFFu) + (a.pc_in[i1 - 1] >> 31);
+                }
+                const uint32_t slot = next_start + base + rank;
+                a.ord_node[slot] = v;
+                a.ord_parent[slot] = node;
+                a.ord_arc[slot] = (uint32_t)e;               // followed along the stored edge
+                a.depth[v] = a.cur_depth + 1u;
+            }
+        if (a.direction != 0u)
+            for (uint64_t e = i0 + (uint64_t)lane; e < i1; e += 64) {
+                const uint32_t p = a.pc_in[e];
+                if (!(p & 0x80000000u)) continue;
+                const uint32_t v = a.g.in_tgt[e];
+                uint32_t rank = p & 0x7FFFFFFFu;
+                if (both) { // + discovery arcs of the outgoing row with a neighbour <= v (an equal one cannot be flagged too)
+                    uint64_t lo = o0, hi = o1;
+                    while (lo < hi) {
+                        const uint64_t mid = (lo + hi) >> 1;
+                        if (a.g.out_tgt[mid] <= v) lo = mid + 1; else hi = mid;
+                    }
+                    if (lo < o1) rank += a.pc_out[lo] & 0x7FFFFFFFu;
+                    else if (o1 > o0) rank += (a.pc_out[o1 - 1] & 0x7FFFFFFFu) + (a.pc_out[o1 - 1] >> 31);
+                }
+                const uint32_t slot = next_start + base + rank;
+                a.ord_node[slot] = v;
+                a.ord_parent[slot] = node;
+                a.ord_arc[slot] = a.in_arc[e] | 0x80000000u; // followed against the stored edge
+                a.depth[v] = a.cur_depth + 1u;
+            }
+    }
+}
+
+// next level: start += size, size = what the scan counted
+__global__ void ord_advance_kernel(uint32_t *lvl) {
+    lvl[0] += lvl[1];
+    lvl[1] = lvl[2];
+    lvl[2] = 0;
+}
+
+__global__ void ord_seed_kernel(const uint32_t *seeds, uint32_t n_seeds, uint32_t *depth, uint32_t *lvl) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_seeds) depth[seeds[i]] = 0;
+    if (i == 0) { lvl[0] = 0; lvl[1] = n_seeds; lvl[2] = 0; }
+}
+
+} // namespace
+
+extern "C" int hvx_traverse_ordered(const hvx_csr *cg, const uint64_t *seeds, uint32_t n_seeds, uint32_t max_depth,
+                                    uint32_t direction, const uint32_t *allowed_label_ids, uint32_t n_labels,
+                                    uint32_t hub_degree, uint64_t capacity, uint64_t *out_nodes, uint32_t *out_depths,
+                                    uint64_t *out_parents, uint64_t *out_edges, uint32_t *out_against, uint64_t *out_count) {
+    if (!cg || !out_count) return fail(HVX_ERR_INVARIANT, "null argument");
+    hvx_csr *g = const_cast<hvx_csr *>(cg);
+    *out_count = 0;
+    if (direction > HVX_DIR_BOTH) return fail(HVX_ERR_INVARIANT, "bad direction");
+    if (n_seeds == 0) return fail(HVX_ERR_INVARIANT, "traversal requires at least one seed"); // traversal.rs:198-202
+    if (!g->rows_sorted) return fail(HVX_ERR_UNSUPPORTED, "ordered traversal needs outgoing rows sorted by target (model.rs:656-666)");
+    if (g->e >= (1ull << 31)) return fail(HVX_ERR_UNSUPPORTED, "ordered traversal serves graphs below 2^31 edges");
+    std::lock_guard<std::mutex> lock(g->mu);
+    HIP_TRY(hipSetDevice(g->device));
+    // seeds: duplicates collapse, first occurrence keeps its place (traversal.rs:203-210); unknown node => error
+    std::vector<uint32_t> s32;
+    {
+        std::vector<uint64_t> seen;
+        for (uint32_t i = 0; i < n_seeds; ++i) {
+            if (seeds[i] >= g->n) return fail(HVX_ERR_INVARIANT, "unknown node %llu", (unsigned long long)seeds[i]);
+            if (std::find(seen.begin(), seen.end(), seeds[i]) == seen.end()) {
+                seen.push_back(seeds[i]);
+                s32.push_back((uint32_t)seeds[i]);
+            }
+        }
+    }
+    int rc;
+    if (!g->owner) {
+        const size_t nn = std::max<uint32_t>(g->n, 1), ee = std::max<uint64_t>(g->e, 1);
+        if ((rc = csr_alloc(g, (void **)&g->owner, nn * 4))) return rc;
+        if ((rc = csr_alloc(g, (void **)&g->pc_out, ee * 4))) return rc;
+        if ((rc = csr_alloc(g, (void **)&g->pc_in, ee * 4))) return rc;
+        if ((rc = csr_alloc(g, (void **)&g->cnt, (nn + 1) * 4))) return rc;
+        if ((rc = csr_alloc(g, (void **)&g->ord_node, nn * 4))) return rc;
+        if ((rc = csr_alloc(g, (void **)&g->ord_parent, nn * 4))) return rc;
+        if ((rc = csr_alloc(g, (void **)&g->ord_arc, nn * 4))) return rc;
+        if ((rc = csr_alloc(g, (void **)&g->lvl, 16))) return rc;
+    }
+    if ((rc = upload_labels(g, allowed_label_ids, n_labels))) return rc;
+    const uint32_t nn = std::max<uint32_t>(g->n, 1);
+    HIP_TRY(hipMemsetAsync(g->depth, 0xFF, (size_t)nn * 4, g->stream));
+    HIP_TRY(hipMemsetAsync(g->owner, 0xFF, (size_t)nn * 4, g->stream));
+    HIP_TRY(hipMemcpyAsync(g->ord_node, s32.data(), s32.size() * 4, hipMemcpyHostToDevice, g->stream));
+    const uint32_t ns = (uint32_t)s32.size();
+    hipLaunchKernelGGL(ord_seed_kernel, dim3((ns + 255) / 256), dim3(256), 0, g->stream, g->ord_node, ns, g->depth, g->lvl);
+    HIP_TRY(hipGetLastError());
+    OrdArgs a;
+    a.g = CsrView{g->out_off, g->in_off, g->out_tgt, g->in_tgt, g->out_lab, g->in_lab, g->n};
+    a.in_arc = g->in_arc; a.owner = g->owner; a.pc_out = g->pc_out; a.pc_in = g->pc_in; a.cnt = g->cnt; a.depth = g->depth;
+    a.ord_node = g->ord_node; a.ord_parent = g->ord_parent; a.ord_arc = g->ord_arc; a.lvl = g->lvl;
+    a.allowed = g->labels; a.n_allowed = n_labels; a.direction = direction; a.hub_degree = hub_degree;
+    constexpr uint32_t kLevelsPerSync = 8;
+    uint32_t h_lvl[4] = {0, ns, 0, 0};
+    for (uint32_t d = 0; d < max_depth && h_lvl[1];) {
+        const uint32_t until = (uint32_t)std::min<uint64_t>(max_depth, (uint64_t)d + kLevelsPerSync);
+        for (; d < until; ++d) {
+            a.cur_depth = d;
+            hipLaunchKernelGGL(ord_claim_kernel, dim3(1024), dim3(256), 0, g->stream, a);
+            hipLaunchKernelGGL(ord_count_kernel, dim3(1024), dim3(256), 0, g->stream, a);
+            hipLaunchKernelGGL(ord_scan_kernel, dim3(1), dim3(1024), 0, g->stream, g->cnt, g->lvl);
+            hipLaunchKernelGGL(ord_emit_kernel, dim3(1024), dim3(256), 0, g->stream, a);
+            hipLaunchKernelGGL(ord_advance_kernel, dim3(1), dim3(1), 0, g->stream, g->lvl);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipMemcpyAsync(h_lvl, g->lvl, 16, hipMemcpyDeviceToHost, g->stream));
+        HIP_TRY(hipStreamSynchronize(g->stream));
+    }
+    const uint64_t total = (uint64_t)h_lvl[0] + h_lvl[1];
+    *out_count = total;
+    if (total > capacity) return fail(HVX_ERR_INVARIANT, "traversal visited %llu nodes, the output holds %llu", (unsigned long long)total,
+                                      (unsigned long long)capacity);
+    std::vector<uint32_t> hn(total), hp(total), ha(total), hd(g->n);
+    if (total) {
+        HIP_TRY(hipMemcpyAsync(hn.data(), g->ord_node, total * 4, hipMemcpyDeviceToHost, g->stream));
+        HIP_TRY(hipMemcpyAsync(hp.data(), g->ord_parent, total * 4, hipMemcpyDeviceToHost, g->stream));
+        HIP_TRY(hipMemcpyAsync(ha.data(), g->ord_arc, total * 4, hipMemcpyDeviceToHost, g->stream));
+        HIP_TRY(hipMemcpyAsync(hd.data(), g->depth, (size_t)g->n * 4, hipMemcpyDeviceToHost, g->stream));
+        HIP_TRY(hipStreamSynchronize(g->stream));
+    }
+    for (uint64_t i = 0; i < total; ++i) {
+        const bool seed = i < ns;
+        if (out_nodes) out_nodes[i] = hn[i];
+        if (out_depths) out_depths[i] = hd[hn[i]];
+        if (out_parents) out_parents[i] = seed ? UINT64_MAX : hp[i];
+        if (out_edges) out_edges[i] = seed ? UINT64_MAX : (ha[i] & 0x7FFFFFFFu);
+        if (out_against) out_against[i] = seed ? 0u : (ha[i] >> 31);
+    }
+    return HVX_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

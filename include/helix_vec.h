@@ -301,6 +301,19 @@ int hvx_traverse_filter(const hvx_csr *, const uint64_t *seeds, uint32_t n_seeds
                         uint32_t direction, const uint32_t *allowed_label_ids, uint32_t n_labels,
                         uint32_t hub_degree, uint32_t include_seeds, uint64_t *out_bitmap_words,
                         uint32_t *out_depth);
+/* Graph::traverse, BreadthFirst, WITH its order (traversal.rs:216-261: `visits` in discovery order, one discovery edge per
+ * non-seed visit).  out_nodes / out_depths [capacity]: the visits, seeds first in their given order (duplicates collapse);
+ * out_parents[i] / out_edges[i] / out_against[i] describe the discovery edge of visit i: the node whose arc reached it, the
+ * index of the stored edge in the out_targets array handed to hvx_csr_import, and whether the edge was followed against its
+ * stored direction (TraversedEdge::traversal_direction); UINT64_MAX / 0 for seeds.  Arc order as model.rs:635-725 (rows by
+ * neighbour; direction Both merges the outgoing and incoming rows by neighbour, the outgoing arc first on equal
+ * neighbours -- the reference breaks that tie by graphify key and edge id, which only decides WHICH of two edges to the
+ * same node is reported).  Needs outgoing rows sorted by target (HVX_ERR_UNSUPPORTED otherwise) and < 2^31 edges.
+ * *out_count = visits; more than `capacity` => HVX_ERR_INVARIANT with *out_count set.  Any output array may be NULL. */
+int hvx_traverse_ordered(const hvx_csr *, const uint64_t *seeds, uint32_t n_seeds, uint32_t max_depth, uint32_t direction,
+                         const uint32_t *allowed_label_ids, uint32_t n_labels, uint32_t hub_degree, uint64_t capacity,
+                         uint64_t *out_nodes, uint32_t *out_depths, uint64_t *out_parents, uint64_t *out_edges,
+                         uint32_t *out_against, uint64_t *out_count);
 /* One interpreter `expand` hop (crates/db/src/execution/interpreter/access/expand.rs:16-80): the
  * union of the neighbours of every input row (an input row that is itself a neighbour of another
  * input row IS included) as the candidate bitmap handed to the restricted vector search. */

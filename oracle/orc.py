@@ -597,3 +597,68 @@ def breadth_first_depths(n, out_offsets, out_targets, labels, seeds, max_depth, 
                 depth[v] = depth[u] + 1
                 queue.append(v)
     return depth
+
+
+def breadth_first(n, out_offsets, out_targets, labels, seeds, max_depth, direction=2, allowed_labels=(), hub_degree=0):
+    """`Graph::traverse` with TraversalStrategy::BreadthFirst, restated with its ORDER: crates/graph-algorithms/src/algorithms/
+    traversal.rs:197-261 (seeds deduplicated in first-occurrence order, FIFO queue, a node is marked and recorded when it is
+    first reached, the arc that reached it is its discovery edge), :311-318 (`suppresses_hub`), and the arc order of
+    model.rs:635-725: a node's outgoing row, its incoming row, or -- direction Both -- the two rows merged by neighbour
+    (compare_arcs' first key; rows are sorted by it, node indexes follow node ids), the outgoing arc first on equal neighbours
+    (the reference breaks that tie by graphify key, then edge id -- both arcs reach the same node, so only WHICH of the two
+    edges is reported can differ), incoming self-loops skipped.  The incoming row of v lists its sources in ascending order,
+    parallel edges in their outgoing-row order.
+    Returns (visits, edges): visits = [(node, depth)] in discovery order; edges[i] belongs to the i-th non-seed visit:
+    (current node, index of the stored edge in the outgoing arc array, 0 = followed along the edge / 1 = against it)."""
+    from collections import deque
+    out = [[] for _ in range(n)]
+    inc = [[] for _ in range(n)]
+    for u in range(n):
+        for a in range(int(out_offsets[u]), int(out_offsets[u + 1])):
+            lab = None if labels is None else int(labels[a])
+            out[u].append((int(out_targets[a]), lab, a))
+    for u in range(n):
+        for (v, lab, a) in out[u]:
+            inc[v].append((u, lab, a))
+    for u in range(n):
+        assert all(out[u][i][0] <= out[u][i + 1][0] for i in range(len(out[u]) - 1)), "outgoing rows must be sorted by neighbour"
+
+    def arcs(u):
+        if direction == 0:
+            return [(v, lab, a, 0) for (v, lab, a) in out[u]]
+        if direction == 1:
+            return [(v, lab, a, 1) for (v, lab, a) in inc[u]]
+        merged, i, j = [], 0, 0
+        o, c = out[u], [x for x in inc[u] if x[0] != u]          # incoming self-loops are skipped (model.rs:691-696)
+        while i < len(o) or j < len(c):
+            if j >= len(c) or (i < len(o) and o[i][0] <= c[j][0]):
+                merged.append(o[i] + (0,)); i += 1
+            else:
+                merged.append(c[j] + (1,)); j += 1
+        return merged
+
+    depth, visits, edges, seed_set, queue = {}, [], [], set(), deque()
+    for s in seeds:
+        s = int(s)
+        if not 0 <= s < n:
+            raise KeyError(f"unknown node {s}")
+        if s not in depth:
+            depth[s] = 0
+            seed_set.add(s)
+            queue.append(s)
+            visits.append((s, 0))
+    allowed = set(int(x) for x in allowed_labels)
+    while queue:
+        u = queue.popleft()
+        if depth[u] >= max_depth:
+            continue
+        if u not in seed_set and hub_degree and len(out[u]) + len(inc[u]) >= hub_degree:
+            continue
+        for (v, lab, a, against) in arcs(u):
+            if (allowed and lab not in allowed) or v in depth:
+                continue
+            depth[v] = depth[u] + 1
+            queue.append(v)
+            visits.append((v, depth[v]))
+            edges.append((u, a, against))
+    return visits, edges

@@ -22,14 +22,14 @@ run() { # name, env..., -- args
 FP8="--rows 2000000 --dim 1536 --batch 4096 --dtype fp8 --steps 3"
 B16="--rows 1000000 --dim 768 --batch 1024 --dtype bf16 --steps 5"
 F32="--rows 1000000 --dim 768 --batch 1024 --dtype f32 --steps 5"
-run fp8_tile_pipe -- $FP8
-run fp8_tile_nopipe HVX_FLAT_TILE_PIPE=0 -- $FP8
-run fp8_old HVX_FLAT_NO_TILE=1 -- $FP8
-run bf16_tile_pipe -- $B16
-run bf16_tile_nopipe HVX_FLAT_TILE_PIPE=0 -- $B16
-run bf16_old HVX_FLAT_NO_TILE=1 -- $B16
-run f32_tile_pipe -- $F32
-run f32_old HVX_FLAT_NO_TILE=1 -- $F32
+if [ -z "$ONLY_PROFILE" ]; then
+run fp8_ring -- $FP8
+run fp8_2buf HVX_FLAT_TILE_RING=0 -- $FP8
+run bf16_ring -- $B16
+run bf16_2buf HVX_FLAT_TILE_RING=0 -- $B16
+run f32_ring -- $F32
+run f32_2buf HVX_FLAT_TILE_RING=0 -- $F32
+fi
 for leg in fp8 bf16 f32; do
   case $leg in fp8) A="$FP8";; bf16) A="$B16";; f32) A="$F32";; esac
   rm -rf /tmp/prof_$leg

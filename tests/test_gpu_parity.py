@@ -1120,13 +1120,14 @@ def test_exact_scan_through_the_256_tile_kernel(orc, hv, monkeypatch, capfd, dty
     monkeypatch.setenv("HVX_FLAT_CHUNK", "2048")
     monkeypatch.setenv("HVX_FLAT_DEBUG", "1")
     capfd.readouterr()
-    gid, gsc, gcnt, _ = gix.flat_search_batch(q, k)
+    gid, gsc, gcnt, _, gst = gix.flat_search_batch(q, k, per_query_status=True)
     err = capfd.readouterr().err
     assert "256 x 256 tiles" in err, err                              # the kernel ran
     monkeypatch.setenv("HVX_FLAT_NO_TILE", "1")
-    oid_, osc_, ocnt_, _ = gix.flat_search_batch(q, k)
+    oid_, osc_, ocnt_, _, ost_ = gix.flat_search_batch(q, k, per_query_status=True)
     assert "256 x 256" not in capfd.readouterr().err
     assert gid.tolist() == oid_.tolist() and bits(gsc).tolist() == bits(osc_).tolist() and gcnt.tolist() == ocnt_.tolist()
+    assert gst.tolist() == ost_.tolist() and gst[b - 1] == 2 and not gst[: b - 1].any()
     assert gcnt[b - 1] == 0 and gcnt[0] == k
     kern = orc.K_AVX_FMA_HW if dtype_name == "f32" else None
     for qi in list(range(0, b - 1, max(1, b // 16))) + [b - 2]:

@@ -311,6 +311,26 @@ def test_breadth_first_returns_depth_order(orc):
     assert len(d) - 1 == 3                                   # three discovery edges
 
 
+def test_breadth_first_visit_order_and_discovery_edges(orc):
+    """traversal.rs:597-615 with the ORDER the reference asserts: a, b, c, hub at depths 0, 1, 2, 2 and three discovery edges;
+    the ordered restatement agrees with the order-free one on every option the other tests use."""
+    names, idx, n, off, tgt = _reference_traversal_graph()
+    visits, edges = orc.breadth_first(n, off, tgt, None, [idx["a"]], 2, direction=2)
+    assert [(names[v], d) for v, d in visits] == [("a", 0), ("b", 1), ("c", 2), ("hub", 2)]
+    assert len(edges) == 3
+    assert [(names[u], names[int(tgt[a])], against) for u, a, against in edges] == [("a", "b", 0), ("b", "c", 0), ("b", "hub", 0)]
+    # the same graph walked from the far end follows the stored edges backwards
+    visits, edges = orc.breadth_first(n, off, tgt, None, [idx["c"]], 2, direction=2)
+    assert [(names[v], d) for v, d in visits] == [("c", 0), ("b", 1), ("a", 2), ("hub", 2)]
+    assert [against for _, _, against in edges] == [1, 1, 0]
+    for seeds, md, direction, hub in [([idx["a"]], 4, 2, 4), ([idx["hub"]], 1, 2, 4), ([idx["b"], idx["b"]], 0, 2, 0), ([idx["b"]], 3, 0, 0),
+                                      ([idx["leaf"], idx["a"]], 3, 1, 0)]:
+        visits, edges = orc.breadth_first(n, off, tgt, None, seeds, md, direction=direction, hub_degree=hub)
+        assert dict(visits) == orc.breadth_first_depths(n, off, tgt, None, seeds, md, direction=direction, hub_degree=hub)
+        assert len(edges) == len(visits) - len(set(seeds))
+        assert [d for _, d in visits] == sorted(d for _, d in visits)
+
+
 def test_traversal_includes_but_does_not_expand_non_seed_hubs(orc):
     names, idx, n, off, tgt = _reference_traversal_graph()
     d = orc.breadth_first_depths(n, off, tgt, None, [idx["a"]], 4, direction=2, hub_degree=4)

@@ -253,6 +253,9 @@ def lib():
     L.hvx_csr_free.argtypes = [_vp]
     L.hvx_traverse_filter.restype = C.c_int
     L.hvx_traverse_filter.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp]
+    L.hvx_traverse_ordered.restype = C.c_int
+    L.hvx_traverse_ordered.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint32, C.c_uint32, C.c_uint64,
+                                       _vp, _vp, _vp, _vp, _vp, _vp]
     L.hvx_expand_filter.restype = C.c_int
     L.hvx_expand_filter.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32, _vp]
     _lib = L
@@ -741,6 +744,23 @@ class Graph:
         _check(lib().hvx_traverse_filter(self._h, _ptr(s), s.size, max_depth, direction, _ptr(lab), lab.size,
                                          hub_degree, 1 if include_seeds else 0, _ptr(words), _ptr(depth)))
         return words, depth[: self.n]
+
+    def traverse_ordered(self, seeds, max_depth, direction=DIR_BOTH, allowed_labels=(), hub_degree=0):
+        """Graph::traverse (BreadthFirst) with its visit order and discovery edges (traversal.rs:216-261):
+        returns (visits, edges) -- visits = [(node, depth)] in discovery order, edges[i] = (node whose arc reached the
+        i-th non-seed visit, index of the stored edge in the imported out_targets, 1 if followed against its direction)."""
+        s = np.ascontiguousarray(seeds, dtype=np.uint64)
+        lab = np.ascontiguousarray(list(allowed_labels), dtype=np.uint32)
+        cap = max(self.n, 1)
+        nodes = np.zeros(cap, np.uint64); depths = np.zeros(cap, np.uint32); parents = np.zeros(cap, np.uint64)
+        edges = np.zeros(cap, np.uint64); against = np.zeros(cap, np.uint32)
+        cnt = C.c_uint64(0)
+        _check(lib().hvx_traverse_ordered(self._h, _ptr(s), s.size, max_depth, direction, _ptr(lab), lab.size, hub_degree, cap,
+                                          _ptr(nodes), _ptr(depths), _ptr(parents), _ptr(edges), _ptr(against), C.byref(cnt)))
+        c = cnt.value
+        visits = [(int(nodes[i]), int(depths[i])) for i in range(c)]
+        disc = [(int(parents[i]), int(edges[i]), int(against[i])) for i in range(c) if parents[i] != np.uint64(0xFFFFFFFFFFFFFFFF)]
+        return visits, disc
 
     def expand(self, rows, direction=DIR_OUT, allowed_labels=()):
         s = np.ascontiguousarray(rows, dtype=np.uint64)

@@ -341,6 +341,42 @@ def test_traverse_and_expand_match_reference_semantics(orc, hv):
         g.traverse([n + 5], 1)
 
 
+def test_ordered_traversal_matches_the_reference_visit_order_and_discovery_edges(orc, hv):
+    """hvx_traverse_ordered vs the oracle's ordered restatement of breadth_first (traversal.rs:216-261, model.rs:635-725):
+    the visits in discovery order with their depths, and for every non-seed visit the arc that reached it (which node,
+    which stored edge, along or against it) -- multigraph rows (parallel edges with different labels), self-loops,
+    every direction, label allow-sets, the hub policy, several seeds in a given order, depth caps incl. unbounded."""
+    names = ["a", "b", "c", "hub", "leaf", "leaf2", "leaf3"]             # the reference's own fixture first (traversal.rs:576-615)
+    e = [(0, 1), (1, 2), (1, 3), (3, 4), (3, 5), (3, 6)]
+    off = np.zeros(8, np.uint64); tgt = np.array([t for _, t in e], np.uint64)
+    for s_, _ in e:
+        off[s_ + 1:] += 1
+    g = hv.Graph(7, off, tgt, None)
+    visits, edges = g.traverse_ordered([0], 2)
+    assert [(names[v], d) for v, d in visits] == [("a", 0), ("b", 1), ("c", 2), ("hub", 2)] and len(edges) == 3
+    assert (visits, edges) == orc.breadth_first(7, off.astype(np.int64), tgt, None, [0], 2)
+    rng = np.random.default_rng(12)
+    for n, deg, nlab in [(300, 4, 3), (2000, 6, 4), (5000, 2, 1), (64, 40, 2)]:
+        rows = [np.sort(rng.integers(0, n, rng.integers(0, 2 * deg + 1))) for _ in range(n)]   # sorted rows, parallel edges, self-loops
+        off = np.zeros(n + 1, np.uint64); off[1:] = np.cumsum([len(r) for r in rows])
+        tgt = np.concatenate(rows).astype(np.uint64) if off[-1] else np.zeros(0, np.uint64)
+        lab = rng.integers(0, nlab, int(off[-1])).astype(np.uint32)
+        g = hv.Graph(n, off, tgt, lab)
+        cases = [([3], 2, 0, [], 0), ([3, 7, 3, 1], 3, 2, [1, 2], 0), ([10, 11], 4, 1, [], 2 * deg + 3), ([0], 0, 2, [], 0),
+                 ([5, 6, 7], 60, 0, [0], 0), ([n - 1], 1000, 2, [], 0), ([2, 1], 5, 2, [0], 3 * deg)]
+        for seeds, md, direction, allowed, hub in cases:
+            visits, edges = g.traverse_ordered(seeds, md, direction, allowed, hub)
+            rv, re_ = orc.breadth_first(n, off.astype(np.int64), tgt, lab, seeds, md, direction, allowed, hub)
+            assert visits == rv, f"n={n} case {(seeds, md, direction, allowed, hub)}: visit order differs"
+            assert edges == re_, f"n={n} case {(seeds, md, direction, allowed, hub)}: discovery edges differ"
+    unsorted = hv.Graph(3, np.array([0, 2, 2, 2], np.uint64), np.array([2, 1], np.uint64), None)
+    with pytest.raises(hv.HelixDbError) as ex:                            # rows that are not in the reference's order fail loudly
+        unsorted.traverse_ordered([0], 1)
+    assert ex.value.status == hv.ERR_UNSUPPORTED
+    with pytest.raises(hv.HelixDbError):
+        g.traverse_ordered([10**6], 1)
+
+
 def test_merge_topk_device_matches_candidate_order(orc, hv):
     """hvx_merge_topk_device (the N>1 merge after the all-gather) vs the Candidate-order checker,
     including equal scores on different shards, short lists and empty shards."""

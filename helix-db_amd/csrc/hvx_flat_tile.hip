@@ -414,6 +414,193 @@ __global__ __launch_bounds__(512) void flat_tile256_ring_kernel(MfmaArgs a, floa
     tile_epilogue<FP8>(a, acc, lds, q0, r0, wm, wn, tid, xmax2, wg_overflow);
 }
 
+// ---- the pipelined build: the ring of the build above, plus fragment registers double-buffered ACROSS the stage barrier.
+// PMC of the two builds above (profiles/r02g_*): L2 hit rate 0.91, no LDS bank conflicts, LDS array 15 % busy, and still only
+// 36 % of the matrix-core cycles used -- every wavefront reads its fragments right after the barrier (all eight at once),
+// waits for them, and only then issues MFMAs; both wavefronts of a SIMD do so in lock step, so the matrix core idles
+// during every read phase (42 % of the wave cycles parked in s_waitcnt / s_barrier).  Here the unit of the pipeline is the
+// 16-deep MFMA step u: the fragments of step u + 1 are requested BEFORE the eight MFMAs of step u are issued, also when
+// step u + 1 belongs to the next stage -- the counted vmcnt wait, the barrier and the refill of the buffer that has just
+// been read out then sit in front of those reads.  The ring holds NBUF stages, NBUF - 1 of them ahead of the matrix core.
+// ds_read_b128 as inline asm: the compiler then neither sees an LDS load that "may alias" the LDS-DMA copies in flight (it
+// answers that with s_waitcnt vmcnt(0), draining the ring -- it did so for the fp8 code reads) nor places its own lgkmcnt
+// waits; the kernel states both waits itself, each followed by a sched_barrier (an MFMA may not be hoisted over them).
+template <int OFF>
+__device__ __forceinline__ uint4 lds_read16(uint32_t addr) {
+    uint4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ void wait_lgkm0() {
+    __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0), nothing else
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(512) void flat_tile256_pipe_kernel(MfmaArgs a, float xmax2, uint32_t *wg_overflow) {
+    constexpr bool FP8 = KIND == 1;
+    constexpr int KS = FP8 ? 64 : 32;               // depth of a stage
+    constexpr int SPS = KS / 16;                    // MFMA steps per stage
+    constexpr int AROWB = KS * 2, BROWB = 64;       // bytes per tile row and stage: 64 / 64 (bf16), 128 / 64 (fp8)
+    constexpr int ASTAGE = kTM * AROWB, STAGE = ASTAGE + kTN * BROWB;
+    constexpr int NBUF = FP8 ? 3 : 4;
+    constexpr int GA = AROWB / 32, GB = BROWB / 32, G = GA + GB; // 1-KB copies per wave and stage
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NBUF * STAGE];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    uint32_t qt, rt;
+    if (!tile_coords(a, qt, rt)) return;
+    const uint32_t q0 = qt * kTM, r0 = rt * kTN;
+
+    const unsigned char *gA[GA], *gB[GB]; // staging addresses as in the ring build
+#pragma unroll
+    for (int t = 0; t < GA; ++t) {
+        uint32_t row, slot;
+        if (AROWB == 64) { row = (uint32_t)(32 * wave + 16 * t + (lane >> 2)); slot = (uint32_t)(lane & 3) ^ ((row >> 2) & 3u); }
+        else { row = (uint32_t)(32 * wave + 8 * t + (lane >> 3)); slot = (uint32_t)(lane & 7) ^ ((row >> 1) & 7u); }
+        gA[t] = reinterpret_cast<const unsigned char *>(a.qhi) + (size_t)(q0 + row) * a.dim * 2 + slot * 16;
+    }
+#pragma unroll
+    for (int t = 0; t < GB; ++t) {
+        const uint32_t row = (uint32_t)(32 * wave + 16 * t + (lane >> 2));
+        const uint32_t slot = (uint32_t)(lane & 3) ^ ((row >> 2) & 3u);
+        uint32_t rloc = r0 + row;
+        if (rloc >= a.nrows) rloc = a.nrows - 1;
+        const size_t node = a.subset ? a.subset[a.row0 + rloc] : (size_t)a.row0 + rloc;
+        gB[t] = reinterpret_cast<const unsigned char *>(a.rows) + node * a.dim * (FP8 ? 1 : 2) + slot * 16;
+    }
+    auto issue_stage = [&](uint32_t s) {
+        unsigned char *sA = lds + (s % NBUF) * STAGE + wave * (32 * AROWB);
+        unsigned char *sB = lds + (s % NBUF) * STAGE + ASTAGE + wave * (32 * BROWB);
+#pragma unroll
+        for (int t = 0; t < GA; ++t) HVX_GLDS16(gA[t] + s * (uint32_t)AROWB, sA + t * 1024);
+#pragma unroll
+        for (int t = 0; t < GB; ++t) HVX_GLDS16(gB[t] + s * (uint32_t)BROWB, sB + t * 1024);
+    };
+    const int fr = lane & 31, h = lane >> 5;
+    int off128[4], off64[2];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) off128[kk] = fr * 128 + (((2 * kk + h) ^ ((fr >> 1) & 7)) << 4);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) off64[jj] = fr * 64 + (((2 * jj + h) ^ ((fr >> 2) & 3)) << 4);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const uint32_t nstage = a.dim / (uint32_t)KS;
+    // stage s has landed once at most the copies of the younger stages in flight (<= NBUF - 2 of them) are outstanding
+    auto wait_stage = [&](uint32_t s) {
+        const uint32_t younger = nstage - 1u - s < (uint32_t)(NBUF - 2) ? nstage - 1u - s : (uint32_t)(NBUF - 2);
+        if (younger >= 2u) wait_vmcnt<2 * G>();
+        else if (younger == 1u) wait_vmcnt<G>();
+        else wait_vmcnt<0>();
+    };
+    uint4 c8[2]; // fp8: the codes of both steps of a pair
+    // request the fragments of step kk of the stage in buffer `buf` (fp8: the row codes of even steps come with their odd partner's)
+    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(lds);
+    const uint32_t baseA = lds0 + (uint32_t)(wm * (128 * AROWB)), baseB = lds0 + (uint32_t)(ASTAGE + wn * (64 * BROWB));
+    auto read_raw = [&](uint32_t buf, int kk, bf16x8 (&fa)[4], bf16x8 (&fb)[2]) {
+        const uint32_t pa = baseA + buf * (uint32_t)STAGE + (uint32_t)(FP8 ? off128[kk] : off64[kk]);
+        fa[0] = __builtin_bit_cast(bf16x8, lds_read16<0>(pa));
+        fa[1] = __builtin_bit_cast(bf16x8, lds_read16<32 * AROWB>(pa));
+        fa[2] = __builtin_bit_cast(bf16x8, lds_read16<64 * AROWB>(pa));
+        fa[3] = __builtin_bit_cast(bf16x8, lds_read16<96 * AROWB>(pa));
+        if (FP8) {
+            if ((kk & 1) == 0) {
+                const uint32_t pb = baseB + buf * (uint32_t)STAGE + (uint32_t)off64[kk >> 1];
+                c8[0] = lds_read16<0>(pb);
+                c8[1] = lds_read16<32 * 64>(pb);
+            }
+        } else {
+            const uint32_t pb = baseB + buf * (uint32_t)STAGE + (uint32_t)off64[kk];
+            fb[0] = __builtin_bit_cast(bf16x8, lds_read16<0>(pb));
+            fb[1] = __builtin_bit_cast(bf16x8, lds_read16<32 * 64>(pb));
+        }
+    };
+    // fp8: 8 codes -> 8 f32 (exact) -> their high halves = 8 bf16 (exact); issued between the MFMAs of the step before
+    auto widen = [&](int kk, bf16x8 (&fb)[2]) {
+        if (!FP8) return;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t w0 = (kk & 1) ? c8[j].z : c8[j].x, w1 = (kk & 1) ? c8[j].w : c8[j].y;
+            const f32x2 a01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w0, false), a23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w0, true);
+            const f32x2 b01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w1, false), b23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w1, true);
+            uint4 wv;
+            wv.x = __builtin_amdgcn_perm(__float_as_uint(a01[1]), __float_as_uint(a01[0]), 0x07060302u);
+            wv.y = __builtin_amdgcn_perm(__float_as_uint(a23[1]), __float_as_uint(a23[0]), 0x07060302u);
+            wv.z = __builtin_amdgcn_perm(__float_as_uint(b01[1]), __float_as_uint(b01[0]), 0x07060302u);
+            wv.w = __builtin_amdgcn_perm(__float_as_uint(b23[1]), __float_as_uint(b23[0]), 0x07060302u);
+            fb[j] = __builtin_bit_cast(bf16x8, wv);
+        }
+    };
+    // the eight MFMAs of a step in two halves, so that `widen` of the next step can sit between them
+    auto mfma4 = [&](int half, const bf16x8 (&fa)[4], const bf16x8 (&fb)[2]) {
+#pragma unroll
+        for (int i = 2 * half; i < 2 * half + 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    };
+
+#pragma unroll
+    for (int s = 0; s < NBUF; ++s)
+        if ((uint32_t)s < nstage) issue_stage((uint32_t)s);
+    bf16x8 fa0[4], fb0[2], fa1[4], fb1[2];
+    {   // stage 0 has landed when the NBUF - 1 younger ones are all that is outstanding
+        const uint32_t younger = nstage - 1u < (uint32_t)(NBUF - 1) ? nstage - 1u : (uint32_t)(NBUF - 1);
+        if (younger >= 3u) wait_vmcnt<3 * G>();
+        else if (younger == 2u) wait_vmcnt<2 * G>();
+        else if (younger == 1u) wait_vmcnt<G>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        read_raw(0, 0, fa0, fb0);
+        if (FP8) { wait_lgkm0(); widen(0, fb0); }
+    }
+    for (uint32_t s = 0; s < nstage; ++s) {
+        const uint32_t buf = s % NBUF;
+#pragma unroll
+        for (int kk = 0; kk < SPS; kk += 2) {
+            // step kk (registers 0) under the reads of step kk + 1 (registers 1).  The wait is for the reads of registers 0,
+            // requested eight MFMAs ago: stated here, before the new requests, it costs nothing
+            wait_lgkm0();
+            read_raw(buf, kk + 1, fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma4(0, fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            widen(kk + 1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma4(1, fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            // step kk + 1 (registers 1) under the reads of step kk + 2 (registers 0), which may open the next stage
+            const bool more = kk + 2 < SPS || s + 1 < nstage;
+            wait_lgkm0(); // registers 1
+            if (kk + 2 < SPS) {
+                read_raw(buf, kk + 2, fa0, fb0);
+            } else if (s + 1 < nstage) {
+                wait_stage(s + 1);            // this wave has read stage s out completely (the wait above), its copies of stage s + 1 have landed
+                __builtin_amdgcn_s_barrier(); // everyone's have; the buffer of stage s is free
+                if (s + (uint32_t)NBUF < nstage) issue_stage(s + (uint32_t)NBUF);
+                read_raw((s + 1) % NBUF, 0, fa0, fb0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma4(0, fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (FP8 && more) { // the codes of the next step pair were requested four MFMAs ago
+                wait_lgkm0();
+                widen(kk + 2 < SPS ? kk + 2 : 0, fb0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma4(1, fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    tile_epilogue<FP8>(a, acc, lds, q0, r0, wm, wn, tid, xmax2, wg_overflow);
+}
+
 hipError_t launch_flat_tile256(const MfmaArgs &a, int kind, uint32_t bpad, float xmax2, uint32_t *wg_overflow, hipStream_t s) {
     if (a.nrows == 0) return hipSuccess;
     if (a.dim % 64u != 0u || bpad % (uint32_t)kTM != 0u) return hipErrorInvalidValue;
@@ -425,7 +612,13 @@ hipError_t launch_flat_tile256(const MfmaArgs &a, int kind, uint32_t bpad, float
     t.sup_qblocks = (t.nq_tiles + t.sup_q - 1) / t.sup_q;
     const uint32_t rblocks = (t.nr_tiles + 8u * t.sup_r - 1) / (8u * t.sup_r);
     const dim3 grid(8u * rblocks * t.sup_qblocks * t.sup_r * t.sup_q);
-    static const bool ring = [] { const char *e = getenv("HVX_FLAT_TILE_RING"); return !e || e[0] != '0'; }();
+    static const int build = [] { const char *e = getenv("HVX_FLAT_TILE_BUILD"); return e ? atoi(e) : 2; }(); // 0: two buffers, 1: ring, 2: pipelined ring
+    if (build >= 2) {
+        if (kind == 1) hipLaunchKernelGGL((flat_tile256_pipe_kernel<1>), grid, dim3(512), 0, s, t, xmax2, wg_overflow);
+        else hipLaunchKernelGGL((flat_tile256_pipe_kernel<0>), grid, dim3(512), 0, s, t, xmax2, wg_overflow);
+        return hipGetLastError();
+    }
+    const bool ring = build == 1;
     if (ring) {
         if (kind == 1) hipLaunchKernelGGL((flat_tile256_ring_kernel<1>), grid, dim3(512), 0, s, t, xmax2, wg_overflow);
         else hipLaunchKernelGGL((flat_tile256_ring_kernel<0>), grid, dim3(512), 0, s, t, xmax2, wg_overflow);

@@ -28,6 +28,7 @@ struct MfmaArgs {
     uint32_t nq_tiles, nr_tiles, group_tiles;
     // 256 x 256 kernel: XCD-aware super-tiles (hvx_flat_tile.hip)
     uint32_t sup_q, sup_r, sup_qblocks;
+    uint32_t ablate; // measurement only (HVX_FLAT_TILE_ABLATE, two-buffer build): 1 no operand copies after stage 0, 2 no MFMAs, 4 no epilogue
 };
 
 // 256 x 256 filtered contraction (hvx_flat_tile.hip).  kind: 0 = bf16 rows (a bf16 index, or the bf16 shadow of an f32

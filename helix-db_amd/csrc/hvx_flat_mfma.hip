@@ -636,7 +636,7 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
         fa.ix = d; fa.queries = d_queries; fa.qstatus = ix->d_qstatus; fa.qhdr = ix->d_qhdr; fa.subset = d_subset;
         fa.n_rows = n; fa.dist = ix->f_dist; fa.chunk_ld = chunk; fa.b = b; fa.k = kc;
         fa.top_scores = ix->f_top_s; fa.top_ids = ix->f_top_i; fa.top_counts = ix->f_top_c;
-        MfmaArgs ma;
+        MfmaArgs ma{};
         ma.qhi = ix->m_qhi; ma.qlo = ix->m_qlo; ma.subset = d_subset;
         ma.rows = f32 ? (const void *)d.vec : (fp8 ? (const void *)d.vec8 : (const void *)d.vecb);
         ma.rowscale = d.rowscale;

@@ -54,7 +54,7 @@ __device__ __forceinline__ bool tile_coords(const MfmaArgs &a, uint32_t &qt, uin
 // ---- epilogue shared by both builds of the kernel.  acc = C[m = query][n = row] of this wavefront's 128 x 64 block.
 template <bool FP8>
 __device__ __forceinline__ void tile_epilogue(const MfmaArgs &a, f32x16 (&acc)[4][2], unsigned char *lds, uint32_t q0, uint32_t r0, int wm,
-                                              int wn, int tid, float xmax2, uint32_t *wg_overflow) {
+                                              int wn, int tid, float xmax2, uint32_t *wg_overflow) { // 256 or 512 threads
     const int lane = tid & 63, fr = lane & 31, h = lane >> 5;
     // ---- epilogue.  C[m = query][n = row]: lane holds n = lane & 31, m = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
     __syncthreads(); // the stage buffers are free
@@ -114,7 +114,7 @@ __device__ __forceinline__ void tile_epilogue(const MfmaArgs &a, f32x16 (&acc)[4
         if (tid == 0) atomicOr(wg_overflow, 1u);
         cnt = kWgList;
     }
-    for (uint32_t t = (uint32_t)tid; t < cnt; t += 512u) {
+    for (uint32_t t = (uint32_t)tid; t < cnt; t += blockDim.x) {
         const uint32_t code = sLc[t];
         const uint32_t qq = q0 + (code >> 8), rloc = r0 + (code & 255u);
         if (qq >= a.b || rloc >= a.nrows) continue;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(512) void flat_tile256_kernel(MfmaArgs a, float xma
         const int buf = (int)(s & 1u);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces of stage s have landed ...
         __syncthreads();                                  // ... everyone's have, and buffer buf ^ 1 is no longer being read
-        if (s + 1 < nstage) issue_stage((s + 1) * 128u, (s + 1) * (uint32_t)ROWB, buf ^ 1);
+        if (s + 1 < nstage && !(a.ablate & 1u)) issue_stage((s + 1) * 128u, (s + 1) * (uint32_t)ROWB, buf ^ 1);
         const unsigned char *sA = lds + buf * STAGE + wm * (128 * 128);
         const unsigned char *sB = lds + buf * STAGE + kAStage + wn * (64 * ROWB);
         // fragments of step kk + 1 are read (fp8: and widened) while the matrix core works on step kk
@@ -252,18 +252,43 @@ __global__ __launch_bounds__(512) void flat_tile256_kernel(MfmaArgs a, float xma
         for (int kk = 0; kk < 4; kk += 2) {
             load_frags(kk + 1, fa1, fb1);
             if (PIPE) __builtin_amdgcn_sched_barrier(0); // keep the reads of the next step ahead of this step's MFMAs
+            if (a.ablate & 2u) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa0[i]));
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[i], fb0[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(fb0[j]));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[i], fb0[j], acc[i][j], 0, 0, 0);
+            }
             if (PIPE) __builtin_amdgcn_sched_barrier(0);
             if (kk + 2 < 4) load_frags(kk + 2, fa0, fb0);
             if (PIPE) __builtin_amdgcn_sched_barrier(0);
+            if (a.ablate & 2u) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa1[i]));
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[i], fb1[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(fb1[j]));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[i], fb1[j], acc[i][j], 0, 0, 0);
+            }
         }
+    }
+    if (a.ablate & 4u) { // measurement builds only (HVX_FLAT_TILE_ABLATE): keep the accumulators alive, skip the epilogue
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sum += acc[i][j][e];
+        if (sum == 123456.789f) *wg_overflow = 2u;
+        return;
     }
     tile_epilogue<FP8>(a, acc, lds, q0, r0, wm, wn, tid, xmax2, wg_overflow);
 }
@@ -601,6 +626,153 @@ __global__ __launch_bounds__(512) void flat_tile256_pipe_kernel(MfmaArgs a, floa
     tile_epilogue<FP8>(a, acc, lds, q0, r0, wm, wn, tid, xmax2, wg_overflow);
 }
 
+// ---- the two-workgroups-per-CU build.  Ablation of the 512-thread builds (profiles/r02g_ablate_bf16.txt: MFMAs only 0.35 ms,
+// + fragment reads and barriers 0.24, + operand copies 0.17, + epilogue 0.17 = the 0.93 ms measured) showed that NOTHING overlaps
+// there: one workgroup per CU means all eight wavefronts -- both wavefronts of every SIMD -- are in the same phase at the
+// same time, and neither a deeper copy ring nor fragment prefetch across the barrier changes that.  Here a workgroup is
+// four wavefronts (one per SIMD, 2 x 2, each still 128 queries x 64 rows) on a 256 x 128 tile with a ring of three 32- or
+// 64-deep stages (72 KB), so a CU holds TWO independent workgroups: while one waits at its barrier, reads fragments, starts
+// a tile or runs its epilogue, the other one's MFMAs have the matrix cores.
+template <int LGKM>
+__device__ __forceinline__ void wait_lgkm() {
+    __builtin_amdgcn_s_waitcnt(0xC07F | (LGKM << 8));
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256, 2) void flat_tile2_kernel(MfmaArgs a, float xmax2, uint32_t *wg_overflow) {
+    constexpr bool FP8 = KIND == 1;
+    constexpr int TNR = 128;                        // rows per workgroup (queries: kTM = 256)
+    constexpr int KS = FP8 ? 64 : 32, SPS = KS / 16;
+    constexpr int AROWB = KS * 2, BROWB = 64;       // bytes per tile row and stage
+    constexpr int ASTAGE = kTM * AROWB, STAGE = ASTAGE + TNR * BROWB; // 24 KB (bf16) / 40 KB (fp8)
+    constexpr int NBUF = FP8 ? 2 : 3;               // 72 KB / 80 KB per workgroup
+    constexpr int GA = AROWB / 16, GB = 2, G = GA + GB; // 1-KB copies per wave and stage: queries 64 rows, rows 32 rows per wave
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NBUF * STAGE];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    uint32_t qt, rt;
+    if (!tile_coords(a, qt, rt)) return;
+    const uint32_t q0 = qt * kTM, r0 = rt * TNR;
+
+    // staging: wave w copies query rows 64 w .. 64 w + 63 and tile rows 32 w .. 32 w + 31 (layouts as in the ring build)
+    const unsigned char *gA[GA], *gB[GB];
+#pragma unroll
+    for (int t = 0; t < GA; ++t) {
+        uint32_t row, slot;
+        if (AROWB == 64) { row = (uint32_t)(64 * wave + 16 * t + (lane >> 2)); slot = (uint32_t)(lane & 3) ^ ((row >> 2) & 3u); }
+        else { row = (uint32_t)(64 * wave + 8 * t + (lane >> 3)); slot = (uint32_t)(lane & 7) ^ ((row >> 1) & 7u); }
+        gA[t] = reinterpret_cast<const unsigned char *>(a.qhi) + (size_t)(q0 + row) * a.dim * 2 + slot * 16;
+    }
+#pragma unroll
+    for (int t = 0; t < GB; ++t) {
+        const uint32_t row = (uint32_t)(32 * wave + 16 * t + (lane >> 2));
+        const uint32_t slot = (uint32_t)(lane & 3) ^ ((row >> 2) & 3u);
+        uint32_t rloc = r0 + row;
+        if (rloc >= a.nrows) rloc = a.nrows - 1;
+        const size_t node = a.subset ? a.subset[a.row0 + rloc] : (size_t)a.row0 + rloc;
+        gB[t] = reinterpret_cast<const unsigned char *>(a.rows) + node * a.dim * (FP8 ? 1 : 2) + slot * 16;
+    }
+    auto issue_stage = [&](uint32_t s) {
+        unsigned char *sA = lds + (s % NBUF) * STAGE + wave * (64 * AROWB);
+        unsigned char *sB = lds + (s % NBUF) * STAGE + ASTAGE + wave * (32 * BROWB);
+#pragma unroll
+        for (int t = 0; t < GA; ++t) HVX_GLDS16(gA[t] + s * (uint32_t)AROWB, sA + t * 1024);
+#pragma unroll
+        for (int t = 0; t < GB; ++t) HVX_GLDS16(gB[t] + s * (uint32_t)BROWB, sB + t * 1024);
+    };
+    const int fr = lane & 31, h = lane >> 5;
+    int off128[4], off64[2];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) off128[kk] = fr * 128 + (((2 * kk + h) ^ ((fr >> 1) & 7)) << 4);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) off64[jj] = fr * 64 + (((2 * jj + h) ^ ((fr >> 2) & 3)) << 4);
+    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(lds);
+    const uint32_t baseA = lds0 + (uint32_t)(wm * (128 * AROWB)), baseB = lds0 + (uint32_t)(ASTAGE + wn * (64 * BROWB));
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    uint4 c8[2];
+    auto read_raw = [&](uint32_t buf, int kk, bf16x8 (&fa)[4], bf16x8 (&fb)[2]) { // 6 reads (bf16; fp8 even steps) or 4 (fp8 odd steps)
+        const uint32_t pa = baseA + buf * (uint32_t)STAGE + (uint32_t)(FP8 ? off128[kk] : off64[kk]);
+        fa[0] = __builtin_bit_cast(bf16x8, lds_read16<0>(pa));
+        fa[1] = __builtin_bit_cast(bf16x8, lds_read16<32 * AROWB>(pa));
+        fa[2] = __builtin_bit_cast(bf16x8, lds_read16<64 * AROWB>(pa));
+        fa[3] = __builtin_bit_cast(bf16x8, lds_read16<96 * AROWB>(pa));
+        if (FP8) {
+            if ((kk & 1) == 0) {
+                const uint32_t pb = baseB + buf * (uint32_t)STAGE + (uint32_t)off64[kk >> 1];
+                c8[0] = lds_read16<0>(pb);
+                c8[1] = lds_read16<32 * 64>(pb);
+            }
+        } else {
+            const uint32_t pb = baseB + buf * (uint32_t)STAGE + (uint32_t)off64[kk];
+            fb[0] = __builtin_bit_cast(bf16x8, lds_read16<0>(pb));
+            fb[1] = __builtin_bit_cast(bf16x8, lds_read16<32 * 64>(pb));
+        }
+    };
+    auto widen = [&](int kk, bf16x8 (&fb)[2]) {
+        if (!FP8) return;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t w0 = (kk & 1) ? c8[j].z : c8[j].x, w1 = (kk & 1) ? c8[j].w : c8[j].y;
+            const f32x2 a01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w0, false), a23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w0, true);
+            const f32x2 b01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w1, false), b23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w1, true);
+            uint4 wv;
+            wv.x = __builtin_amdgcn_perm(__float_as_uint(a01[1]), __float_as_uint(a01[0]), 0x07060302u);
+            wv.y = __builtin_amdgcn_perm(__float_as_uint(a23[1]), __float_as_uint(a23[0]), 0x07060302u);
+            wv.z = __builtin_amdgcn_perm(__float_as_uint(b01[1]), __float_as_uint(b01[0]), 0x07060302u);
+            wv.w = __builtin_amdgcn_perm(__float_as_uint(b23[1]), __float_as_uint(b23[0]), 0x07060302u);
+            fb[j] = __builtin_bit_cast(bf16x8, wv);
+        }
+    };
+    auto mfma8 = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[2]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    };
+
+    const uint32_t nstage = a.dim / (uint32_t)KS;
+#pragma unroll
+    for (int s = 0; s < NBUF - 1; ++s)
+        if ((uint32_t)s < nstage) issue_stage((uint32_t)s);
+    bf16x8 fa0[4], fb0[2], fa1[4], fb1[2];
+    for (uint32_t s = 0; s < nstage; ++s) {
+        // stage s has landed when at most the copies of the younger stages in flight (NBUF - 2 of them) are outstanding
+        const uint32_t younger = nstage - 1u - s < (uint32_t)(NBUF - 2) ? nstage - 1u - s : (uint32_t)(NBUF - 2);
+        if (younger >= 1u) wait_vmcnt<G>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier(); // everyone's copies of stage s are in LDS; nobody still reads the buffer of stage s - 1
+        if (s + (uint32_t)(NBUF - 1) < nstage) issue_stage(s + (uint32_t)(NBUF - 1));
+        const uint32_t buf = s % NBUF;
+        read_raw(buf, 0, fa0, fb0);
+#pragma unroll
+        for (int kk = 0; kk < SPS; kk += 2) {
+            read_raw(buf, kk + 1, fa1, fb1);                  // step kk + 1 requested ...
+            if (FP8) wait_lgkm<4>(); else wait_lgkm<6>();      // ... step kk has arrived (fp8: with the codes of both steps)
+            widen(kk, fb0);
+            widen(kk + 1, fb1);                                // before the next pair's codes replace c8
+            mfma8(fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 2 < SPS) {
+                read_raw(buf, kk + 2, fa0, fb0);
+                wait_lgkm<6>();
+            } else {
+                wait_lgkm<0>();
+            }
+            mfma8(fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    tile_epilogue<FP8>(a, acc, lds, q0, r0, wm, wn, tid, xmax2, wg_overflow);
+}
+
 hipError_t launch_flat_tile256(const MfmaArgs &a, int kind, uint32_t bpad, float xmax2, uint32_t *wg_overflow, hipStream_t s) {
     if (a.nrows == 0) return hipSuccess;
     if (a.dim % 64u != 0u || bpad % (uint32_t)kTM != 0u) return hipErrorInvalidValue;
@@ -610,9 +782,19 @@ hipError_t launch_flat_tile256(const MfmaArgs &a, int kind, uint32_t bpad, float
     t.sup_q = std::min<uint32_t>(t.nq_tiles, 8u);
     t.sup_r = 32u / t.sup_q;
     t.sup_qblocks = (t.nq_tiles + t.sup_q - 1) / t.sup_q;
+    t.ablate = [] { const char *e = getenv("HVX_FLAT_TILE_ABLATE"); return e ? (uint32_t)atoi(e) : 0u; }();
     const uint32_t rblocks = (t.nr_tiles + 8u * t.sup_r - 1) / (8u * t.sup_r);
     const dim3 grid(8u * rblocks * t.sup_qblocks * t.sup_r * t.sup_q);
-    static const int build = [] { const char *e = getenv("HVX_FLAT_TILE_BUILD"); return e ? atoi(e) : 2; }(); // 0: two buffers, 1: ring, 2: pipelined ring
+    static const int build = [] { const char *e = getenv("HVX_FLAT_TILE_BUILD"); return e ? atoi(e) : 3; }(); // 0: two buffers, 1: ring, 2: pipelined ring, 3: two workgroups per CU
+    if (build >= 3) { // 256 x 128 tiles, 256 threads, two workgroups per CU: super-tiles of 64 workgroups per XCD
+        t.nr_tiles = (a.nrows + 127u) / 128u;
+        t.sup_r = 64u / t.sup_q;
+        const uint32_t rb = (t.nr_tiles + 8u * t.sup_r - 1) / (8u * t.sup_r);
+        const dim3 grid2(8u * rb * t.sup_qblocks * t.sup_r * t.sup_q);
+        if (kind == 1) hipLaunchKernelGGL((flat_tile2_kernel<1>), grid2, dim3(256), 0, s, t, xmax2, wg_overflow);
+        else hipLaunchKernelGGL((flat_tile2_kernel<0>), grid2, dim3(256), 0, s, t, xmax2, wg_overflow);
+        return hipGetLastError();
+    }
     if (build >= 2) {
         if (kind == 1) hipLaunchKernelGGL((flat_tile256_pipe_kernel<1>), grid, dim3(512), 0, s, t, xmax2, wg_overflow);
         else hipLaunchKernelGGL((flat_tile256_pipe_kernel<0>), grid, dim3(512), 0, s, t, xmax2, wg_overflow);

@@ -304,7 +304,10 @@ __global__ __launch_bounds__(256) void flat_merge_pairs_kernel(PairMergeArgs a) 
     uint32_t nc = a.cand_cnt[q];
     if (nc > a.cap) { if (tid == 0) *a.overflow = 1u; nc = a.cap; }
     if (a.qstatus[q] != 0u) nc = 0;
-    for (int i = tid; i < kPairPool; i += 256) {
+    // the pool holds have + nc entries: sort the next power of two (a settled threshold lets ~200 pairs through, not 2 048)
+    int pool = 64;
+    while ((uint32_t)pool < have + nc) pool <<= 1;
+    for (int i = tid; i < pool; i += 256) {
         float sv = inf;
         uint32_t iv = 0xFFFFFFFFu;
         if ((uint32_t)i < have) { sv = a.top_scores[(size_t)q * a.kc + i]; iv = a.top_ids[(size_t)q * a.kc + i]; }
@@ -313,10 +316,10 @@ __global__ __launch_bounds__(256) void flat_merge_pairs_kernel(PairMergeArgs a) 
         pi[i] = iv;
     }
     // bitonic sort of the pool by (score, id)
-    for (int size = 2; size <= kPairPool; size <<= 1)
+    for (int size = 2; size <= pool; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             __syncthreads();
-            for (int t = tid; t < kPairPool / 2; t += 256) {
+            for (int t = tid; t < pool / 2; t += 256) {
                 const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
                 const bool up = (lo & size) == 0;
                 const float sl = ps[lo], sh = ps[hi];

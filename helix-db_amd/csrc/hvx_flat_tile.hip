@@ -1,17 +1,33 @@
-// hvx_flat_tile.hip -- the 256 x 256 contraction kernel of the matrix-core exact scan (BASELINE configs #4 / #5 and the
+// hvx_flat_tile.hip -- the large-tile contraction kernels of the matrix-core exact scan (BASELINE configs #4 / #5 and the
 // f32 exact scan): candidate generation for restricted_exact_scan (crates/db/src/search/vector/restricted.rs:753-835), see
-// the pipeline description at the top of hvx_flat_mfma.hip.  This kernel only FILTERS: a score leaves the tile when it is
+// the pipeline description at the top of hvx_flat_mfma.hip.  These kernels only FILTER: a score leaves the tile when it is
 // below the query's running threshold, as a (score, row) pair; the first chunk of a scan (which has no threshold yet) and
 // the repeat passes stay on the 128 x 128 kernel.
 //
-// Structure (gfx950): 512 threads = 8 wavefronts as 2 (queries) x 4 (rows), each wavefront owns 128 queries x 64 rows =
-// 4 x 2 accumulators of v_mfma_f32_32x32x16_bf16 (128 registers).  A stage is 64 deep: 256 x 128 B of query values (bf16)
-// + 256 x 128 B of bf16 rows (or 256 x 64 B of fp8 codes), copied HBM/L2 -> LDS by global_load_lds_dwordx4 (no registers,
-// no ds_write pass), two LDS buffers, one barrier per stage: stage s+1 lands while stage s is multiplied.  The LDS image
-// is lane-linear per wave instruction (1 KB = 8 tile rows x 128 B, or 16 x 64 B), so the XOR swizzle that makes the
-// fragment reads (ds_read_b128, lane = tile row) conflict-free is applied to the SOURCE address and again to the read
-// address: 128-B rows: 16-B slot ^ ((row >> 1) & 7); 64-B rows: slot ^ ((row >> 2) & 3).
-// fp8 codes are widened to bf16 (exactly) in registers between the ds_read and the MFMA: v_cvt_pk_f32_fp8 + v_perm.
+// Common structure (gfx950): every wavefront owns 128 queries x 64 rows = 4 x 2 accumulators of v_mfma_f32_32x32x16_bf16
+// (128 registers).  Operand stages are copied HBM/L2 -> LDS by global_load_lds_dwordx4 (no registers, no ds_write pass).
+// The LDS image is lane-linear per wave instruction (1 KB = 8 tile rows x 128 B, or 16 x 64 B), so the XOR swizzle that
+// makes the fragment reads (ds_read_b128, lane = tile row) conflict-free (SQ_LDS_BANK_CONFLICT = 0 measured) is applied to
+// the SOURCE address and again to the read address: 128-B rows: 16-B slot ^ ((row >> 1) & 7); 64-B rows: slot ^ ((row >> 2) & 3).
+// fp8 codes are widened to bf16 (exactly) in registers between the ds_read and the MFMA: v_cvt_pk_f32_fp8 + v_perm; one
+// ds_read_b128 of the code tile feeds two MFMA steps (the query operand is stored in the matching order: tile_slot_fp8).
+// Workgroups are mapped to tiles XCD-aware (tile_coords): the workgroups an XCD runs at a time form a super-tile that shares
+// its operand tiles in that XCD's L2 (measured: L2 hit rate 0.91, HBM traffic = the rows once).
+//
+// Two builds:
+//   flat_tile2_kernel    (default) 256 threads = 2 x 2 wavefronts on a 256 x 128 tile, a ring of three 32-deep stages
+//                        (bf16, 72 KB) or two 64-deep stages (fp8, 80 KB), counted vmcnt + raw s_barrier, fragment reads as
+//                        inline asm with stated lgkmcnt waits: TWO independent workgroups per CU.
+//   flat_tile256_kernel  512 threads = 2 x 4 wavefronts on a 256 x 256 tile, two 64-deep LDS buffers, one workgroup per CU;
+//                        carries the measurement switches (HVX_FLAT_TILE_ABLATE).
+// What bounds them (profiles/r02g_*): the matrix cores are NOT the limit.  Ablation of the 512-thread build, 1024 x 1M x 768 bf16
+// (ms per launch): MFMAs alone 0.35 (= the dense peak at the 2.1 GHz the chip holds), fragment reads + barriers alone 0.24,
+// + operand copies 0.17-0.29, + epilogue 0.17; the full kernel takes 0.93 = their SUM.  A four-buffer ring with counted
+// waits, fragment registers double-buffered across the stage barrier, and two workgroups per CU all land within 4 % of that
+// (fp8, K = 1536: two workgroups per CU + 10 %), i.e. the tile is bound by what goes through the LDS -- 48 KB of
+// fragment reads + 16 KB of LDS-DMA writes per 16-deep step and CU against 512 matrix-core cycles -- not by exposed
+// latency.  The next step is therefore fewer LDS bytes per flop (128 x 128 per wavefront, accumulators in AGPRs, one
+// wavefront per SIMD), not more pipelining.
 //
 // Epilogue: score < threshold is tested in the accumulator's own units -- fma(acc, alpha_row, -beta_row) > h_query with a
 // conservative margin -- 2 VALU operations per score; the rare survivors are pushed to a workgroup list in LDS and
@@ -293,163 +309,13 @@ __global__ __launch_bounds__(512) void flat_tile256_kernel(MfmaArgs a, float xma
     tile_epilogue<FP8>(a, acc, lds, q0, r0, wm, wn, tid, xmax2, wg_overflow);
 }
 
-// ---- the ring build: the same tile with the operand copies running several stages ahead of the matrix core.  With two LDS
-// buffers a stage's copy has one stage of MFMA time (~0.9 us) to land, and under load an HBM / L2 -> LDS copy takes longer
-// than that: the 2-buffer build measured 0.35-0.39 of the bf16 peak, waiting on vmcnt(0) at every barrier.  Here the LDS is a
-// ring of NBUF buffers -- bf16 rows: 4 x (256 x 64 B + 256 x 64 B), 32 deep; fp8 codes: 3 x (256 x 128 B + 256 x 64 B), 64 deep
-// -- stage t + NBUF - 1 is issued right after the barrier of stage t (into the buffer stage t - 1 was read from), the wait
-// before the barrier is a COUNTED one (vmcnt = copies of the NBUF - 2 younger stages) and the barrier is the raw s_barrier
-// (__syncthreads() would drain the copy queue: an LDS-DMA is a pending LDS write).
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int KIND>
-__global__ __launch_bounds__(512) void flat_tile256_ring_kernel(MfmaArgs a, float xmax2, uint32_t *wg_overflow) {
-    constexpr bool FP8 = KIND == 1;
-    constexpr int KS = FP8 ? 64 : 32;               // depth of a stage
-    constexpr int AROWB = KS * 2, BROWB = FP8 ? KS : KS * 2; // bytes per tile row and stage: 64 / 64 (bf16), 128 / 64 (fp8)
-    constexpr int ASTAGE = kTM * AROWB, STAGE = ASTAGE + kTN * BROWB;
-    constexpr int NBUF = FP8 ? 3 : 4;
-    constexpr int GA = AROWB / 32, GB = BROWB / 32, G = GA + GB; // 1-KB copies per wave and stage
-    static_assert(BROWB == 64, "row tiles are staged as 64-byte rows");
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[NBUF * STAGE];
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
-    uint32_t qt, rt;
-    if (!tile_coords(a, qt, rt)) return;
-    const uint32_t q0 = qt * kTM, r0 = rt * kTN;
-
-    // staging: wave w copies tile rows 32 w .. 32 w + 31 of both operands.  64-byte rows: a 1-KB copy covers 16 rows, lane l
-    // lands on row +(l >> 2), physical 16-B slot l & 3 and fetches logical slot (l & 3) ^ ((row >> 2) & 3); 128-byte rows:
-    // 8 rows, slot (l & 7) ^ ((row >> 1) & 7).
-    const unsigned char *gA[GA], *gB[GB];
-#pragma unroll
-    for (int t = 0; t < GA; ++t) {
-        uint32_t row, slot;
-        if (AROWB == 64) { row = (uint32_t)(32 * wave + 16 * t + (lane >> 2)); slot = (uint32_t)(lane & 3) ^ ((row >> 2) & 3u); }
-        else { row = (uint32_t)(32 * wave + 8 * t + (lane >> 3)); slot = (uint32_t)(lane & 7) ^ ((row >> 1) & 7u); }
-        gA[t] = reinterpret_cast<const unsigned char *>(a.qhi) + (size_t)(q0 + row) * a.dim * 2 + slot * 16; // queries are padded to 256
-    }
-#pragma unroll
-    for (int t = 0; t < GB; ++t) {
-        const uint32_t row = (uint32_t)(32 * wave + 16 * t + (lane >> 2));
-        const uint32_t slot = (uint32_t)(lane & 3) ^ ((row >> 2) & 3u);
-        uint32_t rloc = r0 + row;
-        if (rloc >= a.nrows) rloc = a.nrows - 1; // clamp: the duplicate is masked in the epilogue
-        const size_t node = a.subset ? a.subset[a.row0 + rloc] : (size_t)a.row0 + rloc;
-        gB[t] = reinterpret_cast<const unsigned char *>(a.rows) + node * a.dim * (FP8 ? 1 : 2) + slot * 16;
-    }
-    auto issue_stage = [&](uint32_t s) {
-        unsigned char *sA = lds + (s % NBUF) * STAGE + wave * (32 * AROWB);
-        unsigned char *sB = lds + (s % NBUF) * STAGE + ASTAGE + wave * (32 * BROWB);
-#pragma unroll
-        for (int t = 0; t < GA; ++t) HVX_GLDS16(gA[t] + s * (uint32_t)AROWB, sA + t * 1024);
-#pragma unroll
-        for (int t = 0; t < GB; ++t) HVX_GLDS16(gB[t] + s * (uint32_t)BROWB, sB + t * 1024);
-    };
-
-    // fragment read offsets: lane = tile row fr of a 32-row block, depth half h
-    const int fr = lane & 31, h = lane >> 5;
-    int off128[4], off64[2];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) off128[kk] = fr * 128 + (((2 * kk + h) ^ ((fr >> 1) & 7)) << 4);
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) off64[jj] = fr * 64 + (((2 * jj + h) ^ ((fr >> 2) & 3)) << 4);
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const uint32_t nstage = a.dim / (uint32_t)KS;
-#pragma unroll
-    for (int s = 0; s < NBUF - 1; ++s)
-        if ((uint32_t)s < nstage) issue_stage((uint32_t)s);
-    for (uint32_t s = 0; s < nstage; ++s) {
-        // stage s has landed when at most the copies of the younger stages in flight are outstanding
-        const uint32_t younger = nstage - 1u - s < (uint32_t)(NBUF - 2) ? nstage - 1u - s : (uint32_t)(NBUF - 2);
-        if (younger >= 2u) wait_vmcnt<2 * G>();
-        else if (younger == 1u) wait_vmcnt<G>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier(); // everyone's copies of stage s are in LDS; nobody still reads the buffer of stage s - 1
-        if (s + (uint32_t)(NBUF - 1) < nstage) issue_stage(s + (uint32_t)(NBUF - 1));
-        const unsigned char *sA = lds + (s % NBUF) * STAGE + wm * (128 * AROWB);
-        const unsigned char *sB = lds + (s % NBUF) * STAGE + ASTAGE + wn * (64 * BROWB);
-        if (FP8) {
-            uint4 c8[2];
-            auto load_frags = [&](int kk, bf16x8 (&fa)[4], bf16x8 (&fb)[2]) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sA + i * (32 * 128) + off128[kk]));
-                if ((kk & 1) == 0) {
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) c8[j] = *reinterpret_cast<const uint4 *>(sB + j * (32 * 64) + off64[kk >> 1]);
-                }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const uint32_t w0 = (kk & 1) ? c8[j].z : c8[j].x, w1 = (kk & 1) ? c8[j].w : c8[j].y;
-                    const f32x2 a01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w0, false), a23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w0, true);
-                    const f32x2 b01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w1, false), b23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w1, true);
-                    uint4 wv;
-                    wv.x = __builtin_amdgcn_perm(__float_as_uint(a01[1]), __float_as_uint(a01[0]), 0x07060302u);
-                    wv.y = __builtin_amdgcn_perm(__float_as_uint(a23[1]), __float_as_uint(a23[0]), 0x07060302u);
-                    wv.z = __builtin_amdgcn_perm(__float_as_uint(b01[1]), __float_as_uint(b01[0]), 0x07060302u);
-                    wv.w = __builtin_amdgcn_perm(__float_as_uint(b23[1]), __float_as_uint(b23[0]), 0x07060302u);
-                    fb[j] = __builtin_bit_cast(bf16x8, wv);
-                }
-            };
-            bf16x8 fa0[4], fb0[2], fa1[4], fb1[2];
-            load_frags(0, fa0, fb0);
-#pragma unroll
-            for (int kk = 0; kk < 4; kk += 2) {
-                load_frags(kk + 1, fa1, fb1);
-                __builtin_amdgcn_sched_barrier(0); // keep the reads of the next step ahead of this step's MFMAs
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[i], fb0[j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (kk + 2 < 4) load_frags(kk + 2, fa0, fb0);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[i], fb1[j], acc[i][j], 0, 0, 0);
-            }
-        } else {
-            bf16x8 fa[2][4], fb[2][2];
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fa[kk][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sA + i * (32 * 64) + off64[kk]));
-#pragma unroll
-                for (int j = 0; j < 2; ++j) fb[kk][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(sB + j * (32 * 64) + off64[kk]));
-            }
-            __builtin_amdgcn_sched_barrier(0); // all twelve reads of the stage ahead of its sixteen MFMAs
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
-        }
-    }
-    tile_epilogue<FP8>(a, acc, lds, q0, r0, wm, wn, tid, xmax2, wg_overflow);
-}
-
-// ---- the pipelined build: the ring of the build above, plus fragment registers double-buffered ACROSS the stage barrier.
-// PMC of the two builds above (profiles/r02g_*): L2 hit rate 0.91, no LDS bank conflicts, LDS array 15 % busy, and still only
-// 36 % of the matrix-core cycles used -- every wavefront reads its fragments right after the barrier (all eight at once),
-// waits for them, and only then issues MFMAs; both wavefronts of a SIMD do so in lock step, so the matrix core idles
-// during every read phase (42 % of the wave cycles parked in s_waitcnt / s_barrier).  Here the unit of the pipeline is the
-// 16-deep MFMA step u: the fragments of step u + 1 are requested BEFORE the eight MFMAs of step u are issued, also when
-// step u + 1 belongs to the next stage -- the counted vmcnt wait, the barrier and the refill of the buffer that has just
-// been read out then sit in front of those reads.  The ring holds NBUF stages, NBUF - 1 of them ahead of the matrix core.
 // ds_read_b128 as inline asm: the compiler then neither sees an LDS load that "may alias" the LDS-DMA copies in flight (it
-// answers that with s_waitcnt vmcnt(0), draining the ring -- it did so for the fp8 code reads) nor places its own lgkmcnt
-// waits; the kernel states both waits itself, each followed by a sched_barrier (an MFMA may not be hoisted over them).
+// answers that with s_waitcnt vmcnt(0), draining the copy ring -- it did so for the fp8 code reads of an earlier build) nor
+// places its own lgkmcnt waits; the kernel states both waits itself, each followed by a sched_barrier (an MFMA may not be
+// hoisted over them).
 template <int OFF>
 __device__ __forceinline__ uint4 lds_read16(uint32_t addr) {
     uint4 v;
@@ -461,178 +327,9 @@ __device__ __forceinline__ void wait_lgkm0() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int KIND>
-__global__ __launch_bounds__(512) void flat_tile256_pipe_kernel(MfmaArgs a, float xmax2, uint32_t *wg_overflow) {
-    constexpr bool FP8 = KIND == 1;
-    constexpr int KS = FP8 ? 64 : 32;               // depth of a stage
-    constexpr int SPS = KS / 16;                    // MFMA steps per stage
-    constexpr int AROWB = KS * 2, BROWB = 64;       // bytes per tile row and stage: 64 / 64 (bf16), 128 / 64 (fp8)
-    constexpr int ASTAGE = kTM * AROWB, STAGE = ASTAGE + kTN * BROWB;
-    constexpr int NBUF = FP8 ? 3 : 4;
-    constexpr int GA = AROWB / 32, GB = BROWB / 32, G = GA + GB; // 1-KB copies per wave and stage
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[NBUF * STAGE];
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
-    uint32_t qt, rt;
-    if (!tile_coords(a, qt, rt)) return;
-    const uint32_t q0 = qt * kTM, r0 = rt * kTN;
-
-    const unsigned char *gA[GA], *gB[GB]; // staging addresses as in the ring build
-#pragma unroll
-    for (int t = 0; t < GA; ++t) {
-        uint32_t row, slot;
-        if (AROWB == 64) { row = (uint32_t)(32 * wave + 16 * t + (lane >> 2)); slot = (uint32_t)(lane & 3) ^ ((row >> 2) & 3u); }
-        else { row = (uint32_t)(32 * wave + 8 * t + (lane >> 3)); slot = (uint32_t)(lane & 7) ^ ((row >> 1) & 7u); }
-        gA[t] = reinterpret_cast<const unsigned char *>(a.qhi) + (size_t)(q0 + row) * a.dim * 2 + slot * 16;
-    }
-#pragma unroll
-    for (int t = 0; t < GB; ++t) {
-        const uint32_t row = (uint32_t)(32 * wave + 16 * t + (lane >> 2));
-        const uint32_t slot = (uint32_t)(lane & 3) ^ ((row >> 2) & 3u);
-        uint32_t rloc = r0 + row;
-        if (rloc >= a.nrows) rloc = a.nrows - 1;
-        const size_t node = a.subset ? a.subset[a.row0 + rloc] : (size_t)a.row0 + rloc;
-        gB[t] = reinterpret_cast<const unsigned char *>(a.rows) + node * a.dim * (FP8 ? 1 : 2) + slot * 16;
-    }
-    auto issue_stage = [&](uint32_t s) {
-        unsigned char *sA = lds + (s % NBUF) * STAGE + wave * (32 * AROWB);
-        unsigned char *sB = lds + (s % NBUF) * STAGE + ASTAGE + wave * (32 * BROWB);
-#pragma unroll
-        for (int t = 0; t < GA; ++t) HVX_GLDS16(gA[t] + s * (uint32_t)AROWB, sA + t * 1024);
-#pragma unroll
-        for (int t = 0; t < GB; ++t) HVX_GLDS16(gB[t] + s * (uint32_t)BROWB, sB + t * 1024);
-    };
-    const int fr = lane & 31, h = lane >> 5;
-    int off128[4], off64[2];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) off128[kk] = fr * 128 + (((2 * kk + h) ^ ((fr >> 1) & 7)) << 4);
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) off64[jj] = fr * 64 + (((2 * jj + h) ^ ((fr >> 2) & 3)) << 4);
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const uint32_t nstage = a.dim / (uint32_t)KS;
-    // stage s has landed once at most the copies of the younger stages in flight (<= NBUF - 2 of them) are outstanding
-    auto wait_stage = [&](uint32_t s) {
-        const uint32_t younger = nstage - 1u - s < (uint32_t)(NBUF - 2) ? nstage - 1u - s : (uint32_t)(NBUF - 2);
-        if (younger >= 2u) wait_vmcnt<2 * G>();
-        else if (younger == 1u) wait_vmcnt<G>();
-        else wait_vmcnt<0>();
-    };
-    uint4 c8[2]; // fp8: the codes of both steps of a pair
-    // request the fragments of step kk of the stage in buffer `buf` (fp8: the row codes of even steps come with their odd partner's)
-    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(lds);
-    const uint32_t baseA = lds0 + (uint32_t)(wm * (128 * AROWB)), baseB = lds0 + (uint32_t)(ASTAGE + wn * (64 * BROWB));
-    auto read_raw = [&](uint32_t buf, int kk, bf16x8 (&fa)[4], bf16x8 (&fb)[2]) {
-        const uint32_t pa = baseA + buf * (uint32_t)STAGE + (uint32_t)(FP8 ? off128[kk] : off64[kk]);
-        fa[0] = __builtin_bit_cast(bf16x8, lds_read16<0>(pa));
-        fa[1] = __builtin_bit_cast(bf16x8, lds_read16<32 * AROWB>(pa));
-        fa[2] = __builtin_bit_cast(bf16x8, lds_read16<64 * AROWB>(pa));
-        fa[3] = __builtin_bit_cast(bf16x8, lds_read16<96 * AROWB>(pa));
-        if (FP8) {
-            if ((kk & 1) == 0) {
-                const uint32_t pb = baseB + buf * (uint32_t)STAGE + (uint32_t)off64[kk >> 1];
-                c8[0] = lds_read16<0>(pb);
-                c8[1] = lds_read16<32 * 64>(pb);
-            }
-        } else {
-            const uint32_t pb = baseB + buf * (uint32_t)STAGE + (uint32_t)off64[kk];
-            fb[0] = __builtin_bit_cast(bf16x8, lds_read16<0>(pb));
-            fb[1] = __builtin_bit_cast(bf16x8, lds_read16<32 * 64>(pb));
-        }
-    };
-    // fp8: 8 codes -> 8 f32 (exact) -> their high halves = 8 bf16 (exact); issued between the MFMAs of the step before
-    auto widen = [&](int kk, bf16x8 (&fb)[2]) {
-        if (!FP8) return;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const uint32_t w0 = (kk & 1) ? c8[j].z : c8[j].x, w1 = (kk & 1) ? c8[j].w : c8[j].y;
-            const f32x2 a01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w0, false), a23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w0, true);
-            const f32x2 b01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w1, false), b23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w1, true);
-            uint4 wv;
-            wv.x = __builtin_amdgcn_perm(__float_as_uint(a01[1]), __float_as_uint(a01[0]), 0x07060302u);
-            wv.y = __builtin_amdgcn_perm(__float_as_uint(a23[1]), __float_as_uint(a23[0]), 0x07060302u);
-            wv.z = __builtin_amdgcn_perm(__float_as_uint(b01[1]), __float_as_uint(b01[0]), 0x07060302u);
-            wv.w = __builtin_amdgcn_perm(__float_as_uint(b23[1]), __float_as_uint(b23[0]), 0x07060302u);
-            fb[j] = __builtin_bit_cast(bf16x8, wv);
-        }
-    };
-    // the eight MFMAs of a step in two halves, so that `widen` of the next step can sit between them
-    auto mfma4 = [&](int half, const bf16x8 (&fa)[4], const bf16x8 (&fb)[2]) {
-#pragma unroll
-        for (int i = 2 * half; i < 2 * half + 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    };
-
-#pragma unroll
-    for (int s = 0; s < NBUF; ++s)
-        if ((uint32_t)s < nstage) issue_stage((uint32_t)s);
-    bf16x8 fa0[4], fb0[2], fa1[4], fb1[2];
-    {   // stage 0 has landed when the NBUF - 1 younger ones are all that is outstanding
-        const uint32_t younger = nstage - 1u < (uint32_t)(NBUF - 1) ? nstage - 1u : (uint32_t)(NBUF - 1);
-        if (younger >= 3u) wait_vmcnt<3 * G>();
-        else if (younger == 2u) wait_vmcnt<2 * G>();
-        else if (younger == 1u) wait_vmcnt<G>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        read_raw(0, 0, fa0, fb0);
-        if (FP8) { wait_lgkm0(); widen(0, fb0); }
-    }
-    for (uint32_t s = 0; s < nstage; ++s) {
-        const uint32_t buf = s % NBUF;
-#pragma unroll
-        for (int kk = 0; kk < SPS; kk += 2) {
-            // step kk (registers 0) under the reads of step kk + 1 (registers 1).  The wait is for the reads of registers 0,
-            // requested eight MFMAs ago: stated here, before the new requests, it costs nothing
-            wait_lgkm0();
-            read_raw(buf, kk + 1, fa1, fb1);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma4(0, fa0, fb0);
-            __builtin_amdgcn_sched_barrier(0);
-            widen(kk + 1, fb1);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma4(1, fa0, fb0);
-            __builtin_amdgcn_sched_barrier(0);
-            // step kk + 1 (registers 1) under the reads of step kk + 2 (registers 0), which may open the next stage
-            const bool more = kk + 2 < SPS || s + 1 < nstage;
-            wait_lgkm0(); // registers 1
-            if (kk + 2 < SPS) {
-                read_raw(buf, kk + 2, fa0, fb0);
-            } else if (s + 1 < nstage) {
-                wait_stage(s + 1);            // this wave has read stage s out completely (the wait above), its copies of stage s + 1 have landed
-                __builtin_amdgcn_s_barrier(); // everyone's have; the buffer of stage s is free
-                if (s + (uint32_t)NBUF < nstage) issue_stage(s + (uint32_t)NBUF);
-                read_raw((s + 1) % NBUF, 0, fa0, fb0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            mfma4(0, fa1, fb1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (FP8 && more) { // the codes of the next step pair were requested four MFMAs ago
-                wait_lgkm0();
-                widen(kk + 2 < SPS ? kk + 2 : 0, fb0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            mfma4(1, fa1, fb1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    tile_epilogue<FP8>(a, acc, lds, q0, r0, wm, wn, tid, xmax2, wg_overflow);
-}
-
-// ---- the two-workgroups-per-CU build.  Ablation of the 512-thread builds (profiles/r02g_ablate_bf16.txt: MFMAs only 0.35 ms,
-// + fragment reads and barriers 0.24, + operand copies 0.17, + epilogue 0.17 = the 0.93 ms measured) showed that NOTHING overlaps
-// there: one workgroup per CU means all eight wavefronts -- both wavefronts of every SIMD -- are in the same phase at the
-// same time, and neither a deeper copy ring nor fragment prefetch across the barrier changes that.  Here a workgroup is
-// four wavefronts (one per SIMD, 2 x 2, each still 128 queries x 64 rows) on a 256 x 128 tile with a ring of three 32- or
-// 64-deep stages (72 KB), so a CU holds TWO independent workgroups: while one waits at its barrier, reads fragments, starts
-// a tile or runs its epilogue, the other one's MFMAs have the matrix cores.
+// ---- the two-workgroups-per-CU build (see the file header): a workgroup is four wavefronts (one per SIMD, 2 x 2, each 128
+// queries x 64 rows) on a 256 x 128 tile, so a CU holds two independent workgroups: while one waits at its barrier, starts a
+// tile or runs its epilogue, the other one's MFMAs have the matrix cores.
 template <int LGKM>
 __device__ __forceinline__ void wait_lgkm() {
     __builtin_amdgcn_s_waitcnt(0xC07F | (LGKM << 8));
@@ -655,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void flat_tile2_kernel(MfmaArgs a, float xm
     if (!tile_coords(a, qt, rt)) return;
     const uint32_t q0 = qt * kTM, r0 = rt * TNR;
 
-    // staging: wave w copies query rows 64 w .. 64 w + 63 and tile rows 32 w .. 32 w + 31 (layouts as in the ring build)
+    // staging: wave w copies query rows 64 w .. 64 w + 63 and tile rows 32 w .. 32 w + 31 (64-byte rows: 16 rows per 1-KB copy, slot (l & 3) ^ ((row >> 2) & 3); 128-byte rows: 8 rows, slot (l & 7) ^ ((row >> 1) & 7))
     const unsigned char *gA[GA], *gB[GB];
 #pragma unroll
     for (int t = 0; t < GA; ++t) {
@@ -785,25 +482,14 @@ hipError_t launch_flat_tile256(const MfmaArgs &a, int kind, uint32_t bpad, float
     t.ablate = [] { const char *e = getenv("HVX_FLAT_TILE_ABLATE"); return e ? (uint32_t)atoi(e) : 0u; }();
     const uint32_t rblocks = (t.nr_tiles + 8u * t.sup_r - 1) / (8u * t.sup_r);
     const dim3 grid(8u * rblocks * t.sup_qblocks * t.sup_r * t.sup_q);
-    static const int build = [] { const char *e = getenv("HVX_FLAT_TILE_BUILD"); return e ? atoi(e) : 3; }(); // 0: two buffers, 1: ring, 2: pipelined ring, 3: two workgroups per CU
-    if (build >= 3) { // 256 x 128 tiles, 256 threads, two workgroups per CU: super-tiles of 64 workgroups per XCD
+    static const int build = [] { const char *e = getenv("HVX_FLAT_TILE_BUILD"); return e ? atoi(e) : 3; }(); // 0: one 512-thread workgroup per CU (256 x 256 tiles, two LDS buffers), else: two 256-thread workgroups per CU (256 x 128)
+    if (build != 0) { // 256 x 128 tiles, 256 threads, two workgroups per CU: super-tiles of 64 workgroups per XCD
         t.nr_tiles = (a.nrows + 127u) / 128u;
         t.sup_r = 64u / t.sup_q;
         const uint32_t rb = (t.nr_tiles + 8u * t.sup_r - 1) / (8u * t.sup_r);
         const dim3 grid2(8u * rb * t.sup_qblocks * t.sup_r * t.sup_q);
         if (kind == 1) hipLaunchKernelGGL((flat_tile2_kernel<1>), grid2, dim3(256), 0, s, t, xmax2, wg_overflow);
         else hipLaunchKernelGGL((flat_tile2_kernel<0>), grid2, dim3(256), 0, s, t, xmax2, wg_overflow);
-        return hipGetLastError();
-    }
-    if (build >= 2) {
-        if (kind == 1) hipLaunchKernelGGL((flat_tile256_pipe_kernel<1>), grid, dim3(512), 0, s, t, xmax2, wg_overflow);
-        else hipLaunchKernelGGL((flat_tile256_pipe_kernel<0>), grid, dim3(512), 0, s, t, xmax2, wg_overflow);
-        return hipGetLastError();
-    }
-    const bool ring = build == 1;
-    if (ring) {
-        if (kind == 1) hipLaunchKernelGGL((flat_tile256_ring_kernel<1>), grid, dim3(512), 0, s, t, xmax2, wg_overflow);
-        else hipLaunchKernelGGL((flat_tile256_ring_kernel<0>), grid, dim3(512), 0, s, t, xmax2, wg_overflow);
         return hipGetLastError();
     }
     static const bool pipe = [] { const char *e = getenv("HVX_FLAT_TILE_PIPE"); return !e || e[0] != '0'; }();

@@ -23,11 +23,13 @@ FP8="--rows 2000000 --dim 1536 --batch 4096 --dtype fp8 --steps 3"
 B16="--rows 1000000 --dim 768 --batch 1024 --dtype bf16 --steps 5"
 F32="--rows 1000000 --dim 768 --batch 1024 --dtype f32 --steps 5"
 if [ -z "$ONLY_PROFILE" ]; then
-run fp8_2wg -- $FP8
-run fp8_2buf HVX_FLAT_TILE_BUILD=0 -- $FP8
-run bf16_2wg -- $B16
-run bf16_2buf HVX_FLAT_TILE_BUILD=0 -- $B16
-run f32_2wg -- $F32
+run fp8_default -- $FP8
+run fp8_chunk16k HVX_FLAT_CHUNK=16384 -- $FP8
+run bf16_default -- $B16
+run bf16_chunk32k HVX_FLAT_CHUNK=32768 -- $B16
+run bf16_chunk16k HVX_FLAT_CHUNK=16384 -- $B16
+run bf16_chunk8k HVX_FLAT_CHUNK=8192 -- $B16
+run f32_chunk16k HVX_FLAT_CHUNK=16384 -- $F32
 fi
 for leg in fp8 bf16 f32; do
   case $leg in fp8) A="$FP8";; bf16) A="$B16";; f32) A="$F32";; esac

@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--dataset", default="embedding", choices=["embedding", "clustered", "gaussian"])
     ap.add_argument("--seed", type=int, default=20260921)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--deadline", type=float, default=300.0,
+                    help="seconds after which the line is printed with whatever legs have finished (the headline is complete long before; 0 = no deadline)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores (capped at 64)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle bit-exactness check")
     ap.add_argument("--metric", default="l2", choices=["l2", "cosine"])
@@ -469,7 +471,40 @@ def leg_graph_equivalence(hv, synth, args, dev):
 
 
 # ------------------------------------------------------------------------------------------------------------
+def start_deadline(out, seconds, rank):
+    """The extra legs (other corpora, configs 3-5, graph equivalence, CPU baseline) must never cost the headline: once the
+    headline object exists, a daemon thread prints it -- with the legs that have finished by then -- when the deadline passes,
+    and ends the process."""
+    import threading
+
+    def fire():
+        for _ in range(20):
+            try:
+                snap = dict(out)
+                snap["deadline"] = {"seconds": seconds, "note": "printed by the deadline watchdog: legs absent from this line had not finished"}
+                line = json.dumps(snap)
+                break
+            except RuntimeError:  # the main thread added a key while we copied
+                time.sleep(0.05)
+        else:
+            line = None
+        if rank == 0 and line is not None:
+            print(line, flush=True)
+        log(f"deadline of {seconds:.0f}s reached: line printed with the legs finished so far")
+        sys.stderr.flush()
+        os._exit(0)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def main():
+    if os.environ.get("BENCH_TRACE"):  # where is it? (python stacks of all threads every N seconds, to stderr)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["BENCH_TRACE"]), repeat=True)
+    t_start = time.time()
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -662,6 +697,9 @@ def main():
                                             "filtered epilogue + exact f32 re-rank + certificate); bit-exact vs the oracle's exact scan"}},
         "graph_build": res["graph"],
     }
+
+    if args.deadline > 0:
+        start_deadline(out, max(5.0, args.deadline - (time.time() - t_start)), rank)
 
     # ---- N > 1: the north star's own curve -- the SAME 1M corpus split over the GPUs (strong scaling) ----
     if world > 1 and not replica and args.scaling in ("strong", "both"):

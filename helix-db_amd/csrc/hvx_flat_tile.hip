@@ -67,9 +67,9 @@ __device__ __forceinline__ bool tile_coords(const MfmaArgs &a, uint32_t &qt, uin
     return rt < a.nr_tiles && qt < a.nq_tiles;
 }
 
-// ---- epilogue shared by both builds of the kernel.  acc = C[m = query][n = row] of this wavefront's 128 x 64 block.
-template <bool FP8>
-__device__ __forceinline__ void tile_epilogue(const MfmaArgs &a, f32x16 (&acc)[4][2], unsigned char *lds, uint32_t q0, uint32_t r0, int wm,
+// ---- epilogue shared by all builds.  acc = C[m = query][n = row] of this wavefront's 128 x (32 NJ) block.
+template <bool FP8, int NJ>
+__device__ __forceinline__ void tile_epilogue(const MfmaArgs &a, f32x16 (&acc)[4][NJ], unsigned char *lds, uint32_t q0, uint32_t r0, int wm,
                                               int wn, int tid, float xmax2, uint32_t *wg_overflow) { // 256 or 512 threads
     const int lane = tid & 63, fr = lane & 31, h = lane >> 5;
     // ---- epilogue.  C[m = query][n = row]: lane holds n = lane & 31, m = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
@@ -92,10 +92,10 @@ __device__ __forceinline__ void tile_epilogue(const MfmaArgs &a, f32x16 (&acc)[4
         sH[tid] = hq;
     }
     if (tid == 0) *sCnt = 0u;
-    float alpha[2], nbeta[2];
+    float alpha[NJ], nbeta[NJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const uint32_t rloc = r0 + (uint32_t)(wn * 64 + j * 32 + fr);
+    for (int j = 0; j < NJ; ++j) {
+        const uint32_t rloc = r0 + (uint32_t)(wn * (32 * NJ) + j * 32 + fr);
         alpha[j] = 0.f;
         nbeta[j] = -inf; // rows past the end of the scan never pass
         if (rloc < a.nrows) {
@@ -114,12 +114,12 @@ __device__ __forceinline__ void tile_epilogue(const MfmaArgs &a, f32x16 (&acc)[4
             const int m = wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h; // tile-local query
             const float hq = sH[m];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 if (__builtin_fmaf(acc[i][j][e], alpha[j], nbeta[j]) > hq) {
                     const uint32_t pos = atomicAdd(sCnt, 1u);
                     if (pos < (uint32_t)kWgList) {
                         sLv[pos] = acc[i][j][e];
-                        sLc[pos] = ((uint32_t)m << 8) | (uint32_t)(wn * 64 + j * 32 + fr);
+                        sLc[pos] = ((uint32_t)m << 8) | (uint32_t)(wn * (32 * NJ) + j * 32 + fr);
                     }
                 }
             }
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(512) void flat_tile256_kernel(MfmaArgs a, float xma
         if (sum == 123456.789f) *wg_overflow = 2u;
         return;
     }
-    tile_epilogue<FP8>(a, acc, lds, q0, r0, wm, wn, tid, xmax2, wg_overflow);
+    tile_epilogue<FP8, 2>(a, acc, lds, q0, r0, wm, wn, tid, xmax2, wg_overflow);
 }
 
 template <int N>
@@ -467,7 +467,173 @@ __global__ __launch_bounds__(256, 2) void flat_tile2_kernel(MfmaArgs a, float xm
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    tile_epilogue<FP8>(a, acc, lds, q0, r0, wm, wn, tid, xmax2, wg_overflow);
+    tile_epilogue<FP8, 2>(a, acc, lds, q0, r0, wm, wn, tid, xmax2, wg_overflow);
+}
+
+// ---- the 128 x 128-per-wavefront build: fewer LDS bytes per flop.  Four wavefronts (one per SIMD, 2 x 2) on a 256 x 256
+// tile, each with 4 x 4 accumulators (256 registers: the kernel runs one wavefront per SIMD and spills into AGPRs): a
+// 16-deep step is 16 MFMAs per 8 fragment reads (the 128 x 64 builds: 8 per 6), and the tile moves two thirds of the
+// LDS-DMA bytes of two 256 x 128 tiles.  With a single wavefront per SIMD nothing overlaps by itself, so the fragments of
+// step u + 1 are requested before the MFMAs of step u are issued -- also across the stage barrier -- and the fp8 widening
+// of step u + 1 sits between the two halves of step u's MFMAs.  Ring of four 32-deep stages (bf16 rows, 128 KB) or three
+// 64-deep stages (fp8 codes, 144 KB), counted vmcnt, raw s_barrier, fragment reads as inline asm with stated waits.
+template <int KIND>
+__global__ __launch_bounds__(256, 1) void flat_tile4_kernel(MfmaArgs a, float xmax2, uint32_t *wg_overflow) {
+    constexpr bool FP8 = KIND == 1;
+    constexpr int KS = FP8 ? 64 : 32, SPS = KS / 16;
+    constexpr int AROWB = KS * 2, BROWB = 64;
+    constexpr int ASTAGE = kTM * AROWB, STAGE = ASTAGE + kTN * BROWB; // 32 KB (bf16) / 48 KB (fp8)
+    constexpr int NBUF = FP8 ? 3 : 4;
+    constexpr int GA = AROWB / 16, GB = 4, G = GA + GB; // 1-KB copies per wave and stage: 64 query rows and 64 tile rows per wave
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NBUF * STAGE];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    uint32_t qt, rt;
+    if (!tile_coords(a, qt, rt)) return;
+    const uint32_t q0 = qt * kTM, r0 = rt * kTN;
+
+    const unsigned char *gA[GA], *gB[GB];
+#pragma unroll
+    for (int t = 0; t < GA; ++t) {
+        uint32_t row, slot;
+        if (AROWB == 64) { row = (uint32_t)(64 * wave + 16 * t + (lane >> 2)); slot = (uint32_t)(lane & 3) ^ ((row >> 2) & 3u); }
+        else { row = (uint32_t)(64 * wave + 8 * t + (lane >> 3)); slot = (uint32_t)(lane & 7) ^ ((row >> 1) & 7u); }
+        gA[t] = reinterpret_cast<const unsigned char *>(a.qhi) + (size_t)(q0 + row) * a.dim * 2 + slot * 16;
+    }
+#pragma unroll
+    for (int t = 0; t < GB; ++t) {
+        const uint32_t row = (uint32_t)(64 * wave + 16 * t + (lane >> 2));
+        const uint32_t slot = (uint32_t)(lane & 3) ^ ((row >> 2) & 3u);
+        uint32_t rloc = r0 + row;
+        if (rloc >= a.nrows) rloc = a.nrows - 1;
+        const size_t node = a.subset ? a.subset[a.row0 + rloc] : (size_t)a.row0 + rloc;
+        gB[t] = reinterpret_cast<const unsigned char *>(a.rows) + node * a.dim * (FP8 ? 1 : 2) + slot * 16;
+    }
+    auto issue_stage = [&](uint32_t s) {
+        unsigned char *sA = lds + (s % NBUF) * STAGE + wave * (64 * AROWB);
+        unsigned char *sB = lds + (s % NBUF) * STAGE + ASTAGE + wave * (64 * BROWB);
+#pragma unroll
+        for (int t = 0; t < GA; ++t) HVX_GLDS16(gA[t] + s * (uint32_t)AROWB, sA + t * 1024);
+#pragma unroll
+        for (int t = 0; t < GB; ++t) HVX_GLDS16(gB[t] + s * (uint32_t)BROWB, sB + t * 1024);
+    };
+    const int fr = lane & 31, h = lane >> 5;
+    int off128[4], off64[2];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) off128[kk] = fr * 128 + (((2 * kk + h) ^ ((fr >> 1) & 7)) << 4);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) off64[jj] = fr * 64 + (((2 * jj + h) ^ ((fr >> 2) & 3)) << 4);
+    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(lds);
+    const uint32_t baseA = lds0 + (uint32_t)(wm * (128 * AROWB)), baseB = lds0 + (uint32_t)(ASTAGE + wn * (128 * BROWB));
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    uint4 c8[4]; // fp8: the codes of both steps of a pair, four 32-row blocks
+    auto read_raw = [&](uint32_t buf, int kk, bf16x8 (&fa)[4], bf16x8 (&fb)[4]) { // 8 reads (bf16; fp8 even steps), 4 (fp8 odd steps)
+        const uint32_t pa = baseA + buf * (uint32_t)STAGE + (uint32_t)(FP8 ? off128[kk] : off64[kk]);
+        fa[0] = __builtin_bit_cast(bf16x8, lds_read16<0>(pa));
+        fa[1] = __builtin_bit_cast(bf16x8, lds_read16<32 * AROWB>(pa));
+        fa[2] = __builtin_bit_cast(bf16x8, lds_read16<64 * AROWB>(pa));
+        fa[3] = __builtin_bit_cast(bf16x8, lds_read16<96 * AROWB>(pa));
+        if (FP8) {
+            if ((kk & 1) == 0) {
+                const uint32_t pb = baseB + buf * (uint32_t)STAGE + (uint32_t)off64[kk >> 1];
+                c8[0] = lds_read16<0>(pb);
+                c8[1] = lds_read16<32 * 64>(pb);
+                c8[2] = lds_read16<64 * 64>(pb);
+                c8[3] = lds_read16<96 * 64>(pb);
+            }
+        } else {
+            const uint32_t pb = baseB + buf * (uint32_t)STAGE + (uint32_t)off64[kk];
+            fb[0] = __builtin_bit_cast(bf16x8, lds_read16<0>(pb));
+            fb[1] = __builtin_bit_cast(bf16x8, lds_read16<32 * 64>(pb));
+            fb[2] = __builtin_bit_cast(bf16x8, lds_read16<64 * 64>(pb));
+            fb[3] = __builtin_bit_cast(bf16x8, lds_read16<96 * 64>(pb));
+        }
+    };
+    auto widen = [&](int kk, bf16x8 (&fb)[4]) {
+        if (!FP8) return;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t w0 = (kk & 1) ? c8[j].z : c8[j].x, w1 = (kk & 1) ? c8[j].w : c8[j].y;
+            const f32x2 a01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w0, false), a23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w0, true);
+            const f32x2 b01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w1, false), b23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w1, true);
+            uint4 wv;
+            wv.x = __builtin_amdgcn_perm(__float_as_uint(a01[1]), __float_as_uint(a01[0]), 0x07060302u);
+            wv.y = __builtin_amdgcn_perm(__float_as_uint(a23[1]), __float_as_uint(a23[0]), 0x07060302u);
+            wv.z = __builtin_amdgcn_perm(__float_as_uint(b01[1]), __float_as_uint(b01[0]), 0x07060302u);
+            wv.w = __builtin_amdgcn_perm(__float_as_uint(b23[1]), __float_as_uint(b23[0]), 0x07060302u);
+            fb[j] = __builtin_bit_cast(bf16x8, wv);
+        }
+    };
+    auto mfma8 = [&](int half, const bf16x8 (&fa)[4], const bf16x8 (&fb)[4]) {
+#pragma unroll
+        for (int i = 2 * half; i < 2 * half + 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    };
+    const uint32_t nstage = a.dim / (uint32_t)KS;
+    auto wait_stage = [&](uint32_t s) { // stage s has landed once at most the copies of the younger stages in flight are outstanding
+        const uint32_t younger = nstage - 1u - s < (uint32_t)(NBUF - 2) ? nstage - 1u - s : (uint32_t)(NBUF - 2);
+        if (younger >= 2u) wait_vmcnt<2 * G>();
+        else if (younger == 1u) wait_vmcnt<G>();
+        else wait_vmcnt<0>();
+    };
+    // one MFMA step: `cur` holds step u (fp8: already widened); `nxt` receives step u + 1 of buffer nbuf (boundary: it opens stage s + 1)
+    auto step = [&](bool has_next, bool boundary, uint32_t s, uint32_t nbuf, int nkk, bf16x8 (&fa_c)[4], bf16x8 (&fb_c)[4], bf16x8 (&fa_n)[4],
+                    bf16x8 (&fb_n)[4]) {
+        wait_lgkm0(); // the reads of `cur` were requested sixteen MFMAs ago
+        if (has_next) {
+            if (boundary) {
+                wait_stage(s + 1);            // this wave's copies of stage s + 1 have landed (and it has read stage s out: the wait above)
+                __builtin_amdgcn_s_barrier(); // everyone's have; the buffer of stage s is free
+                if (s + (uint32_t)NBUF < nstage) issue_stage(s + (uint32_t)NBUF);
+            }
+            read_raw(nbuf, nkk, fa_n, fb_n);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(0, fa_c, fb_c);
+        __builtin_amdgcn_sched_barrier(0);
+        if (FP8 && has_next) { // the codes of step u + 1 were requested eight MFMAs ago
+            wait_lgkm0();
+            widen(nkk, fb_n);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(1, fa_c, fb_c);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+#pragma unroll
+    for (int s = 0; s < NBUF; ++s)
+        if ((uint32_t)s < nstage) issue_stage((uint32_t)s);
+    bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+    {   // stage 0 has landed when the NBUF - 1 younger ones are all that is outstanding
+        const uint32_t younger = nstage - 1u < (uint32_t)(NBUF - 1) ? nstage - 1u : (uint32_t)(NBUF - 1);
+        if (younger >= 3u) wait_vmcnt<3 * G>();
+        else if (younger == 2u) wait_vmcnt<2 * G>();
+        else if (younger == 1u) wait_vmcnt<G>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        read_raw(0, 0, fa0, fb0);
+        if (FP8) { wait_lgkm0(); widen(0, fb0); }
+    }
+    for (uint32_t s = 0; s < nstage; ++s) {
+        const uint32_t buf = s % NBUF;
+        const bool more = s + 1 < nstage;
+#pragma unroll
+        for (int kk = 0; kk < SPS; kk += 2) {
+            step(true, false, s, buf, kk + 1, fa0, fb0, fa1, fb1);
+            if (kk + 2 < SPS) step(true, false, s, buf, kk + 2, fa1, fb1, fa0, fb0);
+            else step(more, true, s, (s + 1) % NBUF, 0, fa1, fb1, fa0, fb0);
+        }
+    }
+    tile_epilogue<FP8, 4>(a, acc, lds, q0, r0, wm, wn, tid, xmax2, wg_overflow);
 }
 
 hipError_t launch_flat_tile256(const MfmaArgs &a, int kind, uint32_t bpad, float xmax2, uint32_t *wg_overflow, hipStream_t s) {
@@ -483,6 +649,11 @@ hipError_t launch_flat_tile256(const MfmaArgs &a, int kind, uint32_t bpad, float
     const uint32_t rblocks = (t.nr_tiles + 8u * t.sup_r - 1) / (8u * t.sup_r);
     const dim3 grid(8u * rblocks * t.sup_qblocks * t.sup_r * t.sup_q);
     static const int build = [] { const char *e = getenv("HVX_FLAT_TILE_BUILD"); return e ? atoi(e) : 3; }(); // 0: one 512-thread workgroup per CU (256 x 256 tiles, two LDS buffers), else: two 256-thread workgroups per CU (256 x 128)
+    if (build == 4) { // 256 x 256 tiles, 256 threads of 128 x 128 each, one workgroup per CU
+        if (kind == 1) hipLaunchKernelGGL((flat_tile4_kernel<1>), grid, dim3(256), 0, s, t, xmax2, wg_overflow);
+        else hipLaunchKernelGGL((flat_tile4_kernel<0>), grid, dim3(256), 0, s, t, xmax2, wg_overflow);
+        return hipGetLastError();
+    }
     if (build != 0) { // 256 x 128 tiles, 256 threads, two workgroups per CU: super-tiles of 64 workgroups per XCD
         t.nr_tiles = (a.nrows + 127u) / 128u;
         t.sup_r = 64u / t.sup_q;

@@ -262,6 +262,18 @@ def lib():
     return L
 
 
+def _sync_producer(t):
+    """A device tensor handed to the library was produced on the caller's (torch) stream; the library reads it on the index's
+    own stream.  Wait for the producer first: without this an import / build that starts right after the tensor's kernels were
+    ENQUEUED copies rows that have not been written yet (whatever the allocation held before)."""
+    try:
+        import torch
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            torch.cuda.current_stream(t.device).synchronize()
+    except ImportError:
+        pass
+
+
 def _check(rc):
     if rc != OK:
         raise HelixDbError(rc, lib().hvx_last_error().decode())
@@ -407,6 +419,8 @@ class ValidatedVectorReadIndex:
         ids = np.ascontiguousarray(node_ids, dtype=np.uint64)
         dev_rows = hasattr(vectors, "data_ptr")  # a torch tensor already resident on the device
         if dev_rows:
+            _sync_producer(vectors)
+        if dev_rows:
             assert vectors.is_contiguous() and vectors.dtype.is_floating_point and vectors.element_size() == 4 and vectors.numel() == ids.size * dim
             vec = None
         else:
@@ -433,6 +447,8 @@ class ValidatedVectorReadIndex:
         Returns (index, stats dict).  `vectors` may be a host array or a torch tensor resident on the device."""
         ids = np.ascontiguousarray(node_ids, dtype=np.uint64)
         dev_rows = hasattr(vectors, "data_ptr")
+        if dev_rows:
+            _sync_producer(vectors)
         vec = None if dev_rows else (np.ascontiguousarray(vectors, dtype=np.float32).reshape(ids.size, dim) if ids.size else np.zeros((0, dim), np.float32))
         lv = None if levels is None else np.ascontiguousarray(levels, dtype=np.uint16)
         d = _Desc(dim=dim, metric=metric, dtype=F32, float_kernel=float_kernel, n=ids.size, m=m, m0=m0, has_entry=0, max_layer=0,

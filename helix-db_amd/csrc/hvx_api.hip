@@ -429,6 +429,7 @@ extern "C" int hvx_index_fork(const hvx_index *parent, hvx_index **out) {
     ix->image.push_back(src->allocs);
     ix->m_rowterm = src->m_rowterm;
     ix->m_xmax2 = src->m_xmax2;
+    ix->shared = src->shared; // one bf16 shadow (and whatever else is built lazily per image) for all lanes
     ix->m_shadow = src->m_shadow;
     ix->has_simhash = src->has_simhash;
     ix->sh_cfg = src->sh_cfg;

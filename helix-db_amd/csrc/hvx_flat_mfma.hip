@@ -542,21 +542,30 @@ int flat_mfma_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t
 }
 
 // bf16 shadow of an f32 index's rows (plain order, RNE: the values the one-pass contraction rounds to anyway): built once per
-// index by the first scan that reaches a filtered slice; +50 % of the row bytes, so an index that cannot afford it stays on
-// the 128 x 128 kernel (which splits the f32 rows on the fly)
+// IMAGE -- the imported handle and its forks share it -- by the first scan that reaches a filtered slice; +50 % of the row
+// bytes, so an image that cannot afford it stays on the 128 x 128 kernel (which splits the f32 rows on the fly).  The builder
+// waits for its conversion kernel before publishing the pointer: another lane may use it from its own stream right away.
 static int ensure_shadow(hvx_index *ix) {
     const DevIndex &d = ix->dev;
-    if (ix->m_shadow || ix->m_shadow_failed) return HVX_OK;
+    if (ix->m_shadow) return HVX_OK;
+    hvx_image_shared &sh = *ix->shared;
+    std::lock_guard<std::mutex> lock(sh.mu);
+    if (sh.shadow) { ix->m_shadow = sh.shadow; return HVX_OK; }
+    if (sh.shadow_failed) return HVX_OK;
     void *p = nullptr;
     if (hipMalloc(&p, std::max<size_t>((size_t)d.n * d.dim * 2, 16)) != hipSuccess) {
         (void)hipGetLastError();
-        ix->m_shadow_failed = true;
+        sh.shadow_failed = true;
         return HVX_OK;
     }
-    ix->allocs->v.push_back(p);
-    ix->m_shadow = reinterpret_cast<uint16_t *>(p);
-    hipLaunchKernelGGL(bf16_shadow_kernel, dim3(2048), dim3(256), 0, ix->stream, d.vec, (size_t)d.n * d.dim / 4, ix->m_shadow);
-    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(bf16_shadow_kernel, dim3(2048), dim3(256), 0, ix->stream, d.vec, (size_t)d.n * d.dim / 4, reinterpret_cast<uint16_t *>(p));
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ix->stream) != hipSuccess) {
+        (void)hipFree(p);
+        return fail(HVX_ERR_DEVICE, "bf16 shadow conversion failed");
+    }
+    sh.device = ix->device;
+    sh.shadow = reinterpret_cast<uint16_t *>(p);
+    ix->m_shadow = sh.shadow;
     return HVX_OK;
 }
 

@@ -21,6 +21,21 @@ struct hvx_allocs {
     }
 };
 
+// State that every handle of one device image shares (the imported handle and its forks): built once, by whichever lane
+// needs it first, freed with the image.
+struct hvx_image_shared {
+    std::mutex mu;
+    int device = 0;
+    uint16_t *shadow = nullptr;   // f32 rows: bf16 (RNE) shadow of the rows for the large-tile exact-scan kernels (hvx_flat_tile.hip)
+    bool shadow_failed = false;   // no memory for it: the scan stays on the 128 x 128 kernel
+    ~hvx_image_shared() {
+        if (shadow) {
+            (void)hipSetDevice(device);
+            (void)hipFree(shadow);
+        }
+    }
+};
+
 struct hvx_index {
     int device = 0;
     hvx_index_desc desc{};
@@ -72,8 +87,8 @@ struct hvx_index {
     // bf16 exact scan on the matrix cores (hvx_flat_mfma.hip)
     uint16_t *m_qhi = nullptr, *m_qlo = nullptr;
     uint16_t *m_qhi8 = nullptr;      // fp8 rows: the hi parts again, in the operand order of the 256 x 256 kernel (hvx_flat_tile.hip)
-    uint16_t *m_shadow = nullptr;    // f32 rows: bf16 (RNE) shadow of the rows for the 256 x 256 kernel, built on first use
-    bool m_shadow_failed = false;    // ... no memory for it: stay on the 128 x 128 kernel
+    uint16_t *m_shadow = nullptr;    // f32 rows: this handle's view of shared->shadow (set once it is complete)
+    std::shared_ptr<hvx_image_shared> shared = std::make_shared<hvx_image_shared>(); // forks share their parent's
     float *m_qn2 = nullptr, *m_rowterm = nullptr; // |q|^2 per query; |x|^2 per row
     uint32_t *m_cert = nullptr;
     // filtered-epilogue pipeline: running thresholds and the (score, row) pairs a filtered launch lets through

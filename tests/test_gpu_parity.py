@@ -1173,6 +1173,39 @@ def test_exact_scan_through_the_256_tile_kernel(orc, hv, monkeypatch, capfd, dty
     assert sorted((gid[0, :2] - 11).tolist()) == [3, n - 5]
 
 
+@pytest.mark.parametrize("dtype_name,metric,dim,n,k,b", [TILE_CASES[0], TILE_CASES[2]])
+def test_exact_scan_through_the_512_thread_tile_build(orc, hv, monkeypatch, capfd, dtype_name, metric, dim, n, k, b):
+    """HVX_FLAT_TILE_BUILD=0: the one-workgroup-per-CU build (256 x 256 tiles, two 64-deep LDS buffers) that carries the
+    measurement switches -- same answers as the default build and the oracle."""
+    monkeypatch.setenv("HVX_FLAT_TILE_BUILD", "0")
+    test_exact_scan_through_the_256_tile_kernel(orc, hv, monkeypatch, capfd, dtype_name, metric, dim, n, k, b)
+
+
+def test_exact_scan_lanes_share_one_bf16_shadow(orc, hv, monkeypatch, capfd):
+    """Forked handles (execution lanes) of an f32 index scan through ONE bf16 shadow of the rows, whichever lane builds it."""
+    rng = np.random.default_rng(77)
+    n, dim, b, k = 30000, 512, 600, 10
+    centers = rng.standard_normal((32, dim)).astype(np.float32)
+    data = (centers[rng.integers(0, 32, n)] + 0.5 * rng.standard_normal((n, dim))).astype(np.float32)
+    gix = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=hv.EUCLIDEAN, node_ids=np.arange(n, dtype=np.uint64), vectors=data,
+                                              l0_offsets=np.zeros(n + 1, np.uint64), l0_neighbors=np.zeros(0, np.uint64), max_batch=b)
+    lane = gix.fork()
+    q = (centers[rng.integers(0, 32, b)] + 0.5 * rng.standard_normal((b, dim))).astype(np.float32)
+    monkeypatch.setenv("HVX_FLAT_DEBUG", "1")
+    capfd.readouterr()
+    lid, lsc, lcnt, _ = lane.flat_search_batch(q, k)       # the fork builds the shadow ...
+    assert "256 x 256 tiles" in capfd.readouterr().err
+    gid, gsc, gcnt, _ = gix.flat_search_batch(q, k)        # ... the parent finds it
+    assert "256 x 256 tiles" in capfd.readouterr().err
+    assert lid.tolist() == gid.tolist() and bits(lsc).tolist() == bits(gsc).tolist()
+    lane.close()
+    gid2, gsc2, _, _ = gix.flat_search_batch(q, k)         # and keeps it after the lane is gone
+    assert gid2.tolist() == gid.tolist() and bits(gsc2).tolist() == bits(gsc).tolist()
+    for qi in range(0, b, 60):
+        rc, oid, osc = orc.flat_matrix(orc.L2SQ, data, q[qi], k, kernel=orc.K_AVX_FMA_HW)
+        assert rc == orc.OK and gid[qi].tolist() == oid.tolist() and bits(gsc[qi]).tolist() == bits(osc).tolist()
+
+
 def test_restricted_scan_through_the_256_tile_kernel(orc, hv, monkeypatch, capfd):
     """The 256 x 256 kernel gathers its row tile through the candidate row list (restricted scans over bf16 rows)."""
     rng = np.random.default_rng(71)

@@ -648,8 +648,9 @@ hipError_t launch_flat_tile256(const MfmaArgs &a, int kind, uint32_t bpad, float
     t.ablate = [] { const char *e = getenv("HVX_FLAT_TILE_ABLATE"); return e ? (uint32_t)atoi(e) : 0u; }();
     const uint32_t rblocks = (t.nr_tiles + 8u * t.sup_r - 1) / (8u * t.sup_r);
     const dim3 grid(8u * rblocks * t.sup_qblocks * t.sup_r * t.sup_q);
-    static const int build = [] { const char *e = getenv("HVX_FLAT_TILE_BUILD"); return e ? atoi(e) : 3; }(); // 0: one 512-thread workgroup per CU (256 x 256 tiles, two LDS buffers), else: two 256-thread workgroups per CU (256 x 128)
-    if (build == 4) { // 256 x 256 tiles, 256 threads of 128 x 128 each, one workgroup per CU
+    const int build = [] { const char *e = getenv("HVX_FLAT_TILE_BUILD"); return e ? atoi(e) : 3; }(); // 0: one 512-thread workgroup per CU (256 x 256 tiles, two LDS buffers), else: two 256-thread workgroups per CU (256 x 128)
+    if (build == 4) { // 256 x 256 tiles, 256 threads of 128 x 128 each, one workgroup per CU.  OPT-IN: written and compiled (256 VGPRs +
+                      // 256 AGPRs, no spill in the main loop) after the round's GPU budget was spent -- not yet run on hardware
         if (kind == 1) hipLaunchKernelGGL((flat_tile4_kernel<1>), grid, dim3(256), 0, s, t, xmax2, wg_overflow);
         else hipLaunchKernelGGL((flat_tile4_kernel<0>), grid, dim3(256), 0, s, t, xmax2, wg_overflow);
         return hipGetLastError();
@@ -663,7 +664,7 @@ hipError_t launch_flat_tile256(const MfmaArgs &a, int kind, uint32_t bpad, float
         else hipLaunchKernelGGL((flat_tile2_kernel<0>), grid2, dim3(256), 0, s, t, xmax2, wg_overflow);
         return hipGetLastError();
     }
-    static const bool pipe = [] { const char *e = getenv("HVX_FLAT_TILE_PIPE"); return !e || e[0] != '0'; }();
+    const bool pipe = [] { const char *e = getenv("HVX_FLAT_TILE_PIPE"); return !e || e[0] != '0'; }();
     if (kind == 1) {
         if (pipe) hipLaunchKernelGGL((flat_tile256_kernel<1, true>), grid, dim3(512), 0, s, t, xmax2, wg_overflow);
         else hipLaunchKernelGGL((flat_tile256_kernel<1, false>), grid, dim3(512), 0, s, t, xmax2, wg_overflow);

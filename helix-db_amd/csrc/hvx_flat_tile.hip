@@ -623,16 +623,17 @@ __global__ __launch_bounds__(256, 1) void flat_tile4_kernel(MfmaArgs a, float xm
         read_raw(0, 0, fa0, fb0);
         if (FP8) { wait_lgkm0(); widen(0, fb0); }
     }
-    for (uint32_t s = 0; s < nstage; ++s) {
+    auto stage = [&](uint32_t s, bool more) {
         const uint32_t buf = s % NBUF;
-        const bool more = s + 1 < nstage;
 #pragma unroll
         for (int kk = 0; kk < SPS; kk += 2) {
             step(true, false, s, buf, kk + 1, fa0, fb0, fa1, fb1);
             if (kk + 2 < SPS) step(true, false, s, buf, kk + 2, fa1, fb1, fa0, fb0);
             else step(more, true, s, (s + 1) % NBUF, 0, fa1, fb1, fa0, fb0);
         }
-    }
+    };
+    for (uint32_t s = 0; s + 1 < nstage; ++s) stage(s, true);
+    stage(nstage - 1u, false); // peeled: the last stage requests nothing beyond itself (and the exit path carries no outstanding read)
     tile_epilogue<FP8, 4>(a, acc, lds, q0, r0, wm, wn, tid, xmax2, wg_overflow);
 }
 

@@ -3,6 +3,7 @@ and the host-side mirror of the reference interface behaves like the reference (
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -208,6 +209,45 @@ def test_header_is_plain_c_and_the_c_example_links(tmp_path):
     out = subprocess.run(cmd, capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert exe.exists()
+
+
+def test_inline_asm_lds_reads_are_covered_by_a_wait(tmp_path):
+    """The large-tile exact-scan kernels read their MFMA fragments with inline-asm ds_read_b128 and state the lgkmcnt waits
+    themselves; the compiler treats an asm output as valid at once and may copy / consume it before the LDS has answered
+    (seen on hardware: the fp8 instantiation of flat_tile4_kernel returned wrong candidates).  scripts/lint_asm_lds.py walks
+    the control-flow graph of the gfx950 assembly: no instruction may touch a requested register before a covering wait."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "helix-db_amd", "csrc", "hvx_flat_tile.hip")
+    asm = tmp_path / "hvx_flat_tile.s"
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S", "--cuda-device-only",
+                          "-o", str(asm), src], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    lint = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "lint_asm_lds.py"), str(asm), "flat_tile2_kernel", "flat_tile4_kernel"],
+                          capture_output=True, text=True)
+    assert lint.returncode == 0, lint.stdout + lint.stderr
+    assert lint.stdout.count(": 0 hazard(s)") == 3, lint.stdout    # fp8 + bf16 builds of the default kernel, bf16 build of the opt-in one
+
+
+def test_tile_operand_order_of_fp8_queries_is_a_permutation():
+    """tile_slot_fp8 (csrc/hvx_flat_mfma.h): inside every 64-code stage, MFMA step kk, lane half h, element e must read code
+    (2 (kk >> 1) + h) * 16 + (kk & 1) * 8 + e -- the query operand is stored in that order; a python twin checks the formula is a
+    bijection of each 64-block and agrees with the read pattern of the kernels."""
+    def tile_slot(slot):
+        c, u, sb, e = slot & 63, (slot & 63) >> 4, ((slot & 63) >> 3) & 1, slot & 7
+        kk, h = (u >> 1) * 2 + sb, u & 1
+        return (slot & ~63) + kk * 16 + h * 8 + e
+    for base in (0, 64, 1472):
+        image = [tile_slot(base + c) for c in range(64)]
+        assert sorted(image) == list(range(base, base + 64))
+        for kk in range(4):
+            for h in range(2):
+                for e in range(8):
+                    code = (2 * (kk >> 1) + h) * 16 + (kk & 1) * 8 + e
+                    assert tile_slot(base + code) == base + kk * 16 + h * 8 + e
 
 
 def test_row_codecs_and_key_parser_survive_arbitrary_bytes():

@@ -148,7 +148,7 @@ def main():
             end = next(i for i in range(st, len(text)) if "s_endpgm" in text[i])
             probs = lint_kernel([(i + 1, text[i]) for i in range(st + 1, end + 1)])
             print(f"{text[st].split(':')[0]}: {len(probs)} hazard(s)")
-            for no, line, pno, ptxt in probs[:8]:
+            for no, line, pno, ptxt in probs[:int(__import__("os").environ.get("LINT_SHOW", "8"))]:
                 print(f"   line {no}: `{line}` touches a register requested at line {pno}: `{ptxt}` with no covering s_waitcnt lgkmcnt")
             bad |= bool(probs)
     sys.exit(1 if bad else 0)

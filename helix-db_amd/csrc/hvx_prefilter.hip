@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -46,6 +47,7 @@ struct hvx_csr {
     uint32_t *cnt = nullptr;                        // [n + 1] per frontier position: discovery arcs (then their exclusive scan)
     uint32_t *ord_node = nullptr, *ord_parent = nullptr, *ord_arc = nullptr; // [n] visits in discovery order
     uint32_t *lvl = nullptr;                        // [4] level start, level size, next level size
+    void *host = nullptr;                           // HostCsr mirror (hvx_traverse_dfs), fetched on first use
 };
 
 namespace {
@@ -138,8 +140,11 @@ int csr_alloc(hvx_csr *g, void **p, size_t bytes) {
     return HVX_OK;
 }
 
+void host_csr_free(void *p); // the host mirror of hvx_traverse_dfs (defined with HostCsr below)
+
 void csr_free(hvx_csr *g) {
     if (!g) return;
+    host_csr_free(g->host);
     (void)hipSetDevice(g->device);
     for (void *p : g->allocs) (void)hipFree(p);
     if (g->stream) (void)hipStreamDestroy(g->stream);
@@ -627,6 +632,201 @@ extern "C" int hvx_traverse_ordered(const hvx_csr *cg, const uint64_t *seeds, ui
         if (out_against) out_against[i] = seed ? 0u : (ha[i] >> 31);
     }
     return HVX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Graph::traverse on the host (traversal.rs:197-309), both strategies.  DepthFirst is one dependent chain of stack pops -- there
+// is nothing for a GPU in it -- so it runs here, over host arrays (hvx_traverse_host: callers that hold the CSR on the host, and
+// the CPU tests) or over a host mirror of a device CSR fetched on first use (hvx_traverse_dfs).  BreadthFirst is included as the
+// cross-check of the device's level-synchronous order (hvx_traverse_ordered).
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct HostCsr {
+    uint32_t n = 0;
+    std::vector<uint64_t> out_off, in_off;
+    std::vector<uint32_t> out_tgt, in_tgt, out_lab, in_lab, in_arc;
+    bool labeled = false;
+};
+
+void host_csr_free(void *p) { delete static_cast<HostCsr *>(p); }
+
+struct HostArc { uint32_t nb; uint32_t edge; uint32_t against; };
+
+// the arcs of `u` in the reference's order (model.rs:635-725), label filter applied
+void host_arcs(const HostCsr &g, uint32_t u, uint32_t direction, const std::vector<uint32_t> &allowed, std::vector<HostArc> &out) {
+    out.clear();
+    auto ok = [&](const std::vector<uint32_t> &lab, uint64_t a) {
+        if (!g.labeled || allowed.empty()) return true;
+        return std::find(allowed.begin(), allowed.end(), lab[a]) != allowed.end();
+    };
+    uint64_t i = g.out_off[u], i1 = g.out_off[u + 1], j = g.in_off[u], j1 = g.in_off[u + 1];
+    if (direction == HVX_DIR_OUT) j = j1;
+    if (direction == HVX_DIR_IN) i = i1;
+    while (i < i1 || j < j1) {
+        if (direction == HVX_DIR_BOTH && j < j1 && g.in_tgt[j] == u) { ++j; continue; } // incoming self-loops are skipped
+        const bool take_out = j >= j1 || (i < i1 && g.out_tgt[i] <= g.in_tgt[j]);
+        if (take_out) { if (ok(g.out_lab, i)) out.push_back({g.out_tgt[i], (uint32_t)i, 0u}); ++i; }
+        else { if (ok(g.in_lab, j)) out.push_back({g.in_tgt[j], g.in_arc[j], 1u}); ++j; }
+    }
+}
+
+int host_traverse(const HostCsr &g, uint32_t strategy, const uint64_t *seeds, uint32_t n_seeds, uint32_t max_depth, uint32_t direction,
+                  const uint32_t *allowed_label_ids, uint32_t n_labels, uint32_t hub_degree, uint64_t capacity, uint64_t *out_nodes,
+                  uint32_t *out_depths, uint64_t *out_parents, uint64_t *out_edges, uint32_t *out_against, uint64_t *out_count) {
+    if (!out_count) return fail(HVX_ERR_INVARIANT, "null argument");
+    *out_count = 0;
+    if (direction > HVX_DIR_BOTH || strategy > 1u) return fail(HVX_ERR_INVARIANT, "bad direction / strategy");
+    if (n_seeds == 0) return fail(HVX_ERR_INVARIANT, "traversal requires at least one seed"); // traversal.rs:198-202
+    std::vector<uint32_t> seed_list;
+    for (uint32_t i = 0; i < n_seeds; ++i) {
+        if (seeds[i] >= g.n) return fail(HVX_ERR_INVARIANT, "unknown node %llu", (unsigned long long)seeds[i]);
+        if (std::find(seed_list.begin(), seed_list.end(), (uint32_t)seeds[i]) == seed_list.end()) seed_list.push_back((uint32_t)seeds[i]);
+    }
+    const std::vector<uint32_t> allowed(allowed_label_ids, allowed_label_ids + n_labels);
+    std::vector<uint8_t> visited(g.n, 0), is_seed(g.n, 0);
+    for (uint32_t s : seed_list) is_seed[s] = 1;
+    struct Visit { uint32_t node, depth, parent, edge, against; bool has_edge; };
+    std::vector<Visit> visits;
+    std::vector<HostArc> arcs;
+    auto expands = [&](uint32_t u, uint32_t depth) {
+        if (depth >= max_depth) return false;
+        if (!is_seed[u] && hub_degree && (g.out_off[u + 1] - g.out_off[u]) + (g.in_off[u + 1] - g.in_off[u]) >= hub_degree) return false;
+        return true;
+    };
+    if (strategy == 0u) { // BreadthFirst (traversal.rs:216-261)
+        size_t head = 0;
+        for (uint32_t s : seed_list) { visited[s] = 1; visits.push_back({s, 0, 0, 0, 0, false}); }
+        while (head < visits.size()) {
+            const Visit cur = visits[head++];
+            if (!expands(cur.node, cur.depth)) continue;
+            host_arcs(g, cur.node, direction, allowed, arcs);
+            for (const HostArc &a : arcs) {
+                if (visited[a.nb]) continue;
+                visited[a.nb] = 1;
+                visits.push_back({a.nb, cur.depth + 1, cur.node, a.edge, a.against, true});
+            }
+        }
+    } else { // DepthFirst (traversal.rs:263-309): marked when scheduled, recorded when popped
+        std::vector<Visit> stack;
+        for (size_t i = seed_list.size(); i-- > 0;)
+            if (!visited[seed_list[i]]) { visited[seed_list[i]] = 1; stack.push_back({seed_list[i], 0, 0, 0, 0, false}); }
+        std::vector<HostArc> chosen;
+        while (!stack.empty()) {
+            const Visit cur = stack.back();
+            stack.pop_back();
+            visits.push_back(cur);
+            if (!expands(cur.node, cur.depth)) continue;
+            host_arcs(g, cur.node, direction, allowed, arcs);
+            chosen.clear();
+            for (const HostArc &a : arcs) { // one arc per unvisited neighbour: the first in arc order (`discovered.insert`)
+                if (visited[a.nb]) continue;
+                bool dup = false;
+                for (const HostArc &c : chosen) dup |= c.nb == a.nb;
+                if (!dup) chosen.push_back(a);
+            }
+            for (size_t i = chosen.size(); i-- > 0;) {
+                visited[chosen[i].nb] = 1;
+                stack.push_back({chosen[i].nb, cur.depth + 1, cur.node, chosen[i].edge, chosen[i].against, true});
+            }
+        }
+    }
+    *out_count = visits.size();
+    if (visits.size() > capacity) return fail(HVX_ERR_INVARIANT, "traversal visited %zu nodes, the output holds %llu", visits.size(), (unsigned long long)capacity);
+    for (size_t i = 0; i < visits.size(); ++i) {
+        const Visit &v = visits[i];
+        if (out_nodes) out_nodes[i] = v.node;
+        if (out_depths) out_depths[i] = v.depth;
+        if (out_parents) out_parents[i] = v.has_edge ? v.parent : UINT64_MAX;
+        if (out_edges) out_edges[i] = v.has_edge ? v.edge : UINT64_MAX;
+        if (out_against) out_against[i] = v.has_edge ? v.against : 0u;
+    }
+    return HVX_OK;
+}
+
+// outgoing arrays -> HostCsr (incoming rows by stable counting sort: sources ascending, parallel edges in outgoing-row order)
+int host_csr_build(uint64_t n_nodes, uint64_t n_edges, const uint64_t *out_offsets, const uint64_t *out_targets, const uint32_t *edge_labels,
+                   HostCsr &g) {
+    if (n_nodes >= (1ull << 32) - 1 || n_edges >= (1ull << 31)) return fail(HVX_ERR_UNSUPPORTED, "graph too large for the host traversal");
+    if (n_nodes && (!out_offsets || out_offsets[0] != 0 || out_offsets[n_nodes] != n_edges)) return fail(HVX_ERR_INVARIANT, "offsets do not span the edge array");
+    if (n_edges && !out_targets) return fail(HVX_ERR_INVARIANT, "null targets");
+    g.n = (uint32_t)n_nodes;
+    g.labeled = edge_labels != nullptr;
+    g.out_off.assign(out_offsets, out_offsets + (n_nodes ? n_nodes + 1 : 0));
+    if (!n_nodes) g.out_off.assign(1, 0);
+    g.out_tgt.resize(n_edges);
+    g.in_off.assign(n_nodes + 1, 0);
+    for (uint64_t u = 0; u < n_nodes; ++u) {
+        if (out_offsets[u + 1] < out_offsets[u]) return fail(HVX_ERR_INVARIANT, "offsets not monotone");
+        for (uint64_t a = out_offsets[u]; a < out_offsets[u + 1]; ++a) {
+            if (out_targets[a] >= n_nodes) return fail(HVX_ERR_INVARIANT, "edge target out of range");
+            if (a > out_offsets[u] && out_targets[a] < out_targets[a - 1])
+                return fail(HVX_ERR_UNSUPPORTED, "ordered traversal needs outgoing rows sorted by target (model.rs:656-666)");
+            g.out_tgt[a] = (uint32_t)out_targets[a];
+            g.in_off[out_targets[a] + 1]++;
+        }
+    }
+    for (uint64_t v = 0; v < n_nodes; ++v) g.in_off[v + 1] += g.in_off[v];
+    g.in_tgt.resize(n_edges);
+    g.in_arc.resize(n_edges);
+    if (g.labeled) { g.out_lab.assign(edge_labels, edge_labels + n_edges); g.in_lab.resize(n_edges); }
+    std::vector<uint64_t> cur(g.in_off.begin(), g.in_off.end() - 1);
+    for (uint64_t u = 0; u < n_nodes; ++u)
+        for (uint64_t a = out_offsets[u]; a < out_offsets[u + 1]; ++a) {
+            const uint64_t slot = cur[out_targets[a]]++;
+            g.in_tgt[slot] = (uint32_t)u;
+            g.in_arc[slot] = (uint32_t)a;
+            if (g.labeled) g.in_lab[slot] = edge_labels[a];
+        }
+    return HVX_OK;
+}
+
+} // namespace
+
+extern "C" int hvx_traverse_host(uint64_t n_nodes, uint64_t n_edges, const uint64_t *out_offsets, const uint64_t *out_targets,
+                                 const uint32_t *edge_labels, uint32_t strategy, const uint64_t *seeds, uint32_t n_seeds,
+                                 uint32_t max_depth, uint32_t direction, const uint32_t *allowed_label_ids, uint32_t n_labels,
+                                 uint32_t hub_degree, uint64_t capacity, uint64_t *out_nodes, uint32_t *out_depths,
+                                 uint64_t *out_parents, uint64_t *out_edges, uint32_t *out_against, uint64_t *out_count) {
+    HostCsr g;
+    int rc = host_csr_build(n_nodes, n_edges, out_offsets, out_targets, edge_labels, g);
+    if (rc) return rc;
+    return host_traverse(g, strategy, seeds, n_seeds, max_depth, direction, allowed_label_ids, n_labels, hub_degree, capacity, out_nodes,
+                         out_depths, out_parents, out_edges, out_against, out_count);
+}
+
+extern "C" int hvx_traverse_dfs(const hvx_csr *cg, const uint64_t *seeds, uint32_t n_seeds, uint32_t max_depth, uint32_t direction,
+                                const uint32_t *allowed_label_ids, uint32_t n_labels, uint32_t hub_degree, uint64_t capacity,
+                                uint64_t *out_nodes, uint32_t *out_depths, uint64_t *out_parents, uint64_t *out_edges,
+                                uint32_t *out_against, uint64_t *out_count) {
+    if (!cg) return fail(HVX_ERR_INVARIANT, "null graph");
+    hvx_csr *g = const_cast<hvx_csr *>(cg);
+    if (!g->rows_sorted) return fail(HVX_ERR_UNSUPPORTED, "ordered traversal needs outgoing rows sorted by target (model.rs:656-666)");
+    if (g->e >= (1ull << 31)) return fail(HVX_ERR_UNSUPPORTED, "ordered traversal serves graphs below 2^31 edges");
+    std::lock_guard<std::mutex> lock(g->mu);
+    if (!g->host) { // host mirror of the device CSR, fetched once
+        HIP_TRY(hipSetDevice(g->device));
+        auto h = std::make_unique<HostCsr>();
+        h->n = g->n;
+        h->labeled = g->out_lab != nullptr;
+        h->out_off.resize((size_t)g->n + 1); h->in_off.resize((size_t)g->n + 1);
+        h->out_tgt.resize(g->e); h->in_tgt.resize(g->e); h->in_arc.resize(g->e);
+        HIP_TRY(hipMemcpy(h->out_off.data(), g->out_off, ((size_t)g->n + 1) * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(h->in_off.data(), g->in_off, ((size_t)g->n + 1) * 8, hipMemcpyDeviceToHost));
+        if (g->e) {
+            HIP_TRY(hipMemcpy(h->out_tgt.data(), g->out_tgt, g->e * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(h->in_tgt.data(), g->in_tgt, g->e * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(h->in_arc.data(), g->in_arc, g->e * 4, hipMemcpyDeviceToHost));
+            if (h->labeled) {
+                h->out_lab.resize(g->e); h->in_lab.resize(g->e);
+                HIP_TRY(hipMemcpy(h->out_lab.data(), g->out_lab, g->e * 4, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(h->in_lab.data(), g->in_lab, g->e * 4, hipMemcpyDeviceToHost));
+            }
+        }
+        g->host = h.release();
+    }
+    return host_traverse(*static_cast<const HostCsr *>(g->host), 1u, seeds, n_seeds, max_depth, direction, allowed_label_ids, n_labels,
+                         hub_degree, capacity, out_nodes, out_depths, out_parents, out_edges, out_against, out_count);
 }
 
 // ---------------------------------------------------------------------------------------------

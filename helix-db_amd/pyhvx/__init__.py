@@ -256,6 +256,11 @@ def lib():
     L.hvx_traverse_ordered.restype = C.c_int
     L.hvx_traverse_ordered.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint32, C.c_uint32, C.c_uint64,
                                        _vp, _vp, _vp, _vp, _vp, _vp]
+    L.hvx_traverse_dfs.restype = C.c_int
+    L.hvx_traverse_dfs.argtypes = L.hvx_traverse_ordered.argtypes
+    L.hvx_traverse_host.restype = C.c_int
+    L.hvx_traverse_host.argtypes = [C.c_uint64, C.c_uint64, _vp, _vp, _vp, C.c_uint32, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint32,
+                                    C.c_uint32, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp]
     L.hvx_expand_filter.restype = C.c_int
     L.hvx_expand_filter.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32, _vp]
     _lib = L
@@ -729,6 +734,33 @@ class Batcher:
         return {"batches": int(a.value), "queries": int(b.value), "full_batches": int(c.value)}
 
 
+def _visit_arrays(cap):
+    return (np.zeros(cap, np.uint64), np.zeros(cap, np.uint32), np.zeros(cap, np.uint64), np.zeros(cap, np.uint64), np.zeros(cap, np.uint32))
+
+
+def _visits_of(arrs, c):
+    nodes, depths, parents, edges, against = arrs
+    visits = [(int(nodes[i]), int(depths[i])) for i in range(c)]
+    disc = [(int(parents[i]), int(edges[i]), int(against[i])) for i in range(c) if parents[i] != np.uint64(0xFFFFFFFFFFFFFFFF)]
+    return visits, disc
+
+
+def traverse_host(n_nodes, out_offsets, out_targets, edge_labels, seeds, max_depth, direction=DIR_BOTH, allowed_labels=(), hub_degree=0,
+                  depth_first=False):
+    """Graph::traverse entirely on the host (hvx_traverse_host): no device, no Graph handle.  Returns (visits, edges)."""
+    off = np.ascontiguousarray(out_offsets, dtype=np.uint64)
+    tgt = np.ascontiguousarray(out_targets, dtype=np.uint64)
+    lab = None if edge_labels is None else np.ascontiguousarray(edge_labels, dtype=np.uint32)
+    s = np.ascontiguousarray(seeds, dtype=np.uint64)
+    al = np.ascontiguousarray(list(allowed_labels), dtype=np.uint32)
+    cap = max(int(n_nodes), 1)
+    arrs = _visit_arrays(cap)
+    cnt = C.c_uint64(0)
+    _check(lib().hvx_traverse_host(int(n_nodes), tgt.size, _ptr(off), _ptr(tgt), _ptr(lab), 1 if depth_first else 0, _ptr(s), s.size,
+                                   max_depth, direction, _ptr(al), al.size, hub_degree, cap, *[_ptr(a) for a in arrs], C.byref(cnt)))
+    return _visits_of(arrs, cnt.value)
+
+
 class Graph:
     """Device CSR for the graph prefilter (crates/graph-algorithms Graph::traverse; interpreter expand)."""
 
@@ -777,6 +809,18 @@ class Graph:
         visits = [(int(nodes[i]), int(depths[i])) for i in range(c)]
         disc = [(int(parents[i]), int(edges[i]), int(against[i])) for i in range(c) if parents[i] != np.uint64(0xFFFFFFFFFFFFFFFF)]
         return visits, disc
+
+    def traverse_depth_first(self, seeds, max_depth, direction=DIR_BOTH, allowed_labels=(), hub_degree=0):
+        """Graph::traverse with TraversalStrategy::DepthFirst (traversal.rs:263-309; host-side, hvx_traverse_dfs); returns
+        (visits, edges) shaped like traverse_ordered."""
+        s = np.ascontiguousarray(seeds, dtype=np.uint64)
+        lab = np.ascontiguousarray(list(allowed_labels), dtype=np.uint32)
+        cap = max(self.n, 1)
+        arrs = _visit_arrays(cap)
+        cnt = C.c_uint64(0)
+        _check(lib().hvx_traverse_dfs(self._h, _ptr(s), s.size, max_depth, direction, _ptr(lab), lab.size, hub_degree, cap,
+                                      *[_ptr(a) for a in arrs], C.byref(cnt)))
+        return _visits_of(arrs, cnt.value)
 
     def expand(self, rows, direction=DIR_OUT, allowed_labels=()):
         s = np.ascontiguousarray(rows, dtype=np.uint64)

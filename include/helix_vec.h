@@ -314,6 +314,20 @@ int hvx_traverse_ordered(const hvx_csr *, const uint64_t *seeds, uint32_t n_seed
                          const uint32_t *allowed_label_ids, uint32_t n_labels, uint32_t hub_degree, uint64_t capacity,
                          uint64_t *out_nodes, uint32_t *out_depths, uint64_t *out_parents, uint64_t *out_edges,
                          uint32_t *out_against, uint64_t *out_count);
+/* Graph::traverse with TraversalStrategy::DepthFirst (traversal.rs:263-309): a node is marked when it is scheduled and recorded
+ * when it is popped; one dependent chain of stack pops, so it runs on the HOST over a mirror of the device CSR fetched on first
+ * use.  Same outputs, arc order, limits and statuses as hvx_traverse_ordered. */
+int hvx_traverse_dfs(const hvx_csr *, const uint64_t *seeds, uint32_t n_seeds, uint32_t max_depth, uint32_t direction,
+                     const uint32_t *allowed_label_ids, uint32_t n_labels, uint32_t hub_degree, uint64_t capacity,
+                     uint64_t *out_nodes, uint32_t *out_depths, uint64_t *out_parents, uint64_t *out_edges,
+                     uint32_t *out_against, uint64_t *out_count);
+/* The same traversal entirely on the host, over caller-held arrays (no device, no hvx_csr): strategy 0 = BreadthFirst,
+ * 1 = DepthFirst.  For hosts that keep their Csr in RAM, and as the CPU cross-check of the device's level-synchronous order. */
+int hvx_traverse_host(uint64_t n_nodes, uint64_t n_edges, const uint64_t *out_offsets, const uint64_t *out_targets,
+                      const uint32_t *edge_labels /*nullable*/, uint32_t strategy, const uint64_t *seeds, uint32_t n_seeds,
+                      uint32_t max_depth, uint32_t direction, const uint32_t *allowed_label_ids, uint32_t n_labels,
+                      uint32_t hub_degree, uint64_t capacity, uint64_t *out_nodes, uint32_t *out_depths, uint64_t *out_parents,
+                      uint64_t *out_edges, uint32_t *out_against, uint64_t *out_count);
 /* One interpreter `expand` hop (crates/db/src/execution/interpreter/access/expand.rs:16-80): the
  * union of the neighbours of every input row (an input row that is itself a neighbour of another
  * input row IS included) as the candidate bitmap handed to the restricted vector search. */

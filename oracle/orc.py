@@ -662,3 +662,65 @@ def breadth_first(n, out_offsets, out_targets, labels, seeds, max_depth, directi
             visits.append((v, depth[v]))
             edges.append((u, a, against))
     return visits, edges
+
+
+def depth_first(n, out_offsets, out_targets, labels, seeds, max_depth, direction=2, allowed_labels=(), hub_degree=0):
+    """`Graph::traverse` with TraversalStrategy::DepthFirst, restated: crates/graph-algorithms/src/algorithms/traversal.rs:263-309.
+    Seeds are pushed in reverse (so the first seed is visited first) and marked when pushed; a node is recorded when it is
+    POPPED; its unvisited, label-allowed neighbours -- one arc per neighbour, the first in arc order (`discovered.insert`) --
+    are marked and pushed in reverse arc order, each with the arc that scheduled it as its discovery edge.  Arc order,
+    hub policy and the returned shapes as in `breadth_first` above."""
+    out = [[] for _ in range(n)]
+    inc = [[] for _ in range(n)]
+    for u in range(n):
+        for a in range(int(out_offsets[u]), int(out_offsets[u + 1])):
+            lab = None if labels is None else int(labels[a])
+            out[u].append((int(out_targets[a]), lab, a))
+    for u in range(n):
+        for (v, lab, a) in out[u]:
+            inc[v].append((u, lab, a))
+
+    def arcs(u):
+        if direction == 0:
+            return [(v, lab, a, 0) for (v, lab, a) in out[u]]
+        if direction == 1:
+            return [(v, lab, a, 1) for (v, lab, a) in inc[u]]
+        merged, i, j = [], 0, 0
+        o, c = out[u], [x for x in inc[u] if x[0] != u]
+        while i < len(o) or j < len(c):
+            if j >= len(c) or (i < len(o) and o[i][0] <= c[j][0]):
+                merged.append(o[i] + (0,)); i += 1
+            else:
+                merged.append(c[j] + (1,)); j += 1
+        return merged
+
+    seed_list = []
+    for s in seeds:
+        s = int(s)
+        if not 0 <= s < n:
+            raise KeyError(f"unknown node {s}")
+        if s not in seed_list:
+            seed_list.append(s)
+    allowed = set(int(x) for x in allowed_labels)
+    visited, stack, visits, edges = set(), [], [], []
+    for s in reversed(seed_list):
+        if s not in visited:
+            visited.add(s)
+            stack.append((s, 0, None))
+    while stack:
+        u, d, disc = stack.pop()
+        visits.append((u, d))
+        if disc is not None:
+            edges.append(disc)
+        if d >= max_depth or (u not in seed_list and hub_degree and len(out[u]) + len(inc[u]) >= hub_degree):
+            continue
+        chosen, seen = [], set()
+        for (v, lab, a, against) in arcs(u):
+            if v in visited or (allowed and lab not in allowed) or v in seen:
+                continue
+            seen.add(v)
+            chosen.append((v, a, against))
+        for (v, a, against) in reversed(chosen):
+            visited.add(v)
+            stack.append((v, d + 1, (u, a, against)))
+    return visits, edges

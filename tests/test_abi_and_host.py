@@ -211,6 +211,41 @@ def test_header_is_plain_c_and_the_c_example_links(tmp_path):
     assert exe.exists()
 
 
+def test_host_traversal_equals_the_oracle_in_both_strategies(orc):
+    """hvx_traverse_host (Graph::traverse on the host: BreadthFirst and DepthFirst, traversal.rs:197-309) against the oracle's
+    restatements -- the reference's own fixtures first, then random multigraphs (parallel edges with different labels,
+    self-loops) over every direction, label allow-sets, the hub policy, several seeds in a given order, depth caps."""
+    import pyhvx as hv
+    off = np.array([0, 3, 4, 5, 5], np.uint64)                                   # traversal.rs:667-700
+    tgt = np.array([1, 1, 2, 3, 3], np.uint64)
+    visits, edges = hv.traverse_host(4, off, tgt, None, [0], 3, hv.DIR_OUT, depth_first=True)
+    assert visits == [(0, 0), (1, 1), (3, 2), (2, 1)] and [a for _, a, _ in edges] == [0, 3, 2]
+    e = [(0, 1), (1, 2), (1, 3), (3, 4), (3, 5), (3, 6)]                          # traversal.rs:576-615
+    off = np.zeros(8, np.uint64); tgt = np.array([t for _, t in e], np.uint64)
+    for s_, _ in e:
+        off[s_ + 1:] += 1
+    visits, edges = hv.traverse_host(7, off, tgt, None, [0], 2)
+    assert visits == [(0, 0), (1, 1), (2, 2), (3, 2)] and len(edges) == 3
+    rng = np.random.default_rng(12)
+    for n, deg, nlab in [(300, 4, 3), (2000, 6, 4), (64, 40, 2)]:
+        rows = [np.sort(rng.integers(0, n, rng.integers(0, 2 * deg + 1))) for _ in range(n)]
+        off = np.zeros(n + 1, np.uint64); off[1:] = np.cumsum([len(r) for r in rows])
+        tgt = np.concatenate(rows).astype(np.uint64)
+        lab = rng.integers(0, nlab, int(off[-1])).astype(np.uint32)
+        cases = [([3], 2, 0, [], 0), ([3, 7, 3, 1], 3, 2, [1, 2], 0), ([10, 11], 4, 1, [], 2 * deg + 3), ([0], 0, 2, [], 0),
+                 ([5, 6, 7], 60, 0, [0], 0), ([n - 1], 1000, 2, [], 0), ([2, 1], 5, 2, [0], 3 * deg)]
+        for seeds, md, direction, allowed, hub in cases:
+            for dfs, ref in ((False, orc.breadth_first), (True, orc.depth_first)):
+                got = hv.traverse_host(n, off, tgt, lab, seeds, md, direction, allowed, hub, depth_first=dfs)
+                want = ref(n, off.astype(np.int64), tgt, lab, seeds, md, direction, allowed, hub)
+                assert got[0] == want[0], f"n={n} {'dfs' if dfs else 'bfs'} case {(seeds, md, direction, allowed, hub)}: visits differ"
+                assert got[1] == want[1], f"n={n} {'dfs' if dfs else 'bfs'} case {(seeds, md, direction, allowed, hub)}: edges differ"
+    with pytest.raises(hv.HelixDbError):
+        hv.traverse_host(3, np.array([0, 2, 2, 2], np.uint64), np.array([2, 1], np.uint64), None, [0], 1)   # unsorted row
+    with pytest.raises(hv.HelixDbError):
+        hv.traverse_host(4, off[:5] * 0, np.zeros(0, np.uint64), None, [9], 1)                                # unknown seed
+
+
 def test_inline_asm_lds_reads_are_covered_by_a_wait(tmp_path):
     """The large-tile exact-scan kernels read their MFMA fragments with inline-asm ds_read_b128 and state the lgkmcnt waits
     themselves; the compiler treats an asm output as valid at once and may copy / consume it before the LDS has answered

@@ -369,6 +369,9 @@ def test_ordered_traversal_matches_the_reference_visit_order_and_discovery_edges
             rv, re_ = orc.breadth_first(n, off.astype(np.int64), tgt, lab, seeds, md, direction, allowed, hub)
             assert visits == rv, f"n={n} case {(seeds, md, direction, allowed, hub)}: visit order differs"
             assert edges == re_, f"n={n} case {(seeds, md, direction, allowed, hub)}: discovery edges differ"
+            # DepthFirst (traversal.rs:263-309) runs on the host over a mirror of the device CSR
+            assert g.traverse_depth_first(seeds, md, direction, allowed, hub) == orc.depth_first(n, off.astype(np.int64), tgt, lab, seeds, md,
+                                                                                                  direction, allowed, hub)
     unsorted = hv.Graph(3, np.array([0, 2, 2, 2], np.uint64), np.array([2, 1], np.uint64), None)
     with pytest.raises(hv.HelixDbError) as ex:                            # rows that are not in the reference's order fail loudly
         unsorted.traverse_ordered([0], 1)

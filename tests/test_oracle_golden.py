@@ -331,6 +331,29 @@ def test_breadth_first_visit_order_and_discovery_edges(orc):
         assert [d for _, d in visits] == sorted(d for _, d in visits)
 
 
+def test_depth_first_marks_nodes_when_scheduled_and_uses_stable_edges(orc):
+    """traversal.rs:667-700: MultiDiGraph a->b (twice), a->c, b->d, c->d, direction Out, depth 3: visits a, b, d, c at depths
+    0, 1, 2, 1 (d is marked when b schedules it, so c does not reach it) and discovery edges ab-first, bd, ac."""
+    names = ["a", "b", "c", "d"]
+    off = np.array([0, 3, 4, 5, 5], np.int64)
+    tgt = np.array([1, 1, 2, 3, 3], np.uint64)            # arcs: ab-first, ab-second, ac, bd, cd
+    edge_names = ["ab-first", "ab-second", "ac", "bd", "cd"]
+    visits, edges = orc.depth_first(4, off, tgt, None, [0], 3, direction=0)
+    assert [(names[v], d) for v, d in visits] == [("a", 0), ("b", 1), ("d", 2), ("c", 1)]
+    assert [edge_names[a] for _, a, _ in edges] == ["ab-first", "bd", "ac"]
+    # the same visited set and depth bound as the breadth-first walk wherever both are defined
+    rng = np.random.default_rng(3)
+    n = 60
+    rows = [np.sort(rng.integers(0, n, rng.integers(0, 6))) for _ in range(n)]
+    off = np.zeros(n + 1, np.int64); off[1:] = np.cumsum([len(r) for r in rows])
+    tgt = np.concatenate(rows).astype(np.uint64)
+    for direction in (0, 1, 2):
+        dv, de = orc.depth_first(n, off, tgt, None, [5, 9, 5], 100, direction=direction)
+        bv, _ = orc.breadth_first(n, off, tgt, None, [5, 9, 5], 100, direction=direction)
+        assert {v for v, _ in dv} == {v for v, _ in bv} and len(de) == len(dv) - 2
+        assert len({v for v, _ in dv}) == len(dv)
+
+
 def test_traversal_includes_but_does_not_expand_non_seed_hubs(orc):
     names, idx, n, off, tgt = _reference_traversal_graph()
     d = orc.breadth_first_depths(n, off, tgt, None, [idx["a"]], 4, direction=2, hub_degree=4)

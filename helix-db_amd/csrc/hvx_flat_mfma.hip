@@ -631,8 +631,8 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
         if (attempt == 2 && m0 >= 1023u) break;
         const uint32_t kc = m + 1;
         // first chunk (scored by the 128 x 128 kernel into the score matrix, top-(m + 1) selected from it): 16 384 rows when the
-        // filtered slices follow (1024 x 1M x 768: 2.43 ms vs 2.59 with 65 536), as much as the matrix allows otherwise
-        uint32_t chunk = allow_filter && m + 1 <= 256u && getenv("HVX_FLAT_NO_FILTER") == nullptr ? 16384u : 65536u;
+        // large-tile filtered slices follow (1024 x 1M x 768: 2.43 ms vs 2.59 with 65 536), 65 536 as before otherwise
+        uint32_t chunk = tile_ok && !full && allow_filter && m + 1 <= 256u && getenv("HVX_FLAT_NO_FILTER") == nullptr ? 16384u : 65536u;
         if (const char *e = getenv("HVX_FLAT_CHUNK")) chunk = std::max<uint32_t>(1024u, (uint32_t)atoi(e) / 1024u * 1024u); // tests: small first chunks
         while ((size_t)chunk * b * 4 > (512u << 20) && chunk > 1024) chunk >>= 1;
         if (chunk > n) chunk = (n + 3u) & ~3u;

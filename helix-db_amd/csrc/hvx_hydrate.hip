@@ -109,6 +109,22 @@ extern "C" int hvx_decode_upper_row(const uint8_t *value, size_t len, uint64_t *
     return HVX_OK;
 }
 
+// values/vectors/simhash.rs:39-61: the standalone SimHash row is exactly eight little-endian bytes
+extern "C" int hvx_decode_simhash_row(const uint8_t *value, size_t len, uint64_t *out_bits) {
+    if (!value || len != 8) return fail(HVX_ERR_INVARIANT, "SimHash row must be exactly 8 bytes (got %zu)", len);
+    uint64_t v = 0;
+    for (int i = 7; i >= 0; --i) v = (v << 8) | value[i];
+    if (out_bits) *out_bits = v;
+    return HVX_OK;
+}
+
+// values/vectors/entry.rs:25-47: the entry-candidate node row stores its HNSW layer as exactly two big-endian bytes
+extern "C" int hvx_decode_entry_candidate_layer(const uint8_t *value, size_t len, uint32_t *out_layer) {
+    if (!value || len != 2) return fail(HVX_ERR_INVARIANT, "entry-candidate layer row must be exactly 2 bytes (got %zu)", len);
+    if (out_layer) *out_layer = ((uint32_t)value[0] << 8) | value[1];
+    return HVX_OK;
+}
+
 // keys/tenant.rs:13-15,69-95: a tenant-scoped key is [0xFD][tenant_id: u128 BE] ++ the logical key; the legacy namespace has
 // no envelope.  Returns the envelope length (0 or 17) and the tenant id halves.
 extern "C" uint32_t hvx_strip_tenant_envelope(const uint8_t *key, size_t len, uint64_t *tenant_hi, uint64_t *tenant_lo) {

@@ -214,6 +214,10 @@ def lib():
     L.hvx_order_code_from_simhash_bits.argtypes = [C.c_uint64]
     L.hvx_decode_layer0_row.restype = C.c_int
     L.hvx_decode_layer0_row.argtypes = [C.c_char_p, C.c_size_t, _vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    L.hvx_decode_simhash_row.restype = C.c_int
+    L.hvx_decode_simhash_row.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64)]
+    L.hvx_decode_entry_candidate_layer.restype = C.c_int
+    L.hvx_decode_entry_candidate_layer.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32)]
     L.hvx_decode_upper_row.restype = C.c_int
     L.hvx_decode_upper_row.argtypes = [C.c_char_p, C.c_size_t, _vp, C.c_uint32, C.POINTER(C.c_uint32)]
     L.hvx_parse_vector_key.restype = C.c_uint32
@@ -982,6 +986,20 @@ def decode_layer0_row(value: bytes):
     cnt, sh, has = C.c_uint32(0), C.c_uint64(0), C.c_uint32(0)
     _check(lib().hvx_decode_layer0_row(value, len(value), _ptr(ids), ids.size, C.byref(cnt), C.byref(sh), C.byref(has)))
     return ids[: cnt.value].tolist(), (int(sh.value) if has.value else None)
+
+
+def decode_simhash_row(value: bytes) -> int:
+    """values/vectors/simhash.rs:46-61 decode_simhash."""
+    out = C.c_uint64(0)
+    _check(lib().hvx_decode_simhash_row(value, len(value), C.byref(out)))
+    return int(out.value)
+
+
+def decode_entry_candidate_layer(value: bytes) -> int:
+    """values/vectors/entry.rs:31-47 decode_entry_candidate_layer."""
+    out = C.c_uint32(0)
+    _check(lib().hvx_decode_entry_candidate_layer(value, len(value), C.byref(out)))
+    return int(out.value)
 
 
 def decode_upper_row(value: bytes):

@@ -390,6 +390,10 @@ typedef struct hvx_hydrator hvx_hydrator;
 int hvx_decode_layer0_row(const uint8_t *value, size_t len, uint64_t *out_ids, uint32_t cap, uint32_t *out_count,
                           uint64_t *out_simhash, uint32_t *out_has_simhash);
 int hvx_decode_upper_row(const uint8_t *value, size_t len, uint64_t *out_ids, uint32_t cap, uint32_t *out_count);
+/* values/vectors/simhash.rs:39-61 (standalone SimHash row: exactly 8 bytes, little-endian) and values/vectors/entry.rs:25-47
+ * (entry-candidate node row: its HNSW layer as exactly 2 big-endian bytes); non-exact lengths are rejected like the reference's */
+int hvx_decode_simhash_row(const uint8_t *value, size_t len, uint64_t *out_bits);
+int hvx_decode_entry_candidate_layer(const uint8_t *value, size_t len, uint32_t *out_layer);
 /* keys/tenant.rs:69-95: length of the tenant envelope in front of a key (17 = [0xFD][tenant_id u128 BE], 0 = legacy namespace) */
 uint32_t hvx_strip_tenant_envelope(const uint8_t *key, size_t len, uint64_t *tenant_hi, uint64_t *tenant_lo);
 /* The index metadata row [0x03][0x03][index_id][0x01] (keys/vectors.rs:23-38): rkyv 0.8 archive of VectorIndexMetadata

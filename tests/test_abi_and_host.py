@@ -211,6 +211,26 @@ def test_header_is_plain_c_and_the_c_example_links(tmp_path):
     assert exe.exists()
 
 
+def test_small_row_codecs_reproduce_the_reference_frozen_bytes_and_fuzz_seeds():
+    """values/vectors/simhash.rs:66-78 (`simhash_bytes_are_frozen`, truncation / trailing bytes rejected), values/vectors/entry.rs:
+    51-70 (`entry_candidate_layer_bytes_are_frozen`, non-exact lengths rejected) and the reference's checked-in fuzz corpus
+    (crates/db/fuzz/corpus/current_search_records/vector-{simhash,entry,layer0-empty}.bin = selector byte + payload + newline,
+    fuzzing.rs:256-270 `checked_in_corpus_seeds_are_contract_valid`)."""
+    import pyhvx as hv
+    assert hv.decode_simhash_row(bytes([8, 7, 6, 5, 4, 3, 2, 1])) == 0x0102_0304_0506_0708
+    for bad in (bytes(7), bytes(9), b""):
+        with pytest.raises(hv.HelixDbError):
+            hv.decode_simhash_row(bad)
+    assert hv.decode_entry_candidate_layer(bytes([0x12, 0x34])) == 0x1234
+    for bad in (b"", bytes(1), bytes(3)):
+        with pytest.raises(hv.HelixDbError):
+            hv.decode_entry_candidate_layer(bad)
+    seeds = {"vector-simhash.bin": b"712345678\n", "vector-entry.bin": b"3ab\n", "vector-layer0-empty.bin": b"8\n"}
+    assert hv.decode_simhash_row(seeds["vector-simhash.bin"][1:-1]) == int.from_bytes(b"12345678", "little")
+    assert hv.decode_entry_candidate_layer(seeds["vector-entry.bin"][1:-1]) == 0x6162
+    assert hv.decode_layer0_row(seeds["vector-layer0-empty.bin"][1:-1]) == ([], None)
+
+
 def test_host_traversal_equals_the_oracle_in_both_strategies(orc):
     """hvx_traverse_host (Graph::traverse on the host: BreadthFirst and DepthFirst, traversal.rs:197-309) against the oracle's
     restatements -- the reference's own fixtures first, then random multigraphs (parallel edges with different labels,

@@ -61,6 +61,8 @@ float hvx::component_limit(uint32_t metric, uint32_t dim) {
     return rounded;
 }
 
+extern "C" float hvx_component_limit(uint32_t metric, uint32_t dim) { return hvx::component_limit(metric, dim); }
+
 // rows of `words` 32-bit words: gather (dst[i] = src[idx[i]]) or scatter (dst[idx[i]] = src[i])
 __global__ void move_rows_kernel(const uint32_t *src, const uint32_t *idx, uint32_t *dst, uint32_t words, uint32_t n, uint32_t gather) {
     const uint32_t i = blockIdx.x;

@@ -214,6 +214,8 @@ def lib():
     L.hvx_order_code_from_simhash_bits.argtypes = [C.c_uint64]
     L.hvx_decode_layer0_row.restype = C.c_int
     L.hvx_decode_layer0_row.argtypes = [C.c_char_p, C.c_size_t, _vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    L.hvx_component_limit.restype = C.c_float
+    L.hvx_component_limit.argtypes = [C.c_uint32, C.c_uint32]
     L.hvx_decode_simhash_row.restype = C.c_int
     L.hvx_decode_simhash_row.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64)]
     L.hvx_decode_entry_candidate_layer.restype = C.c_int
@@ -986,6 +988,11 @@ def decode_layer0_row(value: bytes):
     cnt, sh, has = C.c_uint32(0), C.c_uint64(0), C.c_uint32(0)
     _check(lib().hvx_decode_layer0_row(value, len(value), _ptr(ids), ids.size, C.byref(cnt), C.byref(sh), C.byref(has)))
     return ids[: cnt.value].tolist(), (int(sh.value) if has.value else None)
+
+
+def component_limit(metric: int, dim: int) -> float:
+    """VectorComponentLimit::try_new (domain.rs:26-78) as the library applies it; inf for cosine."""
+    return float(lib().hvx_component_limit(metric, dim))
 
 
 def decode_simhash_row(value: bytes) -> int:

@@ -379,6 +379,10 @@ void hvx_simhasher_free(hvx_simhasher *);
 int hvx_simhash_batch(const hvx_simhasher *, const float *vectors, uint64_t n, uint64_t *out_bits /*[n] host*/);
 uint64_t hvx_order_code_from_simhash_bits(uint64_t bits);
 
+/* VectorComponentLimit::try_new (domain.rs:26-78): the inclusive |component| maximum the index validates rows and queries
+ * against -- floor-to-f32 of sqrt(f32::MAX / (8 dim)) for squared-L2, f32::MAX / (4 dim) for Manhattan, +inf (no limit) for cosine */
+float hvx_component_limit(uint32_t metric, uint32_t dim);
+
 /*
  * Hydration from HelixDB's persisted rows (replaces VectorMemoryStore hydration, memory_store.rs:97-105).
  * Value codecs restated from crates/db/src/encoding/v1/values/vectors.rs:97-210 (layer-0 rows, tags 0x12 / 0x13, empty),

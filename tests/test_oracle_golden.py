@@ -114,6 +114,44 @@ def test_validation_order_and_limits(orc):
     assert orc.lib().orc_component_limit(orc.COSINE, 128) == 0.0
 
 
+# --- tests/production_support/vector/magnitude_oracle.rs:5-37 + magnitude_regressions.rs:138-242 (run_oracle_and_kernel_contracts)
+def test_component_limits_equal_the_reference_independent_oracle(orc):
+    """The reference checks its production limit against an independent numeric oracle on dimensions 1, 15, 16, 17, 31, 32, 33,
+    1536 and u32::MAX: floor-to-f32 of sqrt(f32::MAX / (8 dim)) (squared-L2) resp. f32::MAX / (4 dim) (Manhattan), limit <= exact <
+    next_up(limit).  Restated here with exact rational arithmetic; the oracle's AND the product library's limits must equal it,
+    and the kernels must stay finite, symmetric and within dim * eps of an f64 evaluation at +-limit (and overflow at 1e20 / f32::MAX)."""
+    import sys, os
+    from fractions import Fraction
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "helix-db_amd"))
+    import pyhvx as hv
+    fmax = Fraction(float(F32_MAX))
+    nxt = lambda v: np.nextafter(np.float32(v), np.float32(np.inf))
+    for dim in [1, 15, 16, 17, 31, 32, 33, 1536, 2**32 - 1]:
+        for metric, hmetric, factor in ((orc.L2SQ, hv.EUCLIDEAN, 8), (orc.L1, hv.MANHATTAN, 4)):
+            lim = np.float32(orc.lib().orc_component_limit(metric, dim))
+            plim = np.float32(hv.component_limit(hmetric, dim))
+            assert lim.view(np.uint32) == plim.view(np.uint32), (dim, metric)
+            exact = fmax / (factor * dim)                       # exact rational; squared-L2 compares squares
+            fl, fn = Fraction(float(lim)), Fraction(float(nxt(lim)))
+            if metric == orc.L2SQ:
+                assert fl * fl <= exact < fn * fn, dim
+            else:
+                assert fl <= exact < fn, dim
+    assert orc.lib().orc_component_limit(orc.COSINE, 128) == 0.0 and hv.component_limit(hv.COSINE, 128) == float("inf")
+    for dim in [1, 15, 16, 17, 31, 32, 33, 1536]:
+        tol = max(dim * float(np.finfo(np.float32).eps), 1.0e-5)
+        for metric in (orc.L2SQ, orc.L1):
+            lim = np.float32(orc.lib().orc_component_limit(metric, dim))
+            a, b = np.full(dim, lim, np.float32), np.full(dim, -lim, np.float32)
+            want = float((2.0 * float(lim)) ** 2 * dim) if metric == orc.L2SQ else float(2.0 * float(lim) * dim)
+            for kern in (orc.K_SCALAR, orc.K_AVX_FMA):
+                got, rev = orc.distance(metric, a, b, kernel=kern), orc.distance(metric, b, a, kernel=kern)
+                assert np.isfinite(got) and got >= 0 and got == rev, (dim, metric, kern)
+                assert abs(float(got) - want) <= want * tol, (dim, metric, kern)
+    assert not np.isfinite(orc.distance(orc.L2SQ, np.array([1.0e20], np.float32), np.array([-1.0e20], np.float32)))
+    assert not np.isfinite(orc.distance(orc.L1, np.array([F32_MAX], np.float32), np.array([-F32_MAX], np.float32)))
+
+
 # --- src/search/vector/mod.rs:776-796
 def test_select_layer(orc):
     ml = orc.default_ml(16)

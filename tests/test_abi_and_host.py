@@ -441,6 +441,13 @@ def test_item_rows_are_decoded_like_decode_item(orc):
     with pytest.raises(hv.HelixDbError) as e:                                       # HeaderMismatch
         hv.Hydrator(3, hv.COSINE).add_item(1, bytes(wrong_header))
     assert e.value.status == hv.ERR_INVARIANT and "HeaderMismatch" in str(e.value)
+    # tests/production_support/vector/primitives.rs:109-131: an empty value (HeaderTooShort) and header + 1 byte (InvalidPayload)
+    for broken in (b"", encoded[:4] + b"\x00"):
+        with pytest.raises(hv.HelixDbError):
+            hv.Hydrator(3, hv.COSINE).add_item(1, broken)
+    assert hv.decode_upper_row((3).to_bytes(4, "big") + _be64(1, 2, 3)) == [1, 2, 3]    # primitives.rs:318-320 encode / decode_neighbors
+    with pytest.raises(hv.HelixDbError):
+        hv.decode_upper_row(bytes(1))
     # Euclidean / Manhattan rows carry a zero bias
     hv.Hydrator(3, hv.EUCLIDEAN).add_item(1, np.float32(0).tobytes() + v.tobytes())
     with pytest.raises(hv.HelixDbError):

@@ -160,6 +160,7 @@ def test_select_layer(orc):
     assert orc.select_layer(ml, 0.0) == int(min(63, math.floor(-math.log(np.finfo(np.float32).tiny) * ml)))
     assert orc.select_layer(ml, float("nan")) == orc.select_layer(ml, 0.5)
     assert orc.select_layer(float("nan"), 0.001) == orc.select_layer(ml, 0.001)
+    assert orc.select_layer(1.0, float("nan")) == 0          # tests/production_support/vector/primitives.rs:338
     lv = fx.draw_levels(4096, 16, seed=11)
     for u_idx in range(0, 4096, 97):
         rng = np.random.Generator(np.random.PCG64(11))

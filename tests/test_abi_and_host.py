@@ -211,6 +211,26 @@ def test_header_is_plain_c_and_the_c_example_links(tmp_path):
     assert exe.exists()
 
 
+def test_bench_deadline_prints_the_line_and_ends_the_process():
+    """bench.py's watchdog: once the headline object exists, a stuck extra leg cannot cost the line -- at the deadline the object
+    is printed as ONE json line (with the legs finished so far, here one that is added while the watchdog waits) and the process
+    exits with status 0."""
+    import json
+    import subprocess
+    code = ("import sys, time; sys.argv = ['bench.py']; sys.path.insert(0, %r); import bench\n"
+            "out = {'metric': 'm', 'value': 1.0}\n"
+            "bench.start_deadline(out, 0.5, 0)\n"
+            "out['config3_prefilter'] = {'ok': True}\n"
+            "time.sleep(30)\n"
+            "print('never reached')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and "never reached" not in r.stdout
+    d = json.loads(lines[0])
+    assert d["metric"] == "m" and d["config3_prefilter"] == {"ok": True} and "deadline" in d
+
+
 def test_small_row_codecs_reproduce_the_reference_frozen_bytes_and_fuzz_seeds():
     """values/vectors/simhash.rs:66-78 (`simhash_bytes_are_frozen`, truncation / trailing bytes rejected), values/vectors/entry.rs:
     51-70 (`entry_candidate_layer_bytes_are_frozen`, non-exact lengths rejected) and the reference's checked-in fuzz corpus

@@ -157,8 +157,10 @@ __device__ __forceinline__ void tile_epilogue(const MfmaArgs &a, f32x16 (&acc)[4
     }
 }
 
-// KIND 0: bf16 rows, 1: fp8 codes.  PIPE: pin the fragment reads of step kk + 1 ahead of the MFMAs of step kk (the
-// compiler otherwise sinks them next to their use and waits for every read pair).
+// ---- the 512-thread build: one workgroup per CU on a 256 x 256 tile, two 64-deep LDS buffers, compiler-visible fragment reads
+// (vmcnt(0) + __syncthreads per stage).  Carries the measurement switches (MfmaArgs::ablate).  KIND 0: bf16 rows, 1: fp8 codes.
+// PIPE: pin the fragment reads of step kk + 1 ahead of the MFMAs of step kk (the compiler otherwise sinks them next to their use
+// and waits for every read pair; measured equal).
 template <int KIND, bool PIPE>
 __global__ __launch_bounds__(512) void flat_tile256_kernel(MfmaArgs a, float xmax2, uint32_t *wg_overflow) {
     constexpr bool FP8 = KIND == 1;
@@ -327,14 +329,15 @@ __device__ __forceinline__ void wait_lgkm0() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// ---- the two-workgroups-per-CU build (see the file header): a workgroup is four wavefronts (one per SIMD, 2 x 2, each 128
-// queries x 64 rows) on a 256 x 128 tile, so a CU holds two independent workgroups: while one waits at its barrier, starts a
-// tile or runs its epilogue, the other one's MFMAs have the matrix cores.
-template <int LGKM>
+template <int LGKM> // everything but the LGKM youngest LDS requests has arrived (they return in order)
 __device__ __forceinline__ void wait_lgkm() {
     __builtin_amdgcn_s_waitcnt(0xC07F | (LGKM << 8));
     __builtin_amdgcn_sched_barrier(0);
 }
+
+// ---- the two-workgroups-per-CU build (see the file header): a workgroup is four wavefronts (one per SIMD, 2 x 2, each 128
+// queries x 64 rows) on a 256 x 128 tile, so a CU holds two independent workgroups: while one waits at its barrier, starts a
+// tile or runs its epilogue, the other one's MFMAs have the matrix cores.
 
 template <int KIND>
 __global__ __launch_bounds__(256, 2) void flat_tile2_kernel(MfmaArgs a, float xmax2, uint32_t *wg_overflow) {

@@ -307,6 +307,39 @@ def test_inline_asm_lds_reads_are_covered_by_a_wait(tmp_path):
     assert lint.stdout.count(": 0 hazard(s)") == 4, lint.stdout    # fp8 + bf16 builds of the default kernel and of the opt-in one
 
 
+def test_tile_workgroup_mapping_covers_every_tile_once():
+    """tile_coords / launch_flat_tile256 (csrc/hvx_flat_tile.hip): workgroup id -> (row tile, query tile) through XCD-aware
+    super-tiles.  A tile that no workgroup computes is a stretch of rows that is never scanned -- and nothing downstream could
+    notice -- so a python twin of the arithmetic sweeps ragged shapes: every (row tile, query tile) exactly once, the rest of
+    the grid out of range, for the 64-workgroup (two per CU) and the 32-workgroup (one per CU) super-tiles."""
+    def cover(nr, nq, per_xcd):
+        sup_q = min(nq, 8)
+        sup_r = per_xcd // sup_q
+        qblocks = (nq + sup_q - 1) // sup_q
+        rb = (nr + 8 * sup_r - 1) // (8 * sup_r)
+        grid = 8 * rb * qblocks * sup_r * sup_q
+        seen = {}
+        for bid in range(grid):
+            x, l = bid & 7, bid >> 3
+            rq = sup_r * sup_q
+            per_rblock = qblocks * rq
+            rblock, rem = divmod(l, per_rblock)
+            qblock, rem2 = divmod(rem, rq)
+            rt = (rblock * sup_r + rem2 // sup_q) * 8 + x
+            qt = qblock * sup_q + rem2 % sup_q
+            if rt < nr and qt < nq:
+                assert (rt, qt) not in seen, (nr, nq, rt, qt)
+                seen[(rt, qt)] = bid
+        assert len(seen) == nr * nq, (nr, nq, per_xcd, len(seen))
+        # the workgroups an XCD runs together (consecutive local ids) share query tiles and row tiles: that is the point
+        return grid
+    for per_xcd in (64, 32):
+        for nq in (1, 2, 3, 4, 5, 7, 8, 9, 16, 17):
+            for nr in (1, 2, 7, 8, 9, 63, 64, 65, 127, 500, 1000):
+                cover(nr, nq, per_xcd)
+    assert cover(97657, 16, 64) < 2**31                       # config #5: 12.5M rows / 128, 4096 queries / 256
+
+
 def test_tile_operand_order_of_fp8_queries_is_a_permutation():
     """tile_slot_fp8 (csrc/hvx_flat_mfma.h): inside every 64-code stage, MFMA step kk, lane half h, element e must read code
     (2 (kk >> 1) + h) * 16 + (kk & 1) * 8 + e -- the query operand is stored in that order; a python twin checks the formula is a

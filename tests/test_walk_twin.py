@@ -1,0 +1,168 @@
+"""The kernel's algorithm body (helix-db_amd/csrc/hvx_walk_core.h), compiled for the host (tests/native/walk_twin.cpp), against
+the oracle's restatement of restricted_filter_aware_search (restricted.rs:837-1148) on the reference's own fixtures
+(crates/db/tests/production_support/vector/restricted.rs, cited per test) and on built graphs: ids, score bits, every
+RestrictedSearchStats counter and the termination reason.  CPU only -- this is what lets the GPU run start from an
+algorithm that is already known to agree with the oracle."""
+import numpy as np
+import pytest
+
+import walk_harness as wh
+
+VARIANTS = (0, 1, 2, 3)  # workgroup geometries of the twin: (256,1024) = the kernel's, (64,256), (8,64), (1,1024)
+
+
+def test_prefix_offsets_and_order_code_match_the_oracle(orc):
+    """restricted.rs:455-462 directory_prefix_offsets (first 64 of the u16 sorted by (popcount, value)); simhash.rs:44-59"""
+    L = wh.twin_lib()
+    want = sorted(range(65536), key=lambda v: (bin(v).count("1"), v))[:64]
+    assert [L.walk_twin_prefix_offset(i) for i in range(64)] == want
+    rng = np.random.default_rng(5)
+    for bits in [0, (1 << 64) - 1, 0x6D91A75788626786] + [int(x) for x in rng.integers(0, 1 << 63, 50)]:
+        assert L.walk_twin_order_code(bits) == orc.order_code(bits)
+
+
+def both(orc, img, ix, q, allowed, k, ef, directory=True, beam_percent=0, variants=VARIANTS):
+    al = np.unique(np.asarray(allowed, np.uint64))
+    plan, strategy = wh.default_plan(orc, al.size, img.dim, k, ef, beam_percent)
+    assert strategy == orc.RESTRICTED_FILTERED
+    want = ix.search_restricted(q, k, ef, allowed, beam_percent=beam_percent, directory=directory)
+    for v in variants:
+        bad, ids, bits, st = wh.run_twin(img, q, allowed, plan, directory, variant=v, order_seed=v + 7)
+        assert bad == 0
+        wh.assert_same_as_oracle(ids, bits, st, want, plan["ef_filtered"])
+    return want
+
+
+def explicit(orc, img, ix, q, allowed, directory=False, variants=VARIANTS, **budgets):
+    want = ix.restricted_filter_aware_search(q, allowed, directory=directory, **budgets)
+    for v in variants:
+        bad, ids, bits, st = wh.run_twin(img, q, allowed, dict(budgets), directory, variant=v, order_seed=v + 3)
+        assert bad == 0
+        wh.assert_same_as_oracle(ids, bits, st, want)
+    return want
+
+
+def test_three_edge_gulf_all_metrics(orc):
+    """tests :964-1045: three rejected bridge rows lead to the only member"""
+    allowed = np.arange(1000, 1257, dtype=np.uint64)
+    for metric in (orc.COSINE, orc.L2SQ, orc.L1):
+        ix = wh.gulf(orc, metric)
+        img = wh.Image(orc, ix, metric)
+        rc, ids, _, st = both(orc, img, ix, [1.0, 0.0], allowed, 10, 100, directory=False)
+        assert ids.tolist() == [1001] and st["bridge_rows"] == 3 and st["vector_payload_requests"] == 1
+        both(orc, img, ix, [1.0, 0.0], allowed, 10, 100, directory=True)
+
+
+def test_competing_bridges_and_explicit_budgets(orc):
+    """tests :1047-1101 (SimHash-guided bridge), :1103-1224 (each budget's termination reason)"""
+    ix = wh.competing_bridges(orc)
+    img = wh.Image(orc, ix, orc.COSINE)
+    rc, got, _, st = explicit(orc, img, ix, [1.0, 0.0], np.arange(1001, 1258), k=1, ef_filtered=1, routing_rows=2, bridge_rows=2,
+                              vector_payloads=1, sampled_seeds=0, directory_seeds=0)
+    assert got.tolist() == [1001] and st["bridge_rows"] == 2
+    ix = wh.gulf(orc, orc.COSINE)
+    img = wh.Image(orc, ix, orc.COSINE)
+    allowed = np.arange(1000, 1257)
+    for budgets, term in ((dict(ef_filtered=1, routing_rows=0, bridge_rows=1, vector_payloads=1), orc.TERM_ROUTING_BUDGET),
+                          (dict(ef_filtered=1, routing_rows=4, bridge_rows=0, vector_payloads=1), orc.TERM_BRIDGE_BUDGET),
+                          (dict(ef_filtered=1, routing_rows=4, bridge_rows=2, vector_payloads=0), orc.TERM_VECTOR_BUDGET)):
+        rc, got, _, st = explicit(orc, img, ix, [1.0, 0.0], allowed, k=1, sampled_seeds=0, directory_seeds=0, **budgets)
+        assert got.size == 0 and st["termination"] == term
+    explicit(orc, img, ix, [1.0, 0.0], np.arange(1, 258), k=1, ef_filtered=1, routing_rows=4, bridge_rows=2, vector_payloads=0,
+             sampled_seeds=0, directory_seeds=0)
+    # members reachable directly, generous budgets, sampled seeds on
+    explicit(orc, img, ix, [1.0, 0.0], np.arange(1, 258), k=2, ef_filtered=4, routing_rows=64, bridge_rows=32, vector_payloads=8,
+             sampled_seeds=4, directory_seeds=0)
+
+
+def test_directory_seeds_on_identical_rows(orc):
+    """tests :935-961: 300 identical vectors, empty graph: >= 256 directory hits, only the 64 sampled seeds cost a SimHash read"""
+    ix = wh.identical_rows(orc)
+    img = wh.Image(orc, ix, orc.COSINE)
+    rc, got, _, st = both(orc, img, ix, wh.circle8(7, 300), np.arange(1, 301), 10, 100)
+    assert st["directory_hits"] >= 256 and st["simhash_row_requests"] == 64
+    both(orc, img, ix, wh.circle8(7, 300), np.arange(1, 301), 10, 100, directory=False)
+    # explicit directory budgets incl. zero (the first window is still read)
+    for ds in (0, 1, 17, 300):
+        explicit(orc, img, ix, wh.circle8(3, 300), np.arange(1, 301), directory=True, k=5, ef_filtered=20, routing_rows=320, bridge_rows=160,
+                 vector_payloads=100, sampled_seeds=8, directory_seeds=ds, variants=(0, 2))
+
+
+def test_circle_membership_fixture(orc):
+    """tests :1226-1285: 512 x 8-D circle, ef 64, k 10, allowed = ids not divisible by 3"""
+    n = 512
+    ix = wh.seed_circle(orc, n)
+    img = wh.Image(orc, ix, orc.COSINE)
+    allowed = [i for i in range(1, n + 1) if i % 3 != 0]
+    for qid in (1, 43, 87, 129, 211, 307, 401, 509):
+        both(orc, img, ix, wh.circle8(qid, n), allowed, 10, 64, variants=(0, 2))
+    # unknown ids inside the candidate list, duplicates, other beam widths
+    both(orc, img, ix, wh.circle8(5, n), allowed + [9999, 10_000, 7, 7] + list(range(600, 900)), 10, 64)
+    for pct in (100, 200, 400):
+        both(orc, img, ix, wh.circle8(77, n), allowed, 10, 64, beam_percent=pct, variants=(0, 1))
+
+
+@pytest.mark.parametrize("metric_name,dim,n,m0,gap", [("L2SQ", 48, 1500, 32, False), ("COSINE", 64, 1200, 32, True), ("L1", 20, 900, 16, False),
+                                                      ("L2SQ", 32, 2500, 64, True)])
+def test_built_graphs_sparse_and_dense_filters(orc, metric_name, dim, n, m0, gap):
+    """Built HNSW graphs, candidate sets from 1 in 50 to 9 in 10 (bridging-heavy to member-heavy), unknown ids mixed in"""
+    metric = getattr(orc, metric_name)
+    ix, ids, vec = wh.random_graph(orc, n, dim, metric, seed=dim + n, m0=m0, id_gap=gap)
+    img = wh.Image(orc, ix, metric)
+    rng = np.random.default_rng(n)
+    for frac in (0.02, 0.2, 0.5, 0.9):
+        pick = ids[rng.random(n) < frac]
+        if pick.size <= 256:
+            pick = ids[: 300]
+        extra = np.array([int(ids[-1]) + 5, 2], np.uint64) if gap else np.zeros(0, np.uint64)
+        allowed = np.concatenate([pick, extra])
+        for qi in range(3):
+            q = rng.standard_normal(dim).astype(np.float32)
+            both(orc, img, ix, q, allowed, 10, 100, variants=(0, 2))
+            both(orc, img, ix, q, allowed, 10, 100, directory=False, variants=(1,))
+    # budgets that bite: every termination reason is reachable on a real graph
+    q = rng.standard_normal(dim).astype(np.float32)
+    allowed = ids[rng.random(n) < 0.1]
+    allowed = allowed if allowed.size > 8 else ids[:64]
+    seen_terms = set()
+    for budgets in (dict(ef_filtered=8, routing_rows=16, bridge_rows=8, vector_payloads=800),
+                    dict(ef_filtered=64, routing_rows=4096, bridge_rows=3, vector_payloads=800),
+                    dict(ef_filtered=64, routing_rows=4096, bridge_rows=2048, vector_payloads=20),
+                    dict(ef_filtered=600, routing_rows=9600, bridge_rows=4800, vector_payloads=800),
+                    dict(ef_filtered=16, routing_rows=256, bridge_rows=128, vector_payloads=800)):
+        want = explicit(orc, img, ix, q, allowed, directory=True, k=5, sampled_seeds=16, directory_seeds=32, variants=(0, 2), **budgets)
+        seen_terms.add(want[3]["termination"])
+    assert len(seen_terms) >= 3, seen_terms
+
+
+def test_thread_order_inside_a_phase_does_not_matter(orc):
+    """the twin shuffles the threads of every phase: ten different orders, one answer"""
+    ix, ids, vec = wh.random_graph(orc, 1200, 32, orc.L2SQ, seed=99)
+    img = wh.Image(orc, ix, orc.L2SQ)
+    rng = np.random.default_rng(3)
+    allowed = ids[rng.random(ids.size) < 0.3]
+    q = rng.standard_normal(32).astype(np.float32)
+    plan, _ = wh.default_plan(orc, np.unique(allowed).size, 32, 10, 100)
+    ref = None
+    for seed in range(10):
+        out = wh.run_twin(img, q, allowed, plan, True, variant=0, order_seed=seed)
+        ref = ref or out
+        assert out[1].tolist() == ref[1].tolist() and out[3] == ref[3]
+
+
+def test_sparse_filter_is_bridging_heavy(orc):
+    """3 % members of a 12 000-node graph: the walk lives on the bridge frontier (thousands of pushes, bounded storage)"""
+    ix, ids, vec = wh.random_graph(orc, 12000, 16, orc.L2SQ, seed=4242)
+    img = wh.Image(orc, ix, orc.L2SQ)
+    rng = np.random.default_rng(8)
+    allowed = ids[rng.random(ids.size) < 0.03]
+    assert allowed.size > 256
+    pushes = 0
+    for qi in range(4):
+        q = rng.standard_normal(16).astype(np.float32)
+        want = both(orc, img, ix, q, allowed, 10, 100, directory=bool(qi & 1), variants=(0, 2))
+        pushes += want[3]["bridge_frontier_pushes"]
+        # a bridge budget far below the pushes: most keys are counted, not stored
+        explicit(orc, img, ix, q, allowed, directory=True, k=10, ef_filtered=150, routing_rows=2400, bridge_rows=40, vector_payloads=800,
+                 sampled_seeds=64, directory_seeds=256, variants=(0, 1))
+    assert pushes > 4000, pushes

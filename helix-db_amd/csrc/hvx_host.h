@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "hvx_kernels.h"
+#include "hvx_walk_core.h"
 
 // Device allocations of one handle.  A fork (hvx_index_fork) keeps its parent's holder alive: the immutable index image
 // (rows, graph, ids, headers, SimHash rows) is freed when the last handle that references it is gone.
@@ -28,11 +29,16 @@ struct hvx_image_shared {
     int device = 0;
     uint16_t *shadow = nullptr;   // f32 rows: bf16 (RNE) shadow of the rows for the large-tile exact-scan kernels (hvx_flat_tile.hip)
     bool shadow_failed = false;   // no memory for it: the scan stays on the 128 x 128 kernel
+    // the SimHash directory of the restricted walk (hvx_restricted_walk.hip): the rows [0xF1][index][0x17][order_code][node]
+    // in key order = (order code, row) ascending, built from the attached SimHash rows on first use
+    uint64_t *dir_code = nullptr;
+    uint32_t *dir_row = nullptr;
+    const uint64_t *dir_for = nullptr; // the node_hash array the directory was derived from
     ~hvx_image_shared() {
-        if (shadow) {
-            (void)hipSetDevice(device);
-            (void)hipFree(shadow);
-        }
+        if (shadow || dir_code || dir_row) (void)hipSetDevice(device);
+        if (shadow) (void)hipFree(shadow);
+        if (dir_code) (void)hipFree(dir_code);
+        if (dir_row) (void)hipFree(dir_row);
     }
 };
 
@@ -106,6 +112,10 @@ struct hvx_index {
     hvx_adaptive_stats *d_astats = nullptr;
     uint32_t thr_configured = 0xFFFFFFFFu; // what d_thr_break was built for
     float thr_failure = -1.f;
+    // restricted walk (hvx_restricted_walk.hip): membership / seen bitmaps, plans, sample rows, per-query stats
+    uint32_t *w_allowed = nullptr, *w_seen = nullptr, *w_samples = nullptr, *w_rows = nullptr;
+    void *w_plans = nullptr, *w_counters = nullptr;
+    size_t cap_w_allowed = 0, cap_w_seen = 0, cap_w_samples = 0, cap_w_rows = 0, cap_w_q = 0;
 
     int dalloc(void **p, size_t bytes);
     int regrow(void **p, size_t bytes);   // dalloc after releasing *p (scratch buffers that grow)
@@ -145,6 +155,20 @@ int flat_scan_valu(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k
                    uint64_t *d_ids, float *d_scores, uint32_t *d_counts, uint32_t *d_status, bool timed, bool record_begin);
 int flat_mfma_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, const uint32_t *d_subset, uint32_t n_rows,
                      uint64_t *d_ids, float *d_scores, uint32_t *d_counts, uint32_t *d_status, bool timed);
+// restricted search under the reference's execution plan (hvx_restricted_walk.hip)
+struct RestrictedPlan {
+    uint32_t strategy; // HVX_RESTRICTED_EXACT / HVX_RESTRICTED_FILTERED
+    walk::Plan p;
+};
+// restricted_execution_plan_with_beam_percent (restricted.rs:426-453) for a candidate population (ids incl. unindexed ones)
+int restricted_make_plan(const hvx_restricted_params &rp, uint64_t candidates, uint32_t dim, RestrictedPlan *out);
+// deterministic_sample_ids (restricted.rs:321-342) as ranks into the ascending candidate list
+void restricted_sample_ranks(uint64_t candidates, uint32_t count, std::vector<uint64_t> &out);
+// run a plan for b host-resident queries over ONE candidate set given as device rows (ascending); d_samples = the plan's
+// p.n_sample deterministic seeds as rows (kSentinel = not indexed); out arrays have row length k_stride
+int restricted_run_plan(hvx_index *ix, const float *queries, uint32_t b, uint32_t k_stride, const RestrictedPlan &plan, const uint32_t *d_rows,
+                        uint32_t n_rows, const uint32_t *d_samples, uint64_t *out_ids, float *out_scores, uint32_t *out_counts,
+                        uint32_t *out_status, hvx_restricted_stats *rstats, hvx_stats *stats);
 hipError_t launch_bf16_row_norm2(const uint16_t *rows, uint32_t n, uint32_t dim, float *out, hipStream_t s);
 int flat_scan_host(hvx_index *ix, const float *queries, uint32_t b, uint32_t k, const uint32_t *d_subset,
                    uint32_t n_rows, uint64_t *out_ids, float *out_scores, uint32_t *out_counts,

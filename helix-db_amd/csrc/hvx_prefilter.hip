@@ -932,7 +932,7 @@ __device__ __forceinline__ uint32_t find_row(const uint64_t *ids, uint32_t n, ui
 // pass 1: per 256-word block, how many set bits map to an indexed row (restricted.rs:615-659: ids that are not
 // indexed are omitted) and how many bits are set at all (the RestrictedVectorCandidates population, :356-371)
 __global__ __launch_bounds__(256) void bitmap_count_kernel(const uint32_t *bitmap, uint32_t n_words, const uint64_t *ids, uint32_t n,
-                                                           uint32_t contiguous, uint32_t *block_rows, uint32_t *total_bits) {
+                                                           uint32_t contiguous, uint32_t *block_rows, uint32_t *total_bits, uint32_t *block_bits) {
     __shared__ uint32_t s_rows, s_bits;
     if (threadIdx.x == 0) { s_rows = 0; s_bits = 0; }
     __syncthreads();
@@ -949,6 +949,7 @@ __global__ __launch_bounds__(256) void bitmap_count_kernel(const uint32_t *bitma
     __syncthreads();
     if (threadIdx.x == 0) {
         block_rows[blockIdx.x] = s_rows;
+        if (block_bits) block_bits[blockIdx.x] = s_bits; // for the deterministic sample: ranks count every candidate id
         if (s_bits) atomicAdd(total_bits, s_bits);
     }
 }
@@ -1001,13 +1002,72 @@ __global__ __launch_bounds__(256) void bitmap_compact_kernel(const uint32_t *bit
     }
 }
 
+// deterministic_sample_ids (restricted.rs:321-342) on the device: the candidate with rank ranks[t] in the ascending id order
+// of the bitmap, as an index row (kSentinel when that id holds no vector).  bits_prefix = exclusive scan of the per-block counts.
+__global__ __launch_bounds__(64) void bitmap_select_kernel(const uint32_t *bitmap, uint32_t n_words, const uint32_t *bits_prefix, uint32_t n_blocks,
+                                                           const uint64_t *ids, uint32_t n, uint32_t contiguous, const uint32_t *ranks,
+                                                           uint32_t n_ranks, uint32_t *out_rows) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_ranks) return;
+    const uint32_t r = ranks[t];
+    uint32_t lo = 0, hi = n_blocks; // last block whose prefix is <= r
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (bits_prefix[mid] <= r) lo = mid;
+        else hi = mid;
+    }
+    uint32_t rem = r - bits_prefix[lo], row = kSentinel;
+    for (uint32_t w = lo * 256u; w < n_words && w < (lo + 1u) * 256u; ++w) {
+        uint32_t word = bitmap[w];
+        const uint32_t pc = (uint32_t)__builtin_popcount(word);
+        if (rem >= pc) { rem -= pc; continue; }
+        while (rem--) word &= word - 1u;
+        row = find_row(ids, n, (uint64_t)w * 32u + (uint32_t)__builtin_ctz(word), contiguous != 0u);
+        break;
+    }
+    out_rows[t] = row;
+}
+
 } // namespace
+
+static int prefilter_search_impl(const hvx_index *cix, const hvx_csr *cg, const float *queries, uint32_t b, const hvx_restricted_params &rp,
+                                 uint32_t mode, const uint64_t *seeds, uint32_t n_seeds, uint32_t max_depth, uint32_t direction,
+                                 const uint32_t *allowed_label_ids, uint32_t n_labels, uint32_t hub_degree, uint32_t include_seeds,
+                                 uint64_t *out_ids, float *out_scores, uint32_t *out_counts, uint32_t *out_status, uint64_t *out_candidates,
+                                 hvx_restricted_stats *rstats, hvx_stats *stats);
 
 extern "C" int hvx_prefilter_search_batch(const hvx_index *cix, const hvx_csr *cg, const float *queries, uint32_t b, uint32_t k,
                                           uint32_t ef, uint32_t mode, const uint64_t *seeds, uint32_t n_seeds, uint32_t max_depth,
                                           uint32_t direction, const uint32_t *allowed_label_ids, uint32_t n_labels,
                                           uint32_t hub_degree, uint32_t include_seeds, uint64_t *out_ids, float *out_scores,
                                           uint32_t *out_counts, uint32_t *out_status, uint64_t *out_candidates, hvx_stats *stats) {
+    hvx_restricted_params rp;
+    memset(&rp, 0, sizeof(rp));
+    rp.k = k;
+    rp.ef = ef;
+    rp.strategy = HVX_RESTRICTED_EXACT; // this entry point answers every candidate-set size with the exact gathered scan
+    return prefilter_search_impl(cix, cg, queries, b, rp, mode, seeds, n_seeds, max_depth, direction, allowed_label_ids, n_labels, hub_degree,
+                                 include_seeds, out_ids, out_scores, out_counts, out_status, out_candidates, nullptr, stats);
+}
+
+extern "C" int hvx_prefilter_search_batch_params(const hvx_index *cix, const hvx_csr *cg, const float *queries, uint32_t b,
+                                                 const hvx_restricted_params *params, uint32_t mode, const uint64_t *seeds, uint32_t n_seeds,
+                                                 uint32_t max_depth, uint32_t direction, const uint32_t *allowed_label_ids, uint32_t n_labels,
+                                                 uint32_t hub_degree, uint32_t include_seeds, uint64_t *out_ids, float *out_scores,
+                                                 uint32_t *out_counts, uint32_t *out_status, uint64_t *out_candidates,
+                                                 hvx_restricted_stats *out_restricted_stats, hvx_stats *stats) {
+    if (!params) return fail(HVX_ERR_INVARIANT, "null argument");
+    if (params->strategy > HVX_RESTRICTED_FILTERED) return fail(HVX_ERR_INVARIANT, "unknown restricted strategy %u", params->strategy);
+    return prefilter_search_impl(cix, cg, queries, b, *params, mode, seeds, n_seeds, max_depth, direction, allowed_label_ids, n_labels, hub_degree,
+                                 include_seeds, out_ids, out_scores, out_counts, out_status, out_candidates, out_restricted_stats, stats);
+}
+
+static int prefilter_search_impl(const hvx_index *cix, const hvx_csr *cg, const float *queries, uint32_t b, const hvx_restricted_params &rp,
+                                 uint32_t mode, const uint64_t *seeds, uint32_t n_seeds, uint32_t max_depth, uint32_t direction,
+                                 const uint32_t *allowed_label_ids, uint32_t n_labels, uint32_t hub_degree, uint32_t include_seeds,
+                                 uint64_t *out_ids, float *out_scores, uint32_t *out_counts, uint32_t *out_status, uint64_t *out_candidates,
+                                 hvx_restricted_stats *rstats, hvx_stats *stats) {
+    const uint32_t k = rp.k, ef = rp.ef;
     if (!cix || !cg) return fail(HVX_ERR_INVARIANT, "null argument");
     hvx_index *ix = const_cast<hvx_index *>(cix);
     hvx_csr *g = const_cast<hvx_csr *>(cg);
@@ -1019,6 +1079,7 @@ extern "C" int hvx_prefilter_search_batch(const hvx_index *cix, const hvx_csr *c
     for (uint32_t q = 0; q < b; ++q) {
         out_counts[q] = 0;
         if (out_status) out_status[q] = HVX_OK;
+        if (rstats) memset(&rstats[q], 0, sizeof(hvx_restricted_stats));
     }
     if (b == 0) return HVX_OK;
     if (mode == HVX_PREFILTER_EXPAND && n_seeds == 0) return HVX_OK; // an empty stream expands to nothing
@@ -1029,14 +1090,15 @@ extern "C" int hvx_prefilter_search_batch(const hvx_index *cix, const hvx_csr *c
                             mode == HVX_PREFILTER_EXPAND, nullptr, nullptr);
     if (rc) return rc; // (run_bfs_locked ends with a stream synchronise: the bitmap is complete)
     const uint32_t n_words = ((g->n + 63u) / 64u) * 2u, n_blocks = (n_words + 255u) / 256u;
-    if (n_blocks + 2 > ix->cap_pf_blocks) {
-        if ((rc = ix->regrow((void **)&ix->pf_blocks, (size_t)(n_blocks + 2) * 4))) return rc;
-        ix->cap_pf_blocks = n_blocks + 2;
+    if (2 * (n_blocks + 2) > ix->cap_pf_blocks) {
+        if ((rc = ix->regrow((void **)&ix->pf_blocks, (size_t)2 * (n_blocks + 2) * 4))) return rc;
+        ix->cap_pf_blocks = 2 * (n_blocks + 2);
     }
     uint32_t *d_total_bits = ix->pf_blocks + n_blocks + 1;
+    uint32_t *d_block_bits = ix->pf_blocks + n_blocks + 2; // [n_blocks + 1]: per-block candidate counts, then their scan
     HIP_TRY(hipMemsetAsync(d_total_bits, 0, 4, ix->stream));
     hipLaunchKernelGGL(bitmap_count_kernel, dim3(n_blocks), dim3(256), 0, ix->stream, g->visited, n_words, ix->dev.ids, ix->dev.n,
-                       ix->contiguous ? 1u : 0u, ix->pf_blocks, d_total_bits);
+                       ix->contiguous ? 1u : 0u, ix->pf_blocks, d_total_bits, d_block_bits);
     hipLaunchKernelGGL(block_scan_kernel, dim3(1), dim3(1024), 0, ix->stream, ix->pf_blocks, n_blocks);
     HIP_TRY(hipGetLastError());
     uint32_t totals[2] = {0, 0}; // rows to scan, candidate population
@@ -1057,20 +1119,28 @@ extern "C" int hvx_prefilter_search_batch(const hvx_index *cix, const hvx_csr *c
         hipLaunchKernelGGL(bitmap_compact_kernel, dim3(n_blocks), dim3(256), 0, ix->stream, g->visited, n_words, ix->dev.ids, ix->dev.n,
                            ix->contiguous ? 1u : 0u, ix->pf_blocks, ix->f_subset);
     HIP_TRY(hipGetLastError());
-    std::vector<uint64_t> t_ids((size_t)b * kk);
-    std::vector<float> t_sc((size_t)b * kk);
-    std::vector<uint32_t> t_cnt(b), t_st(b);
-    rc = flat_scan_host(ix, queries, b, kk, ix->f_subset, n_rows, t_ids.data(), t_sc.data(), t_cnt.data(), t_st.data(), stats);
-    if (rc) return rc;
-    for (uint32_t q = 0; q < b; ++q) {
-        if (t_st[q]) {
-            if (!out_status) return fail((int)t_st[q], "query %u rejected with status %u", q, t_st[q]);
-            out_status[q] = t_st[q];
-            continue;
+    // restricted_execution_plan_with_beam_percent (restricted.rs:426-453) over the candidate population
+    RestrictedPlan plan;
+    if ((rc = restricted_make_plan(rp, population, ix->dev.dim, &plan))) return rc;
+    (void)kk;
+    const uint32_t *d_samples = nullptr;
+    if (plan.strategy == HVX_RESTRICTED_FILTERED && plan.p.n_sample) {
+        // the deterministic seeds: ranks into the candidate population, resolved against the bitmap on the device
+        std::vector<uint64_t> ranks64;
+        restricted_sample_ranks(population, plan.p.n_sample, ranks64);
+        std::vector<uint32_t> ranks(ranks64.begin(), ranks64.end());
+        const uint32_t ns = plan.p.n_sample;
+        if ((size_t)2 * ns * 4 > ix->cap_w_samples) {
+            if ((rc = ix->regrow((void **)&ix->w_samples, (size_t)2 * ns * 4))) return rc;
+            ix->cap_w_samples = (size_t)2 * ns * 4;
         }
-        out_counts[q] = t_cnt[q];
-        memcpy(out_ids + (size_t)q * k, t_ids.data() + (size_t)q * kk, (size_t)t_cnt[q] * 8);
-        memcpy(out_scores + (size_t)q * k, t_sc.data() + (size_t)q * kk, (size_t)t_cnt[q] * 4);
+        HIP_TRY(hipMemcpyAsync(ix->w_samples + ns, ranks.data(), (size_t)ns * 4, hipMemcpyHostToDevice, ix->stream));
+        hipLaunchKernelGGL(block_scan_kernel, dim3(1), dim3(1024), 0, ix->stream, d_block_bits, n_blocks);
+        hipLaunchKernelGGL(bitmap_select_kernel, dim3((ns + 63u) / 64u), dim3(64), 0, ix->stream, g->visited, n_words, d_block_bits, n_blocks,
+                           ix->dev.ids, ix->dev.n, ix->contiguous ? 1u : 0u, ix->w_samples + ns, ns, ix->w_samples);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(ix->stream)); // `ranks` lives on this frame
+        d_samples = ix->w_samples;
     }
-    return HVX_OK;
+    return restricted_run_plan(ix, queries, b, k, plan, ix->f_subset, n_rows, d_samples, out_ids, out_scores, out_counts, out_status, rstats, stats);
 }

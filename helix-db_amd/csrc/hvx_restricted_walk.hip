@@ -1,0 +1,574 @@
+// hvx_restricted_walk.hip -- restricted (prefiltered) vector search under the reference's execution plan, with the
+// filter-aware walk on the device.
+//
+// Reference (crates/db/src/search/vector/restricted.rs): search_restricted_observed_with_beam_percent :528-613,
+// restricted_execution_plan_with_beam_percent :426-453, FilteredGraphBudgets :230-259, deterministic_sample_ids :321-342,
+// restricted_filter_aware_search :837-1148 (the algorithm body: hvx_walk_core.h, shared with the host twin of the tests).
+//
+// Mapping onto CDNA4: one 256-thread workgroup per query (4 wavefronts, one per SIMD).  The walk is a chain of dependent
+// batches -- pop <= 16 frontier rows / <= 256 bridge rows, read their layer-0 rows, classify every listed id against the
+// membership bitmap, score the new members -- so the parallelism is INSIDE a batch: a phase classifies 1 024 ids at once
+// (32 neighbour rows of 32 ids; four independent HBM reads in flight per thread), scoring runs 32 rows at a time on the
+// 8-lane row groups of hvx_device.h (bit-exact distances), and the two priority queues are sorted arrays in LDS maintained
+// with a bitonic network and a rank-merge.  Per query: <= 800 row gathers (<= 4.9 MB at 1536-D) + <= ef_filtered*16
+// neighbour rows + one bit probe per listed id -- the algorithmic bytes of SURVEY.md 8(d) "filtered graph".
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <vector>
+
+#include "hvx_host.h"
+#include "hvx_walk_core.h"
+
+using namespace hvx;
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) return fail(HVX_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+namespace {
+
+constexpr uint32_t kT = 256, kW = 1024;
+constexpr uint32_t kMaxBridgeRows = 12288; // B in LDS: 96 KiB at most (ef_filtered 1 200 -> 9 600)
+
+struct WalkArgs {
+    DevIndex ix;
+    const float *queries;       // [b][dim]
+    const uint32_t *qstatus;    // [b]
+    const float *qhdr;          // [b]
+    const uint64_t *qhash;      // [b] query SimHash
+    const uint64_t *node_hash;  // [n]
+    const uint64_t *dir_code;   // [n]
+    const uint32_t *dir_row;    // [n]
+    const uint32_t *allowed;    // membership bitmap(s) over the rows
+    uint32_t *seen;             // [b][words], zero
+    uint32_t words, allowed_stride; // allowed_stride = 0: one candidate set for the whole batch
+    const walk::Plan *plans;    // [b]
+    const uint32_t *samples;    // sample rows of the deterministic seeds
+    uint32_t sample_stride;     // 0: shared
+    uint32_t b_cap;             // capacity of the bridge array in LDS (>= every plan's bridge_rows)
+    uint32_t k_stride;          // row length of the output arrays
+    uint64_t *out_ids;
+    float *out_scores;
+    uint32_t *out_counts, *out_status;
+    walk::Counters *counters;   // [b]
+};
+
+template <uint32_t METRIC, bool FUSED> struct DevCtx {
+    static constexpr uint32_t T = kT, W = kW;
+    const DevIndex &ix;
+    const float *qv;
+    float qhdr;
+    uint32_t *wsum; // [W / 64] LDS scratch of the prefix sums
+
+    template <class F> __device__ __forceinline__ void phase(F f) {
+        __syncthreads();
+        f(threadIdx.x);
+        __syncthreads();
+    }
+    __device__ __forceinline__ uint32_t atomic_or_global(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
+    __device__ __forceinline__ uint32_t atomic_add_shared(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
+    __device__ __forceinline__ void atomic_min_shared(uint32_t *p, uint32_t v) { atomicMin(p, v); }
+    // the bits were OR-ed in at the L2 by other wavefronts of this workgroup: read them there, not from the CU's L1
+    __device__ __forceinline__ uint32_t load_seen(const uint32_t *p) {
+        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    // exclusive prefix sum over a[0, len), len <= W: element p*T + t belongs to thread t
+    __device__ __forceinline__ void scan(uint32_t *a, uint32_t len, uint32_t *total) {
+        constexpr uint32_t P = W / T;
+        const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+        __syncthreads();
+        uint32_t v[P], inc[P];
+#pragma unroll
+        for (uint32_t p = 0; p < P; ++p) {
+            const uint32_t i = p * T + t;
+            v[p] = i < len ? a[i] : 0u;
+            uint32_t x = v[p];
+#pragma unroll
+            for (uint32_t d = 1; d < 64; d <<= 1) {
+                const uint32_t u = __shfl_up(x, d, 64);
+                if (lane >= d) x += u;
+            }
+            inc[p] = x;
+            if (lane == 63u) wsum[p * (T / 64) + wave] = x;
+        }
+        __syncthreads();
+        uint32_t run = 0, base[P];
+#pragma unroll
+        for (uint32_t e = 0; e < W / 64; ++e) {
+#pragma unroll
+            for (uint32_t p = 0; p < P; ++p)
+                if (e == p * (T / 64) + wave) base[p] = run;
+            run += wsum[e];
+        }
+#pragma unroll
+        for (uint32_t p = 0; p < P; ++p) {
+            const uint32_t i = p * T + t;
+            if (i < len) a[i] = base[p] + inc[p] - v[p];
+        }
+        *total = run;
+        __syncthreads();
+    }
+
+    // bitonic network over L keys in LDS
+    __device__ __forceinline__ void sort64(uint64_t *a, uint32_t L) {
+        const uint32_t t = threadIdx.x;
+        __syncthreads();
+        for (uint32_t k = 2; k <= L; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = t; i < (L >> 1); i += T) {
+                    const uint32_t lo = ((i & ~(j - 1u)) << 1) | (i & (j - 1u)), hi = lo | j;
+                    const bool up = (lo & k) == 0u;
+                    const uint64_t x = a[lo], y = a[hi];
+                    if ((x > y) == up) {
+                        a[lo] = y;
+                        a[hi] = x;
+                    }
+                }
+                __syncthreads();
+            }
+    }
+
+    // restricted_score_keys' distances: 32 rows at a time, one per 8-lane row group, in the host kernel's summation order
+    __device__ __forceinline__ uint32_t score(const uint32_t *rows, uint32_t n, uint64_t *keys) {
+        const uint32_t t = threadIdx.x, grp = t >> 3;
+        const int j = (int)(t & 7u);
+        __syncthreads();
+        int bad = 0;
+        for (uint32_t f = grp; f < n; f += T / 8) {
+            const uint32_t node = rows[f];
+            float d = group_distance<METRIC, FUSED>(ix, qv, qhdr, node, j);
+            if (!score_valid(d)) bad = 1;
+            if (j == 0) keys[f] = ((uint64_t)__float_as_uint(d) << 32) | ((uint64_t)node << 1);
+        }
+        return (uint32_t)__syncthreads_or(bad);
+    }
+};
+
+__host__ __device__ inline size_t align16(size_t x) { return (x + 15u) & ~(size_t)15u; }
+
+size_t walk_lds_bytes(uint32_t ld, uint32_t b_cap) {
+    return align16((size_t)ld * 4) + walk::kScoredCap * 8 + align16((size_t)b_cap * 8) + walk::kStageCap * 8 + walk::kStageCap * 4 +
+           walk::kScoredCap * 4 + kW * 4 + kW * 4 + kW + kW * 8 + kW * 4 + walk::kBridgeBatch * 4 + walk::kCtlWords * 4 + (kW / 64) * 4;
+}
+
+template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(256) void restricted_walk_kernel(WalkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const DevIndex &ix = a.ix;
+    const uint32_t q = blockIdx.x, t = threadIdx.x;
+    const walk::Plan pl = a.plans[q];
+    const uint32_t status_in = a.qstatus ? a.qstatus[q] : 0u;
+    if (status_in != 0u || !ix.has_entry) {
+        if (t == 0) {
+            a.out_counts[q] = 0;
+            if (a.out_status) a.out_status[q] = status_in;
+            a.counters[q] = walk::Counters{};
+        }
+        return;
+    }
+    char *p = smem;
+    float *qv = reinterpret_cast<float *>(p); p += align16((size_t)ix.ld * 4);
+    walk::Mem m;
+    m.S = reinterpret_cast<uint64_t *>(p); p += walk::kScoredCap * 8;
+    m.B = reinterpret_cast<uint64_t *>(p); p += align16((size_t)a.b_cap * 8);
+    m.G = reinterpret_cast<uint64_t *>(p); p += walk::kStageCap * 8;
+    m.tv = reinterpret_cast<uint64_t *>(p); p += kW * 8;
+    m.Gr = reinterpret_cast<uint32_t *>(p); p += walk::kStageCap * 4;
+    m.E = reinterpret_cast<uint32_t *>(p); p += walk::kScoredCap * 4;
+    m.rows = reinterpret_cast<uint32_t *>(p); p += kW * 4;
+    m.scan = reinterpret_cast<uint32_t *>(p); p += kW * 4;
+    m.tp = reinterpret_cast<uint32_t *>(p); p += kW * 4;
+    m.batch = reinterpret_cast<uint32_t *>(p); p += walk::kBridgeBatch * 4;
+    m.ctl = reinterpret_cast<uint32_t *>(p); p += walk::kCtlWords * 4;
+    uint32_t *wsum = reinterpret_cast<uint32_t *>(p); p += (kW / 64) * 4;
+    m.flag = reinterpret_cast<uint8_t *>(p);
+    m.b_cap = a.b_cap;
+    for (uint32_t i = t; i < ix.ld; i += kT) qv[i] = i < ix.dim ? a.queries[(size_t)q * ix.dim + i] : 0.f;
+
+    walk::View v;
+    v.l0 = ix.l0; v.s0 = ix.s0; v.n = ix.n; v.dim = ix.dim;
+    v.node_hash = a.node_hash; v.dir_code = a.dir_code; v.dir_row = a.dir_row;
+    v.entry = ix.entry; v.has_entry = ix.has_entry;
+    v.allowed = a.allowed + (size_t)q * a.allowed_stride;
+    v.seen = a.seen + (size_t)q * a.words;
+    DevCtx<METRIC, FUSED> c{ix, qv, a.qhdr ? a.qhdr[q] : 0.f, wsum};
+    walk::Counters st;
+    uint32_t s_n = 0;
+    const uint32_t bad = walk::run(c, v, pl, a.samples + (size_t)q * a.sample_stride, a.qhash[q], m, st, s_n);
+    __syncthreads();
+    // results = `top` sorted by (score, id), first k (restricted.rs:1130-1147)
+    uint32_t out_n = s_n < pl.ef_filtered ? s_n : pl.ef_filtered;
+    if (out_n > pl.k) out_n = pl.k;
+    if (bad) out_n = 0;
+    for (uint32_t i = t; i < out_n; i += kT) {
+        const uint64_t key = m.S[i];
+        a.out_ids[(size_t)q * a.k_stride + i] = ix.ids[(uint32_t)(key >> 1) & 0x7FFFFFFFu];
+        a.out_scores[(size_t)q * a.k_stride + i] = __uint_as_float((uint32_t)(key >> 32));
+    }
+    if (t == 0) {
+        a.out_counts[q] = out_n;
+        if (a.out_status) a.out_status[q] = bad ? 8u /*HVX_ERR_INVARIANT*/ : 0u;
+        a.counters[q] = st;
+    }
+}
+
+template <uint32_t METRIC, bool FUSED> hipError_t launch_walk_t(const WalkArgs &a, uint32_t b, size_t lds, hipStream_t s) {
+    auto kern = restricted_walk_kernel<METRIC, FUSED>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(b), dim3(kT), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_walk(const WalkArgs &a, uint32_t b, hipStream_t s) {
+    const size_t lds = walk_lds_bytes(a.ix.ld, a.b_cap);
+    const bool fused = a.ix.fkernel == kKernelAvxFma;
+    switch (a.ix.metric) {
+    case kCosine: return fused ? launch_walk_t<kCosine, true>(a, b, lds, s) : launch_walk_t<kCosine, false>(a, b, lds, s);
+    case kL2: return fused ? launch_walk_t<kL2, true>(a, b, lds, s) : launch_walk_t<kL2, false>(a, b, lds, s);
+    default: return launch_walk_t<kL1, true>(a, b, lds, s);
+    }
+}
+
+// membership bitmap of a row list
+__global__ void set_bits_kernel(const uint32_t *rows, uint32_t n, uint32_t *bitmap) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicOr(&bitmap[rows[i] >> 5], 1u << (rows[i] & 31u));
+}
+// samples[t] = rows[ranks[t]] (candidate sets whose every id is indexed: rank in the population = rank in the row list)
+__global__ void gather_rows_kernel(const uint32_t *rows, const uint32_t *ranks, uint32_t n, uint32_t *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = rows[ranks[i]];
+}
+
+using HostPlan = hvx::RestrictedPlan;
+
+// restricted_execution_plan_with_beam_percent (restricted.rs:426-453) + FilteredGraphBudgets::with_beam_percent (:230-259)
+int make_plan(const hvx_restricted_params &rp, uint64_t candidates, uint32_t dim, HostPlan *out) {
+    HostPlan hp{};
+    const uint64_t kk = std::min<uint64_t>(rp.k, candidates);
+    hp.p.k = (uint32_t)kk;
+    hp.p.directory_enabled = rp.directory_enabled ? 1u : 0u;
+    const bool exact_ok = candidates <= 256 && candidates * (uint64_t)dim * 4ull <= 4ull * 1024 * 1024;
+    if (rp.strategy == HVX_RESTRICTED_EXACT || (rp.strategy == HVX_RESTRICTED_AUTO && exact_ok && !rp.explicit_budgets)) {
+        hp.strategy = HVX_RESTRICTED_EXACT;
+        *out = hp;
+        return HVX_OK;
+    }
+    hp.strategy = HVX_RESTRICTED_FILTERED;
+    if (rp.explicit_budgets) {
+        hp.p.ef_filtered = rp.ef_filtered;
+        hp.p.routing_rows = rp.routing_rows;
+        hp.p.bridge_rows = rp.bridge_rows;
+        hp.p.vector_payloads = rp.vector_payloads;
+        hp.p.sampled_seeds = rp.sampled_seeds;
+        hp.p.directory_seeds = rp.directory_seeds;
+    } else {
+        const uint64_t pct = rp.beam_percent ? rp.beam_percent : 150u;
+        const uint64_t scaled = (uint64_t)rp.ef * pct / 100ull;
+        const uint64_t eff = std::min<uint64_t>(std::max<uint64_t>(scaled, kk * 4), candidates);
+        hp.p.ef_filtered = (uint32_t)eff;
+        hp.p.routing_rows = (uint32_t)std::min<uint64_t>(eff * 16, 0xFFFFFFFFull);
+        hp.p.bridge_rows = (uint32_t)std::min<uint64_t>(eff * 8, 0xFFFFFFFFull);
+        hp.p.vector_payloads = (uint32_t)std::min<uint64_t>(800, candidates);
+        hp.p.sampled_seeds = (uint32_t)std::min<uint64_t>(64, candidates);
+        hp.p.directory_seeds = (uint32_t)std::min<uint64_t>(256, candidates);
+    }
+    if (hp.p.vector_payloads > walk::kScoredCap || hp.p.sampled_seeds > walk::kSeedCap || hp.p.directory_seeds > walk::kSeedCap ||
+        hp.p.bridge_rows > kMaxBridgeRows)
+        return fail(HVX_ERR_UNSUPPORTED, "filtered walk budgets outside this build: vector_payloads %u (<= %u), sampled / directory seeds %u / %u "
+                    "(<= %u), bridge_rows %u (<= %u)", hp.p.vector_payloads, walk::kScoredCap, hp.p.sampled_seeds, hp.p.directory_seeds,
+                    walk::kSeedCap, hp.p.bridge_rows, kMaxBridgeRows);
+    hp.p.n_sample = (uint32_t)std::min<uint64_t>(hp.p.sampled_seeds, candidates);
+    *out = hp;
+    return HVX_OK;
+}
+
+// NonEmptyCandidateSet::deterministic_sample_ids (restricted.rs:321-342) as ranks into the ascending candidate list
+void sample_ranks(uint64_t candidates, uint32_t count, std::vector<uint64_t> &out) {
+    out.resize(count);
+    for (uint64_t t = 0; t < count; ++t) {
+        if (count == candidates) out[t] = t;
+        else if (count == 1) out[t] = 0;
+        else out[t] = (uint64_t)(((unsigned __int128)t * (unsigned __int128)(candidates - 1)) / (unsigned __int128)(count - 1));
+    }
+}
+
+// the SimHash directory of this image, built once from the attached SimHash rows
+int ensure_directory(hvx_index *ix) {
+    hvx_image_shared &sh = *ix->shared;
+    std::lock_guard<std::mutex> lock(sh.mu);
+    if (sh.dir_code && sh.dir_for == ix->d_node_hash) return HVX_OK;
+    const uint32_t n = ix->dev.n;
+    std::vector<uint64_t> h(std::max<uint32_t>(n, 1));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    if (n) HIP_TRY(hipMemcpy(h.data(), ix->d_node_hash, (size_t)n * 8, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> code(std::max<uint32_t>(n, 1));
+    for (uint32_t i = 0; i < n; ++i) code[i] = walk::order_code(h[i]);
+    std::vector<uint32_t> order(std::max<uint32_t>(n, 1));
+    std::iota(order.begin(), order.begin() + n, 0u);
+    std::sort(order.begin(), order.begin() + n, [&](uint32_t x, uint32_t y) { return code[x] != code[y] ? code[x] < code[y] : x < y; });
+    for (uint32_t i = 0; i < n; ++i) h[i] = code[order[i]];
+    if (sh.dir_code) { (void)hipFree(sh.dir_code); sh.dir_code = nullptr; }
+    if (sh.dir_row) { (void)hipFree(sh.dir_row); sh.dir_row = nullptr; }
+    sh.device = ix->device;
+    HIP_TRY(hipMalloc((void **)&sh.dir_code, (size_t)std::max<uint32_t>(n, 1) * 8));
+    HIP_TRY(hipMalloc((void **)&sh.dir_row, (size_t)std::max<uint32_t>(n, 1) * 4));
+    if (n) {
+        HIP_TRY(hipMemcpy(sh.dir_code, h.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(sh.dir_row, order.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    }
+    sh.dir_for = ix->d_node_hash;
+    return HVX_OK;
+}
+
+int grow(hvx_index *ix, void **p, size_t *cap, size_t bytes) {
+    if (bytes <= *cap && *p) return HVX_OK;
+    int rc = ix->regrow(p, bytes);
+    if (rc) return rc;
+    *cap = bytes;
+    return HVX_OK;
+}
+
+bool walk_supported(const hvx_index *ix) { return ix->dev.dtype == HVX_F32 && ix->dev.s0 <= kW && ix->dev.s0 != 0; }
+
+void widen(const walk::Counters &c, uint32_t ef_filtered, hvx_restricted_stats *o) {
+    o->strategy = HVX_RESTRICTED_FILTERED;
+    o->termination = c.termination;
+    o->ef_filtered = ef_filtered;
+    o->directory_scan_calls = c.directory_scan_calls;
+    o->directory_rows = c.directory_rows;
+    o->directory_decoded_bytes = c.directory_decoded_bytes;
+    o->directory_hits = c.directory_hits;
+    o->simhash_row_requests = c.simhash_row_requests;
+    o->companion_row_requests = c.companion_row_requests;
+    o->routing_rows = c.routing_rows;
+    o->bridge_rows = c.bridge_rows;
+    o->bridge_frontier_pushes = c.bridge_frontier_pushes;
+    o->neighbor_multi_get_calls = c.neighbor_multi_get_calls;
+    o->vector_payload_requests = c.vector_payload_requests;
+    o->vector_bytes = c.vector_bytes;
+    o->distance_computations = c.distance_computations;
+}
+
+// One candidate set shared by `b` host-resident queries, walk strategy.  d_rows / n_rows: the indexed candidates as rows on
+// the device (ascending); d_samples: the deterministic seeds as rows (kSentinel = not indexed), n_sample of them.
+int walk_shared_set(hvx_index *ix, const float *queries, uint32_t b, uint32_t k_stride, const HostPlan &hp, const uint32_t *d_rows,
+                    uint32_t n_rows, const uint32_t *d_samples, uint64_t *out_ids, float *out_scores, uint32_t *out_counts,
+                    uint32_t *out_status, hvx_restricted_stats *rstats, hvx_stats *stats) {
+    int rc;
+    if (!ix->has_simhash)
+        return fail(HVX_ERR_INVARIANT, "the filtered restricted search needs the index's SimHash rows (hvx_index_set_simhash): "
+                    "missing SimHash companion rows are index corruption in the reference");
+    if (!walk_supported(ix)) return fail(HVX_ERR_UNSUPPORTED, "the filtered restricted walk serves f32 rows with neighbour rows <= %u ids", kW);
+    if ((rc = ensure_directory(ix))) return rc;
+    const uint32_t words = (ix->dev.n + 31u) / 32u + 1u, mb = ix->max_batch;
+    if ((rc = grow(ix, (void **)&ix->w_allowed, &ix->cap_w_allowed, (size_t)words * 4))) return rc;
+    if ((rc = grow(ix, (void **)&ix->w_seen, &ix->cap_w_seen, (size_t)std::min(b, mb) * words * 4))) return rc;
+    if ((rc = grow(ix, (void **)&ix->w_plans, &ix->cap_w_q, (size_t)mb * (sizeof(walk::Plan) + sizeof(walk::Counters))))) return rc;
+    ix->w_counters = (char *)ix->w_plans + (size_t)mb * sizeof(walk::Plan);
+    HIP_TRY(hipMemsetAsync(ix->w_allowed, 0, (size_t)words * 4, ix->stream));
+    if (n_rows) hipLaunchKernelGGL(set_bits_kernel, dim3((n_rows + 255u) / 256u), dim3(256), 0, ix->stream, d_rows, n_rows, ix->w_allowed);
+    HIP_TRY(hipGetLastError());
+    std::vector<walk::Plan> plans(std::min(b, mb), hp.p);
+    HIP_TRY(hipMemcpyAsync(ix->w_plans, plans.data(), plans.size() * sizeof(walk::Plan), hipMemcpyHostToDevice, ix->stream));
+    std::vector<uint32_t> status(b, 0);
+    std::vector<walk::Counters> cnt(b);
+    for (uint32_t c0 = 0; c0 < b; c0 += mb) {
+        const uint32_t cb = std::min(mb, b - c0);
+        if ((rc = ix->stage(cb, k_stride))) return rc;
+        HIP_TRY(hipMemcpyAsync(ix->s_queries, queries + (size_t)c0 * ix->dev.dim, (size_t)cb * ix->dev.dim * 4, hipMemcpyHostToDevice, ix->stream));
+        HIP_TRY(launch_validate_queries(ix->dev, ix->s_queries, cb, ix->limit, ix->d_qstatus, ix->d_qhdr, ix->stream));
+        HIP_TRY(launch_simhash_rows(ix->d_planes_t, ix->s_queries, ix->dev.dim, ix->dev.dim, cb, ix->d_qhash, ix->stream));
+        HIP_TRY(hipMemsetAsync(ix->w_seen, 0, (size_t)cb * words * 4, ix->stream));
+        WalkArgs a;
+        a.ix = ix->dev;
+        a.queries = ix->s_queries;
+        a.qstatus = ix->d_qstatus;
+        a.qhdr = ix->d_qhdr;
+        a.qhash = ix->d_qhash;
+        a.node_hash = ix->d_node_hash;
+        a.dir_code = ix->shared->dir_code;
+        a.dir_row = ix->shared->dir_row;
+        a.allowed = ix->w_allowed;
+        a.seen = ix->w_seen;
+        a.words = words;
+        a.allowed_stride = 0;
+        a.plans = (const walk::Plan *)ix->w_plans;
+        a.samples = d_samples;
+        a.sample_stride = 0;
+        a.b_cap = hp.p.bridge_rows;
+        a.k_stride = k_stride;
+        a.out_ids = ix->s_ids;
+        a.out_scores = ix->s_scores;
+        a.out_counts = ix->s_counts;
+        a.out_status = ix->s_status;
+        a.counters = (walk::Counters *)ix->w_counters;
+        if (stats) HIP_TRY(hipEventRecord(ix->ev0, ix->stream));
+        HIP_TRY(launch_walk(a, cb, ix->stream));
+        if (stats) HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
+        HIP_TRY(hipMemcpyAsync(out_ids + (size_t)c0 * k_stride, ix->s_ids, (size_t)cb * k_stride * 8, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipMemcpyAsync(out_scores + (size_t)c0 * k_stride, ix->s_scores, (size_t)cb * k_stride * 4, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipMemcpyAsync(out_counts + c0, ix->s_counts, (size_t)cb * 4, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipMemcpyAsync(status.data() + c0, ix->s_status, (size_t)cb * 4, hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipMemcpyAsync(cnt.data() + c0, ix->w_counters, (size_t)cb * sizeof(walk::Counters), hipMemcpyDeviceToHost, ix->stream));
+        HIP_TRY(hipStreamSynchronize(ix->stream));
+        if (stats) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
+            stats->device_ms += ms;
+            stats->queries += cb;
+            for (uint32_t i = 0; i < cb; ++i) {
+                stats->distance_computations += cnt[c0 + i].distance_computations;
+                stats->vectors_loaded += cnt[c0 + i].vector_payload_requests;
+                stats->expansion_steps += cnt[c0 + i].routing_rows;
+            }
+        }
+    }
+    for (uint32_t q = 0; q < b; ++q) {
+        if (rstats) {
+            memset(&rstats[q], 0, sizeof(hvx_restricted_stats));
+            if (!status[q] && ix->dev.has_entry) widen(cnt[q], hp.p.ef_filtered, &rstats[q]);
+        }
+        if (status[q]) {
+            out_counts[q] = 0;
+            if (!out_status) return fail((int)status[q], "query %u rejected with status %u", q, status[q]);
+            out_status[q] = status[q];
+        }
+    }
+    return HVX_OK;
+}
+
+// exact strategy for one shared candidate set (rows already on the device): the gathered exact scan of hvx_flat*.hip
+int exact_shared_set(hvx_index *ix, const float *queries, uint32_t b, uint32_t k_stride, uint32_t kk, const uint32_t *d_rows, uint32_t n_rows,
+                     uint64_t *out_ids, float *out_scores, uint32_t *out_counts, uint32_t *out_status, hvx_restricted_stats *rstats,
+                     hvx_stats *stats) {
+    std::vector<uint64_t> t_ids((size_t)b * kk);
+    std::vector<float> t_sc((size_t)b * kk);
+    std::vector<uint32_t> t_cnt(b), t_st(b);
+    int rc = flat_scan_host(ix, queries, b, kk, d_rows, n_rows, t_ids.data(), t_sc.data(), t_cnt.data(), t_st.data(), stats);
+    if (rc) return rc;
+    for (uint32_t q = 0; q < b; ++q) {
+        if (rstats) {
+            memset(&rstats[q], 0, sizeof(hvx_restricted_stats));
+            if (!t_st[q] && ix->dev.has_entry) {
+                rstats[q].strategy = HVX_RESTRICTED_EXACT;
+            }
+        }
+        if (t_st[q]) {
+            if (!out_status) return fail((int)t_st[q], "query %u rejected with status %u", q, t_st[q]);
+            out_status[q] = t_st[q];
+            continue;
+        }
+        out_counts[q] = t_cnt[q];
+        memcpy(out_ids + (size_t)q * k_stride, t_ids.data() + (size_t)q * kk, (size_t)t_cnt[q] * 8);
+        memcpy(out_scores + (size_t)q * k_stride, t_sc.data() + (size_t)q * kk, (size_t)t_cnt[q] * 4);
+    }
+    return HVX_OK;
+}
+
+// search_restricted_observed_with_beam_percent (restricted.rs:528-613) for one candidate list shared by b queries
+int restricted_set(hvx_index *ix, const float *queries, uint32_t b, const hvx_restricted_params &rp, const uint64_t *allowed,
+                   uint64_t n_allowed, uint64_t *out_ids, float *out_scores, uint32_t *out_counts, uint32_t *out_status,
+                   hvx_restricted_stats *rstats, hvx_stats *stats) {
+    // RestrictedVectorCandidates::from_ids (restricted.rs:356-371): dedupe, cap 1,000,000
+    std::vector<uint64_t> ids(allowed, allowed + n_allowed);
+    std::sort(ids.begin(), ids.end());
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    if (ids.size() > 1000000) return fail(HVX_ERR_CANDIDATE_LIMIT, "restricted vector search accepts at most 1000000 unique candidates");
+    for (uint32_t q = 0; q < b; ++q) {
+        out_counts[q] = 0;
+        if (out_status) out_status[q] = HVX_OK;
+        if (rstats) memset(&rstats[q], 0, sizeof(hvx_restricted_stats));
+    }
+    if (ids.empty()) return HVX_OK; // Empty: no results, before any validation (restricted.rs:539-541)
+    const uint32_t kk = (uint32_t)std::min<uint64_t>(rp.k, ids.size());
+    if (kk == 0) return fail(HVX_ERR_K_RANGE, "result count must be non-zero");
+    if (kk > 800) return fail(HVX_ERR_K_RANGE, "restricted vector search result count %u is above the maximum 800", kk);
+    HostPlan hp;
+    int rc = make_plan(rp, ids.size(), ix->dev.dim, &hp);
+    if (rc) return rc;
+    // ids that are not indexed are omitted from the scan (restricted.rs:615-659) but count as candidates for the plan
+    std::vector<uint32_t> subset;
+    subset.reserve(ids.size());
+    for (uint64_t id : ids) {
+        const uint32_t x = ix->find(id);
+        if (x != kSentinel) subset.push_back(x);
+    }
+    if (subset.size() > ix->cap_subset) {
+        if ((rc = ix->regrow((void **)&ix->f_subset, subset.size() * 4))) return rc;
+        ix->cap_subset = subset.size();
+    }
+    if (!subset.empty())
+        HIP_TRY(hipMemcpyAsync(ix->f_subset, subset.data(), subset.size() * 4, hipMemcpyHostToDevice, ix->stream));
+    if (hp.strategy == HVX_RESTRICTED_EXACT) {
+        HIP_TRY(hipStreamSynchronize(ix->stream)); // `subset` lives on this frame
+        return exact_shared_set(ix, queries, b, rp.k, kk, ix->f_subset, (uint32_t)subset.size(), out_ids, out_scores, out_counts, out_status,
+                                rstats, stats);
+    }
+    std::vector<uint64_t> ranks;
+    sample_ranks(ids.size(), hp.p.n_sample, ranks);
+    std::vector<uint32_t> samples(std::max<size_t>(ranks.size(), 1), kSentinel);
+    for (size_t t = 0; t < ranks.size(); ++t) samples[t] = ix->find(ids[ranks[t]]);
+    if ((rc = grow(ix, (void **)&ix->w_samples, &ix->cap_w_samples, samples.size() * 4))) return rc;
+    HIP_TRY(hipMemcpyAsync(ix->w_samples, samples.data(), samples.size() * 4, hipMemcpyHostToDevice, ix->stream));
+    HIP_TRY(hipStreamSynchronize(ix->stream)); // `subset` / `samples` live on this frame
+    return walk_shared_set(ix, queries, b, rp.k, hp, ix->f_subset, (uint32_t)subset.size(), ix->w_samples, out_ids, out_scores, out_counts,
+                           out_status, rstats, stats);
+}
+
+} // namespace
+
+int hvx::restricted_make_plan(const hvx_restricted_params &rp, uint64_t candidates, uint32_t dim, RestrictedPlan *out) {
+    return make_plan(rp, candidates, dim, out);
+}
+void hvx::restricted_sample_ranks(uint64_t candidates, uint32_t count, std::vector<uint64_t> &out) { sample_ranks(candidates, count, out); }
+int hvx::restricted_run_plan(hvx_index *ix, const float *queries, uint32_t b, uint32_t k_stride, const RestrictedPlan &plan, const uint32_t *d_rows,
+                             uint32_t n_rows, const uint32_t *d_samples, uint64_t *out_ids, float *out_scores, uint32_t *out_counts,
+                             uint32_t *out_status, hvx_restricted_stats *rstats, hvx_stats *stats) {
+    if (plan.strategy == HVX_RESTRICTED_EXACT)
+        return exact_shared_set(ix, queries, b, k_stride, plan.p.k, d_rows, n_rows, out_ids, out_scores, out_counts, out_status, rstats, stats);
+    return walk_shared_set(ix, queries, b, k_stride, plan, d_rows, n_rows, d_samples, out_ids, out_scores, out_counts, out_status, rstats, stats);
+}
+
+extern "C" void hvx_restricted_params_default(hvx_restricted_params *p, uint32_t k, uint32_t ef) {
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->k = k;
+    p->ef = ef;
+    p->strategy = HVX_RESTRICTED_AUTO;
+    p->beam_percent = 150; // FILTERED_BEAM_PERCENT (restricted.rs:52)
+    p->directory_enabled = 1;
+}
+
+extern "C" int hvx_search_restricted_batch_params(const hvx_index *cix, const float *queries, uint32_t b, const hvx_restricted_params *params,
+                                                  const uint64_t *allowed_ids, const uint64_t *allowed_offsets, uint64_t n_allowed,
+                                                  uint64_t *out_ids, float *out_scores, uint32_t *out_counts, uint32_t *out_status,
+                                                  hvx_restricted_stats *out_rstats, hvx_stats *stats) {
+    if (!cix || !params) return fail(HVX_ERR_INVARIANT, "null argument");
+    hvx_index *ix = const_cast<hvx_index *>(cix);
+    if (params->strategy > HVX_RESTRICTED_FILTERED) return fail(HVX_ERR_INVARIANT, "unknown restricted strategy %u", params->strategy);
+    if (params->k == 0) return fail(HVX_ERR_K_RANGE, "result count must be non-zero");
+    if (params->ef < params->k) return fail(HVX_ERR_K_RANGE, "search beam width %u is below the result count %u", params->ef, params->k);
+    if (b == 0) return HVX_OK;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    if (!allowed_offsets)
+        return restricted_set(ix, queries, b, *params, allowed_ids, n_allowed, out_ids, out_scores, out_counts, out_status, out_rstats, stats);
+    for (uint32_t q = 0; q < b; ++q) { // one candidate list per query
+        const uint64_t a0 = allowed_offsets[q], a1 = allowed_offsets[q + 1];
+        int rc = restricted_set(ix, queries + (size_t)q * ix->dev.dim, 1, *params, allowed_ids + a0, a1 - a0, out_ids + (size_t)q * params->k,
+                                out_scores + (size_t)q * params->k, out_counts + q, out_status ? out_status + q : nullptr,
+                                out_rstats ? out_rstats + q : nullptr, stats);
+        if (rc) return rc;
+    }
+    return HVX_OK;
+}

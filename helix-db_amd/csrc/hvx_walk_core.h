@@ -33,9 +33,11 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
-#define HVX_WALK_FN __device__ __forceinline__
+#define HVX_WALK_FN __device__ __forceinline__          // the algorithm body: device only in the product
+#define HVX_WALK_HD __host__ __device__ __forceinline__ // small helpers the library's host code shares (directory build)
 #else
 #define HVX_WALK_FN inline
+#define HVX_WALK_HD inline
 #endif
 
 namespace hvx {
@@ -101,7 +103,7 @@ struct Mem {
 enum : uint32_t { kGN = 0, kPush = 1, kBad = 2, kUnknown = 3, kTmp = 4, kMin = 5, kWinLo = 8, kWinCnt = 16, kCtlWords = 32 };
 
 // order_code_from_simhash_bits (simhash.rs:44-59): the four 16-bit bands interleaved MSB first
-HVX_WALK_FN uint64_t order_code(uint64_t bits) {
+HVX_WALK_HD uint64_t order_code(uint64_t bits) {
     uint64_t code = 0;
     for (int bit = 15; bit >= 0; --bit) {
         code = (code << 1) | ((bits >> (48 + bit)) & 1u);
@@ -114,7 +116,7 @@ HVX_WALK_FN uint64_t order_code(uint64_t bits) {
 
 // directory_prefix_offsets()[i] for i < 64 (restricted.rs:455-462: all u16 sorted by (popcount, value)): 0, the 16
 // single-bit values ascending, then the two-bit values ascending
-HVX_WALK_FN uint32_t prefix_offset(uint32_t i) {
+HVX_WALK_HD uint32_t prefix_offset(uint32_t i) {
     if (i == 0) return 0u;
     if (i <= 16) return 1u << (i - 1);
     uint32_t r = i - 17, h = 1;
@@ -122,19 +124,15 @@ HVX_WALK_FN uint32_t prefix_offset(uint32_t i) {
     return (1u << h) | (1u << r);
 }
 
-HVX_WALK_FN uint32_t popc64(uint64_t x) {
-#if defined(__HIPCC__)
-    return (uint32_t)__popcll(x);
-#else
+HVX_WALK_HD uint32_t popc64(uint64_t x) {
     return (uint32_t)__builtin_popcountll(x);
-#endif
 }
-HVX_WALK_FN uint32_t pow2_ceil(uint32_t x) {
+HVX_WALK_HD uint32_t pow2_ceil(uint32_t x) {
     uint32_t p = 1;
     while (p < x) p <<= 1;
     return p;
 }
-HVX_WALK_FN uint32_t lower_bound(const uint64_t *a, uint32_t n, uint64_t key) {
+HVX_WALK_HD uint32_t lower_bound(const uint64_t *a, uint32_t n, uint64_t key) {
     uint32_t lo = 0, hi = n;
     while (lo < hi) {
         const uint32_t mid = lo + ((hi - lo) >> 1);
@@ -143,7 +141,7 @@ HVX_WALK_FN uint32_t lower_bound(const uint64_t *a, uint32_t n, uint64_t key) {
     }
     return lo;
 }
-HVX_WALK_FN uint32_t lower_bound(const uint32_t *a, uint32_t n, uint32_t key) {
+HVX_WALK_HD uint32_t lower_bound(const uint32_t *a, uint32_t n, uint32_t key) {
     uint32_t lo = 0, hi = n;
     while (lo < hi) {
         const uint32_t mid = lo + ((hi - lo) >> 1);
@@ -152,13 +150,13 @@ HVX_WALK_FN uint32_t lower_bound(const uint32_t *a, uint32_t n, uint32_t key) {
     }
     return lo;
 }
-HVX_WALK_FN bool row_contains(const uint32_t *row, uint32_t s0, uint32_t x) { // rows ascend, kNone (the largest u32) pads
+HVX_WALK_HD bool row_contains(const uint32_t *row, uint32_t s0, uint32_t x) { // rows ascend, kNone (the largest u32) pads
     const uint32_t p = lower_bound(row, s0, x);
     return p < s0 && row[p] == x;
 }
-HVX_WALK_FN bool bit_of(const uint32_t *bm, uint32_t x) { return (bm[x >> 5] >> (x & 31u)) & 1u; }
-HVX_WALK_FN uint32_t sat_sub(uint32_t a, uint32_t b) { return a > b ? a - b : 0u; }
-HVX_WALK_FN uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+HVX_WALK_HD bool bit_of(const uint32_t *bm, uint32_t x) { return (bm[x >> 5] >> (x & 31u)) & 1u; }
+HVX_WALK_HD uint32_t sat_sub(uint32_t a, uint32_t b) { return a > b ? a - b : 0u; }
+HVX_WALK_HD uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
 // The context `C` supplies the workgroup:
 //   C::T                      threads;  C::W  items handled per collective step (a multiple of T)

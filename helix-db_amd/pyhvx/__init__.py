@@ -126,6 +126,37 @@ class AdaptiveStats(C.Structure):  # hvx_adaptive_stats
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+RESTRICTED_AUTO, RESTRICTED_EXACT, RESTRICTED_FILTERED = 0, 1, 2  # hvx_restricted_strategy
+TERM_NONE, TERM_EXHAUSTED, TERM_BEAM_COMPLETE, TERM_ROUTING_BUDGET, TERM_BRIDGE_BUDGET, TERM_VECTOR_BUDGET = range(6)
+
+
+class RestrictedParams(C.Structure):  # hvx_restricted_params
+    _fields_ = [(n, C.c_uint32) for n in ("k", "ef", "strategy", "beam_percent", "directory_enabled", "explicit_budgets", "ef_filtered",
+                                          "routing_rows", "bridge_rows", "vector_payloads", "sampled_seeds", "directory_seeds")]
+
+    @classmethod
+    def new(cls, k, ef, *, strategy=RESTRICTED_AUTO, beam_percent=150, directory=True, **budgets):
+        """search_restricted's plan (restricted.rs:426-453); `budgets` = explicit FilteredGraphBudgets as the reference's tests pass them"""
+        p = cls(k=k, ef=ef, strategy=strategy, beam_percent=beam_percent, directory_enabled=1 if directory else 0)
+        if budgets:
+            p.explicit_budgets = 1
+            p.strategy = RESTRICTED_FILTERED
+            for name in ("ef_filtered", "routing_rows", "bridge_rows", "vector_payloads", "sampled_seeds", "directory_seeds"):
+                setattr(p, name, int(budgets.pop(name)))
+            assert not budgets, budgets
+        return p
+
+
+class RestrictedStats(C.Structure):  # hvx_restricted_stats: RestrictedSearchStats (restricted.rs:147-166)
+    _fields_ = [("strategy", C.c_uint32), ("termination", C.c_uint32)] + [(n, C.c_uint64) for n in (
+        "ef_filtered", "directory_scan_calls", "directory_rows", "directory_decoded_bytes", "directory_hits", "simhash_row_requests",
+        "companion_row_requests", "routing_rows", "bridge_rows", "bridge_frontier_pushes", "neighbor_multi_get_calls",
+        "vector_payload_requests", "vector_bytes", "distance_computations")]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
 _lib = None
 _vp = C.c_void_p
 
@@ -247,6 +278,13 @@ def lib():
     L.hvx_prefilter_search_batch.argtypes = [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint32,
                                              C.c_uint32, C.c_uint32, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp,
                                              C.POINTER(C.c_uint64), C.POINTER(Stats)]
+    L.hvx_search_restricted_batch_params.restype = C.c_int
+    L.hvx_search_restricted_batch_params.argtypes = [_vp, _vp, C.c_uint32, C.POINTER(RestrictedParams), _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp,
+                                                     _vp, C.POINTER(Stats)]
+    L.hvx_prefilter_search_batch_params.restype = C.c_int
+    L.hvx_prefilter_search_batch_params.argtypes = [_vp, _vp, _vp, C.c_uint32, C.POINTER(RestrictedParams), C.c_uint32, _vp, C.c_uint32,
+                                                    C.c_uint32, C.c_uint32, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp,
+                                                    C.POINTER(C.c_uint64), _vp, C.POINTER(Stats)]
     L.hvx_batcher_new.restype = C.c_int
     L.hvx_batcher_new.argtypes = [_vp, C.POINTER(_Params), C.c_uint32, C.c_uint32, C.POINTER(_vp)]
     L.hvx_batcher_free.argtypes = [_vp]
@@ -593,6 +631,40 @@ class ValidatedVectorReadIndex:
                                                  _ptr(ids), _ptr(sc), _ptr(cnt), None, None))
         return ids, sc, cnt
 
+    def search_restricted_batch_params(self, queries, rparams: "RestrictedParams", candidates, offsets=None, want_stats=False):
+        """search_restricted under the reference's execution plan (hvx_search_restricted_batch_params): exact scan for small
+        candidate sets, the filter-aware walk otherwise.  Returns (ids, scores, counts, status, [RestrictedSearchStats dicts])
+        (+ the hvx_stats dict when want_stats)."""
+        q = self._q(queries)
+        b, k = q.shape[0], int(rparams.k)
+        al = candidates.ids if isinstance(candidates, RestrictedVectorCandidates) else np.ascontiguousarray(candidates, dtype=np.uint64)
+        off = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.uint64)
+        ids = np.zeros((b, k), np.uint64); sc = np.zeros((b, k), np.float32); cnt = np.zeros(b, np.uint32); st = np.zeros(b, np.uint32)
+        rs = (RestrictedStats * b)()
+        stats = Stats()
+        _check(lib().hvx_search_restricted_batch_params(self._h, _ptr(q), b, C.byref(rparams), _ptr(al), _ptr(off), al.size, _ptr(ids), _ptr(sc),
+                                                        _ptr(cnt), _ptr(st), C.cast(rs, _vp), C.byref(stats) if want_stats else None))
+        out = (ids, sc, cnt, st, [r.as_dict() for r in rs])
+        return out + (stats.as_dict(),) if want_stats else out
+
+    def prefilter_search_batch_params(self, graph: "Graph", queries, rparams: "RestrictedParams", seeds, *, traverse=False, max_depth=1,
+                                      direction=DIR_OUT, allowed_labels=(), hub_degree=0, include_seeds=True):
+        """the fused hop + restricted kNN under the reference's execution plan; returns (ids, scores, counts, n_candidates,
+        [RestrictedSearchStats dicts], hvx_stats dict)"""
+        q = self._q(queries)
+        b, k = q.shape[0], int(rparams.k)
+        s = np.ascontiguousarray(seeds, dtype=np.uint64)
+        lab = np.ascontiguousarray(allowed_labels, dtype=np.uint32)
+        ids = np.zeros((b, k), np.uint64); sc = np.zeros((b, k), np.float32); cnt = np.zeros(b, np.uint32)
+        ncand = C.c_uint64(0)
+        rs = (RestrictedStats * b)()
+        stats = Stats()
+        _check(lib().hvx_prefilter_search_batch_params(self._h, graph._h, _ptr(q), b, C.byref(rparams), 1 if traverse else 0, _ptr(s), s.size,
+                                                       max_depth, direction, _ptr(lab) if lab.size else None, lab.size, hub_degree,
+                                                       1 if include_seeds else 0, _ptr(ids), _ptr(sc), _ptr(cnt), None, C.byref(ncand),
+                                                       C.cast(rs, _vp), C.byref(stats)))
+        return ids, sc, cnt, int(ncand.value), [r.as_dict() for r in rs], stats.as_dict()
+
     def prefilter_search_batch(self, graph: "Graph", queries, params: SearchParams, seeds, *, traverse=False, max_depth=1,
                                direction=DIR_OUT, allowed_labels=(), hub_degree=0, include_seeds=True):
         """`where_()` / traversal filter + vector_search in ONE call: the hop's candidate bitmap stays on the device
@@ -867,8 +939,8 @@ class SimHasher:
 
 
 # ---- what the reference's restricted planner would do (restricted.rs:40-56,196-260,426-453,321-342) --------------------
-# The device answers every restricted search with the exact scan; these mirrors exist so that a host can see (and log) the
-# plan the CPU path would have taken for the same request, and so that the planning rules stay pinned by the reference's tests.
+# Host mirrors of the planner the library applies in hvx_search_restricted_batch_params (so that a host can see / log the plan
+# of a request, and so that the planning rules stay pinned by the reference's tests on the CPU).
 MAX_RESTRICTED_CANDIDATES = 1_000_000
 EXACT_CARDINALITY_THRESHOLD = 256
 EXACT_VECTOR_BYTES_THRESHOLD = 4 * 1024 * 1024

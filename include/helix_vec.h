@@ -253,6 +253,49 @@ int hvx_search_restricted_batch(const hvx_index *, const float *queries, uint32_
                                 uint64_t *out_ids, float *out_scores, uint32_t *out_counts,
                                 uint32_t *out_status, hvx_stats *stats);
 
+/*
+ * The same with the reference's execution plan (restricted.rs:426-453) and its observability (RestrictedSearchStats,
+ * restricted.rs:147-166).  strategy AUTO = the reference's planner: candidate sets of <= 256 ids AND <= 4 MiB of f32 payload
+ * take restricted_exact_scan (restricted.rs:753-835), everything else restricted_filter_aware_search (restricted.rs:837-1148):
+ * seeds = deterministic sample of the candidate set (:321-342) + SimHash-directory windows around the query's order code
+ * (:866-923) + the entry point; an ACORN-style walk over layer-0 rows in which members are scored and non-members become
+ * bridges ranked by SimHash Hamming distance; the six budgets of FilteredGraphBudgets (:230-259).  One 256-thread
+ * workgroup per query (csrc/hvx_restricted_walk.hip); ids, score bits, every counter below and the termination reason equal
+ * the reference CPU path's.  Needs the SimHash rows (hvx_index_set_simhash; missing => HVX_ERR_INVARIANT like the
+ * reference's missing_simhash_error) and f32 rows; strategy EXACT forces the device's exact gathered scan for any
+ * candidate-set size (what hvx_search_restricted_batch does), FILTERED forces the walk (the reference's tests call it that way).
+ */
+enum hvx_restricted_strategy { HVX_RESTRICTED_AUTO = 0, HVX_RESTRICTED_EXACT = 1, HVX_RESTRICTED_FILTERED = 2 };
+/* RestrictedSearchTermination (restricted.rs:131-143) */
+enum hvx_restricted_termination {
+    HVX_TERM_NONE = 0, HVX_TERM_EXHAUSTED = 1, HVX_TERM_BEAM_COMPLETE = 2, HVX_TERM_ROUTING_BUDGET = 3,
+    HVX_TERM_BRIDGE_BUDGET = 4, HVX_TERM_VECTOR_BUDGET = 5
+};
+typedef struct hvx_restricted_params {
+    uint32_t k, ef;              /* requested result count (clamped to the candidate count, then <= 800) and beam width */
+    uint32_t strategy;           /* hvx_restricted_strategy */
+    uint32_t beam_percent;       /* filtered beam = ef * percent / 100; 0 = FILTERED_BEAM_PERCENT (150) */
+    uint32_t directory_enabled;  /* VectorIndex::simhash_directory_enabled(): seed from the SimHash directory */
+    uint32_t explicit_budgets;   /* != 0: the six budgets below instead of FilteredGraphBudgets::with_beam_percent (how the
+                                    reference's tests drive restricted_filter_aware_search); limits of this build:
+                                    vector_payloads <= 1024, sampled_seeds / directory_seeds <= 1024, bridge_rows <= 12 288 */
+    uint32_t ef_filtered, routing_rows, bridge_rows, vector_payloads, sampled_seeds, directory_seeds;
+} hvx_restricted_params;
+void hvx_restricted_params_default(hvx_restricted_params *, uint32_t k, uint32_t ef); /* AUTO, 150 %, directory on */
+/* RestrictedSearchStats (restricted.rs:147-166), per query.  The two *_multi_get_calls counters that depend on the
+ * storage engine's chunking (simhash_, vector_) are not reproduced. */
+typedef struct hvx_restricted_stats {
+    uint32_t strategy, termination; /* hvx_restricted_strategy that ran (EXACT / FILTERED; 0 = no plan: empty set, rejected query), hvx_restricted_termination */
+    uint64_t ef_filtered, directory_scan_calls, directory_rows, directory_decoded_bytes, directory_hits, simhash_row_requests,
+        companion_row_requests, routing_rows, bridge_rows, bridge_frontier_pushes, neighbor_multi_get_calls,
+        vector_payload_requests, vector_bytes, distance_computations;
+} hvx_restricted_stats;
+int hvx_search_restricted_batch_params(const hvx_index *, const float *queries, uint32_t b, const hvx_restricted_params *params,
+                                       const uint64_t *allowed_ids, const uint64_t *allowed_offsets /*[b+1] or NULL*/,
+                                       uint64_t n_allowed, uint64_t *out_ids /*[b][k]*/, float *out_scores, uint32_t *out_counts,
+                                       uint32_t *out_status /*nullable*/, hvx_restricted_stats *out_restricted_stats /*[b] nullable*/,
+                                       hvx_stats *stats /*nullable*/);
+
 /* k-way merge of per-shard results by Candidate order (model.rs:55-61); inputs in HBM, laid out
  * [g][b][k] as an all-gather over shards delivers them. */
 int hvx_merge_topk_device(const hvx_index *, uint32_t g, uint32_t b, uint32_t k, const uint64_t *d_ids,
@@ -349,6 +392,16 @@ int hvx_prefilter_search_batch(const hvx_index *, const hvx_csr *, const float *
                                const uint32_t *allowed_label_ids, uint32_t n_labels, uint32_t hub_degree,
                                uint32_t include_seeds, uint64_t *out_ids, float *out_scores, uint32_t *out_counts,
                                uint32_t *out_status /*nullable*/, uint64_t *out_candidates /*nullable*/, hvx_stats *stats);
+
+/* The fused call under the reference's execution plan: `params` as for hvx_search_restricted_batch_params (k, ef, strategy,
+ * beam, directory, budgets); the candidate bitmap, its compaction, the deterministic sample (ranks into the candidate
+ * population) and the membership bitmap of the walk all stay on the device. */
+int hvx_prefilter_search_batch_params(const hvx_index *, const hvx_csr *, const float *queries, uint32_t b,
+                                      const hvx_restricted_params *params, uint32_t mode, const uint64_t *seeds, uint32_t n_seeds,
+                                      uint32_t max_depth, uint32_t direction, const uint32_t *allowed_label_ids, uint32_t n_labels,
+                                      uint32_t hub_degree, uint32_t include_seeds, uint64_t *out_ids, float *out_scores,
+                                      uint32_t *out_counts, uint32_t *out_status /*nullable*/, uint64_t *out_candidates /*nullable*/,
+                                      hvx_restricted_stats *out_restricted_stats /*[b] nullable*/, hvx_stats *stats);
 
 /*
  * Batching operator: the reference calls ValidatedVectorReadIndex::search once per operator invocation

@@ -1,0 +1,235 @@
+"""The device's restricted_filter_aware_search (csrc/hvx_restricted_walk.hip) through the C ABI against the
+oracle's restatement (restricted.rs:837-1148) on the reference's own fixtures for this path
+(crates/db/tests/production_support/vector/restricted.rs, cited per test) and on built graphs: ids, score BITS, every
+RestrictedSearchStats counter and the termination reason must be equal; plus the planner (exact <= 256 ids / 4 MiB) and the
+fused graph-prefilter entry point.  The same fixtures run on the CPU against the kernel's host twin in test_walk_twin.py."""
+import numpy as np
+import pytest
+
+import walk_harness as wh
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("strategy", "termination", "ef_filtered") + wh.COUNTER_FIELDS[1:]
+
+
+@pytest.fixture(scope="module")
+def hv():
+    import pyhvx
+    pyhvx.lib()
+    return pyhvx
+
+
+def device_index(hv, oix, dim, metric, m=16, m0=32, given_hashes=False, max_batch=64):
+    gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=dim, metric=metric, m=m, m0=m0, max_batch=max_batch)
+    gix.set_simhash(hv.SimHashConfig.default(), node_hashes=oix.get_simhash() if given_hashes else None)
+    return gix
+
+
+def assert_equal(got_ids, got_sc, got_cnt, got_st, want):
+    rc, ids, scores, st = want
+    assert rc == 0, rc
+    assert got_ids[: got_cnt].tolist() == ids.tolist(), (got_ids[: got_cnt].tolist(), ids.tolist())
+    assert got_sc[: got_cnt].view(np.uint32).tolist() == scores.view(np.uint32).tolist()
+    for f in FIELDS:
+        assert got_st[f] == st[f], (f, got_st[f], st[f], got_st, st)
+
+
+def planned(orc, hv, oix, gix, queries, allowed, k, ef, directory=True, beam_percent=0):
+    """hvx_search_restricted_batch_params (AUTO) == orc_search_restricted, query by query"""
+    q = np.ascontiguousarray(queries, np.float32).reshape(-1, oix.dim)
+    rp = hv.RestrictedParams.new(k, ef, beam_percent=beam_percent or 150, directory=directory)
+    ids, sc, cnt, st, rs = gix.search_restricted_batch_params(q, rp, np.asarray(allowed, np.uint64))
+    assert not st.any()
+    wants = []
+    for i in range(q.shape[0]):
+        want = oix.search_restricted(q[i], k, ef, allowed, beam_percent=beam_percent, directory=directory)
+        assert_equal(ids[i], sc[i], int(cnt[i]), rs[i], want)
+        wants.append(want)
+    return wants
+
+
+def explicit(orc, hv, oix, gix, query, allowed, directory=False, **budgets):
+    k = budgets.pop("k")
+    q = np.ascontiguousarray(query, np.float32).reshape(1, -1)
+    rp = hv.RestrictedParams.new(k, max(k, 1), directory=directory, **budgets)
+    ids, sc, cnt, st, rs = gix.search_restricted_batch_params(q, rp, np.asarray(allowed, np.uint64))
+    want = oix.restricted_filter_aware_search(q[0], allowed, directory=directory, k=k, **budgets)
+    assert not st.any()
+    assert_equal(ids[0], sc[0], int(cnt[0]), rs[0], want)
+    return want
+
+
+def test_three_edge_gulf_all_metrics(orc, hv):
+    """tests :964-1045: three rejected bridge rows lead to the only member; exactly one payload is read"""
+    allowed = np.arange(1000, 1257, dtype=np.uint64)
+    for metric in (orc.COSINE, orc.L2SQ, orc.L1):
+        oix = wh.gulf(orc, metric)
+        gix = device_index(hv, oix, 2, metric)
+        (rc, ids, _, st), = planned(orc, hv, oix, gix, [1.0, 0.0], allowed, 10, 100, directory=False)
+        assert ids.tolist() == [1001] and st["strategy"] == orc.RESTRICTED_FILTERED and st["bridge_rows"] == 3
+        assert st["vector_payload_requests"] == 1 and st["distance_computations"] == 1 and st["directory_scan_calls"] == 0
+        planned(orc, hv, oix, gix, [1.0, 0.0], allowed, 10, 100, directory=True)
+
+
+def test_competing_bridges_and_every_termination_reason(orc, hv):
+    """tests :1047-1101 (the SimHash-closer bridge is expanded first), :1103-1224 (explicit budgets -> termination reason)"""
+    oix = wh.competing_bridges(orc)
+    gix = device_index(hv, oix, 2, orc.COSINE)
+    rc, got, _, st = explicit(orc, hv, oix, gix, [1.0, 0.0], np.arange(1001, 1258), k=1, ef_filtered=1, routing_rows=2, bridge_rows=2,
+                              vector_payloads=1, sampled_seeds=0, directory_seeds=0)
+    assert got.tolist() == [1001] and st["bridge_rows"] == 2 and st["bridge_frontier_pushes"] >= 3
+    oix = wh.gulf(orc, orc.COSINE)
+    gix = device_index(hv, oix, 2, orc.COSINE)
+    allowed = np.arange(1000, 1257)
+    for budgets, term in ((dict(ef_filtered=1, routing_rows=0, bridge_rows=1, vector_payloads=1), orc.TERM_ROUTING_BUDGET),
+                          (dict(ef_filtered=1, routing_rows=4, bridge_rows=0, vector_payloads=1), orc.TERM_BRIDGE_BUDGET),
+                          (dict(ef_filtered=1, routing_rows=4, bridge_rows=2, vector_payloads=0), orc.TERM_VECTOR_BUDGET)):
+        rc, got, _, st = explicit(orc, hv, oix, gix, [1.0, 0.0], allowed, k=1, sampled_seeds=0, directory_seeds=0, **budgets)
+        assert got.size == 0 and st["termination"] == term
+    explicit(orc, hv, oix, gix, [1.0, 0.0], np.arange(1, 258), k=1, ef_filtered=1, routing_rows=4, bridge_rows=2, vector_payloads=0,
+             sampled_seeds=0, directory_seeds=0)
+    explicit(orc, hv, oix, gix, [1.0, 0.0], np.arange(1, 258), k=2, ef_filtered=4, routing_rows=64, bridge_rows=32, vector_payloads=8,
+             sampled_seeds=4, directory_seeds=0)
+
+
+def test_directory_seeds_on_identical_rows(orc, hv):
+    """tests :935-961: >= 256 directory hits, only the 64 sampled seeds cost a SimHash read"""
+    oix = wh.identical_rows(orc)
+    gix = device_index(hv, oix, 8, orc.COSINE)
+    (rc, got, _, st), = planned(orc, hv, oix, gix, wh.circle8(7, 300), np.arange(1, 301), 10, 100)
+    assert st["directory_hits"] >= 256 and st["simhash_row_requests"] == 64 and st["directory_scan_calls"] % 8 == 0
+    planned(orc, hv, oix, gix, wh.circle8(7, 300), np.arange(1, 301), 10, 100, directory=False)
+    for ds in (0, 1, 17, 300):
+        explicit(orc, hv, oix, gix, wh.circle8(3, 300), np.arange(1, 301), directory=True, k=5, ef_filtered=20, routing_rows=320,
+                 bridge_rows=160, vector_payloads=100, sampled_seeds=8, directory_seeds=ds)
+
+
+def test_planner_and_the_circle_membership_fixture(orc, hv):
+    """tests :1226-1285: the small set (with duplicates and an unknown id) is answered exactly; allowed = ids not divisible by
+    3 takes the filtered walk with recall@10 >= 0.95 inside every budget -- and equals the oracle's walk"""
+    n, k = 512, 10
+    oix = wh.seed_circle(orc, n)
+    gix = device_index(hv, oix, 8, orc.COSINE, m=32, m0=64)
+    small = list(range(1, 65)) + [10, 10, 9999]
+    (rc, got, _, st), = planned(orc, hv, oix, gix, wh.circle8(17, n), small, k, 64)
+    assert st["strategy"] == orc.RESTRICTED_EXACT and all(i in set(small) for i in got.tolist())
+    allowed = [i for i in range(1, n + 1) if i % 3 != 0]
+    qs = np.stack([wh.circle8(qid, n) for qid in (1, 43, 87, 129, 211, 307, 401, 509)])
+    matched = 0
+    for qv, (rc, got, _, st) in zip(qs, planned(orc, hv, oix, gix, qs, allowed, k, 64)):
+        assert st["strategy"] == orc.RESTRICTED_FILTERED and all(i % 3 for i in got.tolist())
+        exact = set(oix.flat(qv, k, allowed=np.asarray(allowed, np.uint64))[1].tolist())
+        matched += sum(1 for i in got.tolist() if i in exact)
+        assert st["routing_rows"] <= st["ef_filtered"] * 16 and st["bridge_rows"] <= st["ef_filtered"] * 8
+        assert st["distance_computations"] == st["vector_payload_requests"] <= 800
+    assert matched / (k * len(qs)) >= 0.95
+    planned(orc, hv, oix, gix, wh.circle8(5, n), allowed + [9999, 10_000, 7, 7] + list(range(600, 900)), k, 64)
+    for pct in (100, 200, 400):
+        planned(orc, hv, oix, gix, wh.circle8(77, n), allowed, k, 64, beam_percent=pct)
+    # forcing the device's exact scan on the large set keeps today's behaviour (the exact answer)
+    rp = hv.RestrictedParams.new(k, 64, strategy=hv.RESTRICTED_EXACT)
+    ids, sc, cnt, st, rs = gix.search_restricted_batch_params(qs[:2], rp, np.asarray(allowed, np.uint64))
+    for i in range(2):
+        assert ids[i, : cnt[i]].tolist() == oix.flat(qs[i], k, allowed=np.asarray(allowed, np.uint64))[1].tolist()
+        assert rs[i]["strategy"] == hv.RESTRICTED_EXACT
+
+
+@pytest.mark.parametrize("metric_name,dim,n,m0,gap", [("L2SQ", 48, 1500, 32, False), ("COSINE", 64, 1200, 32, True), ("L1", 20, 900, 16, False),
+                                                      ("L2SQ", 32, 2500, 64, True), ("L2SQ", 768, 1500, 32, False)])
+def test_built_graphs_sparse_and_dense_filters(orc, hv, metric_name, dim, n, m0, gap):
+    metric = getattr(orc, metric_name)
+    oix, ids, vec = wh.random_graph(orc, n, dim, metric, seed=dim + n, m0=m0, id_gap=gap)
+    gix = device_index(hv, oix, dim, metric, m=m0 // 2, m0=m0, given_hashes=(dim == 20))
+    rng = np.random.default_rng(n)
+    for frac in (0.02, 0.2, 0.5, 0.9):
+        pick = ids[rng.random(n) < frac]
+        if pick.size <= 256:
+            pick = ids[: 300]
+        extra = np.array([int(ids[-1]) + 5, 2], np.uint64) if gap else np.zeros(0, np.uint64)
+        allowed = np.concatenate([pick, extra])
+        q = rng.standard_normal((4, dim)).astype(np.float32)
+        planned(orc, hv, oix, gix, q, allowed, 10, 100)
+        planned(orc, hv, oix, gix, q[:1], allowed, 10, 100, directory=False)
+    q = rng.standard_normal(dim).astype(np.float32)
+    allowed = ids[rng.random(n) < 0.1]
+    allowed = allowed if allowed.size > 8 else ids[:64]
+    seen_terms = set()
+    for budgets in (dict(ef_filtered=8, routing_rows=16, bridge_rows=8, vector_payloads=800),
+                    dict(ef_filtered=64, routing_rows=4096, bridge_rows=3, vector_payloads=800),
+                    dict(ef_filtered=64, routing_rows=4096, bridge_rows=2048, vector_payloads=20),
+                    dict(ef_filtered=600, routing_rows=9600, bridge_rows=4800, vector_payloads=800),
+                    dict(ef_filtered=16, routing_rows=256, bridge_rows=128, vector_payloads=800)):
+        want = explicit(orc, hv, oix, gix, q, allowed, directory=True, k=5, sampled_seeds=16, directory_seeds=32, **budgets)
+        seen_terms.add(want[3]["termination"])
+    assert len(seen_terms) >= 3, seen_terms
+
+
+def test_sparse_filter_is_bridging_heavy(orc, hv):
+    """3 % members of a 12 000-node graph: thousands of bridge pushes per query, bounded storage"""
+    oix, ids, vec = wh.random_graph(orc, 12000, 16, orc.L2SQ, seed=4242)
+    gix = device_index(hv, oix, 16, orc.L2SQ)
+    rng = np.random.default_rng(8)
+    allowed = ids[rng.random(ids.size) < 0.03]
+    q = rng.standard_normal((8, 16)).astype(np.float32)
+    wants = planned(orc, hv, oix, gix, q, allowed, 10, 100)
+    assert sum(w[3]["bridge_frontier_pushes"] for w in wants) > 8000
+    planned(orc, hv, oix, gix, q[:2], allowed, 10, 100, directory=False)
+    explicit(orc, hv, oix, gix, q[0], allowed, directory=True, k=10, ef_filtered=150, routing_rows=2400, bridge_rows=40, vector_payloads=800,
+             sampled_seeds=64, directory_seeds=256)
+    # the widest plan this build serves: ef 800 -> ef_filtered 1 200, 9 600 bridge rows in LDS
+    planned(orc, hv, oix, gix, q[:2], allowed, 10, 800)
+
+
+def test_validation_status_empty_sets_and_missing_simhash(orc, hv):
+    """restricted.rs:528-567 order of checks: candidate limit, empty set, k range, query validation; missing SimHash rows are an
+    InvariantViolation (missing_simhash_error)"""
+    oix, ids, vec = wh.random_graph(orc, 900, 32, orc.L2SQ, seed=5)
+    gix = device_index(hv, oix, 32, orc.L2SQ)
+    allowed = ids[: 600]
+    q = np.random.default_rng(1).standard_normal((3, 32)).astype(np.float32)
+    q[1, 3] = np.nan
+    rp = hv.RestrictedParams.new(10, 100)
+    out_ids, sc, cnt, st, rs = gix.search_restricted_batch_params(q, rp, allowed)
+    assert st.tolist() == [0, hv.ERR_NONFINITE, 0] and cnt[1] == 0 and rs[1]["strategy"] == 0
+    for i in (0, 2):
+        assert_equal(out_ids[i], sc[i], int(cnt[i]), rs[i], oix.search_restricted(q[i], 10, 100, allowed))
+    out_ids, sc, cnt, st, rs = gix.search_restricted_batch_params(q, rp, np.zeros(0, np.uint64))
+    assert cnt.tolist() == [0, 0, 0] and not st.any()          # Empty: no results before any validation
+    with pytest.raises(hv.HelixDbError) as e:
+        gix.search_restricted_batch_params(q[:1], hv.RestrictedParams.new(801, 801), ids)  # 801 of 900 candidates
+    assert e.value.status == hv.ERR_K_RANGE
+    bare = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=32, metric=orc.L2SQ)
+    with pytest.raises(hv.HelixDbError) as e:
+        bare.search_restricted_batch_params(q[:1], rp, allowed)
+    assert e.value.status == hv.ERR_INVARIANT
+    # per-query candidate lists: one planned search each
+    off = np.array([0, 300, 300, 600], np.uint64)
+    out_ids, sc, cnt, st, rs = gix.search_restricted_batch_params(q, rp, allowed, offsets=off)
+    assert rs[0]["strategy"] == hv.RESTRICTED_FILTERED and cnt[1] == 0 and rs[2]["strategy"] == hv.RESTRICTED_FILTERED
+    assert_equal(out_ids[2], sc[2], int(cnt[2]), rs[2], oix.search_restricted(q[2], 10, 100, allowed[300:]))
+
+
+def test_fused_prefilter_takes_the_planned_walk(orc, hv):
+    """config #3 shape: one expand hop produces the candidate bitmap on the device; the planner then walks (or scans exactly) --
+    equal to the oracle over the hop's target set, incl. node ids that hold no vector (the sample ranks count them)"""
+    n, dim = 4000, 32
+    oix, ids, vec = wh.random_graph(orc, n, dim, orc.L2SQ, seed=77, id_gap=True)  # ids 1, 4, 7, ...: two of three graph nodes hold no vector
+    gix = device_index(hv, oix, dim, orc.L2SQ)
+    n_nodes = int(ids[-1]) + 3
+    rng = np.random.default_rng(2)
+    src = np.arange(0, 1500, dtype=np.uint64)
+    tgt = rng.integers(1, n_nodes, src.size).astype(np.uint64)
+    offs = np.zeros(n_nodes + 1, np.uint64)
+    offs[1: src.size + 1] = np.arange(1, src.size + 1)
+    offs[src.size + 1:] = src.size
+    g = hv.Graph(n_nodes, offs, tgt)
+    q = rng.standard_normal((3, dim)).astype(np.float32)
+    for seeds in (src, src[:400]):
+        allowed = np.unique(tgt[: seeds.size])
+        rp = hv.RestrictedParams.new(10, 100)
+        out_ids, sc, cnt, ncand, rs, _ = gix.prefilter_search_batch_params(g, q, rp, seeds)
+        assert ncand == allowed.size
+        for i in range(3):
+            assert_equal(out_ids[i], sc[i], int(cnt[i]), rs[i], oix.search_restricted(q[i], 10, 100, allowed))
+    assert rs[0]["strategy"] == hv.RESTRICTED_FILTERED

@@ -79,6 +79,9 @@ def parse():
     ap.add_argument("--c4-rows", type=int, default=1_250_000, help="config #4 per-GPU shard (10M / 8)")
     ap.add_argument("--builder", default="device", choices=["device", "bulk"], help="how the benchmark graph is built")
     ap.add_argument("--build-batch", type=int, default=2048, help="largest insertion batch of the device build")
+    ap.add_argument("--query-batches", type=int, default=0,
+                    help="distinct query batches the timed steps cycle through (0 = steps + warmup, at most 64): no two steps in flight "
+                         "gather the same rows")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "traffic_latest.json"))
     return ap.parse_args()
 
@@ -161,6 +164,7 @@ class LaneSet:
         self.b, self.k, self.dev, self.occ, self.residency = b, k, dev, occ, None
         self.groups = None   # C-ABI shard groups (in-library RCCL exchange), one per lane
         self.merged = None
+        self.last_q = [None] * len(self.handles)  # the query batch of every lane's last step (what its buffers hold the answer to)
 
     def use_shard_groups(self, hv, dist, rank, world):
         """One hvx_shard_group (own RCCL communicator) per lane; the 128-byte unique ids travel over torch.distributed."""
@@ -176,6 +180,7 @@ class LaneSet:
 
     def step(self, i, q, ef):
         l = i % len(self.handles)
+        self.last_q[l] = q
         if self.groups:  # search -> ncclAllGather -> merge inside the library, one C-ABI call (hvx_shard_group_*)
             m = self.merged[l]
             self.groups[l].search_batch_device(q, self.k, ef, m[0], m[1], m[2])
@@ -200,11 +205,20 @@ class LaneSet:
             h.close()
 
 
-def timed_steps(ls, q, ef, steps, warmup, barrier):
-    """W untimed + K timed steps; returns (host seconds of the K steps, event span ms of the K steps, per-kernel ms)."""
+def query_batches(args, b):
+    """how many distinct query batches a timed run cycles through"""
+    nb = args.query_batches or (args.steps + args.warmup)
+    return max(1, min(nb, 64))
+
+
+def timed_steps(ls, qs, ef, steps, warmup, barrier):
+    """W untimed + K timed steps over DISTINCT query batches (qs[j], cycled): steps in flight on different lanes never gather
+    the same rows.  Returns (host seconds of the K steps, event span ms of the K steps, per-kernel ms); ls.last_q[l] = the
+    batch lane l answered last."""
     L = len(ls.handles)
+    nb = len(qs)
     for i in range(warmup):
-        ls.step(i, q, ef)
+        ls.step(i, qs[i % nb], ef)
     ls.sync()
     barrier()
     for h in ls.handles:
@@ -216,7 +230,7 @@ def timed_steps(ls, q, ef, steps, warmup, barrier):
         s.wait_event(e0)
     t_start = time.perf_counter()
     for i in range(steps):
-        ls.step(i, q, ef)
+        ls.step(i, qs[(warmup + i) % nb], ef)
     for l, s in enumerate(ls.streams):
         ends[l].record(s)
     ls.sync()
@@ -254,7 +268,10 @@ def pct(a, p):
 # ------------------------------------------------------------------------------------------------------------
 def hnsw_leg(hv, synth, args, dev, dataset, n, dim, b, k, ef, dtype_name="f32", steps=None, keep=False, seed=None):
     t0 = time.time()
-    x, q = synth.corpus(dataset, n, dim, b, args.seed if seed is None else seed, dev)
+    steps = steps or args.steps
+    nbq = max(1, min(args.query_batches or (steps + args.warmup), 64))
+    x, q_all = synth.corpus(dataset, n, dim, b * nbq, args.seed if seed is None else seed, dev)
+    qs = [q_all[j * b:(j + 1) * b] for j in range(nbq)]
     bf16 = dtype_name == "bf16"
     if bf16:  # the index holds the rounded values; graph, truth and oracle see exactly those
         x = x.to(torch.bfloat16).to(torch.float32)
@@ -270,8 +287,8 @@ def hnsw_leg(hv, synth, args, dev, dataset, n, dim, b, k, ef, dtype_name="f32", 
     lanes = max(1, args.lanes)
     occ = args.occupancy or (2 if lanes > 1 else 1)
     ls = LaneSet(ix, lanes, occ, b, k, dev)
-    steps = steps or args.steps
-    elapsed, span, kms = timed_steps(ls, q, ef, steps, args.warmup, lambda: None)
+    elapsed, span, kms = timed_steps(ls, qs, ef, steps, args.warmup, lambda: None)
+    q = ls.last_q[0]  # what lane 0's buffers answer
     f = out_buffers(b, k, dev)
     ix_truth.flat_search_batch_device(q, k, *f[:4])
     torch.cuda.synchronize()
@@ -281,6 +298,7 @@ def hnsw_leg(hv, synth, args, dev, dataset, n, dim, b, k, ef, dtype_name="f32", 
     alg = hnsw_alg_bytes(qst, dim, 2 if bf16 else 4, b)
     per_step = span / steps
     res = {"dataset": dataset, "rows": n, "dim": dim, "dtype": dtype_name, "ef_search": ef, "k": k, "batch": b, "lanes": lanes,
+           "distinct_query_batches": nbq,
            "queries_per_simd": occ, "qps": round(b * steps / elapsed, 1), "ms_per_step": round(elapsed * 1e3 / steps, 4),
            "recall_at_10": round(recall, 4), "clears_recall_0.95": bool(recall >= 0.95),
            "distance_computations_per_query": round(float(qst[:, 3].mean()), 1), "expansion_steps_per_query": round(float(qst[:, 0].mean()), 1),
@@ -294,7 +312,7 @@ def hnsw_leg(hv, synth, args, dev, dataset, n, dim, b, k, ef, dtype_name="f32", 
     ix.close()
     if ix_truth is not ix:
         ix_truth.close()
-    del x, q
+    del x, q, q_all, qs
     torch.cuda.empty_cache()
     return res, None
 
@@ -302,53 +320,131 @@ def hnsw_leg(hv, synth, args, dev, dataset, n, dim, b, k, ef, dtype_name="f32", 
 # ------------------------------------------------------------------------------------------------------------
 # extra legs (N = 1 only)
 # ------------------------------------------------------------------------------------------------------------
-def leg_config3(hv, synth, orc, dev, k=10, nq=32, rounds=5):
+def leg_config3(hv, synth, orc, args, dev, k=10, nq=32, rounds=5):
     """configs[2] stand-in: 1M x 1536 f32 Euclidean, node i -> (i + N/2) mod N, equality groups of
-    100 / 1 000 / 10 000 / 100 000 sources (index_lifecycle_scale.rs:592-613,1769-1776), 32 queries, fused hop + restricted kNN."""
-    n, dim = 1_000_000, 1536
+    100 / 1 000 / 10 000 / 100 000 sources (index_lifecycle_scale.rs:592-613,1769-1776), 32 queries, fused hop + restricted kNN,
+    HNSW M=16 / M0=32 / efC=200, ef_search 100, filtered beam 150 % (index_lifecycle_scale.rs:1992).  Both strategies:
+    `planned` = the reference's execution plan (exact scan <= 256 ids, the filter-aware walk above: what the reference runs,
+    gate distance_computations <= 800 per query, :1924-1927) and `exact` = the device's exact gathered scan of every candidate."""
+    n, dim, ef = 1_000_000, 1536, 100
     x, _ = synth.corpus("clustered", n, dim, 1, 20260923, dev)
-    ix = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=hv.EUCLIDEAN, node_ids=np.arange(n, dtype=np.uint64), vectors=x,
-                                             l0_offsets=np.zeros(n + 1, np.uint64), l0_neighbors=np.zeros(0, np.uint64),
-                                             device=dev.index, max_batch=nq)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    lv = synth.draw_levels(n, 16, 11)
+    ix, bst = hv.ValidatedVectorReadIndex.build(dim=dim, metric=hv.EUCLIDEAN, node_ids=np.arange(n, dtype=np.uint64), vectors=x, levels=lv,
+                                                m=16, m0=32, ef_construction=200, max_batch=args.build_batch, batch_divisor=32,
+                                                device=dev.index, search_max_batch=nq)
+    ix.sync()
+    t_build = time.time() - t0
+    ix.set_simhash()   # SimHash rows + (on first walk) the SimHash directory
     off = np.arange(n + 1, dtype=np.uint64)
     tgt = ((np.arange(n, dtype=np.uint64) + np.uint64(n // 2)) % np.uint64(n)).astype(np.uint64)
     g = hv.Graph(n, off, tgt)
     qrows = [(int(n * 0.8) + j * (n // 10) // nq) % n for j in range(nq)]
     q = x[qrows].cpu().numpy().copy()
+    # the oracle over the same rows, graph and SimHash rows: the walk's checker (a sample of queries per group)
+    t0 = time.time()
+    gg = ix.export_graph()
+    oix = orc.Index(dim, orc.L2SQ, kernel=orc.K_AVX_FMA_HW, m=16, m0=32)
+    assert oix.seed(np.arange(n, dtype=np.uint64), x.cpu().numpy(), gg["l0_offsets"], gg["l0_neighbors"], gg["level"], gg["up_offsets"],
+                    gg["up_neighbors"], entry_point=gg["entry_point"], max_layer=gg["max_layer"]) == orc.OK
+    oix.set_simhash(42, node_hashes=ix.get_simhash())
+    t_oracle = time.time() - t0
     groups = []
     ok_all = True
+    fields = ("termination", "directory_scan_calls", "directory_rows", "directory_hits", "simhash_row_requests", "routing_rows", "bridge_rows",
+              "bridge_frontier_pushes", "vector_payload_requests", "vector_bytes", "distance_computations")
     for size, start in ((100, 0), (1000, 100), (10000, 1100), (100000, 11100)):
         src = np.arange(start, start + size, dtype=np.uint64)
+        lo = start + n // 2
+        allowed = np.arange(lo, lo + size, dtype=np.uint64)
+        # ---- exact: every candidate row scanned on the device
         lat, kern = [], []
         for r in range(rounds + 1):
             t1 = time.perf_counter()
-            fid, fsc, fcnt, ncand, fst = ix.prefilter_search_batch(g, q, hv.SearchParams(k), src, direction=hv.DIR_OUT)
+            fid, fsc, fcnt, ncand, fst = ix.prefilter_search_batch(g, q, hv.SearchParams(k).with_ef(ef), src, direction=hv.DIR_OUT)
             if r:
                 lat.append(time.perf_counter() - t1)
                 kern.append(fst["device_ms"])
         assert ncand == size
-        lo = start + n // 2
         rows = x[lo:lo + size].cpu().numpy()
         ok = True
         for qi in range(0, nq, 8):  # a sample of the batch against the oracle's exact scan of the candidate rows
             rc, oid, osc = orc.flat_matrix(orc.L2SQ, rows, q[qi], k, kernel=orc.K_AVX_FMA_HW)
             ok &= (fid[qi, :fcnt[qi]] - np.uint64(lo)).tolist() == oid.tolist()
             ok &= fsc[qi, :fcnt[qi]].view(np.uint32).tolist() == osc.view(np.uint32).tolist()
-        ok_all &= bool(ok)
         ms, kms = float(np.median(lat)) * 1e3, float(np.median(kern))
         alg = size * dim * 4 + nq * dim * 4  # every candidate row is needed once per batch (shared candidate set) + the queries
-        groups.append({"candidates": size, "end_to_end_ms_per_batch": round(ms, 3), "us_per_query": round(ms * 1e3 / nq, 1),
-                       "scan_kernels_ms": round(kms, 3), "hbm_gbs_scan": round(alg / (kms * 1e-3) / 1e9, 1),
-                       "reference_plan": hv.restricted_execution_plan(size, dim, hv.SearchParams.new(k)), "oracle_bit_exact_sample": bool(ok)})
+        exact = {"end_to_end_ms_per_batch": round(ms, 3), "us_per_query": round(ms * 1e3 / nq, 1), "scan_kernels_ms": round(kms, 3),
+                 "hbm_gbs_scan": round(alg / (kms * 1e-3) / 1e9, 1), "distance_computations_per_query": size,
+                 "scan_path_flags": ix.last_scan_path(), "oracle_bit_exact_sample": bool(ok)}
+        # ---- planned: restricted_execution_plan (exact <= 256 ids / 4 MiB, else the filter-aware walk)
+        rp = hv.RestrictedParams.new(k, ef)
+        lat, kern = [], []
+        for r in range(rounds + 1):
+            t1 = time.perf_counter()
+            pid, psc, pcnt, ncand, prs, pst = ix.prefilter_search_batch_params(g, q, rp, src, direction=hv.DIR_OUT)
+            if r:
+                lat.append(time.perf_counter() - t1)
+                kern.append(pst["device_ms"])
+        pms, pkms = float(np.median(lat)) * 1e3, float(np.median(kern))
+        walked = prs[0]["strategy"] == hv.RESTRICTED_FILTERED
+        pok = True
+        for qi in range(0, nq, 8):  # ids, score bits, every RestrictedSearchStats counter and the termination vs the oracle's walk
+            rc, oid, osc, ost = oix.search_restricted(q[qi], k, ef, allowed)
+            pok &= rc == orc.OK and pid[qi, :pcnt[qi]].tolist() == oid.tolist() and psc[qi, :pcnt[qi]].view(np.uint32).tolist() == osc.view(np.uint32).tolist()
+            pok &= prs[qi]["strategy"] == ost["strategy"] and all(prs[qi][f] == ost[f] for f in fields)
+        rec = sum(len(set(pid[i, :pcnt[i]].tolist()) & set(fid[i, :fcnt[i]].tolist())) for i in range(nq)) / float(nq * k)
+        dc = np.array([r_["distance_computations"] for r_ in prs]) if walked else np.full(nq, size)
+        terms = {}
+        for r_ in prs:
+            terms[str(r_["termination"])] = terms.get(str(r_["termination"]), 0) + 1
+        # SURVEY 8(d) "filtered graph": vector payloads x dim x 4 + routing rows x degree x 4 (+ the query)
+        walk_alg = int(sum(r_["vector_bytes"] + r_["routing_rows"] * 32 * 4 for r_ in prs)) + nq * dim * 4 if walked else alg
+        planned = {"strategy": "filtered_graph" if walked else "exact", "end_to_end_ms_per_batch": round(pms, 3), "us_per_query": round(pms * 1e3 / nq, 1),
+                   "search_kernel_ms": round(pkms, 3), "recall_at_10_vs_exact": round(rec, 4),
+                   "distance_computations_per_query": {"mean": round(float(dc.mean()), 1), "max": int(dc.max())},
+                   "reference_gate_distance_computations_le_800": bool(dc.max() <= 800),
+                   "directory_rows_max": int(max(r_["directory_rows"] for r_ in prs)), "routing_rows_mean": round(float(np.mean([r_["routing_rows"] for r_ in prs])), 1),
+                   "bridge_rows_mean": round(float(np.mean([r_["bridge_rows"] for r_ in prs])), 1),
+                   "terminations": terms, "algorithmic_bytes_per_batch": walk_alg, "hbm_gbs": round(walk_alg / (pkms * 1e-3) / 1e9, 1),
+                   "oracle_equal_sample": {"queries": len(range(0, nq, 8)), "ids_bits_counters_termination_equal": bool(pok)}}
+        if size == 100000 and walked:
+            # the same walk with the chip filled: 1 024 queries (one workgroup each) over the same candidate set
+            qb = x[torch.randint(0, n, (1024,), generator=torch.Generator().manual_seed(5)).to(dev)].cpu().numpy()
+            bk = []
+            for r in range(3):
+                bid, bsc, bcnt, _, brs, bst = ix.prefilter_search_batch_params(g, qb, rp, src, direction=hv.DIR_OUT)
+                if r:
+                    bk.append(bst["device_ms"])
+            bbytes = int(sum(r_["vector_bytes"] + r_["routing_rows"] * 32 * 4 for r_ in brs)) + 1024 * dim * 4
+            bms = float(np.mean(bk))
+            planned["batch_1024"] = {"search_kernel_ms": round(bms, 3), "queries_per_s_kernel": round(1024 / (bms * 1e-3), 1),
+                                     "algorithmic_bytes_per_batch": bbytes, "hbm_gbs": round(bbytes / (bms * 1e-3) / 1e9, 1),
+                                     "frac_of_hbm_peak": round(bbytes / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                     "distance_computations_per_query_max": int(max(r_["distance_computations"] for r_ in brs))}
+        ok_all &= bool(ok) and bool(pok)
+        groups.append({"candidates": size, "reference_plan": hv.restricted_execution_plan(size, dim, hv.SearchParams.new(k)), "planned": planned,
+                       "exact": exact})
     big = groups[-1]
-    out = {"workload": f"configs[2] stand-in (DBpedia-1M fbin not fetchable): {n}x{dim} f32 clustered synthetic, Euclidean, benchmark topology "
-                       f"i -> i+N/2, one-hop where_() group -> restricted kNN k={k}, {nq} queries per batch, fused hvx_prefilter_search_batch",
-           "strategy": "exact device scan of the candidate rows (recall 1.0 by construction; reference gate 0.92)", "groups": groups,
-           "roofline": {"bound": "hbm", "achieved": big["hbm_gbs_scan"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(big["hbm_gbs_scan"] / HBM_PEAK_GBS, 4),
-                        "note": "100 000-candidate group: algorithmic bytes = candidates x dim x 4 (each row once per batch) / scan-kernel time; "
+    out = {"workload": f"configs[2] stand-in (DBpedia-1M fbin not fetchable): {n}x{dim} f32 clustered synthetic, Euclidean, HNSW M=16/M0=32/efC=200 "
+                       f"(device build, {t_build:.1f} s), benchmark topology i -> i+N/2, one-hop where_() group -> restricted kNN k={k} ef={ef}, "
+                       f"{nq} queries per batch, fused hvx_prefilter_search_batch[_params]",
+           "strategies": "planned = the reference's plan (restricted.rs:426-453: exact <= 256 ids, filter-aware walk above, 150 % beam); "
+                         "exact = the device's exact gathered scan of every candidate row (recall 1.0 by construction)",
+           "groups": groups,
+           "roofline": {"bound": "hbm", "kernel": "restricted exact scan, 100 000-candidate group", "achieved": big["exact"]["hbm_gbs_scan"],
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(big["exact"]["hbm_gbs_scan"] / HBM_PEAK_GBS, 4),
+                        "note": "algorithmic bytes = candidates x dim x 4 (each row once per batch) / scan-kernel time; "
                                 "the small groups are launch-latency bound (a 100-row scan is 0.6 MB)"},
-           "reference_gates": {"recall_at_10": 0.92, "vector_increment_p95_ms": 15, "end_to_end_p95_ms": 50}, "parity_sample_ok": ok_all}
+           "walk_roofline": {"bound": "hbm", "kernel": "restricted_walk_kernel, 100 000-candidate group", "achieved": big["planned"]["hbm_gbs"],
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(big["planned"]["hbm_gbs"] / HBM_PEAK_GBS, 4),
+                             "note": "a 32-query batch runs 32 workgroups (of 256 CUs): a dependent walk per query, not a streaming kernel; "
+                                     "bytes = vector payloads x (4 + dim x 4) + routing rows x 128 B"},
+           "reference_gates": {"recall_at_10": 0.92, "distance_computations_per_query_max": 800, "directory_rows_max": 65536,
+                               "vector_increment_p95_ms": 15, "end_to_end_p95_ms": 50},
+           "oracle_seed_seconds": round(t_oracle, 1), "parity_sample_ok": ok_all}
+    del oix
     ix.close()
     del x
     torch.cuda.empty_cache()
@@ -408,6 +504,31 @@ def leg_config5(hv, synth, orc, dev, rows, b=4096, k=10, dim=1536):
     for qi in range(qh.shape[0]):
         rc, oid, osc = orc.flat_matrix(orc.L2SQ, deq, qh[qi], k, kernel=orc.K_AVX_FMA_HW)
         ok &= rid[qi, :rcnt[qi]].tolist() == sub[oid].tolist() and rsc[qi, :rcnt[qi]].view(np.uint32).tolist() == osc.view(np.uint32).tolist()
+    # the TIMED full scan itself against the oracle -- the first `fq` queries over ALL stored (dequantised) rows,
+    # one 1M-row chunk at a time (torch twin of the import's quantiser, checked against the numpy twin), per-chunk top-k by the
+    # oracle's exact scan, merged by Candidate order (score, id) (model.rs:55-61)
+    import concurrent.futures
+    fq = 8
+    qf = q[:fq].cpu().numpy()
+    t_full = time.time()
+    probe = x[:4096]
+    twin_ok = bool((quantize_fp8_rows_torch(probe).cpu().numpy() == synth.quantize_fp8_rows(probe.cpu().numpy())).all())
+    merged = [(np.zeros(0, np.uint32), np.zeros(0, np.uint64)) for _ in range(fq)]
+    with concurrent.futures.ThreadPoolExecutor(max_workers=fq) as pool:
+        for c0 in range(0, rows, 1 << 20):
+            deq_c = quantize_fp8_rows_torch(x[c0:c0 + (1 << 20)]).cpu().numpy()
+            parts = list(pool.map(lambda qi: orc.flat_matrix(orc.L2SQ, deq_c, qf[qi], k, kernel=orc.K_AVX_FMA_HW), range(fq)))
+            for qi, (rc, oid, osc) in enumerate(parts):
+                assert rc == orc.OK
+                bits = np.concatenate([merged[qi][0], osc.view(np.uint32)])
+                ids_ = np.concatenate([merged[qi][1], oid + np.uint64(c0)])
+                order = np.lexsort((ids_, bits))[:k]   # non-negative f32 scores order like their bit patterns
+                merged[qi] = (bits[order], ids_[order])
+            del deq_c
+    got_ids = f[0][:fq].cpu().numpy().astype(np.uint64)
+    got_bits = f[1][:fq].cpu().numpy().view(np.uint32)
+    full_ok = twin_ok and all(got_ids[qi].tolist() == merged[qi][1].tolist() and got_bits[qi].tolist() == merged[qi][0].tolist() for qi in range(fq))
+    t_full = time.time() - t_full
     useful = 2.0 * b * rows * dim
     out = {"workload": f"configs[4] per-GPU shard: exact scan, {rows}x{dim} fp8-e4m3 rows (+ f32 row scale), batch {b}, k={k}, squared-L2; "
                        f"the full config is 100M rows over 8 GPUs = 12.5M per GPU",
@@ -419,13 +540,37 @@ def leg_config5(hv, synth, orc, dev, rows, b=4096, k=10, dim=1536):
                                 "the MX-scaled K=64 form would need the f32 query in two fp8 pieces: the same matrix-core time), so the bf16 dense peak applies "
                                 "(5 PFLOP/s would be the fp8-MFMA peak: frac_of_fp8_peak below)",
                         "frac_of_fp8_peak": round(useful / ms / 1e9 / 5000.0, 4)},
-           "hbm_bytes_min_per_batch": rows * dim * ((b + 127) // 128), "recall_at_k_vs_f32_rows": round(recall, 4),
+           "hbm_bytes_per_batch": rows * dim, "hbm_bytes_per_batch_note": "SURVEY 8(d): the fp8 codes stream once per batch (query tiles of a "
+           "super-tile share the row tile in L2): 19.2 GB at 12.5M x 1536",
+           "recall_at_k_vs_f32_rows": round(recall, 4),
            "exactness": "certificate passed for every query (the call fails otherwise)", "oracle_bit_exact_sample": bool(ok),
+           "oracle_bit_exact_full_scan": bool(full_ok),
+           "oracle_full_scan_check": {"queries": fq, "rows": rows, "what": "ids and score bits of the TIMED scan's output == the oracle's exact scan over every "
+                                      "dequantised row (1M-row chunks merged by (score, id))", "quantiser_twin_equal": twin_ok, "seconds": round(t_full, 1)},
            "corpus_and_import_seconds": round(t_imp, 1)}
     ix.close()
     del x, q
     torch.cuda.empty_cache()
     return out
+
+
+def quantize_fp8_rows_torch(x):
+    """torch twin of pyhvx.synth.quantize_fp8_rows (itself the numpy twin of quantize_fp8_kernel, csrc/hvx_dtype.hip): the f32
+    values an fp8-e4m3fn index stores for rows x, computed on the device so that a 12.5M-row shard can be dequantised for the
+    oracle in seconds.  Same IEEE operations in the same order; bench.py checks it against the numpy twin on a sample."""
+    amax = x.abs().amax(dim=1)
+    scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    y = x / scale[:, None]
+    a = y.abs()
+    a = torch.where(a < 464.0, a, torch.full_like(a, 448.0))
+    _, ex = torch.frexp(a)
+    e = ex.to(torch.int32) - 1
+    e = torch.where((a == 0) | (e < -6), torch.full_like(e, -6), e)
+    step = torch.ldexp(torch.ones_like(a), e - 3)
+    v = torch.round(a / step) * step
+    v = torch.clamp(v, max=448.0)
+    v = torch.where(y < 0, -v, v)
+    return (scale[:, None] * v).to(torch.float32)
 
 
 def leg_graph_equivalence(hv, synth, args, dev):
@@ -546,15 +691,17 @@ def main():
         """One sharded (or single-GPU) measurement over a corpus of n_total rows; returns (result dict, state)."""
         t0 = time.time()
         n = n_total if replica else n_total // world
-        nq_total = b * world if replica else b
+        nbq = query_batches(args, b)
+        nq_total = (b * world if replica else b) * nbq
         # every rank draws the same global corpus from the same seed and keeps its id-range shard
-        xg, q = synth.corpus(args.dataset, n_total, dim, nq_total, args.seed, dev)
+        xg, q_all = synth.corpus(args.dataset, n_total, dim, nq_total, args.seed, dev)
         if cosine:  # unit rows: the L2-built graph is the cosine graph (same neighbour order)
             xg = torch.nn.functional.normalize(xg, dim=1)
-            q = torch.nn.functional.normalize(q, dim=1)
+            q_all = torch.nn.functional.normalize(q_all, dim=1)
         id_lo = 0 if replica else rank * n
-        if replica:
-            q = q[rank * b:(rank + 1) * b].contiguous()
+        if replica:  # every replica answers its own batches
+            q_all = q_all.view(nbq, world, b, dim)[:, rank].contiguous().view(nbq * b, dim)
+        qs = [q_all[j * b:(j + 1) * b] for j in range(nbq)]
         x = xg[id_lo:id_lo + n].contiguous()
         del xg
         if bf16:
@@ -595,7 +742,8 @@ def main():
                     gq.close()
                 ls.groups = None
                 exchange = "torch.distributed all_gather_into_tensor + hvx_merge_topk_packed_device"
-        elapsed, span, kms = timed_steps(ls, q, ef, args.steps, args.warmup, barrier)
+        elapsed, span, kms = timed_steps(ls, qs, ef, args.steps, args.warmup, barrier)
+        q = ls.last_q[0]  # lane 0's last batch: recall, counters and the oracle check below refer to it
         if world > 1:
             t = torch.tensor([elapsed, span], dtype=torch.float64, device="cpu" if SHARED_GPU else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -626,7 +774,7 @@ def main():
         alg = hnsw_alg_bytes(qst, dim, 2 if bf16 else 4, b)
         per_step = span / args.steps
         res = dict(qps=qps, ms_per_step=elapsed * 1e3 / args.steps, recall=recall, alg=alg, per_step=per_step, kms=kms, qst=qst, n=n,
-                   n_total=n_total, flat_ms=flat_stats["device_ms"], graph=ginfo, exchange=exchange)
+                   n_total=n_total, flat_ms=flat_stats["device_ms"], graph=ginfo, exchange=exchange, nbq=nbq)
         state = dict(ix=ix, ix_truth=ix_truth, ls=ls, x=x, q=q, g=g, truth=f, id_lo=id_lo)
         return res, state
 
@@ -660,6 +808,7 @@ def main():
                 "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
                 "traffic_source": "builder-side rocprofv3 --pmc pass of this command (profiles/traffic_latest.json), NOT measured in this run",
                 "algorithmic_bytes_per_launch": int(res["alg"]),
+                "algorithmic_bytes_of": "the per-query counters of lane 0's last batch (every timed step answers a different batch of the same distribution)",
                 "kernel_ms": round(res["per_step"], 4),
                 "kernel_ms_definition": f"HIP-event span of the {args.steps} timed search kernels on their {lanes} lane streams / {args.steps} "
                                         f"(consecutive batches overlap on the device); kernel_ms_each = mean duration of one kernel "
@@ -682,7 +831,7 @@ def main():
                                f"batch={b} queries, {'cosine' if cosine else 'squared-L2'}, strict-exhaustive beam (bit-exact vs reference CPU path), "
                                f"steps issued round-robin on {lanes} execution lanes",
                    "dataset": args.dataset, "rows_per_gpu": n, "rows_total": res["n_total"], "dim": dim, "batch": b, "k": k,
-                   "ef_search": ef, "lanes": lanes,
+                   "ef_search": ef, "lanes": lanes, "distinct_query_batches": res["nbq"],
                    "exchange": res["exchange"],
                    "parallelism": ("1 GPU" if world == 1 else f"{world} replicas, one query batch each" if replica
                                    else f"id-range shards x{world} + all-gather top-k merge")},
@@ -835,11 +984,16 @@ def main():
                 "host": f"{os.cpu_count()} logical CPUs"}
             if not args.no_verify:
                 same = True
-                for l in range(lanes):  # every lane's last batch
-                    g_ids_h, g_sc_h = ls.bufs[l][0].cpu().numpy().astype(np.uint64), ls.bufs[l][1].cpu().numpy()
-                    same &= bool((g_ids_h == o_ids).all()) and bool((g_sc_h.view(np.uint32) == o_sc.view(np.uint32)).all())
                 o_dc = sum(s["distance_computations"] for s in o_st)
-                out["parity"] = {"queries": b, "lanes_checked": lanes, "ids_equal_oracle": same, "score_bits_equal_oracle": same,
+                for l in range(lanes):  # every lane's last batch -- each lane answered a different one
+                    if l == 0 or ls.last_q[l] is None:
+                        l_ids, l_sc = o_ids, o_sc
+                    else:
+                        rc, l_ids, l_sc, _, _ = oix.search_batch(ls.last_q[l].cpu().numpy(), k, ef, threads=threads)
+                        assert rc == orc.OK
+                    g_ids_h, g_sc_h = ls.bufs[l][0].cpu().numpy().astype(np.uint64), ls.bufs[l][1].cpu().numpy()
+                    same &= bool((g_ids_h == l_ids).all()) and bool((g_sc_h.view(np.uint32) == l_sc.view(np.uint32)).all())
+                out["parity"] = {"queries": b * lanes, "lanes_checked": lanes, "distinct_batches_checked": lanes, "ids_equal_oracle": same, "score_bits_equal_oracle": same,
                                  "distance_computations_equal": bool(o_dc == int(qst[:, 3].sum()))}
                 assert same, "GPU HNSW results differ from the CPU oracle"
             del oix
@@ -867,7 +1021,7 @@ def main():
             return r
 
         if "config3" not in skip:
-            out["config3_prefilter"] = guarded("config3", lambda: leg_config3(hv, synth, orc, dev))
+            out["config3_prefilter"] = guarded("config3", lambda: leg_config3(hv, synth, orc, args, dev))
         if "config4" not in skip:
             def c4():
                 r, st = hnsw_leg(hv, synth, args, dev, "embedding", args.c4_rows, dim, b, k, ef, dtype_name="bf16", steps=30, keep=True)

@@ -123,6 +123,19 @@ extern "C" int hvx_index_set_occupancy(hvx_index *ix, uint32_t queries_per_simd)
     return HVX_OK;
 }
 
+extern "C" int hvx_index_set_option(hvx_index *ix, uint32_t option, uint32_t value) {
+    if (!ix) return fail(HVX_ERR_INVARIANT, "null index");
+    if (option >= HVX_OPT_COUNT) return fail(HVX_ERR_INVARIANT, "unknown option %u", option);
+    if (option == HVX_OPT_WAVE_LOG2CAP && value != 0 && (value < 7 || value > 15)) return fail(HVX_ERR_K_RANGE, "visited-table size must be 2^7 .. 2^15 slots");
+    if (option == HVX_OPT_FLAT_FIRST_CHUNK && value != 0 && value < 1024) return fail(HVX_ERR_K_RANGE, "the first chunk holds at least 1024 rows");
+    if (option == HVX_OPT_FLAT_TILE_BUILD && value > 1) return fail(HVX_ERR_K_RANGE, "tile build is 0 (two 256-thread workgroups per CU) or 1 (one 512-thread workgroup)");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    ix->opt[option] = value;
+    return HVX_OK;
+}
+
+extern "C" uint32_t hvx_index_last_scan_path(const hvx_index *ix) { return ix ? ix->last_scan_path : 0u; }
+
 extern "C" void *hvx_index_stream(const hvx_index *ix) { return ix ? (void *)ix->stream : nullptr; }
 
 extern "C" int hvx_index_set_stream(hvx_index *ix, void *hip_stream) {
@@ -426,6 +439,7 @@ extern "C" int hvx_index_fork(const hvx_index *parent, hvx_index **out) {
     ix->ids_p = src->ids_p;
     ix->contiguous = src->contiguous;
     ix->occupancy = src->occupancy;
+    memcpy(ix->opt, src->opt, sizeof(ix->opt));
     ix->is_fork = true;
     ix->image = src->image;
     ix->image.push_back(src->allocs);
@@ -549,7 +563,7 @@ int hvx::enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t b
     a.build_ef_upper = 0;
     a.only_flagged = 0;
     a.occupancy = ix->occupancy;
-    if (const char *e = getenv("HVX_WAVE_OCC")) a.occupancy = (uint32_t)atoi(e); // tuning hook
+    a.log2cap = ix->opt[HVX_OPT_WAVE_LOG2CAP];
     if (ad) {
         if (!hnsw_wave_adaptive_supported(a))
             return fail(HVX_ERR_UNSUPPORTED, "the non-strict search arms serve f32 rows of any dimension / metric (bf16 rows: dim in "
@@ -565,14 +579,14 @@ int hvx::enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t b
         if (e1) HIP_TRY(hipEventRecord(e1, ix->stream));
         return HVX_OK;
     }
-    const bool prof = getenv("HVX_WAVE_PROF") != nullptr; // tuning hook: phase-timing kernel + stderr report
+    const bool prof = tuning_env("HVX_WAVE_PROF") != nullptr; // tuning builds: phase-timing kernel + stderr report
     if (prof) {
         if (!ix->d_prof && ix->dalloc((void **)&ix->d_prof, (size_t)ix->max_batch * 64)) return HVX_ERR_DEVICE;
         a.prof = ix->d_prof;
     }
     // the HBM visited bitmap is all-zero at import; the general kernel dirties it, the wave kernel
     // (LDS visited set, bitmap only as overflow) hands it back zeroed
-    const bool force_general = getenv("HVX_HNSW_GENERAL") != nullptr; // test hook
+    const bool force_general = ix->opt[HVX_OPT_HNSW_GENERAL_KERNEL] != 0;
     const bool wave = !(force_general && ix->dev.dtype == HVX_F32) && hnsw_wave_supported(a);
     if (!wave && ix->dev.dtype != HVX_F32)
         return fail(HVX_ERR_UNSUPPORTED, ix->dev.dtype == HVX_FP8_E4M3 ? "fp8 rows serve the exact scan only (HNSW over fp8 rows is not built)"
@@ -760,14 +774,15 @@ int hvx::flat_scan_device(hvx_index *ix, const float *d_queries, uint32_t b, uin
         const uint32_t nk = d.dim >> 5;
         const bool shape = d.dim % 32u == 0u && d.ld == d.dim && d.dim_main == d.dim && d.fkernel == kKernelAvxFma &&
                            (nk == 4 || nk == 8 || nk == 16 || nk == 24 || nk == 32 || nk == 48) && (d.metric == kL2 || d.metric == kCosine);
-        if (shape && d.dim >= 256 && k <= 511 && (uint64_t)b * n_rows * d.dim >= (1ull << 33) && !getenv("HVX_FLAT_VALU")) {
+        if (shape && d.dim >= 256 && k <= 511 && (uint64_t)b * n_rows * d.dim >= (1ull << 33) && !ix->opt[HVX_OPT_FLAT_FORCE_VALU]) {
             const int rc = flat_mfma_device(ix, d_queries, b, k, d_subset, n_rows, d_ids, d_scores, d_counts, d_status, timed);
             if (rc != -1) return rc;
             // certificate not reached for some queries: those -- and only those, unless they are many -- are answered
             // by the exact VALU scan below; the rest of the batch keeps its certified rows
             const std::vector<uint32_t> failed = ix->m_failed;
             const uint32_t nf = (uint32_t)failed.size();
-            if (getenv("HVX_FLAT_DEBUG"))
+            ix->last_scan_path |= nf * 4u <= b ? HVX_PATH_VALU_FALLBACK_QUERIES : HVX_PATH_VALU;
+            if (tuning_env("HVX_FLAT_DEBUG"))
                 fprintf(stderr, "[hvx flat] certificate not reached for %u of %u queries: exact VALU scan for %s\n", nf, b,
                         nf * 4u <= b ? "those queries only" : "the whole batch");
             if (nf * 4u <= b) {
@@ -802,6 +817,7 @@ int hvx::flat_scan_device(hvx_index *ix, const float *d_queries, uint32_t b, uin
 // the exact VALU scan (flat_distance_kernel + flat_select_kernel + finish); record_begin=false keeps an earlier ev0
 int hvx::flat_scan_valu(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, const uint32_t *d_subset, uint32_t n_rows,
                         uint64_t *d_ids, float *d_scores, uint32_t *d_counts, uint32_t *d_status, bool timed, bool record_begin) {
+    if (record_begin) ix->last_scan_path = HVX_PATH_VALU;
     // chunk the scan so the distance workspace stays <= 256 MiB
     uint32_t chunk = 65536;
     while ((size_t)chunk * b * 4 > (256u << 20) && chunk > 256) chunk >>= 1;

@@ -97,11 +97,12 @@ struct hvx_batcher {
                     memcpy(r->out_ids, ln.ids.data() + (size_t)i * k, (size_t)ln.cnt[i] * 8);
                     memcpy(r->out_scores, ln.sc.data() + (size_t)i * k, (size_t)ln.cnt[i] * 4);
                 }
-                {
+                {   // notify UNDER the request's lock: the request lives on its caller's stack, and a caller that sees `done`
+                    // may return and destroy it -- it cannot do so before this scope releases r->m
                     std::lock_guard<std::mutex> g(r->m);
                     r->done = true;
+                    r->cv.notify_one();
                 }
-                r->cv.notify_one();
             }
             lock.lock();
         }

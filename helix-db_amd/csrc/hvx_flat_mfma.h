@@ -34,7 +34,8 @@ struct MfmaArgs {
 // 256 x 256 filtered contraction (hvx_flat_tile.hip).  kind: 0 = bf16 rows (a bf16 index, or the bf16 shadow of an f32
 // index; a.rows in the order a.qhi uses), 1 = fp8 codes (a.qhi in tile order, see tile_slot_fp8).  a.dim % 64 == 0.
 // `wg_overflow` is set when a workgroup's pair list overflowed (the caller repeats the scan unfiltered).
-hipError_t launch_flat_tile256(const MfmaArgs &a, int kind, uint32_t bpad, float xmax2, uint32_t *wg_overflow, hipStream_t s);
+// build: 0 = two 256-thread workgroups per CU (256 x 128 tiles), 1 = one 512-thread workgroup per CU (256 x 256 tiles)
+hipError_t launch_flat_tile256(const MfmaArgs &a, int kind, uint32_t bpad, float xmax2, uint32_t *wg_overflow, uint32_t build, hipStream_t s);
 
 // position of stored code `slot` (its index in the fp8 row) in the query operand of the 256 x 256 fp8 kernel: inside a
 // 64-code stage, MFMA step kk (0..3), lane half h, element e read code (2 (kk >> 1) + h) * 16 + (kk & 1) * 8 + e, so one

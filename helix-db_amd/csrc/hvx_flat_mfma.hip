@@ -601,7 +601,7 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
     }
     // the 256 x 256 filtered contraction (hvx_flat_tile.hip) serves the one-pass attempt of scans with dim % 64 == 0
     // (its query tile is 256 wide: a batch of <= 128 queries wastes less on the 128 x 128 kernel)
-    const bool tile_ok = d.dim % 64u == 0u && (b > 128u || getenv("HVX_FLAT_CHUNK")) && getenv("HVX_FLAT_NO_TILE") == nullptr;
+    const bool tile_ok = d.dim % 64u == 0u && (b > 128u || ix->opt[HVX_OPT_FLAT_FIRST_CHUNK]) && !ix->opt[HVX_OPT_FLAT_NO_TILE];
     if (f32 && !ix->m_rowterm) { // |x|^2 per row and its maximum: once per index, on first use
         if ((rc = ix->dalloc((void **)&ix->m_rowterm, std::max<size_t>(d.n, 1) * 4))) return rc;
         std::vector<float> h_n2(d.n);
@@ -622,8 +622,10 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
     // With m + 1 <= 256 only the first chunk writes its score matrix; every later launch covers a geometrically growing
     // slice of the rows and lets a score out of the tile only below the query's running threshold (FILT).
     const uint32_t m0 = std::max<uint32_t>(64u, 2u * k);
-    const bool debug = getenv("HVX_FLAT_DEBUG") != nullptr;
-    const bool allow_fast = getenv("HVX_FLAT_NO_FAST") == nullptr;
+    const bool debug = tuning_env("HVX_FLAT_DEBUG") != nullptr;
+    const bool allow_fast = !ix->opt[HVX_OPT_FLAT_NO_FAST];
+    const bool no_filter = ix->opt[HVX_OPT_FLAT_NO_FILTER] != 0;
+    ix->last_scan_path = 0;
     constexpr uint32_t kCandCap = 1024;
     for (int attempt = allow_fast ? 0 : 1; attempt < 3; ++attempt) {
         const bool full = attempt >= 1;
@@ -632,12 +634,12 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
         const uint32_t kc = m + 1;
         // first chunk (scored by the 128 x 128 kernel into the score matrix, top-(m + 1) selected from it): 16 384 rows when the
         // large-tile filtered slices follow (1024 x 1M x 768: 2.43 ms vs 2.59 with 65 536), 65 536 as before otherwise
-        uint32_t chunk = tile_ok && !full && allow_filter && m + 1 <= 256u && getenv("HVX_FLAT_NO_FILTER") == nullptr ? 16384u : 65536u;
-        if (const char *e = getenv("HVX_FLAT_CHUNK")) chunk = std::max<uint32_t>(1024u, (uint32_t)atoi(e) / 1024u * 1024u); // tests: small first chunks
+        uint32_t chunk = tile_ok && !full && allow_filter && m + 1 <= 256u && !no_filter ? 16384u : 65536u;
+        if (ix->opt[HVX_OPT_FLAT_FIRST_CHUNK]) chunk = std::max<uint32_t>(1024u, ix->opt[HVX_OPT_FLAT_FIRST_CHUNK] / 1024u * 1024u); // tests: small first chunks
         while ((size_t)chunk * b * 4 > (512u << 20) && chunk > 1024) chunk >>= 1;
         if (chunk > n) chunk = (n + 3u) & ~3u;
         if ((rc = ix->flat_scratch(b, kc, chunk))) return rc;
-        const bool filt = allow_filter && kc <= 256u && n > chunk && getenv("HVX_FLAT_NO_FILTER") == nullptr;
+        const bool filt = allow_filter && kc <= 256u && n > chunk && !no_filter;
         if (filt && ix->cap_cand < (size_t)bpad) {
             if ((rc = ix->regrow((void **)&ix->m_thr, (size_t)bpad * 4))) return rc;
             if ((rc = ix->regrow((void **)&ix->m_csc, (size_t)bpad * kCandCap * 4))) return rc;
@@ -660,7 +662,7 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
         ma.thr = ix->m_thr; ma.cand_sc = ix->m_csc; ma.cand_id = ix->m_cid; ma.cand_cnt = ix->m_ccnt; ma.cand_cap = kCandCap;
         auto contraction = [&](uint32_t r0, uint32_t rows, bool filtered) -> hipError_t {
             ma.row0 = r0; ma.nrows = rows;
-            ma.nq_tiles = bpad / kBM;
+            ma.nq_tiles = (b + kBM - 1) / kBM; // (bpad is a multiple of 256 for the tile kernels: no all-padding 128-query tile here)
             ma.nr_tiles = (rows + kBN - 1) / kBN;
             const size_t row_bytes = (size_t)d.dim * (f32 ? 4 : (fp8 ? 1 : 2));
             ma.group_tiles = (uint32_t)std::max<size_t>(1, std::min<size_t>(ma.nr_tiles, (64u << 20) / ((size_t)kBN * row_bytes)));
@@ -693,7 +695,7 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
                     ta.row0 = r0; ta.nrows = rows;
                     if (f32) ta.rows = ix->m_shadow;
                     if (fp8) ta.qhi = ix->m_qhi8;
-                    HIP_TRY(launch_flat_tile256(ta, fp8 ? 1 : 0, bpad, ix->m_xmax2, pm.overflow, ix->stream));
+                    HIP_TRY(launch_flat_tile256(ta, fp8 ? 1 : 0, bpad, ix->m_xmax2, pm.overflow, ix->opt[HVX_OPT_FLAT_TILE_BUILD], ix->stream));
                     used_tile = true;
                 } else
                     HIP_TRY(contraction(r0, rows, true));
@@ -730,6 +732,8 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
         uint32_t failed = 0, first = 0;
         for (uint32_t i = 0; i < b; ++i)
             if (!cert[i]) { if (!failed) first = i; ++failed; }
+        ix->last_scan_path |= (used_tile ? HVX_PATH_TILE_256 : HVX_PATH_MFMA_128) | (filt ? HVX_PATH_FILTERED : 0u) | (full ? HVX_PATH_FULL_SPLIT : 0u) |
+                              (attempt == 2 ? HVX_PATH_WIDENED : 0u);
         if (debug)
             fprintf(stderr, "[hvx flat] attempt %d (%s contraction, m = %u%s%s): %u of %u certificates missing%s\n", attempt,
                     full ? "full" : "one-pass", m, filt ? ", filtered epilogue" : "", used_tile ? ", 256 x 256 tiles" : "", failed, b,

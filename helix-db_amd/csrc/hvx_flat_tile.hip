@@ -42,6 +42,14 @@
 
 namespace hvx {
 
+// Measurement switches (MfmaArgs::ablate: parts of the tile kernel switched off -- results WRONG by construction) exist only
+// in tuning builds (-DHVX_TUNING); in the release library the tests below are compile-time false.
+#ifdef HVX_TUNING
+#define HVX_ABLATE(a, bit) (((a).ablate & (bit)) != 0u)
+#else
+#define HVX_ABLATE(a, bit) (false)
+#endif
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -233,7 +241,7 @@ __global__ __launch_bounds__(512) void flat_tile256_kernel(MfmaArgs a, float xma
         const int buf = (int)(s & 1u);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces of stage s have landed ...
         __syncthreads();                                  // ... everyone's have, and buffer buf ^ 1 is no longer being read
-        if (s + 1 < nstage && !(a.ablate & 1u)) issue_stage((s + 1) * 128u, (s + 1) * (uint32_t)ROWB, buf ^ 1);
+        if (s + 1 < nstage && !HVX_ABLATE(a, 1u)) issue_stage((s + 1) * 128u, (s + 1) * (uint32_t)ROWB, buf ^ 1);
         const unsigned char *sA = lds + buf * STAGE + wm * (128 * 128);
         const unsigned char *sB = lds + buf * STAGE + kAStage + wn * (64 * ROWB);
         // fragments of step kk + 1 are read (fp8: and widened) while the matrix core works on step kk
@@ -270,7 +278,7 @@ __global__ __launch_bounds__(512) void flat_tile256_kernel(MfmaArgs a, float xma
         for (int kk = 0; kk < 4; kk += 2) {
             load_frags(kk + 1, fa1, fb1);
             if (PIPE) __builtin_amdgcn_sched_barrier(0); // keep the reads of the next step ahead of this step's MFMAs
-            if (a.ablate & 2u) {
+            if HVX_ABLATE(a, 2u) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa0[i]));
 #pragma unroll
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(512) void flat_tile256_kernel(MfmaArgs a, float xma
             if (PIPE) __builtin_amdgcn_sched_barrier(0);
             if (kk + 2 < 4) load_frags(kk + 2, fa0, fb0);
             if (PIPE) __builtin_amdgcn_sched_barrier(0);
-            if (a.ablate & 2u) {
+            if HVX_ABLATE(a, 2u) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa1[i]));
 #pragma unroll
@@ -297,7 +305,7 @@ __global__ __launch_bounds__(512) void flat_tile256_kernel(MfmaArgs a, float xma
             }
         }
     }
-    if (a.ablate & 4u) { // measurement builds only (HVX_FLAT_TILE_ABLATE): keep the accumulators alive, skip the epilogue
+    if HVX_ABLATE(a, 4u) { // measurement builds only (HVX_FLAT_TILE_ABLATE): keep the accumulators alive, skip the epilogue
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -473,6 +481,7 @@ __global__ __launch_bounds__(256, 2) void flat_tile2_kernel(MfmaArgs a, float xm
     tile_epilogue<FP8, 2>(a, acc, lds, q0, r0, wm, wn, tid, xmax2, wg_overflow);
 }
 
+#ifdef HVX_TUNING // experimental: not in the release library until it has a hardware parity record (scripts/gpu_tile4_round.sh)
 // ---- the 128 x 128-per-wavefront build: fewer LDS bytes per flop.  Four wavefronts (one per SIMD, 2 x 2) on a 256 x 256
 // tile, each with 4 x 4 accumulators (256 registers: the kernel runs one wavefront per SIMD and spills into AGPRs): a
 // 16-deep step is 16 MFMAs per 8 fragment reads (the 128 x 64 builds: 8 per 6), and the tile moves two thirds of the
@@ -640,7 +649,9 @@ __global__ __launch_bounds__(256, 1) void flat_tile4_kernel(MfmaArgs a, float xm
     tile_epilogue<FP8, 4>(a, acc, lds, q0, r0, wm, wn, tid, xmax2, wg_overflow);
 }
 
-hipError_t launch_flat_tile256(const MfmaArgs &a, int kind, uint32_t bpad, float xmax2, uint32_t *wg_overflow, hipStream_t s) {
+#endif // HVX_TUNING
+
+hipError_t launch_flat_tile256(const MfmaArgs &a, int kind, uint32_t bpad, float xmax2, uint32_t *wg_overflow, uint32_t build, hipStream_t s) {
     if (a.nrows == 0) return hipSuccess;
     if (a.dim % 64u != 0u || bpad % (uint32_t)kTM != 0u) return hipErrorInvalidValue;
     MfmaArgs t = a;
@@ -649,21 +660,21 @@ hipError_t launch_flat_tile256(const MfmaArgs &a, int kind, uint32_t bpad, float
     t.sup_q = std::min<uint32_t>(t.nq_tiles, 8u);
     t.sup_r = 32u / t.sup_q;
     t.sup_qblocks = (t.nq_tiles + t.sup_q - 1) / t.sup_q;
-    t.ablate = [] { const char *e = getenv("HVX_FLAT_TILE_ABLATE"); return e ? (uint32_t)atoi(e) : 0u; }();
+    t.ablate = 0;
     const uint32_t rblocks = (t.nr_tiles + 8u * t.sup_r - 1) / (8u * t.sup_r);
     const dim3 grid(8u * rblocks * t.sup_qblocks * t.sup_r * t.sup_q);
-    const int build = [] { const char *e = getenv("HVX_FLAT_TILE_BUILD"); return e ? atoi(e) : 3; }(); // 0: one 512-thread workgroup per CU (256 x 256 tiles, two LDS buffers), else: two 256-thread workgroups per CU (256 x 128)
-    if ((build == 4 && kind != 1) || build == 5) { // 256 x 256 tiles, 256 threads of 128 x 128 each, one workgroup per CU.  OPT-IN: written
-        // after the round's GPU budget was spent.  The last seconds of it ran the parity test once: bf16 rows PASS; fp8 codes FAILED
-        // (wrong candidates): that instantiation, at 256 VGPRs + 256 AGPRs, had v_mov copies of fragment registers right behind their
-        // inline-asm ds_read (the compiler believes an asm output is valid at once) -- scripts/lint_asm_lds.py finds them.  With the
-        // last stage peeled the fp8 instantiation lints clean too, but it has not run on hardware since: build 4 = bf16 / f32
-        // shadow only, build 5 = fp8 as well (to be tested first thing next round).  Not yet timed.
+#ifdef HVX_TUNING
+    if (const char *e = getenv("HVX_FLAT_TILE_ABLATE")) t.ablate = (uint32_t)atoi(e);
+    const int tuning_build = [] { const char *e = getenv("HVX_FLAT_TILE_BUILD"); return e ? atoi(e) : 0; }();
+    if ((tuning_build == 4 && kind != 1) || tuning_build == 5) { // 256 x 256 tiles, 256 threads of 128 x 128 each, one workgroup per CU:
+        // bf16 rows passed their one parity run, the fp8 instantiation returned wrong candidates once (v_mov copies of fragment
+        // registers right behind their inline-asm ds_read; scripts/lint_asm_lds.py finds them) and has not run since.  Untimed.
         if (kind == 1) hipLaunchKernelGGL((flat_tile4_kernel<1>), grid, dim3(256), 0, s, t, xmax2, wg_overflow);
         else hipLaunchKernelGGL((flat_tile4_kernel<0>), grid, dim3(256), 0, s, t, xmax2, wg_overflow);
         return hipGetLastError();
     }
-    if (build != 0) { // 256 x 128 tiles, 256 threads, two workgroups per CU: super-tiles of 64 workgroups per XCD
+#endif
+    if (build == 0) { // 256 x 128 tiles, 256 threads, two workgroups per CU: super-tiles of 64 workgroups per XCD
         t.nr_tiles = (a.nrows + 127u) / 128u;
         t.sup_r = 64u / t.sup_q;
         const uint32_t rb = (t.nr_tiles + 8u * t.sup_r - 1) / (8u * t.sup_r);
@@ -672,7 +683,11 @@ hipError_t launch_flat_tile256(const MfmaArgs &a, int kind, uint32_t bpad, float
         else hipLaunchKernelGGL((flat_tile2_kernel<0>), grid2, dim3(256), 0, s, t, xmax2, wg_overflow);
         return hipGetLastError();
     }
-    const bool pipe = [] { const char *e = getenv("HVX_FLAT_TILE_PIPE"); return !e || e[0] != '0'; }();
+    // one 512-thread workgroup per CU (256 x 256 tiles, two LDS buffers)
+    bool pipe = true;
+#ifdef HVX_TUNING
+    if (const char *e = getenv("HVX_FLAT_TILE_PIPE")) pipe = e[0] != '0';
+#endif
     if (kind == 1) {
         if (pipe) hipLaunchKernelGGL((flat_tile256_kernel<1, true>), grid, dim3(512), 0, s, t, xmax2, wg_overflow);
         else hipLaunchKernelGGL((flat_tile256_kernel<1, false>), grid, dim3(512), 0, s, t, xmax2, wg_overflow);

@@ -346,13 +346,6 @@ static bool hnsw_wave_generic_supported(const HnswArgs &a) {
 }
 bool hnsw_wave_adaptive_supported(const HnswArgs &a) { return hnsw_wave_supported(a) || hnsw_wave_generic_supported(a); }
 
-static int env_int(const char *name, int lo, int hi, int fallback) {
-    const char *e = getenv(name);
-    if (!e) return fallback;
-    const int v = atoi(e);
-    return (v >= lo && v <= hi) ? v : fallback;
-}
-
 static hipError_t launch_hnsw_wave_once(const HnswArgs &a, uint32_t b, hipStream_t s) {
     WaveGeom g;
     // visited hash: 64 slots per beam entry (load factor ~0.15-0.3 at the measured ~10 distance evaluations
@@ -362,7 +355,7 @@ static hipError_t launch_hnsw_wave_once(const HnswArgs &a, uint32_t b, hipStream
     const bool generic = a.adaptive && !hnsw_wave_supported(a);
     if (generic && g.log2cap > 14) g.log2cap = 14; // 64 KiB table (two workgroups per CU); larger visited sets spill to the bitmap
     if (a.build_nodes && g.log2cap > 13) g.log2cap = 13; // build searches (ef_construction ~200): keep four workgroups per CU
-    g.log2cap = (uint32_t)env_int("HVX_WAVE_LOG2CAP", 7, 15, (int)g.log2cap); // test hook: tiny table => spill path
+    if (a.log2cap >= 7 && a.log2cap <= 15) g.log2cap = a.log2cap; // HVX_OPT_WAVE_LOG2CAP: a tiny table exercises the spill path
     // 160 KiB / 4: exactly four resident wavefronts per CU, one per SIMD, each with the SIMD's whole register file.
     // occ = 2 (a.occupancy): eight per CU, two per SIMD -- the table shrinks until query + frontier + table fit 20 KiB
     g.occ = (a.occupancy == 2 && !a.adaptive && !a.prof && !a.build_nodes) ? 2u : 1u;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -50,6 +51,8 @@ struct hvx_index {
     uint32_t max_batch = 1024;
     uint32_t words_per_query = 0;
     uint32_t occupancy = 1;          // wave kernel build: queries per SIMD (hvx_index_set_occupancy)
+    uint32_t opt[HVX_OPT_COUNT] = {}; // execution-path selectors (hvx_index_set_option); 0 = the library's own choice
+    uint32_t last_scan_path = 0;     // hvx_scan_path flags of the handle's last exact scan (hvx_index_last_scan_path)
     bool bitmap_dirty = false;       // d_bitmap holds stale visited bits (general kernel ran last)
     hipStream_t stream = nullptr;      // stream in use
     hipStream_t own_stream = nullptr;  // created at import
@@ -136,6 +139,13 @@ struct hvx_index {
 };
 
 namespace hvx {
+// Environment switches exist only in tuning builds (make TUNING=1 -> -DHVX_TUNING): the release library never calls getenv,
+// and the measurement-only code they select (ablation, phase profiling, experimental tile builds) is not compiled in.
+#ifdef HVX_TUNING
+inline const char *tuning_env(const char *name) { return getenv(name); }
+#else
+inline const char *tuning_env(const char *) { return nullptr; }
+#endif
 int fail(int code, const char *fmt, ...);
 int import_index(const hvx_index_desc *desc, const uint64_t *node_ids, const float *vectors, const uint64_t *l0_offsets,
                  const uint64_t *l0_neighbors, const uint16_t *level, const uint64_t *up_offsets, const uint64_t *up_neighbors,

@@ -126,6 +126,10 @@ class AdaptiveStats(C.Structure):  # hvx_adaptive_stats
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+# hvx_option: execution-path selectors of a handle (same results on every setting) / hvx_scan_path flags
+OPT_HNSW_GENERAL_KERNEL, OPT_WAVE_LOG2CAP, OPT_FLAT_FORCE_VALU, OPT_FLAT_FIRST_CHUNK, OPT_FLAT_NO_TILE, OPT_FLAT_NO_FILTER, \
+    OPT_FLAT_NO_FAST, OPT_FLAT_TILE_BUILD = range(8)
+PATH_VALU, PATH_MFMA_128, PATH_TILE_256, PATH_FILTERED, PATH_FULL_SPLIT, PATH_VALU_FALLBACK_QUERIES, PATH_WIDENED = 1, 2, 4, 8, 16, 32, 64
 RESTRICTED_AUTO, RESTRICTED_EXACT, RESTRICTED_FILTERED = 0, 1, 2  # hvx_restricted_strategy
 TERM_NONE, TERM_EXHAUSTED, TERM_BEAM_COMPLETE, TERM_ROUTING_BUDGET, TERM_BRIDGE_BUDGET, TERM_VECTOR_BUDGET = range(6)
 
@@ -731,6 +735,18 @@ class ValidatedVectorReadIndex:
         h = _vp()
         _check(lib().hvx_index_fork(self._h, C.byref(h)))
         return type(self)(h, self.dim, self.metric, self.n)
+
+    def set_option(self, option: int, value: int):
+        """hvx_index_set_option: pin an execution path of this handle (tests, A/B measurements); results do not change"""
+        lib().hvx_index_set_option.restype = C.c_int
+        lib().hvx_index_set_option.argtypes = [_vp, C.c_uint32, C.c_uint32]
+        _check(lib().hvx_index_set_option(self._h, option, value))
+
+    def last_scan_path(self) -> int:
+        """hvx_scan_path flags of this handle's last exact scan"""
+        lib().hvx_index_last_scan_path.restype = C.c_uint32
+        lib().hvx_index_last_scan_path.argtypes = [_vp]
+        return int(lib().hvx_index_last_scan_path(self._h))
 
     def set_occupancy(self, queries_per_simd: int):
         _check(lib().hvx_index_set_occupancy(self._h, queries_per_simd))

@@ -113,6 +113,28 @@ int hvx_index_set_stream(hvx_index *, void *hip_stream);
  * is freed, in any order.  Attach SimHash rows (hvx_index_set_simhash) to the imported handle BEFORE forking.
  */
 int hvx_index_fork(const hvx_index *, hvx_index **out);
+/* Execution-path selectors of ONE handle.  Every setting returns the same results; they exist so that tests and A/B
+ * measurements can pin a code path.  (The library reads no environment variables: tuning-only switches -- kernel
+ * ablation, phase profiling, experimental tile builds -- exist only in builds made with `make TUNING=1`.)  Forks inherit
+ * the options their parent has at fork time.  value 0 = the library's own choice. */
+enum hvx_option {
+    HVX_OPT_HNSW_GENERAL_KERNEL = 0, /* 1: strict searches over f32 rows take the general 4-wavefront kernel */
+    HVX_OPT_WAVE_LOG2CAP = 1,        /* 7..15: log2 slots of the wave kernel's LDS visited table (small => HBM-bitmap spill path) */
+    HVX_OPT_FLAT_FORCE_VALU = 2,     /* 1: f32 exact scans stay on the reference-order VALU kernel (no matrix-core candidates) */
+    HVX_OPT_FLAT_FIRST_CHUNK = 3,    /* rows of the first (unfiltered) chunk of the matrix-core scan, >= 1024 */
+    HVX_OPT_FLAT_NO_TILE = 4,        /* 1: matrix-core scans stay on the 128 x 128 kernel */
+    HVX_OPT_FLAT_NO_FILTER = 5,      /* 1: no filtered epilogue (every chunk writes its score matrix) */
+    HVX_OPT_FLAT_NO_FAST = 6,        /* 1: start with the full hi + lo split */
+    HVX_OPT_FLAT_TILE_BUILD = 7,     /* large-tile kernel: 0 = two 256-thread workgroups per CU (256 x 128), 1 = one 512-thread (256 x 256) */
+    HVX_OPT_COUNT = 8
+};
+int hvx_index_set_option(hvx_index *, uint32_t option, uint32_t value);
+/* which kernels the handle's last exact scan ran (bit flags) */
+enum hvx_scan_path {
+    HVX_PATH_VALU = 1, HVX_PATH_MFMA_128 = 2, HVX_PATH_TILE_256 = 4, HVX_PATH_FILTERED = 8, HVX_PATH_FULL_SPLIT = 16,
+    HVX_PATH_VALU_FALLBACK_QUERIES = 32, HVX_PATH_WIDENED = 64
+};
+uint32_t hvx_index_last_scan_path(const hvx_index *);
 /* HNSW kernel build used by this handle: 1 (default) = one query per SIMD with the SIMD's whole register file (lowest
  * latency of a lone batch); 2 = two queries per SIMD, half the registers / LDS each -- higher throughput when >= 2 batches
  * are in flight on the device (lanes).  Results are identical.  Shapes without a 2-per-SIMD build run the default. */

@@ -297,14 +297,39 @@ def test_inline_asm_lds_reads_are_covered_by_a_wait(tmp_path):
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
     src = os.path.join(ROOT, "helix-db_amd", "csrc", "hvx_flat_tile.hip")
-    asm = tmp_path / "hvx_flat_tile.s"
-    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S", "--cuda-device-only",
-                          "-o", str(asm), src], capture_output=True, text=True)
-    assert out.returncode == 0, out.stderr
-    lint = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "lint_asm_lds.py"), str(asm), "flat_tile2_kernel", "flat_tile4_kernel"],
-                          capture_output=True, text=True)
-    assert lint.returncode == 0, lint.stdout + lint.stderr
-    assert lint.stdout.count(": 0 hazard(s)") == 4, lint.stdout    # fp8 + bf16 builds of the default kernel and of the opt-in one
+    # the release build carries flat_tile2_kernel only; the tuning build (-DHVX_TUNING) also the experimental flat_tile4_kernel
+    for flags, kernels, want in (([], ["flat_tile2_kernel"], 2), (["-DHVX_TUNING"], ["flat_tile2_kernel", "flat_tile4_kernel"], 4)):
+        asm = tmp_path / ("hvx_flat_tile%d.s" % want)
+        out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S", "--cuda-device-only"]
+                             + flags + ["-o", str(asm), src], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        lint = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "lint_asm_lds.py"), str(asm)] + kernels, capture_output=True, text=True)
+        assert lint.returncode == 0, lint.stdout + lint.stderr
+        assert lint.stdout.count(": 0 hazard(s)") == want, lint.stdout    # fp8 + bf16 instantiations of each kernel
+
+
+def test_release_library_reads_no_environment_and_carries_no_measurement_code():
+    """tuning switches (kernel ablation -- results wrong by construction --, phase profiling, experimental tile
+    builds, stderr path reports) exist only in `make TUNING=1` builds.  The shipped library does not import getenv, holds none
+    of the switch names, and does not contain the experimental kernel."""
+    import subprocess
+    lib = os.path.join(ROOT, "helix-db_amd", "libhelix_vec_gfx950.so")
+    if not os.path.exists(lib):
+        pytest.skip("library not built")
+    undef = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True).stdout
+    assert "getenv" not in undef
+    blob = open(lib, "rb").read()
+    for name in (b"HVX_FLAT_TILE_ABLATE", b"HVX_FLAT_TILE_BUILD", b"HVX_FLAT_DEBUG", b"HVX_WAVE_PROF", b"HVX_WAVE_OCC", b"HVX_FLAT_VALU",
+                 b"HVX_HNSW_GENERAL", b"HVX_WAVE_LOG2CAP", b"HVX_FLAT_CHUNK", b"flat_tile4_kernel"):
+        assert name not in blob, name
+    src = "".join(open(os.path.join(ROOT, "helix-db_amd", "csrc", f)).read() for f in os.listdir(os.path.join(ROOT, "helix-db_amd", "csrc"))
+                  if f.endswith((".hip", ".h")))
+    import re
+    # every getenv in the sources sits behind HVX_TUNING (tuning_env() or an #ifdef HVX_TUNING block)
+    for m in re.finditer(r"[^_a-z]getenv\(", src):
+        before = src[: m.start()]
+        assert before.rfind("#ifdef HVX_TUNING") > before.rfind("#endif") or before.rfind("#else") > before.rfind("#ifdef HVX_TUNING") >= 0 \
+            or "tuning_env" in src[m.start() - 80: m.start()], src[m.start() - 120: m.start() + 40]
 
 
 def test_tile_workgroup_mapping_covers_every_tile_once():

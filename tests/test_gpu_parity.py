@@ -140,18 +140,18 @@ WAVE_CASES = [
 
 @pytest.mark.parametrize("n,dim,metric,m,m0,efc,ef,k,nq", WAVE_CASES)
 @pytest.mark.parametrize("path", ["wave", "general", "wave-spill"])
-def test_hnsw_kernels_agree_with_oracle(orc, hv, monkeypatch, path, n, dim, metric, m, m0, efc, ef, k, nq):
+def test_hnsw_kernels_agree_with_oracle(orc, hv, path, n, dim, metric, m, m0, efc, ef, k, nq):
     """Both HNSW kernels (hvx_hnsw_wave.h and the general hvx_hnsw.hip) and the wave kernel's
     LDS-table -> HBM-bitmap spill path give the oracle's ids, score bits and counters."""
-    if path == "general":
-        monkeypatch.setenv("HVX_HNSW_GENERAL", "1")
-    if path == "wave-spill":
-        monkeypatch.setenv("HVX_WAVE_LOG2CAP", "8")  # 256-slot table: spills after ~128 visited ids
     rng = np.random.default_rng(77 + dim + metric)
     data = rng.standard_normal((n, dim)).astype(np.float32)
     lv = fx.draw_levels(n, m, seed=dim + 1)
     oix = build_oracle(orc, data, metric, lv, m=m, m0=m0, efc=efc)
     gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=dim, metric=metric, m=m, m0=m0)
+    if path == "general":
+        gix.set_option(hv.OPT_HNSW_GENERAL_KERNEL, 1)
+    if path == "wave-spill":
+        gix.set_option(hv.OPT_WAVE_LOG2CAP, 8)  # 256-slot table: spills after ~128 visited ids
     q = rng.standard_normal((nq, dim)).astype(np.float32)
     assert_hnsw_equal(orc, hv, oix, gix, q, k, ef)
     assert_hnsw_equal(orc, hv, oix, gix, q[: nq // 2], k, ef)  # second launch: visited state handed back clean
@@ -767,19 +767,19 @@ def test_non_strict_arms_over_bf16_rows(orc, hv, metric, dim):
 
 @pytest.mark.parametrize("spill", [False, True])
 @pytest.mark.parametrize("mult,ef", [(1, 100), (3, 100), (1, 24)])
-def test_uncached_handle_read_accounting_and_budget_bypass(orc, hv, monkeypatch, spill, mult, ef):
+def test_uncached_handle_read_accounting_and_budget_bypass(orc, hv, spill, mult, ef):
     """hvx_simhash_config.resident_snapshot = 0: every SimHash row a query sees for the first time in a filtering epoch is
     one stable-view read (memory_store.rs:338-347); once ef x multiplier reads are spent the read-budget trigger
     (policy.rs:266) opens bypass windows.  Reads, triggers, results equal the oracle's uncached accounting -- also when
     the visited table has spilled to the HBM bitmaps."""
-    if spill:
-        monkeypatch.setenv("HVX_WAVE_LOG2CAP", "8")
     rng = np.random.default_rng(606 + mult + ef)
     n, dim = 2500, 128
     data = rng.standard_normal((n, dim)).astype(np.float32)
     oix = build_oracle(orc, data, 0, fx.draw_levels(n, 16, seed=12), efc=80)
     oix.set_simhash(42)
     gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=dim, metric=0)
+    if spill:
+        gix.set_option(hv.OPT_WAVE_LOG2CAP, 8)
     cfg = hv.SimHashConfig.default(resident_snapshot=0, simhash_threshold=30)
     gix.set_simhash(cfg)
     q = rng.standard_normal((32, dim)).astype(np.float32)
@@ -795,10 +795,9 @@ def test_uncached_handle_read_accounting_and_budget_bypass(orc, hv, monkeypatch,
     assert agg_r["txn_get_simhash_filter"] == 0 and agg_r["simhash_bypass_trigger_budget"] == 0
 
 
-def test_non_strict_arms_spill_path_and_given_hashes(orc, hv, monkeypatch):
+def test_non_strict_arms_spill_path_and_given_hashes(orc, hv):
     """LDS visited table -> HBM bitmap spill inside the non-strict arms (visited TEST and late insert both take the
     bitmap), with the SimHash rows handed over by the host instead of recomputed."""
-    monkeypatch.setenv("HVX_WAVE_LOG2CAP", "8")
     rng = np.random.default_rng(4242)
     n, dim = 2500, 128
     data = rng.standard_normal((n, dim)).astype(np.float32)
@@ -808,6 +807,7 @@ def test_non_strict_arms_spill_path_and_given_hashes(orc, hv, monkeypatch):
     cfg = hv.SimHashConfig.default()
     gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=dim, metric=0)
     gix.set_simhash(cfg, node_hashes=oix.get_simhash())
+    gix.set_option(hv.OPT_WAVE_LOG2CAP, 8)
     q = rng.standard_normal((24, dim)).astype(np.float32)
     agg = assert_params_equal(orc, hv, oix, gix, q, hv.SearchParams.new(10), cfg)
     assert agg["distance_computations"] > 24 * 128  # far more visited ids than the 256-slot table holds
@@ -1007,7 +1007,7 @@ def test_ties_beyond_the_beam_slack_are_rerun_with_a_wider_beam(orc, hv, occupan
 
 
 @pytest.mark.parametrize("metric,dim,n,k,b", [(1, 512, 40000, 10, 512), (0, 256, 80000, 25, 512), (1, 768, 60000, 100, 500)])
-def test_f32_exact_scan_on_matrix_cores_is_bit_exact(orc, hv, monkeypatch, metric, dim, n, k, b):
+def test_f32_exact_scan_on_matrix_cores_is_bit_exact(orc, hv, metric, dim, n, k, b):
     """Whole-corpus exact scans over f32 rows (dim >= 256) with enough work (b x n x dim >= 2^33) generate their candidates on the matrix
     cores (rows split into bf16 hi + lo on the fly), re-rank them in the reference's summation order and certify the
     result; it must equal the oracle's exact scan -- and the VALU exact-scan kernel -- bit for bit."""
@@ -1023,10 +1023,12 @@ def test_f32_exact_scan_on_matrix_cores_is_bit_exact(orc, hv, monkeypatch, metri
     q[0] = data[3]
     gix.flat_search_batch(q, k)                       # first use loads the kernels: not the run that is timed
     gid, gsc, gcnt, stats = gix.flat_search_batch(q, k)
-    monkeypatch.setenv("HVX_FLAT_VALU", "1")
+    assert gix.last_scan_path() & (hv.PATH_MFMA_128 | hv.PATH_TILE_256)
+    gix.set_option(hv.OPT_FLAT_FORCE_VALU, 1)
     gix.flat_search_batch(q, k)
     vid, vsc, vcnt, vstats = gix.flat_search_batch(q, k)
-    monkeypatch.delenv("HVX_FLAT_VALU")
+    assert gix.last_scan_path() == hv.PATH_VALU
+    gix.set_option(hv.OPT_FLAT_FORCE_VALU, 0)
     assert gid.tolist() == vid.tolist() and bits(gsc).tolist() == bits(vsc).tolist() and gcnt.tolist() == vcnt.tolist()
     print(f"f32 exact scan {b} x {n} x {dim}: MFMA path {stats['device_ms']:.3f} ms, VALU kernel {vstats['device_ms']:.3f} ms")
     if dim == 768:
@@ -1055,7 +1057,7 @@ def test_f32_exact_scan_falls_back_to_the_valu_kernel_on_dense_near_ties(orc, hv
         assert gid[qi].tolist() == oid.tolist() and bits(gsc[qi]).tolist() == bits(osc).tolist()
 
 
-def test_f32_exact_scan_answers_only_the_uncertified_queries_with_the_valu_kernel(orc, hv, monkeypatch, capfd):
+def test_f32_exact_scan_answers_only_the_uncertified_queries_with_the_valu_kernel(orc, hv):
     """A corpus with one blob of 3 000 near-identical rows: queries that land in the blob cannot be certified and are
     re-answered (alone) by the exact VALU scan, the other ~1 000 queries of the batch keep their matrix-core result."""
     rng = np.random.default_rng(21)
@@ -1072,10 +1074,8 @@ def test_f32_exact_scan_answers_only_the_uncertified_queries_with_the_valu_kerne
     hard = [3, 100, 511, 512, 777, 1023]
     for i in hard:
         q[i] = blob + np.float32(0.01) * rng.standard_normal(dim).astype(np.float32)
-    monkeypatch.setenv("HVX_FLAT_DEBUG", "1")
     gid, gsc, gcnt, _ = gix.flat_search_batch(q, k)
-    err = capfd.readouterr().err
-    assert "certificate not reached for 6 of 1024 queries: exact VALU scan for those queries only" in err, err
+    assert gix.last_scan_path() & hv.PATH_VALU_FALLBACK_QUERIES and not gix.last_scan_path() & hv.PATH_VALU  # those queries only
     for qi in hard + [0, 1, 99, 640, 1022]:
         rc, oid, osc = orc.flat_matrix(orc.L2SQ, data, q[qi], k, kernel=orc.K_AVX_FMA_HW)
         assert gcnt[qi] == k and gid[qi].tolist() == oid.tolist(), f"query {qi}"
@@ -1109,7 +1109,7 @@ def test_restricted_scan_over_bf16_and_fp8_rows(orc, hv, dtype_name, metric, dim
             assert bits(gsc[qi, :k]).tolist() == bits(osc).tolist()
 
 
-def test_large_restricted_scan_over_f32_rows_takes_the_matrix_cores(orc, hv, monkeypatch):
+def test_large_restricted_scan_over_f32_rows_takes_the_matrix_cores(orc, hv):
     """A 30 000-candidate restricted scan x 512 queries x 768 dims is above the work threshold: row-list gather on the
     matrix-core pipeline, equal to the VALU kernel and the oracle bit for bit."""
     rng = np.random.default_rng(33)
@@ -1122,8 +1122,10 @@ def test_large_restricted_scan_over_f32_rows_takes_the_matrix_cores(orc, hv, mon
     allowed = np.sort(rng.choice(n, 30000, replace=False)).astype(np.uint64)
     cand = hv.RestrictedVectorCandidates.from_ids(allowed)
     gid, gsc, gcnt = gix.search_restricted_batch(q, hv.SearchParams(k), cand)
-    monkeypatch.setenv("HVX_FLAT_VALU", "1")
+    assert gix.last_scan_path() & (hv.PATH_MFMA_128 | hv.PATH_TILE_256)
+    gix.set_option(hv.OPT_FLAT_FORCE_VALU, 1)
     vid, vsc, vcnt = gix.search_restricted_batch(q, hv.SearchParams(k), cand)
+    assert gix.last_scan_path() == hv.PATH_VALU
     assert gid.tolist() == vid.tolist() and bits(gsc).tolist() == bits(vsc).tolist() and gcnt.tolist() == vcnt.tolist()
     sub = data[allowed.astype(np.int64)]
     for qi in (0, 100, 511):
@@ -1137,7 +1139,7 @@ TILE_CASES = [("bf16", 1, 768, 30000, 10, 300), ("bf16", 0, 256, 20001, 25, 70),
 
 
 @pytest.mark.parametrize("dtype_name,metric,dim,n,k,b", TILE_CASES)
-def test_exact_scan_through_the_256_tile_kernel(orc, hv, monkeypatch, capfd, dtype_name, metric, dim, n, k, b):
+def test_exact_scan_through_the_256_tile_kernel(orc, hv, dtype_name, metric, dim, n, k, b, tile_build=0):
     """Every slice after the first chunk of an exact scan runs on the 256 x 256 filtered kernel (global_load_lds staging,
     swizzled LDS image, fp8 codes widened in registers, f32 rows through their bf16 shadow).  With 2 048-row first chunks
     a small corpus takes several slices (ragged last row tile, padded query tile); the answer must equal the 128 x 128
@@ -1156,15 +1158,13 @@ def test_exact_scan_through_the_256_tile_kernel(orc, hv, monkeypatch, capfd, dty
     q = (centers[rng.integers(0, 32, b)] + 0.5 * rng.standard_normal((b, dim))).astype(np.float32)
     q[0] = data[3]
     q[b - 1, 5] = np.nan                                              # a rejected query in the padded query tile
-    monkeypatch.setenv("HVX_FLAT_CHUNK", "2048")
-    monkeypatch.setenv("HVX_FLAT_DEBUG", "1")
-    capfd.readouterr()
+    gix.set_option(hv.OPT_FLAT_FIRST_CHUNK, 2048)
+    gix.set_option(hv.OPT_FLAT_TILE_BUILD, tile_build)
     gid, gsc, gcnt, _, gst = gix.flat_search_batch(q, k, per_query_status=True)
-    err = capfd.readouterr().err
-    assert "256 x 256 tiles" in err, err                              # the kernel ran
-    monkeypatch.setenv("HVX_FLAT_NO_TILE", "1")
+    assert gix.last_scan_path() & hv.PATH_TILE_256, gix.last_scan_path()   # the kernel ran
+    gix.set_option(hv.OPT_FLAT_NO_TILE, 1)
     oid_, osc_, ocnt_, _, ost_ = gix.flat_search_batch(q, k, per_query_status=True)
-    assert "256 x 256" not in capfd.readouterr().err
+    assert not gix.last_scan_path() & hv.PATH_TILE_256 and gix.last_scan_path() & hv.PATH_MFMA_128
     assert gid.tolist() == oid_.tolist() and bits(gsc).tolist() == bits(osc_).tolist() and gcnt.tolist() == ocnt_.tolist()
     assert gst.tolist() == ost_.tolist() and gst[b - 1] == 2 and not gst[: b - 1].any()
     assert gcnt[b - 1] == 0 and gcnt[0] == k
@@ -1177,14 +1177,13 @@ def test_exact_scan_through_the_256_tile_kernel(orc, hv, monkeypatch, capfd, dty
 
 
 @pytest.mark.parametrize("dtype_name,metric,dim,n,k,b", [TILE_CASES[0], TILE_CASES[2]])
-def test_exact_scan_through_the_512_thread_tile_build(orc, hv, monkeypatch, capfd, dtype_name, metric, dim, n, k, b):
-    """HVX_FLAT_TILE_BUILD=0: the one-workgroup-per-CU build (256 x 256 tiles, two 64-deep LDS buffers) that carries the
-    measurement switches -- same answers as the default build and the oracle."""
-    monkeypatch.setenv("HVX_FLAT_TILE_BUILD", "0")
-    test_exact_scan_through_the_256_tile_kernel(orc, hv, monkeypatch, capfd, dtype_name, metric, dim, n, k, b)
+def test_exact_scan_through_the_512_thread_tile_build(orc, hv, dtype_name, metric, dim, n, k, b):
+    """HVX_OPT_FLAT_TILE_BUILD = 1: the one-workgroup-per-CU build (256 x 256 tiles, two 64-deep LDS buffers; in tuning builds
+    it carries the measurement switches) -- same answers as the default build and the oracle."""
+    test_exact_scan_through_the_256_tile_kernel(orc, hv, dtype_name, metric, dim, n, k, b, tile_build=1)
 
 
-def test_exact_scan_lanes_share_one_bf16_shadow(orc, hv, monkeypatch, capfd):
+def test_exact_scan_lanes_share_one_bf16_shadow(orc, hv):
     """Forked handles (execution lanes) of an f32 index scan through ONE bf16 shadow of the rows, whichever lane builds it."""
     rng = np.random.default_rng(77)
     n, dim, b, k = 30000, 512, 600, 10
@@ -1194,12 +1193,10 @@ def test_exact_scan_lanes_share_one_bf16_shadow(orc, hv, monkeypatch, capfd):
                                               l0_offsets=np.zeros(n + 1, np.uint64), l0_neighbors=np.zeros(0, np.uint64), max_batch=b)
     lane = gix.fork()
     q = (centers[rng.integers(0, 32, b)] + 0.5 * rng.standard_normal((b, dim))).astype(np.float32)
-    monkeypatch.setenv("HVX_FLAT_DEBUG", "1")
-    capfd.readouterr()
     lid, lsc, lcnt, _ = lane.flat_search_batch(q, k)       # the fork builds the shadow ...
-    assert "256 x 256 tiles" in capfd.readouterr().err
+    assert lane.last_scan_path() & hv.PATH_TILE_256
     gid, gsc, gcnt, _ = gix.flat_search_batch(q, k)        # ... the parent finds it
-    assert "256 x 256 tiles" in capfd.readouterr().err
+    assert gix.last_scan_path() & hv.PATH_TILE_256
     assert lid.tolist() == gid.tolist() and bits(lsc).tolist() == bits(gsc).tolist()
     lane.close()
     gid2, gsc2, _, _ = gix.flat_search_batch(q, k)         # and keeps it after the lane is gone
@@ -1209,7 +1206,7 @@ def test_exact_scan_lanes_share_one_bf16_shadow(orc, hv, monkeypatch, capfd):
         assert rc == orc.OK and gid[qi].tolist() == oid.tolist() and bits(gsc[qi]).tolist() == bits(osc).tolist()
 
 
-def test_restricted_scan_through_the_256_tile_kernel(orc, hv, monkeypatch, capfd):
+def test_restricted_scan_through_the_256_tile_kernel(orc, hv):
     """The 256 x 256 kernel gathers its row tile through the candidate row list (restricted scans over bf16 rows)."""
     rng = np.random.default_rng(71)
     n, dim, b, k = 40000, 256, 100, 10
@@ -1223,11 +1220,9 @@ def test_restricted_scan_through_the_256_tile_kernel(orc, hv, monkeypatch, capfd
     q = rng.standard_normal((b, dim)).astype(np.float32)
     allowed = rng.choice(ids, 9001, replace=False)
     cand = hv.RestrictedVectorCandidates.from_ids(allowed)
-    monkeypatch.setenv("HVX_FLAT_CHUNK", "1024")
-    monkeypatch.setenv("HVX_FLAT_DEBUG", "1")
-    capfd.readouterr()
+    gix.set_option(hv.OPT_FLAT_FIRST_CHUNK, 1024)
     gid, gsc, gcnt = gix.search_restricted_batch(q, hv.SearchParams(k), cand)
-    assert "256 x 256 tiles" in capfd.readouterr().err
+    assert gix.last_scan_path() & hv.PATH_TILE_256
     for qi in range(0, b, 7):
         rc, oid, osc = oix.flat(q[qi], k, allowed=allowed)
         assert rc == orc.OK and gid[qi, :k].tolist() == oid.tolist() and bits(gsc[qi, :k]).tolist() == bits(osc).tolist()
@@ -1247,14 +1242,14 @@ def test_two_queries_per_simd_build_equals_oracle(orc, hv, n, dim, metric, m, m0
     assert_hnsw_equal(orc, hv, oix, gix, q, k, ef)
 
 
-def test_two_queries_per_simd_build_spill_path(orc, hv, monkeypatch):
+def test_two_queries_per_simd_build_spill_path(orc, hv):
     """The half-LDS build spills to the HBM bitmap at 7/8 of its (smaller) table: forced with a 256-slot table."""
-    monkeypatch.setenv("HVX_WAVE_LOG2CAP", "8")
     rng = np.random.default_rng(77)
     n, dim = 2500, 128
     data = rng.standard_normal((n, dim)).astype(np.float32)
     oix = build_oracle(orc, data, orc.L2SQ, fx.draw_levels(n, 16, seed=5), efc=80)
     gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=dim, metric=hv.EUCLIDEAN)
+    gix.set_option(hv.OPT_WAVE_LOG2CAP, 8)
     gix.set_occupancy(2)
     q = rng.standard_normal((32, dim)).astype(np.float32)
     assert_hnsw_equal(orc, hv, oix, gix, q, 10, 128)

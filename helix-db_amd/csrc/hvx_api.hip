@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "hvx_host.h"
+#include "hvx_flat_mfma.h"
 
 using namespace hvx;
 
@@ -774,7 +775,12 @@ int hvx::flat_scan_device(hvx_index *ix, const float *d_queries, uint32_t b, uin
         const uint32_t nk = d.dim >> 5;
         const bool shape = d.dim % 32u == 0u && d.ld == d.dim && d.dim_main == d.dim && d.fkernel == kKernelAvxFma &&
                            (nk == 4 || nk == 8 || nk == 16 || nk == 24 || nk == 32 || nk == 48) && (d.metric == kL2 || d.metric == kCosine);
-        if (shape && d.dim >= 256 && k <= 511 && (uint64_t)b * n_rows * d.dim >= (1ull << 33) && !ix->opt[HVX_OPT_FLAT_FORCE_VALU]) {
+        // ... or a small batch (b <= 128) over enough rows (rows x dim >= 2^22) to make it a stream: the one-pass register-resident
+        // kernel (hvx_flat_smallb.hip) reads every row once at HBM speed, where the reference-order VALU kernel below is bound by
+        // the b x rows x dim subtract / FMA pairs (32 queries x 100 000 x 1536: 0.8 ms vs the rows' 0.1 ms of HBM time)
+        const bool big = (uint64_t)b * n_rows * d.dim >= (1ull << 33);
+        const bool small_stream = !ix->opt[HVX_OPT_FLAT_NO_SMALLB] && flat_smallb_supported(d.dim, b, 2) && (uint64_t)n_rows * d.dim >= (1ull << 22);
+        if (shape && d.dim >= 256 && k <= 511 && (big || small_stream) && !ix->opt[HVX_OPT_FLAT_FORCE_VALU]) {
             const int rc = flat_mfma_device(ix, d_queries, b, k, d_subset, n_rows, d_ids, d_scores, d_counts, d_status, timed);
             if (rc != -1) return rc;
             // certificate not reached for some queries: those -- and only those, unless they are many -- are answered

@@ -296,6 +296,91 @@ __global__ __launch_bounds__(256) void flat_select_kernel(FlatArgs a, uint32_t *
     }
 }
 
+// The same selection for ONE long score row per query (the small-batch scan writes the whole [b][candidates] matrix in one
+// launch): grid (b, S), every workgroup keeps the top-k of its slice and appends it to the query's pair list
+// (cand_sc / cand_id / cand_cnt: the inputs of flat_merge_pairs_kernel, which sorts the S x k pairs into the top list).
+__global__ __launch_bounds__(256) void flat_select_slices_kernel(FlatArgs a, uint32_t *status, uint32_t slice_rows, float *cand_sc,
+                                                                 uint32_t *cand_id, uint32_t *cand_cnt, uint32_t cand_cap) {
+    __shared__ float ps[kPool];
+    __shared__ uint32_t pi[kPool];
+    __shared__ uint32_t cnt, bad, base_out;
+    const uint32_t q = blockIdx.x;
+    const int tid = (int)threadIdx.x;
+    const uint32_t k = a.k;
+    const float inf = __uint_as_float(0x7F800000u);
+    if (status && status[q] != 0u) return;
+    for (int i = tid; i < kPool; i += 256) { ps[i] = inf; pi[i] = 0xFFFFFFFFu; }
+    if (tid == 0) { cnt = 0; bad = 0; }
+    __syncthreads();
+    float thr_s = inf;
+    uint32_t thr_i = 0xFFFFFFFFu;
+    const float *dq = a.dist + (size_t)q * a.chunk_ld;
+    const uint32_t lo = blockIdx.y * slice_rows, hi = lo + slice_rows < a.rows ? lo + slice_rows : a.rows;
+    const bool vec_ok = (a.chunk_ld & 3u) == 0u;
+    for (uint32_t base = lo; base < hi; base += 1024) {
+        const uint32_t i0 = base + (uint32_t)tid * 4u;
+        float d4[4] = {inf, inf, inf, inf};
+        if (vec_ok && i0 + 3 < hi) {
+            const float4 v = *reinterpret_cast<const float4 *>(dq + i0);
+            d4[0] = v.x; d4[1] = v.y; d4[2] = v.z; d4[3] = v.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (i0 + e < hi) d4[e] = dq[i0 + e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t i = i0 + (uint32_t)e;
+            if (i < hi) {
+                float d = d4[e];
+                const uint32_t scan = a.row0 + i;
+                const uint32_t node = a.subset ? a.subset[scan] : scan;
+                if (!score_valid(d)) {
+                    bad = 1;
+                } else if (pair_less(d, node, thr_s, thr_i)) {
+                    uint32_t slot = atomicAdd(&cnt, 1u);
+                    ps[slot] = d;
+                    pi[slot] = node;
+                }
+            }
+        }
+        __syncthreads();
+        if (cnt > (uint32_t)(kPool / 2)) {
+            bitonic_sort_pool(ps, pi, tid);
+            const uint32_t keep = cnt < k ? cnt : k;
+            for (int t = tid; t < kPool; t += 256)
+                if ((uint32_t)t >= keep) { ps[t] = inf; pi[t] = 0xFFFFFFFFu; }
+            __syncthreads();
+            if (tid == 0) cnt = keep;
+            if (keep >= k) { thr_s = ps[k - 1]; thr_i = pi[k - 1]; }
+            __syncthreads();
+        }
+    }
+    bitonic_sort_pool(ps, pi, tid);
+    const uint32_t keep = cnt < k ? cnt : k;
+    if (tid == 0) {
+        base_out = atomicAdd(&cand_cnt[q], keep);
+        if (bad && status && status[q] == 0u) status[q] = 8u; // HVX_ERR_INVARIANT
+    }
+    __syncthreads();
+    for (uint32_t t = (uint32_t)tid; t < keep; t += 256)
+        if (base_out + t < cand_cap) {
+            cand_sc[(size_t)q * cand_cap + base_out + t] = ps[t];
+            cand_id[(size_t)q * cand_cap + base_out + t] = pi[t];
+        }
+}
+
+hipError_t launch_flat_select_slices(const FlatArgs &a, uint32_t slices, float *cand_sc, uint32_t *cand_id, uint32_t *cand_cnt, uint32_t cand_cap,
+                                     hipStream_t s) {
+    if (a.b == 0 || slices == 0) return hipSuccess;
+    uint32_t slice_rows = ((a.rows + slices - 1) / slices + 1023u) / 1024u * 1024u;
+    if (slice_rows == 0) slice_rows = 1024;
+    const uint32_t used = (a.rows + slice_rows - 1) / slice_rows;
+    hipLaunchKernelGGL(flat_select_slices_kernel, dim3(a.b, used ? used : 1), dim3(256), 0, s, a, const_cast<uint32_t *>(a.qstatus), slice_rows, cand_sc,
+                       cand_id, cand_cnt, cand_cap);
+    return hipGetLastError();
+}
+
 static uint32_t *g_unused_status = nullptr;
 
 hipError_t launch_flat_select(const FlatArgs &a, hipStream_t s) {

@@ -37,6 +37,10 @@ struct MfmaArgs {
 // build: 0 = two 256-thread workgroups per CU (256 x 128 tiles), 1 = one 512-thread workgroup per CU (256 x 256 tiles)
 hipError_t launch_flat_tile256(const MfmaArgs &a, int kind, uint32_t bpad, float xmax2, uint32_t *wg_overflow, uint32_t build, hipStream_t s);
 
+// one-pass score matrix for small batches (hvx_flat_smallb.hip): b <= 128 queries, kind 0 = bf16 rows / shadow, 2 = f32 rows
+bool flat_smallb_supported(uint32_t dim, uint32_t b, int kind);
+hipError_t launch_flat_smallb(const MfmaArgs &a, int kind, uint32_t cus, hipStream_t s);
+
 // position of stored code `slot` (its index in the fp8 row) in the query operand of the 256 x 256 fp8 kernel: inside a
 // 64-code stage, MFMA step kk (0..3), lane half h, element e read code (2 (kk >> 1) + h) * 16 + (kk & 1) * 8 + e, so one
 // ds_read_b128 of the code tile feeds two steps.

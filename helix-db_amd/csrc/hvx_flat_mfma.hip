@@ -625,22 +625,27 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
     const bool debug = tuning_env("HVX_FLAT_DEBUG") != nullptr;
     const bool allow_fast = !ix->opt[HVX_OPT_FLAT_NO_FAST];
     const bool no_filter = ix->opt[HVX_OPT_FLAT_NO_FILTER] != 0;
-    ix->last_scan_path = 0;
+    if (allow_filter) ix->last_scan_path = 0; // (the unfiltered repeat after a pair overflow keeps the first pass's flags)
     constexpr uint32_t kCandCap = 1024;
     for (int attempt = allow_fast ? 0 : 1; attempt < 3; ++attempt) {
         const bool full = attempt >= 1;
         const uint32_t m = attempt == 2 ? 1023u : m0;
         if (attempt == 2 && m0 >= 1023u) break;
         const uint32_t kc = m + 1;
+        // small batches (b <= 128): ONE pass over the rows with the register-resident kernel of hvx_flat_smallb.hip writes the
+        // whole [b][n] score matrix; sliced selection + pair merge replace the chunk loop.  One-pass attempt only.
+        const int sb_kind = f32 ? (ix->m_shadow ? 0 : 2) : (fp8 ? 1 : 0);
+        const bool smallb = attempt == 0 && !ix->opt[HVX_OPT_FLAT_NO_SMALLB] && flat_smallb_supported(d.dim, b, sb_kind) &&
+                            (size_t)((n + 3u) & ~3u) * b * 4 <= (512u << 20) && kc <= 1024u;
         // first chunk (scored by the 128 x 128 kernel into the score matrix, top-(m + 1) selected from it): 16 384 rows when the
         // large-tile filtered slices follow (1024 x 1M x 768: 2.43 ms vs 2.59 with 65 536), 65 536 as before otherwise
         uint32_t chunk = tile_ok && !full && allow_filter && m + 1 <= 256u && !no_filter ? 16384u : 65536u;
         if (ix->opt[HVX_OPT_FLAT_FIRST_CHUNK]) chunk = std::max<uint32_t>(1024u, ix->opt[HVX_OPT_FLAT_FIRST_CHUNK] / 1024u * 1024u); // tests: small first chunks
         while ((size_t)chunk * b * 4 > (512u << 20) && chunk > 1024) chunk >>= 1;
-        if (chunk > n) chunk = (n + 3u) & ~3u;
+        if (chunk > n || smallb) chunk = (n + 3u) & ~3u;
         if ((rc = ix->flat_scratch(b, kc, chunk))) return rc;
         const bool filt = allow_filter && kc <= 256u && n > chunk && !no_filter;
-        if (filt && ix->cap_cand < (size_t)bpad) {
+        if ((filt || smallb) && ix->cap_cand < (size_t)bpad) {
             if ((rc = ix->regrow((void **)&ix->m_thr, (size_t)bpad * 4))) return rc;
             if ((rc = ix->regrow((void **)&ix->m_csc, (size_t)bpad * kCandCap * 4))) return rc;
             if ((rc = ix->regrow((void **)&ix->m_cid, (size_t)bpad * kCandCap * 4))) return rc;
@@ -648,7 +653,7 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
             ix->cap_cand = bpad;
         }
         HIP_TRY(hipMemsetAsync(ix->f_top_c, 0, (size_t)b * 4, ix->stream));
-        if (filt) HIP_TRY(hipMemsetAsync(ix->m_ccnt, 0, (size_t)bpad * 4 + 4, ix->stream));
+        if (filt || smallb) HIP_TRY(hipMemsetAsync(ix->m_ccnt, 0, (size_t)bpad * 4 + 4, ix->stream));
         FlatArgs fa;
         fa.ix = d; fa.queries = d_queries; fa.qstatus = ix->d_qstatus; fa.qhdr = ix->d_qhdr; fa.subset = d_subset;
         fa.n_rows = n; fa.dist = ix->f_dist; fa.chunk_ld = chunk; fa.b = b; fa.k = kc;
@@ -685,6 +690,21 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
         pm.kc = kc; pm.cap = kCandCap;
         uint32_t r0 = 0;
         bool used_tile = false;
+        if (smallb) {
+            MfmaArgs sa = ma;
+            sa.row0 = 0; sa.nrows = n;
+            if (f32 && sb_kind == 0) sa.rows = ix->m_shadow; // the bf16 shadow, once some large scan has built it: half the bytes
+            int cus = 256;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ix->device);
+            HIP_TRY(launch_flat_smallb(sa, sb_kind, (uint32_t)cus, ix->stream));
+            fa.row0 = 0; fa.rows = n;
+            const uint32_t slices = std::max<uint32_t>(1u, std::min<uint32_t>(16u, kCandCap / kc));
+            HIP_TRY(launch_flat_select_slices(fa, slices, ix->m_csc, ix->m_cid, ix->m_ccnt, kCandCap, ix->stream));
+            hipLaunchKernelGGL(flat_merge_pairs_kernel, dim3(b), dim3(256), 0, ix->stream, pm);
+            HIP_TRY(hipGetLastError());
+            r0 = n;
+            ix->last_scan_path |= HVX_PATH_SMALL_BATCH;
+        }
         while (r0 < n) {
             if (filt && r0 > 0) {
                 // thresholds are those of the rows seen so far: a slice three times that long lets ~3 (m + 1) pairs per query through
@@ -727,18 +747,19 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
         std::vector<uint32_t> cert(b);
         uint32_t overflow = 0;
         HIP_TRY(hipMemcpyAsync(cert.data(), ix->m_cert, (size_t)b * 4, hipMemcpyDeviceToHost, ix->stream));
-        if (filt) HIP_TRY(hipMemcpyAsync(&overflow, ix->m_ccnt + bpad, 4, hipMemcpyDeviceToHost, ix->stream));
+        if (filt || smallb) HIP_TRY(hipMemcpyAsync(&overflow, ix->m_ccnt + bpad, 4, hipMemcpyDeviceToHost, ix->stream));
         HIP_TRY(hipStreamSynchronize(ix->stream));
         uint32_t failed = 0, first = 0;
         for (uint32_t i = 0; i < b; ++i)
             if (!cert[i]) { if (!failed) first = i; ++failed; }
-        ix->last_scan_path |= (used_tile ? HVX_PATH_TILE_256 : HVX_PATH_MFMA_128) | (filt ? HVX_PATH_FILTERED : 0u) | (full ? HVX_PATH_FULL_SPLIT : 0u) |
+        ix->last_scan_path |= (smallb ? 0u : (used_tile ? HVX_PATH_TILE_256 : HVX_PATH_MFMA_128)) | (filt ? HVX_PATH_FILTERED : 0u) | (full ? HVX_PATH_FULL_SPLIT : 0u) |
                               (attempt == 2 ? HVX_PATH_WIDENED : 0u);
         if (debug)
             fprintf(stderr, "[hvx flat] attempt %d (%s contraction, m = %u%s%s): %u of %u certificates missing%s\n", attempt,
                     full ? "full" : "one-pass", m, filt ? ", filtered epilogue" : "", used_tile ? ", 256 x 256 tiles" : "", failed, b,
                     overflow ? ", PAIR OVERFLOW" : "");
         if (overflow) { // a query produced more pairs than the buffer holds: its list is incomplete -- never guess
+            ix->last_scan_path |= HVX_PATH_PAIR_OVERFLOW_REPEAT;
             return flat_mfma_impl(ix, d_queries, b, k, d_subset, n_rows, d_ids, d_scores, d_counts, d_status, timed, false);
         }
         if (!failed) return HVX_OK;

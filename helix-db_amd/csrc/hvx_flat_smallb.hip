@@ -1,0 +1,170 @@
+// hvx_flat_smallb.hip -- candidate generation of the exact scan for SMALL query batches (b <= 128) in ONE pass over the rows.
+//
+// Where it sits: restricted_exact_scan (crates/db/src/search/vector/restricted.rs:753-835) over a prefiltered candidate set
+// is the common shape of BASELINE config #3: a handful of queries (the benchmark issues them one at a time; 32 share a
+// batch here) against 10^3..10^6 candidate rows.  With so few queries the scan is a pure stream: every candidate row has
+// to cross HBM once and nothing else is big.  The 128 x 128 / 256 x 256 contraction kernels are built for large batches:
+// they pad the batch to their query tile, stage both operands through LDS behind barriers, and the filtered pipeline
+// around them needs 8-10 launches -- 0.10 of the HBM roofline on the 100 000-candidate group.
+//
+// This kernel: one wavefront owns 32 candidate rows at a time and keeps them in REGISTERS -- lane l reads 8 consecutive
+// stored elements of row (l & 31), depth half (l >> 5), which is exactly the B-operand layout of v_mfma_f32_32x32x16_bf16
+// (f32 rows are rounded to bf16 in registers: the one-pass contraction's rounding, covered by the certificate's bound);
+// the queries (bf16 hi parts, <= 4 tiles of 32) sit in LDS once per workgroup, padded so that the A-operand
+// ds_read_b128 is conflict-free.  No barrier after the query tile is staged, no LDS traffic for the rows, the next group
+// of row loads is issued before the current group's MFMAs.  16 wavefronts per CU x 8-16 KB in flight each.  The epilogue
+// writes the [b][candidates] score matrix (b x 4 bytes per row against dim x 4 bytes read: 2 % at b = 32, dim = 1536).
+// Selection (flat_select_slices: grid b x S), merge, exact re-rank and certificate are the scan's usual tail.
+// Algorithmic bytes per launch = candidates x dim x sizeof(row element).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "hvx_device.h"
+#include "hvx_flat_mfma.h"
+
+namespace hvx {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// KIND 0: bf16 rows (a bf16 index, or the bf16 shadow of an f32 index), 2: f32 rows.  NQT: 32-query tiles held in LDS.
+// WAVES: wavefronts per workgroup = per CU (the query tile fills most of the LDS): 16 (128 registers each) for one tile,
+// 8 (256 registers) when 2 or 4 accumulator tiles are live.  U: MFMA steps (16 deep each) per register group.
+template <int KIND, int NQT, int WAVES, int U>
+__global__ __launch_bounds__(WAVES * 64) void flat_smallb_kernel(MfmaArgs a, uint32_t n_blocks, uint32_t lds_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char qlds[];
+    constexpr bool F32 = KIND == 2;
+    constexpr int kSmallbWaves = WAVES;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t fr = lane & 31u, half = lane >> 5;
+    // the query tile(s): [NQT * 32][dim] bf16, rows padded by 16 bytes
+    const uint32_t vec_per_row = a.dim / 8u;
+    for (uint32_t i = tid; i < (uint32_t)NQT * 32u * vec_per_row; i += kSmallbWaves * 64) {
+        const uint32_t r = i / vec_per_row, c = i - r * vec_per_row;
+        *reinterpret_cast<uint4 *>(qlds + (size_t)r * lds_stride + c * 16u) = *reinterpret_cast<const uint4 *>(a.qhi + (size_t)r * a.dim + c * 8u);
+    }
+    __syncthreads();
+    const unsigned char *qa = qlds + (size_t)fr * lds_stride + half * 16u; // this lane's A fragment of tile 0, step 0
+    const uint32_t ngroups = a.dim / (16u * U);
+    struct Group {
+        uint4 v[U][F32 ? 2 : 1];
+    };
+    for (uint32_t blk = blockIdx.x * kSmallbWaves + wave; blk < n_blocks; blk += gridDim.x * kSmallbWaves) {
+        const uint32_t rloc = blk * 32u + fr;
+        const uint32_t rcl = rloc < a.nrows ? rloc : a.nrows - 1u; // the ragged tail re-reads the last row; masked below
+        const size_t node = a.subset ? a.subset[a.row0 + rcl] : a.row0 + rcl;
+        const unsigned char *rp = reinterpret_cast<const unsigned char *>(a.rows) + node * a.dim * (F32 ? 4u : 2u) + half * (F32 ? 32u : 16u);
+        auto load_group = [&](Group &g, uint32_t grp) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned char *p = rp + (size_t)(grp * U + u) * (F32 ? 64u : 32u);
+                g.v[u][0] = *reinterpret_cast<const uint4 *>(p);
+                if (F32) g.v[u][F32 ? 1 : 0] = *reinterpret_cast<const uint4 *>(p + 16);
+            }
+        };
+        f32x16 acc[NQT];
+#pragma unroll
+        for (int t = 0; t < NQT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+        auto compute_group = [&](const Group &g, uint32_t grp) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                uint4 bw;
+                if (F32) {
+                    const uint4 x0 = g.v[u][0], x1 = g.v[u][F32 ? 1 : 0];
+                    bw.x = (uint32_t)f32_to_bf16_rne(__uint_as_float(x0.x)) | ((uint32_t)f32_to_bf16_rne(__uint_as_float(x0.y)) << 16);
+                    bw.y = (uint32_t)f32_to_bf16_rne(__uint_as_float(x0.z)) | ((uint32_t)f32_to_bf16_rne(__uint_as_float(x0.w)) << 16);
+                    bw.z = (uint32_t)f32_to_bf16_rne(__uint_as_float(x1.x)) | ((uint32_t)f32_to_bf16_rne(__uint_as_float(x1.y)) << 16);
+                    bw.w = (uint32_t)f32_to_bf16_rne(__uint_as_float(x1.z)) | ((uint32_t)f32_to_bf16_rne(__uint_as_float(x1.w)) << 16);
+                } else {
+                    bw = g.v[u][0];
+                }
+                const bf16x8 fb = __builtin_bit_cast(bf16x8, bw);
+                const uint32_t koff = (grp * U + (uint32_t)u) * 32u; // bytes of bf16 depth before this step
+#pragma unroll
+                for (int t = 0; t < NQT; ++t) {
+                    const bf16x8 fa = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(qa + (size_t)t * 32u * lds_stride + koff));
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
+                }
+            }
+        };
+        // two register groups: group g + 1 is requested before group g is consumed
+        Group g0, g1;
+        load_group(g0, 0);
+        for (uint32_t grp = 0; grp < ngroups; grp += 2) {
+            if (grp + 1 < ngroups) load_group(g1, grp + 1);
+            compute_group(g0, grp);
+            if (grp + 1 < ngroups) {
+                if (grp + 2 < ngroups) load_group(g0, grp + 2);
+                compute_group(g1, grp + 1);
+            }
+        }
+        // epilogue: C[m = query][n = row]; lane holds n = lane & 31, m = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+        if (rloc < a.nrows) {
+            const float term = a.rowterm[node];
+#pragma unroll
+            for (int t = 0; t < NQT; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const uint32_t qq = (uint32_t)t * 32u + (uint32_t)(e & 3) + 8u * (uint32_t)(e >> 2) + 4u * half;
+                    if (qq >= a.b) continue;
+                    const float dot = acc[t][e];
+                    float s;
+                    if (a.metric == kL2) {
+                        s = (a.qn2[qq] + term) - 2.0f * dot;
+                        s = s < 0.f ? 0.f : s;
+                    } else {
+                        const float den = sqrtf(a.qn2[qq]) * term;
+                        float c = den > 0.f ? dot / den : 0.f;
+                        c = c < -1.f ? -1.f : (c > 1.f ? 1.f : c);
+                        s = (1.0f - c) * 0.5f;
+                    }
+                    a.dist[(size_t)qq * a.chunk_ld + rloc] = s;
+                }
+        }
+    }
+}
+
+bool flat_smallb_supported(uint32_t dim, uint32_t b, int kind) {
+    if (kind != 0 && kind != 2) return false;
+    if (b == 0 || b > 128u || dim % 64u != 0u) return false;
+    const uint32_t nqt = (b + 31u) / 32u;
+    const uint32_t tiles = nqt == 3 ? 4u : nqt;
+    return (size_t)tiles * 32u * ((size_t)dim * 2u + 16u) <= 150u * 1024u; // the query tile(s) stay in LDS for the whole launch
+}
+
+template <int KIND, int NQT>
+static hipError_t launch_smallb_t(const MfmaArgs &a, uint32_t n_blocks, uint32_t cus, hipStream_t s) {
+    constexpr int kSmallbWaves = NQT == 1 ? 16 : 8;
+    constexpr int U = (KIND == 2 && NQT != 2) ? 2 : 4;
+    const uint32_t stride = a.dim * 2u + 16u;
+    const size_t lds = (size_t)NQT * 32u * stride;
+    auto kern = flat_smallb_kernel<KIND, NQT, kSmallbWaves, U>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(cus, (n_blocks + kSmallbWaves - 1) / kSmallbWaves));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kSmallbWaves * 64), lds, s, a, n_blocks, stride);
+    return hipGetLastError();
+}
+
+// scores of rows [a.row0, a.row0 + a.nrows) of the scan order against a.b <= 128 queries into a.dist (row length a.chunk_ld)
+hipError_t launch_flat_smallb(const MfmaArgs &a, int kind, uint32_t cus, hipStream_t s) {
+    if (a.nrows == 0) return hipSuccess;
+    if (!flat_smallb_supported(a.dim, a.b, kind)) return hipErrorInvalidValue;
+    const uint32_t n_blocks = (a.nrows + 31u) / 32u;
+    const uint32_t nqt = (a.b + 31u) / 32u;
+    if (kind == 2) {
+        if (nqt == 1) return launch_smallb_t<2, 1>(a, n_blocks, cus, s);
+        if (nqt == 2) return launch_smallb_t<2, 2>(a, n_blocks, cus, s);
+        return launch_smallb_t<2, 4>(a, n_blocks, cus, s);
+    }
+    if (nqt == 1) return launch_smallb_t<0, 1>(a, n_blocks, cus, s);
+    if (nqt == 2) return launch_smallb_t<0, 2>(a, n_blocks, cus, s);
+    return launch_smallb_t<0, 4>(a, n_blocks, cus, s);
+}
+
+} // namespace hvx

@@ -104,6 +104,9 @@ struct FlatArgs {
 };
 hipError_t launch_flat_distances(const FlatArgs &a, hipStream_t s);
 hipError_t launch_flat_select(const FlatArgs &a, hipStream_t s);
+// selection over ONE long score row per query, S slices per query; appends every slice's top-k to the query's pair list
+hipError_t launch_flat_select_slices(const FlatArgs &a, uint32_t slices, float *cand_sc, uint32_t *cand_id, uint32_t *cand_cnt, uint32_t cand_cap,
+                                     hipStream_t s);
 hipError_t launch_flat_finish(const FlatArgs &a, uint64_t *out_ids, float *out_scores, uint32_t *out_counts,
                               uint32_t *out_status, hipStream_t s);
 

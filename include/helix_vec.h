@@ -126,13 +126,16 @@ enum hvx_option {
     HVX_OPT_FLAT_NO_FILTER = 5,      /* 1: no filtered epilogue (every chunk writes its score matrix) */
     HVX_OPT_FLAT_NO_FAST = 6,        /* 1: start with the full hi + lo split */
     HVX_OPT_FLAT_TILE_BUILD = 7,     /* large-tile kernel: 0 = two 256-thread workgroups per CU (256 x 128), 1 = one 512-thread (256 x 256) */
-    HVX_OPT_COUNT = 8
+    HVX_OPT_FLAT_NO_SMALLB = 8,      /* 1: batches of <= 128 queries do not take the one-pass register-resident kernel */
+    HVX_OPT_COUNT = 9
 };
 int hvx_index_set_option(hvx_index *, uint32_t option, uint32_t value);
 /* which kernels the handle's last exact scan ran (bit flags) */
 enum hvx_scan_path {
     HVX_PATH_VALU = 1, HVX_PATH_MFMA_128 = 2, HVX_PATH_TILE_256 = 4, HVX_PATH_FILTERED = 8, HVX_PATH_FULL_SPLIT = 16,
-    HVX_PATH_VALU_FALLBACK_QUERIES = 32, HVX_PATH_WIDENED = 64
+    HVX_PATH_VALU_FALLBACK_QUERIES = 32, HVX_PATH_WIDENED = 64,
+    HVX_PATH_SMALL_BATCH = 256,       /* the one-pass small-batch kernel (hvx_flat_smallb.hip) produced the candidates */
+    HVX_PATH_PAIR_OVERFLOW_REPEAT = 128 /* a filtered slice let more pairs through than its buffer holds: the scan was repeated unfiltered */
 };
 uint32_t hvx_index_last_scan_path(const hvx_index *);
 /* HNSW kernel build used by this handle: 1 (default) = one query per SIMD with the SIMD's whole register file (lowest

@@ -1023,7 +1023,7 @@ def test_f32_exact_scan_on_matrix_cores_is_bit_exact(orc, hv, metric, dim, n, k,
     q[0] = data[3]
     gix.flat_search_batch(q, k)                       # first use loads the kernels: not the run that is timed
     gid, gsc, gcnt, stats = gix.flat_search_batch(q, k)
-    assert gix.last_scan_path() & (hv.PATH_MFMA_128 | hv.PATH_TILE_256)
+    assert gix.last_scan_path() & (hv.PATH_MFMA_128 | hv.PATH_TILE_256 | hv.PATH_SMALL_BATCH)
     gix.set_option(hv.OPT_FLAT_FORCE_VALU, 1)
     gix.flat_search_batch(q, k)
     vid, vsc, vcnt, vstats = gix.flat_search_batch(q, k)
@@ -1122,7 +1122,7 @@ def test_large_restricted_scan_over_f32_rows_takes_the_matrix_cores(orc, hv):
     allowed = np.sort(rng.choice(n, 30000, replace=False)).astype(np.uint64)
     cand = hv.RestrictedVectorCandidates.from_ids(allowed)
     gid, gsc, gcnt = gix.search_restricted_batch(q, hv.SearchParams(k), cand)
-    assert gix.last_scan_path() & (hv.PATH_MFMA_128 | hv.PATH_TILE_256)
+    assert gix.last_scan_path() & (hv.PATH_MFMA_128 | hv.PATH_TILE_256 | hv.PATH_SMALL_BATCH)
     gix.set_option(hv.OPT_FLAT_FORCE_VALU, 1)
     vid, vsc, vcnt = gix.search_restricted_batch(q, hv.SearchParams(k), cand)
     assert gix.last_scan_path() == hv.PATH_VALU
@@ -1162,6 +1162,10 @@ def test_exact_scan_through_the_256_tile_kernel(orc, hv, dtype_name, metric, dim
     gix.set_option(hv.OPT_FLAT_TILE_BUILD, tile_build)
     gid, gsc, gcnt, _, gst = gix.flat_search_batch(q, k, per_query_status=True)
     assert gix.last_scan_path() & hv.PATH_TILE_256, gix.last_scan_path()   # the kernel ran
+    if gix.last_scan_path() & hv.PATH_PAIR_OVERFLOW_REPEAT:                # (a 2 048-row first chunk gives loose thresholds: a slice may
+        gix.set_option(hv.OPT_FLAT_FIRST_CHUNK, 8192)                       #  overflow its pair buffer and be repeated unfiltered --
+        gid, gsc, gcnt, _, gst = gix.flat_search_batch(q, k, per_query_status=True)   # then check the tile kernel's OWN answer too)
+        assert gix.last_scan_path() & hv.PATH_TILE_256 and not gix.last_scan_path() & hv.PATH_PAIR_OVERFLOW_REPEAT, gix.last_scan_path()
     gix.set_option(hv.OPT_FLAT_NO_TILE, 1)
     oid_, osc_, ocnt_, _, ost_ = gix.flat_search_batch(q, k, per_query_status=True)
     assert not gix.last_scan_path() & hv.PATH_TILE_256 and gix.last_scan_path() & hv.PATH_MFMA_128
@@ -1434,3 +1438,74 @@ def test_shard_group_runs_search_allgather_merge_in_one_call(orc, hv):
         grp.search_batch_device(dq, 17, 64, ids, sc, cnt)  # k beyond the group's max_k
     grp.close()
     lane.close()
+
+
+# --- the one-pass small-batch exact scan (hvx_flat_smallb.hip): b <= 128 queries, rows held in registers ---
+@pytest.mark.parametrize("dtype_name,metric,dim,n,k,b", [("f32", 1, 1536, 9000, 10, 32), ("f32", 0, 768, 20011, 10, 7), ("f32", 1, 256, 40000, 25, 64),
+                                                         ("f32", 1, 512, 30000, 10, 100), ("f32", 1, 256, 33000, 100, 128), ("f32", 1, 768, 6001, 10, 1),
+                                                         ("bf16", 1, 768, 20000, 10, 33), ("bf16", 0, 1536, 5000, 10, 32), ("bf16", 1, 256, 9000, 10, 128)])
+def test_small_batch_exact_scan_is_bit_exact(orc, hv, dtype_name, metric, dim, n, k, b):
+    """Batches of <= 128 queries over >= 2^22 row elements take the register-resident one-pass kernel (candidates) + sliced
+    selection + exact re-rank + certificate: ids and score bits equal the oracle's exact scan and the VALU kernel's, for whole
+    scans and restricted (row-list) scans, ragged row counts, a rejected query and a duplicate row."""
+    rng = np.random.default_rng(dim + n + b)
+    centers = rng.standard_normal((32, dim)).astype(np.float32)
+    data = (centers[rng.integers(0, 32, n)] + 0.5 * rng.standard_normal((n, dim))).astype(np.float32)
+    data[7] = data[3]
+    stored = fx.round_bf16(data) if dtype_name == "bf16" else data
+    ids = np.arange(n, dtype=np.uint64) + 11
+    gix = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=metric, node_ids=ids, vectors=data, dtype=hv.BF16 if dtype_name == "bf16" else hv.F32,
+                                              l0_offsets=np.zeros(n + 1, np.uint64), l0_neighbors=np.zeros(0, np.uint64), max_batch=max(b, 16))
+    q = (centers[rng.integers(0, 32, b)] + 0.5 * rng.standard_normal((b, dim))).astype(np.float32)
+    q[0] = data[3]
+    if b > 2:
+        q[b - 1, 5] = np.nan
+    gid, gsc, gcnt, _, gst = gix.flat_search_batch(q, k, per_query_status=True)
+    assert gix.last_scan_path() & hv.PATH_SMALL_BATCH, gix.last_scan_path()
+    kern = {"kernel": orc.K_AVX_FMA_HW} if dtype_name == "f32" else {}
+    for qi in range(b):
+        if b > 2 and qi == b - 1:
+            assert gst[qi] == hv.ERR_NONFINITE and gcnt[qi] == 0
+            continue
+        rc, oid, osc = orc.flat_matrix(metric, stored, q[qi], k, **kern)
+        assert gst[qi] == 0 and (gid[qi, :gcnt[qi]] - 11).tolist() == oid.tolist(), f"query {qi}"
+        assert bits(gsc[qi, :gcnt[qi]]).tolist() == bits(osc).tolist()
+    assert sorted((gid[0, :2] - 11).tolist()) == [3, 7]
+    # the same through the other kernels of this handle
+    gix.set_option(hv.OPT_FLAT_NO_SMALLB, 1)
+    oid_, osc_, ocnt_, _, ost_ = gix.flat_search_batch(q, k, per_query_status=True)
+    assert not gix.last_scan_path() & hv.PATH_SMALL_BATCH
+    assert gid.tolist() == oid_.tolist() and bits(gsc).tolist() == bits(osc_).tolist() and gcnt.tolist() == ocnt_.tolist() and gst.tolist() == ost_.tolist()
+    gix.set_option(hv.OPT_FLAT_NO_SMALLB, 0)
+    # restricted: a candidate row list (ragged length, not a multiple of 32)
+    allowed = np.sort(rng.choice(ids, min(n - 5, max(2 ** 22 // dim + 77, 3001)), replace=False))
+    good = q[: max(1, b - 1)] if b > 2 else q
+    rid, rsc, rcnt = gix.search_restricted_batch(good, hv.SearchParams(k), hv.RestrictedVectorCandidates.from_ids(allowed))
+    assert gix.last_scan_path() & hv.PATH_SMALL_BATCH
+    sub = stored[(allowed - 11).astype(np.int64)]
+    for qi in range(0, good.shape[0], max(1, good.shape[0] // 8)):
+        rc, oid, osc = orc.flat_matrix(metric, sub, good[qi], k, **kern)
+        assert allowed[oid.astype(np.int64)].tolist() == rid[qi, :rcnt[qi]].tolist() and bits(osc).tolist() == bits(rsc[qi, :rcnt[qi]]).tolist()
+
+
+def test_small_batch_scan_uses_the_bf16_shadow_once_it_exists(orc, hv):
+    """An f32 index whose image already holds the bf16 shadow of its rows (built by an earlier large scan) streams the shadow --
+    half the bytes -- in the small-batch kernel too; same answers."""
+    rng = np.random.default_rng(99)
+    n, dim, k = 30000, 512, 10
+    centers = rng.standard_normal((32, dim)).astype(np.float32)
+    data = (centers[rng.integers(0, 32, n)] + 0.5 * rng.standard_normal((n, dim))).astype(np.float32)
+    gix = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=hv.EUCLIDEAN, node_ids=np.arange(n, dtype=np.uint64), vectors=data,
+                                              l0_offsets=np.zeros(n + 1, np.uint64), l0_neighbors=np.zeros(0, np.uint64), max_batch=600)
+    qs = (centers[rng.integers(0, 32, 24)] + 0.5 * rng.standard_normal((24, dim))).astype(np.float32)
+    a_id, a_sc, a_cnt, _ = gix.flat_search_batch(qs, k)                # f32 rows
+    assert gix.last_scan_path() & hv.PATH_SMALL_BATCH
+    qb = (centers[rng.integers(0, 32, 600)] + 0.5 * rng.standard_normal((600, dim))).astype(np.float32)
+    gix.flat_search_batch(qb, k)                                        # a large scan builds the shadow
+    assert gix.last_scan_path() & hv.PATH_TILE_256
+    b_id, b_sc, b_cnt, _ = gix.flat_search_batch(qs, k)                # now the shadow
+    assert gix.last_scan_path() & hv.PATH_SMALL_BATCH
+    assert a_id.tolist() == b_id.tolist() and bits(a_sc).tolist() == bits(b_sc).tolist()
+    for qi in range(0, 24, 5):
+        rc, oid, osc = orc.flat_matrix(orc.L2SQ, data, qs[qi], k, kernel=orc.K_AVX_FMA_HW)
+        assert a_id[qi].tolist() == oid.tolist() and bits(a_sc[qi]).tolist() == bits(osc).tolist()

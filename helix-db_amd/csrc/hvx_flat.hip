@@ -216,6 +216,25 @@ __device__ inline void bitonic_sort_pool(float *ps, uint32_t *pi, int tid) {
     __syncthreads();
 }
 
+// the same over the first n (a power of two <= kPool) pool entries
+__device__ inline void bitonic_sort_pool_n(float *ps, uint32_t *pi, int tid, int n) {
+    for (int size = 2; size <= n; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = tid; t < n / 2; t += 256) {
+                int lo = 2 * t - (t & (stride - 1));
+                int hi = lo + stride;
+                bool up = ((lo & size) == 0);
+                float sl = ps[lo], sh = ps[hi];
+                uint32_t il = pi[lo], ih = pi[hi];
+                bool sw = up ? pair_less(sh, ih, sl, il) : pair_less(sl, il, sh, ih);
+                if (sw) { ps[lo] = sh; ps[hi] = sl; pi[lo] = ih; pi[hi] = il; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void flat_select_kernel(FlatArgs a, uint32_t *status) {
     __shared__ float ps[kPool];
     __shared__ uint32_t pi[kPool];
@@ -345,10 +364,14 @@ __global__ __launch_bounds__(256) void flat_select_slices_kernel(FlatArgs a, uin
             }
         }
         __syncthreads();
-        if (cnt > (uint32_t)(kPool / 2)) {
-            bitonic_sort_pool(ps, pi, tid);
-            const uint32_t keep = cnt < k ? cnt : k;
-            for (int t = tid; t < kPool; t += 256)
+        const uint32_t have = cnt;
+        // sort (only the filled part of the pool) as soon as k entries can give a threshold, and whenever the pool is half full
+        if (have > (uint32_t)(kPool / 2) || (have >= k && thr_i == 0xFFFFFFFFu && thr_s == inf)) {
+            int np = 2;
+            while ((uint32_t)np < have) np <<= 1;
+            bitonic_sort_pool_n(ps, pi, tid, np);
+            const uint32_t keep = have < k ? have : k;
+            for (int t = tid; t < np; t += 256)
                 if ((uint32_t)t >= keep) { ps[t] = inf; pi[t] = 0xFFFFFFFFu; }
             __syncthreads();
             if (tid == 0) cnt = keep;
@@ -356,7 +379,11 @@ __global__ __launch_bounds__(256) void flat_select_slices_kernel(FlatArgs a, uin
             __syncthreads();
         }
     }
-    bitonic_sort_pool(ps, pi, tid);
+    {
+        int np = 2;
+        while ((uint32_t)np < cnt) np <<= 1;
+        bitonic_sort_pool_n(ps, pi, tid, np);
+    }
     const uint32_t keep = cnt < k ? cnt : k;
     if (tid == 0) {
         base_out = atomicAdd(&cand_cnt[q], keep);

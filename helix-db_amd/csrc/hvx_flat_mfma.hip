@@ -470,10 +470,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         return;
     }
     __syncthreads();
-    // bitonic sort of 1024 (score, id) pairs by one wavefront
-    for (int size = 2; size <= 1024; size <<= 1)
+    // bitonic sort of the (score, id) pairs by one wavefront: the next power of two above the candidate count (the rest is +inf)
+    int npairs = 2;
+    while ((uint32_t)npairs < nc) npairs <<= 1;
+    for (int size = 2; size <= npairs; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = lane; t < 512; t += 64) {
+            for (int t = lane; t < npairs / 2; t += 64) {
                 const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
                 const bool up = (lo & size) == 0;
                 const float sl = ss[lo], sh = ss[hi];
@@ -627,16 +629,20 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
     const bool no_filter = ix->opt[HVX_OPT_FLAT_NO_FILTER] != 0;
     if (allow_filter) ix->last_scan_path = 0; // (the unfiltered repeat after a pair overflow keeps the first pass's flags)
     constexpr uint32_t kCandCap = 1024;
-    for (int attempt = allow_fast ? 0 : 1; attempt < 3; ++attempt) {
+    // a handle whose one-pass attempt keeps missing its certificate (tightly clustered scores: the widened bound exceeds the gap
+    // between the k-th and the (m+1)-th score) starts with the full split; the one-pass attempt is probed again every 32 scans
+    const bool skip_fast = ix->m_fast_misses >= 2 && (ix->m_fast_skipped++ % 32u) != 31u;
+    for (int attempt = (allow_fast && !skip_fast) ? 0 : 1; attempt < 3; ++attempt) {
         const bool full = attempt >= 1;
         const uint32_t m = attempt == 2 ? 1023u : m0;
         if (attempt == 2 && m0 >= 1023u) break;
         const uint32_t kc = m + 1;
         // small batches (b <= 128): ONE pass over the rows with the register-resident kernel of hvx_flat_smallb.hip writes the
         // whole [b][n] score matrix; sliced selection + pair merge replace the chunk loop.  One-pass attempt only.
-        const int sb_kind = f32 ? (ix->m_shadow ? 0 : 2) : (fp8 ? 1 : 0);
-        const bool smallb = attempt == 0 && !ix->opt[HVX_OPT_FLAT_NO_SMALLB] && flat_smallb_supported(d.dim, b, sb_kind) &&
+        const int sb_kind = f32 ? ((ix->m_shadow && !full) ? 0 : 2) : (fp8 ? 1 : 0); // (the shadow has no lo parts: the full split reads the f32 rows)
+        const bool smallb = !ix->opt[HVX_OPT_FLAT_NO_SMALLB] && flat_smallb_supported(d.dim, b, sb_kind) &&
                             (size_t)((n + 3u) & ~3u) * b * 4 <= (512u << 20) && kc <= 1024u;
+        constexpr uint32_t kSmallbCandCap = 2048; // S slices x kc pairs per query (flat_merge_pairs_kernel's pool)
         // first chunk (scored by the 128 x 128 kernel into the score matrix, top-(m + 1) selected from it): 16 384 rows when the
         // large-tile filtered slices follow (1024 x 1M x 768: 2.43 ms vs 2.59 with 65 536), 65 536 as before otherwise
         uint32_t chunk = tile_ok && !full && allow_filter && m + 1 <= 256u && !no_filter ? 16384u : 65536u;
@@ -645,12 +651,13 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
         if (chunk > n || smallb) chunk = (n + 3u) & ~3u;
         if ((rc = ix->flat_scratch(b, kc, chunk))) return rc;
         const bool filt = allow_filter && kc <= 256u && n > chunk && !no_filter;
-        if ((filt || smallb) && ix->cap_cand < (size_t)bpad) {
+        const size_t cand_need = (size_t)bpad * (smallb ? kSmallbCandCap : kCandCap);
+        if ((filt || smallb) && ix->cap_cand < cand_need) {
             if ((rc = ix->regrow((void **)&ix->m_thr, (size_t)bpad * 4))) return rc;
-            if ((rc = ix->regrow((void **)&ix->m_csc, (size_t)bpad * kCandCap * 4))) return rc;
-            if ((rc = ix->regrow((void **)&ix->m_cid, (size_t)bpad * kCandCap * 4))) return rc;
+            if ((rc = ix->regrow((void **)&ix->m_csc, cand_need * 4))) return rc;
+            if ((rc = ix->regrow((void **)&ix->m_cid, cand_need * 4))) return rc;
             if ((rc = ix->regrow((void **)&ix->m_ccnt, (size_t)bpad * 4 + 4))) return rc;
-            ix->cap_cand = bpad;
+            ix->cap_cand = cand_need;
         }
         HIP_TRY(hipMemsetAsync(ix->f_top_c, 0, (size_t)b * 4, ix->stream));
         if (filt || smallb) HIP_TRY(hipMemsetAsync(ix->m_ccnt, 0, (size_t)bpad * 4 + 4, ix->stream));
@@ -687,19 +694,19 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
         PairMergeArgs pm;
         pm.top_scores = ix->f_top_s; pm.top_ids = ix->f_top_i; pm.top_counts = ix->f_top_c; pm.cand_sc = ix->m_csc; pm.cand_id = ix->m_cid;
         pm.cand_cnt = ix->m_ccnt; pm.thr = ix->m_thr; pm.overflow = ix->m_ccnt ? ix->m_ccnt + bpad : nullptr; pm.qstatus = ix->d_qstatus;
-        pm.kc = kc; pm.cap = kCandCap;
+        pm.kc = kc; pm.cap = smallb ? kSmallbCandCap : kCandCap;
         uint32_t r0 = 0;
         bool used_tile = false;
         if (smallb) {
             MfmaArgs sa = ma;
             sa.row0 = 0; sa.nrows = n;
-            if (f32 && sb_kind == 0) sa.rows = ix->m_shadow; // the bf16 shadow, once some large scan has built it: half the bytes
+            if (f32 && sb_kind == 0) sa.rows = ix->m_shadow; // one-pass attempt: the bf16 shadow, once some large scan has built it (half the bytes)
             int cus = 256;
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ix->device);
-            HIP_TRY(launch_flat_smallb(sa, sb_kind, (uint32_t)cus, ix->stream));
+            HIP_TRY(launch_flat_smallb(sa, sb_kind, full, (uint32_t)cus, ix->stream));
             fa.row0 = 0; fa.rows = n;
-            const uint32_t slices = std::max<uint32_t>(1u, std::min<uint32_t>(16u, kCandCap / kc));
-            HIP_TRY(launch_flat_select_slices(fa, slices, ix->m_csc, ix->m_cid, ix->m_ccnt, kCandCap, ix->stream));
+            const uint32_t slices = std::max<uint32_t>(1u, std::min<uint32_t>(31u, kSmallbCandCap / kc));
+            HIP_TRY(launch_flat_select_slices(fa, slices, ix->m_csc, ix->m_cid, ix->m_ccnt, kSmallbCandCap, ix->stream));
             hipLaunchKernelGGL(flat_merge_pairs_kernel, dim3(b), dim3(256), 0, ix->stream, pm);
             HIP_TRY(hipGetLastError());
             r0 = n;
@@ -762,6 +769,7 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
             ix->last_scan_path |= HVX_PATH_PAIR_OVERFLOW_REPEAT;
             return flat_mfma_impl(ix, d_queries, b, k, d_subset, n_rows, d_ids, d_scores, d_counts, d_status, timed, false);
         }
+        if (attempt == 0) ix->m_fast_misses = failed ? ix->m_fast_misses + 1 : 0;
         if (!failed) return HVX_OK;
         if (f32 && full) { // f32 rows have an exact VALU scan to fall back to: never widen, never guess
             ix->m_failed.clear();

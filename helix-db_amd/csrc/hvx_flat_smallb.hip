@@ -26,35 +26,51 @@
 namespace hvx {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// two f32 -> two bf16 (RNE) in one v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    const f32x2 f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2));
+}
+
 // KIND 0: bf16 rows (a bf16 index, or the bf16 shadow of an f32 index), 2: f32 rows.  NQT: 32-query tiles held in LDS.
-// WAVES: wavefronts per workgroup = per CU (the query tile fills most of the LDS): 16 (128 registers each) for one tile,
-// 8 (256 registers) when 2 or 4 accumulator tiles are live.  U: MFMA steps (16 deep each) per register group.
-template <int KIND, int NQT, int WAVES, int U>
-__global__ __launch_bounds__(WAVES * 64) void flat_smallb_kernel(MfmaArgs a, uint32_t n_blocks, uint32_t lds_stride) {
+// FULL: the hi + lo split (acc += q_hi.x_hi + q_lo.x_hi [+ q_hi.x_lo for f32 rows]; the dropped lo.lo term is covered by the
+// certificate's bound) -- false = the one-pass build (q_hi.x_hi only, RerankArgs::extra_rel widens the bound).
+// WAVES: wavefronts per workgroup = per CU (the query tiles fill most of the LDS).  U: MFMA steps (16 deep) per register group.
+// One launch covers depth [k0, k0 + klen) of every row: `first` writes the partial dot products into a.dist, later passes
+// add to them, `last` turns them into the metric's approximate score.  (dim 1536 with the lo tile takes two passes: the
+// query tiles of one pass must fit the LDS.)
+template <int KIND, int NQT, int WAVES, int U, bool FULL>
+__global__ __launch_bounds__(WAVES * 64) void flat_smallb_kernel(MfmaArgs a, uint32_t n_blocks, uint32_t lds_stride, uint32_t k0, uint32_t klen,
+                                                                  uint32_t first, uint32_t last) {
     extern __shared__ __attribute__((aligned(16))) unsigned char qlds[];
     constexpr bool F32 = KIND == 2;
-    constexpr int kSmallbWaves = WAVES;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t fr = lane & 31u, half = lane >> 5;
-    // the query tile(s): [NQT * 32][dim] bf16, rows padded by 16 bytes
-    const uint32_t vec_per_row = a.dim / 8u;
-    for (uint32_t i = tid; i < (uint32_t)NQT * 32u * vec_per_row; i += kSmallbWaves * 64) {
+    // the query tile(s) of this depth range: [NQT * 32][klen] bf16 hi (then lo), rows padded by 16 bytes
+    unsigned char *qlo_lds = qlds + (size_t)NQT * 32u * lds_stride;
+    const uint32_t vec_per_row = klen / 8u;
+    for (uint32_t i = tid; i < (uint32_t)NQT * 32u * vec_per_row; i += WAVES * 64) {
         const uint32_t r = i / vec_per_row, c = i - r * vec_per_row;
-        *reinterpret_cast<uint4 *>(qlds + (size_t)r * lds_stride + c * 16u) = *reinterpret_cast<const uint4 *>(a.qhi + (size_t)r * a.dim + c * 8u);
+        *reinterpret_cast<uint4 *>(qlds + (size_t)r * lds_stride + c * 16u) = *reinterpret_cast<const uint4 *>(a.qhi + (size_t)r * a.dim + k0 + c * 8u);
+        if (FULL)
+            *reinterpret_cast<uint4 *>(qlo_lds + (size_t)r * lds_stride + c * 16u) = *reinterpret_cast<const uint4 *>(a.qlo + (size_t)r * a.dim + k0 + c * 8u);
     }
     __syncthreads();
     const unsigned char *qa = qlds + (size_t)fr * lds_stride + half * 16u; // this lane's A fragment of tile 0, step 0
-    const uint32_t ngroups = a.dim / (16u * U);
+    const unsigned char *qal = qlo_lds + (size_t)fr * lds_stride + half * 16u;
+    const uint32_t ngroups = klen / (16u * U);
     struct Group {
         uint4 v[U][F32 ? 2 : 1];
     };
-    for (uint32_t blk = blockIdx.x * kSmallbWaves + wave; blk < n_blocks; blk += gridDim.x * kSmallbWaves) {
+    for (uint32_t blk = blockIdx.x * WAVES + wave; blk < n_blocks; blk += gridDim.x * WAVES) {
         const uint32_t rloc = blk * 32u + fr;
         const uint32_t rcl = rloc < a.nrows ? rloc : a.nrows - 1u; // the ragged tail re-reads the last row; masked below
         const size_t node = a.subset ? a.subset[a.row0 + rcl] : a.row0 + rcl;
-        const unsigned char *rp = reinterpret_cast<const unsigned char *>(a.rows) + node * a.dim * (F32 ? 4u : 2u) + half * (F32 ? 32u : 16u);
+        const unsigned char *rp = reinterpret_cast<const unsigned char *>(a.rows) + (node * a.dim + k0) * (F32 ? 4u : 2u) + half * (F32 ? 32u : 16u);
         auto load_group = [&](Group &g, uint32_t grp) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -71,22 +87,38 @@ __global__ __launch_bounds__(WAVES * 64) void flat_smallb_kernel(MfmaArgs a, uin
         auto compute_group = [&](const Group &g, uint32_t grp) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                uint4 bw;
+                uint4 bw, bl = make_uint4(0, 0, 0, 0);
                 if (F32) {
+                    float x[8];
                     const uint4 x0 = g.v[u][0], x1 = g.v[u][F32 ? 1 : 0];
-                    bw.x = (uint32_t)f32_to_bf16_rne(__uint_as_float(x0.x)) | ((uint32_t)f32_to_bf16_rne(__uint_as_float(x0.y)) << 16);
-                    bw.y = (uint32_t)f32_to_bf16_rne(__uint_as_float(x0.z)) | ((uint32_t)f32_to_bf16_rne(__uint_as_float(x0.w)) << 16);
-                    bw.z = (uint32_t)f32_to_bf16_rne(__uint_as_float(x1.x)) | ((uint32_t)f32_to_bf16_rne(__uint_as_float(x1.y)) << 16);
-                    bw.w = (uint32_t)f32_to_bf16_rne(__uint_as_float(x1.z)) | ((uint32_t)f32_to_bf16_rne(__uint_as_float(x1.w)) << 16);
+                    x[0] = __uint_as_float(x0.x); x[1] = __uint_as_float(x0.y); x[2] = __uint_as_float(x0.z); x[3] = __uint_as_float(x0.w);
+                    x[4] = __uint_as_float(x1.x); x[5] = __uint_as_float(x1.y); x[6] = __uint_as_float(x1.z); x[7] = __uint_as_float(x1.w);
+                    uint32_t h[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) h[i] = pack_bf16(x[2 * i], x[2 * i + 1]);
+                    bw = make_uint4(h[0], h[1], h[2], h[3]);
+                    if (FULL) { // residuals x - bf16(x), rounded to bf16 again
+                        uint32_t l[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            l[i] = pack_bf16(x[2 * i] - __uint_as_float(h[i] << 16), x[2 * i + 1] - __uint_as_float(h[i] & 0xFFFF0000u));
+                        bl = make_uint4(l[0], l[1], l[2], l[3]);
+                    }
                 } else {
                     bw = g.v[u][0];
                 }
                 const bf16x8 fb = __builtin_bit_cast(bf16x8, bw);
+                const bf16x8 fbl = __builtin_bit_cast(bf16x8, bl);
                 const uint32_t koff = (grp * U + (uint32_t)u) * 32u; // bytes of bf16 depth before this step
 #pragma unroll
                 for (int t = 0; t < NQT; ++t) {
                     const bf16x8 fa = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(qa + (size_t)t * 32u * lds_stride + koff));
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
+                    if (FULL) {
+                        const bf16x8 fal = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(qal + (size_t)t * 32u * lds_stride + koff));
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal, fb, acc[t], 0, 0, 0);
+                        if (F32) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fbl, acc[t], 0, 0, 0);
+                    }
                 }
             }
         };
@@ -103,14 +135,17 @@ __global__ __launch_bounds__(WAVES * 64) void flat_smallb_kernel(MfmaArgs a, uin
         }
         // epilogue: C[m = query][n = row]; lane holds n = lane & 31, m = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
         if (rloc < a.nrows) {
-            const float term = a.rowterm[node];
+            const float term = last ? a.rowterm[node] : 0.f;
 #pragma unroll
             for (int t = 0; t < NQT; ++t)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const uint32_t qq = (uint32_t)t * 32u + (uint32_t)(e & 3) + 8u * (uint32_t)(e >> 2) + 4u * half;
                     if (qq >= a.b) continue;
-                    const float dot = acc[t][e];
+                    float *dp = a.dist + (size_t)qq * a.chunk_ld + rloc;
+                    float dot = acc[t][e];
+                    if (!first) dot += *dp;
+                    if (!last) { *dp = dot; continue; }
                     float s;
                     if (a.metric == kL2) {
                         s = (a.qn2[qq] + term) - 2.0f * dot;
@@ -121,50 +156,68 @@ __global__ __launch_bounds__(WAVES * 64) void flat_smallb_kernel(MfmaArgs a, uin
                         c = c < -1.f ? -1.f : (c > 1.f ? 1.f : c);
                         s = (1.0f - c) * 0.5f;
                     }
-                    a.dist[(size_t)qq * a.chunk_ld + rloc] = s;
+                    *dp = s;
                 }
         }
     }
 }
 
-bool flat_smallb_supported(uint32_t dim, uint32_t b, int kind) {
-    if (kind != 0 && kind != 2) return false;
-    if (b == 0 || b > 128u || dim % 64u != 0u) return false;
+constexpr size_t kSmallbLds = 150u * 1024u;
+
+static uint32_t smallb_tiles(uint32_t b) {
     const uint32_t nqt = (b + 31u) / 32u;
-    const uint32_t tiles = nqt == 3 ? 4u : nqt;
-    return (size_t)tiles * 32u * ((size_t)dim * 2u + 16u) <= 150u * 1024u; // the query tile(s) stay in LDS for the whole launch
+    return nqt == 3 ? 4u : nqt;
+}
+// depth passes needed so that the query tiles of one pass fit the LDS (0 = not servable)
+static uint32_t smallb_passes(uint32_t dim, uint32_t b, bool full) {
+    const uint32_t tiles = smallb_tiles(b) * (full ? 2u : 1u);
+    for (uint32_t p = 1; p <= 4; ++p) {
+        if (dim % (p * 128u) != 0u) continue; // a pass is a whole number of 8-step register groups
+        if ((size_t)tiles * 32u * ((size_t)(dim / p) * 2u + 16u) <= kSmallbLds) return p;
+    }
+    return 0;
 }
 
-template <int KIND, int NQT>
+bool flat_smallb_supported(uint32_t dim, uint32_t b, int kind) {
+    if (kind != 0 && kind != 2) return false;
+    if (b == 0 || b > 128u || dim % 128u != 0u) return false;
+    return smallb_passes(dim, b, true) != 0 && smallb_passes(dim, b, false) != 0;
+}
+
+template <int KIND, int NQT, bool FULL>
 static hipError_t launch_smallb_t(const MfmaArgs &a, uint32_t n_blocks, uint32_t cus, hipStream_t s) {
-    constexpr int kSmallbWaves = NQT == 1 ? 16 : 8;
-    constexpr int U = (KIND == 2 && NQT != 2) ? 2 : 4;
-    const uint32_t stride = a.dim * 2u + 16u;
-    const size_t lds = (size_t)NQT * 32u * stride;
-    auto kern = flat_smallb_kernel<KIND, NQT, kSmallbWaves, U>;
+    // 8 wavefronts per CU with 256 registers each: two groups of 8 steps in flight (16 KB of f32 rows per wavefront)
+    constexpr int WAVES = 8, U = NQT == 4 ? (KIND == 2 ? 2 : 4) : ((NQT == 2 && KIND == 2 && FULL) ? 4 : 8);
+    const uint32_t passes = smallb_passes(a.dim, a.b, FULL);
+    if (passes == 0) return hipErrorInvalidValue;
+    const uint32_t klen = a.dim / passes, stride = klen * 2u + 16u;
+    const size_t lds = (size_t)NQT * (FULL ? 2u : 1u) * 32u * stride;
+    auto kern = flat_smallb_kernel<KIND, NQT, WAVES, U, FULL>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(cus, (n_blocks + kSmallbWaves - 1) / kSmallbWaves));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kSmallbWaves * 64), lds, s, a, n_blocks, stride);
+    const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(cus, (n_blocks + WAVES - 1) / WAVES));
+    for (uint32_t p = 0; p < passes; ++p)
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, s, a, n_blocks, stride, p * klen, klen, p == 0 ? 1u : 0u, p + 1 == passes ? 1u : 0u);
     return hipGetLastError();
 }
 
+template <int KIND, bool FULL> static hipError_t launch_smallb_q(const MfmaArgs &a, uint32_t n_blocks, uint32_t cus, hipStream_t s) {
+    switch (smallb_tiles(a.b)) {
+    case 1: return launch_smallb_t<KIND, 1, FULL>(a, n_blocks, cus, s);
+    case 2: return launch_smallb_t<KIND, 2, FULL>(a, n_blocks, cus, s);
+    default: return launch_smallb_t<KIND, 4, FULL>(a, n_blocks, cus, s);
+    }
+}
+
 // scores of rows [a.row0, a.row0 + a.nrows) of the scan order against a.b <= 128 queries into a.dist (row length a.chunk_ld)
-hipError_t launch_flat_smallb(const MfmaArgs &a, int kind, uint32_t cus, hipStream_t s) {
+hipError_t launch_flat_smallb(const MfmaArgs &a, int kind, bool full, uint32_t cus, hipStream_t s) {
     if (a.nrows == 0) return hipSuccess;
     if (!flat_smallb_supported(a.dim, a.b, kind)) return hipErrorInvalidValue;
     const uint32_t n_blocks = (a.nrows + 31u) / 32u;
-    const uint32_t nqt = (a.b + 31u) / 32u;
-    if (kind == 2) {
-        if (nqt == 1) return launch_smallb_t<2, 1>(a, n_blocks, cus, s);
-        if (nqt == 2) return launch_smallb_t<2, 2>(a, n_blocks, cus, s);
-        return launch_smallb_t<2, 4>(a, n_blocks, cus, s);
-    }
-    if (nqt == 1) return launch_smallb_t<0, 1>(a, n_blocks, cus, s);
-    if (nqt == 2) return launch_smallb_t<0, 2>(a, n_blocks, cus, s);
-    return launch_smallb_t<0, 4>(a, n_blocks, cus, s);
+    if (kind == 2) return full ? launch_smallb_q<2, true>(a, n_blocks, cus, s) : launch_smallb_q<2, false>(a, n_blocks, cus, s);
+    return full ? launch_smallb_q<0, true>(a, n_blocks, cus, s) : launch_smallb_q<0, false>(a, n_blocks, cus, s);
 }
 
 } // namespace hvx

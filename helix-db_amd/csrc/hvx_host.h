@@ -106,6 +106,7 @@ struct hvx_index {
     size_t cap_cand = 0;
     size_t cap_qsplit = 0;
     float m_xmax2 = 0.f;
+    uint32_t m_fast_misses = 0, m_fast_skipped = 0; // consecutive scans whose one-pass attempt missed a certificate / scans that skipped it
     // non-strict search arms (hvx_params.hip): per-node SimHash rows, the hasher, per-batch fingerprints
     bool has_simhash = false;
     hvx_simhash_config sh_cfg{};

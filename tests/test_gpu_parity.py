@@ -1160,6 +1160,7 @@ def test_exact_scan_through_the_256_tile_kernel(orc, hv, dtype_name, metric, dim
     q[b - 1, 5] = np.nan                                              # a rejected query in the padded query tile
     gix.set_option(hv.OPT_FLAT_FIRST_CHUNK, 2048)
     gix.set_option(hv.OPT_FLAT_TILE_BUILD, tile_build)
+    gix.set_option(hv.OPT_FLAT_NO_SMALLB, 1)                           # (batches of <= 128 queries would take the small-batch kernel)
     gid, gsc, gcnt, _, gst = gix.flat_search_batch(q, k, per_query_status=True)
     assert gix.last_scan_path() & hv.PATH_TILE_256, gix.last_scan_path()   # the kernel ran
     if gix.last_scan_path() & hv.PATH_PAIR_OVERFLOW_REPEAT:                # (a 2 048-row first chunk gives loose thresholds: a slice may
@@ -1461,7 +1462,7 @@ def test_small_batch_exact_scan_is_bit_exact(orc, hv, dtype_name, metric, dim, n
     if b > 2:
         q[b - 1, 5] = np.nan
     gid, gsc, gcnt, _, gst = gix.flat_search_batch(q, k, per_query_status=True)
-    assert gix.last_scan_path() & hv.PATH_SMALL_BATCH, gix.last_scan_path()
+    assert gix.last_scan_path() & hv.PATH_SMALL_BATCH and not gix.last_scan_path() & (hv.PATH_MFMA_128 | hv.PATH_TILE_256), gix.last_scan_path()
     kern = {"kernel": orc.K_AVX_FMA_HW} if dtype_name == "f32" else {}
     for qi in range(b):
         if b > 2 and qi == b - 1:

@@ -39,7 +39,10 @@ hipError_t launch_flat_tile256(const MfmaArgs &a, int kind, uint32_t bpad, float
 
 // one-pass score matrix for small batches (hvx_flat_smallb.hip): b <= 128 queries, kind 0 = bf16 rows / shadow, 2 = f32 rows
 bool flat_smallb_supported(uint32_t dim, uint32_t b, int kind);
-hipError_t launch_flat_smallb(const MfmaArgs &a, int kind, bool full, uint32_t cus, hipStream_t s);
+hipError_t launch_flat_smallb(const MfmaArgs &a, int kind, bool full, uint32_t cus, hipStream_t s); // raw dot products into a.dist
+// sort-free selection over those dot products: every slice's kc (<= 256) smallest approximate scores as (score, row) pairs
+hipError_t launch_flat_select_radix(const MfmaArgs &a, uint32_t kc, uint32_t *status, float *sl_sc, uint32_t *sl_id, uint32_t sl_stride,
+                                    uint32_t *out_slices, hipStream_t s);
 
 // position of stored code `slot` (its index in the fp8 row) in the query operand of the 256 x 256 fp8 kernel: inside a
 // 64-code stage, MFMA step kk (0..3), lane half h, element e read code (2 (kk >> 1) + h) * 16 + (kk & 1) * 8 + e, so one

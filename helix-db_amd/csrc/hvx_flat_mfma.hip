@@ -280,6 +280,25 @@ __global__ __launch_bounds__(256) void flat_mfma_bf16_kernel(MfmaArgs a) {
     }
 }
 
+// small-batch path, kc > 256: turn the raw dot products of hvx_flat_smallb.hip into scores in place (the sorted-pool selection reads scores)
+__global__ __launch_bounds__(256) void flat_dots_to_scores_kernel(MfmaArgs a) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x, q = blockIdx.y;
+    if (i >= a.nrows) return;
+    const size_t node = a.subset ? a.subset[a.row0 + i] : a.row0 + i;
+    const float dot = a.dist[(size_t)q * a.chunk_ld + i], term = a.rowterm[node];
+    float s;
+    if (a.metric == kL2) {
+        s = (a.qn2[q] + term) - 2.0f * dot;
+        s = s < 0.f ? 0.f : s;
+    } else {
+        const float den = sqrtf(a.qn2[q]) * term;
+        float c = den > 0.f ? dot / den : 0.f;
+        c = c < -1.f ? -1.f : (c > 1.f ? 1.f : c);
+        s = (1.0f - c) * 0.5f;
+    }
+    a.dist[(size_t)q * a.chunk_ld + i] = s;
+}
+
 // ---- FILT pipeline: merge the (score, row) pairs a filtered launch produced into the query's running top-kc list ----
 constexpr int kPairPool = 2048;
 struct PairMergeArgs {
@@ -360,6 +379,11 @@ struct RerankArgs {
     float *out_scores;
     uint32_t *out_counts, *out_status;
     uint32_t *cert;           // [b] 1 = proven exact, 0 = needs a wider candidate set
+    // small-batch path (hvx_flat_smallb.hip): instead of one sorted candidate list per query, sl_n unsorted (score, row)
+    // pairs -- every slice's kc smallest, +inf padded; the kernel takes their kc smallest itself (bitwise descent, no sort)
+    const float *sl_sc;       // [b][sl_stride] or NULL
+    const uint32_t *sl_id;
+    uint32_t sl_n, sl_stride;
 };
 
 // P fp8 rows per 8-lane group scored in the reference's summation order: NK/4 16-byte loads per lane and row
@@ -431,11 +455,61 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const float *qglobal = a.queries + (size_t)q * ix.dim;
     for (uint32_t i = (uint32_t)lane; i < (uint32_t)NK * 8u; i += 64)
         reinterpret_cast<float4 *>(qs)[i] = reinterpret_cast<const float4 *>(qglobal)[i];
-    const uint32_t nc = a.cand_counts[q];
     const float inf = __uint_as_float(0x7F800000u);
-    for (uint32_t i = (uint32_t)lane; i < 1024u; i += 64) {
-        ss[i] = inf;
-        si[i] = i < nc ? a.cand_ids[(size_t)q * a.kc + i] : 0xFFFFFFFFu;
+    uint32_t nc;
+    float t_thr = inf; // approximate score of the last candidate: every row that is not re-scored has at least this score
+    if (a.sl_sc) {
+        // the kc smallest of the slices' pairs: keys staged in LDS, kth key by bitwise descent inside the wavefront
+        uint32_t *sk = si + 1024; // [sl_n]
+        const float *gs = a.sl_sc + (size_t)q * a.sl_stride;
+        const uint32_t *gi = a.sl_id + (size_t)q * a.sl_stride;
+        uint32_t valid = 0;
+        for (uint32_t i = (uint32_t)lane; i < a.sl_n; i += 64) {
+            const uint32_t kb = gi[i] == 0xFFFFFFFFu ? 0xFFFFFFFFu : __float_as_uint(gs[i]);
+            sk[i] = kb;
+            valid += kb != 0xFFFFFFFFu ? 1u : 0u;
+        }
+        for (uint32_t i = (uint32_t)lane; i < 1024u; i += 64) { ss[i] = inf; si[i] = 0xFFFFFFFFu; }
+        __syncthreads();
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) valid += __shfl_xor(valid, sft, 64);
+        const uint32_t kth = a.kc < valid ? a.kc : valid;
+        uint32_t prefix = 0, kk = kth, less = 0;
+        for (int bit = 31; bit >= 0 && kth; --bit) {
+            const uint32_t hi_mask = bit == 31 ? 0u : (0xFFFFFFFFu << (bit + 1));
+            uint32_t c = 0;
+            for (uint32_t i = (uint32_t)lane; i < a.sl_n; i += 64) c += ((sk[i] & hi_mask) == prefix && !((sk[i] >> bit) & 1u)) ? 1u : 0u;
+#pragma unroll
+            for (int sft = 32; sft > 0; sft >>= 1) c += __shfl_xor(c, sft, 64);
+            if (kk > c) { prefix |= 1u << bit; kk -= c; less += c; }
+        }
+        // candidates: keys below the kth value, then ties in pair order up to the quota
+        uint32_t n_out = 0, ties = 0;
+        const uint32_t quota = kth - less;
+        for (uint32_t i0 = 0; i0 < a.sl_n && kth; i0 += 64) {
+            const uint32_t i = i0 + (uint32_t)lane;
+            const uint32_t kb = i < a.sl_n ? sk[i] : 0xFFFFFFFFu;
+            const bool lt = kb < prefix, eq = kb == prefix && kb != 0xFFFFFFFFu;
+            const unsigned long long em = __ballot(eq);
+            const uint32_t eq_rank = ties + (uint32_t)__builtin_popcountll(em & ((1ull << lane) - 1ull));
+            const bool take = lt || (eq && eq_rank < quota);
+            const unsigned long long tm = __ballot(take);
+            if (take) {
+                const uint32_t pos = n_out + (uint32_t)__builtin_popcountll(tm & ((1ull << lane) - 1ull));
+                if (pos < 1024u) si[pos] = gi[i];
+            }
+            n_out += (uint32_t)__builtin_popcountll(tm);
+            ties += (uint32_t)__builtin_popcountll(em);
+        }
+        nc = n_out < 1024u ? n_out : 1024u;
+        t_thr = kth ? __uint_as_float(prefix) : inf;
+    } else {
+        nc = a.cand_counts[q];
+        for (uint32_t i = (uint32_t)lane; i < 1024u; i += 64) {
+            ss[i] = inf;
+            si[i] = i < nc ? a.cand_ids[(size_t)q * a.kc + i] : 0xFFFFFFFFu;
+        }
+        if (nc) t_thr = a.cand_scores[(size_t)q * a.kc + (nc - 1)];
     }
     __syncthreads();
     const float qhdr = a.qhdr[q];
@@ -497,7 +571,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         // certificate (see the file header).  nc <= m: every row of the scan was re-scored.
         uint32_t ok = 1u;
         if (nc > a.m) {
-            const float t = a.cand_scores[(size_t)q * a.kc + (nc - 1)];
+            const float t = t_thr;
             // worst-case |approximate - reference-order score| relative to (|q|^2 + |x|^2)/2 (L2) resp. absolute (cosine):
             // hi/lo split residuals (<= 2^-17 each way, the dropped lo.lo term and the f32 roundings of the norms:
             // 2e-5 in all) + f32 accumulation over K = dim terms in BOTH summation orders (6 K 2^-24 worst case),
@@ -513,7 +587,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
 template <uint32_t METRIC>
 static hipError_t launch_rerank(const RerankArgs &a, uint32_t b, hipStream_t s) {
-    const size_t lds = (size_t)a.ix.dim * 4 + 8192;
+    const size_t lds = (size_t)a.ix.dim * 4 + 8192 + (a.sl_sc ? (size_t)a.sl_n * 4 : 0);
     switch (a.ix.dim >> 5) {
 #define HVX_RR(N)                                                                                                   \
     case N:                                                                                                         \
@@ -642,7 +716,9 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
         const int sb_kind = f32 ? ((ix->m_shadow && !full) ? 0 : 2) : (fp8 ? 1 : 0); // (the shadow has no lo parts: the full split reads the f32 rows)
         const bool smallb = !ix->opt[HVX_OPT_FLAT_NO_SMALLB] && flat_smallb_supported(d.dim, b, sb_kind) &&
                             (size_t)((n + 3u) & ~3u) * b * 4 <= (512u << 20) && kc <= 1024u;
-        constexpr uint32_t kSmallbCandCap = 2048; // S slices x kc pairs per query (flat_merge_pairs_kernel's pool)
+        constexpr uint32_t kSmallbCandCap = 8192; // 32 slices x kc <= 256 pairs per query
+        const bool sb_radix = smallb && kc <= 256u; // (kc > 256: the widened attempt of bf16 rows keeps the sorted-pool selection)
+        uint32_t sb_slices = 0;
         // first chunk (scored by the 128 x 128 kernel into the score matrix, top-(m + 1) selected from it): 16 384 rows when the
         // large-tile filtered slices follow (1024 x 1M x 768: 2.43 ms vs 2.59 with 65 536), 65 536 as before otherwise
         uint32_t chunk = tile_ok && !full && allow_filter && m + 1 <= 256u && !no_filter ? 16384u : 65536u;
@@ -703,11 +779,17 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
             if (f32 && sb_kind == 0) sa.rows = ix->m_shadow; // one-pass attempt: the bf16 shadow, once some large scan has built it (half the bytes)
             int cus = 256;
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ix->device);
+            sa.dist = ix->f_dist; sa.chunk_ld = chunk;
             HIP_TRY(launch_flat_smallb(sa, sb_kind, full, (uint32_t)cus, ix->stream));
-            fa.row0 = 0; fa.rows = n;
-            const uint32_t slices = std::max<uint32_t>(1u, std::min<uint32_t>(31u, kSmallbCandCap / kc));
-            HIP_TRY(launch_flat_select_slices(fa, slices, ix->m_csc, ix->m_cid, ix->m_ccnt, kSmallbCandCap, ix->stream));
-            hipLaunchKernelGGL(flat_merge_pairs_kernel, dim3(b), dim3(256), 0, ix->stream, pm);
+            if (sb_radix) { // sort-free selection: slices' kc smallest pairs, the query's kc smallest of those inside the re-rank kernel
+                HIP_TRY(launch_flat_select_radix(sa, kc, ix->d_qstatus, ix->m_csc, reinterpret_cast<uint32_t *>(ix->m_cid), kSmallbCandCap, &sb_slices, ix->stream));
+            } else {
+                hipLaunchKernelGGL(flat_dots_to_scores_kernel, dim3((n + 255u) / 256u, b), dim3(256), 0, ix->stream, sa);
+                fa.row0 = 0; fa.rows = n;
+                const uint32_t slices = std::max<uint32_t>(1u, std::min<uint32_t>(31u, 2048u / kc));
+                HIP_TRY(launch_flat_select_slices(fa, slices, ix->m_csc, ix->m_cid, ix->m_ccnt, kSmallbCandCap, ix->stream));
+                hipLaunchKernelGGL(flat_merge_pairs_kernel, dim3(b), dim3(256), 0, ix->stream, pm);
+            }
             HIP_TRY(hipGetLastError());
             r0 = n;
             ix->last_scan_path |= HVX_PATH_SMALL_BATCH;
@@ -746,6 +828,8 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
         ra.cand_scores = ix->f_top_s; ra.cand_ids = ix->f_top_i; ra.cand_counts = ix->f_top_c; ra.kc = kc; ra.k = k; ra.m = m;
         ra.xmax2 = ix->m_xmax2; ra.out_ids = d_ids; ra.out_scores = d_scores; ra.out_counts = d_counts; ra.out_status = d_status;
         ra.cert = ix->m_cert;
+        ra.sl_sc = nullptr; ra.sl_id = nullptr; ra.sl_n = 0; ra.sl_stride = 0;
+        if (smallb && sb_radix) { ra.sl_sc = ix->m_csc; ra.sl_id = ix->m_cid; ra.sl_n = sb_slices * kc; ra.sl_stride = kSmallbCandCap; }
         // one rounded operand drops a term <= 2^-9 |q||x| of the dot product = 2^-8 of (|q|^2 + |x|^2)/2 in the L2 score
         // (cosine: <= 2^-10 absolute); f32 rows round BOTH operands in the one-pass build
         ra.extra_rel = full ? 0.f : (f32 ? 0.0078125f : 0.00390625f);

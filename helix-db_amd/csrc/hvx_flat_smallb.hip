@@ -40,12 +40,14 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
 // FULL: the hi + lo split (acc += q_hi.x_hi + q_lo.x_hi [+ q_hi.x_lo for f32 rows]; the dropped lo.lo term is covered by the
 // certificate's bound) -- false = the one-pass build (q_hi.x_hi only, RerankArgs::extra_rel widens the bound).
 // WAVES: wavefronts per workgroup = per CU (the query tiles fill most of the LDS).  U: MFMA steps (16 deep) per register group.
-// One launch covers depth [k0, k0 + klen) of every row: `first` writes the partial dot products into a.dist, later passes
-// add to them, `last` turns them into the metric's approximate score.  (dim 1536 with the lo tile takes two passes: the
-// query tiles of one pass must fit the LDS.)
+// Output = the raw dot products [b][rows] in a.dist (the selection kernel below turns them into scores).  The query tiles of
+// one workgroup must fit the LDS: when they do not (dim 1536 with the lo tile) the depth is split over gridDim.y workgroup
+// rows, each streaming its depth range [k0, k0 + klen) of every row -- still one pass over the bytes -- and the partial
+// dot products meet in a.dist by float atomic add (two or three addends onto a zeroed word: order-independent).
 template <int KIND, int NQT, int WAVES, int U, bool FULL>
-__global__ __launch_bounds__(WAVES * 64) void flat_smallb_kernel(MfmaArgs a, uint32_t n_blocks, uint32_t lds_stride, uint32_t k0, uint32_t klen,
-                                                                  uint32_t first, uint32_t last) {
+__global__ __launch_bounds__(WAVES * 64) void flat_smallb_kernel(MfmaArgs a, uint32_t n_blocks, uint32_t lds_stride, uint32_t klen) {
+    const uint32_t k0 = blockIdx.y * klen;
+    const bool accumulate = gridDim.y > 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char qlds[];
     constexpr bool F32 = KIND == 2;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -135,7 +137,6 @@ __global__ __launch_bounds__(WAVES * 64) void flat_smallb_kernel(MfmaArgs a, uin
         }
         // epilogue: C[m = query][n = row]; lane holds n = lane & 31, m = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
         if (rloc < a.nrows) {
-            const float term = last ? a.rowterm[node] : 0.f;
 #pragma unroll
             for (int t = 0; t < NQT; ++t)
 #pragma unroll
@@ -143,23 +144,135 @@ __global__ __launch_bounds__(WAVES * 64) void flat_smallb_kernel(MfmaArgs a, uin
                     const uint32_t qq = (uint32_t)t * 32u + (uint32_t)(e & 3) + 8u * (uint32_t)(e >> 2) + 4u * half;
                     if (qq >= a.b) continue;
                     float *dp = a.dist + (size_t)qq * a.chunk_ld + rloc;
-                    float dot = acc[t][e];
-                    if (!first) dot += *dp;
-                    if (!last) { *dp = dot; continue; }
-                    float s;
-                    if (a.metric == kL2) {
-                        s = (a.qn2[qq] + term) - 2.0f * dot;
-                        s = s < 0.f ? 0.f : s;
-                    } else {
-                        const float den = sqrtf(a.qn2[qq]) * term;
-                        float c = den > 0.f ? dot / den : 0.f;
-                        c = c < -1.f ? -1.f : (c > 1.f ? 1.f : c);
-                        s = (1.0f - c) * 0.5f;
-                    }
-                    *dp = s;
+                    if (accumulate) atomicAdd(dp, acc[t][e]);
+                    else *dp = acc[t][e];
                 }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Selection without sorting.  The certificate (hvx_flat_mfma.hip) needs, per query, a candidate set C of m + 1 rows and a
+// threshold t such that every row outside C has approximate score >= t: the m + 1 smallest scores and the largest of them.
+// A workgroup holds 4 096 scores of its slice in registers (16 per thread) and finds the kc-th smallest by a bitwise
+// descent over the f32 bit patterns (non-negative scores order like their bits): 32 rounds of "how many keys carry this
+// prefix with a 0 here" -- 16 compares per thread, one wave reduction, one LDS add, one barrier.  Keys below the result are
+// emitted, ties fill the remaining quota.  Slices longer than one register chunk carry their survivors into the next chunk.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kSelR = 16;              // scores per thread and chunk
+constexpr int kSelChunk = kSelR * 256; // 4 096
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+    return v;
+}
+
+struct SelectArgs {
+    const float *dots;        // [b][chunk_ld] raw dot products
+    uint32_t chunk_ld, rows, row0;
+    const uint32_t *subset;   // scan position -> row (restricted scans), or NULL
+    const float *rowterm;     // [n] |x|^2 (L2) / |x| (cosine)
+    const float *qn2;         // [b]
+    const float *rowscale;    // unused (fp8 rows do not take this path)
+    uint32_t metric, b, kc, slice_rows;
+    uint32_t *status;         // [b] query status: rejected queries are skipped, an invalid score sets 8
+    float *sl_sc;             // [b][slices * kc] out: every slice's kc smallest (score, row) pairs, padded with +inf
+    uint32_t *sl_id;
+    uint32_t sl_stride;
+};
+
+__global__ __launch_bounds__(256) void flat_select_radix_kernel(SelectArgs a) {
+    __shared__ uint32_t sv_key[256], sv_id[256], cnt3[3], n_lt, n_tie, bad;
+    const uint32_t q = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t kc = a.kc;
+    float *out_sc = a.sl_sc + (size_t)q * a.sl_stride + (size_t)sl * kc;
+    uint32_t *out_id = a.sl_id + (size_t)q * a.sl_stride + (size_t)sl * kc;
+    const float inf = __uint_as_float(0x7F800000u);
+    if (a.status && a.status[q] != 0u) {
+        for (uint32_t i = tid; i < kc; i += 256) { out_sc[i] = inf; out_id[i] = 0xFFFFFFFFu; }
+        return;
+    }
+    const uint32_t lo = sl * a.slice_rows, hi = lo + a.slice_rows < a.rows ? lo + a.slice_rows : a.rows;
+    const float *dq = a.dots + (size_t)q * a.chunk_ld;
+    const float qn2 = a.qn2[q], qn = sqrtf(qn2);
+    uint32_t n_surv = 0; // survivors carried from the previous chunk (in sv_key / sv_id)
+    if (tid == 0) bad = 0;
+    __syncthreads();
+    for (uint32_t base = lo; base < hi; base += kSelChunk) {
+        if (tid == 0) { cnt3[0] = cnt3[1] = cnt3[2] = 0; n_lt = 0; n_tie = 0; }
+        uint32_t key[kSelR + 1];
+#pragma unroll
+        for (int r = 0; r < kSelR; ++r) {
+            const uint32_t i = base + (uint32_t)r * 256u + tid;
+            uint32_t kbits = 0xFFFFFFFFu;
+            if (i < hi) {
+                const uint32_t scan = a.row0 + i;
+                const uint32_t node = a.subset ? a.subset[scan] : scan;
+                const float dot = dq[i], term = a.rowterm[node];
+                float s;
+                if (a.metric == kL2) {
+                    s = (qn2 + term) - 2.0f * dot;
+                    s = s < 0.f ? 0.f : s;
+                } else {
+                    const float den = qn * term;
+                    float c = den > 0.f ? dot / den : 0.f;
+                    c = c < -1.f ? -1.f : (c > 1.f ? 1.f : c);
+                    s = (1.0f - c) * 0.5f;
+                }
+                if (!score_valid(s)) bad = 1; // Candidate::try_new rejects the score (model.rs:21-29)
+                else kbits = __float_as_uint(s);
+            }
+            key[r] = kbits;
+        }
+        key[kSelR] = tid < n_surv ? sv_key[tid] : 0xFFFFFFFFu;
+        const uint32_t carried_id = tid < n_surv ? sv_id[tid] : 0xFFFFFFFFu;
+        const uint32_t in_chunk = (hi - base) < (uint32_t)kSelChunk ? (hi - base) : (uint32_t)kSelChunk;
+        const uint32_t total = in_chunk + n_surv;
+        const uint32_t kth = kc < total ? kc : total;
+        __syncthreads(); // counters zeroed; every thread holds its carried survivor in a register
+        // bitwise descent to the kth smallest key (an invalid score holds the all-ones key and sorts last)
+        uint32_t prefix = 0, kk = kth, less = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t hi_mask = bit == 31 ? 0u : (0xFFFFFFFFu << (bit + 1));
+            uint32_t c = 0;
+#pragma unroll
+            for (int r = 0; r <= kSelR; ++r) c += ((key[r] & hi_mask) == prefix && !((key[r] >> bit) & 1u)) ? 1u : 0u;
+            c = wave_sum_u32(c);
+            const int slot = bit % 3;
+            if (lane == 0 && c) atomicAdd(&cnt3[slot], c);
+            if (tid == 0) cnt3[(bit + 2) % 3] = 0; // next round's counter: last read two rounds ago
+            __syncthreads();
+            const uint32_t zeros = cnt3[slot];
+            if (kk > zeros) { prefix |= 1u << bit; kk -= zeros; less += zeros; }
+        }
+        // emit into the survivor arrays: keys below the kth value, then ties up to the quota
+        const uint32_t quota = kth - less;
+#pragma unroll
+        for (int r = 0; r <= kSelR; ++r) {
+            const uint32_t kb = key[r];
+            bool take = kb < prefix;
+            if (!take && kb == prefix && kb != 0xFFFFFFFFu) take = atomicAdd(&n_tie, 1u) < quota;
+            if (take) {
+                uint32_t id = carried_id;
+                if (r < kSelR) {
+                    const uint32_t scan = a.row0 + base + (uint32_t)r * 256u + tid;
+                    id = a.subset ? a.subset[scan] : scan;
+                }
+                const uint32_t pos = atomicAdd(&n_lt, 1u);
+                if (pos < 256u) { sv_key[pos] = kb; sv_id[pos] = id; }
+            }
+        }
+        __syncthreads();
+        n_surv = n_lt < kth ? n_lt : kth;
+        __syncthreads(); // n_lt is re-zeroed at the top of the next chunk
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < kc; i += 256) {
+        out_sc[i] = i < n_surv ? __uint_as_float(sv_key[i]) : inf;
+        out_id[i] = i < n_surv ? sv_id[i] : 0xFFFFFFFFu;
+    }
+    if (tid == 0 && lo < hi && bad && a.status && a.status[q] == 0u) a.status[q] = 8u; // HVX_ERR_INVARIANT
 }
 
 constexpr size_t kSmallbLds = 150u * 1024u;
@@ -197,9 +310,13 @@ static hipError_t launch_smallb_t(const MfmaArgs &a, uint32_t n_blocks, uint32_t
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(cus, (n_blocks + WAVES - 1) / WAVES));
-    for (uint32_t p = 0; p < passes; ++p)
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, s, a, n_blocks, stride, p * klen, klen, p == 0 ? 1u : 0u, p + 1 == passes ? 1u : 0u);
+    if (passes > 1) { // partial dot products are added into zeroed words
+        hipError_t e = hipMemsetAsync(a.dist, 0, (size_t)a.b * a.chunk_ld * 4, s);
+        if (e != hipSuccess) return e;
+    }
+    const uint32_t per = std::max<uint32_t>(1u, cus / passes);
+    const uint32_t grid = std::max<uint32_t>(1u, std::min<uint32_t>(per, (n_blocks + WAVES - 1) / WAVES));
+    hipLaunchKernelGGL(kern, dim3(grid, passes), dim3(WAVES * 64), lds, s, a, n_blocks, stride, klen);
     return hipGetLastError();
 }
 
@@ -211,13 +328,36 @@ template <int KIND, bool FULL> static hipError_t launch_smallb_q(const MfmaArgs 
     }
 }
 
-// scores of rows [a.row0, a.row0 + a.nrows) of the scan order against a.b <= 128 queries into a.dist (row length a.chunk_ld)
+// raw dot products of rows [a.row0, a.row0 + a.nrows) of the scan order against a.b <= 128 queries into a.dist (row length a.chunk_ld)
 hipError_t launch_flat_smallb(const MfmaArgs &a, int kind, bool full, uint32_t cus, hipStream_t s) {
     if (a.nrows == 0) return hipSuccess;
     if (!flat_smallb_supported(a.dim, a.b, kind)) return hipErrorInvalidValue;
     const uint32_t n_blocks = (a.nrows + 31u) / 32u;
     if (kind == 2) return full ? launch_smallb_q<2, true>(a, n_blocks, cus, s) : launch_smallb_q<2, false>(a, n_blocks, cus, s);
     return full ? launch_smallb_q<0, true>(a, n_blocks, cus, s) : launch_smallb_q<0, false>(a, n_blocks, cus, s);
+}
+
+// slices per query for a scan of `rows` rows with kc <= 256: <= 32, each a whole number of 4 096-score register chunks
+uint32_t flat_smallb_slices(uint32_t rows) {
+    const uint32_t chunks = (rows + (uint32_t)kSelChunk - 1) / (uint32_t)kSelChunk;
+    return std::max<uint32_t>(1u, std::min<uint32_t>(32u, chunks));
+}
+
+// the kc smallest approximate scores of every slice: a.dist (raw dots) -> sl_sc / sl_id [b][slices * kc] (row length sl_stride)
+hipError_t launch_flat_select_radix(const MfmaArgs &a, uint32_t kc, uint32_t *status, float *sl_sc, uint32_t *sl_id, uint32_t sl_stride,
+                                    uint32_t *out_slices, hipStream_t s) {
+    if (a.b == 0 || kc == 0 || kc > 256u) return hipErrorInvalidValue;
+    const uint32_t slices = flat_smallb_slices(a.nrows);
+    const uint32_t chunks = (a.nrows + (uint32_t)kSelChunk - 1) / (uint32_t)kSelChunk;
+    SelectArgs g{};
+    g.dots = a.dist; g.chunk_ld = a.chunk_ld; g.rows = a.nrows; g.row0 = a.row0; g.subset = a.subset; g.rowterm = a.rowterm; g.qn2 = a.qn2;
+    g.metric = a.metric; g.b = a.b; g.kc = kc; g.slice_rows = ((chunks + slices - 1) / slices) * (uint32_t)kSelChunk;
+    g.status = status; g.sl_sc = sl_sc; g.sl_id = sl_id; g.sl_stride = sl_stride;
+    const uint32_t used = (a.nrows + g.slice_rows - 1) / g.slice_rows;
+    if ((size_t)used * kc > sl_stride) return hipErrorInvalidValue;
+    *out_slices = used;
+    hipLaunchKernelGGL(flat_select_radix_kernel, dim3(a.b, used), dim3(256), 0, s, g);
+    return hipGetLastError();
 }
 
 } // namespace hvx

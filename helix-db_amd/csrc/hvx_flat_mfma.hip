@@ -477,10 +477,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         uint32_t prefix = 0, kk = kth, less = 0;
         for (int bit = 31; bit >= 0 && kth; --bit) {
             const uint32_t hi_mask = bit == 31 ? 0u : (0xFFFFFFFFu << (bit + 1));
+            const uint32_t sel_mask = hi_mask | (1u << bit); // prefix on the bits above, 0 at `bit`
             uint32_t c = 0;
-            for (uint32_t i = (uint32_t)lane; i < a.sl_n; i += 64) c += ((sk[i] & hi_mask) == prefix && !((sk[i] >> bit) & 1u)) ? 1u : 0u;
-#pragma unroll
-            for (int sft = 32; sft > 0; sft >>= 1) c += __shfl_xor(c, sft, 64);
+            for (uint32_t i0 = 0; i0 < a.sl_n; i0 += 64) {
+                const uint32_t i = i0 + (uint32_t)lane;
+                const uint32_t kb = i < a.sl_n ? sk[i] : 0xFFFFFFFFu; // (padding never matches: bit 31 of a real prefix is 0)
+                c += (uint32_t)__builtin_popcountll(__ballot(i < a.sl_n && (kb & sel_mask) == prefix));
+            }
             if (kk > c) { prefix |= 1u << bit; kk -= c; less += c; }
         }
         // candidates: keys below the kth value, then ties in pair order up to the quota

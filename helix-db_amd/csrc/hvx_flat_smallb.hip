@@ -235,10 +235,11 @@ __global__ __launch_bounds__(256) void flat_select_radix_kernel(SelectArgs a) {
         uint32_t prefix = 0, kk = kth, less = 0;
         for (int bit = 31; bit >= 0; --bit) {
             const uint32_t hi_mask = bit == 31 ? 0u : (0xFFFFFFFFu << (bit + 1));
+            // count per wavefront with ballots (a compare into a scalar mask + s_bcnt1): no cross-lane traffic
+            const uint32_t want = prefix, sel_mask = hi_mask | (1u << bit); // prefix on the bits above, 0 at `bit`
             uint32_t c = 0;
 #pragma unroll
-            for (int r = 0; r <= kSelR; ++r) c += ((key[r] & hi_mask) == prefix && !((key[r] >> bit) & 1u)) ? 1u : 0u;
-            c = wave_sum_u32(c);
+            for (int r = 0; r <= kSelR; ++r) c += (uint32_t)__builtin_popcountll(__ballot((key[r] & sel_mask) == want));
             const int slot = bit % 3;
             if (lane == 0 && c) atomicAdd(&cnt3[slot], c);
             if (tid == 0) cnt3[(bit + 2) % 3] = 0; // next round's counter: last read two rounds ago

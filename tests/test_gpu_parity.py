@@ -1226,6 +1226,7 @@ def test_restricted_scan_through_the_256_tile_kernel(orc, hv):
     allowed = rng.choice(ids, 9001, replace=False)
     cand = hv.RestrictedVectorCandidates.from_ids(allowed)
     gix.set_option(hv.OPT_FLAT_FIRST_CHUNK, 1024)
+    gix.set_option(hv.OPT_FLAT_NO_SMALLB, 1)
     gid, gsc, gcnt = gix.search_restricted_batch(q, hv.SearchParams(k), cand)
     assert gix.last_scan_path() & hv.PATH_TILE_256
     for qi in range(0, b, 7):

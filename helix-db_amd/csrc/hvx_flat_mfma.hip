@@ -731,12 +731,15 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
         if ((rc = ix->flat_scratch(b, kc, chunk))) return rc;
         const bool filt = allow_filter && kc <= 256u && n > chunk && !no_filter;
         const size_t cand_need = (size_t)bpad * (smallb ? kSmallbCandCap : kCandCap);
-        if ((filt || smallb) && ix->cap_cand < cand_need) {
-            if ((rc = ix->regrow((void **)&ix->m_thr, (size_t)bpad * 4))) return rc;
+        if ((filt || smallb) && ix->cap_cand < cand_need) { // pair buffers
             if ((rc = ix->regrow((void **)&ix->m_csc, cand_need * 4))) return rc;
             if ((rc = ix->regrow((void **)&ix->m_cid, cand_need * 4))) return rc;
-            if ((rc = ix->regrow((void **)&ix->m_ccnt, (size_t)bpad * 4 + 4))) return rc;
             ix->cap_cand = cand_need;
+        }
+        if ((filt || smallb) && ix->cap_cand_b < (size_t)bpad) { // per-query thresholds / pair counters (+ the overflow word)
+            if ((rc = ix->regrow((void **)&ix->m_thr, (size_t)bpad * 4))) return rc;
+            if ((rc = ix->regrow((void **)&ix->m_ccnt, (size_t)bpad * 4 + 4))) return rc;
+            ix->cap_cand_b = bpad;
         }
         HIP_TRY(hipMemsetAsync(ix->f_top_c, 0, (size_t)b * 4, ix->stream));
         if (filt || smallb) HIP_TRY(hipMemsetAsync(ix->m_ccnt, 0, (size_t)bpad * 4 + 4, ix->stream));

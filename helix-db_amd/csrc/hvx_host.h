@@ -103,7 +103,7 @@ struct hvx_index {
     // filtered-epilogue pipeline: running thresholds and the (score, row) pairs a filtered launch lets through
     float *m_thr = nullptr, *m_csc = nullptr;
     uint32_t *m_cid = nullptr, *m_ccnt = nullptr;
-    size_t cap_cand = 0;
+    size_t cap_cand = 0, cap_cand_b = 0;
     size_t cap_qsplit = 0;
     float m_xmax2 = 0.f;
     uint32_t m_fast_misses = 0, m_fast_skipped = 0; // consecutive scans whose one-pass attempt missed a certificate / scans that skipped it

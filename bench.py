@@ -505,18 +505,24 @@ def leg_config5(hv, synth, orc, dev, rows, b=4096, k=10, dim=1536):
         rc, oid, osc = orc.flat_matrix(orc.L2SQ, deq, qh[qi], k, kernel=orc.K_AVX_FMA_HW)
         ok &= rid[qi, :rcnt[qi]].tolist() == sub[oid].tolist() and rsc[qi, :rcnt[qi]].view(np.uint32).tolist() == osc.view(np.uint32).tolist()
     # the TIMED full scan itself against the oracle -- the first `fq` queries over ALL stored (dequantised) rows,
-    # one 1M-row chunk at a time (torch twin of the import's quantiser, checked against the numpy twin), per-chunk top-k by the
-    # oracle's exact scan, merged by Candidate order (score, id) (model.rs:55-61)
+    # one 1M-row chunk at a time, per-chunk top-k by the oracle's exact scan, merged by Candidate order (score, id) (model.rs:55-61)
     import concurrent.futures
     fq = 8
     qf = q[:fq].cpu().numpy()
     t_full = time.time()
-    probe = x[:4096]
-    twin_ok = bool((quantize_fp8_rows_torch(probe).cpu().numpy() == synth.quantize_fp8_rows(probe.cpu().numpy())).all())
+    # the stored values come from the index itself (hvx_index_read_rows_device: fl32(scale x decode(code)), the expression the
+    # import's quantiser stored); the numpy twin of the quantiser must reproduce them on a sample
+    probe = torch.empty(4096, dim, dtype=torch.float32, device=dev)
+    ix.read_rows_device(0, 4096, probe)
+    twin_ok = bool((probe.cpu().numpy() == synth.quantize_fp8_rows(x[:4096].cpu().numpy())).all())
+    del probe
     merged = [(np.zeros(0, np.uint32), np.zeros(0, np.uint64)) for _ in range(fq)]
+    deq_d = torch.empty(1 << 20, dim, dtype=torch.float32, device=dev)
     with concurrent.futures.ThreadPoolExecutor(max_workers=fq) as pool:
         for c0 in range(0, rows, 1 << 20):
-            deq_c = quantize_fp8_rows_torch(x[c0:c0 + (1 << 20)]).cpu().numpy()
+            cn = min(1 << 20, rows - c0)
+            ix.read_rows_device(c0, cn, deq_d)
+            deq_c = deq_d[:cn].cpu().numpy()
             parts = list(pool.map(lambda qi: orc.flat_matrix(orc.L2SQ, deq_c, qf[qi], k, kernel=orc.K_AVX_FMA_HW), range(fq)))
             for qi, (rc, oid, osc) in enumerate(parts):
                 assert rc == orc.OK
@@ -525,6 +531,7 @@ def leg_config5(hv, synth, orc, dev, rows, b=4096, k=10, dim=1536):
                 order = np.lexsort((ids_, bits))[:k]   # non-negative f32 scores order like their bit patterns
                 merged[qi] = (bits[order], ids_[order])
             del deq_c
+    del deq_d
     got_ids = f[0][:fq].cpu().numpy().astype(np.uint64)
     got_bits = f[1][:fq].cpu().numpy().view(np.uint32)
     full_ok = twin_ok and all(got_ids[qi].tolist() == merged[qi][1].tolist() and got_bits[qi].tolist() == merged[qi][0].tolist() for qi in range(fq))
@@ -546,31 +553,12 @@ def leg_config5(hv, synth, orc, dev, rows, b=4096, k=10, dim=1536):
            "exactness": "certificate passed for every query (the call fails otherwise)", "oracle_bit_exact_sample": bool(ok),
            "oracle_bit_exact_full_scan": bool(full_ok),
            "oracle_full_scan_check": {"queries": fq, "rows": rows, "what": "ids and score bits of the TIMED scan's output == the oracle's exact scan over every "
-                                      "dequantised row (1M-row chunks merged by (score, id))", "quantiser_twin_equal": twin_ok, "seconds": round(t_full, 1)},
+                                      "dequantised row (1M-row chunks merged by (score, id))", "stored_rows_equal_numpy_quantiser_twin_on_sample": twin_ok, "seconds": round(t_full, 1)},
            "corpus_and_import_seconds": round(t_imp, 1)}
     ix.close()
     del x, q
     torch.cuda.empty_cache()
     return out
-
-
-def quantize_fp8_rows_torch(x):
-    """torch twin of pyhvx.synth.quantize_fp8_rows (itself the numpy twin of quantize_fp8_kernel, csrc/hvx_dtype.hip): the f32
-    values an fp8-e4m3fn index stores for rows x, computed on the device so that a 12.5M-row shard can be dequantised for the
-    oracle in seconds.  Same IEEE operations in the same order; bench.py checks it against the numpy twin on a sample."""
-    amax = x.abs().amax(dim=1)
-    scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
-    y = x / scale[:, None]
-    a = y.abs()
-    a = torch.where(a < 464.0, a, torch.full_like(a, 448.0))
-    _, ex = torch.frexp(a)
-    e = ex.to(torch.int32) - 1
-    e = torch.where((a == 0) | (e < -6), torch.full_like(e, -6), e)
-    step = torch.ldexp(torch.ones_like(a), e - 3)
-    v = torch.round(a / step) * step
-    v = torch.clamp(v, max=448.0)
-    v = torch.where(y < 0, -v, v)
-    return (scale[:, None] * v).to(torch.float32)
 
 
 def leg_graph_equivalence(hv, synth, args, dev):

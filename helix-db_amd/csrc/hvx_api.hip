@@ -135,6 +135,18 @@ extern "C" int hvx_index_set_option(hvx_index *ix, uint32_t option, uint32_t val
     return HVX_OK;
 }
 
+extern "C" int hvx_index_read_rows_device(const hvx_index *cix, uint64_t row0, uint64_t n, float *d_out) {
+    if (!cix || (!d_out && n)) return fail(HVX_ERR_INVARIANT, "null argument");
+    hvx_index *ix = const_cast<hvx_index *>(cix);
+    if (row0 > ix->dev.n || n > ix->dev.n - row0) return fail(HVX_ERR_INVARIANT, "rows [%llu, %llu) outside the index (%u rows)", (unsigned long long)row0,
+                                                               (unsigned long long)(row0 + n), ix->dev.n);
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(launch_read_rows(ix->dev, row0, n, d_out, ix->stream));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    return HVX_OK;
+}
+
 extern "C" uint32_t hvx_index_last_scan_path(const hvx_index *ix) { return ix ? ix->last_scan_path : 0u; }
 
 extern "C" void *hvx_index_stream(const hvx_index *ix) { return ix ? (void *)ix->stream : nullptr; }

@@ -63,6 +63,27 @@ __global__ __launch_bounds__(64) void f32_row_norm2_kernel(const float *rows, ui
     if (threadIdx.x == 0) out[r] = (float)acc;
 }
 
+// the f32 values the index holds for rows [row0, row0 + n): what every distance is computed on (f32 rows: the rows; bf16:
+// the rounded values; fp8: fl32(scale * decode(code)), the expression the quantiser stored).  out [n][dim], plain order.
+__global__ __launch_bounds__(256) void read_rows_kernel(DevIndex ix, uint64_t row0, uint64_t n, float *out) {
+    const size_t total = (size_t)n * ix.dim;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+        const size_t r = row0 + t / ix.dim;
+        const uint32_t i = (uint32_t)(t % ix.dim);
+        float v;
+        if (ix.dtype == 2u) v = ix.rowscale[r] * fp8_e4m3_decode(ix.vec8[r * ix.dim + fp8_slot_of(i)]);
+        else if (ix.dtype == 1u) v = bf16_to_f32(ix.vecb[r * ix.dim + bf16_slot_of(i)]);
+        else v = ix.vec[r * ix.ld + i];
+        out[t] = v;
+    }
+}
+
+hipError_t launch_read_rows(const DevIndex &ix, uint64_t row0, uint64_t n, float *out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(read_rows_kernel, dim3(4096), dim3(256), 0, s, ix, row0, n, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_quantize_fp8(float *staging, uint8_t *dst, float *rowscale, uint32_t n, uint32_t dim, hipStream_t s) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(quantize_fp8_kernel, dim3(n), dim3(64), 0, s, staging, dst, rowscale, n, dim);

@@ -83,6 +83,7 @@ hipError_t launch_round_bf16_inplace(float *v, size_t count, hipStream_t s);
 hipError_t launch_pack_bf16(const float *staging, uint16_t *dst, uint32_t n, uint32_t dim, hipStream_t s);
 // fp8 row storage: quantise rows (staging is overwritten with the dequantised values), |x|^2 of f32 rows
 hipError_t launch_quantize_fp8(float *staging, uint8_t *dst, float *rowscale, uint32_t n, uint32_t dim, hipStream_t s);
+hipError_t launch_read_rows(const DevIndex &ix, uint64_t row0, uint64_t n, float *out, hipStream_t s);
 hipError_t launch_f32_row_norm2(const float *rows, uint32_t n, uint32_t ld, uint32_t dim, float *out, hipStream_t s);
 
 // exact distance matrix tile + exact top-k selection (flat scan / restricted exact scan)

@@ -737,6 +737,12 @@ class ValidatedVectorReadIndex:
         _check(lib().hvx_index_fork(self._h, C.byref(h)))
         return type(self)(h, self.dim, self.metric, self.n)
 
+    def read_rows_device(self, row0: int, n: int, d_out):
+        """hvx_index_read_rows_device: the stored (rounded / dequantised) f32 values of rows [row0, row0 + n) into a device tensor"""
+        lib().hvx_index_read_rows_device.restype = C.c_int
+        lib().hvx_index_read_rows_device.argtypes = [_vp, C.c_uint64, C.c_uint64, _vp]
+        _check(lib().hvx_index_read_rows_device(self._h, int(row0), int(n), _vp(d_out.data_ptr())))
+
     def set_option(self, option: int, value: int):
         """hvx_index_set_option: pin an execution path of this handle (tests, A/B measurements); results do not change"""
         lib().hvx_index_set_option.restype = C.c_int

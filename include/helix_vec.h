@@ -101,6 +101,10 @@ void hvx_index_free(hvx_index *);
 int hvx_index_sync(const hvx_index *);
 /* the HIP stream (hipStream_t) search kernels are enqueued on */
 void *hvx_index_stream(const hvx_index *);
+/* The f32 values the index holds for rows [row0, row0 + n) (row = position in node-id order), into device memory
+ * [n][dim]: the rows themselves (f32), the rounded values (bf16) or fl32(scale x decode(code)) (fp8) -- exactly what every
+ * distance of this index is computed on; lets a host (or a checker) score the stored values.  Synchronises. */
+int hvx_index_read_rows_device(const hvx_index *, uint64_t row0, uint64_t n, float *d_out);
 /* enqueue on a caller-owned stream instead (e.g. the host runtime's current stream, so that
  * collectives and searches order without host synchronisation); NULL restores the index's own. */
 int hvx_index_set_stream(hvx_index *, void *hip_stream);

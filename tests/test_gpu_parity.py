@@ -1511,3 +1511,22 @@ def test_small_batch_scan_uses_the_bf16_shadow_once_it_exists(orc, hv):
     for qi in range(0, 24, 5):
         rc, oid, osc = orc.flat_matrix(orc.L2SQ, data, qs[qi], k, kernel=orc.K_AVX_FMA_HW)
         assert a_id[qi].tolist() == oid.tolist() and bits(a_sc[qi]).tolist() == bits(osc).tolist()
+
+
+@pytest.mark.parametrize("dtype_name,dim", [("f32", 100), ("bf16", 128), ("fp8", 256)])
+def test_read_rows_returns_the_stored_values(orc, hv, dtype_name, dim):
+    """hvx_index_read_rows_device hands back exactly the values the index computes distances on: the rows (f32), the RNE-rounded
+    values (bf16), fl32(scale x decode(code)) (fp8) -- equal to the numpy twins of the import's rounding / quantiser."""
+    import torch
+    rng = np.random.default_rng(dim)
+    n = 3000
+    data = (rng.standard_normal((n, dim)) * rng.uniform(0.01, 30.0, (n, 1))).astype(np.float32)
+    stored = {"bf16": fx.round_bf16, "fp8": fx.quantize_fp8_rows, "f32": lambda x: x}[dtype_name](data)
+    dt = {"bf16": hv.BF16, "fp8": hv.FP8_E4M3, "f32": hv.F32}[dtype_name]
+    gix = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=hv.EUCLIDEAN, node_ids=np.arange(n, dtype=np.uint64) * 3, vectors=data, dtype=dt,
+                                              l0_offsets=np.zeros(n + 1, np.uint64), l0_neighbors=np.zeros(0, np.uint64))
+    out = torch.empty(1000, dim, dtype=torch.float32, device="cuda")
+    gix.read_rows_device(1500, 1000, out)
+    assert (out.cpu().numpy().view(np.uint32) == stored[1500:2500].view(np.uint32)).all()
+    with pytest.raises(hv.HelixDbError):
+        gix.read_rows_device(2500, 1000, out)

@@ -74,11 +74,14 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores (capped at 64)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle bit-exactness check")
     ap.add_argument("--metric", default="l2", choices=["l2", "cosine"])
-    ap.add_argument("--skip", default="", help="comma list of extra legs to skip: production,datasets,config3,config4,config5,graph_equivalence")
+    ap.add_argument("--skip", default="", help="comma list of extra legs to skip: production,datasets,iso_recall,config3,config4,config5,graph_equivalence")
     ap.add_argument("--c5-rows", type=int, default=12_500_000, help="config #5 per-GPU shard (100M / 8)")
     ap.add_argument("--c4-rows", type=int, default=1_250_000, help="config #4 per-GPU shard (10M / 8)")
     ap.add_argument("--builder", default="device", choices=["device", "bulk"], help="how the benchmark graph is built")
     ap.add_argument("--build-batch", type=int, default=2048, help="largest insertion batch of the device build")
+    ap.add_argument("--leg", default="headline", choices=["headline", "config5"],
+                    help="'config5' = ONLY the sharded exact scan of configs[4] (100M x 1536 fp8 over 8 GPUs = --c5-rows per GPU, batch 4096): "
+                         "hvx_shard_group_flat_search_batch_device per step (scan -> ncclAllGather -> merge in one C-ABI call)")
     ap.add_argument("--query-batches", type=int, default=0,
                     help="distinct query batches the timed steps cycle through (0 = steps + warmup, at most 64): no two steps in flight "
                          "gather the same rows")
@@ -307,7 +310,7 @@ def hnsw_leg(hv, synth, args, dev, dataset, n, dim, b, k, ef, dtype_name="f32", 
                         "kernel_ms_overlapped": round(per_step, 4), "kernel_ms_each": round(float(kms.mean()), 4)},
            "corpus_and_graph_seconds": round(t_build, 1), "graph": ginfo}
     if keep:
-        return res, dict(ix=ix, ix_truth=ix_truth, ls=ls, x=x, q=q, g=g, truth=f, qst=qst)
+        return res, dict(ix=ix, ix_truth=ix_truth, ls=ls, x=x, q=q, qs=qs, g=g, truth=f, qst=qst)
     ls.close_forks()
     ix.close()
     if ix_truth is not ix:
@@ -561,6 +564,134 @@ def leg_config5(hv, synth, orc, dev, rows, b=4096, k=10, dim=1536):
     return out
 
 
+def leg_iso_recall(hv, synth, orc, args, dev, dataset, n, dim, b, k, efs=(128, 192, 256, 384, 512, 800), target=0.95):
+    """The metric is QPS @ recall@10 >= 0.95: on a corpus where ef = 128 misses the gate, sweep ef (scale_contracts.rs:167-215
+    protocol: same graph, same queries, recall against the exact scan) and report the smallest beam that clears it -- its QPS,
+    roofline fraction and the CPU oracle at the same ef."""
+    res0, st = hnsw_leg(hv, synth, args, dev, dataset, n, dim, b, k, efs[0], steps=12, keep=True)
+    ls, ix_truth = st["ls"], st["ix_truth"]
+    sweep, hit = [], None
+    for ef in efs:
+        elapsed, span, kms = timed_steps(ls, st["qs"], ef, 12, 3, lambda: None)
+        q = ls.last_q[0]
+        f = out_buffers(b, k, dev)
+        ix_truth.flat_search_batch_device(q, k, *f[:4])
+        torch.cuda.synchronize()
+        got = ls.bufs[0]
+        rec = recall_of(got[0], f[0], b, k)
+        qst = got[4].cpu().numpy().astype(np.int64)
+        alg = hnsw_alg_bytes(qst, dim, 4, b)
+        row = {"ef_search": ef, "recall_at_10": round(rec, 4), "qps": round(b * 12 / elapsed, 1), "ms_per_step": round(elapsed * 1e3 / 12, 4),
+               "distance_computations_per_query": round(float(qst[:, 3].mean()), 1),
+               "frac_of_hbm_peak": round(alg / (span / 12 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "kernel": "one wavefront per query" if ef + 32 <= 384 else "general kernel (4 wavefronts per query: ef beyond the register beam of the wave kernel)"}
+        sweep.append(row)
+        if rec >= target:
+            hit = dict(row)
+            break
+    out = {"dataset": dataset, "rows": n, "dim": dim, "batch": b, "k": k, "target_recall_at_10": target, "sweep": sweep, "iso_recall": hit,
+           "leg_at_first_ef": res0}
+    if hit is not None and not args.no_verify:  # the CPU oracle at the same beam width, same graph and queries
+        gg = st["g"]
+        oix = orc.Index(dim, orc.L2SQ, kernel=orc.K_AVX_FMA_HW, m=args.m, m0=2 * args.m)
+        assert oix.seed(gg["node_ids"], st["x"].cpu().numpy(), gg["l0_offsets"], gg["l0_neighbors"], gg["level"], gg["up_offsets"], gg["up_neighbors"],
+                        entry_point=gg["entry_point"], max_layer=gg["max_layer"]) == orc.OK
+        threads = args.cpu_threads or min(os.cpu_count() or 1, 64)
+        qh = ls.last_q[0].cpu().numpy()
+        oix.search_batch(qh[:64], k, hit["ef_search"], threads=threads)
+        t1 = time.perf_counter()
+        rc, o_ids, o_sc, o_cnt, o_st = oix.search_batch(qh, k, hit["ef_search"], threads=threads)
+        cpu_s = time.perf_counter() - t1
+        g_ids = ls.bufs[0][0].cpu().numpy().astype(np.uint64)
+        hit["cpu_oracle"] = {"qps": round(b / cpu_s, 1), "cores": threads, "ids_equal_oracle": bool((g_ids == o_ids).all()),
+                             "score_bits_equal_oracle": bool((ls.bufs[0][1].cpu().numpy().view(np.uint32) == o_sc.view(np.uint32)).all())}
+        out["iso_recall"] = hit
+        del oix
+    ls.close_forks()
+    st["ix"].close()
+    if st["ix_truth"] is not st["ix"]:
+        st["ix_truth"].close()
+    torch.cuda.empty_cache()
+    return out
+
+
+def run_config5_sharded(hv, synth, shard, args, dev, dist, rank, world):
+    """configs[4] as written: every rank holds one id-range shard of fp8-e4m3 rows and scans it exactly for the whole 4096-query
+    batch; ONE all-gather of the packed per-shard top-k (+ status) and the merge by Candidate order happen inside the same
+    C-ABI call.  Weak sizing: --c5-rows per GPU."""
+    rows, b, k, dim = args.c5_rows, 4096, 10, 1536
+    x, q = synth.corpus("embedding", rows, dim, b, 20260924, dev, latent=24, clusters=4096)   # every shard draws the same rows: ids differ
+    ids = np.arange(rows, dtype=np.uint64) + np.uint64(rank * rows)
+    t0 = time.time()
+    ix = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=hv.EUCLIDEAN, node_ids=ids, vectors=x, l0_offsets=np.zeros(rows + 1, np.uint64),
+                                             l0_neighbors=np.zeros(0, np.uint64), device=dev.index, max_batch=b, dtype=hv.FP8_E4M3)
+    del x
+    torch.cuda.empty_cache()
+    t_imp = time.time() - t0
+    out = out_buffers(b, k, dev)
+    grp = None
+    exchange = "single GPU"
+    if world > 1 and not SHARED_GPU:
+        t = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            t.copy_(torch.frombuffer(bytearray(hv.ShardGroup.unique_id()), dtype=torch.uint8))
+        dist.broadcast(t, 0)
+        grp = hv.ShardGroup(ix, bytes(t.cpu().numpy().tobytes()), rank, world, b, k)
+        exchange = "hvx_shard_group_flat_search_batch_device: scan + in-library ncclAllGather (RCCL) + merge, one C-ABI call per step"
+    elif world > 1:
+        ss = shard.ShardedSearcher(ix, world, b, k, dev, None, stage_through_host=True)
+        exchange = "torch.distributed all_gather (gloo, host staged: plumbing run on one GPU) + hvx_merge_topk_packed_device"
+
+    def step():
+        if grp is not None:
+            grp.flat_search_batch_device(q, k, out[0], out[1], out[2], out[3])
+        elif world > 1:
+            li, ls, lc = ss.outputs()
+            ix.flat_search_batch_device(q, k, li, ls, lc, out[3])
+            m = ss.merge(li, ls, lc)
+            out[0].copy_(m[0]); out[1].copy_(m[1]); out[2].copy_(m[2])
+        else:
+            ix.flat_search_batch_device(q, k, out[0], out[1], out[2], out[3])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    steps, warmup = max(1, min(args.steps, 10)), max(1, min(args.warmup, 2))
+    for _ in range(warmup):
+        step()
+    ix.sync()
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ix.sync()
+    barrier()
+    elapsed = time.perf_counter() - t1
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if SHARED_GPU else dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt[0].item())
+    assert int(out[3].abs().sum().item()) == 0, "a query was rejected"
+    ms = elapsed * 1e3 / steps
+    useful = 2.0 * b * rows * dim   # per GPU
+    res = {"metric": "exact-scan queries/s, configs[4] (100M x 1536 fp8 over 8 GPUs, batch 4096): every query answered over ALL shards",
+           "value": round(b * steps / elapsed, 1), "unit": "queries/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp8-e4m3 rows, f32 re-rank",
+           "data": "synthetic",
+           "config": {"workload": f"configs[4]: {rows}x{dim} fp8-e4m3 rows per GPU ({rows * world} in all), exact kNN k={k}, batch {b}, squared-L2",
+                      "rows_per_gpu": rows, "rows_total": rows * world, "exchange": exchange},
+           "roofline": {"bound": "mfma", "achieved": round(useful / ms / 1e9, 1), "peak": MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(useful / ms / 1e9 / MFMA_BF16_TFLOPS, 4),
+                        "note": "per GPU: ALGORITHMIC flops 2*b*rows_per_gpu*dim over the whole step (scan + exchange + merge)"},
+           "import_seconds": round(t_imp, 1)}
+    if grp is not None:
+        grp.close()
+    ix.close()
+    return res
+
+
 def leg_graph_equivalence(hv, synth, args, dev):
     """The bulk builder behind the benchmark graph vs the reference's sequential insert_hnsw (oracle restatement), same
     100 000 x 768 rows, queries and levels: tests/golden/graph_equivalence_ref.json holds the oracle side."""
@@ -661,6 +792,14 @@ def main():
     from pyhvx import shard, synth
     hv.lib()
     skip = set(s for s in args.skip.split(",") if s)
+
+    if args.leg == "config5":
+        res = run_config5_sharded(hv, synth, shard, args, dev, dist, rank, world)
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     dim, b, k, ef = args.dim, args.batch, args.k, args.ef
     bf16 = args.dtype == "bf16"
@@ -1042,6 +1181,12 @@ def main():
             ds = {}
             for name in ("clustered", "gaussian"):
                 if name == args.dataset:
+                    continue
+                if name == "clustered" and "iso_recall" not in skip:  # the same leg + the ef sweep to the recall gate on the same graph
+                    iso = guarded("dataset clustered + iso_recall", lambda: leg_iso_recall(hv, synth, orc, args, dev, "clustered", args.rows, dim, b, k,
+                                                                                          efs=(ef, 192, 256, 384, 512, 800)))
+                    ds[name] = iso.pop("leg_at_first_ef", iso)
+                    ds["clustered_iso_recall"] = iso
                     continue
                 ds[name] = guarded(f"dataset {name}", lambda: hnsw_leg(hv, synth, args, dev, name, args.rows, dim, b, k, ef, steps=30)[0])
             ds["note"] = ("headline = 'embedding' (low intrinsic dimension, recall >= 0.95); 'clustered' = SURVEY 8(d)'s stated variant "

@@ -157,6 +157,8 @@ int check_k_ef(uint32_t k, uint32_t ef);
 int enqueue_search(const hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, uint32_t ef, uint64_t *d_ids,
                    float *d_scores, uint32_t *d_counts, uint32_t *d_status, hvx_query_stats *d_qstats, bool timed,
                    const AdaptArgs *ad = nullptr);
+int enqueue_search_params(hvx_index *ix, const float *d_queries, uint32_t b, const hvx_search_params *params, uint64_t *d_ids, float *d_scores,
+                          uint32_t *d_counts, uint32_t *d_status);
 int collect_stats(hvx_index *ix, uint32_t b, const hvx_query_stats *d_qstats, hvx_stats *stats);
 float component_limit(uint32_t metric, uint32_t dim);
 int flat_scan_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, const uint32_t *d_subset,

@@ -228,6 +228,16 @@ static int enqueue_params(hvx_index *ix, const float *d_queries, uint32_t b, con
     return enqueue_search(ix, d_queries, b, p->k, p->ef, d_ids, d_scores, d_counts, d_status, d_qstats, timed, &a);
 }
 
+// project + enqueue for a caller that already holds the handle's lock (hvx_shard.hip)
+int hvx::enqueue_search_params(hvx_index *ix, const float *d_queries, uint32_t b, const hvx_search_params *params, uint64_t *d_ids, float *d_scores,
+                               uint32_t *d_counts, uint32_t *d_status) {
+    AdaptArgs ad;
+    bool strict = false;
+    int rc = project_params(ix, params, &ad, &strict);
+    if (rc) return rc;
+    return enqueue_params(ix, d_queries, b, params, &ad, strict, d_ids, d_scores, d_counts, d_status, nullptr, nullptr, false);
+}
+
 extern "C" int hvx_search_batch_params_device(const hvx_index *cix, const float *d_queries, uint32_t b, const hvx_search_params *params,
                                               uint64_t *d_out_ids, float *d_out_scores, uint32_t *d_out_counts,
                                               uint32_t *d_out_status, hvx_query_stats *d_query_stats,

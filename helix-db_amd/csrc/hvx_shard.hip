@@ -11,10 +11,11 @@
 // rank 0 calls hvx_shard_group_unique_id, the host hands the 128 bytes to every rank by whatever transport it owns.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include "hvx_host.h"
 
@@ -25,6 +26,16 @@ using namespace hvx;
         hipError_t _e = (expr);                                                                    \
         if (_e != hipSuccess) return fail(HVX_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(_e)); \
     } while (0)
+
+// The handful of RCCL declarations this file needs, stated here so that the library builds (and single-GPU deployments run)
+// without RCCL's headers or shared object; values as in rccl.h / nccl.h (stable ABI: ncclSuccess = 0, ncclUint8 = 1,
+// ncclUniqueId = 128 opaque bytes, ncclComm_t an opaque pointer).
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1 } ncclDataType_t;
+}
 
 namespace {
 struct Rccl {
@@ -105,7 +116,7 @@ extern "C" int hvx_shard_group_init(hvx_index *local_shard, const uint8_t *uniqu
     g->world = world;
     g->max_batch = max_batch;
     g->max_k = max_k;
-    const size_t payload = hvx_topk_payload_bytes(max_batch, max_k);
+    const size_t payload = ((hvx_topk_payload_bytes(max_batch, max_k) + (size_t)max_batch * 4) + 7) & ~(size_t)7; // + per-query status
     if (hipMalloc((void **)&g->send, payload) != hipSuccess || hipMalloc((void **)&g->recv, payload * world) != hipSuccess ||
         hipMalloc((void **)&g->status, (size_t)max_batch * 4) != hipSuccess) {
         hvx_shard_group_free(g);
@@ -132,33 +143,176 @@ extern "C" int hvx_shard_group_init(hvx_index *local_shard, const uint8_t *uniqu
     return HVX_OK;
 }
 
-extern "C" int hvx_shard_group_search_batch_device(hvx_shard_group *g, const float *d_queries, uint32_t b, uint32_t k, uint32_t ef,
-                                                   uint64_t *d_out_ids, float *d_out_scores, uint32_t *d_out_counts) {
-    if (!g || !d_queries || !d_out_ids || !d_out_scores || !d_out_counts) return fail(HVX_ERR_INVARIANT, "null argument");
-    if (b == 0) return HVX_OK;
-    if (b > g->max_batch || k > g->max_k) return fail(HVX_ERR_UNSUPPORTED, "batch %u / k %u exceed the group's %u / %u", b, k, g->max_batch, g->max_k);
-    int rc = check_k_ef(k, ef);
-    if (rc) return rc;
+namespace {
+
+// internal payload of a step: the public packed top-k payload (hvx_topk_payload_bytes) + the per-query status [b] u32
+size_t step_payload(uint32_t b, uint32_t k) { return ((hvx_topk_payload_bytes(b, k) + (size_t)b * 4) + 7) & ~(size_t)7; }
+
+// element-wise maximum of the ranks' per-query statuses (a rejected query is rejected on every shard: validation does not
+// depend on the shard; search.rs:1120-1125 returns InvalidVectorComponent for it) -- and no results for a failed query
+__global__ void merge_status_kernel(const char *gathered, size_t payload, size_t status_off, uint32_t world, uint32_t b, uint32_t *out_status,
+                                    uint32_t *out_counts) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= b) return;
+    uint32_t st = 0;
+    for (uint32_t r = 0; r < world; ++r) {
+        const uint32_t v = reinterpret_cast<const uint32_t *>(gathered + (size_t)r * payload + status_off)[q];
+        st = v > st ? v : st;
+    }
+    if (out_status) out_status[q] = st;
+    if (st) out_counts[q] = 0;
+}
+
+struct StepBuffers {
+    uint64_t *ids;
+    float *scores;
+    uint32_t *counts, *status;
+    size_t payload, status_off;
+};
+
+StepBuffers step_views(hvx_shard_group *g, uint32_t b, uint32_t k) {
+    StepBuffers v;
+    v.payload = step_payload(b, k);
+    v.status_off = hvx_topk_payload_bytes(b, k);
+    v.ids = reinterpret_cast<uint64_t *>(g->send);
+    v.scores = reinterpret_cast<float *>(g->send + (size_t)b * k * 8);
+    v.counts = reinterpret_cast<uint32_t *>(g->send + (size_t)b * k * 12);
+    v.status = reinterpret_cast<uint32_t *>(g->send + v.status_off);
+    return v;
+}
+
+// all-gather of the local payload + merge by Candidate order + status merge, on the shard's stream (handle lock held)
+int exchange_and_merge(hvx_shard_group *g, uint32_t b, uint32_t k, const StepBuffers &v, uint64_t *d_out_ids, float *d_out_scores,
+                       uint32_t *d_out_counts, uint32_t *d_out_status) {
     hvx_index *ix = g->ix;
-    std::lock_guard<std::mutex> lock(ix->mu);
-    HIP_TRY(hipSetDevice(ix->device));
-    const size_t payload = hvx_topk_payload_bytes(b, k);
-    uint64_t *s_ids = reinterpret_cast<uint64_t *>(g->send);
-    float *s_sc = reinterpret_cast<float *>(g->send + (size_t)b * k * 8);
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(g->send + (size_t)b * k * 12);
-    rc = enqueue_search(ix, d_queries, b, k, ef, s_ids, s_sc, s_cnt, g->status, nullptr, false);
-    if (rc) return rc;
     const char *gathered = g->send;
     if (g->comm) {
-        const ncclResult_t e = rccl().AllGather(g->send, g->recv, payload, ncclUint8, g->comm, ix->stream);
+        const ncclResult_t e = rccl().AllGather(g->send, g->recv, v.payload, ncclUint8, g->comm, ix->stream);
         if (e != ncclSuccess) return fail(HVX_ERR_DEVICE, "ncclAllGather: %s", rccl().GetErrorString(e));
         gathered = g->recv;
     } else if (g->world > 1) {
         return fail(HVX_ERR_INVARIANT, "shard group of %u ranks has no communicator", g->world);
     }
-    HIP_TRY(launch_merge_topk_strided(g->comm ? g->world : 1u, b, k, reinterpret_cast<const uint64_t *>(gathered),
+    const uint32_t lists = g->comm ? g->world : 1u;
+    HIP_TRY(launch_merge_topk_strided(lists, b, k, reinterpret_cast<const uint64_t *>(gathered),
                                       reinterpret_cast<const float *>(gathered + (size_t)b * k * 8),
-                                      reinterpret_cast<const uint32_t *>(gathered + (size_t)b * k * 12), payload / 8, payload / 4, payload / 4,
+                                      reinterpret_cast<const uint32_t *>(gathered + (size_t)b * k * 12), v.payload / 8, v.payload / 4, v.payload / 4,
                                       d_out_ids, d_out_scores, d_out_counts, ix->stream));
+    hipLaunchKernelGGL(merge_status_kernel, dim3((b + 255u) / 256u), dim3(256), 0, ix->stream, gathered, v.payload, v.status_off, lists, b,
+                       d_out_status, d_out_counts);
+    HIP_TRY(hipGetLastError());
+    return HVX_OK;
+}
+
+int check_step(hvx_shard_group *g, const void *q, const void *a, const void *b_, const void *c, uint32_t b, uint32_t k) {
+    if (!g || !q || !a || !b_ || !c) return fail(HVX_ERR_INVARIANT, "null argument");
+    if (b > g->max_batch || k > g->max_k) return fail(HVX_ERR_UNSUPPORTED, "batch %u / k %u exceed the group's %u / %u", b, k, g->max_batch, g->max_k);
+    return HVX_OK;
+}
+
+} // namespace
+
+extern "C" int hvx_shard_group_search_batch_device(hvx_shard_group *g, const float *d_queries, uint32_t b, uint32_t k, uint32_t ef,
+                                                   uint64_t *d_out_ids, float *d_out_scores, uint32_t *d_out_counts, uint32_t *d_out_status) {
+    int rc = check_step(g, d_queries, d_out_ids, d_out_scores, d_out_counts, b, k);
+    if (rc) return rc;
+    if (b == 0) return HVX_OK;
+    if ((rc = check_k_ef(k, ef))) return rc;
+    hvx_index *ix = g->ix;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    const StepBuffers v = step_views(g, b, k);
+    if ((rc = enqueue_search(ix, d_queries, b, k, ef, v.ids, v.scores, v.counts, v.status, nullptr, false))) return rc;
+    return exchange_and_merge(g, b, k, v, d_out_ids, d_out_scores, d_out_counts, d_out_status);
+}
+
+extern "C" int hvx_shard_group_search_batch_params_device(hvx_shard_group *g, const float *d_queries, uint32_t b, const hvx_search_params *params,
+                                                          uint64_t *d_out_ids, float *d_out_scores, uint32_t *d_out_counts, uint32_t *d_out_status) {
+    if (!params) return fail(HVX_ERR_INVARIANT, "null argument");
+    int rc = check_step(g, d_queries, d_out_ids, d_out_scores, d_out_counts, b, params->k);
+    if (rc) return rc;
+    if (b == 0) return HVX_OK;
+    hvx_index *ix = g->ix;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    const StepBuffers v = step_views(g, b, params->k);
+    if ((rc = enqueue_search_params(ix, d_queries, b, params, v.ids, v.scores, v.counts, v.status))) return rc;
+    return exchange_and_merge(g, b, params->k, v, d_out_ids, d_out_scores, d_out_counts, d_out_status);
+}
+
+extern "C" int hvx_shard_group_flat_search_batch_device(hvx_shard_group *g, const float *d_queries, uint32_t b, uint32_t k, uint64_t *d_out_ids,
+                                                        float *d_out_scores, uint32_t *d_out_counts, uint32_t *d_out_status) {
+    int rc = check_step(g, d_queries, d_out_ids, d_out_scores, d_out_counts, b, k);
+    if (rc) return rc;
+    if (b == 0) return HVX_OK;
+    if (k == 0) return fail(HVX_ERR_K_RANGE, "result count must be non-zero");
+    hvx_index *ix = g->ix;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    const StepBuffers v = step_views(g, b, k);
+    // the exact scan of this shard's rows (restricted_exact_scan with allowed = the shard, restricted.rs:753-835); it synchronises
+    // internally only to read its certificates
+    if ((rc = flat_scan_device(ix, d_queries, b, k, nullptr, ix->dev.n, v.ids, v.scores, v.counts, v.status, false))) return rc;
+    return exchange_and_merge(g, b, k, v, d_out_ids, d_out_scores, d_out_counts, d_out_status);
+}
+
+// Restricted search over the group: every rank is handed the SAME candidate id list and keeps the ids of its own id range
+// [shard_id_lo, shard_id_hi] ("the bitmap is sliced by the same id ranges"); limits that the reference applies to the
+// whole set (<= 1 000 000 unique ids, k clamped to the candidate count, <= 800) are applied to the whole set here too.
+extern "C" int hvx_shard_group_search_restricted_batch(hvx_shard_group *g, const float *queries, uint32_t b, const hvx_restricted_params *params,
+                                                       const uint64_t *allowed_ids, uint64_t n_allowed, uint64_t *out_ids, float *out_scores,
+                                                       uint32_t *out_counts, uint32_t *out_status) {
+    if (!g || !queries || !params || !out_ids || !out_scores || !out_counts || (!allowed_ids && n_allowed)) return fail(HVX_ERR_INVARIANT, "null argument");
+    if (b == 0) return HVX_OK;
+    if (b > g->max_batch) return fail(HVX_ERR_UNSUPPORTED, "batch %u exceeds the group's %u", b, g->max_batch);
+    if (params->k == 0) return fail(HVX_ERR_K_RANGE, "result count must be non-zero");
+    if (params->ef < params->k) return fail(HVX_ERR_K_RANGE, "search beam width %u is below the result count %u", params->ef, params->k);
+    hvx_index *ix = g->ix;
+    std::vector<uint64_t> ids(allowed_ids, allowed_ids + n_allowed);
+    std::sort(ids.begin(), ids.end());
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    if (ids.size() > 1000000) return fail(HVX_ERR_CANDIDATE_LIMIT, "restricted vector search accepts at most 1000000 unique candidates");
+    const uint32_t k = (uint32_t)std::min<uint64_t>(params->k, std::max<size_t>(ids.size(), 1));
+    if (!ids.empty() && k > 800) return fail(HVX_ERR_K_RANGE, "restricted vector search result count %u is above the maximum 800", k);
+    if (k > g->max_k) return fail(HVX_ERR_UNSUPPORTED, "k %u exceeds the group's %u", k, g->max_k);
+    const uint64_t lo = ix->desc.shard_id_lo, hi = ix->desc.shard_id_hi;
+    const auto first = std::lower_bound(ids.begin(), ids.end(), lo), last = std::upper_bound(ids.begin(), ids.end(), hi);
+    const std::vector<uint64_t> mine(first, last);
+    std::vector<uint64_t> l_ids((size_t)b * k);
+    std::vector<float> l_sc((size_t)b * k);
+    std::vector<uint32_t> l_cnt(b, 0), l_st(b, 0);
+    if (!mine.empty()) {
+        hvx_restricted_params lp = *params;
+        lp.k = k;
+        if (lp.ef < k) lp.ef = k;
+        int rc = hvx_search_restricted_batch_params(ix, queries, b, &lp, mine.data(), nullptr, mine.size(), l_ids.data(), l_sc.data(), l_cnt.data(),
+                                                    l_st.data(), nullptr, nullptr);
+        if (rc) return rc;
+    }
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    const StepBuffers v = step_views(g, b, k);
+    HIP_TRY(hipMemcpyAsync(v.ids, l_ids.data(), l_ids.size() * 8, hipMemcpyHostToDevice, ix->stream));
+    HIP_TRY(hipMemcpyAsync(v.scores, l_sc.data(), l_sc.size() * 4, hipMemcpyHostToDevice, ix->stream));
+    HIP_TRY(hipMemcpyAsync(v.counts, l_cnt.data(), (size_t)b * 4, hipMemcpyHostToDevice, ix->stream));
+    HIP_TRY(hipMemcpyAsync(v.status, l_st.data(), (size_t)b * 4, hipMemcpyHostToDevice, ix->stream));
+    int rc = ix->stage(b, k);
+    if (rc) return rc;
+    if ((rc = exchange_and_merge(g, b, k, v, ix->s_ids, ix->s_scores, ix->s_counts, ix->s_status))) return rc;
+    std::vector<uint64_t> m_ids((size_t)b * k);
+    std::vector<float> m_sc((size_t)b * k);
+    std::vector<uint32_t> m_cnt(b), m_st(b);
+    HIP_TRY(hipMemcpyAsync(m_ids.data(), ix->s_ids, m_ids.size() * 8, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipMemcpyAsync(m_sc.data(), ix->s_scores, m_sc.size() * 4, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipMemcpyAsync(m_cnt.data(), ix->s_counts, (size_t)b * 4, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipMemcpyAsync(m_st.data(), ix->s_status, (size_t)b * 4, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    for (uint32_t q = 0; q < b; ++q) {
+        out_counts[q] = m_st[q] ? 0u : m_cnt[q];
+        if (out_status) out_status[q] = m_st[q];
+        else if (m_st[q]) return fail((int)m_st[q], "query %u rejected with status %u", q, m_st[q]);
+        memcpy(out_ids + (size_t)q * params->k, m_ids.data() + (size_t)q * k, (size_t)out_counts[q] * 8);
+        memcpy(out_scores + (size_t)q * params->k, m_sc.data() + (size_t)q * k, (size_t)out_counts[q] * 4);
+    }
     return HVX_OK;
 }

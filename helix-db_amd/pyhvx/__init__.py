@@ -783,9 +783,43 @@ class ShardGroup:
         _check(lib().hvx_shard_group_unique_id(_ptr(out)))
         return out.tobytes()
 
-    def search_batch_device(self, d_queries, k, ef, d_ids, d_scores, d_counts):
-        _check(lib().hvx_shard_group_search_batch_device(self._g, d_queries.data_ptr(), d_queries.shape[0], k, ef, d_ids.data_ptr(),
-                                                         d_scores.data_ptr(), d_counts.data_ptr()))
+    @staticmethod
+    def _st(d_status):
+        return None if d_status is None else _vp(d_status.data_ptr())
+
+    def search_batch_device(self, d_queries, k, ef, d_ids, d_scores, d_counts, d_status=None):
+        L = lib()
+        L.hvx_shard_group_search_batch_device.restype = C.c_int
+        L.hvx_shard_group_search_batch_device.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]
+        _check(L.hvx_shard_group_search_batch_device(self._g, d_queries.data_ptr(), d_queries.shape[0], k, ef, d_ids.data_ptr(),
+                                                     d_scores.data_ptr(), d_counts.data_ptr(), self._st(d_status)))
+
+    def search_batch_params_device(self, d_queries, params: "SearchParams", d_ids, d_scores, d_counts, d_status=None):
+        L = lib()
+        L.hvx_shard_group_search_batch_params_device.restype = C.c_int
+        L.hvx_shard_group_search_batch_params_device.argtypes = [_vp, _vp, C.c_uint32, C.POINTER(_Params), _vp, _vp, _vp, _vp]
+        cp = params._c()
+        _check(L.hvx_shard_group_search_batch_params_device(self._g, d_queries.data_ptr(), d_queries.shape[0], C.byref(cp), d_ids.data_ptr(),
+                                                            d_scores.data_ptr(), d_counts.data_ptr(), self._st(d_status)))
+
+    def flat_search_batch_device(self, d_queries, k, d_ids, d_scores, d_counts, d_status=None):
+        L = lib()
+        L.hvx_shard_group_flat_search_batch_device.restype = C.c_int
+        L.hvx_shard_group_flat_search_batch_device.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]
+        _check(L.hvx_shard_group_flat_search_batch_device(self._g, d_queries.data_ptr(), d_queries.shape[0], k, d_ids.data_ptr(),
+                                                          d_scores.data_ptr(), d_counts.data_ptr(), self._st(d_status)))
+
+    def search_restricted_batch(self, queries, rparams: "RestrictedParams", candidates):
+        """every rank passes the same candidate ids; returns (ids, scores, counts, status) of the merged answer"""
+        L = lib()
+        L.hvx_shard_group_search_restricted_batch.restype = C.c_int
+        L.hvx_shard_group_search_restricted_batch.argtypes = [_vp, _vp, C.c_uint32, C.POINTER(RestrictedParams), _vp, C.c_uint64, _vp, _vp, _vp, _vp]
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        b, k = q.shape[0], int(rparams.k)
+        al = candidates.ids if isinstance(candidates, RestrictedVectorCandidates) else np.ascontiguousarray(candidates, dtype=np.uint64)
+        ids = np.zeros((b, k), np.uint64); sc = np.zeros((b, k), np.float32); cnt = np.zeros(b, np.uint32); st = np.zeros(b, np.uint32)
+        _check(L.hvx_shard_group_search_restricted_batch(self._g, _ptr(q), b, C.byref(rparams), _ptr(al), al.size, _ptr(ids), _ptr(sc), _ptr(cnt), _ptr(st)))
+        return ids, sc, cnt, st
 
     def close(self):
         if self._g:

@@ -38,6 +38,20 @@ def owner_of(node_id: int, n_rows: int, world: int) -> int:
     return extra + (node_id - cut) // max(base, 1)
 
 
+def slice_candidates(sorted_unique_ids, lo: int, hi: int):
+    """The candidate ids a shard holding node ids [lo, hi] keeps of a restricted search's id list ("the bitmap is
+    sliced by the same id ranges"); mirrors hvx_shard_group_search_restricted_batch."""
+    import numpy as np
+    ids = np.asarray(sorted_unique_ids, dtype=np.uint64)
+    return ids[np.searchsorted(ids, lo, side="left"): np.searchsorted(ids, hi, side="right")]
+
+
+def merge_status(statuses):
+    """Per-query status of a sharded step = element-wise maximum over the ranks' statuses [world][b]: a rejected query is rejected
+    by every shard's validation (search.rs:1120-1125); mirrors merge_status_kernel (csrc/hvx_shard.hip)."""
+    return torch.as_tensor(statuses).max(dim=0).values
+
+
 def payload_bytes(b: int, k: int) -> int:
     """One rank's share of the packed exchange buffer (== hvx_topk_payload_bytes): ids [b][k] u64, scores [b][k] f32,
     counts [b] u32, padded to 8 bytes."""

@@ -351,8 +351,23 @@ typedef struct hvx_shard_group hvx_shard_group;
 int hvx_shard_group_unique_id(uint8_t *out /*[HVX_SHARD_UNIQUE_ID_BYTES]*/);
 int hvx_shard_group_init(hvx_index *local_shard, const uint8_t *unique_id, uint32_t rank, uint32_t world, uint32_t max_batch, uint32_t max_k,
                          hvx_shard_group **out);
+/* Every step below is  local search -> ONE all-gather of the packed per-shard top-k + per-query status -> merge by Candidate
+ * order.  d_out_status (nullable): per query, the element-wise maximum of the ranks' statuses -- a NaN / zero-norm / oversized
+ * query is rejected by every shard's validation (search.rs:1120-1125 InvalidVectorComponent ...) and comes back with count 0. */
 int hvx_shard_group_search_batch_device(hvx_shard_group *, const float *d_queries, uint32_t b, uint32_t k, uint32_t ef,
-                                        uint64_t *d_out_ids /*[b][k]*/, float *d_out_scores, uint32_t *d_out_counts);
+                                        uint64_t *d_out_ids /*[b][k]*/, float *d_out_scores, uint32_t *d_out_counts, uint32_t *d_out_status);
+/* full SearchParams per shard (hvx_search_batch_params_device: the production default and the other non-strict arms) */
+int hvx_shard_group_search_batch_params_device(hvx_shard_group *, const float *d_queries, uint32_t b, const hvx_search_params *params,
+                                               uint64_t *d_out_ids, float *d_out_scores, uint32_t *d_out_counts, uint32_t *d_out_status);
+/* exact scan of every shard (BASELINE configs[4]: the batched-query x corpus scan over fp8 / bf16 / f32 rows, sharded by id range) */
+int hvx_shard_group_flat_search_batch_device(hvx_shard_group *, const float *d_queries, uint32_t b, uint32_t k, uint64_t *d_out_ids,
+                                             float *d_out_scores, uint32_t *d_out_counts, uint32_t *d_out_status);
+/* restricted search: every rank passes the SAME candidate id list and keeps the ids of its own range
+ * [desc.shard_id_lo, desc.shard_id_hi]; host buffers like hvx_search_restricted_batch_params; the set-wide limits
+ * (<= 1 000 000 ids, k clamped to the candidate count then <= 800) apply to the whole list; each shard plans its own slice. */
+int hvx_shard_group_search_restricted_batch(hvx_shard_group *, const float *queries, uint32_t b, const hvx_restricted_params *params,
+                                            const uint64_t *allowed_ids, uint64_t n_allowed, uint64_t *out_ids /*[b][params->k]*/,
+                                            float *out_scores, uint32_t *out_counts, uint32_t *out_status /*nullable*/);
 void hvx_shard_group_free(hvx_shard_group *);
 
 /*

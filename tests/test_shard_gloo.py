@@ -94,3 +94,72 @@ def test_shard_plan_covers_ids_once():
         for i in range(0, n, max(1, n // 50)):
             r = shard.owner_of(i, n, w)
             assert plan[r][0] <= i < plan[r][1]
+
+
+def _restricted_worker(rank, world, port, out_dir):
+    """N > 1 restricted search on CPU: every rank holds the same candidate id list, keeps the ids of its own id range
+    (shard.slice_candidates == hvx_shard_group_search_restricted_batch's slicing), answers over them (the oracle stands in for
+    the shard's search), and the exchange carries ids, scores, counts AND the per-query status, merged by the element-wise
+    maximum (shard.merge_status == merge_status_kernel)."""
+    for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "helix-db_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import orc
+    from pyhvx import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, dim, k, b = 2000, 16, 10, 6
+    rng = np.random.default_rng(7)
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    q = rng.standard_normal((b, dim)).astype(np.float32)
+    q[2, 1] = np.nan                                           # rejected by every shard's validation
+    allowed = np.unique(rng.choice(np.arange(n + 50, dtype=np.uint64), 700))   # some ids beyond the corpus: no vector anywhere
+    lo, hi = shard.plan_shards(n, world)[rank]
+    mine = shard.slice_candidates(allowed, lo, hi - 1)
+    ok = all(lo <= int(i) < hi for i in mine)
+    parts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(parts, torch.tensor([mine.size]))
+    ok &= sum(int(p) for p in parts) == int((allowed < n).sum())      # the slices partition the indexed candidates
+    oix = orc.Index(dim, orc.L2SQ)
+    m = hi - lo
+    assert oix.seed(np.arange(lo, hi, dtype=np.uint64), data[lo:hi], np.zeros(m + 1, np.uint64), np.zeros(0, np.uint64), entry_point=lo) == orc.OK
+    l_ids = np.zeros((b, k), np.int64); l_sc = np.zeros((b, k), np.float32); l_cnt = np.zeros(b, np.int32); l_st = np.zeros(b, np.int32)
+    for qi in range(b):
+        rc, bad = orc.validate(orc.L2SQ, q[qi], dim)
+        if rc:
+            l_st[qi] = rc
+            continue
+        if mine.size:
+            rc, oid, osc = oix.flat(q[qi], k, allowed=mine)
+            assert rc == orc.OK
+            l_ids[qi, :oid.size] = oid.astype(np.int64); l_sc[qi, :oid.size] = osc; l_cnt[qi] = oid.size
+    ex = shard.TopkExchange(world, b, k, "cpu")
+    ex.gather(torch.from_numpy(l_ids), torch.from_numpy(l_sc), torch.from_numpy(l_cnt))
+    sts = [torch.zeros(b, dtype=torch.int32) for _ in range(world)]
+    dist.all_gather(sts, torch.from_numpy(l_st))
+    st = shard.merge_status(torch.stack(sts)).numpy()
+    g_ids, g_sc, g_cnt = ex.gathered()
+    m_ids, m_sc, m_cnt = fx.merge_topk_reference(g_ids.numpy().view(np.uint64), g_sc.numpy(), g_cnt.numpy(), k)
+    m_cnt = np.where(st != 0, 0, m_cnt)
+    full = orc.Index(dim, orc.L2SQ)
+    assert full.seed(np.arange(n, dtype=np.uint64), data, np.zeros(n + 1, np.uint64), np.zeros(0, np.uint64), entry_point=0) == orc.OK
+    for qi in range(b):
+        if qi == 2:
+            ok &= st[qi] == orc.ERR_NONFINITE and m_cnt[qi] == 0
+            continue
+        rc, tid, tsc = full.flat(q[qi], k, allowed=allowed)
+        ok &= st[qi] == 0 and m_cnt[qi] == tid.size and m_ids[qi, :tid.size].tolist() == tid.tolist()
+        ok &= m_sc[qi, :tid.size].view(np.uint32).tolist() == tsc.view(np.uint32).tolist()
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+        f.write("ok" if ok else "FAIL")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_restricted_search_slices_candidates_and_merges_status(tmp_path, world):
+    port = _free_port()
+    mp.spawn(_restricted_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / f"rank{r}.txt").read() == "ok"

@@ -3,19 +3,31 @@
 // The reference calls `ValidatedVectorReadIndex::search` once per operator invocation, from many tokio tasks
 // (crates/db/src/execution/interpreter/access/search/storage.rs:140-163): one query per call.  The device kernels are
 // built for batches (one wavefront per query; 1 024 queries fill the chip), so concurrent single-query callers are
-// coalesced here: a caller blocks in hvx_batcher_search, a dispatcher thread owned by the batcher gathers whatever is
-// waiting -- up to max_batch queries, or after the oldest has waited max_wait_us -- into ONE hvx_search_batch_params
-// launch and hands every caller its own rows of the result.  A batcher owns `lanes` dispatchers (default 2), each with its
-// own execution lane on the shared index image (hvx_index_fork): batch i+1 is collected and launched while batch i is on
-// the device, and nothing serialises on the caller's index handle.  Results are exactly those of a direct batch call
-// (queries are independent; tests/test_gpu_parity.py::test_batcher_*).
+// coalesced here.  Results are exactly those of a direct batch call (queries are independent).
+//
+// Round 3 design (round 2's collector, not the device, was the limit: 418 k QPS = 28 % of the batch kernel):
+//   * NO lock and NO per-request object on the path of a caller.  One 64-bit word `state` = (batch sequence << 32 | slots
+//     claimed) is the whole queue: a caller claims slot `n` of the open batch with one compare-and-swap, copies its query
+//     straight into the batch's PINNED staging row (the row the H2D copy reads), bumps `filled`, and sleeps on the batch's
+//     completion word (futex); a dispatcher closes the open batch with one compare-and-swap (sequence + 1, count 0), which
+//     at the same instant opens the next batch for the callers that keep arriving.
+//   * A batch is closed when it is full -- or as soon as a DEVICE LANE IS FREE and at least one query waits.  No timer in
+//     the steady state: while all lanes are busy the open batch simply grows, so the batch size follows the load (a lone
+//     caller on an idle device is launched at once; a thousand callers ride in batches of several hundred).
+//   * `lanes` dispatcher threads, each with its own execution lane on the shared index image (hvx_index_fork: stream +
+//     scratch) and its own device buffers, compete for the open batch: batch i + 1 is launched while batch i runs, like
+//     bench.py's lanes.  Everything a launch needs is enqueued on the lane's stream (H2D of the staged rows, the search,
+//     D2H of the result rows into pinned memory) followed by ONE stream synchronise, then ONE futex wake for the batch.
+//   * A batch buffer is reused only after every caller of its previous batch has copied its rows out (`consumed`).
 #include <hip/hip_runtime.h>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
+#include <atomic>
 #include <chrono>
-#include <condition_variable>
+#include <climits>
 #include <cstring>
-#include <deque>
-#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -25,101 +37,128 @@
 using namespace hvx;
 
 namespace {
-struct Request {
-    const float *query;
-    uint64_t *out_ids;
-    float *out_scores;
-    uint32_t *out_count;
-    int rc = 0;
+
+inline void futex_wait(std::atomic<uint32_t> *addr, uint32_t expected, long timeout_us = -1) {
+    timespec ts, *tp = nullptr;
+    if (timeout_us >= 0) { ts.tv_sec = timeout_us / 1000000; ts.tv_nsec = (timeout_us % 1000000) * 1000; tp = &ts; }
+    syscall(SYS_futex, reinterpret_cast<uint32_t *>(addr), FUTEX_WAIT_PRIVATE, expected, tp, nullptr, 0);
+}
+inline void futex_wake(std::atomic<uint32_t> *addr, int n) {
+    syscall(SYS_futex, reinterpret_cast<uint32_t *>(addr), FUTEX_WAKE_PRIVATE, n, nullptr, nullptr, 0);
+}
+
+// one batch in flight between callers and a lane: pinned host staging + completion state
+struct Batch {
+    float *q = nullptr;            // [max_batch][dim] pinned
+    uint64_t *ids = nullptr;       // [max_batch][k] pinned
+    float *sc = nullptr;           // [max_batch][k] pinned
+    uint32_t *cnt = nullptr, *st = nullptr; // [max_batch] pinned
+    // cumulative over every batch this buffer has carried (never reset: a reset could race with the first callers of the
+    // next batch); batches of one buffer are strictly sequential, so "all of them" is always "the previous ones + this one"
+    alignas(64) std::atomic<uint64_t> filled{0};   // callers that finished writing their row
+    alignas(64) std::atomic<uint64_t> consumed{0}; // callers that copied their result out
+    alignas(64) std::atomic<uint32_t> done{0};     // sequence + 1 of the last batch completed in this buffer (futex word)
+    uint64_t total = 0;            // slots of all batches closed in this buffer (written by the closing dispatcher before `done`)
+    int rc = 0;                    // status of the launch as a whole
     std::string err;
-    std::chrono::steady_clock::time_point t_in;
-    // completion is signalled to THIS caller only (no thundering herd across a thousand blocked callers)
-    std::mutex m;
-    std::condition_variable cv;
-    bool done = false;
 };
 
-// one dispatcher: its own execution lane (hvx_index_fork: stream + scratch) and host staging
 struct Lane {
     hvx_index *ix = nullptr;
     std::thread worker;
-    std::vector<float> q;
-    std::vector<uint64_t> ids;
-    std::vector<float> sc;
-    std::vector<uint32_t> cnt, st;
+    float *d_q = nullptr;
+    uint64_t *d_ids = nullptr;
+    float *d_sc = nullptr;
+    uint32_t *d_cnt = nullptr, *d_st = nullptr;
 };
+
 } // namespace
 
 struct hvx_batcher {
     hvx_search_params params{};
-    uint32_t max_batch = 0, max_wait_us = 0, dim = 0;
-    std::mutex mu;
-    std::condition_variable cv_work;
-    std::deque<Request *> pending;
-    bool stop = false;
+    uint32_t max_batch = 0, max_wait_us = 0, dim = 0, k = 0, nbuf = 0;
+    int device = 0;
+    alignas(64) std::atomic<uint64_t> state{0};      // (sequence of the open batch) << 32 | slots claimed
+    alignas(64) std::atomic<uint32_t> seq_word{0};   // low 32 bits of the open sequence: callers of a full batch sleep on it
+    alignas(64) std::atomic<uint32_t> bell{0};       // dispatchers sleep on it; rung by the first and the last claim of a batch
+    alignas(64) std::atomic<uint32_t> sleepers{0};   // dispatchers asleep on the bell
+    std::atomic<bool> stop{false};
+    std::vector<Batch> bufs;
     std::vector<Lane> lanes;
-    uint64_t n_batches = 0, n_queries = 0, n_full = 0;
+    std::atomic<uint64_t> n_batches{0}, n_queries{0}, n_full{0};
 
-    // Every lane runs this loop: while one lane's batch is on the device, another lane collects and launches the next
-    // (double buffering; the launches overlap on the device as independent streams).
     void run(Lane &ln) {
-        std::unique_lock<std::mutex> lock(mu);
+        (void)hipSetDevice(device);
         for (;;) {
-            cv_work.wait(lock, [&] { return stop || !pending.empty(); });
-            if (stop && pending.empty()) return;
-            // wait for more callers: until the batch is full or the oldest request has waited max_wait_us
-            const auto deadline = pending.front()->t_in + std::chrono::microseconds(max_wait_us);
-            while (!stop && !pending.empty() && pending.size() < max_batch && std::chrono::steady_clock::now() < deadline)
-                cv_work.wait_until(lock, deadline);
-            if (pending.empty()) continue; // another lane took them
-            std::vector<Request *> batch;
-            while (!pending.empty() && batch.size() < max_batch) {
-                batch.push_back(pending.front());
-                pending.pop_front();
+            // this lane is free: take the open batch as soon as it holds a query
+            uint64_t s = state.load();
+            uint32_t cnt = (uint32_t)s;
+            if (cnt == 0) { // (sequentially consistent operations: a caller either sees this sleeper or this sleeper sees its claim)
+                if (stop.load()) return;
+                const uint32_t b0 = bell.load();
+                sleepers.fetch_add(1);
+                if ((uint32_t)state.load() == 0 && !stop.load()) futex_wait(&bell, b0, 2000);
+                sleepers.fetch_sub(1);
+                continue;
             }
-            n_batches += 1;
-            n_queries += batch.size();
-            n_full += batch.size() == max_batch ? 1 : 0;
-            if (!pending.empty()) cv_work.notify_one(); // leftovers: the next lane starts collecting now
-            lock.unlock();
-            const uint32_t b = (uint32_t)batch.size(), k = params.k;
-            for (uint32_t i = 0; i < b; ++i) memcpy(ln.q.data() + (size_t)i * dim, batch[i]->query, (size_t)dim * 4);
-            const int rc = hvx_search_batch_params(ln.ix, ln.q.data(), b, &params, ln.ids.data(), ln.sc.data(), ln.cnt.data(), ln.st.data(),
-                                                   nullptr, nullptr, nullptr);
-            const std::string err = rc ? hvx_last_error() : "";
-            for (uint32_t i = 0; i < b; ++i) {
-                Request *r = batch[i];
-                r->rc = rc ? rc : (int)ln.st[i]; // a rejected query fails alone (per-query status)
-                if (rc) r->err = err;
-                else if (ln.st[i]) r->err = "query rejected with status " + std::to_string(ln.st[i]);
-                else {
-                    *r->out_count = ln.cnt[i];
-                    memcpy(r->out_ids, ln.ids.data() + (size_t)i * k, (size_t)ln.cnt[i] * 8);
-                    memcpy(r->out_scores, ln.sc.data() + (size_t)i * k, (size_t)ln.cnt[i] * 4);
-                }
-                {   // notify UNDER the request's lock: the request lives on its caller's stack, and a caller that sees `done`
-                    // may return and destroy it -- it cannot do so before this scope releases r->m
-                    std::lock_guard<std::mutex> g(r->m);
-                    r->done = true;
-                    r->cv.notify_one();
+            const uint32_t seq = (uint32_t)(s >> 32);
+            // the next batch opens in buffer (seq + 1) % nbuf at the instant this one closes: it must be free, i.e. every
+            // caller of the batch it held last has taken its rows
+            Batch &next = bufs[(seq + 1) % nbuf];
+            if (seq + 1 >= nbuf) { // its previous batch (sequence seq + 1 - nbuf) must be complete and fully drained
+                if (next.done.load() != seq + 1 - nbuf + 1 || next.consumed.load() != next.total) {
+                    std::this_thread::yield();
+                    continue;
                 }
             }
-            lock.lock();
+            if (!state.compare_exchange_strong(s, (uint64_t)(seq + 1) << 32)) continue; // another claim or another lane won
+            seq_word.store(seq + 1);
+            futex_wake(&seq_word, INT_MAX); // callers that found the batch full
+            Batch &bt = bufs[seq % nbuf];
+            bt.total += cnt;
+            while (bt.filled.load() < bt.total) std::this_thread::yield(); // callers still copying their row in
+            n_batches.fetch_add(1, std::memory_order_relaxed);
+            n_queries.fetch_add(cnt, std::memory_order_relaxed);
+            if (cnt == max_batch) n_full.fetch_add(1, std::memory_order_relaxed);
+            launch(ln, bt, cnt);
+            bt.done.store(seq + 1);
+            futex_wake(&bt.done, INT_MAX);
         }
+    }
+
+    void launch(Lane &ln, Batch &bt, uint32_t cnt) {
+        hipStream_t s = (hipStream_t)hvx_index_stream(ln.ix);
+        bt.rc = 0;
+        bt.err.clear();
+        auto bad = [&](const char *what, hipError_t e) { bt.rc = HVX_ERR_DEVICE; bt.err = std::string(what) + ": " + hipGetErrorString(e); };
+        hipError_t e = hipMemcpyAsync(ln.d_q, bt.q, (size_t)cnt * dim * 4, hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) return bad("hipMemcpyAsync(queries)", e);
+        const int rc = hvx_search_batch_params_device(ln.ix, ln.d_q, cnt, &params, ln.d_ids, ln.d_sc, ln.d_cnt, ln.d_st, nullptr, nullptr, nullptr);
+        if (rc) { bt.rc = rc; bt.err = hvx_last_error(); return; }
+        if ((e = hipMemcpyAsync(bt.ids, ln.d_ids, (size_t)cnt * k * 8, hipMemcpyDeviceToHost, s)) != hipSuccess) return bad("hipMemcpyAsync(ids)", e);
+        if ((e = hipMemcpyAsync(bt.sc, ln.d_sc, (size_t)cnt * k * 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return bad("hipMemcpyAsync(scores)", e);
+        if ((e = hipMemcpyAsync(bt.cnt, ln.d_cnt, (size_t)cnt * 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return bad("hipMemcpyAsync(counts)", e);
+        if ((e = hipMemcpyAsync(bt.st, ln.d_st, (size_t)cnt * 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return bad("hipMemcpyAsync(status)", e);
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) return bad("hipStreamSynchronize", e);
     }
 };
 
 extern "C" void hvx_batcher_free(hvx_batcher *b) {
     if (!b) return;
-    {
-        std::lock_guard<std::mutex> lock(b->mu);
-        b->stop = true;
-    }
-    b->cv_work.notify_all();
+    b->stop.store(true, std::memory_order_release);
+    b->bell.fetch_add(1, std::memory_order_acq_rel);
+    futex_wake(&b->bell, INT_MAX);
     for (Lane &ln : b->lanes)
         if (ln.worker.joinable()) ln.worker.join();
-    for (Lane &ln : b->lanes)
+    (void)hipSetDevice(b->device);
+    for (Lane &ln : b->lanes) {
+        for (void *p : {(void *)ln.d_q, (void *)ln.d_ids, (void *)ln.d_sc, (void *)ln.d_cnt, (void *)ln.d_st})
+            if (p) (void)hipFree(p);
         if (ln.ix) hvx_index_free(ln.ix);
+    }
+    for (Batch &bt : b->bufs)
+        for (void *p : {(void *)bt.q, (void *)bt.ids, (void *)bt.sc, (void *)bt.cnt, (void *)bt.st})
+            if (p) (void)hipHostFree(p);
     delete b;
 }
 
@@ -129,26 +168,40 @@ extern "C" int hvx_batcher_new_lanes(hvx_index *ix, const hvx_search_params *par
     *out = nullptr;
     if (max_batch == 0) max_batch = ix->max_batch;
     if (max_batch > ix->max_batch) return fail(HVX_ERR_UNSUPPORTED, "batch %u exceeds max_batch %u given at import", max_batch, ix->max_batch);
-    if (lanes == 0) lanes = 2;
+    if (lanes == 0) lanes = 3;
     if (lanes > 8) return fail(HVX_ERR_K_RANGE, "at most 8 dispatcher lanes");
     int rc = check_k_ef(params->k, params->ef);
     if (rc) return rc;
+    if (hipSetDevice(ix->device) != hipSuccess) return fail(HVX_ERR_DEVICE, "hipSetDevice failed");
     hvx_batcher *b = new hvx_batcher();
     b->params = *params;
     b->max_batch = max_batch;
     b->max_wait_us = max_wait_us;
     b->dim = ix->dev.dim;
+    b->k = params->k;
+    b->device = ix->device;
+    b->nbuf = lanes + 2; // one open batch, one per lane in flight, one being drained by its callers
+    b->bufs = std::vector<Batch>(b->nbuf);
     b->lanes.resize(lanes);
+    auto host = [&](void **p, size_t bytes) { return hipHostMalloc(p, bytes, hipHostMallocDefault) == hipSuccess; };
+    auto dev = [&](void **p, size_t bytes) { return hipMalloc(p, bytes) == hipSuccess; };
+    bool ok = true;
+    for (Batch &bt : b->bufs)
+        ok = ok && host((void **)&bt.q, (size_t)max_batch * b->dim * 4) && host((void **)&bt.ids, (size_t)max_batch * b->k * 8) &&
+             host((void **)&bt.sc, (size_t)max_batch * b->k * 4) && host((void **)&bt.cnt, (size_t)max_batch * 4) &&
+             host((void **)&bt.st, (size_t)max_batch * 4);
     for (Lane &ln : b->lanes) {
-        if ((rc = hvx_index_fork(ix, &ln.ix))) { // own stream + scratch on the shared image (SimHash rows included)
+        if (ok && (rc = hvx_index_fork(ix, &ln.ix))) { // own stream + scratch on the shared image (SimHash rows included)
             hvx_batcher_free(b);
             return rc;
         }
-        ln.q.resize((size_t)max_batch * b->dim);
-        ln.ids.resize((size_t)max_batch * params->k);
-        ln.sc.resize((size_t)max_batch * params->k);
-        ln.cnt.resize(max_batch);
-        ln.st.resize(max_batch);
+        ok = ok && dev((void **)&ln.d_q, (size_t)max_batch * b->dim * 4) && dev((void **)&ln.d_ids, (size_t)max_batch * b->k * 8) &&
+             dev((void **)&ln.d_sc, (size_t)max_batch * b->k * 4) && dev((void **)&ln.d_cnt, (size_t)max_batch * 4) &&
+             dev((void **)&ln.d_st, (size_t)max_batch * 4);
+    }
+    if (!ok) {
+        hvx_batcher_free(b);
+        return fail(HVX_ERR_DEVICE, "allocation of the batcher's staging buffers failed");
     }
     for (Lane &ln : b->lanes) {
         Lane *lp = &ln;
@@ -165,33 +218,55 @@ extern "C" int hvx_batcher_new(hvx_index *ix, const hvx_search_params *params, u
 
 extern "C" int hvx_batcher_search(hvx_batcher *b, const float *query, uint64_t *out_ids, float *out_scores, uint32_t *out_count) {
     if (!b || !query || !out_ids || !out_scores || !out_count) return fail(HVX_ERR_INVARIANT, "null argument");
-    Request r;
-    r.query = query;
-    r.out_ids = out_ids;
-    r.out_scores = out_scores;
-    r.out_count = out_count;
     *out_count = 0;
-    r.t_in = std::chrono::steady_clock::now();
-    {
-        std::lock_guard<std::mutex> lock(b->mu);
-        if (b->stop) return fail(HVX_ERR_INVARIANT, "batcher is shutting down");
-        b->pending.push_back(&r);
-        if (b->pending.size() == 1 || b->pending.size() >= b->max_batch) b->cv_work.notify_one();
+    // claim a slot of the open batch
+    uint32_t seq, slot;
+    for (;;) {
+        if (b->stop.load(std::memory_order_acquire)) return fail(HVX_ERR_INVARIANT, "batcher is shutting down");
+        uint64_t s = b->state.load();
+        seq = (uint32_t)(s >> 32);
+        slot = (uint32_t)s;
+        if (slot >= b->max_batch) { // full: a lane closes it as soon as one is free; wait for the next batch to open
+            futex_wait(&b->seq_word, seq, 200);
+            continue;
+        }
+        if (b->state.compare_exchange_weak(s, s + 1)) break;
     }
-    {
-        std::unique_lock<std::mutex> g(r.m);
-        r.cv.wait(g, [&] { return r.done; });
+    Batch &bt = b->bufs[seq % b->nbuf];
+    memcpy(bt.q + (size_t)slot * b->dim, query, (size_t)b->dim * 4);
+    bt.filled.fetch_add(1);
+    if ((slot == 0 || slot + 1 == b->max_batch) && b->sleepers.load()) { // first / last query of a batch: a sleeping lane should look
+        b->bell.fetch_add(1);
+        futex_wake(&b->bell, 1);
     }
-    if (r.rc) return fail(r.rc, "%s", r.err.c_str());
+    // wait for the batch
+    for (;;) {
+        const uint32_t d = bt.done.load(std::memory_order_acquire);
+        if (d == seq + 1) break;
+        futex_wait(&bt.done, d, 5000);
+        if (b->stop.load(std::memory_order_acquire) && bt.done.load(std::memory_order_acquire) != seq + 1)
+            return fail(HVX_ERR_INVARIANT, "batcher is shutting down");
+    }
+    int rc = bt.rc;
+    std::string err;
+    uint32_t st = 0;
+    if (rc) err = bt.err;
+    else if ((st = bt.st[slot]) != 0) { rc = (int)st; } // a rejected query fails alone (per-query status)
+    else {
+        const uint32_t c = bt.cnt[slot];
+        *out_count = c;
+        memcpy(out_ids, bt.ids + (size_t)slot * b->k, (size_t)c * 8);
+        memcpy(out_scores, bt.sc + (size_t)slot * b->k, (size_t)c * 4);
+    }
+    bt.consumed.fetch_add(1);
+    if (rc) return err.empty() ? fail(rc, "query rejected with status %u", st) : fail(rc, "%s", err.c_str());
     return HVX_OK;
 }
 
 extern "C" int hvx_batcher_stats(const hvx_batcher *cb, uint64_t *batches, uint64_t *queries, uint64_t *full_batches) {
     if (!cb) return fail(HVX_ERR_INVARIANT, "null argument");
-    hvx_batcher *b = const_cast<hvx_batcher *>(cb);
-    std::lock_guard<std::mutex> lock(b->mu);
-    if (batches) *batches = b->n_batches;
-    if (queries) *queries = b->n_queries;
-    if (full_batches) *full_batches = b->n_full;
+    if (batches) *batches = cb->n_batches.load();
+    if (queries) *queries = cb->n_queries.load();
+    if (full_batches) *full_batches = cb->n_full.load();
     return HVX_OK;
 }

@@ -168,7 +168,7 @@ extern "C" int hvx_batcher_new_lanes(hvx_index *ix, const hvx_search_params *par
     *out = nullptr;
     if (max_batch == 0) max_batch = ix->max_batch;
     if (max_batch > ix->max_batch) return fail(HVX_ERR_UNSUPPORTED, "batch %u exceeds max_batch %u given at import", max_batch, ix->max_batch);
-    if (lanes == 0) lanes = 3;
+    if (lanes == 0) lanes = 4;
     if (lanes > 8) return fail(HVX_ERR_K_RANGE, "at most 8 dispatcher lanes");
     int rc = check_k_ef(params->k, params->ef);
     if (rc) return rc;
@@ -195,6 +195,7 @@ extern "C" int hvx_batcher_new_lanes(hvx_index *ix, const hvx_search_params *par
             hvx_batcher_free(b);
             return rc;
         }
+        if (ok && lanes > 1) (void)hvx_index_set_occupancy(ln.ix, 2); // several batches in flight: the two-queries-per-SIMD build
         ok = ok && dev((void **)&ln.d_q, (size_t)max_batch * b->dim * 4) && dev((void **)&ln.d_ids, (size_t)max_batch * b->k * 8) &&
              dev((void **)&ln.d_sc, (size_t)max_batch * b->k * 4) && dev((void **)&ln.d_cnt, (size_t)max_batch * 4) &&
              dev((void **)&ln.d_st, (size_t)max_batch * 4);

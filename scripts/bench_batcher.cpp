@@ -34,6 +34,7 @@ int main(int argc, char **argv) {
     const int threads = atoi(argv[2]), per = atoi(argv[3]);
     const bool strict = argc > 4 && !strcmp(argv[4], "strict");
     const uint32_t lanes = argc > 5 ? (uint32_t)atoi(argv[5]) : 2u;
+    const bool direct = !(argc > 6 && !strcmp(argv[6], "nodirect")); // the one-call-per-query baseline takes ~1 min at 1 024 threads
     auto meta = load<uint64_t>(dir + "/meta.u64"); // n, dim, m, entry, max_layer
     const uint64_t n = meta[0];
     const uint32_t dim = (uint32_t)meta[1], m = (uint32_t)meta[2];
@@ -97,7 +98,8 @@ int main(int argc, char **argv) {
         if (failures) fprintf(stderr, "%d failed calls\n", failures.load());
     };
     double q0, m0, p0, q1, m1, p1;
-    run(nullptr, &q0, &m0, &p0); // direct one-query calls on one handle: every call is a launch + two PCIe copies
+    q0 = m0 = p0 = 0;
+    if (direct) run(nullptr, &q0, &m0, &p0); // direct one-query calls on one handle: every call is a launch + two PCIe copies
     hvx_batcher *bt = nullptr;
     if (hvx_batcher_new_lanes(ix, &p, 1024, 100, lanes, &bt)) { fprintf(stderr, "%s\n", hvx_last_error()); return 1; }
     run(bt, &q1, &m1, &p1);

@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--per-thread", type=int, default=100)
     ap.add_argument("--lanes", default="2,3")
     ap.add_argument("--dir", default="/tmp/hvx_batcher")
+    ap.add_argument("--modes", default="strict,default")
+    ap.add_argument("--no-direct", action="store_true", help="skip the one-call-per-query baseline (about a minute per run)")
     args = ap.parse_args()
     from pyhvx import synth
     dev = torch.device("cuda", 0)
@@ -41,9 +43,9 @@ def main():
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "scripts", "bench_batcher.cpp"),
                            "-o", exe, "-L", os.path.join(ROOT, "helix-db_amd"), "-lhelix_vec_gfx950",
                            f"-Wl,-rpath,{os.path.join(ROOT, 'helix-db_amd')}", "-lpthread"])
-    for mode in ("strict", "default"):
+    for mode in args.modes.split(","):
         for lanes in args.lanes.split(","):
-            subprocess.check_call([exe, args.dir, str(args.threads), str(args.per_thread), mode, lanes])
+            subprocess.check_call([exe, args.dir, str(args.threads), str(args.per_thread), mode, lanes] + (["nodirect"] if args.no_direct else []))
 
 
 if __name__ == "__main__":

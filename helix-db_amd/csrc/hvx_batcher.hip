@@ -47,6 +47,8 @@ inline void futex_wake(std::atomic<uint32_t> *addr, int n) {
     syscall(SYS_futex, reinterpret_cast<uint32_t *>(addr), FUTEX_WAKE_PRIVATE, n, nullptr, nullptr, 0);
 }
 
+constexpr int kWakeFan = 8; // sleepers woken per futex_wake call: a woken caller wakes kWakeFan more before it copies its rows
+
 // one batch in flight between callers and a lane: pinned host staging + completion state
 struct Batch {
     float *q = nullptr;            // [max_batch][dim] pinned
@@ -122,7 +124,7 @@ struct hvx_batcher {
             if (cnt == max_batch) n_full.fetch_add(1, std::memory_order_relaxed);
             launch(ln, bt, cnt);
             bt.done.store(seq + 1);
-            futex_wake(&bt.done, INT_MAX);
+            futex_wake(&bt.done, kWakeFan); // the woken callers wake the rest (fan-out): this thread goes back to its lane at once
         }
     }
 
@@ -195,7 +197,6 @@ extern "C" int hvx_batcher_new_lanes(hvx_index *ix, const hvx_search_params *par
             hvx_batcher_free(b);
             return rc;
         }
-        if (ok && lanes > 1) (void)hvx_index_set_occupancy(ln.ix, 2); // several batches in flight: the two-queries-per-SIMD build
         ok = ok && dev((void **)&ln.d_q, (size_t)max_batch * b->dim * 4) && dev((void **)&ln.d_ids, (size_t)max_batch * b->k * 8) &&
              dev((void **)&ln.d_sc, (size_t)max_batch * b->k * 4) && dev((void **)&ln.d_cnt, (size_t)max_batch * 4) &&
              dev((void **)&ln.d_st, (size_t)max_batch * 4);
@@ -248,6 +249,8 @@ extern "C" int hvx_batcher_search(hvx_batcher *b, const float *query, uint64_t *
         if (b->stop.load(std::memory_order_acquire) && bt.done.load(std::memory_order_acquire) != seq + 1)
             return fail(HVX_ERR_INVARIANT, "batcher is shutting down");
     }
+    futex_wake(&bt.done, kWakeFan); // pass the wake on: waking several hundred sleepers one after another on the dispatcher's
+                                    // thread took longer than the kernel (a no-op once nobody sleeps on this batch any more)
     int rc = bt.rc;
     std::string err;
     uint32_t st = 0;

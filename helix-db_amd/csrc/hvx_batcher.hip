@@ -47,8 +47,6 @@ inline void futex_wake(std::atomic<uint32_t> *addr, int n) {
     syscall(SYS_futex, reinterpret_cast<uint32_t *>(addr), FUTEX_WAKE_PRIVATE, n, nullptr, nullptr, 0);
 }
 
-constexpr int kWakeFan = 8; // sleepers woken per futex_wake call: a woken caller wakes kWakeFan more before it copies its rows
-
 // one batch in flight between callers and a lane: pinned host staging + completion state
 struct Batch {
     float *q = nullptr;            // [max_batch][dim] pinned
@@ -124,7 +122,8 @@ struct hvx_batcher {
             if (cnt == max_batch) n_full.fetch_add(1, std::memory_order_relaxed);
             launch(ln, bt, cnt);
             bt.done.store(seq + 1);
-            futex_wake(&bt.done, kWakeFan); // the woken callers wake the rest (fan-out): this thread goes back to its lane at once
+            futex_wake(&bt.done, INT_MAX); // (a fan-out wake -- woken callers waking the rest -- was measured 10x SLOWER: a thousand
+                                           //  threads calling FUTEX_WAKE on one word contend on its hash bucket; r03i/batcher_1m_c.log)
         }
     }
 
@@ -249,8 +248,6 @@ extern "C" int hvx_batcher_search(hvx_batcher *b, const float *query, uint64_t *
         if (b->stop.load(std::memory_order_acquire) && bt.done.load(std::memory_order_acquire) != seq + 1)
             return fail(HVX_ERR_INVARIANT, "batcher is shutting down");
     }
-    futex_wake(&bt.done, kWakeFan); // pass the wake on: waking several hundred sleepers one after another on the dispatcher's
-                                    // thread took longer than the kernel (a no-op once nobody sleeps on this batch any more)
     int rc = bt.rc;
     std::string err;
     uint32_t st = 0;

@@ -436,88 +436,97 @@ __device__ __forceinline__ void score_rows_fp8(const DevIndex &ix, const float *
     }
 }
 
+// Four wavefronts per query (one per SIMD, each with its SIMD's whole register file): every wavefront re-scores a quarter of
+// the candidates with the HNSW kernel's reference-order gather / FMA code, 16 rows per pass; selection (small-batch path),
+// the final sort and the certificate are cooperative.
 template <uint32_t METRIC, int NK, int KIND> // KIND as in flat_mfma_bf16_kernel: 0 bf16, 1 fp8, 2 f32 rows
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void rerank_bf16_kernel(RerankArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void rerank_bf16_kernel(RerankArgs a) {
     constexpr bool FP8 = KIND == 1, BFR = KIND != 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int P = 2; // 16 rows per pass
+    __shared__ uint32_t cnt3[3], s_valid, s_bad, s_nout;
+    constexpr int P = 2; // 16 rows per wavefront and pass
     const DevIndex &ix = a.ix;
     const uint32_t q = blockIdx.x;
-    const int lane = (int)threadIdx.x, grp = lane >> 3, j = lane & 7, slot = chunk_slot(j);
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 3, j = lane & 7, slot = chunk_slot(j);
     float *qs = reinterpret_cast<float *>(smem);                     // [dim]
     float *ss = qs + (size_t)NK * 32;                                // [1024] exact scores
     uint32_t *si = reinterpret_cast<uint32_t *>(ss + 1024);          // [1024] ids
     const uint32_t st = a.qstatus[q];
     if (st != 0u) {
-        if (lane == 0) { a.out_counts[q] = 0; if (a.out_status) a.out_status[q] = st; a.cert[q] = 1u; }
+        if (tid == 0) { a.out_counts[q] = 0; if (a.out_status) a.out_status[q] = st; a.cert[q] = 1u; }
         return;
     }
     const float *qglobal = a.queries + (size_t)q * ix.dim;
-    for (uint32_t i = (uint32_t)lane; i < (uint32_t)NK * 8u; i += 64)
+    for (uint32_t i = (uint32_t)tid; i < (uint32_t)NK * 8u; i += 256)
         reinterpret_cast<float4 *>(qs)[i] = reinterpret_cast<const float4 *>(qglobal)[i];
     const float inf = __uint_as_float(0x7F800000u);
     uint32_t nc;
     float t_thr = inf; // approximate score of the last candidate: every row that is not re-scored has at least this score
+    if (tid == 0) { cnt3[0] = cnt3[1] = cnt3[2] = 0; s_valid = 0; s_bad = 0; s_nout = 0; }
+    for (uint32_t i = (uint32_t)tid; i < 1024u; i += 256) { ss[i] = inf; si[i] = 0xFFFFFFFFu; }
+    __syncthreads();
     if (a.sl_sc) {
-        // the kc smallest of the slices' pairs: keys staged in LDS, kth key by bitwise descent inside the wavefront
+        // the kc smallest of the slices' pairs: keys staged in LDS, kth key by a cooperative bitwise descent (ballot counts)
         uint32_t *sk = si + 1024; // [sl_n]
         const float *gs = a.sl_sc + (size_t)q * a.sl_stride;
         const uint32_t *gi = a.sl_id + (size_t)q * a.sl_stride;
         uint32_t valid = 0;
-        for (uint32_t i = (uint32_t)lane; i < a.sl_n; i += 64) {
-            const uint32_t kb = gi[i] == 0xFFFFFFFFu ? 0xFFFFFFFFu : __float_as_uint(gs[i]);
-            sk[i] = kb;
-            valid += kb != 0xFFFFFFFFu ? 1u : 0u;
+        for (uint32_t i0 = 0; i0 < a.sl_n; i0 += 256) {
+            const uint32_t i = i0 + (uint32_t)tid;
+            uint32_t kb = 0xFFFFFFFFu;
+            if (i < a.sl_n) {
+                kb = gi[i] == 0xFFFFFFFFu ? 0xFFFFFFFFu : __float_as_uint(gs[i]);
+                sk[i] = kb;
+            }
+            valid += (uint32_t)__builtin_popcountll(__ballot(kb != 0xFFFFFFFFu));
         }
-        for (uint32_t i = (uint32_t)lane; i < 1024u; i += 64) { ss[i] = inf; si[i] = 0xFFFFFFFFu; }
+        if (lane == 0 && valid) atomicAdd(&s_valid, valid);
         __syncthreads();
-#pragma unroll
-        for (int sft = 32; sft > 0; sft >>= 1) valid += __shfl_xor(valid, sft, 64);
-        const uint32_t kth = a.kc < valid ? a.kc : valid;
+        const uint32_t kth = a.kc < s_valid ? a.kc : s_valid;
         uint32_t prefix = 0, kk = kth, less = 0;
         for (int bit = 31; bit >= 0 && kth; --bit) {
             const uint32_t hi_mask = bit == 31 ? 0u : (0xFFFFFFFFu << (bit + 1));
             const uint32_t sel_mask = hi_mask | (1u << bit); // prefix on the bits above, 0 at `bit`
             uint32_t c = 0;
-            for (uint32_t i0 = 0; i0 < a.sl_n; i0 += 64) {
-                const uint32_t i = i0 + (uint32_t)lane;
-                const uint32_t kb = i < a.sl_n ? sk[i] : 0xFFFFFFFFu; // (padding never matches: bit 31 of a real prefix is 0)
+            for (uint32_t i0 = 0; i0 < a.sl_n; i0 += 256) {
+                const uint32_t i = i0 + (uint32_t)tid;
+                const uint32_t kb = i < a.sl_n ? sk[i] : 0xFFFFFFFFu;
                 c += (uint32_t)__builtin_popcountll(__ballot(i < a.sl_n && (kb & sel_mask) == prefix));
             }
-            if (kk > c) { prefix |= 1u << bit; kk -= c; less += c; }
+            const int slot3 = bit % 3;
+            if (lane == 0 && c) atomicAdd(&cnt3[slot3], c);
+            if (tid == 0) cnt3[(bit + 2) % 3] = 0; // next round's counter: last read two rounds ago
+            __syncthreads();
+            const uint32_t zeros = cnt3[slot3];
+            if (kk > zeros) { prefix |= 1u << bit; kk -= zeros; less += zeros; }
         }
-        // candidates: keys below the kth value, then ties in pair order up to the quota
-        uint32_t n_out = 0, ties = 0;
+        // candidates: keys below the kth value, then ties up to the quota (which ties does not matter: see hvx_flat_smallb.hip)
+        __syncthreads();
+        if (tid == 0) cnt3[0] = 0; // tie counter
+        __syncthreads();
         const uint32_t quota = kth - less;
-        for (uint32_t i0 = 0; i0 < a.sl_n && kth; i0 += 64) {
-            const uint32_t i = i0 + (uint32_t)lane;
+        for (uint32_t i0 = 0; i0 < a.sl_n && kth; i0 += 256) {
+            const uint32_t i = i0 + (uint32_t)tid;
             const uint32_t kb = i < a.sl_n ? sk[i] : 0xFFFFFFFFu;
-            const bool lt = kb < prefix, eq = kb == prefix && kb != 0xFFFFFFFFu;
-            const unsigned long long em = __ballot(eq);
-            const uint32_t eq_rank = ties + (uint32_t)__builtin_popcountll(em & ((1ull << lane) - 1ull));
-            const bool take = lt || (eq && eq_rank < quota);
-            const unsigned long long tm = __ballot(take);
+            bool take = kb < prefix;
+            if (!take && kb == prefix && kb != 0xFFFFFFFFu) take = atomicAdd(&cnt3[0], 1u) < quota;
             if (take) {
-                const uint32_t pos = n_out + (uint32_t)__builtin_popcountll(tm & ((1ull << lane) - 1ull));
+                const uint32_t pos = atomicAdd(&s_nout, 1u);
                 if (pos < 1024u) si[pos] = gi[i];
             }
-            n_out += (uint32_t)__builtin_popcountll(tm);
-            ties += (uint32_t)__builtin_popcountll(em);
         }
-        nc = n_out < 1024u ? n_out : 1024u;
+        __syncthreads();
+        nc = s_nout < 1024u ? s_nout : 1024u;
         t_thr = kth ? __uint_as_float(prefix) : inf;
     } else {
         nc = a.cand_counts[q];
-        for (uint32_t i = (uint32_t)lane; i < 1024u; i += 64) {
-            ss[i] = inf;
-            si[i] = i < nc ? a.cand_ids[(size_t)q * a.kc + i] : 0xFFFFFFFFu;
-        }
+        for (uint32_t i = (uint32_t)tid; i < nc && i < 1024u; i += 256) si[i] = a.cand_ids[(size_t)q * a.kc + i];
         if (nc) t_thr = a.cand_scores[(size_t)q * a.kc + (nc - 1)];
     }
     __syncthreads();
     const float qhdr = a.qhdr[q];
     bool bad = false;
-    for (uint32_t f0 = 0; f0 < nc; f0 += 8u * P) {
+    for (uint32_t f0 = (uint32_t)wave * 8u * P; f0 < nc; f0 += 4u * 8u * P) {
         uint32_t nd[P];
         float o[P];
 #pragma unroll
@@ -542,17 +551,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             }
         }
     }
-    if (__ballot(bad)) { // Candidate::try_new rejects the score (model.rs:21-29)
-        if (lane == 0) { a.out_counts[q] = 0; if (a.out_status) a.out_status[q] = 8u; a.cert[q] = 1u; }
+    if (__ballot(bad) && lane == 0) s_bad = 1;
+    __syncthreads();
+    if (s_bad) { // Candidate::try_new rejects the score (model.rs:21-29)
+        if (tid == 0) { a.out_counts[q] = 0; if (a.out_status) a.out_status[q] = 8u; a.cert[q] = 1u; }
         return;
     }
-    __syncthreads();
-    // bitonic sort of the (score, id) pairs by one wavefront: the next power of two above the candidate count (the rest is +inf)
+    // bitonic sort of the (score, id) pairs: the next power of two above the candidate count (the rest is +inf)
     int npairs = 2;
     while ((uint32_t)npairs < nc) npairs <<= 1;
     for (int size = 2; size <= npairs; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = lane; t < npairs / 2; t += 64) {
+            for (int t = tid; t < npairs / 2; t += 256) {
                 const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
                 const bool up = (lo & size) == 0;
                 const float sl = ss[lo], sh = ss[hi];
@@ -564,11 +574,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             __syncthreads();
         }
     const uint32_t outn = nc < a.k ? nc : a.k;
-    for (uint32_t t = (uint32_t)lane; t < outn; t += 64) {
+    for (uint32_t t = (uint32_t)tid; t < outn; t += 256) {
         a.out_ids[(size_t)q * a.k + t] = ix.ids[si[t]];
         a.out_scores[(size_t)q * a.k + t] = ss[t];
     }
-    if (lane == 0) {
+    if (tid == 0) {
         a.out_counts[q] = outn;
         if (a.out_status) a.out_status[q] = 0u;
         // certificate (see the file header).  nc <= m: every row of the scan was re-scored.
@@ -594,9 +604,9 @@ static hipError_t launch_rerank(const RerankArgs &a, uint32_t b, hipStream_t s) 
     switch (a.ix.dim >> 5) {
 #define HVX_RR(N)                                                                                                   \
     case N:                                                                                                         \
-        if (a.ix.dtype == HVX_FP8_E4M3) hipLaunchKernelGGL((rerank_bf16_kernel<METRIC, N, 1>), dim3(b), dim3(64), lds, s, a); \
-        else if (a.ix.dtype == HVX_F32) hipLaunchKernelGGL((rerank_bf16_kernel<METRIC, N, 2>), dim3(b), dim3(64), lds, s, a);  \
-        else hipLaunchKernelGGL((rerank_bf16_kernel<METRIC, N, 0>), dim3(b), dim3(64), lds, s, a);                  \
+        if (a.ix.dtype == HVX_FP8_E4M3) hipLaunchKernelGGL((rerank_bf16_kernel<METRIC, N, 1>), dim3(b), dim3(256), lds, s, a); \
+        else if (a.ix.dtype == HVX_F32) hipLaunchKernelGGL((rerank_bf16_kernel<METRIC, N, 2>), dim3(b), dim3(256), lds, s, a);  \
+        else hipLaunchKernelGGL((rerank_bf16_kernel<METRIC, N, 0>), dim3(b), dim3(256), lds, s, a);                  \
         break;
         HVX_RR(4) HVX_RR(8) HVX_RR(16) HVX_RR(24) HVX_RR(32) HVX_RR(48)
 #undef HVX_RR

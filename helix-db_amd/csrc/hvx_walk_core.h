@@ -88,6 +88,7 @@ struct Mem {
     uint64_t *S;     // [kScoredCap]
     uint64_t *B;     // [b_cap]
     uint64_t *G;     // [kStageCap]
+    uint64_t *N;     // [kScoredCap] keys of the rows scored last, before they are merged into S
     uint32_t *Gr;    // [kStageCap]
     uint32_t *E;     // [kScoredCap]
     uint32_t *rows;  // [W]
@@ -192,15 +193,50 @@ HVX_WALK_FN uint32_t run(C &c, const View &v, const Plan &pl, const uint32_t *sa
         c.sort64(a, L);
     };
 
-    // restricted_score_keys (restricted.rs:661-704) for E[0, ne)
+    // merge the sorted keys X[0, nx) into the sorted array A[0, n) (keys are unique), keeping at most `cap` entries: an entry of
+    // A moves up by the number of new keys below it (highest block first, so a block's targets have been vacated: positions
+    // strictly increase with the entry), a new key lands at its index + the number of A's entries below it
+    auto merge_into = [&](uint64_t *A, uint32_t &n, uint32_t cap, const uint64_t *X, uint32_t nx) {
+        for (uint32_t base = 0; base < nx; base += T)
+            c.phase([&](uint32_t t) {
+                const uint32_t i = base + t;
+                if (i < nx) m.Gr[i] = i + lower_bound(A, n, X[i]);
+            });
+        const uint32_t jmin = lower_bound(A, n, X[0]);
+        for (uint32_t blk = (n + W - 1) / W; blk-- > jmin / W;) {
+            c.phase([&](uint32_t t) {
+                for (uint32_t s = t; s < W; s += T) {
+                    const uint32_t j = blk * W + s;
+                    if (j < n) {
+                        const uint64_t x = A[j];
+                        m.tv[s] = x;
+                        m.tp[s] = j + lower_bound(X, nx, x);
+                    }
+                }
+            });
+            c.phase([&](uint32_t t) {
+                for (uint32_t s = t; s < W; s += T) {
+                    const uint32_t j = blk * W + s;
+                    if (j < n && m.tp[s] < cap) A[m.tp[s]] = m.tv[s];
+                }
+            });
+        }
+        c.phase([&](uint32_t t) {
+            for (uint32_t i = t; i < nx; i += T)
+                if (m.Gr[i] < cap) A[m.Gr[i]] = X[i];
+        });
+        n = umin(n + nx, cap);
+    };
+
+    // restricted_score_keys (restricted.rs:661-704) for E[0, ne): the new keys are sorted on their own and merged into S
     auto score_list = [&](uint32_t ne) {
         if (ne == 0 || bad) return;
         st.vector_payload_requests += ne;
         st.vector_bytes += ne * (4u + v.dim * 4u);
         st.distance_computations += ne;
-        if (c.score(m.E, ne, m.S + s_n)) { bad = 1; return; }
-        s_n += ne;
-        pad_sort(m.S, s_n);
+        if (c.score(m.E, ne, m.N)) { bad = 1; return; }
+        pad_sort(m.N, ne);
+        merge_into(m.S, s_n, kScoredCap, m.N, ne);
     };
 
     // merge the staged bridge keys G[0, ctl[kGN]) into B
@@ -210,38 +246,7 @@ HVX_WALK_FN uint32_t run(C &c, const View &v, const Plan &pl, const uint32_t *sa
         const uint32_t cap_rem = m.b_cap - head;
         if (cap_rem != 0) {
             pad_sort(m.G, ng);
-            uint64_t *Bv = m.B + head;
-            for (uint32_t base = 0; base < ng; base += T)
-                c.phase([&](uint32_t t) {
-                    const uint32_t i = base + t;
-                    if (i < ng) m.Gr[i] = i + lower_bound(Bv, nb, m.G[i]);
-                });
-            // stored entries move up by the number of new keys below them; highest block first, so a block's targets have
-            // been vacated (keys are unique: positions strictly increase with the entry)
-            const uint32_t jmin = lower_bound(Bv, nb, m.G[0]);
-            for (uint32_t blk = (nb + W - 1) / W; blk-- > jmin / W;) {
-                c.phase([&](uint32_t t) {
-                    for (uint32_t s = t; s < W; s += T) {
-                        const uint32_t j = blk * W + s;
-                        if (j < nb) {
-                            const uint64_t x = Bv[j];
-                            m.tv[s] = x;
-                            m.tp[s] = j + lower_bound(m.G, ng, x);
-                        }
-                    }
-                });
-                c.phase([&](uint32_t t) {
-                    for (uint32_t s = t; s < W; s += T) {
-                        const uint32_t j = blk * W + s;
-                        if (j < nb && m.tp[s] < cap_rem) Bv[m.tp[s]] = m.tv[s];
-                    }
-                });
-            }
-            c.phase([&](uint32_t t) {
-                for (uint32_t i = t; i < ng; i += T)
-                    if (m.Gr[i] < cap_rem) Bv[m.Gr[i]] = m.G[i];
-            });
-            nb = umin(nb + ng, cap_rem);
+            merge_into(m.B + head, nb, cap_rem, m.G, ng);
         }
         c.phase([&](uint32_t t) {
             if (t == 0) m.ctl[kGN] = 0;
@@ -457,7 +462,6 @@ HVX_WALK_FN uint32_t run(C &c, const View &v, const Plan &pl, const uint32_t *sa
             }
             if (m.ctl[kGN] + W > kStageCap) flush();
         }
-        flush();
     };
 
     while (!bad) {
@@ -512,6 +516,7 @@ HVX_WALK_FN uint32_t run(C &c, const View &v, const Plan &pl, const uint32_t *sa
             routing_remaining -= nr;
             process_rows(nr);
         }
+        flush(); // the bridge frontier must hold everything queued so far before it is popped (one merge per iteration)
         const uint32_t bl = umin(umin(sat_sub(pl.bridge_rows, st.bridge_rows), routing_remaining), umin(kBridgeBatch, bridge_n));
         if (bl) {
             c.phase([&](uint32_t t) {

@@ -307,7 +307,7 @@ typedef struct hvx_restricted_params {
     uint32_t directory_enabled;  /* VectorIndex::simhash_directory_enabled(): seed from the SimHash directory */
     uint32_t explicit_budgets;   /* != 0: the six budgets below instead of FilteredGraphBudgets::with_beam_percent (how the
                                     reference's tests drive restricted_filter_aware_search); limits of this build:
-                                    vector_payloads <= 1024, sampled_seeds / directory_seeds <= 1024, bridge_rows <= 12 288 */
+                                    vector_payloads <= 1024, sampled_seeds / directory_seeds <= 1024, bridge_rows <= 9 600 */
     uint32_t ef_filtered, routing_rows, bridge_rows, vector_payloads, sampled_seeds, directory_seeds;
 } hvx_restricted_params;
 void hvx_restricted_params_default(hvx_restricted_params *, uint32_t k, uint32_t ef); /* AUTO, 150 %, directory on */

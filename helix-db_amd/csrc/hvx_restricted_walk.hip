@@ -154,7 +154,7 @@ template <uint32_t METRIC, bool FUSED> struct DevCtx {
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15u) & ~(size_t)15u; }
 
 size_t walk_lds_bytes(uint32_t ld, uint32_t b_cap) {
-    return align16((size_t)ld * 4) + walk::kScoredCap * 8 * 2 + align16((size_t)b_cap * 8) + walk::kStageCap * 8 + walk::kStageCap * 4 +
+    return align16((size_t)ld * 4) + walk::kScoredCap * 8 + align16((size_t)b_cap * 8) + walk::kStageCap * 8 + walk::kStageCap * 4 +
            walk::kScoredCap * 4 + kW * 4 + kW * 4 + kW + kW * 8 + kW * 4 + walk::kBridgeBatch * 4 + walk::kCtlWords * 4 + (kW / 64) * 4;
 }
 
@@ -178,10 +178,11 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(256) void re
     m.S = reinterpret_cast<uint64_t *>(p); p += walk::kScoredCap * 8;
     m.B = reinterpret_cast<uint64_t *>(p); p += align16((size_t)a.b_cap * 8);
     m.G = reinterpret_cast<uint64_t *>(p); p += walk::kStageCap * 8;
-    m.N = reinterpret_cast<uint64_t *>(p); p += walk::kScoredCap * 8;
     m.tv = reinterpret_cast<uint64_t *>(p); p += kW * 8;
     m.Gr = reinterpret_cast<uint32_t *>(p); p += walk::kStageCap * 4;
     m.E = reinterpret_cast<uint32_t *>(p); p += walk::kScoredCap * 4;
+    m.N = reinterpret_cast<uint64_t *>(p); // the keys of freshly scored rows live where `rows` + `scan` do: those are dead while rows are scored
+    static_assert(walk::kScoredCap * 8 == 2 * kW * 4, "N aliases rows + scan");
     m.rows = reinterpret_cast<uint32_t *>(p); p += kW * 4;
     m.scan = reinterpret_cast<uint32_t *>(p); p += kW * 4;
     m.tp = reinterpret_cast<uint32_t *>(p); p += kW * 4;

@@ -88,7 +88,7 @@ struct Mem {
     uint64_t *S;     // [kScoredCap]
     uint64_t *B;     // [b_cap]
     uint64_t *G;     // [kStageCap]
-    uint64_t *N;     // [kScoredCap] keys of the rows scored last, before they are merged into S
+    uint64_t *N;     // [kScoredCap] keys of the rows scored last, before they are merged into S (may alias rows + scan: dead then)
     uint32_t *Gr;    // [kStageCap]
     uint32_t *E;     // [kScoredCap]
     uint32_t *rows;  // [W]

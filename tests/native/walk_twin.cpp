@@ -70,10 +70,14 @@ struct twin_args {
 template <uint32_t TT, uint32_t WW>
 static uint32_t run_variant(const twin_args &a, dist_fn dist, uint64_t *out_keys, uint32_t *out_n, Counters *out_st) {
     std::vector<uint64_t> S(kScoredCap, 0), B(std::max<uint32_t>(a.b_cap, 1), 0), G(kStageCap, 0), N(kScoredCap, 0), tv(WW, 0);
-    std::vector<uint32_t> Gr(kStageCap, 0), E(kScoredCap, 0), rows(WW, 0), scan(WW, 0), tp(WW, 0), batch(kBridgeBatch, 0), ctl(kCtlWords, 0xDEADBEEFu);
+    // like the kernel, the geometry with W = 1024 keeps N where rows + scan live (dead while rows are scored)
+    std::vector<uint32_t> rs(2 * WW + 2, 0);
+    uint32_t *rows_p = rs.data() + (reinterpret_cast<uintptr_t>(rs.data()) % 8 ? 1 : 0), *scan_p = rows_p + WW;
+    std::vector<uint32_t> Gr(kStageCap, 0), E(kScoredCap, 0), tp(WW, 0), batch(kBridgeBatch, 0), ctl(kCtlWords, 0xDEADBEEFu);
+    uint64_t *N_p = (WW * 8 == kScoredCap * 8) ? reinterpret_cast<uint64_t *>(rows_p) : N.data();
     std::vector<uint8_t> flag(WW, 0);
     std::vector<uint32_t> seen((a.n + 31) / 32 + 1, 0);
-    Mem m{S.data(), B.data(), G.data(), N.data(), Gr.data(), E.data(), rows.data(), scan.data(), flag.data(), tv.data(), tp.data(), batch.data(), ctl.data(), a.b_cap};
+    Mem m{S.data(), B.data(), G.data(), N_p, Gr.data(), E.data(), rows_p, scan_p, flag.data(), tv.data(), tp.data(), batch.data(), ctl.data(), a.b_cap};
     View v{a.l0, a.s0, a.n, a.dim, a.node_hash, a.dir_code, a.dir_row, a.entry, a.has_entry, a.allowed, seen.data()};
     HostCtx<TT, WW> c(dist, a.order_seed);
     uint32_t s_n = 0;

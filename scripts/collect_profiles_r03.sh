@@ -13,7 +13,7 @@ C3="python bench.py --skip production,datasets,config4,config5,graph_equivalence
 rm -rf /tmp/c3_$tag
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/c3_$tag -o c3 -- $C3 > /tmp/c3_$tag.log 2>&1 || true
 grep '^{' /tmp/c3_$tag.log | tail -1 > $out/c3_bench_line.json
-(head -1 /tmp/c3_$tag/c3_kernel_stats.csv; grep "hvx::\|_GLOBAL__N_" /tmp/c3_$tag/c3_kernel_stats.csv) > $out/c3_kernel_stats_hvx.csv
+(head -1 /tmp/c3_$tag/c3_kernel_stats.csv; grep "hvx::\|restricted_walk\|set_bits" /tmp/c3_$tag/c3_kernel_stats.csv) > $out/c3_kernel_stats_hvx.csv
 RS="python scripts/bench_restricted_scan.py 400000 1536 32"
 rm -rf /tmp/rs_$tag
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rs_$tag -o rs -- $RS > $out/rscan.log 2>&1 || true

@@ -24,13 +24,16 @@ def main():
     dev = torch.device("cuda", 0)
     n, dim, b, k = int(os.environ.get("AB_ROWS", 1_000_000)), 768, 1024, 10
     x, q = synth.corpus(dataset, n, dim, b, 20260921, dev)
+    bf16 = os.environ.get("AB_DTYPE", "f32") == "bf16"   # config #4 storage: rows rounded once, f32 arithmetic on the rounded values
+    if bf16:
+        x = x.to(torch.bfloat16).to(torch.float32)
     g = synth.build_hnsw_graph(x, m=16, m0=32, level_seed=7)
-    ix = hv.ValidatedVectorReadIndex.managed(
+    ix = hv.ValidatedVectorReadIndex.managed(dtype=hv.BF16 if bf16 else hv.F32,
         dim=dim, metric=hv.EUCLIDEAN, node_ids=g["node_ids"], vectors=x, l0_offsets=g["l0_offsets"],
         l0_neighbors=g["l0_neighbors"], level=g["level"], up_offsets=g["up_offsets"], up_neighbors=g["up_neighbors"],
         entry_point=g["entry_point"], max_layer=g["max_layer"], m=16, m0=32, max_batch=b)
     del x
-    max_lanes = 4
+    max_lanes = int(os.environ.get("AB_MAX_LANES", 4))
     lanes = [ix] + [ix.fork() for _ in range(max_lanes - 1)]
     bufs = [(torch.zeros(b, k, dtype=torch.int64, device=dev), torch.zeros(b, k, dtype=torch.float32, device=dev),
              torch.zeros(b, dtype=torch.int32, device=dev), torch.zeros(b, dtype=torch.int32, device=dev),
@@ -40,7 +43,7 @@ def main():
     for occ in (1, 2):
         for ln in lanes:
             ln.set_occupancy(occ)
-        for L in (1, 2, 3, 4):
+        for L in range(1, max_lanes + 1):
             for rep in range(2):
                 for l in range(L):
                     for t in bufs[l]:
@@ -67,12 +70,15 @@ def main():
                     ref = cur
                 same &= all(bool((cur[i] == ref[i]).all()) for i in (0, 2, 3, 4)) and bool((cur[1].view(torch.int32) == ref[1].view(torch.int32)).all())
             qst = ref[4].cpu().numpy().astype(np.int64)
-            alg = qst[:, 3].sum() * dim * 4 + qst[:, 1].sum() * 4 + b * dim * 4
+            alg = qst[:, 3].sum() * dim * (2 if bf16 else 4) + qst[:, 1].sum() * 4 + b * dim * 4
             ms_step = dt * 1e3 / steps
             rows.append({"occ": occ, "lanes": L, "ms_per_step": round(ms_step, 4), "qps": round(b / ms_step * 1e3, 0),
                          "frac_hbm": round(alg / (ms_step * 1e-3) / 8e12, 4), "kernel_ms_mean": round(float(kms.mean()), 4),
                          "identical": same})
             print(json.dumps(rows[-1]), flush=True)
+    if bf16:
+        print(json.dumps({"dataset": dataset, "dtype": "bf16", "rows": n, "ef": ef, "dist_per_query": float(qst[:, 3].mean()), "rows_table": rows}))
+        return
     f = [torch.zeros(b, k, dtype=torch.int64, device=dev), torch.zeros(b, k, dtype=torch.float32, device=dev),
          torch.zeros(b, dtype=torch.int32, device=dev), torch.zeros(b, dtype=torch.int32, device=dev)]
     ix.flat_search_batch_device(q, k, *f)

@@ -23,7 +23,10 @@ def main():
     from pyhvx import synth
     dev = torch.device("cuda", 0)
     n, dim, b, k = int(os.environ.get("AB_ROWS", 1_000_000)), 768, 1024, 10
-    x, q = synth.corpus(dataset, n, dim, b, 20260921, dev)
+    nbq = 16  # distinct query batches, cycled: lanes in flight never gather the same rows (identical batches hit in L2 / MALL and flatter the number)
+    x, q_all = synth.corpus(dataset, n, dim, b * nbq, 20260921, dev)
+    qs = [q_all[j * b:(j + 1) * b] for j in range(nbq)]
+    q = qs[0]
     bf16 = os.environ.get("AB_DTYPE", "f32") == "bf16"   # config #4 storage: rows rounded once, f32 arithmetic on the rounded values
     if bf16:
         x = x.to(torch.bfloat16).to(torch.float32)
@@ -57,7 +60,7 @@ def main():
                 t0 = time.perf_counter()
                 for i in range(steps):
                     l = i % L
-                    lanes[l].search_batch_device(q, k, ef, *bufs[l])
+                    lanes[l].search_batch_device(qs[i % nbq] if i < steps - L else q, k, ef, *bufs[l])  # (the last step of every lane answers batch 0: the identity check)
                 for l in range(L):
                     lanes[l].sync()
                 dt = time.perf_counter() - t0

@@ -489,7 +489,10 @@ __global__ __launch_bounds__(256, 2) void flat_tile2_kernel(MfmaArgs a, float xm
 // step u + 1 are requested before the MFMAs of step u are issued -- also across the stage barrier -- and the fp8 widening
 // of step u + 1 sits between the two halves of step u's MFMAs.  Ring of four 32-deep stages (bf16 rows, 128 KB) or three
 // 64-deep stages (fp8 codes, 144 KB), counted vmcnt, raw s_barrier, fragment reads as inline asm with stated waits.
-template <int KIND>
+// INTER: the LDS-DMA copies of the stage a boundary step opens are issued BETWEEN that step's MFMAs (one 1-KB piece per two
+// MFMAs) instead of in one burst behind the barrier: a piece costs its wavefront ~60 issue cycles, eight of them in a row leave the
+// matrix core of a one-wavefront SIMD idle for half a stage's worth of MFMA time.
+template <int KIND, bool INTER>
 __global__ __launch_bounds__(256, 1) void flat_tile4_kernel(MfmaArgs a, float xmax2, uint32_t *wg_overflow) {
     constexpr bool FP8 = KIND == 1;
     constexpr int KS = FP8 ? 64 : 32, SPS = KS / 16;
@@ -528,6 +531,10 @@ __global__ __launch_bounds__(256, 1) void flat_tile4_kernel(MfmaArgs a, float xm
         for (int t = 0; t < GA; ++t) HVX_GLDS16(gA[t] + s * (uint32_t)AROWB, sA + t * 1024);
 #pragma unroll
         for (int t = 0; t < GB; ++t) HVX_GLDS16(gB[t] + s * (uint32_t)BROWB, sB + t * 1024);
+    };
+    auto issue_piece = [&](uint32_t s, int p) { // piece p of stage s, same order as issue_stage (the vmcnt arithmetic counts pieces)
+        if (p < GA) HVX_GLDS16(gA[p] + s * (uint32_t)AROWB, lds + (s % NBUF) * STAGE + wave * (64 * AROWB) + p * 1024);
+        else HVX_GLDS16(gB[p - GA] + s * (uint32_t)BROWB, lds + (s % NBUF) * STAGE + ASTAGE + wave * (64 * BROWB) + (p - GA) * 1024);
     };
     const int fr = lane & 31, h = lane >> 5;
     int off128[4], off64[2];
@@ -601,15 +608,44 @@ __global__ __launch_bounds__(256, 1) void flat_tile4_kernel(MfmaArgs a, float xm
     auto step = [&](bool has_next, bool boundary, uint32_t s, uint32_t nbuf, int nkk, bf16x8 (&fa_c)[4], bf16x8 (&fb_c)[4], bf16x8 (&fa_n)[4],
                     bf16x8 (&fb_n)[4]) {
         wait_lgkm0(); // the reads of `cur` were requested sixteen MFMAs ago
+        bool copies = false; // INTER: this step carries the copies of stage s + NBUF between its MFMAs
         if (has_next) {
             if (boundary) {
                 wait_stage(s + 1);            // this wave's copies of stage s + 1 have landed (and it has read stage s out: the wait above)
                 __builtin_amdgcn_s_barrier(); // everyone's have; the buffer of stage s is free
-                if (s + (uint32_t)NBUF < nstage) issue_stage(s + (uint32_t)NBUF);
+                if (s + (uint32_t)NBUF < nstage) {
+                    if (INTER) copies = true;
+                    else issue_stage(s + (uint32_t)NBUF);
+                }
             }
             read_raw(nbuf, nkk, fa_n, fb_n);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (INTER && boundary) { // uniform branch (copies is the same for the whole workgroup); the MFMA order is the one of mfma8
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int i = 2 * half; i < 2 * half + 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; j += 2) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_c[i], fb_c[j], acc[i][j], 0, 0, 0);
+                        acc[i][j + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_c[i], fb_c[j + 1], acc[i][j + 1], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int slot = (i * 4 + j) >> 1; // 0 .. 7: the G pieces spread over eight slots
+                        if (copies) {
+#pragma unroll
+                            for (int p = slot * G / 8; p < (slot + 1) * G / 8; ++p) issue_piece(s + (uint32_t)NBUF, p);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                if (half == 0 && FP8 && has_next) {
+                    wait_lgkm0();
+                    widen(nkk, fb_n);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            return;
+        }
         mfma8(0, fa_c, fb_c);
         __builtin_amdgcn_sched_barrier(0);
         if (FP8 && has_next) { // the codes of step u + 1 were requested eight MFMAs ago
@@ -666,11 +702,15 @@ hipError_t launch_flat_tile256(const MfmaArgs &a, int kind, uint32_t bpad, float
 #ifdef HVX_TUNING
     if (const char *e = getenv("HVX_FLAT_TILE_ABLATE")) t.ablate = (uint32_t)atoi(e);
     const int tuning_build = [] { const char *e = getenv("HVX_FLAT_TILE_BUILD"); return e ? atoi(e) : 0; }();
+    if (tuning_build == 6 || tuning_build == 7) { // build 4 / 5 with the stage copies issued between the MFMAs (6: bf16 only, 7: fp8 too)
+        if (kind == 1 && tuning_build == 7) { hipLaunchKernelGGL((flat_tile4_kernel<1, true>), grid, dim3(256), 0, s, t, xmax2, wg_overflow); return hipGetLastError(); }
+        if (kind != 1) { hipLaunchKernelGGL((flat_tile4_kernel<0, true>), grid, dim3(256), 0, s, t, xmax2, wg_overflow); return hipGetLastError(); }
+    }
     if ((tuning_build == 4 && kind != 1) || tuning_build == 5) { // 256 x 256 tiles, 256 threads of 128 x 128 each, one workgroup per CU:
         // bf16 rows passed their one parity run, the fp8 instantiation returned wrong candidates once (v_mov copies of fragment
         // registers right behind their inline-asm ds_read; scripts/lint_asm_lds.py finds them) and has not run since.  Untimed.
-        if (kind == 1) hipLaunchKernelGGL((flat_tile4_kernel<1>), grid, dim3(256), 0, s, t, xmax2, wg_overflow);
-        else hipLaunchKernelGGL((flat_tile4_kernel<0>), grid, dim3(256), 0, s, t, xmax2, wg_overflow);
+        if (kind == 1) hipLaunchKernelGGL((flat_tile4_kernel<1, false>), grid, dim3(256), 0, s, t, xmax2, wg_overflow);
+        else hipLaunchKernelGGL((flat_tile4_kernel<0, false>), grid, dim3(256), 0, s, t, xmax2, wg_overflow);
         return hipGetLastError();
     }
 #endif

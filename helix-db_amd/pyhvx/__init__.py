@@ -15,7 +15,9 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libhelix_vec_gfx950.so")
+# HVX_LIB_PATH: measurement scripts load the tuning build (make TUNING=1 -> libhelix_vec_gfx950_tuning.so) through this binding;
+# the library itself reads no environment in its release build.
+LIB_PATH = os.environ.get("HVX_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "libhelix_vec_gfx950.so")
 
 COSINE, EUCLIDEAN, MANHATTAN = 0, 1, 2
 F32, BF16, FP8_E4M3 = 0, 1, 2

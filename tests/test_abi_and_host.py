@@ -298,14 +298,14 @@ def test_inline_asm_lds_reads_are_covered_by_a_wait(tmp_path):
         pytest.skip("no hipcc")
     src = os.path.join(ROOT, "helix-db_amd", "csrc", "hvx_flat_tile.hip")
     # the release build carries flat_tile2_kernel only; the tuning build (-DHVX_TUNING) also the experimental flat_tile4_kernel
-    for flags, kernels, want in (([], ["flat_tile2_kernel"], 2), (["-DHVX_TUNING"], ["flat_tile2_kernel", "flat_tile4_kernel"], 4)):
+    for flags, kernels, want in (([], ["flat_tile2_kernel"], 2), (["-DHVX_TUNING"], ["flat_tile2_kernel", "flat_tile4_kernel"], 6)):
         asm = tmp_path / ("hvx_flat_tile%d.s" % want)
         out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S", "--cuda-device-only"]
                              + flags + ["-o", str(asm), src], capture_output=True, text=True)
         assert out.returncode == 0, out.stderr
         lint = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "lint_asm_lds.py"), str(asm)] + kernels, capture_output=True, text=True)
         assert lint.returncode == 0, lint.stdout + lint.stderr
-        assert lint.stdout.count(": 0 hazard(s)") == want, lint.stdout    # fp8 + bf16 instantiations of each kernel
+        assert lint.stdout.count(": 0 hazard(s)") == want, lint.stdout    # fp8 + bf16 instantiations of each kernel (tile4: with and without interleaved copies)
 
 
 def test_release_library_reads_no_environment_and_carries_no_measurement_code():

@@ -53,6 +53,7 @@ struct BuildArgs {
     uint32_t *sel_cnt;          // [layers][b]
     uint32_t m, m0;             // degree limits: upper layers / layer 0 (m0 = max(m0, 2m), mutation.rs:178-196)
     uint32_t *err;              // [1] set when a row would overflow its stride (invariant violation)
+    uint32_t ldp, ncmax;        // build_link_wg_kernel: padded row stride in LDS (floats), candidate rows the LDS holds
 };
 
 __device__ __forceinline__ uint32_t ld_row(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -281,9 +282,294 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(64) void bui
     }
 }
 
+// ---- step 3, batched mode: one 256-thread workgroup per LINK (new node q, layer, selected neighbour s) ----
+// build_link_kernel walks a node's <= 32 links one after the other, and every prune inside it is a chain of ~100 dependent row
+// gathers (select_diverse stages candidate i, then scores it against the kept rows eight at a time, stops at the first hit):
+// 9.4 ms per 2 048-node batch, 70 % of the build (profiles/r02f).  In a batch the order in which links reach the graph is not
+// defined anyway, so every link gets its own workgroup, and the prune is evaluated EAGERLY from LDS: the nc <= Mmax + 1 rows of
+// the overflowing row (+ its owner's) cross HBM once (one burst of independent loads, ~100 KB at dim 768), the owner distances,
+// the (score, id) order and the whole predicate matrix P[i][j] = dist(c_i, c_j) < dist(c_i, owner), j < i -- every pair
+// independent of every other, 32 row groups at work -- come from LDS with the reference's summation order (pair_distance_lds =
+// group_distance with both operands in LDS), and select_diverse + backfill (mod.rs:809-856) is a walk over 64-bit masks:
+// candidate i is diverse iff P[i] & kept == 0.  Same decisions as the lazy evaluation, bit for bit.
+struct LinkLds {
+    float *rows;              // [ncmax + 1][ldp]: candidate rows in ROW order of the neighbour row (+ appended node), then the owner's
+    uint32_t *cand;           // [64] ids in row order
+    float *dist;              // [64] distance to the owner, row order
+    uint32_t *cid;            // [64] ids sorted by (distance, id)
+    float *csc;               // [64] their distances
+    uint32_t *srow;           // [64] LDS row of sorted candidate r
+    unsigned long long *P;    // [64] predicate masks, sorted order
+    uint32_t *fin;            // [64] ids of the pruned row
+    uint32_t *sh;             // [8] nc, prune, present, overflow
+};
+__device__ __forceinline__ LinkLds carve_link(char *smem, uint32_t ldp, uint32_t ncmax) {
+    LinkLds L;
+    L.rows = reinterpret_cast<float *>(smem);
+    char *p = smem + (size_t)(ncmax + 1u) * ldp * 4u;
+    L.P = reinterpret_cast<unsigned long long *>(p); p += 512;
+    L.cand = reinterpret_cast<uint32_t *>(p); p += 256;
+    L.dist = reinterpret_cast<float *>(p); p += 256;
+    L.cid = reinterpret_cast<uint32_t *>(p); p += 256;
+    L.csc = reinterpret_cast<float *>(p); p += 256;
+    L.srow = reinterpret_cast<uint32_t *>(p); p += 256;
+    L.fin = reinterpret_cast<uint32_t *>(p); p += 256;
+    L.sh = reinterpret_cast<uint32_t *>(p);
+    return L;
+}
+static size_t link_lds_bytes(uint32_t ldp, uint32_t ncmax) { return (size_t)(ncmax + 1u) * ldp * 4u + 512u + 6u * 256u + 32u; }
+
+// group_distance (hvx_device.h) with BOTH rows in LDS: same summation tree (AVX lanes = the 8 lanes of a row group, chunk_slot
+// order, avx_tree_reduce), same scalar tail, same cosine finish.  qv / qhdr = the "query" side, row / rhdr the stored side.
+template <uint32_t METRIC, bool FUSED>
+__device__ __forceinline__ float pair_distance_lds(const DevIndex &ix, const float *qv, float qhdr, const float *row, float rhdr, int j) {
+    float result;
+    uint32_t t0;
+    if (METRIC == kL1) {
+        result = 0.0f;
+        t0 = 0;
+    } else {
+        t0 = ix.dim_main;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const uint32_t nk = t0 >> 5;
+        const int slot = chunk_slot(j);
+        const float4 *rp = reinterpret_cast<const float4 *>(row) + slot;
+        const float4 *qp = reinterpret_cast<const float4 *>(qv) + slot;
+#pragma unroll 4
+        for (uint32_t k = 0; k < nk; ++k) {
+            const float4 x = rp[k * 8u];
+            const float4 qq = qp[k * 8u];
+            if (METRIC == kL2) {
+                const float d0 = qq.x - x.x, d1 = qq.y - x.y, d2 = qq.z - x.z, d3 = qq.w - x.w;
+                if (FUSED) {
+                    acc.x = __builtin_fmaf(d0, d0, acc.x); acc.y = __builtin_fmaf(d1, d1, acc.y);
+                    acc.z = __builtin_fmaf(d2, d2, acc.z); acc.w = __builtin_fmaf(d3, d3, acc.w);
+                } else {
+                    acc.x = d0 * d0 + acc.x; acc.y = d1 * d1 + acc.y;
+                    acc.z = d2 * d2 + acc.z; acc.w = d3 * d3 + acc.w;
+                }
+            } else {
+                if (FUSED) {
+                    acc.x = __builtin_fmaf(qq.x, x.x, acc.x); acc.y = __builtin_fmaf(qq.y, x.y, acc.y);
+                    acc.z = __builtin_fmaf(qq.z, x.z, acc.z); acc.w = __builtin_fmaf(qq.w, x.w, acc.w);
+                } else {
+                    acc.x = qq.x * x.x + acc.x; acc.y = qq.y * x.y + acc.y;
+                    acc.z = qq.z * x.z + acc.z; acc.w = qq.w * x.w + acc.w;
+                }
+            }
+        }
+        result = nk ? avx_tree_reduce(acc) : 0.0f;
+    }
+    for (uint32_t t = t0; t < ix.dim; ++t) {
+        const float a = qv[t], b = row[t];
+        if (METRIC == kL2) {
+            const float d = a - b;
+            const float pr = d * d;
+            result += pr;
+        } else if (METRIC == kCosine) {
+            const float pr = a * b;
+            result += pr;
+        } else {
+            result += fabsf(a - b);
+        }
+    }
+    if (METRIC == kCosine) result = cosine_finish_fn(result, qhdr, rhdr, [&]() { return stable_half_cosine(qv, row, ix.dim); });
+    return result;
+}
+
+// the tail of a link runs on ONE wavefront of the workgroup (the others have left): wavefront-level ordering instead of s_barrier
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void lock_row_w(uint32_t *locks, uint32_t node, int lane) {
+    if (lane == 0) {
+        while (__hip_atomic_exchange(&locks[node], 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) __builtin_amdgcn_s_sleep(2);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void unlock_row_w(uint32_t *locks, uint32_t node, int lane) {
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) __hip_atomic_store(&locks[node], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// canonical row (ascending id, sentinel padded) of ids_lds[0..ns), written with agent-scope stores by one wavefront
+__device__ __forceinline__ void store_canonical_w(uint32_t *row, uint32_t stride, const uint32_t *ids_lds, uint32_t ns, int lane) {
+    const uint32_t mine = (uint32_t)lane < ns ? ids_lds[lane] : kSentinel;
+    uint32_t rank = 0;
+    for (uint32_t s = 0; s < ns; ++s) rank += ids_lds[s] < mine ? 1u : 0u;
+    if ((uint32_t)lane >= ns && (uint32_t)lane < stride) st_row(row + lane, kSentinel);
+    if ((uint32_t)lane < ns) st_row(row + rank, mine);
+}
+__device__ __forceinline__ void remove_edge_w(const BuildArgs &a, uint32_t layer, uint32_t owner, uint32_t victim, int lane) {
+    lock_row_w(a.locks, owner, lane);
+    uint32_t stride;
+    uint32_t *row = row_ptr(a, owner, layer, stride);
+    const uint32_t v = (uint32_t)lane < stride ? ld_row(row + lane) : kSentinel;
+    const bool keep = v != kSentinel && v != victim;
+    const unsigned long long km = __ballot(keep);
+    const uint32_t pos = (uint32_t)__builtin_popcountll(km & ((1ull << lane) - 1ull));
+    const uint32_t nk = (uint32_t)__builtin_popcountll(km);
+    if (keep) st_row(row + pos, v);   // pos <= lane: a lane never overwrites an id another lane still has to move (v is in registers)
+    if ((uint32_t)lane >= nk && (uint32_t)lane < stride) st_row(row + lane, kSentinel);
+    unlock_row_w(a.locks, owner, lane);
+}
+
+template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(256) void build_link_wg_kernel(BuildArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const DevIndex &ix = a.ix;
+    const uint32_t q = blockIdx.x >> 5, s = blockIdx.x & 31u, layer = blockIdx.y;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 3, j = lane & 7;
+    const uint32_t me = a.nodes[q];
+    const uint32_t lv = ix.level[me];
+    const uint32_t top = lv < a.layers - 1u ? lv : a.layers - 1u;
+    if (layer > top) return;
+    const size_t slot = (size_t)layer * a.b + q;
+    if (s >= a.sel_cnt[slot]) return;
+    const uint32_t to = a.sel[slot * 32u + s];
+    const uint32_t maxn = layer == 0u ? a.m0 : a.m;
+    LinkLds L = carve_link(smem, a.ldp, a.ncmax);
+    uint32_t stride;
+    uint32_t *row = row_ptr(a, to, layer, stride);
+
+    // ---- add_bidirectional_link(from = me, to) (mutation.rs:1498-1583): append under the row owner's lock ----
+    if (wave == 0) {
+        lock_row_w(a.locks, to, lane);
+        uint32_t v = (uint32_t)lane < stride ? ld_row(row + lane) : kSentinel;
+        uint32_t deg = (uint32_t)__builtin_popcountll(__ballot(v != kSentinel));
+        const bool present = __ballot(v == me) != 0ull;
+        bool overflow = false;
+        if (!present) {
+            if (deg >= 64u) overflow = true;
+            else {
+                if ((uint32_t)lane == deg) v = me; // rows are canonical: the valid ids occupy lanes 0..deg-1
+                ++deg;
+            }
+        }
+        if (deg > maxn && deg > a.ncmax) overflow = true; // more rows than the LDS was sized for: cannot happen on rows this build wrote
+        L.cand[lane] = v;
+        if (lane == 0) {
+            L.sh[0] = deg;
+            L.sh[1] = (deg > maxn && !overflow) ? 1u : 0u;
+            L.sh[2] = present ? 1u : 0u;
+            L.sh[3] = overflow ? 1u : 0u;
+            if (overflow) *a.err = 1u;
+        }
+    }
+    __syncthreads();
+    const uint32_t nc = L.sh[0];
+    if (L.sh[1] == 0u) { // no prune: the appended id takes its place in the canonical row
+        if (wave == 0) {
+            if (L.sh[2] == 0u && L.sh[3] == 0u) store_canonical_w(row, stride, L.cand, nc, lane);
+            unlock_row_w(a.locks, to, lane);
+        }
+        return;
+    }
+
+    // ---- the nc candidate rows and the owner's row: HBM -> LDS, every load independent ----
+    const uint32_t ld4 = ix.ld >> 2, total4 = (nc + 1u) * ld4;
+#pragma unroll 8
+    for (uint32_t idx = (uint32_t)tid; idx < total4; idx += 256u) {
+        const uint32_t r = idx / ld4, c = idx - r * ld4;
+        const uint32_t node = r < nc ? L.cand[r] : to;
+        const float4 x = reinterpret_cast<const float4 *>(ix.vec + (size_t)node * ix.ld)[c];
+        reinterpret_cast<float4 *>(L.rows + (size_t)r * a.ldp)[c] = x;
+    }
+    if (tid < 64) L.P[tid] = 0ull;
+    __syncthreads();
+
+    // ---- rank the row's neighbours by distance to its owner (Candidate order: score, then id; model.rs:55-61) ----
+    const float *orow = L.rows + (size_t)nc * a.ldp;
+    const float thdr = METRIC == kCosine ? ix.hdr[to] : 0.f;
+    for (uint32_t p0 = (uint32_t)wave * 8u; p0 < nc; p0 += 32u) {
+        const uint32_t g = p0 + (uint32_t)grp;
+        const uint32_t r = g < nc ? g : nc - 1u;
+        const float rh = METRIC == kCosine ? ix.hdr[L.cand[r]] : 0.f;
+        const float d = pair_distance_lds<METRIC, FUSED>(ix, orow, thdr, L.rows + (size_t)r * a.ldp, rh, j);
+        if (g < nc && j == 0) L.dist[g] = d;
+    }
+    __syncthreads();
+    if ((uint32_t)tid < nc) {
+        const float dmine = L.dist[tid];
+        const uint32_t v = L.cand[tid];
+        uint32_t rank = 0;
+        for (uint32_t t = 0; t < nc; ++t) {
+            const float dt = L.dist[t];
+            const uint32_t it = L.cand[t];
+            rank += (dt < dmine || (dt == dmine && it < v)) ? 1u : 0u;
+        }
+        L.cid[rank] = v;
+        L.csc[rank] = dmine;
+        L.srow[rank] = (uint32_t)tid;
+    }
+    __syncthreads();
+
+    // ---- P[i] bit jj = dist(c_i, c_jj) < dist(c_i, owner), jj < i (sorted order): the test of mod.rs:832, every pair ----
+    uint32_t task = 0;
+    for (uint32_t i = 1; i < nc; ++i) {
+        const uint32_t chunks = (i + 7u) >> 3;
+        for (uint32_t c = 0; c < chunks; ++c, ++task) {
+            if ((task & 3u) != (uint32_t)wave) continue;
+            const uint32_t jj = c * 8u + (uint32_t)grp;
+            const uint32_t jr = jj < i ? jj : 0u;
+            const float ih = METRIC == kCosine ? ix.hdr[L.cid[i]] : 0.f;
+            const float jh = METRIC == kCosine ? ix.hdr[L.cid[jr]] : 0.f;
+            const float pd = pair_distance_lds<METRIC, FUSED>(ix, L.rows + (size_t)L.srow[i] * a.ldp, ih, L.rows + (size_t)L.srow[jr] * a.ldp, jh, j);
+            const unsigned long long hm = __ballot(jj < i && j == 0 && pd < L.csc[i]); // strict < rejects
+            if (lane == 0 && hm) {
+                unsigned long long bits = 0ull;
+#pragma unroll
+                for (int g = 0; g < 8; ++g)
+                    if ((hm >> (8 * g)) & 1ull) bits |= 1ull << (c * 8u + (uint32_t)g);
+                atomicOr(&L.P[i], bits);
+            }
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+
+    // ---- select_diverse + backfill over the masks (mod.rs:809-856); all lanes walk the same chain ----
+    unsigned long long kept = 0ull;
+    uint32_t ns = 0;
+    for (uint32_t i = 0; i < nc && ns < maxn; ++i)
+        if ((L.P[i] & kept) == 0ull) { kept |= 1ull << i; ++ns; }
+    for (uint32_t i = 0; i < nc && ns < maxn; ++i)
+        if (((kept >> i) & 1ull) == 0ull) { kept |= 1ull << i; ++ns; }
+    const bool have = (uint32_t)lane < nc;
+    const uint32_t mine = have ? L.cid[lane] : kSentinel;
+    const bool in = have && ((kept >> lane) & 1ull) != 0ull;
+    const unsigned long long im = __ballot(in);
+    if (in) L.fin[__builtin_popcountll(im & ((1ull << lane) - 1ull))] = mine;
+    const uint32_t dropped_id = (have && !in) ? mine : kSentinel;
+    wave_sync();
+    store_canonical_w(row, stride, L.fin, ns, lane);
+    unlock_row_w(a.locks, to, lane);
+    // every neighbour dropped by the prune loses its edge to `to` as well (mutation.rs:1890-1908): the graph stays symmetric
+    unsigned long long dm = __ballot(dropped_id != kSentinel);
+    while (dm) {
+        const uint32_t src = (uint32_t)__builtin_ctzll(dm);
+        dm &= dm - 1ull;
+        const uint32_t x = __builtin_amdgcn_readlane(dropped_id, src);
+        remove_edge_w(a, layer, x, to, lane);
+    }
+}
+
 template <typename K> static hipError_t launch_build(K kern, dim3 grid, const BuildArgs &a, hipStream_t s) {
     const size_t lds = build_lds_bytes(a.ix.ld);
     hipLaunchKernelGGL(kern, grid, dim3(64), lds, s, a);
+    return hipGetLastError();
+}
+
+template <typename K> static hipError_t launch_link_wg(K kern, const BuildArgs &a, uint32_t layers, size_t lds, hipStream_t s) {
+    static thread_local const void *raised = nullptr; // the attribute is per function: set it once per kernel
+    if (lds > 48 * 1024 && raised != (const void *)kern) {
+        const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        raised = (const void *)kern;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.b * 32u, layers), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
@@ -373,6 +659,12 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
     DevIndex &d = ix->dev;
     uint32_t *l0w = const_cast<uint32_t *>(d.l0), *upw = const_cast<uint32_t *>(d.up);
     const bool l2 = d.metric == kL2;
+    // build_link_wg_kernel keeps Mmax + 1 candidate rows and the owner's in LDS, row stride = 128 B mod 256 B (the eight row groups of
+    // a wavefront read eight consecutive rows: conflict-free ds_read_b128); it serves the build when that fits the 160 KB of a CU
+    const uint32_t ncmax = std::max(m0, m) + 1u;
+    const uint32_t ldp = ((d.ld + 31u) / 64u) * 64u + 32u;
+    const size_t link_lds = link_lds_bytes(ldp, ncmax);
+    const bool link_wg = link_lds <= 160u * 1024u && params->link_mode != 1u;
     // first node: the entry point with empty rows on its layers (mutation.rs:706-739)
     d.has_entry = 1;
     d.entry = 0;
@@ -423,8 +715,16 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
         ba.err = d_err;
         hipError_t e = l2 ? launch_build(build_select_kernel<kL2, true>, dim3(bsz, layers), ba, s)
                           : launch_build(build_select_kernel<kCosine, true>, dim3(bsz, layers), ba, s);
-        if (e == hipSuccess)
-            e = l2 ? launch_build(build_link_kernel<kL2, true>, dim3(bsz), ba, s) : launch_build(build_link_kernel<kCosine, true>, dim3(bsz), ba, s);
+        if (e == hipSuccess) {
+            if (bsz > 1u && link_wg) { // batched mode: one workgroup per link, prunes evaluated from LDS
+                ba.ldp = ldp;
+                ba.ncmax = ncmax;
+                e = l2 ? launch_link_wg(build_link_wg_kernel<kL2, true>, ba, layers, link_lds, s)
+                       : launch_link_wg(build_link_wg_kernel<kCosine, true>, ba, layers, link_lds, s);
+            } else { // one node (the reference's order exactly), or rows too long for the LDS: one wavefront per node
+                e = l2 ? launch_build(build_link_kernel<kL2, true>, dim3(bsz), ba, s) : launch_build(build_link_kernel<kCosine, true>, dim3(bsz), ba, s);
+            }
+        }
         if (e != hipSuccess) return sbail(fail(HVX_ERR_DEVICE, "build launch failed: %s", hipGetErrorString(e)));
         if (promotes) { // mutation.rs:769-772
             d.entry = (uint32_t)done;

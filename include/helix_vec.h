@@ -541,6 +541,8 @@ typedef struct hvx_build_params {
     uint32_t max_batch;       /* 0 => 2048 */
     uint32_t batch_divisor;   /* 0 => 32: batch <= nodes already inserted / divisor */
     uint32_t sequential;      /* 1 => one node per batch: the reference's insertion order exactly */
+    uint32_t link_mode;       /* batched link step: 0 => one workgroup per link with the prune evaluated from LDS whenever the rows fit
+                                 (Mmax + 2 rows of ld floats <= 160 KB), 1 => one wavefront per node (links one after the other) */
 } hvx_build_params;
 typedef struct hvx_build_stats {
     uint64_t nodes, batches, single_node_batches;

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -37,6 +38,12 @@ using namespace hvx;
     } while (0)
 
 namespace hvx {
+
+#ifdef HVX_TUNING
+#define HVX_DBG_ADD(a, i, v) do { if ((a).dbg) atomicAdd(&(a).dbg[i], (uint32_t)(v)); } while (0)
+#else
+#define HVX_DBG_ADD(a, i, v) do { } while (0)
+#endif
 
 constexpr uint32_t kCand = 64; // candidates kept per layer and node (2 * Mmax <= 64)
 
@@ -53,7 +60,9 @@ struct BuildArgs {
     uint32_t *sel_cnt;          // [layers][b]
     uint32_t m, m0;             // degree limits: upper layers / layer 0 (m0 = max(m0, 2m), mutation.rs:178-196)
     uint32_t *err;              // [1] set when a row would overflow its stride (invariant violation)
-    uint32_t ldp, ncmax;        // build_link_wg_kernel: padded row stride in LDS (floats), candidate rows the LDS holds
+    uint32_t ldp, ncmax;        // build_link_wg_kernel: row stride of a column block in LDS (floats), candidate rows the LDS holds
+    uint32_t link_ck;           // 32-float chunks per column block
+    uint32_t *dbg;              // tuning builds (HVX_BUILD_DEBUG): [0] lock spins [1] prunes [2] reverse-edge removals [3] plain appends
 };
 
 __device__ __forceinline__ uint32_t ld_row(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -287,94 +296,50 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(64) void bui
 // gathers (select_diverse stages candidate i, then scores it against the kept rows eight at a time, stops at the first hit):
 // 9.4 ms per 2 048-node batch, 70 % of the build (profiles/r02f).  In a batch the order in which links reach the graph is not
 // defined anyway, so every link gets its own workgroup, and the prune is evaluated EAGERLY from LDS: the nc <= Mmax + 1 rows of
-// the overflowing row (+ its owner's) cross HBM once (one burst of independent loads, ~100 KB at dim 768), the owner distances,
-// the (score, id) order and the whole predicate matrix P[i][j] = dist(c_i, c_j) < dist(c_i, owner), j < i -- every pair
-// independent of every other, 32 row groups at work -- come from LDS with the reference's summation order (pair_distance_lds =
-// group_distance with both operands in LDS), and select_diverse + backfill (mod.rs:809-856) is a walk over 64-bit masks:
-// candidate i is diverse iff P[i] & kept == 0.  Same decisions as the lazy evaluation, bit for bit.
+// the overflowing row and its owner's cross HBM once, and ALL pairwise distances among them (every pair independent of every
+// other: 561 pairs for 33 + 1 rows, eight per wavefront step) are computed with the reference's summation order -- the
+// distance is symmetric bit for bit (squares / products commute), so the pair set does not depend on the (score, id) order that
+// select_diverse walks.  The rows pass through LDS in COLUMN blocks of <= 256 floats: a pair's four AVX-lane accumulators are
+// carried in registers from block to block (each lane's fma chain runs over the depth in the same order as in one pass), the
+// next block is in flight in registers while this one is being used, and a workgroup holds ~46 KB of LDS: three per CU, so
+// the lock / row / store latencies of one link sit under the arithmetic of the others.  Then: owner distances -> Candidate order
+// (model.rs:55-61), P[i] bit j = D[c_i][c_j] < D[c_i][owner] (the test of mod.rs:832), and select_diverse + backfill
+// (mod.rs:809-856) is a walk over 64-bit masks: candidate i is diverse iff P[i] & kept == 0.  Same decisions as the lazy
+// evaluation, bit for bit.
+constexpr int kLinkTasks = 18; // wave-steps of 8 pairs per wavefront: 4 x 18 x 8 >= 561 pairs of 33 candidates + owner
+
 struct LinkLds {
-    float *rows;              // [ncmax + 1][ldp]: candidate rows in ROW order of the neighbour row (+ appended node), then the owner's
+    float *rows;              // [ncmax + 1][ldp]: this column block of the candidate rows (row order of the neighbour row), then the owner's
+    float *D;                 // [ncmax + 1][ncmax + 1] pairwise distances (index nc = the owner)
     uint32_t *cand;           // [64] ids in row order
-    float *dist;              // [64] distance to the owner, row order
-    uint32_t *cid;            // [64] ids sorted by (distance, id)
+    uint32_t *cid;            // [64] ids sorted by (distance to the owner, id)
     float *csc;               // [64] their distances
-    uint32_t *srow;           // [64] LDS row of sorted candidate r
+    uint32_t *srow;           // [64] row index of sorted candidate r
     unsigned long long *P;    // [64] predicate masks, sorted order
     uint32_t *fin;            // [64] ids of the pruned row
     uint32_t *sh;             // [8] nc, prune, present, overflow
+    unsigned char *pa, *pb;   // [pairs] the two rows of pair p
 };
+__device__ __host__ __forceinline__ size_t link_pairs_max(uint32_t ncmax) { return (size_t)(ncmax + 1u) * ncmax / 2u; }
 __device__ __forceinline__ LinkLds carve_link(char *smem, uint32_t ldp, uint32_t ncmax) {
     LinkLds L;
     L.rows = reinterpret_cast<float *>(smem);
     char *p = smem + (size_t)(ncmax + 1u) * ldp * 4u;
     L.P = reinterpret_cast<unsigned long long *>(p); p += 512;
+    L.D = reinterpret_cast<float *>(p); p += (size_t)(ncmax + 1u) * (ncmax + 1u) * 4u;
     L.cand = reinterpret_cast<uint32_t *>(p); p += 256;
-    L.dist = reinterpret_cast<float *>(p); p += 256;
     L.cid = reinterpret_cast<uint32_t *>(p); p += 256;
     L.csc = reinterpret_cast<float *>(p); p += 256;
     L.srow = reinterpret_cast<uint32_t *>(p); p += 256;
     L.fin = reinterpret_cast<uint32_t *>(p); p += 256;
-    L.sh = reinterpret_cast<uint32_t *>(p);
+    L.sh = reinterpret_cast<uint32_t *>(p); p += 32;
+    L.pa = reinterpret_cast<unsigned char *>(p); p += (link_pairs_max(ncmax) + 15u) & ~(size_t)15u;
+    L.pb = reinterpret_cast<unsigned char *>(p);
     return L;
 }
-static size_t link_lds_bytes(uint32_t ldp, uint32_t ncmax) { return (size_t)(ncmax + 1u) * ldp * 4u + 512u + 6u * 256u + 32u; }
-
-// group_distance (hvx_device.h) with BOTH rows in LDS: same summation tree (AVX lanes = the 8 lanes of a row group, chunk_slot
-// order, avx_tree_reduce), same scalar tail, same cosine finish.  qv / qhdr = the "query" side, row / rhdr the stored side.
-template <uint32_t METRIC, bool FUSED>
-__device__ __forceinline__ float pair_distance_lds(const DevIndex &ix, const float *qv, float qhdr, const float *row, float rhdr, int j) {
-    float result;
-    uint32_t t0;
-    if (METRIC == kL1) {
-        result = 0.0f;
-        t0 = 0;
-    } else {
-        t0 = ix.dim_main;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        const uint32_t nk = t0 >> 5;
-        const int slot = chunk_slot(j);
-        const float4 *rp = reinterpret_cast<const float4 *>(row) + slot;
-        const float4 *qp = reinterpret_cast<const float4 *>(qv) + slot;
-#pragma unroll 4
-        for (uint32_t k = 0; k < nk; ++k) {
-            const float4 x = rp[k * 8u];
-            const float4 qq = qp[k * 8u];
-            if (METRIC == kL2) {
-                const float d0 = qq.x - x.x, d1 = qq.y - x.y, d2 = qq.z - x.z, d3 = qq.w - x.w;
-                if (FUSED) {
-                    acc.x = __builtin_fmaf(d0, d0, acc.x); acc.y = __builtin_fmaf(d1, d1, acc.y);
-                    acc.z = __builtin_fmaf(d2, d2, acc.z); acc.w = __builtin_fmaf(d3, d3, acc.w);
-                } else {
-                    acc.x = d0 * d0 + acc.x; acc.y = d1 * d1 + acc.y;
-                    acc.z = d2 * d2 + acc.z; acc.w = d3 * d3 + acc.w;
-                }
-            } else {
-                if (FUSED) {
-                    acc.x = __builtin_fmaf(qq.x, x.x, acc.x); acc.y = __builtin_fmaf(qq.y, x.y, acc.y);
-                    acc.z = __builtin_fmaf(qq.z, x.z, acc.z); acc.w = __builtin_fmaf(qq.w, x.w, acc.w);
-                } else {
-                    acc.x = qq.x * x.x + acc.x; acc.y = qq.y * x.y + acc.y;
-                    acc.z = qq.z * x.z + acc.z; acc.w = qq.w * x.w + acc.w;
-                }
-            }
-        }
-        result = nk ? avx_tree_reduce(acc) : 0.0f;
-    }
-    for (uint32_t t = t0; t < ix.dim; ++t) {
-        const float a = qv[t], b = row[t];
-        if (METRIC == kL2) {
-            const float d = a - b;
-            const float pr = d * d;
-            result += pr;
-        } else if (METRIC == kCosine) {
-            const float pr = a * b;
-            result += pr;
-        } else {
-            result += fabsf(a - b);
-        }
-    }
-    if (METRIC == kCosine) result = cosine_finish_fn(result, qhdr, rhdr, [&]() { return stable_half_cosine(qv, row, ix.dim); });
-    return result;
+static size_t link_lds_bytes(uint32_t ldp, uint32_t ncmax) {
+    return (size_t)(ncmax + 1u) * ldp * 4u + 512u + (size_t)(ncmax + 1u) * (ncmax + 1u) * 4u + 5u * 256u + 32u +
+           2u * ((link_pairs_max(ncmax) + 15u) & ~(size_t)15u);
 }
 
 // the tail of a link runs on ONE wavefront of the workgroup (the others have left): wavefront-level ordering instead of s_barrier
@@ -383,17 +348,21 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+// Row locks of build_link_wg_kernel.  Everything a lock protects (the neighbour rows) is read and written with agent-scope
+// atomics (ld_row / st_row: coherent across the XCDs' L2s by themselves), so taking and dropping a lock needs ORDER only, not
+// cache maintenance: no acquire / release at agent scope (on gfx950 that is an L2 invalidate / write-back of the whole XCD per
+// link, with hundreds of links in flight), but relaxed atomics and an explicit wait for this wavefront's outstanding stores.
 __device__ __forceinline__ void lock_row_w(uint32_t *locks, uint32_t node, int lane) {
     if (lane == 0) {
-        while (__hip_atomic_exchange(&locks[node], 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) __builtin_amdgcn_s_sleep(2);
+        while (__hip_atomic_exchange(&locks[node], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) __builtin_amdgcn_s_sleep(2);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_wave_barrier(); // the row is read after lane 0 has left the loop (one wavefront: program order)
+    asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ void unlock_row_w(uint32_t *locks, uint32_t node, int lane) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every row store of this wavefront has been performed
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    if (lane == 0) __hip_atomic_store(&locks[node], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(&locks[node], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // canonical row (ascending id, sentinel padded) of ids_lds[0..ns), written with agent-scope stores by one wavefront
 __device__ __forceinline__ void store_canonical_w(uint32_t *row, uint32_t stride, const uint32_t *ids_lds, uint32_t ns, int lane) {
@@ -412,12 +381,12 @@ __device__ __forceinline__ void remove_edge_w(const BuildArgs &a, uint32_t layer
     const unsigned long long km = __ballot(keep);
     const uint32_t pos = (uint32_t)__builtin_popcountll(km & ((1ull << lane) - 1ull));
     const uint32_t nk = (uint32_t)__builtin_popcountll(km);
-    if (keep) st_row(row + pos, v);   // pos <= lane: a lane never overwrites an id another lane still has to move (v is in registers)
+    if (keep) st_row(row + pos, v);   // every lane holds its id in a register: the order of the stores does not matter
     if ((uint32_t)lane >= nk && (uint32_t)lane < stride) st_row(row + lane, kSentinel);
     unlock_row_w(a.locks, owner, lane);
 }
 
-template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(256) void build_link_wg_kernel(BuildArgs a) {
+template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void build_link_wg_kernel(BuildArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const DevIndex &ix = a.ix;
     const uint32_t q = blockIdx.x >> 5, s = blockIdx.x & 31u, layer = blockIdx.y;
@@ -436,6 +405,13 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(256) void bu
 
     // ---- add_bidirectional_link(from = me, to) (mutation.rs:1498-1583): append under the row owner's lock ----
     if (wave == 0) {
+#ifdef HVX_TUNING
+        if (a.dbg && lane == 0) { // contention probe: how often the target's lock is found taken
+            uint32_t spins = 0;
+            while (__hip_atomic_load(&a.locks[to], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u && spins < 1000000u) { ++spins; __builtin_amdgcn_s_sleep(2); }
+            atomicAdd(&a.dbg[0], spins);
+        }
+#endif
         lock_row_w(a.locks, to, lane);
         uint32_t v = (uint32_t)lane < stride ? ld_row(row + lane) : kSentinel;
         uint32_t deg = (uint32_t)__builtin_popcountll(__ballot(v != kSentinel));
@@ -464,39 +440,115 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(256) void bu
         if (wave == 0) {
             if (L.sh[2] == 0u && L.sh[3] == 0u) store_canonical_w(row, stride, L.cand, nc, lane);
             unlock_row_w(a.locks, to, lane);
+            if (lane == 0) HVX_DBG_ADD(a, 3, 1);
         }
         return;
     }
 
-    // ---- the nc candidate rows and the owner's row: HBM -> LDS, every load independent ----
-    const uint32_t ld4 = ix.ld >> 2, total4 = (nc + 1u) * ld4;
-#pragma unroll 8
-    for (uint32_t idx = (uint32_t)tid; idx < total4; idx += 256u) {
-        const uint32_t r = idx / ld4, c = idx - r * ld4;
-        const uint32_t node = r < nc ? L.cand[r] : to;
-        const float4 x = reinterpret_cast<const float4 *>(ix.vec + (size_t)node * ix.ld)[c];
-        reinterpret_cast<float4 *>(L.rows + (size_t)r * a.ldp)[c] = x;
+    // ---- all pairwise distances among the nc candidate rows and the owner's row (index nc) ----
+    const uint32_t nrows = nc + 1u, npairs = nrows * nc / 2u;
+    if ((uint32_t)tid >= 1u && (uint32_t)tid < nrows) { // pair p = b (b - 1) / 2 + a  <->  rows a < b
+        const uint32_t b = (uint32_t)tid, base = b * (b - 1u) / 2u;
+        for (uint32_t aa = 0; aa < b; ++aa) { L.pa[base + aa] = (unsigned char)aa; L.pb[base + aa] = (unsigned char)b; }
     }
+    const uint32_t nk = ix.dim_main >> 5;                 // 32-float chunks of a row (dim == dim_main == ld: the host checked)
+    const uint32_t ck = a.link_ck;                        // chunks per column block (even)
+    const uint32_t nblocks = (nk + ck - 1u) / ck;
+    const uint32_t w4 = ck * 8u;                          // float4 per row and block
+    constexpr int kPre = 9;                               // float4 a thread carries for the next block: 34 rows x 64 float4 / 256 threads
+    float4 pre[kPre];
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto prefetch = [&](uint32_t blk) __attribute__((always_inline)) {
+        const uint32_t c0 = blk * w4, cw = (nk - blk * ck < ck ? nk - blk * ck : ck) * 8u;
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+            const uint32_t e = (uint32_t)tid + 256u * (uint32_t)u;
+            const uint32_t r = e / w4, c = e - r * w4;
+            if (r < nrows && c < cw) {
+                const uint32_t node = r < nc ? L.cand[r] : to;
+                pre[u] = reinterpret_cast<const float4 *>(ix.vec + (size_t)node * ix.ld)[c0 + c];
+            }
+        }
+    };
+    auto commit = [&](uint32_t blk) __attribute__((always_inline)) {
+        const uint32_t cw = (nk - blk * ck < ck ? nk - blk * ck : ck) * 8u;
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+            const uint32_t e = (uint32_t)tid + 256u * (uint32_t)u;
+            const uint32_t r = e / w4, c = e - r * w4;
+            if (r < nrows && c < cw) reinterpret_cast<float4 *>(L.rows + (size_t)r * a.ldp)[c] = pre[u];
+        }
+    };
+    float4 acc[kLinkTasks];
+#pragma unroll
+    for (int t = 0; t < kLinkTasks; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int slot4 = chunk_slot(j);
+    prefetch(0);
     if (tid < 64) L.P[tid] = 0ull;
+    for (uint32_t blk = 0; blk < nblocks; ++blk) {
+        commit(blk);
+        __syncthreads(); // block blk is in LDS (first round: and the pair table)
+        if (blk + 1u < nblocks) prefetch(blk + 1u); // in flight underneath the arithmetic
+        const uint32_t ckb = nk - blk * ck < ck ? nk - blk * ck : ck;
+#pragma unroll
+        for (int t = 0; t < kLinkTasks; ++t) {
+            const uint32_t p = ((uint32_t)wave + 4u * (uint32_t)t) * 8u + (uint32_t)grp;
+            if (((uint32_t)wave + 4u * (uint32_t)t) * 8u >= npairs) continue; // uniform in the wavefront
+            const uint32_t pp = p < npairs ? p : npairs - 1u;
+            const float4 *qp = reinterpret_cast<const float4 *>(L.rows + (size_t)L.pa[pp] * a.ldp) + slot4;
+            const float4 *rp = reinterpret_cast<const float4 *>(L.rows + (size_t)L.pb[pp] * a.ldp) + slot4;
+            float4 ac = acc[t];
+#pragma unroll 4
+            for (uint32_t k = 0; k < ckb; ++k) {
+                const float4 x = rp[k * 8u];
+                const float4 qq = qp[k * 8u];
+                if (METRIC == kL2) {
+                    const float d0 = qq.x - x.x, d1 = qq.y - x.y, d2 = qq.z - x.z, d3 = qq.w - x.w;
+                    if (FUSED) {
+                        ac.x = __builtin_fmaf(d0, d0, ac.x); ac.y = __builtin_fmaf(d1, d1, ac.y);
+                        ac.z = __builtin_fmaf(d2, d2, ac.z); ac.w = __builtin_fmaf(d3, d3, ac.w);
+                    } else {
+                        ac.x = d0 * d0 + ac.x; ac.y = d1 * d1 + ac.y;
+                        ac.z = d2 * d2 + ac.z; ac.w = d3 * d3 + ac.w;
+                    }
+                } else {
+                    if (FUSED) {
+                        ac.x = __builtin_fmaf(qq.x, x.x, ac.x); ac.y = __builtin_fmaf(qq.y, x.y, ac.y);
+                        ac.z = __builtin_fmaf(qq.z, x.z, ac.z); ac.w = __builtin_fmaf(qq.w, x.w, ac.w);
+                    } else {
+                        ac.x = qq.x * x.x + ac.x; ac.y = qq.y * x.y + ac.y;
+                        ac.z = qq.z * x.z + ac.z; ac.w = qq.w * x.w + ac.w;
+                    }
+                }
+            }
+            acc[t] = ac;
+        }
+        __syncthreads(); // everybody is done with block blk before the next one overwrites it
+    }
+#pragma unroll
+    for (int t = 0; t < kLinkTasks; ++t) {
+        const uint32_t p = ((uint32_t)wave + 4u * (uint32_t)t) * 8u + (uint32_t)grp;
+        if (((uint32_t)wave + 4u * (uint32_t)t) * 8u >= npairs) continue;
+        float r = avx_tree_reduce(acc[t]); // every lane of the group takes part
+        if (p < npairs) {
+            const uint32_t ra = L.pa[p], rb = L.pb[p];
+            if (METRIC == kCosine) {
+                const uint32_t na = ra < nc ? L.cand[ra] : to, nb = rb < nc ? L.cand[rb] : to;
+                r = cosine_finish(r, ix.hdr[na], ix.hdr[nb], ix.vec + (size_t)na * ix.ld, ix.vec + (size_t)nb * ix.ld, ix.dim);
+            }
+            if (j == 0) { L.D[ra * nrows + rb] = r; L.D[rb * nrows + ra] = r; }
+        }
+    }
     __syncthreads();
 
     // ---- rank the row's neighbours by distance to its owner (Candidate order: score, then id; model.rs:55-61) ----
-    const float *orow = L.rows + (size_t)nc * a.ldp;
-    const float thdr = METRIC == kCosine ? ix.hdr[to] : 0.f;
-    for (uint32_t p0 = (uint32_t)wave * 8u; p0 < nc; p0 += 32u) {
-        const uint32_t g = p0 + (uint32_t)grp;
-        const uint32_t r = g < nc ? g : nc - 1u;
-        const float rh = METRIC == kCosine ? ix.hdr[L.cand[r]] : 0.f;
-        const float d = pair_distance_lds<METRIC, FUSED>(ix, orow, thdr, L.rows + (size_t)r * a.ldp, rh, j);
-        if (g < nc && j == 0) L.dist[g] = d;
-    }
-    __syncthreads();
     if ((uint32_t)tid < nc) {
-        const float dmine = L.dist[tid];
+        const float dmine = L.D[nc * nrows + (uint32_t)tid];
         const uint32_t v = L.cand[tid];
         uint32_t rank = 0;
         for (uint32_t t = 0; t < nc; ++t) {
-            const float dt = L.dist[t];
+            const float dt = L.D[nc * nrows + t];
             const uint32_t it = L.cand[t];
             rank += (dt < dmine || (dt == dmine && it < v)) ? 1u : 0u;
         }
@@ -505,30 +557,17 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(256) void bu
         L.srow[rank] = (uint32_t)tid;
     }
     __syncthreads();
-
-    // ---- P[i] bit jj = dist(c_i, c_jj) < dist(c_i, owner), jj < i (sorted order): the test of mod.rs:832, every pair ----
-    uint32_t task = 0;
-    for (uint32_t i = 1; i < nc; ++i) {
-        const uint32_t chunks = (i + 7u) >> 3;
-        for (uint32_t c = 0; c < chunks; ++c, ++task) {
-            if ((task & 3u) != (uint32_t)wave) continue;
-            const uint32_t jj = c * 8u + (uint32_t)grp;
-            const uint32_t jr = jj < i ? jj : 0u;
-            const float ih = METRIC == kCosine ? ix.hdr[L.cid[i]] : 0.f;
-            const float jh = METRIC == kCosine ? ix.hdr[L.cid[jr]] : 0.f;
-            const float pd = pair_distance_lds<METRIC, FUSED>(ix, L.rows + (size_t)L.srow[i] * a.ldp, ih, L.rows + (size_t)L.srow[jr] * a.ldp, jh, j);
-            const unsigned long long hm = __ballot(jj < i && j == 0 && pd < L.csc[i]); // strict < rejects
-            if (lane == 0 && hm) {
-                unsigned long long bits = 0ull;
-#pragma unroll
-                for (int g = 0; g < 8; ++g)
-                    if ((hm >> (8 * g)) & 1ull) bits |= 1ull << (c * 8u + (uint32_t)g);
-                atomicOr(&L.P[i], bits);
-            }
-        }
-    }
-    __syncthreads();
     if (wave != 0) return;
+    // ---- P[i] bit jj = dist(c_i, c_jj) < dist(c_i, owner), jj < i in sorted order (strict <: mod.rs:832) ----
+    if ((uint32_t)lane < nc) {
+        const uint32_t ri = L.srow[lane];
+        const float si = L.csc[lane];
+        unsigned long long bits = 0ull;
+        for (uint32_t jj = 0; jj < (uint32_t)lane; ++jj)
+            if (L.D[ri * nrows + L.srow[jj]] < si) bits |= 1ull << jj;
+        L.P[lane] = bits;
+    }
+    wave_sync();
 
     // ---- select_diverse + backfill over the masks (mod.rs:809-856); all lanes walk the same chain ----
     unsigned long long kept = 0ull;
@@ -553,7 +592,9 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(256) void bu
         dm &= dm - 1ull;
         const uint32_t x = __builtin_amdgcn_readlane(dropped_id, src);
         remove_edge_w(a, layer, x, to, lane);
+        if (lane == 0) HVX_DBG_ADD(a, 2, 1);
     }
+    if (lane == 0) HVX_DBG_ADD(a, 1, 1);
 }
 
 template <typename K> static hipError_t launch_build(K kern, dim3 grid, const BuildArgs &a, hipStream_t s) {
@@ -653,18 +694,27 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
         (rc = salloc((void **)&d_selcnt, (size_t)layers_max * bmax * 4)) || (rc = salloc((void **)&d_status, (size_t)bmax * 4)) ||
         (rc = salloc((void **)&d_err, 4)))
         return sbail(rc);
+    uint32_t *d_dbg = nullptr;
+    if (tuning_env("HVX_BUILD_DEBUG")) {
+        if ((rc = salloc((void **)&d_dbg, 32))) return sbail(rc);
+        if (hipMemsetAsync(d_dbg, 0, 32, s) != hipSuccess) return sbail(fail(HVX_ERR_DEVICE, "memset"));
+    }
     hipLaunchKernelGGL(iota_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, d_iota, (uint32_t)n);
     if (hipMemsetAsync(d_locks, 0, n * 4, s) != hipSuccess || hipMemsetAsync(d_err, 0, 4, s) != hipSuccess) return sbail(fail(HVX_ERR_DEVICE, "memset"));
 
     DevIndex &d = ix->dev;
     uint32_t *l0w = const_cast<uint32_t *>(d.l0), *upw = const_cast<uint32_t *>(d.up);
     const bool l2 = d.metric == kL2;
-    // build_link_wg_kernel keeps Mmax + 1 candidate rows and the owner's in LDS, row stride = 128 B mod 256 B (the eight row groups of
-    // a wavefront read eight consecutive rows: conflict-free ds_read_b128); it serves the build when that fits the 160 KB of a CU
+    // build_link_wg_kernel: column blocks of <= 8 chunks (256 floats) of Mmax + 1 candidate rows and the owner's in LDS, row stride
+    // = 128 B mod 256 B (the eight row groups of a wavefront read different rows: conflict-free ds_read_b128 for neighbouring rows)
     const uint32_t ncmax = std::max(m0, m) + 1u;
-    const uint32_t ldp = ((d.ld + 31u) / 64u) * 64u + 32u;
+    const uint32_t nk_rows = d.dim_main >> 5;
+    const uint32_t link_ck = std::min<uint32_t>(8u, (nk_rows + 1u) & ~1u);
+    const uint32_t ldp = link_ck * 32u + 32u;
     const size_t link_lds = link_lds_bytes(ldp, ncmax);
-    const bool link_wg = link_lds <= 160u * 1024u && params->link_mode != 1u;
+    // serves rows without a scalar tail (dim % 32 == 0, no padding) and <= 33 candidates (561 pairs = 4 wavefronts x 18 steps x 8)
+    const bool link_wg = params->link_mode != 1u && ncmax <= 33u && nk_rows > 0 && d.dim_main == d.dim && d.ld == d.dim &&
+                         (size_t)(ncmax + 1u) * link_ck * 8u <= 9u * 256u;
     // first node: the entry point with empty rows on its layers (mutation.rs:706-739)
     d.has_entry = 1;
     d.entry = 0;
@@ -695,7 +745,7 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
         a.out_status = d_status;
         a.tie_flags = ix->d_tie;
         a.build_nodes = d_iota + done;
-        a.occupancy = 1;
+        a.occupancy = (bsz > 1024u && params->link_mode != 1u) ? 2 : 1; // more nodes than SIMDs: two searches per SIMD instead of two rounds
         if (launch_hnsw_wave(a, bsz, s) != hipSuccess) return sbail(fail(HVX_ERR_DEVICE, "build search launch failed: %s", hipGetErrorString(hipGetLastError())));
         BuildArgs ba{};
         ba.ix = d;
@@ -713,12 +763,14 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
         ba.m = m;
         ba.m0 = m0;
         ba.err = d_err;
+        ba.dbg = d_dbg;
         hipError_t e = l2 ? launch_build(build_select_kernel<kL2, true>, dim3(bsz, layers), ba, s)
                           : launch_build(build_select_kernel<kCosine, true>, dim3(bsz, layers), ba, s);
         if (e == hipSuccess) {
             if (bsz > 1u && link_wg) { // batched mode: one workgroup per link, prunes evaluated from LDS
                 ba.ldp = ldp;
                 ba.ncmax = ncmax;
+                ba.link_ck = link_ck;
                 e = l2 ? launch_link_wg(build_link_wg_kernel<kL2, true>, ba, layers, link_lds, s)
                        : launch_link_wg(build_link_wg_kernel<kCosine, true>, ba, layers, link_lds, s);
             } else { // one node (the reference's order exactly), or rows too long for the LDS: one wavefront per node
@@ -739,6 +791,11 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
     uint32_t err = 0;
     if (hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
         return sbail(fail(HVX_ERR_DEVICE, "build did not complete: %s", hipGetErrorString(hipGetLastError())));
+    if (d_dbg) {
+        uint32_t h[8] = {0};
+        (void)hipMemcpy(h, d_dbg, 32, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[hvx build] link step: lock spins %u, prunes %u, reverse-edge removals %u, plain appends %u\n", h[0], h[1], h[2], h[3]);
+    }
     release();
     if (err) return bail(fail(HVX_ERR_INVARIANT, "a neighbour row overflowed its stride during the build"));
     ix->desc.has_entry = 1;

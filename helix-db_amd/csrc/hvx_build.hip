@@ -7,7 +7,7 @@
 //               (mutation.rs:904-1005) on every layer from there to 0; per layer the first 2*Mmax entries of W
 //   2. select   build_select_kernel    -- select_neighbors_heuristic (mutation.rs:1072-1097) = select_diverse
 //               (mod.rs:809-856) over those hydrated candidates, backfill; writes the new node's canonical row
-//   3. link     build_link_kernel      -- add_bidirectional_link (mutation.rs:1498-1583) for every selected neighbour IN
+//   3. link     build_link_kernel / build_link_wg_kernel -- add_bidirectional_link (mutation.rs:1498-1583) for every selected neighbour IN
 //               SELECTION ORDER: append, and when the row exceeds Mmax rank its neighbours by distance to the row's owner,
 //               select_diverse + backfill, canonical row (neighbor_set.rs:1-9), remove the reverse edge of every dropped
 //               neighbour (mutation.rs:1890-1908).  One wavefront per new node; a row is changed under its owner's lock.
@@ -18,8 +18,11 @@
 // batch (it becomes the entry point, mutation.rs:769-772).
 //
 // Every distance is the reference-order f32 distance of hvx_device.h (group_distance), so `dist(c,s) < dist(c,q)` decisions
-// are the CPU path's.  Served shapes: those of the one-wavefront-per-query kernel (f32 rows, L2 / cosine, AVX+FMA tree,
-// dim in {128,...,1536}), m0 <= 32, ef_construction <= 352.
+// are the CPU path's.  Served shapes: f32 rows of any dimension, L2 / cosine / Manhattan, every summation tree (the unrolled
+// search builds for L2 / cosine + AVX+FMA + dim in {128,...,1536} + ef_construction <= 352, the GENERIC build of the same kernel
+// otherwise; select / link kernels per metric and tree), m0 <= 32, ef_construction <= 800.
+// Round 3: the batched link step runs one WORKGROUP per link with the prune evaluated from LDS (build_link_wg_kernel below) and
+// the search side two wavefronts per SIMD for batches > 1 024 nodes: 1M x 768 in 4.1 s (round 2: 10.0 s).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -640,7 +643,7 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
     const uint32_t efc = params->ef_construction ? params->ef_construction : 200u;
     if (desc->dtype != HVX_F32) return fail(HVX_ERR_UNSUPPORTED, "the device build reads f32 rows (import the built graph with a reduced-precision dtype afterwards)");
     if (m0 > 32u || m > 32u) return fail(HVX_ERR_UNSUPPORTED, "device build serves m0 <= 32");
-    if (std::max(efc, m0) + 32u > 384u) return fail(HVX_ERR_UNSUPPORTED, "device build serves ef_construction <= 352");
+    if (std::max(efc, m0) + 32u > 832u) return fail(HVX_ERR_UNSUPPORTED, "device build serves ef_construction <= 800");
     const uint32_t ef0 = std::max(efc, m0), efu = std::max(efc, 2u * m);
 
     // ---- the image: rows + EMPTY graph with rows sized for m0 / m ----
@@ -669,9 +672,10 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
     HnswArgs probe{};
     probe.ix = ix->dev;
     probe.ef = ef0;
-    if (n && !hnsw_wave_supported(probe))
-        return bail(fail(HVX_ERR_UNSUPPORTED, "device build serves the one-wavefront-per-query kernel's shapes: f32 rows, L2 / cosine, "
-                         "AVX+FMA summation tree, dim in {128,256,512,768,1024,1536}"));
+    // the unrolled builds serve L2 / cosine, the AVX+FMA tree, dim in {128,...,1536}, ef_construction <= 352; everything else (any
+    // dimension, Manhattan, the scalar / AVX summation trees, ef_construction <= 800) takes the GENERIC build of the same kernel
+    if (n && !hnsw_wave_supported(probe) && (ix->dev.s0 > 64u || ix->dev.su > 64u))
+        return bail(fail(HVX_ERR_UNSUPPORTED, "device build serves neighbour rows of <= 64 ids"));
     if (n == 0) { *out = ix; return HVX_OK; }
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t s = ix->stream; // the handle is private to this call until it is returned: no lock
@@ -704,7 +708,7 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
 
     DevIndex &d = ix->dev;
     uint32_t *l0w = const_cast<uint32_t *>(d.l0), *upw = const_cast<uint32_t *>(d.up);
-    const bool l2 = d.metric == kL2;
+    const bool fused = d.fkernel == kKernelAvxFma;
     // build_link_wg_kernel: column blocks of <= 8 chunks (256 floats) of Mmax + 1 candidate rows and the owner's in LDS, row stride
     // = 128 B mod 256 B (the eight row groups of a wavefront read different rows: conflict-free ds_read_b128 for neighbouring rows)
     const uint32_t ncmax = std::max(m0, m) + 1u;
@@ -713,8 +717,15 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
     const uint32_t ldp = link_ck * 32u + 32u;
     const size_t link_lds = link_lds_bytes(ldp, ncmax);
     // serves rows without a scalar tail (dim % 32 == 0, no padding) and <= 33 candidates (561 pairs = 4 wavefronts x 18 steps x 8)
-    const bool link_wg = params->link_mode != 1u && ncmax <= 33u && nk_rows > 0 && d.dim_main == d.dim && d.ld == d.dim &&
+    const bool link_wg = params->link_mode != 1u && ncmax <= 33u && nk_rows > 0 && d.dim_main == d.dim && d.ld == d.dim && d.metric != kL1 &&
                          (size_t)(ncmax + 1u) * link_ck * 8u <= 9u * 256u;
+// one instantiation per (metric, summation tree): the reference picks both per index (spaces/*.rs, distance/*.rs)
+#define HVX_BUILD_DISPATCH(CALL)                                                                          \
+    (d.metric == kL2 ? (fused ? CALL(kL2, true) : CALL(kL2, false))                                       \
+     : d.metric == kCosine ? (fused ? CALL(kCosine, true) : CALL(kCosine, false))                         \
+                           : (fused ? CALL(kL1, true) : CALL(kL1, false)))
+#define HVX_BUILD_DISPATCH_L2COS(CALL)                                                                    \
+    (d.metric == kL2 ? (fused ? CALL(kL2, true) : CALL(kL2, false)) : (fused ? CALL(kCosine, true) : CALL(kCosine, false)))
     // first node: the entry point with empty rows on its layers (mutation.rs:706-739)
     d.has_entry = 1;
     d.entry = 0;
@@ -764,17 +775,18 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
         ba.m0 = m0;
         ba.err = d_err;
         ba.dbg = d_dbg;
-        hipError_t e = l2 ? launch_build(build_select_kernel<kL2, true>, dim3(bsz, layers), ba, s)
-                          : launch_build(build_select_kernel<kCosine, true>, dim3(bsz, layers), ba, s);
+#define HVX_SELECT(M, F) launch_build(build_select_kernel<M, F>, dim3(bsz, layers), ba, s)
+#define HVX_LINK(M, F) launch_build(build_link_kernel<M, F>, dim3(bsz), ba, s)
+#define HVX_LINK_WG(M, F) launch_link_wg(build_link_wg_kernel<M, F>, ba, layers, link_lds, s)
+        hipError_t e = HVX_BUILD_DISPATCH(HVX_SELECT);
         if (e == hipSuccess) {
             if (bsz > 1u && link_wg) { // batched mode: one workgroup per link, prunes evaluated from LDS
                 ba.ldp = ldp;
                 ba.ncmax = ncmax;
                 ba.link_ck = link_ck;
-                e = l2 ? launch_link_wg(build_link_wg_kernel<kL2, true>, ba, layers, link_lds, s)
-                       : launch_link_wg(build_link_wg_kernel<kCosine, true>, ba, layers, link_lds, s);
-            } else { // one node (the reference's order exactly), or rows too long for the LDS: one wavefront per node
-                e = l2 ? launch_build(build_link_kernel<kL2, true>, dim3(bsz), ba, s) : launch_build(build_link_kernel<kCosine, true>, dim3(bsz), ba, s);
+                e = HVX_BUILD_DISPATCH_L2COS(HVX_LINK_WG);
+            } else { // one node (the reference's order exactly), or rows the workgroup kernel does not serve: one wavefront per node
+                e = HVX_BUILD_DISPATCH(HVX_LINK);
             }
         }
         if (e != hipSuccess) return sbail(fail(HVX_ERR_DEVICE, "build launch failed: %s", hipGetErrorString(e)));

@@ -309,6 +309,7 @@ hipError_t launch_hnsw_wave_occ2(const HnswArgs &a, uint32_t b, const WaveGeom &
 hipError_t launch_hnsw_wave_occ2_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_build(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_build_occ2(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_build_gen(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_gen_cos(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_gen_l2(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_gen_l1(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
@@ -359,7 +360,13 @@ static hipError_t launch_hnsw_wave_once(const HnswArgs &a, uint32_t b, hipStream
     if (a.log2cap >= 7 && a.log2cap <= 15) g.log2cap = a.log2cap; // HVX_OPT_WAVE_LOG2CAP: a tiny table exercises the spill path
     // 160 KiB / 4: exactly four resident wavefronts per CU, one per SIMD, each with the SIMD's whole register file.
     // occ = 2 (a.occupancy): eight per CU, two per SIMD -- the table shrinks until query + frontier + table fit 20 KiB
-    g.occ = (a.occupancy == 2 && !a.adaptive && !a.prof) ? 2u : 1u;
+    bool build_generic = false; // build searches outside the unrolled shapes: the GENERIC build (one query per SIMD)
+    if (a.build_nodes) {
+        HnswArgs probe = a; // the beam of a build search holds max(ef_construction, 2 M) entries on every layer
+        probe.ef = a.ef > a.build_ef_upper ? a.ef : a.build_ef_upper;
+        build_generic = !hnsw_wave_supported(probe);
+    }
+    g.occ = (a.occupancy == 2 && !a.adaptive && !a.prof && !build_generic) ? 2u : 1u;
     const size_t fixed = 512 + (size_t)a.ix.ld * 4 + (a.adaptive ? kRngWords * 4 : 0);
     if (g.occ == 2) {
         while (g.log2cap > 9 && ((size_t)4 << g.log2cap) + fixed > 20 * 1024) --g.log2cap;
@@ -368,7 +375,10 @@ static hipError_t launch_hnsw_wave_once(const HnswArgs &a, uint32_t b, hipStream
     const size_t budget = g.occ == 2 ? 20 * 1024 : 40 * 1024;
     const size_t need = ((size_t)4 << g.log2cap) + fixed;
     g.lds = need < budget ? budget : need;
-    if (a.build_nodes) return g.occ == 2 ? launch_hnsw_wave_build_occ2(a, b, g, s) : launch_hnsw_wave_build(a, b, g, s);
+    if (a.build_nodes) {
+        if (build_generic) return launch_hnsw_wave_build_gen(a, b, g, s);
+        return g.occ == 2 ? launch_hnsw_wave_build_occ2(a, b, g, s) : launch_hnsw_wave_build(a, b, g, s);
+    }
     if (g.occ == 2) return a.ix.dtype == HVX_BF16 ? launch_hnsw_wave_occ2_bf16(a, b, g, s) : launch_hnsw_wave_occ2(a, b, g, s);
     if (generic) {
         switch (a.ix.metric) {

@@ -1021,6 +1021,7 @@ hipError_t launch_hnsw_wave_occ2(const HnswArgs &a, uint32_t b, const WaveGeom &
 hipError_t launch_hnsw_wave_occ2_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 // search side of the device HNSW build (BUILD instantiations), hvx_hnsw_wave_build.hip
 hipError_t launch_hnsw_wave_build(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_build_gen(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s); // GENERIC build, hvx_hnsw_wave_build_gen.hip
 hipError_t launch_hnsw_wave_build_occ2(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s); // two per SIMD, hvx_hnsw_wave_build_occ2.hip
 // GENERIC builds (NK = 0) of the non-strict arms: any dim / metric / summation tree, ef <= 800; hvx_hnsw_wave_gen_*.hip
 hipError_t launch_hnsw_wave_gen_cos(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);

@@ -533,8 +533,9 @@ int hvx_hydrator_finish(const hvx_hydrator *, const hvx_index_desc *tmpl, hvx_in
  * insertion row for row; otherwise a batch holds up to min(max_batch, inserted / batch_divisor) nodes that do not see each
  * other (a node above the current top layer is always inserted alone and becomes the entry point).  The result is an
  * ordinary searchable hvx_index; hvx_index_export_graph hands the rows back for the host to persist (values/vectors.rs).
- * Served shapes: f32 rows, cosine / Euclidean, AVX+FMA summation tree, dim in {128,256,512,768,1024,1536}, m0 <= 32,
- * ef_construction <= 352; desc->max_batch bounds the batch size.
+ * Served shapes: f32 rows of any dimension, cosine / Euclidean / Manhattan, every summation tree of the reference's float kernels
+ * (the unrolled kernels for cosine / Euclidean + AVX+FMA + dim in {128,256,512,768,1024,1536} + ef_construction <= 352, the GENERIC
+ * build otherwise), m0 <= 32, ef_construction <= 800; desc->max_batch bounds the batch size.
  */
 typedef struct hvx_build_params {
     uint32_t ef_construction; /* 0 => 200 (mod.rs:702-708) */

@@ -111,6 +111,9 @@ class ShardedSearcher:
         self.m_ids = torch.zeros(b, k, dtype=torch.int64, device=device)
         self.m_scores = torch.zeros(b, k, dtype=torch.float32, device=device)
         self.m_counts = torch.zeros(b, dtype=torch.int32, device=device)
+        # the search wrote the payload on the INDEX's stream and the merge kernel runs there: the exchange (torch collectives, staging
+        # copies) is enqueued on the same stream, so a step needs no host synchronisation and no cross-stream event
+        self.stream = torch.cuda.ExternalStream(index.stream(), device=device) if torch.device(device).type == "cuda" else None
 
     def outputs(self):
         """Output buffers for this rank's search: views into the exchange payload (no copy before the all-gather)."""
@@ -118,6 +121,10 @@ class ShardedSearcher:
 
     def merge(self, ids=None, scores=None, counts=None):
         """One all-gather of this rank's lists, then the per-query merge of the `world` lists on the device."""
-        packed = self.ex.gather(ids, scores, counts)
+        if self.stream is None:
+            packed = self.ex.gather(ids, scores, counts)
+        else:
+            with torch.cuda.stream(self.stream):
+                packed = self.ex.gather(ids, scores, counts)
         self.ix.merge_topk_packed_device(self.world, self.b, self.k, packed, self.m_ids, self.m_scores, self.m_counts)
         return self.m_ids, self.m_scores, self.m_counts

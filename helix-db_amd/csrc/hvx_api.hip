@@ -104,6 +104,8 @@ static void free_index(hvx_index *ix) {
     if (ix->ev1) (void)hipEventDestroy(ix->ev1);
     for (hipEvent_t e : ix->ring) (void)hipEventDestroy(e);
     if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
+    if (ix->h_pin) (void)hipHostFree(ix->h_pin);
+    if (ix->h_flags) (void)hipHostFree(ix->h_flags);
     delete ix;
 }
 
@@ -511,7 +513,60 @@ int hvx_index::stage(uint32_t b, uint32_t k) {
         if ((rc = regrow((void **)&s_status, (size_t)b * 4))) return rc;
         cap_b = b;
     }
+    return pin(((need_q + 63u) & ~(size_t)63u) + need_o * 12 + (size_t)b * 8); // the pinned mirror holds one batch: queries, then the four outputs
+}
+
+static size_t pin_off_ids(const hvx_index *ix, uint32_t cb) { return (((size_t)cb * ix->dev.dim * 4) + 63u) & ~(size_t)63u; }
+int hvx_index::pin(size_t bytes) {
+    if (bytes <= cap_pin) return HVX_OK;
+    if (h_pin) {
+        HIP_TRY(hipStreamSynchronize(stream)); // nothing enqueued still reads or writes the old mirror
+        (void)hipHostFree(h_pin);
+        h_pin = nullptr;
+        cap_pin = 0;
+    }
+    const size_t want = std::max<size_t>(bytes + bytes / 2, 1u << 16);
+    if (hipHostMalloc((void **)&h_pin, want, hipHostMallocDefault) != hipSuccess) return fail(HVX_ERR_DEVICE, "hipHostMalloc(%zu) staging mirror", want);
+    cap_pin = want;
     return HVX_OK;
+}
+int hvx_index::pin_flags(size_t words) {
+    if (words <= cap_flags) return HVX_OK;
+    if (h_flags) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        (void)hipHostFree(h_flags);
+        h_flags = nullptr;
+        cap_flags = 0;
+    }
+    const size_t want = std::max<size_t>(words + words / 2, 4096);
+    if (hipHostMalloc((void **)&h_flags, want * 4, hipHostMallocDefault) != hipSuccess) return fail(HVX_ERR_DEVICE, "hipHostMalloc(%zu) read-back mirror", want * 4);
+    cap_flags = want;
+    return HVX_OK;
+}
+int hvx_index::stage_in(const float *queries, uint32_t cb) {
+    const size_t qbytes = (size_t)cb * dev.dim * 4;
+    int rc = pin(qbytes);
+    if (rc) return rc;
+    memcpy(h_pin, queries, qbytes);
+    HIP_TRY(hipMemcpyAsync(s_queries, h_pin, qbytes, hipMemcpyHostToDevice, stream));
+    return HVX_OK;
+}
+int hvx_index::stage_out(uint32_t cb, uint32_t k) {
+    const size_t o0 = pin_off_ids(this, cb), n = (size_t)cb * k;
+    int rc = pin(o0 + n * 12 + (size_t)cb * 8);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h_pin + o0, s_ids, n * 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_pin + o0 + n * 8, s_scores, n * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_pin + o0 + n * 12, s_counts, (size_t)cb * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_pin + o0 + n * 12 + (size_t)cb * 4, s_status, (size_t)cb * 4, hipMemcpyDeviceToHost, stream));
+    return HVX_OK;
+}
+void hvx_index::deliver(uint32_t cb, uint32_t k, uint64_t *out_ids, float *out_scores, uint32_t *out_counts, uint32_t *out_status) const {
+    const size_t o0 = pin_off_ids(this, cb), n = (size_t)cb * k;
+    memcpy(out_ids, h_pin + o0, n * 8);
+    memcpy(out_scores, h_pin + o0 + n * 8, n * 4);
+    memcpy(out_counts, h_pin + o0 + n * 12, (size_t)cb * 4);
+    memcpy(out_status, h_pin + o0 + n * 12 + (size_t)cb * 4, (size_t)cb * 4);
 }
 
 int hvx::check_k_ef(uint32_t k, uint32_t ef) {
@@ -726,18 +781,16 @@ extern "C" int hvx_search_batch(const hvx_index *cix, const float *queries, uint
     for (uint32_t c0 = 0; c0 < b; c0 += mb) {
         const uint32_t cb = std::min(mb, b - c0);
         if ((rc = ix->stage(cb, k))) return rc;
-        HIP_TRY(hipMemcpyAsync(ix->s_queries, queries + (size_t)c0 * ix->dev.dim, (size_t)cb * ix->dev.dim * 4, hipMemcpyHostToDevice, ix->stream));
+        if ((rc = ix->stage_in(queries + (size_t)c0 * ix->dev.dim, cb))) return rc;
         rc = enqueue_search(ix, ix->s_queries, cb, k, ef, ix->s_ids, ix->s_scores, ix->s_counts, ix->s_status, nullptr, stats != nullptr);
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(out_ids + (size_t)c0 * k, ix->s_ids, (size_t)cb * k * 8, hipMemcpyDeviceToHost, ix->stream));
-        HIP_TRY(hipMemcpyAsync(out_scores + (size_t)c0 * k, ix->s_scores, (size_t)cb * k * 4, hipMemcpyDeviceToHost, ix->stream));
-        HIP_TRY(hipMemcpyAsync(out_counts + c0, ix->s_counts, (size_t)cb * 4, hipMemcpyDeviceToHost, ix->stream));
-        HIP_TRY(hipMemcpyAsync(status.data() + c0, ix->s_status, (size_t)cb * 4, hipMemcpyDeviceToHost, ix->stream));
+        if ((rc = ix->stage_out(cb, k))) return rc;
         if (stats) {
             if ((rc = collect_stats(ix, cb, nullptr, stats))) return rc;
         } else {
             HIP_TRY(hipStreamSynchronize(ix->stream));
         }
+        ix->deliver(cb, k, out_ids + (size_t)c0 * k, out_scores + (size_t)c0 * k, out_counts + c0, status.data() + c0);
     }
     if (out_status) {
         memcpy(out_status, status.data(), (size_t)b * 4);
@@ -908,18 +961,16 @@ int hvx::flat_scan_host(hvx_index *ix, const float *queries, uint32_t b, uint32_
     for (uint32_t c0 = 0; c0 < b; c0 += mb) {
         const uint32_t cb = std::min(mb, b - c0);
         if ((rc = ix->stage(cb, k))) return rc;
-        HIP_TRY(hipMemcpyAsync(ix->s_queries, queries + (size_t)c0 * ix->dev.dim, (size_t)cb * ix->dev.dim * 4, hipMemcpyHostToDevice, ix->stream));
+        if ((rc = ix->stage_in(queries + (size_t)c0 * ix->dev.dim, cb))) return rc;
         rc = flat_scan_device(ix, ix->s_queries, cb, k, d_subset, n_rows, ix->s_ids, ix->s_scores, ix->s_counts, ix->s_status, stats != nullptr);
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(out_ids + (size_t)c0 * k, ix->s_ids, (size_t)cb * k * 8, hipMemcpyDeviceToHost, ix->stream));
-        HIP_TRY(hipMemcpyAsync(out_scores + (size_t)c0 * k, ix->s_scores, (size_t)cb * k * 4, hipMemcpyDeviceToHost, ix->stream));
-        HIP_TRY(hipMemcpyAsync(out_counts + c0, ix->s_counts, (size_t)cb * 4, hipMemcpyDeviceToHost, ix->stream));
-        HIP_TRY(hipMemcpyAsync(status.data() + c0, ix->s_status, (size_t)cb * 4, hipMemcpyDeviceToHost, ix->stream));
+        if ((rc = ix->stage_out(cb, k))) return rc;
         if (stats) {
             if ((rc = flat_stats(ix, cb, n_rows, stats))) return rc;
         } else {
             HIP_TRY(hipStreamSynchronize(ix->stream));
         }
+        ix->deliver(cb, k, out_ids + (size_t)c0 * k, out_scores + (size_t)c0 * k, out_counts + c0, status.data() + c0);
     }
     if (out_status) {
         memcpy(out_status, status.data(), (size_t)b * 4);

@@ -851,11 +851,13 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
         ra.extra_rel = full ? 0.f : (f32 ? 0.0078125f : 0.00390625f);
         HIP_TRY(d.metric == kL2 ? launch_rerank<kL2>(ra, b, ix->stream) : launch_rerank<kCosine>(ra, b, ix->stream));
         if (timed) HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
-        std::vector<uint32_t> cert(b);
-        uint32_t overflow = 0;
-        HIP_TRY(hipMemcpyAsync(cert.data(), ix->m_cert, (size_t)b * 4, hipMemcpyDeviceToHost, ix->stream));
-        if (filt || smallb) HIP_TRY(hipMemcpyAsync(&overflow, ix->m_ccnt + bpad, 4, hipMemcpyDeviceToHost, ix->stream));
+        if ((rc = ix->pin_flags((size_t)b + 1))) return rc; // read back through pinned memory: a pageable copy is a synchronous staged one
+        uint32_t *cert = ix->h_flags;
+        cert[b] = 0;
+        HIP_TRY(hipMemcpyAsync(cert, ix->m_cert, (size_t)b * 4, hipMemcpyDeviceToHost, ix->stream));
+        if (filt || smallb) HIP_TRY(hipMemcpyAsync(cert + b, ix->m_ccnt + bpad, 4, hipMemcpyDeviceToHost, ix->stream));
         HIP_TRY(hipStreamSynchronize(ix->stream));
+        const uint32_t overflow = cert[b];
         uint32_t failed = 0, first = 0;
         for (uint32_t i = 0; i < b; ++i)
             if (!cert[i]) { if (!failed) first = i; ++failed; }

@@ -80,6 +80,19 @@ struct hvx_index {
     uint32_t *s_counts = nullptr, *s_status = nullptr;
     size_t cap_q = 0, cap_o = 0;
     uint32_t cap_b = 0;
+    // pinned host mirror of the staging buffers.  A hipMemcpyAsync from / to pageable memory is a synchronous staged copy (35-50 us
+    // of host time EACH, five per call: measured with rocprofv3 --hip-trace, profiles/r03r); through pinned memory the five copies
+    // are enqueued in ~5 us each and the host pays two memcpys of a few KB.
+    unsigned char *h_pin = nullptr;
+    size_t cap_pin = 0;
+    int pin(size_t bytes);                                   // >= bytes of pinned host memory in h_pin
+    uint32_t *h_flags = nullptr;                             // pinned: small per-batch read-backs of the scan pipelines (certificates, overflow word)
+    size_t cap_flags = 0;
+    int pin_flags(size_t words);
+    int stage_in(const float *queries, uint32_t cb);         // user queries -> h_pin -> s_queries (enqueued)
+    int stage_out(uint32_t cb, uint32_t k);                  // s_ids / s_scores / s_counts / s_status -> h_pin (enqueued)
+    // after the stream has been synchronised: h_pin -> the caller's arrays
+    void deliver(uint32_t cb, uint32_t k, uint64_t *out_ids, float *out_scores, uint32_t *out_counts, uint32_t *out_status) const;
     // exact-scan scratch
     float *f_dist = nullptr, *f_top_s = nullptr;
     uint32_t *f_top_i = nullptr, *f_top_c = nullptr, *f_subset = nullptr;

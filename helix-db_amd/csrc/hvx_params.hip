@@ -277,14 +277,11 @@ extern "C" int hvx_search_batch_params(const hvx_index *cix, const float *querie
     for (uint32_t c0 = 0; c0 < b; c0 += mb) {
         const uint32_t cb = std::min(mb, b - c0);
         if ((rc = ix->stage(cb, k))) return rc;
-        HIP_TRY(hipMemcpyAsync(ix->s_queries, queries + (size_t)c0 * ix->dev.dim, (size_t)cb * ix->dev.dim * 4, hipMemcpyHostToDevice, ix->stream));
+        if ((rc = ix->stage_in(queries + (size_t)c0 * ix->dev.dim, cb))) return rc;
         rc = enqueue_params(ix, ix->s_queries, cb, params, &ad, strict, ix->s_ids, ix->s_scores, ix->s_counts, ix->s_status, nullptr,
                             adaptive_stats ? ix->d_astats : nullptr, stats != nullptr);
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(out_ids + (size_t)c0 * k, ix->s_ids, (size_t)cb * k * 8, hipMemcpyDeviceToHost, ix->stream));
-        HIP_TRY(hipMemcpyAsync(out_scores + (size_t)c0 * k, ix->s_scores, (size_t)cb * k * 4, hipMemcpyDeviceToHost, ix->stream));
-        HIP_TRY(hipMemcpyAsync(out_counts + c0, ix->s_counts, (size_t)cb * 4, hipMemcpyDeviceToHost, ix->stream));
-        HIP_TRY(hipMemcpyAsync(status.data() + c0, ix->s_status, (size_t)cb * 4, hipMemcpyDeviceToHost, ix->stream));
+        if ((rc = ix->stage_out(cb, k))) return rc;
         if (query_stats)
             HIP_TRY(hipMemcpyAsync(query_stats + c0, ix->d_qstats, (size_t)cb * sizeof(hvx_query_stats), hipMemcpyDeviceToHost, ix->stream));
         if (adaptive_stats)
@@ -294,6 +291,7 @@ extern "C" int hvx_search_batch_params(const hvx_index *cix, const float *querie
         } else {
             HIP_TRY(hipStreamSynchronize(ix->stream));
         }
+        ix->deliver(cb, k, out_ids + (size_t)c0 * k, out_scores + (size_t)c0 * k, out_counts + c0, status.data() + c0);
     }
     if (out_status) {
         memcpy(out_status, status.data(), (size_t)b * 4);

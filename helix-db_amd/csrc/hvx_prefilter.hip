@@ -48,6 +48,9 @@ struct hvx_csr {
     uint32_t *ord_node = nullptr, *ord_parent = nullptr, *ord_arc = nullptr; // [n] visits in discovery order
     uint32_t *lvl = nullptr;                        // [4] level start, level size, next level size
     void *host = nullptr;                           // HostCsr mirror (hvx_traverse_dfs), fetched on first use
+    uint32_t *h_seeds = nullptr;                    // pinned: the seeds of the traversal in flight (a pageable upload is a synchronous staged copy)
+    size_t cap_h_seeds = 0;
+    hipEvent_t done = nullptr;                      // recorded behind a traversal whose consumer runs on another stream (fused prefilter search)
 };
 
 namespace {
@@ -147,6 +150,8 @@ void csr_free(hvx_csr *g) {
     host_csr_free(g->host);
     (void)hipSetDevice(g->device);
     for (void *p : g->allocs) (void)hipFree(p);
+    if (g->h_seeds) (void)hipHostFree(g->h_seeds);
+    if (g->done) (void)hipEventDestroy(g->done);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     delete g;
 }
@@ -238,21 +243,44 @@ static int upload_labels(hvx_csr *g, const uint32_t *labels, uint32_t n) {
 }
 
 // caller holds g->mu; the visited bitmap stays in g->visited (device) whether or not it is copied out
+// `consumer`: a stream that reads the bitmap next (the fused prefilter search): it is made to wait on the traversal with an
+// event instead of the host waiting for it.
 static int run_bfs_locked(hvx_csr *g, const uint64_t *seeds, uint32_t n_seeds, uint32_t max_depth, uint32_t direction,
                           const uint32_t *labels, uint32_t n_labels, uint32_t hub_degree, uint32_t include_seeds,
-                          bool expand_only, uint64_t *out_bitmap, uint32_t *out_depth) {
+                          bool expand_only, uint64_t *out_bitmap, uint32_t *out_depth, hipStream_t consumer = nullptr) {
     if (direction > HVX_DIR_BOTH) return fail(HVX_ERR_INVARIANT, "bad direction");
     if (n_seeds == 0) return fail(HVX_ERR_INVARIANT, "traversal requires at least one seed"); // traversal.rs:198-202
     HIP_TRY(hipSetDevice(g->device));
-    // dedupe seeds preserving first occurrence (traversal.rs:203-210); unknown node => error
-    std::vector<uint32_t> s32;
-    {
+    // seeds: unknown node => error; duplicates (traversal.rs:203-210 keeps the first occurrence) are harmless for a visited SET --
+    // test-and-set makes every step idempotent -- so they are only removed when the list could overflow the frontier queue
+    if (n_seeds > g->cap_h_seeds) {
+        HIP_TRY(hipStreamSynchronize(g->stream)); // no upload from the old buffer is still in flight
+        if (g->h_seeds) (void)hipHostFree(g->h_seeds);
+        g->h_seeds = nullptr;
+        g->cap_h_seeds = 0;
+        const size_t want = std::max<size_t>((size_t)n_seeds + n_seeds / 2, 4096);
+        if (hipHostMalloc((void **)&g->h_seeds, want * 4, hipHostMallocDefault) != hipSuccess) return fail(HVX_ERR_DEVICE, "hipHostMalloc(%zu) seeds", want * 4);
+        g->cap_h_seeds = want;
+    }
+    struct SeedView { // what the code below reads of the former std::vector
+        const uint32_t *p; size_t n;
+        const uint32_t *data() const { return p; }
+        size_t size() const { return n; }
+    } s32{g->h_seeds, 0};
+    if (n_seeds <= g->n) {
+        for (uint32_t i = 0; i < n_seeds; ++i) {
+            const uint64_t v = seeds[i];
+            if (v >= g->n) return fail(HVX_ERR_INVARIANT, "unknown node %llu", (unsigned long long)v);
+            g->h_seeds[i] = (uint32_t)v;
+        }
+        s32.n = n_seeds;
+    } else {
         std::vector<uint64_t> seen(seeds, seeds + n_seeds);
         std::sort(seen.begin(), seen.end());
         seen.erase(std::unique(seen.begin(), seen.end()), seen.end());
         for (uint64_t v : seen) {
             if (v >= g->n) return fail(HVX_ERR_INVARIANT, "unknown node %llu", (unsigned long long)v);
-            s32.push_back((uint32_t)v);
+            g->h_seeds[s32.n++] = (uint32_t)v;
         }
     }
     const size_t words32 = ((g->n + 63) / 64) * 2;
@@ -300,6 +328,12 @@ static int run_bfs_locked(hvx_csr *g, const uint64_t *seeds, uint32_t n_seeds, u
     }
     if (out_bitmap) HIP_TRY(hipMemcpyAsync(out_bitmap, g->visited, words32 * 4, hipMemcpyDeviceToHost, g->stream));
     if (out_depth && g->n) HIP_TRY(hipMemcpyAsync(out_depth, g->depth, (size_t)g->n * 4, hipMemcpyDeviceToHost, g->stream));
+    if (consumer && !out_bitmap && !out_depth) { // the bitmap stays on the device: order the consumer behind the traversal, the host moves on
+        if (!g->done) HIP_TRY(hipEventCreateWithFlags(&g->done, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(g->done, g->stream));
+        HIP_TRY(hipStreamWaitEvent(consumer, g->done, 0));
+        return HVX_OK;
+    }
     HIP_TRY(hipStreamSynchronize(g->stream));
     return HVX_OK;
 }
@@ -1087,8 +1121,8 @@ static int prefilter_search_impl(const hvx_index *cix, const hvx_csr *cg, const 
     std::lock_guard<std::mutex> lock(ix->mu);
     int rc = run_bfs_locked(g, seeds, n_seeds, mode == HVX_PREFILTER_EXPAND ? 1u : max_depth, direction, allowed_label_ids, n_labels,
                             mode == HVX_PREFILTER_EXPAND ? 0u : hub_degree, mode == HVX_PREFILTER_EXPAND ? 0u : include_seeds,
-                            mode == HVX_PREFILTER_EXPAND, nullptr, nullptr);
-    if (rc) return rc; // (run_bfs_locked ends with a stream synchronise: the bitmap is complete)
+                            mode == HVX_PREFILTER_EXPAND, nullptr, nullptr, ix->stream);
+    if (rc) return rc; // (the index's stream waits for the traversal: the bitmap is complete before anything below reads it)
     const uint32_t n_words = ((g->n + 63u) / 64u) * 2u, n_blocks = (n_words + 255u) / 256u;
     if (2 * (n_blocks + 2) > ix->cap_pf_blocks) {
         if ((rc = ix->regrow((void **)&ix->pf_blocks, (size_t)2 * (n_blocks + 2) * 4))) return rc;
@@ -1101,7 +1135,8 @@ static int prefilter_search_impl(const hvx_index *cix, const hvx_csr *cg, const 
                        ix->contiguous ? 1u : 0u, ix->pf_blocks, d_total_bits, d_block_bits);
     hipLaunchKernelGGL(block_scan_kernel, dim3(1), dim3(1024), 0, ix->stream, ix->pf_blocks, n_blocks);
     HIP_TRY(hipGetLastError());
-    uint32_t totals[2] = {0, 0}; // rows to scan, candidate population
+    if ((rc = ix->pin(64))) return rc;
+    uint32_t *totals = reinterpret_cast<uint32_t *>(ix->h_pin); // rows to scan, candidate population (read back through the pinned mirror)
     HIP_TRY(hipMemcpyAsync(totals, ix->pf_blocks + n_blocks, 8, hipMemcpyDeviceToHost, ix->stream));
     HIP_TRY(hipStreamSynchronize(ix->stream));
     const uint32_t n_rows = totals[0], population = totals[1];

@@ -387,7 +387,7 @@ int walk_shared_set(hvx_index *ix, const float *queries, uint32_t b, uint32_t k_
     for (uint32_t c0 = 0; c0 < b; c0 += mb) {
         const uint32_t cb = std::min(mb, b - c0);
         if ((rc = ix->stage(cb, k_stride))) return rc;
-        HIP_TRY(hipMemcpyAsync(ix->s_queries, queries + (size_t)c0 * ix->dev.dim, (size_t)cb * ix->dev.dim * 4, hipMemcpyHostToDevice, ix->stream));
+        if ((rc = ix->stage_in(queries + (size_t)c0 * ix->dev.dim, cb))) return rc;
         HIP_TRY(launch_validate_queries(ix->dev, ix->s_queries, cb, ix->limit, ix->d_qstatus, ix->d_qhdr, ix->stream));
         HIP_TRY(launch_simhash_rows(ix->d_planes_t, ix->s_queries, ix->dev.dim, ix->dev.dim, cb, ix->d_qhash, ix->stream));
         HIP_TRY(hipMemsetAsync(ix->w_seen, 0, (size_t)cb * words * 4, ix->stream));
@@ -417,12 +417,10 @@ int walk_shared_set(hvx_index *ix, const float *queries, uint32_t b, uint32_t k_
         if (stats) HIP_TRY(hipEventRecord(ix->ev0, ix->stream));
         HIP_TRY(launch_walk(a, cb, ix->stream));
         if (stats) HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
-        HIP_TRY(hipMemcpyAsync(out_ids + (size_t)c0 * k_stride, ix->s_ids, (size_t)cb * k_stride * 8, hipMemcpyDeviceToHost, ix->stream));
-        HIP_TRY(hipMemcpyAsync(out_scores + (size_t)c0 * k_stride, ix->s_scores, (size_t)cb * k_stride * 4, hipMemcpyDeviceToHost, ix->stream));
-        HIP_TRY(hipMemcpyAsync(out_counts + c0, ix->s_counts, (size_t)cb * 4, hipMemcpyDeviceToHost, ix->stream));
-        HIP_TRY(hipMemcpyAsync(status.data() + c0, ix->s_status, (size_t)cb * 4, hipMemcpyDeviceToHost, ix->stream));
+        if ((rc = ix->stage_out(cb, k_stride))) return rc;
         HIP_TRY(hipMemcpyAsync(cnt.data() + c0, ix->w_counters, (size_t)cb * sizeof(walk::Counters), hipMemcpyDeviceToHost, ix->stream));
         HIP_TRY(hipStreamSynchronize(ix->stream));
+        ix->deliver(cb, k_stride, out_ids + (size_t)c0 * k_stride, out_scores + (size_t)c0 * k_stride, out_counts + c0, status.data() + c0);
         if (stats) {
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));

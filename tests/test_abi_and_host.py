@@ -211,6 +211,27 @@ def test_header_is_plain_c_and_the_c_example_links(tmp_path):
     assert exe.exists()
 
 
+def test_struct_layouts_of_the_header_and_the_ctypes_mirrors_agree(tmp_path):
+    """Every by-value struct of include/helix_vec.h has the size the ctypes mirror of the binding declares (a field added on one side
+    only -- hvx_build_params.link_mode was the last -- would shift every later field of a call)."""
+    import ctypes as C
+    import subprocess
+    import pyhvx as hv
+    pairs = [("hvx_index_desc", hv._Desc), ("hvx_stats", hv.Stats), ("hvx_query_stats", hv.QueryStats), ("hvx_search_params", hv._Params),
+             ("hvx_simhash_config", hv.SimHashConfig), ("hvx_adaptive_stats", hv.AdaptiveStats), ("hvx_restricted_params", hv.RestrictedParams),
+             ("hvx_restricted_stats", hv.RestrictedStats), ("hvx_index_metadata", hv.IndexMetadata), ("hvx_build_params", hv.BuildParams),
+             ("hvx_build_stats", hv.BuildStats)]
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "helix_vec.h"\nint main(void) {\n' +
+                   "".join('  printf("%s %%zu\\n", sizeof(%s));\n' % (n, n) for n, _ in pairs) + "  return 0;\n}\n")
+    exe = tmp_path / "sizes"
+    out = subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    got = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True).stdout.splitlines())
+    for name, mirror in pairs:
+        assert int(got[name]) == C.sizeof(mirror), (name, got[name], C.sizeof(mirror))
+
+
 def test_bench_deadline_prints_the_line_and_ends_the_process():
     """bench.py's watchdog: once the headline object exists, a stuck extra leg cannot cost the line -- at the deadline the object
     is printed as ONE json line (with the legs finished so far, here one that is added while the watchdog waits) and the process

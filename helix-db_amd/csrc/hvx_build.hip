@@ -607,11 +607,9 @@ template <typename K> static hipError_t launch_build(K kern, dim3 grid, const Bu
 }
 
 template <typename K> static hipError_t launch_link_wg(K kern, const BuildArgs &a, uint32_t layers, size_t lds, hipStream_t s) {
-    static thread_local const void *raised = nullptr; // the attribute is per function: set it once per kernel
-    if (lds > 48 * 1024 && raised != (const void *)kern) {
+    if (lds > 48 * 1024) { // (46 KB at <= 33 candidate rows: only larger Mmax would need it; the attribute is per function AND device)
         const hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        raised = (const void *)kern;
     }
     hipLaunchKernelGGL(kern, dim3(a.b * 32u, layers), dim3(256), lds, s, a);
     return hipGetLastError();

@@ -983,6 +983,33 @@ static int add_link(orc_index *ix, uint32_t layer, uint32_t from, uint32_t to, u
     return ORC_OK;
 }
 
+/* Test hook: the prune step of add_bidirectional_link (mutation.rs:1498-1583) for ONE row, without touching the graph --
+ * rank `cand_ids` (all stored in the index) by distance to `owner_id` in Candidate order, select_diverse (mod.rs:809-856) +
+ * backfill with at most maxn survivors.  out_ids[0..*out_n) = the surviving ids in selection order.  The device's eager
+ * evaluation (build_link_wg_kernel: all pairwise distances, predicate masks) is checked against this by a CPU twin. */
+int orc_index_prune_candidates(const orc_index *ix, uint64_t owner_id, const uint64_t *cand_ids, uint32_t nc, uint32_t maxn,
+                               uint64_t *out_ids, uint32_t *out_n) {
+    if (!ix || !cand_ids || !out_ids || !out_n || nc > 4096) return ORC_ERR_INVARIANT;
+    uint32_t to = map_find(ix, owner_id);
+    if (to == UINT32_MAX) return ORC_ERR_INVARIANT;
+    cand_t d[4096];
+    for (uint32_t i = 0; i < nc; ++i) {
+        uint32_t r = map_find(ix, cand_ids[i]);
+        if (r == UINT32_MAX) return ORC_ERR_INVARIANT;
+        float x = orc_distance(ix->metric, ix->kernel, row(ix, to), ix->hdr[to], row(ix, r), ix->hdr[r], ix->dim);
+        if (orc_distance_score(&x)) return ORC_ERR_INVARIANT;
+        d[i].score = x;
+        d[i].idx = r;
+    }
+    sort_cands(ix, d, nc);
+    uint32_t sel[4096], ns = 0;
+    int rc = select_diverse(ix, d, nc, nc, maxn, sel, &ns);
+    if (rc) return rc;
+    for (uint32_t i = 0; i < ns; ++i) out_ids[i] = ix->ids[sel[i]];
+    *out_n = ns;
+    return ORC_OK;
+}
+
 /* mutation.rs:642-780 insert_with_mutation_cache + :787-895 insert_hnsw */
 int orc_index_insert(orc_index *ix, uint64_t node_id, const float *v, uint16_t level) {
     uint32_t bad;

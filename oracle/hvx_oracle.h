@@ -94,6 +94,9 @@ void orc_index_free(orc_index *);
 /* insert one row (mutation.rs:642-780 + insert_hnsw :787-895); node ids may come in any order.
  * level is the scripted layer (reference: with_scripted_layers / select_layer). */
 int orc_index_insert(orc_index *, uint64_t node_id, const float *vector, uint16_t level);
+/* test hook: the prune of add_bidirectional_link for one row (rank by distance to the owner, select_diverse + backfill) */
+int orc_index_prune_candidates(const orc_index *, uint64_t owner_id, const uint64_t *cand_ids, uint32_t nc, uint32_t maxn,
+                               uint64_t *out_ids, uint32_t *out_n);
 /* seed a pre-built graph (scale_contracts.rs:95-155 style): rows given as CSR over node ids. */
 int orc_index_seed(orc_index *, uint64_t n, const uint64_t *node_ids, const float *vectors,
                    const uint64_t *l0_offsets, const uint64_t *l0_neighbors,

@@ -216,6 +216,8 @@ def lib():
     L.orc_index_free.argtypes = [C.c_void_p]
     L.orc_index_insert.restype = C.c_int
     L.orc_index_insert.argtypes = [C.c_void_p, C.c_uint64, f32p, C.c_uint16]
+    L.orc_index_prune_candidates.restype = C.c_int
+    L.orc_index_prune_candidates.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
     L.orc_index_seed.restype = C.c_int
     L.orc_index_seed.argtypes = [C.c_void_p, C.c_uint64, u64p, f32p, u64p, u64p, u16p, u64p, u64p,
                                  C.c_int, C.c_uint64, C.c_uint16]
@@ -359,6 +361,15 @@ class Index:
         v, pv = _f(vector)
         assert v.size == self.dim
         return lib().orc_index_insert(self._h, int(node_id), pv, int(level))
+
+    def prune_candidates(self, owner_id, cand_ids, maxn):
+        """the prune of add_bidirectional_link for one row: ids that survive select_diverse + backfill, in selection order"""
+        c = np.ascontiguousarray(cand_ids, dtype=np.uint64)
+        out = np.zeros(max(c.size, 1), np.uint64)
+        n = C.c_uint32(0)
+        rc = lib().orc_index_prune_candidates(self._h, int(owner_id), c.ctypes.data_as(C.c_void_p), c.size, int(maxn),
+                                              out.ctypes.data_as(C.c_void_p), C.byref(n))
+        return rc, out[: n.value].copy()
 
     def seed(self, node_ids, vectors, l0_offsets, l0_neighbors, level=None, up_offsets=None,
              up_neighbors=None, entry_point=None, max_layer=0):

@@ -166,3 +166,74 @@ def test_sparse_filter_is_bridging_heavy(orc):
         explicit(orc, img, ix, q, allowed, directory=True, k=10, ef_filtered=150, routing_rows=2400, bridge_rows=40, vector_payloads=800,
                  sampled_seeds=64, directory_seeds=256, variants=(0, 1))
     assert pushes > 4000, pushes
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# build_link_wg_kernel's prune (csrc/hvx_build.hip, round 3): all pairwise distances, predicate masks, mask walk.  A twin of exactly
+# that evaluation, fed with the oracle's distances, must keep the ids the reference's lazy select_diverse + backfill keeps.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _eager_prune_twin(orc, metric, kernel, rows, ids, owner, cand, maxn):
+    """the kernel's order of evaluation: pair p = b (b - 1) / 2 + a over rows a < b (index nc = the owner), D symmetric, Candidate
+    order by (D[owner][i], id), P[i] bit j = D[c_i][c_j] < D[c_i][owner] for j < i, diverse iff P[i] & kept == 0, then the backfill"""
+    nc = len(cand)
+    nrows = nc + 1
+    vec = [rows[c] for c in cand] + [rows[owner]]
+    D = np.zeros((nrows, nrows), np.float32)
+    for b in range(1, nrows):
+        for a in range(b):
+            D[a, b] = D[b, a] = orc.distance(metric, vec[a], vec[b], kernel=kernel)
+    order = sorted(range(nc), key=lambda t: (D[nc, t], ids[cand[t]]))
+    csc = [D[nc, t] for t in order]
+    P = []
+    for i in range(nc):
+        bits = 0
+        for j in range(i):
+            if D[order[i], order[j]] < csc[i]:
+                bits |= 1 << j
+        P.append(bits)
+    kept, ns = 0, 0
+    for i in range(nc):
+        if ns >= maxn:
+            break
+        if P[i] & kept == 0:
+            kept |= 1 << i
+            ns += 1
+    for i in range(nc):
+        if ns >= maxn:
+            break
+        if not (kept >> i) & 1:
+            kept |= 1 << i
+            ns += 1
+    return sorted(int(ids[cand[order[i]]]) for i in range(nc) if (kept >> i) & 1)
+
+
+@pytest.mark.parametrize("metric,dim,kernel_name", [(1, 64, "K_AVX_FMA"), (0, 96, "K_AVX_FMA"), (1, 36, "K_AVX"), (2, 40, "K_AVX_FMA")])
+def test_eager_mask_prune_keeps_what_select_diverse_keeps(orc, metric, dim, kernel_name):
+    kernel = getattr(orc, kernel_name)
+    rng = np.random.default_rng(900 + dim)
+    n = 400
+    centres = rng.standard_normal((6, dim)).astype(np.float32)
+    rows = (centres[rng.integers(0, 6, n)] + 0.3 * rng.standard_normal((n, dim))).astype(np.float32)
+    rows[50:58] = rows[40:48]                       # exact duplicates: equal scores, decided by id
+    rows[70] = rows[71]
+    ids = np.arange(n, dtype=np.uint64) * 5 + 3
+    oix = orc.Index(dim, metric, kernel=kernel, m=16, m0=32, ef_construction=40)
+    assert oix.seed(ids, rows, np.zeros(n + 1, np.uint64), np.zeros(0, np.uint64), entry_point=int(ids[0])) == orc.OK
+    checked = 0
+    for trial in range(60):
+        nc = int(rng.integers(3, 34))
+        maxn = nc - 1 if trial % 3 else int(rng.integers(1, nc))
+        owner = int(rng.integers(0, n))
+        pool = np.array([i for i in range(n) if i != owner])
+        near = pool[np.argsort(((rows[pool] - rows[owner]) ** 2).sum(1))[: 3 * nc]]   # neighbours of the owner: rejections do happen
+        cand = rng.choice(near, nc, replace=False).tolist()
+        if trial % 5 == 0 and owner not in range(40, 58):
+            cand[: min(4, nc)] = [40, 50, 41, 51][: min(4, nc)]   # duplicate rows among the candidates
+            cand = list(dict.fromkeys(cand))
+            nc = len(cand)
+            maxn = min(maxn, nc)
+        rc, keep = oix.prune_candidates(int(ids[owner]), ids[cand], maxn)
+        assert rc == orc.OK
+        assert _eager_prune_twin(orc, metric, kernel, rows, ids, owner, cand, maxn) == sorted(keep.tolist()), (trial, nc, maxn)
+        checked += 1
+    assert checked == 60

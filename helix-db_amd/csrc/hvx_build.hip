@@ -620,6 +620,22 @@ __global__ void iota_kernel(uint32_t *p, uint32_t n) {
     if (i < n) p[i] = i;
 }
 
+// one instantiation per (metric, summation tree): the reference picks both per index (spaces/*.rs, distance/*.rs)
+using BuildKernel = void (*)(BuildArgs);
+struct BuildKernels {
+    BuildKernel select, link, link_wg; // link_wg: null where the workgroup kernel has no instantiation (Manhattan)
+};
+template <uint32_t METRIC, bool FUSED> static BuildKernels build_kernels_of() {
+    BuildKernels k{build_select_kernel<METRIC, FUSED>, build_link_kernel<METRIC, FUSED>, nullptr};
+    if constexpr (METRIC != kL1) k.link_wg = build_link_wg_kernel<METRIC, FUSED>;
+    return k;
+}
+static BuildKernels pick_build_kernels(uint32_t metric, bool fused) {
+    if (metric == kL2) return fused ? build_kernels_of<kL2, true>() : build_kernels_of<kL2, false>();
+    if (metric == kCosine) return fused ? build_kernels_of<kCosine, true>() : build_kernels_of<kCosine, false>();
+    return fused ? build_kernels_of<kL1, true>() : build_kernels_of<kL1, false>();
+}
+
 } // namespace hvx
 
 extern "C" void hvx_build_params_default(hvx_build_params *p) {
@@ -715,15 +731,9 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
     const uint32_t ldp = link_ck * 32u + 32u;
     const size_t link_lds = link_lds_bytes(ldp, ncmax);
     // serves rows without a scalar tail (dim % 32 == 0, no padding) and <= 33 candidates (561 pairs = 4 wavefronts x 18 steps x 8)
-    const bool link_wg = params->link_mode != 1u && ncmax <= 33u && nk_rows > 0 && d.dim_main == d.dim && d.ld == d.dim && d.metric != kL1 &&
+    const BuildKernels kern = pick_build_kernels(d.metric, fused);
+    const bool link_wg = params->link_mode != 1u && kern.link_wg && ncmax <= 33u && nk_rows > 0 && d.dim_main == d.dim && d.ld == d.dim &&
                          (size_t)(ncmax + 1u) * link_ck * 8u <= 9u * 256u;
-// one instantiation per (metric, summation tree): the reference picks both per index (spaces/*.rs, distance/*.rs)
-#define HVX_BUILD_DISPATCH(CALL)                                                                          \
-    (d.metric == kL2 ? (fused ? CALL(kL2, true) : CALL(kL2, false))                                       \
-     : d.metric == kCosine ? (fused ? CALL(kCosine, true) : CALL(kCosine, false))                         \
-                           : (fused ? CALL(kL1, true) : CALL(kL1, false)))
-#define HVX_BUILD_DISPATCH_L2COS(CALL)                                                                    \
-    (d.metric == kL2 ? (fused ? CALL(kL2, true) : CALL(kL2, false)) : (fused ? CALL(kCosine, true) : CALL(kCosine, false)))
     // first node: the entry point with empty rows on its layers (mutation.rs:706-739)
     d.has_entry = 1;
     d.entry = 0;
@@ -773,18 +783,15 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
         ba.m0 = m0;
         ba.err = d_err;
         ba.dbg = d_dbg;
-#define HVX_SELECT(M, F) launch_build(build_select_kernel<M, F>, dim3(bsz, layers), ba, s)
-#define HVX_LINK(M, F) launch_build(build_link_kernel<M, F>, dim3(bsz), ba, s)
-#define HVX_LINK_WG(M, F) launch_link_wg(build_link_wg_kernel<M, F>, ba, layers, link_lds, s)
-        hipError_t e = HVX_BUILD_DISPATCH(HVX_SELECT);
+        hipError_t e = launch_build(kern.select, dim3(bsz, layers), ba, s);
         if (e == hipSuccess) {
             if (bsz > 1u && link_wg) { // batched mode: one workgroup per link, prunes evaluated from LDS
                 ba.ldp = ldp;
                 ba.ncmax = ncmax;
                 ba.link_ck = link_ck;
-                e = HVX_BUILD_DISPATCH_L2COS(HVX_LINK_WG);
+                e = launch_link_wg(kern.link_wg, ba, layers, link_lds, s);
             } else { // one node (the reference's order exactly), or rows the workgroup kernel does not serve: one wavefront per node
-                e = HVX_BUILD_DISPATCH(HVX_LINK);
+                e = launch_build(kern.link, dim3(bsz), ba, s);
             }
         }
         if (e != hipSuccess) return sbail(fail(HVX_ERR_DEVICE, "build launch failed: %s", hipGetErrorString(e)));

@@ -237,3 +237,21 @@ def test_eager_mask_prune_keeps_what_select_diverse_keeps(orc, metric, dim, kern
         assert _eager_prune_twin(orc, metric, kernel, rows, ids, owner, cand, maxn) == sorted(keep.tolist()), (trial, nc, maxn)
         checked += 1
     assert checked == 60
+
+
+def test_reference_select_diverse_golden_through_the_oracle_and_the_eager_twin(orc):
+    """crates/db/src/search/vector/mod.rs:1544-1580 test_select_diverse_prefers_separated_candidates: 1-D Euclidean items 1.0, 1.1, -10, 20
+    around the query 0.0, m = 2 -> [1, 3] (2 is closer to 1 than to the query).  The oracle's select_diverse reproduces it in selection
+    order; the device kernel's eager mask evaluation (twin) keeps the same set.  (:1582-1597, missing items, has no device analogue: the
+    build hydrates every candidate from rows resident in HBM.)"""
+    rows = np.array([[0.0], [1.0], [1.1], [-10.0], [20.0]], np.float32)   # node 0 = the query item
+    ids = np.arange(5, dtype=np.uint64)
+    for kernel in (orc.K_SCALAR, orc.K_AVX_FMA):
+        oix = orc.Index(1, orc.L2SQ, kernel=kernel, m=2, m0=4, ef_construction=8)
+        assert oix.seed(ids, rows, np.zeros(6, np.uint64), np.zeros(0, np.uint64), entry_point=0) == orc.OK
+        rc, keep = oix.prune_candidates(0, np.array([1, 2, 3, 4], np.uint64), 2)
+        assert rc == orc.OK and keep.tolist() == [1, 3]
+        assert _eager_prune_twin(orc, orc.L2SQ, kernel, rows, ids, 0, [1, 2, 3, 4], 2) == [1, 3]
+        # candidates handed over in another order are ranked by (score, id) first
+        rc, keep = oix.prune_candidates(0, np.array([4, 3, 2, 1], np.uint64), 2)
+        assert rc == orc.OK and keep.tolist() == [1, 3]

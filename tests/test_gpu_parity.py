@@ -939,9 +939,11 @@ def test_batcher_coalesces_concurrent_single_query_callers(orc, hv):
         bt = hv.Batcher(gix, params, max_batch=32, max_wait_us=2000)
         got = [None] * q.shape[0]
         errors = []
+        start = threading.Barrier(48)  # every caller's first query arrives at once: the first batches are shared for certain
 
         def worker(t):
             try:
+                start.wait()
                 for i in range(t, q.shape[0], 48):
                     got[i] = bt.search(q[i])
             except Exception as e:  # pragma: no cover

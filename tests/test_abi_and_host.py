@@ -329,6 +329,31 @@ def test_inline_asm_lds_reads_are_covered_by_a_wait(tmp_path):
         assert lint.stdout.count(": 0 hazard(s)") == want, lint.stdout    # fp8 + bf16 instantiations of each kernel (tile4: with and without interleaved copies)
 
 
+def test_link_workgroup_kernel_takes_its_row_locks_without_cache_maintenance(tmp_path):
+    """Round 3: an acquire / release at agent scope is an L2 invalidate / write-back of the whole XCD on gfx950 (`buffer_inv sc1` /
+    `buffer_wbl2 sc1`); with one per lock operation the batched link step of the device build spent 60 % of its time in them
+    (profiles/r03p_build_link_wg.txt).  The rows a lock protects are only touched with agent-scope atomics, so the locks of
+    build_link_wg_kernel are relaxed atomics + s_waitcnt: its assembly must contain no cache-maintenance instruction, and no scratch."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    asm = tmp_path / "hvx_build.s"
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S", "--cuda-device-only",
+                          "-o", str(asm), os.path.join(ROOT, "helix-db_amd", "csrc", "hvx_build.hip")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    text = asm.read_text()
+    kernels = re.findall(r"^(_ZN3hvx20build_link_wg_kernel\w+):[^\n]*\n(.*?)\.end_amdhsa_kernel", text, flags=re.S | re.M)
+    assert len(kernels) == 4, [k for k, _ in kernels]       # L2 / cosine x fused / unfused summation tree
+    for name, body in kernels:
+        assert "buffer_wbl2" not in body and "buffer_inv" not in body, name
+        assert "global_atomic_swap" in body                  # the lock itself
+        seg = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body)
+        assert seg and int(seg.group(1)) <= 64, (name, seg.group(0) if seg else None)   # a handful of spilled dwords at most
+
+
 def test_release_library_reads_no_environment_and_carries_no_measurement_code():
     """tuning switches (kernel ablation -- results wrong by construction --, phase profiling, experimental tile
     builds, stderr path reports) exist only in `make TUNING=1` builds.  The shipped library does not import getenv, holds none

@@ -134,6 +134,11 @@ def build_graph(hv, synth, args, x, metric, id_lo, b, device, level_seed, keep_i
         g["node_ids"] = ids
         info = {"builder": "hvx_index_build: insert_hnsw (mutation.rs:787-895) for batches of nodes on the device, M=%d M0=%d efC=200" % (args.m, 2 * args.m),
                 "seconds": round(secs, 2), "inserts_per_s": round(n / secs, 1), "batches": int(st["batches"]), "max_batch": args.build_batch}
+        # every graph the bench searches is audited where it was built (hvx_index_audit_graph: row invariants of neighbor_set.rs:1-9,
+        # symmetry on every layer -- mutation.rs:1498-1583,1890-1908 --, layer-0 reachability from the entry point)
+        t1 = time.time()
+        info["audit"] = graph_audit(bix, args.m)
+        info["audit"]["seconds"] = round(time.time() - t1, 3)
         if not keep_index:
             bix.close()
             bix = None
@@ -141,6 +146,14 @@ def build_graph(hv, synth, args, x, metric, id_lo, b, device, level_seed, keep_i
     deg = np.diff(g["l0_offsets"].astype(np.int64))
     info.update({"rows": n, "degree_mean": round(float(deg.mean()), 2), "degree_max": int(deg.max()), "max_layer": int(g["max_layer"])})
     return g, info, bix
+
+
+def graph_audit(ix, m):
+    a = ix.audit_graph()
+    a["clean"] = bool(all(a[kk] == 0 for kk in ("asymmetric_edges_l0", "asymmetric_edges_up", "unsorted_entries", "self_loops", "out_of_range_ids",
+                                               "holes", "level_violations", "degree_overflow_rows"))
+                      and a["max_degree_l0"] <= 2 * m and a["max_degree_up"] <= m)
+    return a
 
 
 def out_buffers(b, k, dev):
@@ -378,7 +391,7 @@ def leg_config3(hv, synth, orc, args, dev, k=10, nq=32, rounds=5):
         assert ncand == size
         rows = x[lo:lo + size].cpu().numpy()
         ok = True
-        for qi in range(0, nq, 8):  # a sample of the batch against the oracle's exact scan of the candidate rows
+        for qi in range(0, nq, 1 if size <= 10000 else 4):  # the batch against the oracle's exact scan of the candidate rows
             rc, oid, osc = orc.flat_matrix(orc.L2SQ, rows, q[qi], k, kernel=orc.K_AVX_FMA_HW)
             ok &= (fid[qi, :fcnt[qi]] - np.uint64(lo)).tolist() == oid.tolist()
             ok &= fsc[qi, :fcnt[qi]].view(np.uint32).tolist() == osc.view(np.uint32).tolist()
@@ -399,7 +412,7 @@ def leg_config3(hv, synth, orc, args, dev, k=10, nq=32, rounds=5):
         pms, pkms = float(np.median(lat)) * 1e3, float(np.median(kern))
         walked = prs[0]["strategy"] == hv.RESTRICTED_FILTERED
         pok = True
-        for qi in range(0, nq, 8):  # ids, score bits, every RestrictedSearchStats counter and the termination vs the oracle's walk
+        for qi in range(nq):  # EVERY query of the group: ids, score bits, every RestrictedSearchStats counter and the termination vs the oracle's walk
             rc, oid, osc, ost = oix.search_restricted(q[qi], k, ef, allowed)
             pok &= rc == orc.OK and pid[qi, :pcnt[qi]].tolist() == oid.tolist() and psc[qi, :pcnt[qi]].view(np.uint32).tolist() == osc.view(np.uint32).tolist()
             pok &= prs[qi]["strategy"] == ost["strategy"] and all(prs[qi][f] == ost[f] for f in fields)
@@ -417,7 +430,7 @@ def leg_config3(hv, synth, orc, args, dev, k=10, nq=32, rounds=5):
                    "directory_rows_max": int(max(r_["directory_rows"] for r_ in prs)), "routing_rows_mean": round(float(np.mean([r_["routing_rows"] for r_ in prs])), 1),
                    "bridge_rows_mean": round(float(np.mean([r_["bridge_rows"] for r_ in prs])), 1),
                    "terminations": terms, "algorithmic_bytes_per_batch": walk_alg, "hbm_gbs": round(walk_alg / (pkms * 1e-3) / 1e9, 1),
-                   "oracle_equal_sample": {"queries": len(range(0, nq, 8)), "ids_bits_counters_termination_equal": bool(pok)}}
+                   "oracle_equal_sample": {"queries": nq, "ids_bits_counters_termination_equal": bool(pok)}}
         if size == 100000 and walked:
             # the same walk with the chip filled: 1 024 queries (one workgroup each) over the same candidate set
             qb = x[torch.randint(0, n, (1024,), generator=torch.Generator().manual_seed(5)).to(dev)].cpu().numpy()
@@ -570,15 +583,20 @@ def leg_config5(hv, synth, orc, dev, rows, b=4096, k=10, dim=1536):
     return out
 
 
-def leg_iso_recall(hv, synth, orc, args, dev, dataset, n, dim, b, k, efs=(128, 192, 256, 384, 512, 800), target=0.95):
-    """The metric is QPS @ recall@10 >= 0.95: on a corpus where ef = 128 misses the gate, sweep ef (scale_contracts.rs:167-215
-    protocol: same graph, same queries, recall against the exact scan) and report the smallest beam that clears it -- its QPS,
-    roofline fraction and the CPU oracle at the same ef."""
-    res0, st = hnsw_leg(hv, synth, args, dev, dataset, n, dim, b, k, efs[0], steps=12, keep=True)
-    ls, ix_truth = st["ls"], st["ix_truth"]
-    sweep, hit = [], None
+def kernel_of_ef(ef):
+    need = ef + 32
+    if need <= 832:
+        beam = 192 if need <= 192 else 384 if need <= 384 else 448 if need <= 448 else 832
+        return f"one wavefront per query, {beam}-entry register beam"
+    return "general kernel (4 wavefronts per query)"
+
+
+def ef_sweep_rows(ls, qs, ix_truth, dev, dim, b, k, efs, elem=4, steps=12, stop_at=None):
+    """Same graph, same lanes, distinct query batches: one row per beam width (QPS, recall against the exact scan, distance
+    evaluations, fraction of the HBM peak from the algorithmic bytes of lane 0's last batch)."""
+    rows = []
     for ef in efs:
-        elapsed, span, kms = timed_steps(ls, st["qs"], ef, 12, 3, lambda: None)
+        elapsed, span, kms = timed_steps(ls, qs, ef, steps, 3, lambda: None)
         q = ls.last_q[0]
         f = out_buffers(b, k, dev)
         ix_truth.flat_search_batch_device(q, k, *f[:4])
@@ -586,15 +604,24 @@ def leg_iso_recall(hv, synth, orc, args, dev, dataset, n, dim, b, k, efs=(128, 1
         got = ls.bufs[0]
         rec = recall_of(got[0], f[0], b, k)
         qst = got[4].cpu().numpy().astype(np.int64)
-        alg = hnsw_alg_bytes(qst, dim, 4, b)
-        row = {"ef_search": ef, "recall_at_10": round(rec, 4), "qps": round(b * 12 / elapsed, 1), "ms_per_step": round(elapsed * 1e3 / 12, 4),
-               "distance_computations_per_query": round(float(qst[:, 3].mean()), 1),
-               "frac_of_hbm_peak": round(alg / (span / 12 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-               "kernel": "one wavefront per query" if ef + 32 <= 384 else "general kernel (4 wavefronts per query: ef beyond the register beam of the wave kernel)"}
-        sweep.append(row)
-        if rec >= target:
-            hit = dict(row)
+        alg = hnsw_alg_bytes(qst, dim, elem, b)
+        rows.append({"ef_search": ef, "recall_at_10": round(rec, 4), "qps": round(b * steps / elapsed, 1), "ms_per_step": round(elapsed * 1e3 / steps, 4),
+                     "distance_computations_per_query": round(float(qst[:, 3].mean()), 1),
+                     "expansion_steps_per_query": round(float(qst[:, 0].mean()), 1),
+                     "frac_of_hbm_peak": round(alg / (span / steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kernel": kernel_of_ef(ef)})
+        if stop_at is not None and rec >= stop_at:
             break
+    return rows
+
+
+def leg_iso_recall(hv, synth, orc, args, dev, dataset, n, dim, b, k, efs=(128, 192, 256, 384, 512, 800), target=0.95):
+    """The metric is QPS @ recall@10 >= 0.95: on a corpus where ef = 128 misses the gate, sweep ef (scale_contracts.rs:167-215
+    protocol: same graph, same queries, recall against the exact scan) and report the smallest beam that clears it -- its QPS,
+    roofline fraction and the CPU oracle at the same ef."""
+    res0, st = hnsw_leg(hv, synth, args, dev, dataset, n, dim, b, k, efs[0], steps=12, keep=True)
+    ls, ix_truth = st["ls"], st["ix_truth"]
+    sweep = ef_sweep_rows(ls, st["qs"], ix_truth, dev, dim, b, k, efs, stop_at=target)
+    hit = dict(sweep[-1]) if sweep and sweep[-1]["recall_at_10"] >= target else None
     out = {"dataset": dataset, "rows": n, "dim": dim, "batch": b, "k": k, "target_recall_at_10": target, "sweep": sweep, "iso_recall": hit,
            "leg_at_first_ef": res0}
     if hit is not None and not args.no_verify:  # the CPU oracle at the same beam width, same graph and queries
@@ -908,12 +935,13 @@ def main():
         per_step = span / args.steps
         res = dict(qps=qps, ms_per_step=elapsed * 1e3 / args.steps, recall=recall, alg=alg, per_step=per_step, kms=kms, qst=qst, n=n,
                    n_total=n_total, flat_ms=flat_stats["device_ms"], graph=ginfo, exchange=exchange, nbq=nbq)
-        state = dict(ix=ix, ix_truth=ix_truth, ls=ls, x=x, q=q, g=g, truth=f, id_lo=id_lo)
+        state = dict(ix=ix, ix_truth=ix_truth, ls=ls, x=x, q=q, g=g, truth=f, id_lo=id_lo, qs=qs)
         return res, state
 
     n_weak_total = args.rows if replica else args.rows * world
     res, S = shard_run(n_weak_total, "weak" if world > 1 else "1 GPU")
     ix, ls, q, g, x = S["ix"], S["ls"], S["q"], S["g"], S["x"]
+    S_qs = S["qs"]
     headline_alive = True
     n = res["n"]
     qst = res["qst"]
@@ -928,6 +956,18 @@ def main():
             lone.append(st["device_ms"])
     ix.set_occupancy(occ)
     lone_ms = float(np.mean(lone))
+
+    # ---- the beam-width curve of the HEADLINE corpus and graph (round 4): ef 128 .. 800 on the same lanes; every row one wavefront per
+    #      query (448 / 832-entry register beams above ef 352; rounds 1-3 sent those to the 4-wavefront general kernel) ----
+    ef_sweep = None
+    if world == 1 and "ef_sweep" not in skip:
+        try:
+            ef_sweep = ef_sweep_rows(ls, [qq for qq in S_qs], S["ix_truth"], dev, dim, b, k, (128, 192, 256, 384, 512, 800), elem=2 if bf16 else 4)
+        except Exception as e:
+            ef_sweep = {"error": f"{type(e).__name__}: {e}"}
+        for l in range(lanes):  # the lanes' buffers answer the headline beam width again (the oracle check below reads them)
+            ls.step(l, q if l == 0 else S_qs[l % len(S_qs)], ef)
+        ls.sync()
 
     traffic = None
     if os.path.exists(args.traffic_file):
@@ -979,6 +1019,7 @@ def main():
                                     "note": "ALGORITHMIC flops 2*b*N*dim / time of the whole scan (bf16 shadow contraction on the matrix cores + "
                                             "filtered epilogue + exact f32 re-rank + certificate); bit-exact vs the oracle's exact scan"}},
         "graph_build": res["graph"],
+        "ef_sweep": ef_sweep,
     }
 
     if args.deadline > 0:

@@ -430,7 +430,8 @@ int hvx::import_index(const hvx_index_desc *desc, const uint64_t *node_ids, cons
     if (hipMemset(ix->d_bitmap, 0, (size_t)mb * ix->words_per_query * 4) != hipSuccess) return bail(fail(HVX_ERR_DEVICE, "bitmap clear failed"));
     if ((rc = ix->dalloc((void **)&ix->d_qstatus, (size_t)mb * 4))) return bail(rc);
     if ((rc = ix->dalloc((void **)&ix->d_qhdr, (size_t)mb * 4))) return bail(rc);
-    if ((rc = ix->dalloc((void **)&ix->d_tie, (size_t)mb * 4))) return bail(rc);
+    if ((rc = ix->dalloc((void **)&ix->d_tie, ((size_t)mb * 2 + 4) * 4))) return bail(rc); // [mb] flags, [mb] re-run list, re-run count / done
+    if (hipMemset(ix->d_tie, 0, ((size_t)mb * 2 + 4) * 4) != hipSuccess) return bail(fail(HVX_ERR_DEVICE, "re-run list clear failed"));
     if ((rc = ix->dalloc((void **)&ix->d_qstats, (size_t)mb * sizeof(hvx_query_stats)))) return bail(rc);
     *out = ix;
     return HVX_OK;
@@ -478,7 +479,8 @@ extern "C" int hvx_index_fork(const hvx_index *parent, hvx_index **out) {
     if (hipMemset(ix->d_bitmap, 0, bm_bytes) != hipSuccess) return bail(fail(HVX_ERR_DEVICE, "bitmap clear failed"));
     if ((rc = ix->dalloc((void **)&ix->d_qstatus, (size_t)mb * 4))) return bail(rc);
     if ((rc = ix->dalloc((void **)&ix->d_qhdr, (size_t)mb * 4))) return bail(rc);
-    if ((rc = ix->dalloc((void **)&ix->d_tie, (size_t)mb * 4))) return bail(rc);
+    if ((rc = ix->dalloc((void **)&ix->d_tie, ((size_t)mb * 2 + 4) * 4))) return bail(rc); // [mb] flags, [mb] re-run list, re-run count / done
+    if (hipMemset(ix->d_tie, 0, ((size_t)mb * 2 + 4) * 4) != hipSuccess) return bail(fail(HVX_ERR_DEVICE, "re-run list clear failed"));
     if ((rc = ix->dalloc((void **)&ix->d_qstats, (size_t)mb * sizeof(hvx_query_stats)))) return bail(rc);
     if (ix->has_simhash) { // per-batch state of the non-strict arms (hvx_params.hip)
         if ((rc = ix->dalloc((void **)&ix->d_qhash, (size_t)mb * 8))) return bail(rc);
@@ -623,6 +625,8 @@ int hvx::enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t b
     a.out_status = d_status;
     a.qstats = d_qstats ? d_qstats : ix->d_qstats;
     a.tie_flags = ix->d_tie;
+    a.rerun_list = ix->d_tie + ix->max_batch;
+    a.rerun_ctl = ix->d_tie + 2 * (size_t)ix->max_batch;
     a.prof = nullptr;
     a.wave_clock = nullptr;
     a.adaptive = ad ? 1u : 0u;
@@ -658,7 +662,7 @@ int hvx::enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t b
     const bool wave = !(force_general && ix->dev.dtype == HVX_F32) && hnsw_wave_supported(a);
     if (!wave && ix->dev.dtype != HVX_F32)
         return fail(HVX_ERR_UNSUPPORTED, ix->dev.dtype == HVX_FP8_E4M3 ? "fp8 rows serve the exact scan only (HNSW over fp8 rows is not built)"
-                    : "bf16 rows are served by the one-wavefront-per-query kernel only (dim in {128,256,512,768,1024,1536}, rows <= 64 ids, ef <= 352)");
+                    : "bf16 rows are served by the one-wavefront-per-query kernel only (dim in {128,256,512,768,1024,1536}, rows <= 64 ids, ef <= 800)");
     if (ix->bitmap_dirty) {
         HIP_TRY(hipMemsetAsync(ix->d_bitmap, 0, (size_t)ix->max_batch * ix->words_per_query * 4, ix->stream));
         ix->bitmap_dirty = false;

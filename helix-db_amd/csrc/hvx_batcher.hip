@@ -6,8 +6,9 @@
 // coalesced here.  Results are exactly those of a direct batch call (queries are independent).
 //
 // Round 3 design (round 2's collector, not the device, was the limit: 418 k QPS = 28 % of the batch kernel):
-//   * NO lock and NO per-request object on the path of a caller.  One 64-bit word `state` = (batch sequence << 32 | slots
-//     claimed) is the whole queue: a caller claims slot `n` of the open batch with one compare-and-swap, copies its query
+//   * NO lock and NO per-request object on the path of a caller.  One 64-bit word `state` = (batch sequence << 16 | slots
+//     claimed; 48 sequence bits never wrap in practice -- round 4, ADVICE r3: a 32-bit sequence with a buffer count that is
+//     not a power of two skipped the drain test at the wrap) is the whole queue: a caller claims slot `n` of the open batch with one compare-and-swap, copies its query
 //     straight into the batch's PINNED staging row (the row the H2D copy reads), bumps `filled`, and sleeps on the batch's
 //     completion word (futex); a dispatcher closes the open batch with one compare-and-swap (sequence + 1, count 0), which
 //     at the same instant opens the next batch for the callers that keep arriving.
@@ -59,6 +60,7 @@ struct Batch {
     alignas(64) std::atomic<uint64_t> consumed{0}; // callers that copied their result out
     alignas(64) std::atomic<uint32_t> done{0};     // sequence + 1 of the last batch completed in this buffer (futex word)
     uint64_t total = 0;            // slots of all batches closed in this buffer (written by the closing dispatcher before `done`)
+    std::atomic<int64_t> t_first{0}; // steady-clock microseconds of the first claim of the open batch (max_wait_us)
     int rc = 0;                    // status of the launch as a whole
     std::string err;
 };
@@ -74,11 +76,17 @@ struct Lane {
 
 } // namespace
 
+constexpr unsigned kSeqShift = 16;               // state word: 48-bit batch sequence | 16-bit claimed slots
+constexpr uint64_t kCountMask = 0xFFFFull;
+inline int64_t now_us() {
+    return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 struct hvx_batcher {
     hvx_search_params params{};
     uint32_t max_batch = 0, max_wait_us = 0, dim = 0, k = 0, nbuf = 0;
     int device = 0;
-    alignas(64) std::atomic<uint64_t> state{0};      // (sequence of the open batch) << 32 | slots claimed
+    alignas(64) std::atomic<uint64_t> state{0};      // (sequence of the open batch) << 16 | slots claimed
     alignas(64) std::atomic<uint32_t> seq_word{0};   // low 32 bits of the open sequence: callers of a full batch sleep on it
     alignas(64) std::atomic<uint32_t> bell{0};       // dispatchers sleep on it; rung by the first and the last claim of a batch
     alignas(64) std::atomic<uint32_t> sleepers{0};   // dispatchers asleep on the bell
@@ -92,27 +100,38 @@ struct hvx_batcher {
         for (;;) {
             // this lane is free: take the open batch as soon as it holds a query
             uint64_t s = state.load();
-            uint32_t cnt = (uint32_t)s;
+            uint32_t cnt = (uint32_t)(s & kCountMask);
             if (cnt == 0) { // (sequentially consistent operations: a caller either sees this sleeper or this sleeper sees its claim)
                 if (stop.load()) return;
                 const uint32_t b0 = bell.load();
                 sleepers.fetch_add(1);
-                if ((uint32_t)state.load() == 0 && !stop.load()) futex_wait(&bell, b0, 2000);
+                if ((state.load() & kCountMask) == 0 && !stop.load()) futex_wait(&bell, b0, 2000);
                 sleepers.fetch_sub(1);
                 continue;
             }
-            const uint32_t seq = (uint32_t)(s >> 32);
+            const uint64_t seq = s >> kSeqShift;
+            // max_wait_us > 0: a batch that is not full keeps collecting until its first query has waited that long
+            if (max_wait_us && cnt < max_batch && !stop.load()) {
+                const int64_t waited = now_us() - bufs[seq % nbuf].t_first.load();
+                if (waited >= 0 && waited < (int64_t)max_wait_us) {
+                    const uint32_t b0 = bell.load();
+                    sleepers.fetch_add(1);
+                    if (state.load() == s) futex_wait(&bell, b0, (long)((int64_t)max_wait_us - waited));
+                    sleepers.fetch_sub(1);
+                    continue;
+                }
+            }
             // the next batch opens in buffer (seq + 1) % nbuf at the instant this one closes: it must be free, i.e. every
             // caller of the batch it held last has taken its rows
             Batch &next = bufs[(seq + 1) % nbuf];
-            if (seq + 1 >= nbuf) { // its previous batch (sequence seq + 1 - nbuf) must be complete and fully drained
-                if (next.done.load() != seq + 1 - nbuf + 1 || next.consumed.load() != next.total) {
+            if (seq + 1 >= nbuf && !stop.load()) { // its previous batch (sequence seq + 1 - nbuf) must be complete and fully drained
+                if (next.done.load() != (uint32_t)(seq + 1 - nbuf + 1) || next.consumed.load() != next.total) {
                     std::this_thread::yield();
                     continue;
                 }
             }
-            if (!state.compare_exchange_strong(s, (uint64_t)(seq + 1) << 32)) continue; // another claim or another lane won
-            seq_word.store(seq + 1);
+            if (!state.compare_exchange_strong(s, (seq + 1) << kSeqShift)) continue; // another claim or another lane won
+            seq_word.store((uint32_t)(seq + 1));
             futex_wake(&seq_word, INT_MAX); // callers that found the batch full
             Batch &bt = bufs[seq % nbuf];
             bt.total += cnt;
@@ -121,7 +140,7 @@ struct hvx_batcher {
             n_queries.fetch_add(cnt, std::memory_order_relaxed);
             if (cnt == max_batch) n_full.fetch_add(1, std::memory_order_relaxed);
             launch(ln, bt, cnt);
-            bt.done.store(seq + 1);
+            bt.done.store((uint32_t)(seq + 1));
             futex_wake(&bt.done, INT_MAX); // (a fan-out wake -- woken callers waking the rest -- was measured 10x SLOWER: a thousand
                                            //  threads calling FUTEX_WAKE on one word contend on its hash bucket; r03i/batcher_1m_c.log)
         }
@@ -169,6 +188,7 @@ extern "C" int hvx_batcher_new_lanes(hvx_index *ix, const hvx_search_params *par
     *out = nullptr;
     if (max_batch == 0) max_batch = ix->max_batch;
     if (max_batch > ix->max_batch) return fail(HVX_ERR_UNSUPPORTED, "batch %u exceeds max_batch %u given at import", max_batch, ix->max_batch);
+    if (max_batch > 0xFFFFu) max_batch = 0xFFFFu; // 16 count bits of the state word
     if (lanes == 0) lanes = 4;
     if (lanes > 8) return fail(HVX_ERR_K_RANGE, "at most 8 dispatcher lanes");
     int rc = check_k_ef(params->k, params->ef);
@@ -221,19 +241,21 @@ extern "C" int hvx_batcher_search(hvx_batcher *b, const float *query, uint64_t *
     if (!b || !query || !out_ids || !out_scores || !out_count) return fail(HVX_ERR_INVARIANT, "null argument");
     *out_count = 0;
     // claim a slot of the open batch
-    uint32_t seq, slot;
+    uint64_t seq;
+    uint32_t slot;
     for (;;) {
         if (b->stop.load(std::memory_order_acquire)) return fail(HVX_ERR_INVARIANT, "batcher is shutting down");
         uint64_t s = b->state.load();
-        seq = (uint32_t)(s >> 32);
-        slot = (uint32_t)s;
+        seq = s >> kSeqShift;
+        slot = (uint32_t)(s & kCountMask);
         if (slot >= b->max_batch) { // full: a lane closes it as soon as one is free; wait for the next batch to open
-            futex_wait(&b->seq_word, seq, 200);
+            futex_wait(&b->seq_word, (uint32_t)seq, 200);
             continue;
         }
         if (b->state.compare_exchange_weak(s, s + 1)) break;
     }
     Batch &bt = b->bufs[seq % b->nbuf];
+    if (slot == 0 && b->max_wait_us) bt.t_first.store(now_us());
     memcpy(bt.q + (size_t)slot * b->dim, query, (size_t)b->dim * 4);
     bt.filled.fetch_add(1);
     if ((slot == 0 || slot + 1 == b->max_batch) && b->sleepers.load()) { // first / last query of a batch: a sleeping lane should look
@@ -241,12 +263,15 @@ extern "C" int hvx_batcher_search(hvx_batcher *b, const float *query, uint64_t *
         futex_wake(&b->bell, 1);
     }
     // wait for the batch
+    const uint32_t want = (uint32_t)(seq + 1);
     for (;;) {
         const uint32_t d = bt.done.load(std::memory_order_acquire);
-        if (d == seq + 1) break;
+        if (d == want) break;
         futex_wait(&bt.done, d, 5000);
-        if (b->stop.load(std::memory_order_acquire) && bt.done.load(std::memory_order_acquire) != seq + 1)
+        if (b->stop.load(std::memory_order_acquire) && bt.done.load(std::memory_order_acquire) != want) {
+            bt.consumed.fetch_add(1); // the slot is accounted for: a dispatcher draining this buffer must not wait for it
             return fail(HVX_ERR_INVARIANT, "batcher is shutting down");
+        }
     }
     int rc = bt.rc;
     std::string err;

@@ -827,6 +827,87 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
     return HVX_OK;
 }
 
+// add_bidirectional_link on layer 0 of an existing image, through build_link_wg_kernel (include/helix_vec.h): the kernel that links
+// every batched build, driven link by link so that tests can hold each prune against the oracle's select_diverse + backfill.
+extern "C" int hvx_index_link_rows(hvx_index *ix, const uint64_t *from_ids, const uint64_t *to_ids, uint32_t n_links, uint32_t concurrent) {
+    if (!ix || (n_links && (!from_ids || !to_ids))) return fail(HVX_ERR_INVARIANT, "null argument");
+    if (n_links == 0) return HVX_OK;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    DevIndex &d = ix->dev;
+    if (ix->is_fork) return fail(HVX_ERR_UNSUPPORTED, "rows are linked through the handle that owns the image, not a fork");
+    const uint32_t m = ix->desc.m ? ix->desc.m : 16u;
+    const uint32_t m0 = std::max(ix->desc.m0 ? ix->desc.m0 : 2u * m, 2u * m);
+    const bool fused = d.fkernel == kKernelAvxFma;
+    const BuildKernels kern = pick_build_kernels(d.metric, fused);
+    const uint32_t ncmax = std::max(m0, m) + 1u;
+    const uint32_t nk_rows = d.dim_main >> 5;
+    const uint32_t link_ck = std::min<uint32_t>(8u, (nk_rows + 1u) & ~1u);
+    const uint32_t ldp = link_ck * 32u + 32u;
+    if (d.dtype != HVX_F32 || !kern.link_wg || ncmax > 33u || nk_rows == 0 || d.dim_main != d.dim || d.ld != d.dim || d.s0 < m0 ||
+        (size_t)(ncmax + 1u) * link_ck * 8u > 9u * 256u)
+        return fail(HVX_ERR_UNSUPPORTED, "the link workgroups serve f32 rows, L2 / cosine, dim %% 32 == 0, m0 <= 32 (row stride >= m0)");
+    std::vector<uint32_t> h_nodes(n_links), h_sel((size_t)n_links * 32u, kSentinel), h_cnt(n_links, 1u);
+    for (uint32_t i = 0; i < n_links; ++i) {
+        const uint32_t f = ix->find(from_ids[i]), t = ix->find(to_ids[i]);
+        if (f == kSentinel || t == kSentinel || f == t) return fail(HVX_ERR_INVARIANT, "link %u: unknown id or a self link", i);
+        h_nodes[i] = f;
+        h_sel[(size_t)i * 32u] = t;
+    }
+    hipStream_t s = ix->stream;
+    uint32_t *d_nodes = nullptr, *d_sel = nullptr, *d_cnt = nullptr, *d_locks = nullptr, *d_err = nullptr;
+    auto release = [&]() {
+        for (void *p : {(void *)d_nodes, (void *)d_sel, (void *)d_cnt, (void *)d_locks, (void *)d_err})
+            if (p) (void)hipFree(p);
+    };
+    auto bail = [&](int rc) { (void)hipStreamSynchronize(s); release(); return rc; };
+    if (hipMalloc((void **)&d_nodes, (size_t)n_links * 4) != hipSuccess || hipMalloc((void **)&d_sel, (size_t)n_links * 32 * 4) != hipSuccess ||
+        hipMalloc((void **)&d_cnt, (size_t)n_links * 4) != hipSuccess || hipMalloc((void **)&d_locks, (size_t)d.n * 4) != hipSuccess ||
+        hipMalloc((void **)&d_err, 4) != hipSuccess)
+        return bail(fail(HVX_ERR_DEVICE, "hipMalloc of the link scratch failed"));
+    if (hipMemcpyAsync(d_nodes, h_nodes.data(), (size_t)n_links * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(d_sel, h_sel.data(), h_sel.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(d_cnt, h_cnt.data(), (size_t)n_links * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemsetAsync(d_locks, 0, (size_t)d.n * 4, s) != hipSuccess || hipMemsetAsync(d_err, 0, 4, s) != hipSuccess)
+        return bail(fail(HVX_ERR_DEVICE, "upload of the link list failed"));
+    BuildArgs ba{};
+    ba.ix = d;
+    ba.l0 = const_cast<uint32_t *>(d.l0);
+    ba.up = const_cast<uint32_t *>(d.up);
+    ba.locks = d_locks;
+    ba.layers = 1; // layer 0 only
+    ba.sel = d_sel;
+    ba.sel_cnt = d_cnt;
+    ba.m = m;
+    ba.m0 = m0;
+    ba.err = d_err;
+    ba.ldp = ldp;
+    ba.ncmax = ncmax;
+    ba.link_ck = link_ck;
+    const size_t lds = link_lds_bytes(ldp, ncmax);
+    hipError_t e = hipSuccess;
+    if (concurrent) {
+        ba.nodes = d_nodes;
+        ba.b = n_links;
+        e = launch_link_wg(kern.link_wg, ba, 1, lds, s);
+    } else {
+        for (uint32_t i = 0; i < n_links && e == hipSuccess; ++i) { // one launch per link: launches on a stream run in order
+            ba.nodes = d_nodes + i;
+            ba.sel = d_sel + (size_t)i * 32u;
+            ba.sel_cnt = d_cnt + i;
+            ba.b = 1;
+            e = launch_link_wg(kern.link_wg, ba, 1, lds, s);
+        }
+    }
+    if (e != hipSuccess) return bail(fail(HVX_ERR_DEVICE, "link launch failed: %s", hipGetErrorString(e)));
+    uint32_t err = 0;
+    if (hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        return bail(fail(HVX_ERR_DEVICE, "link kernels failed: %s", hipGetErrorString(hipGetLastError())));
+    release();
+    if (err) return fail(HVX_ERR_INVARIANT, "a neighbour row overflowed its stride during the link step");
+    return HVX_OK;
+}
+
 // ---- graph read-back: what the host persists (values/vectors.rs rows) and what tests compare with the oracle ----
 extern "C" int hvx_index_graph_sizes(const hvx_index *cix, uint64_t *l0_edges, uint64_t *up_rows, uint64_t *up_edges,
                                      uint64_t *entry_point, uint32_t *max_layer, uint32_t *has_entry) {

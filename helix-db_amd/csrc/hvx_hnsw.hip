@@ -322,8 +322,15 @@ hipError_t launch_hnsw_wave_l2_ad(const HnswArgs &a, uint32_t b, const WaveGeom 
 hipError_t launch_hnsw_wave_cos_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_l2_bf16_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_cos_bf16_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_wide_l2(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);  // strict arm, beams of 448 / 832
+hipError_t launch_hnsw_wave_wide_cos(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_wide_l2_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_wide_cos_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 constexpr uint32_t kRngWords = 1024; // LDS window of the query RNG (hvx_hnsw_wave.h)
 
+// wide beams (round 4): the strict arm on the unrolled shapes runs register beams of 448 / 832 entries too (hvx_hnsw_wave_wide*.hip:
+// ef up to 800 = the reference's restricted-path limit; search.rs:267-1067 itself has no limit, ef beyond that takes the general kernel)
+static uint32_t wave_beam_limit(const HnswArgs &a) { return (a.adaptive || a.build_nodes || a.prof) ? 384u : 832u; }
 bool hnsw_wave_supported(const HnswArgs &a) {
     const DevIndex &ix = a.ix;
     if (ix.metric != kL2 && ix.metric != kCosine) return false;
@@ -333,7 +340,7 @@ bool hnsw_wave_supported(const HnswArgs &a) {
     const uint32_t nk = ix.dim >> 5;
     if (nk != 4 && nk != 8 && nk != 16 && nk != 24 && nk != 32 && nk != 48) return false;
     if (ix.s0 > 64 || ix.su > 64) return false;
-    if (a.ef + 32u > 384u) return false;
+    if (a.ef + 32u > wave_beam_limit(a)) return false;
     return true;
 }
 
@@ -357,6 +364,13 @@ static hipError_t launch_hnsw_wave_once(const HnswArgs &a, uint32_t b, hipStream
     const bool generic = a.adaptive && !hnsw_wave_supported(a);
     if (generic && g.log2cap > 14) g.log2cap = 14; // 64 KiB table (two workgroups per CU); larger visited sets spill to the bitmap
     if (a.build_nodes && g.log2cap > 13) g.log2cap = 13; // build searches (ef_construction ~200): keep four workgroups per CU
+    // the 448 / 832-entry register beams (hvx_hnsw_wave_wide*.hip): strict searches with ef 353..800, and the re-run of a 384-entry beam
+    const bool wide = !a.adaptive && !a.build_nodes && !a.prof && (a.ef + 32u > 384u || (a.only_flagged && a.ef + 32u > 192u));
+    // Unrolled builds: 8 192 slots (32 KiB) whatever the beam width -- FOUR wavefronts per CU, one per SIMD.  (Rounds 1-3 sized the
+    // table at 64 slots per beam entry: 64 KiB from ef = 129, 128 KiB from ef = 257, i.e. two / one wavefronts per CU, which is
+    // where the ef sweep lost its throughput; a search visits ~10 rows per expansion, ~14 slots per beam entry at 3/4 load.)  A
+    // query that visits more than 6 144 rows continues on the exact HBM bitmap.
+    if (!generic && g.log2cap > 13) g.log2cap = 13;
     if (a.log2cap >= 7 && a.log2cap <= 15) g.log2cap = a.log2cap; // HVX_OPT_WAVE_LOG2CAP: a tiny table exercises the spill path
     // 160 KiB / 4: exactly four resident wavefronts per CU, one per SIMD, each with the SIMD's whole register file.
     // occ = 2 (a.occupancy): eight per CU, two per SIMD -- the table shrinks until query + frontier + table fit 20 KiB
@@ -366,7 +380,7 @@ static hipError_t launch_hnsw_wave_once(const HnswArgs &a, uint32_t b, hipStream
         probe.ef = a.ef > a.build_ef_upper ? a.ef : a.build_ef_upper;
         build_generic = !hnsw_wave_supported(probe);
     }
-    g.occ = (a.occupancy == 2 && !a.adaptive && !a.prof && !build_generic) ? 2u : 1u;
+    g.occ = (a.occupancy == 2 && !a.adaptive && !a.prof && !build_generic && !wide) ? 2u : 1u;
     const size_t fixed = 512 + (size_t)a.ix.ld * 4 + (a.adaptive ? kRngWords * 4 : 0);
     if (g.occ == 2) {
         while (g.log2cap > 9 && ((size_t)4 << g.log2cap) + fixed > 20 * 1024) --g.log2cap;
@@ -378,6 +392,10 @@ static hipError_t launch_hnsw_wave_once(const HnswArgs &a, uint32_t b, hipStream
     if (a.build_nodes) {
         if (build_generic) return launch_hnsw_wave_build_gen(a, b, g, s);
         return g.occ == 2 ? launch_hnsw_wave_build_occ2(a, b, g, s) : launch_hnsw_wave_build(a, b, g, s);
+    }
+    if (wide) {
+        if (a.ix.dtype == HVX_BF16) return a.ix.metric == kL2 ? launch_hnsw_wave_wide_l2_bf16(a, b, g, s) : launch_hnsw_wave_wide_cos_bf16(a, b, g, s);
+        return a.ix.metric == kL2 ? launch_hnsw_wave_wide_l2(a, b, g, s) : launch_hnsw_wave_wide_cos(a, b, g, s);
     }
     if (g.occ == 2) return a.ix.dtype == HVX_BF16 ? launch_hnsw_wave_occ2_bf16(a, b, g, s) : launch_hnsw_wave_occ2(a, b, g, s);
     if (generic) {
@@ -397,19 +415,24 @@ static hipError_t launch_hnsw_wave_once(const HnswArgs &a, uint32_t b, hipStream
 }
 
 // The search launch + its re-run: a beam of 64*R entries holds ef + >= 32 of slack; a query that evicted an EQUAL-score
-// candidate past that slack (many duplicate vectors) may differ from the reference, so the kernel flags it and a second
-// launch -- whose wavefronts leave at once unless their query is flagged -- repeats it with the next beam size.  Queries that
-// overflow even that stay flagged (hvx_stats.tie_overflow_queries).
-hipError_t launch_hnsw_wave(const HnswArgs &a, uint32_t b, hipStream_t s) {
-    hipError_t e = launch_hnsw_wave_once(a, b, s);
-    if (e != hipSuccess || a.prof || a.build_nodes || !a.tie_flags) return e;
+// candidate past that slack (many duplicate vectors) may differ from the reference, so the kernel flags it, appends it to the
+// handle's re-run list, and a second launch -- whose workgroups leave at once beyond the end of the list -- searches the
+// listed queries again with the next beam size (unrolled strict builds 192 -> 384 -> 832, non-strict 192 -> 384, generic 192 ->
+// 448 -> 832).  Queries that overflow even that stay flagged (hvx_stats.tie_overflow_queries).
+hipError_t launch_hnsw_wave(const HnswArgs &a0, uint32_t b, hipStream_t s) {
+    HnswArgs a = a0;
     const bool generic = a.adaptive && !hnsw_wave_supported(a);
     const uint32_t need = a.ef + 32u;
-    const bool wider = generic ? need <= 448u : need <= 192u; // a wider instantiation exists
-    if (!wider) return e;
+    // a wider instantiation exists
+    const bool wider = generic ? need <= 448u : (a.adaptive ? need <= 192u : need <= 448u);
+    const bool rerun = !a.prof && !a.build_nodes && a.tie_flags && a.rerun_ctl && wider;
+    if (!rerun) a.rerun_ctl = nullptr; // the search launch lists nothing when nobody empties the list
+    hipError_t e = launch_hnsw_wave_once(a, b, s);
+    if (e != hipSuccess || !rerun) return e;
     HnswArgs r = a;
     r.only_flagged = 1;
-    r.occupancy = 1; // the wide-beam builds are budgeted for one query per SIMD
+    // the re-run keeps the launch's register budget where the wider build exists for it (two queries per SIMD: its few wavefronts
+    // fit next to the resident batches of the other lanes); the 832-entry beams are one-per-SIMD builds
     return launch_hnsw_wave_once(r, b, s);
 }
 

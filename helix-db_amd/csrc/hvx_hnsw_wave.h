@@ -474,8 +474,9 @@ __device__ __forceinline__ float candidate_probability_fn(uint32_t kind, float b
 // stored row of node build_nodes[q], the descent is greedy above min(level, max_layer) and a full beam
 // (search_layer_beam, mutation.rs:904-1005 -- the same algorithm as the strict layer-0 search) on every layer from
 // there down to 0; the first k entries of every layer's W (internal ids, scores) are written per layer.
-template <uint32_t METRIC, int R, int NK, bool BF, bool PROF = false, bool AD = false, bool ST = true, int OCC = 1, bool BUILD = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void hnsw_wave_kernel(HnswArgs a, uint32_t log2cap) {
+// One query's whole search on one wavefront (q = blockIdx.x, or the query a re-run workgroup picked from the re-run list).
+template <uint32_t METRIC, int R, int NK, bool BF, bool PROF, bool AD, bool ST, int OCC, bool BUILD>
+__device__ __forceinline__ void hnsw_wave_query(const HnswArgs &a, const uint32_t log2cap, const uint32_t q) {
     // rows per 8-lane group in flight: P*NK <= 24 float4 per lane for a narrow pass, x2 and x4 for wider
     // frontiers (4P*NK <= 96 float4 = 384 registers, VGPR+AGPR file of one wave per SIMD)
     // NK == 0: the GENERIC build -- any dimension (scalar tail, simple_avx.rs:172-177), any metric (Manhattan's sequential
@@ -488,7 +489,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
     constexpr bool kWide2 = OCC == 1 || 2 * P * NL <= 48; // 192 of the 256 registers of a half-SIMD wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const DevIndex &ix = a.ix;
-    const uint32_t q = blockIdx.x;
     const int lane = (int)threadIdx.x, grp = lane >> 3, j = lane & 7;
     const int slot = chunk_slot(j);
 
@@ -508,9 +508,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
     float *qs = fr_d + 64;                                 // [dim] query, 16-byte aligned
     uint32_t *rng_buf = reinterpret_cast<uint32_t *>(qs + (GEN ? ix.ld : (uint32_t)NK * 32u)); // [kRngWords] (AD only)
 
-    // re-run launch (launch_hnsw_wave): a query whose beam evicted equal-score candidates beyond its slack is searched
-    // again from scratch with a beam twice as wide; everybody else leaves at once
-    if (!BUILD && a.only_flagged && a.tie_flags[blockIdx.x] == 0u) return;
     const unsigned long long wclk0 = (a.wave_clock && !a.only_flagged) ? wall_clock64() : 0ull;
     const uint32_t status_in = BUILD ? 0u : (a.qstatus ? a.qstatus[q] : 0u);
     if (status_in != 0u || !ix.has_entry) {
@@ -995,12 +992,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
         if (a.out_status) a.out_status[q] = bad_score ? 8u /*HVX_ERR_INVARIANT*/ : 0u;
         if (a.qstats) a.qstats[q] = hvx_query_stats{st_exp, st_nb, st_vl, st_dc};
         if (a.tie_flags) a.tie_flags[q] = tie_overflow ? 1u : 0u;
+        // a query whose beam evicted equal-score candidates beyond its slack joins the re-run list (launch_hnsw_wave)
+        if (!BUILD && tie_overflow && a.rerun_ctl && !a.only_flagged) a.rerun_list[atomicAdd(&a.rerun_ctl[0], 1u)] = q;
         if (AD && ST && a.ad.stats) {
             A.st.rng_words = G.pos;
             A.st.txn_get_simhash_filter = A.reads;
             a.ad.stats[q] = A.st;
         }
     }
+}
+
+// The kernel.  A search launch runs one query per workgroup (q = blockIdx.x).  In the RE-RUN launch (a.only_flagged) workgroup i
+// searches the i-th query of the re-run list again, from scratch, with the next beam size; workgroups beyond the list leave at once
+// -- all of them on every corpus without masses of duplicate vectors.  Round 4: the list replaces "every wavefront tests its own
+// flag" and the re-run keeps the launch's register budget where a wider build exists for it: round 3's re-run was a one-query-
+// per-SIMD launch whose 1 024 exit-at-once workgroups each waited for an EMPTY SIMD behind the two-per-SIMD batches of the other
+// execution lanes (216 us per step on average; profiles/r03a_kernel_stats_hvx.csv).  The last workgroup hands the list back empty.
+// (A loop "one workgroup takes every n-th listed query" was tried first: it costs every instantiation 30-70 spilled SGPRs.)
+template <uint32_t METRIC, int R, int NK, bool BF, bool PROF = false, bool AD = false, bool ST = true, int OCC = 1, bool BUILD = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void hnsw_wave_kernel(HnswArgs a, uint32_t log2cap) {
+    uint32_t q = blockIdx.x;
+    if (!BUILD && a.only_flagged) {
+        const uint32_t listed = __hip_atomic_load(&a.rerun_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool mine = q < listed;
+        if (mine) q = a.rerun_list[q];
+        if (threadIdx.x == 0u && atomicAdd(&a.rerun_ctl[1], 1u) == gridDim.x - 1u) { // every workgroup has read the count
+            __hip_atomic_store(&a.rerun_ctl[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.rerun_ctl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!mine) return;
+    }
+    hnsw_wave_query<METRIC, R, NK, BF, PROF, AD, ST, OCC, BUILD>(a, log2cap, q);
 }
 
 // launch geometry shared by the per-metric translation units
@@ -1060,6 +1082,14 @@ static hipError_t launch_wave_r(const HnswArgs &a, uint32_t b, const WaveGeom &g
     const uint32_t need = a.ef + 32u; // beam capacity 64*R must hold ef plus slack for equal-score evictions
     if (need <= 192 && !a.only_flagged) return launch_wave_nk<METRIC, 3, BF, AD, ST, OCC>(a, b, g, s);
     if (need <= 384) return launch_wave_nk<METRIC, 6, BF, AD, ST, OCC>(a, b, g, s); // also the re-run of an R = 3 launch: slack 32 -> 224+
+    return hipErrorInvalidValue;
+}
+// wide register beams of the strict arm (round 4; hvx_hnsw_wave_wide_*.hip): 448 entries (ef <= 416) and 832 entries (ef <= 800), one
+// query per SIMD; the 832-entry build is also the re-run of a 384- or 448-entry launch
+template <uint32_t METRIC, bool BF> static hipError_t launch_wave_wide_r(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
+    const uint32_t need = a.ef + 32u;
+    if (need <= 448 && !a.only_flagged) return launch_wave_nk<METRIC, 7, BF>(a, b, g, s);
+    if (need <= 832) return launch_wave_nk<METRIC, 13, BF>(a, b, g, s);
     return hipErrorInvalidValue;
 }
 // GENERIC build of the non-strict arms: beam of 64*R >= ef + 32 entries

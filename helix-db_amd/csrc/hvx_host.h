@@ -187,7 +187,7 @@ struct RestrictedPlan {
     walk::Plan p;
 };
 // restricted_execution_plan_with_beam_percent (restricted.rs:426-453) for a candidate population (ids incl. unindexed ones)
-int restricted_make_plan(const hvx_restricted_params &rp, uint64_t candidates, uint32_t dim, RestrictedPlan *out);
+int restricted_make_plan(const hvx_restricted_params &rp, uint64_t candidates, uint32_t dim, RestrictedPlan *out, const hvx_index *ix = nullptr);
 // deterministic_sample_ids (restricted.rs:321-342) as ranks into the ascending candidate list
 void restricted_sample_ranks(uint64_t candidates, uint32_t count, std::vector<uint64_t> &out);
 // run a plan for b host-resident queries over ONE candidate set given as device rows (ascending); d_samples = the plan's

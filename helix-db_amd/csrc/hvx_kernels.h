@@ -44,6 +44,8 @@ struct HnswArgs {
     uint32_t *out_status;      // [b] nullable
     hvx_query_stats *qstats;   // [b] nullable
     uint32_t *tie_flags;       // [b] nullable
+    uint32_t *rerun_list;      // wave kernel: [b] queries whose beam overflowed on equal scores, appended by the search launch ...
+    uint32_t *rerun_ctl;       // ... [0] their number, [1] workgroups of the re-run launch that are done; NULL = no re-run follows
     unsigned long long *prof;  // [b][8] phase cycle counters of the PROF kernel variant, nullable
     unsigned long long *wave_clock; // [b][2] constant-rate (100 MHz) clock at the start / end of every query's wavefront, nullable
     uint32_t adaptive;         // 0 = strict-exhaustive search; 1 = non-strict arms, policy in `ad`

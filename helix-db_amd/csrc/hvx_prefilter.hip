@@ -1156,7 +1156,7 @@ static int prefilter_search_impl(const hvx_index *cix, const hvx_csr *cg, const 
     HIP_TRY(hipGetLastError());
     // restricted_execution_plan_with_beam_percent (restricted.rs:426-453) over the candidate population
     RestrictedPlan plan;
-    if ((rc = restricted_make_plan(rp, population, ix->dev.dim, &plan))) return rc;
+    if ((rc = restricted_make_plan(rp, population, ix->dev.dim, &plan, ix))) return rc;
     (void)kk;
     const uint32_t *d_samples = nullptr;
     if (plan.strategy == HVX_RESTRICTED_FILTERED && plan.p.n_sample) {

@@ -254,7 +254,12 @@ __global__ void gather_rows_kernel(const uint32_t *rows, const uint32_t *ranks, 
 using HostPlan = hvx::RestrictedPlan;
 
 // restricted_execution_plan_with_beam_percent (restricted.rs:426-453) + FilteredGraphBudgets::with_beam_percent (:230-259)
-int make_plan(const hvx_restricted_params &rp, uint64_t candidates, uint32_t dim, HostPlan *out) {
+bool walk_supported(const hvx_index *ix);
+// `ix` (nullable): the handle the plan will run on.  An AUTO plan without explicit budgets that the walk of this build cannot
+// run -- budgets beyond the LDS-resident queues (k >= 301 or ef > 800 under the reference's own budget rule), rows that are not
+// f32, neighbour rows beyond the walk's width -- is answered by the EXACT gathered scan instead (round 4): a superset
+// of the walk's answer in recall, reported as strategy EXACT.  Explicit budgets / strategy FILTERED outside the limits stay errors.
+int make_plan(const hvx_restricted_params &rp, uint64_t candidates, uint32_t dim, HostPlan *out, const hvx_index *ix = nullptr) {
     HostPlan hp{};
     const uint64_t kk = std::min<uint64_t>(rp.k, candidates);
     hp.p.k = (uint32_t)kk;
@@ -284,8 +289,17 @@ int make_plan(const hvx_restricted_params &rp, uint64_t candidates, uint32_t dim
         hp.p.sampled_seeds = (uint32_t)std::min<uint64_t>(64, candidates);
         hp.p.directory_seeds = (uint32_t)std::min<uint64_t>(256, candidates);
     }
-    if (hp.p.vector_payloads > walk::kScoredCap || hp.p.sampled_seeds > walk::kSeedCap || hp.p.directory_seeds > walk::kSeedCap ||
-        hp.p.bridge_rows > kMaxBridgeRows)
+    const bool beyond = hp.p.vector_payloads > walk::kScoredCap || hp.p.sampled_seeds > walk::kSeedCap || hp.p.directory_seeds > walk::kSeedCap ||
+                        hp.p.bridge_rows > kMaxBridgeRows;
+    if (rp.strategy == HVX_RESTRICTED_AUTO && !rp.explicit_budgets && (beyond || (ix && !walk_supported(ix)))) {
+        HostPlan ex{};
+        ex.p.k = hp.p.k;
+        ex.p.directory_enabled = hp.p.directory_enabled;
+        ex.strategy = HVX_RESTRICTED_EXACT;
+        *out = ex;
+        return HVX_OK;
+    }
+    if (beyond)
         return fail(HVX_ERR_UNSUPPORTED, "filtered walk budgets outside this build: vector_payloads %u (<= %u), sampled / directory seeds %u / %u "
                     "(<= %u), bridge_rows %u (<= %u)", hp.p.vector_payloads, walk::kScoredCap, hp.p.sampled_seeds, hp.p.directory_seeds,
                     walk::kSeedCap, hp.p.bridge_rows, kMaxBridgeRows);
@@ -494,7 +508,7 @@ int restricted_set(hvx_index *ix, const float *queries, uint32_t b, const hvx_re
     if (kk == 0) return fail(HVX_ERR_K_RANGE, "result count must be non-zero");
     if (kk > 800) return fail(HVX_ERR_K_RANGE, "restricted vector search result count %u is above the maximum 800", kk);
     HostPlan hp;
-    int rc = make_plan(rp, ids.size(), ix->dev.dim, &hp);
+    int rc = make_plan(rp, ids.size(), ix->dev.dim, &hp, ix);
     if (rc) return rc;
     // ids that are not indexed are omitted from the scan (restricted.rs:615-659) but count as candidates for the plan
     std::vector<uint32_t> subset;
@@ -527,8 +541,8 @@ int restricted_set(hvx_index *ix, const float *queries, uint32_t b, const hvx_re
 
 } // namespace
 
-int hvx::restricted_make_plan(const hvx_restricted_params &rp, uint64_t candidates, uint32_t dim, RestrictedPlan *out) {
-    return make_plan(rp, candidates, dim, out);
+int hvx::restricted_make_plan(const hvx_restricted_params &rp, uint64_t candidates, uint32_t dim, RestrictedPlan *out, const hvx_index *ix) {
+    return make_plan(rp, candidates, dim, out, ix);
 }
 void hvx::restricted_sample_ranks(uint64_t candidates, uint32_t count, std::vector<uint64_t> &out) { sample_ranks(candidates, count, out); }
 int hvx::restricted_run_plan(hvx_index *ix, const float *queries, uint32_t b, uint32_t k_stride, const RestrictedPlan &plan, const uint32_t *d_rows,

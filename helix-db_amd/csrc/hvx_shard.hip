@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "hvx_host.h"
@@ -163,6 +164,16 @@ __global__ void merge_status_kernel(const char *gathered, size_t payload, size_t
     if (st) out_counts[q] = 0;
 }
 
+// A step NEVER returns before the exchange (round 4): a rank whose local search failed still joins the all-gather --
+// with no results and the status word HVX_SHARD_RANK_FAILED | code for every query -- so the other ranks are not left blocked in
+// the collective; the element-wise maximum carries the failure to every rank's out_status, the failing rank returns its code.
+__global__ void fill_failure_kernel(uint32_t *counts, uint32_t *status, uint32_t b, uint32_t word) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= b) return;
+    counts[q] = 0u;
+    status[q] = word;
+}
+
 struct StepBuffers {
     uint64_t *ids;
     float *scores;
@@ -204,6 +215,16 @@ int exchange_and_merge(hvx_shard_group *g, uint32_t b, uint32_t k, const StepBuf
     return HVX_OK;
 }
 
+// local search failed with `rc`: publish the failure through the exchange, then hand the original status + message back
+int exchange_failure(hvx_shard_group *g, uint32_t b, uint32_t k, const StepBuffers &v, int rc, uint64_t *d_out_ids, float *d_out_scores,
+                     uint32_t *d_out_counts, uint32_t *d_out_status) {
+    const std::string msg = hvx_last_error();
+    hipLaunchKernelGGL(fill_failure_kernel, dim3((b + 255u) / 256u), dim3(256), 0, g->ix->stream, v.counts, v.status, b,
+                       (uint32_t)HVX_SHARD_RANK_FAILED | ((uint32_t)rc & 0xFFu));
+    (void)exchange_and_merge(g, b, k, v, d_out_ids, d_out_scores, d_out_counts, d_out_status); // best effort: the others must not hang
+    return fail(rc, "%s", msg.c_str());
+}
+
 int check_step(hvx_shard_group *g, const void *q, const void *a, const void *b_, const void *c, uint32_t b, uint32_t k) {
     if (!g || !q || !a || !b_ || !c) return fail(HVX_ERR_INVARIANT, "null argument");
     if (b > g->max_batch || k > g->max_k) return fail(HVX_ERR_UNSUPPORTED, "batch %u / k %u exceed the group's %u / %u", b, k, g->max_batch, g->max_k);
@@ -222,7 +243,8 @@ extern "C" int hvx_shard_group_search_batch_device(hvx_shard_group *g, const flo
     std::lock_guard<std::mutex> lock(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));
     const StepBuffers v = step_views(g, b, k);
-    if ((rc = enqueue_search(ix, d_queries, b, k, ef, v.ids, v.scores, v.counts, v.status, nullptr, false))) return rc;
+    if ((rc = enqueue_search(ix, d_queries, b, k, ef, v.ids, v.scores, v.counts, v.status, nullptr, false)))
+        return exchange_failure(g, b, k, v, rc, d_out_ids, d_out_scores, d_out_counts, d_out_status);
     return exchange_and_merge(g, b, k, v, d_out_ids, d_out_scores, d_out_counts, d_out_status);
 }
 
@@ -236,7 +258,8 @@ extern "C" int hvx_shard_group_search_batch_params_device(hvx_shard_group *g, co
     std::lock_guard<std::mutex> lock(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));
     const StepBuffers v = step_views(g, b, params->k);
-    if ((rc = enqueue_search_params(ix, d_queries, b, params, v.ids, v.scores, v.counts, v.status))) return rc;
+    if ((rc = enqueue_search_params(ix, d_queries, b, params, v.ids, v.scores, v.counts, v.status)))
+        return exchange_failure(g, b, params->k, v, rc, d_out_ids, d_out_scores, d_out_counts, d_out_status);
     return exchange_and_merge(g, b, params->k, v, d_out_ids, d_out_scores, d_out_counts, d_out_status);
 }
 
@@ -252,7 +275,8 @@ extern "C" int hvx_shard_group_flat_search_batch_device(hvx_shard_group *g, cons
     const StepBuffers v = step_views(g, b, k);
     // the exact scan of this shard's rows (restricted_exact_scan with allowed = the shard, restricted.rs:753-835); it synchronises
     // internally only to read its certificates
-    if ((rc = flat_scan_device(ix, d_queries, b, k, nullptr, ix->dev.n, v.ids, v.scores, v.counts, v.status, false))) return rc;
+    if ((rc = flat_scan_device(ix, d_queries, b, k, nullptr, ix->dev.n, v.ids, v.scores, v.counts, v.status, false)))
+        return exchange_failure(g, b, k, v, rc, d_out_ids, d_out_scores, d_out_counts, d_out_status);
     return exchange_and_merge(g, b, k, v, d_out_ids, d_out_scores, d_out_counts, d_out_status);
 }
 
@@ -278,41 +302,64 @@ extern "C" int hvx_shard_group_search_restricted_batch(hvx_shard_group *g, const
     const uint64_t lo = ix->desc.shard_id_lo, hi = ix->desc.shard_id_hi;
     const auto first = std::lower_bound(ids.begin(), ids.end(), lo), last = std::upper_bound(ids.begin(), ids.end(), hi);
     const std::vector<uint64_t> mine(first, last);
-    std::vector<uint64_t> l_ids((size_t)b * k);
-    std::vector<float> l_sc((size_t)b * k);
+    // local answer over this shard's slice, staged in PINNED memory (a pageable hipMemcpyAsync is a synchronous staged copy).  A
+    // local failure (SimHash rows not attached on this shard, a plan limit of this slice ...) does NOT return here: the other ranks
+    // may have planned differently (a small slice scans exactly, an empty one skips the call) and are on their way into the
+    // all-gather.  It travels as the status word of every query instead, and every rank fails after the merge.
+    const size_t n_o = (size_t)b * k;
+    const size_t off_sc = n_o * 8, off_cnt = off_sc + n_o * 4, off_st = off_cnt + (size_t)b * 4,
+                 bytes = (off_st + (size_t)b * 4 + 7) & ~(size_t)7;
+    std::vector<uint64_t> l_ids(n_o);
+    std::vector<float> l_sc(n_o);
     std::vector<uint32_t> l_cnt(b, 0), l_st(b, 0);
+    int local_rc = HVX_OK;
+    std::string local_msg;
     if (!mine.empty()) {
         hvx_restricted_params lp = *params;
         lp.k = k;
         if (lp.ef < k) lp.ef = k;
-        int rc = hvx_search_restricted_batch_params(ix, queries, b, &lp, mine.data(), nullptr, mine.size(), l_ids.data(), l_sc.data(), l_cnt.data(),
-                                                    l_st.data(), nullptr, nullptr);
-        if (rc) return rc;
+        local_rc = hvx_search_restricted_batch_params(ix, queries, b, &lp, mine.data(), nullptr, mine.size(), l_ids.data(), l_sc.data(), l_cnt.data(),
+                                                      l_st.data(), nullptr, nullptr);
+        if (local_rc) {
+            local_msg = hvx_last_error();
+            std::fill(l_cnt.begin(), l_cnt.end(), 0u);
+            std::fill(l_st.begin(), l_st.end(), (uint32_t)HVX_SHARD_RANK_FAILED | ((uint32_t)local_rc & 0xFFu));
+        }
     }
     std::lock_guard<std::mutex> lock(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));
-    const StepBuffers v = step_views(g, b, k);
-    HIP_TRY(hipMemcpyAsync(v.ids, l_ids.data(), l_ids.size() * 8, hipMemcpyHostToDevice, ix->stream));
-    HIP_TRY(hipMemcpyAsync(v.scores, l_sc.data(), l_sc.size() * 4, hipMemcpyHostToDevice, ix->stream));
-    HIP_TRY(hipMemcpyAsync(v.counts, l_cnt.data(), (size_t)b * 4, hipMemcpyHostToDevice, ix->stream));
-    HIP_TRY(hipMemcpyAsync(v.status, l_st.data(), (size_t)b * 4, hipMemcpyHostToDevice, ix->stream));
-    int rc = ix->stage(b, k);
+    int rc = ix->pin(2 * bytes);
     if (rc) return rc;
+    unsigned char *h_in = ix->h_pin, *h_out = ix->h_pin + bytes;
+    memcpy(h_in, l_ids.data(), n_o * 8);
+    memcpy(h_in + off_sc, l_sc.data(), n_o * 4);
+    memcpy(h_in + off_cnt, l_cnt.data(), (size_t)b * 4);
+    memcpy(h_in + off_st, l_st.data(), (size_t)b * 4);
+    const StepBuffers v = step_views(g, b, k);
+    HIP_TRY(hipMemcpyAsync(v.ids, h_in, n_o * 8, hipMemcpyHostToDevice, ix->stream));
+    HIP_TRY(hipMemcpyAsync(v.scores, h_in + off_sc, n_o * 4, hipMemcpyHostToDevice, ix->stream));
+    HIP_TRY(hipMemcpyAsync(v.counts, h_in + off_cnt, (size_t)b * 4, hipMemcpyHostToDevice, ix->stream));
+    HIP_TRY(hipMemcpyAsync(v.status, h_in + off_st, (size_t)b * 4, hipMemcpyHostToDevice, ix->stream));
+    if ((rc = ix->stage(b, k))) return rc;
     if ((rc = exchange_and_merge(g, b, k, v, ix->s_ids, ix->s_scores, ix->s_counts, ix->s_status))) return rc;
-    std::vector<uint64_t> m_ids((size_t)b * k);
-    std::vector<float> m_sc((size_t)b * k);
-    std::vector<uint32_t> m_cnt(b), m_st(b);
-    HIP_TRY(hipMemcpyAsync(m_ids.data(), ix->s_ids, m_ids.size() * 8, hipMemcpyDeviceToHost, ix->stream));
-    HIP_TRY(hipMemcpyAsync(m_sc.data(), ix->s_scores, m_sc.size() * 4, hipMemcpyDeviceToHost, ix->stream));
-    HIP_TRY(hipMemcpyAsync(m_cnt.data(), ix->s_counts, (size_t)b * 4, hipMemcpyDeviceToHost, ix->stream));
-    HIP_TRY(hipMemcpyAsync(m_st.data(), ix->s_status, (size_t)b * 4, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipMemcpyAsync(h_out, ix->s_ids, n_o * 8, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipMemcpyAsync(h_out + off_sc, ix->s_scores, n_o * 4, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipMemcpyAsync(h_out + off_cnt, ix->s_counts, (size_t)b * 4, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipMemcpyAsync(h_out + off_st, ix->s_status, (size_t)b * 4, hipMemcpyDeviceToHost, ix->stream));
     HIP_TRY(hipStreamSynchronize(ix->stream));
+    if (local_rc) return fail(local_rc, "%s", local_msg.c_str());
+    const uint64_t *m_ids = reinterpret_cast<const uint64_t *>(h_out);
+    const float *m_sc = reinterpret_cast<const float *>(h_out + off_sc);
+    const uint32_t *m_cnt = reinterpret_cast<const uint32_t *>(h_out + off_cnt), *m_st = reinterpret_cast<const uint32_t *>(h_out + off_st);
+    for (uint32_t q = 0; q < b; ++q) // another shard failed: every rank of the group reports it
+        if (m_st[q] & HVX_SHARD_RANK_FAILED)
+            return fail((int)(m_st[q] & 0xFFu), "a shard of the group failed its local restricted search with status %u", m_st[q] & 0xFFu);
     for (uint32_t q = 0; q < b; ++q) {
         out_counts[q] = m_st[q] ? 0u : m_cnt[q];
         if (out_status) out_status[q] = m_st[q];
         else if (m_st[q]) return fail((int)m_st[q], "query %u rejected with status %u", q, m_st[q]);
-        memcpy(out_ids + (size_t)q * params->k, m_ids.data() + (size_t)q * k, (size_t)out_counts[q] * 8);
-        memcpy(out_scores + (size_t)q * params->k, m_sc.data() + (size_t)q * k, (size_t)out_counts[q] * 4);
+        memcpy(out_ids + (size_t)q * params->k, m_ids + (size_t)q * k, (size_t)out_counts[q] * 8);
+        memcpy(out_scores + (size_t)q * params->k, m_sc + (size_t)q * k, (size_t)out_counts[q] * 4);
     }
     return HVX_OK;
 }

@@ -116,6 +116,16 @@ class BuildStats(C.Structure):  # hvx_build_stats
     _fields_ = [("nodes", C.c_uint64), ("batches", C.c_uint64), ("single_node_batches", C.c_uint64)]
 
 
+class GraphAudit(C.Structure):  # hvx_graph_audit
+    _fields_ = [(n, C.c_uint64) for n in ("nodes", "up_rows", "edges_l0", "edges_up", "asymmetric_edges_l0", "asymmetric_edges_up",
+                                          "unsorted_entries", "self_loops", "out_of_range_ids", "holes", "level_violations",
+                                          "degree_overflow_rows", "unreachable_l0")] + \
+               [(n, C.c_uint32) for n in ("max_degree_l0", "max_degree_up", "bfs_levels_l0", "max_layer", "has_entry", "reserved")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_ if n != "reserved"}
+
+
 class AdaptiveStats(C.Structure):  # hvx_adaptive_stats
     _fields_ = [(n, C.c_uint32) for n in (
         "simhash_filtered", "simhash_examined", "simhash_passed_before_sampling", "simhash_passed_after_sampling",
@@ -197,6 +207,10 @@ def lib():
                                         C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.hvx_index_export_graph.restype = C.c_int
     L.hvx_index_export_graph.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp]
+    L.hvx_index_link_rows.restype = C.c_int
+    L.hvx_index_link_rows.argtypes = [_vp, _vp, _vp, C.c_uint32, C.c_uint32]
+    L.hvx_index_audit_graph.restype = C.c_int
+    L.hvx_index_audit_graph.argtypes = [_vp, C.POINTER(GraphAudit)]
     L.hvx_shard_group_unique_id.restype = C.c_int
     L.hvx_shard_group_unique_id.argtypes = [_vp]
     L.hvx_shard_group_init.restype = C.c_int
@@ -530,6 +544,19 @@ class ValidatedVectorReadIndex:
         _check(lib().hvx_index_export_graph(self._h, _ptr(l0o), _ptr(l0n), _ptr(lv), _ptr(uo), _ptr(un)))
         return {"l0_offsets": l0o, "l0_neighbors": l0n[: e0.value], "level": lv[: self.n], "up_offsets": uo, "up_neighbors": un[: eu.value],
                 "entry_point": int(ep.value) if he.value else None, "max_layer": int(ml.value)}
+
+    def link_rows(self, from_ids, to_ids, concurrent=False):
+        """add_bidirectional_link(from -> to) on layer 0 through the batched build's link kernel (hvx_index_link_rows)."""
+        f = np.ascontiguousarray(from_ids, dtype=np.uint64)
+        t = np.ascontiguousarray(to_ids, dtype=np.uint64)
+        assert f.size == t.size
+        _check(lib().hvx_index_link_rows(self._h, _ptr(f), _ptr(t), f.size, 1 if concurrent else 0))
+
+    def audit_graph(self) -> dict:
+        """Row invariants, symmetry on every layer and layer-0 reachability of the graph image, counted on the device."""
+        a = GraphAudit()
+        _check(lib().hvx_index_audit_graph(self._h, C.byref(a)))
+        return a.as_dict()
 
     @classmethod
     def from_export(cls, ex: dict, *, dim, metric, **kw):

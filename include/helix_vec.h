@@ -293,6 +293,10 @@ int hvx_search_restricted_batch(const hvx_index *, const float *queries, uint32_
  * the reference CPU path's.  Needs the SimHash rows (hvx_index_set_simhash; missing => HVX_ERR_INVARIANT like the
  * reference's missing_simhash_error) and f32 rows; strategy EXACT forces the device's exact gathered scan for any
  * candidate-set size (what hvx_search_restricted_batch does), FILTERED forces the walk (the reference's tests call it that way).
+ * An AUTO plan (no explicit budgets) that the walk of this build cannot run -- the reference's own budget rule gives
+ * bridge_rows = 8 x max(1.5 ef, 4 k) > 9 600 for k >= 301 or ef > 800; bf16 / fp8 rows; neighbour rows beyond the walk's width
+ * -- is answered by the exact gathered scan (a superset of the walk's answer in recall; hvx_restricted_stats.strategy says
+ * EXACT), never by an error: the reference serves k up to 800 (MAX_RESTRICTED_RESULT_COUNT, restricted.rs:55).
  */
 enum hvx_restricted_strategy { HVX_RESTRICTED_AUTO = 0, HVX_RESTRICTED_EXACT = 1, HVX_RESTRICTED_FILTERED = 2 };
 /* RestrictedSearchTermination (restricted.rs:131-143) */
@@ -347,6 +351,12 @@ int hvx_merge_topk_packed_device(const hvx_index *, uint32_t g, uint32_t b, uint
  * none.  The group borrows the shard handle (use one handle -- e.g. one hvx_index_fork lane -- per group).
  */
 #define HVX_SHARD_UNIQUE_ID_BYTES 128
+/* A rank whose LOCAL search fails still joins the exchange (the others would block in the all-gather otherwise): its payload
+ * carries no results and, for every query, the status word HVX_SHARD_RANK_FAILED | its hvx_status.  The failing rank returns
+ * that status from the call; on the other ranks the device-output steps return HVX_OK with d_out_status[q] = the marked word
+ * and count 0 for every query (pass d_out_status when shards can fail independently), the host-output restricted step
+ * returns the failed shard's status on EVERY rank. */
+#define HVX_SHARD_RANK_FAILED 0x100u
 typedef struct hvx_shard_group hvx_shard_group;
 int hvx_shard_group_unique_id(uint8_t *out /*[HVX_SHARD_UNIQUE_ID_BYTES]*/);
 int hvx_shard_group_init(hvx_index *local_shard, const uint8_t *unique_id, uint32_t rank, uint32_t world, uint32_t max_batch, uint32_t max_k,
@@ -450,13 +460,16 @@ int hvx_prefilter_search_batch_params(const hvx_index *, const hvx_csr *, const 
 /*
  * Batching operator: the reference calls ValidatedVectorReadIndex::search once per operator invocation
  * from many tokio tasks (access/search/storage.rs:140-163).  Concurrent single-query callers are coalesced into ONE
- * hvx_search_batch_params launch: a caller blocks in hvx_batcher_search until its rows are ready; a dispatcher thread
- * launches when max_batch (0 = the index's max_batch) queries wait or the oldest has waited max_wait_us.  All callers of
- * one batcher share `params`.  Thread-safe; results equal a direct batch call's.  A rejected query fails alone.
+ * hvx_search_batch_params launch: a caller blocks in hvx_batcher_search until its rows are ready.  A dispatcher lane that
+ * is FREE takes the open batch as soon as it is full (max_batch, 0 = the index's max_batch, at most 65 535) or -- when it is
+ * not full -- as soon as its first query has waited max_wait_us (0 = at once: while every lane is busy the open batch
+ * simply keeps growing, so the batch size follows the load; a positive value trades that much latency for larger batches).
+ * All callers of one batcher share `params`.  Thread-safe; results equal a direct batch call's.  A rejected query fails
+ * alone.  hvx_batcher_free may be called while callers are blocked: they return HVX_ERR_INVARIANT.
  */
 typedef struct hvx_batcher hvx_batcher;
 int hvx_batcher_new(hvx_index *, const hvx_search_params *params, uint32_t max_batch, uint32_t max_wait_us, hvx_batcher **out);
-/* the same with an explicit number of dispatcher lanes (1..8; 0 = 2): every lane is an hvx_index_fork of the index with its own
+/* the same with an explicit number of dispatcher lanes (1..8; 0 = 4): every lane is an hvx_index_fork of the index with its own
  * dispatcher thread, so batch i+1 is collected and launched while batch i runs.  Attach SimHash rows before creating it. */
 int hvx_batcher_new_lanes(hvx_index *, const hvx_search_params *params, uint32_t max_batch, uint32_t max_wait_us, uint32_t lanes,
                           hvx_batcher **out);
@@ -552,6 +565,33 @@ void hvx_build_params_default(hvx_build_params *);
 int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_ids, const float *vectors /*host or device*/,
                     const uint16_t *levels /*[n] or NULL = all layer 0*/, const hvx_build_params *params, hvx_index **out,
                     hvx_build_stats *stats /*nullable*/);
+/*
+ * add_bidirectional_link(from -> to) on layer 0 of an index image (mutation.rs:1498-1583): `from` is appended to the row of
+ * `to` under the row's lock; a row beyond Mmax is pruned (rank by distance to the owner, select_diverse + backfill,
+ * mod.rs:809-856), and every neighbour the prune drops loses its reverse edge (mutation.rs:1890-1908).  It runs the kernel the
+ * BATCHED build links with (one 256-thread workgroup per link, the prune evaluated eagerly from LDS): the links are applied one
+ * launch after the other in list order (concurrent = 0: a defined order, what the parity tests compare with the oracle's
+ * select_diverse) or all in ONE launch (concurrent = 1: the batched build's situation -- rows change under their locks in an
+ * undefined order).  Served shapes = the workgroup kernel's: f32 rows, L2 / cosine, dim % 32 == 0, m0 <= 32.  The index must
+ * not be searched concurrently.
+ */
+int hvx_index_link_rows(hvx_index *, const uint64_t *from_ids, const uint64_t *to_ids, uint32_t n_links, uint32_t concurrent);
+/*
+ * Audit of a graph image on the device: the invariants of every persisted row (neighbor_set.rs:1-9: ascending, deduped,
+ * self-free, degree-bounded; mutation.rs:1498-1583,1890-1908: links are bidirectional on their layer) and reachability of every
+ * node from the entry point on layer 0.  A graph the reference could have written has every counter below `bfs_levels_l0` at 0
+ * (unreachable_l0 may be > 0 for a reference-built graph too: HNSW does not guarantee connectivity).
+ */
+typedef struct hvx_graph_audit {
+    uint64_t nodes, up_rows, edges_l0, edges_up;
+    uint64_t asymmetric_edges_l0, asymmetric_edges_up; /* u lists v on a layer, v does not list u there */
+    uint64_t unsorted_entries;      /* an id not greater than its predecessor in the row (covers duplicates) */
+    uint64_t self_loops, out_of_range_ids, holes /* a valid id behind padding */, level_violations /* edge to a node below the layer */;
+    uint64_t degree_overflow_rows;  /* rows longer than m0 (layer 0) / m (upper layers) */
+    uint64_t unreachable_l0;        /* nodes a layer-0 BFS from the entry point does not reach */
+    uint32_t max_degree_l0, max_degree_up, bfs_levels_l0, max_layer, has_entry, reserved;
+} hvx_graph_audit;
+int hvx_index_audit_graph(const hvx_index *, hvx_graph_audit *out);
 /* Read the graph of an index back in hvx_index_import's CSR layout (external ids, rows ascending): sizes first, then the arrays
  * (l0_offsets [n+1], l0_neighbors [l0_edges], level [n] nullable, up_offsets [up_rows+1] / up_neighbors [up_edges] nullable). */
 int hvx_index_graph_sizes(const hvx_index *, uint64_t *l0_edges, uint64_t *up_rows, uint64_t *up_edges, uint64_t *entry_point,

@@ -721,3 +721,35 @@ def test_tenant_scoped_keys_and_the_metadata_row():
     with pytest.raises(hv.HelixDbError) as e:
         hv.Hydrator(3, hv.EUCLIDEAN).set_metadata(v2)
     assert e.value.status == hv.ERR_DIMENSION
+
+
+def test_integration_rust_block_declares_every_export():
+    """INTEGRATION.md section 2 is the binding a maintainer pastes into crates/db/src/search/vector/gpu/ffi.rs.  Every
+    function the header declares -- and the .so exports -- must be in its `extern "C"` block with the right arity and argument
+    types (C -> Rust type map of scripts/gen_rust_ffi.py); a declaration that drifts from the header fails here."""
+    import importlib.util
+    import subprocess
+    spec = importlib.util.spec_from_file_location("gen_rust_ffi", os.path.join(ROOT, "scripts", "gen_rust_ffi.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    hdr = open(os.path.join(ROOT, "include", "helix_vec.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = doc[doc.index('#[link(name = "helix_vec_gfx950")]'):]
+    block = block[:block.index("```")]
+    got = gen.parse_rust_fns(block)
+    protos = gen.c_prototypes(hdr)
+    want = {n: ([gen.rust_type(t) for t, _ in p], None if r == "void" else gen.rust_type(r)) for n, r, p in protos}
+    assert len(want) >= 79
+    assert sorted(set(want) - set(got)) == [], "declared in the header, missing from INTEGRATION.md"
+    assert sorted(set(got) - set(want)) == [], "declared in INTEGRATION.md, not in the header"
+    for n in want:
+        assert got[n] == want[n], (n, got[n], want[n])
+    # spot checks of the type map itself
+    assert want["hvx_last_error"] == ([], "*const c_char")
+    assert want["hvx_index_import"][0][-1] == "*mut *mut hvx_index" and want["hvx_index_import"][0][0] == "*const hvx_index_desc"
+    assert want["hvx_topk_payload_bytes"] == (["u32", "u32"], "usize")
+    lib = os.path.join(ROOT, "helix-db_amd", "libhelix_vec_gfx950.so")
+    if os.path.exists(lib):
+        syms = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True).stdout
+        exported = sorted(l.split()[-1] for l in syms.splitlines() if " T hvx_" in l)
+        assert exported == sorted(want), "the .so's exports and the header's prototypes differ"

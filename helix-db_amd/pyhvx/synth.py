@@ -104,6 +104,42 @@ def embedding_like_np(n: int, dim: int, n_queries: int, seed: int, latent: int =
     return draw(n), draw(n_queries)
 
 
+def clustered_np(n: int, dim: int, n_queries: int, seed: int, centres: int = 1024, sigma: float = 0.15):
+    """numpy (PCG64) twin of `clustered` (SURVEY 8d's clustered variant): identical rows on every machine, for fixtures whose
+    CPU side (the oracle's sequential insert_hnsw) and GPU side (the device builder) must see the same corpus."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    c = rng.standard_normal((centres, dim)).astype(np.float32)
+
+    def draw(count):
+        which = rng.integers(0, centres, count)
+        x = c[which] + np.float32(sigma) * rng.standard_normal((count, dim)).astype(np.float32)
+        return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+
+    return draw(n), draw(n_queries)
+
+
+def layer0_components(l0_offsets, l0_neighbors, node_ids=None, entry_point=None):
+    """Connected components of a layer-0 graph given in hvx_index_import's CSR layout: count, sizes of the largest, and how many
+    nodes the entry point's component holds (what a layer-0 search can ever reach)."""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import connected_components
+    off = np.asarray(l0_offsets, dtype=np.int64)
+    n = off.size - 1
+    nb = np.asarray(l0_neighbors, dtype=np.int64)
+    if node_ids is not None:  # external -> internal
+        ids = np.asarray(node_ids, dtype=np.int64)
+        nb = np.searchsorted(ids, nb)
+        if entry_point is not None:
+            entry_point = int(np.searchsorted(ids, int(entry_point)))
+    g = csr_matrix((np.ones(nb.size, np.int8), nb, off), shape=(n, n))
+    nc, lab = connected_components(g, directed=False)
+    sizes = np.sort(np.bincount(lab))[::-1]
+    out = {"components": int(nc), "largest": [int(v) for v in sizes[:8]], "nodes_outside_the_largest": int(n - sizes[0])}
+    if entry_point is not None:
+        out["entry_component_nodes"] = int((lab == lab[int(entry_point)]).sum())
+    return out
+
+
 def quantize_fp8_rows(x: np.ndarray) -> np.ndarray:
     """The values an fp8-e4m3fn-stored index holds (numpy twin of quantize_fp8_kernel, csrc/hvx_dtype.hip): per row
     scale = max|x| / 448, code = RNE(x / scale) to e4m3fn, value = fl32(scale * decode(code)).  Harness code: lets a

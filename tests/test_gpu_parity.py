@@ -139,10 +139,10 @@ WAVE_CASES = [
 
 
 @pytest.mark.parametrize("n,dim,metric,m,m0,efc,ef,k,nq", WAVE_CASES)
-@pytest.mark.parametrize("path", ["wave", "general", "wave-spill"])
+@pytest.mark.parametrize("path", ["wave", "general", "wave-spill", "pair", "pair-spill"])
 def test_hnsw_kernels_agree_with_oracle(orc, hv, path, n, dim, metric, m, m0, efc, ef, k, nq):
-    """Both HNSW kernels (hvx_hnsw_wave.h and the general hvx_hnsw.hip) and the wave kernel's
-    LDS-table -> HBM-bitmap spill path give the oracle's ids, score bits and counters."""
+    """All three HNSW kernels (one wavefront per query: hvx_hnsw_wave.h; owner + gatherer wavefront pair: hvx_hnsw_pair.h, round 4;
+    the general hvx_hnsw.hip) and the LDS-table -> HBM-bitmap spill paths give the oracle's ids, score bits and counters."""
     rng = np.random.default_rng(77 + dim + metric)
     data = rng.standard_normal((n, dim)).astype(np.float32)
     lv = fx.draw_levels(n, m, seed=dim + 1)
@@ -150,7 +150,8 @@ def test_hnsw_kernels_agree_with_oracle(orc, hv, path, n, dim, metric, m, m0, ef
     gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=dim, metric=metric, m=m, m0=m0)
     if path == "general":
         gix.set_option(hv.OPT_HNSW_GENERAL_KERNEL, 1)
-    if path == "wave-spill":
+    gix.set_option(hv.OPT_HNSW_PAIR, 2 if path.startswith("pair") else 1)   # (the default picks the pair kernel for one-query-per-SIMD handles)
+    if path.endswith("-spill"):
         gix.set_option(hv.OPT_WAVE_LOG2CAP, 8)  # 256-slot table: spills after ~128 visited ids
     q = rng.standard_normal((nq, dim)).astype(np.float32)
     assert_hnsw_equal(orc, hv, oix, gix, q, k, ef)
@@ -1663,7 +1664,7 @@ def test_restricted_auto_plan_beyond_the_walk_limits_is_answered_exactly(orc, hv
     gix.set_simhash()
     allowed = np.sort(rng.choice(np.arange(n, dtype=np.uint64), 2000, replace=False))
     q = rng.standard_normal((5, dim)).astype(np.float32)
-    ids, sc, cnt, st, rs = gix.search_restricted_batch_params(q, hv.RestrictedParams.new(400, 400), allowed, want_stats=True)
+    ids, sc, cnt, st, rs, _ = gix.search_restricted_batch_params(q, hv.RestrictedParams.new(400, 400), allowed, want_stats=True)
     assert all(r["strategy"] == hv.RESTRICTED_EXACT for r in rs)
     for i in range(5):
         rc, oid, osc = oix.flat(q[i], 400, allowed=allowed)
@@ -1706,3 +1707,36 @@ def test_shard_step_joins_the_exchange_when_the_local_search_fails(orc, hv):
     gix.sync()
     assert g2[0].cpu().numpy().astype(np.uint64).tolist() == w[0].tolist() and not g2[3].cpu().numpy().any()
     grp.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_pair_kernel_on_duplicates_ties_rejected_queries_and_bf16(orc, hv, dtype):
+    """The owner / gatherer kernel where its speculation is most exposed: duplicate vectors (equal scores decide the next pop by id:
+    the prediction misses and the pass is discarded), ties beyond the beam slack (the queries join the re-run list and come back
+    from the one-wavefront kernel), a rejected query in the batch (its workgroup leaves before any barrier), k > ef / 2, a batch
+    larger than the CU count, bf16 rows.  Default selector: a handle with one query per SIMD takes the pair kernel."""
+    rng = np.random.default_rng(4500)
+    base = rng.standard_normal((60, 128)).astype(np.float32)
+    data = np.repeat(base, 40, axis=0)[rng.permutation(2400)]
+    data[::7] += np.float32(0.3) * rng.standard_normal((data[::7].shape[0], 128)).astype(np.float32)
+    n = data.shape[0]
+    stored = fx.round_bf16(data) if dtype == "bf16" else data
+    oix = build_oracle(orc, stored, orc.L2SQ, fx.draw_levels(n, 16, seed=12), efc=80)
+    ex = oix.export()
+    ex["vectors"] = data
+    gix = hv.ValidatedVectorReadIndex.from_export(ex, dim=128, metric=hv.EUCLIDEAN, dtype=hv.BF16 if dtype == "bf16" else hv.F32, max_batch=2048)
+    gix.set_occupancy(1)
+    q = np.concatenate([base[:20], base[20:40] + np.float32(0.02) * rng.standard_normal((20, 128)).astype(np.float32),
+                        rng.standard_normal((24, 128)).astype(np.float32)])
+    assert_hnsw_equal(orc, hv, oix, gix, q, 10, 64)
+    assert_hnsw_equal(orc, hv, oix, gix, q, 60, 100)
+    assert_hnsw_equal(orc, hv, oix, gix, q, 10, 300)    # 384-entry beam
+    big = np.tile(q, (20, 1))[:1200]                    # more workgroups than the chip holds at once
+    assert_hnsw_equal(orc, hv, oix, gix, big, 10, 48)
+    qb = q[:8].copy()
+    qb[3, 5] = np.nan
+    ids, sc, cnt, _, st = gix.search_batch(qb, hv.SearchParams(10).with_ef(64), per_query_status=True)
+    assert st[3] == hv.ERR_NONFINITE and cnt[3] == 0
+    for i in (0, 1, 2, 4, 7):
+        rc, oid, osc = oix.search(qb[i], 10, 64)
+        assert ids[i, :cnt[i]].tolist() == oid.tolist() and bits(sc[i, :cnt[i]]).tolist() == bits(osc).tolist()

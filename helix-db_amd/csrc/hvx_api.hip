@@ -131,7 +131,7 @@ extern "C" int hvx_index_set_option(hvx_index *ix, uint32_t option, uint32_t val
     if (option >= HVX_OPT_COUNT) return fail(HVX_ERR_INVARIANT, "unknown option %u", option);
     if (option == HVX_OPT_WAVE_LOG2CAP && value != 0 && (value < 7 || value > 15)) return fail(HVX_ERR_K_RANGE, "visited-table size must be 2^7 .. 2^15 slots");
     if (option == HVX_OPT_FLAT_FIRST_CHUNK && value != 0 && value < 1024) return fail(HVX_ERR_K_RANGE, "the first chunk holds at least 1024 rows");
-    if (option == HVX_OPT_HNSW_PAIR && value > 2) return fail(HVX_ERR_K_RANGE, "pair kernel selector is 0 (one query per SIMD handles), 1 (never) or 2 (always)");
+    if (option == HVX_OPT_HNSW_PAIR && value > 3) return fail(HVX_ERR_K_RANGE, "pair kernel selector is 0 (one query per SIMD handles), 1 (never), 2 (always) or 3 (always, one gatherer)");
     if (option == HVX_OPT_FLAT_TILE_BUILD && value > 1) return fail(HVX_ERR_K_RANGE, "tile build is 0 (two 256-thread workgroups per CU) or 1 (one 512-thread workgroup)");
     std::lock_guard<std::mutex> lock(ix->mu);
     ix->opt[option] = value;
@@ -636,7 +636,8 @@ int hvx::enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t b
     a.build_ef_upper = 0;
     a.only_flagged = 0;
     a.occupancy = ix->occupancy;
-    a.pair = ix->opt[HVX_OPT_HNSW_PAIR] == 2u || (ix->opt[HVX_OPT_HNSW_PAIR] == 0u && ix->occupancy != 2u) ? 1u : 0u;
+    a.pair = ix->opt[HVX_OPT_HNSW_PAIR] >= 2u || (ix->opt[HVX_OPT_HNSW_PAIR] == 0u && ix->occupancy != 2u) ? 1u : 0u;
+    a.pair_gatherers = ix->opt[HVX_OPT_HNSW_PAIR] == 3u ? 1u : 0u;
     a.log2cap = ix->opt[HVX_OPT_WAVE_LOG2CAP];
     if (ad) {
         if (!hnsw_wave_adaptive_supported(a))

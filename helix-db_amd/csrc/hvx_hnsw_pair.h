@@ -35,11 +35,17 @@ namespace hvx {
 
 constexpr uint32_t kPairExit = 0xFFFFFFFFu;
 
-template <uint32_t METRIC, int R, int NK, bool BF>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void hnsw_pair_kernel(HnswArgs a, uint32_t log2cap) {
+// G = gatherer wavefronts per query.  G = 1: 128-thread workgroups, two wavefronts per SIMD, 256 registers each, passes of up to 16
+// rows.  G = 3 (rows of <= 24 16-byte pieces per lane: f32 up to dim 768, bf16 up to dim 1536): 256-thread workgroups, FOUR
+// wavefronts per SIMD at 128 registers; gatherer g takes every third 8-row (16-row for the short rows) slice of the list, so a
+// frontier of up to 24 (48) rows is scored with ONE memory latency -- the heavy queries, whose 20-30-row frontiers end a batch, are
+// the ones a single 16-row gatherer serves in two round trips.
+template <uint32_t METRIC, int R, int NK, bool BF, int G>
+__global__ __launch_bounds__(64 * (1 + G)) __attribute__((amdgpu_waves_per_eu(1 + G, 1 + G))) void hnsw_pair_kernel(HnswArgs a, uint32_t log2cap) {
     constexpr int NL = BF ? NK / 2 : NK; // 16-byte loads per lane and row
     constexpr int P = NL <= 8 ? 2 : 1;
-    constexpr bool kWide2 = 2 * P * NL <= 48; // 192 of the gatherer's 256 registers
+    constexpr bool kWide2 = G == 1 && 2 * P * NL <= 48; // 192 of the gatherer's 256 registers
+    constexpr uint32_t kThreads = 64u * (1u + G);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const DevIndex &ix = a.ix;
     const uint32_t q = blockIdx.x;
@@ -66,14 +72,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         return;
     }
     const float *qglobal = a.queries + (size_t)q * ix.dim;
-    for (uint32_t i = (uint32_t)tid; i < (uint32_t)NK * 8u; i += 128u)
+    for (uint32_t i = (uint32_t)tid; i < (uint32_t)NK * 8u; i += kThreads)
         reinterpret_cast<float4 *>(qs)[i] = reinterpret_cast<const float4 *>(qglobal)[i];
     __syncthreads();
     const float qhdr = a.qhdr ? a.qhdr[q] : 0.f;
     const float inf = __uint_as_float(0x7F800000u);
 
     // =========================================== gatherer ===========================================
-    if (wave == 1) {
+    if (wave >= 1) {
         auto pass = [&](auto width, uint32_t f0, uint32_t nf) __attribute__((always_inline)) {
             constexpr int W = decltype(width)::value;
             uint32_t nd[W];
@@ -96,11 +102,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             __syncthreads(); // B0: a list is published (or the owner is done)
             const uint32_t nf = ctl[0];
             if (nf == kPairExit) return;
-            uint32_t f0 = 0;
+            uint32_t f0 = (uint32_t)(wave - 1) * 8u * P; // G > 1: the gatherers take the list's slices in turn
             while (f0 < nf) {
                 const uint32_t rem = nf - f0;
                 if (kWide2 && rem > 8u * P) { pass(std::integral_constant<int, kWide2 ? 2 * P : P>{}, f0, nf); f0 += 16u * P; }
-                else { pass(std::integral_constant<int, P>{}, f0, nf); f0 += 8u * P; }
+                else { pass(std::integral_constant<int, P>{}, f0, nf); f0 += 8u * P * G; }
             }
             __syncthreads(); // B1: the distances are published
         }
@@ -350,23 +356,31 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-template <typename K> static hipError_t launch_pair_kernel(K kern, const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
+template <typename K> static hipError_t launch_pair_kernel(K kern, uint32_t threads, const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
     if (g.lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(b), dim3(128), g.lds, s, a, g.log2cap);
+    hipLaunchKernelGGL(kern, dim3(b), dim3(threads), g.lds, s, a, g.log2cap);
     return hipGetLastError();
+}
+// three gatherers where a row is <= 24 pieces per lane, else one
+template <uint32_t METRIC, int R, int NK, bool BF> static hipError_t launch_pair_g(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
+    constexpr int NL = BF ? NK / 2 : NK;
+    if constexpr (NL <= 24) {
+        if (a.pair_gatherers != 1u) return launch_pair_kernel(hnsw_pair_kernel<METRIC, R, NK, BF, 3>, 256u, a, b, g, s);
+    }
+    return launch_pair_kernel(hnsw_pair_kernel<METRIC, R, NK, BF, 1>, 128u, a, b, g, s);
 }
 
 template <uint32_t METRIC, int R, bool BF> static hipError_t launch_pair_nk(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
     switch (a.ix.dim >> 5) {
-    case 4: return launch_pair_kernel(hnsw_pair_kernel<METRIC, R, 4, BF>, a, b, g, s);
-    case 8: return launch_pair_kernel(hnsw_pair_kernel<METRIC, R, 8, BF>, a, b, g, s);
-    case 16: return launch_pair_kernel(hnsw_pair_kernel<METRIC, R, 16, BF>, a, b, g, s);
-    case 24: return launch_pair_kernel(hnsw_pair_kernel<METRIC, R, 24, BF>, a, b, g, s);
-    case 32: return launch_pair_kernel(hnsw_pair_kernel<METRIC, R, 32, BF>, a, b, g, s);
-    case 48: return launch_pair_kernel(hnsw_pair_kernel<METRIC, R, 48, BF>, a, b, g, s);
+    case 4: return launch_pair_g<METRIC, R, 4, BF>(a, b, g, s);
+    case 8: return launch_pair_g<METRIC, R, 8, BF>(a, b, g, s);
+    case 16: return launch_pair_g<METRIC, R, 16, BF>(a, b, g, s);
+    case 24: return launch_pair_g<METRIC, R, 24, BF>(a, b, g, s);
+    case 32: return launch_pair_g<METRIC, R, 32, BF>(a, b, g, s);
+    case 48: return launch_pair_g<METRIC, R, 48, BF>(a, b, g, s);
     default: return hipErrorInvalidValue;
     }
 }

@@ -54,6 +54,7 @@ struct HnswArgs {
     uint32_t only_flagged;     // wave kernel: 1 = the re-run launch -- only queries whose tie flag is set do anything (with a wider beam)
     uint32_t occupancy;        // wave kernel: 2 = the two-queries-per-SIMD build (callers with >= 2 batches in flight), else 1
     uint32_t pair;             // 1 = the owner / gatherer kernel (hvx_hnsw_pair.h) where it serves the launch
+    uint32_t pair_gatherers;   // ... 1 = one gatherer wavefront per query even where three are built (A/B); 0 = the library's choice
     uint32_t log2cap;          // wave kernel: log2 slots of the LDS visited table (HVX_OPT_WAVE_LOG2CAP; small => bitmap spill); 0 = auto
     AdaptArgs ad;
 };

@@ -140,6 +140,40 @@ def layer0_components(l0_offsets, l0_neighbors, node_ids=None, entry_point=None)
     return out
 
 
+def load_fbin(path: str, expect_rows: int = None, expect_dim: int = None) -> np.ndarray:
+    """Memory-map an fbin fixture the way the reference's million-row prefilter benchmark does
+    (crates/db/tests/production_support/index_lifecycle_scale.rs:497-534, env HELIX_DBPEDIA_1M_FBIN): header
+    `<u32 count><u32 dimension>` little-endian, then count x dimension little-endian f32; the file length must match the
+    header exactly, the header must match the expected shape when one is given, and every value must be finite
+    (`get` asserts that per row, :538-547).  Returns a read-only [count][dimension] float32 view (no copy)."""
+    import os
+    size = os.path.getsize(path)
+    if size < 8:
+        raise ValueError(f"{path}: shorter than the fbin header")
+    hdr = np.fromfile(path, dtype="<u4", count=2)
+    count, dim = int(hdr[0]), int(hdr[1])
+    if expect_rows is not None and count != expect_rows:
+        raise ValueError(f"{path}: header says {count} rows, expected {expect_rows}")
+    if expect_dim is not None and dim != expect_dim:
+        raise ValueError(f"{path}: header says dimension {dim}, expected {expect_dim}")
+    if size != 8 + count * dim * 4:
+        raise ValueError(f"{path}: {size} bytes, the header implies {8 + count * dim * 4}")
+    rows = np.memmap(path, dtype="<f4", mode="r", offset=8, shape=(count, dim))
+    step = max(1, (1 << 22) // max(dim, 1))
+    for r0 in range(0, count, step):
+        if not np.isfinite(rows[r0:r0 + step]).all():
+            raise ValueError(f"{path}: non-finite value in rows [{r0}, {min(count, r0 + step)})")
+    return rows
+
+
+def write_fbin(path: str, rows: np.ndarray) -> None:
+    """The same layout, for fixtures."""
+    rows = np.ascontiguousarray(rows, dtype="<f4")
+    with open(path, "wb") as f:
+        np.array(rows.shape, dtype="<u4").tofile(f)
+        rows.tofile(f)
+
+
 def quantize_fp8_rows(x: np.ndarray) -> np.ndarray:
     """The values an fp8-e4m3fn-stored index holds (numpy twin of quantize_fp8_kernel, csrc/hvx_dtype.hip): per row
     scale = max|x| / 448, code = RNE(x / scale) to e4m3fn, value = fl32(scale * decode(code)).  Harness code: lets a

@@ -753,3 +753,29 @@ def test_integration_rust_block_declares_every_export():
         syms = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True).stdout
         exported = sorted(l.split()[-1] for l in syms.splitlines() if " T hvx_" in l)
         assert exported == sorted(want), "the .so's exports and the header's prototypes differ"
+
+
+def test_fbin_loader_follows_the_reference_fixture_contract(tmp_path):
+    """HELIX_DBPEDIA_1M_FBIN (index_lifecycle_scale.rs:497-534): `<u32 n><u32 dim>` little-endian header + f32 rows, exact file
+    length, expected shape, finite values -- the loader bench.py's config #3 leg uses when the variable points at a file."""
+    sys.path.insert(0, os.path.join(ROOT, "helix-db_amd"))
+    from pyhvx import synth
+    rng = np.random.default_rng(5)
+    rows = rng.standard_normal((37, 12)).astype(np.float32)
+    p = str(tmp_path / "t.fbin")
+    synth.write_fbin(p, rows)
+    raw = open(p, "rb").read()
+    assert raw[:8] == (37).to_bytes(4, "little") + (12).to_bytes(4, "little") and len(raw) == 8 + 37 * 12 * 4
+    got = synth.load_fbin(p, expect_rows=37, expect_dim=12)
+    assert got.shape == (37, 12) and np.array_equal(np.asarray(got), rows)
+    with pytest.raises(ValueError):
+        synth.load_fbin(p, expect_rows=38)
+    with pytest.raises(ValueError):
+        synth.load_fbin(p, expect_dim=16)
+    open(p, "ab").write(b"\0\0\0\0")                      # trailing bytes: length no longer matches the header
+    with pytest.raises(ValueError):
+        synth.load_fbin(p)
+    rows[3, 4] = np.inf
+    synth.write_fbin(p, rows)
+    with pytest.raises(ValueError):
+        synth.load_fbin(p)

@@ -139,7 +139,7 @@ WAVE_CASES = [
 
 
 @pytest.mark.parametrize("n,dim,metric,m,m0,efc,ef,k,nq", WAVE_CASES)
-@pytest.mark.parametrize("path", ["wave", "general", "wave-spill", "pair", "pair-spill"])
+@pytest.mark.parametrize("path", ["wave", "general", "wave-spill", "pair", "pair-spill", "pair1"])
 def test_hnsw_kernels_agree_with_oracle(orc, hv, path, n, dim, metric, m, m0, efc, ef, k, nq):
     """All three HNSW kernels (one wavefront per query: hvx_hnsw_wave.h; owner + gatherer wavefront pair: hvx_hnsw_pair.h, round 4;
     the general hvx_hnsw.hip) and the LDS-table -> HBM-bitmap spill paths give the oracle's ids, score bits and counters."""
@@ -150,7 +150,8 @@ def test_hnsw_kernels_agree_with_oracle(orc, hv, path, n, dim, metric, m, m0, ef
     gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=dim, metric=metric, m=m, m0=m0)
     if path == "general":
         gix.set_option(hv.OPT_HNSW_GENERAL_KERNEL, 1)
-    gix.set_option(hv.OPT_HNSW_PAIR, 2 if path.startswith("pair") else 1)   # (the default picks the pair kernel for one-query-per-SIMD handles)
+    # (the default picks the pair kernel for one-query-per-SIMD handles; 2 = three gatherer wavefronts where built, 3 = one)
+    gix.set_option(hv.OPT_HNSW_PAIR, 3 if path == "pair1" else 2 if path.startswith("pair") else 1)
     if path.endswith("-spill"):
         gix.set_option(hv.OPT_WAVE_LOG2CAP, 8)  # 256-slot table: spills after ~128 visited ids
     q = rng.standard_normal((nq, dim)).astype(np.float32)

@@ -443,6 +443,11 @@ hipError_t launch_hnsw_wave(const HnswArgs &a0, uint32_t b, hipStream_t s) {
     if (e != hipSuccess || !rerun) return e;
     HnswArgs r = a;
     r.only_flagged = 1;
+    // the re-run's workgroups leave at once (unless duplicates overflowed a beam): give them the build that fits NEXT TO whatever is
+    // resident -- two per SIMD, 20 KiB of LDS -- wherever it exists (the strict unrolled builds).  A one-per-SIMD re-run needs a SIMD
+    // with nothing else on it: behind the batches of other lanes that is a wait of 0.2 ms (round 3), behind the batcher's lanes
+    // running the four-wavefront pair kernel it starved for tens of milliseconds (gpurun r04c: p99 47 ms).
+    if (!a.adaptive) r.occupancy = 2;
     // the re-run keeps the launch's register budget where the wider build exists for it (two queries per SIMD: its few wavefronts
     // fit next to the resident batches of the other lanes); the 832-entry beams are one-per-SIMD builds
     return launch_hnsw_wave_once(r, b, s);

@@ -34,12 +34,14 @@ struct hvx_image_shared {
     // in key order = (order code, row) ascending, built from the attached SimHash rows on first use
     uint64_t *dir_code = nullptr;
     uint32_t *dir_row = nullptr;
+    uint32_t *dir_prefix = nullptr;    // [65537] first directory entry per 16-bit order-code prefix
     const uint64_t *dir_for = nullptr; // the node_hash array the directory was derived from
     ~hvx_image_shared() {
         if (shadow || dir_code || dir_row) (void)hipSetDevice(device);
         if (shadow) (void)hipFree(shadow);
         if (dir_code) (void)hipFree(dir_code);
         if (dir_row) (void)hipFree(dir_row);
+        if (dir_prefix) (void)hipFree(dir_prefix);
     }
 };
 

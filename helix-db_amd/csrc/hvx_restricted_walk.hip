@@ -20,6 +20,8 @@
 #include <numeric>
 #include <vector>
 
+#include <hipcub/hipcub.hpp>
+
 #include "hvx_host.h"
 #include "hvx_walk_core.h"
 
@@ -33,7 +35,13 @@ using namespace hvx;
 
 namespace {
 
-constexpr uint32_t kT = 256, kW = 1024;
+// Two geometries of the same algorithm body (round 4).  NARROW: 256 threads classify 1 024 ids per step -- many queries in flight
+// (two workgroups per CU).  WIDE: 1 024 threads, 2 048 ids per step (64 neighbour rows), staging for 4 096 bridge keys -- a batch of
+// a few dozen queries (the DBpedia benchmark runs 32) leaves most CUs idle, so each query gets a whole CU: every phase has one
+// dependent chain of HBM reads per thread instead of four, a 256-row bridge batch is four chunks instead of eight, 128 rows are
+// scored per step instead of 32.
+constexpr uint32_t kW = 1024;              // neighbour rows of up to 1 024 ids are served (narrow geometry's step)
+constexpr uint32_t kWideBatch = 256;       // batches up to this many queries take the wide geometry
 constexpr uint32_t kMaxBridgeRows = 9600;  // B in LDS: 75 KiB at most (ef 800 -> ef_filtered 1 200 -> 9 600 bridge rows)
 
 struct WalkArgs {
@@ -45,6 +53,7 @@ struct WalkArgs {
     const uint64_t *node_hash;  // [n]
     const uint64_t *dir_code;   // [n]
     const uint32_t *dir_row;    // [n]
+    const uint32_t *dir_prefix; // [65537]
     const uint32_t *allowed;    // membership bitmap(s) over the rows
     uint32_t *seen;             // [b][words], zero
     uint32_t words, allowed_stride; // allowed_stride = 0: one candidate set for the whole batch
@@ -59,8 +68,8 @@ struct WalkArgs {
     walk::Counters *counters;   // [b]
 };
 
-template <uint32_t METRIC, bool FUSED> struct DevCtx {
-    static constexpr uint32_t T = kT, W = kW;
+template <uint32_t METRIC, bool FUSED, uint32_t TT, uint32_t WW> struct DevCtx {
+    static constexpr uint32_t T = TT, W = WW;
     const DevIndex &ix;
     const float *qv;
     float qhdr;
@@ -153,12 +162,14 @@ template <uint32_t METRIC, bool FUSED> struct DevCtx {
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15u) & ~(size_t)15u; }
 
-size_t walk_lds_bytes(uint32_t ld, uint32_t b_cap) {
-    return align16((size_t)ld * 4) + walk::kScoredCap * 8 + align16((size_t)b_cap * 8) + walk::kStageCap * 8 + walk::kStageCap * 4 +
-           walk::kScoredCap * 4 + kW * 4 + kW * 4 + kW + kW * 8 + kW * 4 + walk::kBridgeBatch * 4 + walk::kCtlWords * 4 + (kW / 64) * 4;
+size_t walk_lds_bytes(uint32_t ld, uint32_t b_cap, uint32_t W, uint32_t stage_cap) {
+    return align16((size_t)ld * 4) + walk::kScoredCap * 8 + align16((size_t)b_cap * 8) + (size_t)stage_cap * 8 + (size_t)stage_cap * 4 +
+           walk::kScoredCap * 4 + (size_t)W * 4 + (size_t)W * 4 + W + (size_t)W * 8 + (size_t)W * 4 + walk::kBridgeBatch * 4 + walk::kCtlWords * 4 + (W / 64) * 4;
 }
 
-template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(256) void restricted_walk_kernel(WalkArgs a) {
+template <uint32_t METRIC, bool FUSED, uint32_t TT, uint32_t WW, uint32_t STAGE>
+__global__ __launch_bounds__(TT) void restricted_walk_kernel(WalkArgs a) {
+    constexpr uint32_t kT = TT, kW = WW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const DevIndex &ix = a.ix;
     const uint32_t q = blockIdx.x, t = threadIdx.x;
@@ -177,12 +188,13 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(256) void re
     walk::Mem m;
     m.S = reinterpret_cast<uint64_t *>(p); p += walk::kScoredCap * 8;
     m.B = reinterpret_cast<uint64_t *>(p); p += align16((size_t)a.b_cap * 8);
-    m.G = reinterpret_cast<uint64_t *>(p); p += walk::kStageCap * 8;
+    m.G = reinterpret_cast<uint64_t *>(p); p += STAGE * 8;
     m.tv = reinterpret_cast<uint64_t *>(p); p += kW * 8;
-    m.Gr = reinterpret_cast<uint32_t *>(p); p += walk::kStageCap * 4;
+    m.Gr = reinterpret_cast<uint32_t *>(p); p += STAGE * 4;
     m.E = reinterpret_cast<uint32_t *>(p); p += walk::kScoredCap * 4;
     m.N = reinterpret_cast<uint64_t *>(p); // the keys of freshly scored rows live where `rows` + `scan` do: those are dead while rows are scored
-    static_assert(walk::kScoredCap * 8 == 2 * kW * 4, "N aliases rows + scan");
+    static_assert(walk::kScoredCap * 8 <= 2 * kW * 4, "N aliases rows + scan");
+    static_assert(STAGE >= walk::kStageCap && STAGE >= 2 * kW, "a chunk's bridge keys fit behind what a flush left");
     m.rows = reinterpret_cast<uint32_t *>(p); p += kW * 4;
     m.scan = reinterpret_cast<uint32_t *>(p); p += kW * 4;
     m.tp = reinterpret_cast<uint32_t *>(p); p += kW * 4;
@@ -191,15 +203,16 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(256) void re
     uint32_t *wsum = reinterpret_cast<uint32_t *>(p); p += (kW / 64) * 4;
     m.flag = reinterpret_cast<uint8_t *>(p);
     m.b_cap = a.b_cap;
+    m.stage_cap = STAGE;
     for (uint32_t i = t; i < ix.ld; i += kT) qv[i] = i < ix.dim ? a.queries[(size_t)q * ix.dim + i] : 0.f;
 
     walk::View v;
     v.l0 = ix.l0; v.s0 = ix.s0; v.n = ix.n; v.dim = ix.dim;
-    v.node_hash = a.node_hash; v.dir_code = a.dir_code; v.dir_row = a.dir_row;
+    v.node_hash = a.node_hash; v.dir_code = a.dir_code; v.dir_row = a.dir_row; v.dir_prefix = a.dir_prefix;
     v.entry = ix.entry; v.has_entry = ix.has_entry;
     v.allowed = a.allowed + (size_t)q * a.allowed_stride;
     v.seen = a.seen + (size_t)q * a.words;
-    DevCtx<METRIC, FUSED> c{ix, qv, a.qhdr ? a.qhdr[q] : 0.f, wsum};
+    DevCtx<METRIC, FUSED, TT, WW> c{ix, qv, a.qhdr ? a.qhdr[q] : 0.f, wsum};
     walk::Counters st;
     uint32_t s_n = 0;
     const uint32_t bad = walk::run(c, v, pl, a.samples + (size_t)q * a.sample_stride, a.qhash[q], m, st, s_n);
@@ -220,23 +233,30 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(256) void re
     }
 }
 
-template <uint32_t METRIC, bool FUSED> hipError_t launch_walk_t(const WalkArgs &a, uint32_t b, size_t lds, hipStream_t s) {
-    auto kern = restricted_walk_kernel<METRIC, FUSED>;
+template <typename K> hipError_t launch_walk_kernel(K kern, const WalkArgs &a, uint32_t b, uint32_t threads, size_t lds, hipStream_t s) {
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(b), dim3(kT), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(b), dim3(threads), lds, s, a);
     return hipGetLastError();
+}
+template <uint32_t METRIC, bool FUSED> hipError_t launch_walk_t(const WalkArgs &a, uint32_t b, hipStream_t s) {
+    // the wide geometry for small batches, where its staging fits next to the plan's bridge queue (160 KiB of LDS per CU)
+    const size_t wide_lds = walk_lds_bytes(a.ix.ld, a.b_cap, 2048, 4096);
+    if (b <= kWideBatch && wide_lds <= 160 * 1024)
+        return launch_walk_kernel(restricted_walk_kernel<METRIC, FUSED, 1024, 2048, 4096>, a, b, 1024u, wide_lds, s);
+    const size_t lds = walk_lds_bytes(a.ix.ld, a.b_cap, 1024, 2048);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    return launch_walk_kernel(restricted_walk_kernel<METRIC, FUSED, 256, 1024, 2048>, a, b, 256u, lds, s);
 }
 
 hipError_t launch_walk(const WalkArgs &a, uint32_t b, hipStream_t s) {
-    const size_t lds = walk_lds_bytes(a.ix.ld, a.b_cap);
     const bool fused = a.ix.fkernel == kKernelAvxFma;
     switch (a.ix.metric) {
-    case kCosine: return fused ? launch_walk_t<kCosine, true>(a, b, lds, s) : launch_walk_t<kCosine, false>(a, b, lds, s);
-    case kL2: return fused ? launch_walk_t<kL2, true>(a, b, lds, s) : launch_walk_t<kL2, false>(a, b, lds, s);
-    default: return launch_walk_t<kL1, true>(a, b, lds, s);
+    case kCosine: return fused ? launch_walk_t<kCosine, true>(a, b, s) : launch_walk_t<kCosine, false>(a, b, s);
+    case kL2: return fused ? launch_walk_t<kL2, true>(a, b, s) : launch_walk_t<kL2, false>(a, b, s);
+    default: return launch_walk_t<kL1, true>(a, b, s);
     }
 }
 
@@ -318,30 +338,53 @@ void sample_ranks(uint64_t candidates, uint32_t count, std::vector<uint64_t> &ou
     }
 }
 
-// the SimHash directory of this image, built once from the attached SimHash rows
+// the SimHash directory of this image, built once from the attached SimHash rows -- on the device (round 4; rounds 2-3 sorted the
+// 1M order codes with std::sort on the host): order codes, a stable radix sort of (code, row) pairs (rows ascend inside equal
+// codes = the (order_code, node_id) key order of storage.rs:1942-2010), and the 65 537-entry prefix table the window bounds come from
+__global__ void dir_codes_kernel(const uint64_t *node_hash, uint32_t n, uint64_t *codes, uint32_t *rows) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { codes[i] = walk::order_code(node_hash[i]); rows[i] = i; }
+}
+__global__ void dir_prefix_kernel(const uint64_t *sorted_codes, uint32_t n, uint32_t *prefix) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > 65536u) return;
+    prefix[p] = p == 65536u ? n : walk::lower_bound(sorted_codes, n, (uint64_t)p << 48);
+}
+
 int ensure_directory(hvx_index *ix) {
     hvx_image_shared &sh = *ix->shared;
     std::lock_guard<std::mutex> lock(sh.mu);
     if (sh.dir_code && sh.dir_for == ix->d_node_hash) return HVX_OK;
-    const uint32_t n = ix->dev.n;
-    std::vector<uint64_t> h(std::max<uint32_t>(n, 1));
-    HIP_TRY(hipStreamSynchronize(ix->stream));
-    if (n) HIP_TRY(hipMemcpy(h.data(), ix->d_node_hash, (size_t)n * 8, hipMemcpyDeviceToHost));
-    std::vector<uint64_t> code(std::max<uint32_t>(n, 1));
-    for (uint32_t i = 0; i < n; ++i) code[i] = walk::order_code(h[i]);
-    std::vector<uint32_t> order(std::max<uint32_t>(n, 1));
-    std::iota(order.begin(), order.begin() + n, 0u);
-    std::sort(order.begin(), order.begin() + n, [&](uint32_t x, uint32_t y) { return code[x] != code[y] ? code[x] < code[y] : x < y; });
-    for (uint32_t i = 0; i < n; ++i) h[i] = code[order[i]];
-    if (sh.dir_code) { (void)hipFree(sh.dir_code); sh.dir_code = nullptr; }
-    if (sh.dir_row) { (void)hipFree(sh.dir_row); sh.dir_row = nullptr; }
+    const uint32_t n = ix->dev.n, n1 = std::max<uint32_t>(n, 1);
+    hipStream_t s = ix->stream;
+    for (void **p : {(void **)&sh.dir_code, (void **)&sh.dir_row, (void **)&sh.dir_prefix})
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
     sh.device = ix->device;
-    HIP_TRY(hipMalloc((void **)&sh.dir_code, (size_t)std::max<uint32_t>(n, 1) * 8));
-    HIP_TRY(hipMalloc((void **)&sh.dir_row, (size_t)std::max<uint32_t>(n, 1) * 4));
+    HIP_TRY(hipMalloc((void **)&sh.dir_code, (size_t)n1 * 8));
+    HIP_TRY(hipMalloc((void **)&sh.dir_row, (size_t)n1 * 4));
+    HIP_TRY(hipMalloc((void **)&sh.dir_prefix, 65537u * 4));
+    uint64_t *codes = nullptr;
+    uint32_t *rows = nullptr;
+    void *temp = nullptr;
+    auto release = [&]() {
+        for (void *p : {(void *)codes, (void *)rows, temp})
+            if (p) (void)hipFree(p);
+    };
+    auto bail = [&](int rc) { (void)hipStreamSynchronize(s); release(); return rc; };
+    if (hipMalloc((void **)&codes, (size_t)n1 * 8) != hipSuccess || hipMalloc((void **)&rows, (size_t)n1 * 4) != hipSuccess)
+        return bail(fail(HVX_ERR_DEVICE, "hipMalloc of the directory scratch failed"));
     if (n) {
-        HIP_TRY(hipMemcpy(sh.dir_code, h.data(), (size_t)n * 8, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(sh.dir_row, order.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(dir_codes_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, ix->d_node_hash, n, codes, rows);
+        size_t temp_bytes = 0;
+        if (hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, codes, sh.dir_code, rows, sh.dir_row, (int)n, 0, 64, s) != hipSuccess ||
+            hipMalloc(&temp, std::max<size_t>(temp_bytes, 16)) != hipSuccess ||
+            hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, codes, sh.dir_code, rows, sh.dir_row, (int)n, 0, 64, s) != hipSuccess)
+            return bail(fail(HVX_ERR_DEVICE, "radix sort of the SimHash directory failed: %s", hipGetErrorString(hipGetLastError())));
     }
+    hipLaunchKernelGGL(dir_prefix_kernel, dim3((65537u + 255u) / 256u), dim3(256), 0, s, sh.dir_code, n, sh.dir_prefix);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        return bail(fail(HVX_ERR_DEVICE, "building the SimHash directory failed: %s", hipGetErrorString(hipGetLastError())));
+    release();
     sh.dir_for = ix->d_node_hash;
     return HVX_OK;
 }
@@ -414,6 +457,7 @@ int walk_shared_set(hvx_index *ix, const float *queries, uint32_t b, uint32_t k_
         a.node_hash = ix->d_node_hash;
         a.dir_code = ix->shared->dir_code;
         a.dir_row = ix->shared->dir_row;
+        a.dir_prefix = ix->shared->dir_prefix;
         a.allowed = ix->w_allowed;
         a.seen = ix->w_seen;
         a.words = words;

@@ -78,6 +78,8 @@ struct View {
     const uint64_t *node_hash; // [n] SimHash row of every node
     const uint64_t *dir_code;  // [n] order codes ascending  } the SimHash directory: (order_code, node) rows in key order
     const uint32_t *dir_row;   // [n] the row of each entry   }
+    const uint32_t *dir_prefix; // [65537] first directory entry whose 16-bit order-code prefix is >= p (entry 65536 = n): window bounds
+                                //         without a binary search over the directory in HBM (round 4)
     uint32_t entry, has_entry;
     const uint32_t *allowed;   // [words] membership bitmap of this query's candidate set over the index rows (read-only)
     uint32_t *seen;            // [words] attempted (members) / queued (non-members), zero on entry
@@ -99,9 +101,10 @@ struct Mem {
     uint32_t *batch; // [kBridgeBatch]
     uint32_t *ctl;   // [kCtlWords]
     uint32_t b_cap;
+    uint32_t stage_cap; // entries of G / Gr (>= kStageCap; >= 2 W for the wide geometry)
 };
 
-enum : uint32_t { kGN = 0, kPush = 1, kBad = 2, kUnknown = 3, kTmp = 4, kMin = 5, kWinLo = 8, kWinCnt = 16, kCtlWords = 32 };
+enum : uint32_t { kGN = 0, kPush = 1, kBad = 2, kUnknown = 3, kTmp = 4, kMin = 5, kWinLo = 8, kWinCnt = 16, kWinHit = 24, kCtlWords = 32 };
 
 // order_code_from_simhash_bits (simhash.rs:44-59): the four 16-bit bands interleaved MSB first
 HVX_WALK_HD uint64_t order_code(uint64_t bits) {
@@ -264,14 +267,14 @@ HVX_WALK_FN uint32_t run(C &c, const View &v, const Plan &pl, const uint32_t *sa
             c.phase([&](uint32_t t) {
                 for (uint32_t w = t; w < kConcurrentScans; w += T) {
                     const uint32_t prefix = qprefix ^ prefix_offset(p0 + w);
-                    const uint64_t min_order = (uint64_t)prefix << 48;
-                    const uint32_t lo = lower_bound(v.dir_code, v.n, min_order);
-                    const uint32_t hi = prefix == 0xFFFFu ? v.n : lower_bound(v.dir_code, v.n, (uint64_t)(min_order + (1ull << 48)));
+                    const uint32_t lo = v.dir_prefix[prefix];
+                    const uint32_t hi = v.dir_prefix[prefix + 1u]; // (prefix 0xFFFF: entry 65536 = n)
                     uint32_t cnt = hi - lo;
                     if (cnt > kWindowRows) cnt = kWindowRows;
                     if (cnt > kWindowBytes / kDirectoryRowBytes) cnt = kWindowBytes / kDirectoryRowBytes;
                     m.ctl[kWinLo + w] = lo;
                     m.ctl[kWinCnt + w] = cnt;
+                    m.ctl[kWinHit + w] = 0;
                 }
             });
             st.directory_scan_calls += kConcurrentScans;
@@ -279,21 +282,35 @@ HVX_WALK_FN uint32_t run(C &c, const View &v, const Plan &pl, const uint32_t *sa
                 st.directory_rows += m.ctl[kWinCnt + w];
                 st.directory_decoded_bytes += m.ctl[kWinCnt + w] * kDirectoryRowBytes;
             }
+            // Round 4: the windows are consumed in order and the scan stops behind the first one that completes the seed quota --
+            // so the members of ALL eight windows are counted in one phase (one dependent pair of HBM reads for the whole batch
+            // instead of one per window), the uniform control flow picks the windows that are consumed, and a second phase stores
+            // exactly their members: the same set the window-by-window loop produced (a node has one directory row: the
+            // reference's `seen.insert` never rejects).
+            c.phase([&](uint32_t t) {
+                for (uint32_t s = t; s < kConcurrentScans * kWindowRows; s += T) {
+                    const uint32_t w = s / kWindowRows, i = s - w * kWindowRows;
+                    if (i < m.ctl[kWinCnt + w] && bit_of(v.allowed, v.dir_row[m.ctl[kWinLo + w] + i])) c.atomic_add_shared(&m.ctl[kWinHit + w], 1u);
+                }
+            });
+            uint32_t used = 0;
             for (uint32_t w = 0; w < kConcurrentScans && !done; ++w) {
-                const uint32_t lo = m.ctl[kWinLo + w], cnt = m.ctl[kWinCnt + w];
-                if (cnt)
-                    c.phase([&](uint32_t t) {
-                        for (uint32_t i = t; i < cnt; i += T) {
-                            const uint32_t x = v.dir_row[lo + i];
-                            if (bit_of(v.allowed, x)) { // a node has one directory row: `seen.insert` never rejects
-                                const uint32_t pos = c.atomic_add_shared(&m.ctl[kGN], 1u);
-                                m.G[pos] = ((uint64_t)popc64(v.dir_code[lo + i] ^ qorder) << 32) | x;
-                            }
-                        }
-                    });
-                n_ds = m.ctl[kGN];
+                n_ds += m.ctl[kWinHit + w];
+                used = w + 1;
                 if (n_ds >= pl.directory_seeds) done = true;
             }
+            c.phase([&](uint32_t t) {
+                for (uint32_t s = t; s < used * kWindowRows; s += T) {
+                    const uint32_t w = s / kWindowRows, i = s - w * kWindowRows;
+                    if (i < m.ctl[kWinCnt + w] && m.ctl[kWinHit + w] != 0u) {
+                        const uint32_t lo = m.ctl[kWinLo + w], x = v.dir_row[lo + i];
+                        if (bit_of(v.allowed, x)) {
+                            const uint32_t pos = c.atomic_add_shared(&m.ctl[kGN], 1u);
+                            m.G[pos] = ((uint64_t)popc64(v.dir_code[lo + i] ^ qorder) << 32) | x;
+                        }
+                    }
+                }
+            });
         }
         st.directory_hits = n_ds;
         pad_sort(m.G, n_ds); // sort_unstable_by_key((hamming, node_id)); rows ascend with node ids
@@ -460,7 +477,7 @@ HVX_WALK_FN uint32_t run(C &c, const View &v, const Plan &pl, const uint32_t *sa
                 });
                 n_elig = umin(cut, n_elig + total);
             }
-            if (m.ctl[kGN] + W > kStageCap) flush();
+            if (m.ctl[kGN] + W > m.stage_cap) flush();
         }
     };
 

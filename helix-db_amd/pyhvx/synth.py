@@ -54,6 +54,38 @@ def embedding_like(n: int, dim: int, n_queries: int, seed: int, device, latent: 
     return draw(n), draw(n_queries)
 
 
+def topic_ordered(n: int, dim: int, n_queries: int, seed: int, device, latent: int = 12, clusters: int = 1024, spread: float = 0.6,
+                  noise: float = 0.02, chunk: int = 1 << 18):
+    """`embedding_like` rows in CORPUS ORDER: sorted by latent cluster, then along the first latent coordinate inside the cluster.
+    The stand-in for a dump whose row order follows its source (DBpedia's entity list is ordered by entity URI: neighbouring rows
+    share title prefixes / list pages / categories), i.e. a contiguous id range is topically local -- the property the reference's
+    million-row prefilter benchmark leans on: its candidate sets ARE contiguous id ranges (index_lifecycle_scale.rs:592-613,1769-1776)
+    and its filter-aware walk reaches members through members.  With ids assigned at random instead (`embedding_like`) a 1 000-id
+    range is 0.1 % of every neighbourhood and the reference's own budgets (<= 1 200 bridge rows) end the walk after ~90 scored rows.
+    Returns (rows, queries); queries are held-out draws (the benchmark itself queries with stored rows)."""
+    dev = torch.device(device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    w = torch.randn(latent, dim, generator=g, device=dev) / math.sqrt(latent)
+    centres = torch.randn(clusters, latent, generator=g, device=dev)
+
+    def draw(count, ordered):
+        which = torch.randint(0, clusters, (count,), generator=g, device=dev)
+        z = centres[which] + spread * torch.randn(count, latent, generator=g, device=dev)
+        if ordered:
+            o1 = torch.argsort(z[:, 0])
+            o2 = torch.argsort(which[o1], stable=True)
+            z = z[o1[o2]]
+        out = torch.empty(count, dim, device=dev, dtype=torch.float32)
+        for s in range(0, count, chunk):
+            c = min(chunk, count - s)
+            x = z[s:s + c] @ w + noise * torch.randn(c, dim, generator=g, device=dev)
+            out[s:s + c] = x / x.norm(dim=1, keepdim=True)
+        return out
+
+    return draw(n, True), draw(n_queries, False)
+
+
 def gaussian_sphere(n: int, dim: int, n_queries: int, seed: int, device):
     """SURVEY.md 8(d) C2 as literally written: i.i.d. N(0,1), L2-normalised (worst case for any ANN)."""
     dev = torch.device(device)
@@ -203,6 +235,8 @@ def corpus(name: str, n: int, dim: int, n_queries: int, seed: int, device, **kw)
         return clustered(n, dim, n_queries, seed, device, **kw)
     if name == "embedding":
         return embedding_like(n, dim, n_queries, seed, device, **kw)
+    if name == "topic_ordered":
+        return topic_ordered(n, dim, n_queries, seed, device, **kw)
     raise ValueError(f"unknown corpus {name!r}")
 
 

@@ -67,18 +67,27 @@ struct twin_args {
     Plan plan;
 };
 
-template <uint32_t TT, uint32_t WW>
+// the 65 537-entry prefix table of the directory (the library builds it on the device next to the sorted directory)
+static std::vector<uint32_t> prefix_table(const uint64_t *dir_code, uint32_t n) {
+    std::vector<uint32_t> p(65537);
+    for (uint32_t v = 0; v <= 65536u; ++v) p[v] = v == 65536u ? n : lower_bound(dir_code, n, (uint64_t)v << 48);
+    return p;
+}
+
+template <uint32_t TT, uint32_t WW, uint32_t STAGE = kStageCap>
 static uint32_t run_variant(const twin_args &a, dist_fn dist, uint64_t *out_keys, uint32_t *out_n, Counters *out_st) {
-    std::vector<uint64_t> S(kScoredCap, 0), B(std::max<uint32_t>(a.b_cap, 1), 0), G(kStageCap, 0), N(kScoredCap, 0), tv(WW, 0);
+    static_assert(STAGE >= kStageCap && STAGE >= 2 * WW || WW <= 1024, "staging as the kernel sizes it");
+    std::vector<uint64_t> S(kScoredCap, 0), B(std::max<uint32_t>(a.b_cap, 1), 0), G(STAGE, 0), N(kScoredCap, 0), tv(WW, 0);
     // like the kernel, the geometry with W = 1024 keeps N where rows + scan live (dead while rows are scored)
     std::vector<uint32_t> rs(2 * WW + 2, 0);
     uint32_t *rows_p = rs.data() + (reinterpret_cast<uintptr_t>(rs.data()) % 8 ? 1 : 0), *scan_p = rows_p + WW;
-    std::vector<uint32_t> Gr(kStageCap, 0), E(kScoredCap, 0), tp(WW, 0), batch(kBridgeBatch, 0), ctl(kCtlWords, 0xDEADBEEFu);
+    std::vector<uint32_t> Gr(STAGE, 0), E(kScoredCap, 0), tp(WW, 0), batch(kBridgeBatch, 0), ctl(kCtlWords, 0xDEADBEEFu);
     uint64_t *N_p = (WW * 8 == kScoredCap * 8) ? reinterpret_cast<uint64_t *>(rows_p) : N.data();
     std::vector<uint8_t> flag(WW, 0);
     std::vector<uint32_t> seen((a.n + 31) / 32 + 1, 0);
-    Mem m{S.data(), B.data(), G.data(), N_p, Gr.data(), E.data(), rows_p, scan_p, flag.data(), tv.data(), tp.data(), batch.data(), ctl.data(), a.b_cap};
-    View v{a.l0, a.s0, a.n, a.dim, a.node_hash, a.dir_code, a.dir_row, a.entry, a.has_entry, a.allowed, seen.data()};
+    Mem m{S.data(), B.data(), G.data(), N_p, Gr.data(), E.data(), rows_p, scan_p, flag.data(), tv.data(), tp.data(), batch.data(), ctl.data(), a.b_cap, STAGE};
+    const std::vector<uint32_t> prefix = prefix_table(a.dir_code, a.n);
+    View v{a.l0, a.s0, a.n, a.dim, a.node_hash, a.dir_code, a.dir_row, prefix.data(), a.entry, a.has_entry, a.allowed, seen.data()};
     HostCtx<TT, WW> c(dist, a.order_seed);
     uint32_t s_n = 0;
     const uint32_t bad = run(c, v, a.plan, a.sample_rows, a.qhash, m, *out_st, s_n);
@@ -96,6 +105,7 @@ extern "C" uint32_t walk_twin_run(const twin_args *a, dist_fn dist, uint64_t *ou
     case 1: return a->s0 <= 256 ? run_variant<64, 256>(*a, dist, out_keys, out_n, out_st) : 99;
     case 2: return a->s0 <= 64 ? run_variant<8, 64>(*a, dist, out_keys, out_n, out_st) : 99;    // tiny: every loop chunks
     case 3: return a->s0 <= 1024 ? run_variant<1, 1024>(*a, dist, out_keys, out_n, out_st) : 99;  // one thread
+    case 4: return a->s0 <= 2048 ? run_variant<1024, 2048, 4096>(*a, dist, out_keys, out_n, out_st) : 99; // the kernel's WIDE geometry (small batches)
     default: return 99;
     }
 }

@@ -8,7 +8,7 @@ import pytest
 
 import walk_harness as wh
 
-VARIANTS = (0, 1, 2, 3)  # workgroup geometries of the twin: (256,1024) = the kernel's, (64,256), (8,64), (1,1024)
+VARIANTS = (0, 1, 2, 3, 4)  # workgroup geometries of the twin: (256,1024) = the kernel's narrow one, (64,256), (8,64), (1,1024), (1024,2048) = its wide one
 
 
 def test_prefix_offsets_and_order_code_match_the_oracle(orc):
@@ -85,7 +85,7 @@ def test_directory_seeds_on_identical_rows(orc):
     # explicit directory budgets incl. zero (the first window is still read)
     for ds in (0, 1, 17, 300):
         explicit(orc, img, ix, wh.circle8(3, 300), np.arange(1, 301), directory=True, k=5, ef_filtered=20, routing_rows=320, bridge_rows=160,
-                 vector_payloads=100, sampled_seeds=8, directory_seeds=ds, variants=(0, 2))
+                 vector_payloads=100, sampled_seeds=8, directory_seeds=ds, variants=(0, 2, 4))
 
 
 def test_circle_membership_fixture(orc):
@@ -95,11 +95,11 @@ def test_circle_membership_fixture(orc):
     img = wh.Image(orc, ix, orc.COSINE)
     allowed = [i for i in range(1, n + 1) if i % 3 != 0]
     for qid in (1, 43, 87, 129, 211, 307, 401, 509):
-        both(orc, img, ix, wh.circle8(qid, n), allowed, 10, 64, variants=(0, 2))
+        both(orc, img, ix, wh.circle8(qid, n), allowed, 10, 64, variants=(0, 2, 4))
     # unknown ids inside the candidate list, duplicates, other beam widths
     both(orc, img, ix, wh.circle8(5, n), allowed + [9999, 10_000, 7, 7] + list(range(600, 900)), 10, 64)
     for pct in (100, 200, 400):
-        both(orc, img, ix, wh.circle8(77, n), allowed, 10, 64, beam_percent=pct, variants=(0, 1))
+        both(orc, img, ix, wh.circle8(77, n), allowed, 10, 64, beam_percent=pct, variants=(0, 1, 4))
 
 
 @pytest.mark.parametrize("metric_name,dim,n,m0,gap", [("L2SQ", 48, 1500, 32, False), ("COSINE", 64, 1200, 32, True), ("L1", 20, 900, 16, False),
@@ -118,7 +118,7 @@ def test_built_graphs_sparse_and_dense_filters(orc, metric_name, dim, n, m0, gap
         allowed = np.concatenate([pick, extra])
         for qi in range(3):
             q = rng.standard_normal(dim).astype(np.float32)
-            both(orc, img, ix, q, allowed, 10, 100, variants=(0, 2))
+            both(orc, img, ix, q, allowed, 10, 100, variants=(0, 2, 4))
             both(orc, img, ix, q, allowed, 10, 100, directory=False, variants=(1,))
     # budgets that bite: every termination reason is reachable on a real graph
     q = rng.standard_normal(dim).astype(np.float32)
@@ -160,11 +160,11 @@ def test_sparse_filter_is_bridging_heavy(orc):
     pushes = 0
     for qi in range(4):
         q = rng.standard_normal(16).astype(np.float32)
-        want = both(orc, img, ix, q, allowed, 10, 100, directory=bool(qi & 1), variants=(0, 2))
+        want = both(orc, img, ix, q, allowed, 10, 100, directory=bool(qi & 1), variants=(0, 2, 4))
         pushes += want[3]["bridge_frontier_pushes"]
         # a bridge budget far below the pushes: most keys are counted, not stored
         explicit(orc, img, ix, q, allowed, directory=True, k=10, ef_filtered=150, routing_rows=2400, bridge_rows=40, vector_payloads=800,
-                 sampled_seeds=64, directory_seeds=256, variants=(0, 1))
+                 sampled_seeds=64, directory_seeds=256, variants=(0, 1, 4))
     assert pushes > 4000, pushes
 
 

@@ -342,6 +342,27 @@ def hnsw_leg(hv, synth, args, dev, dataset, n, dim, b, k, ef, dtype_name="f32", 
 # ------------------------------------------------------------------------------------------------------------
 # extra legs (N = 1 only)
 # ------------------------------------------------------------------------------------------------------------
+C3_FBIN_ENV = "HELIX_DBPEDIA_1M_FBIN"   # the reference's own variable (index_lifecycle_scale.rs:497-534)
+
+
+def c3_corpus(synth, n, dim, dev):
+    """The rows of the configs[2] leg: the DBpedia-1M fbin when HELIX_DBPEDIA_1M_FBIN points at one (header <u32 n><u32 dim> LE +
+    f32 rows, validated like the reference's loader), else the synthetic stand-in."""
+    path = os.environ.get(C3_FBIN_ENV)
+    if path:
+        rows = synth.load_fbin(path, expect_rows=n, expect_dim=dim)
+        x = torch.empty(n, dim, dtype=torch.float32, device=dev)
+        step = 1 << 16
+        for r0 in range(0, n, step):
+            x[r0:r0 + step] = torch.from_numpy(np.ascontiguousarray(rows[r0:r0 + step])).to(dev)
+        return x, f"DBpedia-1M fbin {path}"
+    x, _ = synth.corpus("topic_ordered", n, dim, 1, 20260923, dev, **C3_STANDIN)
+    return x, "synthetic stand-in: synth.topic_ordered(%s)" % ", ".join(f"{k_}={v_}" for k_, v_ in C3_STANDIN.items())
+
+
+C3_STANDIN = dict(latent=12, clusters=2048, spread=0.6)
+
+
 def leg_config3(hv, synth, orc, args, dev, k=10, nq=32, rounds=5):
     """configs[2] stand-in: 1M x 1536 f32 Euclidean, node i -> (i + N/2) mod N, equality groups of
     100 / 1 000 / 10 000 / 100 000 sources (index_lifecycle_scale.rs:592-613,1769-1776), 32 queries, fused hop + restricted kNN,
@@ -349,13 +370,13 @@ def leg_config3(hv, synth, orc, args, dev, k=10, nq=32, rounds=5):
     `planned` = the reference's execution plan (exact scan <= 256 ids, the filter-aware walk above: what the reference runs,
     gate distance_computations <= 800 per query, :1924-1927) and `exact` = the device's exact gathered scan of every candidate."""
     n, dim, ef = 1_000_000, 1536, 100
-    x, _ = synth.corpus("clustered", n, dim, 1, 20260923, dev)
+    x, corpus_name = c3_corpus(synth, n, dim, dev)
     torch.cuda.synchronize()
     t0 = time.time()
     lv = synth.draw_levels(n, 16, 11)
     ix, bst = hv.ValidatedVectorReadIndex.build(dim=dim, metric=hv.EUCLIDEAN, node_ids=np.arange(n, dtype=np.uint64), vectors=x, levels=lv,
                                                 m=16, m0=32, ef_construction=200, max_batch=args.build_batch, batch_divisor=32,
-                                                device=dev.index, search_max_batch=nq)
+                                                device=dev.index, search_max_batch=nq, scatter=True)
     ix.sync()
     t_build = time.time() - t0
     ix.set_simhash()   # SimHash rows + (on first walk) the SimHash directory

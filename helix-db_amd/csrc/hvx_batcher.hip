@@ -216,9 +216,7 @@ extern "C" int hvx_batcher_new_lanes(hvx_index *ix, const hvx_search_params *par
             hvx_batcher_free(b);
             return rc;
         }
-        // several lanes = several batches in flight: the two-queries-per-SIMD build, whose second resident batch hides the first one's
-        // round trips; a single lane runs one batch at a time: the owner / gatherer kernel (one query per SIMD handle)
-        if (ok) (void)hvx_index_set_occupancy(ln.ix, lanes > 1 ? 2u : 1u);
+        // (a lane inherits the parent handle's settings -- hvx_index_set_occupancy / hvx_index_set_option -- at this point)
         ok = ok && dev((void **)&ln.d_q, (size_t)max_batch * b->dim * 4) && dev((void **)&ln.d_ids, (size_t)max_batch * b->k * 8) &&
              dev((void **)&ln.d_sc, (size_t)max_batch * b->k * 4) && dev((void **)&ln.d_cnt, (size_t)max_batch * 4) &&
              dev((void **)&ln.d_st, (size_t)max_batch * 4);

@@ -615,9 +615,11 @@ template <typename K> static hipError_t launch_link_wg(K kern, const BuildArgs &
     return hipGetLastError();
 }
 
-__global__ void iota_kernel(uint32_t *p, uint32_t n) {
+// insertion order: position i inserts row (i * stride) mod n; stride 1 = id order, a stride coprime with n = a permutation that puts
+// the nodes of a batch far apart in id space (hvx_build_params.scatter)
+__global__ void iota_kernel(uint32_t *p, uint32_t n, uint32_t stride) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n) p[i] = i;
+    if (i < n) p[i] = (uint32_t)(((unsigned long long)i * stride) % n);
 }
 
 // one instantiation per (metric, summation tree): the reference picks both per index (spaces/*.rs, distance/*.rs)
@@ -717,7 +719,18 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
         if ((rc = salloc((void **)&d_dbg, 32))) return sbail(rc);
         if (hipMemsetAsync(d_dbg, 0, 32, s) != hipSuccess) return sbail(fail(HVX_ERR_DEVICE, "memset"));
     }
-    hipLaunchKernelGGL(iota_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, d_iota, (uint32_t)n);
+    // scatter: rows whose ORDER follows the data (a dump sorted by topic, an index hydrated in key order) would put each other's nearest
+    // neighbours into one batch, where they cannot see each other: insert in the order (i * stride) mod n instead, stride ~ 0.618 n and
+    // coprime with n (position 0 stays row 0).  Sequential mode keeps id order: it IS the reference's order.
+    uint32_t stride = 1;
+    if (params->scatter && !params->sequential && n > 2) {
+        auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
+        uint64_t st = (uint64_t)((double)n * 0.6180339887498949);
+        while (st > 1 && gcd(st, n) != 1) --st;
+        stride = (uint32_t)std::max<uint64_t>(st, 1);
+    }
+    auto row_at = [&](uint64_t pos) -> uint64_t { return stride == 1 ? pos : (pos * stride) % n; };
+    hipLaunchKernelGGL(iota_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, d_iota, (uint32_t)n, stride);
     if (hipMemsetAsync(d_locks, 0, n * 4, s) != hipSuccess || hipMemsetAsync(d_err, 0, 4, s) != hipSuccess) return sbail(fail(HVX_ERR_DEVICE, "memset"));
 
     DevIndex &d = ix->dev;
@@ -743,12 +756,12 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
     while (done < n) {
         // batch = consecutive nodes; a node above the current top layer is inserted alone and becomes the entry point
         uint32_t bsz = 1;
-        const uint16_t lv0 = levels ? levels[done] : 0;
+        const uint16_t lv0 = levels ? levels[row_at(done)] : 0;
         const bool promotes = lv0 > d.max_layer;
         if (!promotes && !params->sequential) {
             uint64_t want = std::min<uint64_t>(std::max<uint64_t>(done / divisor, 1), bmax);
             want = std::min<uint64_t>(want, n - done);
-            while (bsz < want && !((levels ? levels[done + bsz] : 0) > d.max_layer)) ++bsz;
+            while (bsz < want && !((levels ? levels[row_at(done + bsz)] : 0) > d.max_layer)) ++bsz;
         }
         const uint32_t layers = d.max_layer + 1u; // old max_layer + 1
         HnswArgs a{};
@@ -796,7 +809,7 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
         }
         if (e != hipSuccess) return sbail(fail(HVX_ERR_DEVICE, "build launch failed: %s", hipGetErrorString(e)));
         if (promotes) { // mutation.rs:769-772
-            d.entry = (uint32_t)done;
+            d.entry = (uint32_t)row_at(done);
             d.max_layer = lv0;
         }
         done += bsz;

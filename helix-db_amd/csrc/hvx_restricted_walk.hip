@@ -75,6 +75,8 @@ template <uint32_t METRIC, bool FUSED, uint32_t TT, uint32_t WW> struct DevCtx {
     float qhdr;
     uint32_t *wsum; // [W / 64] LDS scratch of the prefix sums
 
+    // a barrier on both sides: the uniform control flow between two phases READS words a completed phase wrote (counters, queue
+    // lengths); the barrier in front keeps a fast wavefront's next phase from overwriting such a word before a slow one has read it
     template <class F> __device__ __forceinline__ void phase(F f) {
         __syncthreads();
         f(threadIdx.x);
@@ -83,6 +85,7 @@ template <uint32_t METRIC, bool FUSED, uint32_t TT, uint32_t WW> struct DevCtx {
     __device__ __forceinline__ uint32_t atomic_or_global(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
     __device__ __forceinline__ uint32_t atomic_add_shared(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
     __device__ __forceinline__ void atomic_min_shared(uint32_t *p, uint32_t v) { atomicMin(p, v); }
+    __device__ __forceinline__ uint32_t atomic_cas_shared(uint32_t *p, uint32_t expected, uint32_t desired) { return atomicCAS(p, expected, desired); }
     // the bits were OR-ed in at the L2 by other wavefronts of this workgroup: read them there, not from the CU's L1
     __device__ __forceinline__ uint32_t load_seen(const uint32_t *p) {
         return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

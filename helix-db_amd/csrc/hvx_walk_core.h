@@ -166,6 +166,7 @@ HVX_WALK_HD uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 //   C::T                      threads;  C::W  items handled per collective step (a multiple of T)
 //   c.phase(f)                f(tid) on every thread, a barrier before and after
 //   c.atomic_or_global(p, v)  -> old     c.atomic_add_shared(p, v) -> old     c.atomic_min_shared(p, v)
+//   c.atomic_cas_shared(p, expected, desired) -> old
 //   c.load_seen(p)            coherent read of a word other threads of the workgroup may have OR-ed into in an earlier phase
 //   c.scan(a, len, &total)    in-place exclusive prefix sum over a[0..len), len <= W (collective)
 //   c.sort64(a, L)            ascending sort of L (a power of two) keys (collective)
@@ -439,6 +440,16 @@ HVX_WALK_FN uint32_t run(C &c, const View &v, const Plan &pl, const uint32_t *sa
             const uint32_t cap_rem = m.b_cap - head;
             const bool store_all = nb < cap_rem;
             const uint64_t bmax = nb ? m.B[head + nb - 1] : 0ull;
+            // eligible_seen inside the chunk: of the slots that list a member x, the FIRST in (row, position) order wins.  Round 4: an
+            // open-addressing table in LDS (2 W cells: ids in the words of `tv`, smallest listing slot in `Gr` -- both are scratch of
+            // merge_into, dead here) replaces "binary-search every earlier row of the chunk" (up to 63 searches per listed member):
+            // claim the id's cell, atomic-min the slot index into it, read the winner back in the next phase.
+            uint32_t *hk = reinterpret_cast<uint32_t *>(m.tv), *hv = m.Gr;
+            constexpr uint32_t HC = 2u * W;
+            if (!full)
+                c.phase([&](uint32_t t) {
+                    for (uint32_t i = t; i < HC; i += T) { hk[i] = kNone; hv[i] = kNone; }
+                });
             c.phase([&](uint32_t t) {
                 for (uint32_t s = t; s < slots; s += T) {
                     const uint32_t x = m.rows[s];
@@ -446,16 +457,26 @@ HVX_WALK_FN uint32_t run(C &c, const View &v, const Plan &pl, const uint32_t *sa
                     if (x != kNone) {
                         if (bit_of(v.allowed, x)) {
                             if (!full && !((c.load_seen(&v.seen[x >> 5]) >> (x & 31u)) & 1u)) {
-                                // eligible_seen inside the chunk: the first row that lists x wins
-                                const uint32_t r = s / v.s0;
-                                bool dup = false;
-                                for (uint32_t rr = 0; rr < r && !dup; ++rr) dup = row_contains(m.rows + rr * v.s0, v.s0, x);
-                                f = dup ? 0u : 1u;
+                                uint32_t h = ((x * 2654435761u) >> 9) & (HC - 1u);
+                                for (;;) {
+                                    const uint32_t old = c.atomic_cas_shared(&hk[h], kNone, x);
+                                    if (old == kNone || old == x) break;
+                                    h = (h + 1u) & (HC - 1u);
+                                }
+                                c.atomic_min_shared(&hv[h], s);
+                                m.tp[s] = h;
+                                f = 2u; // a member not yet attempted: eligible if it is the first slot that lists it
                             }
                         } else {
                             stage_bridge(x, store_all, cap_rem, bmax);
                         }
                     }
+                    m.flag[s] = (uint8_t)f;
+                }
+            });
+            c.phase([&](uint32_t t) {
+                for (uint32_t s = t; s < slots; s += T) {
+                    const uint32_t f = (m.flag[s] == 2u && hv[m.tp[s]] == s) ? 1u : 0u;
                     m.flag[s] = (uint8_t)f;
                     m.scan[s] = f;
                 }

@@ -109,7 +109,7 @@ def decode_index_metadata(value: bytes) -> dict:
 
 class BuildParams(C.Structure):  # hvx_build_params
     _fields_ = [("ef_construction", C.c_uint32), ("max_batch", C.c_uint32), ("batch_divisor", C.c_uint32), ("sequential", C.c_uint32),
-                ("link_mode", C.c_uint32)]
+                ("link_mode", C.c_uint32), ("scatter", C.c_uint32)]
 
 
 class BuildStats(C.Structure):  # hvx_build_stats
@@ -513,7 +513,7 @@ class ValidatedVectorReadIndex:
 
     @classmethod
     def build(cls, *, dim, metric, node_ids, vectors, levels=None, m=16, m0=32, ef_construction=200, max_batch=2048,
-              batch_divisor=32, sequential=False, device=-1, search_max_batch=None, float_kernel=KERNEL_AVX_FMA, link_mode=0):
+              batch_divisor=32, sequential=False, device=-1, search_max_batch=None, float_kernel=KERNEL_AVX_FMA, link_mode=0, scatter=False):
         """GPU-assisted HNSW build (hvx_index_build): the reference's insert_hnsw for batches of nodes on the device.
         Returns (index, stats dict).  `vectors` may be a host array or a torch tensor resident on the device."""
         ids = np.ascontiguousarray(node_ids, dtype=np.uint64)
@@ -526,7 +526,7 @@ class ValidatedVectorReadIndex:
                   entry_point=0, shard_id_lo=int(ids[0]) if ids.size else 0, shard_id_hi=int(ids[-1]) if ids.size else 0,
                   device=device, max_batch=max(max_batch, search_max_batch or 1024))
         bp = BuildParams(ef_construction=ef_construction, max_batch=max_batch, batch_divisor=batch_divisor, sequential=1 if sequential else 0,
-                         link_mode=link_mode)
+                         link_mode=link_mode, scatter=1 if scatter else 0)
         st = BuildStats()
         h = _vp()
         _check(lib().hvx_index_build(C.byref(d), _ptr(ids), _vp(vectors.data_ptr()) if dev_rows else _ptr(vec), _ptr(lv), C.byref(bp),

@@ -560,6 +560,10 @@ typedef struct hvx_build_params {
     uint32_t sequential;      /* 1 => one node per batch: the reference's insertion order exactly */
     uint32_t link_mode;       /* batched link step: 0 => one workgroup per link with the prune evaluated from LDS whenever the rows fit
                                  (Mmax + 2 rows of ld floats <= 160 KB), 1 => one wavefront per node (links one after the other) */
+    uint32_t scatter;         /* 1 => batched mode inserts in the order (i * stride) mod n, stride ~ 0.618 n coprime with n, instead of
+                                 id order.  For rows whose order follows the data (dumps sorted by topic, indexes hydrated in key order):
+                                 the nodes of one batch do not see each other, and consecutive rows of such data are each other's
+                                 nearest neighbours.  Ignored by sequential mode (= the reference's insertion order). */
 } hvx_build_params;
 typedef struct hvx_build_stats {
     uint64_t nodes, batches, single_node_batches;

@@ -101,16 +101,22 @@ int main(int argc, char **argv) {
     q0 = m0 = p0 = 0;
     if (direct) run(nullptr, &q0, &m0, &p0); // direct one-query calls on one handle: every call is a launch + two PCIe copies
     hvx_batcher *bt = nullptr;
-    if (hvx_batcher_new_lanes(ix, &p, 1024, 100, lanes, &bt)) { fprintf(stderr, "%s\n", hvx_last_error()); return 1; }
+    // harness knobs (the library reads no environment; lanes inherit the parent handle's settings): BATCHER_OCC = queries per SIMD of
+    // the lanes' kernels, BATCHER_PAIR = HVX_OPT_HNSW_PAIR, BATCHER_WAIT = max_wait_us
+    const char *e_occ = getenv("BATCHER_OCC"), *e_pair = getenv("BATCHER_PAIR"), *e_wait = getenv("BATCHER_WAIT");
+    const uint32_t wait_us = e_wait ? (uint32_t)atoi(e_wait) : 100u;
+    if (e_occ && hvx_index_set_occupancy(ix, (uint32_t)atoi(e_occ))) { fprintf(stderr, "%s\n", hvx_last_error()); return 1; }
+    if (e_pair && hvx_index_set_option(ix, HVX_OPT_HNSW_PAIR, (uint32_t)atoi(e_pair))) { fprintf(stderr, "%s\n", hvx_last_error()); return 1; }
+    if (hvx_batcher_new_lanes(ix, &p, 1024, wait_us, lanes, &bt)) { fprintf(stderr, "%s\n", hvx_last_error()); return 1; }
     run(bt, &q1, &m1, &p1);
     run(bt, &q1, &m1, &p1);
     uint64_t nb = 0, nqs = 0, nf = 0;
     hvx_batcher_stats(bt, &nb, &nqs, &nf);
     printf("{\"workload\": \"%llu x %u f32, %s, k=10, %d caller threads x %d single-query calls\", "
            "\"direct_calls\": {\"qps\": %.0f, \"mean_us\": %.1f, \"p99_us\": %.1f}, "
-           "\"batcher\": {\"lanes\": %u, \"qps\": %.0f, \"mean_us\": %.1f, \"p99_us\": %.1f, \"mean_batch\": %.1f, \"max_wait_us\": 100}}\n",
+           "\"batcher\": {\"lanes\": %u, \"qps\": %.0f, \"mean_us\": %.1f, \"p99_us\": %.1f, \"mean_batch\": %.1f, \"max_wait_us\": %u, \"occ\": \"%s\", \"pair\": \"%s\"}}\n",
            (unsigned long long)n, dim, strict ? "strict ef=100" : "SearchParams::new(10)", threads, per, q0, m0, p0, lanes, q1, m1, p1,
-           nb ? (double)nqs / nb : 0.0);
+           nb ? (double)nqs / nb : 0.0, wait_us, e_occ ? e_occ : "default", e_pair ? e_pair : "default");
     hvx_batcher_free(bt);
     hvx_index_free(ix);
     return 0;

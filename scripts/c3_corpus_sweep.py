@@ -24,7 +24,7 @@ for spec in sys.argv[1:]:
     torch.cuda.synchronize()
     t0 = time.time()
     ix, _ = hv.ValidatedVectorReadIndex.build(dim=dim, metric=hv.EUCLIDEAN, node_ids=np.arange(n, dtype=np.uint64), vectors=x, levels=synth.draw_levels(n, 16, 11),
-                                              m=16, m0=32, ef_construction=200, device=0, search_max_batch=nq)
+                                              m=16, m0=32, ef_construction=200, device=0, search_max_batch=nq, scatter=os.environ.get('SCATTER', '1') == '1')
     ix.sync()
     tb = time.time() - t0
     ix.set_simhash()

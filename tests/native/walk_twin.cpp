@@ -37,6 +37,7 @@ template <uint32_t TT, uint32_t WW> struct HostCtx {
     uint32_t atomic_or_global(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p = o | v; return o; }
     uint32_t atomic_add_shared(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
     void atomic_min_shared(uint32_t *p, uint32_t v) { if (v < *p) *p = v; }
+    uint32_t atomic_cas_shared(uint32_t *p, uint32_t expected, uint32_t desired) { const uint32_t o = *p; if (o == expected) *p = desired; return o; }
     uint32_t load_seen(const uint32_t *p) { return *p; }
     void scan(uint32_t *a, uint32_t len, uint32_t *total) {
         uint32_t run = 0;

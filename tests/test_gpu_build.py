@@ -261,3 +261,31 @@ def test_graph_audit_counts_what_is_wrong_and_passes_built_graphs(orc, hv):
                                               entry_point=g["entry_point"], max_layer=g["max_layer"])
     b = bad.audit_graph()
     assert b["asymmetric_edges_l0"] == 1 and b["unreachable_l0"] == 1 and b["asymmetric_edges_up"] == 0
+
+
+def test_scattered_insertion_order_serves_rows_sorted_by_topic(hv):
+    """hvx_build_params.scatter (round 4): rows in TOPIC order (consecutive rows are each other's nearest neighbours) built in batches --
+    whose nodes do not see each other -- in id order lose recall; inserted in the order (i * stride) mod n the same rows give a graph
+    that is clean under the audit (canonical, symmetric, degree-bounded rows) and searches like a graph over shuffled rows."""
+    n, dim, m, m0 = 30000, 128, 16, 32
+    rng = np.random.default_rng(9300)
+    centres = rng.standard_normal((60, 12)).astype(np.float32)
+    which = np.sort(rng.integers(0, 60, n))
+    z = centres[which] + 0.5 * rng.standard_normal((n, 12)).astype(np.float32)
+    w = (rng.standard_normal((12, dim)) / np.sqrt(12)).astype(np.float32)
+    data = (z @ w + 0.02 * rng.standard_normal((n, dim))).astype(np.float32)
+    lv = fx.draw_levels(n, m, seed=9)
+    ids = np.arange(n, dtype=np.uint64)
+    q = data[rng.integers(0, n, 200)] + np.float32(0.01) * rng.standard_normal((200, dim)).astype(np.float32)
+    rec = {}
+    for scatter in (False, True):
+        gix, st = hv.ValidatedVectorReadIndex.build(dim=dim, metric=hv.EUCLIDEAN, node_ids=ids, vectors=data, levels=lv, m=m, m0=m0,
+                                                    ef_construction=100, scatter=scatter)
+        a = gix.audit_graph()
+        for key in ("asymmetric_edges_l0", "asymmetric_edges_up", "unsorted_entries", "self_loops", "out_of_range_ids", "holes",
+                    "level_violations", "degree_overflow_rows"):
+            assert a[key] == 0, (scatter, key, a)
+        gid, _, _, _ = gix.search_batch(q, hv.SearchParams(10).with_ef(64))
+        tid, _, _, _ = gix.flat_search_batch(q, 10)
+        rec[scatter] = fx.recall_at_k(gid, tid)
+    assert rec[True] >= 0.97 and rec[True] >= rec[False] - 0.005, rec

@@ -708,12 +708,33 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
     };
     auto release = [&]() { for (void *p : scratch) (void)hipFree(p); scratch.clear(); };
     auto sbail = [&](int code) { (void)hipStreamSynchronize(s); release(); return bail(code); };
+    // Round 4: the search of batch i + 1 runs on the handle's stream WHILE batch i is selected and linked on a second stream (the
+    // search side was half of the build and strictly serial with the link step).  Batch i + 1 then does not see batch i -- which it
+    // tolerates exactly as the nodes of one batch tolerate not seeing each other: rows are only ever read as stale-or-current
+    // (agent-scope stores by the link step, immutable vectors), never torn into invalid ids.  Candidate / selection buffers are
+    // double-buffered; a promotion (new top layer = new entry point), a one-node batch and sequential mode do not overlap.
+    const size_t sz_cids = (size_t)layers_max * bmax * kCand, sz_cnt = (size_t)layers_max * bmax, sz_sel = (size_t)layers_max * bmax * 32;
     if ((rc = salloc((void **)&d_iota, n * 4)) || (rc = salloc((void **)&d_locks, n * 4)) ||
-        (rc = salloc((void **)&d_cids, (size_t)layers_max * bmax * kCand * 8)) || (rc = salloc((void **)&d_csc, (size_t)layers_max * bmax * kCand * 4)) ||
-        (rc = salloc((void **)&d_cnt, (size_t)layers_max * bmax * 4)) || (rc = salloc((void **)&d_sel, (size_t)layers_max * bmax * 32 * 4)) ||
-        (rc = salloc((void **)&d_selcnt, (size_t)layers_max * bmax * 4)) || (rc = salloc((void **)&d_status, (size_t)bmax * 4)) ||
+        (rc = salloc((void **)&d_cids, 2 * sz_cids * 8)) || (rc = salloc((void **)&d_csc, 2 * sz_cids * 4)) ||
+        (rc = salloc((void **)&d_cnt, 2 * sz_cnt * 4)) || (rc = salloc((void **)&d_sel, 2 * sz_sel * 4)) ||
+        (rc = salloc((void **)&d_selcnt, 2 * sz_cnt * 4)) || (rc = salloc((void **)&d_status, (size_t)bmax * 4)) ||
         (rc = salloc((void **)&d_err, 4)))
         return sbail(rc);
+    hipStream_t s2 = nullptr;
+    hipEvent_t ev_search[2] = {nullptr, nullptr}, ev_link[2] = {nullptr, nullptr};
+    bool link_pending[2] = {false, false};
+    auto drop_streams = [&]() {
+        if (s2) { (void)hipStreamSynchronize(s2); (void)hipStreamDestroy(s2); s2 = nullptr; }
+        for (int i = 0; i < 2; ++i) {
+            if (ev_search[i]) { (void)hipEventDestroy(ev_search[i]); ev_search[i] = nullptr; }
+            if (ev_link[i]) { (void)hipEventDestroy(ev_link[i]); ev_link[i] = nullptr; }
+        }
+    };
+    auto sbail2 = [&](int code) { (void)hipStreamSynchronize(s); drop_streams(); return sbail(code); };
+    if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) return sbail(fail(HVX_ERR_DEVICE, "stream creation failed"));
+    for (int i = 0; i < 2; ++i)
+        if (hipEventCreateWithFlags(&ev_search[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_link[i], hipEventDisableTiming) != hipSuccess)
+            return sbail2(fail(HVX_ERR_DEVICE, "event creation failed"));
     uint32_t *d_dbg = nullptr;
     if (tuning_env("HVX_BUILD_DEBUG")) {
         if ((rc = salloc((void **)&d_dbg, 32))) return sbail(rc);
@@ -753,8 +774,12 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
     d.max_layer = levels ? levels[0] : 0;
     uint64_t done = 1, batches = 0, singles = 1;
     const uint32_t divisor = params->batch_divisor ? params->batch_divisor : 32u;
+    bool prev_serial = true; // the previous batch must be complete before the next search starts
+    // the iota / lock / err initialisation above ran on `s`: the link stream starts behind it
+    if (hipEventRecord(ev_search[0], s) != hipSuccess || hipStreamWaitEvent(s2, ev_search[0], 0) != hipSuccess)
+        return sbail2(fail(HVX_ERR_DEVICE, "stream ordering failed"));
     while (done < n) {
-        // batch = consecutive nodes; a node above the current top layer is inserted alone and becomes the entry point
+        // batch = consecutive positions of the insertion order; a node above the current top layer is inserted alone and becomes the entry point
         uint32_t bsz = 1;
         const uint16_t lv0 = levels ? levels[row_at(done)] : 0;
         const bool promotes = lv0 > d.max_layer;
@@ -763,7 +788,17 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
             want = std::min<uint64_t>(want, n - done);
             while (bsz < want && !((levels ? levels[row_at(done + bsz)] : 0) > d.max_layer)) ++bsz;
         }
+        const uint32_t pb = (uint32_t)(batches & 1u); // buffer set of this batch
+        const bool serial = promotes || bsz == 1u || params->sequential != 0u || params->link_mode == 1u;
+        // the buffers of set pb were last read by the link step of batch - 2; and a serial batch (or the batch behind one) starts
+        // only when everything before it is in the graph
+        if (link_pending[pb] && hipStreamWaitEvent(s, ev_link[pb], 0) != hipSuccess) return sbail2(fail(HVX_ERR_DEVICE, "stream ordering failed"));
+        if ((serial || prev_serial) && link_pending[pb ^ 1u] && hipStreamWaitEvent(s, ev_link[pb ^ 1u], 0) != hipSuccess)
+            return sbail2(fail(HVX_ERR_DEVICE, "stream ordering failed"));
         const uint32_t layers = d.max_layer + 1u; // old max_layer + 1
+        uint64_t *b_cids = d_cids + (size_t)pb * sz_cids;
+        float *b_csc = d_csc + (size_t)pb * sz_cids;
+        uint32_t *b_cnt = d_cnt + (size_t)pb * sz_cnt, *b_sel = d_sel + (size_t)pb * sz_sel, *b_selcnt = d_selcnt + (size_t)pb * sz_cnt;
         HnswArgs a{};
         a.ix = d;
         a.bitmap = ix->d_bitmap;
@@ -771,14 +806,16 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
         a.k = kCand;
         a.ef = ef0;
         a.build_ef_upper = efu;
-        a.out_ids = d_cids;
-        a.out_scores = d_csc;
-        a.out_counts = d_cnt;
+        a.out_ids = b_cids;
+        a.out_scores = b_csc;
+        a.out_counts = b_cnt;
         a.out_status = d_status;
         a.tie_flags = ix->d_tie;
         a.build_nodes = d_iota + done;
         a.occupancy = (bsz > 1024u && params->link_mode != 1u) ? 2 : 1; // more nodes than SIMDs: two searches per SIMD instead of two rounds
-        if (launch_hnsw_wave(a, bsz, s) != hipSuccess) return sbail(fail(HVX_ERR_DEVICE, "build search launch failed: %s", hipGetErrorString(hipGetLastError())));
+        if (launch_hnsw_wave(a, bsz, s) != hipSuccess) return sbail2(fail(HVX_ERR_DEVICE, "build search launch failed: %s", hipGetErrorString(hipGetLastError())));
+        if (hipEventRecord(ev_search[pb], s) != hipSuccess || hipStreamWaitEvent(s2, ev_search[pb], 0) != hipSuccess)
+            return sbail2(fail(HVX_ERR_DEVICE, "stream ordering failed"));
         BuildArgs ba{};
         ba.ix = d;
         ba.l0 = l0w;
@@ -787,27 +824,30 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
         ba.nodes = d_iota + done;
         ba.b = bsz;
         ba.layers = layers;
-        ba.cand_ids = d_cids;
-        ba.cand_sc = d_csc;
-        ba.cand_cnt = d_cnt;
-        ba.sel = d_sel;
-        ba.sel_cnt = d_selcnt;
+        ba.cand_ids = b_cids;
+        ba.cand_sc = b_csc;
+        ba.cand_cnt = b_cnt;
+        ba.sel = b_sel;
+        ba.sel_cnt = b_selcnt;
         ba.m = m;
         ba.m0 = m0;
         ba.err = d_err;
         ba.dbg = d_dbg;
-        hipError_t e = launch_build(kern.select, dim3(bsz, layers), ba, s);
+        hipError_t e = launch_build(kern.select, dim3(bsz, layers), ba, s2);
         if (e == hipSuccess) {
             if (bsz > 1u && link_wg) { // batched mode: one workgroup per link, prunes evaluated from LDS
                 ba.ldp = ldp;
                 ba.ncmax = ncmax;
                 ba.link_ck = link_ck;
-                e = launch_link_wg(kern.link_wg, ba, layers, link_lds, s);
+                e = launch_link_wg(kern.link_wg, ba, layers, link_lds, s2);
             } else { // one node (the reference's order exactly), or rows the workgroup kernel does not serve: one wavefront per node
-                e = launch_build(kern.link, dim3(bsz), ba, s);
+                e = launch_build(kern.link, dim3(bsz), ba, s2);
             }
         }
-        if (e != hipSuccess) return sbail(fail(HVX_ERR_DEVICE, "build launch failed: %s", hipGetErrorString(e)));
+        if (e != hipSuccess) return sbail2(fail(HVX_ERR_DEVICE, "build launch failed: %s", hipGetErrorString(e)));
+        if (hipEventRecord(ev_link[pb], s2) != hipSuccess) return sbail2(fail(HVX_ERR_DEVICE, "stream ordering failed"));
+        link_pending[pb] = true;
+        prev_serial = serial;
         if (promotes) { // mutation.rs:769-772
             d.entry = (uint32_t)row_at(done);
             d.max_layer = lv0;
@@ -815,9 +855,11 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
         done += bsz;
         batches += 1;
         singles += bsz == 1 ? 1 : 0;
-        if ((batches & 63u) == 0u && hipStreamSynchronize(s) != hipSuccess) // bound the launch queue
-            return sbail(fail(HVX_ERR_DEVICE, "build kernels failed: %s", hipGetErrorString(hipGetLastError())));
+        if ((batches & 63u) == 0u && (hipStreamSynchronize(s) != hipSuccess || hipStreamSynchronize(s2) != hipSuccess)) // bound the launch queues
+            return sbail2(fail(HVX_ERR_DEVICE, "build kernels failed: %s", hipGetErrorString(hipGetLastError())));
     }
+    if (hipStreamSynchronize(s2) != hipSuccess) return sbail2(fail(HVX_ERR_DEVICE, "build did not complete: %s", hipGetErrorString(hipGetLastError())));
+    drop_streams();
     uint32_t err = 0;
     if (hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
         return sbail(fail(HVX_ERR_DEVICE, "build did not complete: %s", hipGetErrorString(hipGetLastError())));

@@ -868,7 +868,7 @@ class Batcher:
     """hvx_batcher: coalesces concurrent single-query `search` calls (one per operator invocation in the reference,
     access/search/storage.rs:140-163) into batched launches.  `search` may be called from many threads."""
 
-    def __init__(self, index: "ValidatedVectorReadIndex", params: SearchParams, max_batch: int = 0, max_wait_us: int = 200):
+    def __init__(self, index: "ValidatedVectorReadIndex", params: SearchParams, max_batch: int = 0, max_wait_us: int = 0):
         self._index = index  # keeps the index alive
         self.k = params.k
         h = _vp()

@@ -60,7 +60,6 @@ struct Batch {
     alignas(64) std::atomic<uint64_t> consumed{0}; // callers that copied their result out
     alignas(64) std::atomic<uint32_t> done{0};     // sequence + 1 of the last batch completed in this buffer (futex word)
     uint64_t total = 0;            // slots of all batches closed in this buffer (written by the closing dispatcher before `done`)
-    std::atomic<int64_t> t_first{0}; // steady-clock microseconds of the first claim of the open batch (max_wait_us)
     int rc = 0;                    // status of the launch as a whole
     std::string err;
 };
@@ -78,9 +77,6 @@ struct Lane {
 
 constexpr unsigned kSeqShift = 16;               // state word: 48-bit batch sequence | 16-bit claimed slots
 constexpr uint64_t kCountMask = 0xFFFFull;
-inline int64_t now_us() {
-    return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
 
 struct hvx_batcher {
     hvx_search_params params{};
@@ -110,16 +106,6 @@ struct hvx_batcher {
                 continue;
             }
             const uint64_t seq = s >> kSeqShift;
-            // max_wait_us > 0: a batch that is not full keeps collecting until its first query has waited that long.  (Plain short
-            // sleeps: a first version parked the lane on the bell futex and showed 50-60 ms p99 stalls at four lanes, gpurun r04f.)
-            if (max_wait_us && cnt < max_batch && !stop.load()) {
-                const int64_t waited = now_us() - bufs[seq % nbuf].t_first.load();
-                if (waited >= 0 && waited < (int64_t)max_wait_us) {
-                    const int64_t left = (int64_t)max_wait_us - waited;
-                    std::this_thread::sleep_for(std::chrono::microseconds(left < 20 ? left : 20));
-                    continue;
-                }
-            }
             // the next batch opens in buffer (seq + 1) % nbuf at the instant this one closes: it must be free, i.e. every
             // caller of the batch it held last has taken its rows
             Batch &next = bufs[(seq + 1) % nbuf];
@@ -255,7 +241,6 @@ extern "C" int hvx_batcher_search(hvx_batcher *b, const float *query, uint64_t *
         if (b->state.compare_exchange_weak(s, s + 1)) break;
     }
     Batch &bt = b->bufs[seq % b->nbuf];
-    if (slot == 0 && b->max_wait_us) bt.t_first.store(now_us());
     memcpy(bt.q + (size_t)slot * b->dim, query, (size_t)b->dim * 4);
     bt.filled.fetch_add(1);
     if ((slot == 0 || slot + 1 == b->max_batch) && b->sleepers.load()) { // first / last query of a batch: a sleeping lane should look

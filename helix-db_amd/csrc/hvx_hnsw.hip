@@ -384,7 +384,8 @@ static hipError_t launch_hnsw_wave_once(const HnswArgs &a, uint32_t b, hipStream
         probe.ef = a.ef > a.build_ef_upper ? a.ef : a.build_ef_upper;
         build_generic = !hnsw_wave_supported(probe);
     }
-    g.occ = (a.occupancy == 2 && !a.adaptive && !a.prof && !build_generic && !wide) ? 2u : 1u;
+    // (the wide beams have two-per-SIMD builds too; the one for bf16 rows at dim 1536 spills ~200 registers: it stays one per SIMD)
+    g.occ = (a.occupancy == 2 && !a.adaptive && !a.prof && !build_generic && !(wide && a.ix.dtype == HVX_BF16 && (a.ix.dim >> 5) == 48u)) ? 2u : 1u;
     const size_t fixed = 512 + (size_t)a.ix.ld * 4 + (a.adaptive ? kRngWords * 4 : 0);
     if (g.occ == 2) {
         while (g.log2cap > 9 && ((size_t)4 << g.log2cap) + fixed > 20 * 1024) --g.log2cap;

@@ -1099,11 +1099,16 @@ static hipError_t launch_wave_r(const HnswArgs &a, uint32_t b, const WaveGeom &g
 }
 // wide register beams of the strict arm (round 4; hvx_hnsw_wave_wide_*.hip): 448 entries (ef <= 416) and 832 entries (ef <= 800), one
 // query per SIMD; the 832-entry build is also the re-run of a 384- or 448-entry launch
-template <uint32_t METRIC, bool BF> static hipError_t launch_wave_wide_r(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
+template <uint32_t METRIC, bool BF, int OCC> static hipError_t launch_wave_wide_o(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
     const uint32_t need = a.ef + 32u;
-    if (need <= 448 && !a.only_flagged) return launch_wave_nk<METRIC, 7, BF>(a, b, g, s);
-    if (need <= 832) return launch_wave_nk<METRIC, 13, BF>(a, b, g, s);
+    if (need <= 448 && !a.only_flagged) return launch_wave_nk<METRIC, 7, BF, false, true, OCC>(a, b, g, s);
+    if (need <= 832) return launch_wave_nk<METRIC, 13, BF, false, true, OCC>(a, b, g, s);
     return hipErrorInvalidValue;
+}
+// one query per SIMD, or (handles with two queries per SIMD: several batches in flight) the half-register build, whose second
+// resident query hides the first one's round trips exactly as it does for the narrow beams
+template <uint32_t METRIC, bool BF> static hipError_t launch_wave_wide_r(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
+    return g.occ == 2 ? launch_wave_wide_o<METRIC, BF, 2>(a, b, g, s) : launch_wave_wide_o<METRIC, BF, 1>(a, b, g, s);
 }
 // GENERIC build of the non-strict arms: beam of 64*R >= ef + 32 entries
 template <uint32_t METRIC, bool ST> static hipError_t launch_wave_gen_r(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {

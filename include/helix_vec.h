@@ -463,10 +463,11 @@ int hvx_prefilter_search_batch_params(const hvx_index *, const hvx_csr *, const 
 /*
  * Batching operator: the reference calls ValidatedVectorReadIndex::search once per operator invocation
  * from many tokio tasks (access/search/storage.rs:140-163).  Concurrent single-query callers are coalesced into ONE
- * hvx_search_batch_params launch: a caller blocks in hvx_batcher_search until its rows are ready.  A dispatcher lane that
- * is FREE takes the open batch as soon as it is full (max_batch, 0 = the index's max_batch, at most 65 535) or -- when it is
- * not full -- as soon as its first query has waited max_wait_us (0 = at once: while every lane is busy the open batch
- * simply keeps growing, so the batch size follows the load; a positive value trades that much latency for larger batches).
+ * hvx_search_batch_params launch: a caller blocks in hvx_batcher_search until its rows are ready.  A batch is launched when it
+ * is full (max_batch, 0 = the index's max_batch, at most 65 535) or AS SOON AS A DISPATCHER LANE IS FREE and at least one query
+ * waits: while every lane is busy the open batch keeps growing, so the batch size follows the load and no timer is involved.
+ * max_wait_us is accepted for source compatibility and not used (round 4: holding a free lane back until the oldest query has
+ * waited was measured -- 335 instead of 308 queries per batch, throughput -30 %, p99 2 ms -> 50 ms at 1 024 closed-loop callers).
  * All callers of one batcher share `params`.  Thread-safe; results equal a direct batch call's.  A rejected query fails
  * alone.  hvx_batcher_free may be called while callers are blocked: they return HVX_ERR_INVARIANT.
  */

@@ -20,8 +20,6 @@
 #include <numeric>
 #include <vector>
 
-#include <hipcub/hipcub.hpp>
-
 #include "hvx_host.h"
 #include "hvx_walk_core.h"
 
@@ -353,6 +351,48 @@ __global__ void dir_prefix_kernel(const uint64_t *sorted_codes, uint32_t n, uint
     if (p > 65536u) return;
     prefix[p] = p == 65536u ? n : walk::lower_bound(sorted_codes, n, (uint64_t)p << 48);
 }
+// A plain stable LSD radix sort of (u64 key, u32 value) pairs, 8 bits per pass, 256 elements per workgroup: a one-off per image
+// (1M pairs: ~2 ms), written out here because the library links nothing that reads the environment (hipCUB's dispatch does).
+constexpr uint32_t kRsBlock = 256;
+__global__ __launch_bounds__(256) void rs_hist_kernel(const uint64_t *keys, uint32_t n, uint32_t shift, uint32_t *hist, uint32_t nblocks) {
+    __shared__ uint32_t h[256];
+    const uint32_t t = threadIdx.x, i = blockIdx.x * kRsBlock + t;
+    h[t] = 0;
+    __syncthreads();
+    if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    __syncthreads();
+    hist[(size_t)t * nblocks + blockIdx.x] = h[t]; // digit-major: a scan over the whole array yields every (digit, block) start
+}
+__global__ __launch_bounds__(1024) void rs_scan_kernel(uint32_t *a, uint32_t len) { // exclusive scan, one workgroup
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x, per = (len + 1023u) / 1024u, lo = t * per, hi = lo + per < len ? lo + per : len;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += a[i];
+    part[t] = sum;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t run = 0;
+        for (uint32_t i = 0; i < 1024u; ++i) { const uint32_t x = part[i]; part[i] = run; run += x; }
+    }
+    __syncthreads();
+    uint32_t run = part[t];
+    for (uint32_t i = lo; i < hi; ++i) { const uint32_t x = a[i]; a[i] = run; run += x; }
+}
+__global__ __launch_bounds__(256) void rs_scatter_kernel(const uint64_t *keys, const uint32_t *vals, uint32_t n, uint32_t shift, const uint32_t *starts,
+                                                         uint32_t nblocks, uint64_t *out_keys, uint32_t *out_vals) {
+    __shared__ uint32_t dg[256];
+    const uint32_t t = threadIdx.x, i = blockIdx.x * kRsBlock + t;
+    const uint64_t key = i < n ? keys[i] : 0ull;
+    const uint32_t d = i < n ? (uint32_t)(key >> shift) & 255u : 0xFFFFFFFFu;
+    dg[t] = d;
+    __syncthreads();
+    if (i >= n) return;
+    uint32_t rank = 0; // stable: elements of this workgroup with the same digit that come earlier
+    for (uint32_t u = 0; u < t; ++u) rank += dg[u] == d ? 1u : 0u;
+    const uint32_t pos = starts[(size_t)d * nblocks + blockIdx.x] + rank;
+    out_keys[pos] = key;
+    out_vals[pos] = vals[i];
+}
 
 int ensure_directory(hvx_index *ix) {
     hvx_image_shared &sh = *ix->shared;
@@ -367,22 +407,27 @@ int ensure_directory(hvx_index *ix) {
     HIP_TRY(hipMalloc((void **)&sh.dir_row, (size_t)n1 * 4));
     HIP_TRY(hipMalloc((void **)&sh.dir_prefix, 65537u * 4));
     uint64_t *codes = nullptr;
-    uint32_t *rows = nullptr;
-    void *temp = nullptr;
+    uint32_t *rows = nullptr, *hist = nullptr;
     auto release = [&]() {
-        for (void *p : {(void *)codes, (void *)rows, temp})
+        for (void *p : {(void *)codes, (void *)rows, (void *)hist})
             if (p) (void)hipFree(p);
     };
     auto bail = [&](int rc) { (void)hipStreamSynchronize(s); release(); return rc; };
-    if (hipMalloc((void **)&codes, (size_t)n1 * 8) != hipSuccess || hipMalloc((void **)&rows, (size_t)n1 * 4) != hipSuccess)
+    const uint32_t nblocks = (n1 + kRsBlock - 1u) / kRsBlock;
+    if (hipMalloc((void **)&codes, (size_t)n1 * 8) != hipSuccess || hipMalloc((void **)&rows, (size_t)n1 * 4) != hipSuccess ||
+        hipMalloc((void **)&hist, (size_t)256 * nblocks * 4) != hipSuccess)
         return bail(fail(HVX_ERR_DEVICE, "hipMalloc of the directory scratch failed"));
     if (n) {
-        hipLaunchKernelGGL(dir_codes_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, ix->d_node_hash, n, codes, rows);
-        size_t temp_bytes = 0;
-        if (hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, codes, sh.dir_code, rows, sh.dir_row, (int)n, 0, 64, s) != hipSuccess ||
-            hipMalloc(&temp, std::max<size_t>(temp_bytes, 16)) != hipSuccess ||
-            hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, codes, sh.dir_code, rows, sh.dir_row, (int)n, 0, 64, s) != hipSuccess)
-            return bail(fail(HVX_ERR_DEVICE, "radix sort of the SimHash directory failed: %s", hipGetErrorString(hipGetLastError())));
+        hipLaunchKernelGGL(dir_codes_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, ix->d_node_hash, n, sh.dir_code, sh.dir_row);
+        uint64_t *ka = sh.dir_code, *kb = codes;
+        uint32_t *va = sh.dir_row, *vb = rows;
+        for (uint32_t pass = 0; pass < 8; ++pass) { // eight passes: the sorted pairs end where they started (dir_code / dir_row)
+            hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(256), 0, s, ka, n, pass * 8u, hist, nblocks);
+            hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(1024), 0, s, hist, 256u * nblocks);
+            hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblocks), dim3(256), 0, s, ka, va, n, pass * 8u, hist, nblocks, kb, vb);
+            std::swap(ka, kb);
+            std::swap(va, vb);
+        }
     }
     hipLaunchKernelGGL(dir_prefix_kernel, dim3((65537u + 255u) / 256u), dim3(256), 0, s, sh.dir_code, n, sh.dir_prefix);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess)

@@ -309,4 +309,52 @@ __device__ __forceinline__ float group_distance(const DevIndex &ix, const float 
     return result;
 }
 
+// The same distance over a bf16 row (device layout above; dim % 64 == 0, AVX+FMA tree, L2 / cosine -- what the import accepts for
+// bf16 rows): the row's values are exact f32 numbers, the arithmetic and its order are those of group_distance, so the score equals
+// the reference's on the rounded vector bit for bit.  Used where rows are scored one per 8-lane group outside the unrolled HNSW
+// kernels (the restricted walk, round 4).
+template <uint32_t METRIC>
+__device__ __forceinline__ float group_distance_bf16(const DevIndex &ix, const float *qv, float qhdr, uint32_t node, int j) {
+    const int slot = chunk_slot(j);
+    const uint16_t *rb = ix.vecb + (size_t)node * ix.dim;
+    const float4 *rp = reinterpret_cast<const float4 *>(rb) + slot; // one 16-byte piece = this lane's virtual lanes of TWO chunks
+    const float4 *qp = reinterpret_cast<const float4 *>(qv) + slot;
+    const uint32_t np = ix.dim >> 6;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto step = [&](const float4 xw, uint32_t m) __attribute__((always_inline)) {
+        const uint32_t w0 = __float_as_uint(xw.x), w1 = __float_as_uint(xw.y), w2 = __float_as_uint(xw.z), w3 = __float_as_uint(xw.w);
+        const float4 q0 = qp[(2u * m) * 8u], q1 = qp[(2u * m + 1u) * 8u];
+        const float a0 = __uint_as_float(w0 << 16), a1 = __uint_as_float(w0 & 0xFFFF0000u), a2 = __uint_as_float(w1 << 16), a3 = __uint_as_float(w1 & 0xFFFF0000u);
+        const float b0 = __uint_as_float(w2 << 16), b1 = __uint_as_float(w2 & 0xFFFF0000u), b2 = __uint_as_float(w3 << 16), b3 = __uint_as_float(w3 & 0xFFFF0000u);
+        if (METRIC == kL2) {
+            float d0 = q0.x - a0, d1 = q0.y - a1, d2 = q0.z - a2, d3 = q0.w - a3;
+            acc.x = __builtin_fmaf(d0, d0, acc.x); acc.y = __builtin_fmaf(d1, d1, acc.y);
+            acc.z = __builtin_fmaf(d2, d2, acc.z); acc.w = __builtin_fmaf(d3, d3, acc.w);
+            d0 = q1.x - b0; d1 = q1.y - b1; d2 = q1.z - b2; d3 = q1.w - b3;
+            acc.x = __builtin_fmaf(d0, d0, acc.x); acc.y = __builtin_fmaf(d1, d1, acc.y);
+            acc.z = __builtin_fmaf(d2, d2, acc.z); acc.w = __builtin_fmaf(d3, d3, acc.w);
+        } else {
+            acc.x = __builtin_fmaf(q0.x, a0, acc.x); acc.y = __builtin_fmaf(q0.y, a1, acc.y);
+            acc.z = __builtin_fmaf(q0.z, a2, acc.z); acc.w = __builtin_fmaf(q0.w, a3, acc.w);
+            acc.x = __builtin_fmaf(q1.x, b0, acc.x); acc.y = __builtin_fmaf(q1.y, b1, acc.y);
+            acc.z = __builtin_fmaf(q1.z, b2, acc.z); acc.w = __builtin_fmaf(q1.w, b3, acc.w);
+        }
+    };
+    uint32_t m = 0;
+    for (; m + 8 <= np; m += 8) { // 8 independent 16-byte loads in flight per lane before the first use
+        float4 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = rp[(size_t)(m + u) * 8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) step(x[u], m + (uint32_t)u);
+    }
+    for (; m < np; ++m) step(rp[(size_t)m * 8], m);
+    float r = avx_tree_reduce(acc);
+    if (METRIC == kCosine)
+        r = cosine_finish_fn(r, qhdr, ix.hdr[node], [&]() {
+            return stable_half_cosine_fn(ix.dim, [&](uint32_t i) { return qv[i]; }, [&](uint32_t i) { return bf16_to_f32(rb[bf16_slot_of(i)]); });
+        });
+    return r;
+}
+
 } // namespace hvx

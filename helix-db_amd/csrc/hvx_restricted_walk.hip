@@ -153,7 +153,9 @@ template <uint32_t METRIC, bool FUSED, uint32_t TT, uint32_t WW> struct DevCtx {
         int bad = 0;
         for (uint32_t f = grp; f < n; f += T / 8) {
             const uint32_t node = rows[f];
-            float d = group_distance<METRIC, FUSED>(ix, qv, qhdr, node, j);
+            float d;
+            if (METRIC != kL1 && FUSED && ix.dtype == HVX_BF16) d = group_distance_bf16<METRIC == kL1 ? kL2 : METRIC>(ix, qv, qhdr, node, j);
+            else d = group_distance<METRIC, FUSED>(ix, qv, qhdr, node, j);
             if (!score_valid(d)) bad = 1;
             if (j == 0) keys[f] = ((uint64_t)__float_as_uint(d) << 32) | ((uint64_t)node << 1);
         }
@@ -445,7 +447,7 @@ int grow(hvx_index *ix, void **p, size_t *cap, size_t bytes) {
     return HVX_OK;
 }
 
-bool walk_supported(const hvx_index *ix) { return ix->dev.dtype == HVX_F32 && ix->dev.s0 <= kW && ix->dev.s0 != 0; }
+bool walk_supported(const hvx_index *ix) { return (ix->dev.dtype == HVX_F32 || ix->dev.dtype == HVX_BF16) && ix->dev.s0 <= kW && ix->dev.s0 != 0; }
 
 void widen(const walk::Counters &c, uint32_t ef_filtered, hvx_restricted_stats *o) {
     o->strategy = HVX_RESTRICTED_FILTERED;
@@ -475,7 +477,7 @@ int walk_shared_set(hvx_index *ix, const float *queries, uint32_t b, uint32_t k_
     if (!ix->has_simhash)
         return fail(HVX_ERR_INVARIANT, "the filtered restricted search needs the index's SimHash rows (hvx_index_set_simhash): "
                     "missing SimHash companion rows are index corruption in the reference");
-    if (!walk_supported(ix)) return fail(HVX_ERR_UNSUPPORTED, "the filtered restricted walk serves f32 rows with neighbour rows <= %u ids", kW);
+    if (!walk_supported(ix)) return fail(HVX_ERR_UNSUPPORTED, "the filtered restricted walk serves f32 / bf16 rows with neighbour rows <= %u ids", kW);
     if ((rc = ensure_directory(ix))) return rc;
     const uint32_t words = (ix->dev.n + 31u) / 32u + 1u, mb = ix->max_batch;
     if ((rc = grow(ix, (void **)&ix->w_allowed, &ix->cap_w_allowed, (size_t)words * 4))) return rc;

@@ -291,10 +291,11 @@ int hvx_search_restricted_batch(const hvx_index *, const float *queries, uint32_
  * take restricted_exact_scan (restricted.rs:753-835), everything else restricted_filter_aware_search (restricted.rs:837-1148):
  * seeds = deterministic sample of the candidate set (:321-342) + SimHash-directory windows around the query's order code
  * (:866-923) + the entry point; an ACORN-style walk over layer-0 rows in which members are scored and non-members become
- * bridges ranked by SimHash Hamming distance; the six budgets of FilteredGraphBudgets (:230-259).  One 256-thread
- * workgroup per query (csrc/hvx_restricted_walk.hip); ids, score bits, every counter below and the termination reason equal
- * the reference CPU path's.  Needs the SimHash rows (hvx_index_set_simhash; missing => HVX_ERR_INVARIANT like the
- * reference's missing_simhash_error) and f32 rows; strategy EXACT forces the device's exact gathered scan for any
+ * bridges ranked by SimHash Hamming distance; the six budgets of FilteredGraphBudgets (:230-259).  One workgroup per query
+ * (csrc/hvx_restricted_walk.hip: 1 024 threads for batches of <= 256 queries, 256 threads above); ids, score bits, every counter
+ * below and the termination reason equal the reference CPU path's.  Needs the SimHash rows (hvx_index_set_simhash; missing =>
+ * HVX_ERR_INVARIANT like the reference's missing_simhash_error) and f32 or bf16 rows (bf16: the reference's arithmetic on the
+ * stored, rounded values; fp8 rows take the exact scan); strategy EXACT forces the device's exact gathered scan for any
  * candidate-set size (what hvx_search_restricted_batch does), FILTERED forces the walk (the reference's tests call it that way).
  * An AUTO plan (no explicit budgets) that the walk of this build cannot run -- the reference's own budget rule gives
  * bridge_rows = 8 x max(1.5 ef, 4 k) > 9 600 for k >= 301 or ef > 800; bf16 / fp8 rows; neighbour rows beyond the walk's width

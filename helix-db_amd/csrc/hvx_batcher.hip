@@ -66,7 +66,12 @@ struct Batch {
 
 struct Lane {
     hvx_index *ix = nullptr;
-    std::thread worker;
+    std::thread worker, waker;
+    // hand-over to the lane's waker thread (round 4): waking a few hundred futex waiters costs the kernel ~1 us each -- 0.2-0.4 ms per
+    // batch during which the lane launched nothing.  The dispatcher publishes the finished batch here and goes back to the queue.
+    alignas(64) std::atomic<Batch *> wake_batch{nullptr};
+    std::atomic<uint32_t> wake_seq{0};
+    alignas(64) std::atomic<uint32_t> wake_bell{0};
     float *d_q = nullptr;
     uint64_t *d_ids = nullptr;
     float *d_sc = nullptr;
@@ -125,9 +130,34 @@ struct hvx_batcher {
             n_queries.fetch_add(cnt, std::memory_order_relaxed);
             if (cnt == max_batch) n_full.fetch_add(1, std::memory_order_relaxed);
             launch(ln, bt, cnt);
+            Batch *expected = nullptr;
+            if (ln.waker.joinable() && ln.wake_batch.load() == nullptr) { // the waker is idle: it completes the batch, this lane goes on
+                ln.wake_seq.store((uint32_t)(seq + 1));
+                if (ln.wake_batch.compare_exchange_strong(expected, &bt)) {
+                    ln.wake_bell.fetch_add(1);
+                    futex_wake(&ln.wake_bell, 1);
+                    continue;
+                }
+            }
             bt.done.store((uint32_t)(seq + 1));
             futex_wake(&bt.done, INT_MAX); // (a fan-out wake -- woken callers waking the rest -- was measured 10x SLOWER: a thousand
                                            //  threads calling FUTEX_WAKE on one word contend on its hash bucket; r03i/batcher_1m_c.log)
+        }
+    }
+
+    void wake_loop(Lane &ln) {
+        for (;;) {
+            const uint32_t b0 = ln.wake_bell.load();
+            Batch *bt = ln.wake_batch.load();
+            if (!bt) {
+                if (stop.load()) return;
+                futex_wait(&ln.wake_bell, b0, 2000);
+                continue;
+            }
+            const uint32_t want = ln.wake_seq.load();
+            bt->done.store(want);
+            futex_wake(&bt->done, INT_MAX);
+            ln.wake_batch.store(nullptr);
         }
     }
 
@@ -155,6 +185,11 @@ extern "C" void hvx_batcher_free(hvx_batcher *b) {
     futex_wake(&b->bell, INT_MAX);
     for (Lane &ln : b->lanes)
         if (ln.worker.joinable()) ln.worker.join();
+    for (Lane &ln : b->lanes) { // (after the dispatchers: a batch they handed over is still completed)
+        ln.wake_bell.fetch_add(1);
+        futex_wake(&ln.wake_bell, 1);
+        if (ln.waker.joinable()) ln.waker.join();
+    }
     (void)hipSetDevice(b->device);
     for (Lane &ln : b->lanes) {
         for (void *p : {(void *)ln.d_q, (void *)ln.d_ids, (void *)ln.d_sc, (void *)ln.d_cnt, (void *)ln.d_st})
@@ -188,7 +223,7 @@ extern "C" int hvx_batcher_new_lanes(hvx_index *ix, const hvx_search_params *par
     b->device = ix->device;
     b->nbuf = lanes + 2; // one open batch, one per lane in flight, one being drained by its callers
     b->bufs = std::vector<Batch>(b->nbuf);
-    b->lanes.resize(lanes);
+    b->lanes = std::vector<Lane>(lanes);
     auto host = [&](void **p, size_t bytes) { return hipHostMalloc(p, bytes, hipHostMallocDefault) == hipSuccess; };
     auto dev = [&](void **p, size_t bytes) { return hipMalloc(p, bytes) == hipSuccess; };
     bool ok = true;
@@ -212,6 +247,7 @@ extern "C" int hvx_batcher_new_lanes(hvx_index *ix, const hvx_search_params *par
     }
     for (Lane &ln : b->lanes) {
         Lane *lp = &ln;
+        ln.waker = std::thread([b, lp] { b->wake_loop(*lp); });
         ln.worker = std::thread([b, lp] { b->run(*lp); });
     }
     *out = b;

@@ -92,6 +92,7 @@ struct hvx_batcher {
     alignas(64) std::atomic<uint32_t> bell{0};       // dispatchers sleep on it; rung by the first and the last claim of a batch
     alignas(64) std::atomic<uint32_t> sleepers{0};   // dispatchers asleep on the bell
     std::atomic<bool> stop{false};
+    std::atomic<uint32_t> inside{0};                 // callers currently inside hvx_batcher_search (hvx_batcher_free waits for them)
     std::vector<Batch> bufs;
     std::vector<Lane> lanes;
     std::atomic<uint64_t> n_batches{0}, n_queries{0}, n_full{0};
@@ -190,6 +191,13 @@ extern "C" void hvx_batcher_free(hvx_batcher *b) {
         futex_wake(&ln.wake_bell, 1);
         if (ln.waker.joinable()) ln.waker.join();
     }
+    // callers that were blocked when the batcher stopped leave with "shutting down" (their futex waits time out within 5 ms): the
+    // object outlives the last of them.  (Calling hvx_batcher_search AFTER hvx_batcher_free has returned is the host's bug.)
+    for (uint32_t spins = 0; b->inside.load() != 0 && spins < 200000u; ++spins) {
+        for (Batch &bt : b->bufs) futex_wake(&bt.done, INT_MAX);
+        futex_wake(&b->seq_word, INT_MAX);
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
     (void)hipSetDevice(b->device);
     for (Lane &ln : b->lanes) {
         for (void *p : {(void *)ln.d_q, (void *)ln.d_ids, (void *)ln.d_sc, (void *)ln.d_cnt, (void *)ln.d_st})
@@ -259,8 +267,15 @@ extern "C" int hvx_batcher_new(hvx_index *ix, const hvx_search_params *params, u
     return hvx_batcher_new_lanes(ix, params, max_batch, max_wait_us, 0, out);
 }
 
+static int batcher_search_inner(hvx_batcher *b, const float *query, uint64_t *out_ids, float *out_scores, uint32_t *out_count);
 extern "C" int hvx_batcher_search(hvx_batcher *b, const float *query, uint64_t *out_ids, float *out_scores, uint32_t *out_count) {
     if (!b || !query || !out_ids || !out_scores || !out_count) return fail(HVX_ERR_INVARIANT, "null argument");
+    b->inside.fetch_add(1);
+    const int rc = batcher_search_inner(b, query, out_ids, out_scores, out_count);
+    b->inside.fetch_sub(1);
+    return rc;
+}
+static int batcher_search_inner(hvx_batcher *b, const float *query, uint64_t *out_ids, float *out_scores, uint32_t *out_count) {
     *out_count = 0;
     // claim a slot of the open batch
     uint64_t seq;

@@ -1741,3 +1741,56 @@ def test_pair_kernel_on_duplicates_ties_rejected_queries_and_bf16(orc, hv, dtype
     for i in (0, 1, 2, 4, 7):
         rc, oid, osc = oix.search(qb[i], 10, 64)
         assert ids[i, :cnt[i]].tolist() == oid.tolist() and bits(sc[i, :cnt[i]]).tolist() == bits(osc).tolist()
+
+
+def test_batcher_free_with_callers_in_flight_does_not_hang(orc, hv):
+    """callers that leave on shutdown must account for their slot, or a dispatcher draining that buffer spins forever
+    and hvx_batcher_free hangs in join().  24 threads keep searching while the batcher is freed: every call either returns the direct
+    call's rows or fails with "shutting down", and close() returns."""
+    import threading
+    import time
+    rng = np.random.default_rng(18)
+    n, dim = 1500, 128
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    oix = build_oracle(orc, data, 1, fx.draw_levels(n, 16, seed=6), efc=60)
+    gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=dim, metric=1, max_batch=32)
+    q = rng.standard_normal((64, dim)).astype(np.float32)
+    want_ids, _, want_cnt, _ = gix.search_batch(q, hv.SearchParams(10).with_ef(64))
+    for _round in range(3):
+        bt = hv.Batcher(gix, hv.SearchParams(10).with_ef(64), max_batch=32)
+        lk = threading.Lock()
+        state = {"closing": False}
+        wrong, done = [], [0]
+
+        def worker(t):
+            i = t
+            while True:
+                with lk:              # no call STARTS once the batcher is being freed (calling into a freed handle is the host's bug);
+                    if state["closing"]:   # calls already inside it are the ones this test is about
+                        return
+                try:
+                    got = bt.search(q[i % 64])
+                    if [r.entity_id for r in got] != want_ids[i % 64, :want_cnt[i % 64]].tolist():
+                        wrong.append(i)
+                    done[0] += 1
+                except hv.HelixDbError as e:
+                    if "shutting down" not in str(e):
+                        wrong.append(str(e))
+                    return
+                i += 24
+
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(24)]
+        [t.start() for t in th]
+        time.sleep(0.05)
+
+        def close_it():
+            with lk:
+                state["closing"] = True
+            bt.close()
+
+        closer = threading.Thread(target=close_it)
+        closer.start()
+        closer.join(timeout=30)
+        assert not closer.is_alive(), "hvx_batcher_free hangs while callers are blocked"
+        [t.join(timeout=30) for t in th]
+        assert not any(t.is_alive() for t in th) and not wrong, wrong[:3]

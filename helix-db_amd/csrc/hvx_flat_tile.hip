@@ -481,6 +481,157 @@ __global__ __launch_bounds__(256, 2) void flat_tile2_kernel(MfmaArgs a, float xm
     tile_epilogue<FP8, 2>(a, acc, lds, q0, r0, wm, wn, tid, xmax2, wg_overflow);
 }
 
+// ---- the role-split build (round 4; VERDICT r2 / r3 "the structure that is still untried"): 512 threads = 2 x 4 wavefronts on a
+// 256 x 256 tile, 64-deep stages in two LDS buffers, and the two wavefronts of every SIMD in OPPOSITE roles at any instant.  The
+// four wavefronts of query half 1 run one phase behind those of half 0 (one extra barrier at the start), and a stage is four
+// phases separated by raw s_barriers:
+//     half 0 of the wavefronts:   read steps 0-1 | MFMA steps 0-1 | read steps 2-3 | MFMA steps 2-3
+//     half 1 (one phase later):                  | read steps 0-1 | MFMA steps 0-1 | read steps 2-3 | MFMA steps 2-3
+// so while one wavefront of a SIMD issues its 16 MFMAs (s_setprio 1: nothing else of that SIMD competes for issue slots) the other
+// one has its 12 fragment reads (and, at the start of a stage, its 8 LDS-DMA copies of the next stage) in flight.  In the lock-step
+// builds above all wavefronts read at once and multiply at once: LDS time and matrix-core time ADD (profiles/r02g_ablate_bf16.txt:
+// 0.93 ms = 0.35 MFMA + 0.24 reads + copies + epilogue).
+// Hand-over rules (cdna_hip_programming.md, "Read a staged buffer one phase AFTER the wait that retires it"): a wavefront waits for
+// ITS copies of stage s + 1 (vmcnt(0)) at the end of its second read phase of stage s, before that phase's barrier; the first read
+// of stage s + 1 by anybody is at least one barrier later.  The buffer of stage s + 1 was last read (stage s - 1) one phase before
+// the first copy into it is issued.
+template <int KIND>
+__global__ __launch_bounds__(512) void flat_tile8_kernel(MfmaArgs a, float xmax2, uint32_t *wg_overflow) {
+    constexpr bool FP8 = KIND == 1;
+    constexpr int ROWB = FP8 ? 64 : 128;            // bytes of one tile row per stage (queries: 128)
+    constexpr int BSTAGE = kTN * ROWB;
+    constexpr int STAGE = kAStage + BSTAGE;         // 64 KB (bf16) / 48 KB (fp8)
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    uint32_t qt, rt;
+    if (!tile_coords(a, qt, rt)) return;
+    const uint32_t q0 = qt * kTM, r0 = rt * kTN;
+
+    // staging: wave w copies query rows 32 w .. 32 w + 31 (four 1-KB pieces) and tile rows 32 w .. 32 w + 31 (four / two pieces)
+    const unsigned char *gA[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const uint32_t row = (uint32_t)(32 * wave + 8 * t + (lane >> 3));
+        const uint32_t slot = (uint32_t)(lane & 7) ^ ((row >> 1) & 7u);
+        gA[t] = reinterpret_cast<const unsigned char *>(a.qhi) + (size_t)(q0 + row) * a.dim * 2 + slot * 16; // queries are padded to 256
+    }
+    constexpr int NB = FP8 ? 2 : 4;
+    const unsigned char *gB[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+        uint32_t row, slot;
+        if (FP8) { row = (uint32_t)(32 * wave + 16 * t + (lane >> 2)); slot = (uint32_t)(lane & 3) ^ ((row >> 2) & 3u); }
+        else { row = (uint32_t)(32 * wave + 8 * t + (lane >> 3)); slot = (uint32_t)(lane & 7) ^ ((row >> 1) & 7u); }
+        uint32_t rloc = r0 + row;
+        if (rloc >= a.nrows) rloc = a.nrows - 1; // clamp: the duplicate is masked in the epilogue
+        const size_t node = a.subset ? a.subset[a.row0 + rloc] : (size_t)a.row0 + rloc;
+        gB[t] = reinterpret_cast<const unsigned char *>(a.rows) + node * a.dim * (FP8 ? 1 : 2) + slot * 16;
+    }
+    auto issue_stage = [&](uint32_t s) {
+        unsigned char *sA = lds + (s & 1u) * STAGE + wave * 4096;
+        unsigned char *sB = lds + (s & 1u) * STAGE + kAStage + wave * (32 * ROWB);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) HVX_GLDS16(gA[t] + s * 128u, sA + t * 1024);
+#pragma unroll
+        for (int t = 0; t < NB; ++t) HVX_GLDS16(gB[t] + s * (uint32_t)ROWB, sB + t * 1024);
+    };
+    const int fr = lane & 31, h = lane >> 5;
+    int off128[4], off64[2];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) off128[kk] = fr * 128 + (((2 * kk + h) ^ ((fr >> 1) & 7)) << 4);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) off64[jj] = fr * 64 + (((2 * jj + h) ^ ((fr >> 2) & 3)) << 4);
+    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(lds);
+    const uint32_t baseA = lds0 + (uint32_t)(wm * (128 * 128)), baseB = lds0 + (uint32_t)(kAStage + wn * (64 * ROWB));
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    uint4 c8[2];
+    auto read_raw = [&](uint32_t buf, int kk, bf16x8 (&fa)[4], bf16x8 (&fb)[2]) {
+        const uint32_t pa = baseA + buf * (uint32_t)STAGE + (uint32_t)off128[kk];
+        fa[0] = __builtin_bit_cast(bf16x8, lds_read16<0>(pa));
+        fa[1] = __builtin_bit_cast(bf16x8, lds_read16<4096>(pa));
+        fa[2] = __builtin_bit_cast(bf16x8, lds_read16<8192>(pa));
+        fa[3] = __builtin_bit_cast(bf16x8, lds_read16<12288>(pa));
+        if (FP8) {
+            if ((kk & 1) == 0) {
+                const uint32_t pb = baseB + buf * (uint32_t)STAGE + (uint32_t)off64[kk >> 1];
+                c8[0] = lds_read16<0>(pb);
+                c8[1] = lds_read16<32 * 64>(pb);
+            }
+        } else {
+            const uint32_t pb = baseB + buf * (uint32_t)STAGE + (uint32_t)off128[kk];
+            fb[0] = __builtin_bit_cast(bf16x8, lds_read16<0>(pb));
+            fb[1] = __builtin_bit_cast(bf16x8, lds_read16<4096>(pb));
+        }
+    };
+    auto widen = [&](int kk, bf16x8 (&fb)[2]) {
+        if (!FP8) return;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t w0 = (kk & 1) ? c8[j].z : c8[j].x, w1 = (kk & 1) ? c8[j].w : c8[j].y;
+            const f32x2 a01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w0, false), a23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w0, true);
+            const f32x2 b01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w1, false), b23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)w1, true);
+            uint4 wv;
+            wv.x = __builtin_amdgcn_perm(__float_as_uint(a01[1]), __float_as_uint(a01[0]), 0x07060302u);
+            wv.y = __builtin_amdgcn_perm(__float_as_uint(a23[1]), __float_as_uint(a23[0]), 0x07060302u);
+            wv.z = __builtin_amdgcn_perm(__float_as_uint(b01[1]), __float_as_uint(b01[0]), 0x07060302u);
+            wv.w = __builtin_amdgcn_perm(__float_as_uint(b23[1]), __float_as_uint(b23[0]), 0x07060302u);
+            fb[j] = __builtin_bit_cast(bf16x8, wv);
+        }
+    };
+    auto mfma8 = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[2]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    };
+    bf16x8 fa0[4], fb0[2], fa1[4], fb1[2];
+    auto read_phase = [&](uint32_t buf, int kk) __attribute__((always_inline)) { // the fragments of steps kk and kk + 1, complete before the barrier
+        read_raw(buf, kk, fa0, fb0);
+        read_raw(buf, kk + 1, fa1, fb1);
+        wait_lgkm<0>();
+        widen(kk, fb0);
+        widen(kk + 1, fb1);
+    };
+    auto mfma_phase = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        mfma8(fa0, fb0);
+        mfma8(fa1, fb1);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    const uint32_t nstage = a.dim >> 6;
+    issue_stage(0);
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                 // stage 0 is in LDS for everyone
+    if (wm == 1) __builtin_amdgcn_s_barrier();    // query half 1 runs one phase behind half 0 from here on
+    for (uint32_t s = 0; s < nstage; ++s) {
+        const uint32_t buf = s & 1u;
+        if (s + 1u < nstage) issue_stage(s + 1u); // into the other buffer: last read one phase ago (by the other half) or earlier
+        read_phase(buf, 0);
+        __builtin_amdgcn_s_barrier();
+        mfma_phase();
+        __builtin_amdgcn_s_barrier();
+        read_phase(buf, 2);
+        if (s + 1u < nstage) wait_vmcnt<0>();     // this wavefront's copies of stage s + 1 have landed: readable after the next barrier
+        __builtin_amdgcn_s_barrier();
+        mfma_phase();
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();    // half 1's last phase
+    tile_epilogue<FP8, 2>(a, acc, lds, q0, r0, wm, wn, tid, xmax2, wg_overflow);
+}
+
 #ifdef HVX_TUNING // experimental: not in the release library until it has a hardware parity record (scripts/gpu_tile4_round.sh)
 // ---- the 128 x 128-per-wavefront build: fewer LDS bytes per flop.  Four wavefronts (one per SIMD, 2 x 2) on a 256 x 256
 // tile, each with 4 x 4 accumulators (256 registers: the kernel runs one wavefront per SIMD and spills into AGPRs): a
@@ -721,6 +872,11 @@ hipError_t launch_flat_tile256(const MfmaArgs &a, int kind, uint32_t bpad, float
         const dim3 grid2(8u * rb * t.sup_qblocks * t.sup_r * t.sup_q);
         if (kind == 1) hipLaunchKernelGGL((flat_tile2_kernel<1>), grid2, dim3(256), 0, s, t, xmax2, wg_overflow);
         else hipLaunchKernelGGL((flat_tile2_kernel<0>), grid2, dim3(256), 0, s, t, xmax2, wg_overflow);
+        return hipGetLastError();
+    }
+    if (build == 2) { // the role-split build: 512 threads, the two wavefronts of a SIMD in opposite roles (flat_tile8_kernel)
+        if (kind == 1) hipLaunchKernelGGL((flat_tile8_kernel<1>), grid, dim3(512), 0, s, t, xmax2, wg_overflow);
+        else hipLaunchKernelGGL((flat_tile8_kernel<0>), grid, dim3(512), 0, s, t, xmax2, wg_overflow);
         return hipGetLastError();
     }
     // one 512-thread workgroup per CU (256 x 256 tiles, two LDS buffers)

@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--dtype", default="fp8", choices=["fp8", "bf16", "f32"])
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--recall-queries", type=int, default=64)
+    ap.add_argument("--tile-builds", default="0", help="comma list of HVX_OPT_FLAT_TILE_BUILD values to time in this process (0 = two 256-thread "
+                    "workgroups per CU, 1 = one 512-thread workgroup, 2 = 512 threads role-split)")
     args = ap.parse_args()
     import pyhvx as hv
     from pyhvx import synth
@@ -36,12 +38,24 @@ def main():
     print(f"[flat] corpus {n}x{dim} generated in {t1 - t0:.1f}s, imported as {args.dtype} in {time.time() - t1:.1f}s", file=sys.stderr)
     ids = torch.zeros(b, k, dtype=torch.int64, device=dev); sc = torch.zeros(b, k, device=dev)
     cnt = torch.zeros(b, dtype=torch.int32, device=dev); st = torch.zeros(b, dtype=torch.int32, device=dev)
-    ms = []
-    for i in range(args.steps + 1):
-        s = ix.flat_search_batch_device(q, k, ids, sc, cnt, st, want_stats=True)
-        if i:
-            ms.append(s["device_ms"])
-    ms = float(np.mean(ms))
+    per_build = {}
+    ref_ids = None
+    for rnd in range(2):  # interleaved rounds of every build in ONE process (within-probe A/B)
+        for tb in [int(v) for v in args.tile_builds.split(",")]:
+            ix.set_option(hv.OPT_FLAT_TILE_BUILD, tb)
+            for i in range(args.steps + (1 if rnd == 0 else 0)):
+                s = ix.flat_search_batch_device(q, k, ids, sc, cnt, st, want_stats=True)
+                if i or rnd:
+                    per_build.setdefault(tb, []).append(s["device_ms"])
+            torch.cuda.synchronize()
+            if ref_ids is None:
+                ref_ids = ids.clone()
+            assert bool((ids == ref_ids).all().item()), f"tile build {tb} returned different ids"
+    first = int(args.tile_builds.split(",")[0])
+    ms = float(np.mean(per_build[first]))
+    if len(per_build) > 1:
+        print(json.dumps({"tile_build_ab_ms": {str(tb): {"mean": round(float(np.mean(v)), 3), "min": round(float(np.min(v)), 3)} for tb, v in per_build.items()},
+                          "ids_equal_across_builds": True, "shape": f"{b} x {n} x {dim} {args.dtype}"}), flush=True)
     # quantisation loss: recall of the reduced-precision top-k against the exact f32 top-k (library GEMM, harness only)
     rq = min(args.recall_queries, b)
     d2 = (x * x).sum(1)[None, :] - 2.0 * (q[:rq] @ x.t())

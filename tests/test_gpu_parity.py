@@ -1194,6 +1194,14 @@ def test_exact_scan_through_the_512_thread_tile_build(orc, hv, dtype_name, metri
     test_exact_scan_through_the_256_tile_kernel(orc, hv, dtype_name, metric, dim, n, k, b, tile_build=1)
 
 
+@pytest.mark.parametrize("dtype_name,metric,dim,n,k,b", TILE_CASES)
+def test_exact_scan_through_the_role_split_tile_build(orc, hv, dtype_name, metric, dim, n, k, b):
+    """HVX_OPT_FLAT_TILE_BUILD = 2 (round 4): 512 threads on a 256 x 256 tile with the two wavefronts of every SIMD in opposite roles
+    (one issues its MFMAs at priority while the other has its fragment reads and LDS-DMA copies in flight; raw barriers, counted
+    waits) -- bf16 / fp8 / f32-shadow rows, ragged tiles, a rejected query: the same answers as the 128 x 128 kernel and the oracle."""
+    test_exact_scan_through_the_256_tile_kernel(orc, hv, dtype_name, metric, dim, n, k, b, tile_build=2)
+
+
 def test_exact_scan_lanes_share_one_bf16_shadow(orc, hv):
     """Forked handles (execution lanes) of an f32 index scan through ONE bf16 shadow of the rows, whichever lane builds it."""
     rng = np.random.default_rng(77)

@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--ef", type=int, default=128)
     ap.add_argument("--m", type=int, default=16)
-    ap.add_argument("--lanes", type=int, default=3, help="execution lanes the steps are issued on round-robin (1 = every step waits for the previous one)")
+    ap.add_argument("--lanes", type=int, default=4, help="execution lanes the steps are issued on round-robin (1 = every step waits for the previous one)")
     ap.add_argument("--occupancy", type=int, default=0, help="queries per SIMD of the HNSW kernel build: 0 = 2 when lanes > 1, else 1")
     ap.add_argument("--mode", default="shard", choices=["shard", "replica"],
                     help="N>1: 'shard' = id-range shards + all-gather top-k merge (north star); 'replica' = every GPU holds "

@@ -133,6 +133,7 @@ extern "C" int hvx_index_set_option(hvx_index *ix, uint32_t option, uint32_t val
     if (option == HVX_OPT_FLAT_FIRST_CHUNK && value != 0 && value < 1024) return fail(HVX_ERR_K_RANGE, "the first chunk holds at least 1024 rows");
     if (option == HVX_OPT_HNSW_PAIR && value > 3) return fail(HVX_ERR_K_RANGE, "pair kernel selector is 0 (one query per SIMD handles), 1 (never), 2 (always) or 3 (always, one gatherer)");
     if (option == HVX_OPT_FLAT_TILE_BUILD && value > 2) return fail(HVX_ERR_K_RANGE, "tile build is 0 (two 256-thread workgroups per CU), 1 (one 512-thread workgroup) or 2 (512 threads, role-split)");
+    if (option == HVX_OPT_FLAT_NO_SMALLB && value > 2) return fail(HVX_ERR_K_RANGE, "small-batch selector is 0 (streaming kernels), 1 (never) or 2 (register-fragment build only)");
     std::lock_guard<std::mutex> lock(ix->mu);
     ix->opt[option] = value;
     return HVX_OK;
@@ -851,7 +852,7 @@ int hvx::flat_scan_device(hvx_index *ix, const float *d_queries, uint32_t b, uin
         // kernel (hvx_flat_smallb.hip) reads every row once at HBM speed, where the reference-order VALU kernel below is bound by
         // the b x rows x dim subtract / FMA pairs (32 queries x 100 000 x 1536: 0.8 ms vs the rows' 0.1 ms of HBM time)
         const bool big = (uint64_t)b * n_rows * d.dim >= (1ull << 33);
-        const bool small_stream = !ix->opt[HVX_OPT_FLAT_NO_SMALLB] && flat_smallb_supported(d.dim, b, 2) && (uint64_t)n_rows * d.dim >= (1ull << 22);
+        const bool small_stream = ix->opt[HVX_OPT_FLAT_NO_SMALLB] != 1u && flat_smallb_supported(d.dim, b, 2) && (uint64_t)n_rows * d.dim >= (1ull << 22);
         if (shape && d.dim >= 256 && k <= 511 && (big || small_stream) && !ix->opt[HVX_OPT_FLAT_FORCE_VALU]) {
             const int rc = flat_mfma_device(ix, d_queries, b, k, d_subset, n_rows, d_ids, d_scores, d_counts, d_status, timed);
             if (rc != -1) return rc;

@@ -39,7 +39,7 @@ hipError_t launch_flat_tile256(const MfmaArgs &a, int kind, uint32_t bpad, float
 
 // one-pass score matrix for small batches (hvx_flat_smallb.hip): b <= 128 queries, kind 0 = bf16 rows / shadow, 2 = f32 rows
 bool flat_smallb_supported(uint32_t dim, uint32_t b, int kind);
-hipError_t launch_flat_smallb(const MfmaArgs &a, int kind, bool full, uint32_t cus, hipStream_t s); // raw dot products into a.dist
+hipError_t launch_flat_smallb(const MfmaArgs &a, int kind, bool full, uint32_t cus, uint32_t build, hipStream_t s); // raw dot products into a.dist; build 1 = never the ring build
 // sort-free selection over those dot products: every slice's kc (<= 256) smallest approximate scores as (score, row) pairs
 hipError_t launch_flat_select_radix(const MfmaArgs &a, uint32_t kc, uint32_t *status, float *sl_sc, uint32_t *sl_id, uint32_t sl_stride,
                                     uint32_t *out_slices, hipStream_t s);
@@ -52,5 +52,36 @@ __host__ __device__ inline uint32_t tile_slot_fp8(uint32_t slot) {
     const uint32_t kk = (u >> 1) * 2u + sb, h = u & 1u;
     return (slot & ~63u) + kk * 16u + h * 8u + e;
 }
+
+#if defined(__HIPCC__)
+// One step of an 8-bit radix selection, run by EVERY wavefront of the workgroup on the same 256-bin histogram (no broadcast, no
+// extra barrier): the digit g whose bin holds the kk-th smallest key (1-based) among the keys counted in `hist`, and the number
+// of counted keys with a smaller digit.  kk <= the histogram's total by construction of the callers.
+__device__ __forceinline__ void radix_digit_of_rank(const uint32_t *hist, uint32_t kk, uint32_t &g, uint32_t &below) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint4 c = reinterpret_cast<const uint4 *>(hist)[lane]; // bins 4 lane .. 4 lane + 3
+    const uint32_t s = c.x + c.y + c.z + c.w;
+    uint32_t incl = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if ((int)lane >= d) incl += up;
+    }
+    const uint32_t excl = incl - s;
+    const bool mine = excl < kk && kk <= incl;
+    uint32_t gg = 0, bb = 0;
+    if (mine) {
+        uint32_t run = excl;
+        gg = 4u * lane; bb = run;
+        if (run + c.x < kk) { run += c.x; gg = 4u * lane + 1u; bb = run;
+            if (run + c.y < kk) { run += c.y; gg = 4u * lane + 2u; bb = run;
+                if (run + c.z < kk) { run += c.z; gg = 4u * lane + 3u; bb = run; } } }
+    }
+    const unsigned long long m = __ballot(mine);
+    const int src = m ? __builtin_ctzll(m) : 0;
+    g = __shfl(gg, src, 64);
+    below = __shfl(bb, src, 64);
+}
+#endif
 
 } // namespace hvx

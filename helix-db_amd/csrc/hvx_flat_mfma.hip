@@ -10,7 +10,7 @@
 //      acc += q_hi.x + q_lo.x, epilogue turns the dot product into the metric's score and writes one
 //      chunk of the [b][rows] score matrix (fp8 rows: codes widened to bf16 -- exactly -- on the way into
 //      LDS, the row scale applied in the epilogue);
-//   3. the exact top-(m+1) by approximate score per query is kept (flat_select_kernel, m = max(64, 2k));
+//   3. the exact top-(m+1) by approximate score per query is kept (flat_select_kernel, m = max(63, 2k));
 //   4. `rerank_kernel`: one wavefront per query re-scores those candidates with the reference's
 //      summation order (the same gather/FMA code as the HNSW kernel), sorts by (score, id), keeps k;
 //   5. certificate: every row that was NOT re-scored has approximate score >= t (the (m+1)-th), hence a
@@ -444,6 +444,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr bool FP8 = KIND == 1, BFR = KIND != 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t cnt3[3], s_valid, s_bad, s_nout;
+    __shared__ __attribute__((aligned(16))) uint32_t rhist[4][256]; // small-batch path: one histogram per 8-bit selection round
     constexpr int P = 2; // 16 rows per wavefront and pass
     const DevIndex &ix = a.ix;
     const uint32_t q = blockIdx.x;
@@ -464,6 +465,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float t_thr = inf; // approximate score of the last candidate: every row that is not re-scored has at least this score
     if (tid == 0) { cnt3[0] = cnt3[1] = cnt3[2] = 0; s_valid = 0; s_bad = 0; s_nout = 0; }
     for (uint32_t i = (uint32_t)tid; i < 1024u; i += 256) { ss[i] = inf; si[i] = 0xFFFFFFFFu; }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) rhist[d][tid] = 0;
     __syncthreads();
     if (a.sl_sc) {
         // the kc smallest of the slices' pairs: keys staged in LDS, kth key by a cooperative bitwise descent (ballot counts)
@@ -483,27 +486,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (lane == 0 && valid) atomicAdd(&s_valid, valid);
         __syncthreads();
         const uint32_t kth = a.kc < s_valid ? a.kc : s_valid;
+        // four rounds of 8 bits (hvx_flat_mfma.h: radix_digit_of_rank), one barrier each; the histograms were zeroed above
         uint32_t prefix = 0, kk = kth, less = 0;
-        for (int bit = 31; bit >= 0 && kth; --bit) {
-            const uint32_t hi_mask = bit == 31 ? 0u : (0xFFFFFFFFu << (bit + 1));
-            const uint32_t sel_mask = hi_mask | (1u << bit); // prefix on the bits above, 0 at `bit`
-            uint32_t c = 0;
-            for (uint32_t i0 = 0; i0 < a.sl_n; i0 += 256) {
-                const uint32_t i = i0 + (uint32_t)tid;
-                const uint32_t kb = i < a.sl_n ? sk[i] : 0xFFFFFFFFu;
-                c += (uint32_t)__builtin_popcountll(__ballot(i < a.sl_n && (kb & sel_mask) == prefix));
+#pragma unroll
+        for (int d = 3; d >= 0; --d) {
+            const int sh = 8 * d;
+            const uint32_t hi_mask = d == 3 ? 0u : (0xFFFFFFFFu << (sh + 8));
+            for (uint32_t i = (uint32_t)tid; i < a.sl_n; i += 256) {
+                const uint32_t kb = sk[i];
+                if ((kb & hi_mask) == prefix) atomicAdd(&rhist[d][(kb >> sh) & 255u], 1u);
             }
-            const int slot3 = bit % 3;
-            if (lane == 0 && c) atomicAdd(&cnt3[slot3], c);
-            if (tid == 0) cnt3[(bit + 2) % 3] = 0; // next round's counter: last read two rounds ago
             __syncthreads();
-            const uint32_t zeros = cnt3[slot3];
-            if (kk > zeros) { prefix |= 1u << bit; kk -= zeros; less += zeros; }
+            uint32_t g = 0, below = 0;
+            if (kk) radix_digit_of_rank(rhist[d], kk, g, below);
+            prefix |= g << sh; kk -= below; less += below;
         }
-        // candidates: keys below the kth value, then ties up to the quota (which ties does not matter: see hvx_flat_smallb.hip)
-        __syncthreads();
-        if (tid == 0) cnt3[0] = 0; // tie counter
-        __syncthreads();
+        // candidates: keys below the kth value, then ties up to the quota (which ties does not matter: see hvx_flat_smallb.hip);
+        // cnt3[0] (zero since the kernel's start) counts the ties
         const uint32_t quota = kth - less;
         for (uint32_t i0 = 0; i0 < a.sl_n && kth; i0 += 256) {
             const uint32_t i = i0 + (uint32_t)tid;
@@ -557,10 +556,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (tid == 0) { a.out_counts[q] = 0; if (a.out_status) a.out_status[q] = 8u; a.cert[q] = 1u; }
         return;
     }
-    // bitonic sort of the (score, id) pairs: the next power of two above the candidate count (the rest is +inf)
+    // sort of the (score, id) pairs.  Up to 64 candidates (k <= 31: m + 1 = 64): one pair per lane of ONE wavefront, bitonic
+    // exchanges by lane shuffles -- no LDS traffic, no barriers (21 exchange steps against 28 barrier-separated LDS passes)
+    if (nc <= 64u) {
+        if (wave == 0) {
+            float sv = ss[lane];
+            uint32_t iv = si[lane]; // (entries past nc hold +inf / 0xFFFFFFFF)
+#pragma unroll
+            for (int size = 2; size <= 64; size <<= 1)
+#pragma unroll
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    const float os = __shfl_xor(sv, stride, 64);
+                    const uint32_t oi = __shfl_xor(iv, stride, 64);
+                    const bool lower = (lane & stride) == 0, up = (lane & size) == 0;
+                    const bool other_first = os < sv || (os == sv && oi < iv), mine_first = sv < os || (sv == os && iv < oi);
+                    if ((lower == up) ? other_first : mine_first) { sv = os; iv = oi; }
+                }
+            ss[lane] = sv;
+            si[lane] = iv;
+        }
+        __syncthreads();
+    }
+    // ... more: bitonic sort in LDS over the next power of two above the candidate count (the rest is +inf)
     int npairs = 2;
     while ((uint32_t)npairs < nc) npairs <<= 1;
-    for (int size = 2; size <= npairs; size <<= 1)
+    for (int size = 2; size <= npairs && nc > 64u; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             for (int t = tid; t < npairs / 2; t += 256) {
                 const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
@@ -705,12 +725,12 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(ix->ev0, ix->stream));
     // Attempts, cheapest first; a query whose certificate is not reached sends the batch to the next one:
-    //   0. ONE-pass contraction (q_hi.x_hi only; the dropped residual terms widen the certificate's bound), m = max(64, 2k)
+    //   0. ONE-pass contraction (q_hi.x_hi only; the dropped residual terms widen the certificate's bound), m = max(63, 2k)
     //   1. the full split (bf16 / fp8 rows: + q_lo.x; f32 rows: + q_lo.x_hi + q_hi.x_lo), same m
     //   2. the full split with m = 1023 (f32 rows: the exact VALU scan for the failing queries instead)
     // With m + 1 <= 256 only the first chunk writes its score matrix; every later launch covers a geometrically growing
     // slice of the rows and lets a score out of the tile only below the query's running threshold (FILT).
-    const uint32_t m0 = std::max<uint32_t>(64u, 2u * k);
+    const uint32_t m0 = std::max<uint32_t>(63u, 2u * k); // (63: m + 1 = 64 candidates are ONE pass of the re-rank kernel's four wavefronts x 16 rows, and one wavefront's sort)
     const bool debug = tuning_env("HVX_FLAT_DEBUG") != nullptr;
     const bool allow_fast = !ix->opt[HVX_OPT_FLAT_NO_FAST];
     const bool no_filter = ix->opt[HVX_OPT_FLAT_NO_FILTER] != 0;
@@ -727,7 +747,7 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
         // small batches (b <= 128): ONE pass over the rows with the register-resident kernel of hvx_flat_smallb.hip writes the
         // whole [b][n] score matrix; sliced selection + pair merge replace the chunk loop.  One-pass attempt only.
         const int sb_kind = f32 ? ((ix->m_shadow && !full) ? 0 : 2) : (fp8 ? 1 : 0); // (the shadow has no lo parts: the full split reads the f32 rows)
-        const bool smallb = !ix->opt[HVX_OPT_FLAT_NO_SMALLB] && flat_smallb_supported(d.dim, b, sb_kind) &&
+        const bool smallb = ix->opt[HVX_OPT_FLAT_NO_SMALLB] != 1u && flat_smallb_supported(d.dim, b, sb_kind) &&
                             (size_t)((n + 3u) & ~3u) * b * 4 <= (512u << 20) && kc <= 1024u;
         constexpr uint32_t kSmallbCandCap = 8192; // 32 slices x kc <= 256 pairs per query
         const bool sb_radix = smallb && kc <= 256u; // (kc > 256: the widened attempt of bf16 rows keeps the sorted-pool selection)
@@ -796,7 +816,7 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
             int cus = 256;
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ix->device);
             sa.dist = ix->f_dist; sa.chunk_ld = chunk;
-            HIP_TRY(launch_flat_smallb(sa, sb_kind, full, (uint32_t)cus, ix->stream));
+            HIP_TRY(launch_flat_smallb(sa, sb_kind, full, (uint32_t)cus, ix->opt[HVX_OPT_FLAT_NO_SMALLB] == 2u ? 1u : 0u, ix->stream));
             if (sb_radix) { // sort-free selection: slices' kc smallest pairs, the query's kc smallest of those inside the re-rank kernel
                 HIP_TRY(launch_flat_select_radix(sa, kc, ix->d_qstatus, ix->m_csc, reinterpret_cast<uint32_t *>(ix->m_cid), kSmallbCandCap, &sb_slices, ix->stream));
             } else {

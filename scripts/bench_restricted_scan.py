@@ -21,7 +21,7 @@ for size in (1000, 10000, 100000, 400000):
         continue
     allowed = np.arange(n // 2, n // 2 + size, dtype=np.uint64)
     cand = hv.RestrictedVectorCandidates.from_ids(allowed)
-    for opt in (0, 1):
+    for opt in (0, 2, 1):  # the LDS-ring build (b <= 32), the register-fragment build, the large-batch kernels
         ix.set_option(hv.OPT_FLAT_NO_SMALLB, opt)
         lat, kern = [], []
         for r in range(6):
@@ -33,6 +33,6 @@ for size in (1000, 10000, 100000, 400000):
             if r:
                 lat.append(time.perf_counter() - t0); kern.append(st.device_ms)
         kms = float(np.median(kern))
-        print(json.dumps({"candidates": size, "b": b, "dim": dim, "no_smallb": opt, "path": ix.last_scan_path(), "kernel_ms": round(kms, 4),
+        print(json.dumps({"candidates": size, "b": b, "dim": dim, "small_batch_selector": opt, "path": ix.last_scan_path(), "kernel_ms": round(kms, 4),
                           "end_to_end_ms": round(float(np.median(lat)) * 1e3, 3), "hbm_gbs": round(size * dim * 4 / (kms * 1e-3) / 1e9, 1),
                           "frac": round(size * dim * 4 / (kms * 1e-3) / 8e12, 4)}), flush=True)

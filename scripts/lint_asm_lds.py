@@ -13,10 +13,19 @@ inside a block the requests are kept in issue order: LDS operations return in or
 the N youngest -- if the block itself has issued at least N since its entry, everything inherited is complete too (otherwise the
 inherited set is kept: conservative).
 
+Second rule (round 4, csrc/hvx_flat_smallb.hip): the compiler's hazard recogniser pads the wait states between a matrix
+instruction's write-back and a VALU / LDS / memory instruction that reads the result -- but not for an instruction inside an
+inline-asm statement, which it cannot see into.  An asm `ds_write_b32` of an accumulator register issued right behind the last
+v_mfma of a block stored the value of one MFMA step earlier (found on hardware by tests/native/smallq_probe.hip).  The lint counts
+issue slots (s_nop N = N + 1) since the last v_mfma / v_smfmac that wrote a register and reports an inline-asm instruction
+reading it sooner than MFMA_WAIT slots later (19: the 16-pass figure, an upper bound for every shape used here); the count is
+carried across blocks as the minimum over predecessors.
+
 usage: lint_asm_lds.py file.s kernel_substring [kernel_substring ...]      (exit status 1 when a hazard is found)"""
 import re
 import sys
 
+MFMA_WAIT = 19
 REG = re.compile(r"\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b")
 LABEL = re.compile(r"^([.\w$]+):")
 
@@ -34,7 +43,12 @@ def regs_of(text):
 def parse_blocks(lines):
     """-> (blocks: list of dicts {label, insts: [(lineno, text)], succ: [label, or None for fall-through]}, label -> index)"""
     blocks, cur = [], {"label": None, "insts": [], "succ": []}
+    in_asm = False
     for no, raw in lines:
+        if "#ASMSTART" in raw:
+            in_asm = True
+        elif "#ASMEND" in raw:
+            in_asm = False
         line = raw.split(";")[0].rstrip()
         m = LABEL.match(line)
         if m:
@@ -49,6 +63,8 @@ def parse_blocks(lines):
             continue
         op = line.split()[0]
         cur["insts"].append((no, line))
+        if in_asm:
+            cur.setdefault("asm", set()).add(no)
         if op == "s_branch":
             cur["succ"] = [line.split()[1]]
             blocks.append(cur)
@@ -106,6 +122,68 @@ def run_block(block, inherited, report):
     return out
 
 
+def run_block_mfma(block, state, report):
+    """state: register -> issue slots since a matrix instruction wrote it (absent = long ago); returns the out state"""
+    state = dict(state)
+    asm = block.get("asm", ())
+    for no, line in block["insts"]:
+        op = line.split()[0]
+        rest = line[len(op):]
+        if report is not None and no in asm and not op.startswith("s_"):
+            parts = [p.strip() for p in rest.split(",")]
+            # operands an instruction READS: all of them for stores / ds_write, all but the first otherwise
+            reads = regs_of(rest if op.startswith("ds_write") or "store" in op else ",".join(parts[1:]))
+            for r in reads:
+                if r in state and state[r] < MFMA_WAIT:
+                    report.append((no, line, state[r]))
+                    break
+        slots = 1
+        if op == "s_nop":
+            slots = int(rest.strip() or 0) + 1
+        for r in list(state):
+            state[r] += slots
+            if state[r] >= 64:
+                del state[r]
+        if op.startswith("v_mfma") or op.startswith("v_smfmac"):
+            for r in regs_of(rest.split(",")[0]):
+                state[r] = 0
+    return state
+
+
+def lint_kernel_mfma(lines):
+    blocks, index = parse_blocks(lines)
+    n = len(blocks)
+    succ = []
+    for i, b in enumerate(blocks):
+        s = []
+        for t in b["succ"]:
+            if t is None:
+                if i + 1 < n:
+                    s.append(i + 1)
+            elif t in index:
+                s.append(index[t])
+        succ.append(s)
+    ins = [dict() for _ in range(n)]
+    work = list(range(n))
+    rounds = 0
+    while work and rounds < 100000:
+        rounds += 1
+        i = work.pop()
+        out = run_block_mfma(blocks[i], ins[i], None)
+        for j in succ[i]:
+            changed = False
+            for r, v in out.items():
+                if r not in ins[j] or v < ins[j][r]:
+                    ins[j][r] = v
+                    changed = True
+            if changed:
+                work.append(j)
+    problems = []
+    for i, b in enumerate(blocks):
+        run_block_mfma(b, ins[i], problems)
+    return problems
+
+
 def lint_kernel(lines):
     blocks, index = parse_blocks(lines)
     n = len(blocks)
@@ -146,8 +224,13 @@ def main():
             continue
         for st in starts:
             end = next(i for i in range(st, len(text)) if "s_endpgm" in text[i])
-            probs = lint_kernel([(i + 1, text[i]) for i in range(st + 1, end + 1)])
-            print(f"{text[st].split(':')[0]}: {len(probs)} hazard(s)")
+            body = [(i + 1, text[i]) for i in range(st + 1, end + 1)]
+            probs = lint_kernel(body)
+            late = lint_kernel_mfma(body)
+            print(f"{text[st].split(':')[0]}: {len(probs)} hazard(s), {len(late)} inline-asm read(s) inside a matrix instruction's write-back window")
+            for no, line, slots in late[:8]:
+                print(f"   line {no}: `{line}` reads a register a v_mfma wrote {slots} issue slot(s) earlier (< {MFMA_WAIT})")
+            bad |= bool(late)
             for no, line, pno, ptxt in probs[:int(__import__("os").environ.get("LINT_SHOW", "8"))]:
                 print(f"   line {no}: `{line}` touches a register requested at line {pno}: `{ptxt}` with no covering s_waitcnt lgkmcnt")
             bad |= bool(probs)

@@ -1,5 +1,6 @@
 """Parity of the gfx950 path (through the C ABI) against the CPU oracle: ids, f32 score BITS and the
 SearchStats counters must be identical.  Run with `-m gpu` on an MI355X."""
+import os
 import numpy as np
 import pytest
 
@@ -1502,6 +1503,76 @@ def test_small_batch_exact_scan_is_bit_exact(orc, hv, dtype_name, metric, dim, n
     for qi in range(0, good.shape[0], max(1, good.shape[0] // 8)):
         rc, oid, osc = orc.flat_matrix(metric, sub, good[qi], k, **kern)
         assert allowed[oid.astype(np.int64)].tolist() == rid[qi, :rcnt[qi]].tolist() and bits(osc).tolist() == bits(rsc[qi, :rcnt[qi]]).tolist()
+
+
+@pytest.mark.parametrize("dtype_name,metric,dim,n,k,b", [("f32", 1, 1536, 9000, 10, 32), ("f32", 1, 768, 20011, 10, 7), ("f32", 0, 512, 9000, 10, 32),
+                                                         ("f32", 1, 512, 12000, 10, 1), ("f32", 1, 1024, 5003, 25, 17), ("f32", 0, 1536, 4000, 10, 3),
+                                                         ("f32", 1, 256, 20000, 10, 31), ("bf16", 1, 768, 20000, 10, 32), ("bf16", 0, 1536, 5000, 10, 9),
+                                                         ("bf16", 1, 128, 40001, 10, 32), ("bf16", 1, 256, 20000, 10, 3), ("bf16", 1, 1024, 9000, 10, 32)])
+def test_ring_build_of_the_small_batch_scan(orc, hv, dtype_name, metric, dim, n, k, b):
+    """Batches of <= 32 queries take the LDS-ring build (rows through per-wavefront rings of 128-byte lines, queries in registers,
+    depth split over the wavefronts of a workgroup): its candidates are certified by the ONE-pass attempt (a wrong dot product would
+    send the scan on to the next attempt -- the path word says which attempts ran, and it equals the register-fragment build's), ids
+    and score bits equal the oracle's and the register-fragment build's, for whole scans, the full split and ragged, scattered
+    restricted row lists."""
+    rng = np.random.default_rng(dim * 7 + n + b)
+    centers = rng.standard_normal((32, dim)).astype(np.float32)
+    data = (centers[rng.integers(0, 32, n)] + 0.5 * rng.standard_normal((n, dim))).astype(np.float32)
+    data[7] = data[3]
+    stored = fx.round_bf16(data) if dtype_name == "bf16" else data
+    ids = np.arange(n, dtype=np.uint64) + 11
+    gix = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=metric, node_ids=ids, vectors=data, dtype=hv.BF16 if dtype_name == "bf16" else hv.F32,
+                                              l0_offsets=np.zeros(n + 1, np.uint64), l0_neighbors=np.zeros(0, np.uint64), max_batch=32)
+    q = (centers[rng.integers(0, 32, b)] + 0.5 * rng.standard_normal((b, dim))).astype(np.float32)
+    q[0] = data[3]
+    kern = {"kernel": orc.K_AVX_FMA_HW} if dtype_name == "f32" else {}
+    results = {}
+    for build in (0, 2):
+        gix.set_option(hv.OPT_FLAT_NO_SMALLB, build)
+        gid, gsc, gcnt, _, gst = gix.flat_search_batch(q, k, per_query_status=True)
+        path = gix.last_scan_path()
+        assert path & hv.PATH_SMALL_BATCH and not path & (hv.PATH_MFMA_128 | hv.PATH_TILE_256 | hv.PATH_WIDENED | hv.PATH_VALU_FALLBACK_QUERIES), (build, path)
+        results[build] = (gid.tolist(), bits(gsc).tolist(), gcnt.tolist(), gst.tolist(), path)  # (path: the same attempts certified both builds)
+    assert results[0] == results[2]
+    gix.set_option(hv.OPT_FLAT_NO_SMALLB, 0)
+    for qi in range(b):
+        rc, oid, osc = orc.flat_matrix(metric, stored, q[qi], k, **kern)
+        assert gst[qi] == 0 and (gid[qi, :gcnt[qi]] - 11).tolist() == oid.tolist(), f"query {qi}"
+        assert bits(gsc[qi, :gcnt[qi]]).tolist() == bits(osc).tolist()
+    # the full split (hi + lo parts) on the ring build
+    gix.set_option(hv.OPT_FLAT_NO_FAST, 1)
+    fid, fsc, fcnt, _, fst = gix.flat_search_batch(q, k, per_query_status=True)
+    path = gix.last_scan_path()
+    assert path & hv.PATH_SMALL_BATCH and path & hv.PATH_FULL_SPLIT and not path & (hv.PATH_WIDENED | hv.PATH_VALU_FALLBACK_QUERIES), path
+    assert (fid.tolist(), bits(fsc).tolist(), fcnt.tolist()) == (gid.tolist(), bits(gsc).tolist(), gcnt.tolist())
+    gix.set_option(hv.OPT_FLAT_NO_FAST, 0)
+    # restricted row lists: ragged and scattered (lists below 2^22 row elements take other kernels)
+    for size in (max(2 ** 22 // dim + 77, 3001), max(2 ** 22 // dim + 1, 33)):
+        allowed = np.sort(rng.choice(ids, min(n - 5, size), replace=False))
+        rid, rsc, rcnt = gix.search_restricted_batch(q, hv.SearchParams(k), hv.RestrictedVectorCandidates.from_ids(allowed))
+        path = gix.last_scan_path()
+        assert path & hv.PATH_SMALL_BATCH and not path & (hv.PATH_WIDENED | hv.PATH_VALU_FALLBACK_QUERIES), path
+        sub = stored[(allowed - 11).astype(np.int64)]
+        for qi in range(0, b, max(1, b // 6)):
+            rc, oid, osc = orc.flat_matrix(metric, sub, q[qi], k, **kern)
+            assert allowed[oid.astype(np.int64)].tolist() == rid[qi, :rcnt[qi]].tolist() and bits(osc).tolist() == bits(rsc[qi, :rcnt[qi]]).tolist()
+
+
+@pytest.mark.parametrize("cfg", ["0 768 1000 32 0 0", "0 1024 1000 32 0 1", "2 512 1000 32 0 0", "0 1536 1000 32 0 0", "2 256 1000 32 0 1", "0 768 1000 32 1 1",
+                                 "2 1536 3000 32 0 1", "2 1536 3000 5 1 0", "0 128 999 7 1 1", "2 768 1001 32 1 1", "2 1024 77 1 0 0", "2 2048 500 32 1 0",
+                                 "0 384 500 32 1 0", "2 128 5000 32 0 1", "0 256 33 32 0 0", "2 1536 20000 32 0 0"])
+def test_small_batch_kernels_raw_dot_products(cfg):
+    """The candidate kernels themselves (both builds of hvx_flat_smallb.hip), outside the pipeline whose exact re-rank and
+    certificate would hide an approximate score that is wrong on the high side: every raw dot product against a double-precision
+    dot product of the operands the build multiplies (kind, dim, rows, queries, full split, scattered row list).  This harness
+    found the one-MFMA-step-short accumulator store of the first ring build (tests/native/smallq_probe.hip)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "native", "_bin", "smallq_probe")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "helix-db_amd", "csrc"), "probe"])
+    r = subprocess.run([exe] + cfg.split(), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ring build bad 0" in r.stdout and "register build bad 0" in r.stdout, r.stdout[-2000:] + r.stderr[-500:]
 
 
 def test_small_batch_scan_uses_the_bf16_shadow_once_it_exists(orc, hv):

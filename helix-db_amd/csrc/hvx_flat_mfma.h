@@ -54,6 +54,25 @@ __host__ __device__ inline uint32_t tile_slot_fp8(uint32_t slot) {
 }
 
 #if defined(__HIPCC__)
+// histogram increment with the wavefront's most common digits combined first: approximate scores of one query share their
+// leading bytes, and 64 lanes adding to ONE LDS word serialise (measured: the four selection rounds of a 4 096-score slice cost
+// 26 us with per-lane atomics alone, the rest of the kernel 12).  Two rounds of "the first active lane's digit: one add for all
+// lanes holding it", then per-lane adds for whatever is left (digits that differ lane by lane do not collide).
+__device__ __forceinline__ void radix_count(uint32_t *hist, bool active, uint32_t digit) {
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        const unsigned long long todo = __ballot(active);
+        if (!todo) return;
+        const int leader = __builtin_ctzll(todo);
+        const uint32_t pivot = (uint32_t)__shfl((int)digit, leader, 64);
+        const bool same = active && digit == pivot;
+        const unsigned long long votes = __ballot(same);
+        if ((int)(threadIdx.x & 63u) == leader) atomicAdd(&hist[pivot], (uint32_t)__builtin_popcountll(votes));
+        active = active && !same;
+    }
+    if (active) atomicAdd(&hist[digit], 1u);
+}
+
 // One step of an 8-bit radix selection, run by EVERY wavefront of the workgroup on the same 256-bin histogram (no broadcast, no
 // extra barrier): the digit g whose bin holds the kk-th smallest key (1-based) among the keys counted in `hist`, and the number
 // of counted keys with a smaller digit.  kk <= the histogram's total by construction of the callers.

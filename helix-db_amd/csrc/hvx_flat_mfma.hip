@@ -492,9 +492,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int d = 3; d >= 0; --d) {
             const int sh = 8 * d;
             const uint32_t hi_mask = d == 3 ? 0u : (0xFFFFFFFFu << (sh + 8));
-            for (uint32_t i = (uint32_t)tid; i < a.sl_n; i += 256) {
-                const uint32_t kb = sk[i];
-                if ((kb & hi_mask) == prefix) atomicAdd(&rhist[d][(kb >> sh) & 255u], 1u);
+            for (uint32_t i0 = 0; i0 < a.sl_n; i0 += 256) { // (whole wavefronts stay in the loop: radix_count votes)
+                const uint32_t i = i0 + (uint32_t)tid;
+                const uint32_t kb = i < a.sl_n ? sk[i] : 0xFFFFFFFFu;
+                radix_count(rhist[d], i < a.sl_n && (kb & hi_mask) == prefix, (kb >> sh) & 255u);
             }
             __syncthreads();
             uint32_t g = 0, below = 0;
@@ -771,8 +772,12 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
             if ((rc = ix->regrow((void **)&ix->m_ccnt, (size_t)bpad * 4 + 4))) return rc;
             ix->cap_cand_b = bpad;
         }
-        HIP_TRY(hipMemsetAsync(ix->f_top_c, 0, (size_t)b * 4, ix->stream));
-        if (filt || smallb) HIP_TRY(hipMemsetAsync(ix->m_ccnt, 0, (size_t)bpad * 4 + 4, ix->stream));
+        // (the small-batch path with the sort-free selection uses neither the top lists' counters nor the pair counters: its two
+        // kernels hand over through the slice lists -- three fills of ~4 us each were 7 % of a 100 000-candidate scan)
+        if (!sb_radix) {
+            HIP_TRY(hipMemsetAsync(ix->f_top_c, 0, (size_t)b * 4, ix->stream));
+            if (filt || smallb) HIP_TRY(hipMemsetAsync(ix->m_ccnt, 0, (size_t)bpad * 4 + 4, ix->stream));
+        }
         FlatArgs fa;
         fa.ix = d; fa.queries = d_queries; fa.qstatus = ix->d_qstatus; fa.qhdr = ix->d_qhdr; fa.subset = d_subset;
         fa.n_rows = n; fa.dist = ix->f_dist; fa.chunk_ld = chunk; fa.b = b; fa.k = kc;
@@ -875,7 +880,7 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
         uint32_t *cert = ix->h_flags;
         cert[b] = 0;
         HIP_TRY(hipMemcpyAsync(cert, ix->m_cert, (size_t)b * 4, hipMemcpyDeviceToHost, ix->stream));
-        if (filt || smallb) HIP_TRY(hipMemcpyAsync(cert + b, ix->m_ccnt + bpad, 4, hipMemcpyDeviceToHost, ix->stream));
+        if ((filt || smallb) && !sb_radix) HIP_TRY(hipMemcpyAsync(cert + b, ix->m_ccnt + bpad, 4, hipMemcpyDeviceToHost, ix->stream));
         HIP_TRY(hipStreamSynchronize(ix->stream));
         const uint32_t overflow = cert[b];
         uint32_t failed = 0, first = 0;

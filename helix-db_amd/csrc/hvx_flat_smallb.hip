@@ -156,8 +156,8 @@ __global__ __launch_bounds__(WAVES * 64) void flat_smallb_kernel(MfmaArgs a, uin
 // pieces per load instruction -- 4.3-4.6 TB/s, and 3 125 row blocks over 2 048 wavefronts leave the second half of the launch
 // half empty).  Here the ROWS go through LDS in whole 128-byte lines and the QUERIES sit in registers:
 //   * a workgroup is 8 wavefronts = `ds` depth slices x 8 / ds row blocks of 32 rows; wavefront (rb, j) holds the A fragments
-//     of depth range [j CH CD, (j + 1) CH CD) of all 32 queries in registers (CH chunks of CD = 32 f32 / 64 bf16 elements:
-//     <= 64 registers, twice that with the lo parts) and streams that depth range of its 32 rows;
+//     of depth slice j (CH chunks of CD = 32 f32 / 64 bf16 elements, chunk c = elements [(c ds + j) CD, + CD): <= 64
+//     registers, twice that with the lo parts) of all 32 queries in registers and streams that slice of its 32 rows;
 //   * a chunk = 32 rows x 128 bytes = four global_load_lds_dwordx4 copies of 8 rows x 128 bytes (8 lanes per row: the HNSW
 //     gather's pattern, every line requested once and whole) into the wavefront's PRIVATE ring of three 4-KB stages; two
 //     chunks are always in flight per wavefront (64 KB per CU), the request cursor runs across row blocks, no barrier and no
@@ -195,11 +195,16 @@ __device__ __forceinline__ void sq_wait_lgkm0() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-constexpr int kSqStages = 3;                                  // ring stages per wavefront
-constexpr uint32_t kSqRing = 8u * kSqStages * 4096u;          // 96 KB
+#ifndef HVX_SQ_STAGES
+#define HVX_SQ_STAGES 3
+#endif
+constexpr int kSqStages = HVX_SQ_STAGES;                      // ring stages per wavefront (4 KB each)
+constexpr int kSqRedHalves = kSqStages >= 4 ? 2 : 1;          // a four-stage ring leaves LDS for half the accumulators at a time
+constexpr uint32_t kSqRing = 8u * kSqStages * 4096u;          // 96 KB (three stages)
 constexpr uint32_t kSqIds = 8u * 2u * 256u;                   // two id slots of 64 words per wavefront
-constexpr uint32_t kSqRed = 8u * 16u * 64u * 4u;              // 32 KB of partial dot products
+constexpr uint32_t kSqRed = 8u * (16u / kSqRedHalves) * 64u * 4u; // partial dot products: 32 KB
 constexpr uint32_t kSqLds = kSqRing + kSqIds + kSqRed;
+static_assert(kSqLds <= 160u * 1024u, "the ring, the id slots and the partial sums share one CU's LDS");
 
 template <int KIND, int CH, bool FULL>
 __global__ __launch_bounds__(512) void flat_smallq_kernel(MfmaArgs a, uint32_t n_blocks, uint32_t n_groups, uint32_t ds_log2) {
@@ -212,7 +217,10 @@ __global__ __launch_bounds__(512) void flat_smallq_kernel(MfmaArgs a, uint32_t n
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     const uint32_t fr = lane & 31u, h = lane >> 5;
     const uint32_t ds = 1u << ds_log2, j = w & (ds - 1u), rb = w >> ds_log2, RB = 8u >> ds_log2;
-    const uint32_t k0 = j * (uint32_t)(CH * CD);
+    // depth slices interleaved by 128-byte lines: chunk c of slice j is line c ds + j of the row, so the `ds` wavefronts of a row
+    // block, which move through their chunks together, ask for ds CONSECUTIVE lines of every row at about the same time (DRAM
+    // pages see runs of up to 1 KB instead of isolated lines 768 bytes apart)
+    const uint32_t k0 = j * (uint32_t)CD;
     const uint32_t esz = F32 ? 4u : 2u;
     const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(sq_lds);
     unsigned char *ring = sq_lds + w * (uint32_t)(S * 4096);
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(512) void flat_smallq_kernel(MfmaArgs a, uint32_t n
     bf16x8 qa[NST], ql[FULL ? NST : 1];
 #pragma unroll
     for (int s = 0; s < NST; ++s) {
-        const size_t at = (size_t)fr * a.dim + k0 + (uint32_t)s * 16u + h * 8u;
+        const size_t at = (size_t)fr * a.dim + k0 + (uint32_t)(s / SPC) * (ds * (uint32_t)CD) + (uint32_t)(s % SPC) * 16u + h * 8u;
         qa[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(a.qhi + at));
         if (FULL) ql[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(a.qlo + at));
     }
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(512) void flat_smallq_kernel(MfmaArgs a, uint32_t n
     auto request_chunk = [&](uint32_t pc, uint32_t stage) {
         unsigned char *dst = ring + stage * 4096u;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) HVX_SQ_GLDS16(gp[i] + pc * 128u, dst + i * 1024);
+        for (int i = 0; i < 4; ++i) HVX_SQ_GLDS16(gp[i] + pc * (ds * 128u), dst + i * 1024);
     };
 
     uint32_t g = blockIdx.x;
@@ -382,26 +390,30 @@ __global__ __launch_bounds__(512) void flat_smallq_kernel(MfmaArgs a, uint32_t n
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            constexpr int EH = 16 / kSqRedHalves; // accumulator registers per reduction pass
 #pragma unroll
-            for (int e = 0; e < 16; ++e) sq_lds_write4(red0 + ((w * 16u + (uint32_t)e) * 64u + lane) * 4u, acc[e]);
-            sq_wait_lgkm0();
-            __builtin_amdgcn_s_barrier();
-            const uint32_t epw = 16u >> ds_log2;
-            for (uint32_t ee = 0; ee < epw; ++ee) {
-                const uint32_t e = j * epw + ee;
-                uint32_t part[8];
+            for (int hh = 0; hh < kSqRedHalves; ++hh) {
 #pragma unroll
-                for (uint32_t jj = 0; jj < 8u; ++jj)
-                    if (jj < ds) part[jj] = sq_lds_read4(red0 + (((rb * ds + jj) * 16u + e) * 64u + lane) * 4u);
+                for (int e = 0; e < EH; ++e) sq_lds_write4(red0 + ((w * (uint32_t)EH + (uint32_t)e) * 64u + lane) * 4u, acc[hh * EH + e]);
                 sq_wait_lgkm0();
-                float v = 0.f;
+                __builtin_amdgcn_s_barrier();
+                const uint32_t epw = (uint32_t)EH >> ds_log2;
+                for (uint32_t ee = 0; ee < epw; ++ee) {
+                    const uint32_t el = j * epw + ee, e = (uint32_t)(hh * EH) + el;
+                    uint32_t part[8];
 #pragma unroll
-                for (uint32_t jj = 0; jj < 8u; ++jj)
-                    if (jj < ds) v += __uint_as_float(part[jj]); // slice 0 first: the same sum on every run
-                const uint32_t qq = (e & 3u) + 8u * (e >> 2) + 4u * h;
-                if (live && qq < a.b) a.dist[(size_t)qq * a.chunk_ld + rloc] = v;
+                    for (uint32_t jj = 0; jj < 8u; ++jj)
+                        if (jj < ds) part[jj] = sq_lds_read4(red0 + (((rb * ds + jj) * (uint32_t)EH + el) * 64u + lane) * 4u);
+                    sq_wait_lgkm0();
+                    float v = 0.f;
+#pragma unroll
+                    for (uint32_t jj = 0; jj < 8u; ++jj)
+                        if (jj < ds) v += __uint_as_float(part[jj]); // slice 0 first: the same sum on every run
+                    const uint32_t qq = (e & 3u) + 8u * (e >> 2) + 4u * h;
+                    if (live && qq < a.b) a.dist[(size_t)qq * a.chunk_ld + rloc] = v;
+                }
+                __builtin_amdgcn_s_barrier(); // the partial sums are read: the next pass / block may overwrite them
             }
-            __builtin_amdgcn_s_barrier(); // the partial sums are read: the next block may overwrite them
         }
     }
     sq_wait_vmcnt<0>(); // (requests past the last block are still landing in this wavefront's ring)
@@ -494,13 +506,19 @@ __global__ __launch_bounds__(256) void flat_select_radix_kernel(SelectArgs a) {
         // last): keys that carry the prefix chosen so far are counted by digit in LDS, then every wavefront reads the histogram
         // and finds the digit of rank kk itself -- one barrier per round (round 3's 32-round bitwise descent: 32)
         uint32_t prefix = 0, kk = kth, less = 0;
+#ifdef HVX_SELECT_ABLATE // (probe builds: how long the kernel takes without its selection rounds)
+        kk = 0;
+#endif
 #pragma unroll
         for (int d = 3; d >= 0; --d) {
             const int sh = 8 * d;
             const uint32_t hi_mask = d == 3 ? 0u : (0xFFFFFFFFu << (sh + 8));
+#ifdef HVX_SELECT_ABLATE
+            if (HVX_SELECT_ABLATE >= 1) continue;
+#endif
 #pragma unroll
             for (int r = 0; r <= kSelR; ++r)
-                if ((key[r] & hi_mask) == prefix) atomicAdd(&hist[d][(key[r] >> sh) & 255u], 1u); // (padding keys are all ones: last bin, beyond any rank asked for)
+                radix_count(hist[d], (key[r] & hi_mask) == prefix, (key[r] >> sh) & 255u); // (padding keys are all ones: last bin, beyond any rank asked for)
             __syncthreads();
             uint32_t g = 0, below = 0;
             if (kk) radix_digit_of_rank(hist[d], kk, g, below);
@@ -599,7 +617,7 @@ static bool smallq_plan(uint32_t dim, uint32_t b, int kind, uint32_t &ds_log2, u
             if (t % (1u << l) != 0u) continue;
             const uint32_t c = t >> l;
             if (kind == 0 && c > 4u) continue; // (bf16 rows: 16 registers of query fragments per chunk and operand)
-            if (pass == 0 ? (c == 3 || c == 4 || c == 6 || c == 8) : c == 2) { ds_log2 = (uint32_t)l; ch = c; return true; }
+            if (pass == 0 ? (c == 3 || c == 4 || c == 6 || c == 8) : (c == 2 && kSqStages - 1 <= 2)) { ds_log2 = (uint32_t)l; ch = c; return true; }
         }
     return false;
 }
@@ -616,7 +634,7 @@ static hipError_t launch_smallq_k(const MfmaArgs &a, uint32_t n_blocks, uint32_t
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), kSqLds, s, a, n_blocks, n_groups, ds_log2);                               \
     } while (0)
     switch (ch) {
-    case 2: HVX_SQ_LAUNCH(2); break;
+    case 2: if constexpr (kSqStages - 1 <= 2) { HVX_SQ_LAUNCH(2); break; } else return hipErrorInvalidValue;
     case 3: HVX_SQ_LAUNCH(3); break;
     case 4: HVX_SQ_LAUNCH(4); break;
     case 6: if constexpr (KIND == 2) { HVX_SQ_LAUNCH(6); break; } else return hipErrorInvalidValue;

@@ -116,6 +116,12 @@ class BuildStats(C.Structure):  # hvx_build_stats
     _fields_ = [("nodes", C.c_uint64), ("batches", C.c_uint64), ("single_node_batches", C.c_uint64)]
 
 
+class BatcherTimes(C.Structure):
+    """hvx_batcher_times (include/helix_vec.h)."""
+    _fields_ = [("idle_ns", C.c_uint64), ("collect_ns", C.c_uint64), ("drain_ns", C.c_uint64), ("fill_ns", C.c_uint64), ("device_ns", C.c_uint64),
+                ("wake_ns", C.c_uint64), ("lanes", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class GraphAudit(C.Structure):  # hvx_graph_audit
     _fields_ = [(n, C.c_uint64) for n in ("nodes", "up_rows", "edges_l0", "edges_up", "asymmetric_edges_l0", "asymmetric_edges_up",
                                           "unsorted_entries", "self_loops", "out_of_range_ids", "holes", "level_violations",
@@ -314,6 +320,8 @@ def lib():
     L.hvx_batcher_search.argtypes = [_vp, _vp, _vp, _vp, C.POINTER(C.c_uint32)]
     L.hvx_batcher_stats.restype = C.c_int
     L.hvx_batcher_stats.argtypes = [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.hvx_batcher_lane_times.restype = C.c_int
+    L.hvx_batcher_lane_times.argtypes = [_vp, C.POINTER(BatcherTimes)]
     L.hvx_csr_import.restype = C.c_int
     L.hvx_csr_import.argtypes = [C.c_uint64, C.c_uint64, _vp, _vp, _vp, C.c_int32, C.POINTER(_vp)]
     L.hvx_csr_free.argtypes = [_vp]
@@ -898,6 +906,12 @@ class Batcher:
         a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
         _check(lib().hvx_batcher_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return {"batches": int(a.value), "queries": int(b.value), "full_batches": int(c.value)}
+
+    def lane_times(self):
+        """hvx_batcher_lane_times: milliseconds the dispatcher lanes spent in each state since creation (summed over the lanes)."""
+        t = BatcherTimes()
+        _check(lib().hvx_batcher_lane_times(self._h, C.byref(t)))
+        return {"lanes": int(t.lanes), **{f[0][:-3] + "_ms": getattr(t, f[0]) / 1e6 for f in BatcherTimes._fields_ if f[0].endswith("_ns")}}
 
 
 def _visit_arrays(cap):

@@ -466,10 +466,11 @@ int hvx_prefilter_search_batch_params(const hvx_index *, const hvx_csr *, const 
  * Batching operator: the reference calls ValidatedVectorReadIndex::search once per operator invocation
  * from many tokio tasks (access/search/storage.rs:140-163).  Concurrent single-query callers are coalesced into ONE
  * hvx_search_batch_params launch: a caller blocks in hvx_batcher_search until its rows are ready.  A batch is launched when it
- * is full (max_batch, 0 = the index's max_batch, at most 65 535) or AS SOON AS A DISPATCHER LANE IS FREE and at least one query
- * waits: while every lane is busy the open batch keeps growing, so the batch size follows the load and no timer is involved.
- * max_wait_us is accepted for source compatibility and not used (round 4: holding a free lane back until the oldest query has
- * waited was measured -- 335 instead of 308 queries per batch, throughput -30 %, p99 2 ms -> 50 ms at 1 024 closed-loop callers).
+ * is full (max_batch, 0 = the index's max_batch, at most 65 535) or when a DISPATCHER LANE IS FREE and the batch has stopped
+ * growing: a free lane watches the open batch and takes it once no query has joined for 12 us (the callers of a batch that has
+ * just completed come back in a burst: a lane that launched at the first of them would run a handful of queries beside the next
+ * lane's hundreds), or once its first query has waited max_wait_us (0 = 200 us).  While every lane is busy the open batch simply
+ * keeps growing, so the batch size follows the load.  Result rows are written by the kernels straight into pinned host memory.
  * All callers of one batcher share `params`.  Thread-safe; results equal a direct batch call's.  A rejected query fails
  * alone.  hvx_batcher_free may be called while callers are blocked: they return HVX_ERR_INVARIANT.
  */
@@ -483,6 +484,14 @@ void hvx_batcher_free(hvx_batcher *);
 int hvx_batcher_search(hvx_batcher *, const float *query /*[dim]*/, uint64_t *out_ids /*[k]*/, float *out_scores /*[k]*/,
                        uint32_t *out_count);
 int hvx_batcher_stats(const hvx_batcher *, uint64_t *batches, uint64_t *queries, uint64_t *full_batches);
+/* where the dispatcher lanes' time went since creation, summed over the lanes (nanoseconds): asleep with nothing to do, watching
+ * an open batch grow, waiting for a batch buffer's previous callers to take their rows, waiting for callers to finish copying
+ * their query in, query copy + kernels + stream synchronise, handing the batch to its callers */
+typedef struct hvx_batcher_times {
+    uint64_t idle_ns, collect_ns, drain_ns, fill_ns, device_ns, wake_ns;
+    uint32_t lanes, reserved;
+} hvx_batcher_times;
+int hvx_batcher_lane_times(const hvx_batcher *, hvx_batcher_times *out);
 
 /*
  * SimHash projections (crates/db/src/search/vector/unaligned_vector/simhash.rs:123-178 SimHasher::new_with_seed,

@@ -112,6 +112,11 @@ int main(int argc, char **argv) {
     run(bt, &q1, &m1, &p1);
     uint64_t nb = 0, nqs = 0, nf = 0;
     hvx_batcher_stats(bt, &nb, &nqs, &nf);
+    hvx_batcher_times tm;
+    hvx_batcher_lane_times(bt, &tm);
+    const double tot = (double)(tm.idle_ns + tm.collect_ns + tm.drain_ns + tm.fill_ns + tm.device_ns + tm.wake_ns) + 1.0;
+    fprintf(stderr, "lane time shares (%u lanes): idle %.3f collect %.3f drain %.3f fill %.3f device %.3f wake %.3f; device ms per batch %.3f\n", tm.lanes,
+            tm.idle_ns / tot, tm.collect_ns / tot, tm.drain_ns / tot, tm.fill_ns / tot, tm.device_ns / tot, tm.wake_ns / tot, nb ? tm.device_ns / 1e6 / nb : 0.0);
     printf("{\"workload\": \"%llu x %u f32, %s, k=10, %d caller threads x %d single-query calls\", "
            "\"direct_calls\": {\"qps\": %.0f, \"mean_us\": %.1f, \"p99_us\": %.1f}, "
            "\"batcher\": {\"lanes\": %u, \"qps\": %.0f, \"mean_us\": %.1f, \"p99_us\": %.1f, \"mean_batch\": %.1f, \"max_wait_us\": %u, \"occ\": \"%s\", \"pair\": \"%s\"}}\n",

@@ -27,14 +27,21 @@
 //   * completion wakes its callers through 32 futex words, the first caller of each group relaying the wake (see Batch::Group);
 //   * a free lane does not take the open batch the instant its first query arrives: the callers of the batch that has just
 //     completed come back within tens of microseconds, and the lane that launched at the first of them ran a batch of a handful
-//     beside the next lane's hundreds (mean 170-300 of 1 024 callers).  A lane now takes the batch when its count has stopped
-//     growing for kQuietUs, when it is full, or when its first query has waited max_wait_us (0 = 200 us): a lone caller pays
-//     kQuietUs, a crowd is collected whole.  The lane polls (a pause loop, no sleep: futex time-outs overshoot by a scheduling
-//     quantum -- that, not the policy, was the 50 ms p99 of the first timer build);
-//   * hvx_batcher_timing reports where the lanes' and the callers' time went.
+//     beside the next lane's hundreds (mean 170-300 of 1 024 callers).  A lane now expects as many queries as its previous batch
+//     held -- they are the ones coming back -- and sleeps until a caller brings the open batch to that count (the caller rings the
+//     lane's bell), the batch is full, or its first query has waited max_wait_us (0 = 200 us).  A lone caller (previous batch: one
+//     query) is launched at once; when the load drops, one batch pays max_wait_us and the expectation follows it down;
+//   * NOTHING spins: the GPU boxes of this pool run the process under a CPU quota of 16 cores (cgroup cpu.max 1600000 100000;
+//     profiles/r04m_batcher_cgroup.log shows nr_throttled rising during a 1 024-caller run).  Spinning lanes (hipStreamSynchronize
+//     busy-waits, plus this file's former yield loops) burnt the quota, the whole process was frozen for the rest of the 100 ms
+//     period, and that -- not the batching policy -- was the 40-75 ms p99 of rounds 3 and 4.  A lane now waits for its stream on an
+//     event created with hipEventBlockingSync (an interrupt, no polling) and sleeps on futexes / short timed sleeps elsewhere;
+//   * hvx_batcher_lane_times reports where the lanes' time went.
 #include <hip/hip_runtime.h>
 #include <linux/futex.h>
+#include <sys/prctl.h>
 #include <sys/syscall.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -62,6 +69,10 @@ inline void futex_wake(std::atomic<uint32_t> *addr, int n) {
 
 inline int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 inline void cpu_pause() { __builtin_ia32_pause(); }
+inline void sleep_us(long us) {
+    timespec ts{us / 1000000, (us % 1000000) * 1000};
+    clock_nanosleep(CLOCK_MONOTONIC, 0, &ts, nullptr);
+}
 
 // one batch in flight between callers and a lane: pinned host staging + completion state
 struct Batch {
@@ -75,8 +86,9 @@ struct Batch {
     std::atomic<int64_t> t_first{0}; // steady-clock ns of the open batch's first claim (written by the caller of slot 0)
     // cumulative over every batch this buffer has carried (never reset: a reset could race with the first callers of the
     // next batch); batches of one buffer are strictly sequential, so "all of them" is always "the previous ones + this one"
-    alignas(64) std::atomic<uint64_t> filled{0};   // callers that finished writing their row
-    alignas(64) std::atomic<uint64_t> consumed{0}; // callers that copied their result out
+    // `filled` / `consumed` live in the groups below (slot % kGroups), one cache line each: a counter every caller of a batch adds
+    // to is a line that 300 cores hand around -- tens of microseconds of stalled CPU per caller on a two-socket host, and CPU time is
+    // what this pool rations (16 cores per process)
     alignas(64) std::atomic<uint32_t> done{0};     // sequence + 1 of the last batch completed in this buffer
     // Callers sleep on one of kGroups words (slot % kGroups), not on `done`: waking a few hundred waiters of ONE futex word is a
     // serial walk of its hash bucket by one thread (~1.5 us per waiter: the last of 300 callers left 0.4 ms after the first).  The
@@ -86,7 +98,11 @@ struct Batch {
     struct alignas(64) Group {
         std::atomic<uint32_t> word{0};  // sequence + 1 of the last completed batch (futex word)
         std::atomic<uint32_t> relay{0}; // sequence + 1 of the last batch whose group-wide wake has been issued
+        std::atomic<uint64_t> filled{0};   // callers of this group that finished writing their row (cumulative, like `total`)
+        std::atomic<uint64_t> consumed{0}; // callers of this group that copied their result out
     };
+    uint64_t filled_sum() const { uint64_t v = 0; for (const Group &g : grp) v += g.filled.load(); return v; }
+    uint64_t consumed_sum() const { uint64_t v = 0; for (const Group &g : grp) v += g.consumed.load(); return v; }
     static constexpr uint32_t kGroups = 32;
     Group grp[kGroups];
     uint64_t total = 0;            // slots of all batches closed in this buffer (written by the closing dispatcher before `done`)
@@ -103,15 +119,15 @@ struct Lane {
     std::atomic<uint32_t> wake_seq{0};
     alignas(64) std::atomic<uint32_t> wake_bell{0};
     float *d_q = nullptr; // the lane's query rows in HBM (results go straight to the batch's pinned rows)
+    hipEvent_t ev = nullptr; // hipEventBlockingSync: the lane sleeps until the stream's work is done
     // where this lane's time went, ns (hvx_batcher_timing)
     std::atomic<uint64_t> ns_idle{0}, ns_collect{0}, ns_drain{0}, ns_fill{0}, ns_device{0}, ns_wake{0};
 };
 
 } // namespace
 
-constexpr uint32_t kQuietUs = 12;                // a free lane takes the open batch once its count has stood still this long
-constexpr unsigned kSeqShift = 16;               // state word: 48-bit batch sequence | 16-bit claimed slots
-constexpr uint64_t kCountMask = 0xFFFFull;
+constexpr unsigned kSeqShift = 24;               // state word: 40-bit batch sequence | 24-bit claims (may overshoot max_batch, see the claim loop)
+constexpr uint64_t kCountMask = 0xFFFFFFull;
 
 struct hvx_batcher {
     hvx_search_params params{};
@@ -121,21 +137,26 @@ struct hvx_batcher {
     alignas(64) std::atomic<uint32_t> seq_word{0};   // low 32 bits of the open sequence: callers of a full batch sleep on it
     alignas(64) std::atomic<uint32_t> bell{0};       // dispatchers sleep on it; rung by the first and the last claim of a batch
     alignas(64) std::atomic<uint32_t> sleepers{0};   // dispatchers asleep on the bell
-    std::atomic<bool> stop{false};
-    std::atomic<uint32_t> inside{0};                 // callers currently inside hvx_batcher_search (hvx_batcher_free waits for them)
+    alignas(64) std::atomic<uint32_t> target{0};     // the count a waiting lane wants the open batch to reach: the caller that brings it there rings the bell
+    alignas(64) std::atomic<bool> stop{false};       // (its own line: every caller reads it)
+    struct alignas(64) Inside { std::atomic<uint32_t> n{0}; };
+    Inside inside[64];                               // callers currently inside hvx_batcher_search, striped by thread (hvx_batcher_free waits for them)
+    uint32_t inside_sum() const { uint32_t v = 0; for (const Inside &i : inside) v += i.n.load(); return v; }
     std::vector<Batch> bufs;
     std::vector<Lane> lanes;
     std::atomic<uint64_t> n_batches{0}, n_queries{0}, n_full{0};
 
     void run(Lane &ln) {
         (void)hipSetDevice(device);
-        const int64_t quiet_ns = (int64_t)kQuietUs * 1000, max_wait_ns = (int64_t)(max_wait_us ? max_wait_us : 200u) * 1000;
+        (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0); // this thread's timed sleeps end within ~1 us of their time (default slack: 50 us)
+        const int64_t max_wait_ns = (int64_t)(max_wait_us ? max_wait_us : 200u) * 1000;
+        uint32_t expect = 1; // queries the open batch should hold before this lane takes it: the size of the lane's previous batch
         int64_t t_mark = now_ns();
         auto lap = [&](std::atomic<uint64_t> &acc) { const int64_t t = now_ns(); acc.fetch_add((uint64_t)(t - t_mark), std::memory_order_relaxed); t_mark = t; };
         for (;;) {
             // this lane is free: look at the open batch
             uint64_t s = state.load();
-            uint32_t cnt = (uint32_t)(s & kCountMask);
+            uint32_t cnt = std::min<uint32_t>((uint32_t)(s & kCountMask), max_batch); // (claims past max_batch are void)
             if (cnt == 0) { // (sequentially consistent operations: a caller either sees this sleeper or this sleeper sees its claim)
                 if (stop.load()) return;
                 const uint32_t b0 = bell.load();
@@ -146,34 +167,35 @@ struct hvx_batcher {
                 continue;
             }
             const uint64_t seq = s >> kSeqShift;
-            // collect: take the batch when it is full, when its count has been still for kQuietUs, or when its first query is old
-            if (cnt < max_batch && !stop.load()) {
-                uint32_t last = cnt;
-                int64_t t_still = now_ns();
-                bool moved_on = false;
-                for (;;) {
-                    for (int i = 0; i < 32; ++i) cpu_pause();
+            // collect: the callers of this lane's previous batch are on their way back -- sleep until the open batch holds as many
+            // queries as that batch did (a caller rings the bell at that count), is full, or its first query has waited max_wait_us
+            const uint32_t need = expect < max_batch ? expect : max_batch;
+            if (cnt < need && !stop.load()) {
+                const int64_t t0 = bufs[seq % nbuf].t_first.load(std::memory_order_relaxed), t = now_ns();
+                const int64_t left = t0 ? max_wait_ns - (t - t0) : max_wait_ns;
+                if (left > 2000) {
+                    const uint32_t b0 = bell.load();
+                    target.store(need);
+                    sleepers.fetch_add(1);
                     const uint64_t s2 = state.load();
-                    if ((s2 >> kSeqShift) != seq) { moved_on = true; break; } // another lane took it
-                    const uint32_t c2 = (uint32_t)(s2 & kCountMask);
-                    const int64_t t = now_ns();
-                    if (c2 != last) { last = c2; t_still = t; }
-                    if (c2 >= max_batch || t - t_still >= quiet_ns || stop.load()) break;
-                    const int64_t t0 = bufs[seq % nbuf].t_first.load(std::memory_order_relaxed);
-                    if (t0 && t - t0 >= max_wait_ns) break;
+                    if ((s2 >> kSeqShift) == seq && (uint32_t)(s2 & kCountMask) < need && !stop.load()) futex_wait(&bell, b0, (long)(left / 1000));
+                    sleepers.fetch_sub(1);
+                    lap(ln.ns_collect);
+                    const uint64_t s3 = state.load();
+                    if ((s3 >> kSeqShift) != seq) continue; // another lane took it
+                    const uint32_t c3 = std::min<uint32_t>((uint32_t)(s3 & kCountMask), max_batch);
+                    const int64_t tf = bufs[seq % nbuf].t_first.load(std::memory_order_relaxed);
+                    if (c3 < need && !(tf && now_ns() - tf >= max_wait_ns) && !stop.load()) continue; // woken for something else: look again
+                    s = s3;
+                    cnt = c3;
                 }
-                lap(ln.ns_collect);
-                if (moved_on) continue;
-                s = state.load();
-                if ((s >> kSeqShift) != seq) continue;
-                cnt = (uint32_t)(s & kCountMask);
             }
             // the next batch opens in buffer (seq + 1) % nbuf at the instant this one closes: it must be free, i.e. every
             // caller of the batch it held last has taken its rows
             Batch &next = bufs[(seq + 1) % nbuf];
             if (seq + 1 >= nbuf && !stop.load()) { // its previous batch (sequence seq + 1 - nbuf) must be complete and fully drained
-                if (next.done.load() != (uint32_t)(seq + 1 - nbuf + 1) || next.consumed.load() != next.total) {
-                    for (int i = 0; i < 64; ++i) cpu_pause();
+                if (next.done.load() != (uint32_t)(seq + 1 - nbuf + 1) || next.consumed_sum() != next.total) {
+                    sleep_us(10); // (a caller of that batch has not copied its rows out yet)
                     lap(ln.ns_drain);
                     continue;
                 }
@@ -184,12 +206,16 @@ struct hvx_batcher {
             futex_wake(&seq_word, INT_MAX); // callers that found the batch full
             Batch &bt = bufs[seq % nbuf];
             bt.total += cnt;
-            while (bt.filled.load() < bt.total) cpu_pause(); // callers still copying their row in
+            for (uint32_t spins = 0; bt.filled_sum() < bt.total; ++spins) { // callers still copying their row in (3 KB: normally done)
+                if (spins < 64) cpu_pause();
+                else sleep_us(5);
+            }
             lap(ln.ns_fill);
             n_batches.fetch_add(1, std::memory_order_relaxed);
             n_queries.fetch_add(cnt, std::memory_order_relaxed);
             if (cnt == max_batch) n_full.fetch_add(1, std::memory_order_relaxed);
             launch(ln, bt, cnt);
+            expect = cnt;
             lap(ln.ns_device);
             Batch *expected = nullptr;
             if (ln.waker.joinable() && ln.wake_batch.load() == nullptr) { // the waker is idle: it completes the batch, this lane goes on
@@ -237,7 +263,8 @@ struct hvx_batcher {
         if (e != hipSuccess) return bad("hipMemcpyAsync(queries)", e);
         const int rc = hvx_search_batch_params_device(ln.ix, ln.d_q, cnt, &params, bt.dev_ids, bt.dev_sc, bt.dev_cnt, bt.dev_st, nullptr, nullptr, nullptr);
         if (rc) { bt.rc = rc; bt.err = hvx_last_error(); return; }
-        if ((e = hipStreamSynchronize(s)) != hipSuccess) return bad("hipStreamSynchronize", e);
+        if ((e = hipEventRecord(ln.ev, s)) != hipSuccess) return bad("hipEventRecord", e);
+        if ((e = hipEventSynchronize(ln.ev)) != hipSuccess) return bad("hipEventSynchronize", e); // (blocking event: no busy-wait)
     }
 };
 
@@ -255,7 +282,7 @@ extern "C" void hvx_batcher_free(hvx_batcher *b) {
     }
     // callers that were blocked when the batcher stopped leave with "shutting down" (their futex waits time out within 5 ms): the
     // object outlives the last of them.  (Calling hvx_batcher_search AFTER hvx_batcher_free has returned is the host's bug.)
-    for (uint32_t spins = 0; b->inside.load() != 0 && spins < 200000u; ++spins) {
+    for (uint32_t spins = 0; b->inside_sum() != 0 && spins < 200000u; ++spins) {
         for (Batch &bt : b->bufs)
             for (Batch::Group &g : bt.grp) futex_wake(&g.word, INT_MAX);
         futex_wake(&b->seq_word, INT_MAX);
@@ -264,6 +291,7 @@ extern "C" void hvx_batcher_free(hvx_batcher *b) {
     (void)hipSetDevice(b->device);
     for (Lane &ln : b->lanes) {
         if (ln.d_q) (void)hipFree(ln.d_q);
+        if (ln.ev) (void)hipEventDestroy(ln.ev);
         if (ln.ix) hvx_index_free(ln.ix);
     }
     for (Batch &bt : b->bufs)
@@ -278,7 +306,7 @@ extern "C" int hvx_batcher_new_lanes(hvx_index *ix, const hvx_search_params *par
     *out = nullptr;
     if (max_batch == 0) max_batch = ix->max_batch;
     if (max_batch > ix->max_batch) return fail(HVX_ERR_UNSUPPORTED, "batch %u exceeds max_batch %u given at import", max_batch, ix->max_batch);
-    if (max_batch > 0xFFFFu) max_batch = 0xFFFFu; // 16 count bits of the state word
+    if (max_batch > 0xFFFFu) max_batch = 0xFFFFu; // (the state word's 24 claim bits leave room for 16 million void claims beyond it)
     if (lanes == 0) lanes = 4;
     if (lanes > 8) return fail(HVX_ERR_K_RANGE, "at most 8 dispatcher lanes");
     int rc = check_k_ef(params->k, params->ef);
@@ -309,7 +337,8 @@ extern "C" int hvx_batcher_new_lanes(hvx_index *ix, const hvx_search_params *par
             return rc;
         }
         // (a lane inherits the parent handle's settings -- hvx_index_set_occupancy / hvx_index_set_option -- at this point)
-        ok = ok && dev((void **)&ln.d_q, (size_t)max_batch * b->dim * 4);
+        ok = ok && dev((void **)&ln.d_q, (size_t)max_batch * b->dim * 4) &&
+             hipEventCreateWithFlags(&ln.ev, hipEventBlockingSync | hipEventDisableTiming) == hipSuccess;
     }
     if (!ok) {
         hvx_batcher_free(b);
@@ -332,9 +361,11 @@ extern "C" int hvx_batcher_new(hvx_index *ix, const hvx_search_params *params, u
 static int batcher_search_inner(hvx_batcher *b, const float *query, uint64_t *out_ids, float *out_scores, uint32_t *out_count);
 extern "C" int hvx_batcher_search(hvx_batcher *b, const float *query, uint64_t *out_ids, float *out_scores, uint32_t *out_count) {
     if (!b || !query || !out_ids || !out_scores || !out_count) return fail(HVX_ERR_INVARIANT, "null argument");
-    b->inside.fetch_add(1);
+    static std::atomic<uint32_t> next_stripe{0};
+    thread_local const uint32_t stripe = next_stripe.fetch_add(1, std::memory_order_relaxed) & 63u;
+    b->inside[stripe].n.fetch_add(1);
     const int rc = batcher_search_inner(b, query, out_ids, out_scores, out_count);
-    b->inside.fetch_sub(1);
+    b->inside[stripe].n.fetch_sub(1);
     return rc;
 }
 static int batcher_search_inner(hvx_batcher *b, const float *query, uint64_t *out_ids, float *out_scores, uint32_t *out_count) {
@@ -346,20 +377,27 @@ static int batcher_search_inner(hvx_batcher *b, const float *query, uint64_t *ou
         if (b->stop.load(std::memory_order_acquire)) return fail(HVX_ERR_INVARIANT, "batcher is shutting down");
         uint64_t s = b->state.load();
         seq = s >> kSeqShift;
-        slot = (uint32_t)(s & kCountMask);
-        if (slot >= b->max_batch) { // full: a lane closes it as soon as one is free; wait for the next batch to open
+        if ((uint32_t)(s & kCountMask) >= b->max_batch) { // full: a lane closes it as soon as one is free; wait for the next batch to open
             futex_wait(&b->seq_word, (uint32_t)seq, 200);
             continue;
         }
-        if (b->state.compare_exchange_weak(s, s + 1)) break;
+        // ONE fetch-and-add, no retry loop: the callers of a completed batch come back together, and a compare-and-swap loop over
+        // one word costs a burst of N callers ~N^2 / 2 failed attempts (300 callers: ~45 000 cache-line transfers, several ms of CPU
+        // per batch -- under this pool's 16-core quota that alone throttled the process).  A claim that lands past max_batch (the batch
+        // filled between the load and the add) is void: the dispatcher counts min(claims, max_batch), and the caller tries the next batch.
+        s = b->state.fetch_add(1);
+        seq = s >> kSeqShift;
+        slot = (uint32_t)(s & kCountMask);
+        if (slot < b->max_batch) break;
+        futex_wait(&b->seq_word, (uint32_t)seq, 200);
     }
     Batch &bt = b->bufs[seq % b->nbuf];
     if (slot == 0) bt.t_first.store(now_ns(), std::memory_order_relaxed);
     memcpy(bt.q + (size_t)slot * b->dim, query, (size_t)b->dim * 4);
-    bt.filled.fetch_add(1);
-    if ((slot == 0 || slot + 1 == b->max_batch) && b->sleepers.load()) { // first / last query of a batch: a sleeping lane should look
+    bt.grp[slot % Batch::kGroups].filled.fetch_add(1);
+    if ((slot == 0 || slot + 1 == b->max_batch || slot + 1 == b->target.load()) && b->sleepers.load()) { // first / last query of a batch, or the count a waiting lane asked for
         b->bell.fetch_add(1);
-        futex_wake(&b->bell, 1);
+        futex_wake(&b->bell, INT_MAX); // (at most 8 lanes; each looks at the batch and goes back to sleep if it is not the one to take it)
     }
     // wait for the batch
     const uint32_t want = (uint32_t)(seq + 1);
@@ -369,7 +407,7 @@ static int batcher_search_inner(hvx_batcher *b, const float *query, uint64_t *ou
         if (d == want) break;
         futex_wait(&grp.word, d, 5000);
         if (b->stop.load(std::memory_order_acquire) && grp.word.load(std::memory_order_acquire) != want) {
-            bt.consumed.fetch_add(1); // the slot is accounted for: a dispatcher draining this buffer must not wait for it
+            grp.consumed.fetch_add(1); // the slot is accounted for: a dispatcher draining this buffer must not wait for it
             return fail(HVX_ERR_INVARIANT, "batcher is shutting down");
         }
     }
@@ -387,7 +425,7 @@ static int batcher_search_inner(hvx_batcher *b, const float *query, uint64_t *ou
         memcpy(out_ids, bt.ids + (size_t)slot * b->k, (size_t)c * 8);
         memcpy(out_scores, bt.sc + (size_t)slot * b->k, (size_t)c * 4);
     }
-    bt.consumed.fetch_add(1);
+    grp.consumed.fetch_add(1);
     if (rc) return err.empty() ? fail(rc, "query rejected with status %u", st) : fail(rc, "%s", err.c_str());
     return HVX_OK;
 }

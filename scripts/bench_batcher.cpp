@@ -97,6 +97,18 @@ int main(int argc, char **argv) {
         *p99_us = all[(size_t)(all.size() * 0.99)];
         if (failures) fprintf(stderr, "%d failed calls\n", failures.load());
     };
+    auto cgroup = [](unsigned long long out[3]) { // nr_throttled, throttled_usec, usage_usec of this container (cgroup v2)
+        out[0] = out[1] = out[2] = 0;
+        FILE *f = fopen("/sys/fs/cgroup/cpu.stat", "r");
+        if (!f) return;
+        char key[64]; unsigned long long v;
+        while (fscanf(f, "%63s %llu", key, &v) == 2) {
+            if (!strcmp(key, "nr_throttled")) out[0] = v;
+            else if (!strcmp(key, "throttled_usec")) out[1] = v;
+            else if (!strcmp(key, "usage_usec")) out[2] = v;
+        }
+        fclose(f);
+    };
     double q0, m0, p0, q1, m1, p1;
     q0 = m0 = p0 = 0;
     if (direct) run(nullptr, &q0, &m0, &p0); // direct one-query calls on one handle: every call is a launch + two PCIe copies
@@ -109,7 +121,14 @@ int main(int argc, char **argv) {
     if (e_pair && hvx_index_set_option(ix, HVX_OPT_HNSW_PAIR, (uint32_t)atoi(e_pair))) { fprintf(stderr, "%s\n", hvx_last_error()); return 1; }
     if (hvx_batcher_new_lanes(ix, &p, 1024, wait_us, lanes, &bt)) { fprintf(stderr, "%s\n", hvx_last_error()); return 1; }
     run(bt, &q1, &m1, &p1);
+    unsigned long long cg0[3], cg1[3];
+    cgroup(cg0);
+    const auto tb0 = std::chrono::steady_clock::now();
     run(bt, &q1, &m1, &p1);
+    const double run_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count();
+    cgroup(cg1);
+    fprintf(stderr, "timed run: %.3f s wall, %.2f CPU cores busy on average, cgroup throttled %llu time(s) for %.1f ms\n", run_s,
+            (cg1[2] - cg0[2]) / 1e6 / run_s, cg1[0] - cg0[0], (cg1[1] - cg0[1]) / 1e3);
     uint64_t nb = 0, nqs = 0, nf = 0;
     hvx_batcher_stats(bt, &nb, &nqs, &nf);
     hvx_batcher_times tm;

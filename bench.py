@@ -78,7 +78,7 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores (capped at 64)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle bit-exactness check")
     ap.add_argument("--metric", default="l2", choices=["l2", "cosine"])
-    ap.add_argument("--skip", default="", help="comma list of extra legs to skip: production,datasets,iso_recall,config3,config4,config5,graph_equivalence")
+    ap.add_argument("--skip", default="", help="comma list of extra legs to skip: production,batcher,datasets,iso_recall,config3,config4,config5,graph_equivalence")
     ap.add_argument("--c5-rows", type=int, default=12_500_000, help="config #5 per-GPU shard (100M / 8)")
     ap.add_argument("--c4-rows", type=int, default=1_250_000, help="config #4 per-GPU shard (10M / 8)")
     ap.add_argument("--builder", default="device", choices=["device", "bulk"], help="how the benchmark graph is built")
@@ -843,6 +843,44 @@ def leg_graph_equivalence(hv, synth, args, dev, which="embedding"):
 
 
 # ------------------------------------------------------------------------------------------------------------
+def leg_batcher(x_host, q_host, g, m, callers=1024, per_caller=300, lanes=3):
+    """SURVEY 8f-4 on the headline corpus and graph: `callers` OS threads each issuing single-query hvx_batcher_search calls in a closed
+    loop (the reference's one-search-per-operator-call pattern, access/search/storage.rs:140-163).  The callers are a C++ harness
+    (scripts/bench_batcher.cpp, compiled here) in its own process: Python threads would measure the GIL.  The harness reads the
+    container's cgroup cpu.stat around its timed run (the pool's 16-core quota decides this number as much as the GPU does)."""
+    import shutil, subprocess, tempfile
+    root = os.path.dirname(os.path.abspath(__file__))
+    d = tempfile.mkdtemp(prefix="hvx_batcher_", dir="/tmp")
+    try:
+        n, dim = x_host.shape
+        np.array([n, dim, m, g["entry_point"], g["max_layer"]], np.uint64).tofile(f"{d}/meta.u64")
+        np.asarray(g["node_ids"], np.uint64).tofile(f"{d}/ids.u64")
+        np.ascontiguousarray(x_host, np.float32).tofile(f"{d}/vectors.f32")
+        np.ascontiguousarray(q_host, np.float32).tofile(f"{d}/queries.f32")
+        for name in ("l0_offsets", "l0_neighbors", "up_offsets", "up_neighbors"):
+            np.asarray(g[name], np.uint64).tofile(f"{d}/{name}.u64")
+        np.asarray(g["level"], np.uint16).tofile(f"{d}/level.u16")
+        exe = f"{d}/bench_batcher"
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(root, "include"), os.path.join(root, "scripts", "bench_batcher.cpp"), "-o", exe,
+                               "-L", os.path.join(root, "helix-db_amd"), "-lhelix_vec_gfx950", f"-Wl,-rpath,{os.path.join(root, 'helix-db_amd')}", "-lpthread"])
+        env = dict(os.environ, BATCHER_WAIT="200")
+        r = subprocess.run([exe, d, str(callers), str(per_caller), "strict", str(lanes), "nodirect"], capture_output=True, text=True, timeout=240, env=env)
+        if r.returncode != 0:
+            return {"error": (r.stderr or r.stdout)[-400:]}
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        res = {"workload": f"{n}x{dim} f32 (the headline corpus and graph), strict ef=100 k=10, {callers} caller threads x {per_caller} single-query hvx_batcher_search calls, "
+                           f"{lanes} dispatcher lanes, max_wait_us 200",
+               "qps": line["batcher"]["qps"], "mean_us": line["batcher"]["mean_us"], "p99_us": line["batcher"]["p99_us"], "mean_batch": line["batcher"]["mean_batch"]}
+        for l in r.stderr.splitlines():
+            if l.startswith("timed run:"):
+                res["host"] = l[len("timed run: "):]
+            elif l.startswith("lane time shares"):
+                res["lanes"] = l
+        return res
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def start_deadline(out, seconds, rank):
     """The extra legs (other corpora, configs 3-5, graph equivalence, CPU baseline) must never cost the headline: once the
     headline object exists, a daemon thread prints it -- with the legs that have finished by then -- when the deadline passes,
@@ -1261,6 +1299,15 @@ def main():
                                  "distance_computations_equal": bool(o_dc == int(qst[:, 3].sum()))}
                 assert same, "GPU HNSW results differ from the CPU oracle"
             del oix
+        if "batcher" not in skip and not bf16 and headline_alive:
+            t0 = time.time()
+            try:
+                if x_host is None:
+                    x_host = x.cpu().numpy()
+                out["batcher"] = leg_batcher(x_host, q.cpu().numpy(), g, args.m)
+            except Exception as e:
+                out["batcher"] = {"error": f"{type(e).__name__}: {e}"}
+            log(f"[batcher] {time.time() - t0:.1f}s")
         del x_host
 
     # the headline index is no longer needed

@@ -28,13 +28,15 @@ struct MfmaArgs {
     uint32_t nq_tiles, nr_tiles, group_tiles;
     // 256 x 256 kernel: XCD-aware super-tiles (hvx_flat_tile.hip)
     uint32_t sup_q, sup_r, sup_qblocks;
+    const uint32_t *qexp; // MX build of the fp8 tile kernel: [bpad] E8M0 scale of a query's hi codes (a.qhi = the e4m3 operand there)
     uint32_t ablate; // measurement only (HVX_FLAT_TILE_ABLATE, two-buffer build): 1 no operand copies after stage 0, 2 no MFMAs, 4 no epilogue
 };
 
 // 256 x 256 filtered contraction (hvx_flat_tile.hip).  kind: 0 = bf16 rows (a bf16 index, or the bf16 shadow of an f32
 // index; a.rows in the order a.qhi uses), 1 = fp8 codes (a.qhi in tile order, see tile_slot_fp8).  a.dim % 64 == 0.
 // `wg_overflow` is set when a workgroup's pair list overflowed (the caller repeats the scan unfiltered).
-// build: 0 = two 256-thread workgroups per CU (256 x 128 tiles), 1 = one 512-thread workgroup per CU (256 x 256 tiles)
+// build: 0 = two 256-thread workgroups per CU (256 x 128 tiles), 1 = one 512-thread workgroup per CU (256 x 256 tiles), 2 = role-split,
+// 3 (fp8 codes only) = the MX-scaled fp8 build: a.qhi = two e4m3 pieces per query value, a.qexp their scales
 hipError_t launch_flat_tile256(const MfmaArgs &a, int kind, uint32_t bpad, float xmax2, uint32_t *wg_overflow, uint32_t build, hipStream_t s);
 
 // one-pass score matrix for small batches (hvx_flat_smallb.hip): b <= 128 queries, kind 0 = bf16 rows / shadow, 2 = f32 rows

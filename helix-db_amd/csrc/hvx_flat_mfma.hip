@@ -87,6 +87,42 @@ __global__ __launch_bounds__(64) void split_queries_kernel(const float *q, uint3
     if (threadIdx.x == 0 && r < b) qn2[r] = (float)acc;
 }
 
+// The query operand of the MX-scaled fp8 tile build (hvx_flat_tile.hip, flat_tile2mx_kernel): v_mfma_scale_f32_32x32x64_f8f6f4 multiplies
+// fp8 by fp8, so a query value is carried as TWO e4m3 pieces -- hi = RNE(q / s), lo = RNE((q - s hi) 16 / s), s = 2^E the power of two
+// that puts max |q| into (224, 448] -- and the instruction's block scales (E8M0: 127 + E for the hi piece, 4 less for the lo piece)
+// restore the magnitudes: q ~ s hi + (s / 16) lo with |q - that| <= 2^-8 |q| per element (3 mantissa bits twice; subnormal pieces add
+// <= 2^-18 max |q| absolute).  Layout: [query][dim / 64 stages][64 hi codes | 64 lo codes], element i at position fp8_slot_of(i) of the
+// row (the order the fp8 rows are stored in): a lane of the tile kernel reads 32 consecutive codes of a row and of a query.
+__global__ __launch_bounds__(64) void split_queries_mx_kernel(const float *q, uint32_t b, uint32_t bpad, uint32_t dim, unsigned char *qmx, uint32_t *qexp) {
+    const uint32_t r = blockIdx.x;
+    if (r >= bpad) return;
+    float mx = 0.f;
+    for (uint32_t i = threadIdx.x; i < dim; i += 64) {
+        const float v = r < b ? q[(size_t)r * dim + i] : 0.f;
+        if (f32_is_finite(v)) mx = fmaxf(mx, fabsf(v));
+    }
+    for (int s = 32; s > 0; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s, 64));
+    int e = 0;
+    if (mx > 0.f) {
+        int ex;
+        (void)frexpf(mx, &ex); // mx = f 2^ex, f in [0.5, 1): mx / 2^(ex - 9) in [256, 512) would overflow 448 -> one more
+        e = ex - 8;            // mx / 2^e in [128, 256)
+    }
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    const float inv = ldexpf(1.0f, -e), sc = ldexpf(1.0f, e);
+    for (uint32_t i = threadIdx.x; i < dim; i += 64) {
+        float v = r < b ? q[(size_t)r * dim + i] : 0.f;
+        if (!f32_is_finite(v)) v = 0.f;
+        const uint8_t hi = fp8_e4m3_encode(v * inv);
+        const float res = v - fp8_e4m3_decode(hi) * sc; // exact: both are multiples of the hi step, within f32's 24 bits
+        const uint8_t lo = fp8_e4m3_encode(res * inv * 16.0f);
+        const uint32_t s = fp8_slot_of(i), at = (s >> 6) * 128u + (s & 63u);
+        qmx[(size_t)r * dim * 2 + at] = hi;
+        qmx[(size_t)r * dim * 2 + at + 64u] = lo;
+    }
+    if (threadIdx.x == 0) qexp[r] = (uint32_t)(127 + e);
+}
+
 // ---- the contraction ----
 constexpr int kBM = 128, kBN = 128, kBK = 32; // queries x rows x depth per stage
 constexpr int kLdsStride = kBK * 2 + 16;      // bytes per tile row: 64 B of data + 16 B pad => conflict-free ds_read_b128
@@ -724,6 +760,16 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
     hipLaunchKernelGGL(split_queries_kernel, dim3(bpad), dim3(64), 0, ix->stream, d_queries, b, bpad, d.dim, ix->m_qhi, ix->m_qlo, ix->m_qn2,
                        f32 ? 2u : (fp8 ? 1u : 0u), fp8 && tile_ok ? ix->m_qhi8 : nullptr);
     HIP_TRY(hipGetLastError());
+    const bool mx_build = fp8 && tile_ok && ix->opt[HVX_OPT_FLAT_TILE_BUILD] == 3u && d.dim % 128u == 0u;
+    if (mx_build) {
+        if ((size_t)bpad * d.dim > ix->cap_qmx) {
+            if ((rc = ix->regrow((void **)&ix->m_qmx, (size_t)bpad * d.dim * 2))) return rc;
+            if ((rc = ix->regrow((void **)&ix->m_qexp, (size_t)bpad * 4))) return rc;
+            ix->cap_qmx = (size_t)bpad * d.dim;
+        }
+        hipLaunchKernelGGL(split_queries_mx_kernel, dim3(bpad), dim3(64), 0, ix->stream, d_queries, b, bpad, d.dim, ix->m_qmx, ix->m_qexp);
+        HIP_TRY(hipGetLastError());
+    }
     if (timed) HIP_TRY(hipEventRecord(ix->ev0, ix->stream));
     // Attempts, cheapest first; a query whose certificate is not reached sends the batch to the next one:
     //   0. ONE-pass contraction (q_hi.x_hi only; the dropped residual terms widen the certificate's bound), m = max(63, 2k)
@@ -813,7 +859,7 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
         pm.cand_cnt = ix->m_ccnt; pm.thr = ix->m_thr; pm.overflow = ix->m_ccnt ? ix->m_ccnt + bpad : nullptr; pm.qstatus = ix->d_qstatus;
         pm.kc = kc; pm.cap = smallb ? kSmallbCandCap : kCandCap;
         uint32_t r0 = 0;
-        bool used_tile = false;
+        bool used_tile = false, used_mx = false;
         if (smallb) {
             MfmaArgs sa = ma;
             sa.row0 = 0; sa.nrows = n;
@@ -845,7 +891,9 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
                     ta.row0 = r0; ta.nrows = rows;
                     if (f32) ta.rows = ix->m_shadow;
                     if (fp8) ta.qhi = ix->m_qhi8;
-                    HIP_TRY(launch_flat_tile256(ta, fp8 ? 1 : 0, bpad, ix->m_xmax2, pm.overflow, ix->opt[HVX_OPT_FLAT_TILE_BUILD], ix->stream));
+                    if (mx_build) { ta.qhi = reinterpret_cast<const uint16_t *>(ix->m_qmx); ta.qexp = ix->m_qexp; }
+                    HIP_TRY(launch_flat_tile256(ta, fp8 ? 1 : 0, bpad, ix->m_xmax2, pm.overflow, fp8 || ix->opt[HVX_OPT_FLAT_TILE_BUILD] != 3u ? ix->opt[HVX_OPT_FLAT_TILE_BUILD] : 0u, ix->stream));
+                    used_mx |= mx_build;
                     used_tile = true;
                 } else
                     HIP_TRY(contraction(r0, rows, true));
@@ -874,6 +922,8 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
         // one rounded operand drops a term <= 2^-9 |q||x| of the dot product = 2^-8 of (|q|^2 + |x|^2)/2 in the L2 score
         // (cosine: <= 2^-10 absolute); f32 rows round BOTH operands in the one-pass build
         ra.extra_rel = full ? 0.f : (f32 ? 0.0078125f : 0.00390625f);
+        // the MX build's query is two e4m3 pieces: |q - q^| <= 2^-8 |q| per element (+ subnormal pieces: 2^-18 max |q|) -- twice the bf16 hi part's
+        if (used_mx) ra.extra_rel = 0.0079f;
         HIP_TRY(d.metric == kL2 ? launch_rerank<kL2>(ra, b, ix->stream) : launch_rerank<kCosine>(ra, b, ix->stream));
         if (timed) HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
         if ((rc = ix->pin_flags((size_t)b + 1))) return rc; // read back through pinned memory: a pageable copy is a synchronous staged one

@@ -481,6 +481,123 @@ __global__ __launch_bounds__(256, 2) void flat_tile2_kernel(MfmaArgs a, float xm
     tile_epilogue<FP8, 2>(a, acc, lds, q0, r0, wm, wn, tid, xmax2, wg_overflow);
 }
 
+// ---- the MX-scaled fp8 build (round 4; VERDICT r3 missing #6): fp8 rows x fp8 query pieces on v_mfma_scale_f32_32x32x64_f8f6f4, the
+// only large-K low-precision matrix instruction of gfx950 (measured 4 447 TFLOP/s against 1 820 for bf16 32x32x16 in
+// scripts/mfma_rate_probe.hip).  Same tile, same stage geometry and the same copies as flat_tile2_kernel<1>: a stage is 64 deep,
+// a query's stage row is 128 bytes -- but they hold the query as TWO e4m3 pieces (64 hi codes | 64 lo codes, split_queries_mx_kernel)
+// instead of 64 bf16 values, and the row codes go into the matrix cores as they are: no v_cvt_pk_f32_fp8 / v_perm widening (8 VALU
+// operations per fragment), and K = 64 per instruction.  Per stage and wavefront: 4 + 16 fragment reads (ds_read_b128: 32 consecutive
+// codes of a tile row per lane = the operand layout, tests/native/mx_probe.hip), 16 matrix instructions (8 hi, 8 lo; 64 cycles each by
+// the bf16-relative rate, i.e. the same 1 024 cycles per stage as 32 bf16 steps -- the gain, if any, is the measured rate and the
+// missing VALU work).  The query's power-of-two scale rides in the instruction's block scale (E8M0, the lo piece 4 less); the rows'
+// f32 scales stay in the epilogue as before.
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+__global__ __launch_bounds__(256, 2) void flat_tile2mx_kernel(MfmaArgs a, float xmax2, uint32_t *wg_overflow) {
+    constexpr int TNR = 128;
+    constexpr int AROWB = 128, BROWB = 64;
+    constexpr int ASTAGE = kTM * AROWB, STAGE = ASTAGE + TNR * BROWB; // 40 KB
+    constexpr int NBUF = 2;
+    constexpr int GA = AROWB / 16, GB = 2;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NBUF * STAGE];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    uint32_t qt, rt;
+    if (!tile_coords(a, qt, rt)) return;
+    const uint32_t q0 = qt * kTM, r0 = rt * TNR;
+
+    const unsigned char *gA[GA], *gB[GB];
+#pragma unroll
+    for (int t = 0; t < GA; ++t) {
+        const uint32_t row = (uint32_t)(64 * wave + 8 * t + (lane >> 3)), slot = (uint32_t)(lane & 7) ^ ((row >> 1) & 7u);
+        gA[t] = reinterpret_cast<const unsigned char *>(a.qhi) + (size_t)(q0 + row) * a.dim * 2 + slot * 16;
+    }
+#pragma unroll
+    for (int t = 0; t < GB; ++t) {
+        const uint32_t row = (uint32_t)(32 * wave + 16 * t + (lane >> 2));
+        const uint32_t slot = (uint32_t)(lane & 3) ^ ((row >> 2) & 3u);
+        uint32_t rloc = r0 + row;
+        if (rloc >= a.nrows) rloc = a.nrows - 1;
+        const size_t node = a.subset ? a.subset[a.row0 + rloc] : (size_t)a.row0 + rloc;
+        gB[t] = reinterpret_cast<const unsigned char *>(a.rows) + node * a.dim + slot * 16;
+    }
+    auto issue_stage = [&](uint32_t s) {
+        unsigned char *sA = lds + (s % NBUF) * STAGE + wave * (64 * AROWB);
+        unsigned char *sB = lds + (s % NBUF) * STAGE + ASTAGE + wave * (32 * BROWB);
+#pragma unroll
+        for (int t = 0; t < GA; ++t) HVX_GLDS16(gA[t] + s * (uint32_t)AROWB, sA + t * 1024);
+#pragma unroll
+        for (int t = 0; t < GB; ++t) HVX_GLDS16(gB[t] + s * (uint32_t)BROWB, sB + t * 1024);
+    };
+    const int fr = lane & 31, h = lane >> 5;
+    // fragment reads: 32 consecutive codes = two 16-byte slots; queries: hi codes in slots 0-3, lo codes in slots 4-7 of the 128-byte row
+    int offA[2][2], offB[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        offA[0][t] = fr * 128 + (((2 * h + t) ^ ((fr >> 1) & 7)) << 4);
+        offA[1][t] = fr * 128 + (((4 + 2 * h + t) ^ ((fr >> 1) & 7)) << 4);
+        offB[t] = fr * 64 + (((2 * h + t) ^ ((fr >> 2) & 3)) << 4);
+    }
+    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(lds);
+    const uint32_t baseA = lds0 + (uint32_t)(wm * (128 * AROWB)), baseB = lds0 + (uint32_t)(ASTAGE + wn * (64 * BROWB));
+    // block scales of this lane's four query rows (one per 32-query tile): E8M0 of the hi piece, the lo piece is 2^-4 of it
+    int sc_hi[4], sc_lo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = (int)a.qexp[q0 + (uint32_t)(wm * 128 + i * 32 + fr)]; // (queries are padded to 256: the padding rows hold zero codes)
+        sc_hi[i] = e;
+        sc_lo[i] = e >= 4 ? e - 4 : 0;
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto frag = [&](uint32_t addr0, uint32_t addr1) -> i32x8 {
+        const uint4 x = lds_read16<0>(addr0), y = lds_read16<0>(addr1);
+        i32x8 v;
+        v[0] = (int)x.x; v[1] = (int)x.y; v[2] = (int)x.z; v[3] = (int)x.w;
+        v[4] = (int)y.x; v[5] = (int)y.y; v[6] = (int)y.z; v[7] = (int)y.w;
+        return v;
+    };
+    const uint32_t nstage = a.dim / 64u;
+    issue_stage(0);
+    for (uint32_t s = 0; s < nstage; ++s) {
+        wait_vmcnt<0>();              // this wave's copies of stage s have landed ...
+        __builtin_amdgcn_s_barrier(); // ... everyone's have; nobody still reads the other buffer
+        if (s + 1 < nstage) issue_stage(s + 1);
+        const uint32_t buf = s % NBUF, pa = baseA + buf * (uint32_t)STAGE, pb = baseB + buf * (uint32_t)STAGE;
+        // all 20 fragment reads of the stage first, into registers of their own (a read that lands in a register an earlier matrix
+        // instruction may still be fetching its operand from would be a hazard nobody checks for an inline-asm read)
+        i32x8 fb[2], fh[4], fl[4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = frag(pb + (uint32_t)(j * 32 * BROWB + offB[0]), pb + (uint32_t)(j * 32 * BROWB + offB[1]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fh[i] = frag(pa + (uint32_t)(i * 32 * AROWB + offA[0][0]), pa + (uint32_t)(i * 32 * AROWB + offA[0][1]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fl[i] = frag(pa + (uint32_t)(i * 32 * AROWB + offA[1][0]), pa + (uint32_t)(i * 32 * AROWB + offA[1][1]));
+        wait_lgkm<8>(); // the row codes and the hi pieces have arrived (LDS answers in order), the lo pieces are on their way
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fh[i], fb[j], acc[i][j], 0, 0, 0, sc_hi[i], 0, 127);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_lgkm0();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fl[i], fb[j], acc[i][j], 0, 0, 0, sc_lo[i], 0, 127);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    tile_epilogue<true, 2>(a, acc, lds, q0, r0, wm, wn, tid, xmax2, wg_overflow);
+}
+
 // ---- the role-split build (round 4; VERDICT r2 / r3 "the structure that is still untried"): 512 threads = 2 x 4 wavefronts on a
 // 256 x 256 tile, 64-deep stages in two LDS buffers, and the two wavefronts of every SIMD in OPPOSITE roles at any instant.  The
 // four wavefronts of query half 1 run one phase behind those of half 0 (one extra barrier at the start), and a stage is four
@@ -865,12 +982,14 @@ hipError_t launch_flat_tile256(const MfmaArgs &a, int kind, uint32_t bpad, float
         return hipGetLastError();
     }
 #endif
-    if (build == 0) { // 256 x 128 tiles, 256 threads, two workgroups per CU: super-tiles of 64 workgroups per XCD
+    if (build == 3 && kind != 1) return hipErrorInvalidValue; // (the MX build multiplies fp8 codes)
+    if (build == 0 || build == 3) { // 256 x 128 tiles, 256 threads, two workgroups per CU: super-tiles of 64 workgroups per XCD
         t.nr_tiles = (a.nrows + 127u) / 128u;
         t.sup_r = 64u / t.sup_q;
         const uint32_t rb = (t.nr_tiles + 8u * t.sup_r - 1) / (8u * t.sup_r);
         const dim3 grid2(8u * rb * t.sup_qblocks * t.sup_r * t.sup_q);
-        if (kind == 1) hipLaunchKernelGGL((flat_tile2_kernel<1>), grid2, dim3(256), 0, s, t, xmax2, wg_overflow);
+        if (build == 3) hipLaunchKernelGGL(flat_tile2mx_kernel, grid2, dim3(256), 0, s, t, xmax2, wg_overflow);
+        else if (kind == 1) hipLaunchKernelGGL((flat_tile2_kernel<1>), grid2, dim3(256), 0, s, t, xmax2, wg_overflow);
         else hipLaunchKernelGGL((flat_tile2_kernel<0>), grid2, dim3(256), 0, s, t, xmax2, wg_overflow);
         return hipGetLastError();
     }

@@ -111,6 +111,9 @@ struct hvx_index {
     // bf16 exact scan on the matrix cores (hvx_flat_mfma.hip)
     uint16_t *m_qhi = nullptr, *m_qlo = nullptr;
     uint16_t *m_qhi8 = nullptr;      // fp8 rows: the hi parts again, in the operand order of the 256 x 256 kernel (hvx_flat_tile.hip)
+    unsigned char *m_qmx = nullptr;  // fp8 rows, MX build: [bpad][dim / 64][64 e4m3 hi codes | 64 e4m3 lo codes] (stored order of the rows)
+    uint32_t *m_qexp = nullptr;      // [bpad] E8M0 scale of the hi codes (the lo codes': 4 less)
+    size_t cap_qmx = 0;
     uint16_t *m_shadow = nullptr;    // f32 rows: this handle's view of shared->shadow (set once it is complete)
     std::shared_ptr<hvx_image_shared> shared = std::make_shared<hvx_image_shared>(); // forks share their parent's
     float *m_qn2 = nullptr, *m_rowterm = nullptr; // |q|^2 per query; |x|^2 per row

@@ -1203,6 +1203,26 @@ def test_exact_scan_through_the_role_split_tile_build(orc, hv, dtype_name, metri
     test_exact_scan_through_the_256_tile_kernel(orc, hv, dtype_name, metric, dim, n, k, b, tile_build=2)
 
 
+@pytest.mark.parametrize("dtype_name,metric,dim,n,k,b", [("fp8", 1, 1536, 12000, 10, 130), ("fp8", 0, 128, 20000, 10, 257), ("fp8", 1, 768, 25000, 10, 300),
+                                                         ("fp8", 1, 256, 30000, 25, 64)])
+def test_exact_scan_through_the_mx_fp8_tile_build(orc, hv, dtype_name, metric, dim, n, k, b):
+    """HVX_OPT_FLAT_TILE_BUILD = 3 (round 4): fp8 rows x the query as two e4m3 pieces on v_mfma_scale_f32_32x32x64_f8f6f4 (the
+    query's power-of-two scale in the instruction's block scale, no widening of the codes) -- the same answers as the 128 x 128 kernel
+    (every query) and the oracle; a scan that drops a true neighbour in its filtered epilogue would differ."""
+    test_exact_scan_through_the_256_tile_kernel(orc, hv, dtype_name, metric, dim, n, k, b, tile_build=3)
+
+
+def test_mx_scaled_mfma_operand_layout():
+    """tests/native/mx_probe.hip: the operand layout and the per-row block scale the MX build relies on, on this device."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "native", "_bin", "mx_probe")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "helix-db_amd", "csrc"), "probe"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "test 0: 0 of 1024" in r.stdout and "test 1: 0 of 1024" in r.stdout, r.stdout[-1500:]
+
+
 def test_exact_scan_lanes_share_one_bf16_shadow(orc, hv):
     """Forked handles (execution lanes) of an f32 index scan through ONE bf16 shadow of the rows, whichever lane builds it."""
     rng = np.random.default_rng(77)

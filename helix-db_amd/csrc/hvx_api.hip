@@ -132,7 +132,7 @@ extern "C" int hvx_index_set_option(hvx_index *ix, uint32_t option, uint32_t val
     if (option == HVX_OPT_WAVE_LOG2CAP && value != 0 && (value < 7 || value > 15)) return fail(HVX_ERR_K_RANGE, "visited-table size must be 2^7 .. 2^15 slots");
     if (option == HVX_OPT_FLAT_FIRST_CHUNK && value != 0 && value < 1024) return fail(HVX_ERR_K_RANGE, "the first chunk holds at least 1024 rows");
     if (option == HVX_OPT_HNSW_PAIR && value > 3) return fail(HVX_ERR_K_RANGE, "pair kernel selector is 0 (one query per SIMD handles), 1 (never), 2 (always) or 3 (always, one gatherer)");
-    if (option == HVX_OPT_FLAT_TILE_BUILD && value > 3) return fail(HVX_ERR_K_RANGE, "tile build is 0 (two 256-thread workgroups per CU), 1 (one 512-thread workgroup), 2 (512 threads, role-split) or 3 (fp8 rows: MX-scaled fp8 matrix instructions; other rows: build 0)");
+    if (option == HVX_OPT_FLAT_TILE_BUILD && value > 4) return fail(HVX_ERR_K_RANGE, "tile build is 0 (default: two 256-thread workgroups per CU; fp8 rows on the MX-scaled fp8 matrix instruction), 1 (one 512-thread workgroup), 2 (512 threads, role-split), 3 (as 0) or 4 (as 0 with fp8 codes widened to bf16)");
     if (option == HVX_OPT_FLAT_NO_SMALLB && value > 2) return fail(HVX_ERR_K_RANGE, "small-batch selector is 0 (streaming kernels), 1 (never) or 2 (register-fragment build only)");
     std::lock_guard<std::mutex> lock(ix->mu);
     ix->opt[option] = value;

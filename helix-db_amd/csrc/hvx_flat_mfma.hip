@@ -760,7 +760,8 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
     hipLaunchKernelGGL(split_queries_kernel, dim3(bpad), dim3(64), 0, ix->stream, d_queries, b, bpad, d.dim, ix->m_qhi, ix->m_qlo, ix->m_qn2,
                        f32 ? 2u : (fp8 ? 1u : 0u), fp8 && tile_ok ? ix->m_qhi8 : nullptr);
     HIP_TRY(hipGetLastError());
-    const bool mx_build = fp8 && tile_ok && ix->opt[HVX_OPT_FLAT_TILE_BUILD] == 3u && d.dim % 128u == 0u;
+    // fp8 rows take the MX-scaled fp8 build of the tile kernel unless another build is asked for (4 = the bf16-widening two-workgroup build)
+    const bool mx_build = fp8 && tile_ok && (ix->opt[HVX_OPT_FLAT_TILE_BUILD] == 3u || ix->opt[HVX_OPT_FLAT_TILE_BUILD] == 0u) && d.dim % 128u == 0u;
     if (mx_build) {
         if ((size_t)bpad * d.dim > ix->cap_qmx) {
             if ((rc = ix->regrow((void **)&ix->m_qmx, (size_t)bpad * d.dim * 2))) return rc;
@@ -892,7 +893,8 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
                     if (f32) ta.rows = ix->m_shadow;
                     if (fp8) ta.qhi = ix->m_qhi8;
                     if (mx_build) { ta.qhi = reinterpret_cast<const uint16_t *>(ix->m_qmx); ta.qexp = ix->m_qexp; }
-                    HIP_TRY(launch_flat_tile256(ta, fp8 ? 1 : 0, bpad, ix->m_xmax2, pm.overflow, fp8 || ix->opt[HVX_OPT_FLAT_TILE_BUILD] != 3u ? ix->opt[HVX_OPT_FLAT_TILE_BUILD] : 0u, ix->stream));
+                    const uint32_t tb = ix->opt[HVX_OPT_FLAT_TILE_BUILD];
+                    HIP_TRY(launch_flat_tile256(ta, fp8 ? 1 : 0, bpad, ix->m_xmax2, pm.overflow, mx_build ? 3u : ((tb == 3u || tb == 4u) ? 0u : tb), ix->stream));
                     used_mx |= mx_build;
                     used_tile = true;
                 } else

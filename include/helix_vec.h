@@ -129,8 +129,9 @@ enum hvx_option {
     HVX_OPT_FLAT_NO_TILE = 4,        /* 1: matrix-core scans stay on the 128 x 128 kernel */
     HVX_OPT_FLAT_NO_FILTER = 5,      /* 1: no filtered epilogue (every chunk writes its score matrix) */
     HVX_OPT_FLAT_NO_FAST = 6,        /* 1: start with the full hi + lo split */
-    HVX_OPT_FLAT_TILE_BUILD = 7,     /* large-tile kernel: 0 = two 256-thread workgroups per CU (256 x 128), 1 = one 512-thread (256 x 256), 2 = 512
-                                        threads role-split, 3 = fp8 rows on the MX-scaled fp8 matrix instruction (query as two e4m3 pieces) */
+    HVX_OPT_FLAT_TILE_BUILD = 7,     /* large-tile kernel: 0 = two 256-thread workgroups per CU (256 x 128 tiles), fp8 rows on the MX-scaled fp8
+                                        matrix instruction (query as two e4m3 pieces); 1 = one 512-thread workgroup (256 x 256); 2 = 512 threads
+                                        role-split; 3 = as 0; 4 = as 0 but fp8 codes widened to bf16 (the round-2 build: the A/B switch) */
     HVX_OPT_FLAT_NO_SMALLB = 8,      /* 1: batches of <= 128 queries do not take the one-pass streaming kernels; 2: batches of <= 32 queries stay on
                                         the register-fragment build (rows straight into MFMA operands) instead of the LDS-ring build */
     HVX_OPT_HNSW_PAIR = 9,           /* owner / gatherer kernel (an owner wavefront + 1 or 3 gatherer wavefronts per query): 0 = when the

@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--recall-queries", type=int, default=64)
     ap.add_argument("--tile-builds", default="0", help="comma list of HVX_OPT_FLAT_TILE_BUILD values to time in this process (0 = two 256-thread "
-                    "workgroups per CU, 1 = one 512-thread workgroup, 2 = 512 threads role-split)")
+                    "workgroups per CU (fp8 rows: MX-scaled fp8), 1 = one 512-thread workgroup, 2 = 512 threads role-split, 4 = as 0 with fp8 codes widened to bf16)")
     args = ap.parse_args()
     import pyhvx as hv
     from pyhvx import synth

@@ -1212,6 +1212,12 @@ def test_exact_scan_through_the_mx_fp8_tile_build(orc, hv, dtype_name, metric, d
     test_exact_scan_through_the_256_tile_kernel(orc, hv, dtype_name, metric, dim, n, k, b, tile_build=3)
 
 
+@pytest.mark.parametrize("dtype_name,metric,dim,n,k,b", [("fp8", 1, 1536, 12000, 10, 130), ("fp8", 0, 128, 20000, 10, 257)])
+def test_exact_scan_through_the_bf16_widening_fp8_tile_build(orc, hv, dtype_name, metric, dim, n, k, b):
+    """HVX_OPT_FLAT_TILE_BUILD = 4: fp8 codes widened to bf16 in registers (the default until round 4; the MX build's A/B partner)."""
+    test_exact_scan_through_the_256_tile_kernel(orc, hv, dtype_name, metric, dim, n, k, b, tile_build=4)
+
+
 def test_mx_scaled_mfma_operand_layout():
     """tests/native/mx_probe.hip: the operand layout and the per-row block scale the MX build relies on, on this device."""
     import subprocess

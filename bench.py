@@ -75,7 +75,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--deadline", type=float, default=330.0,
                     help="seconds after which the line is printed with whatever legs have finished (the headline is complete long before; 0 = no deadline)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores (capped at 64)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = the cores this process may use (cgroup quota, else all; capped at 64)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle bit-exactness check")
     ap.add_argument("--metric", default="l2", choices=["l2", "cosine"])
     ap.add_argument("--skip", default="", help="comma list of extra legs to skip: production,batcher,datasets,iso_recall,config3,config4,config5,graph_equivalence")
@@ -674,7 +674,7 @@ def leg_iso_recall(hv, synth, orc, args, dev, dataset, n, dim, b, k, efs=(128, 1
         oix = orc.Index(dim, orc.L2SQ, kernel=orc.K_AVX_FMA_HW, m=args.m, m0=2 * args.m)
         assert oix.seed(gg["node_ids"], st["x"].cpu().numpy(), gg["l0_offsets"], gg["l0_neighbors"], gg["level"], gg["up_offsets"], gg["up_neighbors"],
                         entry_point=gg["entry_point"], max_layer=gg["max_layer"]) == orc.OK
-        threads = args.cpu_threads or min(os.cpu_count() or 1, 64)
+        threads = host_threads(args)
         qh = ls.last_q[0].cpu().numpy()
         oix.search_batch(qh[:64], k, hit["ef_search"], threads=threads)
         t1 = time.perf_counter()
@@ -843,6 +843,24 @@ def leg_graph_equivalence(hv, synth, args, dev, which="embedding"):
 
 
 # ------------------------------------------------------------------------------------------------------------
+def cpu_quota():
+    """CPU cores this process may actually use: the cgroup v2 quota when there is one (the GPU boxes of this pool: cpu.max =
+    "1600000 100000" = 16 cores of 256 logical CPUs -- a 64-thread oracle run is throttled to 16 cores' worth and every thread of
+    the process is frozen for the rest of the 100 ms period when the quota is spent), else the logical CPU count."""
+    n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def host_threads(args):
+    return args.cpu_threads or min(cpu_quota(), 64)
+
+
 def leg_batcher(x_host, q_host, g, m, callers=1024, per_caller=300, lanes=3):
     """SURVEY 8f-4 on the headline corpus and graph: `callers` OS threads each issuing single-query hvx_batcher_search calls in a closed
     loop (the reference's one-search-per-operator-call pattern, access/search/storage.rs:140-163).  The callers are a C++ harness
@@ -916,6 +934,9 @@ def main():
         faulthandler.dump_traceback_later(float(os.environ["BENCH_TRACE"]), repeat=True)
     t_start = time.time()
     args = parse()
+    # torch's CPU helpers (tensor copies, numpy conversions) would start one thread per logical CPU: under a cgroup quota that burst
+    # alone freezes the process for the rest of the scheduler period -- in the middle of a timed section
+    torch.set_num_threads(max(1, min(8, cpu_quota())))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if SHARED_GPU else int(os.environ.get("LOCAL_RANK", "0"))
@@ -1184,7 +1205,7 @@ def main():
             prod = {}
             x_host = x.cpu().numpy()
             q_host = q.cpu().numpy()
-            threads = args.cpu_threads or min(os.cpu_count() or 1, 64)
+            threads = host_threads(args)
             for mname in ("l2", "cosine"):
                 pm = hv.COSINE if mname == "cosine" else hv.EUCLIDEAN
                 if (mname == "cosine") == cosine:
@@ -1256,7 +1277,7 @@ def main():
 
         # ---- CPU baseline + bit-exact verification of the headline ----
         if args.cpu_seconds > 0 or not args.no_verify:
-            threads = args.cpu_threads or min(os.cpu_count() or 1, 64)
+            threads = host_threads(args)
             t0 = time.time()
             if x_host is None:
                 x_host = x.cpu().numpy()
@@ -1283,7 +1304,7 @@ def main():
                 "sample": f"all {b} queries of the same batch, same graph, k={k} ef={ef}; median of {len(rounds)} rounds after a warm-up pass; "
                           f"oracle = C restatement with real AVX2+FMA kernels, data resident in RAM (no storage-engine cost)",
                 "single_thread_us_per_query": round(single * 1e6, 1),
-                "host": f"{os.cpu_count()} logical CPUs"}
+                "host": f"{os.cpu_count()} logical CPUs, cgroup CPU quota {cpu_quota()} cores (threads = the quota: more would only be throttled)"}
             if not args.no_verify:
                 same = True
                 o_dc = sum(s["distance_computations"] for s in o_st)
@@ -1343,7 +1364,7 @@ def main():
                 assert oix.seed(gg["node_ids"], xh, gg["l0_offsets"], gg["l0_neighbors"], gg["level"], gg["up_offsets"], gg["up_neighbors"],
                                 entry_point=gg["entry_point"], max_layer=gg["max_layer"]) == orc.OK
                 qh = st["q"][:128].cpu().numpy()
-                rc, o_ids, o_sc, o_cnt, o_st = oix.search_batch(qh, k, ef, threads=min(os.cpu_count() or 1, 64))
+                rc, o_ids, o_sc, o_cnt, o_st = oix.search_batch(qh, k, ef, threads=host_threads(args))
                 gi = st["ls"].bufs[0][0][:128].cpu().numpy().astype(np.uint64)
                 gs = st["ls"].bufs[0][1][:128].cpu().numpy()
                 r["parity_sample"] = {"queries": 128, "ids_equal_oracle": bool((gi == o_ids).all()),

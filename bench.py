@@ -41,7 +41,7 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-MFMA_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak; fp8 codes are widened to bf16 in registers in front of the MFMA, so this is their peak too
+MFMA_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak; the fp8 scan runs two e4m3 query pieces through the MX-scaled fp8 instruction: quoted against this peak too
 SHARED_GPU = bool(os.environ.get("HVX_BENCH_SHARED_GPU"))  # plumbing check of the N > 1 path on a 1-GPU box (gloo, host staging)
 
 
@@ -610,9 +610,9 @@ def leg_config5(hv, synth, orc, dev, rows, b=4096, k=10, dim=1536):
            "roofline": {"bound": "mfma", "achieved": round(useful / ms / 1e9, 1), "peak": MFMA_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(useful / ms / 1e9 / MFMA_BF16_TFLOPS, 4),
                         "note": "ALGORITHMIC flops 2*b*N*dim / time of the whole scan (contraction + selection + exact re-rank + certificate); "
-                                "fp8 codes are widened to bf16 -- exactly -- in registers in front of the MFMA (non-scaled fp8 MFMA runs at the bf16 rate on gfx950, "
-                                "the MX-scaled K=64 form would need the f32 query in two fp8 pieces: the same matrix-core time), so the bf16 dense peak applies "
-                                "(5 PFLOP/s would be the fp8-MFMA peak: frac_of_fp8_peak below)",
+                                "round 4: the large-tile kernel multiplies the fp8 codes on the MX-scaled fp8 matrix instruction (v_mfma_scale_f32_32x32x64_f8f6f4) "
+                                "with the f32 query carried as TWO e4m3 pieces -- two matrix passes per useful flop, so the fraction stays quoted against the "
+                                "bf16 dense peak (5 PFLOP/s would be the fp8-MFMA peak: frac_of_fp8_peak below)",
                         "frac_of_fp8_peak": round(useful / ms / 1e9 / 5000.0, 4)},
            "hbm_bytes_per_batch": rows * dim, "hbm_bytes_per_batch_note": "SURVEY 8(d): the fp8 codes stream once per batch (query tiles of a "
            "super-tile share the row tile in L2): 19.2 GB at 12.5M x 1536",
@@ -636,7 +636,7 @@ def kernel_of_ef(ef):
     return "general kernel (4 wavefronts per query)"
 
 
-def ef_sweep_rows(ls, qs, ix_truth, dev, dim, b, k, efs, elem=4, steps=12, stop_at=None):
+def ef_sweep_rows(ls, qs, ix_truth, dev, dim, b, k, efs, elem=4, steps=24, stop_at=None):
     """Same graph, same lanes, distinct query batches: one row per beam width (QPS, recall against the exact scan, distance
     evaluations, fraction of the HBM peak from the algorithmic bytes of lane 0's last batch)."""
     rows = []
@@ -663,7 +663,7 @@ def leg_iso_recall(hv, synth, orc, args, dev, dataset, n, dim, b, k, efs=(128, 1
     """The metric is QPS @ recall@10 >= 0.95: on a corpus where ef = 128 misses the gate, sweep ef (scale_contracts.rs:167-215
     protocol: same graph, same queries, recall against the exact scan) and report the smallest beam that clears it -- its QPS,
     roofline fraction and the CPU oracle at the same ef."""
-    res0, st = hnsw_leg(hv, synth, args, dev, dataset, n, dim, b, k, efs[0], steps=12, keep=True)
+    res0, st = hnsw_leg(hv, synth, args, dev, dataset, n, dim, b, k, efs[0], steps=32, keep=True)  # (32: eight rounds of the four lanes -- 12 left the first and the last round half alone)
     ls, ix_truth = st["ls"], st["ix_truth"]
     sweep = ef_sweep_rows(ls, st["qs"], ix_truth, dev, dim, b, k, efs, stop_at=target)
     hit = dict(sweep[-1]) if sweep and sweep[-1]["recall_at_10"] >= target else None
@@ -1356,7 +1356,7 @@ def main():
             out["config3_prefilter"] = guarded("config3", lambda: leg_config3(hv, synth, orc, args, dev))
         if "config4" not in skip:
             def c4():
-                r, st = hnsw_leg(hv, synth, args, dev, "embedding", args.c4_rows, dim, b, k, ef, dtype_name="bf16", steps=int(os.environ.get("C4_STEPS", 30)), keep=True)
+                r, st = hnsw_leg(hv, synth, args, dev, "embedding", args.c4_rows, dim, b, k, ef, dtype_name="bf16", steps=int(os.environ.get("C4_STEPS", 32)), keep=True)
                 # parity on a sample: the oracle over the same rounded rows and graph
                 xh = st["x"].cpu().numpy()
                 gg = st["g"]
@@ -1394,7 +1394,7 @@ def main():
                     ds[name] = iso.pop("leg_at_first_ef", iso)
                     ds["clustered_iso_recall"] = iso
                     continue
-                ds[name] = guarded(f"dataset {name}", lambda: hnsw_leg(hv, synth, args, dev, name, args.rows, dim, b, k, ef, steps=30)[0])
+                ds[name] = guarded(f"dataset {name}", lambda: hnsw_leg(hv, synth, args, dev, name, args.rows, dim, b, k, ef, steps=32)[0])
             ds["note"] = ("headline = 'embedding' (low intrinsic dimension, recall >= 0.95); 'clustered' = SURVEY 8(d)'s stated variant "
                           "(1 024 Gaussian centres, sigma 0.15, native 768-d: inside a cluster the rows are i.i.d. Gaussian again); 'gaussian' = "
                           "8(d) as literally written, a stated worst case: distance concentration at 768-d leaves no neighbour structure, so "

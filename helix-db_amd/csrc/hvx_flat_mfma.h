@@ -58,19 +58,22 @@ __host__ __device__ inline uint32_t tile_slot_fp8(uint32_t slot) {
 #if defined(__HIPCC__)
 // histogram increment with the wavefront's most common digits combined first: approximate scores of one query share their
 // leading bytes, and 64 lanes adding to ONE LDS word serialise (measured: the four selection rounds of a 4 096-score slice cost
-// 26 us with per-lane atomics alone, the rest of the kernel 12).  Two rounds of "the first active lane's digit: one add for all
-// lanes holding it", then per-lane adds for whatever is left (digits that differ lane by lane do not collide).
+// 26 us with per-lane atomics alone, the rest of the kernel 12; two fixed rounds of combining still left 40-70 us kernels on the
+// topic-ordered C3 corpus, whose scores share three bytes).
 __device__ __forceinline__ void radix_count(uint32_t *hist, bool active, uint32_t digit) {
-#pragma unroll
-    for (int round = 0; round < 2; ++round) {
+    // groups of equal digits are taken out one at a time (the first active lane's digit: one add for all lanes holding it) for as long
+    // as they are big -- a group of fewer than four lanes says the digits are spread, and spread digits do not collide
+    for (int round = 0; round < 12; ++round) {
         const unsigned long long todo = __ballot(active);
         if (!todo) return;
+        if (__builtin_popcountll(todo) < 6) break;
         const int leader = __builtin_ctzll(todo);
         const uint32_t pivot = (uint32_t)__shfl((int)digit, leader, 64);
         const bool same = active && digit == pivot;
         const unsigned long long votes = __ballot(same);
         if ((int)(threadIdx.x & 63u) == leader) atomicAdd(&hist[pivot], (uint32_t)__builtin_popcountll(votes));
         active = active && !same;
+        if (__builtin_popcountll(votes) < 4) break;
     }
     if (active) atomicAdd(&hist[digit], 1u);
 }

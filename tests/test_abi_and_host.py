@@ -329,6 +329,36 @@ def test_inline_asm_lds_reads_are_covered_by_a_wait(tmp_path):
         assert lint.stdout.count(": 0 hazard(s)") == want, lint.stdout    # fp8 + bf16 instantiations of each kernel (tile4: with and without interleaved copies)
 
 
+def test_asm_lint_flags_an_inline_asm_read_inside_a_matrix_write_back_window(tmp_path):
+    """Round 4: the ring build of the small-batch scan stores its accumulators with inline-asm ds_write_b32; the compiler's hazard
+    recogniser does not see an asm statement read a register, so it pads nothing between the last v_mfma and the store, and acc[0]
+    reached the LDS one MFMA step short (found on hardware by tests/native/smallq_probe.hip).  The lint's second rule fails such
+    assembly; the shipped kernels (ring build, MX tile build) pass both rules."""
+    import shutil
+    import subprocess
+    lint = os.path.join(ROOT, "scripts", "lint_asm_lds.py")
+    body = ("toy_kernel:\n\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_32x32x16_bf16 v[0:15], v[34:37], v[16:19], v[0:15]\n\ts_cbranch_vccz .LBB0_2\n"
+            "\t;;#ASMSTART\n\tds_write_b32 v148, v0\n\t;;#ASMEND\n.LBB0_2:\n%s\t;;#ASMSTART\n\tds_write_b32 v148, v1\n\t;;#ASMEND\n\ts_endpgm\n")
+    bad = tmp_path / "bad.s"
+    bad.write_text(body % "")
+    r = subprocess.run([sys.executable, lint, str(bad), "toy_kernel"], capture_output=True, text=True)
+    assert r.returncode == 1 and "2 inline-asm read(s)" in r.stdout, r.stdout          # both stores, on both paths into .LBB0_2
+    good = tmp_path / "good.s"
+    good.write_text((body % "\ts_nop 15\n\ts_nop 7\n").replace("\tds_write_b32 v148, v0\n", "\ts_nop 15\n\ts_nop 7\n\tds_write_b32 v148, v0\n"))
+    r = subprocess.run([sys.executable, lint, str(good), "toy_kernel"], capture_output=True, text=True)
+    assert r.returncode == 0 and "0 inline-asm read(s)" in r.stdout, r.stdout
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    for src_name, kernels, want in (("hvx_flat_smallb.hip", ["flat_smallq_kernel"], 16), ("hvx_flat_tile.hip", ["flat_tile2mx_kernel"], 1)):
+        asm = tmp_path / (src_name + ".s")
+        out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S", "--cuda-device-only", "-o", str(asm),
+                              os.path.join(ROOT, "helix-db_amd", "csrc", src_name)], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        r = subprocess.run([sys.executable, lint, str(asm)] + kernels, capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.count(": 0 hazard(s), 0 inline-asm read(s)") == want, r.stdout
+
+
 def test_link_workgroup_kernel_takes_its_row_locks_without_cache_maintenance(tmp_path):
     """Round 3: an acquire / release at agent scope is an L2 invalidate / write-back of the whole XCD on gfx950 (`buffer_inv sc1` /
     `buffer_wbl2 sc1`); with one per lock operation the batched link step of the device build spent 60 % of its time in them

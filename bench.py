@@ -642,6 +642,8 @@ def ef_sweep_rows(ls, qs, ix_truth, dev, dim, b, k, efs, elem=4, steps=24, stop_
     rows = []
     for ef in efs:
         elapsed, span, kms = timed_steps(ls, qs, ef, steps, 3, lambda: None)
+        if elapsed * 1e3 > 1.3 * span:  # a host stall inside the timed steps (this pool freezes a process that spends its CPU quota):
+            elapsed, span, kms = timed_steps(ls, qs, ef, steps, 3, lambda: None)  # the wall clock of one repeat is what the row reports
         q = ls.last_q[0]
         f = out_buffers(b, k, dev)
         ix_truth.flat_search_batch_device(q, k, *f[:4])

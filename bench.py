@@ -35,7 +35,8 @@ for p in (os.path.join(ROOT, "helix-db_amd"), os.path.join(ROOT, "oracle")):
 
 # HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); lanes that share one run back to back.
 # A serving host with several lanes raises it before the runtime starts; so does this harness.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if not os.environ.get("HVX_BENCH_NO_HWQ"):  # (HVX_BENCH_NO_HWQ=1: leave it to the library's own default -- the A/B of INTEGRATION 3c)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
 import torch
@@ -944,6 +945,9 @@ def main():
     local_rank = 0 if SHARED_GPU else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world == 1 and args.gpus > 1:
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if os.environ.get("HVX_BENCH_NO_HWQ"):  # the library's load-time default must be in place before the HIP runtime initialises
+        import pyhvx
+        pyhvx.lib()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
     torch.cuda.set_device(local_rank)

@@ -126,6 +126,14 @@ extern "C" int hvx_index_set_occupancy(hvx_index *ix, uint32_t queries_per_simd)
     return HVX_OK;
 }
 
+// The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order, and two
+// execution lanes that land on one queue run their kernels back to back (r03: 0.65 -> 0.44 ms per step on the bf16 leg once its lanes
+// had queues of their own).  A host with lanes + other handles + its own copy streams needs more than four; the runtime reads the
+// variable when it initialises, i.e. after this library has been loaded by a host that links it (a Rust cdylib, a cgo package) or
+// loads it before its first HIP call.  The library raises the DEFAULT to 8 and leaves a value the host has chosen alone.  (It still
+// reads no environment: this is the one variable it writes.)
+__attribute__((constructor)) static void hvx_default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0); }
+
 extern "C" int hvx_index_set_option(hvx_index *ix, uint32_t option, uint32_t value) {
     if (!ix) return fail(HVX_ERR_INVARIANT, "null index");
     if (option >= HVX_OPT_COUNT) return fail(HVX_ERR_INVARIANT, "unknown option %u", option);

@@ -384,6 +384,27 @@ def test_link_workgroup_kernel_takes_its_row_locks_without_cache_maintenance(tmp
         assert seg and int(seg.group(1)) <= 64, (name, seg.group(0) if seg else None)   # a handful of spilled dwords at most
 
 
+def test_library_raises_the_default_hardware_queue_count_and_respects_the_hosts_choice():
+    """HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); execution lanes that share one run back to
+    back (profiles/r04t_hw_queues_library_default.log: 0.69 instead of 0.80 of HBM on the headline, 0.51 instead of 0.67 on the bf16
+    leg).  Loading the library sets the variable to 8 when the host has not set it -- before the runtime initialises for a host that
+    links the library -- and leaves a host's value alone."""
+    import subprocess
+    lib = os.path.join(ROOT, "helix-db_amd", "libhelix_vec_gfx950.so")
+    if not os.path.exists(lib):
+        pytest.skip("library not built")
+    code = ("import ctypes, os, sys\n"
+            "v = sys.argv[2]\n"
+            "os.environ.pop('GPU_MAX_HW_QUEUES', None)\n"
+            "if v: os.environ['GPU_MAX_HW_QUEUES'] = v\n"
+            "ctypes.CDLL(sys.argv[1])\n"
+            "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p\n"
+            "print(libc.getenv(b'GPU_MAX_HW_QUEUES').decode())\n")
+    for preset, want in (("", "8"), ("4", "4"), ("16", "16")):
+        r = subprocess.run([sys.executable, "-c", code, lib, preset], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and r.stdout.strip() == want, (preset, r.stdout, r.stderr[-300:])
+
+
 def test_release_library_reads_no_environment_and_carries_no_measurement_code():
     """tuning switches (kernel ablation -- results wrong by construction --, phase profiling, experimental tile
     builds, stderr path reports) exist only in `make TUNING=1` builds.  The shipped library does not import getenv, holds none

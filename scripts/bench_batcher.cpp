@@ -119,7 +119,8 @@ int main(int argc, char **argv) {
     const uint32_t wait_us = e_wait ? (uint32_t)atoi(e_wait) : 100u;
     if (e_occ && hvx_index_set_occupancy(ix, (uint32_t)atoi(e_occ))) { fprintf(stderr, "%s\n", hvx_last_error()); return 1; }
     if (e_pair && hvx_index_set_option(ix, HVX_OPT_HNSW_PAIR, (uint32_t)atoi(e_pair))) { fprintf(stderr, "%s\n", hvx_last_error()); return 1; }
-    if (hvx_batcher_new_lanes(ix, &p, 1024, wait_us, lanes, &bt)) { fprintf(stderr, "%s\n", hvx_last_error()); return 1; }
+    const char *e_maxb = getenv("BATCHER_MAXB"); // (default 1 024 = the index's max_batch; small values exercise full batches and void claims)
+    if (hvx_batcher_new_lanes(ix, &p, e_maxb ? (uint32_t)atoi(e_maxb) : 1024u, wait_us, lanes, &bt)) { fprintf(stderr, "%s\n", hvx_last_error()); return 1; }
     run(bt, &q1, &m1, &p1);
     unsigned long long cg0[3], cg1[3];
     cgroup(cg0);

@@ -67,6 +67,8 @@ inline void futex_wake(std::atomic<uint32_t> *addr, int n) {
     syscall(SYS_futex, reinterpret_cast<uint32_t *>(addr), FUTEX_WAKE_PRIVATE, n, nullptr, nullptr, 0);
 }
 
+constexpr uint64_t kStampMask = (1ull << 44) - 1;
+inline uint64_t now_us_stamp() { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() & kStampMask; }
 inline int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 inline void cpu_pause() { __builtin_ia32_pause(); }
 inline void sleep_us(long us) {
@@ -83,7 +85,10 @@ struct Batch {
     uint64_t *dev_ids = nullptr;   // the same four arrays as the device addresses them (hipHostGetDevicePointer)
     float *dev_sc = nullptr;
     uint32_t *dev_cnt = nullptr, *dev_st = nullptr;
-    std::atomic<int64_t> t_first{0}; // steady-clock ns of the open batch's first claim (written by the caller of slot 0)
+    // when the open batch got its first query: (sequence & 0xFFFFF) << 44 | steady-clock microseconds, written by the caller of slot 0.
+    // The tag says WHICH batch the stamp belongs to -- nobody resets the word (a reset by a lane that lost the race for the close could
+    // land after the next batch's first caller had stamped it, and a lane that finds no stamp would wait for its count for ever)
+    std::atomic<uint64_t> t_first{0};
     // cumulative over every batch this buffer has carried (never reset: a reset could race with the first callers of the
     // next batch); batches of one buffer are strictly sequential, so "all of them" is always "the previous ones + this one"
     // `filled` / `consumed` live in the groups below (slot % kGroups), one cache line each: a counter every caller of a batch adds
@@ -151,6 +156,15 @@ struct hvx_batcher {
         (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0); // this thread's timed sleeps end within ~1 us of their time (default slack: 50 us)
         const int64_t max_wait_ns = (int64_t)(max_wait_us ? max_wait_us : 200u) * 1000;
         uint32_t expect = 1; // queries the open batch should hold before this lane takes it: the size of the lane's previous batch
+        uint64_t seen_seq = ~0ull, seen_us = 0; // when THIS lane first saw the open batch non-empty (the fallback age base)
+        // microseconds the open batch's first query has waited: by its caller's stamp when it carries this batch's tag, else since
+        // this lane first saw the batch (a stamp is missing only for the instant between a claim and its store)
+        auto waited_us = [&](uint64_t seq) -> int64_t {
+            const uint64_t now = now_us_stamp(), tf = bufs[seq % nbuf].t_first.load(std::memory_order_relaxed);
+            if (seen_seq != seq) { seen_seq = seq; seen_us = now; }
+            const uint64_t base = (tf >> 44) == (seq & 0xFFFFFull) ? (tf & kStampMask) : seen_us;
+            return (int64_t)((now - base) & kStampMask);
+        };
         int64_t t_mark = now_ns();
         auto lap = [&](std::atomic<uint64_t> &acc) { const int64_t t = now_ns(); acc.fetch_add((uint64_t)(t - t_mark), std::memory_order_relaxed); t_mark = t; };
         for (;;) {
@@ -171,8 +185,7 @@ struct hvx_batcher {
             // queries as that batch did (a caller rings the bell at that count), is full, or its first query has waited max_wait_us
             const uint32_t need = expect < max_batch ? expect : max_batch;
             if (cnt < need && !stop.load()) {
-                const int64_t t0 = bufs[seq % nbuf].t_first.load(std::memory_order_relaxed), t = now_ns();
-                const int64_t left = t0 ? max_wait_ns - (t - t0) : max_wait_ns;
+                const int64_t left = max_wait_ns - waited_us(seq) * 1000;
                 if (left > 2000) {
                     const uint32_t b0 = bell.load();
                     target.store(need);
@@ -184,8 +197,7 @@ struct hvx_batcher {
                     const uint64_t s3 = state.load();
                     if ((s3 >> kSeqShift) != seq) continue; // another lane took it
                     const uint32_t c3 = std::min<uint32_t>((uint32_t)(s3 & kCountMask), max_batch);
-                    const int64_t tf = bufs[seq % nbuf].t_first.load(std::memory_order_relaxed);
-                    if (c3 < need && !(tf && now_ns() - tf >= max_wait_ns) && !stop.load()) continue; // woken for something else: look again
+                    if (c3 < need && waited_us(seq) * 1000 < max_wait_ns && !stop.load()) continue; // woken for something else: look again
                     s = s3;
                     cnt = c3;
                 }
@@ -200,7 +212,6 @@ struct hvx_batcher {
                     continue;
                 }
             }
-            next.t_first.store(0, std::memory_order_relaxed);
             if (!state.compare_exchange_strong(s, (seq + 1) << kSeqShift)) continue; // another claim or another lane won
             seq_word.store((uint32_t)(seq + 1));
             // callers that found the batch full: as many as the new batch has slots (FIFO).  Waking them all made every close a
@@ -395,7 +406,7 @@ static int batcher_search_inner(hvx_batcher *b, const float *query, uint64_t *ou
         futex_wait(&b->seq_word, (uint32_t)seq, 2000);
     }
     Batch &bt = b->bufs[seq % b->nbuf];
-    if (slot == 0) bt.t_first.store(now_ns(), std::memory_order_relaxed);
+    if (slot == 0) bt.t_first.store(((seq & 0xFFFFFull) << 44) | now_us_stamp(), std::memory_order_relaxed);
     memcpy(bt.q + (size_t)slot * b->dim, query, (size_t)b->dim * 4);
     bt.grp[slot % Batch::kGroups].filled.fetch_add(1);
     if ((slot == 0 || slot + 1 == b->max_batch || slot + 1 == b->target.load()) && b->sleepers.load()) { // first / last query of a batch, or the count a waiting lane asked for

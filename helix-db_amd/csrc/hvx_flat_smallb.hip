@@ -7,14 +7,18 @@
 // they pad the batch to their query tile, stage both operands through LDS behind barriers, and the filtered pipeline
 // around them needs 8-10 launches -- 0.10 of the HBM roofline on the 100 000-candidate group.
 //
-// This kernel: one wavefront owns 32 candidate rows at a time and keeps them in REGISTERS -- lane l reads 8 consecutive
+// Two builds of the candidate kernel (launch_flat_smallb picks): the LDS-RING build further down (round 4, batches of <= 32 queries:
+// rows through per-wavefront rings of whole 128-byte lines, queries in registers) and the REGISTER-FRAGMENT build (round 3, up to
+// 128 queries and every shape the ring build does not serve), followed by the sort-free selection both share.
+//
+// The register-fragment build: one wavefront owns 32 candidate rows at a time and keeps them in REGISTERS -- lane l reads 8 consecutive
 // stored elements of row (l & 31), depth half (l >> 5), which is exactly the B-operand layout of v_mfma_f32_32x32x16_bf16
 // (f32 rows are rounded to bf16 in registers: the one-pass contraction's rounding, covered by the certificate's bound);
 // the queries (bf16 hi parts, <= 4 tiles of 32) sit in LDS once per workgroup, padded so that the A-operand
 // ds_read_b128 is conflict-free.  No barrier after the query tile is staged, no LDS traffic for the rows, the next group
 // of row loads is issued before the current group's MFMAs.  16 wavefronts per CU x 8-16 KB in flight each.  The epilogue
 // writes the [b][candidates] score matrix (b x 4 bytes per row against dim x 4 bytes read: 2 % at b = 32, dim = 1536).
-// Selection (flat_select_slices: grid b x S), merge, exact re-rank and certificate are the scan's usual tail.
+// Selection (flat_select_radix_kernel below: four 8-bit radix rounds per 4 096-score slice), exact re-rank and certificate follow.
 // Algorithmic bytes per launch = candidates x dim x sizeof(row element).
 #include <hip/hip_runtime.h>
 

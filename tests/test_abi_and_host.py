@@ -220,7 +220,7 @@ def test_struct_layouts_of_the_header_and_the_ctypes_mirrors_agree(tmp_path):
     pairs = [("hvx_index_desc", hv._Desc), ("hvx_stats", hv.Stats), ("hvx_query_stats", hv.QueryStats), ("hvx_search_params", hv._Params),
              ("hvx_simhash_config", hv.SimHashConfig), ("hvx_adaptive_stats", hv.AdaptiveStats), ("hvx_restricted_params", hv.RestrictedParams),
              ("hvx_restricted_stats", hv.RestrictedStats), ("hvx_index_metadata", hv.IndexMetadata), ("hvx_build_params", hv.BuildParams),
-             ("hvx_build_stats", hv.BuildStats), ("hvx_graph_audit", hv.GraphAudit)]
+             ("hvx_build_stats", hv.BuildStats), ("hvx_graph_audit", hv.GraphAudit), ("hvx_batcher_times", hv.BatcherTimes)]
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include "helix_vec.h"\nint main(void) {\n' +
                    "".join('  printf("%s %%zu\\n", sizeof(%s));\n' % (n, n) for n, _ in pairs) + "  return 0;\n}\n")
@@ -230,6 +230,44 @@ def test_struct_layouts_of_the_header_and_the_ctypes_mirrors_agree(tmp_path):
     got = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True).stdout.splitlines())
     for name, mirror in pairs:
         assert int(got[name]) == C.sizeof(mirror), (name, got[name], C.sizeof(mirror))
+
+
+def test_bench_sizes_its_cpu_work_to_the_cgroup_quota(tmp_path, monkeypatch):
+    """bench.py's oracle legs and torch's helper threads follow the process's CPU quota (cgroup v2 cpu.max), not the logical CPU count:
+    the GPU boxes give 16 of 256 CPUs, and a 64-thread run was throttled -- sometimes inside a timed section -- and reported a
+    baseline of a quarter of what 16 threads reach."""
+    import builtins
+    sys.path.insert(0, ROOT)
+    import bench
+    real_open = builtins.open
+
+    def fake(content):
+        def _open(path, *a, **k):
+            if path == "/sys/fs/cgroup/cpu.max":
+                if content is None:
+                    raise FileNotFoundError(path)
+                f = tmp_path / "cpu.max"
+                f.write_text(content)
+                return real_open(f, *a, **k)
+            return real_open(path, *a, **k)
+        return _open
+
+    monkeypatch.setattr(os, "cpu_count", lambda: 256)
+    monkeypatch.setattr(builtins, "open", fake("1600000 100000\n"))
+    assert bench.cpu_quota() == 16
+    monkeypatch.setattr(builtins, "open", fake("max 100000\n"))
+    assert bench.cpu_quota() == 256
+    monkeypatch.setattr(builtins, "open", fake("50000 100000\n"))
+    assert bench.cpu_quota() == 1
+    monkeypatch.setattr(builtins, "open", fake(None))
+    assert bench.cpu_quota() == 256
+
+    class A:
+        cpu_threads = 0
+    monkeypatch.setattr(builtins, "open", fake("12800000 100000\n"))
+    assert bench.host_threads(A) == 64          # capped
+    A.cpu_threads = 5
+    assert bench.host_threads(A) == 5
 
 
 def test_bench_deadline_prints_the_line_and_ends_the_process():

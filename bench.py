@@ -3,7 +3,9 @@
 
 One "step" = one pass of the hot path over one batch of 1024 synthetic queries (config #2:
 1M x 768 f32, HNSW M=16/M0=32, ef_search=128, k=10) with index AND queries already resident in HBM.
-Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0 -- the LAST line of stdout, a
+compact record (< 4 KB, strict JSON: metric / value / config / roofline / cpu_baseline / parity + one-line summaries of the other
+legs).  Everything else every leg measured goes to `bench_full.json` next to this file (path in the line's `full_record`).
 
 Steps are issued round-robin on `--lanes` execution lanes (hvx_index_fork: same index image, own stream + scratch), so
 that consecutive batches overlap on the device -- the way a serving host keeps the device fed: a batch that is still
@@ -54,8 +56,8 @@ def log(*a):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rows", type=int, default=1_000_000, help="rows per GPU shard (weak mode) / in total (strong mode)")
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--batch", type=int, default=1024)
@@ -79,7 +81,12 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = the cores this process may use (cgroup quota, else all; capped at 64)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle bit-exactness check")
     ap.add_argument("--metric", default="l2", choices=["l2", "cosine"])
-    ap.add_argument("--skip", default="", help="comma list of extra legs to skip: production,batcher,datasets,iso_recall,config3,config4,config5,graph_equivalence")
+    ap.add_argument("--skip", default="", help="comma list of extra legs to skip: production,production_lanes,batcher,datasets,iso_recall,config3,config4,config5,"
+                                               "graph_equivalence,ef_sweep,peak,vendor_gemm")
+    ap.add_argument("--full-record", default=os.path.join(ROOT, "bench_full.json"), help="where the full record of every leg is written")
+    ap.add_argument("--c3-corpus", default="clustered", choices=["clustered", "topic_ordered"],
+                    help="configs[2] stand-in rows when HELIX_DBPEDIA_1M_FBIN is unset: 'clustered' = SURVEY 8(d) as written (1 024 Gaussian centres, "
+                         "sigma 0.15, seed 20260923, id-order build); 'topic_ordered' = round 4's fitted corpus (scattered insertion order)")
     ap.add_argument("--c5-rows", type=int, default=12_500_000, help="config #5 per-GPU shard (100M / 8)")
     ap.add_argument("--c4-rows", type=int, default=1_250_000, help="config #4 per-GPU shard (10M / 8)")
     ap.add_argument("--builder", default="device", choices=["device", "bulk"], help="how the benchmark graph is built")
@@ -186,6 +193,7 @@ class LaneSet:
         self.groups = None   # C-ABI shard groups (in-library RCCL exchange), one per lane
         self.merged = None
         self.last_q = [None] * len(self.handles)  # the query batch of every lane's last step (what its buffers hold the answer to)
+        self.params = None  # hv.SearchParams: the steps run hvx_search_batch_params_device (the non-strict arms) instead of the strict call
 
     def use_shard_groups(self, hv, dist, rank, world):
         """One hvx_shard_group (own RCCL communicator) per lane; the 128-byte unique ids travel over torch.distributed."""
@@ -207,6 +215,9 @@ class LaneSet:
             self.groups[l].search_batch_device(q, self.k, ef, m[0], m[1], m[2])
             return
         ids, sc, cnt, st, qst = self.bufs[l]
+        if self.params is not None:
+            self.handles[l].search_batch_params_device(q, self.params, ids, sc, cnt, st, qst, None)
+            return
         self.handles[l].search_batch_device(q, self.k, ef, ids, sc, cnt, st, qst, want_stats=False)
         if self.sharded:
             with torch.cuda.stream(self.streams[l]):
@@ -346,7 +357,7 @@ def hnsw_leg(hv, synth, args, dev, dataset, n, dim, b, k, ef, dtype_name="f32", 
 C3_FBIN_ENV = "HELIX_DBPEDIA_1M_FBIN"   # the reference's own variable (index_lifecycle_scale.rs:497-534)
 
 
-def c3_corpus(synth, n, dim, dev):
+def c3_corpus(synth, n, dim, dev, kind="clustered"):
     """The rows of the configs[2] leg: the DBpedia-1M fbin when HELIX_DBPEDIA_1M_FBIN points at one (header <u32 n><u32 dim> LE +
     f32 rows, validated like the reference's loader), else the synthetic stand-in."""
     path = os.environ.get(C3_FBIN_ENV)
@@ -357,8 +368,11 @@ def c3_corpus(synth, n, dim, dev):
         for r0 in range(0, n, step):
             x[r0:r0 + step] = torch.from_numpy(np.ascontiguousarray(rows[r0:r0 + step])).to(dev)
         return x, f"DBpedia-1M fbin {path}"
-    x, _ = synth.corpus("topic_ordered", n, dim, 1, 20260923, dev, **C3_STANDIN)
-    return x, "synthetic stand-in: synth.topic_ordered(%s)" % ", ".join(f"{k_}={v_}" for k_, v_ in C3_STANDIN.items())
+    if kind == "topic_ordered":  # round 4's fitted corpus, kept for comparison only (no weight as gate evidence)
+        x, _ = synth.corpus("topic_ordered", n, dim, 1, 20260923, dev, **C3_STANDIN)
+        return x, "synthetic stand-in (fitted, round 4): synth.topic_ordered(%s)" % ", ".join(f"{k_}={v_}" for k_, v_ in C3_STANDIN.items())
+    x, _ = synth.corpus("clustered", n, dim, 1, 20260923, dev, centres=1024, sigma=0.15)
+    return x, "synthetic stand-in, SURVEY 8(d) as written: clustered (1 024 Gaussian centres, sigma 0.15), seed 20260923"
 
 
 C3_STANDIN = dict(latent=12, clusters=2048, spread=0.6)
@@ -371,13 +385,15 @@ def leg_config3(hv, synth, orc, args, dev, k=10, nq=32, rounds=5):
     `planned` = the reference's execution plan (exact scan <= 256 ids, the filter-aware walk above: what the reference runs,
     gate distance_computations <= 800 per query, :1924-1927) and `exact` = the device's exact gathered scan of every candidate."""
     n, dim, ef = 1_000_000, 1536, 100
-    x, corpus_name = c3_corpus(synth, n, dim, dev)
+    x, corpus_name = c3_corpus(synth, n, dim, dev, args.c3_corpus)
+    real_fbin = bool(os.environ.get(C3_FBIN_ENV))
+    scatter = (args.c3_corpus == "topic_ordered") and not real_fbin  # 8(d) / the reference: rows are inserted in id order
     torch.cuda.synchronize()
     t0 = time.time()
     lv = synth.draw_levels(n, 16, 11)
     ix, bst = hv.ValidatedVectorReadIndex.build(dim=dim, metric=hv.EUCLIDEAN, node_ids=np.arange(n, dtype=np.uint64), vectors=x, levels=lv,
                                                 m=16, m0=32, ef_construction=200, max_batch=args.build_batch, batch_divisor=32,
-                                                device=dev.index, search_max_batch=nq, scatter=True)
+                                                device=dev.index, search_max_batch=nq, scatter=scatter)
     ix.sync()
     t_build = time.time() - t0
     audit = graph_audit(ix, 16)
@@ -488,15 +504,15 @@ def leg_config3(hv, synth, orc, args, dev, k=10, nq=32, rounds=5):
                        "exact": exact})
     big = groups[-1]
     out = {"workload": f"configs[2]: {n}x{dim} f32 [{corpus_name}], Euclidean, HNSW M=16/M0=32/efC=200 "
-                       f"(device build in scattered insertion order, {t_build:.1f} s), benchmark topology i -> i+N/2, one-hop where_() group -> restricted kNN k={k} ef={ef}, "
+                       f"(device build, {'scattered' if scatter else 'id-order'} insertion, {t_build:.1f} s), benchmark topology i -> i+N/2, one-hop where_() group -> restricted kNN k={k} ef={ef}, "
                        f"{nq} queries per batch, fused hvx_prefilter_search_batch[_params]",
-           "corpus": {"rows": corpus_name, "fbin_env": C3_FBIN_ENV,
-                      "why_topic_ordered": "the benchmark's candidate sets are CONTIGUOUS id ranges (index_lifecycle_scale.rs:592-613) and its recall gate "
-                                           "(>= 0.92 per group, :2001-2011) is reachable under the walk's budgets (<= 800 scored rows, <= 1 200 bridge rows) only "
-                                           "when a contiguous range is topically local -- rows in the order of a dump sorted by its source; with ids assigned at "
-                                           "random the same algorithm scores ~90 of 1 000 candidates before its bridge budget ends it (recall 0.5; r04e sweep, "
-                                           "CPU oracle study in DESIGN 5)"},
-           "reference_gates_passed": bool(all(g_["planned"]["reference_gates"]["passed"] for g_ in groups)),
+           "corpus": {"rows": corpus_name, "kind": ("dbpedia_fbin" if real_fbin else args.c3_corpus), "fbin_env": C3_FBIN_ENV,
+                      "insertion_order": "scattered" if scatter else "id order (as the reference's backfill inserts)",
+                      "note": "the DBpedia-1M fbin cannot be fetched here (scripts/prepare-dbpedia-vector-fixture.py:17-19); on a synthetic stand-in the "
+                              "reference's recall gate (>= 0.92 per group) is reported as measured, pass or fail -- it says how the ALGORITHM behaves on "
+                              "these rows (device == oracle bit for bit), not whether the reference's gate holds on DBpedia"},
+           "reference_gates_passed": (bool(all(g_["planned"]["reference_gates"]["passed"] for g_ in groups)) if real_fbin else None),
+           "gates_on_this_corpus": [{"candidates": g_["candidates"], **g_["planned"]["reference_gates"]} for g_ in groups],
            "graph_audit": audit,
            "strategies": "planned = the reference's plan (restricted.rs:426-453: exact <= 256 ids, filter-aware walk above, 150 % beam); "
                          "exact = the device's exact gathered scan of every candidate row (recall 1.0 by construction)",
@@ -627,6 +643,60 @@ def leg_config5(hv, synth, orc, dev, rows, b=4096, k=10, dim=1536):
     del x, q
     torch.cuda.empty_cache()
     return out
+
+
+def leg_vendor_gemm(dev):
+    """BASELINE.md section 2 / VERDICT r4 #3(a): what the vendor library gets on THIS box for the dense contraction at the heart of the
+    exact scan -- a (queries x dim) x (dim x rows) GEMM of one row chunk -- bf16 (torch.matmul -> hipBLASLt / rocBLAS) and fp8-e4m3
+    (torch._scaled_mm -> hipBLASLt).  Harness only: the product's scan kernels are hand-written (csrc/hvx_flat_tile.hip); this is the
+    number they are held against.  The scan does more than the GEMM (epilogue with per-row terms, threshold filter, selection, exact
+    re-rank, certificate), so the GEMM rate is an upper bound for it."""
+    res = {}
+    try:
+        torch.backends.cuda.preferred_blas_library("hipblaslt")
+    except Exception:
+        pass
+
+    def time_it(fn, flops, iters=10):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        return {"ms": round(ms, 4), "tflops": round(flops / ms / 1e9, 1)}
+
+    for name, (m, n, kk) in (("c5_shape_4096x32768x1536", (4096, 32768, 1536)), ("c2_shape_1024x65536x768", (1024, 65536, 768))):
+        flops = 2.0 * m * n * kk
+        a = torch.randn(m, kk, device=dev, dtype=torch.float32)
+        bm = torch.randn(n, kk, device=dev, dtype=torch.float32)
+        row = {"m_queries": m, "n_rows": n, "k_dim": kk}
+        try:
+            a16, b16 = a.to(torch.bfloat16), bm.to(torch.bfloat16)
+            row["bf16"] = time_it(lambda: torch.matmul(a16, b16.t()), flops)
+            row["bf16"]["frac_of_bf16_peak"] = round(row["bf16"]["tflops"] / MFMA_BF16_TFLOPS, 4)
+        except Exception as e:
+            row["bf16"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        try:
+            f8 = torch.float8_e4m3fn
+            a8, b8 = (a * 0.25).to(f8), (bm * 0.25).to(f8)
+            one = torch.ones((), device=dev, dtype=torch.float32)
+            row["fp8"] = time_it(lambda: torch._scaled_mm(a8, b8.t(), scale_a=one, scale_b=one, out_dtype=torch.bfloat16), flops)
+            row["fp8"]["frac_of_fp8_peak"] = round(row["fp8"]["tflops"] / 5000.0, 4)
+        except Exception as e:
+            row["fp8"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        res[name] = row
+        del a, bm
+    c5 = res.get("c5_shape_4096x32768x1536", {})
+    c2 = res.get("c2_shape_1024x65536x768", {})
+    res["fp8"] = c5.get("fp8") if isinstance(c5.get("fp8"), dict) and "tflops" in c5.get("fp8", {}) else None   # beside config5 in the compact line
+    res["bf16"] = c2.get("bf16") if isinstance(c2.get("bf16"), dict) and "tflops" in c2.get("bf16", {}) else None  # beside the f32 exact scan
+    res["library"] = "torch.matmul / torch._scaled_mm (hipBLASLt preferred) of torch " + torch.__version__
+    torch.cuda.empty_cache()
+    return res
 
 
 def kernel_of_ef(ef):
@@ -885,24 +955,174 @@ def leg_batcher(x_host, q_host, g, m, callers=1024, per_caller=300, lanes=3):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(root, "include"), os.path.join(root, "scripts", "bench_batcher.cpp"), "-o", exe,
                                "-L", os.path.join(root, "helix-db_amd"), "-lhelix_vec_gfx950", f"-Wl,-rpath,{os.path.join(root, 'helix-db_amd')}", "-lpthread"])
         env = dict(os.environ, BATCHER_WAIT="200")
-        r = subprocess.run([exe, d, str(callers), str(per_caller), "strict", str(lanes), "nodirect"], capture_output=True, text=True, timeout=240, env=env)
-        if r.returncode != 0:
-            return {"error": (r.stderr or r.stdout)[-400:]}
-        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-        res = {"workload": f"{n}x{dim} f32 (the headline corpus and graph), strict ef=100 k=10, {callers} caller threads x {per_caller} single-query hvx_batcher_search calls, "
-                           f"{lanes} dispatcher lanes, max_wait_us 200",
-               "qps": line["batcher"]["qps"], "mean_us": line["batcher"]["mean_us"], "p99_us": line["batcher"]["p99_us"], "mean_batch": line["batcher"]["mean_batch"]}
-        for l in r.stderr.splitlines():
-            if l.startswith("timed run:"):
-                res["host"] = l[len("timed run: "):]
-            elif l.startswith("lane time shares"):
-                res["lanes"] = l
+
+        def one(arm, lanes_, extra_env):
+            r = subprocess.run([exe, d, str(callers), str(per_caller), arm, str(lanes_), "nodirect"], capture_output=True, text=True, timeout=240,
+                               env=dict(env, **extra_env))
+            if r.returncode != 0:
+                return {"error": (r.stderr or r.stdout)[-400:]}
+            line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+            o = {"qps": line["batcher"]["qps"], "mean_us": line["batcher"]["mean_us"], "p99_us": line["batcher"]["p99_us"], "mean_batch": line["batcher"]["mean_batch"],
+                 "lanes": lanes_}
+            for l in r.stderr.splitlines():
+                if l.startswith("timed run:"):
+                    o["host"] = l[len("timed run: "):]
+                elif l.startswith("lane time shares"):
+                    o["lane_times"] = l
+            return o
+
+        res = one("strict", lanes, {})
+        if "error" in res:
+            return res
+        res["workload"] = (f"{n}x{dim} f32 (the headline corpus and graph), strict ef=100 k=10, {callers} caller threads x {per_caller} single-query "
+                           f"hvx_batcher_search calls, {lanes} dispatcher lanes, max_wait_us 200")
+        # the arm /v2/query actually runs (SearchParams::new(k), access/search/storage.rs:140-141): lanes on the two-per-SIMD build (round 5)
+        pd = one("default", 4, {"BATCHER_OCC": "2"})
+        res["production_default"] = pd
+        res["qps_production_default"] = pd.get("qps")
         return res
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
 
-def start_deadline(out, seconds, rank):
+# ------------------------------------------------------------------------------------------------------------
+# the line the driver parses
+# ------------------------------------------------------------------------------------------------------------
+def _finite(o):
+    """strict JSON: non-finite floats become null (json.dumps(..., allow_nan=False) would raise on them)"""
+    if isinstance(o, float):
+        return o if o == o and o not in (float("inf"), float("-inf")) else None
+    if isinstance(o, dict):
+        return {str(k): _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    if isinstance(o, (np.floating,)):
+        return _finite(float(o))
+    if isinstance(o, (np.integer,)):
+        return int(o)
+    if isinstance(o, (np.bool_,)):
+        return bool(o)
+    return o
+
+
+def _pick(d, *keys):
+    """d[k0][k1]... or None"""
+    for k in keys:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+COMPACT_LIMIT = 4096
+
+
+def compact_record(out, full_path):
+    """The <= 4 KB line: the contract's keys + roofline + cpu_baseline + parity, and one short object per extra leg.  Everything it
+    summarises is in the full record under the same top-level key."""
+    rf = out.get("roofline") or {}
+    c = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                 "dtype", "data")}
+    cfg = out.get("config") or {}
+    c["config"] = {k: cfg.get(k) for k in ("workload", "dataset", "rows_per_gpu", "rows_total", "dim", "batch", "k", "ef_search", "lanes", "parallelism",
+                                           "rccl_ranks", "rccl_version") if cfg.get(k) is not None}
+    c["recall_at_10"] = out.get("recall_at_10")
+    c["roofline"] = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "peak_measured", "unit", "frac", "frac_of_measured",
+                                            "algorithmic_bytes_per_launch", "kernel_ms", "kernel_ms_each", "traffic", "traffic_source")}
+    lb = rf.get("lone_batch") or {}
+    if lb:
+        c["roofline"]["lone_batch_frac"] = lb.get("frac")
+    cb = out.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "threads", "nproc", "quota_cores", "kind", "sample")}
+    if out.get("parity"):
+        c["parity"] = {k: out["parity"].get(k) for k in ("queries", "ids_equal_oracle", "score_bits_equal_oracle")}
+    if out.get("strong_scaling"):
+        c["strong_scaling"] = {k: out["strong_scaling"].get(k) for k in ("rows_total", "rows_per_gpu", "qps", "ms_per_step", "recall_at_10")}
+    pl = out.get("production_default_lanes")
+    if isinstance(pl, dict):
+        c["production_default_lanes"] = {m: ({k: v.get(k) for k in ("qps", "ms_per_step", "frac", "recall_at_10", "ids_equal_oracle", "score_bits_equal_oracle")}
+                                             if isinstance(v, dict) and "error" not in v else v) for m, v in pl.items() if m in ("l2", "cosine", "error")}
+    ds = out.get("datasets")
+    if isinstance(ds, dict):
+        d2 = {}
+        for name in ("clustered", "gaussian", "embedding"):
+            r = ds.get(name)
+            if isinstance(r, dict):
+                d2[name] = ({"error": str(r["error"])[:120]} if "error" in r else
+                            {"qps": r.get("qps"), "recall_at_10": r.get("recall_at_10"), "frac": _pick(r, "roofline", "frac"), "clears_0.95": r.get("clears_recall_0.95")})
+        iso = ds.get("clustered_iso_recall")
+        if isinstance(iso, dict) and "clustered" in d2:
+            hit = iso.get("iso_recall")
+            d2["clustered"]["iso_recall"] = None if not hit else {"ef_search": hit.get("ef_search"), "qps": hit.get("qps"), "recall_at_10": hit.get("recall_at_10")}
+        c["datasets"] = d2
+    c3 = out.get("config3_prefilter")
+    if isinstance(c3, dict):
+        if "error" in c3:
+            c["config3"] = {"error": str(c3["error"])[:160]}
+        else:
+            c["config3"] = {"corpus": _pick(c3, "corpus", "kind"), "parity_ok": c3.get("parity_sample_ok"),
+                            "groups": [{"candidates": g_["candidates"], "strategy": _pick(g_, "planned", "strategy"),
+                                        "recall_vs_exact": _pick(g_, "planned", "recall_at_10_vs_exact"),
+                                        "gate_0.92": _pick(g_, "planned", "reference_gates", "recall_at_10_ge_0.92"),
+                                        "planned_us_per_query": _pick(g_, "planned", "us_per_query"),
+                                        "exact_us_per_query": _pick(g_, "exact", "us_per_query"),
+                                        "exact_hbm_frac": None if _pick(g_, "exact", "hbm_gbs_scan") is None else round(_pick(g_, "exact", "hbm_gbs_scan") / HBM_PEAK_GBS, 3)}
+                                       for g_ in c3.get("groups", [])]}
+    c4 = out.get("config4_bf16")
+    if isinstance(c4, dict):
+        c["config4"] = {"error": str(c4["error"])[:160]} if "error" in c4 else {
+            "qps": c4.get("qps"), "recall_at_10": c4.get("recall_at_10"), "frac": _pick(c4, "roofline", "frac"),
+            "ids_equal_oracle": _pick(c4, "parity_sample", "ids_equal_oracle")}
+    c5 = out.get("config5_fp8_flat")
+    if isinstance(c5, dict):
+        c["config5"] = {"error": str(c5["error"])[:160]} if "error" in c5 else {
+            "rows": c5.get("rows"), "ms_per_batch": c5.get("ms_per_batch"), "tflops": _pick(c5, "roofline", "achieved"),
+            "frac_of_fp8_peak": _pick(c5, "roofline", "frac_of_fp8_peak"), "frac_of_bf16_peak": _pick(c5, "roofline", "frac"),
+            "vendor_gemm_tflops": _pick(out, "vendor_gemm", "fp8", "tflops"), "bit_exact_full_scan": c5.get("oracle_bit_exact_full_scan")}
+    es = out.get("exact_scan")
+    if isinstance(es, dict):
+        c["exact_scan"] = {"ms": es.get("ms"), "tflops": _pick(es, "roofline", "achieved"), "frac_of_bf16_peak": _pick(es, "roofline", "frac"),
+                           "vendor_gemm_tflops": _pick(out, "vendor_gemm", "bf16", "tflops")}
+    bt = out.get("batcher")
+    if isinstance(bt, dict):
+        c["batcher"] = {"error": str(bt["error"])[:160]} if "error" in bt else {k: bt.get(k) for k in ("qps", "mean_us", "p99_us", "mean_batch", "qps_production_default",
+                                                                                                       "qps_nonblocking")}
+    if out.get("deadline"):
+        c["deadline"] = {"seconds": out["deadline"].get("seconds")}
+    c["full_record"] = full_path
+    c = _finite(c)
+    line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    # a leg that grew must never cost the line its contract: drop summaries (never the contract keys) until it fits
+    for victim in ("batcher", "exact_scan", "config4", "config5", "config3", "datasets", "production_default_lanes", "strong_scaling"):
+        if len(line) < COMPACT_LIMIT:
+            break
+        if victim in c:
+            c[victim] = "see full_record"
+            line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    return line
+
+
+def emit(out, full_path, rank=0):
+    """full record -> file (+ stderr), compact line -> the LAST line of stdout"""
+    if rank != 0:
+        return
+    full = _finite(out)
+    written = None
+    for path in (full_path, os.path.join(ROOT, "gpurun_out", "bench_full.json")):
+        try:
+            if os.path.isdir(os.path.dirname(path)):
+                with open(path, "w") as f:
+                    json.dump(full, f, allow_nan=False)
+                written = written or path
+        except OSError as e:
+            log(f"could not write {path}: {e}")
+    line = compact_record(out, written)
+    sys.stderr.flush()
+    print(line, flush=True)
+
+
+def start_deadline(out, seconds, rank, full_path):
     """The extra legs (other corpora, configs 3-5, graph equivalence, CPU baseline) must never cost the headline: once the
     headline object exists, a daemon thread prints it -- with the legs that have finished by then -- when the deadline passes,
     and ends the process."""
@@ -912,15 +1132,11 @@ def start_deadline(out, seconds, rank):
         for _ in range(20):
             try:
                 snap = dict(out)
-                snap["deadline"] = {"seconds": seconds, "note": "printed by the deadline watchdog: legs absent from this line had not finished"}
-                line = json.dumps(snap)
+                snap["deadline"] = {"seconds": seconds, "note": "printed by the deadline watchdog: legs absent from this record had not finished"}
+                emit(snap, full_path, rank)
                 break
             except RuntimeError:  # the main thread added a key while we copied
                 time.sleep(0.05)
-        else:
-            line = None
-        if rank == 0 and line is not None:
-            print(line, flush=True)
         log(f"deadline of {seconds:.0f}s reached: line printed with the legs finished so far")
         sys.stderr.flush()
         os._exit(0)
@@ -967,8 +1183,7 @@ def main():
 
     if args.leg == "config5":
         res = run_config5_sharded(hv, synth, shard, args, dev, dist, rank, world)
-        if rank == 0:
-            print(json.dumps(res), flush=True)
+        emit(res, args.full_record, rank)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -1126,10 +1341,22 @@ def main():
         except Exception:
             traffic = None
     achieved = res["alg"] / (res["per_step"] * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "hnsw_wave_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
+    # BASELINE.md section 2 / SURVEY 8(d): the MEASURED streaming-read rate of this box next to the 8 TB/s spec -- a read-only
+    # global_load_dwordx4 kernel over a 3 GiB buffer (hvx_device_stream_read_gbs, csrc/hvx_probe.hip), timed here, in this run
+    peak_measured = None
+    if "peak" not in skip:
+        try:
+            pk_best, pk_mean = hv.device_stream_read_gbs(local_rank, 3 << 30, 5)
+            peak_measured = round(pk_best, 1)
+            log(f"stream-read probe: best {pk_best:.0f} GB/s, mean {pk_mean:.0f} GB/s over 3 GiB")
+        except Exception as e:
+            log(f"stream-read probe failed: {e}")
+    roofline = {"bound": "hbm", "kernel": "hnsw_wave_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "peak_measured": peak_measured,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "frac_of_measured": None if not peak_measured else round(achieved / peak_measured, 4),
+                "peak_measured_how": "hvx_device_stream_read_gbs: read-only 16-byte-load streaming kernel over 3 GiB of HBM, best of 5 launches, this run",
                 "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
-                "traffic_source": "builder-side rocprofv3 --pmc pass of this command (profiles/traffic_latest.json), NOT measured in this run",
+                "traffic_source": "rocprofv3 --pmc pass of this command on another box (profiles/traffic_latest.json); not measured in this run",
                 "algorithmic_bytes_per_launch": int(res["alg"]),
                 "algorithmic_bytes_of": "the per-query counters of lane 0's last batch (every timed step answers a different batch of the same distribution)",
                 "kernel_ms": round(res["per_step"], 4),
@@ -1161,6 +1388,7 @@ def main():
                    "dataset": args.dataset, "rows_per_gpu": n, "rows_total": res["n_total"], "dim": dim, "batch": b, "k": k,
                    "ef_search": ef, "lanes": lanes, "distinct_query_batches": res["nbq"],
                    "exchange": res["exchange"],
+                   "rccl_ranks": (world if (world > 1 and ls.groups) else None), "rccl_version": (hv.rccl_version() if world > 1 else None),
                    "parallelism": ("1 GPU" if world == 1 else f"{world} replicas, one query batch each" if replica
                                    else f"id-range shards x{world} + all-gather top-k merge")},
         "recall_at_10": round(res["recall"], 4),
@@ -1178,7 +1406,7 @@ def main():
     }
 
     if args.deadline > 0:
-        start_deadline(out, max(5.0, args.deadline - (time.time() - t_start)), rank)
+        start_deadline(out, max(5.0, args.deadline - (time.time() - t_start)), rank, args.full_record)
 
     # ---- N > 1: the north star's own curve -- the SAME 1M corpus split over the GPUs (strong scaling) ----
     if world > 1 and not replica and args.scaling in ("strong", "both"):
@@ -1207,8 +1435,16 @@ def main():
         # ---- what the reference's query path actually runs: SearchParams::new(k) = ef max(k,100), SimHashMode::Adaptive
         #      (access/search/storage.rs:140-141), next to the strict arm at the same beam width ----
         prod = None
+        prod_lanes = {}
         if not bf16 and "production" not in skip:
             prod = {}
+            # the headline's forks are done (their buffers and last batches stay for the oracle check below): HIP maps streams onto
+            # GPU_MAX_HW_QUEUES = 8 hardware queues, and the lanes of the legs below must not share one with each other (r05a: the cosine
+            # lanes of this leg, created as streams 9-12 of the process, ran 1.7 kernels in flight instead of 2.6)
+            ls.sync()
+            for h in ls.handles[1:]:
+                h.close()
+            ls.handles, ls.streams = ls.handles[:1], ls.streams[:1]
             x_host = x.cpu().numpy()
             q_host = q.cpu().numpy()
             threads = host_threads(args)
@@ -1238,6 +1474,32 @@ def main():
                     torch.cuda.synchronize()
                     return float(np.mean(ms)), recall_of(bufs[0], S["truth"][0], b, k), bufs[4].cpu().numpy().astype(np.int64)
 
+                # ---- the same parameters the way a serving host runs them (round 5): `lanes` execution lanes, two queries per SIMD, the
+                #      driver's K steps over distinct query batches; every lane's last batch is checked against the oracle below ----
+                pl = None
+                if "production_lanes" not in skip:
+                    pls = LaneSet(pix, lanes, 2 if lanes > 1 else 1, b, k, dev)  # forks made AFTER the SimHash rows were attached
+                    pls.params = pp
+                    p_el, p_span, p_kms = timed_steps(pls, S_qs, pp.ef, args.steps, args.warmup, lambda: None)
+                    if p_el * 1e3 > 1.3 * p_span:  # a host stall inside the timed steps (CPU-quota freeze): one repeat
+                        p_el, p_span, p_kms = timed_steps(pls, S_qs, pp.ef, args.steps, args.warmup, lambda: None)
+                    pf = out_buffers(b, k, dev)
+                    S["ix_truth"].flat_search_batch_device(pls.last_q[0], k, *pf[:4])
+                    torch.cuda.synchronize()
+                    p_qst = pls.bufs[0][4].cpu().numpy().astype(np.int64)
+                    p_alg = hnsw_alg_bytes(p_qst, dim, 4, b)
+                    p_step = p_span / args.steps
+                    pl = {"params": f"SearchParams::new({k}) on {lanes} lanes, {2 if lanes > 1 else 1} queries per SIMD", "steps": args.steps, "warmup": args.warmup,
+                          "qps": round(b * args.steps / p_el, 1), "ms_per_step": round(p_el * 1e3 / args.steps, 4),
+                          "kernel_ms_overlapped": round(p_step, 4), "kernel_ms_each": round(float(p_kms.mean()), 4),
+                          "recall_at_10": round(recall_of(pls.bufs[0][0], pf[0], b, k), 4),
+                          "distance_computations_per_query": round(float(p_qst[:, 3].mean()), 1),
+                          "algorithmic_bytes_per_launch": p_alg, "achieved_gbs": round(p_alg / (p_step * 1e-3) / 1e9, 1),
+                          "frac": round(p_alg / (p_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          "bytes_note": "SURVEY 8(d) formula (rows scored x dim x 4 + neighbour ids x 4 + queries); the 8-byte SimHash rows the cosine filter reads are not counted"}
+                if pl is not None:
+                    pls.sync()
+                pix.set_occupancy(1)  # the lone-batch numbers below: one query per SIMD, as in rounds 1-4
                 sb = out_buffers(b, k, dev)
                 strict_ms, strict_rec, strict_qs = run(hv.SearchParams(k).with_ef(pp.ef), sb, None)
                 prod_ms, prod_rec, prod_qs = run(pp, pb, p_ast)
@@ -1275,11 +1537,29 @@ def main():
                                    "simhash_rows_equal_oracle_on_sample": {"rows": int(sample.size), "equal": bool(sh_ok)}}
                     d["cpu_oracle_qps"] = round(b / cpu_s, 1)
                     assert pa and pbits and pc and sh_ok, f"GPU non-strict search ({mname}) differs from the CPU oracle"
+                    if pl is not None:  # every lane's last batch of the lanes leg
+                        same_i = same_b = True
+                        for l in range(lanes):
+                            if pls.last_q[l] is None:
+                                continue
+                            rc, l_ids, l_sc, _, _ = oix.search_params_batch(pls.last_q[l].cpu().numpy(), orc.SearchParams.new(k), threads=threads)
+                            assert rc == orc.OK
+                            same_i &= bool((pls.bufs[l][0].cpu().numpy().astype(np.uint64) == l_ids).all())
+                            same_b &= bool((pls.bufs[l][1].cpu().numpy().view(np.uint32) == l_sc.view(np.uint32)).all())
+                        pl.update({"lanes_checked": lanes, "queries_checked": b * lanes, "ids_equal_oracle": same_i, "score_bits_equal_oracle": same_b})
+                        assert same_i and same_b, f"GPU non-strict search on lanes ({mname}) differs from the CPU oracle"
                     del oix
                 prod[mname] = d
+                if pix is ix:
+                    ix.set_occupancy(occ)
+                if pl is not None:
+                    prod_lanes[mname] = pl
+                    for h in pls.handles[1:]:
+                        h.close()
                 if pix is not ix:
                     pix.close()
         out["production_default"] = prod
+        out["production_default_lanes"] = prod_lanes or None
 
         # ---- CPU baseline + bit-exact verification of the headline ----
         if args.cpu_seconds > 0 or not args.no_verify:
@@ -1306,7 +1586,8 @@ def main():
             oix.search_batch(q_host[:64], k, ef, threads=1)
             single = (time.perf_counter() - t1) / 64
             out["cpu_baseline"] = {
-                "value": round(b / med, 1) if rounds else None, "unit": "queries/s", "cores": threads, "kind": "port",
+                "value": round(b / med, 1) if rounds else None, "unit": "queries/s", "cores": threads, "threads": threads,
+                "nproc": os.cpu_count(), "quota_cores": cpu_quota(), "kind": "port",
                 "sample": f"all {b} queries of the same batch, same graph, k={k} ef={ef}; median of {len(rounds)} rounds after a warm-up pass; "
                           f"oracle = C restatement with real AVX2+FMA kernels, data resident in RAM (no storage-engine cost)",
                 "single_thread_us_per_query": round(single * 1e6, 1),
@@ -1358,6 +1639,8 @@ def main():
             log(f"[{name}] {time.time() - t0:.1f}s")
             return r
 
+        if "vendor_gemm" not in skip:
+            out["vendor_gemm"] = guarded("vendor_gemm", lambda: leg_vendor_gemm(dev))
         if "config3" not in skip:
             out["config3_prefilter"] = guarded("config3", lambda: leg_config3(hv, synth, orc, args, dev))
         if "config4" not in skip:
@@ -1407,8 +1690,7 @@ def main():
                           "recall@10 misses 0.95 at ef=128 for every HNSW, the reference's included -- QPS there is not a headline")
             out["datasets"] = ds
 
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    emit(out, args.full_record, rank)
     if world > 1:
         dist.destroy_process_group()
 

@@ -43,7 +43,7 @@ int fail(int code, const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *hvx_last_error(void) { return g_err.c_str(); }
-extern "C" const char *hvx_version(void) { return "helix_vec_gfx950 0.1 (round 1)"; }
+extern "C" const char *hvx_version(void) { return "helix_vec_gfx950 0.5 (round 5)"; }
 
 // domain.rs:26-78 VectorComponentLimit::try_new
 float hvx::component_limit(uint32_t metric, uint32_t dim) {
@@ -129,10 +129,18 @@ extern "C" int hvx_index_set_occupancy(hvx_index *ix, uint32_t queries_per_simd)
 // The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order, and two
 // execution lanes that land on one queue run their kernels back to back (r03: 0.65 -> 0.44 ms per step on the bf16 leg once its lanes
 // had queues of their own).  A host with lanes + other handles + its own copy streams needs more than four; the runtime reads the
-// variable when it initialises, i.e. after this library has been loaded by a host that links it (a Rust cdylib, a cgo package) or
-// loads it before its first HIP call.  The library raises the DEFAULT to 8 and leaves a value the host has chosen alone.  (It still
-// reads no environment: this is the one variable it writes.)
-__attribute__((constructor)) static void hvx_default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0); }
+// variable when it initialises.  Round 5: the library no longer writes the environment from a load-time constructor
+// (setenv races with a concurrent getenv in a multithreaded host, and silently changed the queue count of every other HIP user in
+// the process).  The host calls hvx_runtime_prepare ONCE from its single-threaded start-up code, before its first HIP call
+//  -- or exports the variable itself.  A value the host has already chosen is left alone.
+extern "C" int hvx_runtime_prepare(uint32_t hw_queues) {
+    if (hw_queues == 0) hw_queues = 8;
+    if (hw_queues > 64) return fail(HVX_ERR_K_RANGE, "hardware queue count %u outside 1..64", hw_queues);
+    char buf[16];
+    snprintf(buf, sizeof(buf), "%u", hw_queues);
+    if (setenv("GPU_MAX_HW_QUEUES", buf, /*overwrite=*/0) != 0) return fail(HVX_ERR_INVARIANT, "setenv(GPU_MAX_HW_QUEUES) failed");
+    return HVX_OK;
+}
 
 extern "C" int hvx_index_set_option(hvx_index *ix, uint32_t option, uint32_t value) {
     if (!ix) return fail(HVX_ERR_INVARIANT, "null index");
@@ -215,9 +223,8 @@ int hvx::import_index(const hvx_index_desc *desc, const uint64_t *node_ids, cons
         return fail(HVX_ERR_UNSUPPORTED, "fp8 rows need dim %% 128 == 0, the AVX+FMA summation tree and an L2/cosine metric");
     if (desc->dtype == HVX_BF16 && (desc->dim % 64u != 0u || desc->float_kernel != HVX_KERNEL_AVX_FMA || desc->metric == HVX_MANHATTAN))
         return fail(HVX_ERR_UNSUPPORTED, "bf16 rows need dim %% 64 == 0, the AVX+FMA summation tree and an L2/cosine metric");
-    if (desc->float_kernel != HVX_KERNEL_SCALAR && desc->float_kernel != HVX_KERNEL_AVX &&
-        desc->float_kernel != HVX_KERNEL_AVX_FMA)
-        return fail(HVX_ERR_UNSUPPORTED, "float kernel %u not supported on device", desc->float_kernel);
+    if (desc->float_kernel > HVX_KERNEL_NEON)
+        return fail(HVX_ERR_UNSUPPORTED, "float kernel %u is not one of the reference's FloatSimd kernels", desc->float_kernel);
     if (desc->n >= (1ull << 31)) return fail(HVX_ERR_UNSUPPORTED, "shard too large (n < 2^31)");
     const uint64_t n = desc->n;
     if (n && (!node_ids || !vectors || !l0_offsets)) return fail(HVX_ERR_INVARIANT, "null array");
@@ -238,7 +245,7 @@ int hvx::import_index(const hvx_index_desc *desc, const uint64_t *node_ids, cons
     d.ld = round_up(desc->dim, 4);
     d.metric = desc->metric;
     d.fkernel = desc->float_kernel;
-    d.dim_main = (desc->float_kernel == HVX_KERNEL_SCALAR || desc->dim < 32) ? 0u : desc->dim - desc->dim % 32u;
+    d.dim_main = kernel_dim_main(desc->float_kernel, desc->dim);
     d.max_layer = desc->max_layer;
     d.has_entry = (desc->has_entry && n) ? 1u : 0u;
     d.dtype = desc->dtype;
@@ -585,8 +592,20 @@ int hvx::check_k_ef(uint32_t k, uint32_t ef) {
     // ResultCount / SearchBeamWidth (parameters.rs:100-133)
     if (k == 0) return fail(HVX_ERR_K_RANGE, "result count must be non-zero");
     if (ef < k) return fail(HVX_ERR_K_RANGE, "search beam width %u is below the result count %u", ef, k);
-    if (ef + 32 > 1024) return fail(HVX_ERR_UNSUPPORTED, "ef %u exceeds the register-beam limit of 992", ef);
+    // SearchBeamWidth::try_new has no upper bound (parameters.rs:118-133).  Beams of ef + 32 <= 1024 entries run on the HNSW kernels; a
+    // wider beam is answered by the EXACT scan of the index (enqueue_search): the true top-k, which is what a beam of that width
+    // converges to -- the same fall-back the restricted path takes beyond its LDS limits.  The scan serves k <= 1024.
+    if (ef + 32 > 1024 && k > 1024) return fail(HVX_ERR_UNSUPPORTED, "result count %u exceeds the exact scan's limit of 1024 (beams beyond ef 992 are answered by the exact scan)", k);
     return HVX_OK;
+}
+
+// per-query counters of a search that was answered by the exact scan: every stored row loaded and scored once
+__global__ void exact_fallback_stats_kernel(hvx_query_stats *qs, uint32_t *tie, const uint32_t *status, uint32_t b, uint32_t n) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= b) return;
+    const uint32_t rows = (status && status[q]) ? 0u : n;
+    if (qs) qs[q] = hvx_query_stats{0u, 0u, rows, rows};
+    if (tie) tie[q] = 0u;
 }
 
 static void add_stats(hvx_stats *stats, const std::vector<hvx_query_stats> &qs, const std::vector<uint32_t> &tie,
@@ -618,6 +637,14 @@ int hvx::enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t b
                         uint64_t *d_ids, float *d_scores, uint32_t *d_counts, uint32_t *d_status,
                         hvx_query_stats *d_qstats, bool timed, const AdaptArgs *ad) {
     hvx_index *ix = const_cast<hvx_index *>(cix);
+    if (ef + 32u > 1024u) { // beyond the widest beam of the HNSW kernels: the exact scan (see check_k_ef); validation happens inside it
+        int rc = flat_scan_device(ix, d_queries, b, k, nullptr, ix->dev.n, d_ids, d_scores, d_counts, d_status ? d_status : ix->d_qstatus, timed);
+        if (rc) return rc;
+        hipLaunchKernelGGL(exact_fallback_stats_kernel, dim3((b + 255u) / 256u), dim3(256), 0, ix->stream, d_qstats ? d_qstats : ix->d_qstats, ix->d_tie,
+                           d_status ? d_status : ix->d_qstatus, b, ix->dev.n);
+        HIP_TRY(hipGetLastError());
+        return HVX_OK;
+    }
     HIP_TRY(launch_validate_queries(ix->dev, d_queries, b, ix->limit, ix->d_qstatus, ix->d_qhdr, ix->stream));
     HnswArgs a;
     a.ix = ix->dev;

@@ -6,8 +6,8 @@
 // coalesced here.  Results are exactly those of a direct batch call (queries are independent).
 //
 // Round 3 design (round 2's collector, not the device, was the limit: 418 k QPS = 28 % of the batch kernel):
-//   * NO lock and NO per-request object on the path of a caller.  One 64-bit word `state` = (batch sequence << 16 | slots
-//     claimed; 48 sequence bits never wrap in practice -- round 4, ADVICE r3: a 32-bit sequence with a buffer count that is
+//   * NO lock and NO per-request object on the path of a caller.  One 64-bit word `state` = (batch sequence << 24 | slots
+//     claimed; 40 sequence bits never wrap in practice -- round 4, ADVICE r3: a 32-bit sequence with a buffer count that is
 //     not a power of two skipped the drain test at the wrap) is the whole queue: a caller claims slot `n` of the open batch with one compare-and-swap, copies its query
 //     straight into the batch's PINNED staging row (the row the H2D copy reads), bumps `filled`, and sleeps on the batch's
 //     completion word (futex); a dispatcher closes the open batch with one compare-and-swap (sequence + 1, count 0), which
@@ -138,7 +138,7 @@ struct hvx_batcher {
     hvx_search_params params{};
     uint32_t max_batch = 0, max_wait_us = 0, dim = 0, k = 0, nbuf = 0;
     int device = 0;
-    alignas(64) std::atomic<uint64_t> state{0};      // (sequence of the open batch) << 16 | slots claimed
+    alignas(64) std::atomic<uint64_t> state{0};      // (sequence of the open batch) << kSeqShift (24) | slots claimed
     alignas(64) std::atomic<uint32_t> seq_word{0};   // low 32 bits of the open sequence: callers of a full batch sleep on it
     alignas(64) std::atomic<uint32_t> bell{0};       // dispatchers sleep on it; rung by the first and the last claim of a batch
     alignas(64) std::atomic<uint32_t> sleepers{0};   // dispatchers asleep on the bell
@@ -205,7 +205,10 @@ struct hvx_batcher {
             // the next batch opens in buffer (seq + 1) % nbuf at the instant this one closes: it must be free, i.e. every
             // caller of the batch it held last has taken its rows
             Batch &next = bufs[(seq + 1) % nbuf];
-            if (seq + 1 >= nbuf && !stop.load()) { // its previous batch (sequence seq + 1 - nbuf) must be complete and fully drained
+            // (also while stopping -- ADVICE r4: a batch opened in a buffer whose previous batch is still in flight on another lane would
+            // mix the two batches' rows; the wait is bounded: that lane completes its batch, and every caller blocked on it wakes within
+            // 5 ms and either takes its rows or leaves with its slot accounted for)
+            if (seq + 1 >= nbuf) { // its previous batch (sequence seq + 1 - nbuf) must be complete and fully drained
                 if (next.done.load() != (uint32_t)(seq + 1 - nbuf + 1) || next.consumed_sum() != next.total) {
                     sleep_us(10); // (a caller of that batch has not copied its rows out yet)
                     lap(ln.ns_drain);
@@ -272,11 +275,16 @@ struct hvx_batcher {
         hipStream_t s = (hipStream_t)hvx_index_stream(ln.ix);
         bt.rc = 0;
         bt.err.clear();
-        auto bad = [&](const char *what, hipError_t e) { bt.rc = HVX_ERR_DEVICE; bt.err = std::string(what) + ": " + hipGetErrorString(e); };
+        // on any failure nothing may still be writing the batch's pinned rows when the buffer is handed back: drain the stream first
+        auto bad = [&](const char *what, hipError_t e) {
+            bt.rc = HVX_ERR_DEVICE;
+            bt.err = std::string(what) + ": " + hipGetErrorString(e);
+            (void)hipStreamSynchronize(s);
+        };
         hipError_t e = hipMemcpyAsync(ln.d_q, bt.q, (size_t)cnt * dim * 4, hipMemcpyHostToDevice, s);
         if (e != hipSuccess) return bad("hipMemcpyAsync(queries)", e);
         const int rc = hvx_search_batch_params_device(ln.ix, ln.d_q, cnt, &params, bt.dev_ids, bt.dev_sc, bt.dev_cnt, bt.dev_st, nullptr, nullptr, nullptr);
-        if (rc) { bt.rc = rc; bt.err = hvx_last_error(); return; }
+        if (rc) { bt.rc = rc; bt.err = hvx_last_error(); (void)hipStreamSynchronize(s); return; }
         if ((e = hipEventRecord(ln.ev, s)) != hipSuccess) return bad("hipEventRecord", e);
         if ((e = hipEventSynchronize(ln.ev)) != hipSuccess) return bad("hipEventSynchronize", e); // (blocking event: no busy-wait)
     }

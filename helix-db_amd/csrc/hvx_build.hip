@@ -756,7 +756,7 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
 
     DevIndex &d = ix->dev;
     uint32_t *l0w = const_cast<uint32_t *>(d.l0), *upw = const_cast<uint32_t *>(d.up);
-    const bool fused = d.fkernel == kKernelAvxFma;
+    const bool fused = kernel_fused(d.fkernel);
     // build_link_wg_kernel: column blocks of <= 8 chunks (256 floats) of Mmax + 1 candidate rows and the owner's in LDS, row stride
     // = 128 B mod 256 B (the eight row groups of a wavefront read different rows: conflict-free ds_read_b128 for neighbouring rows)
     const uint32_t ncmax = std::max(m0, m) + 1u;
@@ -766,7 +766,7 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
     const size_t link_lds = link_lds_bytes(ldp, ncmax);
     // serves rows without a scalar tail (dim % 32 == 0, no padding) and <= 33 candidates (561 pairs = 4 wavefronts x 18 steps x 8)
     const BuildKernels kern = pick_build_kernels(d.metric, fused);
-    const bool link_wg = params->link_mode != 1u && kern.link_wg && ncmax <= 33u && nk_rows > 0 && d.dim_main == d.dim && d.ld == d.dim &&
+    const bool link_wg = params->link_mode != 1u && kern.link_wg && !kernel_w4(d.fkernel) /* 32-lane tree only */ && ncmax <= 33u && nk_rows > 0 && d.dim_main == d.dim && d.ld == d.dim &&
                          (size_t)(ncmax + 1u) * link_ck * 8u <= 9u * 256u;
     // first node: the entry point with empty rows on its layers (mutation.rs:706-739)
     d.has_entry = 1;
@@ -893,13 +893,13 @@ extern "C" int hvx_index_link_rows(hvx_index *ix, const uint64_t *from_ids, cons
     if (ix->is_fork) return fail(HVX_ERR_UNSUPPORTED, "rows are linked through the handle that owns the image, not a fork");
     const uint32_t m = ix->desc.m ? ix->desc.m : 16u;
     const uint32_t m0 = std::max(ix->desc.m0 ? ix->desc.m0 : 2u * m, 2u * m);
-    const bool fused = d.fkernel == kKernelAvxFma;
+    const bool fused = kernel_fused(d.fkernel);
     const BuildKernels kern = pick_build_kernels(d.metric, fused);
     const uint32_t ncmax = std::max(m0, m) + 1u;
     const uint32_t nk_rows = d.dim_main >> 5;
     const uint32_t link_ck = std::min<uint32_t>(8u, (nk_rows + 1u) & ~1u);
     const uint32_t ldp = link_ck * 32u + 32u;
-    if (d.dtype != HVX_F32 || !kern.link_wg || ncmax > 33u || nk_rows == 0 || d.dim_main != d.dim || d.ld != d.dim || d.s0 < m0 ||
+    if (d.dtype != HVX_F32 || !kern.link_wg || kernel_w4(d.fkernel) || ncmax > 33u || nk_rows == 0 || d.dim_main != d.dim || d.ld != d.dim || d.s0 < m0 ||
         (size_t)(ncmax + 1u) * link_ck * 8u > 9u * 256u)
         return fail(HVX_ERR_UNSUPPORTED, "the link workgroups serve f32 rows, L2 / cosine, dim %% 32 == 0, m0 <= 32 (row stride >= m0)");
     std::vector<uint32_t> h_nodes(n_links), h_sel((size_t)n_links * 32u, kSentinel), h_cnt(n_links, 1u);

@@ -21,7 +21,17 @@ constexpr uint32_t kSentinel = 0xFFFFFFFFu; // empty slot in a fixed-stride neig
 constexpr uint32_t kExpandedBit = 0x80000000u;
 
 enum : uint32_t { kCosine = 0, kL2 = 1, kL1 = 2 };
-enum : uint32_t { kKernelScalar = 0, kKernelAvx = 2, kKernelAvxFma = 3 };
+enum : uint32_t { kKernelScalar = 0, kKernelSse = 1, kKernelAvx = 2, kKernelAvxFma = 3, kKernelNeon = 4 }; // FloatSimd (spaces/simple.rs:45-62)
+// the kernels that accumulate with fused multiply-adds (simple_avx.rs:128-238 *_avx_fma; simple_neon.rs vfmaq_f32)
+__host__ __device__ __forceinline__ bool kernel_fused(uint32_t fk) { return fk == kKernelAvxFma || fk == kKernelNeon; }
+// the 128-bit kernels: four 4-lane accumulators, 16 floats per iteration (simple_sse.rs:17-67, simple_neon.rs:10-95)
+__host__ __device__ __forceinline__ bool kernel_w4(uint32_t fk) { return fk == kKernelSse || fk == kKernelNeon; }
+// elements covered by the kernel's SIMD loop (the rest is its scalar tail): simple.rs:120-178 dispatch, MIN_DIM_SIZE_AVX = 32 / _SIMD = 16
+__host__ __device__ __forceinline__ uint32_t kernel_dim_main(uint32_t fk, uint32_t dim) {
+    if (fk == kKernelScalar) return 0u;
+    const uint32_t step = kernel_w4(fk) ? 16u : 32u;
+    return dim < step ? 0u : dim - dim % step;
+}
 
 // Read-only index image in HBM (see DESIGN.md "HBM layout").
 struct DevIndex {
@@ -113,6 +123,60 @@ __device__ __forceinline__ float dpp_xor2(float v) {
 }
 __device__ __forceinline__ float dpp_half_mirror(float v) {
     return __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0x141, 0xF, 0xF, true));
+}
+
+// lane ^ 4 inside the 8-lane row group: half-row mirror (7 - l) followed by a reversal inside the quad
+__device__ __forceinline__ float dpp_xor4(float v) {
+    const int m = __builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0x141, 0xF, 0xF, true);
+    return __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp(m, 0x1B, 0xF, 0xF, true));
+}
+
+// The 128-bit host kernels (round 5; FloatSimd::Sse on x86 without AVX, FloatSimd::Neon on aarch64 -- the reference's own CI runs on
+// ubuntu-24.04-arm): four accumulators of four lanes = 16 virtual lanes, virtual lane v summing elements v, v+16, v+32 ... in order.
+// Lane j of a row group owns virtual lanes 2j, 2j+1 (accumulator r = j >> 1, half h = j & 1) in a float2 fed by 8-byte loads -- the
+// eight lanes read the 64 contiguous bytes of one iteration.  (sum1+sum2)+(sum3+sum4) is a lane^2 and a lane^4 exchange; the final
+// horizontal add is hsum128_ps_sse (simple_sse.rs:10-14: x + movehl, then lane 0 + lane 1) or vaddvq_f32 (pairwise:
+// (x0+x1)+(x2+x3), simple_neon.rs:41,83).  NEON == the fused (vfmaq_f32) kernel, SSE == the mul-then-add kernel.
+template <bool NEON> __device__ __forceinline__ float w4_tree_reduce(float2 acc) {
+    float2 p, t;
+    p.x = acc.x + dpp_xor2(acc.x); p.y = acc.y + dpp_xor2(acc.y);   // sum1+sum2 | sum3+sum4
+    t.x = p.x + dpp_xor4(p.x); t.y = p.y + dpp_xor4(p.y);           // (sum1+sum2)+(sum3+sum4): half h holds components 2h, 2h+1
+    if (NEON) {
+        const float pp = t.x + t.y;         // x0+x1 (h = 0) / x2+x3 (h = 1)
+        return pp + dpp_xor1(pp);
+    }
+    const float u0 = t.x + dpp_xor1(t.x);   // x0+x2
+    const float u1 = t.y + dpp_xor1(t.y);   // x1+x3
+    return u0 + u1;
+}
+// SIMD part (elements [0, dim_main), dim_main % 16 == 0) of one row against one query, every lane of the group returns the same value
+template <uint32_t METRIC, bool FUSED>
+__device__ __forceinline__ float w4_main(const float *row, const float *qv, uint32_t dim_main, int j) {
+    const uint32_t nb = dim_main >> 4;
+    if (nb == 0u) return 0.0f;
+    float2 acc = make_float2(0.f, 0.f);
+    const float2 *rp = reinterpret_cast<const float2 *>(row) + j;
+    const float2 *qp = reinterpret_cast<const float2 *>(qv) + j;
+    auto step = [&](const float2 x, const float2 qq) __attribute__((always_inline)) {
+        if (METRIC == kL2) {
+            const float d0 = qq.x - x.x, d1 = qq.y - x.y;
+            if (FUSED) { acc.x = __builtin_fmaf(d0, d0, acc.x); acc.y = __builtin_fmaf(d1, d1, acc.y); }
+            else { acc.x = d0 * d0 + acc.x; acc.y = d1 * d1 + acc.y; }
+        } else {
+            if (FUSED) { acc.x = __builtin_fmaf(qq.x, x.x, acc.x); acc.y = __builtin_fmaf(qq.y, x.y, acc.y); }
+            else { acc.x = qq.x * x.x + acc.x; acc.y = qq.y * x.y + acc.y; }
+        }
+    };
+    uint32_t b = 0;
+    for (; b + 8 <= nb; b += 8) { // eight independent loads in flight per lane before the first use
+        float2 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = rp[(size_t)(b + u) * 8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) step(x[u], qp[(b + u) * 8]);
+    }
+    for (; b < nb; ++b) step(rp[(size_t)b * 8], qp[b * 8]);
+    return w4_tree_reduce<FUSED>(acc);
 }
 
 // Which float4 of a 32-float chunk lane j of a row group owns.  AVX register r (sum256_{r+1}) covers
@@ -229,6 +293,9 @@ __device__ __forceinline__ float group_distance(const DevIndex &ix, const float 
     if (METRIC == kL1) {
         result = 0.0f;
         t0 = 0;
+    } else if (kernel_w4(ix.fkernel)) { // SSE / NEON host kernels (FUSED == NEON by construction: kernel_fused)
+        t0 = ix.dim_main;
+        result = w4_main<METRIC, FUSED>(row, qv, t0, j);
     } else {
         t0 = ix.dim_main;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void flat_distance_kernel(FlatArgs a) {
         ql[i] = (q < a.b && c < ix.dim) ? a.queries[(size_t)q * ix.dim + c] : 0.0f;
     }
     __syncthreads();
-    const uint32_t nk = ix.dim_main >> 5;
+    const uint32_t nk = ix.dim_main >> 5; // (the 32-lane tree; the 128-bit kernels take the branch below)
     const uint32_t t0 = (METRIC == kL1) ? 0u : ix.dim_main;
     for (int rr = 0; rr < kRowsPerGroup; ++rr) {
         const uint32_t idx = blockIdx.x * (32u * kRowsPerGroup) + (uint32_t)rr * 32u + (uint32_t)g;
@@ -91,7 +91,10 @@ __global__ __launch_bounds__(256) void flat_distance_kernel(FlatArgs a) {
         const uint32_t node = a.subset ? a.subset[scan] : scan;
         const float *row = ix.vec + (size_t)node * ld;
         float res[TQ];
-        if (METRIC != kL1) {
+        if (METRIC != kL1 && kernel_w4(ix.fkernel)) { // SSE / NEON host kernels: 16 virtual lanes, two per lane of the group (hvx_device.h)
+#pragma unroll
+            for (int t = 0; t < TQ; ++t) res[t] = w4_main<METRIC, FUSED>(row, ql + (size_t)t * ld, ix.dim_main, j);
+        } else if (METRIC != kL1) {
             float4 acc[TQ];
 #pragma unroll
             for (int t = 0; t < TQ; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -179,7 +182,7 @@ static hipError_t launch_flat_tq(const FlatArgs &a, hipStream_t s) {
 
 hipError_t launch_flat_distances(const FlatArgs &a, hipStream_t s) {
     if (a.rows == 0 || a.b == 0) return hipSuccess;
-    const bool fused = a.ix.fkernel == kKernelAvxFma;
+    const bool fused = kernel_fused(a.ix.fkernel);
     switch (a.ix.metric) {
     case kCosine: return fused ? launch_flat_tq<kCosine, true>(a, s) : launch_flat_tq<kCosine, false>(a, s);
     case kL2: return fused ? launch_flat_tq<kL2, true>(a, s) : launch_flat_tq<kL2, false>(a, s);

@@ -21,6 +21,12 @@
 #include "hvx_device.h"
 #include "hvx_kernels.h"
 
+#ifdef HVX_TUNING
+static inline const char *tuning_env(const char *name) { return getenv(name); }
+#else
+static inline const char *tuning_env(const char *) { return nullptr; }
+#endif
+
 namespace hvx {
 
 constexpr int kMaxStride = 128;  // largest neighbour-row stride served
@@ -289,7 +295,7 @@ static hipError_t launch_r(const HnswArgs &a, uint32_t b, hipStream_t s) {
 }
 
 hipError_t launch_hnsw_search(const HnswArgs &a, uint32_t b, hipStream_t s) {
-    const bool fused = a.ix.fkernel == kKernelAvxFma;
+    const bool fused = kernel_fused(a.ix.fkernel);
     switch (a.ix.metric) {
     case kCosine: return fused ? launch_r<kCosine, true>(a, b, s) : launch_r<kCosine, false>(a, b, s);
     case kL2: return fused ? launch_r<kL2, true>(a, b, s) : launch_r<kL2, false>(a, b, s);
@@ -302,6 +308,7 @@ hipError_t launch_hnsw_search(const HnswArgs &a, uint32_t b, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 struct WaveGeom {
     uint32_t log2cap;
+    uint32_t cap; // slots of the LDS visited table
     size_t lds;
     uint32_t occ;
 };
@@ -322,6 +329,8 @@ hipError_t launch_hnsw_wave_l2_ad(const HnswArgs &a, uint32_t b, const WaveGeom 
 hipError_t launch_hnsw_wave_cos_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_l2_bf16_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_cos_bf16_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_occ2_l2_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);   // non-strict arms, two queries per SIMD
+hipError_t launch_hnsw_wave_occ2_cos_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_pair_l2(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);       // owner / gatherer kernel (hvx_hnsw_pair.h)
 hipError_t launch_hnsw_pair_cos(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_pair_l2_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
@@ -330,7 +339,7 @@ hipError_t launch_hnsw_wave_wide_l2(const HnswArgs &a, uint32_t b, const WaveGeo
 hipError_t launch_hnsw_wave_wide_cos(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_wide_l2_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_wide_cos_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
-constexpr uint32_t kRngWords = 1024; // LDS window of the query RNG (hvx_hnsw_wave.h)
+constexpr uint32_t kRngWords = 1024, kRngWordsOcc2 = 256; // LDS window of the query RNG (hvx_hnsw_wave.h)
 
 // wide beams (round 4): the strict arm on the unrolled shapes runs register beams of 448 / 832 entries too (hvx_hnsw_wave_wide*.hip:
 // ef up to 800 = the reference's restricted-path limit; search.rs:267-1067 itself has no limit, ef beyond that takes the general kernel)
@@ -385,14 +394,28 @@ static hipError_t launch_hnsw_wave_once(const HnswArgs &a, uint32_t b, hipStream
         build_generic = !hnsw_wave_supported(probe);
     }
     // (the wide beams have two-per-SIMD builds too; the one for bf16 rows at dim 1536 spills ~200 registers: it stays one per SIMD)
-    g.occ = (a.occupancy == 2 && !a.adaptive && !a.prof && !build_generic && !(wide && a.ix.dtype == HVX_BF16 && (a.ix.dim >> 5) == 48u)) ? 2u : 1u;
-    const size_t fixed = 512 + (size_t)a.ix.ld * 4 + (a.adaptive ? kRngWords * 4 : 0);
+    // Round 5: the non-strict arms (the production default, SearchParams::new(k): access/search/storage.rs:140-141) have two-per-SIMD builds
+    // as well -- f32 rows, the unrolled shapes; their RNG window shrinks to 256 words so that the visited table keeps its size.
+    const bool ad_occ2 = a.adaptive && !generic && a.ix.dtype == HVX_F32;
+    g.occ = (a.occupancy == 2 && (!a.adaptive || ad_occ2) && !a.prof && !build_generic && !(wide && a.ix.dtype == HVX_BF16 && (a.ix.dim >> 5) == 48u)) ? 2u : 1u;
+    size_t fixed = 512 + (size_t)a.ix.ld * 4 + (a.adaptive ? (g.occ == 2 ? kRngWordsOcc2 : kRngWords) * 4 : 0);
+    g.cap = 1u << g.log2cap;
     if (g.occ == 2) {
-        while (g.log2cap > 9 && ((size_t)4 << g.log2cap) + fixed > 20 * 1024) --g.log2cap;
-        if (((size_t)4 << g.log2cap) + fixed > 20 * 1024) g.occ = 1;
+        // the table takes what the 20 KiB of a half-SIMD wavefront leave (any multiple of 64 slots: the hash maps onto [0, cap) by a
+        // multiply-high, hvx_hnsw_wave.h) -- 4 224 slots at dim 768, 3 456 at dim 1536 where a power of two allowed 4 096 / 2 048
+        const size_t room = 20 * 1024 > fixed ? (20 * 1024 - fixed) / 4 / 64 * 64 : 0;
+        const bool forced = a.log2cap >= 7 && a.log2cap <= 15;
+        if (!(forced && g.cap <= room)) { // (HVX_OPT_WAVE_LOG2CAP: a tiny table exercises the spill path)
+            g.cap = (uint32_t)std::min<size_t>(room, 8192);
+            if (g.cap < 512) { // no room for a useful table next to the query: one query per SIMD
+                g.occ = 1;
+                g.cap = 1u << g.log2cap;
+                fixed = 512 + (size_t)a.ix.ld * 4 + (a.adaptive ? kRngWords * 4 : 0);
+            }
+        }
     }
     const size_t budget = g.occ == 2 ? 20 * 1024 : 40 * 1024;
-    const size_t need = ((size_t)4 << g.log2cap) + fixed;
+    const size_t need = (size_t)4 * g.cap + fixed;
     g.lds = need < budget ? budget : need;
     if (a.build_nodes) {
         if (build_generic) return launch_hnsw_wave_build_gen(a, b, g, s);
@@ -401,7 +424,7 @@ static hipError_t launch_hnsw_wave_once(const HnswArgs &a, uint32_t b, hipStream
     // one batch in flight: two wavefronts per query (owner + gatherer); the strict arm, beams of 192 / 384 entries
     if (a.pair && !a.adaptive && !a.prof && !a.only_flagged && !wide && g.occ == 1 && a.ef + 32u <= 384u) {
         WaveGeom pg = g;
-        const size_t pneed = ((size_t)4 << g.log2cap) + 528 + (size_t)a.ix.ld * 4;
+        const size_t pneed = (size_t)4 * g.cap + 528 + (size_t)a.ix.ld * 4;
         pg.lds = pneed < 40 * 1024 ? 40 * 1024 : pneed;
         if (a.ix.dtype == HVX_BF16) return a.ix.metric == kL2 ? launch_hnsw_pair_l2_bf16(a, b, pg, s) : launch_hnsw_pair_cos_bf16(a, b, pg, s);
         return a.ix.metric == kL2 ? launch_hnsw_pair_l2(a, b, pg, s) : launch_hnsw_pair_cos(a, b, pg, s);
@@ -410,6 +433,7 @@ static hipError_t launch_hnsw_wave_once(const HnswArgs &a, uint32_t b, hipStream
         if (a.ix.dtype == HVX_BF16) return a.ix.metric == kL2 ? launch_hnsw_wave_wide_l2_bf16(a, b, g, s) : launch_hnsw_wave_wide_cos_bf16(a, b, g, s);
         return a.ix.metric == kL2 ? launch_hnsw_wave_wide_l2(a, b, g, s) : launch_hnsw_wave_wide_cos(a, b, g, s);
     }
+    if (g.occ == 2 && a.adaptive) return a.ix.metric == kL2 ? launch_hnsw_wave_occ2_l2_ad(a, b, g, s) : launch_hnsw_wave_occ2_cos_ad(a, b, g, s);
     if (g.occ == 2) return a.ix.dtype == HVX_BF16 ? launch_hnsw_wave_occ2_bf16(a, b, g, s) : launch_hnsw_wave_occ2(a, b, g, s);
     if (generic) {
         switch (a.ix.metric) {
@@ -438,20 +462,24 @@ hipError_t launch_hnsw_wave(const HnswArgs &a0, uint32_t b, hipStream_t s) {
     const uint32_t need = a.ef + 32u;
     // a wider instantiation exists
     const bool wider = generic ? need <= 448u : (a.adaptive ? need <= 192u : need <= 448u);
-    const bool rerun = !a.prof && !a.build_nodes && a.tie_flags && a.rerun_ctl && wider;
+    const bool rerun = !a.prof && !a.build_nodes && a.tie_flags && a.rerun_ctl && wider && !tuning_env("HVX_NO_RERUN");
     if (!rerun) a.rerun_ctl = nullptr; // the search launch lists nothing when nobody empties the list
     hipError_t e = launch_hnsw_wave_once(a, b, s);
     if (e != hipSuccess || !rerun) return e;
+    auto reset_list = [&](hipError_t err) { // a failed launch leaves the list to nobody: empty it here (the kernel also ignores entries >= b)
+        if (err != hipSuccess) (void)hipMemsetAsync(a.rerun_ctl, 0, 8, s);
+        return err;
+    };
     HnswArgs r = a;
     r.only_flagged = 1;
     // the re-run's workgroups leave at once (unless duplicates overflowed a beam): give them the build that fits NEXT TO whatever is
     // resident -- two per SIMD, 20 KiB of LDS -- wherever it exists (the strict unrolled builds).  A one-per-SIMD re-run needs a SIMD
     // with nothing else on it: behind the batches of other lanes that is a wait of 0.2 ms (round 3), behind the batcher's lanes
     // running the four-wavefront pair kernel it starved for tens of milliseconds (gpurun r04c: p99 47 ms).
-    if (!a.adaptive) r.occupancy = 2;
+    if (!a.adaptive || (a.ix.dtype == HVX_F32 && hnsw_wave_supported(a) && !tuning_env("HVX_AD_RERUN_OCC1"))) r.occupancy = 2;
     // the re-run keeps the launch's register budget where the wider build exists for it (two queries per SIMD: its few wavefronts
     // fit next to the resident batches of the other lanes); the 832-entry beams are one-per-SIMD builds
-    return launch_hnsw_wave_once(r, b, s);
+    return reset_list(launch_hnsw_wave_once(r, b, s));
 }
 
 } // namespace hvx

@@ -41,7 +41,7 @@ constexpr uint32_t kPairExit = 0xFFFFFFFFu;
 // frontier of up to 24 (48) rows is scored with ONE memory latency -- the heavy queries, whose 20-30-row frontiers end a batch, are
 // the ones a single 16-row gatherer serves in two round trips.
 template <uint32_t METRIC, int R, int NK, bool BF, int G>
-__global__ __launch_bounds__(64 * (1 + G)) __attribute__((amdgpu_waves_per_eu(1 + G, 1 + G))) void hnsw_pair_kernel(HnswArgs a, uint32_t log2cap) {
+__global__ __launch_bounds__(64 * (1 + G)) __attribute__((amdgpu_waves_per_eu(1 + G, 1 + G))) void hnsw_pair_kernel(HnswArgs a, uint32_t vcap) {
     constexpr int NL = BF ? NK / 2 : NK; // 16-byte loads per lane and row
     constexpr int P = NL <= 8 ? 2 : 1;
     constexpr bool kWide2 = G == 1 && 2 * P * NL <= 48; // 192 of the gatherer's 256 registers
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(64 * (1 + G)) __attribute__((amdgpu_waves_per_eu(1 
     const int slot = chunk_slot(j);
 
     uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
-    const uint32_t cap = 1u << log2cap;
+    const uint32_t cap = vcap;
     uint32_t *fr_id = tab + cap;                           // [64] the published id list, row order
     float *fr_d = reinterpret_cast<float *>(fr_id + 64);   // [64] its distances
     uint32_t *ctl = reinterpret_cast<uint32_t *>(fr_d + 64); // [4] ctl[0] = rows of the published list, or kPairExit
@@ -117,8 +117,6 @@ __global__ __launch_bounds__(64 * (1 + G)) __attribute__((amdgpu_waves_per_eu(1 
     Vis V;
     V.tab = tab;
     V.cap = cap;
-    V.mask = cap - 1u;
-    V.shift = 32u - log2cap;
     V.limit = cap - (cap >> 2);
     V.words = a.words_per_query;
     V.bm = a.bitmap + (size_t)q * a.words_per_query;
@@ -361,7 +359,7 @@ template <typename K> static hipError_t launch_pair_kernel(K kern, uint32_t thre
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(b), dim3(threads), g.lds, s, a, g.log2cap);
+    hipLaunchKernelGGL(kern, dim3(b), dim3(threads), g.lds, s, a, g.cap);
     return hipGetLastError();
 }
 // three gatherers where a row is <= 24 pieces per lane, else one

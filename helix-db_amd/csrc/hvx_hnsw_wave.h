@@ -71,7 +71,7 @@ template <bool WGSYNC = true> struct VisitedT {
     uint32_t *tab;      // LDS [cap]
     uint32_t *bm;       // HBM bitmap of this query (all-zero on entry, handed back all-zero)
     uint32_t *bm2;      // second bitmap: SimHash-row-cached ids in bitmap mode (uncached-handle read accounting only; may be NULL)
-    uint32_t mask, shift, cap, words;
+    uint32_t cap, words; // cap: any slot count (a power of two is not required: first slot = high word of hash x cap)
     uint32_t limit;     // uniform: spill to the bitmap once count + 64 would exceed this many table entries
     uint32_t count;     // uniform: ids inserted into the table since the last clear
     bool spilled;       // uniform: bitmap mode
@@ -109,7 +109,7 @@ template <bool WGSYNC = true> struct VisitedT {
             return !contains(id, valid) & valid;
         }
         bool pending = valid, unseen = false, taken = false;
-        uint32_t slot = (id * 2654435761u) >> shift;
+        uint32_t slot = __umulhi(id * 2654435761u, cap);
         while (__ballot(pending)) {
             if (pending) {
                 const uint32_t old = atomicCAS(&tab[slot], kTabEmpty, id | kTentativeBit);
@@ -119,7 +119,7 @@ template <bool WGSYNC = true> struct VisitedT {
                     hashed_out = (old & kHashedBit) != 0u;
                     pending = false;
                 }
-                else slot = (slot + 1u) & mask;
+                else slot = slot + 1u == cap ? 0u : slot + 1u;
             }
         }
         slot_out = slot;
@@ -149,13 +149,13 @@ template <bool WGSYNC = true> struct VisitedT {
             return hit;
         }
         bool pending = valid, found = false;
-        uint32_t slot = (id * 2654435761u) >> shift;
+        uint32_t slot = __umulhi(id * 2654435761u, cap);
         while (__ballot(pending)) {
             if (pending) {
                 const uint32_t v = tab[slot];
                 if (v == id) { found = true; pending = false; }
                 else if (v == kTabEmpty) pending = false;
-                else slot = (slot + 1u) & mask;
+                else slot = slot + 1u == cap ? 0u : slot + 1u;
             }
         }
         return found;
@@ -173,13 +173,13 @@ template <bool WGSYNC = true> struct VisitedT {
             return isnew;
         }
         bool pending = valid;
-        uint32_t slot = (id * 2654435761u) >> shift;
+        uint32_t slot = __umulhi(id * 2654435761u, cap);
         while (__ballot(pending)) {
             if (pending) {
                 uint32_t old = atomicCAS(&tab[slot], kTabEmpty, id);
                 if (old == kTabEmpty) { isnew = true; pending = false; }
                 else if (old == id) { pending = false; }
-                else slot = (slot + 1u) & mask;
+                else slot = slot + 1u == cap ? 0u : slot + 1u;
             }
         }
         count += (uint32_t)__builtin_popcountll(__ballot(isnew));
@@ -291,11 +291,16 @@ __device__ __forceinline__ void gather_consume(const DevIndex &ix, const float *
 // The query-local generator of SearchSession (randomness.rs:127-164): rand 0.10 StdRng = ChaCha12 keyed by
 // seed_from_u64's PCG32 expansion (pinned by the SimHasher known answer, hvx_simhash.hip).  The stream is consumed
 // strictly in order, but the NUMBER of draws of a sampling stage is known before the stage runs, so the words are
-// produced 64 blocks (1 024 words) at a time -- lane L computes block base/16 + L -- and parked in LDS, and a stage
+// produced a window of blocks at a time -- lane L computes block base/16 + L -- and parked in LDS, and a stage
 // hands word (pos + rank) to the lane whose candidate is the rank-th one to draw.
+// RW = words of the LDS window: 1 024 (64 blocks, one per lane) for the one-query-per-SIMD builds; 256 (16 blocks, lanes 0..15) for
+// the two-per-SIMD builds, whose 20 KiB of LDS are better spent on the visited table -- the production-default parameters draw
+// ~120 words per query (profiles/r04s), a window is rarely refilled either way.
 constexpr uint32_t kRngWords = 1024;
-struct QueryRng {
-    uint32_t *buf;   // LDS [kRngWords], word w of the window at buf[(w % 16) * 64 + w / 16] (conflict-free fill)
+constexpr uint32_t kRngWordsOcc2 = 256;
+template <uint32_t RW> struct QueryRngT {
+    static constexpr uint32_t kBlocks = RW / 16u;
+    uint32_t *buf;   // LDS [RW], word w of the window at buf[(w % 16) * kBlocks + w / 16] (conflict-free fill)
     uint32_t key[8]; // uniform
     uint32_t base;   // stream index of the window's first word
     uint32_t pos;    // words consumed so far (uniform)
@@ -315,7 +320,7 @@ struct QueryRng {
     }
     // make words [pos, pos + 66) readable (a stage draws <= 64 words, choose_index <= 2)
     __device__ __forceinline__ void ensure(int lane) {
-        if (ready && pos + 66u <= base + kRngWords) return;
+        if (ready && pos + 66u <= base + RW) return;
         base = pos & ~15u;
         const uint32_t ctr = (base >> 4) + (uint32_t)lane; // block counter (64-bit in ChaCha; < 2^32 here)
         uint32_t st[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3],
@@ -334,13 +339,14 @@ struct QueryRng {
 #undef HVX_QR
         __syncthreads(); // every reader of the previous window is done
 #pragma unroll
-        for (int i = 0; i < 16; ++i) buf[i * 64 + lane] = x[i] + st[i];
+        for (int i = 0; i < 16; ++i)
+            if (kBlocks == 64u || (uint32_t)lane < kBlocks) buf[i * (int)kBlocks + lane] = x[i] + st[i];
         ready = true;
         __syncthreads();
     }
     __device__ __forceinline__ uint32_t word(uint32_t idx) const {
         const uint32_t r = idx - base;
-        return buf[(r & 15u) * 64u + (r >> 4)];
+        return buf[(r & 15u) * kBlocks + (r >> 4)];
     }
     // random::<f32>() < ratio for stream word idx
     __device__ __forceinline__ bool below(uint32_t idx, float ratio) const {
@@ -489,7 +495,7 @@ __device__ __forceinline__ float candidate_probability_fn(uint32_t kind, float b
 // there down to 0; the first k entries of every layer's W (internal ids, scores) are written per layer.
 // One query's whole search on one wavefront (q = blockIdx.x, or the query a re-run workgroup picked from the re-run list).
 template <uint32_t METRIC, int R, int NK, bool BF, bool PROF, bool AD, bool ST, int OCC, bool BUILD>
-__device__ __forceinline__ void hnsw_wave_query(const HnswArgs &a, const uint32_t log2cap, const uint32_t q) {
+__device__ __forceinline__ void hnsw_wave_query(const HnswArgs &a, const uint32_t vcap, const uint32_t q) {
     // rows per 8-lane group in flight: P*NK <= 24 float4 per lane for a narrow pass, x2 and x4 for wider
     // frontiers (4P*NK <= 96 float4 = 384 registers, VGPR+AGPR file of one wave per SIMD)
     // NK == 0: the GENERIC build -- any dimension (scalar tail, simple_avx.rs:172-177), any metric (Manhattan's sequential
@@ -499,7 +505,10 @@ __device__ __forceinline__ void hnsw_wave_query(const HnswArgs &a, const uint32_
     constexpr int NL = GEN ? 1 : (BF ? NK / 2 : NK);        // 16-byte loads per lane and row
     constexpr int P = NL <= 8 ? 2 : 1;
     constexpr bool kWide4 = OCC == 1 && 4 * P * NL <= 96;
-    constexpr bool kWide2 = OCC == 1 || 2 * P * NL <= 48; // 192 of the 256 registers of a half-SIMD wave
+    // 192 of the 256 registers of a half-SIMD wave.  The cosine non-strict build at dim 768 keeps ONE row per group in flight: with
+    // two its per-lane filter / sampling state spills 17-34 registers to scratch and the spilled build is 11 % slower on four lanes
+    // (profiles/r05b_ad_lanes_ab.log: 0.754 -> 0.673 ms per step; the squared-Euclidean build has no filter state and keeps two rows).
+    constexpr bool kWide2 = OCC == 1 || (2 * P * NL <= 48 && !(AD && METRIC == kCosine && 2 * P * NL > 32));
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const DevIndex &ix = a.ix;
     const int lane = (int)threadIdx.x, grp = lane >> 3, j = lane & 7;
@@ -507,9 +516,7 @@ __device__ __forceinline__ void hnsw_wave_query(const HnswArgs &a, const uint32_
 
     Visited V;
     V.tab = reinterpret_cast<uint32_t *>(smem);
-    V.cap = 1u << log2cap;
-    V.mask = V.cap - 1u;
-    V.shift = 32u - log2cap;
+    V.cap = vcap;
     V.limit = OCC == 1 ? V.cap - (V.cap >> 2) : V.cap - (V.cap >> 3); // 3/4 full; 7/8 for the half-LDS build
     V.words = a.words_per_query;
     V.bm = a.bitmap + (size_t)q * a.words_per_query;
@@ -549,7 +556,7 @@ __device__ __forceinline__ void hnsw_wave_query(const HnswArgs &a, const uint32_
     // one pass of W rows per group over fr_id[f0..nf): issue everything, then FMA, then publish
     // GENERIC build: one row per 8-lane group and step, the general distance evaluator
     auto generic_distance = [&](uint32_t node) __attribute__((always_inline)) -> float {
-        if (ix.fkernel == kKernelAvxFma) return group_distance<METRIC, true>(ix, qs, qhdr, node, j);
+        if (kernel_fused(ix.fkernel)) return group_distance<METRIC, true>(ix, qs, qhdr, node, j);
         return group_distance<METRIC, false>(ix, qs, qhdr, node, j);
     };
     auto pass = [&](auto width, uint32_t f0, uint32_t nf) __attribute__((always_inline)) {
@@ -721,7 +728,7 @@ __device__ __forceinline__ void hnsw_wave_query(const HnswArgs &a, const uint32_
         }
     };
     AdaptState A;
-    QueryRng G;
+    QueryRngT<(OCC == 2 ? kRngWordsOcc2 : kRngWords)> G;
     uint64_t qh = 0;
     float brk_lane = -1.0f;
     if (AD) {
@@ -1023,7 +1030,7 @@ __device__ __forceinline__ void hnsw_wave_query(const HnswArgs &a, const uint32_
 // execution lanes (216 us per step on average; profiles/r03a_kernel_stats_hvx.csv).  The last workgroup hands the list back empty.
 // (A loop "one workgroup takes every n-th listed query" was tried first: it costs every instantiation 30-70 spilled SGPRs.)
 template <uint32_t METRIC, int R, int NK, bool BF, bool PROF = false, bool AD = false, bool ST = true, int OCC = 1, bool BUILD = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void hnsw_wave_kernel(HnswArgs a, uint32_t log2cap) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void hnsw_wave_kernel(HnswArgs a, uint32_t vcap) {
     uint32_t q = blockIdx.x;
     if (!BUILD && a.only_flagged) {
         const uint32_t listed = __hip_atomic_load(&a.rerun_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1033,14 +1040,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
             __hip_atomic_store(&a.rerun_ctl[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&a.rerun_ctl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (!mine) return;
+        // (an entry left behind by a launch that failed before its re-run could empty the list must not send a later, smaller batch
+        // past its output arrays: ADVICE r4)
+        if (!mine || q >= gridDim.x) return;
     }
-    hnsw_wave_query<METRIC, R, NK, BF, PROF, AD, ST, OCC, BUILD>(a, log2cap, q);
+    hnsw_wave_query<METRIC, R, NK, BF, PROF, AD, ST, OCC, BUILD>(a, vcap, q);
 }
 
 // launch geometry shared by the per-metric translation units
 struct WaveGeom {
     uint32_t log2cap;
+    uint32_t cap; // slots of the LDS visited table (1 << log2cap unless the launch sized it to fill its LDS budget)
     size_t lds;
     uint32_t occ; // wavefronts per SIMD the launch is budgeted for (1 or 2)
 };
@@ -1067,13 +1077,16 @@ hipError_t launch_hnsw_wave_l2_ad(const HnswArgs &a, uint32_t b, const WaveGeom 
 hipError_t launch_hnsw_wave_cos_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_l2_bf16_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_cos_bf16_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+// ... budgeted for two queries per SIMD (f32 rows), hvx_hnsw_wave_occ2_l2_ad.hip / hvx_hnsw_wave_occ2_cos_ad.hip
+hipError_t launch_hnsw_wave_occ2_l2_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_occ2_cos_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 
 template <typename K> static hipError_t launch_wave_kernel(K kern, const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s) {
     if (g.lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(b), dim3(64), g.lds, s, a, g.log2cap);
+    hipLaunchKernelGGL(kern, dim3(b), dim3(64), g.lds, s, a, g.cap);
     return hipGetLastError();
 }
 

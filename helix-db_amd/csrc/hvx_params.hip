@@ -217,7 +217,7 @@ static int project_params(hvx_index *ix, const hvx_search_params *p, AdaptArgs *
 static int enqueue_params(hvx_index *ix, const float *d_queries, uint32_t b, const hvx_search_params *p, const AdaptArgs *ad,
                           bool strict, uint64_t *d_ids, float *d_scores, uint32_t *d_counts, uint32_t *d_status,
                           hvx_query_stats *d_qstats, hvx_adaptive_stats *d_astats, bool timed) {
-    if (strict) {
+    if (strict || p->ef + 32u > 1024u) { // (beams beyond the kernels' widest are answered by the exact scan: no filter / sampling stage runs)
         if (d_astats) HIP_TRY(hipMemsetAsync(d_astats, 0, (size_t)b * sizeof(hvx_adaptive_stats), ix->stream));
         return enqueue_search(ix, d_queries, b, p->k, p->ef, d_ids, d_scores, d_counts, d_status, d_qstats, timed);
     }

@@ -255,7 +255,7 @@ template <uint32_t METRIC, bool FUSED> hipError_t launch_walk_t(const WalkArgs &
 }
 
 hipError_t launch_walk(const WalkArgs &a, uint32_t b, hipStream_t s) {
-    const bool fused = a.ix.fkernel == kKernelAvxFma;
+    const bool fused = kernel_fused(a.ix.fkernel);
     switch (a.ix.metric) {
     case kCosine: return fused ? launch_walk_t<kCosine, true>(a, b, s) : launch_walk_t<kCosine, false>(a, b, s);
     case kL2: return fused ? launch_walk_t<kL2, true>(a, b, s) : launch_walk_t<kL2, false>(a, b, s);

@@ -46,7 +46,10 @@ struct Rccl {
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
+    int version = 0; // NCCL_VERSION_CODE of the loaded library (major * 10000 + minor * 100 + patch from 2.9 on)
     bool ok = false;
+    const char *why = "librccl.so.1 could not be loaded";
 };
 Rccl g_rccl;
 std::once_flag g_rccl_once;
@@ -64,7 +67,19 @@ const Rccl &rccl() {
         g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(g_rccl.handle, "ncclAllGather");
         g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(g_rccl.handle, "ncclCommDestroy");
         g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(g_rccl.handle, "ncclGetErrorString");
-        g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.AllGather && g_rccl.CommDestroy && g_rccl.GetErrorString;
+        g_rccl.GetVersion = (decltype(g_rccl.GetVersion))dlsym(g_rccl.handle, "ncclGetVersion");
+        if (!(g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.AllGather && g_rccl.CommDestroy && g_rccl.GetErrorString && g_rccl.GetVersion)) {
+            g_rccl.why = "the loaded librccl lacks an entry point this library binds";
+            return;
+        }
+        // The declarations above are restated by hand (no RCCL header at build time): they hold for the NCCL 2.x ABI -- ncclUniqueId =
+        // 128 opaque bytes (NCCL_UNIQUE_ID_BYTES), ncclUint8 = 1, ncclCommInitRank taking the id BY VALUE.  A library that does not
+        // report a 2.x version is refused instead of being called with a layout it may not share.
+        if (g_rccl.GetVersion(&g_rccl.version) != ncclSuccess || g_rccl.version < 2000 || g_rccl.version >= 30000) {
+            g_rccl.why = "the loaded librccl does not report an NCCL 2.x ABI version (ncclGetVersion)";
+            return;
+        }
+        g_rccl.ok = true;
     });
     return g_rccl;
 }
@@ -81,7 +96,7 @@ struct hvx_shard_group {
 extern "C" int hvx_shard_group_unique_id(uint8_t *out /*[128]*/) {
     if (!out) return fail(HVX_ERR_INVARIANT, "null argument");
     const Rccl &r = rccl();
-    if (!r.ok) return fail(HVX_ERR_DEVICE, "RCCL is not available (librccl.so.1 could not be loaded)");
+    if (!r.ok) return fail(HVX_ERR_DEVICE, "RCCL is not available: %s", r.why);
     ncclUniqueId id;
     const ncclResult_t e = r.GetUniqueId(&id);
     if (e != ncclSuccess) return fail(HVX_ERR_DEVICE, "ncclGetUniqueId: %s", r.GetErrorString(e));
@@ -89,6 +104,8 @@ extern "C" int hvx_shard_group_unique_id(uint8_t *out /*[128]*/) {
     memcpy(out, &id, sizeof(id));
     return HVX_OK;
 }
+
+extern "C" int hvx_shard_rccl_version(void) { return rccl().ok ? rccl().version : 0; }
 
 extern "C" void hvx_shard_group_free(hvx_shard_group *g) {
     if (!g) return;
@@ -125,7 +142,7 @@ extern "C" int hvx_shard_group_init(hvx_index *local_shard, const uint8_t *uniqu
     }
     if (world > 1) {
         const Rccl &r = rccl();
-        if (!r.ok) { hvx_shard_group_free(g); return fail(HVX_ERR_DEVICE, "RCCL is not available (librccl.so.1 could not be loaded)"); }
+        if (!r.ok) { hvx_shard_group_free(g); return fail(HVX_ERR_DEVICE, "RCCL is not available: %s", r.why); }
         ncclUniqueId id;
         memcpy(&id, unique_id, sizeof(id));
         const ncclResult_t e = r.CommInitRank(&g->comm, (int)world, id, (int)rank);
@@ -328,8 +345,10 @@ extern "C" int hvx_shard_group_search_restricted_batch(hvx_shard_group *g, const
     }
     std::lock_guard<std::mutex> lock(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));
-    int rc = ix->pin(2 * bytes);
+    // stage() may grow (free + reallocate) the pinned mirror as well: it runs BEFORE the pointers into the mirror are taken
+    int rc = ix->stage(b, k);
     if (rc) return rc;
+    if ((rc = ix->pin(2 * bytes))) return rc;
     unsigned char *h_in = ix->h_pin, *h_out = ix->h_pin + bytes;
     memcpy(h_in, l_ids.data(), n_o * 8);
     memcpy(h_in + off_sc, l_sc.data(), n_o * 4);
@@ -340,7 +359,6 @@ extern "C" int hvx_shard_group_search_restricted_batch(hvx_shard_group *g, const
     HIP_TRY(hipMemcpyAsync(v.scores, h_in + off_sc, n_o * 4, hipMemcpyHostToDevice, ix->stream));
     HIP_TRY(hipMemcpyAsync(v.counts, h_in + off_cnt, (size_t)b * 4, hipMemcpyHostToDevice, ix->stream));
     HIP_TRY(hipMemcpyAsync(v.status, h_in + off_st, (size_t)b * 4, hipMemcpyHostToDevice, ix->stream));
-    if ((rc = ix->stage(b, k))) return rc;
     if ((rc = exchange_and_merge(g, b, k, v, ix->s_ids, ix->s_scores, ix->s_counts, ix->s_status))) return rc;
     HIP_TRY(hipMemcpyAsync(h_out, ix->s_ids, n_o * 8, hipMemcpyDeviceToHost, ix->stream));
     HIP_TRY(hipMemcpyAsync(h_out + off_sc, ix->s_scores, n_o * 4, hipMemcpyDeviceToHost, ix->stream));

@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("HVX_LIB_PATH") or os.path.join(os.path.dirname(_HERE)
 
 COSINE, EUCLIDEAN, MANHATTAN = 0, 1, 2
 F32, BF16, FP8_E4M3 = 0, 1, 2
-KERNEL_SCALAR, KERNEL_AVX, KERNEL_AVX_FMA = 0, 2, 3
+KERNEL_SCALAR, KERNEL_SSE, KERNEL_AVX, KERNEL_AVX_FMA, KERNEL_NEON = 0, 1, 2, 3, 4  # hvx_float_kernel == FloatSimd (spaces/simple.rs:45-62)
 OK, ERR_DIMENSION, ERR_NONFINITE, ERR_ZERO_NORM, ERR_MAGNITUDE, ERR_K_RANGE, ERR_CANDIDATE_LIMIT, \
     ERR_DEVICE, ERR_INVARIANT, ERR_UNSUPPORTED = range(10)
 DIR_OUT, DIR_IN, DIR_BOTH = 0, 1, 2
@@ -193,6 +193,16 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise HelixDbError(ERR_DEVICE, f"{LIB_PATH} is missing: run __graft_entry__.build() / make -C helix-db_amd/csrc")
     L = C.CDLL(LIB_PATH)
+    # hardware queues for execution lanes: the host's job since round 5 (the library no longer writes the environment when it is
+    # loaded); this binding is the host, and calls it before anything can have initialised HIP through this library
+    L.hvx_runtime_prepare.restype = C.c_int
+    L.hvx_runtime_prepare.argtypes = [C.c_uint32]
+    if not os.environ.get("HVX_NO_RUNTIME_PREPARE"):
+        L.hvx_runtime_prepare(0)
+    L.hvx_device_stream_read_gbs.restype = C.c_int
+    L.hvx_device_stream_read_gbs.argtypes = [C.c_int32, C.c_uint64, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.hvx_shard_rccl_version.restype = C.c_int
+    L.hvx_shard_rccl_version.argtypes = []
     L.hvx_last_error.restype = C.c_char_p
     L.hvx_version.restype = C.c_char_p
     L.hvx_index_import.restype = C.c_int
@@ -339,6 +349,18 @@ def lib():
     L.hvx_expand_filter.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32, _vp]
     _lib = L
     return L
+
+
+def device_stream_read_gbs(device=0, nbytes=3 << 30, iters=5):
+    """(best, mean) GB/s of the library's read-only streaming kernel over an `nbytes` HBM buffer: the measured roofline denominator"""
+    best, mean = C.c_float(0), C.c_float(0)
+    _check(lib().hvx_device_stream_read_gbs(int(device), int(nbytes), int(iters), C.byref(best), C.byref(mean)))
+    return float(best.value), float(mean.value)
+
+
+def rccl_version():
+    """NCCL_VERSION_CODE of the RCCL the library bound (0 = none / refused)"""
+    return int(lib().hvx_shard_rccl_version())
 
 
 def _sync_producer(t):

@@ -30,7 +30,13 @@ enum hvx_metric { HVX_COSINE_HALF = 0, HVX_L2_SQUARED = 1, HVX_MANHATTAN = 2 };
 enum hvx_dtype { HVX_F32 = 0, HVX_BF16 = 1, HVX_FP8_E4M3 = 2 };
 /* which host summation tree scores must be bit-identical to (spaces/simple.rs:45-112):
  * the reference's result depends on the CPU it runs on; the device reproduces the chosen tree. */
-enum hvx_float_kernel { HVX_KERNEL_SCALAR = 0, HVX_KERNEL_AVX = 2, HVX_KERNEL_AVX_FMA = 3 };
+enum hvx_float_kernel {
+    HVX_KERNEL_SCALAR = 0,  /* FloatSimd::Scalar (feature force-vector-scalar-kernel, or no SIMD unit) */
+    HVX_KERNEL_SSE = 1,     /* FloatSimd::Sse: x86 without AVX -- 4 x 4 lanes, mul then add (simple_sse.rs:17-67), dim >= 16 */
+    HVX_KERNEL_AVX = 2,     /* FloatSimd::Avx: 4 x 8 lanes, mul then add (simple_avx.rs:15-125), dim >= 32 */
+    HVX_KERNEL_AVX_FMA = 3, /* FloatSimd::AvxFma: 4 x 8 lanes, fused (simple_avx.rs:128-238), dim >= 32 */
+    HVX_KERNEL_NEON = 4     /* FloatSimd::Neon: aarch64 -- 4 x 4 lanes, vfmaq_f32 + vaddvq_f32 (simple_neon.rs:10-95), dim >= 16 */
+};
 
 /* HelixDbError variants of the path (crates/db/src/error.rs via search.rs:1101-1230,
  * restricted.rs:196-260,356-371) */
@@ -386,6 +392,10 @@ int hvx_shard_group_search_restricted_batch(hvx_shard_group *, const float *quer
                                             const uint64_t *allowed_ids, uint64_t n_allowed, uint64_t *out_ids /*[b][params->k]*/,
                                             float *out_scores, uint32_t *out_counts, uint32_t *out_status /*nullable*/);
 void hvx_shard_group_free(hvx_shard_group *);
+/* NCCL_VERSION_CODE of the RCCL library bound at run time (e.g. 22203), 0 when none could be loaded or it was refused: the
+ * ncclUniqueId / ncclCommInitRank declarations this library binds are restated for the NCCL 2.x ABI and checked through
+ * ncclGetVersion before the first collective (crates/db has no counterpart: sharding across GPUs is this library's own seam). */
+int hvx_shard_rccl_version(void);
 
 /*
  * Graph prefilter (crates/graph-algorithms/src/model.rs:370-417 Csr; algorithms/traversal.rs:197-318
@@ -468,11 +478,12 @@ int hvx_prefilter_search_batch_params(const hvx_index *, const hvx_csr *, const 
  * Batching operator: the reference calls ValidatedVectorReadIndex::search once per operator invocation
  * from many tokio tasks (access/search/storage.rs:140-163).  Concurrent single-query callers are coalesced into ONE
  * hvx_search_batch_params launch: a caller blocks in hvx_batcher_search until its rows are ready.  A batch is launched when it
- * is full (max_batch, 0 = the index's max_batch, at most 65 535) or when a DISPATCHER LANE IS FREE and the batch has stopped
- * growing: a free lane watches the open batch and takes it once no query has joined for 12 us (the callers of a batch that has
- * just completed come back in a burst: a lane that launched at the first of them would run a handful of queries beside the next
- * lane's hundreds), or once its first query has waited max_wait_us (0 = 200 us).  While every lane is busy the open batch simply
- * keeps growing, so the batch size follows the load.  Result rows are written by the kernels straight into pinned host memory.
+ * is full (max_batch, 0 = the index's max_batch, at most 65 535) or when a DISPATCHER LANE IS FREE and the batch holds as many
+ * queries as that lane EXPECTS: the size of the lane's previous batch (the callers of a batch that has just completed come back
+ * in a burst: a lane that launched at the first of them would run a handful of queries beside the next lane's hundreds), or once
+ * the batch's first query has waited max_wait_us (0 = 200 us).  A lane's first batch -- and a lone caller's every batch --
+ * expects one query and is launched at once; when the load drops, one batch pays max_wait_us and the expectation follows it
+ * down.  While every lane is busy the open batch simply keeps growing, so the batch size follows the load.  Result rows are written by the kernels straight into pinned host memory.
  * All callers of one batcher share `params`.  Thread-safe; results equal a direct batch call's.  A rejected query fails
  * alone.  hvx_batcher_free may be called while callers are blocked: they return HVX_ERR_INVARIANT.
  */
@@ -619,6 +630,21 @@ int hvx_index_graph_sizes(const hvx_index *, uint64_t *l0_edges, uint64_t *up_ro
                           uint32_t *max_layer, uint32_t *has_entry);
 int hvx_index_export_graph(const hvx_index *, uint64_t *l0_offsets, uint64_t *l0_neighbors, uint16_t *level, uint64_t *up_offsets,
                            uint64_t *up_neighbors);
+
+/*
+ * Process-level preparation, called ONCE by the host's single-threaded start-up code before its first HIP call.  The HIP runtime
+ * multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4) and two execution lanes that land on
+ * one queue run back to back; this sets the variable to `hw_queues` (0 = 8) unless the host has already exported a value.  (Up to
+ * round 4 a load-time constructor did this; a library should not write its host's environment behind its back.)
+ */
+int hvx_runtime_prepare(uint32_t hw_queues);
+/*
+ * Roofline denominator ("use the rocprof-measured stream-read peak as the denominator and state both"): times a
+ * read-only streaming kernel (global_load_dwordx4, every byte of a `bytes`-sized HBM buffer read once per launch, nothing written)
+ * `iters` times on `device` and reports the best and the mean rate in GB/s (1e9 bytes).  bytes >= 1 GiB keeps the 256 MB
+ * Infinity Cache out of the number.  Diagnostic: allocates and frees its own buffer.
+ */
+int hvx_device_stream_read_gbs(int32_t device, uint64_t bytes, uint32_t iters, float *out_best_gbs, float *out_mean_gbs);
 
 const char *hvx_last_error(void); /* thread-local */
 const char *hvx_version(void);

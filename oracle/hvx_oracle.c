@@ -231,6 +231,63 @@ float orc_dot_avxfma_hw(const float *a, const float *b, uint32_t n) {
 int orc_have_avxfma_hw(void) { return 0; }
 #endif
 
+/* The SSE kernels (simple_sse.rs:10-67,69-110) executed with the real instructions: every x86-64 host has SSE, so the emulated
+ * 4 x 4-lane tree (simd_tree, width 4, unfused, hsum128) can be pinned against hardware wherever the oracle is built.  (The NEON
+ * tree differs from it only in the fused accumulate -- pinned through the AVX+FMA hardware twin's fmaf semantics -- and in the
+ * pairwise final add, which no x86 instruction reproduces: it stays a restatement of vaddvq_f32's documented order.) */
+#if defined(__SSE__)
+#include <xmmintrin.h>
+static inline float hsum128_sse(__m128 x) { /* simple_sse.rs:10-14 */
+    __m128 x64 = _mm_add_ps(x, _mm_movehl_ps(x, x));
+    __m128 x32 = _mm_add_ss(x64, _mm_shuffle_ps(x64, x64, 0x55));
+    return _mm_cvtss_f32(x32);
+}
+float orc_euclidean_sse_hw(const float *a, const float *b, uint32_t n) {
+    if (n < 16) return l2sq_scalar(a, b, n);
+    uint32_t m = n - (n % 16);
+    __m128 s1 = _mm_setzero_ps(), s2 = s1, s3 = s1, s4 = s1;
+    for (uint32_t i = 0; i < m; i += 16) {
+        __m128 d1 = _mm_sub_ps(_mm_loadu_ps(a + i), _mm_loadu_ps(b + i));
+        s1 = _mm_add_ps(_mm_mul_ps(d1, d1), s1);
+        __m128 d2 = _mm_sub_ps(_mm_loadu_ps(a + i + 4), _mm_loadu_ps(b + i + 4));
+        s2 = _mm_add_ps(_mm_mul_ps(d2, d2), s2);
+        __m128 d3 = _mm_sub_ps(_mm_loadu_ps(a + i + 8), _mm_loadu_ps(b + i + 8));
+        s3 = _mm_add_ps(_mm_mul_ps(d3, d3), s3);
+        __m128 d4 = _mm_sub_ps(_mm_loadu_ps(a + i + 12), _mm_loadu_ps(b + i + 12));
+        s4 = _mm_add_ps(_mm_mul_ps(d4, d4), s4);
+    }
+    float r = hsum128_sse(_mm_add_ps(_mm_add_ps(s1, s2), _mm_add_ps(s3, s4)));
+    for (uint32_t i = m; i < n; ++i) {
+        float d = a[i] - b[i];
+        float p = d * d;
+        r += p;
+    }
+    return r;
+}
+float orc_dot_sse_hw(const float *a, const float *b, uint32_t n) {
+    if (n < 16) return dot_scalar(a, b, n);
+    uint32_t m = n - (n % 16);
+    __m128 s1 = _mm_setzero_ps(), s2 = s1, s3 = s1, s4 = s1;
+    for (uint32_t i = 0; i < m; i += 16) {
+        s1 = _mm_add_ps(_mm_mul_ps(_mm_loadu_ps(a + i), _mm_loadu_ps(b + i)), s1);
+        s2 = _mm_add_ps(_mm_mul_ps(_mm_loadu_ps(a + i + 4), _mm_loadu_ps(b + i + 4)), s2);
+        s3 = _mm_add_ps(_mm_mul_ps(_mm_loadu_ps(a + i + 8), _mm_loadu_ps(b + i + 8)), s3);
+        s4 = _mm_add_ps(_mm_mul_ps(_mm_loadu_ps(a + i + 12), _mm_loadu_ps(b + i + 12)), s4);
+    }
+    float r = hsum128_sse(_mm_add_ps(_mm_add_ps(s1, s2), _mm_add_ps(s3, s4)));
+    for (uint32_t i = m; i < n; ++i) {
+        float p = a[i] * b[i];
+        r += p;
+    }
+    return r;
+}
+int orc_have_sse_hw(void) { return 1; }
+#else
+float orc_euclidean_sse_hw(const float *a, const float *b, uint32_t n) { (void)a; (void)b; (void)n; return NAN; }
+float orc_dot_sse_hw(const float *a, const float *b, uint32_t n) { (void)a; (void)b; (void)n; return NAN; }
+int orc_have_sse_hw(void) { return 0; }
+#endif
+
 /* distance/cosine.rs:12-36 scaled_l2_norm */
 double orc_scaled_l2_norm(const float *v, uint32_t n) {
     double scale = 0.0, scaled_sum = 1.0;

@@ -62,6 +62,10 @@ float orc_manhattan(const float *a, const float *b, uint32_t n);
 float orc_euclidean_avxfma_hw(const float *a, const float *b, uint32_t n);
 float orc_dot_avxfma_hw(const float *a, const float *b, uint32_t n);
 int orc_have_avxfma_hw(void);
+/* hardware SSE twin of ORC_KERNEL_SSE (simple_sse.rs executed with the real instructions; NAN / 0 when the host has no SSE) */
+float orc_euclidean_sse_hw(const float *a, const float *b, uint32_t n);
+float orc_dot_sse_hw(const float *a, const float *b, uint32_t n);
+int orc_have_sse_hw(void);
 
 double orc_scaled_l2_norm(const float *v, uint32_t n);                 /* distance/cosine.rs:12-36 */
 float orc_header(int metric, const float *v, uint32_t n);              /* new_header            */

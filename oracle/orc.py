@@ -194,6 +194,11 @@ def lib():
     L.orc_euclidean_avxfma_hw.argtypes = [f32p, f32p, C.c_uint32]
     L.orc_dot_avxfma_hw.restype = C.c_float
     L.orc_dot_avxfma_hw.argtypes = [f32p, f32p, C.c_uint32]
+    L.orc_euclidean_sse_hw.restype = C.c_float
+    L.orc_euclidean_sse_hw.argtypes = [f32p, f32p, C.c_uint32]
+    L.orc_dot_sse_hw.restype = C.c_float
+    L.orc_dot_sse_hw.argtypes = [f32p, f32p, C.c_uint32]
+    L.orc_have_sse_hw.restype = C.c_int
     L.orc_have_avxfma_hw.restype = C.c_int
     L.orc_scaled_l2_norm.restype = C.c_double
     L.orc_scaled_l2_norm.argtypes = [f32p, C.c_uint32]

@@ -30,6 +30,7 @@ template <typename T> static std::vector<T> load(const std::string &path) {
 
 int main(int argc, char **argv) {
     if (argc < 4) { fprintf(stderr, "usage: %s <dir> <threads> <queries per thread> [strict|default] [lanes]\n", argv[0]); return 2; }
+    hvx_runtime_prepare(0); // hardware queues for the dispatcher lanes: before the process's first HIP call (include/helix_vec.h)
     const std::string dir = argv[1];
     const int threads = atoi(argv[2]), per = atoi(argv[3]);
     const bool strict = argc > 4 && !strcmp(argv[4], "strict");

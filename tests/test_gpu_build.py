@@ -63,11 +63,15 @@ def test_sequential_device_build_equals_the_oracles_insertion_row_for_row(orc, h
                                                         (1000, 48, 2, 8, 16, 50, "avx_fma"),    # Manhattan: sequential order everywhere
                                                         (900, 200, 0, 8, 16, 60, "avx"),        # cosine, AVX tree without FMA
                                                         (700, 36, 1, 6, 12, 40, "scalar"),      # scalar kernel
-                                                        (600, 128, 1, 16, 32, 400, "avx_fma")]) # ef_construction beyond the unrolled beams
+                                                        (600, 128, 1, 16, 32, 400, "avx_fma"),  # ef_construction beyond the unrolled beams
+                                                        (800, 88, 1, 8, 16, 60, "neon"),        # aarch64 hosts: 4 x 4 lanes fused, vaddvq (80 + 8 tail)
+                                                        (800, 72, 0, 8, 16, 60, "sse"),         # x86 without AVX: 4 x 4 lanes, mul then add
+                                                        (600, 256, 0, 16, 32, 80, "neon")])     # an unrolled SHAPE under a 128-bit tree: generic kernels
 def test_sequential_device_build_of_generic_shapes_equals_the_oracle(orc, hv, n, dim, metric, m, m0, efc, kern):
     """VERDICT r2 missing #3: insert_hnsw (mutation.rs:787-895) works for any dimension, metric and M; the device build now
     does too (GENERIC build of the search kernel, select / link kernels per metric and summation tree): row for row."""
-    ok, hk = {"avx_fma": (orc.K_AVX_FMA, hv.KERNEL_AVX_FMA), "avx": (orc.K_AVX, hv.KERNEL_AVX), "scalar": (orc.K_SCALAR, hv.KERNEL_SCALAR)}[kern]
+    ok, hk = {"avx_fma": (orc.K_AVX_FMA, hv.KERNEL_AVX_FMA), "avx": (orc.K_AVX, hv.KERNEL_AVX), "scalar": (orc.K_SCALAR, hv.KERNEL_SCALAR),
+              "sse": (orc.K_SSE, hv.KERNEL_SSE), "neon": (orc.K_NEON, hv.KERNEL_NEON)}[kern]
     rng = np.random.default_rng(7100 + dim + metric + n)
     data = rng.standard_normal((n, dim)).astype(np.float32)
     lv = fx.draw_levels(n, m, seed=n)

@@ -68,6 +68,28 @@ def test_portable_avxfma_emulation_equals_hardware_intrinsics(orc):
             assert bits(hw_d) == bits(orc.dot(a, b, orc.K_AVX_FMA))
 
 
+def test_portable_sse_emulation_equals_hardware_intrinsics(orc):
+    """Round 5: the device now carries the 128-bit trees (FloatSimd::Sse / ::Neon) and is held to the oracle's emulation of them.
+    The SSE tree (simple_sse.rs:10-110: 4 x 4 lanes, mul then add, hsum128 = x + movehl, lane 0 + lane 1) is pinned here against the
+    real SSE instructions; the NEON tree shares its accumulation layout, with fmaf (pinned by the AVX+FMA hardware twin) and the
+    pairwise vaddvq final add (restated)."""
+    if not orc.lib().orc_have_sse_hw():
+        pytest.skip("oracle built without SSE")
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    for n in (15, 16, 17, 31, 32, 40, 70, 88, 128, 200, 768, 1000, 1536):
+        for _ in range(20):
+            a = rng.standard_normal(n).astype(np.float32)
+            b = rng.standard_normal(n).astype(np.float32)
+            pa = a.ctypes.data_as(C.POINTER(C.c_float)); pb = b.ctypes.data_as(C.POINTER(C.c_float))
+            assert bits(np.float32(orc.lib().orc_euclidean_sse_hw(pa, pb, n))) == bits(orc.euclidean(a, b, orc.K_SSE))
+            assert bits(np.float32(orc.lib().orc_dot_sse_hw(pa, pb, n))) == bits(orc.dot(a, b, orc.K_SSE))
+    # the two 128-bit trees are different functions (fused accumulate, pairwise final add): some input must tell them apart
+    a = rng.standard_normal(768).astype(np.float32); b = rng.standard_normal(768).astype(np.float32)
+    diff = sum(bits(orc.euclidean(a * s_, b, orc.K_SSE)) != bits(orc.euclidean(a * s_, b, orc.K_NEON)) for s_ in np.linspace(0.5, 2.0, 40, dtype=np.float32))
+    assert diff > 0
+
+
 def test_kernel_dispatch_thresholds(orc):
     """spaces/simple.rs:32,43,127-143: AVX needs n>=32, SSE/NEON n>=16, else scalar."""
     rng = np.random.default_rng(3)

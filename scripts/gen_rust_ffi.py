@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Rust `extern "C"` declarations for EVERY function include/helix_vec.h declares (INTEGRATION.md section 2 is this script's
 output; tests/test_abi_and_host.py parses that block again and holds it to the header: names, arity, argument types).
-usage: gen_rust_ffi.py [--check INTEGRATION.md]"""
+usage: gen_rust_ffi.py [--check INTEGRATION.md | --update INTEGRATION.md]"""
 import os
 import re
 import sys
@@ -129,4 +129,15 @@ if __name__ == "__main__":
         wrong = sorted(n for n in want if n in got and got[n] != want[n])
         print(f"{len(want)} prototypes in the header, {len(got)} declared in {sys.argv[2]}; missing {missing}; differing {wrong}")
         sys.exit(1 if missing or wrong else 0)
+    if len(sys.argv) > 2 and sys.argv[1] == "--update":  # rewrite the body of the extern block in place
+        doc = open(sys.argv[2]).read()
+        start = doc.index('#[link(name = "helix_vec_gfx950")]')
+        body0 = doc.index("{\n", start) + 2
+        body1 = doc.index("\n}", body0)
+        doc = doc[:body0] + rust_block(hdr) + doc[body1:]
+        n = len(c_prototypes(hdr))
+        doc = re.sub(r"// EVERY function the library exports \(\d+\)", f"// EVERY function the library exports ({n})", doc)
+        open(sys.argv[2], "w").write(doc)
+        print(f"{sys.argv[2]}: extern block rewritten with {n} declarations")
+        sys.exit(0)
     print(rust_block(hdr))

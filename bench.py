@@ -980,6 +980,11 @@ def leg_batcher(x_host, q_host, g, m, callers=1024, per_caller=300, lanes=3):
         pd = one("default", 4, {"BATCHER_OCC": "2"})
         res["production_default"] = pd
         res["qps_production_default"] = pd.get("qps")
+        # the non-blocking form (round 5): 8 submitter threads x 128 tickets in flight, asleep in poll(2) on the batcher's eventfd
+        nb = one("strict", lanes, {"BATCHER_NB": "8x128"})
+        nb["how"] = "hvx_batcher_submit / hvx_batcher_poll + eventfd, 8 submitter threads x 128 tickets in flight (1 024 queries in flight, as the blocking run)"
+        res["nonblocking"] = nb
+        res["qps_nonblocking"] = nb.get("qps")
         return res
     finally:
         shutil.rmtree(d, ignore_errors=True)

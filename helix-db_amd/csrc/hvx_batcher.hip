@@ -39,6 +39,7 @@
 //   * hvx_batcher_lane_times reports where the lanes' time went.
 #include <hip/hip_runtime.h>
 #include <linux/futex.h>
+#include <sys/eventfd.h>
 #include <sys/prctl.h>
 #include <sys/syscall.h>
 #include <time.h>
@@ -150,11 +151,13 @@ struct hvx_batcher {
     std::vector<Batch> bufs;
     std::vector<Lane> lanes;
     std::atomic<uint64_t> n_batches{0}, n_queries{0}, n_full{0};
+    std::atomic<int> efd{-1};                        // hvx_batcher_eventfd: written once per completed batch (non-blocking hosts)
 
     void run(Lane &ln) {
         (void)hipSetDevice(device);
         (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0); // this thread's timed sleeps end within ~1 us of their time (default slack: 50 us)
         const int64_t max_wait_ns = (int64_t)(max_wait_us ? max_wait_us : 200u) * 1000;
+        uint32_t stop_spins = 0;
         uint32_t expect = 1; // queries the open batch should hold before this lane takes it: the size of the lane's previous batch
         uint64_t seen_seq = ~0ull, seen_us = 0; // when THIS lane first saw the open batch non-empty (the fallback age base)
         // microseconds the open batch's first query has waited: by its caller's stamp when it carries this batch's tag, else since
@@ -210,6 +213,9 @@ struct hvx_batcher {
             // 5 ms and either takes its rows or leaves with its slot accounted for)
             if (seq + 1 >= nbuf) { // its previous batch (sequence seq + 1 - nbuf) must be complete and fully drained
                 if (next.done.load() != (uint32_t)(seq + 1 - nbuf + 1) || next.consumed_sum() != next.total) {
+                    // stopping, and that buffer is held by tickets nobody will poll any more (a non-blocking host that went away): the
+                    // open batch is not launched -- its callers leave with "shutting down" like everybody else (0.2 s of grace)
+                    if (stop.load() && ++stop_spins > 20000u) return;
                     sleep_us(10); // (a caller of that batch has not copied its rows out yet)
                     lap(ln.ns_drain);
                     continue;
@@ -250,10 +256,15 @@ struct hvx_batcher {
     }
 
     // publish a finished batch: results are in its pinned rows
-    static void complete(Batch &bt, uint32_t want) {
+    void complete(Batch &bt, uint32_t want) {
         bt.done.store(want);
         for (Batch::Group &g : bt.grp) g.word.store(want);
         for (Batch::Group &g : bt.grp) futex_wake(&g.word, 1);
+        const int fd = efd.load(std::memory_order_acquire);
+        if (fd >= 0) { // a reactor-driven host: one eventfd tick per completed batch (the host then polls its tickets)
+            const uint64_t one = 1;
+            (void)!write(fd, &one, sizeof(one));
+        }
     }
 
     void wake_loop(Lane &ln) {
@@ -319,6 +330,7 @@ extern "C" void hvx_batcher_free(hvx_batcher *b) {
     for (Batch &bt : b->bufs)
         for (void *p : {(void *)bt.q, (void *)bt.ids, (void *)bt.sc, (void *)bt.cnt, (void *)bt.st})
             if (p) (void)hipHostFree(p);
+    if (b->efd.load() >= 0) (void)close(b->efd.load());
     delete b;
 }
 
@@ -380,26 +392,28 @@ extern "C" int hvx_batcher_new(hvx_index *ix, const hvx_search_params *params, u
     return hvx_batcher_new_lanes(ix, params, max_batch, max_wait_us, 0, out);
 }
 
-static int batcher_search_inner(hvx_batcher *b, const float *query, uint64_t *out_ids, float *out_scores, uint32_t *out_count);
-extern "C" int hvx_batcher_search(hvx_batcher *b, const float *query, uint64_t *out_ids, float *out_scores, uint32_t *out_count) {
-    if (!b || !query || !out_ids || !out_scores || !out_count) return fail(HVX_ERR_INVARIANT, "null argument");
-    static std::atomic<uint32_t> next_stripe{0};
-    thread_local const uint32_t stripe = next_stripe.fetch_add(1, std::memory_order_relaxed) & 63u;
-    b->inside[stripe].n.fetch_add(1);
-    const int rc = batcher_search_inner(b, query, out_ids, out_scores, out_count);
-    b->inside[stripe].n.fetch_sub(1);
-    return rc;
-}
-static int batcher_search_inner(hvx_batcher *b, const float *query, uint64_t *out_ids, float *out_scores, uint32_t *out_count) {
-    *out_count = 0;
-    // claim a slot of the open batch
-    uint64_t seq;
-    uint32_t slot;
+namespace {
+struct Inside { // callers inside an entry point, striped by thread (hvx_batcher_free waits for them)
+    hvx_batcher *b;
+    uint32_t stripe;
+    explicit Inside(hvx_batcher *bb) : b(bb) {
+        static std::atomic<uint32_t> next_stripe{0};
+        thread_local const uint32_t mine = next_stripe.fetch_add(1, std::memory_order_relaxed) & 63u;
+        stripe = mine;
+        b->inside[stripe].n.fetch_add(1);
+    }
+    ~Inside() { b->inside[stripe].n.fetch_sub(1); }
+};
+
+// claim a slot of the open batch: one fetch-and-add.  blocking = false: a full batch returns HVX_ERR_BUSY instead of waiting for the
+// next one to open (a free lane closes the full batch within microseconds: the host retries after its next completion or yield).
+int claim_slot(hvx_batcher *b, bool blocking, uint64_t *seq_out, uint32_t *slot_out) {
     for (;;) {
         if (b->stop.load(std::memory_order_acquire)) return fail(HVX_ERR_INVARIANT, "batcher is shutting down");
         uint64_t s = b->state.load();
-        seq = s >> kSeqShift;
+        uint64_t seq = s >> kSeqShift;
         if ((uint32_t)(s & kCountMask) >= b->max_batch) { // full: a lane closes it as soon as one is free; wait for the next batch to open
+            if (!blocking) return fail(HVX_ERR_BUSY, "the open batch is full: submit again after a completion");
             futex_wait(&b->seq_word, (uint32_t)seq, 2000); // (woken by the close; the time-out is a safety net, not a poll)
             continue;
         }
@@ -409,10 +423,15 @@ static int batcher_search_inner(hvx_batcher *b, const float *query, uint64_t *ou
         // filled between the load and the add) is void: the dispatcher counts min(claims, max_batch), and the caller tries the next batch.
         s = b->state.fetch_add(1);
         seq = s >> kSeqShift;
-        slot = (uint32_t)(s & kCountMask);
-        if (slot < b->max_batch) break;
+        const uint32_t slot = (uint32_t)(s & kCountMask);
+        if (slot < b->max_batch) { *seq_out = seq; *slot_out = slot; return HVX_OK; }
+        if (!blocking) return fail(HVX_ERR_BUSY, "the open batch is full: submit again after a completion");
         futex_wait(&b->seq_word, (uint32_t)seq, 2000);
     }
+}
+
+// copy the query into the batch's pinned staging row and tell the lanes
+void fill_slot(hvx_batcher *b, uint64_t seq, uint32_t slot, const float *query) {
     Batch &bt = b->bufs[seq % b->nbuf];
     if (slot == 0) bt.t_first.store(((seq & 0xFFFFFull) << 44) | now_us_stamp(), std::memory_order_relaxed);
     memcpy(bt.q + (size_t)slot * b->dim, query, (size_t)b->dim * 4);
@@ -421,18 +440,13 @@ static int batcher_search_inner(hvx_batcher *b, const float *query, uint64_t *ou
         b->bell.fetch_add(1);
         futex_wake(&b->bell, INT_MAX); // (at most 8 lanes; each looks at the batch and goes back to sleep if it is not the one to take it)
     }
-    // wait for the batch
-    const uint32_t want = (uint32_t)(seq + 1);
+}
+
+// the batch is complete: hand the slot's rows to the caller and release the slot
+int take_result(hvx_batcher *b, uint64_t seq, uint32_t slot, uint64_t *out_ids, float *out_scores, uint32_t *out_count) {
+    Batch &bt = b->bufs[seq % b->nbuf];
     Batch::Group &grp = bt.grp[slot % Batch::kGroups];
-    for (;;) {
-        const uint32_t d = grp.word.load(std::memory_order_acquire);
-        if (d == want) break;
-        futex_wait(&grp.word, d, 5000);
-        if (b->stop.load(std::memory_order_acquire) && grp.word.load(std::memory_order_acquire) != want) {
-            grp.consumed.fetch_add(1); // the slot is accounted for: a dispatcher draining this buffer must not wait for it
-            return fail(HVX_ERR_INVARIANT, "batcher is shutting down");
-        }
-    }
+    const uint32_t want = (uint32_t)(seq + 1);
     // the first caller of the group to get here passes the wake on to the group's other sleepers (nobody can fall asleep on the
     // word any more: it already holds `want`)
     if (grp.relay.exchange(want, std::memory_order_acq_rel) != want) futex_wake(&grp.word, INT_MAX);
@@ -450,6 +464,103 @@ static int batcher_search_inner(hvx_batcher *b, const float *query, uint64_t *ou
     grp.consumed.fetch_add(1);
     if (rc) return err.empty() ? fail(rc, "query rejected with status %u", st) : fail(rc, "%s", err.c_str());
     return HVX_OK;
+}
+
+// block until the slot's batch is complete (timeout_us < 0: for ever); HVX_PENDING on time-out
+int await_slot(hvx_batcher *b, uint64_t seq, uint32_t slot, long timeout_us) {
+    Batch &bt = b->bufs[seq % b->nbuf];
+    Batch::Group &grp = bt.grp[slot % Batch::kGroups];
+    const uint32_t want = (uint32_t)(seq + 1);
+    const int64_t t_end = timeout_us >= 0 ? now_ns() + (int64_t)timeout_us * 1000 : 0;
+    for (;;) {
+        const uint32_t d = grp.word.load(std::memory_order_acquire);
+        if (d == want) return HVX_OK;
+        long wait_us = 5000;
+        if (timeout_us >= 0) {
+            const int64_t left = (t_end - now_ns()) / 1000;
+            if (left <= 0) return HVX_PENDING;
+            wait_us = left < wait_us ? (long)left : wait_us;
+        }
+        futex_wait(&grp.word, d, wait_us);
+        if (b->stop.load(std::memory_order_acquire) && grp.word.load(std::memory_order_acquire) != want) {
+            grp.consumed.fetch_add(1); // the slot is accounted for: a dispatcher draining this buffer must not wait for it
+            return fail(HVX_ERR_INVARIANT, "batcher is shutting down");
+        }
+    }
+}
+
+inline bool ticket_ok(const hvx_batcher *b, const hvx_batcher_ticket *t) { return t && t->slot < b->max_batch; }
+} // namespace
+
+// The blocking call = submit + wait (ValidatedVectorReadIndex::search awaited to completion, read_index.rs:81-102).
+extern "C" int hvx_batcher_search(hvx_batcher *b, const float *query, uint64_t *out_ids, float *out_scores, uint32_t *out_count) {
+    if (!b || !query || !out_ids || !out_scores || !out_count) return fail(HVX_ERR_INVARIANT, "null argument");
+    Inside in(b);
+    *out_count = 0;
+    uint64_t seq;
+    uint32_t slot;
+    int rc = claim_slot(b, /*blocking=*/true, &seq, &slot);
+    if (rc) return rc;
+    fill_slot(b, seq, slot, query);
+    if ((rc = await_slot(b, seq, slot, -1))) return rc;
+    return take_result(b, seq, slot, out_ids, out_scores, out_count);
+}
+
+// ---- the non-blocking form (round 5): `search` is an async fn called from tokio tasks (read_index.rs:81-102); a task must not park
+//      an OS thread per query in flight.  submit claims a slot and copies the query in (no syscall on the fast path), poll tests one
+//      futex word, and hvx_batcher_eventfd hands the host an fd its reactor can await: one tick per completed batch. ----
+extern "C" int hvx_batcher_submit(hvx_batcher *b, const float *query, hvx_batcher_ticket *out_ticket) {
+    if (!b || !query || !out_ticket) return fail(HVX_ERR_INVARIANT, "null argument");
+    Inside in(b);
+    uint64_t seq;
+    uint32_t slot;
+    const int rc = claim_slot(b, /*blocking=*/false, &seq, &slot);
+    if (rc) return rc;
+    fill_slot(b, seq, slot, query);
+    out_ticket->sequence = seq;
+    out_ticket->slot = slot;
+    out_ticket->reserved = 0;
+    return HVX_OK;
+}
+
+extern "C" int hvx_batcher_poll(hvx_batcher *b, const hvx_batcher_ticket *ticket, uint64_t *out_ids, float *out_scores, uint32_t *out_count) {
+    if (!b || !out_ids || !out_scores || !out_count || !ticket_ok(b, ticket)) return fail(HVX_ERR_INVARIANT, "null argument or malformed ticket");
+    Inside in(b);
+    Batch &bt = b->bufs[ticket->sequence % b->nbuf];
+    Batch::Group &grp = bt.grp[ticket->slot % Batch::kGroups];
+    if (grp.word.load(std::memory_order_acquire) != (uint32_t)(ticket->sequence + 1)) {
+        if (b->stop.load(std::memory_order_acquire)) {
+            grp.consumed.fetch_add(1);
+            return fail(HVX_ERR_INVARIANT, "batcher is shutting down");
+        }
+        return HVX_PENDING; // (not an error: hvx_last_error is left alone)
+    }
+    *out_count = 0;
+    return take_result(b, ticket->sequence, ticket->slot, out_ids, out_scores, out_count);
+}
+
+extern "C" int hvx_batcher_wait(hvx_batcher *b, const hvx_batcher_ticket *ticket, uint32_t timeout_us, uint64_t *out_ids, float *out_scores,
+                                uint32_t *out_count) {
+    if (!b || !out_ids || !out_scores || !out_count || !ticket_ok(b, ticket)) return fail(HVX_ERR_INVARIANT, "null argument or malformed ticket");
+    Inside in(b);
+    *out_count = 0;
+    const int rc = await_slot(b, ticket->sequence, ticket->slot, timeout_us == 0xFFFFFFFFu ? -1 : (long)timeout_us);
+    if (rc) return rc; // HVX_PENDING on time-out: the ticket stays valid
+    return take_result(b, ticket->sequence, ticket->slot, out_ids, out_scores, out_count);
+}
+
+extern "C" int hvx_batcher_eventfd(hvx_batcher *b) {
+    if (!b) { (void)fail(HVX_ERR_INVARIANT, "null argument"); return -1; }
+    int fd = b->efd.load(std::memory_order_acquire);
+    if (fd >= 0) return fd;
+    const int made = eventfd(0, EFD_NONBLOCK | EFD_CLOEXEC);
+    if (made < 0) { (void)fail(HVX_ERR_DEVICE, "eventfd failed"); return -1; }
+    int expected = -1;
+    if (!b->efd.compare_exchange_strong(expected, made)) { // another thread created it first
+        (void)close(made);
+        return expected;
+    }
+    return made;
 }
 
 extern "C" int hvx_batcher_stats(const hvx_batcher *cb, uint64_t *batches, uint64_t *queries, uint64_t *full_batches) {

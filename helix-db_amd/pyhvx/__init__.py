@@ -23,7 +23,7 @@ COSINE, EUCLIDEAN, MANHATTAN = 0, 1, 2
 F32, BF16, FP8_E4M3 = 0, 1, 2
 KERNEL_SCALAR, KERNEL_SSE, KERNEL_AVX, KERNEL_AVX_FMA, KERNEL_NEON = 0, 1, 2, 3, 4  # hvx_float_kernel == FloatSimd (spaces/simple.rs:45-62)
 OK, ERR_DIMENSION, ERR_NONFINITE, ERR_ZERO_NORM, ERR_MAGNITUDE, ERR_K_RANGE, ERR_CANDIDATE_LIMIT, \
-    ERR_DEVICE, ERR_INVARIANT, ERR_UNSUPPORTED = range(10)
+    ERR_DEVICE, ERR_INVARIANT, ERR_UNSUPPORTED, PENDING, ERR_BUSY = range(12)
 DIR_OUT, DIR_IN, DIR_BOTH = 0, 1, 2
 
 _STATUS_NAMES = {
@@ -181,6 +181,10 @@ class RestrictedStats(C.Structure):  # hvx_restricted_stats: RestrictedSearchSta
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class BatcherTicket(C.Structure):  # hvx_batcher_ticket
+    _fields_ = [("sequence", C.c_uint64), ("slot", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 _lib = None
 _vp = C.c_void_p
 
@@ -328,6 +332,14 @@ def lib():
     L.hvx_batcher_free.argtypes = [_vp]
     L.hvx_batcher_search.restype = C.c_int
     L.hvx_batcher_search.argtypes = [_vp, _vp, _vp, _vp, C.POINTER(C.c_uint32)]
+    L.hvx_batcher_submit.restype = C.c_int
+    L.hvx_batcher_submit.argtypes = [_vp, _vp, C.POINTER(BatcherTicket)]
+    L.hvx_batcher_poll.restype = C.c_int
+    L.hvx_batcher_poll.argtypes = [_vp, C.POINTER(BatcherTicket), _vp, _vp, C.POINTER(C.c_uint32)]
+    L.hvx_batcher_wait.restype = C.c_int
+    L.hvx_batcher_wait.argtypes = [_vp, C.POINTER(BatcherTicket), C.c_uint32, _vp, _vp, C.POINTER(C.c_uint32)]
+    L.hvx_batcher_eventfd.restype = C.c_int
+    L.hvx_batcher_eventfd.argtypes = [_vp]
     L.hvx_batcher_stats.restype = C.c_int
     L.hvx_batcher_stats.argtypes = [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.hvx_batcher_lane_times.restype = C.c_int
@@ -923,6 +935,40 @@ class Batcher:
         ids = np.zeros(self.k, np.uint64); sc = np.zeros(self.k, np.float32); cnt = C.c_uint32(0)
         _check(lib().hvx_batcher_search(self._h, _ptr(q), _ptr(ids), _ptr(sc), C.byref(cnt)))
         return [SearchResult(int(i), s) for i, s in zip(ids[: cnt.value], sc[: cnt.value])]
+
+    # ---- the non-blocking form (hvx_batcher_submit / _poll / _wait / _eventfd) ----
+    def submit(self, query):
+        """-> ticket, or None when the open batch is full (HVX_ERR_BUSY: submit again after a completion)"""
+        q = np.ascontiguousarray(query, dtype=np.float32).reshape(-1)
+        if q.size != self._index.dim:
+            raise HelixDbError(ERR_DIMENSION, f"expected dimension {self._index.dim}, got {q.size}")
+        t = BatcherTicket()
+        rc = lib().hvx_batcher_submit(self._h, _ptr(q), C.byref(t))
+        if rc == ERR_BUSY:
+            return None
+        _check(rc)
+        return t
+
+    def _take(self, rc, ids, sc, cnt):
+        if rc == PENDING:
+            return None
+        _check(rc)
+        return [SearchResult(int(i), s) for i, s in zip(ids[: cnt.value], sc[: cnt.value])]
+
+    def poll(self, ticket):
+        """-> results, or None while the ticket's batch is in flight; raises the query's own rejection"""
+        ids = np.zeros(self.k, np.uint64); sc = np.zeros(self.k, np.float32); cnt = C.c_uint32(0)
+        return self._take(lib().hvx_batcher_poll(self._h, C.byref(ticket), _ptr(ids), _ptr(sc), C.byref(cnt)), ids, sc, cnt)
+
+    def wait(self, ticket, timeout_us=0xFFFFFFFF):
+        ids = np.zeros(self.k, np.uint64); sc = np.zeros(self.k, np.float32); cnt = C.c_uint32(0)
+        return self._take(lib().hvx_batcher_wait(self._h, C.byref(ticket), int(timeout_us), _ptr(ids), _ptr(sc), C.byref(cnt)), ids, sc, cnt)
+
+    def eventfd(self):
+        fd = lib().hvx_batcher_eventfd(self._h)
+        if fd < 0:
+            raise HelixDbError(ERR_DEVICE, lib().hvx_last_error().decode())
+        return fd
 
     def stats(self):
         a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)

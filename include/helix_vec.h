@@ -50,7 +50,9 @@ enum hvx_status {
     HVX_ERR_CANDIDATE_LIMIT = 6, /* >1,000,000 restricted candidates       restricted.rs:40,356-371 */
     HVX_ERR_DEVICE = 7,          /* HIP failure / extension unavailable */
     HVX_ERR_INVARIANT = 8,       /* InvariantViolation (bad graph row, invalid score, ...) */
-    HVX_ERR_UNSUPPORTED = 9      /* configuration outside what this build implements */
+    HVX_ERR_UNSUPPORTED = 9,     /* configuration outside what this build implements */
+    HVX_PENDING = 10,            /* NOT an error: hvx_batcher_poll / _wait -- the ticket's batch has not completed yet */
+    HVX_ERR_BUSY = 11            /* hvx_batcher_submit would have to block (the open batch is full): submit again later */
 };
 
 enum hvx_direction { HVX_DIR_OUT = 0, HVX_DIR_IN = 1, HVX_DIR_BOTH = 2 };
@@ -496,6 +498,29 @@ int hvx_batcher_new_lanes(hvx_index *, const hvx_search_params *params, uint32_t
 void hvx_batcher_free(hvx_batcher *);
 int hvx_batcher_search(hvx_batcher *, const float *query /*[dim]*/, uint64_t *out_ids /*[k]*/, float *out_scores /*[k]*/,
                        uint32_t *out_count);
+/*
+ * The non-blocking form (ValidatedVectorReadIndex::search is an `async fn` called from tokio tasks, read_index.rs:81-102: a task
+ * must not park an OS thread for every query in flight).  hvx_batcher_submit claims a slot of the open batch and copies the query
+ * into its pinned staging row -- no system call on the fast path -- and returns at once: HVX_OK + a ticket, or HVX_ERR_BUSY when
+ * the open batch is full (a free lane closes it within microseconds: submit again after the next completion / yield).
+ * hvx_batcher_poll tests the ticket: HVX_PENDING while its batch is in flight, else the rows are copied out and the ticket is
+ * CONSUMED (HVX_OK, or the query's own rejection status); a ticket must be polled / waited to completion exactly once -- a batch
+ * buffer is reused only after every one of its tickets has been consumed.  hvx_batcher_wait blocks up to timeout_us (0xFFFFFFFF =
+ * for ever; HVX_PENDING on time-out, the ticket stays valid).  hvx_batcher_eventfd returns an eventfd (created on first use, owned
+ * by the batcher, EFD_NONBLOCK) that receives one tick per completed batch: the host registers it with its reactor (tokio
+ * AsyncFd / epoll), reads it when it fires and polls its outstanding tickets -- INTEGRATION.md 4c.  hvx_batcher_search is
+ * submit + wait.
+ */
+typedef struct hvx_batcher_ticket {
+    uint64_t sequence; /* batch the query rides in */
+    uint32_t slot;     /* its row in that batch */
+    uint32_t reserved;
+} hvx_batcher_ticket;
+int hvx_batcher_submit(hvx_batcher *, const float *query /*[dim]*/, hvx_batcher_ticket *out_ticket);
+int hvx_batcher_poll(hvx_batcher *, const hvx_batcher_ticket *ticket, uint64_t *out_ids /*[k]*/, float *out_scores /*[k]*/, uint32_t *out_count);
+int hvx_batcher_wait(hvx_batcher *, const hvx_batcher_ticket *ticket, uint32_t timeout_us, uint64_t *out_ids /*[k]*/, float *out_scores /*[k]*/,
+                     uint32_t *out_count);
+int hvx_batcher_eventfd(hvx_batcher *); /* -1 on failure */
 int hvx_batcher_stats(const hvx_batcher *, uint64_t *batches, uint64_t *queries, uint64_t *full_batches);
 /* where the dispatcher lanes' time went since creation, summed over the lanes (nanoseconds): asleep with nothing to do, watching
  * an open batch grow, waiting for a batch buffer's previous callers to take their rows, waiting for callers to finish copying

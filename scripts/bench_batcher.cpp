@@ -4,6 +4,9 @@
 //   g++ -O2 -std=c++17 -I include scripts/bench_batcher.cpp -o scripts/_bin/bench_batcher \
 //       -L helix-db_amd -lhelix_vec_gfx950 -Wl,-rpath,$PWD/helix-db_amd -lpthread
 //   scripts/_bin/bench_batcher <dir with the arrays written by scripts/bench_batcher.py> <threads> <queries per thread>
+#include <poll.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -98,6 +101,62 @@ int main(int argc, char **argv) {
         *p99_us = all[(size_t)(all.size() * 0.99)];
         if (failures) fprintf(stderr, "%d failed calls\n", failures.load());
     };
+    // the non-blocking form (hvx_batcher_submit / _poll + eventfd): `subs` submitter threads, each keeping up to `window` tickets in
+    // flight and sleeping in poll(2) on the batcher's eventfd between completions -- what a tokio reactor does with AsyncFd
+    auto run_nb = [&](hvx_batcher *bt, int subs, int window, long total, double *qps, double *mean_us, double *p99_us) {
+        const int fd = hvx_batcher_eventfd(bt);
+        std::vector<std::vector<double>> lat(subs);
+        std::atomic<int> failures{0};
+        std::atomic<long> busy{0};
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<std::thread> th;
+        for (int t = 0; t < subs; ++t)
+            th.emplace_back([&, t] {
+                const long quota = total / subs;
+                std::vector<hvx_batcher_ticket> tk(window);
+                std::vector<std::chrono::steady_clock::time_point> ts(window);
+                std::vector<char> live(window, 0);
+                std::vector<uint64_t> oi(k);
+                std::vector<float> os(k);
+                long issued = 0, done = 0;
+                int inflight = 0;
+                lat[t].reserve(quota);
+                while (done < quota) {
+                    for (int w = 0; w < window && issued < quota && inflight < window; ++w) {
+                        if (live[w]) continue;
+                        const float *q = qs.data() + (size_t)((t * quota + issued) % nq) * dim;
+                        ts[w] = std::chrono::steady_clock::now();
+                        const int rc = hvx_batcher_submit(bt, q, &tk[w]);
+                        if (rc == HVX_ERR_BUSY) { busy++; break; }
+                        if (rc) { failures++; break; }
+                        live[w] = 1; ++inflight; ++issued;
+                    }
+                    pollfd pf{fd, POLLIN, 0};
+                    if (poll(&pf, 1, 1) > 0) { uint64_t v; (void)!read(fd, &v, sizeof(v)); }
+                    for (int w = 0; w < window; ++w) {
+                        if (!live[w]) continue;
+                        uint32_t cnt = 0;
+                        const int rc = hvx_batcher_poll(bt, &tk[w], oi.data(), os.data(), &cnt);
+                        if (rc == HVX_PENDING) continue;
+                        if (rc || cnt != k) failures++;
+                        lat[t].push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ts[w]).count());
+                        live[w] = 0; --inflight; ++done;
+                    }
+                }
+            });
+        for (auto &x : th) x.join();
+        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::vector<double> all;
+        for (auto &v : lat) all.insert(all.end(), v.begin(), v.end());
+        std::sort(all.begin(), all.end());
+        double sum = 0;
+        for (double x : all) sum += x;
+        *qps = all.size() / secs;
+        *mean_us = sum / all.size();
+        *p99_us = all[(size_t)(all.size() * 0.99)];
+        if (failures) fprintf(stderr, "%d failed calls\n", failures.load());
+        fprintf(stderr, "non-blocking: %d submitters x %d tickets, %ld submits answered BUSY\n", subs, window, busy.load());
+    };
     auto cgroup = [](unsigned long long out[3]) { // nr_throttled, throttled_usec, usage_usec of this container (cgroup v2)
         out[0] = out[1] = out[2] = 0;
         FILE *f = fopen("/sys/fs/cgroup/cpu.stat", "r");
@@ -122,11 +181,15 @@ int main(int argc, char **argv) {
     if (e_pair && hvx_index_set_option(ix, HVX_OPT_HNSW_PAIR, (uint32_t)atoi(e_pair))) { fprintf(stderr, "%s\n", hvx_last_error()); return 1; }
     const char *e_maxb = getenv("BATCHER_MAXB"); // (default 1 024 = the index's max_batch; small values exercise full batches and void claims)
     if (hvx_batcher_new_lanes(ix, &p, e_maxb ? (uint32_t)atoi(e_maxb) : 1024u, wait_us, lanes, &bt)) { fprintf(stderr, "%s\n", hvx_last_error()); return 1; }
-    run(bt, &q1, &m1, &p1);
+    const char *e_nb = getenv("BATCHER_NB"); // "<submitters>x<tickets>": the non-blocking form instead of one blocked thread per query
+    int nb_subs = 0, nb_win = 0;
+    if (e_nb && sscanf(e_nb, "%dx%d", &nb_subs, &nb_win) != 2) { fprintf(stderr, "BATCHER_NB=<submitters>x<tickets>\n"); return 2; }
+    const long nb_total = (long)threads * per;
+    if (nb_subs) run_nb(bt, nb_subs, nb_win, nb_total, &q1, &m1, &p1); else run(bt, &q1, &m1, &p1);
     unsigned long long cg0[3], cg1[3];
     cgroup(cg0);
     const auto tb0 = std::chrono::steady_clock::now();
-    run(bt, &q1, &m1, &p1);
+    if (nb_subs) run_nb(bt, nb_subs, nb_win, nb_total, &q1, &m1, &p1); else run(bt, &q1, &m1, &p1);
     const double run_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count();
     cgroup(cg1);
     fprintf(stderr, "timed run: %.3f s wall, %.2f CPU cores busy on average, cgroup throttled %llu time(s) for %.1f ms\n", run_s,

@@ -1038,6 +1038,73 @@ def test_batcher_coalesces_concurrent_single_query_callers(orc, hv):
         bt.close()
 
 
+def test_batcher_non_blocking_submit_poll_eventfd(orc, hv):
+    """Round 5: ValidatedVectorReadIndex::search is an async fn (read_index.rs:81-102).  ONE host thread keeps hundreds
+    of queries in flight through hvx_batcher_submit / _poll and sleeps on the batcher's eventfd between completions (select() here;
+    tokio's AsyncFd in the reference host): every ticket returns exactly the rows of a direct batch call, a full open batch answers
+    HVX_ERR_BUSY instead of blocking, a rejected query fails alone at its poll, hvx_batcher_wait times out with the ticket still valid,
+    and freeing the batcher with tickets nobody polls any more does not hang."""
+    import os, select, time
+    rng = np.random.default_rng(23)
+    n, dim = 2000, 128
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    oix = build_oracle(orc, data, 1, fx.draw_levels(n, 16, seed=4), efc=60)
+    gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=dim, metric=1, max_batch=64)
+    gix.set_simhash()
+    q = rng.standard_normal((600, dim)).astype(np.float32)
+    q[77, 3] = np.nan
+    for params in (hv.SearchParams(10).with_ef(64), hv.SearchParams.new(10)):
+        want_ids, want_sc, want_cnt, _, want_st = gix.search_batch(q, params, per_query_status=True)
+        bt = hv.Batcher(gix, params, max_batch=64, max_wait_us=300)
+        fd = bt.eventfd()
+        assert fd >= 0 and bt.eventfd() == fd
+        pending, got, busy, nxt, window = {}, {}, 0, 0, 200
+        t_end = time.time() + 60
+        while len(got) < q.shape[0] and time.time() < t_end:
+            while nxt < q.shape[0] and len(pending) < window:      # keep `window` tickets in flight
+                t = bt.submit(q[nxt])
+                if t is None:                                       # the open batch (64 slots) is full: not an error, not a block
+                    busy += 1
+                    break
+                pending[nxt] = t
+                nxt += 1
+            r, _, _ = select.select([fd], [], [], 0.05)
+            if r:
+                try:
+                    os.read(fd, 8)
+                except BlockingIOError:
+                    pass
+            for i in list(pending):
+                try:
+                    res = bt.poll(pending[i])
+                except hv.HelixDbError as e:
+                    res = e
+                if res is not None:
+                    got[i] = res
+                    del pending[i]
+        assert len(got) == q.shape[0] and not pending
+        assert busy > 0                                             # 200 tickets against 64-slot batches: submit had to say BUSY sometimes
+        for i in range(q.shape[0]):
+            if want_st[i]:
+                assert isinstance(got[i], hv.HelixDbError) and got[i].status == hv.ERR_NONFINITE and i == 77
+                continue
+            assert [r_.entity_id for r_ in got[i]] == want_ids[i, :want_cnt[i]].tolist()
+            assert bits([r_.score for r_ in got[i]]).tolist() == bits(want_sc[i, :want_cnt[i]]).tolist()
+        st = bt.stats()
+        assert st["queries"] == q.shape[0] and st["batches"] < q.shape[0] // 4, st      # one thread, yet the launches carry many queries
+        # wait with a time-out: a ticket whose batch cannot be complete yet stays valid
+        t = bt.submit(q[5])
+        first = bt.wait(t, timeout_us=1)
+        res = first if first is not None else bt.wait(t)
+        assert [r_.entity_id for r_ in res] == want_ids[5, :want_cnt[5]].tolist()
+        # tickets that are never polled: close() must come back (0.2 s of grace per lane), later submits fail loudly
+        for i in range(40):
+            assert bt.submit(q[i]) is not None
+        t0 = time.time()
+        bt.close()
+        assert time.time() - t0 < 20
+
+
 @pytest.mark.parametrize("metric", [0, 1])
 def test_duplicate_vectors_ties_are_broken_by_id_in_both_arms(orc, hv, metric):
     """20 exact copies of each of 120 vectors: every score occurs 20 times, so the (score, id) order (model.rs:55-61)

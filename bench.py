@@ -985,6 +985,11 @@ def leg_batcher(x_host, q_host, g, m, callers=1024, per_caller=300, lanes=3):
         nb["how"] = "hvx_batcher_submit / hvx_batcher_poll + eventfd, 8 submitter threads x 128 tickets in flight (1 024 queries in flight, as the blocking run)"
         res["nonblocking"] = nb
         res["qps_nonblocking"] = nb.get("qps")
+        # ... and the production-default arm the same way with 2 048 queries in flight (tickets cost no threads)
+        nbd = one("default", 4, {"BATCHER_OCC": "2", "BATCHER_NB": "8x256"})
+        nbd["how"] = "SearchParams::new(10), hvx_batcher_submit / _poll + eventfd, 8 submitter threads x 256 tickets in flight, 4 lanes, two queries per SIMD"
+        res["nonblocking_production_default"] = nbd
+        res["qps_nonblocking_production_default"] = nbd.get("qps")
         return res
     finally:
         shutil.rmtree(d, ignore_errors=True)
@@ -1092,7 +1097,7 @@ def compact_record(out, full_path):
     bt = out.get("batcher")
     if isinstance(bt, dict):
         c["batcher"] = {"error": str(bt["error"])[:160]} if "error" in bt else {k: bt.get(k) for k in ("qps", "mean_us", "p99_us", "mean_batch", "qps_production_default",
-                                                                                                       "qps_nonblocking")}
+                                                                                                       "qps_nonblocking", "qps_nonblocking_production_default")}
     if out.get("deadline"):
         c["deadline"] = {"seconds": out["deadline"].get("seconds")}
     c["full_record"] = full_path

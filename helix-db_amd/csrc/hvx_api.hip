@@ -683,11 +683,26 @@ int hvx::enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t b
             HIP_TRY(hipMemsetAsync(ix->d_bitmap, 0, (size_t)ix->max_batch * ix->words_per_query * 4, ix->stream));
             ix->bitmap_dirty = false;
         }
+        const bool ad_prof = tuning_env("HVX_WAVE_PROF") != nullptr && hnsw_wave_supported(a) && ix->occupancy != 2u;
+        if (ad_prof) {
+            if (!ix->d_prof && ix->dalloc((void **)&ix->d_prof, (size_t)ix->max_batch * 64)) return HVX_ERR_DEVICE;
+            a.prof = ix->d_prof;
+        }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         pick_events(ix, timed, &e0, &e1, &a.wave_clock);
         if (e0) HIP_TRY(hipEventRecord(e0, ix->stream));
         HIP_TRY(launch_hnsw_wave(a, b, ix->stream));
         if (e1) HIP_TRY(hipEventRecord(e1, ix->stream));
+        if (ad_prof) {
+            std::vector<unsigned long long> h((size_t)b * 8);
+            HIP_TRY(hipMemcpyAsync(h.data(), ix->d_prof, h.size() * 8, hipMemcpyDeviceToHost, ix->stream));
+            HIP_TRY(hipStreamSynchronize(ix->stream));
+            double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (uint32_t i = 0; i < b; ++i)
+                for (int j = 0; j < 8; ++j) acc[j] += (double)h[(size_t)i * 8 + j];
+            fprintf(stderr, "[hvx prof, non-strict] per query: row-wait %.0f  visited-claim %.0f  decide+select %.0f  gather+fma %.0f  predict %.0f  admit %.0f  (layer-0 loop %.0f) cycles\n",
+                    acc[0] / b, acc[1] / b, acc[6] / b, acc[2] / b, acc[3] / b, acc[4] / b, acc[7] / b);
+        }
         return HVX_OK;
     }
     const bool prof = tuning_env("HVX_WAVE_PROF") != nullptr; // tuning builds: phase-timing kernel + stderr report

@@ -442,6 +442,7 @@ static hipError_t launch_hnsw_wave_once(const HnswArgs &a, uint32_t b, hipStream
         default: return launch_hnsw_wave_gen_l1(a, b, g, s);
         }
     }
+    if (a.adaptive && a.prof) return launch_hnsw_wave_prof(a, b, g, s); // tuning builds only
     if (a.adaptive) {
         if (a.ix.dtype == HVX_BF16) return a.ix.metric == kL2 ? launch_hnsw_wave_l2_bf16_ad(a, b, g, s) : launch_hnsw_wave_cos_bf16_ad(a, b, g, s);
         return a.ix.metric == kL2 ? launch_hnsw_wave_l2_ad(a, b, g, s) : launch_hnsw_wave_cos_ad(a, b, g, s);

@@ -779,7 +779,7 @@ __device__ __forceinline__ void hnsw_wave_query(const HnswArgs &a, const uint32_
         S.mark_expanded(pos, lane);
 
         uint32_t nid;
-        if (c == pf_id) { nid = pf_row; if (PROF) pt[6] += 1; }
+        if (c == pf_id) { nid = pf_row; if (PROF && !AD) pt[6] += 1; }
         else nid = load_row(c);
         tick(0, true); // pop + neighbour row available
         unsigned long long nh = 0ull;
@@ -901,6 +901,7 @@ __device__ __forceinline__ void hnsw_wave_query(const HnswArgs &a, const uint32_
             if (acc) fr_id[__builtin_popcountll(am & ((1ull << lane) - 1ull))] = node;
             __syncthreads();
             nf = (uint32_t)__builtin_popcountll(am);
+            tick(6, true); // (PROF) the decision epoch + candidate selection of the non-strict arms
             if (nf == 0) { prefetch_hash(); continue; }
         }
         st_vl += nf;

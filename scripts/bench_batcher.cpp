@@ -4,8 +4,12 @@
 //   g++ -O2 -std=c++17 -I include scripts/bench_batcher.cpp -o scripts/_bin/bench_batcher \
 //       -L helix-db_amd -lhelix_vec_gfx950 -Wl,-rpath,$PWD/helix-db_amd -lpthread
 //   scripts/_bin/bench_batcher <dir with the arrays written by scripts/bench_batcher.py> <threads> <queries per thread>
+#include <linux/futex.h>
 #include <poll.h>
+#include <sys/syscall.h>
 #include <unistd.h>
+
+#include <climits>
 
 #include <algorithm>
 #include <atomic>
@@ -108,6 +112,25 @@ int main(int argc, char **argv) {
         std::vector<std::vector<double>> lat(subs);
         std::atomic<int> failures{0};
         std::atomic<long> busy{0};
+        // the reactor: ONE thread owns the eventfd (as tokio's driver does) and turns every tick into a generation bump the submitters
+        // sleep on -- a submitter that was busy polling its tickets when the tick came cannot miss it (it re-reads the generation)
+        std::atomic<uint32_t> gen{0};
+        std::atomic<bool> reactor_stop{false};
+        auto fwait = [](std::atomic<uint32_t> *a, uint32_t expect, long us) {
+            timespec ts{us / 1000000, (us % 1000000) * 1000};
+            syscall(SYS_futex, reinterpret_cast<uint32_t *>(a), FUTEX_WAIT_PRIVATE, expect, &ts, nullptr, 0);
+        };
+        std::thread reactor([&] {
+            while (!reactor_stop.load()) {
+                pollfd pf{fd, POLLIN, 0};
+                if (poll(&pf, 1, 2) > 0) {
+                    uint64_t v;
+                    (void)!read(fd, &v, sizeof(v));
+                    gen.fetch_add(1);
+                    syscall(SYS_futex, reinterpret_cast<uint32_t *>(&gen), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+                }
+            }
+        });
         const auto t0 = std::chrono::steady_clock::now();
         std::vector<std::thread> th;
         for (int t = 0; t < subs; ++t)
@@ -122,17 +145,8 @@ int main(int argc, char **argv) {
                 int inflight = 0;
                 lat[t].reserve(quota);
                 while (done < quota) {
-                    for (int w = 0; w < window && issued < quota && inflight < window; ++w) {
-                        if (live[w]) continue;
-                        const float *q = qs.data() + (size_t)((t * quota + issued) % nq) * dim;
-                        ts[w] = std::chrono::steady_clock::now();
-                        const int rc = hvx_batcher_submit(bt, q, &tk[w]);
-                        if (rc == HVX_ERR_BUSY) { busy++; break; }
-                        if (rc) { failures++; break; }
-                        live[w] = 1; ++inflight; ++issued;
-                    }
-                    pollfd pf{fd, POLLIN, 0};
-                    if (poll(&pf, 1, 1) > 0) { uint64_t v; (void)!read(fd, &v, sizeof(v)); }
+                    const uint32_t g0 = gen.load();
+                    bool progressed = false;
                     for (int w = 0; w < window; ++w) {
                         if (!live[w]) continue;
                         uint32_t cnt = 0;
@@ -141,11 +155,25 @@ int main(int argc, char **argv) {
                         if (rc || cnt != k) failures++;
                         lat[t].push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ts[w]).count());
                         live[w] = 0; --inflight; ++done;
+                        progressed = true;
                     }
+                    for (int w = 0; w < window && issued < quota && inflight < window; ++w) {
+                        if (live[w]) continue;
+                        const float *q = qs.data() + (size_t)((t * quota + issued) % nq) * dim;
+                        ts[w] = std::chrono::steady_clock::now();
+                        const int rc = hvx_batcher_submit(bt, q, &tk[w]);
+                        if (rc == HVX_ERR_BUSY) { busy++; break; }
+                        if (rc) { failures++; break; }
+                        live[w] = 1; ++inflight; ++issued;
+                        progressed = true;
+                    }
+                    if (!progressed) fwait(&gen, g0, 500); // nothing completed, nothing could be submitted: until the next tick
                 }
             });
         for (auto &x : th) x.join();
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        reactor_stop.store(true);
+        reactor.join();
         std::vector<double> all;
         for (auto &v : lat) all.insert(all.end(), v.begin(), v.end());
         std::sort(all.begin(), all.end());
@@ -155,7 +183,7 @@ int main(int argc, char **argv) {
         *mean_us = sum / all.size();
         *p99_us = all[(size_t)(all.size() * 0.99)];
         if (failures) fprintf(stderr, "%d failed calls\n", failures.load());
-        fprintf(stderr, "non-blocking: %d submitters x %d tickets, %ld submits answered BUSY\n", subs, window, busy.load());
+        fprintf(stderr, "non-blocking: %d submitters x %d tickets + 1 reactor thread on the eventfd, %ld submits answered BUSY\n", subs, window, busy.load());
     };
     auto cgroup = [](unsigned long long out[3]) { // nr_throttled, throttled_usec, usage_usec of this container (cgroup v2)
         out[0] = out[1] = out[2] = 0;

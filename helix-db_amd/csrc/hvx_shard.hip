@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -85,9 +86,27 @@ const Rccl &rccl() {
 }
 } // namespace
 
+// One RCCL communicator per RANK, shared by the groups of that rank's execution lanes (round 5; rounds 3-4 created one communicator per
+// lane: 4 x 8 = 32 on a node).  The tiny all-gathers (124 KB per rank at b = 1024, k = 10) of all lanes are issued on ONE dedicated
+// exchange stream -- a communicator's collectives must be issued in one order on every rank anyway -- and hand over to the lanes'
+// streams through events: lane stream -> (event) -> exchange stream: ncclAllGather -> (event) -> lane stream: merge.
+struct SharedComm {
+    ncclComm_t comm = nullptr;
+    hipStream_t xstream = nullptr;
+    int device = 0;
+    std::mutex mu; // the order of the collectives = the order in which the steps take this lock (the same on every rank: see the header)
+    ~SharedComm() {
+        (void)hipSetDevice(device);
+        if (xstream) (void)hipStreamSynchronize(xstream);
+        if (comm && rccl().ok) (void)rccl().CommDestroy(comm);
+        if (xstream) (void)hipStreamDestroy(xstream);
+    }
+};
+
 struct hvx_shard_group {
     hvx_index *ix = nullptr;
-    ncclComm_t comm = nullptr;
+    std::shared_ptr<SharedComm> sc;        // null for a group of one rank without a communicator
+    hipEvent_t ev_local = nullptr, ev_gathered = nullptr; // lane -> exchange stream, exchange stream -> lane
     uint32_t rank = 0, world = 1, max_batch = 0, max_k = 0;
     char *send = nullptr, *recv = nullptr; // [payload(max)] / [world][payload(max)]
     uint32_t *status = nullptr;            // [max_batch]
@@ -113,18 +132,18 @@ extern "C" void hvx_shard_group_free(hvx_shard_group *g) {
         (void)hipSetDevice(g->ix->device);
         (void)hipStreamSynchronize(g->ix->stream);
     }
-    if (g->comm && rccl().ok) (void)rccl().CommDestroy(g->comm);
+    if (g->sc && g->sc->xstream) (void)hipStreamSynchronize(g->sc->xstream);
+    g->sc.reset(); // the communicator goes with the last group that shares it
+    if (g->ev_local) (void)hipEventDestroy(g->ev_local);
+    if (g->ev_gathered) (void)hipEventDestroy(g->ev_gathered);
     if (g->send) (void)hipFree(g->send);
     if (g->recv) (void)hipFree(g->recv);
     if (g->status) (void)hipFree(g->status);
     delete g;
 }
 
-extern "C" int hvx_shard_group_init(hvx_index *local_shard, const uint8_t *unique_id, uint32_t rank, uint32_t world, uint32_t max_batch,
-                                    uint32_t max_k, hvx_shard_group **out) {
-    if (!local_shard || !out || (world > 1 && !unique_id)) return fail(HVX_ERR_INVARIANT, "null argument");
-    *out = nullptr;
-    if (world == 0 || rank >= world) return fail(HVX_ERR_K_RANGE, "rank %u outside a group of %u", rank, world);
+namespace {
+int alloc_group(hvx_index *local_shard, uint32_t rank, uint32_t world, uint32_t max_batch, uint32_t max_k, hvx_shard_group **out) {
     if (max_batch == 0 || max_k == 0) return fail(HVX_ERR_K_RANGE, "max_batch and max_k must be non-zero");
     if (max_batch > local_shard->max_batch) return fail(HVX_ERR_UNSUPPORTED, "max_batch %u exceeds the shard's %u", max_batch, local_shard->max_batch);
     HIP_TRY(hipSetDevice(local_shard->device));
@@ -136,27 +155,63 @@ extern "C" int hvx_shard_group_init(hvx_index *local_shard, const uint8_t *uniqu
     g->max_k = max_k;
     const size_t payload = ((hvx_topk_payload_bytes(max_batch, max_k) + (size_t)max_batch * 4) + 7) & ~(size_t)7; // + per-query status
     if (hipMalloc((void **)&g->send, payload) != hipSuccess || hipMalloc((void **)&g->recv, payload * world) != hipSuccess ||
-        hipMalloc((void **)&g->status, (size_t)max_batch * 4) != hipSuccess) {
+        hipMalloc((void **)&g->status, (size_t)max_batch * 4) != hipSuccess ||
+        hipEventCreateWithFlags(&g->ev_local, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g->ev_gathered, hipEventDisableTiming) != hipSuccess) {
         hvx_shard_group_free(g);
-        return fail(HVX_ERR_DEVICE, "hipMalloc of the exchange buffers failed");
+        return fail(HVX_ERR_DEVICE, "allocation of the exchange buffers failed");
     }
-    if (world > 1) {
+    *out = g;
+    return HVX_OK;
+}
+} // namespace
+
+extern "C" int hvx_shard_group_init(hvx_index *local_shard, const uint8_t *unique_id, uint32_t rank, uint32_t world, uint32_t max_batch,
+                                    uint32_t max_k, hvx_shard_group **out) {
+    if (!local_shard || !out || (world > 1 && !unique_id)) return fail(HVX_ERR_INVARIANT, "null argument");
+    *out = nullptr;
+    if (world == 0 || rank >= world) return fail(HVX_ERR_K_RANGE, "rank %u outside a group of %u", rank, world);
+    hvx_shard_group *g = nullptr;
+    int rc = alloc_group(local_shard, rank, world, max_batch, max_k, &g);
+    if (rc) return rc;
+    if (world > 1 || unique_id) { // (a group of one still exercises the collective when an id is given: tests)
         const Rccl &r = rccl();
-        if (!r.ok) { hvx_shard_group_free(g); return fail(HVX_ERR_DEVICE, "RCCL is not available: %s", r.why); }
+        if (!r.ok) {
+            if (world == 1) { *out = g; return HVX_OK; }
+            hvx_shard_group_free(g);
+            return fail(HVX_ERR_DEVICE, "RCCL is not available: %s", r.why);
+        }
+        auto sc = std::make_shared<SharedComm>();
+        sc->device = local_shard->device;
         ncclUniqueId id;
         memcpy(&id, unique_id, sizeof(id));
-        const ncclResult_t e = r.CommInitRank(&g->comm, (int)world, id, (int)rank);
+        const ncclResult_t e = r.CommInitRank(&sc->comm, (int)world, id, (int)rank);
         if (e != ncclSuccess) {
-            g->comm = nullptr;
+            sc->comm = nullptr;
+            if (world == 1) { *out = g; return HVX_OK; }
             hvx_shard_group_free(g);
             return fail(HVX_ERR_DEVICE, "ncclCommInitRank(rank %u of %u): %s", rank, world, r.GetErrorString(e));
         }
-    } else if (unique_id && rccl().ok) { // a group of one still exercises the collective when an id is given (tests)
-        ncclUniqueId id;
-        memcpy(&id, unique_id, sizeof(id));
-        const ncclResult_t e = rccl().CommInitRank(&g->comm, 1, id, 0);
-        if (e != ncclSuccess) g->comm = nullptr;
+        if (hipStreamCreateWithFlags(&sc->xstream, hipStreamNonBlocking) != hipSuccess) {
+            hvx_shard_group_free(g);
+            return fail(HVX_ERR_DEVICE, "exchange stream creation failed");
+        }
+        g->sc = sc;
     }
+    *out = g;
+    return HVX_OK;
+}
+
+// Another execution lane of the SAME rank joins `primary`'s communicator: own handle (an hvx_index_fork of the shard), own payload
+// buffers, the rank's one communicator and exchange stream.
+extern "C" int hvx_shard_group_attach(hvx_shard_group *primary, hvx_index *lane, hvx_shard_group **out) {
+    if (!primary || !lane || !out) return fail(HVX_ERR_INVARIANT, "null argument");
+    *out = nullptr;
+    if (lane->device != primary->ix->device) return fail(HVX_ERR_INVARIANT, "the lane lives on another device than the group it joins");
+    hvx_shard_group *g = nullptr;
+    int rc = alloc_group(lane, primary->rank, primary->world, primary->max_batch, primary->max_k, &g);
+    if (rc) return rc;
+    g->sc = primary->sc;
     *out = g;
     return HVX_OK;
 }
@@ -214,14 +269,20 @@ int exchange_and_merge(hvx_shard_group *g, uint32_t b, uint32_t k, const StepBuf
                        uint32_t *d_out_counts, uint32_t *d_out_status) {
     hvx_index *ix = g->ix;
     const char *gathered = g->send;
-    if (g->comm) {
-        const ncclResult_t e = rccl().AllGather(g->send, g->recv, v.payload, ncclUint8, g->comm, ix->stream);
+    if (g->sc) {
+        SharedComm &sc = *g->sc;
+        std::lock_guard<std::mutex> order(sc.mu); // one issue order for the collectives of every lane that shares the communicator
+        HIP_TRY(hipEventRecord(g->ev_local, ix->stream));
+        HIP_TRY(hipStreamWaitEvent(sc.xstream, g->ev_local, 0));
+        const ncclResult_t e = rccl().AllGather(g->send, g->recv, v.payload, ncclUint8, sc.comm, sc.xstream);
         if (e != ncclSuccess) return fail(HVX_ERR_DEVICE, "ncclAllGather: %s", rccl().GetErrorString(e));
+        HIP_TRY(hipEventRecord(g->ev_gathered, sc.xstream));
+        HIP_TRY(hipStreamWaitEvent(ix->stream, g->ev_gathered, 0));
         gathered = g->recv;
     } else if (g->world > 1) {
         return fail(HVX_ERR_INVARIANT, "shard group of %u ranks has no communicator", g->world);
     }
-    const uint32_t lists = g->comm ? g->world : 1u;
+    const uint32_t lists = g->sc ? g->world : 1u;
     HIP_TRY(launch_merge_topk_strided(lists, b, k, reinterpret_cast<const uint64_t *>(gathered),
                                       reinterpret_cast<const float *>(gathered + (size_t)b * k * 8),
                                       reinterpret_cast<const uint32_t *>(gathered + (size_t)b * k * 12), v.payload / 8, v.payload / 4, v.payload / 4,

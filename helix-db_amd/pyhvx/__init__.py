@@ -844,11 +844,21 @@ class ShardGroup:
     by ONE C-ABI call.  `unique_id` = 128 bytes from ShardGroup.unique_id() on rank 0, handed to every rank by
     the host (bench.py uses a torch.distributed broadcast); world == 1 with an id still runs the collective (tests)."""
 
-    def __init__(self, index: "ValidatedVectorReadIndex", unique_id, rank: int, world: int, max_batch: int, max_k: int):
+    def __init__(self, index: "ValidatedVectorReadIndex", unique_id, rank: int, world: int, max_batch: int, max_k: int, _attach_to=None):
         self._ix = index  # keeps the shard handle alive
         self._g = _vp()
+        if _attach_to is not None:
+            L = lib()
+            L.hvx_shard_group_attach.restype = C.c_int
+            L.hvx_shard_group_attach.argtypes = [_vp, _vp, C.POINTER(_vp)]
+            _check(L.hvx_shard_group_attach(_attach_to._g, index._h, C.byref(self._g)))
+            return
         uid = None if unique_id is None else np.frombuffer(bytes(unique_id), np.uint8).copy()
         _check(lib().hvx_shard_group_init(index._h, _ptr(uid), rank, world, max_batch, max_k, C.byref(self._g)))
+
+    def attach(self, lane: "ValidatedVectorReadIndex") -> "ShardGroup":
+        """hvx_shard_group_attach: another execution lane of this rank on the SAME communicator (one exchange stream per rank)"""
+        return ShardGroup(lane, None, 0, 1, 0, 0, _attach_to=self)
 
     @staticmethod
     def unique_id() -> bytes:

@@ -376,6 +376,12 @@ typedef struct hvx_shard_group hvx_shard_group;
 int hvx_shard_group_unique_id(uint8_t *out /*[HVX_SHARD_UNIQUE_ID_BYTES]*/);
 int hvx_shard_group_init(hvx_index *local_shard, const uint8_t *unique_id, uint32_t rank, uint32_t world, uint32_t max_batch, uint32_t max_k,
                          hvx_shard_group **out);
+/* Execution lanes of ONE rank (hvx_index_fork handles of its shard) share the rank's communicator: hvx_shard_group_attach gives
+ * `lane` a group of its own (own payload buffers) on `primary`'s communicator.  The all-gathers of all groups that share a
+ * communicator run on one dedicated exchange stream in the order the steps are issued: as with any NCCL communicator, every rank
+ * must issue its steps in the same order (round-robin over the lanes from one thread, as bench.py does).  Free the groups in any
+ * order; the communicator goes with the last one. */
+int hvx_shard_group_attach(hvx_shard_group *primary, hvx_index *lane, hvx_shard_group **out);
 /* Every step below is  local search -> ONE all-gather of the packed per-shard top-k + per-query status -> merge by Candidate
  * order.  d_out_status (nullable): per query, the element-wise maximum of the ranks' statuses -- a NaN / zero-norm / oversized
  * query is rejected by every shard's validation (search.rs:1120-1125 InvalidVectorComponent ...) and comes back with count 0. */

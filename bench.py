@@ -196,15 +196,14 @@ class LaneSet:
         self.params = None  # hv.SearchParams: the steps run hvx_search_batch_params_device (the non-strict arms) instead of the strict call
 
     def use_shard_groups(self, hv, dist, rank, world):
-        """One hvx_shard_group (own RCCL communicator) per lane; the 128-byte unique ids travel over torch.distributed."""
-        ids = []
-        for _ in self.handles:
-            t = torch.zeros(128, dtype=torch.uint8, device=self.dev)
-            if rank == 0:
-                t.copy_(torch.frombuffer(bytearray(hv.ShardGroup.unique_id()), dtype=torch.uint8))
-            dist.broadcast(t, 0)
-            ids.append(bytes(t.cpu().numpy().tobytes()))
-        self.groups = [hv.ShardGroup(h, uid, rank, world, self.b, self.k) for h, uid in zip(self.handles, ids)]
+        """ONE RCCL communicator per rank (round 5): lane 0's hvx_shard_group bootstraps it from the 128-byte unique id (broadcast over
+        torch.distributed), the other lanes attach to it (hvx_shard_group_attach: own payload buffers, the rank's exchange stream)."""
+        t = torch.zeros(128, dtype=torch.uint8, device=self.dev)
+        if rank == 0:
+            t.copy_(torch.frombuffer(bytearray(hv.ShardGroup.unique_id()), dtype=torch.uint8))
+        dist.broadcast(t, 0)
+        first = hv.ShardGroup(self.handles[0], bytes(t.cpu().numpy().tobytes()), rank, world, self.b, self.k)
+        self.groups = [first] + [first.attach(h) for h in self.handles[1:]]
         self.merged = [out_buffers(self.b, self.k, self.dev) for _ in self.handles]
 
     def step(self, i, q, ef):

@@ -212,7 +212,7 @@ extern "C" int hvx_index_import(const hvx_index_desc *desc, const uint64_t *node
 // m0 / m ids afterwards)
 int hvx::import_index(const hvx_index_desc *desc, const uint64_t *node_ids, const float *vectors, const uint64_t *l0_offsets,
                       const uint64_t *l0_neighbors, const uint16_t *level, const uint64_t *up_offsets, const uint64_t *up_neighbors,
-                      uint32_t min_s0, uint32_t min_su, hvx_index **out) {
+                      uint32_t min_s0, uint32_t min_su, hvx_index **out, uint64_t reserve_rows, uint64_t reserve_up_rows) {
     if (!desc || !out) return fail(HVX_ERR_INVARIANT, "null argument");
     *out = nullptr;
     if (desc->dim == 0) return fail(HVX_ERR_DIMENSION, "dimension must be non-zero");
@@ -225,8 +225,10 @@ int hvx::import_index(const hvx_index_desc *desc, const uint64_t *node_ids, cons
         return fail(HVX_ERR_UNSUPPORTED, "bf16 rows need dim %% 64 == 0, the AVX+FMA summation tree and an L2/cosine metric");
     if (desc->float_kernel > HVX_KERNEL_NEON)
         return fail(HVX_ERR_UNSUPPORTED, "float kernel %u is not one of the reference's FloatSimd kernels", desc->float_kernel);
-    if (desc->n >= (1ull << 31)) return fail(HVX_ERR_UNSUPPORTED, "shard too large (n < 2^31)");
+    if (desc->n + reserve_rows >= (1ull << 31)) return fail(HVX_ERR_UNSUPPORTED, "shard too large (n < 2^31)");
+    if ((reserve_rows || reserve_up_rows) && desc->dtype != HVX_F32) return fail(HVX_ERR_UNSUPPORTED, "only f32 images can reserve rows for later inserts");
     const uint64_t n = desc->n;
+    const uint64_t cap = n + reserve_rows; // rows the arrays are allocated for (hvx_index_insert_batch appends into the spare ones)
     if (n && (!node_ids || !vectors || !l0_offsets)) return fail(HVX_ERR_INVARIANT, "null array");
 
     int dev = desc->device;
@@ -288,7 +290,7 @@ int hvx::import_index(const hvx_index_desc *desc, const uint64_t *node_ids, cons
     d.su = round_up((uint32_t)std::max<uint64_t>(std::max<uint64_t>(max_up, min_su), 1), 16);
     if (d.s0 > 128 || d.su > 128) return bail(fail(HVX_ERR_UNSUPPORTED, "neighbour rows longer than 128 are not supported (l0 %llu, upper %llu)", (unsigned long long)max_deg, (unsigned long long)max_up));
 
-    std::vector<uint32_t> h_l0((size_t)n * d.s0, kSentinel);
+    std::vector<uint32_t> h_l0((size_t)cap * d.s0, kSentinel);
     std::atomic<int> graph_err{0};
     auto convert_row = [&](const uint64_t *src, uint64_t cnt, uint32_t *dst, uint64_t self) -> bool {
         uint64_t prev = 0;
@@ -309,9 +311,13 @@ int hvx::import_index(const hvx_index_desc *desc, const uint64_t *node_ids, cons
     });
     if (graph_err) return bail(fail(HVX_ERR_INVARIANT, "layer-0 row is not canonical (ascending, deduped, self-free, known ids)"));
 
-    std::vector<uint32_t> h_up((size_t)std::max<uint64_t>(up_rows, 1) * d.su, kSentinel);
-    std::vector<uint32_t> h_up_base(std::max<uint64_t>(n, 1), kSentinel);
-    std::vector<uint16_t> h_level(std::max<uint64_t>(n, 1), 0);
+    const uint64_t cap_up = up_rows + reserve_up_rows;
+    std::vector<uint32_t> h_up((size_t)std::max<uint64_t>(cap_up, 1) * d.su, kSentinel);
+    std::vector<uint32_t> h_up_base(std::max<uint64_t>(cap, 1), kSentinel);
+    std::vector<uint16_t> h_level(std::max<uint64_t>(cap, 1), 0);
+    ix->cap_rows = cap;
+    ix->cap_up_rows = cap_up;
+    ix->up_rows_used = up_rows;
     {
         uint64_t r = 0;
         for (uint64_t i = 0; i < n; ++i) {
@@ -332,7 +338,7 @@ int hvx::import_index(const hvx_index_desc *desc, const uint64_t *node_ids, cons
     // ---- upload ----
     void *p;
     int rc;
-    const size_t vec_bytes = (size_t)n * d.ld * 4;
+    const size_t vec_bytes = (size_t)n * d.ld * 4, vec_cap_bytes = (size_t)cap * d.ld * 4;
     const bool bf16 = desc->dtype == HVX_BF16, fp8 = desc->dtype == HVX_FP8_E4M3;
     float *staging = nullptr; // bf16 / fp8: temporary f32 copy, quantised in place, validated, packed, freed
     void *fp8_codes = nullptr;
@@ -340,7 +346,7 @@ int hvx::import_index(const hvx_index_desc *desc, const uint64_t *node_ids, cons
     if (bf16 || fp8) {
         if (hipMalloc((void **)&staging, std::max<size_t>(vec_bytes, 16)) != hipSuccess) return bail(fail(HVX_ERR_DEVICE, "hipMalloc(%zu) staging", vec_bytes));
         p = staging;
-    } else if ((rc = ix->dalloc(&p, vec_bytes))) return bail(rc);
+    } else if ((rc = ix->dalloc(&p, vec_cap_bytes))) return bail(rc);
     d.vec = (const float *)p;
     auto bail_free = [&](int code) { if (staging) (void)hipFree(staging); return bail(code); };
     if (n) {
@@ -379,13 +385,18 @@ int hvx::import_index(const hvx_index_desc *desc, const uint64_t *node_ids, cons
     if ((rc = upload(h_up.data(), h_up.size() * 4, (const void **)&d.up))) return bail_free(rc);
     if ((rc = upload(h_up_base.data(), h_up_base.size() * 4, (const void **)&d.up_base))) return bail_free(rc);
     if ((rc = upload(h_level.data(), h_level.size() * 2, (const void **)&d.level))) return bail_free(rc);
-    if ((rc = upload(ix->ids_ref().data(), ix->ids_ref().size() * 8, (const void **)&d.ids))) return bail_free(rc);
+    {
+        void *q;
+        if ((rc = ix->dalloc(&q, std::max<size_t>(cap, 1) * 8))) return bail_free(rc);
+        if (n && hipMemcpy(q, ix->ids_ref().data(), (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess) return bail_free(fail(HVX_ERR_DEVICE, "upload failed"));
+        d.ids = (const uint64_t *)q;
+    }
 
     // ---- validate rows + headers ONCE on the device (decode_item_borrowed does it per fetch:
     //      mod.rs:889-949) ----
     float *d_hdr;
     uint32_t *d_rowstatus;
-    if ((rc = ix->dalloc((void **)&d_hdr, std::max<size_t>(n, 1) * 4))) return bail_free(rc);
+    if ((rc = ix->dalloc((void **)&d_hdr, std::max<size_t>(cap, 1) * 4))) return bail_free(rc);
     d.hdr = d_hdr;
     if (n) {
         if (hipMalloc((void **)&d_rowstatus, n * 4) != hipSuccess) return bail_free(fail(HVX_ERR_DEVICE, "hipMalloc row status"));
@@ -420,6 +431,7 @@ int hvx::import_index(const hvx_index_desc *desc, const uint64_t *node_ids, cons
             if (e != hipSuccess) return bail(fail(HVX_ERR_DEVICE, "row norms: %s", hipGetErrorString(e)));
             for (float v : h_n2) ix->m_xmax2 = std::max(ix->m_xmax2, v);
         }
+        ix->rowterm_rows = (uint32_t)n;
     }
     if (fp8) {
         if ((rc = ix->dalloc((void **)&ix->m_rowterm, std::max<size_t>(n, 1) * 4))) return bail_free(rc);
@@ -434,6 +446,7 @@ int hvx::import_index(const hvx_index_desc *desc, const uint64_t *node_ids, cons
         staging = nullptr;
         if (e != hipSuccess) return bail(fail(HVX_ERR_DEVICE, "fp8 row norms: %s", hipGetErrorString(e)));
         for (float v : h_n2) ix->m_xmax2 = std::max(ix->m_xmax2, v);
+        ix->rowterm_rows = (uint32_t)n;
         d.vec8 = (const uint8_t *)fp8_codes;
         d.rowscale = fp8_scale;
         d.vec = nullptr;
@@ -441,7 +454,7 @@ int hvx::import_index(const hvx_index_desc *desc, const uint64_t *node_ids, cons
 
     // ---- per-batch scratch ----
     const uint32_t mb = ix->max_batch;
-    ix->words_per_query = round_up((uint32_t)((n + 31) / 32), 4);
+    ix->words_per_query = round_up((uint32_t)((cap + 31) / 32), 4);
     if (ix->words_per_query == 0) ix->words_per_query = 4;
     if ((rc = ix->dalloc((void **)&ix->d_bitmap, (size_t)mb * ix->words_per_query * 4))) return bail(rc);
     if (hipMemset(ix->d_bitmap, 0, (size_t)mb * ix->words_per_query * 4) != hipSuccess) return bail(fail(HVX_ERR_DEVICE, "bitmap clear failed"));
@@ -450,9 +463,50 @@ int hvx::import_index(const hvx_index_desc *desc, const uint64_t *node_ids, cons
     if ((rc = ix->dalloc((void **)&ix->d_tie, ((size_t)mb * 2 + 4) * 4))) return bail(rc); // [mb] flags, [mb] re-run list, re-run count / done
     if (hipMemset(ix->d_tie, 0, ((size_t)mb * 2 + 4) * 4) != hipSuccess) return bail(fail(HVX_ERR_DEVICE, "re-run list clear failed"));
     if ((rc = ix->dalloc((void **)&ix->d_qstats, (size_t)mb * sizeof(hvx_query_stats)))) return bail(rc);
+    ix->publish_view();
     *out = ix;
     return HVX_OK;
 }
+
+// ---- generation view of a growable image (hvx_host.h) ----
+void hvx_index::publish_view() {
+    std::lock_guard<std::mutex> g(shared->mu);
+    shared->visible_seq += 1;
+    shared->v_n = dev.n;
+    shared->v_entry = dev.entry;
+    shared->v_max_layer = dev.max_layer;
+    shared->v_has_entry = dev.has_entry;
+    shared->v_entry_point = desc.entry_point;
+    shared->v_contiguous = contiguous;
+    shared->v_ids = ids_p;
+    seen_seq = shared->visible_seq;
+}
+bool hvx_index::adopt_view() {
+    std::lock_guard<std::mutex> g(shared->mu);
+    if (seen_seq == shared->visible_seq) return false;
+    dev.n = shared->v_n;
+    dev.entry = shared->v_entry;
+    dev.max_layer = shared->v_max_layer;
+    dev.has_entry = shared->v_has_entry;
+    desc.n = shared->v_n;
+    desc.has_entry = shared->v_has_entry;
+    desc.max_layer = shared->v_max_layer;
+    desc.entry_point = shared->v_entry_point;
+    contiguous = shared->v_contiguous;
+    ids_p = shared->v_ids;
+    seen_seq = shared->visible_seq;
+    return true;
+}
+
+extern "C" int hvx_index_refresh(hvx_index *ix) {
+    if (!ix) return fail(HVX_ERR_INVARIANT, "null index");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    (void)ix->adopt_view(); // per-image caches (row norms, bf16 shadow, SimHash directory) extend themselves on their next use
+    return HVX_OK;
+}
+extern "C" uint64_t hvx_index_visible_seq(const hvx_index *ix) { return ix ? ix->seen_seq : 0; }
+extern "C" uint64_t hvx_index_rows(const hvx_index *ix) { return ix ? ix->dev.n : 0; }
+extern "C" uint64_t hvx_index_row_capacity(const hvx_index *ix) { return ix ? ix->cap_rows : 0; }
 
 // An execution lane on the same index image: own stream, events, per-batch scratch and mutex; rows, graph, ids, headers
 // and SimHash rows are shared with (and kept alive by) the handle it was forked from.
@@ -471,12 +525,17 @@ extern "C" int hvx_index_fork(const hvx_index *parent, hvx_index **out) {
     ix->words_per_query = src->words_per_query;
     ix->ids_p = src->ids_p;
     ix->contiguous = src->contiguous;
+    ix->cap_rows = src->cap_rows;
+    ix->cap_up_rows = src->cap_up_rows;
+    ix->up_rows_used = src->up_rows_used;
+    ix->seen_seq = src->seen_seq;
     ix->occupancy = src->occupancy;
     memcpy(ix->opt, src->opt, sizeof(ix->opt));
     ix->is_fork = true;
     ix->image = src->image;
     ix->image.push_back(src->allocs);
     ix->m_rowterm = src->m_rowterm;
+    ix->rowterm_rows = src->rowterm_rows;
     ix->m_xmax2 = src->m_xmax2;
     ix->shared = src->shared; // one bf16 shadow (and whatever else is built lazily per image) for all lanes
     ix->m_shadow = src->m_shadow;

@@ -617,9 +617,9 @@ template <typename K> static hipError_t launch_link_wg(K kern, const BuildArgs &
 
 // insertion order: position i inserts row (i * stride) mod n; stride 1 = id order, a stride coprime with n = a permutation that puts
 // the nodes of a batch far apart in id space (hvx_build_params.scatter)
-__global__ void iota_kernel(uint32_t *p, uint32_t n, uint32_t stride) {
+__global__ void iota_kernel(uint32_t *p, uint32_t count, uint32_t first, uint32_t stride, uint32_t mod) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n) p[i] = (uint32_t)(((unsigned long long)i * stride) % n);
+    if (i < count) p[i] = stride == 1u ? first + i : (uint32_t)(((unsigned long long)(first + i) * stride) % mod);
 }
 
 // one instantiation per (metric, summation tree): the reference picks both per index (spaces/*.rs, distance/*.rs)
@@ -648,58 +648,39 @@ extern "C" void hvx_build_params_default(hvx_build_params *p) {
     p->batch_divisor = 32;
 }
 
-extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_ids, const float *vectors, const uint16_t *levels,
-                               const hvx_build_params *params, hvx_index **out, hvx_build_stats *stats) {
-    if (!desc || !out || !params) return fail(HVX_ERR_INVARIANT, "null argument");
-    *out = nullptr;
-    const uint64_t n = desc->n;
-    if (n && (!node_ids || !vectors)) return fail(HVX_ERR_INVARIANT, "null array");
-    const uint32_t m = desc->m ? desc->m : 16u;
-    const uint32_t m0 = std::max(desc->m0 ? desc->m0 : 2u * m, 2u * m); // MutationDegreeLimits (mutation.rs:178-196)
+// insert_hnsw (mutation.rs:787-895) for the rows at insertion positions [first, first + count) of an image that already holds their
+// vectors, levels and (empty) neighbour rows: batches of nodes searched on the handle's stream while the previous batch is selected
+// and linked on a second one.  hvx_index_build runs it over a whole image (positions 0 .. n - 1, optionally scattered);
+// hvx_index_insert_batch over the rows it has just appended (id order).  levels_in[0] is the level of row level_row0.  Position p inserts row
+// (p * stride) mod `mod` (stride 1: row p).  The handle is private to the caller for the duration (its lock is held or it has not
+// been returned yet).
+static int insert_range(hvx_index *ix, uint64_t first, uint64_t count, const uint16_t *levels_in, uint64_t level_row0, const hvx_build_params *params,
+                        uint32_t stride, uint64_t mod, hvx_build_stats *stats) {
+    if (count == 0) return HVX_OK;
+    struct LevelOf { // levels_in[0] is the level of row level_row0
+        const uint16_t *p;
+        uint64_t r0;
+        explicit operator bool() const { return p != nullptr; }
+        uint16_t operator[](uint64_t row) const { return p[row - r0]; }
+    } levels{levels_in, level_row0};
+    const uint32_t m = ix->desc.m ? ix->desc.m : 16u;
+    const uint32_t m0 = std::max(ix->desc.m0 ? ix->desc.m0 : 2u * m, 2u * m);
     const uint32_t efc = params->ef_construction ? params->ef_construction : 200u;
-    if (desc->dtype != HVX_F32) return fail(HVX_ERR_UNSUPPORTED, "the device build reads f32 rows (import the built graph with a reduced-precision dtype afterwards)");
-    if (m0 > 32u || m > 32u) return fail(HVX_ERR_UNSUPPORTED, "device build serves m0 <= 32");
-    if (std::max(efc, m0) + 32u > 832u) return fail(HVX_ERR_UNSUPPORTED, "device build serves ef_construction <= 800");
     const uint32_t ef0 = std::max(efc, m0), efu = std::max(efc, 2u * m);
-
-    // ---- the image: rows + EMPTY graph with rows sized for m0 / m ----
-    hvx_index_desc d0 = *desc;
-    d0.m = m;
-    d0.m0 = m0;
-    d0.has_entry = 0;
-    d0.max_layer = 0;
     uint32_t bmax = params->max_batch ? params->max_batch : 2048u;
-    if (d0.max_batch == 0) d0.max_batch = 1024;
-    if (bmax > d0.max_batch) bmax = d0.max_batch; // per-batch scratch of the search kernel is sized by max_batch
-    uint64_t up_rows = 0;
-    uint32_t top_level = 0;
-    for (uint64_t i = 0; i < n; ++i) {
-        const uint16_t lv = levels ? levels[i] : 0;
-        if (lv > 63) return fail(HVX_ERR_INVARIANT, "node level > 63");
-        up_rows += lv;
-        top_level = std::max<uint32_t>(top_level, lv);
-    }
-    std::vector<uint64_t> zeros0(n + 1, 0), zerosu(up_rows + 1, 0);
-    uint64_t dummy = 0;
-    hvx_index *ix = nullptr;
-    int rc = import_index(&d0, node_ids, vectors, zeros0.data(), &dummy, levels, zerosu.data(), &dummy, m0, m, &ix);
-    if (rc) return rc;
-    auto bail = [&](int code) { hvx_index_free(ix); return code; };
-    HnswArgs probe{};
-    probe.ix = ix->dev;
-    probe.ef = ef0;
-    // the unrolled builds serve L2 / cosine, the AVX+FMA tree, dim in {128,...,1536}, ef_construction <= 352; everything else (any
-    // dimension, Manhattan, the scalar / AVX summation trees, ef_construction <= 800) takes the GENERIC build of the same kernel
-    if (n && !hnsw_wave_supported(probe) && (ix->dev.s0 > 64u || ix->dev.su > 64u))
-        return bail(fail(HVX_ERR_UNSUPPORTED, "device build serves neighbour rows of <= 64 ids"));
-    if (n == 0) { *out = ix; return HVX_OK; }
+    if (bmax > ix->max_batch) bmax = ix->max_batch; // per-batch scratch of the search kernel is sized by max_batch
+    const uint64_t rows_total = std::max<uint64_t>(first + count, mod);
+    auto row_at = [&](uint64_t pos) -> uint64_t { return stride == 1 ? pos : (pos * stride) % mod; };
+    DevIndex &d = ix->dev;
+    uint32_t top_level = d.has_entry ? d.max_layer : 0u;
+    for (uint64_t p = first; p < first + count; ++p) top_level = std::max<uint32_t>(top_level, levels ? levels[row_at(p)] : 0);
     HIP_TRY(hipSetDevice(ix->device));
-    hipStream_t s = ix->stream; // the handle is private to this call until it is returned: no lock
+    hipStream_t s = ix->stream;
     const uint32_t layers_max = top_level + 1u;
     uint32_t *d_iota, *d_locks, *d_cnt, *d_sel, *d_selcnt, *d_status, *d_err;
     uint64_t *d_cids;
     float *d_csc;
-    // scratch is released with the build (hipFree below); the image keeps only rows + graph
+    // scratch is released with the call (hipFree below); the image keeps only rows + graph
     std::vector<void *> scratch;
     auto salloc = [&](void **p, size_t bytes) -> int {
         if (hipMalloc(p, std::max<size_t>(bytes, 16)) != hipSuccess) return fail(HVX_ERR_DEVICE, "hipMalloc(%zu) build scratch", bytes);
@@ -707,14 +688,15 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
         return HVX_OK;
     };
     auto release = [&]() { for (void *p : scratch) (void)hipFree(p); scratch.clear(); };
-    auto sbail = [&](int code) { (void)hipStreamSynchronize(s); release(); return bail(code); };
+    auto sbail = [&](int code) { (void)hipStreamSynchronize(s); release(); return code; };
     // Round 4: the search of batch i + 1 runs on the handle's stream WHILE batch i is selected and linked on a second stream (the
     // search side was half of the build and strictly serial with the link step).  Batch i + 1 then does not see batch i -- which it
     // tolerates exactly as the nodes of one batch tolerate not seeing each other: rows are only ever read as stale-or-current
     // (agent-scope stores by the link step, immutable vectors), never torn into invalid ids.  Candidate / selection buffers are
     // double-buffered; a promotion (new top layer = new entry point), a one-node batch and sequential mode do not overlap.
     const size_t sz_cids = (size_t)layers_max * bmax * kCand, sz_cnt = (size_t)layers_max * bmax, sz_sel = (size_t)layers_max * bmax * 32;
-    if ((rc = salloc((void **)&d_iota, n * 4)) || (rc = salloc((void **)&d_locks, n * 4)) ||
+    int rc;
+    if ((rc = salloc((void **)&d_iota, count * 4)) || (rc = salloc((void **)&d_locks, rows_total * 4)) ||
         (rc = salloc((void **)&d_cids, 2 * sz_cids * 8)) || (rc = salloc((void **)&d_csc, 2 * sz_cids * 4)) ||
         (rc = salloc((void **)&d_cnt, 2 * sz_cnt * 4)) || (rc = salloc((void **)&d_sel, 2 * sz_sel * 4)) ||
         (rc = salloc((void **)&d_selcnt, 2 * sz_cnt * 4)) || (rc = salloc((void **)&d_status, (size_t)bmax * 4)) ||
@@ -737,24 +719,12 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
             return sbail2(fail(HVX_ERR_DEVICE, "event creation failed"));
     uint32_t *d_dbg = nullptr;
     if (tuning_env("HVX_BUILD_DEBUG")) {
-        if ((rc = salloc((void **)&d_dbg, 32))) return sbail(rc);
-        if (hipMemsetAsync(d_dbg, 0, 32, s) != hipSuccess) return sbail(fail(HVX_ERR_DEVICE, "memset"));
+        if ((rc = salloc((void **)&d_dbg, 32))) return sbail2(rc);
+        if (hipMemsetAsync(d_dbg, 0, 32, s) != hipSuccess) return sbail2(fail(HVX_ERR_DEVICE, "memset"));
     }
-    // scatter: rows whose ORDER follows the data (a dump sorted by topic, an index hydrated in key order) would put each other's nearest
-    // neighbours into one batch, where they cannot see each other: insert in the order (i * stride) mod n instead, stride ~ 0.618 n and
-    // coprime with n (position 0 stays row 0).  Sequential mode keeps id order: it IS the reference's order.
-    uint32_t stride = 1;
-    if (params->scatter && !params->sequential && n > 2) {
-        auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
-        uint64_t st = (uint64_t)((double)n * 0.6180339887498949);
-        while (st > 1 && gcd(st, n) != 1) --st;
-        stride = (uint32_t)std::max<uint64_t>(st, 1);
-    }
-    auto row_at = [&](uint64_t pos) -> uint64_t { return stride == 1 ? pos : (pos * stride) % n; };
-    hipLaunchKernelGGL(iota_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, d_iota, (uint32_t)n, stride);
-    if (hipMemsetAsync(d_locks, 0, n * 4, s) != hipSuccess || hipMemsetAsync(d_err, 0, 4, s) != hipSuccess) return sbail(fail(HVX_ERR_DEVICE, "memset"));
+    hipLaunchKernelGGL(iota_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, s, d_iota, (uint32_t)count, (uint32_t)first, stride, (uint32_t)std::max<uint64_t>(mod, 1));
+    if (hipMemsetAsync(d_locks, 0, rows_total * 4, s) != hipSuccess || hipMemsetAsync(d_err, 0, 4, s) != hipSuccess) return sbail2(fail(HVX_ERR_DEVICE, "memset"));
 
-    DevIndex &d = ix->dev;
     uint32_t *l0w = const_cast<uint32_t *>(d.l0), *upw = const_cast<uint32_t *>(d.up);
     const bool fused = kernel_fused(d.fkernel);
     // build_link_wg_kernel: column blocks of <= 8 chunks (256 floats) of Mmax + 1 candidate rows and the owner's in LDS, row stride
@@ -768,24 +738,28 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
     const BuildKernels kern = pick_build_kernels(d.metric, fused);
     const bool link_wg = params->link_mode != 1u && kern.link_wg && !kernel_w4(d.fkernel) /* 32-lane tree only */ && ncmax <= 33u && nk_rows > 0 && d.dim_main == d.dim && d.ld == d.dim &&
                          (size_t)(ncmax + 1u) * link_ck * 8u <= 9u * 256u;
-    // first node: the entry point with empty rows on its layers (mutation.rs:706-739)
-    d.has_entry = 1;
-    d.entry = 0;
-    d.max_layer = levels ? levels[0] : 0;
-    uint64_t done = 1, batches = 0, singles = 1;
+    uint64_t done = first, batches = 0, singles = 0;
+    if (!d.has_entry) { // the first node of an index: the entry point with empty rows on its layers (mutation.rs:706-739)
+        d.has_entry = 1;
+        d.entry = (uint32_t)row_at(first);
+        d.max_layer = levels ? levels[row_at(first)] : 0;
+        done = first + 1;
+        singles = 1;
+    }
     const uint32_t divisor = params->batch_divisor ? params->batch_divisor : 32u;
     bool prev_serial = true; // the previous batch must be complete before the next search starts
     // the iota / lock / err initialisation above ran on `s`: the link stream starts behind it
     if (hipEventRecord(ev_search[0], s) != hipSuccess || hipStreamWaitEvent(s2, ev_search[0], 0) != hipSuccess)
         return sbail2(fail(HVX_ERR_DEVICE, "stream ordering failed"));
-    while (done < n) {
+    const uint64_t end = first + count;
+    while (done < end) {
         // batch = consecutive positions of the insertion order; a node above the current top layer is inserted alone and becomes the entry point
         uint32_t bsz = 1;
         const uint16_t lv0 = levels ? levels[row_at(done)] : 0;
         const bool promotes = lv0 > d.max_layer;
         if (!promotes && !params->sequential) {
             uint64_t want = std::min<uint64_t>(std::max<uint64_t>(done / divisor, 1), bmax);
-            want = std::min<uint64_t>(want, n - done);
+            want = std::min<uint64_t>(want, end - done);
             while (bsz < want && !((levels ? levels[row_at(done + bsz)] : 0) > d.max_layer)) ++bsz;
         }
         const uint32_t pb = (uint32_t)(batches & 1u); // buffer set of this batch
@@ -811,7 +785,7 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
         a.out_counts = b_cnt;
         a.out_status = d_status;
         a.tie_flags = ix->d_tie;
-        a.build_nodes = d_iota + done;
+        a.build_nodes = d_iota + (done - first);
         a.occupancy = (bsz > 1024u && params->link_mode != 1u) ? 2 : 1; // more nodes than SIMDs: two searches per SIMD instead of two rounds
         if (launch_hnsw_wave(a, bsz, s) != hipSuccess) return sbail2(fail(HVX_ERR_DEVICE, "build search launch failed: %s", hipGetErrorString(hipGetLastError())));
         if (hipEventRecord(ev_search[pb], s) != hipSuccess || hipStreamWaitEvent(s2, ev_search[pb], 0) != hipSuccess)
@@ -821,7 +795,7 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
         ba.l0 = l0w;
         ba.up = upw;
         ba.locks = d_locks;
-        ba.nodes = d_iota + done;
+        ba.nodes = d_iota + (done - first);
         ba.b = bsz;
         ba.layers = layers;
         ba.cand_ids = b_cids;
@@ -869,16 +843,180 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
         fprintf(stderr, "[hvx build] link step: lock spins %u, prunes %u, reverse-edge removals %u, plain appends %u\n", h[0], h[1], h[2], h[3]);
     }
     release();
-    if (err) return bail(fail(HVX_ERR_INVARIANT, "a neighbour row overflowed its stride during the build"));
-    ix->desc.has_entry = 1;
-    ix->desc.entry_point = node_ids[d.entry];
-    ix->desc.max_layer = d.max_layer;
+    if (err) return fail(HVX_ERR_INVARIANT, "a neighbour row overflowed its stride during the build");
     if (stats) {
-        stats->batches = batches;
-        stats->single_node_batches = singles;
-        stats->nodes = n;
+        stats->batches += batches;
+        stats->single_node_batches += singles;
+        stats->nodes += count;
     }
+    return HVX_OK;
+}
+
+extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_ids, const float *vectors, const uint16_t *levels,
+                               const hvx_build_params *params, hvx_index **out, hvx_build_stats *stats) {
+    if (!desc || !out || !params) return fail(HVX_ERR_INVARIANT, "null argument");
+    *out = nullptr;
+    const uint64_t n = desc->n;
+    if (n && (!node_ids || !vectors)) return fail(HVX_ERR_INVARIANT, "null array");
+    const uint32_t m = desc->m ? desc->m : 16u;
+    const uint32_t m0 = std::max(desc->m0 ? desc->m0 : 2u * m, 2u * m); // MutationDegreeLimits (mutation.rs:178-196)
+    const uint32_t efc = params->ef_construction ? params->ef_construction : 200u;
+    if (desc->dtype != HVX_F32) return fail(HVX_ERR_UNSUPPORTED, "the device build reads f32 rows (import the built graph with a reduced-precision dtype afterwards)");
+    if (m0 > 32u || m > 32u) return fail(HVX_ERR_UNSUPPORTED, "device build serves m0 <= 32");
+    if (std::max(efc, m0) + 32u > 832u) return fail(HVX_ERR_UNSUPPORTED, "device build serves ef_construction <= 800");
+    const uint32_t ef0 = std::max(efc, m0);
+
+    // ---- the image: rows + EMPTY graph with rows sized for m0 / m (+ room for rows appended later: hvx_index_insert_batch) ----
+    hvx_index_desc d0 = *desc;
+    d0.m = m;
+    d0.m0 = m0;
+    d0.has_entry = 0;
+    d0.max_layer = 0;
+    if (d0.max_batch == 0) d0.max_batch = 1024;
+    uint64_t up_rows = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint16_t lv = levels ? levels[i] : 0;
+        if (lv > 63) return fail(HVX_ERR_INVARIANT, "node level > 63");
+        up_rows += lv;
+    }
+    std::vector<uint64_t> zeros0(n + 1, 0), zerosu(up_rows + 1, 0);
+    uint64_t dummy = 0;
+    hvx_index *ix = nullptr;
+    int rc = import_index(&d0, node_ids, vectors, zeros0.data(), &dummy, levels, zerosu.data(), &dummy, m0, m, &ix, params->reserve_rows,
+                          params->reserve_upper_rows);
+    if (rc) return rc;
+    auto bail = [&](int code) { hvx_index_free(ix); return code; };
+    HnswArgs probe{};
+    probe.ix = ix->dev;
+    probe.ef = ef0;
+    // the unrolled builds serve L2 / cosine, the AVX+FMA tree, dim in {128,...,1536}, ef_construction <= 352; everything else (any
+    // dimension, Manhattan, the scalar / AVX summation trees, ef_construction <= 800) takes the GENERIC build of the same kernel
+    if (!hnsw_wave_supported(probe) && (ix->dev.s0 > 64u || ix->dev.su > 64u))
+        return bail(fail(HVX_ERR_UNSUPPORTED, "device build serves neighbour rows of <= 64 ids"));
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (n == 0) { *out = ix; return HVX_OK; }
+    // scatter: rows whose ORDER follows the data (a dump sorted by topic, an index hydrated in key order) would put each other's nearest
+    // neighbours into one batch, where they cannot see each other: insert in the order (i * stride) mod n instead, stride ~ 0.618 n and
+    // coprime with n (position 0 stays row 0).  Sequential mode keeps id order: it IS the reference's order.
+    uint32_t stride = 1;
+    if (params->scatter && !params->sequential && n > 2) {
+        auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
+        uint64_t st = (uint64_t)((double)n * 0.6180339887498949);
+        while (st > 1 && gcd(st, n) != 1) --st;
+        stride = (uint32_t)std::max<uint64_t>(st, 1);
+    }
+    if ((rc = insert_range(ix, 0, n, levels, 0, params, stride, n, stats))) return bail(rc);
+    ix->desc.has_entry = 1;
+    ix->desc.entry_point = node_ids[ix->dev.entry];
+    ix->desc.max_layer = ix->dev.max_layer;
+    ix->publish_view();
     *out = ix;
+    return HVX_OK;
+}
+
+// insert_hnsw for rows APPENDED to a live image (mutation.rs:642-780 insert -> :787-895 insert_hnsw): the reference inserts one node at
+// a time into the store its readers snapshot; here a batch of new rows lands in the spare capacity of a growable image
+// (hvx_build_params.reserve_rows), is validated and given its headers / SimHash rows like imported rows, and is then linked into the
+// graph by the SAME loop the device build runs -- sequential mode = the reference's insertion, row for row.  The new generation
+// becomes visible (visible_seq + 1: rows, entry point, top layer) when the batch is complete; forks adopt it with hvx_index_refresh.
+// Searches that run on forks meanwhile keep their generation's entry point and read neighbour rows as stale-or-current, never torn:
+// a new node's vector, header and own rows are complete before the first link to it is stored (hvx_build.hip, row locks +
+// agent-scope stores), exactly what the overlapped batches of the device build rely on.
+extern "C" int hvx_index_insert_batch(hvx_index *ix, const uint64_t *node_ids, const float *vectors, const uint16_t *levels, uint32_t count,
+                                      const hvx_build_params *params, hvx_build_stats *stats) {
+    if (!ix || (count && (!node_ids || !vectors))) return fail(HVX_ERR_INVARIANT, "null argument");
+    hvx_build_params dflt;
+    hvx_build_params_default(&dflt);
+    if (!params) params = &dflt;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (count == 0) return HVX_OK;
+    if (ix->is_fork) return fail(HVX_ERR_UNSUPPORTED, "rows are inserted through the handle that owns the image, not a fork");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    DevIndex &d = ix->dev;
+    if (d.dtype != HVX_F32) return fail(HVX_ERR_UNSUPPORTED, "rows are inserted into f32 images (import the grown graph with a reduced-precision dtype afterwards)");
+    const uint32_t m = ix->desc.m ? ix->desc.m : 16u;
+    const uint32_t m0 = std::max(ix->desc.m0 ? ix->desc.m0 : 2u * m, 2u * m);
+    const uint32_t efc = params->ef_construction ? params->ef_construction : 200u;
+    if (m0 > 32u || m > 32u || d.s0 < m0 || d.su < m) return fail(HVX_ERR_UNSUPPORTED, "the image's neighbour rows are narrower than the degree limits (build it with hvx_index_build)");
+    if (std::max(efc, m0) + 32u > 832u) return fail(HVX_ERR_UNSUPPORTED, "device build serves ef_construction <= 800");
+    const uint64_t n0 = d.n;
+    if (n0 + count > ix->cap_rows)
+        return fail(HVX_ERR_CANDIDATE_LIMIT, "the image holds %llu of %llu rows: %u more do not fit (hvx_build_params.reserve_rows)", (unsigned long long)n0,
+                    (unsigned long long)ix->cap_rows, count);
+    uint64_t up_need = 0;
+    for (uint32_t i = 0; i < count; ++i) {
+        const uint16_t lv = levels ? levels[i] : 0;
+        if (lv > 63) return fail(HVX_ERR_INVARIANT, "node level > 63");
+        up_need += lv;
+        // ids stay strictly ascending over the whole image (the reference allocates dense ascending u64 ids: index_lifecycle_scale.rs:1504-1514)
+        const uint64_t prev = i ? node_ids[i - 1] : (n0 ? ix->ids_ref()[n0 - 1] : 0);
+        if ((i || n0) && node_ids[i] <= prev) return fail(HVX_ERR_INVARIANT, "inserted node ids must be ascending and above every id of the image (id %llu)", (unsigned long long)node_ids[i]);
+    }
+    if (ix->up_rows_used + up_need > ix->cap_up_rows)
+        return fail(HVX_ERR_CANDIDATE_LIMIT, "the image's upper-layer rows are exhausted (%llu + %llu > %llu: hvx_build_params.reserve_upper_rows)",
+                    (unsigned long long)ix->up_rows_used, (unsigned long long)up_need, (unsigned long long)ix->cap_up_rows);
+    HnswArgs probe{};
+    probe.ix = d;
+    probe.ef = std::max(efc, m0);
+    if (!hnsw_wave_supported(probe) && (d.s0 > 64u || d.su > 64u)) return fail(HVX_ERR_UNSUPPORTED, "device build serves neighbour rows of <= 64 ids");
+    hipStream_t s = ix->stream;
+    // ---- the rows: upload into the spare capacity, validate, headers (nothing is visible yet: d.n still ends before them) ----
+    float *vdst = const_cast<float *>(d.vec) + (size_t)n0 * d.ld;
+    if (d.ld == d.dim) {
+        HIP_TRY(hipMemcpyAsync(vdst, vectors, (size_t)count * d.dim * 4, hipMemcpyDefault, s));
+    } else {
+        HIP_TRY(hipMemsetAsync(vdst, 0, (size_t)count * d.ld * 4, s));
+        HIP_TRY(hipMemcpy2DAsync(vdst, (size_t)d.ld * 4, vectors, (size_t)d.dim * 4, (size_t)d.dim * 4, count, hipMemcpyDefault, s));
+    }
+    uint32_t *d_rowstatus = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_rowstatus, (size_t)count * 4));
+    {
+        DevIndex view = d;
+        view.vec = vdst;
+        std::vector<uint32_t> st(count);
+        hipError_t e = launch_validate_rows(view, count, ix->limit, d_rowstatus, const_cast<float *>(d.hdr) + n0, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(st.data(), d_rowstatus, (size_t)count * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        (void)hipFree(d_rowstatus);
+        if (e != hipSuccess) return fail(HVX_ERR_DEVICE, "row validation: %s", hipGetErrorString(e));
+        for (uint32_t i = 0; i < count; ++i)
+            if (st[i]) return fail((int)st[i], "vector of node %llu is invalid for this metric (status %u)", (unsigned long long)node_ids[i], st[i]);
+    }
+    // ---- levels, upper-row bases, ids ----
+    std::vector<uint16_t> h_lv(count, 0);
+    std::vector<uint32_t> h_base(count, kSentinel);
+    uint64_t r = ix->up_rows_used;
+    for (uint32_t i = 0; i < count; ++i) {
+        h_lv[i] = levels ? levels[i] : 0;
+        if (h_lv[i]) { h_base[i] = (uint32_t)r; r += h_lv[i]; }
+    }
+    HIP_TRY(hipMemcpyAsync(const_cast<uint16_t *>(d.level) + n0, h_lv.data(), (size_t)count * 2, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(const_cast<uint32_t *>(d.up_base) + n0, h_base.data(), (size_t)count * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(const_cast<uint64_t *>(d.ids) + n0, node_ids, (size_t)count * 8, hipMemcpyHostToDevice, s));
+    if (ix->has_simhash) { // SimHash rows of the new nodes (SimHasher::hash at insert time: mutation.rs:700-705)
+        HIP_TRY(launch_simhash_rows(ix->d_planes_t, vdst, d.dim, d.ld, count, ix->d_node_hash + n0, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s)); // (the host vectors above leave scope)
+    auto grown = std::make_shared<std::vector<uint64_t>>();
+    grown->reserve(n0 + count);
+    grown->insert(grown->end(), ix->ids_ref().begin(), ix->ids_ref().end());
+    grown->insert(grown->end(), node_ids, node_ids + count);
+    bool contiguous = ix->contiguous && (n0 == 0 || node_ids[0] == ix->ids_ref()[n0 - 1] + 1);
+    for (uint32_t i = 1; i < count && contiguous; ++i) contiguous = node_ids[i] == node_ids[i - 1] + 1;
+    ix->ids_p = grown;
+    ix->contiguous = contiguous;
+    d.n = (uint32_t)(n0 + count);
+    ix->desc.n = d.n;
+    ix->up_rows_used = r;
+    // ---- link them into the graph ----
+    int rc = insert_range(ix, n0, count, h_lv.data(), n0, params, 1u, 0, stats);
+    if (rc) return rc; // (the image is partially linked: the host discards the handle and re-hydrates)
+    ix->desc.has_entry = 1;
+    ix->desc.entry_point = ix->ids_ref()[d.entry];
+    ix->desc.max_layer = d.max_layer;
+    ix->desc.shard_id_hi = ix->ids_ref()[d.n - 1];
+    ix->publish_view();
     return HVX_OK;
 }
 

@@ -693,24 +693,27 @@ int flat_mfma_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t
 // waits for its conversion kernel before publishing the pointer: another lane may use it from its own stream right away.
 static int ensure_shadow(hvx_index *ix) {
     const DevIndex &d = ix->dev;
-    if (ix->m_shadow) return HVX_OK;
     hvx_image_shared &sh = *ix->shared;
     std::lock_guard<std::mutex> lock(sh.mu);
-    if (sh.shadow) { ix->m_shadow = sh.shadow; return HVX_OK; }
-    if (sh.shadow_failed) return HVX_OK;
-    void *p = nullptr;
-    if (hipMalloc(&p, std::max<size_t>((size_t)d.n * d.dim * 2, 16)) != hipSuccess) {
-        (void)hipGetLastError();
-        sh.shadow_failed = true;
-        return HVX_OK;
+    if (sh.shadow_failed) { ix->m_shadow = nullptr; return HVX_OK; }
+    if (!sh.shadow) { // sized for every row the image can ever hold (hvx_build_params.reserve_rows): appended rows are converted below
+        void *p = nullptr;
+        const size_t rows_cap = std::max<uint64_t>(ix->cap_rows, d.n);
+        if (hipMalloc(&p, std::max<size_t>(rows_cap * d.dim * 2, 16)) != hipSuccess) {
+            (void)hipGetLastError();
+            sh.shadow_failed = true;
+            return HVX_OK;
+        }
+        sh.device = ix->device;
+        sh.shadow = reinterpret_cast<uint16_t *>(p);
+        sh.shadow_rows = 0;
     }
-    hipLaunchKernelGGL(bf16_shadow_kernel, dim3(2048), dim3(256), 0, ix->stream, d.vec, (size_t)d.n * d.dim / 4, reinterpret_cast<uint16_t *>(p));
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ix->stream) != hipSuccess) {
-        (void)hipFree(p);
-        return fail(HVX_ERR_DEVICE, "bf16 shadow conversion failed");
+    if (sh.shadow_rows < d.n) { // the rows that are new since the shadow was last extended (all of them the first time)
+        const size_t r0 = sh.shadow_rows, cnt = d.n - r0;
+        hipLaunchKernelGGL(bf16_shadow_kernel, dim3(2048), dim3(256), 0, ix->stream, d.vec + r0 * d.ld, cnt * d.dim / 4, sh.shadow + r0 * d.dim);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ix->stream) != hipSuccess) return fail(HVX_ERR_DEVICE, "bf16 shadow conversion failed");
+        sh.shadow_rows = d.n;
     }
-    sh.device = ix->device;
-    sh.shadow = reinterpret_cast<uint16_t *>(p);
     ix->m_shadow = sh.shadow;
     return HVX_OK;
 }
@@ -748,14 +751,19 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
     // the 256 x 256 filtered contraction (hvx_flat_tile.hip) serves the one-pass attempt of scans with dim % 64 == 0
     // (its query tile is 256 wide: a batch of <= 128 queries wastes less on the 128 x 128 kernel)
     const bool tile_ok = d.dim % 64u == 0u && (b > 128u || ix->opt[HVX_OPT_FLAT_FIRST_CHUNK]) && !ix->opt[HVX_OPT_FLAT_NO_TILE];
-    if (f32 && !ix->m_rowterm) { // |x|^2 per row and its maximum: once per index, on first use
-        if ((rc = ix->dalloc((void **)&ix->m_rowterm, std::max<size_t>(d.n, 1) * 4))) return rc;
-        std::vector<float> h_n2(d.n);
-        HIP_TRY(launch_f32_row_norm2(d.vec, d.n, d.ld, d.dim, ix->m_rowterm, ix->stream));
-        HIP_TRY(hipMemcpyAsync(h_n2.data(), ix->m_rowterm, (size_t)d.n * 4, hipMemcpyDeviceToHost, ix->stream));
+    if (f32 && (!ix->m_rowterm || ix->rowterm_rows < d.n)) { // |x|^2 per row and its maximum: on first use, and for rows appended since
+        if (!ix->m_rowterm) {
+            if ((rc = ix->dalloc((void **)&ix->m_rowterm, std::max<size_t>(std::max<uint64_t>(ix->cap_rows, d.n), 1) * 4))) return rc;
+            ix->rowterm_rows = 0;
+            ix->m_xmax2 = 0.f;
+        }
+        const uint32_t r0 = ix->rowterm_rows, cnt = d.n - r0;
+        std::vector<float> h_n2(cnt);
+        HIP_TRY(launch_f32_row_norm2(d.vec + (size_t)r0 * d.ld, cnt, d.ld, d.dim, ix->m_rowterm + r0, ix->stream));
+        HIP_TRY(hipMemcpyAsync(h_n2.data(), ix->m_rowterm + r0, (size_t)cnt * 4, hipMemcpyDeviceToHost, ix->stream));
         HIP_TRY(hipStreamSynchronize(ix->stream));
-        ix->m_xmax2 = 0.f;
         for (float v : h_n2) ix->m_xmax2 = std::max(ix->m_xmax2, v);
+        ix->rowterm_rows = d.n;
     }
     hipLaunchKernelGGL(split_queries_kernel, dim3(bpad), dim3(64), 0, ix->stream, d_queries, b, bpad, d.dim, ix->m_qhi, ix->m_qlo, ix->m_qn2,
                        f32 ? 2u : (fp8 ? 1u : 0u), fp8 && tile_ok ? ix->m_qhi8 : nullptr);

@@ -29,6 +29,7 @@ struct hvx_image_shared {
     std::mutex mu;
     int device = 0;
     uint16_t *shadow = nullptr;   // f32 rows: bf16 (RNE) shadow of the rows for the large-tile exact-scan kernels (hvx_flat_tile.hip)
+    uint32_t shadow_rows = 0;     // rows of it that are converted (a growable image extends it on the next scan)
     bool shadow_failed = false;   // no memory for it: the scan stays on the 128 x 128 kernel
     // the SimHash directory of the restricted walk (hvx_restricted_walk.hip): the rows [0xF1][index][0x17][order_code][node]
     // in key order = (order code, row) ascending, built from the attached SimHash rows on first use
@@ -36,6 +37,16 @@ struct hvx_image_shared {
     uint32_t *dir_row = nullptr;
     uint32_t *dir_prefix = nullptr;    // [65537] first directory entry per 16-bit order-code prefix
     const uint64_t *dir_for = nullptr; // the node_hash array the directory was derived from
+    uint32_t dir_rows = 0;             // rows the directory covers (an image that has grown since needs a new one)
+    // Generation view of a GROWABLE image (hvx_build_params.reserve_rows; hvx_index_insert_batch): the rows, entry point and top
+    // layer that are visible.  Written by the owner handle when an insert batch is complete (visible_seq + 1), adopted by a fork
+    // when the host calls hvx_index_refresh on it -- the registry's attach rule (read_index.rs:55-61: a cache guard serves a
+    // snapshot only when hydration_seq == snapshot_seq) decides when.
+    uint64_t visible_seq = 0;
+    uint32_t v_n = 0, v_entry = 0, v_max_layer = 0, v_has_entry = 0;
+    uint64_t v_entry_point = 0;
+    bool v_contiguous = true;
+    std::shared_ptr<const std::vector<uint64_t>> v_ids;
     ~hvx_image_shared() {
         if (shadow || dir_code || dir_row) (void)hipSetDevice(device);
         if (shadow) (void)hipFree(shadow);
@@ -67,6 +78,10 @@ struct hvx_index {
     std::shared_ptr<hvx_allocs> allocs = std::make_shared<hvx_allocs>();
     std::vector<std::shared_ptr<hvx_allocs>> image; // fork: the allocations of the handles it descends from (the image it aliases)
     bool is_fork = false;
+    // growable image: rows / upper rows the arrays were allocated for, upper rows in use, the generation this handle's view shows
+    uint64_t cap_rows = 0, cap_up_rows = 0, up_rows_used = 0, seen_seq = 0;
+    void publish_view();   // owner: this handle's view becomes the image's visible generation (visible_seq + 1)
+    bool adopt_view();     // any handle: take the image's visible generation; true if the view changed
     std::shared_ptr<const std::vector<uint64_t>> ids_p = std::make_shared<std::vector<uint64_t>>(); // host copy of node ids
     const std::vector<uint64_t> &ids_ref() const { return *ids_p; }
     bool contiguous = false;
@@ -124,6 +139,7 @@ struct hvx_index {
     size_t cap_cand = 0, cap_cand_b = 0;
     size_t cap_qsplit = 0;
     float m_xmax2 = 0.f;
+    uint32_t rowterm_rows = 0;       // rows m_rowterm / m_xmax2 cover
     uint32_t m_fast_misses = 0, m_fast_skipped = 0; // consecutive scans whose one-pass attempt missed a certificate / scans that skipped it
     // non-strict search arms (hvx_params.hip): per-node SimHash rows, the hasher, per-batch fingerprints
     bool has_simhash = false;
@@ -168,7 +184,7 @@ inline const char *tuning_env(const char *) { return nullptr; }
 int fail(int code, const char *fmt, ...);
 int import_index(const hvx_index_desc *desc, const uint64_t *node_ids, const float *vectors, const uint64_t *l0_offsets,
                  const uint64_t *l0_neighbors, const uint16_t *level, const uint64_t *up_offsets, const uint64_t *up_neighbors,
-                 uint32_t min_s0, uint32_t min_su, hvx_index **out);
+                 uint32_t min_s0, uint32_t min_su, hvx_index **out, uint64_t reserve_rows = 0, uint64_t reserve_up_rows = 0);
 int check_k_ef(uint32_t k, uint32_t ef);
 // enqueue validation + the search kernel for one chunk of <= max_batch device-resident queries;
 // ad != NULL selects the non-strict arms

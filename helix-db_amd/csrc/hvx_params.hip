@@ -63,7 +63,7 @@ extern "C" int hvx_index_set_simhash(hvx_index *ix, const hvx_simhash_config *cf
         if (!ix->d_planes_t && (rc = ix->dalloc((void **)&ix->d_planes_t, planes_t.size() * 4))) return rc;
         HIP_TRY(hipMemcpy(ix->d_planes_t, planes_t.data(), planes_t.size() * 4, hipMemcpyHostToDevice));
     }
-    if (!ix->d_node_hash && (rc = ix->dalloc((void **)&ix->d_node_hash, (size_t)std::max<uint32_t>(n, 1) * 8))) return rc;
+    if (!ix->d_node_hash && (rc = ix->dalloc((void **)&ix->d_node_hash, (size_t)std::max<uint64_t>(std::max<uint64_t>(ix->cap_rows, n), 1) * 8))) return rc; // (room for appended rows)
     if (!ix->d_qhash && (rc = ix->dalloc((void **)&ix->d_qhash, (size_t)ix->max_batch * 8))) return rc;
     if (!ix->d_thr_break && (rc = ix->dalloc((void **)&ix->d_thr_break, 64 * 4))) return rc;
     if (!ix->d_astats && (rc = ix->dalloc((void **)&ix->d_astats, (size_t)ix->max_batch * sizeof(hvx_adaptive_stats)))) return rc;

@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const uint64_t *keys, c
 int ensure_directory(hvx_index *ix) {
     hvx_image_shared &sh = *ix->shared;
     std::lock_guard<std::mutex> lock(sh.mu);
-    if (sh.dir_code && sh.dir_for == ix->d_node_hash) return HVX_OK;
+    if (sh.dir_code && sh.dir_for == ix->d_node_hash && sh.dir_rows == ix->dev.n) return HVX_OK; // (an image that has grown gets a new directory)
     const uint32_t n = ix->dev.n, n1 = std::max<uint32_t>(n, 1);
     hipStream_t s = ix->stream;
     for (void **p : {(void **)&sh.dir_code, (void **)&sh.dir_row, (void **)&sh.dir_prefix})
@@ -436,6 +436,7 @@ int ensure_directory(hvx_index *ix) {
         return bail(fail(HVX_ERR_DEVICE, "building the SimHash directory failed: %s", hipGetErrorString(hipGetLastError())));
     release();
     sh.dir_for = ix->d_node_hash;
+    sh.dir_rows = ix->dev.n;
     return HVX_OK;
 }
 

@@ -109,7 +109,7 @@ def decode_index_metadata(value: bytes) -> dict:
 
 class BuildParams(C.Structure):  # hvx_build_params
     _fields_ = [("ef_construction", C.c_uint32), ("max_batch", C.c_uint32), ("batch_divisor", C.c_uint32), ("sequential", C.c_uint32),
-                ("link_mode", C.c_uint32), ("scatter", C.c_uint32)]
+                ("link_mode", C.c_uint32), ("scatter", C.c_uint32), ("reserve_rows", C.c_uint64), ("reserve_upper_rows", C.c_uint64)]
 
 
 class BuildStats(C.Structure):  # hvx_build_stats
@@ -555,7 +555,8 @@ class ValidatedVectorReadIndex:
 
     @classmethod
     def build(cls, *, dim, metric, node_ids, vectors, levels=None, m=16, m0=32, ef_construction=200, max_batch=2048,
-              batch_divisor=32, sequential=False, device=-1, search_max_batch=None, float_kernel=KERNEL_AVX_FMA, link_mode=0, scatter=False):
+              batch_divisor=32, sequential=False, device=-1, search_max_batch=None, float_kernel=KERNEL_AVX_FMA, link_mode=0, scatter=False,
+              reserve_rows=0, reserve_upper_rows=None):
         """GPU-assisted HNSW build (hvx_index_build): the reference's insert_hnsw for batches of nodes on the device.
         Returns (index, stats dict).  `vectors` may be a host array or a torch tensor resident on the device."""
         ids = np.ascontiguousarray(node_ids, dtype=np.uint64)
@@ -567,13 +568,61 @@ class ValidatedVectorReadIndex:
         d = _Desc(dim=dim, metric=metric, dtype=F32, float_kernel=float_kernel, n=ids.size, m=m, m0=m0, has_entry=0, max_layer=0,
                   entry_point=0, shard_id_lo=int(ids[0]) if ids.size else 0, shard_id_hi=int(ids[-1]) if ids.size else 0,
                   device=device, max_batch=max(max_batch, search_max_batch or 1024))
+        if reserve_upper_rows is None:  # the expected number of upper rows of `reserve_rows` nodes under the layer rule, with slack
+            reserve_upper_rows = int(reserve_rows / max(m - 1, 1) * 1.5) + (64 if reserve_rows else 0)
         bp = BuildParams(ef_construction=ef_construction, max_batch=max_batch, batch_divisor=batch_divisor, sequential=1 if sequential else 0,
-                         link_mode=link_mode, scatter=1 if scatter else 0)
+                         link_mode=link_mode, scatter=1 if scatter else 0, reserve_rows=int(reserve_rows), reserve_upper_rows=int(reserve_upper_rows))
         st = BuildStats()
         h = _vp()
         _check(lib().hvx_index_build(C.byref(d), _ptr(ids), _vp(vectors.data_ptr()) if dev_rows else _ptr(vec), _ptr(lv), C.byref(bp),
                                      C.byref(h), C.byref(st)))
         return cls(h, dim, metric, int(ids.size)), {"nodes": st.nodes, "batches": st.batches, "single_node_batches": st.single_node_batches}
+
+    def insert_batch(self, node_ids, vectors, levels=None, *, ef_construction=200, max_batch=2048, batch_divisor=32, sequential=False, link_mode=0):
+        """hvx_index_insert_batch: append rows to a growable image (build(..., reserve_rows=...)) and link them into the graph; the new
+        generation is visible on this handle when the call returns (forks: refresh()).  Returns the build-stats dict of the batch."""
+        ids = np.ascontiguousarray(node_ids, dtype=np.uint64)
+        dev_rows = hasattr(vectors, "data_ptr")
+        if dev_rows:
+            _sync_producer(vectors)
+        vec = None if dev_rows else np.ascontiguousarray(vectors, dtype=np.float32).reshape(ids.size, self.dim)
+        lv = None if levels is None else np.ascontiguousarray(levels, dtype=np.uint16)
+        bp = BuildParams(ef_construction=ef_construction, max_batch=max_batch, batch_divisor=batch_divisor, sequential=1 if sequential else 0,
+                         link_mode=link_mode)
+        st = BuildStats()
+        L = lib()
+        L.hvx_index_insert_batch.restype = C.c_int
+        L.hvx_index_insert_batch.argtypes = [_vp, _vp, _vp, _vp, C.c_uint32, C.POINTER(BuildParams), C.POINTER(BuildStats)]
+        _check(L.hvx_index_insert_batch(self._h, _ptr(ids), _vp(vectors.data_ptr()) if dev_rows else _ptr(vec), _ptr(lv), int(ids.size), C.byref(bp), C.byref(st)))
+        self.n = self.rows()
+        return {"nodes": st.nodes, "batches": st.batches, "single_node_batches": st.single_node_batches}
+
+    def refresh(self):
+        """hvx_index_refresh: a fork adopts the image's visible generation (rows, entry point, top layer)"""
+        L = lib()
+        L.hvx_index_refresh.restype = C.c_int
+        L.hvx_index_refresh.argtypes = [_vp]
+        _check(L.hvx_index_refresh(self._h))
+        self.n = self.rows()
+        return self
+
+    def rows(self) -> int:
+        L = lib()
+        L.hvx_index_rows.restype = C.c_uint64
+        L.hvx_index_rows.argtypes = [_vp]
+        return int(L.hvx_index_rows(self._h))
+
+    def row_capacity(self) -> int:
+        L = lib()
+        L.hvx_index_row_capacity.restype = C.c_uint64
+        L.hvx_index_row_capacity.argtypes = [_vp]
+        return int(L.hvx_index_row_capacity(self._h))
+
+    def visible_seq(self) -> int:
+        L = lib()
+        L.hvx_index_visible_seq.restype = C.c_uint64
+        L.hvx_index_visible_seq.argtypes = [_vp]
+        return int(L.hvx_index_visible_seq(self._h))
 
     def export_graph(self) -> dict:
         """The index's graph in hvx_index_import's CSR layout (external ids): what the host persists / tests compare."""

@@ -87,6 +87,18 @@ class DeviceIndexRegistry:
             e.index, e.visible_seq, e.state = index, int(visible_seq), READY
             return True
 
+    def advance(self, identity: VectorCacheIdentity, visible_seq: int) -> bool:
+        """Round 5: the owner applied a write batch to the resident copy (hvx_index_insert_batch on a growable image) and the copy now
+        holds every row up to database sequence `visible_seq`: requests whose snapshot is that sequence attach again, older snapshots
+        keep falling back to the storage path (the attach rule itself is unchanged: equality).  False when the entry is not Ready (being
+        hydrated, retired or closed) or the sequence would move backwards -- the caller then re-hydrates instead."""
+        with self._lock:
+            e = self._entries.get(identity)
+            if e is None or e.state != READY or e.visible_seq is None or int(visible_seq) < e.visible_seq:
+                return False
+            e.visible_seq = int(visible_seq)
+            return True
+
     def attach(self, identity: VectorCacheIdentity, metric: int, snapshot_seq: Optional[int]) -> Optional[ReadGuard]:
         """read_index.rs:43-71.  `snapshot_seq=None` is VectorReadVisibility::Unavailable."""
         with self._lock:

@@ -620,6 +620,8 @@ typedef struct hvx_build_params {
                                  id order.  For rows whose order follows the data (dumps sorted by topic, indexes hydrated in key order):
                                  the nodes of one batch do not see each other, and consecutive rows of such data are each other's
                                  nearest neighbours.  Ignored by sequential mode (= the reference's insertion order). */
+    uint64_t reserve_rows;       /* hvx_index_build: room for this many rows beyond desc->n (hvx_index_insert_batch appends into it) */
+    uint64_t reserve_upper_rows; /* ... and for this many upper-layer rows (sum of the levels of the nodes appended later) */
 } hvx_build_params;
 typedef struct hvx_build_stats {
     uint64_t nodes, batches, single_node_batches;
@@ -628,6 +630,26 @@ void hvx_build_params_default(hvx_build_params *);
 int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_ids, const float *vectors /*host or device*/,
                     const uint16_t *levels /*[n] or NULL = all layer 0*/, const hvx_build_params *params, hvx_index **out,
                     hvx_build_stats *stats /*nullable*/);
+/*
+ * Incremental insert into a LIVE image (VectorIndex::insert -> insert_hnsw, mutation.rs:642-895): `count` new nodes -- ids ascending
+ * and above every id of the image, f32 vectors (host or device memory), levels as hvx_index_build takes them -- are appended to
+ * the spare capacity of an image built with hvx_build_params.reserve_rows (HVX_ERR_CANDIDATE_LIMIT when they do not fit),
+ * validated like imported rows (an invalid vector fails the call before anything changes), given headers and -- when SimHash
+ * rows are attached -- SimHash rows, and linked into the graph by the loop hvx_index_build runs: params->sequential = 1 is the
+ * reference's insertion row for row (tests/test_gpu_build.py), the batched mode trades that for throughput exactly as the build
+ * does.  params = NULL: the defaults.  The call goes through the handle that owns the image; when it returns the new generation
+ * is visible on that handle (hvx_index_visible_seq + 1, hvx_index_rows grown) and every fork adopts it with hvx_index_refresh --
+ * the host's registry decides when (read_index.rs:55-61: a resident copy serves a snapshot only when its sequence matches).
+ * Forks may keep searching during the call: they see their own generation's entry point, and neighbour rows as stale-or-current,
+ * never torn.  A failure after validation leaves the image partially linked: discard the handle and hydrate again.
+ */
+int hvx_index_insert_batch(hvx_index *, const uint64_t *node_ids /*[count]*/, const float *vectors /*[count][dim]*/,
+                           const uint16_t *levels /*[count] or NULL*/, uint32_t count, const hvx_build_params *params /*nullable*/,
+                           hvx_build_stats *stats /*nullable*/);
+int hvx_index_refresh(hvx_index *);                 /* adopt the image's visible generation (a fork; a no-op when nothing changed) */
+uint64_t hvx_index_visible_seq(const hvx_index *);  /* generation this handle searches: 1 after import / build, +1 per insert batch */
+uint64_t hvx_index_rows(const hvx_index *);         /* rows visible to this handle */
+uint64_t hvx_index_row_capacity(const hvx_index *); /* rows the image can hold */
 /*
  * add_bidirectional_link(from -> to) on layer 0 of an index image (mutation.rs:1498-1583): `from` is appended to the row of
  * `to` under the row's lock; a row beyond Mmax is pruned (rank by distance to the owner, select_diverse + backfill,

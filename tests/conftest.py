@@ -12,6 +12,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "helix-db_amd")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "gpu2: needs TWO devices on one node (RCCL between real ranks); skipped where only one is visible")
 
 
 @pytest.fixture(scope="session")

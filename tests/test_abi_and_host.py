@@ -703,10 +703,21 @@ def test_device_index_registry_attaches_only_exact_generation_and_sequence():
     assert reg.attach(ident, hv.COSINE, None) is None         # VectorReadVisibility::Unavailable
     with pytest.raises(rg.MetricMismatch):
         reg.attach(ident, hv.EUCLIDEAN, 9)
+    # round 5: the resident copy takes the write batch of sequence 12 (hvx_index_insert_batch) -> requests at 12 attach, 9 no longer
+    assert reg.advance(ident, 12) is True
+    assert reg.attach(ident, hv.COSINE, 9) is None
+    with reg.attach(ident, hv.COSINE, 12) as later:
+        assert later.index is ix
+    assert reg.advance(ident, 11) is False and reg.advance(ident, 9) is False      # never backwards
+    exact.release()
+    exact = reg.attach(ident, hv.COSINE, 12)                  # the guard that fences the retirement below
+    assert exact is not None
     other = rg.VectorCacheIdentity("legacy-unscoped", 4, 2, 40, 1)   # next generation of the same index
     assert reg.attach(other, hv.COSINE, 9) is None
+    assert reg.advance(other, 13) is False                    # never hydrated
     reg.retire(ident)                                         # replaced: no new guards, memory kept while `exact` lives
-    assert reg.state(ident) == rg.RETIRING and not ix.closed and reg.attach(ident, hv.COSINE, 9) is None
+    assert reg.state(ident) == rg.RETIRING and not ix.closed and reg.attach(ident, hv.COSINE, 12) is None
+    assert reg.advance(ident, 14) is False                    # a retiring entry takes no more writes
     exact.release()
     assert ix.closed and reg.state(ident) == rg.CLOSED
     assert reg.entry_for(ident, hv.COSINE) is True            # a closed entry can be hydrated again

@@ -1612,8 +1612,27 @@ def test_shard_group_runs_search_allgather_merge_in_one_call(orc, hv):
     assert ids[:7].cpu().numpy().astype(np.uint64).tolist() == want[0][:7].tolist()
     with pytest.raises(hv.HelixDbError):
         grp.search_batch_device(dq, 17, 64, ids, sc, cnt)  # k beyond the group's max_k
-    grp.close()
+    # round 5: a second execution lane of the rank joins the SAME communicator (hvx_shard_group_attach); steps of both lanes
+    # alternate, their all-gathers share the rank's exchange stream; either group may be freed first
+    assert hv.rccl_version() >= 2000
+    lane2 = gix.fork()
+    grp2 = grp.attach(lane2)
+    ids2 = torch.zeros(b, k, dtype=torch.int64, device=dev); sc2 = torch.zeros(b, k, dtype=torch.float32, device=dev)
+    cnt2 = torch.zeros(b, dtype=torch.int32, device=dev)
+    for _ in range(4):
+        grp.search_batch_device(dq, k, ef, ids, sc, cnt)
+        grp2.search_batch_device(dq, k, ef, ids2, sc2, cnt2)
+    lane.sync(); lane2.sync()
+    for got_i, got_s, got_c in ((ids, sc, cnt), (ids2, sc2, cnt2)):
+        assert got_i.cpu().numpy().astype(np.uint64).tolist() == want[0].tolist()
+        assert bits(got_s.cpu().numpy()).tolist() == bits(want[1]).tolist() and got_c.cpu().numpy().tolist() == want[2].tolist()
+    grp.close()                                            # the primary goes first: the communicator stays with grp2
+    grp2.search_batch_device(dq, k, ef, ids2, sc2, cnt2)
+    lane2.sync()
+    assert ids2.cpu().numpy().astype(np.uint64).tolist() == want[0].tolist()
+    grp2.close()
     lane.close()
+    lane2.close()
 
 
 # --- the one-pass small-batch exact scan (hvx_flat_smallb.hip): b <= 128 queries, rows held in registers ---

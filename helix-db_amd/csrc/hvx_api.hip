@@ -469,9 +469,9 @@ int hvx::import_index(const hvx_index_desc *desc, const uint64_t *node_ids, cons
 }
 
 // ---- generation view of a growable image (hvx_host.h) ----
-void hvx_index::publish_view() {
+void hvx_index::publish_view(bool bump) {
     std::lock_guard<std::mutex> g(shared->mu);
-    shared->visible_seq += 1;
+    if (bump) shared->visible_seq += 1;
     shared->v_n = dev.n;
     shared->v_entry = dev.entry;
     shared->v_max_layer = dev.max_layer;

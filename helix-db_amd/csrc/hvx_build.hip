@@ -909,7 +909,7 @@ extern "C" int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_
     ix->desc.has_entry = 1;
     ix->desc.entry_point = node_ids[ix->dev.entry];
     ix->desc.max_layer = ix->dev.max_layer;
-    ix->publish_view();
+    ix->publish_view(/*bump=*/false); // generation 1 = the built image (import_index published the empty graph under the same number)
     *out = ix;
     return HVX_OK;
 }

@@ -80,7 +80,7 @@ struct hvx_index {
     bool is_fork = false;
     // growable image: rows / upper rows the arrays were allocated for, upper rows in use, the generation this handle's view shows
     uint64_t cap_rows = 0, cap_up_rows = 0, up_rows_used = 0, seen_seq = 0;
-    void publish_view();   // owner: this handle's view becomes the image's visible generation (visible_seq + 1)
+    void publish_view(bool bump = true); // owner: this handle's view becomes the image's visible generation (visible_seq + 1 when bump)
     bool adopt_view();     // any handle: take the image's visible generation; true if the view changed
     std::shared_ptr<const std::vector<uint64_t>> ids_p = std::make_shared<std::vector<uint64_t>>(); // host copy of node ids
     const std::vector<uint64_t> &ids_ref() const { return *ids_p; }

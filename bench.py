@@ -251,6 +251,11 @@ def timed_steps(ls, qs, ef, steps, warmup, barrier):
     for i in range(warmup):
         ls.step(i, qs[i % nb], ef)
     ls.sync()
+    # The GPU boxes of this pool run the process under a CPU quota (cgroup cpu.max = 16 cores per 100 ms period): a burst of host threads
+    # right before the timed region (graph export / import, oracle checks) exhausts the period's budget and the kernel then FREEZES every
+    # thread of the process for the rest of it -- in the middle of 20 launches that take 14 ms (r05i: 2.7 ms of wall time per step over
+    # kernels that took 0.70).  One idle scheduler period lets the budget refill; nothing is timed here.
+    time.sleep(0.12)
     barrier()
     for h in ls.handles:
         h.timing_begin((steps + L - 1) // L)
@@ -1036,6 +1041,9 @@ def compact_record(out, full_path):
     c["config"] = {k: cfg.get(k) for k in ("workload", "dataset", "rows_per_gpu", "rows_total", "dim", "batch", "k", "ef_search", "lanes", "parallelism",
                                            "rccl_ranks", "rccl_version") if cfg.get(k) is not None}
     c["recall_at_10"] = out.get("recall_at_10")
+    if out.get("timed_runs", 1) != 1:
+        c["timed_runs"] = out.get("timed_runs")
+        c["host_stall_in_first_run"] = out.get("host_stall_in_first_run")
     c["roofline"] = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "peak_measured", "unit", "frac", "frac_of_measured",
                                             "algorithmic_bytes_per_launch", "kernel_ms", "kernel_ms_each", "traffic", "traffic_source")}
     lb = rf.get("lone_batch") or {}
@@ -1266,6 +1274,14 @@ def main():
                 ls.groups = None
                 exchange = "torch.distributed all_gather_into_tensor + hvx_merge_topk_packed_device"
         elapsed, span, kms = timed_steps(ls, qs, ef, args.steps, args.warmup, barrier)
+        timed_runs, stall = 1, None
+        if world == 1 and elapsed * 1e3 > 1.3 * span:
+            # the wall clock of the K steps is far above the device span of the same K kernels: the host was frozen inside the timed region
+            # (CPU quota, see timed_steps).  The SAME K steps are timed once more; both runs are reported, the line carries the second.
+            stall = {"first_run_ms_per_step": round(elapsed * 1e3 / args.steps, 4), "first_run_kernel_ms": round(span / args.steps, 4)}
+            log(f"[{label}] host stall inside the timed steps ({stall}); timing the same {args.steps} steps again")
+            elapsed, span, kms = timed_steps(ls, qs, ef, args.steps, args.warmup, barrier)
+            timed_runs = 2
         q = ls.last_q[0]  # lane 0's last batch: recall, counters and the oracle check below refer to it
         if world > 1:
             t = torch.tensor([elapsed, span], dtype=torch.float64, device="cpu" if SHARED_GPU else dev)
@@ -1296,7 +1312,7 @@ def main():
         qst = got[4].cpu().numpy().astype(np.int64)
         alg = hnsw_alg_bytes(qst, dim, 2 if bf16 else 4, b)
         per_step = span / args.steps
-        res = dict(qps=qps, ms_per_step=elapsed * 1e3 / args.steps, recall=recall, alg=alg, per_step=per_step, kms=kms, qst=qst, n=n,
+        res = dict(timed_runs=timed_runs, host_stall=stall, qps=qps, ms_per_step=elapsed * 1e3 / args.steps, recall=recall, alg=alg, per_step=per_step, kms=kms, qst=qst, n=n,
                    n_total=n_total, flat_ms=flat_stats["device_ms"], graph=ginfo, exchange=exchange, nbq=nbq)
         state = dict(ix=ix, ix_truth=ix_truth, ls=ls, x=x, q=q, g=g, truth=f, id_lo=id_lo, qs=qs)
         return res, state
@@ -1401,6 +1417,7 @@ def main():
                    "parallelism": ("1 GPU" if world == 1 else f"{world} replicas, one query batch each" if replica
                                    else f"id-range shards x{world} + all-gather top-k merge")},
         "recall_at_10": round(res["recall"], 4),
+        "timed_runs": res["timed_runs"], "host_stall_in_first_run": res["host_stall"],
         "shard_searches_per_s": round(res["qps"] * (1 if replica else world), 1),
         "roofline": roofline,
         "flat_scan_ms": round(res["flat_ms"], 3),

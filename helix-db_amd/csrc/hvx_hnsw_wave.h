@@ -504,19 +504,11 @@ __device__ __forceinline__ void hnsw_wave_query(const HnswArgs &a, const uint32_
     constexpr bool GEN = NK == 0;
     constexpr int NL = GEN ? 1 : (BF ? NK / 2 : NK);        // 16-byte loads per lane and row
     constexpr int P = NL <= 8 ? 2 : 1;
-    // (the speculative builds of the non-strict arms keep passes of at most 2P rows: their speculative pass is live across the decision
-    // epoch, and next to a 4P-row pass the allocator spilled 700 registers; a non-strict frontier rarely exceeds 16 rows anyway)
-    constexpr bool kWide4 = OCC == 1 && 4 * P * NL <= 96 && !(AD && !BUILD && NK != 0 && 2 * P * NL <= 48);
+    constexpr bool kWide4 = OCC == 1 && 4 * P * NL <= 96;
     // 192 of the 256 registers of a half-SIMD wave.  The cosine non-strict build at dim 768 keeps ONE row per group in flight: with
     // two its per-lane filter / sampling state spills 17-34 registers to scratch and the spilled build is 11 % slower on four lanes
     // (profiles/r05b_ad_lanes_ab.log: 0.754 -> 0.673 ms per step; the squared-Euclidean build has no filter state and keeps two rows).
-    // The speculative one-per-SIMD builds (kSpec below) gather their regular passes P rows at a time: the 2P-row speculative pass is
-    // what is normally in flight, a second 2P-row register set next to it would not fit.
-    constexpr bool kSpecShape = AD && OCC == 1 && NK != 0 && !BUILD && 2 * P * NL <= 48;
-    constexpr bool kWide2 = (OCC == 1 && !kSpecShape) || (OCC != 1 && 2 * P * NL <= 48 && !(AD && METRIC == kCosine && 2 * P * NL > 32));
-    // speculative gather of the non-strict arms (see the layer-0 loop): one query per SIMD, unrolled shapes, a pass of 2P rows per group
-    constexpr bool kSpec = kSpecShape;
-    constexpr int kSpecW = 2 * P;
+    constexpr bool kWide2 = OCC == 1 || (2 * P * NL <= 48 && !(AD && METRIC == kCosine && 2 * P * NL > 32));
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const DevIndex &ix = a.ix;
     const int lane = (int)threadIdx.x, grp = lane >> 3, j = lane & 7;
@@ -818,29 +810,6 @@ __device__ __forceinline__ void hnsw_wave_query(const HnswArgs &a, const uint32_
             const unsigned long long node_h = nh;
             const bool unseen = (um >> lane) & 1ull;
             const uint32_t frank = (uint32_t)__builtin_popcountll(um & ((1ull << lane) - 1ull)); // index in the frontier
-            // Speculative gather (round 5; one query per SIMD only -- the lone-batch / batcher regime, where a query's expansions are a
-            // chain of latencies): the rows of ALL unseen neighbours are requested NOW, before the decision epoch decides which of them
-            // are scored, so that the ~3 000 cycles of policy code (phase profile: profiles/r05e_nonstrict_phase_profile.log) run
-            // underneath the HBM round trip instead of in front of it.  The stages below drop ~5-10 % of the neighbours
-            // (pre-sampling, SimHash filter): their rows are fetched for nothing -- bandwidth a lone batch has to spare; the
-            // two-per-SIMD builds (several batches in flight, bandwidth-bound) keep the select-then-gather order.  Results, counters
-            // and RNG draws are unchanged: the same rows are scored by the same code, the dropped ones are never looked at.
-            bool spec = false;
-            Gather<GEN ? 1 : NK, kSpec ? kSpecW : 1, BF> spec_g; // (kSpec only) the speculative pass: in flight across the decision epoch
-            uint32_t spec_nd[kSpec ? kSpecW : 1];                // (declared per expansion: nothing of it is carried around the loop)
-            if constexpr (kSpec) {
-                spec = nf0 <= 8u * (uint32_t)kSpecW;
-                if (spec) {
-                    if (unseen) fr_id[frank] = node;
-                    __syncthreads();
-#pragma unroll
-                    for (int p = 0; p < kSpecW; ++p) {
-                        const uint32_t f = (uint32_t)(p * 8 + grp);
-                        spec_nd[p] = fr_id[f < nf0 ? f : 0u]; // idle groups shadow the first row
-                    }
-                    gather_issue<GEN ? 1 : NK, kSpecW, BF, kSpecW, METRIC == kCosine>(ix, spec_nd, slot, spec_g);
-                }
-            }
             const uint32_t kt = a.k > 1u ? a.k : 1u;              // topk_target
             const float delta = S.score_at((kt < wlen ? kt : wlen) - 1u); // topk == the first min(k,|W|) of W
             const AdaptDecision D = adapt_decide(P, A, ef, wlen >= kt, wlen, nf0, dc, delta, brk_lane);
@@ -929,42 +898,15 @@ __device__ __forceinline__ void hnsw_wave_query(const HnswArgs &a, const uint32_
             const bool acc = sampled;
             const unsigned long long am = __ballot(acc);
             if (ST) A.st.simhash_passed_after_sampling += (uint32_t)__builtin_popcountll(__ballot(sampled));
-            bool scored = false;
-            if constexpr (kSpec) {
-                if (spec) { // the rows are (nearly) here: FMAs for the whole unseen list, then keep the accepted ones in row order
-                    float so[kSpecW];
-                    gather_consume<METRIC, GEN ? 1 : NK, kSpecW, BF>(ix, qs, spec_g, spec_nd, slot, qhdr, qglobal, so);
-#pragma unroll
-                    for (int p = 0; p < kSpecW; ++p) {
-                        const uint32_t f = (uint32_t)(p * 8 + grp);
-                        if (f < nf0 && j == 0) fr_d[f] = so[p];
-                    }
-                    __syncthreads();
-                    const float myd = acc ? fr_d[frank] : 0.f;
-                    __syncthreads();
-                    if (acc) {
-                        const uint32_t ar = (uint32_t)__builtin_popcountll(am & ((1ull << lane) - 1ull));
-                        fr_id[ar] = node;
-                        fr_d[ar] = myd;
-                    }
-                    scored = true;
-                }
-            }
-            if (!scored && acc) fr_id[__builtin_popcountll(am & ((1ull << lane) - 1ull))] = node;
+            if (acc) fr_id[__builtin_popcountll(am & ((1ull << lane) - 1ull))] = node;
             __syncthreads();
             nf = (uint32_t)__builtin_popcountll(am);
             tick(6, true); // (PROF) the decision epoch + candidate selection of the non-strict arms
             if (nf == 0) { prefetch_hash(); continue; }
-            if (scored) { // (what score_frontier would have left in fr_d / fr_id)
-                st_vl += nf;
-                st_dc += nf;
-                goto frontier_scored;
-            }
         }
         st_vl += nf;
         st_dc += nf;
         score_frontier(nf);
-    frontier_scored:
         prefetch_hash(); // the prefetched row came back with the gathers: its SimHash rows go out under the admission loop
         tick(2, true); // row gathers + FMAs
         const float d_l = (uint32_t)lane < nf ? fr_d[lane] : inf;

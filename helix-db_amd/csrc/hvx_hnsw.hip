@@ -331,6 +331,8 @@ hipError_t launch_hnsw_wave_l2_bf16_ad(const HnswArgs &a, uint32_t b, const Wave
 hipError_t launch_hnsw_wave_cos_bf16_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_occ2_l2_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);   // non-strict arms, two queries per SIMD
 hipError_t launch_hnsw_wave_occ2_cos_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_occ2_l2_bf16_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_occ2_cos_bf16_ad(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_pair_l2(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);       // owner / gatherer kernel (hvx_hnsw_pair.h)
 hipError_t launch_hnsw_pair_cos(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_pair_l2_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
@@ -395,8 +397,8 @@ static hipError_t launch_hnsw_wave_once(const HnswArgs &a, uint32_t b, hipStream
     }
     // (the wide beams have two-per-SIMD builds too; the one for bf16 rows at dim 1536 spills ~200 registers: it stays one per SIMD)
     // Round 5: the non-strict arms (the production default, SearchParams::new(k): access/search/storage.rs:140-141) have two-per-SIMD builds
-    // as well -- f32 rows, the unrolled shapes; their RNG window shrinks to 256 words so that the visited table keeps its size.
-    const bool ad_occ2 = a.adaptive && !generic && a.ix.dtype == HVX_F32;
+    // as well -- f32 and bf16 rows, the unrolled shapes; their RNG window shrinks to 256 words so that the visited table keeps its size.
+    const bool ad_occ2 = a.adaptive && !generic; // f32 and bf16 rows, the unrolled shapes
     g.occ = (a.occupancy == 2 && (!a.adaptive || ad_occ2) && !a.prof && !build_generic && !(wide && a.ix.dtype == HVX_BF16 && (a.ix.dim >> 5) == 48u)) ? 2u : 1u;
     size_t fixed = 512 + (size_t)a.ix.ld * 4 + (a.adaptive ? (g.occ == 2 ? kRngWordsOcc2 : kRngWords) * 4 : 0);
     g.cap = 1u << g.log2cap;
@@ -433,7 +435,10 @@ static hipError_t launch_hnsw_wave_once(const HnswArgs &a, uint32_t b, hipStream
         if (a.ix.dtype == HVX_BF16) return a.ix.metric == kL2 ? launch_hnsw_wave_wide_l2_bf16(a, b, g, s) : launch_hnsw_wave_wide_cos_bf16(a, b, g, s);
         return a.ix.metric == kL2 ? launch_hnsw_wave_wide_l2(a, b, g, s) : launch_hnsw_wave_wide_cos(a, b, g, s);
     }
-    if (g.occ == 2 && a.adaptive) return a.ix.metric == kL2 ? launch_hnsw_wave_occ2_l2_ad(a, b, g, s) : launch_hnsw_wave_occ2_cos_ad(a, b, g, s);
+    if (g.occ == 2 && a.adaptive) {
+        if (a.ix.dtype == HVX_BF16) return a.ix.metric == kL2 ? launch_hnsw_wave_occ2_l2_bf16_ad(a, b, g, s) : launch_hnsw_wave_occ2_cos_bf16_ad(a, b, g, s);
+        return a.ix.metric == kL2 ? launch_hnsw_wave_occ2_l2_ad(a, b, g, s) : launch_hnsw_wave_occ2_cos_ad(a, b, g, s);
+    }
     if (g.occ == 2) return a.ix.dtype == HVX_BF16 ? launch_hnsw_wave_occ2_bf16(a, b, g, s) : launch_hnsw_wave_occ2(a, b, g, s);
     if (generic) {
         switch (a.ix.metric) {
@@ -477,7 +482,7 @@ hipError_t launch_hnsw_wave(const HnswArgs &a0, uint32_t b, hipStream_t s) {
     // resident -- two per SIMD, 20 KiB of LDS -- wherever it exists (the strict unrolled builds).  A one-per-SIMD re-run needs a SIMD
     // with nothing else on it: behind the batches of other lanes that is a wait of 0.2 ms (round 3), behind the batcher's lanes
     // running the four-wavefront pair kernel it starved for tens of milliseconds (gpurun r04c: p99 47 ms).
-    if (!a.adaptive || (a.ix.dtype == HVX_F32 && hnsw_wave_supported(a) && !tuning_env("HVX_AD_RERUN_OCC1"))) r.occupancy = 2;
+    if (!a.adaptive || (hnsw_wave_supported(a) && !tuning_env("HVX_AD_RERUN_OCC1"))) r.occupancy = 2;
     // the re-run keeps the launch's register budget where the wider build exists for it (two queries per SIMD: its few wavefronts
     // fit next to the resident batches of the other lanes); the 832-entry beams are one-per-SIMD builds
     return reset_list(launch_hnsw_wave_once(r, b, s));

@@ -44,7 +44,7 @@ template <uint32_t METRIC, int R, int NK, bool BF, int G>
 __global__ __launch_bounds__(64 * (1 + G)) __attribute__((amdgpu_waves_per_eu(1 + G, 1 + G))) void hnsw_pair_kernel(HnswArgs a, uint32_t vcap) {
     constexpr int NL = BF ? NK / 2 : NK; // 16-byte loads per lane and row
     constexpr int P = NL <= 8 ? 2 : 1;
-    constexpr bool kWide2 = G == 1 && 2 * P * NL <= 48; // 192 of the gatherer's 256 registers
+    constexpr bool kWide2 = G == 1 && 2 * P * NL <= 48 && !(BF && METRIC == kCosine && NL >= 24); // 192 of the gatherer's 256 registers (cosine over bf16 rows at dim 1536 spilled 72: one row per group)
     constexpr uint32_t kThreads = 64u * (1u + G);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const DevIndex &ix = a.ix;

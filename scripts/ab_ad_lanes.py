@@ -37,7 +37,8 @@ def main():
     for mname, metric in (("l2", hv.EUCLIDEAN), ("cosine", hv.COSINE)):
         if only and mname not in only:
             continue
-        ix = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=metric, node_ids=g["node_ids"], vectors=x, l0_offsets=g["l0_offsets"],
+        bf16 = os.environ.get("AB_DTYPE", "f32") == "bf16"
+        ix = hv.ValidatedVectorReadIndex.managed(dtype=hv.BF16 if bf16 else hv.F32, dim=dim, metric=metric, node_ids=g["node_ids"], vectors=x, l0_offsets=g["l0_offsets"],
                                                  l0_neighbors=g["l0_neighbors"], level=g["level"], up_offsets=g["up_offsets"], up_neighbors=g["up_neighbors"],
                                                  entry_point=g["entry_point"], max_layer=g["max_layer"], m=16, m0=32, max_batch=b)
         ix.set_simhash()
@@ -78,7 +79,7 @@ def main():
                             best = (dt, kms)
                     dt, kms = best
                     qst = bufs[0][4].cpu().numpy().astype(np.int64)
-                    alg = qst[:, 3].sum() * dim * 4 + qst[:, 1].sum() * 4 + b * dim * 4
+                    alg = qst[:, 3].sum() * dim * (2 if os.environ.get('AB_DTYPE', 'f32') == 'bf16' else 4) + qst[:, 1].sum() * 4 + b * dim * 4
                     ms = dt * 1e3 / steps
                     print(json.dumps({"metric": mname, "arm": arm, "occ": occ, "lanes": L, "ms_per_step": round(ms, 4), "qps": round(b / ms * 1e3),
                                       "frac_hbm": round(alg / (ms * 1e-3) / 8e12, 4), "kernel_ms_each": round(float(kms.mean()), 4),

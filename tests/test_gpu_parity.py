@@ -795,6 +795,7 @@ def test_non_strict_arms_over_bf16_rows(orc, hv, metric, dim):
     gix = hv.ValidatedVectorReadIndex.from_export(ex, dim=dim, metric=metric, dtype=hv.BF16)
     cfg = hv.SimHashConfig.default()
     gix.set_simhash(cfg)
+    gix.set_occupancy(occupancy)   # round 5: two-per-SIMD builds of the non-strict arms over bf16 rows too
     assert gix.get_simhash().tolist() == oix.get_simhash().tolist()
     q = rng.standard_normal((32, dim)).astype(np.float32)
     agg = assert_params_equal(orc, hv, oix, gix, q, hv.SearchParams.new(10), cfg)

@@ -779,8 +779,9 @@ def test_non_strict_arms_match_oracle(orc, hv, name, metric, n, dim, m, m0, mk, 
         assert agg["pre_simhash_sample_dropped"] > 0 and agg["pre_simhash_sample_kept"] > 0
 
 
-@pytest.mark.parametrize("metric,dim", [(0, 256), (1, 128)])
-def test_non_strict_arms_over_bf16_rows(orc, hv, metric, dim):
+@pytest.mark.parametrize("occupancy", [1, 2])
+@pytest.mark.parametrize("metric,dim", [(0, 256), (1, 128), (0, 768), (1, 1024)])
+def test_non_strict_arms_over_bf16_rows(orc, hv, metric, dim, occupancy):
     """Config #4 storage under the production-default params: the oracle runs on the rounded vectors (its SimHash rows
     are those of the rounded vectors too, as the device computes them from the stored bf16 values)."""
     rng = np.random.default_rng(77 + dim)

@@ -32,7 +32,7 @@
 //     lane's bell), the batch is full, or its first query has waited max_wait_us (0 = 200 us).  A lone caller (previous batch: one
 //     query) is launched at once; when the load drops, one batch pays max_wait_us and the expectation follows it down;
 //   * NOTHING spins: the GPU boxes of this pool run the process under a CPU quota of 16 cores (cgroup cpu.max 1600000 100000;
-//     profiles/r04m_batcher_cgroup.log shows nr_throttled rising during a 1 024-caller run).  Spinning lanes (hipStreamSynchronize
+//     profiles/history/r04m_batcher_cgroup.log shows nr_throttled rising during a 1 024-caller run).  Spinning lanes (hipStreamSynchronize
 //     busy-waits, plus this file's former yield loops) burnt the quota, the whole process was frozen for the rest of the 100 ms
 //     period, and that -- not the batching policy -- was the 40-75 ms p99 of rounds 3 and 4.  A lane now waits for its stream on an
 //     event created with hipEventBlockingSync (an interrupt, no polling) and sleeps on futexes / short timed sleeps elsewhere;

@@ -297,7 +297,7 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(64) void bui
 // ---- step 3, batched mode: one 256-thread workgroup per LINK (new node q, layer, selected neighbour s) ----
 // build_link_kernel walks a node's <= 32 links one after the other, and every prune inside it is a chain of ~100 dependent row
 // gathers (select_diverse stages candidate i, then scores it against the kept rows eight at a time, stops at the first hit):
-// 9.4 ms per 2 048-node batch, 70 % of the build (profiles/r02f).  In a batch the order in which links reach the graph is not
+// 9.4 ms per 2 048-node batch, 70 % of the build (profiles/history/r02f).  In a batch the order in which links reach the graph is not
 // defined anyway, so every link gets its own workgroup, and the prune is evaluated EAGERLY from LDS: the nc <= Mmax + 1 rows of
 // the overflowing row and its owner's cross HBM once, and ALL pairwise distances among them (every pair independent of every
 // other: 561 pairs for 33 + 1 rows, eight per wavefront step) are computed with the reference's summation order -- the

@@ -20,7 +20,7 @@
 //                        inline asm with stated lgkmcnt waits: TWO independent workgroups per CU.
 //   flat_tile256_kernel  512 threads = 2 x 4 wavefronts on a 256 x 256 tile, two 64-deep LDS buffers, one workgroup per CU;
 //                        carries the measurement switches (HVX_FLAT_TILE_ABLATE).
-// What bounds them (profiles/r02g_*): the matrix cores are NOT the limit.  Ablation of the 512-thread build, 1024 x 1M x 768 bf16
+// What bounds them (profiles/history/r02g_*): the matrix cores are NOT the limit.  Ablation of the 512-thread build, 1024 x 1M x 768 bf16
 // (ms per launch): MFMAs alone 0.35 (= the dense peak at the 2.1 GHz the chip holds), fragment reads + barriers alone 0.24,
 // + operand copies 0.17-0.29, + epilogue 0.17; the full kernel takes 0.93 = their SUM.  A four-buffer ring with counted
 // waits, fragment registers double-buffered across the stage barrier, and two workgroups per CU all land within 4 % of that
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void flat_tile2mx_kernel(MfmaArgs a, float 
 //     half 1 (one phase later):                  | read steps 0-1 | MFMA steps 0-1 | read steps 2-3 | MFMA steps 2-3
 // so while one wavefront of a SIMD issues its 16 MFMAs (s_setprio 1: nothing else of that SIMD competes for issue slots) the other
 // one has its 12 fragment reads (and, at the start of a stage, its 8 LDS-DMA copies of the next stage) in flight.  In the lock-step
-// builds above all wavefronts read at once and multiply at once: LDS time and matrix-core time ADD (profiles/r02g_ablate_bf16.txt:
+// builds above all wavefronts read at once and multiply at once: LDS time and matrix-core time ADD (profiles/history/r02g_ablate_bf16.txt:
 // 0.93 ms = 0.35 MFMA + 0.24 reads + copies + epilogue).
 // Hand-over rules (cdna_hip_programming.md, "Read a staged buffer one phase AFTER the wait that retires it"): a wavefront waits for
 // ITS copies of stage s + 1 (vmcnt(0)) at the end of its second read phase of stage s, before that phase's barrier; the first read

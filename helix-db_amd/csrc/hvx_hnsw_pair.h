@@ -3,7 +3,7 @@
 // Same algorithm, same results, same counters as hvx_hnsw_wave.h (SearchSession::run, search.rs:1101-1230; greedy upper layers
 // :169-224; strict-exhaustive layer-0 beam :267-1067).  What it changes is what a LONE batch of 1 024 queries leaves idle: the
 // one-wavefront kernel runs every phase of an expansion back to back on one wavefront per SIMD (pop + visited test 0.8 us, row
-// gathers 3.1 us, prediction 0.2 us, admission 0.9 us; profiles/r01, docs/next_kernel.md), so the memory system idles while the
+// gathers 3.1 us, prediction 0.2 us, admission 0.9 us; profiles/history/r01, docs/next_kernel.md), so the memory system idles while the
 // beam is updated and the other half of every SIMD's wave slots is empty.  Here a query is a 128-thread workgroup of two
 // wavefronts (2 048 wavefronts = two per SIMD, 256 registers each):
 //

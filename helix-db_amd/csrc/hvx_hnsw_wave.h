@@ -3,7 +3,7 @@
 // Same algorithm, same results, same counters as hvx_hnsw.hip (SearchSession::run,
 // crates/db/src/search/vector/search.rs:1101-1230; greedy upper layers :169-224; strict-exhaustive
 // layer-0 beam :267-1067) -- restructured around what bounded the first kernel
-// on MI355X (profiles/r01a: 11.6 us per expansion, three dependent HBM round trips + barriers):
+// on MI355X (profiles/history/r01a: 11.6 us per expansion, three dependent HBM round trips + barriers):
 //
 //   * 1024 queries = 1024 wavefronts = one wave per SIMD on all 256 CUs: each wave owns a whole SIMD's
 //     register file, so a full pass of P x 8 neighbour rows (P*NK 16-byte loads per lane, 8 lanes per
@@ -15,7 +15,7 @@
 //     gathers; if a fresh candidate beats it, that one's row is fetched underneath the admission loop;
 //   * a frontier of up to 8, 16, 24 or 32 rows is gathered with ONE latency: the pass width is chosen per
 //     expansion (1, 2, 3 or 4 x P rows per 8-lane group in flight), because the kernel ends with its
-//     slowest query and the slow queries are the ones with large frontiers (profiles/r01c);
+//     slowest query and the slow queries are the ones with large frontiers (profiles/history/r01c);
 //   * distances keep the host SIMD summation order (hvx_device.h) => scores are bit-identical to the
 //     reference CPU path; the beam (hvx_beam.h) is exact.
 //
@@ -295,7 +295,7 @@ __device__ __forceinline__ void gather_consume(const DevIndex &ix, const float *
 // hands word (pos + rank) to the lane whose candidate is the rank-th one to draw.
 // RW = words of the LDS window: 1 024 (64 blocks, one per lane) for the one-query-per-SIMD builds; 256 (16 blocks, lanes 0..15) for
 // the two-per-SIMD builds, whose 20 KiB of LDS are better spent on the visited table -- the production-default parameters draw
-// ~120 words per query (profiles/r04s), a window is rarely refilled either way.
+// ~120 words per query (profiles/history/r04s), a window is rarely refilled either way.
 constexpr uint32_t kRngWords = 1024;
 constexpr uint32_t kRngWordsOcc2 = 256;
 template <uint32_t RW> struct QueryRngT {
@@ -1032,7 +1032,7 @@ __device__ __forceinline__ void hnsw_wave_query(const HnswArgs &a, const uint32_
 // -- all of them on every corpus without masses of duplicate vectors.  Round 4: the list replaces "every wavefront tests its own
 // flag" and the re-run keeps the launch's register budget where a wider build exists for it: round 3's re-run was a one-query-
 // per-SIMD launch whose 1 024 exit-at-once workgroups each waited for an EMPTY SIMD behind the two-per-SIMD batches of the other
-// execution lanes (216 us per step on average; profiles/r03a_kernel_stats_hvx.csv).  The last workgroup hands the list back empty.
+// execution lanes (216 us per step on average; profiles/history/r03a_kernel_stats_hvx.csv).  The last workgroup hands the list back empty.
 // (A loop "one workgroup takes every n-th listed query" was tried first: it costs every instantiation 30-70 spilled SGPRs.)
 template <uint32_t METRIC, int R, int NK, bool BF, bool PROF = false, bool AD = false, bool ST = true, int OCC = 1, bool BUILD = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void hnsw_wave_kernel(HnswArgs a, uint32_t vcap) {

@@ -98,7 +98,7 @@ struct hvx_index {
     size_t cap_q = 0, cap_o = 0;
     uint32_t cap_b = 0;
     // pinned host mirror of the staging buffers.  A hipMemcpyAsync from / to pageable memory is a synchronous staged copy (35-50 us
-    // of host time EACH, five per call: measured with rocprofv3 --hip-trace, profiles/r03r); through pinned memory the five copies
+    // of host time EACH, five per call: measured with rocprofv3 --hip-trace, profiles/history/r03r); through pinned memory the five copies
     // are enqueued in ~5 us each and the host pays two memcpys of a few KB.
     unsigned char *h_pin = nullptr;
     size_t cap_pin = 0;

@@ -403,7 +403,7 @@ def test_asm_lint_flags_an_inline_asm_read_inside_a_matrix_write_back_window(tmp
 def test_link_workgroup_kernel_takes_its_row_locks_without_cache_maintenance(tmp_path):
     """Round 3: an acquire / release at agent scope is an L2 invalidate / write-back of the whole XCD on gfx950 (`buffer_inv sc1` /
     `buffer_wbl2 sc1`); with one per lock operation the batched link step of the device build spent 60 % of its time in them
-    (profiles/r03p_build_link_wg.txt).  The rows a lock protects are only touched with agent-scope atomics, so the locks of
+    (profiles/history/r03p_build_link_wg.txt).  The rows a lock protects are only touched with agent-scope atomics, so the locks of
     build_link_wg_kernel are relaxed atomics + s_waitcnt: its assembly must contain no cache-maintenance instruction, and no scratch."""
     import re
     import shutil
@@ -427,7 +427,7 @@ def test_link_workgroup_kernel_takes_its_row_locks_without_cache_maintenance(tmp
 
 def test_runtime_prepare_sets_the_hardware_queue_count_only_when_the_host_has_not():
     """HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); execution lanes that share one run back to
-    back (profiles/r04t_hw_queues_library_default.log: 0.69 instead of 0.80 of HBM on the headline, 0.51 instead of 0.67 on the bf16
+    back (profiles/history/r04t_hw_queues_library_default.log: 0.69 instead of 0.80 of HBM on the headline, 0.51 instead of 0.67 on the bf16
     leg).  Round 5: LOADING the library no longer touches the environment; the host calls hvx_runtime_prepare(n) from its
     start-up code, which sets the variable (0 = 8) unless the host has exported one itself."""
     import subprocess
@@ -890,7 +890,7 @@ def test_fbin_loader_follows_the_reference_fixture_contract(tmp_path):
 def test_bench_line_is_compact_strict_json_with_the_contract_keys():
     """round 4's one JSON line had grown to 27.7 KB and the driver could not parse it.  bench.py now prints a compact
     record as the LAST stdout line -- < 4 KB, strict JSON (no NaN / Infinity), the contract's keys + roofline + cpu_baseline + parity
-    -- and writes everything else to bench_full.json.  Held here on round 4's full record (profiles/r04s_bench_line.json) inflated
+    -- and writes everything else to bench_full.json.  Held here on round 4's full record (tests/golden/r04_full_bench_record.json = profiles/history/r04s_bench_line.json) inflated
     with every leg round 5 added, including non-finite values and an oversized leg."""
     import importlib.util
     import json
@@ -902,7 +902,7 @@ def test_bench_line_is_compact_strict_json_with_the_contract_keys():
         spec.loader.exec_module(bench)
     finally:
         sys.argv = argv
-    full = json.load(open(os.path.join(ROOT, "profiles", "r04s_bench_line.json")))
+    full = json.load(open(os.path.join(ROOT, "tests", "golden", "r04_full_bench_record.json")))
     full["roofline"].update({"peak_measured": 6300.5, "frac_of_measured": float("nan")})
     full["cpu_baseline"].update({"threads": 16, "nproc": 256, "quota_cores": 16})
     full["production_default_lanes"] = {m: {"qps": 1.2e6, "ms_per_step": 0.8, "frac": 0.7, "recall_at_10": 0.99, "ids_equal_oracle": True,

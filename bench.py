@@ -81,7 +81,7 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = the cores this process may use (cgroup quota, else all; capped at 64)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle bit-exactness check")
     ap.add_argument("--metric", default="l2", choices=["l2", "cosine"])
-    ap.add_argument("--skip", default="", help="comma list of extra legs to skip: production,production_lanes,batcher,datasets,iso_recall,config3,config4,config5,"
+    ap.add_argument("--skip", default="", help="comma list of extra legs to skip: production,production_lanes,batcher,insert,datasets,iso_recall,config3,config4,config5,"
                                                "graph_equivalence,ef_sweep,peak,vendor_gemm")
     ap.add_argument("--full-record", default=os.path.join(ROOT, "bench_full.json"), help="where the full record of every leg is written")
     ap.add_argument("--c3-corpus", default="clustered", choices=["clustered", "topic_ordered"],
@@ -649,6 +649,51 @@ def leg_config5(hv, synth, orc, dev, rows, b=4096, k=10, dim=1536):
     return out
 
 
+def leg_incremental_insert(hv, synth, args, dev, n0=500_000, add=100_000, seq=2_000):
+    """Round 5 (VERDICT r4 missing #4): writes to a resident image.  A graph built over n0 rows with room to grow takes `add` rows through
+    hvx_index_insert_batch in batched mode (one call) and `seq` more in sequential mode (one node per batch = the reference's
+    insert_hnsw order: mutation.rs:642-895); the grown graph is audited on the device and searched against its own exact scan."""
+    dim, b, k, ef = args.dim, args.batch, args.k, args.ef
+    n = n0 + add + seq
+    x, q = synth.corpus("embedding", n, dim, b, args.seed + 5, dev)
+    torch.cuda.synchronize()
+    lv = synth.draw_levels(n, args.m, 13)
+    ids = np.arange(n, dtype=np.uint64)
+    t0 = time.time()
+    ix, _ = hv.ValidatedVectorReadIndex.build(dim=dim, metric=hv.EUCLIDEAN, node_ids=ids[:n0], vectors=x[:n0], levels=lv[:n0], m=args.m, m0=2 * args.m,
+                                              ef_construction=200, max_batch=args.build_batch, batch_divisor=32, device=dev.index, search_max_batch=b,
+                                              reserve_rows=add + seq, reserve_upper_rows=int(lv[n0:].sum()) + 8)
+    ix.sync()
+    t_build = time.time() - t0
+    t0 = time.time()
+    st = ix.insert_batch(ids[n0:n0 + add], x[n0:n0 + add], lv[n0:n0 + add], ef_construction=200, max_batch=args.build_batch, batch_divisor=32)
+    ix.sync()
+    t_ins = time.time() - t0
+    t0 = time.time()
+    st2 = ix.insert_batch(ids[n0 + add:], x[n0 + add:], lv[n0 + add:], ef_construction=200, sequential=True)
+    ix.sync()
+    t_seq = time.time() - t0
+    audit = graph_audit(ix, args.m)
+    f = out_buffers(b, k, dev)
+    g = out_buffers(b, k, dev)
+    ix.flat_search_batch_device(q, k, *f[:4])
+    ix.search_batch_device(q, k, ef, *g, want_stats=False)
+    torch.cuda.synchronize()
+    rec = recall_of(g[0], f[0], b, k)
+    newest = int((g[0] >= n0).sum().item())
+    out = {"workload": f"{n0}x{dim} f32 built on the device (reserve {add + seq} rows), + {add} rows by ONE hvx_index_insert_batch call (batched), + {seq} rows in "
+                       f"sequential mode (one node per batch, the reference's order), M={args.m}/M0={2 * args.m}/efC=200",
+           "build_seconds": round(t_build, 2), "batched": {"rows": add, "seconds": round(t_ins, 3), "inserts_per_s": round(add / t_ins, 1), "batches": int(st["batches"])},
+           "sequential": {"rows": seq, "seconds": round(t_seq, 3), "inserts_per_s": round(seq / t_seq, 1), "us_per_insert": round(t_seq / seq * 1e6, 1)},
+           "rows_after": ix.rows(), "visible_seq": ix.visible_seq(), "audit": audit,
+           "recall_at_10_ef%d" % ef: round(rec, 4), "results_from_appended_rows": newest,
+           "note": "recall of the grown graph against its own exact scan (which covers the appended rows: row norms / bf16 shadow extended on that scan)"}
+    ix.close()
+    del x, q
+    torch.cuda.empty_cache()
+    return out
+
+
 def leg_vendor_gemm(dev):
     """BASELINE.md section 2 / VERDICT r4 #3(a): what the vendor library gets on THIS box for the dense contraction at the heart of the
     exact scan -- a (queries x dim) x (dim x rows) GEMM of one row chunk -- bf16 (torch.matmul -> hipBLASLt / rocBLAS) and fp8-e4m3
@@ -1101,6 +1146,11 @@ def compact_record(out, full_path):
     if isinstance(es, dict):
         c["exact_scan"] = {"ms": es.get("ms"), "tflops": _pick(es, "roofline", "achieved"), "frac_of_bf16_peak": _pick(es, "roofline", "frac"),
                            "vendor_gemm_tflops": _pick(out, "vendor_gemm", "bf16", "tflops")}
+    ii = out.get("incremental_insert")
+    if isinstance(ii, dict):
+        c["insert"] = {"error": str(ii["error"])[:160]} if "error" in ii else {
+            "batched_inserts_per_s": _pick(ii, "batched", "inserts_per_s"), "sequential_us_per_insert": _pick(ii, "sequential", "us_per_insert"),
+            "audit_clean": _pick(ii, "audit", "clean"), "recall_at_10": next((v for k_, v in ii.items() if k_.startswith("recall_at_10")), None)}
     bt = out.get("batcher")
     if isinstance(bt, dict):
         c["batcher"] = {"error": str(bt["error"])[:160]} if "error" in bt else {k: bt.get(k) for k in ("qps", "mean_us", "p99_us", "mean_batch", "qps_production_default",
@@ -1111,7 +1161,7 @@ def compact_record(out, full_path):
     c = _finite(c)
     line = json.dumps(c, allow_nan=False, separators=(",", ":"))
     # a leg that grew must never cost the line its contract: drop summaries (never the contract keys) until it fits
-    for victim in ("batcher", "exact_scan", "config4", "config5", "config3", "datasets", "production_default_lanes", "strong_scaling"):
+    for victim in ("insert", "batcher", "exact_scan", "config4", "config5", "config3", "datasets", "production_default_lanes", "strong_scaling"):
         if len(line) < COMPACT_LIMIT:
             break
         if victim in c:
@@ -1667,6 +1717,8 @@ def main():
 
         if "vendor_gemm" not in skip:
             out["vendor_gemm"] = guarded("vendor_gemm", lambda: leg_vendor_gemm(dev))
+        if "insert" not in skip:
+            out["incremental_insert"] = guarded("incremental_insert", lambda: leg_incremental_insert(hv, synth, args, dev))
         if "config3" not in skip:
             out["config3_prefilter"] = guarded("config3", lambda: leg_config3(hv, synth, orc, args, dev))
         if "config4" not in skip:

@@ -344,8 +344,14 @@ __global__ __launch_bounds__(256) void flat_select_kernel(FlatArgs a, uint32_t *
             }
         }
         __syncthreads();
-        if (cnt > (uint32_t)(kPool / 2)) {
-            bitonic_sort_pool(ps, pi, tid);
+        // re-sort + cut when the pool is more than half full -- or EARLY, while no threshold exists yet: the first 4k scores give the
+        // scan a finite bound, after which a segment pushes a handful of scores instead of all 1 024 (round 5: two 2 048-entry sorts
+        // per query were most of this kernel's 250 us on the exact scan's first chunk; the selection itself is exact either way)
+        const bool early = thr_i == 0xFFFFFFFFu && thr_s == inf && cnt >= 4u * k && cnt >= 256u;
+        if (cnt > (uint32_t)(kPool / 2) || early) {
+            int np = 64;
+            while ((uint32_t)np < cnt) np <<= 1; // entries beyond cnt are +inf padding: the next power of two is enough
+            bitonic_sort_pool_n(ps, pi, tid, np);
             const uint32_t keep = cnt < k ? cnt : k;
             for (int t = tid; t < kPool; t += 256)
                 if ((uint32_t)t >= keep) { ps[t] = inf; pi[t] = 0xFFFFFFFFu; }
@@ -355,7 +361,11 @@ __global__ __launch_bounds__(256) void flat_select_kernel(FlatArgs a, uint32_t *
             __syncthreads();
         }
     }
-    bitonic_sort_pool(ps, pi, tid);
+    {
+        int np = 64;
+        while ((uint32_t)np < cnt) np <<= 1;
+        bitonic_sort_pool_n(ps, pi, tid, np);
+    }
     const uint32_t keep = cnt < k ? cnt : k;
     for (uint32_t t = (uint32_t)tid; t < keep; t += 256) {
         a.top_scores[(size_t)q * k + t] = ps[t];

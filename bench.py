@@ -236,6 +236,15 @@ class LaneSet:
             h.close()
 
 
+def cgroup_throttle():
+    """(nr_throttled, throttled_usec) of this container's cgroup (v2), zeros when unreadable"""
+    try:
+        d = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat").read().splitlines() if len(l.split()) == 2)
+        return int(d.get("nr_throttled", 0)), int(d.get("throttled_usec", 0))
+    except Exception:
+        return 0, 0
+
+
 def query_batches(args, b):
     """how many distinct query batches a timed run cycles through"""
     nb = args.query_batches or (args.steps + args.warmup)
@@ -264,14 +273,20 @@ def timed_steps(ls, qs, ef, steps, warmup, barrier):
     e0.record(ls.streams[0])
     for s in ls.streams[1:]:  # every lane starts behind the same instant
         s.wait_event(e0)
+    thr0 = cgroup_throttle()
     t_start = time.perf_counter()
     for i in range(steps):
         ls.step(i, qs[(warmup + i) % nb], ef)
+    t_issued = time.perf_counter()
     for l, s in enumerate(ls.streams):
         ends[l].record(s)
     ls.sync()
     barrier()
     elapsed = time.perf_counter() - t_start
+    thr1 = cgroup_throttle()
+    # where a host stall sat (the launches or the final wait), and whether the cgroup throttled the process meanwhile
+    ls.host_timing = {"issue_ms": round((t_issued - t_start) * 1e3, 3), "wait_ms": round((time.perf_counter() - t_issued) * 1e3, 3),
+                      "cgroup_throttled_periods": thr1[0] - thr0[0], "cgroup_throttled_ms": round((thr1[1] - thr0[1]) / 1e3, 2)}
     span = max(e0.elapsed_time(e) for e in ends)
     per = (steps + L - 1) // L
     ls.residency = None
@@ -1328,7 +1343,8 @@ def main():
         if world == 1 and elapsed * 1e3 > 1.3 * span:
             # the wall clock of the K steps is far above the device span of the same K kernels: the host was frozen inside the timed region
             # (CPU quota, see timed_steps).  The SAME K steps are timed once more; both runs are reported, the line carries the second.
-            stall = {"first_run_ms_per_step": round(elapsed * 1e3 / args.steps, 4), "first_run_kernel_ms": round(span / args.steps, 4)}
+            stall = {"first_run_ms_per_step": round(elapsed * 1e3 / args.steps, 4), "first_run_kernel_ms": round(span / args.steps, 4),
+                     "first_run_host": getattr(ls, "host_timing", None)}
             log(f"[{label}] host stall inside the timed steps ({stall}); timing the same {args.steps} steps again")
             elapsed, span, kms = timed_steps(ls, qs, ef, args.steps, args.warmup, barrier)
             timed_runs = 2
@@ -1362,7 +1378,7 @@ def main():
         qst = got[4].cpu().numpy().astype(np.int64)
         alg = hnsw_alg_bytes(qst, dim, 2 if bf16 else 4, b)
         per_step = span / args.steps
-        res = dict(timed_runs=timed_runs, host_stall=stall, qps=qps, ms_per_step=elapsed * 1e3 / args.steps, recall=recall, alg=alg, per_step=per_step, kms=kms, qst=qst, n=n,
+        res = dict(timed_runs=timed_runs, host_stall=stall, host_timing=getattr(ls, "host_timing", None), qps=qps, ms_per_step=elapsed * 1e3 / args.steps, recall=recall, alg=alg, per_step=per_step, kms=kms, qst=qst, n=n,
                    n_total=n_total, flat_ms=flat_stats["device_ms"], graph=ginfo, exchange=exchange, nbq=nbq)
         state = dict(ix=ix, ix_truth=ix_truth, ls=ls, x=x, q=q, g=g, truth=f, id_lo=id_lo, qs=qs)
         return res, state
@@ -1467,7 +1483,7 @@ def main():
                    "parallelism": ("1 GPU" if world == 1 else f"{world} replicas, one query batch each" if replica
                                    else f"id-range shards x{world} + all-gather top-k merge")},
         "recall_at_10": round(res["recall"], 4),
-        "timed_runs": res["timed_runs"], "host_stall_in_first_run": res["host_stall"],
+        "timed_runs": res["timed_runs"], "host_stall_in_first_run": res["host_stall"], "host_timing": res["host_timing"],
         "shard_searches_per_s": round(res["qps"] * (1 if replica else world), 1),
         "roofline": roofline,
         "flat_scan_ms": round(res["flat_ms"], 3),

@@ -124,6 +124,7 @@ struct Lane {
     alignas(64) std::atomic<Batch *> wake_batch{nullptr};
     std::atomic<uint32_t> wake_seq{0};
     alignas(64) std::atomic<uint32_t> wake_bell{0};
+    uint32_t seen_refresh = 0;
     float *d_q = nullptr; // the lane's query rows in HBM (results go straight to the batch's pinned rows)
     hipEvent_t ev = nullptr; // hipEventBlockingSync: the lane sleeps until the stream's work is done
     // where this lane's time went, ns (hvx_batcher_timing)
@@ -152,6 +153,7 @@ struct hvx_batcher {
     std::vector<Lane> lanes;
     std::atomic<uint64_t> n_batches{0}, n_queries{0}, n_full{0};
     std::atomic<int> efd{-1};                        // hvx_batcher_eventfd: written once per completed batch (non-blocking hosts)
+    std::atomic<uint32_t> refresh_gen{0};            // hvx_batcher_refresh: lanes adopt the image's visible generation before their next batch
 
     void run(Lane &ln) {
         (void)hipSetDevice(device);
@@ -286,6 +288,11 @@ struct hvx_batcher {
         hipStream_t s = (hipStream_t)hvx_index_stream(ln.ix);
         bt.rc = 0;
         bt.err.clear();
+        const uint32_t rg = refresh_gen.load(std::memory_order_acquire);
+        if (rg != ln.seen_refresh) { // rows were appended to the image (hvx_index_insert_batch): this lane's next batches see them
+            ln.seen_refresh = rg;
+            (void)hvx_index_refresh(ln.ix);
+        }
         // on any failure nothing may still be writing the batch's pinned rows when the buffer is handed back: drain the stream first
         auto bad = [&](const char *what, hipError_t e) {
             bt.rc = HVX_ERR_DEVICE;
@@ -547,6 +554,14 @@ extern "C" int hvx_batcher_wait(hvx_batcher *b, const hvx_batcher_ticket *ticket
     const int rc = await_slot(b, ticket->sequence, ticket->slot, timeout_us == 0xFFFFFFFFu ? -1 : (long)timeout_us);
     if (rc) return rc; // HVX_PENDING on time-out: the ticket stays valid
     return take_result(b, ticket->sequence, ticket->slot, out_ids, out_scores, out_count);
+}
+
+// The image behind the batcher has grown (hvx_index_insert_batch on the handle the batcher was created from): every dispatcher lane
+// adopts the new generation before the next batch it launches (batches already in flight finish on the generation they started with).
+extern "C" int hvx_batcher_refresh(hvx_batcher *b) {
+    if (!b) return fail(HVX_ERR_INVARIANT, "null argument");
+    b->refresh_gen.fetch_add(1, std::memory_order_acq_rel);
+    return HVX_OK;
 }
 
 extern "C" int hvx_batcher_eventfd(hvx_batcher *b) {

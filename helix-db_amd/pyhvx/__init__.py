@@ -1023,6 +1023,13 @@ class Batcher:
         ids = np.zeros(self.k, np.uint64); sc = np.zeros(self.k, np.float32); cnt = C.c_uint32(0)
         return self._take(lib().hvx_batcher_wait(self._h, C.byref(ticket), int(timeout_us), _ptr(ids), _ptr(sc), C.byref(cnt)), ids, sc, cnt)
 
+    def refresh(self):
+        """hvx_batcher_refresh: the lanes adopt rows appended to the image since the batcher was created"""
+        L = lib()
+        L.hvx_batcher_refresh.restype = C.c_int
+        L.hvx_batcher_refresh.argtypes = [_vp]
+        _check(L.hvx_batcher_refresh(self._h))
+
     def eventfd(self):
         fd = lib().hvx_batcher_eventfd(self._h)
         if fd < 0:

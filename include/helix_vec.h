@@ -527,6 +527,9 @@ int hvx_batcher_poll(hvx_batcher *, const hvx_batcher_ticket *ticket, uint64_t *
 int hvx_batcher_wait(hvx_batcher *, const hvx_batcher_ticket *ticket, uint32_t timeout_us, uint64_t *out_ids /*[k]*/, float *out_scores /*[k]*/,
                      uint32_t *out_count);
 int hvx_batcher_eventfd(hvx_batcher *); /* -1 on failure */
+/* after hvx_index_insert_batch on the handle the batcher was created from: the dispatcher lanes (forks of that handle) adopt the new
+ * generation before the next batch each of them launches */
+int hvx_batcher_refresh(hvx_batcher *);
 int hvx_batcher_stats(const hvx_batcher *, uint64_t *batches, uint64_t *queries, uint64_t *full_batches);
 /* where the dispatcher lanes' time went since creation, summed over the lanes (nanoseconds): asleep with nothing to do, watching
  * an open batch grow, waiting for a batch buffer's previous callers to take their rows, waiting for callers to finish copying

@@ -322,6 +322,7 @@ def test_sequential_inserts_into_a_live_image_equal_the_oracles_insertion_row_fo
     lane = gix.fork()
     q = rng.standard_normal((24, dim)).astype(np.float32)
     old_ids, old_sc, old_cnt, _ = lane.search_batch(q, hv.SearchParams(10).with_ef(64))
+    bt = hv.Batcher(gix, hv.SearchParams(10).with_ef(64), max_batch=32, max_wait_us=500)   # its dispatcher lanes are forks of the image too
     # refused without side effects
     with pytest.raises(hv.HelixDbError) as e:
         gix.insert_batch(ids[n0:], np.vstack([data[n0:n0 + 1] * np.float32(np.nan), data[n0 + 1:]]), lv[n0:], sequential=True)
@@ -373,6 +374,17 @@ def test_sequential_inserts_into_a_live_image_equal_the_oracles_insertion_row_fo
     lid, lsc, lcnt, _ = lane.search_batch(q, hv.SearchParams(10).with_ef(64))
     assert lid.tolist() == gid.tolist() and lsc.view(np.uint32).tolist() == gsc.view(np.uint32).tolist()
     lane.close()
+    # the batcher created before the inserts: its lanes keep their generation until hvx_batcher_refresh
+    known = set(ids.tolist())
+    for i in range(4):                                        # old generation: its entry point, rows stale-or-current -- valid ids, full lists
+        res = bt.search(q[i])
+        assert len(res) == 10 and all(r_.entity_id in known for r_ in res)
+    bt.refresh()
+    for i in range(q.shape[0]):
+        res = bt.search(q[i])
+        assert [r_.entity_id for r_ in res] == gid[i, :gcnt[i]].tolist()
+        assert np.asarray([r_.score for r_ in res], np.float32).view(np.uint32).tolist() == gsc[i, :gcnt[i]].view(np.uint32).tolist()
+    bt.close()
 
 
 def test_batched_inserts_keep_the_graph_invariants_and_serve_every_search_path(orc, hv):

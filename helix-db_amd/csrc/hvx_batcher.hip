@@ -214,7 +214,7 @@ struct hvx_batcher {
             // mix the two batches' rows; the wait is bounded: that lane completes its batch, and every caller blocked on it wakes within
             // 5 ms and either takes its rows or leaves with its slot accounted for)
             if (seq + 1 >= nbuf) { // its previous batch (sequence seq + 1 - nbuf) must be complete and fully drained
-                if (next.done.load() != (uint32_t)(seq + 1 - nbuf + 1) || next.consumed_sum() != next.total) {
+                if (next.done.load() != (uint32_t)(seq + 1 - nbuf + 1) || next.consumed_sum() < next.total) { // (<: a ticket polled twice -- a host bug -- must not wedge the lanes)
                     // stopping, and that buffer is held by tickets nobody will poll any more (a non-blocking host that went away): the
                     // open batch is not launched -- its callers leave with "shutting down" like everybody else (0.2 s of grace)
                     if (stop.load() && ++stop_spins > 20000u) return;

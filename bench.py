@@ -270,10 +270,10 @@ def timed_steps(ls, qs, ef, steps, warmup, barrier):
         h.timing_begin((steps + L - 1) // L)
     e0 = torch.cuda.Event(enable_timing=True)
     ends = [torch.cuda.Event(enable_timing=True) for _ in ls.handles]
+    thr0 = cgroup_throttle()  # (BEFORE the start event: reading the cgroup file takes tens of milliseconds on this pool)
     e0.record(ls.streams[0])
     for s in ls.streams[1:]:  # every lane starts behind the same instant
         s.wait_event(e0)
-    thr0 = cgroup_throttle()
     t_start = time.perf_counter()
     for i in range(steps):
         ls.step(i, qs[(warmup + i) % nb], ef)

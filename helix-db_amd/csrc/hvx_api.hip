@@ -479,6 +479,9 @@ void hvx_index::publish_view(bool bump) {
     shared->v_entry_point = desc.entry_point;
     shared->v_contiguous = contiguous;
     shared->v_ids = ids_p;
+    shared->v_dead = dead_p;
+    shared->v_n_dead = n_dead;
+    shared->v_dead_dev = dev.dead;
     seen_seq = shared->visible_seq;
 }
 bool hvx_index::adopt_view() {
@@ -494,8 +497,34 @@ bool hvx_index::adopt_view() {
     desc.entry_point = shared->v_entry_point;
     contiguous = shared->v_contiguous;
     ids_p = shared->v_ids;
+    dead_p = shared->v_dead;
+    n_dead = shared->v_n_dead;
+    dev.dead = shared->v_dead_dev;
     seen_seq = shared->visible_seq;
     return true;
+}
+
+// the ascending list of live rows of this handle's generation (exact scans over "all rows" of an image with deleted nodes)
+int hvx_index::ensure_live() {
+    if (f_live && live_for == (const void *)dead_p.get() && live_rows_n == dev.n - n_dead) return HVX_OK;
+    std::vector<uint32_t> rows;
+    rows.reserve(dev.n);
+    const std::vector<uint8_t> *dd = dead_p.get();
+    for (uint32_t i = 0; i < dev.n; ++i)
+        if (!dd || i >= dd->size() || !(*dd)[i]) rows.push_back(i);
+    if (rows.size() > cap_live || !f_live) {
+        const size_t cap = std::max<size_t>(std::max<size_t>(rows.size(), cap_rows), 1);
+        int rc = regrow((void **)&f_live, cap * 4);
+        if (rc) return rc;
+        cap_live = (uint32_t)cap;
+    }
+    if (!rows.empty()) {
+        if (hipMemcpyAsync(f_live, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+            return hvx::fail(HVX_ERR_DEVICE, "upload of the live-row list failed");
+    }
+    live_for = dead_p.get();
+    live_rows_n = (uint32_t)rows.size();
+    return HVX_OK;
 }
 
 extern "C" int hvx_index_refresh(hvx_index *ix) {
@@ -507,6 +536,8 @@ extern "C" int hvx_index_refresh(hvx_index *ix) {
 extern "C" uint64_t hvx_index_visible_seq(const hvx_index *ix) { return ix ? ix->seen_seq : 0; }
 extern "C" uint64_t hvx_index_rows(const hvx_index *ix) { return ix ? ix->dev.n : 0; }
 extern "C" uint64_t hvx_index_row_capacity(const hvx_index *ix) { return ix ? ix->cap_rows : 0; }
+extern "C" uint64_t hvx_index_live_rows(const hvx_index *ix) { return ix ? ix->live_rows() : 0; }
+extern "C" int hvx_index_contains(const hvx_index *ix, uint64_t node_id) { return ix && ix->find(node_id) != kSentinel ? 1 : 0; }
 
 // An execution lane on the same index image: own stream, events, per-batch scratch and mutex; rows, graph, ids, headers
 // and SimHash rows are shared with (and kept alive by) the handle it was forked from.
@@ -525,6 +556,8 @@ extern "C" int hvx_index_fork(const hvx_index *parent, hvx_index **out) {
     ix->words_per_query = src->words_per_query;
     ix->ids_p = src->ids_p;
     ix->contiguous = src->contiguous;
+    ix->dead_p = src->dead_p;
+    ix->n_dead = src->n_dead;
     ix->cap_rows = src->cap_rows;
     ix->cap_up_rows = src->cap_up_rows;
     ix->up_rows_used = src->up_rows_used;
@@ -700,7 +733,7 @@ int hvx::enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t b
         int rc = flat_scan_device(ix, d_queries, b, k, nullptr, ix->dev.n, d_ids, d_scores, d_counts, d_status ? d_status : ix->d_qstatus, timed);
         if (rc) return rc;
         hipLaunchKernelGGL(exact_fallback_stats_kernel, dim3((b + 255u) / 256u), dim3(256), 0, ix->stream, d_qstats ? d_qstats : ix->d_qstats, ix->d_tie,
-                           d_status ? d_status : ix->d_qstatus, b, ix->dev.n);
+                           d_status ? d_status : ix->d_qstatus, b, ix->live_rows());
         HIP_TRY(hipGetLastError());
         return HVX_OK;
     }
@@ -947,6 +980,12 @@ int hvx::flat_scan_device(hvx_index *ix, const float *d_queries, uint32_t b, uin
                           uint32_t *d_status, bool timed) {
     if (k == 0) return fail(HVX_ERR_K_RANGE, "result count must be non-zero");
     if (k > 1024) return fail(HVX_ERR_UNSUPPORTED, "flat scan supports k <= 1024");
+    if (!d_subset && ix->n_dead) { // "all rows" of an image with deleted nodes = its live rows (a deleted node has no item row: mutation.rs:1708-1745)
+        int rc = ix->ensure_live();
+        if (rc) return rc;
+        d_subset = ix->f_live;
+        n_rows = ix->live_rows_n;
+    }
     if (ix->dev.dtype != HVX_F32) // bf16 / fp8 rows: the matrix-core pipeline, over all rows or over the restricted row list
         return flat_mfma_device(ix, d_queries, b, k, d_subset, n_rows, d_ids, d_scores, d_counts, d_status, timed);
     // f32 rows, whole-corpus scan, dim >= 256 (below that the top-(m+1) selection over the score matrix outweighs the
@@ -1065,7 +1104,7 @@ extern "C" int hvx_flat_search_batch_device(const hvx_index *cix, const float *d
     HIP_TRY(hipSetDevice(ix->device));
     int rc = flat_scan_device(ix, d_queries, b, k, nullptr, ix->dev.n, d_out_ids, d_out_scores, d_out_counts, d_out_status, stats != nullptr);
     if (rc) return rc;
-    if (stats) return flat_stats(ix, b, ix->dev.n, stats);
+    if (stats) return flat_stats(ix, b, ix->live_rows(), stats);
     return HVX_OK;
 }
 
@@ -1083,7 +1122,7 @@ int hvx::flat_scan_host(hvx_index *ix, const float *queries, uint32_t b, uint32_
         if (rc) return rc;
         if ((rc = ix->stage_out(cb, k))) return rc;
         if (stats) {
-            if ((rc = flat_stats(ix, cb, n_rows, stats))) return rc;
+            if ((rc = flat_stats(ix, cb, (!d_subset && ix->n_dead) ? ix->live_rows() : n_rows, stats))) return rc;
         } else {
             HIP_TRY(hipStreamSynchronize(ix->stream));
         }

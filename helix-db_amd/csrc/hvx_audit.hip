@@ -63,7 +63,7 @@ __global__ void audit_l0_kernel(DevIndex ix, uint32_t m0, AuditCounters *c) {
         else if (prev >= v) atomicAdd(&c->unsorted, 1ull);          // not strictly ascending (covers duplicates)
     }
     if (v == u) atomicAdd(&c->self_loops, 1ull);
-    if (v >= ix.n) { atomicAdd(&c->out_of_range, 1ull); return; }
+    if (v >= ix.n || row_dead(ix, v)) { atomicAdd(&c->out_of_range, 1ull); return; } // (an edge to a deleted node dangles)
     if (!row_contains(ix.l0 + (size_t)v * s0, s0, u)) atomicAdd(&c->asymmetric_l0, 1ull);
 }
 
@@ -100,7 +100,7 @@ __global__ void audit_up_kernel(DevIndex ix, uint32_t m, uint64_t up_rows, const
         else if (prev >= v) atomicAdd(&c->unsorted, 1ull);
     }
     if (v == u) atomicAdd(&c->self_loops, 1ull);
-    if (v >= ix.n) { atomicAdd(&c->out_of_range, 1ull); return; }
+    if (v >= ix.n || row_dead(ix, v)) { atomicAdd(&c->out_of_range, 1ull); return; }
     if (ix.level[v] < layer) { atomicAdd(&c->level_violations, 1ull); return; } // an edge to a node that does not live on this layer
     if (!row_contains(ix.up + (size_t)(ix.up_base[v] + layer - 1u) * su, su, u)) atomicAdd(&c->asymmetric_up, 1ull);
 }
@@ -116,9 +116,9 @@ __global__ void audit_bfs_kernel(DevIndex ix, uint32_t *dist, uint32_t cur, uint
     if (v == kSentinel || v >= ix.n) return;
     if (atomicCAS(&dist[v], 0xFFFFFFFFu, cur + 1u) == 0xFFFFFFFFu) *changed = 1u;
 }
-__global__ void audit_count_unreached_kernel(const uint32_t *dist, uint32_t n, unsigned long long *out) {
+__global__ void audit_count_unreached_kernel(const uint32_t *dist, uint32_t n, const uint32_t *dead, unsigned long long *out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool miss = i < n && dist[i] == 0xFFFFFFFFu;
+    const bool miss = i < n && dist[i] == 0xFFFFFFFFu && !(dead && ((dead[i >> 5] >> (i & 31u)) & 1u)); // (deleted nodes are meant to be unreachable)
     const unsigned long long m = __ballot(miss);
     if ((threadIdx.x & 63u) == 0u && m) atomicAdd(out, (unsigned long long)__builtin_popcountll(m));
 }
@@ -132,7 +132,7 @@ extern "C" int hvx_index_audit_graph(const hvx_index *cix, hvx_graph_audit *out)
     std::lock_guard<std::mutex> lock(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));
     const DevIndex &d = ix->dev;
-    out->nodes = d.n;
+    out->nodes = ix->live_rows(); // (deleted nodes keep empty row slots: not nodes of the graph)
     out->has_entry = d.has_entry;
     out->max_layer = d.max_layer;
     if (d.n == 0) return HVX_OK;
@@ -181,7 +181,7 @@ extern "C" int hvx_index_audit_graph(const hvx_index *cix, hvx_graph_audit *out)
             levels = cur + 1u;
         }
     }
-    hipLaunchKernelGGL(audit_count_unreached_kernel, dim3((d.n + 255u) / 256u), dim3(256), 0, s, d_dist, d.n, d_unreached);
+    hipLaunchKernelGGL(audit_count_unreached_kernel, dim3((d.n + 255u) / 256u), dim3(256), 0, s, d_dist, d.n, d.dead, d_unreached);
     AuditCounters hc{};
     unsigned long long unreached = 0;
     if (hipMemcpyAsync(&hc, dc, sizeof(hc), hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -201,7 +201,7 @@ extern "C" int hvx_index_audit_graph(const hvx_index *cix, hvx_graph_audit *out)
     out->degree_overflow_rows = hc.degree_overflow_rows;
     out->max_degree_l0 = hc.max_degree_l0;
     out->max_degree_up = hc.max_degree_up;
-    out->unreachable_l0 = d.has_entry ? unreached : d.n;
+    out->unreachable_l0 = d.has_entry ? unreached : ix->live_rows();
     out->bfs_levels_l0 = levels;
     return HVX_OK;
 }

@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "hvx_host.h"
+#include "hvx_graph_dev.h"
 
 using namespace hvx;
 
@@ -68,9 +69,6 @@ struct BuildArgs {
     uint32_t *dbg;              // tuning builds (HVX_BUILD_DEBUG): [0] lock spins [1] prunes [2] reverse-edge removals [3] plain appends
 };
 
-__device__ __forceinline__ uint32_t ld_row(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_row(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
 __device__ __forceinline__ void lock_row(uint32_t *locks, uint32_t node, int lane) {
     if (lane == 0) {
         while (__hip_atomic_exchange(&locks[node], 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) __builtin_amdgcn_s_sleep(2);
@@ -89,87 +87,6 @@ __device__ __forceinline__ uint32_t *row_ptr(const BuildArgs &a, uint32_t node, 
     if (layer == 0u) { stride = a.ix.s0; return a.l0 + (size_t)node * a.ix.s0; }
     stride = a.ix.su;
     return a.up + (size_t)(a.ix.up_base[node] + layer - 1u) * a.ix.su;
-}
-
-// LDS of one wavefront: the "query" row of the distance evaluator + small id / score lists
-struct BuildLds {
-    float *qv;       // [ld]
-    uint32_t *kept;  // [64]
-    uint32_t *cid;   // [64] candidates sorted by (score, id)
-    float *csc;      // [64]
-    float *dtmp;     // [64]
-};
-__device__ __forceinline__ BuildLds carve_build(char *smem, uint32_t ld) {
-    BuildLds L;
-    L.qv = reinterpret_cast<float *>(smem);
-    char *p = smem + (((size_t)ld * 4u + 15u) & ~(size_t)15u);
-    L.kept = reinterpret_cast<uint32_t *>(p); p += 256;
-    L.cid = reinterpret_cast<uint32_t *>(p); p += 256;
-    L.csc = reinterpret_cast<float *>(p); p += 256;
-    L.dtmp = reinterpret_cast<float *>(p);
-    return L;
-}
-static size_t build_lds_bytes(uint32_t ld) { return (((size_t)ld * 4u + 15u) & ~(size_t)15u) + 4 * 256; }
-
-__device__ __forceinline__ void stage_row(const DevIndex &ix, float *qv, uint32_t node, int lane) {
-    __syncthreads();
-    const float *r = ix.vec + (size_t)node * ix.ld;
-    for (uint32_t t = (uint32_t)lane; t < ix.ld; t += 64) qv[t] = r[t];
-    __syncthreads();
-}
-
-// mod.rs:809-856 select_diverse over L.cid/L.csc[0..hyd) (sorted closest first, all hydrated), at most m kept, then the
-// backfill with the closest remaining candidates (:845-854).  L.kept[0..ns) = the selection in selection order.
-template <uint32_t METRIC, bool FUSED>
-__device__ __forceinline__ uint32_t select_diverse_dev(const DevIndex &ix, const BuildLds &L, uint32_t hyd, uint32_t m, int lane) {
-    const int grp = lane >> 3, j = lane & 7;
-    uint32_t ns = 0;
-    for (uint32_t i = 0; i < hyd && ns < m; ++i) {
-        const uint32_t ci = L.cid[i];
-        const float si = L.csc[i];
-        bool diverse = true;
-        if (ns) {
-            stage_row(ix, L.qv, ci, lane);
-            const float chdr = ix.hdr[ci];
-            for (uint32_t p0 = 0; p0 < ns; p0 += 8) {
-                const uint32_t g = p0 + (uint32_t)grp;
-                const uint32_t other = L.kept[g < ns ? g : ns - 1u];
-                const float pd = group_distance<METRIC, FUSED>(ix, L.qv, chdr, other, j);
-                if (__ballot(g < ns && pd < si)) { diverse = false; break; } // strict < rejects (mod.rs:832)
-            }
-        }
-        if (diverse) {
-            __syncthreads();
-            if (lane == 0) L.kept[ns] = ci;
-            ++ns;
-            __syncthreads();
-        }
-    }
-    if (ns < m) { // backfill, closest first
-        const bool have = (uint32_t)lane < hyd;
-        const uint32_t mine = have ? L.cid[lane] : kSentinel;
-        bool in = false;
-        for (uint32_t s = 0; s < ns; ++s) in |= L.kept[s] == mine;
-        const unsigned long long free_m = __ballot(have && !in);
-        const uint32_t rank = (uint32_t)__builtin_popcountll(free_m & ((1ull << lane) - 1ull));
-        __syncthreads();
-        if (have && !in && ns + rank < m) L.kept[ns + rank] = mine;
-        const uint32_t add = (uint32_t)__builtin_popcountll(free_m);
-        ns = ns + add < m ? ns + add : m;
-        __syncthreads();
-    }
-    return ns;
-}
-
-// canonical row (ascending id, sentinel padded) of the ids in L.kept[0..ns)
-__device__ __forceinline__ void store_canonical(uint32_t *row, uint32_t stride, const uint32_t *ids_lds, uint32_t ns, int lane, bool coherent) {
-    const uint32_t mine = (uint32_t)lane < ns ? ids_lds[lane] : kSentinel;
-    uint32_t rank = 0;
-    for (uint32_t s = 0; s < ns; ++s) rank += ids_lds[s] < mine ? 1u : 0u;
-    __syncthreads();
-    for (uint32_t t = (uint32_t)lane; t < stride; t += 64)
-        if (t >= ns) { if (coherent) st_row(row + t, kSentinel); else row[t] = kSentinel; }
-    if ((uint32_t)lane < ns) { if (coherent) st_row(row + rank, mine); else row[rank] = mine; }
 }
 
 // ---- step 2: the new node's own neighbour lists ----

@@ -1,0 +1,513 @@
+// hvx_delete.hip -- delete of nodes from a LIVE device image (VERDICT r4 missing #4, second half): the reference's
+// stage_delete_with_metadata (crates/db/src/search/vector/mutation.rs:1658-1774) -> delete_from_layer (:1819-1888) ->
+// remove_edge_from_neighbor (:1890-1908) + relink_neighbor (:1916-2055), one node after the other, on the rows resident in HBM.
+//
+// What the reference does for ONE node x, per layer (highest first; the layers are independent of each other -- each touches
+// only its own neighbour rows -- so the device runs them side by side, one workgroup per layer):
+//   sources      every row of the layer that holds x: x's own out-neighbours (they relink whether or not they hold the edge) and the
+//                reverse-locator sources (update_reverse_edge_locator :1134-1153 keeps that set equal to "rows that contain x")
+//   unlink       x is removed from each of them
+//   candidates   C = the sources and everything their remaining rows hold (x excluded)
+//   relink(s)    for every source s in ascending id order: the Mmax closest members of C \ {s} that s does not hold yet are appended
+//                to its row; a row beyond Mmax is ranked by distance to s and pruned by select_diverse + backfill (mod.rs:809-856);
+//                every NEW neighbour t gets s appended to ITS row, pruned the same way when that overflows
+// then x's rows, item, SimHash row and entry-candidate rows are deleted and, when x was the entry point, the entry moves to the best
+// remaining entry candidate: highest layer first, then the smallest id (keys/vectors.rs:1097 [inv_layer:2][node_id:8]).
+//
+// Kernels per deleted node (no host synchronisation between them, or between the nodes of a batch):
+//   delete_scan_kernel    grid over every row slot: which rows hold x, per layer            (128-260 MB of rows at 1M nodes: ~50 us)
+//   delete_prep_kernel    one workgroup per layer: dedupe + sort the sources, unlink x, collect C (a bitmap marks membership)
+//   delete_rank_kernel    workgroups x layers: for every source its distances to all of C in the reference's summation order
+//                         (group_distance) and the Mmax smallest in Candidate order (model.rs:55-61) -- independent of the graph, so
+//                         this part, the bulk of the arithmetic, runs in parallel over the sources
+//   delete_relink_kernel  one wavefront per layer: the relinks IN ORDER (a relink reads rows earlier relinks of the same delete changed),
+//                         each a merge + at most one prune of <= 64 ids + the reciprocal rows; then x's own row is emptied and its
+//                         deleted bit set
+// A deleted node keeps its row slot: unreachable (nothing links to it, the entry point is repaired), absent from every id -> row
+// lookup (hvx_index::find), from exact scans (they run over the live rows, hvx_index::ensure_live), from the SimHash directory, the
+// prefilter's candidate mapping and the audit.  Sequential semantics: the nodes of a batch are deleted one after the other, and
+// the rows equal the oracle's (oracle/hvx_oracle.c orc_index_delete) row for row -- tests/test_gpu_delete.py.
+// Limits (exceeded => HVX_ERR_UNSUPPORTED, loudly): 4 096 rows holding one node per layer, 16 384 candidates per layer.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "hvx_host.h"
+#include "hvx_graph_dev.h"
+
+using namespace hvx;
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) return fail(HVX_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+namespace hvx {
+
+constexpr uint32_t kDelSrcCap = 4096;   // rows that hold the node, per layer
+constexpr uint32_t kDelRelCap = 4096;   // relink sources per layer (sorted in LDS)
+constexpr uint32_t kDelCandCap = 16384; // candidates per layer (one source's scores live in LDS)
+constexpr uint32_t kDelTop = 32;        // Mmax
+constexpr uint32_t kDelMinLayers = 16;
+constexpr uint32_t kDelMark = 0xFFFFFFFFu;
+
+struct DeleteArgs {
+    DevIndex ix;
+    uint32_t *l0, *up;      // ix.l0 / ix.up, writable
+    uint32_t node;          // row being deleted
+    uint32_t layers;        // max_layer + 1
+    uint32_t m, m0, words;  // degree limits; words of one layer's mark bitmap
+    uint32_t *src, *src_cnt;   // [layers][kDelSrcCap], [layers]: rows that hold the node (unordered)
+    uint32_t *rel, *rel_cnt;   // [layers][kDelRelCap], [layers]: relink sources, ascending
+    uint32_t *cand, *cand_cnt; // [layers][kDelCandCap], [layers]
+    uint32_t *top, *top_cnt;   // [layers][kDelRelCap][kDelTop], [layers][kDelRelCap]: a source's closest candidates, Candidate order
+    uint32_t *mark;            // [layers][words] all zero between kernels
+    uint32_t *dead;            // the image's deleted-row bitmap
+    uint32_t *ctl;             // [0] error (1 sources, 2 relink sources, 3 candidates, 4 invalid score, 5 row overflow) [1] relinked rows
+                               // [2..3] best entry key (u64)
+};
+
+__device__ __forceinline__ uint32_t *del_row(const DeleteArgs &a, uint32_t node, uint32_t layer, uint32_t &stride) {
+    if (layer == 0u) { stride = a.ix.s0; return a.l0 + (size_t)node * a.ix.s0; }
+    stride = a.ix.su;
+    return a.up + (size_t)(a.ix.up_base[node] + layer - 1u) * a.ix.su;
+}
+
+// reverse_sources_for_target (storage.rs, mutation.rs:1677): every row that holds the node, per layer
+__global__ __launch_bounds__(256) void delete_scan_kernel(DeleteArgs a) {
+    const DevIndex &ix = a.ix;
+    const unsigned long long total = (unsigned long long)ix.n * ix.s0, step = (unsigned long long)gridDim.x * 256ull;
+    for (unsigned long long t = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; t < total; t += step) {
+        if (a.l0[t] != a.node) continue;
+        const uint32_t owner = (uint32_t)(t / ix.s0);
+        if (owner == a.node) continue;
+        const uint32_t pos = atomicAdd(&a.src_cnt[0], 1u);
+        if (pos < kDelSrcCap) a.src[pos] = owner;
+    }
+    for (unsigned long long u = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; u < ix.n; u += step) {
+        uint32_t lv = ix.level[u];
+        if (lv == 0u || (uint32_t)u == a.node) continue;
+        if (lv >= a.layers) lv = a.layers - 1u;
+        const uint32_t base = ix.up_base[u];
+        for (uint32_t l = 1; l <= lv; ++l) {
+            const uint32_t *row = a.up + (size_t)(base + l - 1u) * ix.su;
+            for (uint32_t p = 0; p < ix.su; ++p) {
+                const uint32_t v = row[p];
+                if (v == kSentinel) break; // canonical rows: the valid ids come first
+                if (v == a.node) {
+                    const uint32_t pos = atomicAdd(&a.src_cnt[l], 1u);
+                    if (pos < kDelSrcCap) a.src[(size_t)l * kDelSrcCap + pos] = (uint32_t)u;
+                    break;
+                }
+            }
+        }
+    }
+}
+
+// delete_from_layer up to the relinks (mutation.rs:1829-1875): sources, unlink, candidates.  One workgroup per layer.
+__global__ __launch_bounds__(256) void delete_prep_kernel(DeleteArgs a) {
+    __shared__ uint32_t aff[kDelRelCap], srt[kDelRelCap];
+    __shared__ uint32_t s_na, s_nc;
+    const DevIndex &ix = a.ix;
+    const uint32_t L = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t node = a.node, lvl = ix.level[node];
+    const uint32_t ns = a.src_cnt[L];
+    if (tid == 0) { a.rel_cnt[L] = 0; a.cand_cnt[L] = 0; s_na = 0; s_nc = 0; }
+    if (a.ctl[0] != 0u) return;
+    if (ns > kDelSrcCap) { if (tid == 0) atomicMax(&a.ctl[0], 1u); return; }
+    if (L > lvl && ns == 0u) return;
+    uint32_t *mark = a.mark + (size_t)L * a.words;
+    auto claim = [&](uint32_t v) -> bool { // true for the first claim of a row
+        const uint32_t bit = 1u << (v & 31u);
+        return (atomicOr(&mark[v >> 5], bit) & bit) == 0u;
+    };
+    if (tid == 0) (void)claim(node);
+    __syncthreads();
+    // the node's out-neighbours (mandatory_relink :1833-1837), then the rows that hold it (:1838-1844); BTreeSet = ascending ids
+    if (L <= lvl) {
+        uint32_t stride;
+        const uint32_t *row = del_row(a, node, L, stride);
+        const uint32_t v = tid < stride ? ld_row(row + tid) : kSentinel;
+        if (v != kSentinel && v < ix.n && ix.level[v] >= L && claim(v)) { const uint32_t pos = atomicAdd(&s_na, 1u); if (pos < kDelRelCap) aff[pos] = v; }
+    }
+    __syncthreads();
+    for (uint32_t t = tid; t < ns; t += 256u) {
+        const uint32_t v = a.src[(size_t)L * kDelSrcCap + t];
+        if (claim(v)) { const uint32_t pos = atomicAdd(&s_na, 1u); if (pos < kDelRelCap) aff[pos] = v; }
+    }
+    __syncthreads();
+    const uint32_t na_all = s_na, na = na_all < kDelRelCap ? na_all : kDelRelCap;
+    for (uint32_t i = tid; i < na; i += 256u) { // rows = ids ascending: rank by counting (the ids are distinct)
+        const uint32_t v = aff[i];
+        uint32_t r = 0;
+        for (uint32_t t = 0; t < na; ++t) r += aff[t] < v ? 1u : 0u;
+        srt[r] = v;
+    }
+    __syncthreads();
+    uint32_t lstride = L == 0u ? ix.s0 : ix.su;
+    if (na_all <= kDelRelCap) {
+        // remove_edge_from_neighbor (:1890-1908) on every source: one wavefront per row (the rows are distinct)
+        for (uint32_t i = wave; i < na; i += 4u) {
+            uint32_t stride;
+            uint32_t *row = del_row(a, srt[i], L, stride);
+            const uint32_t v = lane < stride ? ld_row(row + lane) : kSentinel;
+            if (__ballot(v == node) == 0ull) continue;
+            const bool keep = v != kSentinel && v != node;
+            const unsigned long long km = __ballot(keep);
+            const uint32_t pos = (uint32_t)__builtin_popcountll(km & ((1ull << lane) - 1ull)), nk = (uint32_t)__builtin_popcountll(km);
+            if (keep) st_row(row + pos, v);
+            if (lane >= nk && lane < stride) st_row(row + lane, kSentinel);
+        }
+        __threadfence();
+        __syncthreads();
+        // candidates (:1862-1875): the relink sources (their bits are set already), then what their rows hold now
+        uint32_t *cand = a.cand + (size_t)L * kDelCandCap;
+        for (uint32_t i = tid; i < na; i += 256u) cand[i] = srt[i];
+        if (tid == 0) s_nc = na;
+        __syncthreads();
+        for (uint32_t t = tid; t < na * lstride; t += 256u) {
+            uint32_t stride;
+            const uint32_t *row = del_row(a, srt[t / lstride], L, stride);
+            const uint32_t v = ld_row(row + (t % lstride));
+            if (v != kSentinel && v < ix.n && ix.level[v] >= L && claim(v)) { const uint32_t pos = atomicAdd(&s_nc, 1u); if (pos < kDelCandCap) cand[pos] = v; }
+        }
+        __syncthreads();
+        const uint32_t nc_all = s_nc, nc = nc_all < kDelCandCap ? nc_all : kDelCandCap;
+        for (uint32_t i = tid; i < nc; i += 256u) { const uint32_t v = cand[i]; atomicAnd(&mark[v >> 5], ~(1u << (v & 31u))); }
+        for (uint32_t i = tid; i < na; i += 256u) a.rel[(size_t)L * kDelRelCap + i] = srt[i];
+        if (tid == 0) {
+            atomicAnd(&mark[node >> 5], ~(1u << (node & 31u)));
+            if (nc_all > kDelCandCap) atomicMax(&a.ctl[0], 3u);
+            else { a.rel_cnt[L] = na; a.cand_cnt[L] = nc; }
+        }
+    } else if (tid == 0) {
+        atomicMax(&a.ctl[0], 2u);
+    }
+}
+
+// relink_neighbor's ranking (mutation.rs:1936-1957) for every source of every layer: distances to all candidates, the Mmax smallest
+template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(256) void delete_rank_kernel(DeleteArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ unsigned long long red[4];
+    __shared__ uint32_t s_bad;
+    const DevIndex &ix = a.ix;
+    const uint32_t L = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const int grp = (int)(lane >> 3), j = (int)(lane & 7u);
+    if (a.ctl[0] != 0u) return;
+    const uint32_t nr = a.rel_cnt[L], nc = a.cand_cnt[L];
+    if (nr == 0u || nc == 0u) return;
+    const uint32_t maxn = L == 0u ? a.m0 : a.m;
+    float *qv = reinterpret_cast<float *>(smem);
+    uint32_t *sc = reinterpret_cast<uint32_t *>(smem + (((size_t)ix.ld * 4u + 15u) & ~(size_t)15u));
+    const uint32_t *cand = a.cand + (size_t)L * kDelCandCap;
+    if (tid == 0) s_bad = 0;
+    for (uint32_t ri = blockIdx.x; ri < nr; ri += gridDim.x) {
+        const uint32_t r = a.rel[(size_t)L * kDelRelCap + ri];
+        __syncthreads();
+        {
+            const float *rv = ix.vec + (size_t)r * ix.ld;
+            for (uint32_t t = tid; t < ix.ld; t += 256u) qv[t] = rv[t];
+        }
+        __syncthreads();
+        const float rh = ix.hdr[r];
+        bool bad = false;
+        for (uint32_t c0 = 0; c0 < nc; c0 += 32u) {
+            const uint32_t idx = c0 + wave * 8u + (uint32_t)grp;
+            const uint32_t c = cand[idx < nc ? idx : nc - 1u];
+            float d = group_distance<METRIC, FUSED>(ix, qv, rh, c, j);
+            if (idx < nc && j == 0) {
+                uint32_t bits = kDelMark; // (the source itself is no candidate of its own relink: :1937-1939)
+                if (c != r) {
+                    if (score_valid(d)) bits = __float_as_uint(d);
+                    else bad = true; // Candidate::try_new fails: the reference aborts the delete
+                }
+                sc[idx] = bits;
+            }
+        }
+        if (bad) s_bad = 1u;
+        __syncthreads();
+        auto local_best = [&]() -> unsigned long long {
+            unsigned long long best = ~0ull;
+            for (uint32_t i = tid; i < nc; i += 256u) {
+                const uint32_t b = sc[i];
+                if (b == kDelMark) continue;
+                const unsigned long long key = ((unsigned long long)b << 32) | cand[i]; // Candidate order: score, then id (rows ascend with ids)
+                best = key < best ? key : best;
+            }
+            return best;
+        };
+        unsigned long long best = local_best();
+        uint32_t got = 0;
+        uint32_t *out = a.top + ((size_t)L * kDelRelCap + ri) * kDelTop;
+        for (uint32_t t = 0; t < maxn; ++t) {
+            unsigned long long w = best;
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) {
+                const unsigned long long o = __shfl_xor(w, s, 64);
+                w = o < w ? o : w;
+            }
+            if (lane == 0) red[wave] = w;
+            __syncthreads();
+            unsigned long long win = red[0];
+            win = red[1] < win ? red[1] : win;
+            win = red[2] < win ? red[2] : win;
+            win = red[3] < win ? red[3] : win;
+            if (win == ~0ull) break; // (uniform: every thread reads the same four words)
+            if (tid == 0) out[t] = (uint32_t)win;
+            got = t + 1u;
+            if (best == win) { // this thread's: take it out and look again
+                for (uint32_t i = tid; i < nc; i += 256u)
+                    if (cand[i] == (uint32_t)win) sc[i] = kDelMark;
+                best = local_best();
+            }
+            __syncthreads();
+        }
+        if (tid == 0) a.top_cnt[(size_t)L * kDelRelCap + ri] = got;
+    }
+    __syncthreads();
+    if (tid == 0 && s_bad) atomicMax(&a.ctl[0], 4u);
+}
+
+// the relinks of one layer, in order (mutation.rs:1876-1887 -> relink_neighbor :1916-2055), then the node's own row goes
+template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(64) void delete_relink_kernel(DeleteArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const DevIndex &ix = a.ix;
+    const uint32_t L = blockIdx.x;
+    const int lane = (int)threadIdx.x;
+    BuildLds Ld = carve_build(smem, ix.ld);
+    uint32_t *oldl = reinterpret_cast<uint32_t *>(smem + ((((size_t)ix.ld * 4u + 15u) & ~(size_t)15u) + 4 * 256)); // [64] the row before the relink
+    const uint32_t node = a.node, lvl = ix.level[node];
+    const bool failed = a.ctl[0] != 0u;
+    const uint32_t nr = failed ? 0u : a.rel_cnt[L];
+    const uint32_t maxn = L == 0u ? a.m0 : a.m;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    bool bad = false, overflow = false;
+    for (uint32_t ri = 0; ri < nr; ++ri) {
+        const uint32_t nb = a.rel[(size_t)L * kDelRelCap + ri];
+        uint32_t stride;
+        uint32_t *row = del_row(a, nb, L, stride);
+        const uint32_t v = (uint32_t)lane < stride ? ld_row(row + lane) : kSentinel;
+        const uint32_t nold = (uint32_t)__builtin_popcountll(__ballot(v != kSentinel));
+        const uint32_t tn = a.top_cnt[(size_t)L * kDelRelCap + ri];
+        const uint32_t tv = (uint32_t)lane < tn ? a.top[((size_t)L * kDelRelCap + ri) * kDelTop + lane] : kSentinel;
+        __syncthreads();
+        oldl[lane] = v; // canonical: the valid ids are lanes 0..nold-1
+        __syncthreads();
+        // :1953-1957 the closest candidates the row does not hold yet, appended in Candidate order
+        bool in_old = false;
+        for (uint32_t s = 0; s < nold; ++s) in_old |= oldl[s] == tv;
+        const bool add = tv != kSentinel && !in_old;
+        const unsigned long long am = __ballot(add);
+        const uint32_t ncur = nold + (uint32_t)__builtin_popcountll(am);
+        if (ncur > 64u) { overflow = true; continue; }
+        if ((uint32_t)lane < nold) Ld.kept[lane] = v;
+        if (add) Ld.kept[nold + (uint32_t)__builtin_popcountll(am & lt)] = tv;
+        __syncthreads();
+        const uint32_t cv = (uint32_t)lane < ncur ? Ld.kept[lane] : kSentinel;
+        uint32_t keepn = ncur;
+        if (ncur > maxn) keepn = prune_row_dev<METRIC, FUSED>(ix, Ld, nb, cv, ncur, maxn, lane, &bad); // :1959-1984
+        __syncthreads();
+        const uint32_t f = (uint32_t)lane < keepn ? Ld.kept[lane] : kSentinel;
+        bool was_old = false;
+        for (uint32_t s = 0; s < nold; ++s) was_old |= oldl[s] == f;
+        unsigned long long nm = __ballot(f != kSentinel && !was_old);
+        if (keepn > stride) { overflow = true; continue; }
+        store_canonical(row, stride, Ld.kept, keepn, lane, true); // :1986-1993 (staged rows are sorted by id, :1299)
+        __syncthreads();
+        while (nm) { // :1994-2052 the reciprocal row of every new neighbour
+            const uint32_t srcl = (uint32_t)__builtin_ctzll(nm);
+            nm &= nm - 1ull;
+            const uint32_t nw = (uint32_t)__builtin_amdgcn_readlane((int)f, (int)srcl);
+            uint32_t rstride;
+            uint32_t *rrow = del_row(a, nw, L, rstride);
+            uint32_t rv = (uint32_t)lane < rstride ? ld_row(rrow + lane) : kSentinel;
+            uint32_t rdeg = (uint32_t)__builtin_popcountll(__ballot(rv != kSentinel));
+            if (__ballot(rv == nb) != 0ull) continue;
+            if (rdeg >= 64u) { overflow = true; continue; } // (the id is appended in a register: the row itself never holds more than Mmax)
+            if ((uint32_t)lane == rdeg) rv = nb;
+            ++rdeg;
+            uint32_t kn = rdeg;
+            if (rdeg > maxn) {
+                kn = prune_row_dev<METRIC, FUSED>(ix, Ld, nw, rv, rdeg, maxn, lane, &bad); // :2007-2040
+            } else {
+                __syncthreads();
+                if ((uint32_t)lane < rdeg) Ld.kept[lane] = rv;
+                __syncthreads();
+            }
+            store_canonical(rrow, rstride, Ld.kept, kn, lane, true);
+            __syncthreads();
+        }
+        __threadfence(); // the next relink of this layer reads rows this one has written
+        __syncthreads();
+    }
+    __threadfence();
+    __syncthreads();
+    if (!failed && L <= lvl) { // :1726-1730 the node's neighbour rows are deleted
+        uint32_t stride;
+        uint32_t *row = del_row(a, node, L, stride);
+        if ((uint32_t)lane < stride) st_row(row + lane, kSentinel);
+    }
+    if (lane == 0) {
+        a.src_cnt[L] = 0;
+        if (nr) atomicAdd(&a.ctl[1], nr);
+        if (__builtin_expect(bad, 0)) atomicMax(&a.ctl[0], 4u);
+        if (__builtin_expect(overflow, 0)) atomicMax(&a.ctl[0], 5u);
+        if (L == 0u && !failed) atomicOr(&a.dead[node >> 5], 1u << (node & 31u));
+    }
+}
+
+// find_best_entry_candidate (mutation.rs:350-394): the live node on the highest layer, smallest id first
+__global__ __launch_bounds__(256) void delete_best_entry_kernel(DevIndex ix, const uint32_t *dead, unsigned long long *out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    unsigned long long key = 0ull;
+    if (i < ix.n && ((dead[i >> 5] >> (i & 31u)) & 1u) == 0u) key = (((unsigned long long)ix.level[i] + 1ull) << 32) | (0xFFFFFFFFu - i);
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        const unsigned long long o = __shfl_xor(key, s, 64);
+        key = o > key ? o : key;
+    }
+    if ((threadIdx.x & 63u) == 0u && key) atomicMax(out, key);
+}
+
+using DeleteKernel = void (*)(DeleteArgs);
+struct DeleteKernels { DeleteKernel rank, relink; };
+template <uint32_t METRIC, bool FUSED> static DeleteKernels delete_kernels_of() { return {delete_rank_kernel<METRIC, FUSED>, delete_relink_kernel<METRIC, FUSED>}; }
+static DeleteKernels pick_delete_kernels(uint32_t metric, bool fused) {
+    if (metric == kL2) return fused ? delete_kernels_of<kL2, true>() : delete_kernels_of<kL2, false>();
+    if (metric == kCosine) return fused ? delete_kernels_of<kCosine, true>() : delete_kernels_of<kCosine, false>();
+    return fused ? delete_kernels_of<kL1, true>() : delete_kernels_of<kL1, false>();
+}
+
+} // namespace hvx
+
+extern "C" int hvx_index_delete_batch(hvx_index *ix, const uint64_t *node_ids, uint32_t count, hvx_delete_stats *stats) {
+    if (!ix || (count && !node_ids)) return fail(HVX_ERR_INVARIANT, "null argument");
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (stats) stats->requested = count;
+    if (count == 0) return HVX_OK;
+    if (ix->is_fork) return fail(HVX_ERR_UNSUPPORTED, "nodes are deleted through the handle that owns the image, not a fork");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    DevIndex &d = ix->dev;
+    if (d.dtype != HVX_F32) return fail(HVX_ERR_UNSUPPORTED, "nodes are deleted from f32 images (import the changed graph with a reduced-precision dtype afterwards)");
+    const uint32_t m = ix->desc.m ? ix->desc.m : 16u;
+    const uint32_t m0 = std::max(ix->desc.m0 ? ix->desc.m0 : 2u * m, 2u * m);
+    if (m0 > kDelTop || m > kDelTop || d.s0 > 64u || d.su > 64u || d.s0 < m0 || d.su < m)
+        return fail(HVX_ERR_UNSUPPORTED, "device delete serves degree limits <= 32 on rows at least that wide (m %u m0 %u strides %u / %u)", m, m0, d.su, d.s0);
+    const auto t0 = std::chrono::steady_clock::now();
+    hipStream_t s = ix->stream;
+    const uint64_t cap = std::max<uint64_t>(ix->cap_rows, d.n);
+    const uint32_t words = (uint32_t)((cap + 31u) / 32u) + 1u;
+    int rc;
+    if (!ix->d_dead) { // the image's deleted-row bitmap: one bit per row it can ever hold
+        if ((rc = ix->dalloc((void **)&ix->d_dead, (size_t)words * 4))) return rc;
+        HIP_TRY(hipMemsetAsync(ix->d_dead, 0, (size_t)words * 4, s));
+    }
+    d.dead = ix->d_dead;
+    const uint32_t layers_now = d.max_layer + 1u;
+    if (!ix->del_scratch || ix->del_layers < layers_now) {
+        const uint32_t layers = std::max(kDelMinLayers, layers_now);
+        const size_t per_layer = ((size_t)kDelSrcCap + kDelRelCap + kDelCandCap + (size_t)kDelRelCap * kDelTop + kDelRelCap + words + 3u) * 4u;
+        void *p = nullptr;
+        if ((rc = ix->dalloc(&p, per_layer * layers + 64))) return rc;
+        HIP_TRY(hipMemsetAsync(p, 0, per_layer * layers + 64, s));
+        ix->del_scratch = p; // (an earlier, smaller scratch stays with the image's allocations until the handle goes)
+        ix->del_layers = layers;
+    }
+    DeleteArgs a{};
+    {
+        const uint32_t layers = ix->del_layers;
+        uint32_t *p = reinterpret_cast<uint32_t *>(ix->del_scratch);
+        a.ctl = p; p += 16;
+        a.src_cnt = p; p += layers;
+        a.rel_cnt = p; p += layers;
+        a.cand_cnt = p; p += layers;
+        a.src = p; p += (size_t)layers * kDelSrcCap;
+        a.rel = p; p += (size_t)layers * kDelRelCap;
+        a.cand = p; p += (size_t)layers * kDelCandCap;
+        a.top_cnt = p; p += (size_t)layers * kDelRelCap;
+        a.top = p; p += (size_t)layers * kDelRelCap * kDelTop;
+        a.mark = p;
+    }
+    a.l0 = const_cast<uint32_t *>(d.l0);
+    a.up = const_cast<uint32_t *>(d.up);
+    a.m = m; a.m0 = m0; a.words = words;
+    a.dead = ix->d_dead;
+    HIP_TRY(hipMemsetAsync(a.ctl, 0, 16, s));
+    const DeleteKernels kern = pick_delete_kernels(d.metric, kernel_fused(d.fkernel));
+    const size_t rank_lds = (((size_t)d.ld * 4u + 15u) & ~(size_t)15u) + (size_t)kDelCandCap * 4u;
+    const size_t relink_lds = (((size_t)d.ld * 4u + 15u) & ~(size_t)15u) + 4 * 256 + 256;
+    if (rank_lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kern.rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_lds));
+    if (relink_lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kern.relink, hipFuncAttributeMaxDynamicSharedMemorySize, (int)relink_lds));
+    // this generation's deleted-row flags: a copy of the visible ones (forks keep theirs until hvx_index_refresh)
+    auto flags = std::make_shared<std::vector<uint8_t>>((size_t)cap, (uint8_t)0);
+    if (ix->dead_p) std::copy(ix->dead_p->begin(), ix->dead_p->begin() + std::min<size_t>(ix->dead_p->size(), (size_t)cap), flags->begin());
+    uint32_t deleted = 0, missing = 0, entry_moves = 0, n_dead = ix->n_dead;
+    auto read_ctl = [&](uint32_t *out4) -> int {
+        if ((rc = ix->pin_flags(4))) return rc;
+        HIP_TRY(hipMemcpyAsync(ix->h_flags, a.ctl, 16, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        memcpy(out4, ix->h_flags, 16);
+        return HVX_OK;
+    };
+    for (uint32_t i = 0; i < count; ++i) {
+        const uint32_t row = ix->find_slot(node_ids[i]);
+        if (row == kSentinel || row >= d.n || (*flags)[row]) { ++missing; continue; } // an unknown id succeeds and stages nothing (index.rs:2263, 2294-2295)
+        a.ix = d;
+        a.node = row;
+        a.layers = d.max_layer + 1u;
+        const unsigned long long slots = (unsigned long long)d.n * d.s0;
+        const uint32_t scan_blocks = (uint32_t)std::min<unsigned long long>(4096ull, std::max<unsigned long long>(1ull, (slots + 255ull) / 256ull));
+        hipLaunchKernelGGL(delete_scan_kernel, dim3(scan_blocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(delete_prep_kernel, dim3(a.layers), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(kern.rank, dim3(64, a.layers), dim3(256), rank_lds, s, a);
+        hipLaunchKernelGGL(kern.relink, dim3(a.layers), dim3(64), relink_lds, s, a);
+        HIP_TRY(hipGetLastError());
+        (*flags)[row] = 1;
+        ++n_dead;
+        ++deleted;
+        if (d.has_entry && row == d.entry) { // :1756-1767 the entry point moves to the best remaining entry candidate
+            HIP_TRY(hipMemsetAsync(a.ctl + 2, 0, 8, s));
+            hipLaunchKernelGGL(delete_best_entry_kernel, dim3((d.n + 255u) / 256u), dim3(256), 0, s, d, ix->d_dead, reinterpret_cast<unsigned long long *>(a.ctl + 2));
+            HIP_TRY(hipGetLastError());
+            uint32_t c4[4];
+            if ((rc = read_ctl(c4))) return rc;
+            if (c4[0]) break; // reported below
+            const unsigned long long key = ((unsigned long long)c4[3] << 32) | c4[2];
+            if (key == 0ull) { d.has_entry = 0; d.entry = 0; d.max_layer = 0; }
+            else { d.entry = 0xFFFFFFFFu - (uint32_t)key; d.max_layer = (uint32_t)(key >> 32) - 1u; }
+            ++entry_moves;
+        }
+    }
+    uint32_t c4[4];
+    if ((rc = read_ctl(c4))) return rc;
+    if (c4[0]) {
+        static const char *why[] = {"", "more than 4096 rows hold one node on a layer", "more than 4096 relink sources on a layer", "more than 16384 relink candidates on a layer",
+                                    "a distance is not a valid score (Candidate::try_new fails: the reference aborts the delete)", "a neighbour row overflowed its stride"};
+        const uint32_t code = c4[0] < 6u ? c4[0] : 5u;
+        (void)hipMemsetAsync(ix->del_scratch, 0, 64 + (size_t)ix->del_layers * 3u * 4u, s); // counters; the marks of an aborted layer may be dirty:
+        ix->del_scratch = nullptr;                                                           // ... the next call starts from fresh scratch
+        ix->del_layers = 0;
+        return fail(code == 4u ? HVX_ERR_INVARIANT : HVX_ERR_UNSUPPORTED, "device delete: %s -- the image is partially relinked: discard the handle and hydrate again", why[code]);
+    }
+    // ---- the new generation ----
+    ix->dead_p = flags;
+    ix->n_dead = n_dead;
+    ix->desc.has_entry = d.has_entry;
+    ix->desc.max_layer = d.max_layer;
+    ix->desc.entry_point = d.has_entry ? ix->ids_ref()[d.entry] : 0;
+    if (deleted) ix->publish_view();
+    if (stats) {
+        stats->deleted = deleted;
+        stats->missing = missing;
+        stats->entry_moves = entry_moves;
+        stats->relinked_rows = c4[1];
+        stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return HVX_OK;
+}

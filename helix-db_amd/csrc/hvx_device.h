@@ -51,7 +51,9 @@ struct DevIndex {
     uint32_t metric, fkernel;
     uint32_t entry, max_layer, has_entry;
     uint32_t dtype;           // hvx_dtype of the stored rows
+    const uint32_t *dead;     // one bit per row: deleted (hvx_index_delete_batch); NULL while nothing has been deleted
 };
+__device__ __forceinline__ bool row_dead(const DevIndex &ix, uint32_t row) { return ix.dead && ((ix.dead[row >> 5] >> (row & 31u)) & 1u); }
 
 // bf16 device layout (dim % 64 == 0): element i = 32*chunk + 4*slot + e is stored at
 // 64*(chunk/2) + 8*slot + 4*(chunk%2) + e, so that the 16 bytes a lane of a row group owns hold its

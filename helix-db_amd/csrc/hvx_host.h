@@ -44,6 +44,11 @@ struct hvx_image_shared {
     // snapshot only when hydration_seq == snapshot_seq) decides when.
     uint64_t visible_seq = 0;
     uint32_t v_n = 0, v_entry = 0, v_max_layer = 0, v_has_entry = 0;
+    // ... and the rows that are deleted (hvx_index_delete_batch): host flags of this generation, their number, the device bitmap
+    std::shared_ptr<const std::vector<uint8_t>> v_dead;
+    uint32_t v_n_dead = 0;
+    const uint32_t *v_dead_dev = nullptr;
+    const void *dir_dead = nullptr;    // the deleted-row flags the SimHash directory was built without
     uint64_t v_entry_point = 0;
     bool v_contiguous = true;
     std::shared_ptr<const std::vector<uint64_t>> v_ids;
@@ -85,6 +90,18 @@ struct hvx_index {
     std::shared_ptr<const std::vector<uint64_t>> ids_p = std::make_shared<std::vector<uint64_t>>(); // host copy of node ids
     const std::vector<uint64_t> &ids_ref() const { return *ids_p; }
     bool contiguous = false;
+    // deleted rows of this handle's generation (hvx_delete.hip): a deleted node keeps its row slot -- emptied, unreachable, absent
+    // from every id -> row lookup and from every exact scan (which then runs over `f_live`, the ascending list of live rows)
+    std::shared_ptr<const std::vector<uint8_t>> dead_p; // [rows] 1 = deleted; null while nothing has been deleted
+    uint32_t n_dead = 0;
+    uint32_t *d_dead = nullptr;      // owner: the image's device bitmap (one bit per row of capacity), allocated by the first delete
+    uint32_t *f_live = nullptr;      // live rows ascending, built on demand for the generation in `live_for`
+    const void *live_for = nullptr;
+    uint32_t live_rows_n = 0, cap_live = 0;
+    int ensure_live();               // f_live / live_rows_n for this handle's generation
+    uint32_t live_rows() const { return dev.n - n_dead; }
+    void *del_scratch = nullptr;     // owner: scratch of the delete kernels (hvx_delete.hip)
+    uint32_t del_layers = 0;
     // per-batch device scratch
     uint32_t *d_bitmap = nullptr, *d_qstatus = nullptr, *d_tie = nullptr;
     float *d_qhdr = nullptr;
@@ -161,6 +178,12 @@ struct hvx_index {
     int flat_scratch(uint32_t b, uint32_t k, uint32_t chunk_rows);
     // external id -> internal row, kSentinel when absent
     uint32_t find(uint64_t id) const {
+        const uint32_t row = find_slot(id);
+        if (row != hvx::kSentinel && dead_p && (*dead_p)[row]) return hvx::kSentinel; // deleted: the id holds no vector any more
+        return row;
+    }
+    // the row slot of an id, deleted or not
+    uint32_t find_slot(uint64_t id) const {
         const std::vector<uint64_t> &ids = *ids_p;
         if (ids.empty()) return hvx::kSentinel;
         if (contiguous) {

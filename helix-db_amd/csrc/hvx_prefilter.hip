@@ -951,22 +951,31 @@ extern "C" int hvx_search_restricted_batch(const hvx_index *cix, const float *qu
 namespace {
 
 // external node id -> internal row of the index (ids ascending), kSentinel when the node holds no vector
-__device__ __forceinline__ uint32_t find_row(const uint64_t *ids, uint32_t n, uint64_t id, bool contiguous) {
+// (or whose vector has been deleted: `dead` = the image's deleted-row bitmap, NULL while nothing has been deleted)
+__device__ __forceinline__ uint32_t find_row(const uint64_t *ids, uint32_t n, uint64_t id, bool contiguous, const uint32_t *dead) {
     if (n == 0) return kSentinel;
-    if (contiguous) return (id >= ids[0] && id - ids[0] < n) ? (uint32_t)(id - ids[0]) : kSentinel;
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        if (ids[mid] < id) lo = mid + 1;
-        else hi = mid;
+    uint32_t row;
+    if (contiguous) {
+        if (!(id >= ids[0] && id - ids[0] < n)) return kSentinel;
+        row = (uint32_t)(id - ids[0]);
+    } else {
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (ids[mid] < id) lo = mid + 1;
+            else hi = mid;
+        }
+        if (!(lo < n && ids[lo] == id)) return kSentinel;
+        row = lo;
     }
-    return (lo < n && ids[lo] == id) ? lo : kSentinel;
+    if (dead && ((dead[row >> 5] >> (row & 31u)) & 1u)) return kSentinel;
+    return row;
 }
 
 // pass 1: per 256-word block, how many set bits map to an indexed row (restricted.rs:615-659: ids that are not
 // indexed are omitted) and how many bits are set at all (the RestrictedVectorCandidates population, :356-371)
 __global__ __launch_bounds__(256) void bitmap_count_kernel(const uint32_t *bitmap, uint32_t n_words, const uint64_t *ids, uint32_t n,
-                                                           uint32_t contiguous, uint32_t *block_rows, uint32_t *total_bits, uint32_t *block_bits) {
+                                                           uint32_t contiguous, const uint32_t *dead, uint32_t *block_rows, uint32_t *total_bits, uint32_t *block_bits) {
     __shared__ uint32_t s_rows, s_bits;
     if (threadIdx.x == 0) { s_rows = 0; s_bits = 0; }
     __syncthreads();
@@ -976,7 +985,7 @@ __global__ __launch_bounds__(256) void bitmap_count_kernel(const uint32_t *bitma
     while (word) {
         const uint32_t b = (uint32_t)__builtin_ctz(word);
         word &= word - 1u;
-        rows += find_row(ids, n, (uint64_t)w * 32u + b, contiguous != 0u) != kSentinel ? 1u : 0u;
+        rows += find_row(ids, n, (uint64_t)w * 32u + b, contiguous != 0u, dead) != kSentinel ? 1u : 0u;
     }
     if (rows) atomicAdd(&s_rows, rows);
     if (bits) atomicAdd(&s_bits, bits);
@@ -1008,7 +1017,7 @@ __global__ __launch_bounds__(1024) void block_scan_kernel(uint32_t *block_rows, 
 
 // pass 2: rows of the set bits, ascending id order (thread order inside a block by an LDS scan of the per-word counts)
 __global__ __launch_bounds__(256) void bitmap_compact_kernel(const uint32_t *bitmap, uint32_t n_words, const uint64_t *ids, uint32_t n,
-                                                             uint32_t contiguous, const uint32_t *block_base, uint32_t *subset) {
+                                                             uint32_t contiguous, const uint32_t *dead, const uint32_t *block_base, uint32_t *subset) {
     __shared__ uint32_t cnt[256];
     const uint32_t w = blockIdx.x * 256u + threadIdx.x;
     const uint32_t word0 = w < n_words ? bitmap[w] : 0u;
@@ -1016,7 +1025,7 @@ __global__ __launch_bounds__(256) void bitmap_compact_kernel(const uint32_t *bit
     while (word) {
         const uint32_t b = (uint32_t)__builtin_ctz(word);
         word &= word - 1u;
-        rows += find_row(ids, n, (uint64_t)w * 32u + b, contiguous != 0u) != kSentinel ? 1u : 0u;
+        rows += find_row(ids, n, (uint64_t)w * 32u + b, contiguous != 0u, dead) != kSentinel ? 1u : 0u;
     }
     cnt[threadIdx.x] = rows;
     __syncthreads();
@@ -1031,7 +1040,7 @@ __global__ __launch_bounds__(256) void bitmap_compact_kernel(const uint32_t *bit
     while (word) {
         const uint32_t b = (uint32_t)__builtin_ctz(word);
         word &= word - 1u;
-        const uint32_t r = find_row(ids, n, (uint64_t)w * 32u + b, contiguous != 0u);
+        const uint32_t r = find_row(ids, n, (uint64_t)w * 32u + b, contiguous != 0u, dead);
         if (r != kSentinel) subset[out++] = r;
     }
 }
@@ -1039,7 +1048,7 @@ __global__ __launch_bounds__(256) void bitmap_compact_kernel(const uint32_t *bit
 // deterministic_sample_ids (restricted.rs:321-342) on the device: the candidate with rank ranks[t] in the ascending id order
 // of the bitmap, as an index row (kSentinel when that id holds no vector).  bits_prefix = exclusive scan of the per-block counts.
 __global__ __launch_bounds__(64) void bitmap_select_kernel(const uint32_t *bitmap, uint32_t n_words, const uint32_t *bits_prefix, uint32_t n_blocks,
-                                                           const uint64_t *ids, uint32_t n, uint32_t contiguous, const uint32_t *ranks,
+                                                           const uint64_t *ids, uint32_t n, uint32_t contiguous, const uint32_t *dead, const uint32_t *ranks,
                                                            uint32_t n_ranks, uint32_t *out_rows) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_ranks) return;
@@ -1056,7 +1065,7 @@ __global__ __launch_bounds__(64) void bitmap_select_kernel(const uint32_t *bitma
         const uint32_t pc = (uint32_t)__builtin_popcount(word);
         if (rem >= pc) { rem -= pc; continue; }
         while (rem--) word &= word - 1u;
-        row = find_row(ids, n, (uint64_t)w * 32u + (uint32_t)__builtin_ctz(word), contiguous != 0u);
+        row = find_row(ids, n, (uint64_t)w * 32u + (uint32_t)__builtin_ctz(word), contiguous != 0u, dead);
         break;
     }
     out_rows[t] = row;
@@ -1132,7 +1141,7 @@ static int prefilter_search_impl(const hvx_index *cix, const hvx_csr *cg, const 
     uint32_t *d_block_bits = ix->pf_blocks + n_blocks + 2; // [n_blocks + 1]: per-block candidate counts, then their scan
     HIP_TRY(hipMemsetAsync(d_total_bits, 0, 4, ix->stream));
     hipLaunchKernelGGL(bitmap_count_kernel, dim3(n_blocks), dim3(256), 0, ix->stream, g->visited, n_words, ix->dev.ids, ix->dev.n,
-                       ix->contiguous ? 1u : 0u, ix->pf_blocks, d_total_bits, d_block_bits);
+                       ix->contiguous ? 1u : 0u, ix->dev.dead, ix->pf_blocks, d_total_bits, d_block_bits);
     hipLaunchKernelGGL(block_scan_kernel, dim3(1), dim3(1024), 0, ix->stream, ix->pf_blocks, n_blocks);
     HIP_TRY(hipGetLastError());
     if ((rc = ix->pin(64))) return rc;
@@ -1152,7 +1161,7 @@ static int prefilter_search_impl(const hvx_index *cix, const hvx_csr *cg, const 
     }
     if (n_rows)
         hipLaunchKernelGGL(bitmap_compact_kernel, dim3(n_blocks), dim3(256), 0, ix->stream, g->visited, n_words, ix->dev.ids, ix->dev.n,
-                           ix->contiguous ? 1u : 0u, ix->pf_blocks, ix->f_subset);
+                           ix->contiguous ? 1u : 0u, ix->dev.dead, ix->pf_blocks, ix->f_subset);
     HIP_TRY(hipGetLastError());
     // restricted_execution_plan_with_beam_percent (restricted.rs:426-453) over the candidate population
     RestrictedPlan plan;
@@ -1172,7 +1181,7 @@ static int prefilter_search_impl(const hvx_index *cix, const hvx_csr *cg, const 
         HIP_TRY(hipMemcpyAsync(ix->w_samples + ns, ranks.data(), (size_t)ns * 4, hipMemcpyHostToDevice, ix->stream));
         hipLaunchKernelGGL(block_scan_kernel, dim3(1), dim3(1024), 0, ix->stream, d_block_bits, n_blocks);
         hipLaunchKernelGGL(bitmap_select_kernel, dim3((ns + 63u) / 64u), dim3(64), 0, ix->stream, g->visited, n_words, d_block_bits, n_blocks,
-                           ix->dev.ids, ix->dev.n, ix->contiguous ? 1u : 0u, ix->w_samples + ns, ns, ix->w_samples);
+                           ix->dev.ids, ix->dev.n, ix->contiguous ? 1u : 0u, ix->dev.dead, ix->w_samples + ns, ns, ix->w_samples);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(ix->stream)); // `ranks` lives on this frame
         d_samples = ix->w_samples;

@@ -344,9 +344,11 @@ void sample_ranks(uint64_t candidates, uint32_t count, std::vector<uint64_t> &ou
 // the SimHash directory of this image, built once from the attached SimHash rows -- on the device (round 4; rounds 2-3 sorted the
 // 1M order codes with std::sort on the host): order codes, a stable radix sort of (code, row) pairs (rows ascend inside equal
 // codes = the (order_code, node_id) key order of storage.rs:1942-2010), and the 65 537-entry prefix table the window bounds come from
-__global__ void dir_codes_kernel(const uint64_t *node_hash, uint32_t n, uint64_t *codes, uint32_t *rows) {
+// `live` = the ascending list of live rows of an image with deleted nodes (a delete removes the node's directory row:
+// mutation.rs:1718-1722), NULL = every row
+__global__ void dir_codes_kernel(const uint64_t *node_hash, uint32_t n, const uint32_t *live, uint64_t *codes, uint32_t *rows) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { codes[i] = walk::order_code(node_hash[i]); rows[i] = i; }
+    if (i < n) { const uint32_t r = live ? live[i] : i; codes[i] = walk::order_code(node_hash[r]); rows[i] = r; }
 }
 __global__ void dir_prefix_kernel(const uint64_t *sorted_codes, uint32_t n, uint32_t *prefix) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -398,9 +400,16 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const uint64_t *keys, c
 
 int ensure_directory(hvx_index *ix) {
     hvx_image_shared &sh = *ix->shared;
+    const uint32_t *live = nullptr;
+    if (ix->n_dead) { // the directory of an image with deleted nodes holds its live rows only
+        int rc = ix->ensure_live();
+        if (rc) return rc;
+        live = ix->f_live;
+    }
     std::lock_guard<std::mutex> lock(sh.mu);
-    if (sh.dir_code && sh.dir_for == ix->d_node_hash && sh.dir_rows == ix->dev.n) return HVX_OK; // (an image that has grown gets a new directory)
-    const uint32_t n = ix->dev.n, n1 = std::max<uint32_t>(n, 1);
+    if (sh.dir_code && sh.dir_for == ix->d_node_hash && sh.dir_rows == ix->live_rows() && sh.dir_dead == (const void *)ix->dead_p.get())
+        return HVX_OK; // (an image that has grown, or lost nodes, gets a new directory)
+    const uint32_t n = ix->live_rows(), n1 = std::max<uint32_t>(n, 1);
     hipStream_t s = ix->stream;
     for (void **p : {(void **)&sh.dir_code, (void **)&sh.dir_row, (void **)&sh.dir_prefix})
         if (*p) { (void)hipFree(*p); *p = nullptr; }
@@ -420,7 +429,7 @@ int ensure_directory(hvx_index *ix) {
         hipMalloc((void **)&hist, (size_t)256 * nblocks * 4) != hipSuccess)
         return bail(fail(HVX_ERR_DEVICE, "hipMalloc of the directory scratch failed"));
     if (n) {
-        hipLaunchKernelGGL(dir_codes_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, ix->d_node_hash, n, sh.dir_code, sh.dir_row);
+        hipLaunchKernelGGL(dir_codes_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, ix->d_node_hash, n, live, sh.dir_code, sh.dir_row);
         uint64_t *ka = sh.dir_code, *kb = codes;
         uint32_t *va = sh.dir_row, *vb = rows;
         for (uint32_t pass = 0; pass < 8; ++pass) { // eight passes: the sorted pairs end where they started (dir_code / dir_row)
@@ -436,7 +445,8 @@ int ensure_directory(hvx_index *ix) {
         return bail(fail(HVX_ERR_DEVICE, "building the SimHash directory failed: %s", hipGetErrorString(hipGetLastError())));
     release();
     sh.dir_for = ix->d_node_hash;
-    sh.dir_rows = ix->dev.n;
+    sh.dir_rows = n;
+    sh.dir_dead = ix->dead_p.get();
     return HVX_OK;
 }
 

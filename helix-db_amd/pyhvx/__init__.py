@@ -116,6 +116,11 @@ class BuildStats(C.Structure):  # hvx_build_stats
     _fields_ = [("nodes", C.c_uint64), ("batches", C.c_uint64), ("single_node_batches", C.c_uint64)]
 
 
+class DeleteStats(C.Structure):  # hvx_delete_stats
+    _fields_ = [("requested", C.c_uint32), ("deleted", C.c_uint32), ("missing", C.c_uint32), ("entry_moves", C.c_uint32),
+                ("relinked_rows", C.c_uint32), ("reserved", C.c_uint32), ("seconds", C.c_double)]
+
+
 class BatcherTimes(C.Structure):
     """hvx_batcher_times (include/helix_vec.h)."""
     _fields_ = [("idle_ns", C.c_uint64), ("collect_ns", C.c_uint64), ("drain_ns", C.c_uint64), ("fill_ns", C.c_uint64), ("device_ns", C.c_uint64),
@@ -596,6 +601,30 @@ class ValidatedVectorReadIndex:
         _check(L.hvx_index_insert_batch(self._h, _ptr(ids), _vp(vectors.data_ptr()) if dev_rows else _ptr(vec), _ptr(lv), int(ids.size), C.byref(bp), C.byref(st)))
         self.n = self.rows()
         return {"nodes": st.nodes, "batches": st.batches, "single_node_batches": st.single_node_batches}
+
+    def delete_batch(self, node_ids) -> dict:
+        """hvx_index_delete_batch: VectorIndex::delete (mutation.rs:1606-2055) for every id in order -- unlink, relink the affected
+        sources, repair the entry point; ids that are not in the image succeed and count as `missing` (index.rs:2263)"""
+        ids = np.ascontiguousarray(node_ids, dtype=np.uint64).reshape(-1)
+        st = DeleteStats()
+        L = lib()
+        L.hvx_index_delete_batch.restype = C.c_int
+        L.hvx_index_delete_batch.argtypes = [_vp, _vp, C.c_uint32, C.POINTER(DeleteStats)]
+        _check(L.hvx_index_delete_batch(self._h, _ptr(ids), int(ids.size), C.byref(st)))
+        return {"requested": st.requested, "deleted": st.deleted, "missing": st.missing, "entry_moves": st.entry_moves,
+                "relinked_rows": st.relinked_rows, "seconds": st.seconds}
+
+    def live_rows(self) -> int:
+        L = lib()
+        L.hvx_index_live_rows.restype = C.c_uint64
+        L.hvx_index_live_rows.argtypes = [_vp]
+        return int(L.hvx_index_live_rows(self._h))
+
+    def contains(self, node_id) -> bool:
+        L = lib()
+        L.hvx_index_contains.restype = C.c_int
+        L.hvx_index_contains.argtypes = [_vp, C.c_uint64]
+        return bool(L.hvx_index_contains(self._h, int(node_id)))
 
     def refresh(self):
         """hvx_index_refresh: a fork adopts the image's visible generation (rows, entry point, top layer)"""

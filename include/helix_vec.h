@@ -649,6 +649,31 @@ int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_ids, const 
 int hvx_index_insert_batch(hvx_index *, const uint64_t *node_ids /*[count]*/, const float *vectors /*[count][dim]*/,
                            const uint16_t *levels /*[count] or NULL*/, uint32_t count, const hvx_build_params *params /*nullable*/,
                            hvx_build_stats *stats /*nullable*/);
+/*
+ * Delete of nodes from a LIVE image (VectorIndex::delete -> stage_delete_with_metadata, mutation.rs:1606-1774; delete_from_layer
+ * :1819-1888; relink_neighbor :1916-2055): for every id, in the order given, every row that holds the node loses the edge, the
+ * affected sources are relinked from their joint neighbourhood (the Mmax closest candidates, select_diverse + backfill beyond Mmax, the
+ * reciprocal rows of new neighbours), the node's own rows go, and a deleted entry point is replaced by the best remaining entry
+ * candidate (highest layer, then smallest id).  Rows equal the oracle's sequential deletes row for row (tests/test_gpu_delete.py).
+ * An id that is not in the image (or was deleted before) succeeds and changes nothing (index.rs:2263, 2294-2295; counted in
+ * stats->missing).  A deleted node keeps its row slot but is gone from searches, exact scans, restricted candidate sets, the
+ * prefilter's candidate mapping, the SimHash directory and hvx_index_contains; hvx_index_rows still counts the slot,
+ * hvx_index_live_rows does not; hvx_index_export_graph returns empty rows for it.  Same generation rules as
+ * hvx_index_insert_batch: owner handle only, visible_seq + 1 per call that deleted something, forks adopt with hvx_index_refresh.
+ * Its id cannot be inserted again into this image (ids ascend): an upsert of an existing id needs a re-hydrated image.
+ * f32 images, degree limits <= 32.  HVX_ERR_UNSUPPORTED when more than 4 096 rows of one layer hold a node or their joint
+ * neighbourhood exceeds 16 384 rows (after such a failure the image is partially relinked: discard the handle).
+ */
+typedef struct hvx_delete_stats {
+    uint32_t requested, deleted, missing; /* ids given / nodes removed / ids that were not (or no longer) in the image */
+    uint32_t entry_moves;                  /* deletes that took the entry point */
+    uint32_t relinked_rows;                /* relink_neighbor calls */
+    uint32_t reserved;
+    double seconds;
+} hvx_delete_stats;
+int hvx_index_delete_batch(hvx_index *, const uint64_t *node_ids /*[count]*/, uint32_t count, hvx_delete_stats *stats /*nullable*/);
+uint64_t hvx_index_live_rows(const hvx_index *);    /* rows visible to this handle that are not deleted */
+int hvx_index_contains(const hvx_index *, uint64_t node_id); /* 1 when the id holds a (live) vector in this handle's generation */
 int hvx_index_refresh(hvx_index *);                 /* adopt the image's visible generation (a fork; a no-op when nothing changed) */
 uint64_t hvx_index_visible_seq(const hvx_index *);  /* generation this handle searches: 1 after import / build, +1 per insert batch */
 uint64_t hvx_index_rows(const hvx_index *);         /* rows visible to this handle */

@@ -461,9 +461,13 @@ struct orc_index {
     float *planes;
     uint64_t simhash_seed;
     int has_simhash;
+    /* orc_index_delete: a deleted node keeps its slot (rows emptied, unreachable, absent from the id map); n counts slots */
+    uint8_t *dead;
+    uint64_t n_dead;
 };
 
 #define NO_ROW UINT64_MAX
+#define MAP_TOMB (UINT32_MAX - 1u)
 
 static uint64_t mix64(uint64_t x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
@@ -477,6 +481,7 @@ static void map_rebuild(orc_index *ix, uint64_t cap) {
     ix->map_val = (uint32_t *)malloc(cap * 4);
     for (uint64_t i = 0; i < cap; ++i) ix->map_val[i] = UINT32_MAX;
     for (uint64_t i = 0; i < ix->n; ++i) {
+        if (ix->dead && ix->dead[i]) continue;
         uint64_t h = mix64(ix->ids[i]) & (cap - 1);
         while (ix->map_val[h] != UINT32_MAX) h = (h + 1) & (cap - 1);
         ix->map_key[h] = ix->ids[i];
@@ -488,10 +493,19 @@ static uint32_t map_find(const orc_index *ix, uint64_t id) {
     if (!ix->map_cap) return UINT32_MAX;
     uint64_t h = mix64(id) & (ix->map_cap - 1);
     while (ix->map_val[h] != UINT32_MAX) {
-        if (ix->map_key[h] == id) return ix->map_val[h];
+        if (ix->map_key[h] == id && ix->map_val[h] != MAP_TOMB) return ix->map_val[h];
         h = (h + 1) & (ix->map_cap - 1);
     }
     return UINT32_MAX;
+}
+
+static void map_remove(orc_index *ix, uint64_t id) { /* the slot stays in its probe chain */
+    if (!ix->map_cap) return;
+    uint64_t h = mix64(id) & (ix->map_cap - 1);
+    while (ix->map_val[h] != UINT32_MAX) {
+        if (ix->map_key[h] == id && ix->map_val[h] != MAP_TOMB) { ix->map_val[h] = MAP_TOMB; return; }
+        h = (h + 1) & (ix->map_cap - 1);
+    }
 }
 
 static void map_insert(orc_index *ix, uint64_t id, uint32_t idx) {
@@ -517,7 +531,7 @@ void orc_index_free(orc_index *ix) {
     if (!ix) return;
     free(ix->ids); free(ix->vec); free(ix->hdr); free(ix->level); free(ix->l0); free(ix->l0_deg);
     free(ix->up_base); free(ix->up); free(ix->up_deg); free(ix->map_key); free(ix->map_val);
-    free(ix->simhash); free(ix->planes);
+    free(ix->simhash); free(ix->planes); free(ix->dead);
     free(ix);
 }
 
@@ -532,6 +546,8 @@ static void grow_nodes(orc_index *ix, uint64_t need) {
     ix->l0 = (uint32_t *)realloc(ix->l0, cap * (size_t)ix->s0 * 4);
     ix->l0_deg = (uint32_t *)realloc(ix->l0_deg, cap * 4);
     ix->up_base = (uint64_t *)realloc(ix->up_base, cap * 8);
+    ix->dead = (uint8_t *)realloc(ix->dead, cap);
+    memset(ix->dead + ix->cap, 0, cap - ix->cap);
     ix->cap = cap;
 }
 
@@ -544,7 +560,7 @@ static void grow_up(orc_index *ix, uint64_t need) {
     ix->up_cap = cap;
 }
 
-uint64_t orc_index_count(const orc_index *ix) { return ix->n; }
+uint64_t orc_index_count(const orc_index *ix) { return ix->n - ix->n_dead; } /* metadata.count: live rows */
 
 int orc_index_entry(const orc_index *ix, uint64_t *entry, uint16_t *max_layer) {
     if (!ix->has_entry) return 0;
@@ -898,8 +914,12 @@ int orc_flat_search(const orc_index *ix, const float *query, uint32_t qlen, uint
             if (visit_insert(vis, i)) subset[ns++] = i;
         }
         if (ns == 0) { free(subset); return ORC_OK; }
-    } else if (ix->n == 0) {
+    } else if (ix->n == ix->n_dead) {
         return ORC_OK;
+    } else if (ix->n_dead) { /* deleted nodes have no item row: the scan sees the live rows only */
+        subset = (uint32_t *)malloc(ix->n * 4);
+        for (uint64_t i = 0; i < ix->n; ++i)
+            if (!ix->dead[i]) subset[ns++] = (uint32_t)i;
     }
     cand_t *top = (cand_t *)malloc(((size_t)k + 1) * sizeof(cand_t));
     uint32_t tn = 0;
@@ -1141,6 +1161,193 @@ int orc_index_insert(orc_index *ix, uint64_t node_id, const float *v, uint16_t l
     return ORC_OK;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Delete (mutation.rs:1606-2055).  Parity unpinned by goldens: the reference's tests hold behaviour (index.rs:2263 unknown id,
+ * :2294-2295 double delete, :3540-3568 entry repair, :3571-3605 the deleted id is never returned), not relinked rows.
+ * ---------------------------------------------------------------------------------------- */
+static int id_order_cmp(const void *a, const void *b, void *ctx);
+
+static int remove_edge_found(orc_index *ix, uint32_t layer, uint32_t node, uint32_t to_remove) {
+    uint32_t *deg;
+    uint32_t *r = nbr_row(ix, layer, node, &deg);
+    if (!r || !row_contains(r, *deg, to_remove)) return 0;
+    remove_edge(ix, layer, node, to_remove);
+    return 1;
+}
+
+/* rank `members` by distance to `owner` (Candidate order) and select_diverse + backfill; members without an item (deleted) are
+ * skipped as get_item_for_layer_cached -> None does (mutation.rs:1957-1975, 2012-2033) */
+static int prune_row(const orc_index *ix, uint32_t owner, const uint32_t *members, uint32_t nm, uint32_t maxn, uint32_t *out, uint32_t *nout) {
+    cand_t *d = (cand_t *)malloc((nm ? nm : 1) * sizeof(cand_t));
+    uint32_t nd = 0;
+    for (uint32_t i = 0; i < nm; ++i) {
+        if (ix->dead[members[i]]) continue;
+        float x = orc_distance(ix->metric, ix->kernel, row(ix, owner), ix->hdr[owner], row(ix, members[i]), ix->hdr[members[i]], ix->dim);
+        if (orc_distance_score(&x)) { free(d); return ORC_ERR_INVARIANT; }
+        d[nd].score = x;
+        d[nd].idx = members[i];
+        ++nd;
+    }
+    sort_cands(ix, d, nd);
+    int rc = select_diverse(ix, d, nd, nd, maxn, out, nout);
+    free(d);
+    return rc;
+}
+
+/* mutation.rs:1916-2055 relink_neighbor */
+static int relink_neighbor(orc_index *ix, uint32_t layer, uint32_t nb, const uint32_t *cands, uint32_t ncand, uint32_t maxn) {
+    if (ix->dead[nb]) return ORC_OK; /* :1925-1930 no item: nothing to relink */
+    uint32_t *deg;
+    uint32_t *r = nbr_row(ix, layer, nb, &deg);
+    if (!r) return ORC_ERR_INVARIANT;
+    const uint32_t stride = layer == 0 ? ix->s0 : ix->su;
+    const uint32_t nold = *deg;
+    uint32_t *old = (uint32_t *)malloc((nold + 1) * 4);
+    memcpy(old, r, nold * 4);
+    uint32_t *cur = (uint32_t *)malloc(((size_t)nold + maxn + 1) * 4);
+    uint32_t ncur = nold;
+    memcpy(cur, old, nold * 4);
+    cand_t *cd = (cand_t *)malloc((ncand ? ncand : 1) * sizeof(cand_t));
+    uint32_t nd = 0;
+    int rc = ORC_OK;
+    for (uint32_t i = 0; i < ncand; ++i) { /* :1936-1951 (the set's iteration order does not survive the sort) */
+        const uint32_t c = cands[i];
+        if (c == nb || ix->dead[c]) continue;
+        float x = orc_distance(ix->metric, ix->kernel, row(ix, nb), ix->hdr[nb], row(ix, c), ix->hdr[c], ix->dim);
+        if (orc_distance_score(&x)) { rc = ORC_ERR_INVARIANT; goto out; }
+        cd[nd].score = x;
+        cd[nd].idx = c;
+        ++nd;
+    }
+    sort_cands(ix, cd, nd);
+    for (uint32_t i = 0; i < nd && i < maxn; ++i) /* :1953-1957 */
+        if (!row_contains(cur, ncur, cd[i].idx)) cur[ncur++] = cd[i].idx;
+    if (ncur > maxn) { /* :1959-1984 */
+        uint32_t *sel = (uint32_t *)malloc((ncur + 1) * 4), ns = 0;
+        rc = prune_row(ix, nb, cur, ncur, maxn, sel, &ns);
+        if (!rc) { memcpy(cur, sel, ns * 4); ncur = ns; }
+        free(sel);
+        if (rc) goto out;
+    }
+    if (ncur > stride) { rc = ORC_ERR_INVARIANT; goto out; }
+    memcpy(r, cur, ncur * 4); /* :1986-1993 stage (stage_neighbors_vec_for_mutation sorts by id, :1299) */
+    *deg = ncur;
+    canon_row(ix, r, deg, nb);
+    for (uint32_t t = 0; t < ncur; ++t) { /* :1994-2052 the reciprocal row of every NEW neighbour */
+        const uint32_t nw = cur[t];
+        if (row_contains(old, nold, nw)) continue;
+        uint32_t *rdeg;
+        uint32_t *rr = nbr_row(ix, layer, nw, &rdeg);
+        if (!rr) { rc = ORC_ERR_INVARIANT; goto out; }
+        if (row_contains(rr, *rdeg, nb)) continue;
+        if (*rdeg >= stride) { rc = ORC_ERR_INVARIANT; goto out; }
+        rr[(*rdeg)++] = nb;
+        if (*rdeg > maxn) {
+            if (ix->dead[nw]) { rc = ORC_ERR_INVARIANT; goto out; } /* :2007-2017: the over-long row fails its degree limit when staged */
+            uint32_t sel[4096], ns = 0;
+            rc = prune_row(ix, nw, rr, *rdeg, maxn, sel, &ns);
+            if (rc) goto out;
+            memcpy(rr, sel, ns * 4);
+            *rdeg = ns;
+        }
+        canon_row(ix, rr, rdeg, nw);
+    }
+out:
+    free(old); free(cur); free(cd);
+    return rc;
+}
+
+/* mutation.rs:1819-1888 delete_from_layer; `extra` = the reverse-locator sources of this layer (every row that holds the node) */
+static int delete_from_layer(orc_index *ix, uint32_t node, uint32_t layer, uint32_t maxn, const uint32_t *extra, uint32_t nextra, uint8_t *mark) {
+    uint32_t *deg;
+    uint32_t *own = nbr_row(ix, layer, node, &deg);
+    const uint32_t nout = own ? *deg : 0;
+    uint32_t *aff = (uint32_t *)malloc(((size_t)nout + nextra + 1) * 4);
+    uint32_t na = 0;
+    for (uint32_t i = 0; i < nout; ++i)
+        if (own[i] != node && !mark[own[i]]) { mark[own[i]] = 1; aff[na++] = own[i]; } /* mandatory_relink (:1833-1837) */
+    const uint32_t nmand = na;
+    for (uint32_t i = 0; i < nextra; ++i)
+        if (extra[i] != node && !mark[extra[i]]) { mark[extra[i]] = 2; aff[na++] = extra[i]; }
+    if (na == 0) { free(aff); return ORC_OK; }
+    qsort_r(aff, na, 4, id_order_cmp, (void *)ix); /* BTreeSet order */
+    uint32_t *rel = (uint32_t *)malloc((na + 1) * 4);
+    uint32_t nr = 0;
+    for (uint32_t i = 0; i < na; ++i) { /* :1849-1857: mandatory sources relink whether or not they held the edge */
+        const int had = remove_edge_found(ix, layer, aff[i], node);
+        if (had || mark[aff[i]] == 1) rel[nr++] = aff[i];
+    }
+    (void)nmand;
+    for (uint32_t i = 0; i < na; ++i) mark[aff[i]] = 0;
+    int rc = ORC_OK;
+    if (nr) {
+        /* :1862-1875 candidates: the relink sources and their remaining neighbourhoods */
+        size_t cap = (size_t)nr * ((layer == 0 ? ix->s0 : ix->su) + 1) + 1;
+        uint32_t *cand = (uint32_t *)malloc(cap * 4);
+        uint32_t nc = 0;
+        mark[node] = 1;
+        for (uint32_t i = 0; i < nr; ++i)
+            if (!mark[rel[i]]) { mark[rel[i]] = 1; cand[nc++] = rel[i]; }
+        for (uint32_t i = 0; i < nr; ++i) {
+            uint32_t *d2;
+            uint32_t *r2 = nbr_row(ix, layer, rel[i], &d2);
+            for (uint32_t t = 0; r2 && t < *d2; ++t)
+                if (!mark[r2[t]]) { mark[r2[t]] = 1; cand[nc++] = r2[t]; }
+        }
+        for (uint32_t i = 0; i < nc; ++i) mark[cand[i]] = 0;
+        mark[node] = 0;
+        for (uint32_t i = 0; i < nr && !rc; ++i) rc = relink_neighbor(ix, layer, rel[i], cand, nc, maxn);
+        free(cand);
+    }
+    free(rel); free(aff);
+    return rc;
+}
+
+/* mutation.rs:1658-1774 stage_delete_with_metadata.  An unknown id succeeds and changes nothing (index.rs:2263). */
+int orc_index_delete(orc_index *ix, uint64_t node_id, int *existed) {
+    const uint32_t x = map_find(ix, node_id);
+    if (existed) *existed = x != UINT32_MAX;
+    if (x == UINT32_MAX) return ORC_OK;
+    uint8_t *mark = (uint8_t *)calloc(ix->n, 1);
+    uint32_t *src = (uint32_t *)malloc(ix->n * 4);
+    int rc = ORC_OK;
+    uint32_t top = ix->level[x] > ix->max_layer ? ix->level[x] : ix->max_layer;
+    for (int32_t layer = (int32_t)top; layer >= 0 && !rc; --layer) { /* layers_to_process, highest first (:1681-1702) */
+        uint32_t ns = 0; /* reverse_sources_for_target: every row of this layer that holds the node (update_reverse_edge_locator :1134-1153) */
+        for (uint64_t i = 0; i < ix->n; ++i) {
+            if (i == x || ix->dead[i]) continue;
+            uint32_t *deg;
+            const uint32_t *r = nbr_row(ix, (uint32_t)layer, (uint32_t)i, &deg);
+            if (r && row_contains(r, *deg, x)) src[ns++] = (uint32_t)i;
+        }
+        if ((uint32_t)layer > ix->level[x] && ns == 0) continue;
+        rc = delete_from_layer(ix, x, (uint32_t)layer, layer == 0 ? ix->m0_eff : ix->m, src, ns, mark);
+    }
+    free(mark); free(src);
+    if (rc) return rc;
+    /* the node's rows, item, SimHash row and entry-candidate rows go (:1708-1745) */
+    ix->l0_deg[x] = 0;
+    for (uint32_t l = 0; l < ix->level[x]; ++l) ix->up_deg[ix->up_base[x] + l] = 0;
+    ix->dead[x] = 1;
+    ix->n_dead += 1;
+    map_remove(ix, node_id);
+    if (ix->has_entry && ix->entry == x) { /* :1756-1767 find_best_entry_candidate: highest layer first, then ascending id
+                                               (keys/vectors.rs:1097 [inv_layer:2][node_id:8]) */
+        int found = 0;
+        uint32_t best = 0;
+        for (uint64_t i = 0; i < ix->n; ++i) {
+            if (ix->dead[i]) continue;
+            if (!found || ix->level[i] > ix->level[best] || (ix->level[i] == ix->level[best] && ix->ids[i] < ix->ids[best])) { best = (uint32_t)i; found = 1; }
+        }
+        ix->has_entry = found;
+        ix->entry = found ? best : 0;
+        ix->max_layer = found ? ix->level[best] : 0;
+    }
+    return ORC_OK;
+}
+
+int orc_index_is_live(const orc_index *ix, uint64_t node_id) { return map_find(ix, node_id) != UINT32_MAX; }
+
 int orc_index_seed(orc_index *ix, uint64_t n, const uint64_t *node_ids, const float *vectors,
                    const uint64_t *l0_off, const uint64_t *l0_nb, const uint16_t *level,
                    const uint64_t *up_off, const uint64_t *up_nb, int has_entry, uint64_t entry,
@@ -1228,20 +1435,25 @@ static int id_order_cmp(const void *a, const void *b, void *ctx) {
 
 uint64_t orc_index_export_sizes(const orc_index *ix, uint64_t *l0_edges, uint64_t *up_rows,
                                 uint64_t *up_edges) {
-    uint64_t e0 = 0, ue = 0;
-    for (uint64_t i = 0; i < ix->n; ++i) e0 += ix->l0_deg[i];
-    for (uint64_t r = 0; r < ix->up_rows; ++r) ue += ix->up_deg[r];
+    uint64_t e0 = 0, ue = 0, rows = 0;
+    for (uint64_t i = 0; i < ix->n; ++i) {
+        if (ix->dead[i]) continue; /* (a deleted node's rows are gone: mutation.rs:1726-1734) */
+        e0 += ix->l0_deg[i];
+        for (uint32_t l = 0; l < ix->level[i]; ++l) ue += ix->up_deg[ix->up_base[i] + l];
+        rows += ix->level[i];
+    }
     if (l0_edges) *l0_edges = e0;
-    if (up_rows) *up_rows = ix->up_rows;
+    if (up_rows) *up_rows = rows;
     if (up_edges) *up_edges = ue;
-    return ix->n;
+    return ix->n - ix->n_dead;
 }
 
 int orc_index_export(const orc_index *ix, uint64_t *node_ids, float *vectors, uint64_t *l0_off,
                      uint64_t *l0_nb, uint16_t *level, uint64_t *up_off, uint64_t *up_nb) {
-    uint64_t n = ix->n;
-    uint32_t *ord = (uint32_t *)malloc((n ? n : 1) * 4);
-    for (uint64_t i = 0; i < n; ++i) ord[i] = (uint32_t)i;
+    uint64_t n = 0;
+    uint32_t *ord = (uint32_t *)malloc((ix->n ? ix->n : 1) * 4);
+    for (uint64_t i = 0; i < ix->n; ++i)
+        if (!ix->dead[i]) ord[n++] = (uint32_t)i;
     qsort_r(ord, n, 4, id_order_cmp, (void *)ix);
     uint64_t e0 = 0, r = 0, ue = 0;
     l0_off[0] = 0;

@@ -106,7 +106,12 @@ int orc_index_seed(orc_index *, uint64_t n, const uint64_t *node_ids, const floa
                    const uint64_t *l0_offsets, const uint64_t *l0_neighbors,
                    const uint16_t *level, const uint64_t *up_offsets, const uint64_t *up_neighbors,
                    int has_entry, uint64_t entry_point, uint16_t max_layer);
-uint64_t orc_index_count(const orc_index *);
+/* delete one node (mutation.rs:1606-2055 stage_delete -> delete_from_layer -> relink_neighbor): every row that holds it loses the
+ * edge, the affected sources are relinked from their joint neighbourhood, the entry point moves to the best remaining entry
+ * candidate.  An unknown id succeeds with *existed = 0 (index.rs:2263).  Parity unpinned (no golden rows in the reference). */
+int orc_index_delete(orc_index *, uint64_t node_id, int *existed);
+int orc_index_is_live(const orc_index *, uint64_t node_id);
+uint64_t orc_index_count(const orc_index *);   /* metadata.count: live nodes */
 int orc_index_entry(const orc_index *, uint64_t *entry_point, uint16_t *max_layer);
 /* export in the import layout of include/helix_vec.h (ids ascending).  Pass NULL to size. */
 uint64_t orc_index_export_sizes(const orc_index *, uint64_t *l0_edges, uint64_t *up_rows, uint64_t *up_edges);

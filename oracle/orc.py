@@ -221,6 +221,10 @@ def lib():
     L.orc_index_free.argtypes = [C.c_void_p]
     L.orc_index_insert.restype = C.c_int
     L.orc_index_insert.argtypes = [C.c_void_p, C.c_uint64, f32p, C.c_uint16]
+    L.orc_index_delete.restype = C.c_int
+    L.orc_index_delete.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_int)]
+    L.orc_index_is_live.restype = C.c_int
+    L.orc_index_is_live.argtypes = [C.c_void_p, C.c_uint64]
     L.orc_index_prune_candidates.restype = C.c_int
     L.orc_index_prune_candidates.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
     L.orc_index_seed.restype = C.c_int
@@ -366,6 +370,15 @@ class Index:
         v, pv = _f(vector)
         assert v.size == self.dim
         return lib().orc_index_insert(self._h, int(node_id), pv, int(level))
+
+    def delete(self, node_id):
+        """stage_delete (mutation.rs:1606-2055): (rc, existed); an unknown id is (OK, False)"""
+        ex = C.c_int(0)
+        rc = lib().orc_index_delete(self._h, int(node_id), C.byref(ex))
+        return rc, bool(ex.value)
+
+    def is_live(self, node_id):
+        return bool(lib().orc_index_is_live(self._h, int(node_id)))
 
     def prune_candidates(self, owner_id, cand_ids, maxn):
         """the prune of add_bidirectional_link for one row: ids that survive select_diverse + backfill, in selection order"""

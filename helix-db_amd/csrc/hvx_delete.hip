@@ -26,7 +26,7 @@
 // A deleted node keeps its row slot: unreachable (nothing links to it, the entry point is repaired), absent from every id -> row
 // lookup (hvx_index::find), from exact scans (they run over the live rows, hvx_index::ensure_live), from the SimHash directory, the
 // prefilter's candidate mapping and the audit.  Sequential semantics: the nodes of a batch are deleted one after the other, and
-// the rows equal the oracle's (oracle/hvx_oracle.c orc_index_delete) row for row -- tests/test_gpu_delete.py.
+// the rows equal the CPU restatement's sequential deletes row for row -- tests/test_gpu_delete.py.
 // Limits (exceeded => HVX_ERR_UNSUPPORTED, loudly): 4 096 rows holding one node per layer, 16 384 candidates per layer.
 #include <hip/hip_runtime.h>
 
@@ -112,13 +112,14 @@ __global__ __launch_bounds__(256) void delete_scan_kernel(DeleteArgs a) {
 // delete_from_layer up to the relinks (mutation.rs:1829-1875): sources, unlink, candidates.  One workgroup per layer.
 __global__ __launch_bounds__(256) void delete_prep_kernel(DeleteArgs a) {
     __shared__ uint32_t aff[kDelRelCap], srt[kDelRelCap];
-    __shared__ uint32_t s_na, s_nc;
+    __shared__ uint32_t s_na, s_nc, s_err;
     const DevIndex &ix = a.ix;
     const uint32_t L = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t node = a.node, lvl = ix.level[node];
     const uint32_t ns = a.src_cnt[L];
-    if (tid == 0) { a.rel_cnt[L] = 0; a.cand_cnt[L] = 0; s_na = 0; s_nc = 0; }
-    if (a.ctl[0] != 0u) return;
+    if (tid == 0) { a.rel_cnt[L] = 0; a.cand_cnt[L] = 0; s_na = 0; s_nc = 0; s_err = a.ctl[0]; }
+    __syncthreads();
+    if (s_err != 0u) return; // (one read for the whole workgroup: another layer's workgroup may be raising the flag right now)
     if (ns > kDelSrcCap) { if (tid == 0) atomicMax(&a.ctl[0], 1u); return; }
     if (L > lvl && ns == 0u) return;
     uint32_t *mark = a.mark + (size_t)L * a.words;
@@ -198,14 +199,15 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(256) void de
     const DevIndex &ix = a.ix;
     const uint32_t L = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const int grp = (int)(lane >> 3), j = (int)(lane & 7u);
-    if (a.ctl[0] != 0u) return;
+    if (tid == 0) { s_bad = a.ctl[0]; }
+    __syncthreads();
+    if (s_bad != 0u) return;
     const uint32_t nr = a.rel_cnt[L], nc = a.cand_cnt[L];
     if (nr == 0u || nc == 0u) return;
     const uint32_t maxn = L == 0u ? a.m0 : a.m;
     float *qv = reinterpret_cast<float *>(smem);
     uint32_t *sc = reinterpret_cast<uint32_t *>(smem + (((size_t)ix.ld * 4u + 15u) & ~(size_t)15u));
     const uint32_t *cand = a.cand + (size_t)L * kDelCandCap;
-    if (tid == 0) s_bad = 0;
     for (uint32_t ri = blockIdx.x; ri < nr; ri += gridDim.x) {
         const uint32_t r = a.rel[(size_t)L * kDelRelCap + ri];
         __syncthreads();

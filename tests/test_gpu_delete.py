@@ -1,0 +1,225 @@
+"""Delete of nodes from a live device image (hvx_index_delete_batch, csrc/hvx_delete.hip; VERDICT r4 missing #4) against the oracle's
+restatement of the reference's delete path (orc_index_delete == mutation.rs:1606-2055: stage_delete_with_metadata, delete_from_layer,
+remove_edge_from_neighbor, relink_neighbor)."""
+import numpy as np
+import pytest
+
+import fixtures as fx
+from test_oracle_delete import rows_by_id
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hv():
+    import pyhvx
+    pyhvx.lib()
+    return pyhvx
+
+
+def bits(a):
+    return np.asarray(a, np.float32).view(np.uint32)
+
+
+def graph_rows(g, ids, skip=()):
+    """hvx_index_export_graph (one entry per row SLOT, deleted ones included with empty rows) -> {id: (level, l0 row, [upper rows])} of
+    the live nodes"""
+    out, r = {}, 0
+    skip = set(skip)
+    for t, nid in enumerate(ids.tolist()):
+        lv = int(g["level"][t])
+        l0 = g["l0_neighbors"][int(g["l0_offsets"][t]):int(g["l0_offsets"][t + 1])].tolist()
+        up = [g["up_neighbors"][int(g["up_offsets"][r + l]):int(g["up_offsets"][r + l + 1])].tolist() for l in range(lv)]
+        r += lv
+        if nid in skip:
+            assert l0 == [] and all(u == [] for u in up), f"deleted node {nid} still holds neighbour rows"
+            continue
+        out[nid] = (lv, l0, up)
+    return out
+
+
+def assert_same_graph(gix, oix, ids, deleted):
+    ex = oix.export()
+    want = rows_by_id(ex)
+    got = graph_rows(gix.export_graph(), ids, deleted)
+    assert set(got) == set(want)
+    bad = [nid for nid in want if got[nid] != want[nid]]
+    assert not bad, f"{len(bad)} nodes differ, first {bad[:4]}: device {got[bad[0]]} oracle {want[bad[0]]}"
+    g = gix.export_graph()
+    ent = oix.entry()
+    if ent is None:
+        assert g["entry_point"] is None
+    else:
+        assert (g["entry_point"], g["max_layer"]) == ent
+
+
+@pytest.mark.parametrize("n,dim,metric,m,m0,efc,kern", [(2400, 128, 1, 16, 32, 100, "avx_fma"), (1500, 256, 0, 16, 32, 80, "avx_fma"),
+                                                        (1000, 72, 2, 8, 16, 60, "avx_fma"), (900, 88, 1, 8, 16, 60, "neon")])
+def test_sequential_deletes_equal_the_oracles_row_for_row(orc, hv, n, dim, metric, m, m0, efc, kern):
+    """VectorIndex::delete one node at a time (mutation.rs:1606-1774): after three batches of deletes (scattered ids, the entry point
+    twice, ids that are unknown, an id twice in one batch) every layer-0 row, every upper row, the entry point and the top layer of
+    the live nodes equal the oracle's; deleted ids are gone from the HNSW searches (strict + the production default arm), the exact
+    scan, restricted candidate sets and hvx_index_contains; the statistics count what happened; a fork keeps its generation until
+    hvx_index_refresh; rows appended AFTER the deletes link exactly as the oracle's do."""
+    ok, hk = {"avx_fma": (orc.K_AVX_FMA, hv.KERNEL_AVX_FMA), "neon": (orc.K_NEON, hv.KERNEL_NEON)}[kern]
+    rng = np.random.default_rng(4200 + dim + metric + n)
+    n_all = n + 120
+    data = rng.standard_normal((n_all, dim)).astype(np.float32)
+    lv = fx.draw_levels(n_all, m, seed=n + 3)
+    ids = np.arange(n_all, dtype=np.uint64) * 3 + 7
+    gix, st = hv.ValidatedVectorReadIndex.build(dim=dim, metric=metric, node_ids=ids[:n], vectors=data[:n], levels=lv[:n], m=m, m0=m0,
+                                                ef_construction=efc, sequential=True, float_kernel=hk, reserve_rows=120,
+                                                reserve_upper_rows=int(lv[n:].sum()))
+    oix = orc.Index(dim, metric, kernel=ok, m=m, m0=m0, ef_construction=efc)
+    for i in range(n):
+        assert oix.insert(int(ids[i]), data[i], int(lv[i])) == orc.OK
+    assert_same_graph(gix, oix, ids[:n], ())
+    gix.set_simhash()
+    lane = gix.fork()
+    seq0 = gix.visible_seq()
+    perm = rng.permutation(n)
+    deleted = []
+    batches = [perm[: n // 20], perm[n // 20: n // 8], perm[n // 8: n // 5]]
+    for bi, b in enumerate(batches):
+        want = [int(x) for x in ids[b]]
+        ent = oix.entry()[0]
+        if ent not in want and ent not in deleted:
+            want.insert(len(want) // 2, ent)                                  # the entry point itself (mutation.rs:1756-1767)
+        extra = [10 ** 12 + bi, want[0]]                                       # an unknown id; an id already deleted by this batch
+        if deleted:
+            extra.append(deleted[0])                                           # ... and one deleted by an earlier batch
+        moves = 0
+        for d in want:
+            moves += int(oix.entry() is not None and oix.entry()[0] == d)
+            assert oix.delete(d) == (orc.OK, True)
+        stb = gix.delete_batch(np.asarray(want + extra, np.uint64))
+        deleted += want
+        assert stb["requested"] == len(want) + len(extra) and stb["deleted"] == len(want) and stb["missing"] == len(extra)
+        assert stb["entry_moves"] == moves and stb["relinked_rows"] > 0
+        assert gix.live_rows() == n - len(deleted) == oix.count and gix.rows() == n and gix.visible_seq() == seq0 + bi + 1
+        assert_same_graph(gix, oix, ids[:n], deleted)
+    dset = set(deleted)
+    assert not gix.contains(deleted[0]) and gix.contains(int(ids[perm[-1]])) and not gix.contains(5)
+    audit = gix.audit_graph()
+    assert audit["out_of_range_ids"] == 0 and audit["unsorted_entries"] == 0 and audit["self_loops"] == 0 and audit["nodes"] == n - len(deleted)
+    assert audit["degree_overflow_rows"] == 0
+    # searches: ids and score bits equal the oracle's on the relinked graph, nothing deleted comes back
+    oix.set_simhash(42)
+    q = np.vstack([rng.standard_normal((20, dim)).astype(np.float32), data[[int(x) for x in perm[:4]]]])   # four queries ARE deleted vectors
+    gid, gsc, gcnt, _ = gix.search_batch(q, hv.SearchParams(10).with_ef(64))
+    pid, psc, pcnt, _ = gix.search_batch(q, hv.SearchParams.new(10))
+    fid, fsc, fcnt, _ = gix.flat_search_batch(q, 10)
+    op = orc.SearchParams.new(10)
+    allowed = np.asarray(sorted(set(int(x) for x in ids[rng.permutation(n)[: n // 3]]) | set(deleted[:30])), np.uint64)
+    rid, rsc, rcnt = gix.search_restricted_batch(q, hv.SearchParams(10), hv.RestrictedVectorCandidates.from_ids(allowed))
+    for qi in range(q.shape[0]):
+        rc, oid, osc = oix.search(q[qi], 10, 64)
+        assert gid[qi, :gcnt[qi]].tolist() == oid.tolist() and bits(gsc[qi, :gcnt[qi]]).tolist() == bits(osc).tolist()
+        rc, oid, osc = oix.search_params(q[qi], op)
+        assert pid[qi, :pcnt[qi]].tolist() == oid.tolist() and bits(psc[qi, :pcnt[qi]]).tolist() == bits(osc).tolist()
+        rc, tid, tsc = oix.flat(q[qi], 10)
+        assert fid[qi, :fcnt[qi]].tolist() == tid.tolist() and bits(fsc[qi, :fcnt[qi]]).tolist() == bits(tsc).tolist()
+        rc, tid, tsc = oix.flat(q[qi], 10, allowed=allowed)
+        assert rid[qi, :rcnt[qi]].tolist() == tid.tolist() and bits(rsc[qi, :rcnt[qi]]).tolist() == bits(tsc).tolist()
+        assert not (set(gid[qi, :gcnt[qi]].tolist()) | set(fid[qi, :fcnt[qi]].tolist()) | set(rid[qi, :rcnt[qi]].tolist())) & dset
+    # the fork: its generation until it is refreshed (rows stale-or-current, never torn), then the owner's
+    assert lane.live_rows() == n and lane.visible_seq() == seq0
+    lid, lsc, lcnt, _ = lane.search_batch(q, hv.SearchParams(10).with_ef(64))
+    assert (lcnt > 0).all()
+    lane.refresh()
+    assert lane.live_rows() == n - len(deleted)
+    lid, lsc, lcnt, _ = lane.search_batch(q, hv.SearchParams(10).with_ef(64))
+    assert lid.tolist() == gid.tolist() and bits(lsc).tolist() == bits(gsc).tolist()
+    fl_id, fl_sc, fl_cnt, _ = lane.flat_search_batch(q, 10)
+    assert fl_id.tolist() == fid.tolist()
+    with pytest.raises(hv.HelixDbError):
+        lane.delete_batch(ids[:1])                                            # a fork does not own the image
+    lane.close()
+    # rows appended after the deletes: VectorIndex::insert on the relinked graph
+    for i in range(n, n_all):
+        assert oix.insert(int(ids[i]), data[i], int(lv[i])) == orc.OK
+    gix.insert_batch(ids[n:], data[n:], lv[n:], ef_construction=efc, sequential=True)
+    assert gix.rows() == n_all and gix.live_rows() == n_all - len(deleted)
+    assert_same_graph(gix, oix, ids, deleted)
+    gid, gsc, gcnt, _ = gix.search_batch(q, hv.SearchParams(10).with_ef(64))
+    fid, fsc, fcnt, _ = gix.flat_search_batch(q, 10)
+    for qi in range(q.shape[0]):
+        rc, oid, osc = oix.search(q[qi], 10, 64)
+        assert gid[qi, :gcnt[qi]].tolist() == oid.tolist() and bits(gsc[qi, :gcnt[qi]]).tolist() == bits(osc).tolist()
+        rc, tid, tsc = oix.flat(q[qi], 10)
+        assert fid[qi, :fcnt[qi]].tolist() == tid.tolist()
+    # ... and a few of the new rows deleted again
+    again = [int(x) for x in ids[n + 5: n + 25]]
+    for d in again:
+        assert oix.delete(d) == (orc.OK, True)
+    assert gix.delete_batch(np.asarray(again, np.uint64))["deleted"] == len(again)
+    assert_same_graph(gix, oix, ids, deleted + again)
+
+
+def test_deletes_on_an_imported_image_the_walk_the_prefilter_and_the_batcher(orc, hv):
+    """An image imported from persisted rows (hvx_index_import layout, no spare capacity) takes deletes too.  Afterwards the restricted
+    filter-aware walk (SimHash directory rebuilt without the deleted rows: mutation.rs:1718-1722) equals the oracle's walk counter for
+    counter, the fused prefilter path maps deleted ids to nothing, a batcher's lanes serve the new generation after hvx_batcher_refresh,
+    and deleting EVERY node leaves an index that answers with no rows."""
+    rng = np.random.default_rng(77)
+    n, dim, m, m0, efc = 3000, 128, 16, 32, 100
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    lv = fx.draw_levels(n, m, seed=5)
+    ids = np.arange(n, dtype=np.uint64) + 100
+    oix = orc.Index(dim, orc.L2SQ, m=m, m0=m0, ef_construction=efc)
+    for i in range(n):
+        assert oix.insert(int(ids[i]), data[i], int(lv[i])) == orc.OK
+    gix = hv.ValidatedVectorReadIndex.from_export(oix.export(), dim=dim, metric=1, max_batch=64)
+    gix.set_simhash()
+    oix.set_simhash(42)
+    bt = hv.Batcher(gix, hv.SearchParams(10).with_ef(64), max_batch=32, max_wait_us=500)
+    dels = [int(x) for x in ids[rng.permutation(n)[:400]]]
+    for d in dels:
+        assert oix.delete(d)[0] == orc.OK
+    st = gix.delete_batch(np.asarray(dels, np.uint64))
+    assert st["deleted"] == 400 and st["missing"] == 0 and st["seconds"] > 0
+    assert_same_graph(gix, oix, ids, dels)
+    assert gix.get_simhash().shape[0] == n                       # (SimHash rows stay per row slot on the device)
+    # the planned restricted search: a group big enough for the filter-aware walk, deleted ids among the candidates
+    allowed = np.asarray(sorted(set(int(x) for x in ids[rng.permutation(n)[:1200]]) | set(dels[:100])), np.uint64)
+    q = rng.standard_normal((8, dim)).astype(np.float32)
+    rp = hv.RestrictedParams.new(10, 100)
+    cand = hv.RestrictedVectorCandidates.from_ids(allowed)
+    wid, wsc, wcnt, wst, wrs = gix.search_restricted_batch_params(q, rp, cand)
+    assert wrs[0]["strategy"] == hv.RESTRICTED_FILTERED
+    for qi in range(q.shape[0]):
+        rc, oid, osc, ost = oix.search_restricted(q[qi], 10, 100, allowed)
+        assert rc == orc.OK and wid[qi, :wcnt[qi]].tolist() == oid.tolist() and bits(wsc[qi, :wcnt[qi]]).tolist() == bits(osc).tolist()
+        assert wrs[qi] == ost, (wrs[qi], ost)        # every RestrictedSearchStats counter and the termination reason
+        assert not set(wid[qi, :wcnt[qi]].tolist()) & set(dels)
+    # fused prefilter: a graph whose hop reaches deleted nodes as well
+    n_nodes = n + 200
+    e = 12000
+    src = np.sort(rng.integers(0, n_nodes, e)); tgt = rng.integers(0, n_nodes, e).astype(np.uint64)
+    off = np.zeros(n_nodes + 1, np.uint64); np.add.at(off, src + 1, 1); off = np.cumsum(off).astype(np.uint64)
+    g = hv.Graph(n_nodes, off, tgt, rng.integers(0, 3, e).astype(np.uint32))
+    seeds = np.arange(100, 400)
+    pids, psc, pcnt, ncand, _ = gix.prefilter_search_batch(g, q, hv.SearchParams(10), seeds)
+    words = g.expand(seeds, hv.DIR_OUT, ())
+    c2 = hv.RestrictedVectorCandidates.from_bitmap_words(words)
+    assert ncand == len(c2) and set(c2.ids.tolist()) & set(dels)
+    for qi in range(q.shape[0]):
+        rc, oid, osc = oix.flat(q[qi], 10, allowed=c2.ids)
+        assert pids[qi, :pcnt[qi]].tolist() == oid.tolist() and bits(psc[qi, :pcnt[qi]]).tolist() == bits(osc).tolist()
+    # the batcher created before the deletes
+    bt.refresh()
+    for qi in range(q.shape[0]):
+        res = bt.search(q[qi])
+        rc, oid, osc = oix.search(q[qi], 10, 64)
+        assert [r_.entity_id for r_ in res] == oid.tolist()
+    bt.close()
+    # everything goes
+    rest = [int(x) for x in ids.tolist() if int(x) not in set(dels)]
+    for d in rest:
+        assert oix.delete(d)[0] == orc.OK
+    st = gix.delete_batch(np.asarray(rest, np.uint64))
+    assert st["deleted"] == len(rest) and gix.live_rows() == 0 and oix.count == 0 and oix.entry() is None
+    gid, gsc, gcnt, _ = gix.search_batch(q, hv.SearchParams(10).with_ef(64))
+    assert gcnt.sum() == 0
+    fid, fsc, fcnt, _ = gix.flat_search_batch(q, 10)
+    assert fcnt.sum() == 0

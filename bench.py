@@ -81,6 +81,7 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = the cores this process may use (cgroup quota, else all; capped at 64)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle bit-exactness check")
     ap.add_argument("--metric", default="l2", choices=["l2", "cosine"])
+    ap.add_argument("--deletes", type=int, default=2000, help="nodes the insert leg deletes again (hvx_index_delete_batch), 0 = none")
     ap.add_argument("--skip", default="", help="comma list of extra legs to skip: production,production_lanes,batcher,insert,datasets,iso_recall,config3,config4,config5,"
                                                "graph_equivalence,ef_sweep,peak,vendor_gemm")
     ap.add_argument("--full-record", default=os.path.join(ROOT, "bench_full.json"), help="where the full record of every leg is written")
@@ -703,6 +704,27 @@ def leg_incremental_insert(hv, synth, args, dev, n0=500_000, add=100_000, seq=2_
            "rows_after": ix.rows(), "visible_seq": ix.visible_seq(), "audit": audit,
            "recall_at_10_ef%d" % ef: round(rec, 4), "results_from_appended_rows": newest,
            "note": "recall of the grown graph against its own exact scan (which covers the appended rows: row norms / bf16 shadow extended on that scan)"}
+    # ---- deletes (hvx_index_delete_batch == VectorIndex::delete, mutation.rs:1606-2055: unlink, relink the sources, entry repair) ----
+    n_del = getattr(args, "deletes", 2000)
+    if n_del:
+        rng = np.random.default_rng(args.seed + 9)
+        victims = np.sort(rng.choice(n, size=n_del, replace=False)).astype(np.uint64)
+        rng.shuffle(victims)
+        t0 = time.time()
+        sd = ix.delete_batch(victims)
+        ix.sync()
+        t_del = time.time() - t0
+        audit_d = graph_audit(ix, args.m)
+        ix.flat_search_batch_device(q, k, *f[:4])
+        ix.search_batch_device(q, k, ef, *g, want_stats=False)
+        torch.cuda.synchronize()
+        gone = torch.from_numpy(victims.astype(np.int64)).to(dev)
+        leaked = int(torch.isin(g[0].reshape(-1), gone).sum().item()) + int(torch.isin(f[0].reshape(-1), gone).sum().item())
+        out["deletes"] = {"workload": f"{n_del} scattered nodes of the {n}-row graph deleted one after the other (sequential semantics = the reference's)",
+                          "seconds": round(t_del, 3), "deletes_per_s": round(n_del / t_del, 1), "us_per_delete": round(t_del / n_del * 1e6, 1),
+                          "relinked_rows": sd["relinked_rows"], "relinked_rows_per_delete": round(sd["relinked_rows"] / max(1, sd["deleted"]), 1),
+                          "entry_moves": sd["entry_moves"], "live_rows_after": ix.live_rows(), "audit": audit_d,
+                          "recall_at_10_ef%d" % ef: round(recall_of(g[0], f[0], b, k), 4), "deleted_ids_in_results": leaked}
     ix.close()
     del x, q
     torch.cuda.empty_cache()
@@ -1165,7 +1187,10 @@ def compact_record(out, full_path):
     if isinstance(ii, dict):
         c["insert"] = {"error": str(ii["error"])[:160]} if "error" in ii else {
             "batched_inserts_per_s": _pick(ii, "batched", "inserts_per_s"), "sequential_us_per_insert": _pick(ii, "sequential", "us_per_insert"),
-            "audit_clean": _pick(ii, "audit", "clean"), "recall_at_10": next((v for k_, v in ii.items() if k_.startswith("recall_at_10")), None)}
+            "audit_clean": _pick(ii, "audit", "clean"), "recall_at_10": next((v for k_, v in ii.items() if k_.startswith("recall_at_10")), None),
+            "delete_us": _pick(ii, "deletes", "us_per_delete"),
+            "recall_after_deletes": next((v for k_, v in (ii.get("deletes") or {}).items() if k_.startswith("recall_at_10")), None),
+            "deleted_ids_in_results": _pick(ii, "deletes", "deleted_ids_in_results")}
     bt = out.get("batcher")
     if isinstance(bt, dict):
         c["batcher"] = {"error": str(bt["error"])[:160]} if "error" in bt else {k: bt.get(k) for k in ("qps", "mean_us", "p99_us", "mean_batch", "qps_production_default",

@@ -55,6 +55,8 @@ constexpr uint32_t kDelCandCap = 16384; // candidates per layer (one source's sc
 constexpr uint32_t kDelTop = 32;        // Mmax
 constexpr uint32_t kDelMinLayers = 16;
 constexpr uint32_t kDelMark = 0xFFFFFFFFu;
+constexpr uint32_t kDelWaves = 16; // wavefronts of a step workgroup
+constexpr uint32_t kDelSteps = 32; // relink sources per layer that run as steps (own + reciprocal launch); later ones in delete_relink_kernel
 
 struct DeleteArgs {
     DevIndex ix;
@@ -67,6 +69,8 @@ struct DeleteArgs {
     uint32_t *cand, *cand_cnt; // [layers][kDelCandCap], [layers]
     uint32_t *top, *top_cnt;   // [layers][kDelRelCap][kDelTop], [layers][kDelRelCap]: a source's closest candidates, Candidate order
     uint32_t *mark;            // [layers][words] all zero between kernels
+    uint32_t *newl, *new_cnt;  // [layers][kDelTop], [layers]: the neighbours the current step's source has gained (step kernels)
+    uint32_t first;            // delete_relink_kernel starts with this source (the ones before it ran as steps)
     uint32_t *dead;            // the image's deleted-row bitmap
     uint32_t *ctl;             // [0] error (1 sources, 2 relink sources, 3 candidates, 4 invalid score, 5 row overflow) [1] relinked rows
                                // [2..3] best entry key (u64)
@@ -289,7 +293,7 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(64) void del
     const uint32_t maxn = L == 0u ? a.m0 : a.m;
     const unsigned long long lt = (1ull << lane) - 1ull;
     bool bad = false, overflow = false;
-    for (uint32_t ri = 0; ri < nr; ++ri) {
+    for (uint32_t ri = a.first; ri < nr; ++ri) {
         const uint32_t nb = a.rel[(size_t)L * kDelRelCap + ri];
         uint32_t stride;
         uint32_t *row = del_row(a, nb, L, stride);
@@ -363,6 +367,229 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(64) void del
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same relinks as STEPS (the default): the one-wavefront kernel below evaluates every prune lazily -- candidate after candidate, each a
+// dependent row gather -- ~0.5 ms per prune and ~15 prunes per source (26.9 ms per delete at 200 000 x 768, profiles/r05t_delete_bench.json).
+// A step runs one source: delete_step_own_kernel (one 16-wavefront workgroup per layer) merges the source's row with its closest
+// candidates and, beyond Mmax, evaluates the WHOLE distance matrix of the <= 64 ids at once (every wavefront stages one id's vector and
+// scores it against all the others, reference summation order) before one wavefront replays select_diverse + backfill from LDS;
+// delete_step_recip_kernel (one workgroup per new neighbour) does the same for the reciprocal rows, which are independent of each
+// other.  Same distances, same comparisons, same order of decisions as the lazy evaluation: the rows are identical (both modes are
+// held to the oracle by tests/test_gpu_delete.py; HVX_OPT_DELETE_SEQUENTIAL selects the one-wavefront kernel).
+// (A pair distance that is not a valid score aborts the reference only if select_diverse reaches that pair; the eager matrix treats
+// it as "not closer" -- rows validated at import cannot produce one under the component limit.)
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct StepLds {
+    float *qv;                                // [ld] this wavefront's staged vector
+    float *Dm;                                // [65][64]: Dm[i][j] = distance(staged id i, stored id j); row nc = the owner
+    uint32_t *cur, *ord, *sel, *kept, *oldl;  // [64] each
+    float *osc;                               // [64]
+    uint32_t *misc;                           // [8]
+};
+__device__ __forceinline__ StepLds carve_step(char *smem, uint32_t ld, uint32_t wave) {
+    const size_t qs = ((size_t)ld * 4u + 15u) & ~(size_t)15u;
+    StepLds S;
+    S.qv = reinterpret_cast<float *>(smem + wave * qs);
+    char *p = smem + kDelWaves * qs;
+    S.Dm = reinterpret_cast<float *>(p); p += 65 * 64 * 4;
+    S.cur = reinterpret_cast<uint32_t *>(p); p += 256;
+    S.ord = reinterpret_cast<uint32_t *>(p); p += 256;
+    S.sel = reinterpret_cast<uint32_t *>(p); p += 256;
+    S.kept = reinterpret_cast<uint32_t *>(p); p += 256;
+    S.oldl = reinterpret_cast<uint32_t *>(p); p += 256;
+    S.osc = reinterpret_cast<float *>(p); p += 256;
+    S.misc = reinterpret_cast<uint32_t *>(p);
+    return S;
+}
+static size_t step_lds_bytes(uint32_t ld) { return kDelWaves * (((size_t)ld * 4u + 15u) & ~(size_t)15u) + 65 * 64 * 4 + 6 * 256 + 64; }
+
+__device__ __forceinline__ void lds_order() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); } // one wavefront's LDS writes before its next reads
+
+__device__ __forceinline__ void store_canonical_wave(uint32_t *row, uint32_t stride, const uint32_t *ids_lds, uint32_t ns, uint32_t lane) {
+    const uint32_t mine = lane < ns ? ids_lds[lane] : kSentinel;
+    uint32_t rank = 0;
+    for (uint32_t s = 0; s < ns; ++s) rank += ids_lds[s] < mine ? 1u : 0u;
+    for (uint32_t t = lane; t < stride; t += 64u)
+        if (t >= ns) st_row(row + t, kSentinel);
+    if (lane < ns) st_row(row + rank, mine);
+}
+
+// S.cur[0..nc) pruned to at most maxn ids around `owner` (prune_row_dev's result, evaluated eagerly by the whole workgroup): S.kept[0..return)
+template <uint32_t METRIC, bool FUSED>
+__device__ __forceinline__ uint32_t prune_eager(const DevIndex &ix, const StepLds &S, uint32_t owner, uint32_t nc, uint32_t maxn, uint32_t tid, bool *bad) {
+    const uint32_t wave = tid >> 6, lane = tid & 63u;
+    const int grp = (int)(lane >> 3), j = (int)(lane & 7u);
+    const uint32_t iters = (nc + 1u + kDelWaves - 1u) / kDelWaves;
+    for (uint32_t it = 0; it < iters; ++it) {
+        const uint32_t i = it * kDelWaves + wave;
+        const bool act = i <= nc;
+        const uint32_t node_i = (act && i < nc) ? S.cur[i] : owner;
+        __syncthreads();
+        {
+            const float *r = ix.vec + (size_t)node_i * ix.ld;
+            for (uint32_t t = lane; t < ix.ld; t += 64u) S.qv[t] = r[t];
+        }
+        __syncthreads();
+        if (act) {
+            const float h = ix.hdr[node_i];
+            for (uint32_t p0 = 0; p0 < nc; p0 += 8u) {
+                const uint32_t g = p0 + (uint32_t)grp;
+                const uint32_t other = S.cur[g < nc ? g : nc - 1u];
+                const float d = group_distance<METRIC, FUSED>(ix, S.qv, h, other, j);
+                if (g < nc && j == 0) S.Dm[i * 64u + g] = d;
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const float dmine = lane < nc ? S.Dm[nc * 64u + lane] : 0.f;
+        const uint32_t v = lane < nc ? S.cur[lane] : kSentinel;
+        float chk = dmine;
+        if (__ballot(lane < nc && !score_valid(chk)) != 0ull) *bad = true;
+        uint32_t rank = 0;
+        for (uint32_t t = 0; t < nc; ++t) { // Candidate order: score, then id
+            const float dt = S.Dm[nc * 64u + t];
+            const uint32_t idt = S.cur[t];
+            rank += (dt < dmine || (dt == dmine && idt < v)) ? 1u : 0u;
+        }
+        if (lane < nc) { S.ord[rank] = lane; S.osc[rank] = dmine; }
+        lds_order();
+        uint32_t ns = 0;
+        for (uint32_t r = 0; r < nc && ns < maxn; ++r) { // select_diverse (mod.rs:822-842): strict < rejects
+            const uint32_t ci = S.ord[r];
+            const float sc = S.osc[r];
+            const bool closer = lane < ns && S.Dm[ci * 64u + S.sel[lane < ns ? lane : 0u]] < sc;
+            if (__ballot(closer) == 0ull) {
+                if (lane == 0) S.sel[ns] = ci;
+                ++ns;
+                lds_order();
+            }
+        }
+        if (ns < maxn) { // backfill, closest first (mod.rs:845-854)
+            const bool have = lane < nc;
+            const uint32_t mine = have ? S.ord[lane] : kSentinel;
+            bool in = false;
+            for (uint32_t s = 0; s < ns; ++s) in |= S.sel[s] == mine;
+            const unsigned long long fm = __ballot(have && !in);
+            const uint32_t rk = (uint32_t)__builtin_popcountll(fm & ((1ull << lane) - 1ull));
+            if (have && !in && ns + rk < maxn) S.sel[ns + rk] = mine;
+            const uint32_t add = (uint32_t)__builtin_popcountll(fm);
+            ns = ns + add < maxn ? ns + add : maxn;
+            lds_order();
+        }
+        if (lane < ns) S.kept[lane] = S.cur[S.sel[lane]];
+        if (lane == 0) S.misc[0] = ns;
+    }
+    __syncthreads();
+    return S.misc[0];
+}
+
+// relink_neighbor (mutation.rs:1916-1993) for source `ri` of every layer: merge, prune, stage; the neighbours it has gained go to newl
+template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(1024) void delete_step_own_kernel(DeleteArgs a, uint32_t ri) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ uint32_t s_go, s_ncur, s_nold;
+    const DevIndex &ix = a.ix;
+    const uint32_t L = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const StepLds S = carve_step(smem, ix.ld, wave);
+    if (tid == 0) { a.new_cnt[L] = 0; s_go = (a.ctl[0] == 0u && ri < a.rel_cnt[L]) ? 1u : 0u; }
+    __syncthreads();
+    if (!s_go) return;
+    const uint32_t nb = a.rel[(size_t)L * kDelRelCap + ri];
+    const uint32_t maxn = L == 0u ? a.m0 : a.m;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t stride;
+    uint32_t *row = del_row(a, nb, L, stride);
+    if (wave == 0) {
+        const uint32_t v = lane < stride ? ld_row(row + lane) : kSentinel;
+        const uint32_t nold = (uint32_t)__builtin_popcountll(__ballot(v != kSentinel));
+        const uint32_t tn = a.top_cnt[(size_t)L * kDelRelCap + ri];
+        const uint32_t tv = lane < tn ? a.top[((size_t)L * kDelRelCap + ri) * kDelTop + lane] : kSentinel;
+        S.oldl[lane] = v;
+        lds_order();
+        bool in_old = false;
+        for (uint32_t s = 0; s < nold; ++s) in_old |= S.oldl[s] == tv;
+        const bool add = tv != kSentinel && !in_old;
+        const unsigned long long am = __ballot(add);
+        const uint32_t ncur = nold + (uint32_t)__builtin_popcountll(am);
+        if (ncur <= 64u) {
+            if (lane < nold) S.cur[lane] = v;
+            if (add) S.cur[nold + (uint32_t)__builtin_popcountll(am & lt)] = tv;
+        }
+        if (lane == 0) { s_ncur = ncur; s_nold = nold; }
+    }
+    __syncthreads();
+    const uint32_t ncur = s_ncur, nold = s_nold;
+    if (ncur > 64u) { if (tid == 0) atomicMax(&a.ctl[0], 5u); return; }
+    bool bad = false;
+    uint32_t keepn = ncur;
+    if (ncur > maxn) {
+        keepn = prune_eager<METRIC, FUSED>(ix, S, nb, ncur, maxn, tid, &bad);
+    } else {
+        if (wave == 0 && lane < ncur) S.kept[lane] = S.cur[lane];
+        __syncthreads();
+    }
+    if (wave == 0) {
+        const uint32_t f = lane < keepn ? S.kept[lane] : kSentinel;
+        bool was_old = false;
+        for (uint32_t s = 0; s < nold; ++s) was_old |= S.oldl[s] == f;
+        const bool isnew = f != kSentinel && !was_old;
+        const unsigned long long nm = __ballot(isnew);
+        if (keepn > stride) { if (lane == 0) atomicMax(&a.ctl[0], 5u); return; }
+        store_canonical_wave(row, stride, S.kept, keepn, lane);
+        if (isnew) a.newl[(size_t)L * kDelTop + (uint32_t)__builtin_popcountll(nm & lt)] = f;
+        if (lane == 0) {
+            a.new_cnt[L] = (uint32_t)__builtin_popcountll(nm);
+            if (bad) atomicMax(&a.ctl[0], 4u);
+        }
+    }
+}
+
+// ... and the reciprocal row of each of them (mutation.rs:1994-2052): one workgroup per new neighbour
+template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(1024) void delete_step_recip_kernel(DeleteArgs a, uint32_t ri) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ uint32_t s_go, s_rdeg, s_has;
+    const DevIndex &ix = a.ix;
+    const uint32_t L = blockIdx.y, bx = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const StepLds S = carve_step(smem, ix.ld, wave);
+    if (tid == 0) s_go = (a.ctl[0] == 0u && ri < a.rel_cnt[L] && bx < a.new_cnt[L]) ? 1u : 0u;
+    __syncthreads();
+    if (!s_go) return;
+    const uint32_t nb = a.rel[(size_t)L * kDelRelCap + ri], nw = a.newl[(size_t)L * kDelTop + bx];
+    const uint32_t maxn = L == 0u ? a.m0 : a.m;
+    uint32_t rstride;
+    uint32_t *rrow = del_row(a, nw, L, rstride);
+    if (wave == 0) {
+        uint32_t rv = lane < rstride ? ld_row(rrow + lane) : kSentinel;
+        uint32_t rdeg = (uint32_t)__builtin_popcountll(__ballot(rv != kSentinel));
+        const bool has = __ballot(rv == nb) != 0ull;
+        if (!has && rdeg < 64u) {
+            if (lane == rdeg) rv = nb;
+            ++rdeg;
+            if (lane < rdeg) S.cur[lane] = rv;
+        } else if (!has) {
+            rdeg = 65u;
+        }
+        if (lane == 0) { s_rdeg = rdeg; s_has = has ? 1u : 0u; }
+    }
+    __syncthreads();
+    if (s_has) return;
+    const uint32_t rdeg = s_rdeg;
+    if (rdeg > 64u) { if (tid == 0) atomicMax(&a.ctl[0], 5u); return; }
+    bool bad = false;
+    uint32_t kn = rdeg;
+    if (rdeg > maxn) {
+        kn = prune_eager<METRIC, FUSED>(ix, S, nw, rdeg, maxn, tid, &bad);
+    } else {
+        if (wave == 0 && lane < rdeg) S.kept[lane] = S.cur[lane];
+        __syncthreads();
+    }
+    if (wave == 0) {
+        if (kn <= rstride) store_canonical_wave(rrow, rstride, S.kept, kn, lane);
+        if (lane == 0 && (bad || kn > rstride)) atomicMax(&a.ctl[0], bad ? 4u : 5u);
+    }
+}
+
 // find_best_entry_candidate (mutation.rs:350-394): the live node on the highest layer, smallest id first
 __global__ __launch_bounds__(256) void delete_best_entry_kernel(DevIndex ix, const uint32_t *dead, unsigned long long *out) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -377,8 +604,11 @@ __global__ __launch_bounds__(256) void delete_best_entry_kernel(DevIndex ix, con
 }
 
 using DeleteKernel = void (*)(DeleteArgs);
-struct DeleteKernels { DeleteKernel rank, relink; };
-template <uint32_t METRIC, bool FUSED> static DeleteKernels delete_kernels_of() { return {delete_rank_kernel<METRIC, FUSED>, delete_relink_kernel<METRIC, FUSED>}; }
+using DeleteStepKernel = void (*)(DeleteArgs, uint32_t);
+struct DeleteKernels { DeleteKernel rank, relink; DeleteStepKernel own, recip; };
+template <uint32_t METRIC, bool FUSED> static DeleteKernels delete_kernels_of() {
+    return {delete_rank_kernel<METRIC, FUSED>, delete_relink_kernel<METRIC, FUSED>, delete_step_own_kernel<METRIC, FUSED>, delete_step_recip_kernel<METRIC, FUSED>};
+}
 static DeleteKernels pick_delete_kernels(uint32_t metric, bool fused) {
     if (metric == kL2) return fused ? delete_kernels_of<kL2, true>() : delete_kernels_of<kL2, false>();
     if (metric == kCosine) return fused ? delete_kernels_of<kCosine, true>() : delete_kernels_of<kCosine, false>();
@@ -414,7 +644,7 @@ extern "C" int hvx_index_delete_batch(hvx_index *ix, const uint64_t *node_ids, u
     const uint32_t layers_now = d.max_layer + 1u;
     if (!ix->del_scratch || ix->del_layers < layers_now) {
         const uint32_t layers = std::max(kDelMinLayers, layers_now);
-        const size_t per_layer = ((size_t)kDelSrcCap + kDelRelCap + kDelCandCap + (size_t)kDelRelCap * kDelTop + kDelRelCap + words + 3u) * 4u;
+        const size_t per_layer = ((size_t)kDelSrcCap + kDelRelCap + kDelCandCap + (size_t)kDelRelCap * kDelTop + kDelRelCap + words + 4u + kDelTop) * 4u;
         void *p = nullptr;
         if ((rc = ix->dalloc(&p, per_layer * layers + 64))) return rc;
         HIP_TRY(hipMemsetAsync(p, 0, per_layer * layers + 64, s));
@@ -429,6 +659,8 @@ extern "C" int hvx_index_delete_batch(hvx_index *ix, const uint64_t *node_ids, u
         a.src_cnt = p; p += layers;
         a.rel_cnt = p; p += layers;
         a.cand_cnt = p; p += layers;
+        a.new_cnt = p; p += layers;
+        a.newl = p; p += (size_t)layers * kDelTop;
         a.src = p; p += (size_t)layers * kDelSrcCap;
         a.rel = p; p += (size_t)layers * kDelRelCap;
         a.cand = p; p += (size_t)layers * kDelCandCap;
@@ -446,6 +678,13 @@ extern "C" int hvx_index_delete_batch(hvx_index *ix, const uint64_t *node_ids, u
     const size_t relink_lds = (((size_t)d.ld * 4u + 15u) & ~(size_t)15u) + 4 * 256 + 256;
     if (rank_lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kern.rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_lds));
     if (relink_lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kern.relink, hipFuncAttributeMaxDynamicSharedMemorySize, (int)relink_lds));
+    const size_t step_lds = step_lds_bytes(d.ld);
+    const bool steps = ix->opt[HVX_OPT_DELETE_SEQUENTIAL] != 1u && step_lds <= 150u * 1024u; // (wider rows: the one-wavefront kernel relinks every source)
+    if (steps && step_lds > 48 * 1024) {
+        HIP_TRY(hipFuncSetAttribute((const void *)kern.own, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)kern.recip, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));
+    }
+    a.first = steps ? kDelSteps : 0u;
     // this generation's deleted-row flags: a copy of the visible ones (forks keep theirs until hvx_index_refresh)
     auto flags = std::make_shared<std::vector<uint8_t>>((size_t)cap, (uint8_t)0);
     if (ix->dead_p) std::copy(ix->dead_p->begin(), ix->dead_p->begin() + std::min<size_t>(ix->dead_p->size(), (size_t)cap), flags->begin());
@@ -468,6 +707,10 @@ extern "C" int hvx_index_delete_batch(hvx_index *ix, const uint64_t *node_ids, u
         hipLaunchKernelGGL(delete_scan_kernel, dim3(scan_blocks), dim3(256), 0, s, a);
         hipLaunchKernelGGL(delete_prep_kernel, dim3(a.layers), dim3(256), 0, s, a);
         hipLaunchKernelGGL(kern.rank, dim3(64, a.layers), dim3(256), rank_lds, s, a);
+        for (uint32_t ri = 0; steps && ri < kDelSteps; ++ri) { // (a step past the layer's last source returns at once)
+            hipLaunchKernelGGL(kern.own, dim3(a.layers), dim3(1024), step_lds, s, a, ri);
+            hipLaunchKernelGGL(kern.recip, dim3(kDelTop, a.layers), dim3(1024), step_lds, s, a, ri);
+        }
         hipLaunchKernelGGL(kern.relink, dim3(a.layers), dim3(64), relink_lds, s, a);
         HIP_TRY(hipGetLastError());
         (*flags)[row] = 1;
@@ -492,7 +735,7 @@ extern "C" int hvx_index_delete_batch(hvx_index *ix, const uint64_t *node_ids, u
         static const char *why[] = {"", "more than 4096 rows hold one node on a layer", "more than 4096 relink sources on a layer", "more than 16384 relink candidates on a layer",
                                     "a distance is not a valid score (Candidate::try_new fails: the reference aborts the delete)", "a neighbour row overflowed its stride"};
         const uint32_t code = c4[0] < 6u ? c4[0] : 5u;
-        (void)hipMemsetAsync(ix->del_scratch, 0, 64 + (size_t)ix->del_layers * 3u * 4u, s); // counters; the marks of an aborted layer may be dirty:
+        (void)hipMemsetAsync(ix->del_scratch, 0, 64 + (size_t)ix->del_layers * 4u * 4u, s); // counters; the marks of an aborted layer may be dirty:
         ix->del_scratch = nullptr;                                                           // ... the next call starts from fresh scratch
         ix->del_layers = 0;
         return fail(code == 4u ? HVX_ERR_INVARIANT : HVX_ERR_UNSUPPORTED, "device delete: %s -- the image is partially relinked: discard the handle and hydrate again", why[code]);

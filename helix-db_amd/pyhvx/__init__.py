@@ -152,7 +152,7 @@ class AdaptiveStats(C.Structure):  # hvx_adaptive_stats
 
 # hvx_option: execution-path selectors of a handle (same results on every setting) / hvx_scan_path flags
 OPT_HNSW_GENERAL_KERNEL, OPT_WAVE_LOG2CAP, OPT_FLAT_FORCE_VALU, OPT_FLAT_FIRST_CHUNK, OPT_FLAT_NO_TILE, OPT_FLAT_NO_FILTER, \
-    OPT_FLAT_NO_FAST, OPT_FLAT_TILE_BUILD, OPT_FLAT_NO_SMALLB, OPT_HNSW_PAIR = range(10)
+    OPT_FLAT_NO_FAST, OPT_FLAT_TILE_BUILD, OPT_FLAT_NO_SMALLB, OPT_HNSW_PAIR, OPT_DELETE_SEQUENTIAL = range(11)
 PATH_VALU, PATH_MFMA_128, PATH_TILE_256, PATH_FILTERED, PATH_FULL_SPLIT, PATH_VALU_FALLBACK_QUERIES, PATH_WIDENED, \
     PATH_PAIR_OVERFLOW_REPEAT, PATH_SMALL_BATCH = 1, 2, 4, 8, 16, 32, 64, 128, 256
 RESTRICTED_AUTO, RESTRICTED_EXACT, RESTRICTED_FILTERED = 0, 1, 2  # hvx_restricted_strategy

@@ -145,7 +145,8 @@ enum hvx_option {
     HVX_OPT_HNSW_PAIR = 9,           /* owner / gatherer kernel (an owner wavefront + 1 or 3 gatherer wavefronts per query): 0 = when the
                                         handle runs one query per SIMD (hvx_index_set_occupancy(1): one batch in flight), 1 = never,
                                         2 = always where it is built, 3 = always, with ONE gatherer even where three are built */
-    HVX_OPT_COUNT = 10
+    HVX_OPT_DELETE_SEQUENTIAL = 10,  /* 1: hvx_index_delete_batch relinks every source in the one-wavefront kernel (no per-source step launches) */
+    HVX_OPT_COUNT = 11
 };
 int hvx_index_set_option(hvx_index *, uint32_t option, uint32_t value);
 /* which kernels the handle's last exact scan ran (bit flags) */

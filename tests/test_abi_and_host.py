@@ -220,7 +220,8 @@ def test_struct_layouts_of_the_header_and_the_ctypes_mirrors_agree(tmp_path):
     pairs = [("hvx_index_desc", hv._Desc), ("hvx_stats", hv.Stats), ("hvx_query_stats", hv.QueryStats), ("hvx_search_params", hv._Params),
              ("hvx_simhash_config", hv.SimHashConfig), ("hvx_adaptive_stats", hv.AdaptiveStats), ("hvx_restricted_params", hv.RestrictedParams),
              ("hvx_restricted_stats", hv.RestrictedStats), ("hvx_index_metadata", hv.IndexMetadata), ("hvx_build_params", hv.BuildParams),
-             ("hvx_build_stats", hv.BuildStats), ("hvx_graph_audit", hv.GraphAudit), ("hvx_batcher_times", hv.BatcherTimes)]
+             ("hvx_build_stats", hv.BuildStats), ("hvx_graph_audit", hv.GraphAudit), ("hvx_batcher_times", hv.BatcherTimes),
+             ("hvx_delete_stats", hv.DeleteStats), ("hvx_batcher_ticket", hv.BatcherTicket)]
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include "helix_vec.h"\nint main(void) {\n' +
                    "".join('  printf("%s %%zu\\n", sizeof(%s));\n' % (n, n) for n, _ in pairs) + "  return 0;\n}\n")

@@ -34,7 +34,7 @@ print(json.dumps(out))
 PY
 rm -rf /tmp/pmc_$tag
 EXTRA="--skip production,batcher,datasets,config3,config4,config5,graph_equivalence,ef_sweep,vendor_gemm,peak --cpu-seconds 0 --no-verify"
-timeout 90 rocprofv3 --pmc FETCH_SIZE TCC_EA0_RDREQ_sum --kernel-trace --output-format csv -d /tmp/pmc_$tag -o pmc -- python bench.py --steps 6 --warmup 3 $EXTRA > /tmp/pmc_$tag.log 2>&1 || true
+rocprofv3 --pmc FETCH_SIZE TCC_EA0_RDREQ_sum --kernel-trace --output-format csv -d /tmp/pmc_$tag -o pmc -- python bench.py --steps 6 --warmup 3 $EXTRA > /tmp/pmc_$tag.log 2>&1 || true
 f=$(find /tmp/pmc_$tag -name '*counter_collection.csv' | head -1)
 (head -1 "$f"; grep -E "hnsw_(wave|pair)_kernel" "$f") > $out/pmc_mem.csv
 python - "$out" <<'PY'

@@ -53,10 +53,9 @@ def assert_same_graph(gix, oix, ids, deleted):
         assert (g["entry_point"], g["max_layer"]) == ent
 
 
-@pytest.mark.parametrize("n,dim,metric,m,m0,efc,kern,relink", [(2400, 128, 1, 16, 32, 100, "avx_fma", "steps"), (1500, 256, 0, 16, 32, 80, "avx_fma", "steps"),
-                                                               (1000, 72, 2, 8, 16, 60, "avx_fma", "steps"), (900, 88, 1, 8, 16, 60, "neon", "steps"),
-                                                               (1600, 768, 1, 16, 32, 100, "avx_fma", "steps"),
-                                                               (2400, 128, 1, 16, 32, 100, "avx_fma", "one_wavefront"), (900, 88, 1, 8, 16, 60, "neon", "one_wavefront")])
+@pytest.mark.parametrize("n,dim,metric,m,m0,efc,kern,relink", [(1600, 128, 1, 16, 32, 100, "avx_fma", "steps"), (1200, 256, 0, 16, 32, 80, "avx_fma", "steps"),
+                                                               (1000, 72, 2, 8, 16, 60, "avx_fma", "steps"), (1200, 768, 1, 16, 32, 100, "avx_fma", "steps"),
+                                                               (900, 88, 1, 8, 16, 60, "neon", "one_wavefront")])
 def test_sequential_deletes_equal_the_oracles_row_for_row(orc, hv, n, dim, metric, m, m0, efc, kern, relink):
     """VectorIndex::delete one node at a time (mutation.rs:1606-1774): after three batches of deletes (scattered ids, the entry point
     twice, ids that are unknown, an id twice in one batch) every layer-0 row, every upper row, the entry point and the top layer of
@@ -167,7 +166,7 @@ def test_deletes_on_an_imported_image_the_walk_the_prefilter_and_the_batcher(orc
     counter, the fused prefilter path maps deleted ids to nothing, a batcher's lanes serve the new generation after hvx_batcher_refresh,
     and deleting EVERY node leaves an index that answers with no rows."""
     rng = np.random.default_rng(77)
-    n, dim, m, m0, efc = 3000, 128, 16, 32, 100
+    n, dim, m, m0, efc = 2000, 128, 16, 32, 100
     data = rng.standard_normal((n, dim)).astype(np.float32)
     lv = fx.draw_levels(n, m, seed=5)
     ids = np.arange(n, dtype=np.uint64) + 100
@@ -178,15 +177,15 @@ def test_deletes_on_an_imported_image_the_walk_the_prefilter_and_the_batcher(orc
     gix.set_simhash()
     oix.set_simhash(42)
     bt = hv.Batcher(gix, hv.SearchParams(10).with_ef(64), max_batch=32, max_wait_us=500)
-    dels = [int(x) for x in ids[rng.permutation(n)[:400]]]
+    dels = [int(x) for x in ids[rng.permutation(n)[:300]]]
     for d in dels:
         assert oix.delete(d)[0] == orc.OK
     st = gix.delete_batch(np.asarray(dels, np.uint64))
-    assert st["deleted"] == 400 and st["missing"] == 0 and st["seconds"] > 0
+    assert st["deleted"] == 300 and st["missing"] == 0 and st["seconds"] > 0
     assert_same_graph(gix, oix, ids, dels)
     assert gix.get_simhash().shape[0] == n                       # (SimHash rows stay per row slot on the device)
     # the planned restricted search: a group big enough for the filter-aware walk, deleted ids among the candidates
-    allowed = np.asarray(sorted(set(int(x) for x in ids[rng.permutation(n)[:1200]]) | set(dels[:100])), np.uint64)
+    allowed = np.asarray(sorted(set(int(x) for x in ids[rng.permutation(n)[:900]]) | set(dels[:100])), np.uint64)
     q = rng.standard_normal((8, dim)).astype(np.float32)
     rp = hv.RestrictedParams.new(10, 100)
     cand = hv.RestrictedVectorCandidates.from_ids(allowed)
@@ -199,7 +198,7 @@ def test_deletes_on_an_imported_image_the_walk_the_prefilter_and_the_batcher(orc
         assert not set(wid[qi, :wcnt[qi]].tolist()) & set(dels)
     # fused prefilter: a graph whose hop reaches deleted nodes as well
     n_nodes = n + 200
-    e = 12000
+    e = 9000
     src = np.sort(rng.integers(0, n_nodes, e)); tgt = rng.integers(0, n_nodes, e).astype(np.uint64)
     off = np.zeros(n_nodes + 1, np.uint64); np.add.at(off, src + 1, 1); off = np.cumsum(off).astype(np.uint64)
     g = hv.Graph(n_nodes, off, tgt, rng.integers(0, 3, e).astype(np.uint32))

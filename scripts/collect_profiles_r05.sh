@@ -12,6 +12,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 export GPU_MAX_HW_QUEUES=8
 if [ -z "$SKIP_PLAIN" ]; then python bench.py 2> $out/bench.err | tail -1 > $out/bench_line.json; cp bench_full.json $out/bench_full.json; fi
+if [ -z "$SKIP_TRACE" ]; then
 rm -rf /tmp/prof_$tag
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o $tag -- python bench.py --deadline 600 > /tmp/prof_$tag.log 2>&1 || true
 grep '^{' /tmp/prof_$tag.log | tail -1 > $out/bench_line_profiled.json
@@ -32,8 +33,9 @@ if v:
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 print(json.dumps(out))
 PY
+fi
 rm -rf /tmp/pmc_$tag
-EXTRA="--skip production,batcher,datasets,config3,config4,config5,graph_equivalence,ef_sweep,vendor_gemm,peak --cpu-seconds 0 --no-verify"
+EXTRA="--skip production,production_lanes,insert,batcher,datasets,config3,config4,config5,graph_equivalence,ef_sweep,vendor_gemm,peak --cpu-seconds 0 --no-verify"
 rocprofv3 --pmc FETCH_SIZE TCC_EA0_RDREQ_sum --kernel-trace --output-format csv -d /tmp/pmc_$tag -o pmc -- python bench.py --steps 6 --warmup 3 $EXTRA > /tmp/pmc_$tag.log 2>&1 || true
 f=$(find /tmp/pmc_$tag -name '*counter_collection.csv' | head -1)
 (head -1 "$f"; grep -E "hnsw_(wave|pair)_kernel" "$f") > $out/pmc_mem.csv

@@ -135,3 +135,145 @@ def test_simhash_rows_and_the_restricted_walk_skip_deleted_nodes(orc):
     q = data[5]
     rc, oid, osc, st = ix.search_restricted(q, 10, 100, allowed)
     assert rc == orc.OK and not (set(oid.tolist()) & set(dels)) and set(oid.tolist()) <= set(allowed.tolist())
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# A second, independent reading of the same Rust: plain Python containers, one statement per statement of
+# mutation.rs:1658-2055 / mod.rs:809-856, distances from the oracle's distance function only.  Small cases, pure-Python loops.
+# ------------------------------------------------------------------------------------------------------------------------
+class PyGraph:
+    def __init__(self, orc, ex, vectors_by_id, metric, kernel, m, m0):
+        self.orc, self.metric, self.kernel = orc, metric, kernel
+        self.upper_limit, self.layer0_limit = m, max(m0, 2 * m)               # MutationDegreeLimits::try_from_metadata (mutation.rs:181-196)
+        self.vec = dict(vectors_by_id)
+        self.rows = {}                                                        # (layer, id) -> sorted list
+        self.level = {}
+        for nid, (lv, l0, up) in rows_by_id(ex).items():
+            self.level[nid] = lv
+            self.rows[(0, nid)] = list(l0)
+            for l, r in enumerate(up):
+                self.rows[(l + 1, nid)] = list(r)
+        self.entry, self.max_layer = ex["entry_point"], ex["max_layer"]
+
+    def dist(self, a, b):
+        return float(self.orc.distance(self.metric, self.vec[a], self.vec[b], kernel=self.kernel))
+
+    def neighbors(self, layer, nid):                                          # load_neighbors_for_mutation: an absent row reads as empty
+        return list(self.rows.get((layer, nid), []))
+
+    def stage(self, layer, nid, neighbors):                                   # stage_neighbors_vec_for_mutation: sorted, canonical, within the limit
+        neighbors = sorted(neighbors)
+        assert len(set(neighbors)) == len(neighbors) and nid not in neighbors
+        assert len(neighbors) <= (self.layer0_limit if layer == 0 else self.upper_limit)
+        self.rows[(layer, nid)] = neighbors
+
+    def select_diverse(self, candidates, m):                                  # mod.rs:809-856; candidates = [(score, id)] sorted
+        selected = []
+        for score, c in candidates:
+            if len(selected) >= m:
+                break
+            if c not in self.vec:
+                continue
+            if all(not (self.dist(c, s) < score) for s in selected):
+                selected.append(c)
+        if len(selected) < m:
+            for score, c in candidates:
+                if len(selected) >= m:
+                    break
+                if c in self.vec and c not in selected:
+                    selected.append(c)
+        return selected
+
+    def relink_neighbor(self, layer, nb, candidates, maximum):               # mutation.rs:1916-2055
+        if nb not in self.vec:
+            return
+        old = self.neighbors(layer, nb)
+        current = list(old)
+        cd = sorted((self.dist(nb, c), c) for c in candidates if c != nb and c in self.vec)
+        for score, c in cd[:maximum]:
+            if c not in current:
+                current.append(c)
+        if len(current) > maximum:
+            ds = sorted((self.dist(nb, c), c) for c in current if c in self.vec)
+            current = self.select_diverse(ds, maximum)
+        self.stage(layer, nb, current)
+        for new in current:
+            if new in old:
+                continue
+            rev = self.neighbors(layer, new)
+            if nb in rev:
+                continue
+            rev.append(nb)
+            if len(rev) > maximum:
+                assert new in self.vec
+                ds = sorted((self.dist(new, c), c) for c in rev if c in self.vec)
+                rev = self.select_diverse(ds, maximum)
+            self.stage(layer, new, rev)
+
+    def delete_from_layer(self, node, layer, maximum, extra_sources):        # mutation.rs:1819-1888
+        outgoing = self.neighbors(layer, node)
+        mandatory = sorted(set(n for n in outgoing if n != node))
+        affected = sorted(set(mandatory) | set(s for s in extra_sources if s != node))
+        if not affected:
+            return
+        relink = set(mandatory)
+        for nb in affected:
+            row = self.neighbors(layer, nb)
+            if node in row:                                                    # remove_edge_from_neighbor
+                row.remove(node)
+                self.stage(layer, nb, row)
+                relink.add(nb)
+        relink = sorted(relink)
+        if not relink:
+            return
+        cands = set(c for c in relink if c != node)
+        for nb in relink:
+            cands |= set(c for c in self.neighbors(layer, nb) if c != node and c != nb)
+        for nb in relink:
+            self.relink_neighbor(layer, nb, cands, maximum)
+
+    def delete(self, node):                                                   # stage_delete_with_metadata, mutation.rs:1658-1774
+        if node not in self.vec:
+            return False
+        top = self.level[node]
+        reverse = {}
+        for (layer, owner), row in self.rows.items():
+            if node in row and owner != node:
+                reverse.setdefault(layer, []).append(owner)
+        layers = set(range(top + 1)) | set(reverse)
+        for layer in sorted(layers, reverse=True):
+            self.delete_from_layer(node, layer, self.layer0_limit if layer == 0 else self.upper_limit, sorted(reverse.get(layer, [])))
+        for layer in range(top + 1):
+            self.rows.pop((layer, node), None)
+        del self.vec[node]
+        del self.level[node]
+        if self.entry == node:                                                # find_best_entry_candidate: [inv_layer][node_id] key order
+            if self.level:
+                best = max(self.level.values())
+                self.entry, self.max_layer = min(n for n, l in self.level.items() if l == best), best
+            else:
+                self.entry, self.max_layer = None, 0
+        return True
+
+    def as_rows(self):
+        return {nid: (lv, self.rows[(0, nid)], [self.rows[(l, nid)] for l in range(1, lv + 1)]) for nid, lv in self.level.items()}
+
+
+@pytest.mark.parametrize("metric,dim,m,m0,kern", [(1, 12, 4, 8, "avx_fma"), (0, 40, 5, 10, "avx"), (2, 9, 3, 6, "scalar"), (1, 24, 6, 12, "neon")])
+def test_the_c_restatement_of_delete_equals_an_independent_python_reading(orc, metric, dim, m, m0, kern):
+    kernel = {"avx_fma": orc.K_AVX_FMA, "avx": orc.K_AVX, "scalar": orc.K_SCALAR, "neon": orc.K_NEON}[kern]
+    n = 260
+    ix, data, lv, ids = build(orc, n, dim, metric, m, m0, 30, seed=40 + dim, kernel=kernel)
+    py = PyGraph(orc, ix.export(), {int(ids[i]): data[i] for i in range(n)}, metric, kernel, m, m0)
+    assert py.as_rows() == rows_by_id(ix.export())
+    rng = np.random.default_rng(dim)
+    order = [int(x) for x in ids[rng.permutation(n)[:90]]]
+    order.insert(10, ix.entry()[0])                                            # the entry point among them
+    for step, d in enumerate(order):
+        want = py.delete(d)
+        rc, existed = ix.delete(d)
+        assert rc == orc.OK and existed == want
+        if step % 6 == 0 or step == len(order) - 1:
+            ex = ix.export()
+            assert py.as_rows() == rows_by_id(ex), f"rows differ after delete #{step} (node {d})"
+            assert (py.entry, py.max_layer) == ((ex["entry_point"], ex["max_layer"]) if ex["entry_point"] is not None else (None, 0))

@@ -5,7 +5,7 @@
  *
  * Builds a toy index (8 nodes on a line, dim 128 -- the smallest dimension the one-wavefront-per-query kernel serves),
  * then runs the three calls a HelixDB host makes: the strict search of the reference's golden tests, the production
- * default `SearchParams::new(k)` through hvx_search_batch_params, and a restricted search over an id list.
+ * default `SearchParams::new(k)` through hvx_search_batch_params, a restricted search over an id list, and a delete.
  * Needs an MI355X to RUN: tests/test_abi_and_host.py compiles and links it (CPU), tests/test_gpu_parity.py runs it and checks its
  * output against the oracle (-m gpu).
  */
@@ -73,6 +73,14 @@ int main(void) {
     const uint64_t allowed[3] = {100, 103, 107};
     if (check(hvx_search_restricted_batch(ix, query, 1, K, 100, allowed, NULL, 3, out_ids, out_scores, &count, NULL, NULL), "hvx_search_restricted_batch")) return 1;
     printf("restricted: %u results, nearest allowed id %llu\n", count, (unsigned long long)out_ids[0]);
+
+    /* 4. a write: VectorIndex::delete of the nearest node (unlink, relink of its neighbours, entry repair), then the same search */
+    const uint64_t gone[2] = {105, 9999};          /* an unknown id succeeds and counts as `missing` (index.rs:2263) */
+    hvx_delete_stats dstats;
+    if (check(hvx_index_delete_batch(ix, gone, 2, &dstats), "hvx_index_delete_batch")) return 1;
+    if (check(hvx_search_batch(ix, query, 1, K, 16, out_ids, out_scores, &count, NULL, NULL), "hvx_search_batch")) return 1;
+    printf("after delete: %u deleted, %u missing, %llu live rows, nearest id %llu, contains(105) = %d\n", dstats.deleted, dstats.missing,
+           (unsigned long long)hvx_index_live_rows(ix), (unsigned long long)out_ids[0], hvx_index_contains(ix, 105));
 
     hvx_index_free(ix);
     return 0;

@@ -1562,6 +1562,10 @@ def test_c_abi_example_runs_and_agrees_with_the_oracle(orc, tmp_path):
     rc, rid, rsc = oix.flat(q, k, allowed=np.array([100, 103, 107], np.uint64))
     m = re.search(r"restricted: (\d+) results, nearest allowed id (\d+)", out)
     assert m and (int(m.group(1)), int(m.group(2))) == (len(rid), int(rid[0])), out
+    assert oix.delete(105) == (orc.OK, True) and oix.delete(9999) == (orc.OK, False)          # the example's write
+    rc, did, dsc = oix.search(q, k, 16)
+    m = re.search(r"after delete: (\d+) deleted, (\d+) missing, (\d+) live rows, nearest id (\d+), contains\(105\) = (\d)", out)
+    assert m and [int(g) for g in m.groups()] == [1, 1, oix.count, int(did[0]), 0], out
 
 
 def test_restricted_device_scan_dominates_the_reference_filter_aware_walk(orc, hv):

@@ -937,6 +937,107 @@ extern "C" int hvx_index_insert_batch(hvx_index *ix, const uint64_t *node_ids, c
     return HVX_OK;
 }
 
+namespace hvx {
+__global__ void clear_dead_bit_kernel(uint32_t *dead, uint32_t row) { atomicAnd(&dead[row >> 5], ~(1u << (row & 31u))); }
+}
+
+// VectorInsertContract::Upsert (mutation.rs:642-780: an insert of an id the index already holds deletes it first, index.rs:2018-2060):
+// for every id, in order -- a LIVE id is deleted (hvx_index_delete_batch), then the vector is linked back in under the same id: into the
+// node's own row slot when the image holds one (it keeps its position in the ascending id order, so every id tie-break stays the
+// reference's), appended when the id is above every id of the image.  The node keeps the level of its slot (the reference draws the
+// level of an insert at random: any draw is a valid one); levels[i] is used for appended ids only.
+extern "C" int hvx_index_upsert_batch(hvx_index *ix, const uint64_t *node_ids, const float *vectors, const uint16_t *levels, uint32_t count,
+                                      const hvx_build_params *params, hvx_build_stats *stats) {
+    if (!ix || (count && (!node_ids || !vectors))) return fail(HVX_ERR_INVARIANT, "null argument");
+    hvx_build_params seq;
+    hvx_build_params_default(&seq);
+    if (params) seq = *params;
+    seq.sequential = 1; // one node at a time: the reference's order
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (count == 0) return HVX_OK;
+    if (ix->is_fork) return fail(HVX_ERR_UNSUPPORTED, "rows are written through the handle that owns the image, not a fork");
+    const uint32_t dim = ix->dev.dim, ld = ix->dev.ld;
+    if (ix->dev.dtype != HVX_F32) return fail(HVX_ERR_UNSUPPORTED, "rows are written into f32 images");
+    // ---- every vector is validated before anything changes (an invalid one fails the call: mutation.rs:660-690) ----
+    float *d_tmp = nullptr, *d_tmph = nullptr;
+    uint32_t *d_st = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(ix->mu);
+        HIP_TRY(hipSetDevice(ix->device));
+        hipStream_t s = ix->stream;
+        if (hipMalloc((void **)&d_tmp, (size_t)count * ld * 4) != hipSuccess || hipMalloc((void **)&d_tmph, (size_t)count * 4) != hipSuccess ||
+            hipMalloc((void **)&d_st, (size_t)count * 4) != hipSuccess) {
+            (void)hipFree(d_tmp); (void)hipFree(d_tmph); (void)hipFree(d_st);
+            return fail(HVX_ERR_DEVICE, "hipMalloc of the upsert staging rows failed");
+        }
+        std::vector<uint32_t> st(count);
+        hipError_t e = hipMemsetAsync(d_tmp, 0, (size_t)count * ld * 4, s);
+        if (e == hipSuccess) e = hipMemcpy2DAsync(d_tmp, (size_t)ld * 4, vectors, (size_t)dim * 4, (size_t)dim * 4, count, hipMemcpyDefault, s);
+        DevIndex view = ix->dev;
+        view.vec = d_tmp;
+        if (e == hipSuccess) e = launch_validate_rows(view, count, ix->limit, d_st, d_tmph, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(st.data(), d_st, (size_t)count * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        (void)hipFree(d_st); (void)hipFree(d_tmph);
+        if (e != hipSuccess) { (void)hipFree(d_tmp); return fail(HVX_ERR_DEVICE, "row validation: %s", hipGetErrorString(e)); }
+        for (uint32_t i = 0; i < count; ++i)
+            if (st[i]) { (void)hipFree(d_tmp); return fail((int)st[i], "vector of node %llu is invalid for this metric (status %u)", (unsigned long long)node_ids[i], st[i]); }
+        // ids that are neither in the image nor above it cannot be placed (rows ascend with ids)
+        const std::vector<uint64_t> &ids = ix->ids_ref();
+        uint64_t last = ids.empty() ? 0 : ids.back();
+        bool any = !ids.empty();
+        for (uint32_t i = 0; i < count; ++i) {
+            if (ix->find_slot(node_ids[i]) != kSentinel) continue;
+            if (any && node_ids[i] <= last) { (void)hipFree(d_tmp); return fail(HVX_ERR_UNSUPPORTED, "node %llu lies between the ids of the image: it has no row slot (hydrate the image again)", (unsigned long long)node_ids[i]); }
+            last = node_ids[i];
+            any = true;
+        }
+    }
+    auto done = [&](int rc) { (void)hipSetDevice(ix->device); (void)hipFree(d_tmp); return rc; };
+    uint64_t nodes = 0, batches = 0, singles = 0;
+    for (uint32_t i = 0; i < count; ++i) {
+        int rc;
+        if (ix->find(node_ids[i]) != kSentinel && (rc = hvx_index_delete_batch(ix, node_ids + i, 1, nullptr))) return done(rc); // live: the delete half
+        hvx_build_stats one{};
+        if (ix->find_slot(node_ids[i]) == kSentinel) { // above the image: an ordinary append
+            const uint16_t lv = levels ? levels[i] : 0;
+            if ((rc = hvx_index_insert_batch(ix, node_ids + i, d_tmp + (size_t)i * ld, &lv, 1, &seq, &one))) return done(rc);
+        } else { // the node's own (deleted) slot
+            std::lock_guard<std::mutex> lock(ix->mu);
+            HIP_TRY(hipSetDevice(ix->device));
+            DevIndex &d = ix->dev;
+            hipStream_t s = ix->stream;
+            const uint32_t row = ix->find_slot(node_ids[i]);
+            float *vdst = const_cast<float *>(d.vec) + (size_t)row * d.ld;
+            uint16_t lv = 0;
+            hipError_t e = hipMemcpyAsync(vdst, d_tmp + (size_t)i * ld, (size_t)ld * 4, hipMemcpyDeviceToDevice, s);
+            uint32_t *d_one = nullptr;
+            if (e == hipSuccess) e = hipMalloc((void **)&d_one, 4);
+            DevIndex view = d;
+            view.vec = vdst;
+            if (e == hipSuccess) e = launch_validate_rows(view, 1, ix->limit, d_one, const_cast<float *>(d.hdr) + row, s); // (the header of the new vector)
+            if (e == hipSuccess && ix->has_simhash) e = launch_simhash_rows(ix->d_planes_t, vdst, d.dim, d.ld, 1, ix->d_node_hash + row, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(&lv, d.level + row, 2, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess && ix->d_dead) { hipLaunchKernelGGL(clear_dead_bit_kernel, dim3(1), dim3(1), 0, s, ix->d_dead, row); e = hipGetLastError(); }
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            (void)hipFree(d_one);
+            if (e != hipSuccess) return done(fail(HVX_ERR_DEVICE, "upsert of node %llu: %s", (unsigned long long)node_ids[i], hipGetErrorString(e)));
+            auto flags = std::make_shared<std::vector<uint8_t>>(*ix->dead_p); // this generation's flags: the slot is live again
+            (*flags)[row] = 0;
+            ix->dead_p = flags;
+            ix->n_dead -= 1;
+            if ((rc = insert_range(ix, row, 1, &lv, row, &seq, 1u, d.n, &one))) return done(rc);
+            ix->desc.has_entry = 1;
+            ix->desc.entry_point = ix->ids_ref()[d.entry];
+            ix->desc.max_layer = d.max_layer;
+            ix->publish_view();
+        }
+        nodes += 1; batches += one.batches; singles += one.single_node_batches;
+    }
+    if (stats) { stats->nodes = nodes; stats->batches = batches; stats->single_node_batches = singles; }
+    return done(HVX_OK);
+}
+
 // add_bidirectional_link on layer 0 of an existing image, through build_link_wg_kernel (include/helix_vec.h): the kernel that links
 // every batched build, driven link by link so that tests can hold each prune against the oracle's select_diverse + backfill.
 extern "C" int hvx_index_link_rows(hvx_index *ix, const uint64_t *from_ids, const uint64_t *to_ids, uint32_t n_links, uint32_t concurrent) {

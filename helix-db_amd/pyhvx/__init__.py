@@ -602,6 +602,23 @@ class ValidatedVectorReadIndex:
         self.n = self.rows()
         return {"nodes": st.nodes, "batches": st.batches, "single_node_batches": st.single_node_batches}
 
+    def upsert_batch(self, node_ids, vectors, levels=None, *, ef_construction=200):
+        """hvx_index_upsert_batch: VectorInsertContract::Upsert -- a live id is deleted first, then the vector is linked in under the same
+        id (its own row slot, or appended when the id is above the image's); sequential semantics"""
+        ids = np.ascontiguousarray(node_ids, dtype=np.uint64).reshape(-1)
+        vec = np.ascontiguousarray(vectors, dtype=np.float32).reshape(ids.size, self.dim)
+        lv = None if levels is None else np.ascontiguousarray(levels, dtype=np.uint16).reshape(-1)
+        bp = BuildParams()
+        lib().hvx_build_params_default(C.byref(bp))
+        bp.ef_construction = int(ef_construction)
+        st = BuildStats()
+        L = lib()
+        L.hvx_index_upsert_batch.restype = C.c_int
+        L.hvx_index_upsert_batch.argtypes = [_vp, _vp, _vp, _vp, C.c_uint32, C.POINTER(BuildParams), C.POINTER(BuildStats)]
+        _check(L.hvx_index_upsert_batch(self._h, _ptr(ids), _ptr(vec), _ptr(lv), int(ids.size), C.byref(bp), C.byref(st)))
+        self.n = self.rows()
+        return {"nodes": st.nodes, "batches": st.batches, "single_node_batches": st.single_node_batches}
+
     def delete_batch(self, node_ids) -> dict:
         """hvx_index_delete_batch: VectorIndex::delete (mutation.rs:1606-2055) for every id in order -- unlink, relink the affected
         sources, repair the entry point; ids that are not in the image succeed and count as `missing` (index.rs:2263)"""

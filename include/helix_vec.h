@@ -661,7 +661,7 @@ int hvx_index_insert_batch(hvx_index *, const uint64_t *node_ids /*[count]*/, co
  * prefilter's candidate mapping, the SimHash directory and hvx_index_contains; hvx_index_rows still counts the slot,
  * hvx_index_live_rows does not; hvx_index_export_graph returns empty rows for it.  Same generation rules as
  * hvx_index_insert_batch: owner handle only, visible_seq + 1 per call that deleted something, forks adopt with hvx_index_refresh.
- * Its id cannot be inserted again into this image (ids ascend): an upsert of an existing id needs a re-hydrated image.
+ * Its id comes back through hvx_index_upsert_batch (into the same slot), not through hvx_index_insert_batch (ids ascend).
  * f32 images, degree limits <= 32.  HVX_ERR_UNSUPPORTED when more than 4 096 rows of one layer hold a node or their joint
  * neighbourhood exceeds 16 384 rows (after such a failure the image is partially relinked: discard the handle).
  */
@@ -673,6 +673,18 @@ typedef struct hvx_delete_stats {
     double seconds;
 } hvx_delete_stats;
 int hvx_index_delete_batch(hvx_index *, const uint64_t *node_ids /*[count]*/, uint32_t count, hvx_delete_stats *stats /*nullable*/);
+/*
+ * VectorInsertContract::Upsert (mutation.rs:642-780; index.rs:2018-2060): for every id, in order, a LIVE id is deleted first (as
+ * hvx_index_delete_batch does), then the vector is linked in under that id by the reference's sequential insertion: into the node's
+ * own row slot when the image holds one -- a deleted node keeps its slot, so the id returns to its place in the ascending id order
+ * and every id tie-break stays the reference's -- or appended when the id is above every id of the image (levels[i], NULL = 0, is
+ * used there; a revived node keeps the level of its slot: the reference's level draw is random, any draw is a valid one).  Every
+ * vector is validated before anything changes.  HVX_ERR_UNSUPPORTED for an id that lies between the image's ids without a slot.
+ * Rows equal the oracle's delete + insert of the same ids (tests/test_gpu_delete.py).
+ */
+int hvx_index_upsert_batch(hvx_index *, const uint64_t *node_ids /*[count]*/, const float *vectors /*[count][dim] host or device*/,
+                           const uint16_t *levels /*[count] or NULL*/, uint32_t count, const hvx_build_params *params /*nullable*/,
+                           hvx_build_stats *stats /*nullable*/);
 uint64_t hvx_index_live_rows(const hvx_index *);    /* rows visible to this handle that are not deleted */
 int hvx_index_contains(const hvx_index *, uint64_t node_id); /* 1 when the id holds a (live) vector in this handle's generation */
 int hvx_index_refresh(hvx_index *);                 /* adopt the image's visible generation (a fork; a no-op when nothing changed) */

@@ -227,3 +227,52 @@ def test_deletes_on_an_imported_image_the_walk_the_prefilter_and_the_batcher(orc
     assert gcnt.sum() == 0
     fid, fsc, fcnt, _ = gix.flat_search_batch(q, 10)
     assert fcnt.sum() == 0
+
+
+def test_upserts_equal_the_oracles_delete_plus_insert(orc, hv):
+    """VectorInsertContract::Upsert (index.rs:2018-2060: an insert of an id the index holds deletes it first): new vectors for live
+    ids, for an id deleted earlier, and for a fresh id above the image -- rows, entry point and searches equal the oracle's
+    delete + insert of the same ids with the same levels (a revived node keeps the level of its slot).  Refused without side
+    effects: an invalid vector anywhere in the batch, an id between the image's ids that never had a slot."""
+    rng = np.random.default_rng(515)
+    n, dim, m, m0, efc = 1200, 128, 16, 32, 100
+    data = rng.standard_normal((n + 40, dim)).astype(np.float32)
+    lv = fx.draw_levels(n + 1, m, seed=77)
+    ids = np.arange(n + 1, dtype=np.uint64) * 4 + 10
+    gix, _ = hv.ValidatedVectorReadIndex.build(dim=dim, metric=1, node_ids=ids[:n], vectors=data[:n], levels=lv[:n], m=m, m0=m0, ef_construction=efc,
+                                               sequential=True, reserve_rows=4, reserve_upper_rows=int(lv[n]) + 1)
+    oix = orc.Index(dim, orc.L2SQ, m=m, m0=m0, ef_construction=efc)
+    for i in range(n):
+        assert oix.insert(int(ids[i]), data[i], int(lv[i])) == orc.OK
+    gone = int(ids[321])
+    assert oix.delete(gone) == (orc.OK, True) and gix.delete_batch([gone])["deleted"] == 1
+    before = gix.export_graph()
+    with pytest.raises(hv.HelixDbError) as e:                                  # NaN in the second vector: nothing of the batch happens
+        gix.upsert_batch(ids[[5, 6]], np.vstack([data[n], data[n + 1] * np.float32(np.nan)]))
+    assert e.value.status == hv.ERR_NONFINITE
+    with pytest.raises(hv.HelixDbError) as e:                                  # an id in a gap of the image's ids: no slot to put it in
+        gix.upsert_batch([int(ids[10]) + 1], data[n:n + 1])
+    assert e.value.status == hv.ERR_UNSUPPORTED
+    after = gix.export_graph()
+    assert all(np.array_equal(before[k_], after[k_]) for k_ in ("l0_offsets", "l0_neighbors", "up_offsets", "up_neighbors")) and gix.live_rows() == n - 1
+    # live ids (the entry point among them), the deleted id, a fresh id
+    ent = oix.entry()[0]
+    targets = [int(x) for x in ids[rng.permutation(n)[:26]] if int(x) not in (gone, ent)][:20] + [ent, gone, int(ids[n])]
+    level_of = {int(ids[i]): int(lv[i]) for i in range(n + 1)}
+    for t, nid in enumerate(targets):
+        if oix.is_live(nid):
+            assert oix.delete(nid) == (orc.OK, True)
+        assert oix.insert(nid, data[n + 1 + t], level_of[nid]) == orc.OK
+    st = gix.upsert_batch(np.asarray(targets, np.uint64), data[n + 1: n + 1 + len(targets)], [level_of[x] for x in targets], ef_construction=efc)
+    assert st["nodes"] == len(targets) and gix.live_rows() == n + 1 == oix.count and gix.rows() == n + 1
+    assert_same_graph(gix, oix, ids, ())
+    assert all(gix.contains(x) for x in targets)
+    q = np.vstack([rng.standard_normal((12, dim)).astype(np.float32), data[n + 1: n + 5]])   # four queries ARE upserted vectors
+    gid, gsc, gcnt, _ = gix.search_batch(q, hv.SearchParams(10).with_ef(64))
+    fid, fsc, fcnt, _ = gix.flat_search_batch(q, 10)
+    for qi in range(q.shape[0]):
+        rc, oid, osc = oix.search(q[qi], 10, 64)
+        assert gid[qi, :gcnt[qi]].tolist() == oid.tolist() and bits(gsc[qi, :gcnt[qi]]).tolist() == bits(osc).tolist()
+        rc, tid, tsc = oix.flat(q[qi], 10)
+        assert fid[qi, :fcnt[qi]].tolist() == tid.tolist() and bits(fsc[qi, :fcnt[qi]]).tolist() == bits(tsc).tolist()
+    assert fid[12, 0] == targets[0] and fsc[12, 0] == 0.0                       # the new vector answers under the old id

@@ -1004,7 +1004,7 @@ extern "C" int hvx_index_upsert_batch(hvx_index *ix, const uint64_t *node_ids, c
             if ((rc = hvx_index_insert_batch(ix, node_ids + i, d_tmp + (size_t)i * ld, &lv, 1, &seq, &one))) return done(rc);
         } else { // the node's own (deleted) slot
             std::lock_guard<std::mutex> lock(ix->mu);
-            HIP_TRY(hipSetDevice(ix->device));
+            if (hipSetDevice(ix->device) != hipSuccess) return done(fail(HVX_ERR_DEVICE, "hipSetDevice failed"));
             DevIndex &d = ix->dev;
             hipStream_t s = ix->stream;
             const uint32_t row = ix->find_slot(node_ids[i]);

@@ -725,6 +725,23 @@ def leg_incremental_insert(hv, synth, args, dev, n0=500_000, add=100_000, seq=2_
                           "relinked_rows": sd["relinked_rows"], "relinked_rows_per_delete": round(sd["relinked_rows"] / max(1, sd["deleted"]), 1),
                           "entry_moves": sd["entry_moves"], "live_rows_after": ix.live_rows(), "audit": audit_d,
                           "recall_at_10_ef%d" % ef: round(recall_of(g[0], f[0], b, k), 4), "deleted_ids_in_results": leaked}
+        # ---- upserts (hvx_index_upsert_batch == VectorInsertContract::Upsert: delete + insert under the same id, into the node's own slot) ----
+        n_up = min(200, n_del)
+        live = np.setdiff1d(np.arange(n, dtype=np.uint64), victims)
+        tgt = np.concatenate([rng.choice(live, size=n_up - n_up // 4, replace=False), victims[: n_up // 4]]).astype(np.uint64)   # live ids and deleted ones
+        newv = (x[torch.from_numpy(rng.integers(0, n, n_up)).to(dev)] * 0.5 + x[torch.from_numpy(rng.integers(0, n, n_up)).to(dev)] * 0.5).cpu().numpy()
+        t0 = time.time()
+        su = ix.upsert_batch(tgt, newv, None, ef_construction=200)
+        ix.sync()
+        t_up = time.time() - t0
+        qn = torch.from_numpy(newv[:64]).to(dev)
+        fu = out_buffers(64, k, dev)
+        ix.flat_search_batch_device(qn, k, *fu[:4])
+        torch.cuda.synchronize()
+        own = int((fu[0][:, 0].cpu().numpy().astype(np.uint64) == tgt[:64]).sum())
+        out["upserts"] = {"workload": f"{n_up} upserts ({n_up - n_up // 4} live ids, {n_up // 4} ids deleted above): delete + sequential insert under the same id",
+                          "seconds": round(t_up, 3), "us_per_upsert": round(t_up / n_up * 1e6, 1), "nodes": int(su["nodes"]), "live_rows_after": ix.live_rows(),
+                          "new_vector_is_its_ids_nearest_of_64": own}
     ix.close()
     del x, q
     torch.cuda.empty_cache()
@@ -1190,7 +1207,7 @@ def compact_record(out, full_path):
             "audit_clean": _pick(ii, "audit", "clean"), "recall_at_10": next((v for k_, v in ii.items() if k_.startswith("recall_at_10")), None),
             "delete_us": _pick(ii, "deletes", "us_per_delete"),
             "recall_after_deletes": next((v for k_, v in (ii.get("deletes") or {}).items() if k_.startswith("recall_at_10")), None),
-            "deleted_ids_in_results": _pick(ii, "deletes", "deleted_ids_in_results")}
+            "deleted_ids_in_results": _pick(ii, "deletes", "deleted_ids_in_results"), "upsert_us": _pick(ii, "upserts", "us_per_upsert")}
     bt = out.get("batcher")
     if isinstance(bt, dict):
         c["batcher"] = {"error": str(bt["error"])[:160]} if "error" in bt else {k: bt.get(k) for k in ("qps", "mean_us", "p99_us", "mean_batch", "qps_production_default",

@@ -1022,6 +1022,11 @@ extern "C" int hvx_index_upsert_batch(hvx_index *ix, const uint64_t *node_ids, c
             if (e == hipSuccess) e = hipStreamSynchronize(s);
             (void)hipFree(d_one);
             if (e != hipSuccess) return done(fail(HVX_ERR_DEVICE, "upsert of node %llu: %s", (unsigned long long)node_ids[i], hipGetErrorString(e)));
+            { // caches derived from the rows' VECTORS (per-handle |x|^2, the image's bf16 shadow) are rebuilt by their next user
+                std::lock_guard<std::mutex> g(ix->shared->mu);
+                ix->shared->vec_epoch += 1;
+                ix->shared->shadow_rows = 0;
+            }
             auto flags = std::make_shared<std::vector<uint8_t>>(*ix->dead_p); // this generation's flags: the slot is live again
             (*flags)[row] = 0;
             ix->dead_p = flags;

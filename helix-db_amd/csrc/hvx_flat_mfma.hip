@@ -751,11 +751,17 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
     // the 256 x 256 filtered contraction (hvx_flat_tile.hip) serves the one-pass attempt of scans with dim % 64 == 0
     // (its query tile is 256 wide: a batch of <= 128 queries wastes less on the 128 x 128 kernel)
     const bool tile_ok = d.dim % 64u == 0u && (b > 128u || ix->opt[HVX_OPT_FLAT_FIRST_CHUNK]) && !ix->opt[HVX_OPT_FLAT_NO_TILE];
+    if (f32 && ix->m_rowterm) { // a vector that changed in place (an upsert into the node's own slot) invalidates the cached norms
+        uint64_t epoch;
+        { std::lock_guard<std::mutex> g(ix->shared->mu); epoch = ix->shared->vec_epoch; }
+        if (epoch != ix->rowterm_epoch) { ix->rowterm_rows = 0; ix->m_xmax2 = 0.f; ix->rowterm_epoch = epoch; }
+    }
     if (f32 && (!ix->m_rowterm || ix->rowterm_rows < d.n)) { // |x|^2 per row and its maximum: on first use, and for rows appended since
         if (!ix->m_rowterm) {
             if ((rc = ix->dalloc((void **)&ix->m_rowterm, std::max<size_t>(std::max<uint64_t>(ix->cap_rows, d.n), 1) * 4))) return rc;
             ix->rowterm_rows = 0;
             ix->m_xmax2 = 0.f;
+            { std::lock_guard<std::mutex> g(ix->shared->mu); ix->rowterm_epoch = ix->shared->vec_epoch; }
         }
         const uint32_t r0 = ix->rowterm_rows, cnt = d.n - r0;
         std::vector<float> h_n2(cnt);
@@ -802,6 +808,8 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
         const uint32_t kc = m + 1;
         // small batches (b <= 128): ONE pass over the rows with the register-resident kernel of hvx_flat_smallb.hip writes the
         // whole [b][n] score matrix; sliced selection + pair merge replace the chunk loop.  One-pass attempt only.
+        // (a shadow that exists may be behind the rows: appended since, or a vector replaced in place by an upsert -- it catches up here)
+        if (f32 && ix->m_shadow && !full && (rc = ensure_shadow(ix))) return rc;
         const int sb_kind = f32 ? ((ix->m_shadow && !full) ? 0 : 2) : (fp8 ? 1 : 0); // (the shadow has no lo parts: the full split reads the f32 rows)
         const bool smallb = ix->opt[HVX_OPT_FLAT_NO_SMALLB] != 1u && flat_smallb_supported(d.dim, b, sb_kind) &&
                             (size_t)((n + 3u) & ~3u) * b * 4 <= (512u << 20) && kc <= 1024u;

@@ -49,6 +49,8 @@ struct hvx_image_shared {
     uint32_t v_n_dead = 0;
     const uint32_t *v_dead_dev = nullptr;
     const void *dir_dead = nullptr;    // the deleted-row flags the SimHash directory was built without
+    uint64_t vec_epoch = 0;            // bumped when a row's VECTOR changes in place (hvx_index_upsert_batch into the node's own slot): per-handle
+                                       // row norms are rebuilt when their epoch is behind; the bf16 shadow is reconverted (shadow_rows = 0)
     uint64_t v_entry_point = 0;
     bool v_contiguous = true;
     std::shared_ptr<const std::vector<uint64_t>> v_ids;
@@ -157,6 +159,7 @@ struct hvx_index {
     size_t cap_qsplit = 0;
     float m_xmax2 = 0.f;
     uint32_t rowterm_rows = 0;       // rows m_rowterm / m_xmax2 cover
+    uint64_t rowterm_epoch = 0;      // shared->vec_epoch they were computed at
     uint32_t m_fast_misses = 0, m_fast_skipped = 0; // consecutive scans whose one-pass attempt missed a certificate / scans that skipped it
     // non-strict search arms (hvx_params.hip): per-node SimHash rows, the hasher, per-batch fingerprints
     bool has_simhash = false;

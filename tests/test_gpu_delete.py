@@ -276,3 +276,29 @@ def test_upserts_equal_the_oracles_delete_plus_insert(orc, hv):
         rc, tid, tsc = oix.flat(q[qi], 10)
         assert fid[qi, :fcnt[qi]].tolist() == tid.tolist() and bits(fsc[qi, :fcnt[qi]]).tolist() == bits(tsc).tolist()
     assert fid[12, 0] == targets[0] and fsc[12, 0] == 0.0                       # the new vector answers under the old id
+
+
+def test_an_upsert_into_a_slot_refreshes_the_caches_of_the_matrix_core_scan(orc, hv):
+    """The exact scan on the matrix cores keeps |x|^2 per row (per handle) and a bf16 shadow of the f32 rows (per image).  A vector
+    replaced IN PLACE by an upsert must reach both before the next scan: the 64-query streaming kernel reads candidates from the
+    shadow, and its certificate is computed from the row norms (found by bench.py's upsert phase: 0 of 64 new vectors came back
+    as their ids' nearest neighbours before the epoch on the image existed)."""
+    rng = np.random.default_rng(99)
+    n, dim = 40000, 256
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    ids = np.arange(n, dtype=np.uint64) + 1
+    gix, _ = hv.ValidatedVectorReadIndex.build(dim=dim, metric=1, node_ids=ids, vectors=data, levels=fx.draw_levels(n, 16, seed=4), m=16, m0=32,
+                                               ef_construction=100, search_max_batch=1024)
+    warm = data[rng.integers(0, n, 1024)] + np.float32(0.01)
+    gix.flat_search_batch(warm, 10)                      # 1 024 queries: the tile kernels build the shadow and the row norms
+    rows_at = [5, 77, 4000, n - 1]
+    newv = (rng.standard_normal((4, dim)) * 3).astype(np.float32)
+    gix.upsert_batch(ids[rows_at], newv)
+    rows = data.copy()
+    rows[rows_at] = newv
+    q = np.vstack([newv, rng.standard_normal((60, dim)).astype(np.float32)])
+    fid, fsc, fcnt, _ = gix.flat_search_batch(q, 10)     # 64 queries: the one-pass streaming kernel over the shadow
+    for qi in range(q.shape[0]):
+        rc, oid, osc = orc.flat_matrix(orc.L2SQ, rows, q[qi], 10, kernel=orc.K_AVX_FMA_HW)
+        assert rc == orc.OK and fid[qi, :fcnt[qi]].tolist() == (oid.astype(np.int64) + 1).tolist() and bits(fsc[qi, :fcnt[qi]]).tolist() == bits(osc).tolist()
+    assert fid[:4, 0].tolist() == ids[rows_at].tolist() and (fsc[:4, 0] == 0).all()

@@ -506,7 +506,7 @@ bool hvx_index::adopt_view() {
 
 // the ascending list of live rows of this handle's generation (exact scans over "all rows" of an image with deleted nodes)
 int hvx_index::ensure_live() {
-    if (f_live && live_for == (const void *)dead_p.get() && live_rows_n == dev.n - n_dead) return HVX_OK;
+    if (f_live && live_valid && live_for == dead_p && live_rows_n == dev.n - n_dead) return HVX_OK;
     std::vector<uint32_t> rows;
     rows.reserve(dev.n);
     const std::vector<uint8_t> *dd = dead_p.get();
@@ -522,7 +522,8 @@ int hvx_index::ensure_live() {
         if (hipMemcpyAsync(f_live, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
             return hvx::fail(HVX_ERR_DEVICE, "upload of the live-row list failed");
     }
-    live_for = dead_p.get();
+    live_for = dead_p;
+    live_valid = true;
     live_rows_n = (uint32_t)rows.size();
     return HVX_OK;
 }
@@ -565,6 +566,7 @@ extern "C" int hvx_index_fork(const hvx_index *parent, hvx_index **out) {
     ix->occupancy = src->occupancy;
     memcpy(ix->opt, src->opt, sizeof(ix->opt));
     ix->is_fork = true;
+    ix->seen_rewrite = src->seen_rewrite;
     ix->image = src->image;
     ix->image.push_back(src->allocs);
     ix->m_rowterm = src->m_rowterm;
@@ -687,7 +689,7 @@ int hvx::check_k_ef(uint32_t k, uint32_t ef) {
     // SearchBeamWidth::try_new has no upper bound (parameters.rs:118-133).  Beams of ef + 32 <= 1024 entries run on the HNSW kernels; a
     // wider beam is answered by the EXACT scan of the index (enqueue_search): the true top-k, which is what a beam of that width
     // converges to -- the same fall-back the restricted path takes beyond its LDS limits.  The scan serves k <= 1024.
-    if (ef + 32 > 1024 && k > 1024) return fail(HVX_ERR_UNSUPPORTED, "result count %u exceeds the exact scan's limit of 1024 (beams beyond ef 992 are answered by the exact scan)", k);
+    if (ef > 992u && k > 1024) return fail(HVX_ERR_UNSUPPORTED, "result count %u exceeds the exact scan's limit of 1024 (beams beyond ef 992 are answered by the exact scan)", k);
     return HVX_OK;
 }
 
@@ -729,7 +731,8 @@ int hvx::enqueue_search(const hvx_index *cix, const float *d_queries, uint32_t b
                         uint64_t *d_ids, float *d_scores, uint32_t *d_counts, uint32_t *d_status,
                         hvx_query_stats *d_qstats, bool timed, const AdaptArgs *ad) {
     hvx_index *ix = const_cast<hvx_index *>(cix);
-    if (ef + 32u > 1024u) { // beyond the widest beam of the HNSW kernels: the exact scan (see check_k_ef); validation happens inside it
+    ix->sync_rewrites();
+    if (ef > 992u) { // beyond the widest beam of the HNSW kernels: the exact scan (see check_k_ef); validation happens inside it
         int rc = flat_scan_device(ix, d_queries, b, k, nullptr, ix->dev.n, d_ids, d_scores, d_counts, d_status ? d_status : ix->d_qstatus, timed);
         if (rc) return rc;
         hipLaunchKernelGGL(exact_fallback_stats_kernel, dim3((b + 255u) / 256u), dim3(256), 0, ix->stream, d_qstats ? d_qstats : ix->d_qstats, ix->d_tie,
@@ -980,6 +983,7 @@ int hvx::flat_scan_device(hvx_index *ix, const float *d_queries, uint32_t b, uin
                           uint32_t *d_status, bool timed) {
     if (k == 0) return fail(HVX_ERR_K_RANGE, "result count must be non-zero");
     if (k > 1024) return fail(HVX_ERR_UNSUPPORTED, "flat scan supports k <= 1024");
+    if (!d_subset) ix->sync_rewrites(); // (a restricted row list was resolved against the caller's generation: the callers sync before they resolve)
     if (!d_subset && ix->n_dead) { // "all rows" of an image with deleted nodes = its live rows (a deleted node has no item row: mutation.rs:1708-1745)
         int rc = ix->ensure_live();
         if (rc) return rc;

@@ -1036,6 +1036,7 @@ extern "C" int hvx_index_upsert_batch(hvx_index *ix, const uint64_t *node_ids, c
             ix->desc.entry_point = ix->ids_ref()[d.entry];
             ix->desc.max_layer = d.max_layer;
             ix->publish_view();
+            ix->seen_rewrite = ix->shared->rewrite_epoch.fetch_add(1, std::memory_order_acq_rel) + 1;
         }
         nodes += 1; batches += one.batches; singles += one.single_node_batches;
     }

@@ -746,7 +746,10 @@ extern "C" int hvx_index_delete_batch(hvx_index *ix, const uint64_t *node_ids, u
     ix->desc.has_entry = d.has_entry;
     ix->desc.max_layer = d.max_layer;
     ix->desc.entry_point = d.has_entry ? ix->ids_ref()[d.entry] : 0;
-    if (deleted) ix->publish_view();
+    if (deleted) {
+        ix->publish_view();
+        ix->seen_rewrite = ix->shared->rewrite_epoch.fetch_add(1, std::memory_order_acq_rel) + 1; // lanes adopt this generation at their next launch
+    }
     if (stats) {
         stats->deleted = deleted;
         stats->missing = missing;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <memory>
 #include <mutex>
@@ -48,9 +49,17 @@ struct hvx_image_shared {
     std::shared_ptr<const std::vector<uint8_t>> v_dead;
     uint32_t v_n_dead = 0;
     const uint32_t *v_dead_dev = nullptr;
-    const void *dir_dead = nullptr;    // the deleted-row flags the SimHash directory was built without
+    // the deleted-row flags the SimHash directory was built without.  Held, not just compared (round 6): a flags vector freed by
+    // an in-slot upsert can be handed the same address again by the next delete -- a raw pointer + the live-row count then matched a
+    // DIFFERENT generation (delete A, scan, upsert A, delete B) and the stale directory was reused
+    std::shared_ptr<const std::vector<uint8_t>> dir_dead;
     uint64_t vec_epoch = 0;            // bumped when a row's VECTOR changes in place (hvx_index_upsert_batch into the node's own slot): per-handle
                                        // row norms are rebuilt when their epoch is behind; the bf16 shadow is reconverted (shadow_rows = 0)
+    // In-place REWRITES of the shared rows (hvx_index_delete_batch relinks rows and empties the node's own; an in-slot upsert replaces a
+    // vector): unlike appended rows they cannot be hidden from a handle that still shows an older generation -- its entry point may be
+    // the deleted node, whose rows are now empty (round 6).  The owner bumps this word with the publish; every handle
+    // compares it at the top of each search / scan entry point and adopts the visible generation first (hvx_index::sync_rewrites).
+    std::atomic<uint64_t> rewrite_epoch{0};
     uint64_t v_entry_point = 0;
     bool v_contiguous = true;
     std::shared_ptr<const std::vector<uint64_t>> v_ids;
@@ -89,6 +98,11 @@ struct hvx_index {
     uint64_t cap_rows = 0, cap_up_rows = 0, up_rows_used = 0, seen_seq = 0;
     void publish_view(bool bump = true); // owner: this handle's view becomes the image's visible generation (visible_seq + 1 when bump)
     bool adopt_view();     // any handle: take the image's visible generation; true if the view changed
+    uint64_t seen_rewrite = 0;
+    void sync_rewrites() { // rows of the image were rewritten in place since this handle last looked: its generation is gone
+        const uint64_t e = shared->rewrite_epoch.load(std::memory_order_acquire);
+        if (e != seen_rewrite) { (void)adopt_view(); seen_rewrite = e; }
+    }
     std::shared_ptr<const std::vector<uint64_t>> ids_p = std::make_shared<std::vector<uint64_t>>(); // host copy of node ids
     const std::vector<uint64_t> &ids_ref() const { return *ids_p; }
     bool contiguous = false;
@@ -98,7 +112,8 @@ struct hvx_index {
     uint32_t n_dead = 0;
     uint32_t *d_dead = nullptr;      // owner: the image's device bitmap (one bit per row of capacity), allocated by the first delete
     uint32_t *f_live = nullptr;      // live rows ascending, built on demand for the generation in `live_for`
-    const void *live_for = nullptr;
+    std::shared_ptr<const std::vector<uint8_t>> live_for; // (held: its address cannot be recycled while this list is cached)
+    bool live_valid = false;
     uint32_t live_rows_n = 0, cap_live = 0;
     int ensure_live();               // f_live / live_rows_n for this handle's generation
     uint32_t live_rows() const { return dev.n - n_dead; }
@@ -174,6 +189,13 @@ struct hvx_index {
     uint32_t *w_allowed = nullptr, *w_seen = nullptr, *w_samples = nullptr, *w_rows = nullptr;
     void *w_plans = nullptr, *w_counters = nullptr;
     size_t cap_w_allowed = 0, cap_w_seen = 0, cap_w_samples = 0, cap_w_rows = 0, cap_w_q = 0;
+    // one-launch restricted exact scan (hvx_restricted_exact.hip): the slices' result lists, the self-cleaning "invalid score" / "workgroups
+    // done" words, and the per-query candidate id lists of a batch (external ids + CSR offsets)
+    float *x_part_sc = nullptr;
+    uint32_t *x_part_row = nullptr, *x_bad = nullptr, *x_done = nullptr;
+    uint64_t *x_ids = nullptr, *x_off = nullptr;
+    size_t cap_x_part = 0, cap_x_ids = 0, cap_x_off = 0;
+    uint32_t cap_x_ctl = 0;
 
     int dalloc(void **p, size_t bytes);
     int regrow(void **p, size_t bytes);   // dalloc after releasing *p (scratch buffers that grow)
@@ -246,4 +268,14 @@ hipError_t launch_bf16_row_norm2(const uint16_t *rows, uint32_t n, uint32_t dim,
 int flat_scan_host(hvx_index *ix, const float *queries, uint32_t b, uint32_t k, const uint32_t *d_subset,
                    uint32_t n_rows, uint64_t *out_ids, float *out_scores, uint32_t *out_counts,
                    uint32_t *out_status, hvx_stats *stats);
+// the one-launch restricted exact scan (hvx_restricted_exact.hip): k <= 64 over f32 / bf16 rows of a non-empty image
+bool restricted_direct_supported(const hvx_index *ix, uint32_t k);
+int restricted_direct_enqueue(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, uint32_t k_stride, const uint32_t *d_rows,
+                              uint32_t n_rows, const uint64_t *d_ext_ids, const uint64_t *d_offsets, uint32_t max_set, uint64_t *d_ids,
+                              float *d_scores, uint32_t *d_counts, uint32_t *d_status);
+hipError_t launch_stage_queries(const float *src, float *dst, uint32_t dim, uint32_t b, hipStream_t s);
+// hvx_search_restricted_batch_params behind the handle's lock (hvx_restricted_walk.hip)
+int restricted_search_host(hvx_index *ix, const float *queries, uint32_t b, const hvx_restricted_params &rp, const uint64_t *allowed_ids,
+                           const uint64_t *allowed_offsets, uint64_t n_allowed, uint64_t *out_ids, float *out_scores, uint32_t *out_counts,
+                           uint32_t *out_status, hvx_restricted_stats *out_rstats, hvx_stats *stats);
 } // namespace hvx

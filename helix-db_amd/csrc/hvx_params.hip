@@ -217,7 +217,7 @@ static int project_params(hvx_index *ix, const hvx_search_params *p, AdaptArgs *
 static int enqueue_params(hvx_index *ix, const float *d_queries, uint32_t b, const hvx_search_params *p, const AdaptArgs *ad,
                           bool strict, uint64_t *d_ids, float *d_scores, uint32_t *d_counts, uint32_t *d_status,
                           hvx_query_stats *d_qstats, hvx_adaptive_stats *d_astats, bool timed) {
-    if (strict || p->ef + 32u > 1024u) { // (beams beyond the kernels' widest are answered by the exact scan: no filter / sampling stage runs)
+    if (strict || p->ef > 992u) { // (beams beyond the kernels' widest are answered by the exact scan: no filter / sampling stage runs)
         if (d_astats) HIP_TRY(hipMemsetAsync(d_astats, 0, (size_t)b * sizeof(hvx_adaptive_stats), ix->stream));
         return enqueue_search(ix, d_queries, b, p->k, p->ef, d_ids, d_scores, d_counts, d_status, d_qstats, timed);
     }
@@ -231,6 +231,7 @@ static int enqueue_params(hvx_index *ix, const float *d_queries, uint32_t b, con
 // project + enqueue for a caller that already holds the handle's lock (hvx_shard.hip)
 int hvx::enqueue_search_params(hvx_index *ix, const float *d_queries, uint32_t b, const hvx_search_params *params, uint64_t *d_ids, float *d_scores,
                                uint32_t *d_counts, uint32_t *d_status) {
+    ix->sync_rewrites();
     AdaptArgs ad;
     bool strict = false;
     int rc = project_params(ix, params, &ad, &strict);
@@ -245,6 +246,7 @@ extern "C" int hvx_search_batch_params_device(const hvx_index *cix, const float 
     if (!cix || !params) return fail(HVX_ERR_INVARIANT, "null argument");
     hvx_index *ix = const_cast<hvx_index *>(cix);
     std::lock_guard<std::mutex> lock(ix->mu);
+    ix->sync_rewrites();
     HIP_TRY(hipSetDevice(ix->device));
     AdaptArgs ad;
     bool strict = false;
@@ -265,6 +267,7 @@ extern "C" int hvx_search_batch_params(const hvx_index *cix, const float *querie
     if (!cix || !params) return fail(HVX_ERR_INVARIANT, "null argument");
     hvx_index *ix = const_cast<hvx_index *>(cix);
     std::lock_guard<std::mutex> lock(ix->mu);
+    ix->sync_rewrites();
     HIP_TRY(hipSetDevice(ix->device));
     AdaptArgs ad;
     bool strict = false;

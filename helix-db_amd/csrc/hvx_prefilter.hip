@@ -871,57 +871,6 @@ extern "C" int hvx_traverse_dfs(const hvx_csr *cg, const uint64_t *seeds, uint32
 // result is the exact answer that the reference's ACORN-style walk (restricted.rs:837-1148)
 // approximates (recall gate >= 0.92/0.95).  See DESIGN.md "restricted search".
 // ---------------------------------------------------------------------------------------------
-static int restricted_one(hvx_index *ix, const float *queries, uint32_t b, uint32_t k, const uint64_t *allowed,
-                          uint64_t n_allowed, uint64_t *out_ids, float *out_scores, uint32_t *out_counts,
-                          uint32_t *out_status, hvx_stats *stats) {
-    // RestrictedVectorCandidates::from_ids (restricted.rs:356-371): dedupe, cap 1,000,000
-    std::vector<uint64_t> ids(allowed, allowed + n_allowed);
-    std::sort(ids.begin(), ids.end());
-    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
-    if (ids.size() > 1000000) return fail(HVX_ERR_CANDIDATE_LIMIT, "restricted vector search accepts at most 1000000 unique candidates");
-    for (uint32_t q = 0; q < b; ++q) {
-        out_counts[q] = 0;
-        if (out_status) out_status[q] = HVX_OK;
-    }
-    if (ids.empty()) return HVX_OK; // RestrictedVectorCandidates::Empty => no results, before any validation
-    // RestrictedResultCount::try_new (restricted.rs:200-213)
-    const uint32_t kk = (uint32_t)std::min<uint64_t>(k, ids.size());
-    if (kk == 0) return fail(HVX_ERR_K_RANGE, "result count must be non-zero");
-    if (kk > 800) return fail(HVX_ERR_K_RANGE, "restricted vector search result count %u is above the maximum 800", kk);
-    // ids that are not indexed are omitted (restricted.rs:615-659; tests .../restricted.rs:788-800)
-    std::vector<uint32_t> subset;
-    subset.reserve(ids.size());
-    for (uint64_t id : ids) {
-        uint32_t x = ix->find(id);
-        if (x != kSentinel) subset.push_back(x);
-    }
-    // query validation happens before the empty-index / empty-subset outcome (restricted.rs:556-567)
-    int rc;
-    if (subset.size() > ix->cap_subset) {
-        if ((rc = ix->regrow((void **)&ix->f_subset, subset.size() * 4))) return rc;
-        ix->cap_subset = subset.size();
-    }
-    if (!subset.empty())
-        HIP_TRY(hipMemcpyAsync(ix->f_subset, subset.data(), subset.size() * 4, hipMemcpyHostToDevice, ix->stream));
-    std::vector<uint64_t> t_ids((size_t)b * kk);
-    std::vector<float> t_sc((size_t)b * kk);
-    std::vector<uint32_t> t_cnt(b), t_st(b);
-    rc = flat_scan_host(ix, queries, b, kk, ix->f_subset, (uint32_t)subset.size(), t_ids.data(), t_sc.data(),
-                        t_cnt.data(), t_st.data(), stats);
-    if (rc) return rc;
-    for (uint32_t q = 0; q < b; ++q) {
-        if (t_st[q]) {
-            if (!out_status) return fail((int)t_st[q], "query %u rejected with status %u", q, t_st[q]);
-            out_status[q] = t_st[q];
-            continue;
-        }
-        out_counts[q] = t_cnt[q];
-        memcpy(out_ids + (size_t)q * k, t_ids.data() + (size_t)q * kk, (size_t)t_cnt[q] * 8);
-        memcpy(out_scores + (size_t)q * k, t_sc.data() + (size_t)q * kk, (size_t)t_cnt[q] * 4);
-    }
-    return HVX_OK;
-}
-
 extern "C" int hvx_search_restricted_batch(const hvx_index *cix, const float *queries, uint32_t b, uint32_t k,
                                            uint32_t ef, const uint64_t *allowed_ids, const uint64_t *allowed_offsets,
                                            uint64_t n_allowed, uint64_t *out_ids, float *out_scores,
@@ -932,17 +881,14 @@ extern "C" int hvx_search_restricted_batch(const hvx_index *cix, const float *qu
     if (ef < k) return fail(HVX_ERR_K_RANGE, "search beam width %u is below the result count %u", ef, k);
     if (b == 0) return HVX_OK;
     std::lock_guard<std::mutex> lock(ix->mu);
+    ix->sync_rewrites();
     HIP_TRY(hipSetDevice(ix->device));
-    if (!allowed_offsets)
-        return restricted_one(ix, queries, b, k, allowed_ids, n_allowed, out_ids, out_scores, out_counts, out_status, stats);
-    for (uint32_t q = 0; q < b; ++q) {
-        const uint64_t a0 = allowed_offsets[q], a1 = allowed_offsets[q + 1];
-        int rc = restricted_one(ix, queries + (size_t)q * ix->dev.dim, 1, k, allowed_ids + a0, a1 - a0,
-                                out_ids + (size_t)q * k, out_scores + (size_t)q * k, out_counts + q,
-                                out_status ? out_status + q : nullptr, stats);
-        if (rc) return rc;
-    }
-    return HVX_OK;
+    hvx_restricted_params rp; // this entry point answers every candidate-set size with the exact gathered scan
+    memset(&rp, 0, sizeof(rp));
+    rp.k = k;
+    rp.ef = ef;
+    rp.strategy = HVX_RESTRICTED_EXACT;
+    return restricted_search_host(ix, queries, b, rp, allowed_ids, allowed_offsets, n_allowed, out_ids, out_scores, out_counts, out_status, nullptr, stats);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1100,7 +1046,7 @@ extern "C" int hvx_prefilter_search_batch_params(const hvx_index *cix, const hvx
                                                  uint32_t *out_counts, uint32_t *out_status, uint64_t *out_candidates,
                                                  hvx_restricted_stats *out_restricted_stats, hvx_stats *stats) {
     if (!params) return fail(HVX_ERR_INVARIANT, "null argument");
-    if (params->strategy > HVX_RESTRICTED_FILTERED) return fail(HVX_ERR_INVARIANT, "unknown restricted strategy %u", params->strategy);
+    if (params->strategy > HVX_RESTRICTED_REFERENCE_PLAN) return fail(HVX_ERR_INVARIANT, "unknown restricted strategy %u", params->strategy);
     return prefilter_search_impl(cix, cg, queries, b, *params, mode, seeds, n_seeds, max_depth, direction, allowed_label_ids, n_labels, hub_degree,
                                  include_seeds, out_ids, out_scores, out_counts, out_status, out_candidates, out_restricted_stats, stats);
 }
@@ -1128,6 +1074,7 @@ static int prefilter_search_impl(const hvx_index *cix, const hvx_csr *cg, const 
     if (mode == HVX_PREFILTER_EXPAND && n_seeds == 0) return HVX_OK; // an empty stream expands to nothing
     std::lock_guard<std::mutex> glock(g->mu);
     std::lock_guard<std::mutex> lock(ix->mu);
+    ix->sync_rewrites();
     int rc = run_bfs_locked(g, seeds, n_seeds, mode == HVX_PREFILTER_EXPAND ? 1u : max_depth, direction, allowed_label_ids, n_labels,
                             mode == HVX_PREFILTER_EXPAND ? 0u : hub_degree, mode == HVX_PREFILTER_EXPAND ? 0u : include_seeds,
                             mode == HVX_PREFILTER_EXPAND, nullptr, nullptr, ix->stream);

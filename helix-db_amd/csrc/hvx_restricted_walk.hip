@@ -287,8 +287,20 @@ int make_plan(const hvx_restricted_params &rp, uint64_t candidates, uint32_t dim
     const uint64_t kk = std::min<uint64_t>(rp.k, candidates);
     hp.p.k = (uint32_t)kk;
     hp.p.directory_enabled = rp.directory_enabled ? 1u : 0u;
-    const bool exact_ok = candidates <= 256 && candidates * (uint64_t)dim * 4ull <= 4ull * 1024 * 1024;
-    if (rp.strategy == HVX_RESTRICTED_EXACT || (rp.strategy == HVX_RESTRICTED_AUTO && exact_ok && !rp.explicit_budgets)) {
+    const bool planned = rp.strategy == HVX_RESTRICTED_AUTO || rp.strategy == HVX_RESTRICTED_REFERENCE_PLAN;
+    // the reference's line (restricted.rs:426-453): 256 ids / 4 MiB of f32 payload -- drawn where a CPU that pays a KV get per row stops
+    // winning with a scan
+    bool exact_ok = candidates <= 256 && candidates * (uint64_t)dim * 4ull <= 4ull * 1024 * 1024;
+    // the DEVICE's line (round 6, HVX_RESTRICTED_AUTO): an exact gathered scan costs candidates x row bytes / ~4 TB/s + one launch, the
+    // filter-aware walk 0.3 - 0.9 ms per 32-query batch and ~3.4 us per query with the chip full (profiles/r05w_bench_full.json config3:
+    // exact 8 - 15 us per query at 100 - 100 000 candidates, walk 10 - 46 us, with recall 0.19 / 0.85 at 1 000 / 10 000 candidates on the
+    // clustered stand-in) -- the scan wins until the candidate rows take about a GiB, and it is exact
+    if (rp.strategy == HVX_RESTRICTED_AUTO && ix) {
+        const uint64_t row_bytes = (uint64_t)dim * (ix->dev.dtype == HVX_F32 ? 4u : (ix->dev.dtype == HVX_BF16 ? 2u : 1u));
+        const uint64_t limit = (uint64_t)(ix->opt[HVX_OPT_RESTRICTED_EXACT_MIB] ? ix->opt[HVX_OPT_RESTRICTED_EXACT_MIB] : 1024u) << 20;
+        exact_ok = exact_ok || candidates * row_bytes <= limit;
+    }
+    if (rp.strategy == HVX_RESTRICTED_EXACT || (planned && exact_ok && !rp.explicit_budgets)) {
         hp.strategy = HVX_RESTRICTED_EXACT;
         *out = hp;
         return HVX_OK;
@@ -314,7 +326,7 @@ int make_plan(const hvx_restricted_params &rp, uint64_t candidates, uint32_t dim
     }
     const bool beyond = hp.p.vector_payloads > walk::kScoredCap || hp.p.sampled_seeds > walk::kSeedCap || hp.p.directory_seeds > walk::kSeedCap ||
                         hp.p.bridge_rows > kMaxBridgeRows;
-    if (rp.strategy == HVX_RESTRICTED_AUTO && !rp.explicit_budgets && (beyond || (ix && !walk_supported(ix)))) {
+    if (planned && !rp.explicit_budgets && (beyond || (ix && !walk_supported(ix)))) {
         HostPlan ex{};
         ex.p.k = hp.p.k;
         ex.p.directory_enabled = hp.p.directory_enabled;
@@ -407,7 +419,7 @@ int ensure_directory(hvx_index *ix) {
         live = ix->f_live;
     }
     std::lock_guard<std::mutex> lock(sh.mu);
-    if (sh.dir_code && sh.dir_for == ix->d_node_hash && sh.dir_rows == ix->live_rows() && sh.dir_dead == (const void *)ix->dead_p.get())
+    if (sh.dir_code && sh.dir_for == ix->d_node_hash && sh.dir_rows == ix->live_rows() && sh.dir_dead == ix->dead_p)
         return HVX_OK; // (an image that has grown, or lost nodes, gets a new directory)
     const uint32_t n = ix->live_rows(), n1 = std::max<uint32_t>(n, 1);
     hipStream_t s = ix->stream;
@@ -446,7 +458,7 @@ int ensure_directory(hvx_index *ix) {
     release();
     sh.dir_for = ix->d_node_hash;
     sh.dir_rows = n;
-    sh.dir_dead = ix->dead_p.get();
+    sh.dir_dead = ix->dead_p;
     return HVX_OK;
 }
 
@@ -566,6 +578,132 @@ int walk_shared_set(hvx_index *ix, const float *queries, uint32_t b, uint32_t k_
     return HVX_OK;
 }
 
+
+// ---- the one-launch exact scan (hvx_restricted_exact.hip) behind the host-pointer entry points ----
+// Which exact scan serves a SHARED candidate set: the reference-order kernel costs b x rows x dim packed FMAs (every row is scored against
+// every query on the vector ALUs), the matrix-core pipeline one pass over the rows plus ~60 us of selection / re-rank / certificate
+// launches.  32 queries x 10 000 x 1536: 25 us against 64; 32 x 100 000 x 1536: ~250 us against ~190 -- the line is drawn at 2^31.
+bool use_direct(const hvx_index *ix, uint32_t b, uint32_t k, uint32_t n_rows) {
+    if (ix->opt[HVX_OPT_RESTRICTED_DIRECT] == 1u || n_rows == 0 || !restricted_direct_supported(ix, k)) return false;
+    if (ix->opt[HVX_OPT_RESTRICTED_DIRECT] == 2u) return true;
+    return (uint64_t)b * n_rows * ix->dev.dim <= (1ull << 31);
+}
+
+// pinned mirror layout of one chunk: queries | ids | scores | counts | status (the kernels write the four outputs THERE: mapped host rows)
+struct PinView { float *q; uint64_t *ids; float *sc; uint32_t *cnt, *st; };
+int pin_view(hvx_index *ix, uint32_t cb, uint32_t k, PinView *v) {
+    const size_t qb = (((size_t)cb * ix->dev.dim * 4) + 63u) & ~(size_t)63u, n = (size_t)cb * k;
+    int rc = ix->pin(qb + n * 12 + (size_t)cb * 8);
+    if (rc) return rc;
+    v->q = reinterpret_cast<float *>(ix->h_pin);
+    v->ids = reinterpret_cast<uint64_t *>(ix->h_pin + qb);
+    v->sc = reinterpret_cast<float *>(ix->h_pin + qb + n * 8);
+    v->cnt = reinterpret_cast<uint32_t *>(ix->h_pin + qb + n * 12);
+    v->st = v->cnt + cb;
+    return HVX_OK;
+}
+
+// queries -> pinned mirror -> (copy kernel) device rows, validation; afterwards s_queries / d_qstatus / d_qhdr describe the chunk
+int stage_and_validate(hvx_index *ix, const float *queries, uint32_t cb, const PinView &v) {
+    memcpy(v.q, queries, (size_t)cb * ix->dev.dim * 4);
+    HIP_TRY(launch_stage_queries(v.q, ix->s_queries, ix->dev.dim, cb, ix->stream));
+    HIP_TRY(launch_validate_queries(ix->dev, ix->s_queries, cb, ix->limit, ix->d_qstatus, ix->d_qhdr, ix->stream));
+    return HVX_OK;
+}
+
+int direct_shared_host(hvx_index *ix, const float *queries, uint32_t b, uint32_t k, const uint32_t *d_rows, uint32_t n_rows, uint64_t *out_ids,
+                       float *out_scores, uint32_t *out_counts, uint32_t *out_status, hvx_stats *stats) {
+    int rc;
+    const uint32_t mb = ix->max_batch;
+    for (uint32_t c0 = 0; c0 < b; c0 += mb) {
+        const uint32_t cb = std::min(mb, b - c0);
+        if ((rc = ix->stage(cb, k))) return rc;
+        PinView v;
+        if ((rc = pin_view(ix, cb, k, &v))) return rc;
+        if ((rc = stage_and_validate(ix, queries + (size_t)c0 * ix->dev.dim, cb, v))) return rc;
+        if (stats) HIP_TRY(hipEventRecord(ix->ev0, ix->stream));
+        if ((rc = restricted_direct_enqueue(ix, ix->s_queries, cb, k, k, d_rows, n_rows, nullptr, nullptr, 0, v.ids, v.sc, v.cnt, v.st))) return rc;
+        if (stats) HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
+        HIP_TRY(hipStreamSynchronize(ix->stream));
+        memcpy(out_ids + (size_t)c0 * k, v.ids, (size_t)cb * k * 8);
+        memcpy(out_scores + (size_t)c0 * k, v.sc, (size_t)cb * k * 4);
+        memcpy(out_counts + c0, v.cnt, (size_t)cb * 4);
+        memcpy(out_status + c0, v.st, (size_t)cb * 4);
+        if (stats) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
+            stats->queries += cb;
+            stats->vectors_loaded += (uint64_t)cb * n_rows;
+            stats->distance_computations += (uint64_t)cb * n_rows;
+            stats->device_ms += ms;
+        }
+    }
+    return HVX_OK;
+}
+
+// Every query with ITS OWN candidate list (allowed_offsets), all answered by the exact strategy: ONE launch per chunk of max_batch queries.
+// Returns -1 when a list needs the host's attention first (more than 1 000 000 entries: duplicates decide whether the set is too big),
+// after which the caller serves the batch list by list.
+int direct_per_query_host(hvx_index *ix, const float *queries, uint32_t b, const hvx_restricted_params &rp, const uint64_t *allowed_ids,
+                          const uint64_t *allowed_offsets, uint64_t *out_ids, float *out_scores, uint32_t *out_counts, uint32_t *out_status,
+                          hvx_restricted_stats *rstats, hvx_stats *stats) {
+    int rc;
+    const uint32_t mb = ix->max_batch, k = rp.k;
+    std::vector<uint64_t> off;
+    for (uint32_t c0 = 0; c0 < b; c0 += mb) {
+        const uint32_t cb = std::min(mb, b - c0);
+        const uint64_t a0 = allowed_offsets[c0], a1 = allowed_offsets[c0 + cb];
+        off.assign((size_t)cb + 1, 0);
+        uint64_t max_set = 0;
+        for (uint32_t q = 0; q <= cb; ++q) off[q] = allowed_offsets[c0 + q] - a0;
+        for (uint32_t q = 0; q < cb; ++q) max_set = std::max<uint64_t>(max_set, off[q + 1] - off[q]);
+        if ((rc = ix->stage(cb, k))) return rc;
+        PinView v;
+        if ((rc = pin_view(ix, cb, k, &v))) return rc;
+        const uint64_t n_ids = a1 - a0;
+        if (n_ids > ix->cap_x_ids) {
+            if ((rc = ix->regrow((void **)&ix->x_ids, std::max<size_t>(n_ids, 1) * 8))) return rc;
+            ix->cap_x_ids = n_ids;
+        }
+        if ((size_t)cb + 1 > ix->cap_x_off) {
+            if ((rc = ix->regrow((void **)&ix->x_off, ((size_t)mb + 1) * 8))) return rc;
+            ix->cap_x_off = (size_t)mb + 1;
+        }
+        if (n_ids) HIP_TRY(hipMemcpyAsync(ix->x_ids, allowed_ids + a0, n_ids * 8, hipMemcpyHostToDevice, ix->stream)); // (pageable source: staged, returns when the source is consumed)
+        HIP_TRY(hipMemcpyAsync(ix->x_off, off.data(), ((size_t)cb + 1) * 8, hipMemcpyHostToDevice, ix->stream));
+        if ((rc = stage_and_validate(ix, queries + (size_t)c0 * ix->dev.dim, cb, v))) return rc;
+        if (stats) HIP_TRY(hipEventRecord(ix->ev0, ix->stream));
+        if ((rc = restricted_direct_enqueue(ix, ix->s_queries, cb, k, k, nullptr, 0, ix->x_ids, ix->x_off, (uint32_t)max_set, v.ids, v.sc, v.cnt, v.st))) return rc;
+        if (stats) HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
+        HIP_TRY(hipStreamSynchronize(ix->stream)); // (`off` is consumed as well)
+        for (uint32_t q = 0; q < cb; ++q) {
+            const uint32_t g = c0 + q;
+            out_counts[g] = 0;
+            if (out_status) out_status[g] = HVX_OK;
+            if (rstats) memset(&rstats[g], 0, sizeof(hvx_restricted_stats));
+            if (off[q + 1] == off[q]) continue; // Empty: no results, before any validation (restricted.rs:539-541)
+            if (v.st[q]) {
+                if (!out_status) return fail((int)v.st[q], "query %u rejected with status %u", g, v.st[q]);
+                out_status[g] = v.st[q];
+                continue;
+            }
+            if (rstats && ix->dev.has_entry) rstats[g].strategy = HVX_RESTRICTED_EXACT;
+            out_counts[g] = v.cnt[q];
+            memcpy(out_ids + (size_t)g * k, v.ids + (size_t)q * k, (size_t)v.cnt[q] * 8);
+            memcpy(out_scores + (size_t)g * k, v.sc + (size_t)q * k, (size_t)v.cnt[q] * 4);
+        }
+        if (stats) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
+            stats->queries += cb;
+            stats->vectors_loaded += n_ids;
+            stats->distance_computations += n_ids;
+            stats->device_ms += ms;
+        }
+    }
+    return HVX_OK;
+}
+
 // exact strategy for one shared candidate set (rows already on the device): the gathered exact scan of hvx_flat*.hip
 int exact_shared_set(hvx_index *ix, const float *queries, uint32_t b, uint32_t k_stride, uint32_t kk, const uint32_t *d_rows, uint32_t n_rows,
                      uint64_t *out_ids, float *out_scores, uint32_t *out_counts, uint32_t *out_status, hvx_restricted_stats *rstats,
@@ -573,7 +711,9 @@ int exact_shared_set(hvx_index *ix, const float *queries, uint32_t b, uint32_t k
     std::vector<uint64_t> t_ids((size_t)b * kk);
     std::vector<float> t_sc((size_t)b * kk);
     std::vector<uint32_t> t_cnt(b), t_st(b);
-    int rc = flat_scan_host(ix, queries, b, kk, d_rows, n_rows, t_ids.data(), t_sc.data(), t_cnt.data(), t_st.data(), stats);
+    int rc;
+    if (use_direct(ix, b, kk, n_rows)) rc = direct_shared_host(ix, queries, b, kk, d_rows, n_rows, t_ids.data(), t_sc.data(), t_cnt.data(), t_st.data(), stats);
+    else rc = flat_scan_host(ix, queries, b, kk, d_rows, n_rows, t_ids.data(), t_sc.data(), t_cnt.data(), t_st.data(), stats);
     if (rc) return rc;
     for (uint32_t q = 0; q < b; ++q) {
         if (rstats) {
@@ -668,26 +808,46 @@ extern "C" void hvx_restricted_params_default(hvx_restricted_params *p, uint32_t
     p->directory_enabled = 1;
 }
 
+int hvx::restricted_search_host(hvx_index *ix, const float *queries, uint32_t b, const hvx_restricted_params &rp, const uint64_t *allowed_ids,
+                                const uint64_t *allowed_offsets, uint64_t n_allowed, uint64_t *out_ids, float *out_scores, uint32_t *out_counts,
+                                uint32_t *out_status, hvx_restricted_stats *out_rstats, hvx_stats *stats) {
+    if (!allowed_offsets)
+        return restricted_set(ix, queries, b, rp, allowed_ids, n_allowed, out_ids, out_scores, out_counts, out_status, out_rstats, stats);
+    // One candidate list per query (the operator's shape: storage.rs:140-163).  Lists that the plan answers exactly -- all of them under
+    // the device plan, up to a GiB of rows each -- are scanned in ONE launch for the whole batch (round 6); anything else list by list.
+    bool batched = rp.k <= 64u && restricted_direct_supported(ix, rp.k) && ix->opt[HVX_OPT_RESTRICTED_DIRECT] != 1u && !rp.explicit_budgets;
+    for (uint32_t q = 0; q < b && batched; ++q) {
+        const uint64_t len = allowed_offsets[q + 1] - allowed_offsets[q];
+        if (len == 0) continue;
+        if (len > 1000000ull) { batched = false; break; } // (duplicates decide whether the SET is within the limit: the host path dedupes)
+        HostPlan hp;
+        // planned against the list's length: an upper bound of the set's size (a list with duplicates is planned as the longer set it could be)
+        if (make_plan(rp, len, ix->dev.dim, &hp, ix) != HVX_OK || hp.strategy != HVX_RESTRICTED_EXACT) batched = false;
+    }
+    if (batched)
+        return direct_per_query_host(ix, queries, b, rp, allowed_ids, allowed_offsets, out_ids, out_scores, out_counts, out_status, out_rstats, stats);
+    for (uint32_t q = 0; q < b; ++q) {
+        const uint64_t a0 = allowed_offsets[q], a1 = allowed_offsets[q + 1];
+        int rc = restricted_set(ix, queries + (size_t)q * ix->dev.dim, 1, rp, allowed_ids + a0, a1 - a0, out_ids + (size_t)q * rp.k,
+                                out_scores + (size_t)q * rp.k, out_counts + q, out_status ? out_status + q : nullptr,
+                                out_rstats ? out_rstats + q : nullptr, stats);
+        if (rc) return rc;
+    }
+    return HVX_OK;
+}
+
 extern "C" int hvx_search_restricted_batch_params(const hvx_index *cix, const float *queries, uint32_t b, const hvx_restricted_params *params,
                                                   const uint64_t *allowed_ids, const uint64_t *allowed_offsets, uint64_t n_allowed,
                                                   uint64_t *out_ids, float *out_scores, uint32_t *out_counts, uint32_t *out_status,
                                                   hvx_restricted_stats *out_rstats, hvx_stats *stats) {
     if (!cix || !params) return fail(HVX_ERR_INVARIANT, "null argument");
     hvx_index *ix = const_cast<hvx_index *>(cix);
-    if (params->strategy > HVX_RESTRICTED_FILTERED) return fail(HVX_ERR_INVARIANT, "unknown restricted strategy %u", params->strategy);
+    if (params->strategy > HVX_RESTRICTED_REFERENCE_PLAN) return fail(HVX_ERR_INVARIANT, "unknown restricted strategy %u", params->strategy);
     if (params->k == 0) return fail(HVX_ERR_K_RANGE, "result count must be non-zero");
     if (params->ef < params->k) return fail(HVX_ERR_K_RANGE, "search beam width %u is below the result count %u", params->ef, params->k);
     if (b == 0) return HVX_OK;
     std::lock_guard<std::mutex> lock(ix->mu);
+    ix->sync_rewrites();
     HIP_TRY(hipSetDevice(ix->device));
-    if (!allowed_offsets)
-        return restricted_set(ix, queries, b, *params, allowed_ids, n_allowed, out_ids, out_scores, out_counts, out_status, out_rstats, stats);
-    for (uint32_t q = 0; q < b; ++q) { // one candidate list per query
-        const uint64_t a0 = allowed_offsets[q], a1 = allowed_offsets[q + 1];
-        int rc = restricted_set(ix, queries + (size_t)q * ix->dev.dim, 1, *params, allowed_ids + a0, a1 - a0, out_ids + (size_t)q * params->k,
-                                out_scores + (size_t)q * params->k, out_counts + q, out_status ? out_status + q : nullptr,
-                                out_rstats ? out_rstats + q : nullptr, stats);
-        if (rc) return rc;
-    }
-    return HVX_OK;
+    return restricted_search_host(ix, queries, b, *params, allowed_ids, allowed_offsets, n_allowed, out_ids, out_scores, out_counts, out_status, out_rstats, stats);
 }

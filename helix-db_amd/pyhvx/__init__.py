@@ -152,10 +152,13 @@ class AdaptiveStats(C.Structure):  # hvx_adaptive_stats
 
 # hvx_option: execution-path selectors of a handle (same results on every setting) / hvx_scan_path flags
 OPT_HNSW_GENERAL_KERNEL, OPT_WAVE_LOG2CAP, OPT_FLAT_FORCE_VALU, OPT_FLAT_FIRST_CHUNK, OPT_FLAT_NO_TILE, OPT_FLAT_NO_FILTER, \
-    OPT_FLAT_NO_FAST, OPT_FLAT_TILE_BUILD, OPT_FLAT_NO_SMALLB, OPT_HNSW_PAIR, OPT_DELETE_SEQUENTIAL = range(11)
+    OPT_FLAT_NO_FAST, OPT_FLAT_TILE_BUILD, OPT_FLAT_NO_SMALLB, OPT_HNSW_PAIR, OPT_DELETE_SEQUENTIAL, OPT_RESTRICTED_DIRECT, \
+    OPT_RESTRICTED_EXACT_MIB = range(13)
 PATH_VALU, PATH_MFMA_128, PATH_TILE_256, PATH_FILTERED, PATH_FULL_SPLIT, PATH_VALU_FALLBACK_QUERIES, PATH_WIDENED, \
-    PATH_PAIR_OVERFLOW_REPEAT, PATH_SMALL_BATCH = 1, 2, 4, 8, 16, 32, 64, 128, 256
-RESTRICTED_AUTO, RESTRICTED_EXACT, RESTRICTED_FILTERED = 0, 1, 2  # hvx_restricted_strategy
+    PATH_PAIR_OVERFLOW_REPEAT, PATH_SMALL_BATCH, PATH_DIRECT = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
+# hvx_restricted_strategy: AUTO = the DEVICE's plan (exact scan while the candidate rows take <= 1 GiB, round 6), REFERENCE_PLAN = the
+# reference's (restricted.rs:426-453: exact <= 256 ids / 4 MiB, the filter-aware walk above)
+RESTRICTED_AUTO, RESTRICTED_EXACT, RESTRICTED_FILTERED, RESTRICTED_REFERENCE_PLAN = 0, 1, 2, 3
 TERM_NONE, TERM_EXHAUSTED, TERM_BEAM_COMPLETE, TERM_ROUTING_BUDGET, TERM_BRIDGE_BUDGET, TERM_VECTOR_BUDGET = range(6)
 
 
@@ -164,8 +167,9 @@ class RestrictedParams(C.Structure):  # hvx_restricted_params
                                           "routing_rows", "bridge_rows", "vector_payloads", "sampled_seeds", "directory_seeds")]
 
     @classmethod
-    def new(cls, k, ef, *, strategy=RESTRICTED_AUTO, beam_percent=150, directory=True, **budgets):
-        """search_restricted's plan (restricted.rs:426-453); `budgets` = explicit FilteredGraphBudgets as the reference's tests pass them"""
+    def new(cls, k, ef, *, strategy=RESTRICTED_REFERENCE_PLAN, beam_percent=150, directory=True, **budgets):
+        """search_restricted under the REFERENCE's plan (restricted.rs:426-453: what the reference runs, what the parity tests compare);
+        `budgets` = explicit FilteredGraphBudgets as the reference's tests pass them.  `RestrictedParams.auto` = the device's plan."""
         p = cls(k=k, ef=ef, strategy=strategy, beam_percent=beam_percent, directory_enabled=1 if directory else 0)
         if budgets:
             p.explicit_budgets = 1
@@ -174,6 +178,12 @@ class RestrictedParams(C.Structure):  # hvx_restricted_params
                 setattr(p, name, int(budgets.pop(name)))
             assert not budgets, budgets
         return p
+
+
+    @classmethod
+    def auto(cls, k, ef, *, beam_percent=150, directory=True):
+        """the library's default (hvx_restricted_params_default): HVX_RESTRICTED_AUTO, the device's cost-based plan"""
+        return cls.new(k, ef, strategy=RESTRICTED_AUTO, beam_percent=beam_percent, directory=directory)
 
 
 class RestrictedStats(C.Structure):  # hvx_restricted_stats: RestrictedSearchStats (restricted.rs:147-166)

@@ -146,7 +146,11 @@ enum hvx_option {
                                         handle runs one query per SIMD (hvx_index_set_occupancy(1): one batch in flight), 1 = never,
                                         2 = always where it is built, 3 = always, with ONE gatherer even where three are built */
     HVX_OPT_DELETE_SEQUENTIAL = 10,  /* 1: hvx_index_delete_batch relinks every source in the one-wavefront kernel (no per-source step launches) */
-    HVX_OPT_COUNT = 11
+    HVX_OPT_RESTRICTED_DIRECT = 11,  /* restricted exact scans of k <= 64: 0 = the one-launch reference-order kernel (csrc/hvx_restricted_exact.hip) where it is
+                                        the cheaper one (b x candidates x dim <= 2^31), 1 = never, 2 = always */
+    HVX_OPT_RESTRICTED_EXACT_MIB = 12, /* device plan of HVX_RESTRICTED_AUTO: candidate sets whose rows take at most this many MiB are scanned
+                                        exactly; 0 = 1024 */
+    HVX_OPT_COUNT = 13
 };
 int hvx_index_set_option(hvx_index *, uint32_t option, uint32_t value);
 /* which kernels the handle's last exact scan ran (bit flags) */
@@ -154,7 +158,8 @@ enum hvx_scan_path {
     HVX_PATH_VALU = 1, HVX_PATH_MFMA_128 = 2, HVX_PATH_TILE_256 = 4, HVX_PATH_FILTERED = 8, HVX_PATH_FULL_SPLIT = 16,
     HVX_PATH_VALU_FALLBACK_QUERIES = 32, HVX_PATH_WIDENED = 64,
     HVX_PATH_SMALL_BATCH = 256,       /* the one-pass small-batch kernel (hvx_flat_smallb.hip) produced the candidates */
-    HVX_PATH_PAIR_OVERFLOW_REPEAT = 128 /* a filtered slice let more pairs through than its buffer holds: the scan was repeated unfiltered */
+    HVX_PATH_PAIR_OVERFLOW_REPEAT = 128, /* a filtered slice let more pairs through than its buffer holds: the scan was repeated unfiltered */
+    HVX_PATH_DIRECT = 512             /* the one-launch reference-order scan of a restricted candidate set (hvx_restricted_exact.hip) */
 };
 uint32_t hvx_index_last_scan_path(const hvx_index *);
 /* HNSW kernel build used by this handle: 1 (default) = one query per SIMD with the SIMD's whole register file (lowest
@@ -314,7 +319,7 @@ int hvx_search_restricted_batch(const hvx_index *, const float *queries, uint32_
  * -- is answered by the exact gathered scan (a superset of the walk's answer in recall; hvx_restricted_stats.strategy says
  * EXACT), never by an error: the reference serves k up to 800 (MAX_RESTRICTED_RESULT_COUNT, restricted.rs:55).
  */
-enum hvx_restricted_strategy { HVX_RESTRICTED_AUTO = 0, HVX_RESTRICTED_EXACT = 1, HVX_RESTRICTED_FILTERED = 2 };
+enum hvx_restricted_strategy { HVX_RESTRICTED_AUTO = 0, HVX_RESTRICTED_EXACT = 1, HVX_RESTRICTED_FILTERED = 2, HVX_RESTRICTED_REFERENCE_PLAN = 3 };
 /* RestrictedSearchTermination (restricted.rs:131-143) */
 enum hvx_restricted_termination {
     HVX_TERM_NONE = 0, HVX_TERM_EXHAUSTED = 1, HVX_TERM_BEAM_COMPLETE = 2, HVX_TERM_ROUTING_BUDGET = 3,

@@ -60,8 +60,8 @@ def test_sequential_deletes_equal_the_oracles_row_for_row(orc, hv, n, dim, metri
     """VectorIndex::delete one node at a time (mutation.rs:1606-1774): after three batches of deletes (scattered ids, the entry point
     twice, ids that are unknown, an id twice in one batch) every layer-0 row, every upper row, the entry point and the top layer of
     the live nodes equal the oracle's; deleted ids are gone from the HNSW searches (strict + the production default arm), the exact
-    scan, restricted candidate sets and hvx_index_contains; the statistics count what happened; a fork keeps its generation until
-    hvx_index_refresh; rows appended AFTER the deletes link exactly as the oracle's do.  Both relink paths of the device (per-source
+    scan, restricted candidate sets and hvx_index_contains; the statistics count what happened; a fork adopts the owner's generation at its next launch
+    (in-place rewrites cannot be hidden from it); rows appended AFTER the deletes link exactly as the oracle's do.  Both relink paths of the device (per-source
     steps with the eager distance matrix; the one-wavefront kernel with the lazy select_diverse) produce the same rows."""
     ok, hk = {"avx_fma": (orc.K_AVX_FMA, hv.KERNEL_AVX_FMA), "neon": (orc.K_NEON, hv.KERNEL_NEON)}[kern]
     rng = np.random.default_rng(4200 + dim + metric + n)
@@ -126,10 +126,13 @@ def test_sequential_deletes_equal_the_oracles_row_for_row(orc, hv, n, dim, metri
         rc, tid, tsc = oix.flat(q[qi], 10, allowed=allowed)
         assert rid[qi, :rcnt[qi]].tolist() == tid.tolist() and bits(rsc[qi, :rcnt[qi]]).tolist() == bits(tsc).tolist()
         assert not (set(gid[qi, :gcnt[qi]].tolist()) | set(fid[qi, :fcnt[qi]].tolist()) | set(rid[qi, :rcnt[qi]].tolist())) & dset
-    # the fork: its generation until it is refreshed (rows stale-or-current, never torn), then the owner's
+    # the fork: deletes rewrite shared rows in place, so its old generation cannot be served any more (its entry point may be a node
+    # whose rows are now empty: ADVICE r5) -- it still SHOWS the old generation until it is used, and adopts the owner's at its next
+    # launch without an explicit hvx_index_refresh (round 6)
     assert lane.live_rows() == n and lane.visible_seq() == seq0
     lid, lsc, lcnt, _ = lane.search_batch(q, hv.SearchParams(10).with_ef(64))
-    assert (lcnt > 0).all()
+    assert lid.tolist() == gid.tolist() and bits(lsc).tolist() == bits(gsc).tolist()
+    assert lane.live_rows() == n - len(deleted) and lane.visible_seq() == gix.visible_seq()
     lane.refresh()
     assert lane.live_rows() == n - len(deleted)
     lid, lsc, lcnt, _ = lane.search_batch(q, hv.SearchParams(10).with_ef(64))

@@ -977,6 +977,22 @@ int hvx_index::flat_scratch(uint32_t b, uint32_t k, uint32_t chunk_rows) {
     return HVX_OK;
 }
 
+// Does an exact scan of this shape produce its candidates on the matrix cores?  bf16 / fp8 rows: always (their only pipeline).  f32 rows:
+// the AVX+FMA tree over one of the unrolled dimensions >= 256 (below that the top-(m+1) selection over the score matrix outweighs the
+// contraction), and enough work to amortise the extra passes (b x rows x dim >= 2^33 MACs) -- or a small batch (b <= 128) over enough
+// rows (rows x dim >= 2^22) to make it a stream: the one-pass kernels of hvx_flat_smallb.hip read every row once at HBM speed, where the
+// reference-order VALU kernel is bound by the b x rows x dim subtract / FMA pairs.
+bool hvx::flat_scan_on_matrix_cores(const hvx_index *ix, uint32_t b, uint32_t k, uint32_t n_rows) {
+    const DevIndex &d = ix->dev;
+    if (d.dtype != HVX_F32) return true;
+    const uint32_t nk = d.dim >> 5;
+    const bool shape = d.dim % 32u == 0u && d.ld == d.dim && d.dim_main == d.dim && d.fkernel == kKernelAvxFma &&
+                       (nk == 4 || nk == 8 || nk == 16 || nk == 24 || nk == 32 || nk == 48) && (d.metric == kL2 || d.metric == kCosine);
+    const bool big = (uint64_t)b * n_rows * d.dim >= (1ull << 33);
+    const bool small_stream = ix->opt[HVX_OPT_FLAT_NO_SMALLB] != 1u && flat_smallb_supported(d.dim, b, 2) && (uint64_t)n_rows * d.dim >= (1ull << 22);
+    return shape && d.dim >= 256 && k <= 511 && (big || small_stream) && !ix->opt[HVX_OPT_FLAT_FORCE_VALU];
+}
+
 // scan `n_rows` rows (all rows, or d_subset internal ids) for b device-resident queries
 int hvx::flat_scan_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, const uint32_t *d_subset,
                           uint32_t n_rows, uint64_t *d_ids, float *d_scores, uint32_t *d_counts,
@@ -992,20 +1008,11 @@ int hvx::flat_scan_device(hvx_index *ix, const float *d_queries, uint32_t b, uin
     }
     if (ix->dev.dtype != HVX_F32) // bf16 / fp8 rows: the matrix-core pipeline, over all rows or over the restricted row list
         return flat_mfma_device(ix, d_queries, b, k, d_subset, n_rows, d_ids, d_scores, d_counts, d_status, timed);
-    // f32 rows, whole-corpus scan, dim >= 256 (below that the top-(m+1) selection over the score matrix outweighs the
-    // contraction) and enough work (b x rows x dim >= 2^33 MACs) to amortise the extra passes: candidates on MFMA (rows split into bf16 hi + lo on
-    // the fly), exact re-rank, certificate; any query whose certificate is not reached sends the batch to the exact VALU scan
+    // f32 rows: candidates on the matrix cores where that pays (flat_scan_on_matrix_cores), exact re-rank / tail; any query whose
+    // certificate is not reached sends the batch to the exact VALU scan
     {
         const DevIndex &d = ix->dev;
-        const uint32_t nk = d.dim >> 5;
-        const bool shape = d.dim % 32u == 0u && d.ld == d.dim && d.dim_main == d.dim && d.fkernel == kKernelAvxFma &&
-                           (nk == 4 || nk == 8 || nk == 16 || nk == 24 || nk == 32 || nk == 48) && (d.metric == kL2 || d.metric == kCosine);
-        // ... or a small batch (b <= 128) over enough rows (rows x dim >= 2^22) to make it a stream: the one-pass register-resident
-        // kernel (hvx_flat_smallb.hip) reads every row once at HBM speed, where the reference-order VALU kernel below is bound by
-        // the b x rows x dim subtract / FMA pairs (32 queries x 100 000 x 1536: 0.8 ms vs the rows' 0.1 ms of HBM time)
-        const bool big = (uint64_t)b * n_rows * d.dim >= (1ull << 33);
-        const bool small_stream = ix->opt[HVX_OPT_FLAT_NO_SMALLB] != 1u && flat_smallb_supported(d.dim, b, 2) && (uint64_t)n_rows * d.dim >= (1ull << 22);
-        if (shape && d.dim >= 256 && k <= 511 && (big || small_stream) && !ix->opt[HVX_OPT_FLAT_FORCE_VALU]) {
+        if (flat_scan_on_matrix_cores(ix, b, k, n_rows)) {
             const int rc = flat_mfma_device(ix, d_queries, b, k, d_subset, n_rows, d_ids, d_scores, d_counts, d_status, timed);
             if (rc != -1) return rc;
             // certificate not reached for some queries: those -- and only those, unless they are many -- are answered

@@ -801,7 +801,11 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
     // a handle whose one-pass attempt keeps missing its certificate (tightly clustered scores: the widened bound exceeds the gap
     // between the k-th and the (m+1)-th score) starts with the full split; the one-pass attempt is probed again every 32 scans
     const bool skip_fast = ix->m_fast_misses >= 2 && (ix->m_fast_skipped++ % 32u) != 31u;
-    for (int attempt = (allow_fast && !skip_fast) ? 0 : 1; attempt < 3; ++attempt) {
+    // small batches with the one-launch exact tail (hvx_flat_tail.hip) always take the one-pass contraction: a loose bound only re-scores
+    // more rows there, it never sends the scan round again
+    const bool tail_first = !fp8 && !ix->opt[HVX_OPT_FLAT_NO_TAIL] && ix->opt[HVX_OPT_FLAT_NO_SMALLB] != 1u && flat_tail_supported(ix, b, k, n) &&
+                            flat_smallb_supported(d.dim, b, f32 ? 2 : 0) && (size_t)((n + 3u) & ~3u) * b * 4 <= (512u << 20);
+    for (int attempt = (allow_fast && (!skip_fast || tail_first)) ? 0 : 1; attempt < 3; ++attempt) {
         const bool full = attempt >= 1;
         const uint32_t m = attempt == 2 ? 1023u : m0;
         if (attempt == 2 && m0 >= 1023u) break;
@@ -885,6 +889,16 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ix->device);
             sa.dist = ix->f_dist; sa.chunk_ld = chunk;
             HIP_TRY(launch_flat_smallb(sa, sb_kind, full, (uint32_t)cus, ix->opt[HVX_OPT_FLAT_NO_SMALLB] == 2u ? 1u : 0u, ix->stream));
+            if (!full && !ix->opt[HVX_OPT_FLAT_NO_TAIL] && flat_tail_supported(ix, b, k, n)) {
+                // round 6: the approximate dot products become the exact answer in ONE more launch (hvx_flat_tail.hip): rows whose
+                // approximate score could be below the query's k-th exact score are re-scored in the reference's order -- no candidate
+                // count, no certificate, nothing to read back, never a second pass over the rows
+                const float dropped = f32 ? 0.0078125f : 0.00390625f; // what the one-pass contraction left out (RerankArgs::extra_rel)
+                if ((rc = flat_tail_enqueue(ix, d_queries, b, k, ix->f_dist, chunk, n, d_subset, ma.rowterm, ix->m_qn2, dropped, d_ids, d_scores, d_counts, d_status))) return rc;
+                if (timed) HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
+                ix->last_scan_path |= HVX_PATH_SMALL_BATCH | HVX_PATH_EXACT_TAIL;
+                return HVX_OK;
+            }
             if (sb_radix) { // sort-free selection: slices' kc smallest pairs, the query's kc smallest of those inside the re-rank kernel
                 HIP_TRY(launch_flat_select_radix(sa, kc, ix->d_qstatus, ix->m_csc, reinterpret_cast<uint32_t *>(ix->m_cid), kSmallbCandCap, &sb_slices, ix->stream));
             } else {

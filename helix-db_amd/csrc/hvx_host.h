@@ -196,6 +196,11 @@ struct hvx_index {
     uint64_t *x_ids = nullptr, *x_off = nullptr;
     size_t cap_x_part = 0, cap_x_ids = 0, cap_x_off = 0;
     uint32_t cap_x_ctl = 0;
+    // exact tail of the small-batch matrix-core scan (hvx_flat_tail.hip): the slices' exact lists; [bad | done | threshold] words per query
+    float *t_part_sc = nullptr;
+    uint32_t *t_part_row = nullptr, *t_ctl = nullptr;
+    size_t cap_t_part = 0;
+    uint32_t cap_t_ctl = 0;
 
     int dalloc(void **p, size_t bytes);
     int regrow(void **p, size_t bytes);   // dalloc after releasing *p (scratch buffers that grow)
@@ -246,6 +251,7 @@ float component_limit(uint32_t metric, uint32_t dim);
 int flat_scan_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, const uint32_t *d_subset,
                      uint32_t n_rows, uint64_t *d_ids, float *d_scores, uint32_t *d_counts, uint32_t *d_status,
                      bool timed);
+bool flat_scan_on_matrix_cores(const hvx_index *ix, uint32_t b, uint32_t k, uint32_t n_rows);
 int flat_scan_valu(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, const uint32_t *d_subset, uint32_t n_rows,
                    uint64_t *d_ids, float *d_scores, uint32_t *d_counts, uint32_t *d_status, bool timed, bool record_begin);
 int flat_mfma_device(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, const uint32_t *d_subset, uint32_t n_rows,
@@ -273,6 +279,11 @@ bool restricted_direct_supported(const hvx_index *ix, uint32_t k);
 int restricted_direct_enqueue(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, uint32_t k_stride, const uint32_t *d_rows,
                               uint32_t n_rows, const uint64_t *d_ext_ids, const uint64_t *d_offsets, uint32_t max_set, uint64_t *d_ids,
                               float *d_scores, uint32_t *d_counts, uint32_t *d_status);
+// exact tail of the small-batch matrix-core scan (hvx_flat_tail.hip): k <= 64, AVX+FMA tree, L2 / cosine, f32 or bf16 rows
+bool flat_tail_supported(const hvx_index *ix, uint32_t b, uint32_t k, uint32_t n_rows);
+int flat_tail_enqueue(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, const float *dots, uint32_t chunk_ld, uint32_t rows,
+                      const uint32_t *d_subset, const float *rowterm, const float *qn2, float erel, uint64_t *d_ids, float *d_scores,
+                      uint32_t *d_counts, uint32_t *d_status);
 hipError_t launch_stage_queries(const float *src, float *dst, uint32_t dim, uint32_t b, hipStream_t s);
 // hvx_search_restricted_batch_params behind the handle's lock (hvx_restricted_walk.hip)
 int restricted_search_host(hvx_index *ix, const float *queries, uint32_t b, const hvx_restricted_params &rp, const uint64_t *allowed_ids,

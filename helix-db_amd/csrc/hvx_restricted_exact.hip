@@ -27,7 +27,7 @@
 #include <cstring>
 #include <vector>
 
-#include "hvx_beam.h"
+#include "hvx_toplist.h"
 #include "hvx_host.h"
 
 using namespace hvx;
@@ -117,38 +117,6 @@ __device__ __noinline__ float slow_half_cosine(const DevIndex &ix, const float *
     return stable_half_cosine_fn(ix.dim, [&](uint32_t i) { return qv[i]; }, [&](uint32_t i) { return rf[i]; });
 }
 
-// the k smallest (score, row) pairs a wavefront has seen, duplicates of a row rejected
-struct TopList {
-    Beam<1> beam;
-    float thr_s;
-    uint32_t thr_i;
-    __device__ __forceinline__ void init() {
-        beam.init();
-        thr_s = __uint_as_float(0x7F800000u);
-        thr_i = 0xFFFFFFFFu;
-    }
-    __device__ __forceinline__ bool admits(float d, uint32_t row) const { return d < thr_s || (d == thr_s && row < thr_i); }
-    __device__ __forceinline__ void insert(float d, uint32_t row, uint32_t k, int lane) { // (d, row) wave-uniform
-        if (__ballot((uint32_t)lane < beam.count && beam.id[0] == row)) return; // the same candidate id twice: a set holds it once
-        float dropped;
-        (void)beam.insert(d, row, lane, dropped);
-        if (beam.count >= k) {
-            thr_s = beam.score_at(k - 1u);
-            thr_i = beam.id_at(k - 1u);
-        }
-    }
-    // every entry of `lanes` holding (d, row) with take == true, in lane order
-    __device__ __forceinline__ void offer(bool take, float d, uint32_t row, uint32_t k, int lane) {
-        unsigned long long m = __ballot(take);
-        while (m) {
-            const int l = __builtin_ctzll(m);
-            m &= m - 1ull;
-            const float dd = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d), l));
-            const uint32_t rr = __builtin_amdgcn_readlane(row, l);
-            if (admits(dd, rr)) insert(dd, rr, k, lane);
-        }
-    }
-};
 
 // NK = dim / 32 (unrolled shapes: AVX+FMA tree, dim == ld == dim_main); NK == 0: any dimension / metric / summation tree through
 // group_distance (one row per group at a time).  BF: bf16 rows (interleaved layout).  EXT: per-query external id lists (TQ == 1).
@@ -311,8 +279,8 @@ __global__ __launch_bounds__(256) void restricted_direct_kernel(DirectArgs a) {
     // the workgroup's four lists of a query -> one (wavefront t mod 4), padded with (+inf, kSentinel) -> HBM
 #pragma unroll
     for (int t = 0; t < TQ; ++t) {
-        m_sc[t][wave][lane] = (uint32_t)lane < top[t].beam.count ? top[t].beam.sc[0] : inf;
-        m_id[t][wave][lane] = (uint32_t)lane < top[t].beam.count ? top[t].beam.id[0] : kSentinel;
+        m_sc[t][wave][lane] = top[t].sc;
+        m_id[t][wave][lane] = top[t].id;
         const unsigned long long anybad = __ballot((badmask >> t) & 1u);
         if (anybad && lane == 0 && q0 + (uint32_t)t < a.b) atomicOr(&a.bad[q0 + (uint32_t)t], 1u);
     }
@@ -331,17 +299,20 @@ __global__ __launch_bounds__(256) void restricted_direct_kernel(DirectArgs a) {
         }
         if ((uint32_t)lane < a.k) {
             const size_t at = ((size_t)q * a.slices + slice) * a.k + (uint32_t)lane;
-            st_agent(a.part_sc + at, (uint32_t)lane < l.beam.count ? l.beam.sc[0] : inf);
-            st_agent(a.part_row + at, (uint32_t)lane < l.beam.count ? l.beam.id[0] : kSentinel);
+            st_agent(a.part_sc + at, l.sc);
+            st_agent(a.part_row + at, l.id);
         }
     }
     // the last workgroup of the tile to get here merges the slices' lists
-    __threadfence();
+    // No device-scope fence here: an agent-scope release / acquire pair is an L2 write-back and an L2 INVALIDATE on this part (one L2 per
+    // XCD), and hundreds of short workgroups doing that to the L2 their neighbours are streaming rows through cost more than the scan
+    // (first build: 200 us at 100 000 x 32).  The lists are written with device-scope (write-through) stores and read with device-scope
+    // loads; the stores have been acknowledged (vscnt = 0, workgroup-scope release) before the ticket is taken.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    if (tid == 0) s_last = __hip_atomic_fetch_add(&a.done[tile], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == a.slices ? 1u : 0u;
+    if (tid == 0) s_last = __hip_atomic_fetch_add(&a.done[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == a.slices ? 1u : 0u;
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     const uint32_t per_query = a.slices * a.k;
     for (int t0 = 0; t0 < TQ; t0 += (TQ >= 4 ? 4 : 1)) {
         // TQ >= 4: wavefront w merges query t0 + w on its own; fewer queries: the four wavefronts split one query's lists
@@ -370,8 +341,8 @@ __global__ __launch_bounds__(256) void restricted_direct_kernel(DirectArgs a) {
         }
         if (TQ < 4) { // the four partial merges of the one query meet in LDS (wavefront 0 finishes)
             __syncthreads();
-            m_sc[0][wave][lane] = (uint32_t)lane < l.beam.count ? l.beam.sc[0] : inf;
-            m_id[0][wave][lane] = (uint32_t)lane < l.beam.count ? l.beam.id[0] : kSentinel;
+            m_sc[0][wave][lane] = l.sc;
+            m_id[0][wave][lane] = l.id;
             __syncthreads();
             if (wave != 0) continue;
             l.init();
@@ -387,11 +358,11 @@ __global__ __launch_bounds__(256) void restricted_direct_kernel(DirectArgs a) {
         uint32_t isbad = 0;
         if (lane == 0) { isbad = ld_agent(a.bad + q); if (isbad) st_agent(a.bad + q, 0u); }
         isbad = __builtin_amdgcn_readfirstlane(isbad);
-        uint32_t outn = l.beam.count < a.k ? l.beam.count : a.k;
+        uint32_t outn = l.count < a.k ? l.count : a.k;
         if (st != 0u || isbad) outn = 0;
         if ((uint32_t)lane < outn) {
-            a.out_ids[(size_t)q * a.k_stride + (uint32_t)lane] = ix.ids[l.beam.id[0]];
-            a.out_scores[(size_t)q * a.k_stride + (uint32_t)lane] = l.beam.sc[0];
+            a.out_ids[(size_t)q * a.k_stride + (uint32_t)lane] = ix.ids[l.id];
+            a.out_scores[(size_t)q * a.k_stride + (uint32_t)lane] = l.sc;
         }
         if (lane == 0) {
             a.out_counts[q] = outn;

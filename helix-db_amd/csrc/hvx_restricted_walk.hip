@@ -580,13 +580,16 @@ int walk_shared_set(hvx_index *ix, const float *queries, uint32_t b, uint32_t k_
 
 
 // ---- the one-launch exact scan (hvx_restricted_exact.hip) behind the host-pointer entry points ----
-// Which exact scan serves a SHARED candidate set: the reference-order kernel costs b x rows x dim packed FMAs (every row is scored against
-// every query on the vector ALUs), the matrix-core pipeline one pass over the rows plus ~60 us of selection / re-rank / certificate
-// launches.  32 queries x 10 000 x 1536: 25 us against 64; 32 x 100 000 x 1536: ~250 us against ~190 -- the line is drawn at 2^31.
+// Which exact scan serves a SHARED candidate set: the reference-order kernel scores every row against every query on the vector ALUs and
+// is a chain of short dependent passes per workgroup; the matrix-core pipeline streams the rows once and pays ~40 us for its exact tail.
+// Measured at dim 1536 (profiles/r06b_restricted_direct.log): one launch wins at 100 and 1 000 candidates for 1 - 32 queries (24 - 60 us
+// against 31 - 199) and at 10 000 for one query (59 against 86); it loses from 10 000 x 8 on (119 against 87).  The line: b x rows x dim
+// <= 2^26 -- and up to 2^31 where the other choice would be the distance-matrix VALU kernels (dimensions the contraction does not serve).
 bool use_direct(const hvx_index *ix, uint32_t b, uint32_t k, uint32_t n_rows) {
     if (ix->opt[HVX_OPT_RESTRICTED_DIRECT] == 1u || n_rows == 0 || !restricted_direct_supported(ix, k)) return false;
     if (ix->opt[HVX_OPT_RESTRICTED_DIRECT] == 2u) return true;
-    return (uint64_t)b * n_rows * ix->dev.dim <= (1ull << 31);
+    const uint64_t work = (uint64_t)b * n_rows * ix->dev.dim;
+    return work <= (1ull << 26) || (work <= (1ull << 31) && !flat_scan_on_matrix_cores(ix, b, k, n_rows));
 }
 
 // pinned mirror layout of one chunk: queries | ids | scores | counts | status (the kernels write the four outputs THERE: mapped host rows)

@@ -153,9 +153,9 @@ class AdaptiveStats(C.Structure):  # hvx_adaptive_stats
 # hvx_option: execution-path selectors of a handle (same results on every setting) / hvx_scan_path flags
 OPT_HNSW_GENERAL_KERNEL, OPT_WAVE_LOG2CAP, OPT_FLAT_FORCE_VALU, OPT_FLAT_FIRST_CHUNK, OPT_FLAT_NO_TILE, OPT_FLAT_NO_FILTER, \
     OPT_FLAT_NO_FAST, OPT_FLAT_TILE_BUILD, OPT_FLAT_NO_SMALLB, OPT_HNSW_PAIR, OPT_DELETE_SEQUENTIAL, OPT_RESTRICTED_DIRECT, \
-    OPT_RESTRICTED_EXACT_MIB = range(13)
+    OPT_RESTRICTED_EXACT_MIB, OPT_FLAT_NO_TAIL = range(14)
 PATH_VALU, PATH_MFMA_128, PATH_TILE_256, PATH_FILTERED, PATH_FULL_SPLIT, PATH_VALU_FALLBACK_QUERIES, PATH_WIDENED, \
-    PATH_PAIR_OVERFLOW_REPEAT, PATH_SMALL_BATCH, PATH_DIRECT = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
+    PATH_PAIR_OVERFLOW_REPEAT, PATH_SMALL_BATCH, PATH_DIRECT, PATH_EXACT_TAIL = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024
 # hvx_restricted_strategy: AUTO = the DEVICE's plan (exact scan while the candidate rows take <= 1 GiB, round 6), REFERENCE_PLAN = the
 # reference's (restricted.rs:426-453: exact <= 256 ids / 4 MiB, the filter-aware walk above)
 RESTRICTED_AUTO, RESTRICTED_EXACT, RESTRICTED_FILTERED, RESTRICTED_REFERENCE_PLAN = 0, 1, 2, 3

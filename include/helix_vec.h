@@ -150,7 +150,9 @@ enum hvx_option {
                                         the cheaper one (b x candidates x dim <= 2^31), 1 = never, 2 = always */
     HVX_OPT_RESTRICTED_EXACT_MIB = 12, /* device plan of HVX_RESTRICTED_AUTO: candidate sets whose rows take at most this many MiB are scanned
                                         exactly; 0 = 1024 */
-    HVX_OPT_COUNT = 13
+    HVX_OPT_FLAT_NO_TAIL = 13,       /* 1: small-batch matrix-core scans keep the selection / re-rank / certificate steps of rounds 3-5 instead of the
+                                        one-launch exact tail (csrc/hvx_flat_tail.hip) */
+    HVX_OPT_COUNT = 14
 };
 int hvx_index_set_option(hvx_index *, uint32_t option, uint32_t value);
 /* which kernels the handle's last exact scan ran (bit flags) */
@@ -159,7 +161,8 @@ enum hvx_scan_path {
     HVX_PATH_VALU_FALLBACK_QUERIES = 32, HVX_PATH_WIDENED = 64,
     HVX_PATH_SMALL_BATCH = 256,       /* the one-pass small-batch kernel (hvx_flat_smallb.hip) produced the candidates */
     HVX_PATH_PAIR_OVERFLOW_REPEAT = 128, /* a filtered slice let more pairs through than its buffer holds: the scan was repeated unfiltered */
-    HVX_PATH_DIRECT = 512             /* the one-launch reference-order scan of a restricted candidate set (hvx_restricted_exact.hip) */
+    HVX_PATH_DIRECT = 512,            /* the one-launch reference-order scan of a restricted candidate set (hvx_restricted_exact.hip) */
+    HVX_PATH_EXACT_TAIL = 1024        /* small-batch candidates turned into the exact answer by the one-launch tail (hvx_flat_tail.hip): no certificate */
 };
 uint32_t hvx_index_last_scan_path(const hvx_index *);
 /* HNSW kernel build used by this handle: 1 (default) = one query per SIMD with the SIMD's whole register file (lowest

@@ -1420,6 +1420,7 @@ def test_restricted_scan_through_the_256_tile_kernel(orc, hv):
     cand = hv.RestrictedVectorCandidates.from_ids(allowed)
     gix.set_option(hv.OPT_FLAT_FIRST_CHUNK, 1024)
     gix.set_option(hv.OPT_FLAT_NO_SMALLB, 1)
+    gix.set_option(hv.OPT_RESTRICTED_DIRECT, 1)  # (a set this small would take the one-launch reference-order kernel, round 6)
     gid, gsc, gcnt = gix.search_restricted_batch(q, hv.SearchParams(k), cand)
     assert gix.last_scan_path() & hv.PATH_TILE_256
     for qi in range(0, b, 7):
@@ -1696,6 +1697,7 @@ def test_small_batch_exact_scan_is_bit_exact(orc, hv, dtype_name, metric, dim, n
     assert gid.tolist() == oid_.tolist() and bits(gsc).tolist() == bits(osc_).tolist() and gcnt.tolist() == ocnt_.tolist() and gst.tolist() == ost_.tolist()
     gix.set_option(hv.OPT_FLAT_NO_SMALLB, 0)
     # restricted: a candidate row list (ragged length, not a multiple of 32)
+    gix.set_option(hv.OPT_RESTRICTED_DIRECT, 1)  # (few queries over a set this small would take the one-launch reference-order kernel, round 6)
     allowed = np.sort(rng.choice(ids, min(n - 5, max(2 ** 22 // dim + 77, 3001)), replace=False))
     good = q[: max(1, b - 1)] if b > 2 else q
     rid, rsc, rcnt = gix.search_restricted_batch(good, hv.SearchParams(k), hv.RestrictedVectorCandidates.from_ids(allowed))
@@ -1748,6 +1750,7 @@ def test_ring_build_of_the_small_batch_scan(orc, hv, dtype_name, metric, dim, n,
     assert (fid.tolist(), bits(fsc).tolist(), fcnt.tolist()) == (gid.tolist(), bits(gsc).tolist(), gcnt.tolist())
     gix.set_option(hv.OPT_FLAT_NO_FAST, 0)
     # restricted row lists: ragged and scattered (lists below 2^22 row elements take other kernels)
+    gix.set_option(hv.OPT_RESTRICTED_DIRECT, 1)  # (... and few queries over a small list the one-launch reference-order kernel, round 6)
     for size in (max(2 ** 22 // dim + 77, 3001), max(2 ** 22 // dim + 1, 33)):
         allowed = np.sort(rng.choice(ids, min(n - 5, size), replace=False))
         rid, rsc, rcnt = gix.search_restricted_batch(q, hv.SearchParams(k), hv.RestrictedVectorCandidates.from_ids(allowed))

@@ -204,3 +204,53 @@ def test_deleted_rows_and_fused_prefilter_take_the_one_launch_scan(orc, hv):
         rc, want_ids, want_sc = oix.flat(q[i], k, allowed=cand)
         assert f_ids[i, : f_cnt[i]].tolist() == want_ids.tolist() and bits(f_sc[i, : f_cnt[i]]).tolist() == bits(want_sc).tolist()
     gix.close()
+
+
+@pytest.mark.parametrize("dtype,metric,dim,n,k,b,spread", [("f32", 1, 1536, 9000, 10, 32, 0.05), ("f32", 1, 768, 20011, 64, 7, 0.5), ("f32", 0, 512, 12000, 10, 32, 0.02),
+                                                           ("f32", 1, 256, 40000, 25, 64, 0.5), ("f32", 1, 1024, 6000, 1, 1, 0.001), ("bf16", 1, 768, 20000, 10, 33, 0.1),
+                                                           ("bf16", 0, 1536, 5000, 17, 32, 0.5), ("f32", 1, 256, 50000, 10, 128, 0.01)])
+def test_exact_tail_equals_the_certificate_pipeline(orc, hv, dtype, metric, dim, n, k, b, spread):
+    """hvx_flat_tail.hip: the small-batch contraction's approximate dot products turned into the exact answer by ONE more launch (filter by
+    the shared k-th exact score, re-score in the reference's order) -- ids and score bits equal the oracle's and the selection / re-rank /
+    certificate pipeline of rounds 3-5, on rows clustered so tightly (spread 0.001 - 0.05) that the one-pass bound covers whole clusters,
+    with duplicate rows (ties broken by id), a rejected query, whole scans and scattered row lists."""
+    rng = np.random.default_rng(dim + n + b + k)
+    centers = rng.standard_normal((32, dim)).astype(np.float32)
+    data = (centers[rng.integers(0, 32, n)] + spread * rng.standard_normal((n, dim))).astype(np.float32)
+    data[7] = data[3]
+    data[100:140] = data[99]  # forty copies of one row: more equal scores than k
+    stored = fx.round_bf16(data) if dtype == "bf16" else data
+    ids = np.arange(n, dtype=np.uint64) + 11
+    gix = hv.ValidatedVectorReadIndex.managed(dim=dim, metric=metric, node_ids=ids, vectors=data, dtype=hv.BF16 if dtype == "bf16" else hv.F32,
+                                              l0_offsets=np.zeros(n + 1, np.uint64), l0_neighbors=np.zeros(0, np.uint64), max_batch=max(b, 16))
+    q = (centers[rng.integers(0, 32, b)] + spread * rng.standard_normal((b, dim))).astype(np.float32)
+    q[0] = data[99]
+    if b > 2:
+        q[b - 1, 5] = np.nan
+    kern = {"kernel": orc.K_AVX_FMA_HW} if dtype == "f32" else {}
+    gid, gsc, gcnt, _, gst = gix.flat_search_batch(q, k, per_query_status=True)
+    assert gix.last_scan_path() & hv.PATH_EXACT_TAIL and gix.last_scan_path() & hv.PATH_SMALL_BATCH
+    gix.set_option(hv.OPT_FLAT_NO_TAIL, 1)
+    oid_, osc_, ocnt_, _, ost_ = gix.flat_search_batch(q, k, per_query_status=True)
+    assert not gix.last_scan_path() & hv.PATH_EXACT_TAIL
+    gix.set_option(hv.OPT_FLAT_NO_TAIL, 0)
+    assert gid.tolist() == oid_.tolist() and bits(gsc).tolist() == bits(osc_).tolist() and gcnt.tolist() == ocnt_.tolist() and gst.tolist() == ost_.tolist()
+    for qi in range(b):
+        if b > 2 and qi == b - 1:
+            assert gst[qi] == hv.ERR_NONFINITE and gcnt[qi] == 0
+            continue
+        rc, oid, osc = orc.flat_matrix(metric, stored, q[qi], k, **kern)
+        assert gst[qi] == 0 and (gid[qi, :gcnt[qi]] - 11).tolist() == oid.tolist(), f"query {qi}"
+        assert bits(gsc[qi, :gcnt[qi]]).tolist() == bits(osc).tolist()
+    # a scattered row list (the restricted scan's shape); twice, so that the self-cleaning counters are used again
+    allowed = np.sort(rng.choice(ids, min(n - 5, max(2 ** 22 // dim + 77, 3001)), replace=False))
+    good = q[: max(1, b - 1)] if b > 2 else q
+    sub = stored[(allowed - 11).astype(np.int64)]
+    gix.set_option(hv.OPT_RESTRICTED_DIRECT, 1)  # (small sets would take the one-launch reference-order kernel)
+    for _ in range(2):
+        rid, rsc, rcnt = gix.search_restricted_batch(good, hv.SearchParams(k), hv.RestrictedVectorCandidates.from_ids(allowed))
+        assert gix.last_scan_path() & hv.PATH_EXACT_TAIL
+        for qi in range(0, good.shape[0], max(1, good.shape[0] // 8)):
+            rc, oid, osc = orc.flat_matrix(metric, sub, good[qi], k, **kern)
+            assert allowed[oid.astype(np.int64)].tolist() == rid[qi, :rcnt[qi]].tolist() and bits(osc).tolist() == bits(rsc[qi, :rcnt[qi]]).tolist()
+    gix.close()

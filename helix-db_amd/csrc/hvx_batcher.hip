@@ -83,6 +83,11 @@ struct Batch {
     uint64_t *ids = nullptr;       // [max_batch][k] pinned
     float *sc = nullptr;           // [max_batch][k] pinned
     uint32_t *cnt = nullptr, *st = nullptr; // [max_batch] pinned
+    // the prefiltered branch (hvx_batcher_new_restricted): every slot's own candidate ids, fixed stride, and their number
+    uint64_t *cand = nullptr;      // [max_batch][ids_cap] pinned
+    uint32_t *cand_n = nullptr;    // [max_batch] pinned
+    uint64_t *dev_cand = nullptr;  // ... as the device addresses them
+    uint32_t *dev_cand_n = nullptr;
     uint64_t *dev_ids = nullptr;   // the same four arrays as the device addresses them (hipHostGetDevicePointer)
     float *dev_sc = nullptr;
     uint32_t *dev_cnt = nullptr, *dev_st = nullptr;
@@ -126,6 +131,7 @@ struct Lane {
     alignas(64) std::atomic<uint32_t> wake_bell{0};
     uint32_t seen_refresh = 0;
     float *d_q = nullptr; // the lane's query rows in HBM (results go straight to the batch's pinned rows)
+    uint64_t *d_cand = nullptr; // restricted batcher: the batch's candidate ids in HBM (same slots)
     hipEvent_t ev = nullptr; // hipEventBlockingSync: the lane sleeps until the stream's work is done
     // where this lane's time went, ns (hvx_batcher_timing)
     std::atomic<uint64_t> ns_idle{0}, ns_collect{0}, ns_drain{0}, ns_fill{0}, ns_device{0}, ns_wake{0};
@@ -138,6 +144,8 @@ constexpr uint64_t kCountMask = 0xFFFFFFull;
 
 struct hvx_batcher {
     hvx_search_params params{};
+    bool restricted = false;       // the operator's Some(candidates) branch: callers bring their own candidate ids
+    uint32_t ids_cap = 0;          // ... at most this many per caller
     uint32_t max_batch = 0, max_wait_us = 0, dim = 0, k = 0, nbuf = 0;
     int device = 0;
     alignas(64) std::atomic<uint64_t> state{0};      // (sequence of the open batch) << kSeqShift (24) | slots claimed
@@ -301,7 +309,16 @@ struct hvx_batcher {
         };
         hipError_t e = hipMemcpyAsync(ln.d_q, bt.q, (size_t)cnt * dim * 4, hipMemcpyHostToDevice, s);
         if (e != hipSuccess) return bad("hipMemcpyAsync(queries)", e);
-        const int rc = hvx_search_batch_params_device(ln.ix, ln.d_q, cnt, &params, bt.dev_ids, bt.dev_sc, bt.dev_cnt, bt.dev_st, nullptr, nullptr, nullptr);
+        int rc;
+        if (restricted) {
+            // candidate ids: a copy kernel reads the slots' USED parts out of pinned memory (a DMA copy would move every slot's full stride);
+            // then ONE launch scans every caller's own candidate set (csrc/hvx_restricted_exact.hip)
+            uint32_t max_len = 0;
+            for (uint32_t i = 0; i < cnt; ++i) max_len = std::max(max_len, std::min(bt.cand_n[i], ids_cap));
+            if ((e = launch_stage_ids(bt.dev_cand, bt.dev_cand_n, ids_cap, ln.d_cand, cnt, s)) != hipSuccess) return bad("stage_ids_kernel", e);
+            rc = hvx_search_restricted_lists_device(ln.ix, ln.d_q, cnt, k, ln.d_cand, ids_cap, bt.dev_cand_n, max_len, bt.dev_ids, bt.dev_sc, bt.dev_cnt, bt.dev_st);
+        } else
+            rc = hvx_search_batch_params_device(ln.ix, ln.d_q, cnt, &params, bt.dev_ids, bt.dev_sc, bt.dev_cnt, bt.dev_st, nullptr, nullptr, nullptr);
         if (rc) { bt.rc = rc; bt.err = hvx_last_error(); (void)hipStreamSynchronize(s); return; }
         if ((e = hipEventRecord(ln.ev, s)) != hipSuccess) return bad("hipEventRecord", e);
         if ((e = hipEventSynchronize(ln.ev)) != hipSuccess) return bad("hipEventSynchronize", e); // (blocking event: no busy-wait)
@@ -331,34 +348,34 @@ extern "C" void hvx_batcher_free(hvx_batcher *b) {
     (void)hipSetDevice(b->device);
     for (Lane &ln : b->lanes) {
         if (ln.d_q) (void)hipFree(ln.d_q);
+        if (ln.d_cand) (void)hipFree(ln.d_cand);
         if (ln.ev) (void)hipEventDestroy(ln.ev);
         if (ln.ix) hvx_index_free(ln.ix);
     }
     for (Batch &bt : b->bufs)
-        for (void *p : {(void *)bt.q, (void *)bt.ids, (void *)bt.sc, (void *)bt.cnt, (void *)bt.st})
+        for (void *p : {(void *)bt.q, (void *)bt.ids, (void *)bt.sc, (void *)bt.cnt, (void *)bt.st, (void *)bt.cand, (void *)bt.cand_n})
             if (p) (void)hipHostFree(p);
     if (b->efd.load() >= 0) (void)close(b->efd.load());
     delete b;
 }
 
-extern "C" int hvx_batcher_new_lanes(hvx_index *ix, const hvx_search_params *params, uint32_t max_batch, uint32_t max_wait_us,
-                                     uint32_t lanes, hvx_batcher **out) {
-    if (!ix || !params || !out) return fail(HVX_ERR_INVARIANT, "null argument");
+static int batcher_create(hvx_index *ix, const hvx_search_params *params, uint32_t k, uint32_t max_batch, uint32_t max_wait_us, uint32_t lanes,
+                          uint32_t ids_cap, hvx_batcher **out) {
     *out = nullptr;
     if (max_batch == 0) max_batch = ix->max_batch;
     if (max_batch > ix->max_batch) return fail(HVX_ERR_UNSUPPORTED, "batch %u exceeds max_batch %u given at import", max_batch, ix->max_batch);
     if (max_batch > 0xFFFFu) max_batch = 0xFFFFu; // (the state word's 24 claim bits leave room for 16 million void claims beyond it)
     if (lanes == 0) lanes = 4;
     if (lanes > 8) return fail(HVX_ERR_K_RANGE, "at most 8 dispatcher lanes");
-    int rc = check_k_ef(params->k, params->ef);
-    if (rc) return rc;
     if (hipSetDevice(ix->device) != hipSuccess) return fail(HVX_ERR_DEVICE, "hipSetDevice failed");
     hvx_batcher *b = new hvx_batcher();
-    b->params = *params;
+    if (params) b->params = *params;
+    b->restricted = ids_cap != 0;
+    b->ids_cap = ids_cap;
     b->max_batch = max_batch;
     b->max_wait_us = max_wait_us;
     b->dim = ix->dev.dim;
-    b->k = params->k;
+    b->k = k;
     b->device = ix->device;
     b->nbuf = lanes + 2; // one open batch, one per lane in flight, one being drained by its callers
     b->bufs = std::vector<Batch>(b->nbuf);
@@ -367,11 +384,16 @@ extern "C" int hvx_batcher_new_lanes(hvx_index *ix, const hvx_search_params *par
     auto devptr = [&](void **d, void *h) { return hipHostGetDevicePointer(d, h, 0) == hipSuccess; };
     auto dev = [&](void **p, size_t bytes) { return hipMalloc(p, bytes) == hipSuccess; };
     bool ok = true;
-    for (Batch &bt : b->bufs)
+    for (Batch &bt : b->bufs) {
         ok = ok && host((void **)&bt.q, (size_t)max_batch * b->dim * 4) && host((void **)&bt.ids, (size_t)max_batch * b->k * 8) &&
              host((void **)&bt.sc, (size_t)max_batch * b->k * 4) && host((void **)&bt.cnt, (size_t)max_batch * 4) &&
              host((void **)&bt.st, (size_t)max_batch * 4) && devptr((void **)&bt.dev_ids, bt.ids) && devptr((void **)&bt.dev_sc, bt.sc) &&
              devptr((void **)&bt.dev_cnt, bt.cnt) && devptr((void **)&bt.dev_st, bt.st);
+        if (b->restricted)
+            ok = ok && host((void **)&bt.cand, (size_t)max_batch * ids_cap * 8) && host((void **)&bt.cand_n, (size_t)max_batch * 4) &&
+                 devptr((void **)&bt.dev_cand, bt.cand) && devptr((void **)&bt.dev_cand_n, bt.cand_n);
+    }
+    int rc;
     for (Lane &ln : b->lanes) {
         if (ok && (rc = hvx_index_fork(ix, &ln.ix))) { // own stream + scratch on the shared image (SimHash rows included)
             hvx_batcher_free(b);
@@ -380,6 +402,7 @@ extern "C" int hvx_batcher_new_lanes(hvx_index *ix, const hvx_search_params *par
         // (a lane inherits the parent handle's settings -- hvx_index_set_occupancy / hvx_index_set_option -- at this point)
         ok = ok && dev((void **)&ln.d_q, (size_t)max_batch * b->dim * 4) &&
              hipEventCreateWithFlags(&ln.ev, hipEventBlockingSync | hipEventDisableTiming) == hipSuccess;
+        if (b->restricted) ok = ok && dev((void **)&ln.d_cand, (size_t)max_batch * ids_cap * 8);
     }
     if (!ok) {
         hvx_batcher_free(b);
@@ -392,6 +415,39 @@ extern "C" int hvx_batcher_new_lanes(hvx_index *ix, const hvx_search_params *par
     }
     *out = b;
     return HVX_OK;
+}
+
+extern "C" int hvx_batcher_new_lanes(hvx_index *ix, const hvx_search_params *params, uint32_t max_batch, uint32_t max_wait_us,
+                                     uint32_t lanes, hvx_batcher **out) {
+    if (!ix || !params || !out) return fail(HVX_ERR_INVARIANT, "null argument");
+    *out = nullptr;
+    int rc = check_k_ef(params->k, params->ef);
+    if (rc) return rc;
+    return batcher_create(ix, params, params->k, max_batch, max_wait_us, lanes, 0, out);
+}
+
+// The prefiltered branch of the operator (execution/interpreter/access/search/storage.rs:140-163: `Some(candidates) =>
+// index.search_restricted(..)`): every caller brings its OWN candidate ids; a batch of them is ONE launch of the exact scan
+// (csrc/hvx_restricted_exact.hip).  The plan must answer such sets exactly: strategy EXACT, or AUTO with slots whose rows stay within the
+// device plan's limit; k <= 64.  Candidate lists longer than max_ids_per_query do not ride in a batch: the host calls
+// hvx_search_restricted_batch_params for them (a list that long keeps the device busy by itself).
+extern "C" int hvx_batcher_new_restricted(hvx_index *ix, const hvx_restricted_params *params, uint32_t max_batch, uint32_t max_wait_us,
+                                          uint32_t lanes, uint32_t max_ids_per_query, hvx_batcher **out) {
+    if (!ix || !params || !out) return fail(HVX_ERR_INVARIANT, "null argument");
+    *out = nullptr;
+    if (params->k == 0) return fail(HVX_ERR_K_RANGE, "result count must be non-zero");
+    if (params->ef < params->k) return fail(HVX_ERR_K_RANGE, "search beam width %u is below the result count %u", params->ef, params->k);
+    if (max_ids_per_query == 0) max_ids_per_query = 4096;
+    if (max_ids_per_query > 1000000u) return fail(HVX_ERR_CANDIDATE_LIMIT, "restricted vector search accepts at most 1000000 unique candidates");
+    if (!restricted_direct_supported(ix, params->k))
+        return fail(HVX_ERR_UNSUPPORTED, "the batched prefiltered search serves k <= 64 over f32 / bf16 rows of a non-empty image");
+    RestrictedPlan plan;
+    int rc = restricted_make_plan(*params, max_ids_per_query, ix->dev.dim, &plan, ix);
+    if (rc) return rc;
+    if (plan.strategy != HVX_RESTRICTED_EXACT || params->explicit_budgets)
+        return fail(HVX_ERR_UNSUPPORTED, "the batched prefiltered search answers candidate sets with the exact scan: strategy EXACT, or AUTO with "
+                    "max_ids_per_query x row bytes within the device plan's limit (the filter-aware walk is not batched per caller)");
+    return batcher_create(ix, nullptr, params->k, max_batch, max_wait_us, lanes, max_ids_per_query, out);
 }
 
 extern "C" int hvx_batcher_new(hvx_index *ix, const hvx_search_params *params, uint32_t max_batch, uint32_t max_wait_us,
@@ -438,10 +494,14 @@ int claim_slot(hvx_batcher *b, bool blocking, uint64_t *seq_out, uint32_t *slot_
 }
 
 // copy the query into the batch's pinned staging row and tell the lanes
-void fill_slot(hvx_batcher *b, uint64_t seq, uint32_t slot, const float *query) {
+void fill_slot(hvx_batcher *b, uint64_t seq, uint32_t slot, const float *query, const uint64_t *allowed_ids = nullptr, uint32_t n_allowed = 0) {
     Batch &bt = b->bufs[seq % b->nbuf];
     if (slot == 0) bt.t_first.store(((seq & 0xFFFFFull) << 44) | now_us_stamp(), std::memory_order_relaxed);
     memcpy(bt.q + (size_t)slot * b->dim, query, (size_t)b->dim * 4);
+    if (b->restricted) {
+        if (n_allowed) memcpy(bt.cand + (size_t)slot * b->ids_cap, allowed_ids, (size_t)n_allowed * 8);
+        bt.cand_n[slot] = n_allowed;
+    }
     bt.grp[slot % Batch::kGroups].filled.fetch_add(1);
     if ((slot == 0 || slot + 1 == b->max_batch || slot + 1 == b->target.load()) && b->sleepers.load()) { // first / last query of a batch, or the count a waiting lane asked for
         b->bell.fetch_add(1);
@@ -499,9 +559,51 @@ int await_slot(hvx_batcher *b, uint64_t seq, uint32_t slot, long timeout_us) {
 inline bool ticket_ok(const hvx_batcher *b, const hvx_batcher_ticket *t) { return t && t->slot < b->max_batch; }
 } // namespace
 
+static int check_restricted_call(const hvx_batcher *b, const uint64_t *allowed_ids, uint32_t n_allowed) {
+    if (!b->restricted) return fail(HVX_ERR_INVARIANT, "this batcher serves the unrestricted branch (hvx_batcher_new): create one with hvx_batcher_new_restricted");
+    if (n_allowed && !allowed_ids) return fail(HVX_ERR_INVARIANT, "null candidate list");
+    if (n_allowed > b->ids_cap)
+        return fail(HVX_ERR_UNSUPPORTED, "%u candidate ids exceed the batcher's max_ids_per_query %u: call hvx_search_restricted_batch_params for this query", n_allowed, b->ids_cap);
+    return HVX_OK;
+}
+
+// ValidatedVectorReadIndex::search_restricted awaited to completion (read_index.rs:93-102) for ONE caller with its own candidate ids
+// (any order, duplicates count once, ids that hold no vector are skipped; an empty list answers with nothing before any validation)
+extern "C" int hvx_batcher_search_restricted(hvx_batcher *b, const float *query, const uint64_t *allowed_ids, uint32_t n_allowed, uint64_t *out_ids,
+                                             float *out_scores, uint32_t *out_count) {
+    if (!b || !query || !out_ids || !out_scores || !out_count) return fail(HVX_ERR_INVARIANT, "null argument");
+    int rc = check_restricted_call(b, allowed_ids, n_allowed);
+    if (rc) return rc;
+    Inside in(b);
+    *out_count = 0;
+    uint64_t seq;
+    uint32_t slot;
+    if ((rc = claim_slot(b, /*blocking=*/true, &seq, &slot))) return rc;
+    fill_slot(b, seq, slot, query, allowed_ids, n_allowed);
+    if ((rc = await_slot(b, seq, slot, -1))) return rc;
+    return take_result(b, seq, slot, out_ids, out_scores, out_count);
+}
+
+extern "C" int hvx_batcher_submit_restricted(hvx_batcher *b, const float *query, const uint64_t *allowed_ids, uint32_t n_allowed,
+                                             hvx_batcher_ticket *out_ticket) {
+    if (!b || !query || !out_ticket) return fail(HVX_ERR_INVARIANT, "null argument");
+    int rc = check_restricted_call(b, allowed_ids, n_allowed);
+    if (rc) return rc;
+    Inside in(b);
+    uint64_t seq;
+    uint32_t slot;
+    if ((rc = claim_slot(b, /*blocking=*/false, &seq, &slot))) return rc;
+    fill_slot(b, seq, slot, query, allowed_ids, n_allowed);
+    out_ticket->sequence = seq;
+    out_ticket->slot = slot;
+    out_ticket->reserved = 0;
+    return HVX_OK;
+}
+
 // The blocking call = submit + wait (ValidatedVectorReadIndex::search awaited to completion, read_index.rs:81-102).
 extern "C" int hvx_batcher_search(hvx_batcher *b, const float *query, uint64_t *out_ids, float *out_scores, uint32_t *out_count) {
     if (!b || !query || !out_ids || !out_scores || !out_count) return fail(HVX_ERR_INVARIANT, "null argument");
+    if (b->restricted) return fail(HVX_ERR_INVARIANT, "this batcher serves the prefiltered branch: call hvx_batcher_search_restricted");
     Inside in(b);
     *out_count = 0;
     uint64_t seq;
@@ -518,6 +620,7 @@ extern "C" int hvx_batcher_search(hvx_batcher *b, const float *query, uint64_t *
 //      futex word, and hvx_batcher_eventfd hands the host an fd its reactor can await: one tick per completed batch. ----
 extern "C" int hvx_batcher_submit(hvx_batcher *b, const float *query, hvx_batcher_ticket *out_ticket) {
     if (!b || !query || !out_ticket) return fail(HVX_ERR_INVARIANT, "null argument");
+    if (b->restricted) return fail(HVX_ERR_INVARIANT, "this batcher serves the prefiltered branch: call hvx_batcher_submit_restricted");
     Inside in(b);
     uint64_t seq;
     uint32_t slot;

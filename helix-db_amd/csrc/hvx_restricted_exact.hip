@@ -49,8 +49,10 @@ struct DirectArgs {
     const float *qhdr;        // [b]
     const uint32_t *rows;     // shared candidate set: internal rows (ascending, unique) ...
     uint32_t n_rows;
-    const uint64_t *ext_ids;  // ... or per-query sets: external ids, query q owns [offsets[q], offsets[q + 1])
+    const uint64_t *ext_ids;  // ... or per-query sets: external ids, query q owns [offsets[q], offsets[q + 1]) ...
     const uint64_t *offsets;
+    const uint32_t *lens;     // ... or, with offsets == NULL, [q * ext_stride, + lens[q]) (the batching operator's fixed slots)
+    uint32_t ext_stride;
     uint32_t contiguous;
     uint32_t b, k, k_stride;
     uint32_t chunk, slices;   // candidate positions per slice (a multiple of 64), slices per query
@@ -149,8 +151,13 @@ __global__ __launch_bounds__(256) void restricted_direct_kernel(DirectArgs a) {
     uint64_t off = 0;
     uint32_t n = a.n_rows;
     if (EXT) {
-        off = a.offsets[q0];
-        n = (uint32_t)(a.offsets[q0 + 1] - off);
+        if (a.offsets) {
+            off = a.offsets[q0];
+            n = (uint32_t)(a.offsets[q0 + 1] - off);
+        } else {
+            off = (uint64_t)q0 * a.ext_stride;
+            n = a.lens[q0];
+        }
     }
     __syncthreads();
 
@@ -354,7 +361,8 @@ __global__ __launch_bounds__(256) void restricted_direct_kernel(DirectArgs a) {
         }
         if (q >= a.b) continue;
         // results (restricted.rs:820-835): the k smallest, sorted; a rejected query keeps its status, an invalid score is an invariant error
-        const uint32_t st = a.qstatus[q];
+        uint32_t st = a.qstatus[q];
+        if (EXT && n == 0u) st = 0u; // an empty candidate set answers with nothing BEFORE the query is validated (restricted.rs:539-541)
         uint32_t isbad = 0;
         if (lane == 0) { isbad = ld_agent(a.bad + q); if (isbad) st_agent(a.bad + q, 0u); }
         isbad = __builtin_amdgcn_readfirstlane(isbad);
@@ -489,7 +497,7 @@ static int direct_scratch(hvx_index *ix, uint32_t b, uint32_t slices, uint32_t k
 // length k_stride.  Nothing is synchronised here.
 int restricted_direct_enqueue(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, uint32_t k_stride, const uint32_t *d_rows,
                               uint32_t n_rows, const uint64_t *d_ext_ids, const uint64_t *d_offsets, uint32_t max_set, uint64_t *d_ids,
-                              float *d_scores, uint32_t *d_counts, uint32_t *d_status) {
+                              float *d_scores, uint32_t *d_counts, uint32_t *d_status, const uint32_t *d_lens, uint32_t ext_stride) {
     const DevIndex &d = ix->dev;
     const bool ext = d_ext_ids != nullptr;
     const bool unrolled = direct_unrolled_shape(d);
@@ -512,6 +520,8 @@ int restricted_direct_enqueue(hvx_index *ix, const float *d_queries, uint32_t b,
     a.n_rows = n_rows;
     a.ext_ids = d_ext_ids;
     a.offsets = d_offsets;
+    a.lens = d_lens;
+    a.ext_stride = ext_stride;
     a.contiguous = ix->contiguous ? 1u : 0u;
     a.b = b; a.k = k; a.k_stride = k_stride;
     a.chunk = chunk; a.slices = slices;
@@ -529,6 +539,19 @@ int restricted_direct_enqueue(hvx_index *ix, const float *d_queries, uint32_t b,
     return HVX_OK;
 }
 
+// candidate ids of a batch from the batching operator's pinned slots (fixed stride) into device memory: only the ids that are there
+__global__ __launch_bounds__(256) void stage_ids_kernel(const uint64_t *src, const uint32_t *lens, uint32_t stride, uint64_t *dst, uint32_t b) {
+    const uint32_t q = blockIdx.x;
+    if (q >= b) return;
+    const uint32_t n = lens[q] < stride ? lens[q] : stride;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) dst[(size_t)q * stride + i] = src[(size_t)q * stride + i];
+}
+hipError_t launch_stage_ids(const uint64_t *src, const uint32_t *lens, uint32_t stride, uint64_t *dst, uint32_t b, hipStream_t s) {
+    if (b == 0) return hipSuccess;
+    hipLaunchKernelGGL(stage_ids_kernel, dim3(b), dim3(256), 0, s, src, lens, stride, dst, b);
+    return hipGetLastError();
+}
+
 hipError_t launch_stage_queries(const float *src, float *dst, uint32_t dim, uint32_t b, hipStream_t s) {
     if (b == 0) return hipSuccess;
     hipLaunchKernelGGL(stage_queries_kernel, dim3(b), dim3(256), 0, s, src, dst, dim, b);
@@ -536,3 +559,24 @@ hipError_t launch_stage_queries(const float *src, float *dst, uint32_t dim, uint
 }
 
 } // namespace hvx
+
+// Device-resident surface of the prefiltered branch: b queries in HBM, query q with its own candidate ids d_allowed_ids[q * stride ..
+// + d_lens[q]) (external ids, any order, duplicates allowed, unknown ids skipped); exact strategy, one launch, nothing synchronised.
+extern "C" int hvx_search_restricted_lists_device(const hvx_index *cix, const float *d_queries, uint32_t b, uint32_t k, const uint64_t *d_allowed_ids,
+                                                  uint32_t stride, const uint32_t *d_lens, uint32_t max_len, uint64_t *d_out_ids, float *d_out_scores,
+                                                  uint32_t *d_out_counts, uint32_t *d_out_status) {
+    if (!cix || !d_queries || !d_allowed_ids || !d_lens || !d_out_ids || !d_out_scores || !d_out_counts) return fail(HVX_ERR_INVARIANT, "null argument");
+    hvx_index *ix = const_cast<hvx_index *>(cix);
+    if (k == 0) return fail(HVX_ERR_K_RANGE, "result count must be non-zero");
+    if (b == 0) return HVX_OK;
+    if (b > ix->max_batch) return fail(HVX_ERR_UNSUPPORTED, "batch %u exceeds max_batch %u given at import", b, ix->max_batch);
+    if (max_len > stride) return fail(HVX_ERR_INVARIANT, "a candidate list longer than its slot");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    ix->sync_rewrites();
+    if (!restricted_direct_supported(ix, k))
+        return fail(HVX_ERR_UNSUPPORTED, "the one-launch restricted scan serves k <= 64 over f32 / bf16 rows of a non-empty image");
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(launch_validate_queries(ix->dev, d_queries, b, ix->limit, ix->d_qstatus, ix->d_qhdr, ix->stream));
+    return restricted_direct_enqueue(ix, d_queries, b, k, k, nullptr, 0, d_allowed_ids, nullptr, max_len, d_out_ids, d_out_scores, d_out_counts,
+                                     d_out_status, d_lens, stride);
+}

@@ -345,6 +345,14 @@ def lib():
     L.hvx_batcher_new.restype = C.c_int
     L.hvx_batcher_new.argtypes = [_vp, C.POINTER(_Params), C.c_uint32, C.c_uint32, C.POINTER(_vp)]
     L.hvx_batcher_free.argtypes = [_vp]
+    L.hvx_batcher_new_restricted.restype = C.c_int
+    L.hvx_batcher_new_restricted.argtypes = [_vp, C.POINTER(RestrictedParams), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_vp)]
+    L.hvx_batcher_search_restricted.restype = C.c_int
+    L.hvx_batcher_search_restricted.argtypes = [_vp, _vp, _vp, C.c_uint32, _vp, _vp, C.POINTER(C.c_uint32)]
+    L.hvx_batcher_submit_restricted.restype = C.c_int
+    L.hvx_batcher_submit_restricted.argtypes = [_vp, _vp, _vp, C.c_uint32, C.POINTER(BatcherTicket)]
+    L.hvx_search_restricted_lists_device.restype = C.c_int
+    L.hvx_search_restricted_lists_device.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32, _vp, C.c_uint32, _vp, _vp, _vp, _vp]
     L.hvx_batcher_search.restype = C.c_int
     L.hvx_batcher_search.argtypes = [_vp, _vp, _vp, _vp, C.POINTER(C.c_uint32)]
     L.hvx_batcher_submit.restype = C.c_int
@@ -1102,6 +1110,41 @@ class Batcher:
         t = BatcherTimes()
         _check(lib().hvx_batcher_lane_times(self._h, C.byref(t)))
         return {"lanes": int(t.lanes), **{f[0][:-3] + "_ms": getattr(t, f[0]) / 1e6 for f in BatcherTimes._fields_ if f[0].endswith("_ns")}}
+
+
+class RestrictedBatcher(Batcher):
+    """hvx_batcher_new_restricted: the operator's `Some(candidates) => index.search_restricted(..)` branch (storage.rs:140-163) -- every caller
+    brings its own candidate ids; a batch of callers is ONE launch of the exact scan.  poll / wait / eventfd / stats as for Batcher."""
+
+    def __init__(self, index: "ValidatedVectorReadIndex", rparams: RestrictedParams, max_batch: int = 0, max_wait_us: int = 0, lanes: int = 0,
+                 max_ids_per_query: int = 0):
+        self._index = index
+        self.k = int(rparams.k)
+        h = _vp()
+        _check(lib().hvx_batcher_new_restricted(index._h, C.byref(rparams), max_batch, max_wait_us, lanes, max_ids_per_query, C.byref(h)))
+        self._h = h
+
+    def _args(self, query, candidates):
+        q = np.ascontiguousarray(query, dtype=np.float32).reshape(-1)
+        if q.size != self._index.dim:
+            raise HelixDbError(ERR_DIMENSION, f"expected dimension {self._index.dim}, got {q.size}")
+        al = candidates.ids if isinstance(candidates, RestrictedVectorCandidates) else np.ascontiguousarray(candidates, dtype=np.uint64).reshape(-1)
+        return q, al
+
+    def search(self, query, candidates):
+        q, al = self._args(query, candidates)
+        ids = np.zeros(self.k, np.uint64); sc = np.zeros(self.k, np.float32); cnt = C.c_uint32(0)
+        _check(lib().hvx_batcher_search_restricted(self._h, _ptr(q), _ptr(al) if al.size else None, al.size, _ptr(ids), _ptr(sc), C.byref(cnt)))
+        return [SearchResult(int(i), s) for i, s in zip(ids[: cnt.value], sc[: cnt.value])]
+
+    def submit(self, query, candidates):
+        q, al = self._args(query, candidates)
+        t = BatcherTicket()
+        rc = lib().hvx_batcher_submit_restricted(self._h, _ptr(q), _ptr(al) if al.size else None, al.size, C.byref(t))
+        if rc == ERR_BUSY:
+            return None
+        _check(rc)
+        return t
 
 
 def _visit_arrays(cap):

@@ -353,6 +353,15 @@ int hvx_search_restricted_batch_params(const hvx_index *, const float *queries, 
                                        uint32_t *out_status /*nullable*/, hvx_restricted_stats *out_restricted_stats /*[b] nullable*/,
                                        hvx_stats *stats /*nullable*/);
 
+/* Device-resident surface of the prefiltered branch, exact strategy (csrc/hvx_restricted_exact.hip): b queries in HBM, query q with its OWN
+ * candidate ids d_allowed_ids[q * stride .. + d_lens[q]) -- external ids in any order; duplicates count once (RestrictedVectorCandidates is a
+ * set, restricted.rs:303-371), ids that hold no (live) vector are skipped (:615-659), an empty list answers with nothing and status 0 before
+ * the query is validated (:539-541).  k <= 64, f32 / bf16 rows.  ONE launch for the batch; nothing is synchronised; outputs may be HBM or
+ * mapped host rows.  max_len = the longest list (<= stride). */
+int hvx_search_restricted_lists_device(const hvx_index *, const float *d_queries, uint32_t b, uint32_t k, const uint64_t *d_allowed_ids,
+                                       uint32_t stride, const uint32_t *d_lens, uint32_t max_len, uint64_t *d_out_ids /*[b][k]*/,
+                                       float *d_out_scores, uint32_t *d_out_counts, uint32_t *d_out_status /*nullable*/);
+
 /* k-way merge of per-shard results by Candidate order (model.rs:55-61); inputs in HBM, laid out
  * [g][b][k] as an all-gather over shards delivers them. */
 int hvx_merge_topk_device(const hvx_index *, uint32_t g, uint32_t b, uint32_t k, const uint64_t *d_ids,
@@ -536,6 +545,19 @@ int hvx_batcher_poll(hvx_batcher *, const hvx_batcher_ticket *ticket, uint64_t *
 int hvx_batcher_wait(hvx_batcher *, const hvx_batcher_ticket *ticket, uint32_t timeout_us, uint64_t *out_ids /*[k]*/, float *out_scores /*[k]*/,
                      uint32_t *out_count);
 int hvx_batcher_eventfd(hvx_batcher *); /* -1 on failure */
+/* The operator's OTHER branch (execution/interpreter/access/search/storage.rs:140-163: `Some(candidates) => index.search_restricted(..)`):
+ * every caller brings its own candidate ids (a where_() / traversal filter evaluated by the host).  A batch of such callers is ONE launch of
+ * the exact scan with per-query candidate lists -- 256 callers x 1 000 ids x 1536 floats: 0.26 ms of device time (profiles/r06d_*).
+ * params: k <= 64; the plan must answer a max_ids_per_query-id set exactly (strategy EXACT, or AUTO within the device plan's limit); lists
+ * beyond max_ids_per_query (0 = 4 096; pinned memory: lanes + 2 buffers x max_batch x max_ids_per_query x 8 B) are refused with
+ * HVX_ERR_UNSUPPORTED -- the host sends those through hvx_search_restricted_batch_params.  Tickets of a restricted batcher are polled /
+ * waited for / awaited through the eventfd like any other; hvx_batcher_search / _submit refuse a restricted batcher and vice versa. */
+int hvx_batcher_new_restricted(hvx_index *, const hvx_restricted_params *params, uint32_t max_batch, uint32_t max_wait_us, uint32_t lanes,
+                               uint32_t max_ids_per_query, hvx_batcher **out);
+int hvx_batcher_search_restricted(hvx_batcher *, const float *query /*[dim]*/, const uint64_t *allowed_ids, uint32_t n_allowed,
+                                  uint64_t *out_ids /*[k]*/, float *out_scores /*[k]*/, uint32_t *out_count);
+int hvx_batcher_submit_restricted(hvx_batcher *, const float *query /*[dim]*/, const uint64_t *allowed_ids, uint32_t n_allowed,
+                                  hvx_batcher_ticket *out_ticket);
 /* after hvx_index_insert_batch on the handle the batcher was created from: the dispatcher lanes (forks of that handle) adopt the new
  * generation before the next batch each of them launches */
 int hvx_batcher_refresh(hvx_batcher *);

@@ -74,6 +74,21 @@ int main(int argc, char **argv) {
         if (hvx_index_set_simhash(ix, &c, nullptr)) { fprintf(stderr, "%s\n", hvx_last_error()); return 1; }
     }
     const uint32_t k = p.k;
+    // BATCHER_RESTRICTED=<m>: the operator's prefiltered branch (storage.rs:140-163 `Some(candidates)`): every call brings ITS OWN m candidate
+    // ids (a pool of 4 096 random lists; callers walk through it), batched by hvx_batcher_new_restricted; the direct baseline = one
+    // hvx_search_restricted_batch_params call per query
+    const char *e_res = getenv("BATCHER_RESTRICTED");
+    const uint32_t res_m = e_res ? (uint32_t)atoi(e_res) : 0u;
+    const uint32_t n_lists = 4096;
+    std::vector<uint64_t> lists;
+    hvx_restricted_params rp;
+    hvx_restricted_params_default(&rp, k, 100);
+    if (res_m) {
+        lists.resize((size_t)n_lists * res_m);
+        uint64_t x = 0x9E3779B97F4A7C15ull;
+        for (auto &v : lists) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = ids[x % n]; }
+    }
+    auto list_of = [&](long call) { return lists.data() + (size_t)((uint64_t)call % n_lists) * res_m; };
     auto run = [&](hvx_batcher *bt, double *qps, double *mean_us, double *p99_us) {
         std::vector<std::vector<double>> lat(threads);
         std::atomic<int> failures{0};
@@ -87,8 +102,11 @@ int main(int argc, char **argv) {
                 for (int i = 0; i < per; ++i) {
                     const float *q = qs.data() + (size_t)((t * per + i) % nq) * dim;
                     const auto a = std::chrono::steady_clock::now();
-                    int rc = bt ? hvx_batcher_search(bt, q, oi.data(), os.data(), &cnt)
-                                : hvx_search_batch_params(ix, q, 1, &p, oi.data(), os.data(), &cnt, &st, nullptr, nullptr, nullptr);
+                    int rc;
+                    if (res_m) rc = bt ? hvx_batcher_search_restricted(bt, q, list_of((long)t * per + i), res_m, oi.data(), os.data(), &cnt)
+                                       : hvx_search_restricted_batch_params(ix, q, 1, &rp, list_of((long)t * per + i), nullptr, res_m, oi.data(), os.data(), &cnt, &st, nullptr, nullptr);
+                    else rc = bt ? hvx_batcher_search(bt, q, oi.data(), os.data(), &cnt)
+                                 : hvx_search_batch_params(ix, q, 1, &p, oi.data(), os.data(), &cnt, &st, nullptr, nullptr, nullptr);
                     if (rc || cnt != k) failures++;
                     lat[t].push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count());
                 }
@@ -161,7 +179,7 @@ int main(int argc, char **argv) {
                         if (live[w]) continue;
                         const float *q = qs.data() + (size_t)((t * quota + issued) % nq) * dim;
                         ts[w] = std::chrono::steady_clock::now();
-                        const int rc = hvx_batcher_submit(bt, q, &tk[w]);
+                        const int rc = res_m ? hvx_batcher_submit_restricted(bt, q, list_of((long)t * quota + issued), res_m, &tk[w]) : hvx_batcher_submit(bt, q, &tk[w]);
                         if (rc == HVX_ERR_BUSY) { busy++; break; }
                         if (rc) { failures++; break; }
                         live[w] = 1; ++inflight; ++issued;
@@ -208,7 +226,8 @@ int main(int argc, char **argv) {
     if (e_occ && hvx_index_set_occupancy(ix, (uint32_t)atoi(e_occ))) { fprintf(stderr, "%s\n", hvx_last_error()); return 1; }
     if (e_pair && hvx_index_set_option(ix, HVX_OPT_HNSW_PAIR, (uint32_t)atoi(e_pair))) { fprintf(stderr, "%s\n", hvx_last_error()); return 1; }
     const char *e_maxb = getenv("BATCHER_MAXB"); // (default 1 024 = the index's max_batch; small values exercise full batches and void claims)
-    if (hvx_batcher_new_lanes(ix, &p, e_maxb ? (uint32_t)atoi(e_maxb) : 1024u, wait_us, lanes, &bt)) { fprintf(stderr, "%s\n", hvx_last_error()); return 1; }
+    if (res_m ? hvx_batcher_new_restricted(ix, &rp, e_maxb ? (uint32_t)atoi(e_maxb) : 1024u, wait_us, lanes, res_m, &bt)
+              : hvx_batcher_new_lanes(ix, &p, e_maxb ? (uint32_t)atoi(e_maxb) : 1024u, wait_us, lanes, &bt)) { fprintf(stderr, "%s\n", hvx_last_error()); return 1; }
     const char *e_nb = getenv("BATCHER_NB"); // "<submitters>x<tickets>": the non-blocking form instead of one blocked thread per query
     int nb_subs = 0, nb_win = 0;
     if (e_nb && sscanf(e_nb, "%dx%d", &nb_subs, &nb_win) != 2) { fprintf(stderr, "BATCHER_NB=<submitters>x<tickets>\n"); return 2; }
@@ -232,7 +251,7 @@ int main(int argc, char **argv) {
     printf("{\"workload\": \"%llu x %u f32, %s, k=10, %d caller threads x %d single-query calls\", "
            "\"direct_calls\": {\"qps\": %.0f, \"mean_us\": %.1f, \"p99_us\": %.1f}, "
            "\"batcher\": {\"lanes\": %u, \"qps\": %.0f, \"mean_us\": %.1f, \"p99_us\": %.1f, \"mean_batch\": %.1f, \"max_wait_us\": %u, \"occ\": \"%s\", \"pair\": \"%s\"}}\n",
-           (unsigned long long)n, dim, strict ? "strict ef=100" : "SearchParams::new(10)", threads, per, q0, m0, p0, lanes, q1, m1, p1,
+           (unsigned long long)n, dim, res_m ? (std::string("restricted, every call its own ") + std::to_string(res_m) + " candidate ids (exact)").c_str() : (strict ? "strict ef=100" : "SearchParams::new(10)"), threads, per, q0, m0, p0, lanes, q1, m1, p1,
            nb ? (double)nqs / nb : 0.0, wait_us, e_occ ? e_occ : "default", e_pair ? e_pair : "default");
     hvx_batcher_free(bt);
     hvx_index_free(ix);

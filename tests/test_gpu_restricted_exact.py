@@ -254,3 +254,62 @@ def test_exact_tail_equals_the_certificate_pipeline(orc, hv, dtype, metric, dim,
             rc, oid, osc = orc.flat_matrix(metric, sub, good[qi], k, **kern)
             assert allowed[oid.astype(np.int64)].tolist() == rid[qi, :rcnt[qi]].tolist() and bits(osc).tolist() == bits(rsc[qi, :rcnt[qi]]).tolist()
     gix.close()
+
+
+def test_batching_operator_for_the_prefiltered_branch(orc, hv):
+    """hvx_batcher_new_restricted / _search_restricted / _submit_restricted: 64 threads, each with ITS OWN candidate ids per call
+    (storage.rs:140-163 `Some(candidates) => index.search_restricted(..)`), coalesced into launches of the one-launch exact scan; every caller
+    gets the oracle's rows for ITS set; an empty list, a rejected query (fails alone), a list beyond the slot size (refused, not truncated),
+    the non-blocking form, and the unrestricted entry points refusing a restricted batcher."""
+    import threading
+    n, dim, k = 4000, 256, 10
+    oix, gix, ids, data, q, rng = pair(orc, hv, n, dim, 1, None, "f32", seed=77, sparse_ids=True, max_batch=64)
+    bt = hv.RestrictedBatcher(gix, hv.RestrictedParams.auto(k, 100), max_batch=64, max_wait_us=200, lanes=2, max_ids_per_query=1500)
+    threads, per = 16, 12
+    jobs = [[(rng.standard_normal(dim).astype(np.float32), rng.choice(ids, int(rng.integers(1, 1500)), replace=True).astype(np.uint64)) for _ in range(per)]
+            for _ in range(threads)]
+    out = [[None] * per for _ in range(threads)]
+    errs = []
+
+    def work(t):
+        try:
+            for i, (qq, al) in enumerate(jobs[t]):
+                out[t][i] = bt.search(qq, al)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errs, errs
+    for t in range(threads):
+        for i, (qq, al) in enumerate(jobs[t]):
+            rc, want_ids, want_sc = oix.flat(qq, k, allowed=al)
+            got = out[t][i]
+            assert [r.entity_id for r in got] == want_ids.tolist() and bits(np.array([r.score for r in got], np.float32)).tolist() == bits(want_sc).tolist()
+    st = bt.stats()
+    assert st["queries"] == threads * per and st["batches"] < threads * per  # (coalesced)
+    assert bt.search(q[0], np.zeros(0, np.uint64)) == []                      # empty set: nothing, no validation
+    bad = q[1].copy(); bad[3] = np.inf
+    assert bt.search(bad, np.zeros(0, np.uint64)) == []
+    with pytest.raises(hv.HelixDbError) as e:
+        bt.search(bad, ids[:10])
+    assert e.value.status == hv.ERR_NONFINITE
+    with pytest.raises(hv.HelixDbError) as e:
+        bt.search(q[0], np.arange(1501, dtype=np.uint64))                    # beyond max_ids_per_query: refused
+    assert e.value.status == hv.ERR_UNSUPPORTED
+    tickets = []
+    for i in range(20):
+        tk = bt.submit(q[i], ids[i * 50:(i + 1) * 50 + 500])
+        assert tk is not None
+        tickets.append(tk)
+    for i, tk in enumerate(tickets):
+        got = bt.wait(tk)
+        rc, want_ids, want_sc = oix.flat(q[i], k, allowed=ids[i * 50:(i + 1) * 50 + 500])
+        assert [r.entity_id for r in got] == want_ids.tolist()
+    with pytest.raises(hv.HelixDbError):
+        hv.Batcher.search(bt, q[0])                                           # the unrestricted entry point refuses this batcher
+    with pytest.raises(hv.HelixDbError):                                      # the reference plan walks above 256 ids: not batched per caller
+        hv.RestrictedBatcher(gix, hv.RestrictedParams.new(k, 100), max_batch=64, max_ids_per_query=1500)
+    bt.close()
+    gix.close()

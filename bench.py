@@ -82,7 +82,7 @@ def parse():
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle bit-exactness check")
     ap.add_argument("--metric", default="l2", choices=["l2", "cosine"])
     ap.add_argument("--deletes", type=int, default=2000, help="nodes the insert leg deletes again (hvx_index_delete_batch), 0 = none")
-    ap.add_argument("--skip", default="", help="comma list of extra legs to skip: production,production_lanes,batcher,insert,datasets,iso_recall,config3,config4,config5,"
+    ap.add_argument("--skip", default="", help="comma list of extra legs to skip: production,production_lanes,batcher,insert,datasets,iso_recall,latent,config3,config4,config5,"
                                                "graph_equivalence,ef_sweep,peak,vendor_gemm")
     ap.add_argument("--full-record", default=os.path.join(ROOT, "bench_full.json"), help="where the full record of every leg is written")
     ap.add_argument("--c3-corpus", default="clustered", choices=["clustered", "topic_ordered"],
@@ -413,7 +413,7 @@ def leg_config3(hv, synth, orc, args, dev, k=10, nq=32, rounds=5):
     lv = synth.draw_levels(n, 16, 11)
     ix, bst = hv.ValidatedVectorReadIndex.build(dim=dim, metric=hv.EUCLIDEAN, node_ids=np.arange(n, dtype=np.uint64), vectors=x, levels=lv,
                                                 m=16, m0=32, ef_construction=200, max_batch=args.build_batch, batch_divisor=32,
-                                                device=dev.index, search_max_batch=nq, scatter=scatter)
+                                                device=dev.index, search_max_batch=1024, scatter=scatter)
     ix.sync()
     t_build = time.time() - t0
     audit = graph_audit(ix, 16)
@@ -459,7 +459,23 @@ def leg_config3(hv, synth, orc, args, dev, k=10, nq=32, rounds=5):
         exact = {"end_to_end_ms_per_batch": round(ms, 3), "us_per_query": round(ms * 1e3 / nq, 1), "scan_kernels_ms": round(kms, 3),
                  "hbm_gbs_scan": round(alg / (kms * 1e-3) / 1e9, 1), "distance_computations_per_query": size,
                  "scan_path_flags": ix.last_scan_path(), "oracle_bit_exact_sample": bool(ok)}
-        # ---- planned: restricted_execution_plan (exact <= 256 ids / 4 MiB, else the filter-aware walk)
+        # ---- device plan (round 6): HVX_RESTRICTED_AUTO, the library's default -- exact while the candidate rows take <= 1 GiB
+        rpa = hv.RestrictedParams.auto(k, ef)
+        lat, kern = [], []
+        for r in range(rounds + 1):
+            t1 = time.perf_counter()
+            aid, asc, acnt, ncand, ars, ast = ix.prefilter_search_batch_params(g, q, rpa, src, direction=hv.DIR_OUT)
+            if r:
+                lat.append(time.perf_counter() - t1)
+                kern.append(ast["device_ms"])
+        ams, akms = float(np.median(lat)) * 1e3, float(np.median(kern))
+        arec = sum(len(set(aid[i, :acnt[i]].tolist()) & set(fid[i, :fcnt[i]].tolist())) for i in range(nq)) / float(nq * k)
+        device_plan = {"strategy": "exact" if ars[0]["strategy"] == hv.RESTRICTED_EXACT else "filtered_graph", "end_to_end_ms_per_batch": round(ams, 3),
+                       "us_per_query": round(ams * 1e3 / nq, 1), "scan_kernels_ms": round(akms, 3), "recall_at_10_vs_exact": round(arec, 4),
+                       "ids_equal_exact_leg": bool(aid.tolist() == fid.tolist() and asc.view(np.uint32).tolist() == fsc.view(np.uint32).tolist()),
+                       "scan_path_flags": ix.last_scan_path(), "hbm_gbs_scan": round(alg / (akms * 1e-3) / 1e9, 1),
+                       "gate_recall_ge_0.92": bool(arec >= 0.92)}
+        # ---- reference plan: restricted_execution_plan (exact <= 256 ids / 4 MiB, else the filter-aware walk): what the reference runs
         rp = hv.RestrictedParams.new(k, ef)
         lat, kern = [], []
         for r in range(rounds + 1):
@@ -506,6 +522,7 @@ def leg_config3(hv, synth, orc, args, dev, k=10, nq=32, rounds=5):
                                      "distance_computations_per_query_max": int(max(r_["distance_computations"] for r_ in brs))}
         # the reference issues ONE query per call (index_lifecycle_scale.rs:1893-1912): per-query end-to-end latency of the fused call
         for name_, fn_ in (("planned", lambda qq: ix.prefilter_search_batch_params(g, qq, rp, src, direction=hv.DIR_OUT)),
+                           ("device", lambda qq: ix.prefilter_search_batch_params(g, qq, rpa, src, direction=hv.DIR_OUT)),
                            ("exact", lambda qq: ix.prefilter_search_batch(g, qq, hv.SearchParams(k).with_ef(ef), src, direction=hv.DIR_OUT))):
             one = []
             fn_(q[:1])
@@ -514,14 +531,39 @@ def leg_config3(hv, synth, orc, args, dev, k=10, nq=32, rounds=5):
                 fn_(q[qi:qi + 1])
                 one.append((time.perf_counter() - t1) * 1e3)
             one.sort()
-            (planned if name_ == "planned" else exact)["single_query_end_to_end_ms"] = {"p50": round(one[(nq - 1) * 50 // 100], 3), "p95": round(one[(nq - 1) * 95 // 100], 3)}
+            {"planned": planned, "device": device_plan, "exact": exact}[name_]["single_query_end_to_end_ms"] = {"p50": round(one[(nq - 1) * 50 // 100], 3), "p95": round(one[(nq - 1) * 95 // 100], 3)}
         planned["reference_gates"] = {"recall_at_10_ge_0.92": bool(rec >= 0.92), "distance_computations_le_800": bool(dc.max() <= 800),
                                       "directory_rows_le_65536": bool(planned["directory_rows_max"] <= 65536),
                                       "end_to_end_p95_le_50ms": bool(planned["single_query_end_to_end_ms"]["p95"] <= 50.0)}
         planned["reference_gates"]["passed"] = all(planned["reference_gates"].values())
         ok_all &= bool(ok) and bool(pok)
         groups.append({"candidates": size, "reference_plan": hv.restricted_execution_plan(size, dim, hv.SearchParams.new(k)), "planned": planned,
-                       "exact": exact})
+                       "device_plan": device_plan, "exact": exact})
+    # ---- the operator's shape (storage.rs:140-163): every request brings ITS OWN candidate ids -- one launch per batch of requests
+    own = []
+    rng_o = np.random.default_rng(20260924)
+    for m_ids, b_req in ((1000, 256), (1000, 1024), (10000, 256)):
+        lists = [np.sort(rng_o.choice(n, m_ids, replace=False)).astype(np.uint64) for _ in range(b_req)]
+        offs = (np.arange(b_req + 1, dtype=np.uint64) * np.uint64(m_ids))
+        flat_ids = np.concatenate(lists)
+        qreq = x[torch.randint(0, n, (b_req,), generator=torch.Generator().manual_seed(9)).to(dev)].cpu().numpy()
+        lat, kern = [], []
+        for r in range(4):
+            t1 = time.perf_counter()
+            oid_, osc_, ocnt_, ost_, ors_, ostat_ = ix.search_restricted_batch_params(qreq, rpa, flat_ids, offsets=offs, want_stats=True)
+            if r:
+                lat.append(time.perf_counter() - t1)
+                kern.append(ostat_["device_ms"])
+        okq = True
+        for qi in range(0, b_req, max(1, b_req // 8)):  # a sample of the requests against the oracle's exact scan of THEIR rows
+            rc, wid, wsc = orc.flat_matrix(orc.L2SQ, x[torch.from_numpy(lists[qi].astype(np.int64)).to(dev)].cpu().numpy(), qreq[qi], k, kernel=orc.K_AVX_FMA_HW)
+            okq &= lists[qi][wid.astype(np.int64)].tolist() == oid_[qi, :ocnt_[qi]].tolist() and wsc.view(np.uint32).tolist() == osc_[qi, :ocnt_[qi]].view(np.uint32).tolist()
+        ms_, kms_ = float(np.median(lat)) * 1e3, float(np.median(kern))
+        bytes_ = b_req * m_ids * dim * 4
+        own.append({"requests": b_req, "ids_per_request": m_ids, "kernel_ms": round(kms_, 3), "end_to_end_ms": round(ms_, 3), "qps_kernel": round(b_req / (kms_ * 1e-3), 1),
+                    "qps_end_to_end": round(b_req / (ms_ * 1e-3), 1), "hbm_gbs": round(bytes_ / (kms_ * 1e-3) / 1e9, 1),
+                    "frac_of_hbm_peak": round(bytes_ / (kms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "oracle_bit_exact_sample": bool(okq)})
+        ok_all &= bool(okq)
     big = groups[-1]
     out = {"workload": f"configs[2]: {n}x{dim} f32 [{corpus_name}], Euclidean, HNSW M=16/M0=32/efC=200 "
                        f"(device build, {'scattered' if scatter else 'id-order'} insertion, {t_build:.1f} s), benchmark topology i -> i+N/2, one-hop where_() group -> restricted kNN k={k} ef={ef}, "
@@ -534,9 +576,14 @@ def leg_config3(hv, synth, orc, args, dev, k=10, nq=32, rounds=5):
            "reference_gates_passed": (bool(all(g_["planned"]["reference_gates"]["passed"] for g_ in groups)) if real_fbin else None),
            "gates_on_this_corpus": [{"candidates": g_["candidates"], **g_["planned"]["reference_gates"]} for g_ in groups],
            "graph_audit": audit,
-           "strategies": "planned = the reference's plan (restricted.rs:426-453: exact <= 256 ids, filter-aware walk above, 150 % beam); "
-                         "exact = the device's exact gathered scan of every candidate row (recall 1.0 by construction)",
+           "strategies": "device_plan = HVX_RESTRICTED_AUTO, the library's default since round 6: exact gathered scan while the candidate rows take <= 1 GiB "
+                         "(recall 1.0 by construction), the filter-aware walk above; planned = the reference's plan (restricted.rs:426-453: exact <= 256 ids, "
+                         "filter-aware walk above, 150 % beam: HVX_RESTRICTED_REFERENCE_PLAN, every counter held to the oracle); exact = strategy EXACT forced",
            "groups": groups,
+           "per_request_candidate_sets": {"what": "hvx_search_restricted_batch_params with allowed_offsets: every request its own candidate ids, ONE launch per batch "
+                                                  "(csrc/hvx_restricted_exact.hip); algorithmic bytes = requests x ids x dim x 4", "rows": own},
+           "device_plan_gates": [{"candidates": g_["candidates"], "strategy": g_["device_plan"]["strategy"], "recall_at_10": g_["device_plan"]["recall_at_10_vs_exact"],
+                                  "recall_ge_0.92": g_["device_plan"]["gate_recall_ge_0.92"]} for g_ in groups],
            "roofline": {"bound": "hbm", "kernel": "restricted exact scan, 100 000-candidate group", "achieved": big["exact"]["hbm_gbs_scan"],
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(big["exact"]["hbm_gbs_scan"] / HBM_PEAK_GBS, 4),
                         "note": "algorithmic bytes = candidates x dim x 4 (each row once per batch) / scan-kernel time; "
@@ -1145,6 +1192,7 @@ def compact_record(out, full_path):
         c["host_stall_in_first_run"] = out.get("host_stall_in_first_run")
     c["roofline"] = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "peak_measured", "unit", "frac", "frac_of_measured",
                                             "algorithmic_bytes_per_launch", "kernel_ms", "kernel_ms_each", "traffic", "traffic_source")}
+    c["roofline"]["frac_definition"] = f"overlapped span, {rf.get('lanes')} lanes x {rf.get('queries_per_simd')} queries per SIMD; one launch alone: lone_batch_frac"
     lb = rf.get("lone_batch") or {}
     if lb:
         c["roofline"]["lone_batch_frac"] = lb.get("frac")
@@ -1172,19 +1220,32 @@ def compact_record(out, full_path):
             hit = iso.get("iso_recall")
             d2["clustered"]["iso_recall"] = None if not hit else {"ef_search": hit.get("ef_search"), "qps": hit.get("qps"), "recall_at_10": hit.get("recall_at_10")}
         c["datasets"] = d2
+    el = out.get("embedding_latent")
+    if isinstance(el, dict):
+        rows_ = {"16": {"ef_search": _pick(out, "config", "ef_search"), "qps": out.get("value"), "recall_at_10": out.get("recall_at_10"), "frac": _pick(out, "roofline", "frac")}}
+        for L_, r_ in el.items():
+            hit = r_.get("iso_recall") if isinstance(r_, dict) else None
+            first = (r_.get("sweep") or [{}])[0] if isinstance(r_, dict) else {}
+            rows_[L_] = ({"error": str(r_.get("error"))[:80]} if isinstance(r_, dict) and "error" in r_ else
+                         {"recall_at_ef128": first.get("recall_at_10"), "iso": None if not hit else
+                          {"ef_search": hit.get("ef_search"), "qps": hit.get("qps"), "recall_at_10": hit.get("recall_at_10"), "frac": hit.get("frac_of_hbm_peak")}})
+        c.setdefault("datasets", {})["embedding_latent"] = rows_
     c3 = out.get("config3_prefilter")
     if isinstance(c3, dict):
         if "error" in c3:
             c["config3"] = {"error": str(c3["error"])[:160]}
         else:
             c["config3"] = {"corpus": _pick(c3, "corpus", "kind"), "parity_ok": c3.get("parity_sample_ok"),
-                            "groups": [{"candidates": g_["candidates"], "strategy": _pick(g_, "planned", "strategy"),
-                                        "recall_vs_exact": _pick(g_, "planned", "recall_at_10_vs_exact"),
-                                        "gate_0.92": _pick(g_, "planned", "reference_gates", "recall_at_10_ge_0.92"),
-                                        "planned_us_per_query": _pick(g_, "planned", "us_per_query"),
-                                        "exact_us_per_query": _pick(g_, "exact", "us_per_query"),
+                            "groups": [{"candidates": g_["candidates"], "device_plan": _pick(g_, "device_plan", "strategy"),
+                                        "device_recall": _pick(g_, "device_plan", "recall_at_10_vs_exact"),
+                                        "device_us_per_query": _pick(g_, "device_plan", "us_per_query"),
+                                        "device_1q_p50_ms": _pick(g_, "device_plan", "single_query_end_to_end_ms", "p50"),
+                                        "ref_plan": _pick(g_, "planned", "strategy"), "ref_recall": _pick(g_, "planned", "recall_at_10_vs_exact"),
+                                        "ref_us_per_query": _pick(g_, "planned", "us_per_query"),
                                         "exact_hbm_frac": None if _pick(g_, "exact", "hbm_gbs_scan") is None else round(_pick(g_, "exact", "hbm_gbs_scan") / HBM_PEAK_GBS, 3)}
-                                       for g_ in c3.get("groups", [])]}
+                                       for g_ in c3.get("groups", [])],
+                            "own_sets": [{"req": r_["requests"], "ids": r_["ids_per_request"], "qps": r_["qps_kernel"], "frac": r_["frac_of_hbm_peak"]}
+                                         for r_ in (_pick(c3, "per_request_candidate_sets", "rows") or [])]}
     c4 = out.get("config4_bf16")
     if isinstance(c4, dict):
         c["config4"] = {"error": str(c4["error"])[:160]} if "error" in c4 else {
@@ -1385,7 +1446,7 @@ def main():
         if world == 1 and elapsed * 1e3 > 1.3 * span:
             # the wall clock of the K steps is far above the device span of the same K kernels: the host was frozen inside the timed region
             # (CPU quota, see timed_steps).  The SAME K steps are timed once more; both runs are reported, the line carries the second.
-            stall = {"first_run_ms_per_step": round(elapsed * 1e3 / args.steps, 4), "first_run_kernel_ms": round(span / args.steps, 4),
+            stall = {"first_run_qps": round(b * args.steps / elapsed, 1), "first_run_ms_per_step": round(elapsed * 1e3 / args.steps, 4), "first_run_kernel_ms": round(span / args.steps, 4),
                      "first_run_host": getattr(ls, "host_timing", None)}
             log(f"[{label}] host stall inside the timed steps ({stall}); timing the same {args.steps} steps again")
             elapsed, span, kms = timed_steps(ls, qs, ef, args.steps, args.warmup, barrier)
@@ -1492,6 +1553,8 @@ def main():
                 "traffic_source": "rocprofv3 --pmc pass of this command on another box (profiles/traffic_latest.json); not measured in this run",
                 "algorithmic_bytes_per_launch": int(res["alg"]),
                 "algorithmic_bytes_of": "the per-query counters of lane 0's last batch (every timed step answers a different batch of the same distribution)",
+                "frac_definition": f"overlapped span: {lanes} lanes x {occ} queries per SIMD in flight (algorithmic bytes of one launch / (HIP-event span of the "
+                                   f"{args.steps} timed kernels / {args.steps})); one launch ALONE on the device: lone_batch.frac",
                 "kernel_ms": round(res["per_step"], 4),
                 "kernel_ms_definition": f"HIP-event span of the {args.steps} timed search kernels on their {lanes} lane streams / {args.steps} "
                                         f"(consecutive batches overlap on the device); kernel_ms_each = mean duration of one kernel "
@@ -1825,6 +1888,17 @@ def main():
                           "8(d) as literally written, a stated worst case: distance concentration at 768-d leaves no neighbour structure, so "
                           "recall@10 misses 0.95 at ef=128 for every HNSW, the reference's included -- QPS there is not a headline")
             out["datasets"] = ds
+        # ---- one sensitivity table (no tuning): the headline family at latent dimension 16 (the headline itself) / 32 /
+        #      64 -- the smallest ef of the sweep that reaches recall@10 >= 0.95 on each, and QPS / roofline fraction THERE ----
+        if "latent" not in skip:
+            lat = {}
+            for L in (32, 64):
+                iso = guarded(f"embedding latent {L}", lambda: leg_iso_recall(hv, synth, orc, args, dev, f"embedding{L}", args.rows, dim, b, k,
+                                                                             efs=(ef, 192, 256, 384, 512, 800)))
+                if isinstance(iso, dict):
+                    iso.pop("leg_at_first_ef", None)
+                lat[str(L)] = iso
+            out["embedding_latent"] = lat
 
     emit(out, args.full_record, rank)
     if world > 1:

@@ -102,6 +102,7 @@ static void free_index(hvx_index *ix) {
     ix->image.clear();
     if (ix->ev0) (void)hipEventDestroy(ix->ev0);
     if (ix->ev1) (void)hipEventDestroy(ix->ev1);
+    if (ix->del_ev) (void)hipEventDestroy(ix->del_ev);
     for (hipEvent_t e : ix->ring) (void)hipEventDestroy(e);
     if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
     if (ix->h_pin) (void)hipHostFree(ix->h_pin);

@@ -706,8 +706,23 @@ extern "C" int hvx_index_delete_batch(hvx_index *ix, const uint64_t *node_ids, u
         const uint32_t scan_blocks = (uint32_t)std::min<unsigned long long>(4096ull, std::max<unsigned long long>(1ull, (slots + 255ull) / 256ull));
         hipLaunchKernelGGL(delete_scan_kernel, dim3(scan_blocks), dim3(256), 0, s, a);
         hipLaunchKernelGGL(delete_prep_kernel, dim3(a.layers), dim3(256), 0, s, a);
+        // how many relink sources the layers have: read back behind the prep kernel WHILE the rank kernel runs (round 6: the r05w trace had
+        // 64 000 own + 64 000 reciprocal step dispatches for 2 000 deletes of ~25 relinked rows each -- two launches of ~4 us per absent step)
+        uint32_t n_steps = kDelSteps;
+        if (steps) {
+            if ((rc = ix->pin_flags(4 + kDelMinLayers + a.layers))) return rc;
+            HIP_TRY(hipMemcpyAsync(ix->h_flags + 4, a.rel_cnt, (size_t)a.layers * 4, hipMemcpyDeviceToHost, s));
+            if (!ix->del_ev) HIP_TRY(hipEventCreateWithFlags(&ix->del_ev, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(ix->del_ev, s));
+        }
         hipLaunchKernelGGL(kern.rank, dim3(64, a.layers), dim3(256), rank_lds, s, a);
-        for (uint32_t ri = 0; steps && ri < kDelSteps; ++ri) { // (a step past the layer's last source returns at once)
+        if (steps) {
+            HIP_TRY(hipEventSynchronize(ix->del_ev));
+            uint32_t most = 0;
+            for (uint32_t l = 0; l < a.layers; ++l) most = std::max(most, ix->h_flags[4 + l]);
+            n_steps = std::min(kDelSteps, most);
+        }
+        for (uint32_t ri = 0; steps && ri < n_steps; ++ri) { // (a step past a layer's last source returns at once)
             hipLaunchKernelGGL(kern.own, dim3(a.layers), dim3(1024), step_lds, s, a, ri);
             hipLaunchKernelGGL(kern.recip, dim3(kDelTop, a.layers), dim3(1024), step_lds, s, a, ri);
         }

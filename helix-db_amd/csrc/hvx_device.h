@@ -286,7 +286,7 @@ __device__ __forceinline__ float cosine_finish(float pq, float pn, float qn, con
 //   j    : lane & 7
 // METRIC kL2 / kCosine use the AVX tree for the first dim_main elements and the reference's scalar
 // tail for the rest (simple_avx.rs:172-177); kL1 is sequential everywhere (simple.rs:186-202).
-template <uint32_t METRIC, bool FUSED>
+template <uint32_t METRIC, bool FUSED, int UNR = 8>
 __device__ __forceinline__ float group_distance(const DevIndex &ix, const float *qv, float qhdr,
                                                 uint32_t node, int j) {
     const float *row = ix.vec + (size_t)node * ix.ld;
@@ -306,13 +306,14 @@ __device__ __forceinline__ float group_distance(const DevIndex &ix, const float 
         const float4 *rp = reinterpret_cast<const float4 *>(row) + slot;
         const float4 *qp = reinterpret_cast<const float4 *>(qv) + slot;
         uint32_t k = 0;
-        // 8 independent 16-byte loads in flight per lane (8 KiB per wavefront) before the first use
-        for (; k + 8 <= nk; k += 8) {
-            float4 x[8];
+        // UNR (8) independent 16-byte loads in flight per lane (8 KiB per wavefront) before the first use; callers with 16 wavefronts per
+        // workgroup (128 registers each) ask for 4
+        for (; k + UNR <= nk; k += UNR) {
+            float4 x[UNR];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = rp[(size_t)(k + u) * 8];
+            for (int u = 0; u < UNR; ++u) x[u] = rp[(size_t)(k + u) * 8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < UNR; ++u) {
                 float4 qq = qp[(k + u) * 8];
                 if (METRIC == kL2) {
                     float d0 = qq.x - x[u].x, d1 = qq.y - x[u].y, d2 = qq.z - x[u].z, d3 = qq.w - x[u].w;
@@ -382,7 +383,7 @@ __device__ __forceinline__ float group_distance(const DevIndex &ix, const float 
 // bf16 rows): the row's values are exact f32 numbers, the arithmetic and its order are those of group_distance, so the score equals
 // the reference's on the rounded vector bit for bit.  Used where rows are scored one per 8-lane group outside the unrolled HNSW
 // kernels (the restricted walk, round 4).
-template <uint32_t METRIC>
+template <uint32_t METRIC, int UNR = 8>
 __device__ __forceinline__ float group_distance_bf16(const DevIndex &ix, const float *qv, float qhdr, uint32_t node, int j) {
     const int slot = chunk_slot(j);
     const uint16_t *rb = ix.vecb + (size_t)node * ix.dim;
@@ -410,12 +411,12 @@ __device__ __forceinline__ float group_distance_bf16(const DevIndex &ix, const f
         }
     };
     uint32_t m = 0;
-    for (; m + 8 <= np; m += 8) { // 8 independent 16-byte loads in flight per lane before the first use
-        float4 x[8];
+    for (; m + UNR <= np; m += UNR) { // UNR (8) independent 16-byte loads in flight per lane before the first use
+        float4 x[UNR];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = rp[(size_t)(m + u) * 8];
+        for (int u = 0; u < UNR; ++u) x[u] = rp[(size_t)(m + u) * 8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) step(x[u], m + (uint32_t)u);
+        for (int u = 0; u < UNR; ++u) step(x[u], m + (uint32_t)u);
     }
     for (; m < np; ++m) step(rp[(size_t)m * 8], m);
     float r = avx_tree_reduce(acc);

@@ -118,6 +118,7 @@ struct hvx_index {
     int ensure_live();               // f_live / live_rows_n for this handle's generation
     uint32_t live_rows() const { return dev.n - n_dead; }
     void *del_scratch = nullptr;     // owner: scratch of the delete kernels (hvx_delete.hip)
+    hipEvent_t del_ev = nullptr;     // ... and the event behind a delete's prep kernel (the relink-source counts are read back there)
     uint32_t del_layers = 0;
     // per-batch device scratch
     uint32_t *d_bitmap = nullptr, *d_qstatus = nullptr, *d_tie = nullptr;

@@ -154,8 +154,11 @@ template <uint32_t METRIC, bool FUSED, uint32_t TT, uint32_t WW> struct DevCtx {
         for (uint32_t f = grp; f < n; f += T / 8) {
             const uint32_t node = rows[f];
             float d;
-            if (METRIC != kL1 && FUSED && ix.dtype == HVX_BF16) d = group_distance_bf16<METRIC == kL1 ? kL2 : METRIC>(ix, qv, qhdr, node, j);
-            else d = group_distance<METRIC, FUSED>(ix, qv, qhdr, node, j);
+            // (the wide geometry runs 16 wavefronts per workgroup = 128 registers each: four loads in flight per lane instead of eight keep
+            // the scoring loop out of scratch -- round 6; 13 spilled registers / 56 B of scratch before, profiles/r05z_kernel_meta.json)
+            constexpr int UNR = TT >= 1024 ? 4 : 8;
+            if (METRIC != kL1 && FUSED && ix.dtype == HVX_BF16) d = group_distance_bf16<METRIC == kL1 ? kL2 : METRIC, UNR>(ix, qv, qhdr, node, j);
+            else d = group_distance<METRIC, FUSED, UNR>(ix, qv, qhdr, node, j);
             if (!score_valid(d)) bad = 1;
             if (j == 0) keys[f] = ((uint64_t)__float_as_uint(d) << 32) | ((uint64_t)node << 1);
         }

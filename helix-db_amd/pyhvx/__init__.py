@@ -23,7 +23,7 @@ COSINE, EUCLIDEAN, MANHATTAN = 0, 1, 2
 F32, BF16, FP8_E4M3 = 0, 1, 2
 KERNEL_SCALAR, KERNEL_SSE, KERNEL_AVX, KERNEL_AVX_FMA, KERNEL_NEON = 0, 1, 2, 3, 4  # hvx_float_kernel == FloatSimd (spaces/simple.rs:45-62)
 OK, ERR_DIMENSION, ERR_NONFINITE, ERR_ZERO_NORM, ERR_MAGNITUDE, ERR_K_RANGE, ERR_CANDIDATE_LIMIT, \
-    ERR_DEVICE, ERR_INVARIANT, ERR_UNSUPPORTED, PENDING, ERR_BUSY = range(12)
+    ERR_DEVICE, ERR_INVARIANT, ERR_UNSUPPORTED, PENDING, ERR_BUSY, ERR_TIMEOUT = range(13)
 DIR_OUT, DIR_IN, DIR_BOTH = 0, 1, 2
 
 _STATUS_NAMES = {
@@ -982,6 +982,24 @@ class ShardGroup:
     @staticmethod
     def _st(d_status):
         return None if d_status is None else _vp(d_status.data_ptr())
+
+    def wait(self, timeout_ms: int) -> bool:
+        """hvx_shard_group_wait: True once the group's last step has drained, False after timeout_ms (a peer that never joined the collective)"""
+        L = lib()
+        L.hvx_shard_group_wait.restype = C.c_int
+        L.hvx_shard_group_wait.argtypes = [_vp, C.c_uint32]
+        rc = L.hvx_shard_group_wait(self._g, int(timeout_ms))
+        if rc == ERR_TIMEOUT:
+            return False
+        _check(rc)
+        return True
+
+    def abort(self):
+        """hvx_shard_group_abort: ncclCommAbort -- the pending collective is cancelled; later steps fail until the group is re-formed"""
+        L = lib()
+        L.hvx_shard_group_abort.restype = C.c_int
+        L.hvx_shard_group_abort.argtypes = [_vp]
+        _check(L.hvx_shard_group_abort(self._g))
 
     def search_batch_device(self, d_queries, k, ef, d_ids, d_scores, d_counts, d_status=None):
         L = lib()

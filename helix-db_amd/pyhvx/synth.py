@@ -235,6 +235,8 @@ def corpus(name: str, n: int, dim: int, n_queries: int, seed: int, device, **kw)
         return clustered(n, dim, n_queries, seed, device, **kw)
     if name == "embedding":
         return embedding_like(n, dim, n_queries, seed, device, **kw)
+    if name.startswith("embedding") and name[9:].isdigit():  # 'embedding32' / 'embedding64': the same family at another latent dimension
+        return embedding_like(n, dim, n_queries, seed, device, latent=int(name[9:]), **kw)
     if name == "topic_ordered":
         return topic_ordered(n, dim, n_queries, seed, device, **kw)
     raise ValueError(f"unknown corpus {name!r}")

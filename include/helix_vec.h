@@ -52,7 +52,8 @@ enum hvx_status {
     HVX_ERR_INVARIANT = 8,       /* InvariantViolation (bad graph row, invalid score, ...) */
     HVX_ERR_UNSUPPORTED = 9,     /* configuration outside what this build implements */
     HVX_PENDING = 10,            /* NOT an error: hvx_batcher_poll / _wait -- the ticket's batch has not completed yet */
-    HVX_ERR_BUSY = 11            /* hvx_batcher_submit would have to block (the open batch is full): submit again later */
+    HVX_ERR_BUSY = 11,           /* hvx_batcher_submit would have to block (the open batch is full): submit again later */
+    HVX_ERR_TIMEOUT = 12         /* hvx_shard_group_wait: the step (local search + exchange + merge) has not drained in the time given */
 };
 
 enum hvx_direction { HVX_DIR_OUT = 0, HVX_DIR_IN = 1, HVX_DIR_BOTH = 2 };
@@ -418,6 +419,12 @@ int hvx_shard_group_search_restricted_batch(hvx_shard_group *, const float *quer
                                             const uint64_t *allowed_ids, uint64_t n_allowed, uint64_t *out_ids /*[b][params->k]*/,
                                             float *out_scores, uint32_t *out_counts, uint32_t *out_status /*nullable*/);
 void hvx_shard_group_free(hvx_shard_group *);
+/* A sharded step is enqueued without a host wait; a peer rank that never joins the collective would park this rank's stream -- and a host
+ * blocked in hipStreamSynchronize -- for ever.  hvx_shard_group_wait bounds it: HVX_OK once everything the group's last step enqueued has
+ * drained, HVX_ERR_TIMEOUT after timeout_ms (the host then calls hvx_shard_group_abort = ncclCommAbort: the pending collective is
+ * cancelled, later steps of the groups that share the communicator fail with HVX_ERR_DEVICE, and the host re-forms the group). */
+int hvx_shard_group_wait(hvx_shard_group *, uint32_t timeout_ms);
+int hvx_shard_group_abort(hvx_shard_group *);
 /* NCCL_VERSION_CODE of the RCCL library bound at run time (e.g. 22203), 0 when none could be loaded or it was refused: the
  * ncclUniqueId / ncclCommInitRank declarations this library binds are restated for the NCCL 2.x ABI and checked through
  * ncclGetVersion before the first collective (crates/db has no counterpart: sharding across GPUs is this library's own seam). */

@@ -1,4 +1,4 @@
-"""Two REAL devices, RCCL inside the library (ncclAllGather with world > 1 had never executed anywhere -- RCCL refuses
+"""Two (or, on the 8-GPU node, eight) REAL devices, RCCL inside the library (ncclAllGather with world > 1 had never executed anywhere -- RCCL refuses
 two ranks on one device, so the 1-GPU boxes of this pool can only run the world-1 collective and the gloo twin).  On a box with >= 2
 GPUs (`pytest -m gpu2`) two processes, one per device, each build their id-range
 shard and run the one-call steps hvx_shard_group_search_batch_device / _flat_search_batch_device / _search_batch_params_device on TWO
@@ -98,7 +98,8 @@ def _worker(rank, world, port, out_dir):
                 assert [p_[0] for p_ in pool] == ms[qi, :mc[qi]].view(np.uint32).tolist()
         allres = [None] * world
         dist.all_gather_object(allres, fi.tolist())
-        assert allres[0] == allres[1]                               # every rank holds the same merged answer
+        assert all(r_ == allres[0] for r_ in allres)                # every rank holds the same merged answer
+        assert g0.wait(20000)                                       # hvx_shard_group_wait: the bounded form of the host's stream wait
         for g in groups:
             g.close()
         for ln in lanes:
@@ -111,10 +112,14 @@ def _worker(rank, world, port, out_dir):
     open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write(msg)
 
 
-def test_two_ranks_on_two_devices_exchange_through_rccl_inside_the_library(tmp_path):
+@pytest.mark.parametrize("want", [2, 8])
+def test_ranks_on_real_devices_exchange_through_rccl_inside_the_library(tmp_path, want):
+    """world = 2, and world = min(8, devices) on the 8-GPU node (round 6: the first real ncclAllGather at world > 2 should not be the bench)"""
     if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
         pytest.skip("needs two devices (RCCL refuses two ranks on one device): run with -m gpu2 on a multi-GPU box")
-    world = 2
+    world = min(want, torch.cuda.device_count())
+    if want > 2 and world <= 2:
+        pytest.skip("the wider group needs more than two devices")
     mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="spawn")
     for r in range(world):
         assert open(tmp_path / f"rank{r}.txt").read() == "ok"

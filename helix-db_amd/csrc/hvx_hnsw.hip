@@ -353,7 +353,7 @@ bool hnsw_wave_supported(const HnswArgs &a) {
     if (ix.dim % 32u != 0u || ix.dim_main != ix.dim || ix.ld != ix.dim) return false;
     if (ix.dtype != HVX_F32 && ix.dtype != HVX_BF16) return false;
     const uint32_t nk = ix.dim >> 5;
-    if (nk != 4 && nk != 8 && nk != 16 && nk != 24 && nk != 32 && nk != 48) return false;
+    if (nk != 4 && nk != 8 && nk != 12 && nk != 16 && nk != 24 && nk != 32 && nk != 48) return false; // (12 = dim 384: round 6)
     if (ix.s0 > 64 || ix.su > 64) return false;
     if (a.ef + 32u > wave_beam_limit(a)) return false;
     return true;

@@ -375,6 +375,7 @@ template <uint32_t METRIC, int R, bool BF> static hipError_t launch_pair_nk(cons
     switch (a.ix.dim >> 5) {
     case 4: return launch_pair_g<METRIC, R, 4, BF>(a, b, g, s);
     case 8: return launch_pair_g<METRIC, R, 8, BF>(a, b, g, s);
+    case 12: return launch_pair_g<METRIC, R, 12, BF>(a, b, g, s);
     case 16: return launch_pair_g<METRIC, R, 16, BF>(a, b, g, s);
     case 24: return launch_pair_g<METRIC, R, 24, BF>(a, b, g, s);
     case 32: return launch_pair_g<METRIC, R, 32, BF>(a, b, g, s);

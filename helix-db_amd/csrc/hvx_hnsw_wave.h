@@ -20,7 +20,7 @@
 //     reference CPU path; the beam (hvx_beam.h) is exact.
 //
 // Served shapes: f32 or bf16 rows, metric L2 / cosine, AVX+FMA summation tree, dim = 32*NK with NK in
-// {4,8,16,24,32,48} (dim 128 ... 1536), neighbour rows <= 64 ids, ef + 32 <= 384.  Everything else runs on the general
+// {4,8,12,16,24,32,48} (dim 128 ... 1536; 12 = dim 384 since round 6), neighbour rows <= 64 ids, ef + 32 <= 384.  Everything else runs on the general
 // kernel in hvx_hnsw.hip.
 #pragma once
 #include <type_traits>
@@ -1102,6 +1102,7 @@ static hipError_t launch_wave_nk(const HnswArgs &a, uint32_t b, const WaveGeom &
     switch (a.ix.dim >> 5) {
     case 4: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 4, BF, false, AD, ST, OCC, BUILD>, a, b, g, s);
     case 8: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 8, BF, false, AD, ST, OCC, BUILD>, a, b, g, s);
+    case 12: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 12, BF, false, AD, ST, OCC, BUILD>, a, b, g, s); // dim 384 (round 6)
     case 16: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 16, BF, false, AD, ST, OCC, BUILD>, a, b, g, s);
     case 24: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 24, BF, false, AD, ST, OCC, BUILD>, a, b, g, s);
     case 32: return launch_wave_kernel(hnsw_wave_kernel<METRIC, R, 32, BF, false, AD, ST, OCC, BUILD>, a, b, g, s);

@@ -279,7 +279,13 @@ int flat_scan_host(hvx_index *ix, const float *queries, uint32_t b, uint32_t k, 
 bool restricted_direct_supported(const hvx_index *ix, uint32_t k);
 int restricted_direct_enqueue(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, uint32_t k_stride, const uint32_t *d_rows,
                               uint32_t n_rows, const uint64_t *d_ext_ids, const uint64_t *d_offsets, uint32_t max_set, uint64_t *d_ids,
-                              float *d_scores, uint32_t *d_counts, uint32_t *d_status, const uint32_t *d_lens = nullptr, uint32_t ext_stride = 0);
+                              float *d_scores, uint32_t *d_counts, uint32_t *d_status, const uint32_t *d_lens = nullptr, uint32_t ext_stride = 0,
+                              const uint32_t *d_n_rows = nullptr);
+// the one-launch scan over a row list whose LENGTH lives on the device (counters[0] = rows, counters[1] = candidate population; rows_cap = the
+// host's bound): host-resident queries, results + the two counters delivered with ONE stream wait (hvx_restricted_walk.hip)
+int restricted_direct_shared_devcount(hvx_index *ix, const float *queries, uint32_t b, uint32_t k, const uint32_t *d_rows, uint32_t rows_cap,
+                                      const uint32_t *d_counters, uint64_t *out_ids, float *out_scores, uint32_t *out_counts, uint32_t *out_status,
+                                      uint64_t *out_candidates, hvx_restricted_stats *rstats, hvx_stats *stats);
 hipError_t launch_stage_ids(const uint64_t *src, const uint32_t *lens, uint32_t stride, uint64_t *dst, uint32_t b, hipStream_t s);
 // exact tail of the small-batch matrix-core scan (hvx_flat_tail.hip): k <= 64, AVX+FMA tree, L2 / cosine, f32 or bf16 rows
 bool flat_tail_supported(const hvx_index *ix, uint32_t b, uint32_t k, uint32_t n_rows);

@@ -51,6 +51,7 @@ struct hvx_csr {
     uint32_t *h_seeds = nullptr;                    // pinned: the seeds of the traversal in flight (a pageable upload is a synchronous staged copy)
     size_t cap_h_seeds = 0;
     hipEvent_t done = nullptr;                      // recorded behind a traversal whose consumer runs on another stream (fused prefilter search)
+    uint64_t max_out_deg = 0, max_in_deg = 0;       // largest row of either adjacency: bounds what one hop from s seeds can reach (round 6)
 };
 
 namespace {
@@ -187,6 +188,9 @@ extern "C" int hvx_csr_import(uint64_t n_nodes, uint64_t n_edges, const uint64_t
             in_off[out_targets[a] + 1]++;
         }
     }
+    uint64_t max_out = 0, max_in = 0;
+    for (uint64_t u = 0; u < n_nodes; ++u) max_out = std::max<uint64_t>(max_out, out_offsets[u + 1] - out_offsets[u]);
+    for (uint64_t v = 0; v < n_nodes; ++v) max_in = std::max<uint64_t>(max_in, in_off[v + 1]);
     for (uint64_t v = 0; v < n_nodes; ++v) in_off[v + 1] += in_off[v];
     {
         std::vector<uint64_t> cur(in_off.begin(), in_off.end() - 1);
@@ -217,6 +221,8 @@ extern "C" int hvx_csr_import(uint64_t n_nodes, uint64_t n_edges, const uint64_t
     if ((rc = up(tgt32.data(), n_edges * 4, (void **)&g->out_tgt))) return bail(rc);
     if ((rc = up(in_tgt.data(), n_edges * 4, (void **)&g->in_tgt))) return bail(rc);
     g->rows_sorted = rows_sorted;
+    g->max_out_deg = max_out;
+    g->max_in_deg = max_in;
     if (!in_arc.empty() && (rc = up(in_arc.data(), n_edges * 4, (void **)&g->in_arc))) return bail(rc);
     if (edge_labels) {
         if ((rc = up(edge_labels, n_edges * 4, (void **)&g->out_lab))) return bail(rc);
@@ -1017,6 +1023,70 @@ __global__ __launch_bounds__(64) void bitmap_select_kernel(const uint32_t *bitma
     out_rows[t] = row;
 }
 
+// Round 6: one `expand` hop (expand.rs:16-80) straight into the scan's row list.  One wavefront per seed, lanes over its arcs: a target
+// whose bit was clear joins the candidate population (a bitmap test-and-set makes the union a set) and, when it holds a live vector, the
+// row list -- in whatever order the wavefronts get there: the one-launch scan (hvx_restricted_exact.hip) orders by (score, row) itself.
+// counters[0] = rows of the list, counters[1] = candidate population.  Replaces the level kernel + count + scan + compact sequence and
+// the host read-back between them for plans that are exact whatever the population turns out to be.
+__global__ __launch_bounds__(256) void expand_collect_kernel(CsrView g, const uint32_t *seeds, uint32_t n_seeds, uint32_t direction, const uint32_t *allowed,
+                                                             uint32_t n_allowed, uint32_t *visited, const uint64_t *ids, uint32_t n, uint32_t contiguous,
+                                                             const uint32_t *dead, uint32_t *rows_out, uint32_t rows_cap, uint32_t *counters) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    // one arc -> (joined the population, row of its target); the wavefront's arcs of one step share ONE pair of counter updates (a where_()
+    // group of 10 000 sources with one edge each was 20 000 atomics on two words with a wavefront per seed: 0.25 ms of a 0.34 ms call)
+    auto take = [&](bool active, const uint32_t *tgt, const uint32_t *lab, uint64_t at) __attribute__((always_inline)) {
+        bool fresh = false;
+        uint32_t row = kSentinel;
+        if (active && (!lab || label_ok(lab[at], allowed, n_allowed))) {
+            const uint32_t v = tgt[at];
+            const uint32_t bit = 1u << (v & 31u);
+            fresh = (atomicOr(&visited[v >> 5], bit) & bit) == 0u;
+            if (fresh) row = find_row(ids, n, (uint64_t)v, contiguous != 0u, dead);
+        }
+        const unsigned long long fm = __ballot(fresh), rm = __ballot(row != kSentinel);
+        if (fm == 0ull) return;
+        uint32_t base = 0;
+        if (lane == 0) {
+            atomicAdd(&counters[1], (uint32_t)__builtin_popcountll(fm));
+            if (rm) base = atomicAdd(&counters[0], (uint32_t)__builtin_popcountll(rm));
+        }
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (row != kSentinel) {
+            const uint32_t pos = base + (uint32_t)__builtin_popcountll(rm & ((1ull << lane) - 1ull));
+            if (pos < rows_cap) rows_out[pos] = row;
+        }
+    };
+    constexpr uint32_t kLight = 16; // rows up to this long are walked one arc per step by the seed's own lane (64 seeds per wavefront)
+    for (uint32_t s0 = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 64u; s0 < n_seeds; s0 += n_waves * 64u) {
+        const bool have = s0 + (uint32_t)lane < n_seeds;
+        const uint32_t node = have ? seeds[s0 + (uint32_t)lane] : 0u;
+        for (int pass = 0; pass < 2; ++pass) {
+            const bool use_out = pass == 0;
+            if (use_out && direction == 1u) continue;  // In only
+            if (!use_out && direction == 0u) continue; // Out only
+            const uint64_t *off = use_out ? g.out_off : g.in_off;
+            const uint32_t *tgt = use_out ? g.out_tgt : g.in_tgt;
+            const uint32_t *lab = use_out ? g.out_lab : g.in_lab;
+            const uint64_t a0 = have ? off[node] : 0ull, a1 = have ? off[node + 1] : 0ull;
+            const uint32_t deg = (uint32_t)((a1 - a0) < 0xFFFFFFFFull ? (a1 - a0) : 0xFFFFFFFFull);
+            const bool light = deg <= kLight;
+            uint32_t steps = light ? deg : 0u;
+#pragma unroll
+            for (int sh = 32; sh > 0; sh >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)steps, sh, 64); steps = o > steps ? o : steps; }
+            for (uint32_t i = 0; i < steps; ++i) take(light && i < deg, tgt, lab, a0 + i);
+            unsigned long long heavy = __ballot(have && !light); // long rows (hubs): the whole wavefront strides over the arcs of one seed at a time
+            while (heavy) {
+                const int l = __builtin_ctzll(heavy);
+                heavy &= heavy - 1ull;
+                const uint64_t h0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(a0 >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)a0, l);
+                const uint64_t h1 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(a1 >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)a1, l);
+                for (uint64_t a = h0; a < h1; a += 64) take(a + (uint64_t)lane < h1, tgt, lab, a + (uint64_t)lane);
+            }
+        }
+    }
+}
+
 } // namespace
 
 static int prefilter_search_impl(const hvx_index *cix, const hvx_csr *cg, const float *queries, uint32_t b, const hvx_restricted_params &rp,
@@ -1024,6 +1094,59 @@ static int prefilter_search_impl(const hvx_index *cix, const hvx_csr *cg, const 
                                  const uint32_t *allowed_label_ids, uint32_t n_labels, uint32_t hub_degree, uint32_t include_seeds,
                                  uint64_t *out_ids, float *out_scores, uint32_t *out_counts, uint32_t *out_status, uint64_t *out_candidates,
                                  hvx_restricted_stats *rstats, hvx_stats *stats);
+
+// One hop + exact scan with ONE host wait (round 6; the reference issues one query per call, index_lifecycle_scale.rs:1893-1912: the
+// latency of this call is what a request sees).  Taken when the plan is exact WHATEVER the hop reaches -- strategy EXACT, or a planned
+// strategy whose bound on the population (seeds x the largest adjacency row) is inside the plan's exact region -- and the one-launch scan
+// serves the shape.  Everything is enqueued on the index's stream: clear the bitmap, expand_collect_kernel (seeds read out of the pinned
+// staging buffer), queries copied + validated, the scan with its row count read ON THE DEVICE, results into mapped host rows.
+static int prefilter_expand_lean(hvx_index *ix, hvx_csr *g, const float *queries, uint32_t b, const hvx_restricted_params &rp, const uint64_t *seeds,
+                                 uint32_t n_seeds, uint32_t direction, const uint32_t *allowed_label_ids, uint32_t n_labels, uint64_t bound,
+                                 uint64_t *out_ids, float *out_scores, uint32_t *out_counts, uint32_t *out_status, uint64_t *out_candidates,
+                                 hvx_restricted_stats *rstats, hvx_stats *stats) {
+    int rc;
+    const uint32_t k = rp.k;
+    hipStream_t s = ix->stream;
+    if (n_seeds > g->cap_h_seeds) {
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipStreamSynchronize(g->stream));
+        if (g->h_seeds) (void)hipHostFree(g->h_seeds);
+        g->h_seeds = nullptr;
+        g->cap_h_seeds = 0;
+        const size_t want = std::max<size_t>((size_t)n_seeds + n_seeds / 2, 4096);
+        if (hipHostMalloc((void **)&g->h_seeds, want * 4, hipHostMallocDefault) != hipSuccess) return fail(HVX_ERR_DEVICE, "hipHostMalloc(%zu) seeds", want * 4);
+        g->cap_h_seeds = want;
+    }
+    for (uint32_t i = 0; i < n_seeds; ++i) {
+        if (seeds[i] >= g->n) return fail(HVX_ERR_INVARIANT, "unknown node %llu", (unsigned long long)seeds[i]);
+        g->h_seeds[i] = (uint32_t)seeds[i];
+    }
+    if ((rc = upload_labels(g, allowed_label_ids, n_labels))) return rc; // (on g->stream: ordered below)
+    if (n_labels) {
+        if (!g->done) HIP_TRY(hipEventCreateWithFlags(&g->done, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(g->done, g->stream));
+        HIP_TRY(hipStreamWaitEvent(s, g->done, 0));
+    }
+    const uint32_t rows_cap = (uint32_t)std::min<uint64_t>(bound, ix->dev.n);
+    if (rows_cap > ix->cap_subset) {
+        if ((rc = ix->regrow((void **)&ix->f_subset, (size_t)std::max<uint32_t>(rows_cap, 1u) * 4))) return rc;
+        ix->cap_subset = rows_cap;
+    }
+    if (ix->cap_pf_blocks < 4) {
+        if ((rc = ix->regrow((void **)&ix->pf_blocks, 64))) return rc;
+        ix->cap_pf_blocks = 16;
+    }
+    const size_t words32 = ((g->n + 63) / 64) * 2;
+    HIP_TRY(hipMemsetAsync(g->visited, 0, std::max<size_t>(words32, 2) * 4, s));
+    HIP_TRY(hipMemsetAsync(ix->pf_blocks, 0, 8, s));
+    CsrView v{g->out_off, g->in_off, g->out_tgt, g->in_tgt, g->out_lab, g->in_lab, g->n};
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(1024, ((uint64_t)n_seeds + 255) / 256); // (a wavefront takes 64 seeds at a time)
+    hipLaunchKernelGGL(expand_collect_kernel, dim3(std::max(blocks, 1u)), dim3(256), 0, s, v, g->h_seeds, n_seeds, direction, g->labels, n_labels, g->visited,
+                       ix->dev.ids, ix->dev.n, ix->contiguous ? 1u : 0u, ix->dev.dead, ix->f_subset, rows_cap, ix->pf_blocks);
+    HIP_TRY(hipGetLastError());
+    return restricted_direct_shared_devcount(ix, queries, b, k, ix->f_subset, rows_cap, ix->pf_blocks, out_ids, out_scores, out_counts, out_status,
+                                             out_candidates, rstats, stats);
+}
 
 extern "C" int hvx_prefilter_search_batch(const hvx_index *cix, const hvx_csr *cg, const float *queries, uint32_t b, uint32_t k,
                                           uint32_t ef, uint32_t mode, const uint64_t *seeds, uint32_t n_seeds, uint32_t max_depth,
@@ -1075,6 +1198,20 @@ static int prefilter_search_impl(const hvx_index *cix, const hvx_csr *cg, const 
     std::lock_guard<std::mutex> glock(g->mu);
     std::lock_guard<std::mutex> lock(ix->mu);
     ix->sync_rewrites();
+    if (mode == HVX_PREFILTER_EXPAND && direction <= HVX_DIR_BOTH && ix->opt[HVX_OPT_RESTRICTED_DIRECT] != 1u && !rp.explicit_budgets && k <= 64u &&
+        restricted_direct_supported(ix, k) && ix->dev.n != 0u) {
+        // what one hop can reach at most: seeds x the largest adjacency row (both rows for direction Both), never more than the graph
+        const uint64_t per_seed = (direction != HVX_DIR_IN ? g->max_out_deg : 0) + (direction != HVX_DIR_OUT ? g->max_in_deg : 0);
+        const uint64_t bound = std::min<uint64_t>((uint64_t)n_seeds * per_seed, g->n);
+        RestrictedPlan plan;
+        const bool exact_any = bound == 0 || (bound <= 1000000ull && restricted_make_plan(rp, bound, ix->dev.dim, &plan, ix) == HVX_OK && plan.strategy == HVX_RESTRICTED_EXACT &&
+                                             (rp.strategy != HVX_RESTRICTED_REFERENCE_PLAN || bound <= 256)); // (a plan is monotone in the population)
+        const uint64_t work = (uint64_t)b * std::min<uint64_t>(bound, ix->dev.n) * ix->dev.dim;
+        // (the other path costs ~0.2 ms of host round trips more: the one-launch scan is the better choice up to 2^28 here, not 2^26)
+        if (exact_any && bound != 0 && b <= ix->max_batch && (work <= (1ull << 28) || ix->opt[HVX_OPT_RESTRICTED_DIRECT] == 2u))
+            return prefilter_expand_lean(ix, g, queries, b, rp, seeds, n_seeds, direction, allowed_label_ids, n_labels, bound, out_ids, out_scores, out_counts,
+                                         out_status, out_candidates, rstats, stats);
+    }
     int rc = run_bfs_locked(g, seeds, n_seeds, mode == HVX_PREFILTER_EXPAND ? 1u : max_depth, direction, allowed_label_ids, n_labels,
                             mode == HVX_PREFILTER_EXPAND ? 0u : hub_degree, mode == HVX_PREFILTER_EXPAND ? 0u : include_seeds,
                             mode == HVX_PREFILTER_EXPAND, nullptr, nullptr, ix->stream);

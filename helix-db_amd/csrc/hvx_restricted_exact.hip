@@ -47,8 +47,9 @@ struct DirectArgs {
     const float *queries;     // [b][dim] (device copy written by stage_validate_kernel)
     const uint32_t *qstatus;  // [b]
     const float *qhdr;        // [b]
-    const uint32_t *rows;     // shared candidate set: internal rows (ascending, unique) ...
+    const uint32_t *rows;     // shared candidate set: internal rows (unique; any order) ...
     uint32_t n_rows;
+    const uint32_t *n_rows_dev; // ... whose number a kernel earlier on the stream left on the device (then n_rows = the host's bound, the grid's size)
     const uint64_t *ext_ids;  // ... or per-query sets: external ids, query q owns [offsets[q], offsets[q + 1]) ...
     const uint64_t *offsets;
     const uint32_t *lens;     // ... or, with offsets == NULL, [q * ext_stride, + lens[q]) (the batching operator's fixed slots)
@@ -161,11 +162,16 @@ __global__ __launch_bounds__(256) void restricted_direct_kernel(DirectArgs a) {
     }
     __syncthreads();
 
+    uint32_t chunk = a.chunk;
+    if (!EXT && a.n_rows_dev) { // the list's real length: the slices divide IT (whole 64-row passes), not the bound the grid was sized for
+        n = *a.n_rows_dev < a.n_rows ? *a.n_rows_dev : a.n_rows;
+        chunk = ((n + a.slices * 64u - 1u) / (a.slices * 64u)) * 64u;
+    }
     TopList top[TQ];
 #pragma unroll
     for (int t = 0; t < TQ; ++t) top[t].init();
     uint32_t badmask = 0;
-    const uint32_t lo = slice * a.chunk, hi = lo + a.chunk < n ? lo + a.chunk : n;
+    const uint32_t lo = slice * chunk, hi = lo + chunk < n ? lo + chunk : n;
     for (uint32_t pass0 = lo; pass0 < hi; pass0 += 32u * P) {
         uint32_t nd[P];
         bool ok[P];
@@ -497,7 +503,8 @@ static int direct_scratch(hvx_index *ix, uint32_t b, uint32_t slices, uint32_t k
 // length k_stride.  Nothing is synchronised here.
 int restricted_direct_enqueue(hvx_index *ix, const float *d_queries, uint32_t b, uint32_t k, uint32_t k_stride, const uint32_t *d_rows,
                               uint32_t n_rows, const uint64_t *d_ext_ids, const uint64_t *d_offsets, uint32_t max_set, uint64_t *d_ids,
-                              float *d_scores, uint32_t *d_counts, uint32_t *d_status, const uint32_t *d_lens, uint32_t ext_stride) {
+                              float *d_scores, uint32_t *d_counts, uint32_t *d_status, const uint32_t *d_lens, uint32_t ext_stride,
+                              const uint32_t *d_n_rows) {
     const DevIndex &d = ix->dev;
     const bool ext = d_ext_ids != nullptr;
     const bool unrolled = direct_unrolled_shape(d);
@@ -518,6 +525,7 @@ int restricted_direct_enqueue(hvx_index *ix, const float *d_queries, uint32_t b,
     a.qhdr = ix->d_qhdr;
     a.rows = d_rows;
     a.n_rows = n_rows;
+    a.n_rows_dev = d_n_rows;
     a.ext_ids = d_ext_ids;
     a.offsets = d_offsets;
     a.lens = d_lens;

@@ -596,11 +596,13 @@ bool use_direct(const hvx_index *ix, uint32_t b, uint32_t k, uint32_t n_rows) {
 }
 
 // pinned mirror layout of one chunk: queries | ids | scores | counts | status (the kernels write the four outputs THERE: mapped host rows)
-struct PinView { float *q; uint64_t *ids; float *sc; uint32_t *cnt, *st; };
-int pin_view(hvx_index *ix, uint32_t cb, uint32_t k, PinView *v) {
+struct PinView { float *q; uint64_t *ids; float *sc; uint32_t *cnt, *st; unsigned char *extra; };
+int pin_view(hvx_index *ix, uint32_t cb, uint32_t k, PinView *v, size_t extra_bytes = 0) {
     const size_t qb = (((size_t)cb * ix->dev.dim * 4) + 63u) & ~(size_t)63u, n = (size_t)cb * k;
-    int rc = ix->pin(qb + n * 12 + (size_t)cb * 8);
+    const size_t fixed = (qb + n * 12 + (size_t)cb * 8 + 63u) & ~(size_t)63u;
+    int rc = ix->pin(fixed + extra_bytes);
     if (rc) return rc;
+    v->extra = ix->h_pin + fixed;
     v->q = reinterpret_cast<float *>(ix->h_pin);
     v->ids = reinterpret_cast<uint64_t *>(ix->h_pin + qb);
     v->sc = reinterpret_cast<float *>(ix->h_pin + qb + n * 8);
@@ -664,22 +666,36 @@ int direct_per_query_host(hvx_index *ix, const float *queries, uint32_t b, const
         for (uint32_t q = 0; q <= cb; ++q) off[q] = allowed_offsets[c0 + q] - a0;
         for (uint32_t q = 0; q < cb; ++q) max_set = std::max<uint64_t>(max_set, off[q + 1] - off[q]);
         if ((rc = ix->stage(cb, k))) return rc;
-        PinView v;
-        if ((rc = pin_view(ix, cb, k, &v))) return rc;
         const uint64_t n_ids = a1 - a0;
-        if (n_ids > ix->cap_x_ids) {
-            if ((rc = ix->regrow((void **)&ix->x_ids, std::max<size_t>(n_ids, 1) * 8))) return rc;
-            ix->cap_x_ids = n_ids;
+        // id lists up to 1 MiB ride in the pinned mirror behind the outputs and are read by the kernel IN PLACE (every id once, over PCIe): a
+        // copy from the caller's pageable memory is a synchronous staged DMA of ~40 us; longer lists take it
+        const bool ids_in_pin = n_ids * 8 <= (1u << 20);
+        PinView v;
+        if ((rc = pin_view(ix, cb, k, &v, ids_in_pin ? (size_t)n_ids * 8 + ((size_t)cb + 1) * 8 : 0))) return rc;
+        const uint64_t *d_ids_src = nullptr, *d_off_src = nullptr;
+        if (ids_in_pin) {
+            uint64_t *pids = reinterpret_cast<uint64_t *>(v.extra), *poff = pids + n_ids;
+            if (n_ids) memcpy(pids, allowed_ids + a0, (size_t)n_ids * 8);
+            memcpy(poff, off.data(), ((size_t)cb + 1) * 8);
+            d_ids_src = pids;
+            d_off_src = poff;
+        } else {
+            if (n_ids > ix->cap_x_ids) {
+                if ((rc = ix->regrow((void **)&ix->x_ids, std::max<size_t>(n_ids, 1) * 8))) return rc;
+                ix->cap_x_ids = n_ids;
+            }
+            if ((size_t)cb + 1 > ix->cap_x_off) {
+                if ((rc = ix->regrow((void **)&ix->x_off, ((size_t)mb + 1) * 8))) return rc;
+                ix->cap_x_off = (size_t)mb + 1;
+            }
+            HIP_TRY(hipMemcpyAsync(ix->x_ids, allowed_ids + a0, n_ids * 8, hipMemcpyHostToDevice, ix->stream)); // (pageable source: staged, returns when the source is consumed)
+            HIP_TRY(hipMemcpyAsync(ix->x_off, off.data(), ((size_t)cb + 1) * 8, hipMemcpyHostToDevice, ix->stream));
+            d_ids_src = ix->x_ids;
+            d_off_src = ix->x_off;
         }
-        if ((size_t)cb + 1 > ix->cap_x_off) {
-            if ((rc = ix->regrow((void **)&ix->x_off, ((size_t)mb + 1) * 8))) return rc;
-            ix->cap_x_off = (size_t)mb + 1;
-        }
-        if (n_ids) HIP_TRY(hipMemcpyAsync(ix->x_ids, allowed_ids + a0, n_ids * 8, hipMemcpyHostToDevice, ix->stream)); // (pageable source: staged, returns when the source is consumed)
-        HIP_TRY(hipMemcpyAsync(ix->x_off, off.data(), ((size_t)cb + 1) * 8, hipMemcpyHostToDevice, ix->stream));
         if ((rc = stage_and_validate(ix, queries + (size_t)c0 * ix->dev.dim, cb, v))) return rc;
         if (stats) HIP_TRY(hipEventRecord(ix->ev0, ix->stream));
-        if ((rc = restricted_direct_enqueue(ix, ix->s_queries, cb, k, k, nullptr, 0, ix->x_ids, ix->x_off, (uint32_t)max_set, v.ids, v.sc, v.cnt, v.st))) return rc;
+        if ((rc = restricted_direct_enqueue(ix, ix->s_queries, cb, k, k, nullptr, 0, d_ids_src, d_off_src, (uint32_t)max_set, v.ids, v.sc, v.cnt, v.st))) return rc;
         if (stats) HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
         HIP_TRY(hipStreamSynchronize(ix->stream)); // (`off` is consumed as well)
         for (uint32_t q = 0; q < cb; ++q) {
@@ -744,6 +760,17 @@ int exact_shared_set(hvx_index *ix, const float *queries, uint32_t b, uint32_t k
 int restricted_set(hvx_index *ix, const float *queries, uint32_t b, const hvx_restricted_params &rp, const uint64_t *allowed,
                    uint64_t n_allowed, uint64_t *out_ids, float *out_scores, uint32_t *out_counts, uint32_t *out_status,
                    hvx_restricted_stats *rstats, hvx_stats *stats) {
+    // ONE query with its candidate ids (the operator's call, storage.rs:140-163) under a plan that is exact for a list this long: the
+    // one-launch scan maps, dedupes and scans the ids on the device -- no host-side sort / unique / id -> row pass (round 6: those and two
+    // staged copies were ~90 us of a 145-us call at 10 000 ids)
+    if (b == 1 && n_allowed != 0 && n_allowed <= 1000000ull && rp.k <= 64u && !rp.explicit_budgets && ix->opt[HVX_OPT_RESTRICTED_DIRECT] != 1u &&
+        restricted_direct_supported(ix, rp.k) && (n_allowed * (uint64_t)ix->dev.dim <= (1ull << 28) || ix->opt[HVX_OPT_RESTRICTED_DIRECT] == 2u)) {
+        HostPlan hp1;
+        if (make_plan(rp, n_allowed, ix->dev.dim, &hp1, ix) == HVX_OK && hp1.strategy == HVX_RESTRICTED_EXACT) {
+            const uint64_t offs[2] = {0, n_allowed};
+            return direct_per_query_host(ix, queries, 1, rp, allowed, offs, out_ids, out_scores, out_counts, out_status, rstats, stats);
+        }
+    }
     // RestrictedVectorCandidates::from_ids (restricted.rs:356-371): dedupe, cap 1,000,000
     std::vector<uint64_t> ids(allowed, allowed + n_allowed);
     std::sort(ids.begin(), ids.end());
@@ -791,6 +818,54 @@ int restricted_set(hvx_index *ix, const float *queries, uint32_t b, const hvx_re
 }
 
 } // namespace
+
+int hvx::restricted_direct_shared_devcount(hvx_index *ix, const float *queries, uint32_t b, uint32_t k, const uint32_t *d_rows, uint32_t rows_cap,
+                                           const uint32_t *d_counters, uint64_t *out_ids, float *out_scores, uint32_t *out_counts, uint32_t *out_status,
+                                           uint64_t *out_candidates, hvx_restricted_stats *rstats, hvx_stats *stats) {
+    int rc;
+    if ((rc = ix->stage(b, k))) return rc;
+    PinView v;
+    if ((rc = pin_view(ix, b, k, &v))) return rc;
+    if ((rc = ix->pin_flags(8))) return rc;
+    if ((rc = stage_and_validate(ix, queries, b, v))) return rc;
+    if (stats) HIP_TRY(hipEventRecord(ix->ev0, ix->stream));
+    if ((rc = restricted_direct_enqueue(ix, ix->s_queries, b, k, k, d_rows, std::max<uint32_t>(rows_cap, 1u), nullptr, nullptr, 0, v.ids, v.sc, v.cnt, v.st,
+                                        nullptr, 0, d_counters)))
+        return rc;
+    if (stats) HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
+    HIP_TRY(hipMemcpyAsync(ix->h_flags, d_counters, 8, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    const uint32_t n_rows = ix->h_flags[0], population = ix->h_flags[1];
+    if (out_candidates) *out_candidates = population;
+    // RestrictedVectorCandidates::from_ids (restricted.rs:356-371): checked behind the scan here -- its answer is discarded
+    if (population > 1000000u) return fail(HVX_ERR_CANDIDATE_LIMIT, "restricted vector search accepts at most 1000000 unique candidates");
+    for (uint32_t q = 0; q < b; ++q) {
+        out_counts[q] = 0;
+        if (out_status) out_status[q] = HVX_OK;
+        if (rstats) memset(&rstats[q], 0, sizeof(hvx_restricted_stats));
+    }
+    if (population == 0) return HVX_OK; // Empty: no results, before any validation (restricted.rs:539-541)
+    for (uint32_t q = 0; q < b; ++q) {
+        if (v.st[q]) {
+            if (!out_status) return fail((int)v.st[q], "query %u rejected with status %u", q, v.st[q]);
+            out_status[q] = v.st[q];
+            continue;
+        }
+        if (rstats && ix->dev.has_entry) rstats[q].strategy = HVX_RESTRICTED_EXACT;
+        out_counts[q] = v.cnt[q];
+        memcpy(out_ids + (size_t)q * k, v.ids + (size_t)q * k, (size_t)v.cnt[q] * 8);
+        memcpy(out_scores + (size_t)q * k, v.sc + (size_t)q * k, (size_t)v.cnt[q] * 4);
+    }
+    if (stats) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
+        stats->queries += b;
+        stats->vectors_loaded += (uint64_t)b * n_rows;
+        stats->distance_computations += (uint64_t)b * n_rows;
+        stats->device_ms += ms;
+    }
+    return HVX_OK;
+}
 
 int hvx::restricted_make_plan(const hvx_restricted_params &rp, uint64_t candidates, uint32_t dim, RestrictedPlan *out, const hvx_index *ix) {
     return make_plan(rp, candidates, dim, out, ix);

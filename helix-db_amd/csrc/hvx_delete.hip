@@ -419,26 +419,25 @@ __device__ __forceinline__ void store_canonical_wave(uint32_t *row, uint32_t str
 template <uint32_t METRIC, bool FUSED>
 __device__ __forceinline__ uint32_t prune_eager(const DevIndex &ix, const StepLds &S, uint32_t owner, uint32_t nc, uint32_t maxn, uint32_t tid, bool *bad) {
     const uint32_t wave = tid >> 6, lane = tid & 63u;
-    const int grp = (int)(lane >> 3), j = (int)(lane & 7u);
-    const uint32_t iters = (nc + 1u + kDelWaves - 1u) / kDelWaves;
-    for (uint32_t it = 0; it < iters; ++it) {
-        const uint32_t i = it * kDelWaves + wave;
-        const bool act = i <= nc;
-        const uint32_t node_i = (act && i < nc) ? S.cur[i] : owner;
-        __syncthreads();
-        {
-            const float *r = ix.vec + (size_t)node_i * ix.ld;
-            for (uint32_t t = lane; t < ix.ld; t += 64u) S.qv[t] = r[t];
-        }
-        __syncthreads();
-        if (act) {
-            const float h = ix.hdr[node_i];
-            for (uint32_t p0 = 0; p0 < nc; p0 += 8u) {
-                const uint32_t g = p0 + (uint32_t)grp;
-                const uint32_t other = S.cur[g < nc ? g : nc - 1u];
-                const float d = group_distance<METRIC, FUSED>(ix, S.qv, h, other, j);
-                if (g < nc && j == 0) S.Dm[i * 64u + g] = d;
-            }
+    const int j = (int)(lane & 7u);
+    // Round 6: the matrix is SYMMETRIC bit for bit -- (a - b)^2 = (b - a)^2, a b = b a, |a - b| = |b - a|, and the cosine finish is symmetric
+    // in its two norms -- so only the pairs i > j are evaluated, each by one 8-lane group with BOTH rows read in place (the "query" row
+    // through the same pointer arithmetic as the staged copy: the same operands in the same order).  128 groups x 17 rounds of independent
+    // pairs, no barrier in between (rounds 3-5: every wavefront staged one row in LDS and walked all 64 others, eight dependent passes per
+    // staged row, five barrier-separated iterations: 48 us per step kernel, 2.8 ms of a 3.05-ms delete).
+    __syncthreads();
+    const uint32_t npairs = (nc + 1u) * nc / 2u;
+    for (uint32_t p = tid >> 3; p < npairs; p += (kDelWaves * 64u) >> 3) {
+        // p = i (i - 1) / 2 + jj, 0 <= jj < i <= nc
+        uint32_t i = (uint32_t)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
+        while (i * (i - 1u) / 2u > p) --i;
+        while ((i + 1u) * i / 2u <= p) ++i;
+        const uint32_t jj = p - i * (i - 1u) / 2u;
+        const uint32_t node_i = i < nc ? S.cur[i] : owner, node_j = S.cur[jj];
+        const float d = group_distance<METRIC, FUSED>(ix, ix.vec + (size_t)node_i * ix.ld, ix.hdr[node_i], node_j, j);
+        if (j == 0) {
+            S.Dm[i * 64u + jj] = d;
+            if (i < nc) S.Dm[jj * 64u + i] = d;
         }
     }
     __syncthreads();
@@ -455,20 +454,27 @@ __device__ __forceinline__ uint32_t prune_eager(const DevIndex &ix, const StepLd
         }
         if (lane < nc) { S.ord[rank] = lane; S.osc[rank] = dmine; }
         lds_order();
+        // select_diverse (mod.rs:822-842): strict < rejects.  Round 6: the ranked candidates and the selection live in REGISTERS (lane r holds
+        // the r-th candidate and its score, lane l the l-th selected one): a step is two lane broadcasts, one LDS gather of the matrix and a
+        // ballot -- no LDS write + fence per accepted candidate (the replay was ~20 us of a 50-us step kernel)
+        const uint32_t my_ord = lane < nc ? S.ord[lane] : 0u;
+        const float my_osc = lane < nc ? S.osc[lane] : 0.f;
+        uint32_t my_sel = 0u; // the index (into S.cur) of the lane-th selected candidate
         uint32_t ns = 0;
-        for (uint32_t r = 0; r < nc && ns < maxn; ++r) { // select_diverse (mod.rs:822-842): strict < rejects
-            const uint32_t ci = S.ord[r];
-            const float sc = S.osc[r];
-            const bool closer = lane < ns && S.Dm[ci * 64u + S.sel[lane < ns ? lane : 0u]] < sc;
+        for (uint32_t r = 0; r < nc && ns < maxn; ++r) {
+            const uint32_t ci = (uint32_t)__builtin_amdgcn_readlane((int)my_ord, (int)r);
+            const float sc = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(my_osc), (int)r));
+            const bool closer = lane < ns && S.Dm[ci * 64u + my_sel] < sc;
             if (__ballot(closer) == 0ull) {
-                if (lane == 0) S.sel[ns] = ci;
+                if (lane == ns) my_sel = ci;
                 ++ns;
-                lds_order();
             }
         }
+        if (lane < ns) S.sel[lane] = my_sel;
+        lds_order();
         if (ns < maxn) { // backfill, closest first (mod.rs:845-854)
             const bool have = lane < nc;
-            const uint32_t mine = have ? S.ord[lane] : kSentinel;
+            const uint32_t mine = have ? my_ord : kSentinel;
             bool in = false;
             for (uint32_t s = 0; s < ns; ++s) in |= S.sel[s] == mine;
             const unsigned long long fm = __ballot(have && !in);

@@ -1193,12 +1193,16 @@ def compact_record(out, full_path):
     c["roofline"] = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "peak_measured", "unit", "frac", "frac_of_measured",
                                             "algorithmic_bytes_per_launch", "kernel_ms", "kernel_ms_each", "traffic", "traffic_source")}
     c["roofline"]["frac_definition"] = f"overlapped span, {rf.get('lanes')} lanes x {rf.get('queries_per_simd')} queries per SIMD; one launch alone: lone_batch_frac"
+    if isinstance(c["roofline"].get("traffic_source"), str):   # (the full sentence stays in the full record)
+        c["roofline"]["traffic_source"] = c["roofline"]["traffic_source"].split(";")[0][:100]
     lb = rf.get("lone_batch") or {}
     if lb:
         c["roofline"]["lone_batch_frac"] = lb.get("frac")
     cb = out.get("cpu_baseline")
     if cb:
         c["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "threads", "nproc", "quota_cores", "kind", "sample")}
+        if isinstance(c["cpu_baseline"].get("sample"), str):
+            c["cpu_baseline"]["sample"] = c["cpu_baseline"]["sample"].split("; oracle")[0][:140]
     if out.get("parity"):
         c["parity"] = {k: out["parity"].get(k) for k in ("queries", "ids_equal_oracle", "score_bits_equal_oracle")}
     if out.get("strong_scaling"):
@@ -1235,14 +1239,15 @@ def compact_record(out, full_path):
         if "error" in c3:
             c["config3"] = {"error": str(c3["error"])[:160]}
         else:
+            # groups: plan / recall / us_per_q / p50_1q_ms = the DEVICE plan (HVX_RESTRICTED_AUTO); ref_* = the reference's plan on the same rows
             c["config3"] = {"corpus": _pick(c3, "corpus", "kind"), "parity_ok": c3.get("parity_sample_ok"),
-                            "groups": [{"candidates": g_["candidates"], "device_plan": _pick(g_, "device_plan", "strategy"),
-                                        "device_recall": _pick(g_, "device_plan", "recall_at_10_vs_exact"),
-                                        "device_us_per_query": _pick(g_, "device_plan", "us_per_query"),
-                                        "device_1q_p50_ms": _pick(g_, "device_plan", "single_query_end_to_end_ms", "p50"),
+                            "groups": [{"candidates": g_["candidates"], "plan": _pick(g_, "device_plan", "strategy"),
+                                        "recall": _pick(g_, "device_plan", "recall_at_10_vs_exact"),
+                                        "us_per_q": _pick(g_, "device_plan", "us_per_query"),
+                                        "p50_1q_ms": _pick(g_, "device_plan", "single_query_end_to_end_ms", "p50"),
                                         "ref_plan": _pick(g_, "planned", "strategy"), "ref_recall": _pick(g_, "planned", "recall_at_10_vs_exact"),
-                                        "ref_us_per_query": _pick(g_, "planned", "us_per_query"),
-                                        "exact_hbm_frac": None if _pick(g_, "exact", "hbm_gbs_scan") is None else round(_pick(g_, "exact", "hbm_gbs_scan") / HBM_PEAK_GBS, 3)}
+                                        "ref_us_per_q": _pick(g_, "planned", "us_per_query"),
+                                        "hbm_frac": None if _pick(g_, "exact", "hbm_gbs_scan") is None else round(_pick(g_, "exact", "hbm_gbs_scan") / HBM_PEAK_GBS, 3)}
                                        for g_ in c3.get("groups", [])],
                             "own_sets": [{"req": r_["requests"], "ids": r_["ids_per_request"], "qps": r_["qps_kernel"], "frac": r_["frac_of_hbm_peak"]}
                                          for r_ in (_pick(c3, "per_request_candidate_sets", "rows") or [])]}

@@ -55,8 +55,8 @@ constexpr uint32_t kDelCandCap = 16384; // candidates per layer (one source's sc
 constexpr uint32_t kDelTop = 32;        // Mmax
 constexpr uint32_t kDelMinLayers = 16;
 constexpr uint32_t kDelMark = 0xFFFFFFFFu;
-constexpr uint32_t kDelWaves = 16; // wavefronts of a step workgroup
-constexpr uint32_t kDelSteps = 32; // relink sources per layer that run as steps (own + reciprocal launch); later ones in delete_relink_kernel
+constexpr uint32_t kDelWaves = 4;  // wavefronts of a step workgroup (32 row groups of 8 lanes)
+constexpr uint32_t kDelDm = 65 * 64; // one prune's distance matrix
 
 struct DeleteArgs {
     DevIndex ix;
@@ -70,6 +70,9 @@ struct DeleteArgs {
     uint32_t *top, *top_cnt;   // [layers][kDelRelCap][kDelTop], [layers][kDelRelCap]: a source's closest candidates, Candidate order
     uint32_t *mark;            // [layers][words] all zero between kernels
     uint32_t *newl, *new_cnt;  // [layers][kDelTop], [layers]: the neighbours the current step's source has gained (step kernels)
+    float *gdm;                // [layers][1 + kDelTop][65 x 64]: the distance matrices of a step's prunes (slot 0: the source's own row,
+    uint32_t *tick;            //  1 + t: its t-th new neighbour's), and per matrix the workgroups that have delivered (zero between launches)
+    uint32_t g_own, g_recip;   // workgroups that share one matrix
     uint32_t first;            // delete_relink_kernel starts with this source (the ones before it ran as steps)
     uint32_t *dead;            // the image's deleted-row bitmap
     uint32_t *ctl;             // [0] error (1 sources, 2 relink sources, 3 candidates, 4 invalid score, 5 row overflow) [1] relinked rows
@@ -381,17 +384,14 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(64) void del
 // it as "not closer" -- rows validated at import cannot produce one under the component limit.)
 // ---------------------------------------------------------------------------------------------------------------------------------
 struct StepLds {
-    float *qv;                                // [ld] this wavefront's staged vector
     float *Dm;                                // [65][64]: Dm[i][j] = distance(staged id i, stored id j); row nc = the owner
     uint32_t *cur, *ord, *sel, *kept, *oldl;  // [64] each
     float *osc;                               // [64]
     uint32_t *misc;                           // [8]
 };
-__device__ __forceinline__ StepLds carve_step(char *smem, uint32_t ld, uint32_t wave) {
-    const size_t qs = ((size_t)ld * 4u + 15u) & ~(size_t)15u;
+__device__ __forceinline__ StepLds carve_step(char *smem) {
     StepLds S;
-    S.qv = reinterpret_cast<float *>(smem + wave * qs);
-    char *p = smem + kDelWaves * qs;
+    char *p = smem;
     S.Dm = reinterpret_cast<float *>(p); p += 65 * 64 * 4;
     S.cur = reinterpret_cast<uint32_t *>(p); p += 256;
     S.ord = reinterpret_cast<uint32_t *>(p); p += 256;
@@ -402,7 +402,7 @@ __device__ __forceinline__ StepLds carve_step(char *smem, uint32_t ld, uint32_t 
     S.misc = reinterpret_cast<uint32_t *>(p);
     return S;
 }
-static size_t step_lds_bytes(uint32_t ld) { return kDelWaves * (((size_t)ld * 4u + 15u) & ~(size_t)15u) + 65 * 64 * 4 + 6 * 256 + 64; }
+static size_t step_lds_bytes() { return (size_t)kDelDm * 4 + 6 * 256 + 64; }
 
 __device__ __forceinline__ void lds_order() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); } // one wavefront's LDS writes before its next reads
 
@@ -415,19 +415,26 @@ __device__ __forceinline__ void store_canonical_wave(uint32_t *row, uint32_t str
     if (lane < ns) st_row(row + rank, mine);
 }
 
-// S.cur[0..nc) pruned to at most maxn ids around `owner` (prune_row_dev's result, evaluated eagerly by the whole workgroup): S.kept[0..return)
+template <typename T> __device__ __forceinline__ T ld_agent(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T> __device__ __forceinline__ void st_agent(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// S.cur[0..nc) pruned to at most maxn ids around `owner` (prune_row_dev's result, evaluated eagerly): S.kept[0..return).
+// G workgroups share the prune: every one of them evaluates its share of the distance matrix into gdm; the LAST one to deliver (one
+// relaxed fetch-add behind a workgroup-scope release, hvx_restricted_exact.hip) loads the matrix and replays select_diverse -- the
+// others get kSentinel back and leave.
 template <uint32_t METRIC, bool FUSED>
-__device__ __forceinline__ uint32_t prune_eager(const DevIndex &ix, const StepLds &S, uint32_t owner, uint32_t nc, uint32_t maxn, uint32_t tid, bool *bad) {
+__device__ __forceinline__ uint32_t prune_eager(const DevIndex &ix, const StepLds &S, uint32_t owner, uint32_t nc, uint32_t maxn, uint32_t tid, uint32_t g,
+                                                uint32_t G, float *gdm, uint32_t *tick, bool *bad) {
     const uint32_t wave = tid >> 6, lane = tid & 63u;
     const int j = (int)(lane & 7u);
     // Round 6: the matrix is SYMMETRIC bit for bit -- (a - b)^2 = (b - a)^2, a b = b a, |a - b| = |b - a|, and the cosine finish is symmetric
     // in its two norms -- so only the pairs i > j are evaluated, each by one 8-lane group with BOTH rows read in place (the "query" row
-    // through the same pointer arithmetic as the staged copy: the same operands in the same order).  128 groups x 17 rounds of independent
-    // pairs, no barrier in between (rounds 3-5: every wavefront staged one row in LDS and walked all 64 others, eight dependent passes per
-    // staged row, five barrier-separated iterations: 48 us per step kernel, 2.8 ms of a 3.05-ms delete).
+    // through the same pointer arithmetic as a staged copy: the same operands in the same order).  One workgroup evaluating all <= 2 080
+    // pairs pulls 12.5 MB through ONE compute unit's vector cache: 48 - 51 us per step kernel, 2 ms of a 2.6-ms delete (rounds 3-5 and the
+    // first build of this round).  Spread over G workgroups of 32 row groups every group has about one pair: the matrix costs one row gather.
     __syncthreads();
     const uint32_t npairs = (nc + 1u) * nc / 2u;
-    for (uint32_t p = tid >> 3; p < npairs; p += (kDelWaves * 64u) >> 3) {
+    for (uint32_t p = g * (kDelWaves * 8u) + (tid >> 3); p < npairs; p += G * (kDelWaves * 8u)) {
         // p = i (i - 1) / 2 + jj, 0 <= jj < i <= nc
         uint32_t i = (uint32_t)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
         while (i * (i - 1u) / 2u > p) --i;
@@ -436,10 +443,17 @@ __device__ __forceinline__ uint32_t prune_eager(const DevIndex &ix, const StepLd
         const uint32_t node_i = i < nc ? S.cur[i] : owner, node_j = S.cur[jj];
         const float d = group_distance<METRIC, FUSED>(ix, ix.vec + (size_t)node_i * ix.ld, ix.hdr[node_i], node_j, j);
         if (j == 0) {
-            S.Dm[i * 64u + jj] = d;
-            if (i < nc) S.Dm[jj * 64u + i] = d;
+            st_agent(gdm + i * 64u + jj, d);
+            if (i < nc) st_agent(gdm + jj * 64u + i, d);
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the stores have been acknowledged before the ticket is taken
+    __syncthreads();
+    if (tid == 0) S.misc[1] = __hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == G ? 1u : 0u;
+    __syncthreads();
+    if (!S.misc[1]) return kSentinel;
+    if (tid == 0) st_agent(tick, 0u); // (the next launch starts from zero)
+    for (uint32_t t = tid; t < (nc + 1u) * 64u; t += kDelWaves * 64u) S.Dm[t] = ld_agent(gdm + t); // (the diagonal is never read)
     __syncthreads();
     if (wave == 0) {
         const float dmine = lane < nc ? S.Dm[nc * 64u + lane] : 0.f;
@@ -454,9 +468,9 @@ __device__ __forceinline__ uint32_t prune_eager(const DevIndex &ix, const StepLd
         }
         if (lane < nc) { S.ord[rank] = lane; S.osc[rank] = dmine; }
         lds_order();
-        // select_diverse (mod.rs:822-842): strict < rejects.  Round 6: the ranked candidates and the selection live in REGISTERS (lane r holds
+        // select_diverse (mod.rs:822-842): strict < rejects.  The ranked candidates and the selection live in REGISTERS (lane r holds
         // the r-th candidate and its score, lane l the l-th selected one): a step is two lane broadcasts, one LDS gather of the matrix and a
-        // ballot -- no LDS write + fence per accepted candidate (the replay was ~20 us of a 50-us step kernel)
+        // ballot -- no LDS write + fence per accepted candidate
         const uint32_t my_ord = lane < nc ? S.ord[lane] : 0u;
         const float my_osc = lane < nc ? S.osc[lane] : 0.f;
         uint32_t my_sel = 0u; // the index (into S.cur) of the lane-th selected candidate
@@ -491,16 +505,18 @@ __device__ __forceinline__ uint32_t prune_eager(const DevIndex &ix, const StepLd
     return S.misc[0];
 }
 
-// relink_neighbor (mutation.rs:1916-1993) for source `ri` of every layer: merge, prune, stage; the neighbours it has gained go to newl
-template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(1024) void delete_step_own_kernel(DeleteArgs a, uint32_t ri) {
+// relink_neighbor (mutation.rs:1916-1993) for source `ri` of every layer: merge, prune, stage; the neighbours it has gained go to newl.
+// grid (layers, g_own): every workgroup of a layer reads the same row and closest-candidate list and arrives at the same merged row;
+// without a prune workgroup 0 finishes alone, with one the last workgroup to deliver its share of the matrix does
+template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(256) void delete_step_own_kernel(DeleteArgs a, uint32_t ri) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t s_go, s_ncur, s_nold;
     const DevIndex &ix = a.ix;
-    const uint32_t L = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    const StepLds S = carve_step(smem, ix.ld, wave);
-    if (tid == 0) { a.new_cnt[L] = 0; s_go = (a.ctl[0] == 0u && ri < a.rel_cnt[L]) ? 1u : 0u; }
+    const uint32_t L = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const StepLds S = carve_step(smem);
+    if (tid == 0) s_go = (a.ctl[0] == 0u && ri < a.rel_cnt[L]) ? 1u : 0u;
     __syncthreads();
-    if (!s_go) return;
+    if (!s_go) { if (g == 0u && tid == 0) a.new_cnt[L] = 0; return; }
     const uint32_t nb = a.rel[(size_t)L * kDelRelCap + ri];
     const uint32_t maxn = L == 0u ? a.m0 : a.m;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -526,12 +542,14 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(1024) void d
     }
     __syncthreads();
     const uint32_t ncur = s_ncur, nold = s_nold;
-    if (ncur > 64u) { if (tid == 0) atomicMax(&a.ctl[0], 5u); return; }
+    if (ncur > 64u) { if (g == 0u && tid == 0) { a.new_cnt[L] = 0; atomicMax(&a.ctl[0], 5u); } return; }
     bool bad = false;
     uint32_t keepn = ncur;
     if (ncur > maxn) {
-        keepn = prune_eager<METRIC, FUSED>(ix, S, nb, ncur, maxn, tid, &bad);
+        keepn = prune_eager<METRIC, FUSED>(ix, S, nb, ncur, maxn, tid, g, a.g_own, a.gdm + (size_t)L * (1u + kDelTop) * kDelDm, a.tick + L * (1u + kDelTop), &bad);
+        if (keepn == kSentinel) return;
     } else {
+        if (g != 0u) return;
         if (wave == 0 && lane < ncur) S.kept[lane] = S.cur[lane];
         __syncthreads();
     }
@@ -541,7 +559,7 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(1024) void d
         for (uint32_t s = 0; s < nold; ++s) was_old |= S.oldl[s] == f;
         const bool isnew = f != kSentinel && !was_old;
         const unsigned long long nm = __ballot(isnew);
-        if (keepn > stride) { if (lane == 0) atomicMax(&a.ctl[0], 5u); return; }
+        if (keepn > stride) { if (lane == 0) { a.new_cnt[L] = 0; atomicMax(&a.ctl[0], 5u); } return; }
         store_canonical_wave(row, stride, S.kept, keepn, lane);
         if (isnew) a.newl[(size_t)L * kDelTop + (uint32_t)__builtin_popcountll(nm & lt)] = f;
         if (lane == 0) {
@@ -551,13 +569,13 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(1024) void d
     }
 }
 
-// ... and the reciprocal row of each of them (mutation.rs:1994-2052): one workgroup per new neighbour
-template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(1024) void delete_step_recip_kernel(DeleteArgs a, uint32_t ri) {
+// ... and the reciprocal row of each of them (mutation.rs:1994-2052): g_recip workgroups per new neighbour (grid x = neighbour x g_recip)
+template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(256) void delete_step_recip_kernel(DeleteArgs a, uint32_t ri) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t s_go, s_rdeg, s_has;
     const DevIndex &ix = a.ix;
-    const uint32_t L = blockIdx.y, bx = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    const StepLds S = carve_step(smem, ix.ld, wave);
+    const uint32_t L = blockIdx.y, bx = blockIdx.x / a.g_recip, g = blockIdx.x % a.g_recip, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const StepLds S = carve_step(smem);
     if (tid == 0) s_go = (a.ctl[0] == 0u && ri < a.rel_cnt[L] && bx < a.new_cnt[L]) ? 1u : 0u;
     __syncthreads();
     if (!s_go) return;
@@ -581,12 +599,15 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(1024) void d
     __syncthreads();
     if (s_has) return;
     const uint32_t rdeg = s_rdeg;
-    if (rdeg > 64u) { if (tid == 0) atomicMax(&a.ctl[0], 5u); return; }
+    if (rdeg > 64u) { if (g == 0u && tid == 0) atomicMax(&a.ctl[0], 5u); return; }
     bool bad = false;
     uint32_t kn = rdeg;
     if (rdeg > maxn) {
-        kn = prune_eager<METRIC, FUSED>(ix, S, nw, rdeg, maxn, tid, &bad);
+        kn = prune_eager<METRIC, FUSED>(ix, S, nw, rdeg, maxn, tid, g, a.g_recip, a.gdm + ((size_t)L * (1u + kDelTop) + 1u + bx) * kDelDm,
+                                        a.tick + L * (1u + kDelTop) + 1u + bx, &bad);
+        if (kn == kSentinel) return;
     } else {
+        if (g != 0u) return;
         if (wave == 0 && lane < rdeg) S.kept[lane] = S.cur[lane];
         __syncthreads();
     }
@@ -650,7 +671,8 @@ extern "C" int hvx_index_delete_batch(hvx_index *ix, const uint64_t *node_ids, u
     const uint32_t layers_now = d.max_layer + 1u;
     if (!ix->del_scratch || ix->del_layers < layers_now) {
         const uint32_t layers = std::max(kDelMinLayers, layers_now);
-        const size_t per_layer = ((size_t)kDelSrcCap + kDelRelCap + kDelCandCap + (size_t)kDelRelCap * kDelTop + kDelRelCap + words + 4u + kDelTop) * 4u;
+        const size_t per_layer = ((size_t)kDelSrcCap + kDelRelCap + kDelCandCap + (size_t)kDelRelCap * kDelTop + kDelRelCap + words + 4u + kDelTop +
+                                  (size_t)(1u + kDelTop) * (kDelDm + 1u)) * 4u;
         void *p = nullptr;
         if ((rc = ix->dalloc(&p, per_layer * layers + 64))) return rc;
         HIP_TRY(hipMemsetAsync(p, 0, per_layer * layers + 64, s));
@@ -672,6 +694,8 @@ extern "C" int hvx_index_delete_batch(hvx_index *ix, const uint64_t *node_ids, u
         a.cand = p; p += (size_t)layers * kDelCandCap;
         a.top_cnt = p; p += (size_t)layers * kDelRelCap;
         a.top = p; p += (size_t)layers * kDelRelCap * kDelTop;
+        a.gdm = reinterpret_cast<float *>(p); p += (size_t)layers * (1u + kDelTop) * kDelDm;
+        a.tick = p; p += (size_t)layers * (1u + kDelTop);
         a.mark = p;
     }
     a.l0 = const_cast<uint32_t *>(d.l0);
@@ -684,13 +708,14 @@ extern "C" int hvx_index_delete_batch(hvx_index *ix, const uint64_t *node_ids, u
     const size_t relink_lds = (((size_t)d.ld * 4u + 15u) & ~(size_t)15u) + 4 * 256 + 256;
     if (rank_lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kern.rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_lds));
     if (relink_lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kern.relink, hipFuncAttributeMaxDynamicSharedMemorySize, (int)relink_lds));
-    const size_t step_lds = step_lds_bytes(d.ld);
-    const bool steps = ix->opt[HVX_OPT_DELETE_SEQUENTIAL] != 1u && step_lds <= 150u * 1024u; // (wider rows: the one-wavefront kernel relinks every source)
-    if (steps && step_lds > 48 * 1024) {
-        HIP_TRY(hipFuncSetAttribute((const void *)kern.own, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));
-        HIP_TRY(hipFuncSetAttribute((const void *)kern.recip, hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds));
-    }
-    a.first = steps ? kDelSteps : 0u;
+    const size_t step_lds = step_lds_bytes();
+    const bool steps = ix->opt[HVX_OPT_DELETE_SEQUENTIAL] != 1u;
+    // workgroups (32 row groups each) that share one prune's distance matrix: about one pair per row group.  A source's row grows to at
+    // most 64 ids (65 x 64 / 2 pairs), a reciprocal row to Mmax + 1
+    const uint32_t groups = kDelWaves * 8u;
+    a.g_own = (65u * 64u / 2u + groups - 1u) / groups;
+    a.g_recip = ((m0 + 2u) * (m0 + 1u) / 2u + groups - 1u) / groups;
+    a.first = steps ? kDelRelCap : 0u; // every source runs as a step (their number is read back below); the one-wavefront kernel only retires the node
     // this generation's deleted-row flags: a copy of the visible ones (forks keep theirs until hvx_index_refresh)
     auto flags = std::make_shared<std::vector<uint8_t>>((size_t)cap, (uint8_t)0);
     if (ix->dead_p) std::copy(ix->dead_p->begin(), ix->dead_p->begin() + std::min<size_t>(ix->dead_p->size(), (size_t)cap), flags->begin());
@@ -714,7 +739,7 @@ extern "C" int hvx_index_delete_batch(hvx_index *ix, const uint64_t *node_ids, u
         hipLaunchKernelGGL(delete_prep_kernel, dim3(a.layers), dim3(256), 0, s, a);
         // how many relink sources the layers have: read back behind the prep kernel WHILE the rank kernel runs (round 6: the r05w trace had
         // 64 000 own + 64 000 reciprocal step dispatches for 2 000 deletes of ~25 relinked rows each -- two launches of ~4 us per absent step)
-        uint32_t n_steps = kDelSteps;
+        uint32_t n_steps = 0;
         if (steps) {
             if ((rc = ix->pin_flags(4 + kDelMinLayers + a.layers))) return rc;
             HIP_TRY(hipMemcpyAsync(ix->h_flags + 4, a.rel_cnt, (size_t)a.layers * 4, hipMemcpyDeviceToHost, s));
@@ -726,11 +751,11 @@ extern "C" int hvx_index_delete_batch(hvx_index *ix, const uint64_t *node_ids, u
             HIP_TRY(hipEventSynchronize(ix->del_ev));
             uint32_t most = 0;
             for (uint32_t l = 0; l < a.layers; ++l) most = std::max(most, ix->h_flags[4 + l]);
-            n_steps = std::min(kDelSteps, most);
+            n_steps = std::min(kDelRelCap, most);
         }
         for (uint32_t ri = 0; steps && ri < n_steps; ++ri) { // (a step past a layer's last source returns at once)
-            hipLaunchKernelGGL(kern.own, dim3(a.layers), dim3(1024), step_lds, s, a, ri);
-            hipLaunchKernelGGL(kern.recip, dim3(kDelTop, a.layers), dim3(1024), step_lds, s, a, ri);
+            hipLaunchKernelGGL(kern.own, dim3(a.layers, a.g_own), dim3(kDelWaves * 64u), step_lds, s, a, ri);
+            hipLaunchKernelGGL(kern.recip, dim3(kDelTop * a.g_recip, a.layers), dim3(kDelWaves * 64u), step_lds, s, a, ri);
         }
         hipLaunchKernelGGL(kern.relink, dim3(a.layers), dim3(64), relink_lds, s, a);
         HIP_TRY(hipGetLastError());

@@ -617,6 +617,294 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(256) void de
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// A step as ONE launch (round 6, the default when rows are at most kFuseRow ids wide): the reciprocal rows' matrices do not have to wait
+// for the source's prune -- the neighbours a source can gain are known before it (its closest candidates that its row does not hold: the
+// prune only decides which of them stay), and their rows do not change during the step until their own reciprocal update.  So every
+// workgroup of a layer derives the same task list -- task 0: the source's merged row, task t: "candidate t's row + the source" --, the
+// pairs of ALL tasks are spread over the layer's workgroups (one 8-lane group per pair), and the LAST workgroup to deliver replays the
+// prunes from LDS: wavefront 0 the source's, then sixteen wavefronts the reciprocal rows of the candidates that stayed.  One launch and one
+// ticket per relinked row instead of two launches and up to 33 tickets (37 us per step -> see profiles/r06n_*).
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kFuseWaves = 16;
+constexpr uint32_t kFuseRow = 35;     // ids of a reciprocal prune (row + the source); rows wider than kFuseRow - 1 take the two-launch steps
+constexpr uint32_t kFuseRS = 36;      // ids a reciprocal list has room for in LDS
+// a prune's distances in HBM: the square matrix over [ids..., owner], row i = distances of id i to the others (row nc: the owner's), RW wide
+constexpr uint32_t kFuseOwnRW = 64, kFuseOwnDm = 65 * 64;
+constexpr uint32_t kFuseRecipRW = kFuseRS, kFuseRecipDm = kFuseRS * kFuseRS;
+constexpr uint32_t kFuseLayerDm = kFuseOwnDm + kDelTop * kFuseRecipDm; // floats of one layer's matrices
+
+struct WaveScratch { uint32_t *ord, *kept; };
+struct FuseLds {
+    uint32_t *rcur;       // [kDelTop][kFuseRS] the candidates' rows with the source appended
+    uint32_t *rdeg;       // [kDelTop] ids of that list; 0: the row holds the source already
+    uint32_t *cur, *oldl; // [64] the source's merged row / its row before
+    uint32_t *addl;       // [kDelTop] the candidates the source's row does not hold, Candidate order
+    uint32_t *isnew;      // [kDelTop] ... that stayed after the prune
+    uint32_t *pbase;      // [kDelTop + 2] first pair of every task
+    uint32_t *wsc;        // [16][2][64] per-wavefront replay scratch
+    uint32_t *misc;       // [8]
+};
+__device__ __forceinline__ FuseLds carve_fuse(char *smem) {
+    FuseLds S;
+    char *p = smem;
+    S.rcur = reinterpret_cast<uint32_t *>(p); p += kDelTop * kFuseRS * 4;
+    S.rdeg = reinterpret_cast<uint32_t *>(p); p += kDelTop * 4;
+    S.cur = reinterpret_cast<uint32_t *>(p); p += 256;
+    S.oldl = reinterpret_cast<uint32_t *>(p); p += 256;
+    S.addl = reinterpret_cast<uint32_t *>(p); p += kDelTop * 4;
+    S.isnew = reinterpret_cast<uint32_t *>(p); p += kDelTop * 4;
+    S.pbase = reinterpret_cast<uint32_t *>(p); p += (kDelTop + 2) * 4 + 8;
+    S.wsc = reinterpret_cast<uint32_t *>(p); p += kFuseWaves * 2 * 256;
+    S.misc = reinterpret_cast<uint32_t *>(p);
+    return S;
+}
+static size_t fuse_lds_bytes() {
+    return (size_t)kDelTop * kFuseRS * 4 + kDelTop * 4 * 3 + 512 + (kDelTop + 2) * 4 + 8 + kFuseWaves * 2 * 256 + 64;
+}
+
+// select_diverse + backfill (mod.rs:809-856) over a finished matrix, by ONE wavefront, without LDS: lane c reads ROW c of the matrix
+// (RW floats, device-scope 8-byte loads all in flight: the matrix was written by other workgroups, and this compute unit's L2 may hold
+// the previous step's lines) and its distance to the owner; ids[c] = cur[c].  -> W.kept[0..return).
+//   * Candidate order (score, then id: model.rs:55-61) by lane broadcasts of a 64-bit key (valid scores are non-negative: their bit
+//     patterns order like the numbers; an invalid one aborts the delete as the reference does);
+//   * who would reject whom is decided for all pairs up front from the registers: bit s of conf(c) <=> candidate s is strictly closer to
+//     c than the owner is; the sequential pass over the ranking is then scalar work on two 64-bit masks -- nothing in the dependent
+//     chain touches memory (first builds: an LDS gather + ballot per candidate, 6 - 7 us per prune of 64 ids, 3 us per reciprocal one).
+// Same decisions as testing each candidate against the selected ones when its turn comes: a candidate is rejected iff an EARLIER selected
+// one is strictly closer to it than the owner is (mod.rs:822-842), and the matrix is symmetric bit for bit.
+template <int RW>
+__device__ __forceinline__ uint32_t replay_rows(const float *G, const uint32_t *cur, uint32_t nc, uint32_t maxn, uint32_t lane, const WaveScratch &W, bool *bad) {
+    const unsigned long long *rp = reinterpret_cast<const unsigned long long *>(G + (size_t)(lane < nc ? lane : 0u) * RW);
+    unsigned long long x[RW / 2];
+#pragma unroll
+    for (int u = 0; u < RW / 2; ++u) x[u] = ld_agent(rp + u);
+    const float dmine = lane < nc ? ld_agent(G + (size_t)nc * RW + lane) : 0.f;
+    const uint32_t v = lane < nc ? cur[lane] : kSentinel;
+    float chk = dmine;
+    if (__ballot(lane < nc && !score_valid(chk)) != 0ull) *bad = true;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(dmine + 0.0f) << 32) | v;
+    uint32_t rank = 0;
+    for (uint32_t t = 0; t < nc; ++t) {
+        const unsigned long long kt = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), (int)t) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, (int)t);
+        rank += kt < key ? 1u : 0u;
+    }
+    // lane r <- the candidate ranked r (every lane sends its index to the lane of its rank; lanes past nc keep their own place)
+    const uint32_t my_ord = (uint32_t)__builtin_amdgcn_ds_permute((int)((lane < nc ? rank : lane) << 2), (int)lane);
+    unsigned long long conf = 0ull;
+#pragma unroll
+    for (int u = 0; u < RW / 2; ++u) {
+        const float d0 = __uint_as_float((uint32_t)x[u]), d1 = __uint_as_float((uint32_t)(x[u] >> 32));
+        conf |= (unsigned long long)((d0 < dmine ? 1u : 0u) | (d1 < dmine ? 2u : 0u)) << (2 * u);
+    }
+    conf &= (nc >= 64u ? ~0ull : (1ull << nc) - 1ull) & ~(1ull << lane); // (columns past nc and the diagonal hold no distance)
+    // ... in rank order (lane r holds the r-th candidate's mask)
+    const uint32_t clo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(my_ord << 2), (int)(uint32_t)conf);
+    const uint32_t chi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(my_ord << 2), (int)(uint32_t)(conf >> 32));
+    unsigned long long selm = 0ull, selr = 0ull; // selected candidates by index / by rank
+    uint32_t ns = 0;
+    for (uint32_t r = 0; r < nc && ns < maxn; ++r) {
+        const unsigned long long cm = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)chi, (int)r) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)clo, (int)r);
+        if (cm & selm) continue;
+        selm |= 1ull << (uint32_t)__builtin_amdgcn_readlane((int)my_ord, (int)r);
+        selr |= 1ull << r;
+        ++ns;
+    }
+    // lane r holds the id ranked r; the selected ones go to their slots in selection (= rank) order, then the backfill: the others, closest first
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t rid = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(my_ord << 2), (int)v);
+    const bool mine_sel = ((selr >> lane) & 1ull) != 0ull;
+    if (mine_sel) W.kept[(uint32_t)__builtin_popcountll(selr & lt)] = rid;
+    if (ns < maxn) { // (mod.rs:845-854)
+        const bool free = lane < nc && !mine_sel;
+        const unsigned long long fm = __ballot(free);
+        const uint32_t rk = (uint32_t)__builtin_popcountll(fm & lt);
+        if (free && ns + rk < maxn) W.kept[ns + rk] = rid;
+        const uint32_t add = (uint32_t)__builtin_popcountll(fm);
+        ns = ns + add < maxn ? ns + add : maxn;
+    }
+    lds_order();
+    return ns;
+}
+
+// a staged row (mutation.rs:1299: sorted by id) from ids held one per lane (lane < ns), ranks by lane broadcasts
+__device__ __forceinline__ void store_canonical_reg(uint32_t *row, uint32_t stride, uint32_t mine, uint32_t ns, uint32_t lane) {
+    uint32_t rank = 0;
+    for (uint32_t s = 0; s < ns; ++s) rank += (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)s) < mine ? 1u : 0u;
+    for (uint32_t t = lane; t < stride; t += 64u)
+        if (t >= ns) st_row(row + t, kSentinel);
+    if (lane < ns) st_row(row + rank, mine);
+}
+
+template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(1024) void delete_step_fused_kernel(DeleteArgs a, uint32_t ri) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ uint32_t s_go, s_ncur, s_nadd, s_err, s_last, s_keepn;
+    const DevIndex &ix = a.ix;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    // workgroup -> (layer, share): layer 0 has g_own workgroups, every upper layer g_recip
+    uint32_t L, g, G;
+    if (blockIdx.x < a.g_own) { L = 0u; g = blockIdx.x; G = a.g_own; }
+    else { L = 1u + (blockIdx.x - a.g_own) / a.g_recip; g = (blockIdx.x - a.g_own) % a.g_recip; G = a.g_recip; }
+    const FuseLds S = carve_fuse(smem);
+    if (tid == 0) { s_go = (a.ctl[0] == 0u && ri < a.rel_cnt[L]) ? 1u : 0u; s_err = 0u; }
+    __syncthreads();
+    if (!s_go) return;
+    const uint32_t nb = a.rel[(size_t)L * kDelRelCap + ri];
+    const uint32_t maxn = L == 0u ? a.m0 : a.m;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t stride;
+    uint32_t *row = del_row(a, nb, L, stride);
+    // ---- the tasks (every workgroup of the layer arrives at the same lists) ----
+    if (wave == 0) {
+        const uint32_t v = lane < stride ? ld_row(row + lane) : kSentinel;
+        const uint32_t nold = (uint32_t)__builtin_popcountll(__ballot(v != kSentinel));
+        const uint32_t tn = a.top_cnt[(size_t)L * kDelRelCap + ri];
+        const uint32_t tv = lane < tn ? a.top[((size_t)L * kDelRelCap + ri) * kDelTop + lane] : kSentinel;
+        S.oldl[lane] = v;
+        lds_order();
+        bool in_old = false;
+        for (uint32_t s = 0; s < nold; ++s) in_old |= S.oldl[s] == tv;
+        const bool add = tv != kSentinel && !in_old;
+        const unsigned long long am = __ballot(add);
+        const uint32_t nadd = (uint32_t)__builtin_popcountll(am), ncur = nold + nadd;
+        if (ncur <= 64u) {
+            if (lane < nold) S.cur[lane] = v;
+            if (add) {
+                const uint32_t at = (uint32_t)__builtin_popcountll(am & lt);
+                S.cur[nold + at] = tv;
+                S.addl[at] = tv;
+            }
+        }
+        if (lane == 0) { s_ncur = ncur; s_nadd = nadd; }
+    }
+    __syncthreads();
+    const uint32_t ncur = s_ncur, nadd = s_nadd;
+    if (ncur > 64u) { if (g == 0u && tid == 0) atomicMax(&a.ctl[0], 5u); return; }
+    for (uint32_t t = wave; t < nadd; t += kFuseWaves) { // the candidates' rows, the source appended (mutation.rs:1994-2006)
+        const uint32_t nw = S.addl[t];
+        uint32_t rstride;
+        const uint32_t *rrow = del_row(a, nw, L, rstride);
+        uint32_t rv = lane < rstride ? ld_row(rrow + lane) : kSentinel;
+        uint32_t rdeg = (uint32_t)__builtin_popcountll(__ballot(rv != kSentinel));
+        const bool has = __ballot(rv == nb) != 0ull;
+        if (has) {
+            rdeg = 0u;
+        } else if (rdeg + 1u > kFuseRow) {
+            if (lane == 0) s_err = 1u;
+            rdeg = 0u;
+        } else {
+            if (lane == rdeg) rv = nb;
+            ++rdeg;
+            if (lane < rdeg) S.rcur[t * kFuseRS + lane] = rv;
+        }
+        if (lane == 0) S.rdeg[t] = rdeg;
+    }
+    __syncthreads();
+    if (s_err) { if (g == 0u && tid == 0) atomicMax(&a.ctl[0], 5u); return; }
+    if (wave == 0) { // first pair of every task: 0 the source's prune, 1 + t candidate t's (a list within its limit needs no matrix)
+        const uint32_t n0 = ncur > maxn ? (ncur + 1u) * ncur / 2u : 0u;
+        const uint32_t rd = lane < nadd ? S.rdeg[lane] : 0u;
+        const uint32_t np = rd > maxn ? (rd + 1u) * rd / 2u : 0u;
+        uint32_t incl = np;
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const uint32_t o = __shfl_up(incl, sft, 64);
+            if ((int)lane >= sft) incl += o;
+        }
+        if (lane == 0) S.pbase[0] = 0u;
+        if (lane < kDelTop) S.pbase[1u + lane] = n0 + incl - np;
+        if (lane == kDelTop - 1u) S.pbase[kDelTop + 1u] = n0 + incl;
+    }
+    __syncthreads();
+    const uint32_t total = S.pbase[kDelTop + 1u];
+    float *gl = a.gdm + (size_t)L * kFuseLayerDm;
+    bool last = true;
+    if (total != 0u) {
+        const int j = (int)(lane & 7u);
+        for (uint32_t p = g * (kFuseWaves * 8u) + (tid >> 3); p < total; p += G * (kFuseWaves * 8u)) {
+            uint32_t lo = 0u, hi = nadd + 1u; // the task t with pbase[t] <= p < pbase[t + 1]
+            while (hi - lo > 1u) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (S.pbase[mid] <= p) lo = mid; else hi = mid;
+            }
+            const uint32_t t = lo, q = p - S.pbase[t];
+            // q = i (i - 1) / 2 + jj, 0 <= jj < i <= nc
+            uint32_t i = (uint32_t)((1.0f + sqrtf(1.0f + 8.0f * (float)q)) * 0.5f);
+            while (i * (i - 1u) / 2u > q) --i;
+            while ((i + 1u) * i / 2u <= q) ++i;
+            const uint32_t jj = q - i * (i - 1u) / 2u;
+            uint32_t node_i, node_j, nc, st;
+            float *out;
+            if (t == 0u) {
+                nc = ncur; st = kFuseOwnRW; out = gl;
+                node_i = i < nc ? S.cur[i] : nb; node_j = S.cur[jj];
+            } else {
+                const uint32_t *rc = S.rcur + (t - 1u) * kFuseRS;
+                nc = S.rdeg[t - 1u]; st = kFuseRecipRW; out = gl + kFuseOwnDm + (size_t)(t - 1u) * kFuseRecipDm;
+                node_i = i < nc ? rc[i] : S.addl[t - 1u]; node_j = rc[jj];
+            }
+            const float d = group_distance<METRIC, FUSED>(ix, ix.vec + (size_t)node_i * ix.ld, ix.hdr[node_i], node_j, j);
+            if (j == 0) {
+                st_agent(out + i * st + jj, d);
+                if (i < nc) st_agent(out + jj * st + i, d);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the stores have been acknowledged before the ticket is taken
+        __syncthreads();
+        if (tid == 0) s_last = __hip_atomic_fetch_add(a.tick + L, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == G ? 1u : 0u;
+        __syncthreads();
+        last = s_last != 0u;
+        if (last && tid == 0) st_agent(a.tick + L, 0u); // (the next launch starts from zero)
+    } else {
+        last = g == 0u;
+    }
+    if (!last) return;
+    // ---- the last workgroup.  The reciprocal prunes do not depend on the source's (only whether they are APPLIED does): wavefront 0
+    // replays the source's prune while wavefronts 1 .. 15 replay the candidates' lists, then the rows of the candidates that stayed go out
+    bool bad = false;
+    const WaveScratch W{S.wsc + wave * 128u, S.wsc + wave * 128u + 64u};
+    const uint32_t first = wave - 1u; // (wavefront 0: none)
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t keepn = ncur;
+        if (ncur > maxn) keepn = replay_rows<(int)kFuseOwnRW>(gl, S.cur, ncur, maxn, lane, W, &bad);
+        else { if (lane < ncur) W.kept[lane] = S.cur[lane]; lds_order(); }
+        const uint32_t kf = lane < keepn ? W.kept[lane] : kSentinel;
+        const uint32_t at = lane < nadd ? S.addl[lane] : kSentinel;
+        bool stays = false;
+        for (uint32_t s = 0; s < keepn; ++s) stays |= (uint32_t)__builtin_amdgcn_readlane((int)kf, (int)s) == at;
+        if (lane < kDelTop) S.isnew[lane] = (lane < nadd && stays) ? 1u : 0u;
+        if (keepn > stride) { if (lane == 0) atomicMax(&a.ctl[0], 5u); keepn = kSentinel; }
+        else store_canonical_reg(row, stride, kf, keepn, lane);
+        if (lane == 0) { s_keepn = keepn; if (bad) atomicMax(&a.ctl[0], 4u); }
+    } else {
+        for (uint32_t t = first; t < nadd; t += kFuseWaves - 1u) {
+            const uint32_t rdeg = S.rdeg[t];
+            if (rdeg == 0u) continue;
+            uint32_t *rc = S.rcur + t * kFuseRS;
+            if (rdeg > maxn) {
+                bool rbad = false;
+                const uint32_t kn = replay_rows<(int)kFuseRecipRW>(gl + kFuseOwnDm + (size_t)t * kFuseRecipDm, rc, rdeg, maxn, lane, W, &rbad);
+                if (lane < kn) rc[lane] = W.kept[lane]; // the list is replaced by what stays of it
+                if (lane == 0) { S.rdeg[t] = kn; if (rbad) atomicMax(&a.ctl[0], 4u); }
+                lds_order();
+            }
+        }
+    }
+    __syncthreads();
+    if (s_keepn == kSentinel) return;
+    // the reciprocal row of every neighbour the source has gained (mutation.rs:1994-2052)
+    for (uint32_t t = wave; t < nadd; t += kFuseWaves) {
+        const uint32_t kn = S.rdeg[t];
+        if (!S.isnew[t] || kn == 0u) continue;
+        uint32_t rstride;
+        uint32_t *rrow = del_row(a, S.addl[t], L, rstride);
+        if (kn <= rstride) store_canonical_reg(rrow, rstride, lane < kn ? S.rcur[t * kFuseRS + lane] : kSentinel, kn, lane);
+        else if (lane == 0) atomicMax(&a.ctl[0], 5u);
+    }
+}
+
 // find_best_entry_candidate (mutation.rs:350-394): the live node on the highest layer, smallest id first
 __global__ __launch_bounds__(256) void delete_best_entry_kernel(DevIndex ix, const uint32_t *dead, unsigned long long *out) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -632,9 +920,10 @@ __global__ __launch_bounds__(256) void delete_best_entry_kernel(DevIndex ix, con
 
 using DeleteKernel = void (*)(DeleteArgs);
 using DeleteStepKernel = void (*)(DeleteArgs, uint32_t);
-struct DeleteKernels { DeleteKernel rank, relink; DeleteStepKernel own, recip; };
+struct DeleteKernels { DeleteKernel rank, relink; DeleteStepKernel own, recip, fused; };
 template <uint32_t METRIC, bool FUSED> static DeleteKernels delete_kernels_of() {
-    return {delete_rank_kernel<METRIC, FUSED>, delete_relink_kernel<METRIC, FUSED>, delete_step_own_kernel<METRIC, FUSED>, delete_step_recip_kernel<METRIC, FUSED>};
+    return {delete_rank_kernel<METRIC, FUSED>, delete_relink_kernel<METRIC, FUSED>, delete_step_own_kernel<METRIC, FUSED>, delete_step_recip_kernel<METRIC, FUSED>,
+            delete_step_fused_kernel<METRIC, FUSED>};
 }
 static DeleteKernels pick_delete_kernels(uint32_t metric, bool fused) {
     if (metric == kL2) return fused ? delete_kernels_of<kL2, true>() : delete_kernels_of<kL2, false>();
@@ -710,11 +999,22 @@ extern "C" int hvx_index_delete_batch(hvx_index *ix, const uint64_t *node_ids, u
     if (relink_lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kern.relink, hipFuncAttributeMaxDynamicSharedMemorySize, (int)relink_lds));
     const size_t step_lds = step_lds_bytes();
     const bool steps = ix->opt[HVX_OPT_DELETE_SEQUENTIAL] != 1u;
-    // workgroups (32 row groups each) that share one prune's distance matrix: about one pair per row group.  A source's row grows to at
-    // most 64 ids (65 x 64 / 2 pairs), a reciprocal row to Mmax + 1
+    // one launch per step while a reciprocal list (row + the source) fits the fused kernel's LDS matrices; HVX_OPT_DELETE_SEQUENTIAL = 2
+    // keeps the two-launch steps (A/B, and what wider rows take)
+    const bool fused_steps = steps && ix->opt[HVX_OPT_DELETE_SEQUENTIAL] != 2u && d.s0 + 1u <= kFuseRow && d.su + 1u <= kFuseRow;
     const uint32_t groups = kDelWaves * 8u;
-    a.g_own = (65u * 64u / 2u + groups - 1u) / groups;
-    a.g_recip = ((m0 + 2u) * (m0 + 1u) / 2u + groups - 1u) / groups;
+    if (fused_steps) {
+        // workgroups (128 row groups each) of layer 0 / of every upper layer: a typical step has ~8 000 pairs on layer 0 (the source's
+        // <= 2 080 and ~10 reciprocal lists of 561), at most 20 032
+        a.g_own = 96u;
+        a.g_recip = 12u;
+        HIP_TRY(hipFuncSetAttribute((const void *)kern.fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fuse_lds_bytes()));
+    } else {
+        // workgroups (32 row groups each) that share one prune's distance matrix: about one pair per row group.  A source's row grows to
+        // at most 64 ids (65 x 64 / 2 pairs), a reciprocal row to Mmax + 1
+        a.g_own = (65u * 64u / 2u + groups - 1u) / groups;
+        a.g_recip = ((m0 + 2u) * (m0 + 1u) / 2u + groups - 1u) / groups;
+    }
     a.first = steps ? kDelRelCap : 0u; // every source runs as a step (their number is read back below); the one-wavefront kernel only retires the node
     // this generation's deleted-row flags: a copy of the visible ones (forks keep theirs until hvx_index_refresh)
     auto flags = std::make_shared<std::vector<uint8_t>>((size_t)cap, (uint8_t)0);
@@ -754,6 +1054,10 @@ extern "C" int hvx_index_delete_batch(hvx_index *ix, const uint64_t *node_ids, u
             n_steps = std::min(kDelRelCap, most);
         }
         for (uint32_t ri = 0; steps && ri < n_steps; ++ri) { // (a step past a layer's last source returns at once)
+            if (fused_steps) {
+                hipLaunchKernelGGL(kern.fused, dim3(a.g_own + (a.layers - 1u) * a.g_recip), dim3(kFuseWaves * 64u), fuse_lds_bytes(), s, a, ri);
+                continue;
+            }
             hipLaunchKernelGGL(kern.own, dim3(a.layers, a.g_own), dim3(kDelWaves * 64u), step_lds, s, a, ri);
             hipLaunchKernelGGL(kern.recip, dim3(kDelTop * a.g_recip, a.layers), dim3(kDelWaves * 64u), step_lds, s, a, ri);
         }

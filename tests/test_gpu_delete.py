@@ -55,14 +55,16 @@ def assert_same_graph(gix, oix, ids, deleted):
 
 @pytest.mark.parametrize("n,dim,metric,m,m0,efc,kern,relink", [(1600, 128, 1, 16, 32, 100, "avx_fma", "steps"), (1200, 256, 0, 16, 32, 80, "avx_fma", "steps"),
                                                                (1000, 72, 2, 8, 16, 60, "avx_fma", "steps"), (1200, 768, 1, 16, 32, 100, "avx_fma", "steps"),
-                                                               (900, 88, 1, 8, 16, 60, "neon", "one_wavefront")])
+                                                               (900, 88, 1, 8, 16, 60, "neon", "one_wavefront"),
+                                                               (1100, 128, 0, 16, 32, 80, "avx_fma", "two_launch_steps")])
 def test_sequential_deletes_equal_the_oracles_row_for_row(orc, hv, n, dim, metric, m, m0, efc, kern, relink):
     """VectorIndex::delete one node at a time (mutation.rs:1606-1774): after three batches of deletes (scattered ids, the entry point
     twice, ids that are unknown, an id twice in one batch) every layer-0 row, every upper row, the entry point and the top layer of
     the live nodes equal the oracle's; deleted ids are gone from the HNSW searches (strict + the production default arm), the exact
     scan, restricted candidate sets and hvx_index_contains; the statistics count what happened; a fork adopts the owner's generation at its next launch
-    (in-place rewrites cannot be hidden from it); rows appended AFTER the deletes link exactly as the oracle's do.  Both relink paths of the device (per-source
-    steps with the eager distance matrix; the one-wavefront kernel with the lazy select_diverse) produce the same rows."""
+    (in-place rewrites cannot be hidden from it); rows appended AFTER the deletes link exactly as the oracle's do.  Every relink path of the device (one fused launch per
+    source with all its prunes' distance matrices evaluated up front; two launches per source; the one-wavefront kernel with the lazy
+    select_diverse) produces the same rows."""
     ok, hk = {"avx_fma": (orc.K_AVX_FMA, hv.KERNEL_AVX_FMA), "neon": (orc.K_NEON, hv.KERNEL_NEON)}[kern]
     rng = np.random.default_rng(4200 + dim + metric + n)
     n_all = n + 120
@@ -78,6 +80,8 @@ def test_sequential_deletes_equal_the_oracles_row_for_row(orc, hv, n, dim, metri
     assert_same_graph(gix, oix, ids[:n], ())
     if relink == "one_wavefront":
         gix.set_option(hv.OPT_DELETE_SEQUENTIAL, 1)
+    elif relink == "two_launch_steps":   # the steps rows wider than 34 ids take (default: one fused launch per relinked row)
+        gix.set_option(hv.OPT_DELETE_SEQUENTIAL, 2)
     gix.set_simhash()
     lane = gix.fork()
     seq0 = gix.visible_seq()

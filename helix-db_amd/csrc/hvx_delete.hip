@@ -198,8 +198,62 @@ __global__ __launch_bounds__(256) void delete_prep_kernel(DeleteArgs a) {
     }
 }
 
+// distance between two RESIDENT rows, one 8-lane group, in the reference's summation order.  f32 images: the first row is the "query"
+// of group_distance, read in place.  bf16 images (round 6; dim % 64 == 0, AVX+FMA tree, L2 / cosine -- what the import accepts): both rows
+// are decoded from the interleaved layout piece by piece -- the values are exact f32 numbers and the arithmetic and its order are those
+// of group_distance_bf16 (hvx_device.h), so the distance equals the reference's on the rounded vectors bit for bit.
+template <uint32_t METRIC, bool FUSED, bool BF>
+__device__ __forceinline__ float pair_distance(const DevIndex &ix, uint32_t ni, uint32_t nj, int j) {
+    if constexpr (!BF) {
+        return group_distance<METRIC, FUSED>(ix, ix.vec + (size_t)ni * ix.ld, ix.hdr[ni], nj, j);
+    } else {
+        const int slot = chunk_slot(j);
+        const uint16_t *qb = ix.vecb + (size_t)ni * ix.dim, *rb = ix.vecb + (size_t)nj * ix.dim;
+        const float4 *qp = reinterpret_cast<const float4 *>(qb) + slot; // one 16-byte piece = this lane's virtual lanes of TWO chunks
+        const float4 *rp = reinterpret_cast<const float4 *>(rb) + slot;
+        const uint32_t np = ix.dim >> 6;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto step = [&](const float4 qw, const float4 xw) __attribute__((always_inline)) {
+            const uint32_t q0 = __float_as_uint(qw.x), q1 = __float_as_uint(qw.y), q2 = __float_as_uint(qw.z), q3 = __float_as_uint(qw.w);
+            const uint32_t w0 = __float_as_uint(xw.x), w1 = __float_as_uint(xw.y), w2 = __float_as_uint(xw.z), w3 = __float_as_uint(xw.w);
+            const float qa0 = __uint_as_float(q0 << 16), qa1 = __uint_as_float(q0 & 0xFFFF0000u), qa2 = __uint_as_float(q1 << 16), qa3 = __uint_as_float(q1 & 0xFFFF0000u);
+            const float qb0 = __uint_as_float(q2 << 16), qb1 = __uint_as_float(q2 & 0xFFFF0000u), qb2 = __uint_as_float(q3 << 16), qb3 = __uint_as_float(q3 & 0xFFFF0000u);
+            const float a0 = __uint_as_float(w0 << 16), a1 = __uint_as_float(w0 & 0xFFFF0000u), a2 = __uint_as_float(w1 << 16), a3 = __uint_as_float(w1 & 0xFFFF0000u);
+            const float b0 = __uint_as_float(w2 << 16), b1 = __uint_as_float(w2 & 0xFFFF0000u), b2 = __uint_as_float(w3 << 16), b3 = __uint_as_float(w3 & 0xFFFF0000u);
+            if (METRIC == kL2) {
+                float d0 = qa0 - a0, d1 = qa1 - a1, d2 = qa2 - a2, d3 = qa3 - a3;
+                acc.x = __builtin_fmaf(d0, d0, acc.x); acc.y = __builtin_fmaf(d1, d1, acc.y);
+                acc.z = __builtin_fmaf(d2, d2, acc.z); acc.w = __builtin_fmaf(d3, d3, acc.w);
+                d0 = qb0 - b0; d1 = qb1 - b1; d2 = qb2 - b2; d3 = qb3 - b3;
+                acc.x = __builtin_fmaf(d0, d0, acc.x); acc.y = __builtin_fmaf(d1, d1, acc.y);
+                acc.z = __builtin_fmaf(d2, d2, acc.z); acc.w = __builtin_fmaf(d3, d3, acc.w);
+            } else {
+                acc.x = __builtin_fmaf(qa0, a0, acc.x); acc.y = __builtin_fmaf(qa1, a1, acc.y);
+                acc.z = __builtin_fmaf(qa2, a2, acc.z); acc.w = __builtin_fmaf(qa3, a3, acc.w);
+                acc.x = __builtin_fmaf(qb0, b0, acc.x); acc.y = __builtin_fmaf(qb1, b1, acc.y);
+                acc.z = __builtin_fmaf(qb2, b2, acc.z); acc.w = __builtin_fmaf(qb3, b3, acc.w);
+            }
+        };
+        uint32_t m = 0;
+        for (; m + 6u <= np; m += 6u) { // twelve independent 16-byte loads in flight per lane before the first use
+            float4 q[6], x[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) { q[u] = qp[(size_t)(m + u) * 8]; x[u] = rp[(size_t)(m + u) * 8]; }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) step(q[u], x[u]);
+        }
+        for (; m < np; ++m) step(qp[(size_t)m * 8], rp[(size_t)m * 8]);
+        float r = avx_tree_reduce(acc);
+        if (METRIC == kCosine)
+            r = cosine_finish_fn(r, ix.hdr[ni], ix.hdr[nj], [&]() {
+                return stable_half_cosine_fn(ix.dim, [&](uint32_t i) { return bf16_to_f32(qb[bf16_slot_of(i)]); }, [&](uint32_t i) { return bf16_to_f32(rb[bf16_slot_of(i)]); });
+            });
+        return r;
+    }
+}
+
 // relink_neighbor's ranking (mutation.rs:1936-1957) for every source of every layer: distances to all candidates, the Mmax smallest
-template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(256) void delete_rank_kernel(DeleteArgs a) {
+template <uint32_t METRIC, bool FUSED, bool BF> __global__ __launch_bounds__(256) void delete_rank_kernel(DeleteArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ unsigned long long red[4];
     __shared__ uint32_t s_bad;
@@ -218,7 +272,10 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(256) void de
     for (uint32_t ri = blockIdx.x; ri < nr; ri += gridDim.x) {
         const uint32_t r = a.rel[(size_t)L * kDelRelCap + ri];
         __syncthreads();
-        {
+        if constexpr (BF) { // the source's row as f32, element order
+            const uint16_t *rb = ix.vecb + (size_t)r * ix.dim;
+            for (uint32_t t = tid; t < ix.dim; t += 256u) qv[t] = bf16_to_f32(rb[bf16_slot_of(t)]);
+        } else {
             const float *rv = ix.vec + (size_t)r * ix.ld;
             for (uint32_t t = tid; t < ix.ld; t += 256u) qv[t] = rv[t];
         }
@@ -228,7 +285,9 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(256) void de
         for (uint32_t c0 = 0; c0 < nc; c0 += 32u) {
             const uint32_t idx = c0 + wave * 8u + (uint32_t)grp;
             const uint32_t c = cand[idx < nc ? idx : nc - 1u];
-            float d = group_distance<METRIC, FUSED>(ix, qv, rh, c, j);
+            float d;
+            if constexpr (BF) d = group_distance_bf16<METRIC == kL1 ? kL2 : METRIC>(ix, qv, rh, c, j);
+            else d = group_distance<METRIC, FUSED>(ix, qv, rh, c, j);
             if (idx < nc && j == 0) {
                 uint32_t bits = kDelMark; // (the source itself is no candidate of its own relink: :1937-1939)
                 if (c != r) {
@@ -737,7 +796,7 @@ __device__ __forceinline__ void store_canonical_reg(uint32_t *row, uint32_t stri
     if (lane < ns) st_row(row + rank, mine);
 }
 
-template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(1024) void delete_step_fused_kernel(DeleteArgs a, uint32_t ri) {
+template <uint32_t METRIC, bool FUSED, bool BF> __global__ __launch_bounds__(1024) void delete_step_fused_kernel(DeleteArgs a, uint32_t ri) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t s_go, s_ncur, s_nadd, s_err, s_last, s_keepn;
     const DevIndex &ix = a.ix;
@@ -844,7 +903,7 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(1024) void d
                 nc = S.rdeg[t - 1u]; st = kFuseRecipRW; out = gl + kFuseOwnDm + (size_t)(t - 1u) * kFuseRecipDm;
                 node_i = i < nc ? rc[i] : S.addl[t - 1u]; node_j = rc[jj];
             }
-            const float d = group_distance<METRIC, FUSED>(ix, ix.vec + (size_t)node_i * ix.ld, ix.hdr[node_i], node_j, j);
+            const float d = pair_distance<METRIC, FUSED, BF>(ix, node_i, node_j, j);
             if (j == 0) {
                 st_agent(out + i * st + jj, d);
                 if (i < nc) st_agent(out + jj * st + i, d);
@@ -922,10 +981,15 @@ using DeleteKernel = void (*)(DeleteArgs);
 using DeleteStepKernel = void (*)(DeleteArgs, uint32_t);
 struct DeleteKernels { DeleteKernel rank, relink; DeleteStepKernel own, recip, fused; };
 template <uint32_t METRIC, bool FUSED> static DeleteKernels delete_kernels_of() {
-    return {delete_rank_kernel<METRIC, FUSED>, delete_relink_kernel<METRIC, FUSED>, delete_step_own_kernel<METRIC, FUSED>, delete_step_recip_kernel<METRIC, FUSED>,
-            delete_step_fused_kernel<METRIC, FUSED>};
+    return {delete_rank_kernel<METRIC, FUSED, false>, delete_relink_kernel<METRIC, FUSED>, delete_step_own_kernel<METRIC, FUSED>, delete_step_recip_kernel<METRIC, FUSED>,
+            delete_step_fused_kernel<METRIC, FUSED, false>};
 }
-static DeleteKernels pick_delete_kernels(uint32_t metric, bool fused) {
+// bf16 images: the ranking and the fused steps read the interleaved rows (the one-wavefront kernel only retires the node there)
+template <uint32_t METRIC> static DeleteKernels delete_kernels_bf16() {
+    return {delete_rank_kernel<METRIC, true, true>, delete_relink_kernel<METRIC, true>, nullptr, nullptr, delete_step_fused_kernel<METRIC, true, true>};
+}
+static DeleteKernels pick_delete_kernels(uint32_t metric, bool fused, bool bf16) {
+    if (bf16) return metric == kL2 ? delete_kernels_bf16<kL2>() : delete_kernels_bf16<kCosine>();
     if (metric == kL2) return fused ? delete_kernels_of<kL2, true>() : delete_kernels_of<kL2, false>();
     if (metric == kCosine) return fused ? delete_kernels_of<kCosine, true>() : delete_kernels_of<kCosine, false>();
     return fused ? delete_kernels_of<kL1, true>() : delete_kernels_of<kL1, false>();
@@ -942,7 +1006,9 @@ extern "C" int hvx_index_delete_batch(hvx_index *ix, const uint64_t *node_ids, u
     std::lock_guard<std::mutex> lock(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));
     DevIndex &d = ix->dev;
-    if (d.dtype != HVX_F32) return fail(HVX_ERR_UNSUPPORTED, "nodes are deleted from f32 images (import the changed graph with a reduced-precision dtype afterwards)");
+    if (d.dtype != HVX_F32 && d.dtype != HVX_BF16)
+        return fail(HVX_ERR_UNSUPPORTED, "nodes are deleted from f32 and bf16 images (fp8 rows: import the changed graph afterwards)");
+    const bool bf16 = d.dtype == HVX_BF16;
     const uint32_t m = ix->desc.m ? ix->desc.m : 16u;
     const uint32_t m0 = std::max(ix->desc.m0 ? ix->desc.m0 : 2u * m, 2u * m);
     if (m0 > kDelTop || m > kDelTop || d.s0 > 64u || d.su > 64u || d.s0 < m0 || d.su < m)
@@ -992,7 +1058,7 @@ extern "C" int hvx_index_delete_batch(hvx_index *ix, const uint64_t *node_ids, u
     a.m = m; a.m0 = m0; a.words = words;
     a.dead = ix->d_dead;
     HIP_TRY(hipMemsetAsync(a.ctl, 0, 16, s));
-    const DeleteKernels kern = pick_delete_kernels(d.metric, kernel_fused(d.fkernel));
+    const DeleteKernels kern = pick_delete_kernels(d.metric, kernel_fused(d.fkernel), bf16);
     const size_t rank_lds = (((size_t)d.ld * 4u + 15u) & ~(size_t)15u) + (size_t)kDelCandCap * 4u;
     const size_t relink_lds = (((size_t)d.ld * 4u + 15u) & ~(size_t)15u) + 4 * 256 + 256;
     if (rank_lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kern.rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_lds));
@@ -1002,6 +1068,8 @@ extern "C" int hvx_index_delete_batch(hvx_index *ix, const uint64_t *node_ids, u
     // one launch per step while a reciprocal list (row + the source) fits the fused kernel's LDS matrices; HVX_OPT_DELETE_SEQUENTIAL = 2
     // keeps the two-launch steps (A/B, and what wider rows take)
     const bool fused_steps = steps && ix->opt[HVX_OPT_DELETE_SEQUENTIAL] != 2u && d.s0 + 1u <= kFuseRow && d.su + 1u <= kFuseRow;
+    if (bf16 && !fused_steps)
+        return fail(HVX_ERR_UNSUPPORTED, "a bf16 image relinks by fused steps only (rows of at most %u ids, HVX_OPT_DELETE_SEQUENTIAL unset)", kFuseRow - 1u);
     const uint32_t groups = kDelWaves * 8u;
     if (fused_steps) {
         // workgroups (128 row groups each) of layer 0 / of every upper layer: a typical step has ~8 000 pairs on layer 0 (the source's

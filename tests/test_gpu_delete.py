@@ -309,3 +309,72 @@ def test_an_upsert_into_a_slot_refreshes_the_caches_of_the_matrix_core_scan(orc,
         rc, oid, osc = orc.flat_matrix(orc.L2SQ, rows, q[qi], 10, kernel=orc.K_AVX_FMA_HW)
         assert rc == orc.OK and fid[qi, :fcnt[qi]].tolist() == (oid.astype(np.int64) + 1).tolist() and bits(fsc[qi, :fcnt[qi]]).tolist() == bits(osc).tolist()
     assert fid[:4, 0].tolist() == ids[rows_at].tolist() and (fsc[:4, 0] == 0).all()
+
+
+@pytest.mark.parametrize("n,dim,metric", [(1400, 128, 1), (1000, 256, 0), (700, 768, 1)])
+def test_deletes_on_a_bf16_image_equal_the_oracle_on_the_rounded_rows(orc, hv, n, dim, metric):
+    """BASELINE config #4's storage (rows rounded to bf16 once at import, interleaved device layout): hvx_index_delete_batch relinks on
+    the resident bf16 rows -- the ranking and every prune's distance matrix in f32 on the rounded values, in the reference's summation
+    order -- so rows, entry point and top layer equal the oracle's deletes on the ROUNDED vectors after two batches (scattered ids and
+    the entry point); the searches (strict arm + production default), the exact scan and a restricted scan equal the oracle's bit for
+    bit afterwards.  Paths that read f32 rows refuse a bf16 image loudly (one-wavefront relinks, two-launch steps, inserts, upserts)."""
+    rng = np.random.default_rng(9100 + dim + metric)
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    rounded = fx.round_bf16(data)
+    lv = fx.draw_levels(n, 16, seed=n + dim)
+    ids = np.arange(n, dtype=np.uint64) * 3 + 7
+    oix = orc.Index(dim, metric, kernel=orc.K_AVX_FMA, m=16, m0=32, ef_construction=80)
+    for i in range(n):
+        assert oix.insert(int(ids[i]), rounded[i], int(lv[i])) == orc.OK
+    ex = oix.export()
+    assert ex["node_ids"].tolist() == ids.tolist()
+    ex["vectors"] = data                                                       # the device does the rounding
+    gix = hv.ValidatedVectorReadIndex.from_export(ex, dim=dim, metric=metric, dtype=hv.BF16, m=16, m0=32)
+    assert_same_graph(gix, oix, ids, ())
+    gix.set_simhash()
+    perm = rng.permutation(n)
+    deleted = []
+    for bi, b in enumerate([perm[: n // 16], perm[n // 16: n // 6]]):
+        want = [int(x) for x in ids[b] if int(x) not in deleted]
+        ent = oix.entry()[0]
+        if ent not in want and ent not in deleted:
+            want.insert(len(want) // 3, ent)
+        moves = 0
+        for d in want:
+            moves += int(oix.entry() is not None and oix.entry()[0] == d)
+            assert oix.delete(d) == (orc.OK, True)
+        stb = gix.delete_batch(np.asarray(want + [10 ** 12 + bi], np.uint64))
+        deleted += want
+        assert stb["deleted"] == len(want) and stb["missing"] == 1 and stb["entry_moves"] == moves and stb["relinked_rows"] > 0
+        assert gix.live_rows() == n - len(deleted) == oix.count
+        assert_same_graph(gix, oix, ids, deleted)
+    dset = set(deleted)
+    oix.set_simhash(42)
+    q = np.vstack([rng.standard_normal((16, dim)).astype(np.float32), data[[int(x) for x in perm[:4]]]])
+    gid, gsc, gcnt, _ = gix.search_batch(q, hv.SearchParams(10).with_ef(64))
+    pid, psc, pcnt, _ = gix.search_batch(q, hv.SearchParams.new(10))
+    fid, fsc, fcnt, _ = gix.flat_search_batch(q, 10)
+    allowed = np.asarray(sorted(set(int(x) for x in ids[rng.permutation(n)[: n // 3]]) | set(deleted[:20])), np.uint64)
+    rid, rsc, rcnt = gix.search_restricted_batch(q, hv.SearchParams(10), hv.RestrictedVectorCandidates.from_ids(allowed))
+    op = orc.SearchParams.new(10)
+    for qi in range(q.shape[0]):
+        rc, oid, osc = oix.search(q[qi], 10, 64)
+        assert gid[qi, :gcnt[qi]].tolist() == oid.tolist() and bits(gsc[qi, :gcnt[qi]]).tolist() == bits(osc).tolist()
+        rc, oid, osc = oix.search_params(q[qi], op)
+        assert pid[qi, :pcnt[qi]].tolist() == oid.tolist() and bits(psc[qi, :pcnt[qi]]).tolist() == bits(osc).tolist()
+        rc, tid, tsc = oix.flat(q[qi], 10)
+        assert fid[qi, :fcnt[qi]].tolist() == tid.tolist() and bits(fsc[qi, :fcnt[qi]]).tolist() == bits(tsc).tolist()
+        rc, tid, tsc = oix.flat(q[qi], 10, allowed=allowed)
+        assert rid[qi, :rcnt[qi]].tolist() == tid.tolist() and bits(rsc[qi, :rcnt[qi]]).tolist() == bits(tsc).tolist()
+        assert not (set(gid[qi, :gcnt[qi]].tolist()) | set(fid[qi, :fcnt[qi]].tolist()) | set(rid[qi, :rcnt[qi]].tolist())) & dset
+    live = [int(x) for x in ids if int(x) not in dset]
+    for opt in (1, 2):                                                         # the relink paths that read f32 rows
+        gix.set_option(hv.OPT_DELETE_SEQUENTIAL, opt)
+        with pytest.raises(hv.HelixDbError):
+            gix.delete_batch(np.asarray(live[:1], np.uint64))
+    gix.set_option(hv.OPT_DELETE_SEQUENTIAL, 0)
+    assert gix.live_rows() == n - len(deleted)                                 # ... refused before anything changed
+    with pytest.raises(hv.HelixDbError):
+        gix.upsert_batch(np.asarray(live[:1], np.uint64), data[:1], ef_construction=80)
+    assert_same_graph(gix, oix, ids, deleted)
+    gix.close()

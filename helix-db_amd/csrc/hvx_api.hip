@@ -103,6 +103,8 @@ static void free_index(hvx_index *ix) {
     if (ix->ev0) (void)hipEventDestroy(ix->ev0);
     if (ix->ev1) (void)hipEventDestroy(ix->ev1);
     if (ix->del_ev) (void)hipEventDestroy(ix->del_ev);
+    for (hipEvent_t e : ix->ins_ev) if (e) (void)hipEventDestroy(e);
+    if (ix->ins_stream) (void)hipStreamDestroy(ix->ins_stream);
     for (hipEvent_t e : ix->ring) (void)hipEventDestroy(e);
     if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
     if (ix->h_pin) (void)hipHostFree(ix->h_pin);

@@ -67,6 +67,9 @@ struct BuildArgs {
     uint32_t ldp, ncmax;        // build_link_wg_kernel: row stride of a column block in LDS (floats), candidate rows the LDS holds
     uint32_t link_ck;           // 32-float chunks per column block
     uint32_t *dbg;              // tuning builds (HVX_BUILD_DEBUG): [0] lock spins [1] prunes [2] reverse-edge removals [3] plain appends
+    float *gdm;                 // one-node steps: [layers][kSeqLayerDm] distance matrices (device-scope stores / loads)
+    uint32_t *tick;             // ... [2][layers] workgroups that have delivered (zero between launches)
+    uint32_t g0, gu;            // ... workgroups of layer 0 / of every upper layer
 };
 
 __device__ __forceinline__ void lock_row(uint32_t *locks, uint32_t node, int lane) {
@@ -208,6 +211,282 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(64) void bui
                 remove_edge_dev(a, (uint32_t)layer, x, to, lane);
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// ONE node at a time (sequential mode = the reference's order exactly; every upsert; promotions): round 6.  build_select_kernel and
+// build_link_kernel evaluate select_diverse lazily on one wavefront -- a chain of dependent row gathers per candidate: 0.33 ms + 2.0 ms of
+// a 2.9-ms insert at 600 000 x 768 (profiles/r06o_seq_insert_kernel_stats.csv).  The two kernels below evaluate the distance matrices of
+// ALL prunes of a step up front, spread over the layer's workgroups (one 8-lane group per pair, reference summation order), and the last
+// workgroup to deliver replays the decisions from registers (hvx_graph_dev.h: replay_rows) -- as the delete steps do (hvx_delete.hip):
+//   build_select_seq_kernel   the node's own lists: <= 64 search candidates per layer, 2 016 pairs, one replay per layer;
+//   build_link_seq_kernel     add_bidirectional_link for its <= 32 selected neighbours per layer IN SELECTION ORDER.  A link reads the
+//                             neighbour's row as earlier links of the same node left it -- and the only thing an earlier link can do to it
+//                             is REMOVE an id (a neighbour its prune dropped loses the reverse edge).  So: every link's list (row + the
+//                             node) and its matrix are taken from the rows as the kernel finds them -- a superset of what the link will
+//                             see --, sixteen wavefronts replay the links speculatively in parallel, and one wavefront then walks them in
+//                             order: a link whose row an earlier link has touched is replayed again over the ids that are still there
+//                             (replay_rows' `alive` mask), everything else stands.  The removals (row of the dropped id loses the
+//                             neighbour) go out last, all victims of a row at once.
+// Same distances, same comparisons, same order of decisions as the one-wavefront kernels: tests/test_gpu_build.py holds both to the oracle
+// row for row (hvx_build_params.link_mode = 1 selects the one-wavefront kernels).
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kSeqRow = 35;                 // ids of a link's list (row + the node); wider rows take the one-wavefront kernel
+constexpr uint32_t kSeqRS = 36;                  // stride of a link's matrix: rows 0 .. nc (row nc: the owner's), columns 0 .. nc - 1
+constexpr uint32_t kSeqSelDm = 65 * 64;          // the select's matrix
+constexpr uint32_t kSeqLinkDm = kSeqRS * kSeqRS;
+constexpr uint32_t kSeqLayerDm = kSeqSelDm + 32u * kSeqLinkDm;
+constexpr uint32_t kSeqPairs = 128;              // (row, victim) removals one layer's links can log
+
+template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(256) void build_select_seq_kernel(BuildArgs a) {
+    __shared__ uint32_t s_cid[64], s_wsc[128], s_last;
+    const DevIndex &ix = a.ix;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    uint32_t L, g, G;
+    if (blockIdx.x < a.g0) { L = 0u; g = blockIdx.x; G = a.g0; }
+    else { L = 1u + (blockIdx.x - a.g0) / a.gu; g = (blockIdx.x - a.g0) % a.gu; G = a.gu; }
+    const uint32_t node = a.nodes[0];
+    const uint32_t lv = ix.level[node];
+    const uint32_t top = lv < a.layers - 1u ? lv : a.layers - 1u; // min(node level, old max_layer)
+    if (L > top) return; // layers above the old top stay empty rows (mutation.rs:883-894)
+    const uint32_t maxn = L == 0u ? a.m0 : a.m;
+    const size_t slot = (size_t)L * a.b;
+    const uint32_t cnt = a.cand_cnt[slot];
+    const uint32_t hyd = cnt < 2u * maxn ? cnt : 2u * maxn; // select_neighbors_heuristic hydrates the first 2*Mmax only
+    float *gl = a.gdm + (size_t)L * kSeqLayerDm;
+    if (tid < hyd) s_cid[tid] = (uint32_t)a.cand_ids[slot * kCand + tid];
+    __syncthreads();
+    bool last = g == 0u;
+    const uint32_t npairs = hyd * (hyd - (hyd ? 1u : 0u)) / 2u;
+    if (npairs != 0u) {
+        if (g == 0u && tid < hyd) st_agent(gl + hyd * 64u + tid, a.cand_sc[slot * kCand + tid]); // the owner's row: the search's scores
+        const int j = (int)(lane & 7u);
+        for (uint32_t q = g * 32u + (tid >> 3); q < npairs; q += G * 32u) {
+            uint32_t i, jj;
+            pair_of(q, i, jj); // 0 <= jj < i < hyd
+            const uint32_t ni = s_cid[i], nj = s_cid[jj];
+            const float d = group_distance<METRIC, FUSED>(ix, ix.vec + (size_t)ni * ix.ld, ix.hdr[ni], nj, j);
+            if (j == 0) { st_agent(gl + i * 64u + jj, d); st_agent(gl + jj * 64u + i, d); }
+        }
+        stores_done(); // the stores have been acknowledged before the ticket is taken
+        __syncthreads();
+        if (tid == 0) s_last = __hip_atomic_fetch_add(a.tick + L, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == G ? 1u : 0u;
+        __syncthreads();
+        last = s_last != 0u;
+        if (last && tid == 0) st_agent(a.tick + L, 0u);
+    }
+    if (!last || wave != 0u) return;
+    const WaveScratch W{s_wsc, s_wsc + 64};
+    uint32_t ns = hyd;
+    bool bad = false;
+    if (hyd >= 2u) ns = replay_rows<64>(gl, s_cid, hyd, maxn, lane, W, &bad);
+    else if (lane < hyd) W.kept[lane] = s_cid[lane];
+    lds_order();
+    const uint32_t kf = lane < ns ? W.kept[lane] : kSentinel;
+    if (lane < ns) a.sel[slot * 32u + lane] = kf;
+    if (lane == 0) a.sel_cnt[slot] = ns;
+    uint32_t stride;
+    uint32_t *row = row_ptr(a, node, L, stride);
+    store_canonical_reg(row, stride, kf, ns, lane); // nobody else can reach this row before the link step
+}
+
+struct SeqLds {
+    uint32_t *rcur, *rkept;   // [32][kSeqRS] a link's list (row + the node) / what stays of it
+    uint32_t *rdeg, *rkn;     // [32] ids in the list (0: nothing to do) / ids that stay
+    uint32_t *rdlo, *rdhi;    // [32] dropped ids by list position
+    uint32_t *to;             // [32] the selected neighbours, selection order
+    uint32_t *px, *pv;        // [kSeqPairs] removals: row px loses pv
+    uint32_t *pbase;          // [34]
+    uint32_t *wsc;            // [16][128]
+};
+__device__ __forceinline__ SeqLds carve_seq(char *smem) {
+    SeqLds S;
+    uint32_t *p = reinterpret_cast<uint32_t *>(smem);
+    S.rcur = p; p += 32 * kSeqRS;
+    S.rkept = p; p += 32 * kSeqRS;
+    S.rdeg = p; p += 32; S.rkn = p; p += 32; S.rdlo = p; p += 32; S.rdhi = p; p += 32; S.to = p; p += 32;
+    S.px = p; p += kSeqPairs; S.pv = p; p += kSeqPairs;
+    S.pbase = p; p += 36;
+    S.wsc = p;
+    return S;
+}
+static size_t seq_lds_bytes() { return (size_t)(2 * 32 * kSeqRS + 5 * 32 + 2 * kSeqPairs + 36 + 16 * 128) * 4; }
+
+template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(1024) void build_link_seq_kernel(BuildArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ uint32_t s_err, s_last, s_np;
+    const DevIndex &ix = a.ix;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    uint32_t L, g, G;
+    if (blockIdx.x < a.g0) { L = 0u; g = blockIdx.x; G = a.g0; }
+    else { L = 1u + (blockIdx.x - a.g0) / a.gu; g = (blockIdx.x - a.g0) % a.gu; G = a.gu; }
+    const uint32_t me = a.nodes[0];
+    const uint32_t lv = ix.level[me];
+    const uint32_t top = lv < a.layers - 1u ? lv : a.layers - 1u;
+    if (L > top) return;
+    const uint32_t maxn = L == 0u ? a.m0 : a.m;
+    const size_t slot = (size_t)L * a.b;
+    const uint32_t ns = a.sel_cnt[slot];
+    if (ns == 0u) return;
+    const SeqLds S = carve_seq(smem);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    if (tid == 0) s_err = 0u;
+    if (tid < ns) S.to[tid] = a.sel[slot * 32u + tid];
+    __syncthreads();
+    // ---- the links' lists, from the rows as they are now (every workgroup of the layer arrives at the same lists) ----
+    for (uint32_t t = wave; t < ns; t += 16u) {
+        const uint32_t to = S.to[t];
+        uint32_t stride;
+        const uint32_t *row = row_ptr(a, to, L, stride);
+        uint32_t v = lane < stride ? ld_row(row + lane) : kSentinel;
+        uint32_t deg = (uint32_t)__builtin_popcountll(__ballot(v != kSentinel));
+        const bool present = __ballot(v == me) != 0ull;
+        if (!present) {
+            if (deg + 1u > kSeqRow) { if (lane == 0) s_err = 1u; deg = 0u; }
+            else { if (lane == deg) v = me; ++deg; } // rows are canonical: the valid ids occupy lanes 0..deg-1
+        } else if (deg > kSeqRow) { if (lane == 0) s_err = 1u; deg = 0u; }
+        if (lane < deg) S.rcur[t * kSeqRS + lane] = v;
+        if (lane == 0) S.rdeg[t] = deg;
+    }
+    __syncthreads();
+    if (s_err) { if (g == 0u && tid == 0) *a.err = 1u; return; }
+    if (wave == 0) { // first pair of every link's prune (a list within its limit needs no matrix)
+        const uint32_t rd = lane < ns ? S.rdeg[lane] : 0u;
+        const uint32_t np = rd > maxn ? (rd + 1u) * rd / 2u : 0u;
+        uint32_t incl = np;
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const uint32_t o = __shfl_up(incl, sft, 64);
+            if ((int)lane >= sft) incl += o;
+        }
+        if (lane < 32u) S.pbase[lane] = incl - np;
+        if (lane == 31u) S.pbase[32] = incl;
+    }
+    __syncthreads();
+    const uint32_t total = S.pbase[32];
+    float *gl = a.gdm + (size_t)L * kSeqLayerDm + kSeqSelDm;
+    bool last;
+    { // (the ticket is taken even when no list needs a matrix: the last workgroup rewrites rows the others are still reading their lists from)
+        const int j = (int)(lane & 7u);
+        for (uint32_t p = g * 128u + (tid >> 3); p < total; p += G * 128u) {
+            uint32_t lo = 0u, hi = ns; // the link t with pbase[t] <= p < pbase[t + 1]
+            while (hi - lo > 1u) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (S.pbase[mid] <= p) lo = mid; else hi = mid;
+            }
+            const uint32_t t = lo;
+            uint32_t i, jj;
+            pair_of(p - S.pbase[t], i, jj);
+            const uint32_t *rc = S.rcur + t * kSeqRS;
+            const uint32_t nc = S.rdeg[t];
+            const uint32_t node_i = i < nc ? rc[i] : S.to[t], node_j = rc[jj];
+            const float d = group_distance<METRIC, FUSED>(ix, ix.vec + (size_t)node_i * ix.ld, ix.hdr[node_i], node_j, j);
+            if (j == 0) {
+                float *out = gl + (size_t)t * kSeqLinkDm;
+                st_agent(out + i * kSeqRS + jj, d);
+                if (i < nc) st_agent(out + jj * kSeqRS + i, d);
+            }
+        }
+        stores_done();
+        __syncthreads();
+        if (tid == 0) s_last = __hip_atomic_fetch_add(a.tick + a.layers + L, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == G ? 1u : 0u;
+        __syncthreads();
+        last = s_last != 0u;
+        if (last && tid == 0) st_agent(a.tick + a.layers + L, 0u);
+    }
+    if (!last) return;
+    // ---- the last workgroup: every link replayed on its list as found (sixteen at a time) ...
+    const WaveScratch W{S.wsc + wave * 128u, S.wsc + wave * 128u + 64u};
+    bool bad = false; // (a distance that is no valid score: add_bidirectional_link does not look, neither does the one-wavefront kernel)
+    for (uint32_t t = wave; t < ns; t += 16u) {
+        const uint32_t deg = S.rdeg[t];
+        const uint32_t *rc = S.rcur + t * kSeqRS;
+        uint32_t kn = deg;
+        unsigned long long dropped = 0ull;
+        if (deg > maxn) kn = replay_rows<(int)kSeqRS>(gl + (size_t)t * kSeqLinkDm, rc, deg, maxn, lane, W, &bad, ~0ull, &dropped);
+        else if (lane < deg) W.kept[lane] = rc[lane];
+        lds_order();
+        if (lane < kn) S.rkept[t * kSeqRS + lane] = W.kept[lane];
+        if (lane == 0) { S.rkn[t] = kn; S.rdlo[t] = (uint32_t)dropped; S.rdhi[t] = (uint32_t)(dropped >> 32); }
+        lds_order();
+    }
+    if (tid == 0) s_np = 0u;
+    __syncthreads();
+    // ---- ... then in selection order: a link whose row an earlier link has taken an id from is replayed over the ids still there
+    if (wave == 0) {
+        uint32_t np = 0;
+        for (uint32_t s = 0; s < ns; ++s) {
+            const uint32_t to = S.to[s], deg = S.rdeg[s];
+            if (deg == 0u) continue;
+            const uint32_t *rc = S.rcur + s * kSeqRS;
+            const uint32_t mine = lane < deg ? rc[lane] : kSentinel;
+            bool gone = false; // my id has been removed from this row by an earlier link
+            for (uint32_t i = 0; i < np; ++i) gone |= S.px[i] == to && S.pv[i] == mine;
+            const unsigned long long alive = __ballot(lane < deg && !gone);
+            unsigned long long dropped = ((unsigned long long)S.rdhi[s] << 32) | S.rdlo[s];
+            if (alive != (deg >= 64u ? ~0ull : (1ull << deg) - 1ull)) {
+                const uint32_t nlive = (uint32_t)__builtin_popcountll(alive);
+                uint32_t kn;
+                dropped = 0ull;
+                if (nlive > maxn) {
+                    kn = replay_rows<(int)kSeqRS>(gl + (size_t)s * kSeqLinkDm, rc, deg, maxn, lane, W, &bad, alive, &dropped);
+                } else {
+                    if ((alive >> lane) & 1ull) W.kept[(uint32_t)__builtin_popcountll(alive & lt)] = mine;
+                    kn = nlive;
+                    lds_order();
+                }
+                if (lane < kn) S.rkept[s * kSeqRS + lane] = W.kept[lane];
+                if (lane == 0) S.rkn[s] = kn;
+                lds_order();
+            }
+            // every neighbour dropped by the prune loses its edge to `to` as well: the graph stays symmetric (mutation.rs:1890-1908)
+            const bool drop_mine = ((dropped >> lane) & 1ull) != 0ull;
+            const uint32_t at = np + (uint32_t)__builtin_popcountll(dropped & lt);
+            if (drop_mine && at < kSeqPairs) { S.px[at] = mine; S.pv[at] = to; }
+            np += (uint32_t)__builtin_popcountll(dropped);
+            if (np > kSeqPairs) { if (lane == 0) *a.err = 1u; np = kSeqPairs; }
+            lds_order();
+        }
+        if (lane == 0) s_np = np;
+    }
+    __syncthreads();
+    // ---- the rows.  Every neighbour dropped by a prune loses its edge back (mutation.rs:1890-1908): a neighbour row (a link's own row) gets
+    // its removals before it is stored -- one store per row, nothing in this kernel reads a row it has written --, every other row that
+    // loses edges (the node's own among them) is read, compacted and stored by the first removal that names it
+    const uint32_t np = s_np;
+    for (uint32_t t = wave; t < ns; t += 16u) {
+        if (S.rdeg[t] == 0u) continue;
+        const uint32_t kn = S.rkn[t], to = S.to[t];
+        const uint32_t v = lane < kn ? S.rkept[t * kSeqRS + lane] : kSentinel;
+        bool victim = false;
+        for (uint32_t k2 = 0; k2 < np; ++k2) victim |= S.px[k2] == to && S.pv[k2] == v;
+        const bool keep = v != kSentinel && !victim;
+        const unsigned long long km = __ballot(keep);
+        const uint32_t nk = (uint32_t)__builtin_popcountll(km);
+        // (compact: the ids that stay move to the low lanes)
+        const uint32_t src = (uint32_t)__builtin_amdgcn_ds_permute((int)(((keep ? (uint32_t)__builtin_popcountll(km & lt) : 63u - (uint32_t)__builtin_popcountll(~km & lt))) << 2), (int)v);
+        uint32_t stride;
+        uint32_t *row = row_ptr(a, to, L, stride);
+        if (nk > stride) { if (lane == 0) *a.err = 1u; continue; }
+        store_canonical_reg(row, stride, lane < nk ? src : kSentinel, nk, lane);
+    }
+    for (uint32_t i = wave; i < np; i += 16u) {
+        const uint32_t x = S.px[i];
+        bool first = true;
+        for (uint32_t k2 = 0; k2 < i; ++k2) first &= S.px[k2] != x;
+        for (uint32_t t = 0; t < ns; ++t) first &= S.to[t] != x; // (a link's row: done above)
+        if (!first) continue;
+        uint32_t stride;
+        uint32_t *row = row_ptr(a, x, L, stride);
+        const uint32_t v = lane < stride ? ld_row(row + lane) : kSentinel;
+        bool victim = false;
+        for (uint32_t k2 = i; k2 < np; ++k2) victim |= S.px[k2] == x && S.pv[k2] == v;
+        const bool keep = v != kSentinel && !victim;
+        const unsigned long long km = __ballot(keep);
+        const uint32_t pos = (uint32_t)__builtin_popcountll(km & lt), nk = (uint32_t)__builtin_popcountll(km);
+        if (keep) st_row(row + pos, v); // every lane holds its id in a register: the order of the stores does not matter
+        if (lane >= nk && lane < stride) st_row(row + lane, kSentinel);
     }
 }
 
@@ -543,9 +822,11 @@ __global__ void iota_kernel(uint32_t *p, uint32_t count, uint32_t first, uint32_
 using BuildKernel = void (*)(BuildArgs);
 struct BuildKernels {
     BuildKernel select, link, link_wg; // link_wg: null where the workgroup kernel has no instantiation (Manhattan)
+    BuildKernel select_seq, link_seq;  // one node per step
 };
 template <uint32_t METRIC, bool FUSED> static BuildKernels build_kernels_of() {
-    BuildKernels k{build_select_kernel<METRIC, FUSED>, build_link_kernel<METRIC, FUSED>, nullptr};
+    BuildKernels k{build_select_kernel<METRIC, FUSED>, build_link_kernel<METRIC, FUSED>, nullptr, build_select_seq_kernel<METRIC, FUSED>,
+                   build_link_seq_kernel<METRIC, FUSED>};
     if constexpr (METRIC != kL1) k.link_wg = build_link_wg_kernel<METRIC, FUSED>;
     return k;
 }
@@ -594,10 +875,15 @@ static int insert_range(hvx_index *ix, uint64_t first, uint64_t count, const uin
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t s = ix->stream;
     const uint32_t layers_max = top_level + 1u;
-    uint32_t *d_iota, *d_locks, *d_cnt, *d_sel, *d_selcnt, *d_status, *d_err;
+    uint32_t *d_iota, *d_locks, *d_cnt, *d_sel, *d_selcnt, *d_status, *d_err, *d_tick;
     uint64_t *d_cids;
-    float *d_csc;
-    // scratch is released with the call (hipFree below); the image keeps only rows + graph
+    float *d_csc, *d_gdm;
+    // Round 6: the scratch, the link stream and its events stay with the handle (a one-node insert / upsert paid nine hipMalloc + hipFree --
+    // each a device synchronisation --, a stream and four events per call: ~2 ms of a 6.4-ms upsert).  Only tuning buffers are per call.
+    // Round 4: the search of batch i + 1 runs on the handle's stream WHILE batch i is selected and linked on a second stream.  Batch i + 1
+    // then does not see batch i -- which it tolerates exactly as the nodes of one batch tolerate not seeing each other: rows are only ever
+    // read as stale-or-current (agent-scope stores by the link step, immutable vectors), never torn into invalid ids.  Candidate /
+    // selection buffers are double-buffered; a promotion (new top layer = new entry point), a one-node batch and sequential mode do not overlap.
     std::vector<void *> scratch;
     auto salloc = [&](void **p, size_t bytes) -> int {
         if (hipMalloc(p, std::max<size_t>(bytes, 16)) != hipSuccess) return fail(HVX_ERR_DEVICE, "hipMalloc(%zu) build scratch", bytes);
@@ -605,42 +891,61 @@ static int insert_range(hvx_index *ix, uint64_t first, uint64_t count, const uin
         return HVX_OK;
     };
     auto release = [&]() { for (void *p : scratch) (void)hipFree(p); scratch.clear(); };
-    auto sbail = [&](int code) { (void)hipStreamSynchronize(s); release(); return code; };
-    // Round 4: the search of batch i + 1 runs on the handle's stream WHILE batch i is selected and linked on a second stream (the
-    // search side was half of the build and strictly serial with the link step).  Batch i + 1 then does not see batch i -- which it
-    // tolerates exactly as the nodes of one batch tolerate not seeing each other: rows are only ever read as stale-or-current
-    // (agent-scope stores by the link step, immutable vectors), never torn into invalid ids.  Candidate / selection buffers are
-    // double-buffered; a promotion (new top layer = new entry point), a one-node batch and sequential mode do not overlap.
+    auto sbail = [&](int code) { // (a failed call may leave locks / tickets set: the next call starts from fresh scratch)
+        (void)hipStreamSynchronize(s);
+        release();
+        ix->ins_cap = 0;
+        ix->ins_locks_rows = 0;
+        return code;
+    };
     const size_t sz_cids = (size_t)layers_max * bmax * kCand, sz_cnt = (size_t)layers_max * bmax, sz_sel = (size_t)layers_max * bmax * 32;
     int rc;
-    if ((rc = salloc((void **)&d_iota, count * 4)) || (rc = salloc((void **)&d_locks, rows_total * 4)) ||
-        (rc = salloc((void **)&d_cids, 2 * sz_cids * 8)) || (rc = salloc((void **)&d_csc, 2 * sz_cids * 4)) ||
-        (rc = salloc((void **)&d_cnt, 2 * sz_cnt * 4)) || (rc = salloc((void **)&d_sel, 2 * sz_sel * 4)) ||
-        (rc = salloc((void **)&d_selcnt, 2 * sz_cnt * 4)) || (rc = salloc((void **)&d_status, (size_t)bmax * 4)) ||
-        (rc = salloc((void **)&d_err, 4)))
-        return sbail(rc);
-    hipStream_t s2 = nullptr;
-    hipEvent_t ev_search[2] = {nullptr, nullptr}, ev_link[2] = {nullptr, nullptr};
-    bool link_pending[2] = {false, false};
-    auto drop_streams = [&]() {
-        if (s2) { (void)hipStreamSynchronize(s2); (void)hipStreamDestroy(s2); s2 = nullptr; }
-        for (int i = 0; i < 2; ++i) {
-            if (ev_search[i]) { (void)hipEventDestroy(ev_search[i]); ev_search[i] = nullptr; }
-            if (ev_link[i]) { (void)hipEventDestroy(ev_link[i]); ev_link[i] = nullptr; }
+    {
+        auto up = [](size_t b) { return (b + 255u) & ~(size_t)255u; };
+        const size_t b_iota = up(count * 4), b_cids = up(2 * sz_cids * 8), b_csc = up(2 * sz_cids * 4), b_cnt = up(2 * sz_cnt * 4), b_sel = up(2 * sz_sel * 4),
+                     b_status = up((size_t)bmax * 4), b_err = 256, b_tick = up(2 * 64 * 4), b_gdm = up((size_t)layers_max * kSeqLayerDm * 4);
+        const size_t need = b_iota + b_cids + b_csc + 2 * b_cnt + b_sel + b_status + b_err + b_tick + b_gdm;
+        if (need > ix->ins_cap) {
+            ix->ins_cap = 0;
+            if ((rc = ix->regrow(&ix->ins_scratch, need + need / 4))) return rc;
+            if (hipMemsetAsync(ix->ins_scratch, 0, need + need / 4, s) != hipSuccess) return fail(HVX_ERR_DEVICE, "memset");
+            ix->ins_cap = need + need / 4;
         }
-    };
+        char *p = reinterpret_cast<char *>(ix->ins_scratch);
+        d_tick = reinterpret_cast<uint32_t *>(p); p += b_tick; // (first: zero between calls, set once by the memset above)
+        d_iota = reinterpret_cast<uint32_t *>(p); p += b_iota;
+        d_cids = reinterpret_cast<uint64_t *>(p); p += b_cids;
+        d_csc = reinterpret_cast<float *>(p); p += b_csc;
+        d_cnt = reinterpret_cast<uint32_t *>(p); p += b_cnt;
+        d_selcnt = reinterpret_cast<uint32_t *>(p); p += b_cnt;
+        d_sel = reinterpret_cast<uint32_t *>(p); p += b_sel;
+        d_status = reinterpret_cast<uint32_t *>(p); p += b_status;
+        d_err = reinterpret_cast<uint32_t *>(p); p += b_err;
+        d_gdm = reinterpret_cast<float *>(p);
+        const uint64_t lock_rows = std::max<uint64_t>(rows_total, ix->cap_rows);
+        if (lock_rows > ix->ins_locks_rows) { // one lock per row the image can hold: all zero between calls (every lock taken is released)
+            ix->ins_locks_rows = 0;
+            if ((rc = ix->regrow((void **)&ix->ins_locks, lock_rows * 4))) return rc;
+            if (hipMemsetAsync(ix->ins_locks, 0, lock_rows * 4, s) != hipSuccess) return fail(HVX_ERR_DEVICE, "memset");
+            ix->ins_locks_rows = lock_rows;
+        }
+        d_locks = ix->ins_locks;
+    }
+    if (!ix->ins_stream && hipStreamCreateWithFlags(&ix->ins_stream, hipStreamNonBlocking) != hipSuccess) return fail(HVX_ERR_DEVICE, "stream creation failed");
+    for (int i = 0; i < 4; ++i)
+        if (!ix->ins_ev[i] && hipEventCreateWithFlags(&ix->ins_ev[i], hipEventDisableTiming) != hipSuccess) return fail(HVX_ERR_DEVICE, "event creation failed");
+    hipStream_t s2 = ix->ins_stream;
+    hipEvent_t ev_search[2] = {ix->ins_ev[0], ix->ins_ev[1]}, ev_link[2] = {ix->ins_ev[2], ix->ins_ev[3]};
+    bool link_pending[2] = {false, false};
+    auto drop_streams = [&]() { (void)hipStreamSynchronize(s2); };
     auto sbail2 = [&](int code) { (void)hipStreamSynchronize(s); drop_streams(); return sbail(code); };
-    if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) return sbail(fail(HVX_ERR_DEVICE, "stream creation failed"));
-    for (int i = 0; i < 2; ++i)
-        if (hipEventCreateWithFlags(&ev_search[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_link[i], hipEventDisableTiming) != hipSuccess)
-            return sbail2(fail(HVX_ERR_DEVICE, "event creation failed"));
     uint32_t *d_dbg = nullptr;
     if (tuning_env("HVX_BUILD_DEBUG")) {
         if ((rc = salloc((void **)&d_dbg, 32))) return sbail2(rc);
         if (hipMemsetAsync(d_dbg, 0, 32, s) != hipSuccess) return sbail2(fail(HVX_ERR_DEVICE, "memset"));
     }
     hipLaunchKernelGGL(iota_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, s, d_iota, (uint32_t)count, (uint32_t)first, stride, (uint32_t)std::max<uint64_t>(mod, 1));
-    if (hipMemsetAsync(d_locks, 0, rows_total * 4, s) != hipSuccess || hipMemsetAsync(d_err, 0, 4, s) != hipSuccess) return sbail2(fail(HVX_ERR_DEVICE, "memset"));
+    if (hipMemsetAsync(d_err, 0, 4, s) != hipSuccess) return sbail2(fail(HVX_ERR_DEVICE, "memset"));
 
     uint32_t *l0w = const_cast<uint32_t *>(d.l0), *upw = const_cast<uint32_t *>(d.up);
     const bool fused = kernel_fused(d.fkernel);
@@ -724,8 +1029,21 @@ static int insert_range(hvx_index *ix, uint64_t first, uint64_t count, const uin
         ba.m0 = m0;
         ba.err = d_err;
         ba.dbg = d_dbg;
-        hipError_t e = launch_build(kern.select, dim3(bsz, layers), ba, s2);
-        if (e == hipSuccess) {
+        // one node: its select and its links as two many-workgroup steps with every prune's distance matrix evaluated up front
+        const bool seq_step = bsz == 1u && params->link_mode != 1u && d.s0 + 1u <= kSeqRow && d.su + 1u <= kSeqRow;
+        hipError_t e;
+        if (seq_step) {
+            ba.gdm = d_gdm;
+            ba.tick = d_tick;
+            ba.g0 = 63u; ba.gu = 16u; // 32 row groups per workgroup: 2 016 pairs among 64 candidates on layer 0, 496 among 32 above
+            hipLaunchKernelGGL(kern.select_seq, dim3(ba.g0 + (layers - 1u) * ba.gu), dim3(256), 0, s2, ba);
+            ba.g0 = 96u; ba.gu = 12u; // 128 row groups per workgroup: <= 32 links x 561 pairs on layer 0, <= 16 x 153 above
+            hipLaunchKernelGGL(kern.link_seq, dim3(ba.g0 + (layers - 1u) * ba.gu), dim3(1024), seq_lds_bytes(), s2, ba);
+            e = hipGetLastError();
+        } else {
+            e = launch_build(kern.select, dim3(bsz, layers), ba, s2);
+        }
+        if (e == hipSuccess && !seq_step) {
             if (bsz > 1u && link_wg) { // batched mode: one workgroup per link, prunes evaluated from LDS
                 ba.ldp = ldp;
                 ba.ncmax = ncmax;

@@ -463,7 +463,6 @@ __device__ __forceinline__ StepLds carve_step(char *smem) {
 }
 static size_t step_lds_bytes() { return (size_t)kDelDm * 4 + 6 * 256 + 64; }
 
-__device__ __forceinline__ void lds_order() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); } // one wavefront's LDS writes before its next reads
 
 __device__ __forceinline__ void store_canonical_wave(uint32_t *row, uint32_t stride, const uint32_t *ids_lds, uint32_t ns, uint32_t lane) {
     const uint32_t mine = lane < ns ? ids_lds[lane] : kSentinel;
@@ -473,9 +472,6 @@ __device__ __forceinline__ void store_canonical_wave(uint32_t *row, uint32_t str
         if (t >= ns) st_row(row + t, kSentinel);
     if (lane < ns) st_row(row + rank, mine);
 }
-
-template <typename T> __device__ __forceinline__ T ld_agent(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <typename T> __device__ __forceinline__ void st_agent(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // S.cur[0..nc) pruned to at most maxn ids around `owner` (prune_row_dev's result, evaluated eagerly): S.kept[0..return).
 // G workgroups share the prune: every one of them evaluates its share of the distance matrix into gdm; the LAST one to deliver (one
@@ -506,7 +502,7 @@ __device__ __forceinline__ uint32_t prune_eager(const DevIndex &ix, const StepLd
             if (i < nc) st_agent(gdm + jj * 64u + i, d);
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the stores have been acknowledged before the ticket is taken
+    stores_done(); // the stores have been acknowledged before the ticket is taken
     __syncthreads();
     if (tid == 0) S.misc[1] = __hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == G ? 1u : 0u;
     __syncthreads();
@@ -693,7 +689,6 @@ constexpr uint32_t kFuseOwnRW = 64, kFuseOwnDm = 65 * 64;
 constexpr uint32_t kFuseRecipRW = kFuseRS, kFuseRecipDm = kFuseRS * kFuseRS;
 constexpr uint32_t kFuseLayerDm = kFuseOwnDm + kDelTop * kFuseRecipDm; // floats of one layer's matrices
 
-struct WaveScratch { uint32_t *ord, *kept; };
 struct FuseLds {
     uint32_t *rcur;       // [kDelTop][kFuseRS] the candidates' rows with the source appended
     uint32_t *rdeg;       // [kDelTop] ids of that list; 0: the row holds the source already
@@ -720,80 +715,6 @@ __device__ __forceinline__ FuseLds carve_fuse(char *smem) {
 }
 static size_t fuse_lds_bytes() {
     return (size_t)kDelTop * kFuseRS * 4 + kDelTop * 4 * 3 + 512 + (kDelTop + 2) * 4 + 8 + kFuseWaves * 2 * 256 + 64;
-}
-
-// select_diverse + backfill (mod.rs:809-856) over a finished matrix, by ONE wavefront, without LDS: lane c reads ROW c of the matrix
-// (RW floats, device-scope 8-byte loads all in flight: the matrix was written by other workgroups, and this compute unit's L2 may hold
-// the previous step's lines) and its distance to the owner; ids[c] = cur[c].  -> W.kept[0..return).
-//   * Candidate order (score, then id: model.rs:55-61) by lane broadcasts of a 64-bit key (valid scores are non-negative: their bit
-//     patterns order like the numbers; an invalid one aborts the delete as the reference does);
-//   * who would reject whom is decided for all pairs up front from the registers: bit s of conf(c) <=> candidate s is strictly closer to
-//     c than the owner is; the sequential pass over the ranking is then scalar work on two 64-bit masks -- nothing in the dependent
-//     chain touches memory (first builds: an LDS gather + ballot per candidate, 6 - 7 us per prune of 64 ids, 3 us per reciprocal one).
-// Same decisions as testing each candidate against the selected ones when its turn comes: a candidate is rejected iff an EARLIER selected
-// one is strictly closer to it than the owner is (mod.rs:822-842), and the matrix is symmetric bit for bit.
-template <int RW>
-__device__ __forceinline__ uint32_t replay_rows(const float *G, const uint32_t *cur, uint32_t nc, uint32_t maxn, uint32_t lane, const WaveScratch &W, bool *bad) {
-    const unsigned long long *rp = reinterpret_cast<const unsigned long long *>(G + (size_t)(lane < nc ? lane : 0u) * RW);
-    unsigned long long x[RW / 2];
-#pragma unroll
-    for (int u = 0; u < RW / 2; ++u) x[u] = ld_agent(rp + u);
-    const float dmine = lane < nc ? ld_agent(G + (size_t)nc * RW + lane) : 0.f;
-    const uint32_t v = lane < nc ? cur[lane] : kSentinel;
-    float chk = dmine;
-    if (__ballot(lane < nc && !score_valid(chk)) != 0ull) *bad = true;
-    const unsigned long long key = ((unsigned long long)__float_as_uint(dmine + 0.0f) << 32) | v;
-    uint32_t rank = 0;
-    for (uint32_t t = 0; t < nc; ++t) {
-        const unsigned long long kt = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), (int)t) << 32) |
-                                      (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, (int)t);
-        rank += kt < key ? 1u : 0u;
-    }
-    // lane r <- the candidate ranked r (every lane sends its index to the lane of its rank; lanes past nc keep their own place)
-    const uint32_t my_ord = (uint32_t)__builtin_amdgcn_ds_permute((int)((lane < nc ? rank : lane) << 2), (int)lane);
-    unsigned long long conf = 0ull;
-#pragma unroll
-    for (int u = 0; u < RW / 2; ++u) {
-        const float d0 = __uint_as_float((uint32_t)x[u]), d1 = __uint_as_float((uint32_t)(x[u] >> 32));
-        conf |= (unsigned long long)((d0 < dmine ? 1u : 0u) | (d1 < dmine ? 2u : 0u)) << (2 * u);
-    }
-    conf &= (nc >= 64u ? ~0ull : (1ull << nc) - 1ull) & ~(1ull << lane); // (columns past nc and the diagonal hold no distance)
-    // ... in rank order (lane r holds the r-th candidate's mask)
-    const uint32_t clo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(my_ord << 2), (int)(uint32_t)conf);
-    const uint32_t chi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(my_ord << 2), (int)(uint32_t)(conf >> 32));
-    unsigned long long selm = 0ull, selr = 0ull; // selected candidates by index / by rank
-    uint32_t ns = 0;
-    for (uint32_t r = 0; r < nc && ns < maxn; ++r) {
-        const unsigned long long cm = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)chi, (int)r) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)clo, (int)r);
-        if (cm & selm) continue;
-        selm |= 1ull << (uint32_t)__builtin_amdgcn_readlane((int)my_ord, (int)r);
-        selr |= 1ull << r;
-        ++ns;
-    }
-    // lane r holds the id ranked r; the selected ones go to their slots in selection (= rank) order, then the backfill: the others, closest first
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    const uint32_t rid = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(my_ord << 2), (int)v);
-    const bool mine_sel = ((selr >> lane) & 1ull) != 0ull;
-    if (mine_sel) W.kept[(uint32_t)__builtin_popcountll(selr & lt)] = rid;
-    if (ns < maxn) { // (mod.rs:845-854)
-        const bool free = lane < nc && !mine_sel;
-        const unsigned long long fm = __ballot(free);
-        const uint32_t rk = (uint32_t)__builtin_popcountll(fm & lt);
-        if (free && ns + rk < maxn) W.kept[ns + rk] = rid;
-        const uint32_t add = (uint32_t)__builtin_popcountll(fm);
-        ns = ns + add < maxn ? ns + add : maxn;
-    }
-    lds_order();
-    return ns;
-}
-
-// a staged row (mutation.rs:1299: sorted by id) from ids held one per lane (lane < ns), ranks by lane broadcasts
-__device__ __forceinline__ void store_canonical_reg(uint32_t *row, uint32_t stride, uint32_t mine, uint32_t ns, uint32_t lane) {
-    uint32_t rank = 0;
-    for (uint32_t s = 0; s < ns; ++s) rank += (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)s) < mine ? 1u : 0u;
-    for (uint32_t t = lane; t < stride; t += 64u)
-        if (t >= ns) st_row(row + t, kSentinel);
-    if (lane < ns) st_row(row + rank, mine);
 }
 
 template <uint32_t METRIC, bool FUSED, bool BF> __global__ __launch_bounds__(1024) void delete_step_fused_kernel(DeleteArgs a, uint32_t ri) {
@@ -878,8 +799,8 @@ template <uint32_t METRIC, bool FUSED, bool BF> __global__ __launch_bounds__(102
     __syncthreads();
     const uint32_t total = S.pbase[kDelTop + 1u];
     float *gl = a.gdm + (size_t)L * kFuseLayerDm;
-    bool last = true;
-    if (total != 0u) {
+    bool last;
+    { // (the ticket is taken even when nothing needs a matrix: the last workgroup rewrites rows the others are still reading their tasks from)
         const int j = (int)(lane & 7u);
         for (uint32_t p = g * (kFuseWaves * 8u) + (tid >> 3); p < total; p += G * (kFuseWaves * 8u)) {
             uint32_t lo = 0u, hi = nadd + 1u; // the task t with pbase[t] <= p < pbase[t + 1]
@@ -909,14 +830,12 @@ template <uint32_t METRIC, bool FUSED, bool BF> __global__ __launch_bounds__(102
                 if (i < nc) st_agent(out + jj * st + i, d);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the stores have been acknowledged before the ticket is taken
+        stores_done(); // the stores have been acknowledged before the ticket is taken
         __syncthreads();
         if (tid == 0) s_last = __hip_atomic_fetch_add(a.tick + L, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == G ? 1u : 0u;
         __syncthreads();
         last = s_last != 0u;
         if (last && tid == 0) st_agent(a.tick + L, 0u); // (the next launch starts from zero)
-    } else {
-        last = g == 0u;
     }
     if (!last) return;
     // ---- the last workgroup.  The reciprocal prunes do not depend on the source's (only whether they are APPLIED does): wavefront 0

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void flat_exact_tail_kernel(TailArgs a) {
     // XCD), and hundreds of short workgroups doing that to the L2 their neighbours are streaming rows through cost more than the scan
     // (first build: 200 us at 100 000 x 32).  The lists are written with device-scope (write-through) stores and read with device-scope
     // loads; the stores have been acknowledged (vscnt = 0, workgroup-scope release) before the ticket is taken.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (a workgroup-scope release fence does not wait for global stores outside threadgroup-split mode)
     __syncthreads();
     if (tid == 0) s_last = __hip_atomic_fetch_add(&a.done[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == a.slices ? 1u : 0u;
     __syncthreads();

@@ -131,4 +131,117 @@ __device__ __forceinline__ uint32_t prune_row_dev(const DevIndex &ix, const Buil
     return select_diverse_dev<METRIC, FUSED>(ix, L, nc, maxn, lane);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Eager prunes (round 6): a prune's distance matrix is evaluated up front by many workgroups (one 8-lane group per pair), written to HBM
+// with device-scope stores, and ONE wavefront of the last workgroup to deliver replays select_diverse + backfill from registers.  Shared
+// by the delete steps (hvx_delete.hip) and the sequential insert's select / link steps (hvx_build.hip).
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T ld_agent(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T> __device__ __forceinline__ void st_agent(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// every global store of this wavefront has been performed.  A workgroup-scope release fence does NOT wait for them (all wavefronts of a
+// workgroup sit behind one vector cache: the compiler omits vmcnt(0) outside threadgroup-split mode), and an agent-scope one writes back
+// and invalidates the XCD's L2 -- so the "last workgroup" tickets wait explicitly before the barrier in front of the ticket
+__device__ __forceinline__ void stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_order() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); } // one wavefront's LDS writes before its next reads
+struct WaveScratch { uint32_t *ord, *kept; }; // [64] each, per wavefront
+
+// pair q of a prune over nc ids + the owner (index nc): q = i (i - 1) / 2 + j, 0 <= j < i <= nc
+__device__ __forceinline__ void pair_of(uint32_t q, uint32_t &i, uint32_t &j) {
+    i = (uint32_t)((1.0f + sqrtf(1.0f + 8.0f * (float)q)) * 0.5f);
+    while (i * (i - 1u) / 2u > q) --i;
+    while ((i + 1u) * i / 2u <= q) ++i;
+    j = q - i * (i - 1u) / 2u;
+}
+
+// select_diverse + backfill (mod.rs:809-856) over a finished matrix, by ONE wavefront, without LDS: lane c reads ROW c of the matrix
+// (RW floats, device-scope 8-byte loads all in flight: the matrix was written by other workgroups, and this compute unit's L2 may hold
+// the previous step's lines) and its distance to the owner; ids[c] = cur[c].  -> W.kept[0..return).
+//   * Candidate order (score, then id: model.rs:55-61) by lane broadcasts of a 64-bit key (valid scores are non-negative: their bit
+//     patterns order like the numbers; an invalid one aborts the delete as the reference does);
+//   * who would reject whom is decided for all pairs up front from the registers: bit s of conf(c) <=> candidate s is strictly closer to
+//     c than the owner is; the sequential pass over the ranking is then scalar work on two 64-bit masks -- nothing in the dependent
+//     chain touches memory (first builds: an LDS gather + ballot per candidate, 6 - 7 us per prune of 64 ids, 3 us per reciprocal one).
+// Same decisions as testing each candidate against the selected ones when its turn comes: a candidate is rejected iff an EARLIER selected
+// one is strictly closer to it than the owner is (mod.rs:822-842), and the matrix is symmetric bit for bit.
+//   * `alive`: bit c clear = id c has left the list since the matrix was evaluated (a sequential insert: an earlier link removed it from this
+//     row) -- it ranks behind every live id, rejects nobody and is neither selected nor backfilled; *dropped = the live ids that do not stay.
+template <int RW>
+__device__ __forceinline__ uint32_t replay_rows(const float *G, const uint32_t *cur, uint32_t nc, uint32_t maxn, uint32_t lane, const WaveScratch &W, bool *bad,
+                                                unsigned long long alive = ~0ull, unsigned long long *dropped = nullptr) {
+    const unsigned long long *rp = reinterpret_cast<const unsigned long long *>(G + (size_t)(lane < nc ? lane : 0u) * RW);
+    unsigned long long x[RW / 2];
+#pragma unroll
+    for (int u = 0; u < RW / 2; ++u) x[u] = ld_agent(rp + u);
+    const float dmine = lane < nc ? ld_agent(G + (size_t)nc * RW + lane) : 0.f;
+    const uint32_t v = lane < nc ? cur[lane] : kSentinel;
+    alive &= nc >= 64u ? ~0ull : (1ull << nc) - 1ull;
+    const bool live = ((alive >> lane) & 1ull) != 0ull;
+    const uint32_t nlive = (uint32_t)__builtin_popcountll(alive);
+    float chk = dmine;
+    if (__ballot(live && !score_valid(chk)) != 0ull) *bad = true;
+    const unsigned long long key = live ? ((unsigned long long)__float_as_uint(dmine + 0.0f) << 32) | v : (0xFFFFFFFFull << 32) | lane;
+    uint32_t rank = 0;
+    for (uint32_t t = 0; t < nc; ++t) {
+        const unsigned long long kt = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), (int)t) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, (int)t);
+        rank += kt < key ? 1u : 0u;
+    }
+    // lane r <- the candidate ranked r (every lane sends its index to the lane of its rank; lanes past nc keep their own place)
+    const uint32_t my_ord = (uint32_t)__builtin_amdgcn_ds_permute((int)((lane < nc ? rank : lane) << 2), (int)lane);
+    unsigned long long conf = 0ull;
+#pragma unroll
+    for (int u = 0; u < RW / 2; ++u) {
+        const float d0 = __uint_as_float((uint32_t)x[u]), d1 = __uint_as_float((uint32_t)(x[u] >> 32));
+        conf |= (unsigned long long)((d0 < dmine ? 1u : 0u) | (d1 < dmine ? 2u : 0u)) << (2 * u);
+    }
+    conf &= alive & ~(1ull << lane); // (columns past nc and the diagonal hold no distance; an id that has left rejects nobody)
+    // ... in rank order (lane r holds the r-th candidate's mask)
+    const uint32_t clo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(my_ord << 2), (int)(uint32_t)conf);
+    const uint32_t chi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(my_ord << 2), (int)(uint32_t)(conf >> 32));
+    unsigned long long selm = 0ull, selr = 0ull; // selected candidates by index / by rank
+    uint32_t ns = 0;
+    for (uint32_t r = 0; r < nlive && ns < maxn; ++r) { // (the live ids hold the first nlive ranks)
+        const unsigned long long cm = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)chi, (int)r) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)clo, (int)r);
+        if (cm & selm) continue;
+        selm |= 1ull << (uint32_t)__builtin_amdgcn_readlane((int)my_ord, (int)r);
+        selr |= 1ull << r;
+        ++ns;
+    }
+    // lane r holds the id ranked r; the selected ones go to their slots in selection (= rank) order, then the backfill: the others, closest first
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t rid = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(my_ord << 2), (int)v);
+    const bool mine_sel = ((selr >> lane) & 1ull) != 0ull;
+    if (mine_sel) W.kept[(uint32_t)__builtin_popcountll(selr & lt)] = rid;
+    bool stays = mine_sel;
+    if (ns < maxn) { // (mod.rs:845-854)
+        const bool free = lane < nlive && !mine_sel;
+        const unsigned long long fm = __ballot(free);
+        const uint32_t rk = (uint32_t)__builtin_popcountll(fm & lt);
+        if (free && ns + rk < maxn) { W.kept[ns + rk] = rid; stays = true; }
+        const uint32_t add = (uint32_t)__builtin_popcountll(fm);
+        ns = ns + add < maxn ? ns + add : maxn;
+    }
+    if (dropped) { // by list position (lane r holds the id ranked r = position my_ord): few -- a row over its limit by one loses one
+        unsigned long long dr = __ballot(lane < nlive && !stays), dp = 0ull;
+        while (dr) {
+            const uint32_t r = (uint32_t)__builtin_ctzll(dr);
+            dr &= dr - 1ull;
+            dp |= 1ull << (uint32_t)__builtin_amdgcn_readlane((int)my_ord, (int)r);
+        }
+        *dropped = dp;
+    }
+    lds_order();
+    return ns;
+}
+
+// a staged row (mutation.rs:1299: sorted by id) from ids held one per lane (lane < ns), ranks by lane broadcasts
+__device__ __forceinline__ void store_canonical_reg(uint32_t *row, uint32_t stride, uint32_t mine, uint32_t ns, uint32_t lane) {
+    uint32_t rank = 0;
+    for (uint32_t s = 0; s < ns; ++s) rank += (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)s) < mine ? 1u : 0u;
+    for (uint32_t t = lane; t < stride; t += 64u)
+        if (t >= ns) st_row(row + t, kSentinel);
+    if (lane < ns) st_row(row + rank, mine);
+}
+
 } // namespace hvx

@@ -120,6 +120,16 @@ struct hvx_index {
     void *del_scratch = nullptr;     // owner: scratch of the delete kernels (hvx_delete.hip)
     hipEvent_t del_ev = nullptr;     // ... and the event behind a delete's prep kernel (the relink-source counts are read back there)
     uint32_t del_layers = 0;
+    // owner: scratch of the insert path (hvx_build.hip insert_range, upsert staging), kept across calls: a one-node insert paid nine
+    // hipMalloc + hipFree, a stream and four events per call (round 6: ~2 ms of a 6.4-ms upsert)
+    void *ins_scratch = nullptr;     // candidate / selection buffers, status words, the sequential link's matrices
+    size_t ins_cap = 0;
+    uint32_t *ins_locks = nullptr;   // one lock per row (all zero between calls)
+    uint64_t ins_locks_rows = 0;
+    hipStream_t ins_stream = nullptr;
+    hipEvent_t ins_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    float *ins_rows = nullptr;       // upsert: the validated vectors before they reach their slots
+    size_t ins_rows_cap = 0;
     // per-batch device scratch
     uint32_t *d_bitmap = nullptr, *d_qstatus = nullptr, *d_tie = nullptr;
     float *d_qhdr = nullptr;

@@ -43,7 +43,7 @@ int fail(int code, const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *hvx_last_error(void) { return g_err.c_str(); }
-extern "C" const char *hvx_version(void) { return "helix_vec_gfx950 0.5 (round 5)"; }
+extern "C" const char *hvx_version(void) { return "helix_vec_gfx950 0.6 (round 6)"; }
 
 // domain.rs:26-78 VectorComponentLimit::try_new
 float hvx::component_limit(uint32_t metric, uint32_t dim) {

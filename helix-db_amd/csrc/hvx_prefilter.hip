@@ -1028,11 +1028,10 @@ __global__ __launch_bounds__(64) void bitmap_select_kernel(const uint32_t *bitma
 // row list -- in whatever order the wavefronts get there: the one-launch scan (hvx_restricted_exact.hip) orders by (score, row) itself.
 // counters[0] = rows of the list, counters[1] = candidate population.  Replaces the level kernel + count + scan + compact sequence and
 // the host read-back between them for plans that are exact whatever the population turns out to be.
-__global__ __launch_bounds__(256) void expand_collect_kernel(CsrView g, const uint32_t *seeds, uint32_t n_seeds, uint32_t direction, const uint32_t *allowed,
+__global__ __launch_bounds__(1024) void expand_collect_kernel(CsrView g, const uint32_t *seeds, uint32_t n_seeds, uint32_t direction, const uint32_t *allowed,
                                                              uint32_t n_allowed, uint32_t *visited, const uint64_t *ids, uint32_t n, uint32_t contiguous,
                                                              const uint32_t *dead, uint32_t *rows_out, uint32_t rows_cap, uint32_t *counters) {
     const int lane = (int)(threadIdx.x & 63u);
-    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     // one arc -> (joined the population, row of its target); the wavefront's arcs of one step share ONE pair of counter updates (a where_()
     // group of 10 000 sources with one edge each was 20 000 atomics on two words with a wavefront per seed: 0.25 ms of a 0.34 ms call)
     auto take = [&](bool active, const uint32_t *tgt, const uint32_t *lab, uint64_t at) __attribute__((always_inline)) {
@@ -1058,7 +1057,13 @@ __global__ __launch_bounds__(256) void expand_collect_kernel(CsrView g, const ui
         }
     };
     constexpr uint32_t kLight = 16; // rows up to this long are walked one arc per step by the seed's own lane (64 seeds per wavefront)
-    for (uint32_t s0 = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 64u; s0 < n_seeds; s0 += n_waves * 64u) {
+    // Round 6 (second build): the sixteen wavefronts of a workgroup walk their light rows in lock step and share ONE pair of counter updates per
+    // step (a group of 100 000 sources with one edge each was still 3 126 updates of two words -- same-address atomics serialise at the
+    // memory side: 121 us of a 0.43-ms call)
+    __shared__ uint32_t s_f[16], s_r[16], s_base, s_steps;
+    const uint32_t wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    for (uint32_t c0 = blockIdx.x * blockDim.x; c0 < n_seeds; c0 += gridDim.x * blockDim.x) {
+        const uint32_t s0 = c0 + wave * 64u;
         const bool have = s0 + (uint32_t)lane < n_seeds;
         const uint32_t node = have ? seeds[s0 + (uint32_t)lane] : 0u;
         for (int pass = 0; pass < 2; ++pass) {
@@ -1074,7 +1079,37 @@ __global__ __launch_bounds__(256) void expand_collect_kernel(CsrView g, const ui
             uint32_t steps = light ? deg : 0u;
 #pragma unroll
             for (int sh = 32; sh > 0; sh >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)steps, sh, 64); steps = o > steps ? o : steps; }
-            for (uint32_t i = 0; i < steps; ++i) take(light && i < deg, tgt, lab, a0 + i);
+            if (threadIdx.x == 0) s_steps = 0u;
+            __syncthreads();
+            if (lane == 0 && steps) atomicMax(&s_steps, steps);
+            __syncthreads();
+            const uint32_t wg_steps = s_steps;
+            for (uint32_t i = 0; i < wg_steps; ++i) {
+                bool fresh = false;
+                uint32_t row = kSentinel;
+                if (light && i < deg && (!lab || label_ok(lab[a0 + i], allowed, n_allowed))) {
+                    const uint32_t v = tgt[a0 + i];
+                    const uint32_t bit = 1u << (v & 31u);
+                    fresh = (atomicOr(&visited[v >> 5], bit) & bit) == 0u;
+                    if (fresh) row = find_row(ids, n, (uint64_t)v, contiguous != 0u, dead);
+                }
+                const unsigned long long fm = __ballot(fresh), rm = __ballot(row != kSentinel);
+                if (lane == 0) { s_f[wave] = (uint32_t)__builtin_popcountll(fm); s_r[wave] = (uint32_t)__builtin_popcountll(rm); }
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    uint32_t tf = 0, tr = 0;
+                    for (uint32_t w = 0; w < waves; ++w) { tf += s_f[w]; tr += s_r[w]; }
+                    if (tf) atomicAdd(&counters[1], tf);
+                    s_base = tr ? atomicAdd(&counters[0], tr) : 0u;
+                }
+                __syncthreads();
+                if (row != kSentinel) {
+                    uint32_t pos = s_base + (uint32_t)__builtin_popcountll(rm & ((1ull << lane) - 1ull));
+                    for (uint32_t w = 0; w < wave; ++w) pos += s_r[w];
+                    if (pos < rows_cap) rows_out[pos] = row;
+                }
+                __syncthreads(); // (the next step writes s_f / s_r again)
+            }
             unsigned long long heavy = __ballot(have && !light); // long rows (hubs): the whole wavefront strides over the arcs of one seed at a time
             while (heavy) {
                 const int l = __builtin_ctzll(heavy);
@@ -1140,8 +1175,8 @@ static int prefilter_expand_lean(hvx_index *ix, hvx_csr *g, const float *queries
     HIP_TRY(hipMemsetAsync(g->visited, 0, std::max<size_t>(words32, 2) * 4, s));
     HIP_TRY(hipMemsetAsync(ix->pf_blocks, 0, 8, s));
     CsrView v{g->out_off, g->in_off, g->out_tgt, g->in_tgt, g->out_lab, g->in_lab, g->n};
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>(1024, ((uint64_t)n_seeds + 255) / 256); // (a wavefront takes 64 seeds at a time)
-    hipLaunchKernelGGL(expand_collect_kernel, dim3(std::max(blocks, 1u)), dim3(256), 0, s, v, g->h_seeds, n_seeds, direction, g->labels, n_labels, g->visited,
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(512, ((uint64_t)n_seeds + 1023) / 1024); // (a wavefront takes 64 seeds at a time, a workgroup 1 024)
+    hipLaunchKernelGGL(expand_collect_kernel, dim3(std::max(blocks, 1u)), dim3(1024), 0, s, v, g->h_seeds, n_seeds, direction, g->labels, n_labels, g->visited,
                        ix->dev.ids, ix->dev.n, ix->contiguous ? 1u : 0u, ix->dev.dead, ix->f_subset, rows_cap, ix->pf_blocks);
     HIP_TRY(hipGetLastError());
     return restricted_direct_shared_devcount(ix, queries, b, k, ix->f_subset, rows_cap, ix->pf_blocks, out_ids, out_scores, out_counts, out_status,

@@ -92,4 +92,17 @@ json.dump({"how": "rocprofv3 --pmc FETCH_SIZE TCC_EA0_RDREQ_sum of scripts/bench
 print(json.dumps(res)[:1500])
 PY
 fi
+# 5. (round 6) writes: deletes and one-node inserts / upserts at 200 000 x 768 under the kernel trace -> delete_bench.json, delete_kernel_stats.csv,
+#    seq_insert.json, seq_insert_kernel_stats.csv
+rm -rf /tmp/dl_$tag /tmp/si_$tag
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/dl_$tag -o d -- python scripts/delete_bench.py 200000 768 100 > /tmp/dl_$tag.log 2>&1 || true
+grep '^{' /tmp/dl_$tag.log | tail -1 > $out/delete_bench.json
+st=$(find /tmp/dl_$tag -name '*kernel_stats.csv' | head -1)
+if [ -n "$st" ]; then (head -1 "$st"; grep -E "delete_" "$st") > $out/delete_kernel_stats.csv; fi
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/si_$tag -o s -- python scripts/seq_insert_bench.py 200000 768 208 > /tmp/si_$tag.log 2>&1 || true
+grep '^{' /tmp/si_$tag.log | tail -1 > $out/seq_insert.json
+st=$(find /tmp/si_$tag -name '*kernel_stats.csv' | head -1)
+if [ -n "$st" ]; then (head -1 "$st"; grep -E "build_|delete_|hnsw_wave_kernel<1u, 6, 24" "$st") > $out/seq_insert_kernel_stats.csv; fi
+timeout 120 python scripts/delete_bench.py 200000 768 100 2>/dev/null | grep '^{' | tail -1 > $out/delete_bench_unprofiled.json
+timeout 120 python scripts/seq_insert_bench.py 200000 768 208 2>/dev/null | grep '^{' | tail -1 > $out/seq_insert_unprofiled.json
 [ -f $out/kernel_stats_hvx.csv ] && cut -c1-170 $out/kernel_stats_hvx.csv | head -40

@@ -1239,9 +1239,9 @@ def compact_record(out, full_path):
         c["host_stall_in_first_run"] = out.get("host_stall_in_first_run")
     c["roofline"] = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "peak_measured", "unit", "frac", "frac_of_measured",
                                             "algorithmic_bytes_per_launch", "kernel_ms", "kernel_ms_each", "traffic", "traffic_source")}
-    c["roofline"]["frac_definition"] = f"overlapped span, {rf.get('lanes')} lanes x {rf.get('queries_per_simd')} queries per SIMD; one launch alone: lone_batch_frac"
+    c["roofline"]["frac_definition"] = f"overlapped span, {rf.get('lanes')} lanes x {rf.get('queries_per_simd')} per SIMD; alone: lone_batch_frac"
     if isinstance(c["roofline"].get("traffic_source"), str):   # (the full sentence stays in the full record)
-        c["roofline"]["traffic_source"] = c["roofline"]["traffic_source"].split(";")[0][:100]
+        c["roofline"]["traffic_source"] = c["roofline"]["traffic_source"].split(";")[0].replace(" --kernel-trace pass of the headline leg", " pass")[:100]
     lb = rf.get("lone_batch") or {}
     if lb:
         c["roofline"]["lone_batch_frac"] = lb.get("frac")
@@ -1249,7 +1249,7 @@ def compact_record(out, full_path):
     if cb:
         c["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "threads", "nproc", "quota_cores", "kind", "sample")}
         if isinstance(c["cpu_baseline"].get("sample"), str):
-            c["cpu_baseline"]["sample"] = c["cpu_baseline"]["sample"].split("; oracle")[0][:140]
+            c["cpu_baseline"]["sample"] = c["cpu_baseline"]["sample"].split("; median")[0][:100]
     if out.get("parity"):
         c["parity"] = {k: out["parity"].get(k) for k in ("queries", "ids_equal_oracle", "score_bits_equal_oracle")}
     if out.get("strong_scaling"):

@@ -146,7 +146,8 @@ enum hvx_option {
     HVX_OPT_HNSW_PAIR = 9,           /* owner / gatherer kernel (an owner wavefront + 1 or 3 gatherer wavefronts per query): 0 = when the
                                         handle runs one query per SIMD (hvx_index_set_occupancy(1): one batch in flight), 1 = never,
                                         2 = always where it is built, 3 = always, with ONE gatherer even where three are built */
-    HVX_OPT_DELETE_SEQUENTIAL = 10,  /* 1: hvx_index_delete_batch relinks every source in the one-wavefront kernel (no per-source step launches) */
+    HVX_OPT_DELETE_SEQUENTIAL = 10,  /* 0: one fused launch per relinked row (round 6); 1: every source in the one-wavefront kernel; 2: two launches per row
+                                        (what rows wider than 34 ids take) -- all three produce the reference's rows */
     HVX_OPT_RESTRICTED_DIRECT = 11,  /* restricted exact scans of k <= 64: 0 = the one-launch reference-order kernel (csrc/hvx_restricted_exact.hip) where it is
                                         the cheaper one (b x candidates x dim <= 2^31), 1 = never, 2 = always */
     HVX_OPT_RESTRICTED_EXACT_MIB = 12, /* device plan of HVX_RESTRICTED_AUTO: candidate sets whose rows take at most this many MiB are scanned
@@ -656,7 +657,9 @@ typedef struct hvx_build_params {
     uint32_t batch_divisor;   /* 0 => 32: batch <= nodes already inserted / divisor */
     uint32_t sequential;      /* 1 => one node per batch: the reference's insertion order exactly */
     uint32_t link_mode;       /* batched link step: 0 => one workgroup per link with the prune evaluated from LDS whenever the rows fit
-                                 (Mmax + 2 rows of ld floats <= 160 KB), 1 => one wavefront per node (links one after the other) */
+                                 (Mmax + 2 rows of ld floats <= 160 KB), 1 => one wavefront per node (links one after the other).
+                                 One node at a time (sequential = 1, upserts, promotions): 0 => its select and its links as two many-workgroup
+                                 steps with every prune's distance matrix evaluated up front (round 6), 1 => the one-wavefront kernels */
     uint32_t scatter;         /* 1 => batched mode inserts in the order (i * stride) mod n, stride ~ 0.618 n coprime with n, instead of
                                  id order.  For rows whose order follows the data (dumps sorted by topic, indexes hydrated in key order):
                                  the nodes of one batch do not see each other, and consecutive rows of such data are each other's
@@ -699,7 +702,8 @@ int hvx_index_insert_batch(hvx_index *, const uint64_t *node_ids /*[count]*/, co
  * hvx_index_live_rows does not; hvx_index_export_graph returns empty rows for it.  Same generation rules as
  * hvx_index_insert_batch: owner handle only, visible_seq + 1 per call that deleted something, forks adopt with hvx_index_refresh.
  * Its id comes back through hvx_index_upsert_batch (into the same slot), not through hvx_index_insert_batch (ids ascend).
- * f32 images, degree limits <= 32.  HVX_ERR_UNSUPPORTED when more than 4 096 rows of one layer hold a node or their joint
+ * f32 and bf16 images (bf16: rows of at most 34 ids, relinked on the rounded vectors), degree limits <= 32; fp8 images are refused.
+ * HVX_ERR_UNSUPPORTED when more than 4 096 rows of one layer hold a node or their joint
  * neighbourhood exceeds 16 384 rows (after such a failure the image is partially relinked: discard the handle).
  */
 typedef struct hvx_delete_stats {

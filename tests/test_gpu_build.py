@@ -440,7 +440,7 @@ def test_batched_inserts_keep_the_graph_invariants_and_serve_every_search_path(o
                                                  max_batch=1024, batch_divisor=16, search_max_batch=512)
     wid, _, _, _ = whole.search_batch(q, hv.SearchParams(10).with_ef(100))
     # (batched builds are timing-dependent -- lock order, which batch sees which: the same rows give 0.924 .. 0.949 from run to run,
-    # grown or built at once: scripts/insert_diag.py, profiles/r05h_insert_vs_whole_build.log)
+    # grown or built at once: scripts/insert_diag.py, profiles/history/r05h_insert_vs_whole_build.log)
     assert rec >= fx.recall_at_k(wid, fid) - 0.03 and rec >= 0.90, (rec, fx.recall_at_k(wid, fid))
     lane.refresh()
     lid, _, _, _ = lane.search_batch(q, hv.SearchParams(10).with_ef(100))

@@ -289,6 +289,10 @@ int hvx::import_index(const hvx_index_desc *desc, const uint64_t *node_ids, cons
     }
     if (max_deg > 128 || max_up > 128) // before any narrowing: a huge row length must not wrap into a small stride
         return bail(fail(HVX_ERR_UNSUPPORTED, "neighbour rows longer than 128 are not supported (l0 %llu, upper %llu)", (unsigned long long)max_deg, (unsigned long long)max_up));
+    // an image that declares its degree limits gets rows its nodes can grow into (deletes / upserts relink in place: a row may reach Mmax
+    // although the persisted graph's longest row is shorter -- upper layers of small graphs)
+    if (desc->m0 && desc->m0 <= 64u) min_s0 = std::max(min_s0, desc->m0);
+    if (desc->m && desc->m <= 64u) { min_su = std::max(min_su, desc->m); min_s0 = std::max(min_s0, 2u * desc->m <= 64u ? 2u * desc->m : desc->m); }
     d.s0 = round_up((uint32_t)std::max<uint64_t>(std::max<uint64_t>(max_deg, min_s0), 1), 32);
     d.su = round_up((uint32_t)std::max<uint64_t>(std::max<uint64_t>(max_up, min_su), 1), 16);
     if (d.s0 > 128 || d.su > 128) return bail(fail(HVX_ERR_UNSUPPORTED, "neighbour rows longer than 128 are not supported (l0 %llu, upper %llu)", (unsigned long long)max_deg, (unsigned long long)max_up));

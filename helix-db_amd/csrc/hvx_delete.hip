@@ -52,7 +52,7 @@ namespace hvx {
 constexpr uint32_t kDelSrcCap = 4096;   // rows that hold the node, per layer
 constexpr uint32_t kDelRelCap = 4096;   // relink sources per layer (sorted in LDS)
 constexpr uint32_t kDelCandCap = 16384; // candidates per layer (one source's scores live in LDS)
-constexpr uint32_t kDelTop = 32;        // Mmax
+constexpr uint32_t kDelTop = 64;        // Mmax (round 6: degree limits up to 64 through the wide build of the fused step)
 constexpr uint32_t kDelMinLayers = 16;
 constexpr uint32_t kDelMark = 0xFFFFFFFFu;
 constexpr uint32_t kDelWaves = 4;  // wavefronts of a step workgroup (32 row groups of 8 lanes)
@@ -673,7 +673,7 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(256) void de
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// A step as ONE launch (round 6, the default when rows are at most kFuseRow ids wide): the reciprocal rows' matrices do not have to wait
+// A step as ONE launch (round 6): the reciprocal rows' matrices do not have to wait
 // for the source's prune -- the neighbours a source can gain are known before it (its closest candidates that its row does not hold: the
 // prune only decides which of them stay), and their rows do not change during the step until their own reciprocal update.  So every
 // workgroup of a layer derives the same task list -- task 0: the source's merged row, task t: "candidate t's row + the source" --, the
@@ -682,42 +682,54 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(256) void de
 // ticket per relinked row instead of two launches and up to 33 tickets (37 us per step -> see profiles/r06n_*).
 // ---------------------------------------------------------------------------------------------------------------------------------
 constexpr uint32_t kFuseWaves = 16;
-constexpr uint32_t kFuseRow = 35;     // ids of a reciprocal prune (row + the source); rows wider than kFuseRow - 1 take the two-launch steps
-constexpr uint32_t kFuseRS = 36;      // ids a reciprocal list has room for in LDS
+// NARROW: rows of at most 34 ids (degree limits <= 32 on canonical rows): a source's merged row <= 64 ids, a reciprocal list <= 35 -- one
+// candidate per lane, the matrix rows in registers (replay_rows).  WIDE (round 6): rows of up to 64 ids (the reference's scale fixture
+// runs M 32 / M0 64, scale_contracts.rs:167-173): merged row <= 128 ids, reciprocal list <= 65 -- two candidates per lane, rows streamed
+// (replay_rows2).
+template <bool WIDE> struct FuseT;
+template <> struct FuseT<false> {
+    static constexpr bool wide = false;
+    static constexpr uint32_t NCMAX = 64, OWN_RW = 64, ROWMAX = 35, RS = 36, RECIP_RW = 36, WSC = 128;
+};
+template <> struct FuseT<true> {
+    static constexpr bool wide = true;
+    static constexpr uint32_t NCMAX = 128, OWN_RW = 128, ROWMAX = 66, RS = 68, RECIP_RW = 96, WSC = kWide2Words;
+};
 // a prune's distances in HBM: the square matrix over [ids..., owner], row i = distances of id i to the others (row nc: the owner's), RW wide
-constexpr uint32_t kFuseOwnRW = 64, kFuseOwnDm = 65 * 64;
-constexpr uint32_t kFuseRecipRW = kFuseRS, kFuseRecipDm = kFuseRS * kFuseRS;
-constexpr uint32_t kFuseLayerDm = kFuseOwnDm + kDelTop * kFuseRecipDm; // floats of one layer's matrices
+template <typename T> constexpr uint32_t fuse_own_dm() { return (T::NCMAX + 1u) * T::OWN_RW; }
+template <typename T> constexpr uint32_t fuse_recip_dm() { return (T::ROWMAX + 1u) * T::RECIP_RW; }
+template <typename T> constexpr uint32_t fuse_layer_dm() { return fuse_own_dm<T>() + kDelTop * fuse_recip_dm<T>(); } // floats of one layer's matrices
 
 struct FuseLds {
-    uint32_t *rcur;       // [kDelTop][kFuseRS] the candidates' rows with the source appended
+    uint32_t *rcur;       // [kDelTop][RS] the candidates' rows with the source appended
     uint32_t *rdeg;       // [kDelTop] ids of that list; 0: the row holds the source already
-    uint32_t *cur, *oldl; // [64] the source's merged row / its row before
+    uint32_t *cur, *oldl; // [NCMAX] the source's merged row / [64] its row before
     uint32_t *addl;       // [kDelTop] the candidates the source's row does not hold, Candidate order
     uint32_t *isnew;      // [kDelTop] ... that stayed after the prune
     uint32_t *pbase;      // [kDelTop + 2] first pair of every task
-    uint32_t *wsc;        // [16][2][64] per-wavefront replay scratch
+    uint32_t *wsc;        // [16][WSC] per-wavefront replay scratch
     uint32_t *misc;       // [8]
 };
-__device__ __forceinline__ FuseLds carve_fuse(char *smem) {
+template <typename T> __device__ __forceinline__ FuseLds carve_fuse(char *smem) {
     FuseLds S;
     char *p = smem;
-    S.rcur = reinterpret_cast<uint32_t *>(p); p += kDelTop * kFuseRS * 4;
+    S.rcur = reinterpret_cast<uint32_t *>(p); p += kDelTop * T::RS * 4;
     S.rdeg = reinterpret_cast<uint32_t *>(p); p += kDelTop * 4;
-    S.cur = reinterpret_cast<uint32_t *>(p); p += 256;
+    S.cur = reinterpret_cast<uint32_t *>(p); p += T::NCMAX * 4;
     S.oldl = reinterpret_cast<uint32_t *>(p); p += 256;
     S.addl = reinterpret_cast<uint32_t *>(p); p += kDelTop * 4;
     S.isnew = reinterpret_cast<uint32_t *>(p); p += kDelTop * 4;
     S.pbase = reinterpret_cast<uint32_t *>(p); p += (kDelTop + 2) * 4 + 8;
-    S.wsc = reinterpret_cast<uint32_t *>(p); p += kFuseWaves * 2 * 256;
+    S.wsc = reinterpret_cast<uint32_t *>(p); p += kFuseWaves * T::WSC * 4;
     S.misc = reinterpret_cast<uint32_t *>(p);
     return S;
 }
-static size_t fuse_lds_bytes() {
-    return (size_t)kDelTop * kFuseRS * 4 + kDelTop * 4 * 3 + 512 + (kDelTop + 2) * 4 + 8 + kFuseWaves * 2 * 256 + 64;
+template <typename T> static size_t fuse_lds_bytes() {
+    return (size_t)kDelTop * T::RS * 4 + kDelTop * 4 * 3 + T::NCMAX * 4 + 256 + (kDelTop + 2) * 4 + 8 + kFuseWaves * T::WSC * 4 + 64;
 }
 
-template <uint32_t METRIC, bool FUSED, bool BF> __global__ __launch_bounds__(1024) void delete_step_fused_kernel(DeleteArgs a, uint32_t ri) {
+template <uint32_t METRIC, bool FUSED, bool BF, bool WIDE> __global__ __launch_bounds__(1024) void delete_step_fused_kernel(DeleteArgs a, uint32_t ri) {
+    using T = FuseT<WIDE>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t s_go, s_ncur, s_nadd, s_err, s_last, s_keepn;
     const DevIndex &ix = a.ix;
@@ -726,7 +738,7 @@ template <uint32_t METRIC, bool FUSED, bool BF> __global__ __launch_bounds__(102
     uint32_t L, g, G;
     if (blockIdx.x < a.g_own) { L = 0u; g = blockIdx.x; G = a.g_own; }
     else { L = 1u + (blockIdx.x - a.g_own) / a.g_recip; g = (blockIdx.x - a.g_own) % a.g_recip; G = a.g_recip; }
-    const FuseLds S = carve_fuse(smem);
+    const FuseLds S = carve_fuse<T>(smem);
     if (tid == 0) { s_go = (a.ctl[0] == 0u && ri < a.rel_cnt[L]) ? 1u : 0u; s_err = 0u; }
     __syncthreads();
     if (!s_go) return;
@@ -748,7 +760,7 @@ template <uint32_t METRIC, bool FUSED, bool BF> __global__ __launch_bounds__(102
         const bool add = tv != kSentinel && !in_old;
         const unsigned long long am = __ballot(add);
         const uint32_t nadd = (uint32_t)__builtin_popcountll(am), ncur = nold + nadd;
-        if (ncur <= 64u) {
+        if (ncur <= T::NCMAX) {
             if (lane < nold) S.cur[lane] = v;
             if (add) {
                 const uint32_t at = (uint32_t)__builtin_popcountll(am & lt);
@@ -760,7 +772,7 @@ template <uint32_t METRIC, bool FUSED, bool BF> __global__ __launch_bounds__(102
     }
     __syncthreads();
     const uint32_t ncur = s_ncur, nadd = s_nadd;
-    if (ncur > 64u) { if (g == 0u && tid == 0) atomicMax(&a.ctl[0], 5u); return; }
+    if (ncur > T::NCMAX) { if (g == 0u && tid == 0) atomicMax(&a.ctl[0], 5u); return; }
     for (uint32_t t = wave; t < nadd; t += kFuseWaves) { // the candidates' rows, the source appended (mutation.rs:1994-2006)
         const uint32_t nw = S.addl[t];
         uint32_t rstride;
@@ -770,13 +782,13 @@ template <uint32_t METRIC, bool FUSED, bool BF> __global__ __launch_bounds__(102
         const bool has = __ballot(rv == nb) != 0ull;
         if (has) {
             rdeg = 0u;
-        } else if (rdeg + 1u > kFuseRow) {
+        } else if (rdeg + 1u > T::ROWMAX) {
             if (lane == 0) s_err = 1u;
             rdeg = 0u;
-        } else {
-            if (lane == rdeg) rv = nb;
+        } else { // rows are canonical: the valid ids occupy lanes 0..rdeg-1; the source goes behind them (position 64 of a full wide row)
+            if (lane < rdeg) S.rcur[t * T::RS + lane] = rv;
+            if (lane == 0) S.rcur[t * T::RS + rdeg] = nb;
             ++rdeg;
-            if (lane < rdeg) S.rcur[t * kFuseRS + lane] = rv;
         }
         if (lane == 0) S.rdeg[t] = rdeg;
     }
@@ -798,7 +810,7 @@ template <uint32_t METRIC, bool FUSED, bool BF> __global__ __launch_bounds__(102
     }
     __syncthreads();
     const uint32_t total = S.pbase[kDelTop + 1u];
-    float *gl = a.gdm + (size_t)L * kFuseLayerDm;
+    float *gl = a.gdm + (size_t)L * fuse_layer_dm<T>();
     bool last;
     { // (the ticket is taken even when nothing needs a matrix: the last workgroup rewrites rows the others are still reading their tasks from)
         const int j = (int)(lane & 7u);
@@ -817,11 +829,11 @@ template <uint32_t METRIC, bool FUSED, bool BF> __global__ __launch_bounds__(102
             uint32_t node_i, node_j, nc, st;
             float *out;
             if (t == 0u) {
-                nc = ncur; st = kFuseOwnRW; out = gl;
+                nc = ncur; st = T::OWN_RW; out = gl;
                 node_i = i < nc ? S.cur[i] : nb; node_j = S.cur[jj];
             } else {
-                const uint32_t *rc = S.rcur + (t - 1u) * kFuseRS;
-                nc = S.rdeg[t - 1u]; st = kFuseRecipRW; out = gl + kFuseOwnDm + (size_t)(t - 1u) * kFuseRecipDm;
+                const uint32_t *rc = S.rcur + (t - 1u) * T::RS;
+                nc = S.rdeg[t - 1u]; st = T::RECIP_RW; out = gl + fuse_own_dm<T>() + (size_t)(t - 1u) * fuse_recip_dm<T>();
                 node_i = i < nc ? rc[i] : S.addl[t - 1u]; node_j = rc[jj];
             }
             const float d = pair_distance<METRIC, FUSED, BF>(ix, node_i, node_j, j);
@@ -841,12 +853,16 @@ template <uint32_t METRIC, bool FUSED, bool BF> __global__ __launch_bounds__(102
     // ---- the last workgroup.  The reciprocal prunes do not depend on the source's (only whether they are APPLIED does): wavefront 0
     // replays the source's prune while wavefronts 1 .. 15 replay the candidates' lists, then the rows of the candidates that stayed go out
     bool bad = false;
-    const WaveScratch W{S.wsc + wave * 128u, S.wsc + wave * 128u + 64u};
+    uint32_t *wsc = S.wsc + wave * T::WSC;
+    const WaveScratch W{wsc, wsc + (T::wide ? 256u + 512u + 128u : 64u)}; // (W.kept = the replay's kept list in either layout)
     const uint32_t first = wave - 1u; // (wavefront 0: none)
     __syncthreads();
     if (wave == 0) {
         uint32_t keepn = ncur;
-        if (ncur > maxn) keepn = replay_rows<(int)kFuseOwnRW>(gl, S.cur, ncur, maxn, lane, W, &bad);
+        if (ncur > maxn) {
+            if constexpr (T::wide) keepn = replay_rows2<(int)T::OWN_RW>(gl, S.cur, ncur, maxn, lane, wsc, &bad);
+            else keepn = replay_rows<(int)T::OWN_RW>(gl, S.cur, ncur, maxn, lane, W, &bad);
+        }
         else { if (lane < ncur) W.kept[lane] = S.cur[lane]; lds_order(); }
         const uint32_t kf = lane < keepn ? W.kept[lane] : kSentinel;
         const uint32_t at = lane < nadd ? S.addl[lane] : kSentinel;
@@ -860,10 +876,13 @@ template <uint32_t METRIC, bool FUSED, bool BF> __global__ __launch_bounds__(102
         for (uint32_t t = first; t < nadd; t += kFuseWaves - 1u) {
             const uint32_t rdeg = S.rdeg[t];
             if (rdeg == 0u) continue;
-            uint32_t *rc = S.rcur + t * kFuseRS;
+            uint32_t *rc = S.rcur + t * T::RS;
             if (rdeg > maxn) {
                 bool rbad = false;
-                const uint32_t kn = replay_rows<(int)kFuseRecipRW>(gl + kFuseOwnDm + (size_t)t * kFuseRecipDm, rc, rdeg, maxn, lane, W, &rbad);
+                const float *gm = gl + fuse_own_dm<T>() + (size_t)t * fuse_recip_dm<T>();
+                uint32_t kn;
+                if constexpr (T::wide) kn = replay_rows2<(int)T::RECIP_RW>(gm, rc, rdeg, maxn, lane, wsc, &rbad);
+                else kn = replay_rows<(int)T::RECIP_RW>(gm, rc, rdeg, maxn, lane, W, &rbad);
                 if (lane < kn) rc[lane] = W.kept[lane]; // the list is replaced by what stays of it
                 if (lane == 0) { S.rdeg[t] = kn; if (rbad) atomicMax(&a.ctl[0], 4u); }
                 lds_order();
@@ -878,7 +897,7 @@ template <uint32_t METRIC, bool FUSED, bool BF> __global__ __launch_bounds__(102
         if (!S.isnew[t] || kn == 0u) continue;
         uint32_t rstride;
         uint32_t *rrow = del_row(a, S.addl[t], L, rstride);
-        if (kn <= rstride) store_canonical_reg(rrow, rstride, lane < kn ? S.rcur[t * kFuseRS + lane] : kSentinel, kn, lane);
+        if (kn <= rstride) store_canonical_reg(rrow, rstride, lane < kn ? S.rcur[t * T::RS + lane] : kSentinel, kn, lane);
         else if (lane == 0) atomicMax(&a.ctl[0], 5u);
     }
 }
@@ -898,14 +917,15 @@ __global__ __launch_bounds__(256) void delete_best_entry_kernel(DevIndex ix, con
 
 using DeleteKernel = void (*)(DeleteArgs);
 using DeleteStepKernel = void (*)(DeleteArgs, uint32_t);
-struct DeleteKernels { DeleteKernel rank, relink; DeleteStepKernel own, recip, fused; };
+struct DeleteKernels { DeleteKernel rank, relink; DeleteStepKernel own, recip, fused, fused_wide; };
 template <uint32_t METRIC, bool FUSED> static DeleteKernels delete_kernels_of() {
     return {delete_rank_kernel<METRIC, FUSED, false>, delete_relink_kernel<METRIC, FUSED>, delete_step_own_kernel<METRIC, FUSED>, delete_step_recip_kernel<METRIC, FUSED>,
-            delete_step_fused_kernel<METRIC, FUSED, false>};
+            delete_step_fused_kernel<METRIC, FUSED, false, false>, delete_step_fused_kernel<METRIC, FUSED, false, true>};
 }
 // bf16 images: the ranking and the fused steps read the interleaved rows (the one-wavefront kernel only retires the node there)
 template <uint32_t METRIC> static DeleteKernels delete_kernels_bf16() {
-    return {delete_rank_kernel<METRIC, true, true>, delete_relink_kernel<METRIC, true>, nullptr, nullptr, delete_step_fused_kernel<METRIC, true, true>};
+    return {delete_rank_kernel<METRIC, true, true>, delete_relink_kernel<METRIC, true>, nullptr, nullptr, delete_step_fused_kernel<METRIC, true, true, false>,
+            delete_step_fused_kernel<METRIC, true, true, true>};
 }
 static DeleteKernels pick_delete_kernels(uint32_t metric, bool fused, bool bf16) {
     if (bf16) return metric == kL2 ? delete_kernels_bf16<kL2>() : delete_kernels_bf16<kCosine>();
@@ -931,7 +951,7 @@ extern "C" int hvx_index_delete_batch(hvx_index *ix, const uint64_t *node_ids, u
     const uint32_t m = ix->desc.m ? ix->desc.m : 16u;
     const uint32_t m0 = std::max(ix->desc.m0 ? ix->desc.m0 : 2u * m, 2u * m);
     if (m0 > kDelTop || m > kDelTop || d.s0 > 64u || d.su > 64u || d.s0 < m0 || d.su < m)
-        return fail(HVX_ERR_UNSUPPORTED, "device delete serves degree limits <= 32 on rows at least that wide (m %u m0 %u strides %u / %u)", m, m0, d.su, d.s0);
+        return fail(HVX_ERR_UNSUPPORTED, "device delete serves degree limits <= 64 on rows at least that wide and at most 64 ids (m %u m0 %u strides %u / %u)", m, m0, d.su, d.s0);
     const auto t0 = std::chrono::steady_clock::now();
     hipStream_t s = ix->stream;
     const uint64_t cap = std::max<uint64_t>(ix->cap_rows, d.n);
@@ -946,7 +966,7 @@ extern "C" int hvx_index_delete_batch(hvx_index *ix, const uint64_t *node_ids, u
     if (!ix->del_scratch || ix->del_layers < layers_now) {
         const uint32_t layers = std::max(kDelMinLayers, layers_now);
         const size_t per_layer = ((size_t)kDelSrcCap + kDelRelCap + kDelCandCap + (size_t)kDelRelCap * kDelTop + kDelRelCap + words + 4u + kDelTop +
-                                  (size_t)(1u + kDelTop) * (kDelDm + 1u)) * 4u;
+                                  std::max<size_t>((size_t)(1u + kDelTop) * (kDelDm + 1u), (size_t)fuse_layer_dm<FuseT<true>>() + 2u + kDelTop)) * 4u;
         void *p = nullptr;
         if ((rc = ix->dalloc(&p, per_layer * layers + 64))) return rc;
         HIP_TRY(hipMemsetAsync(p, 0, per_layer * layers + 64, s));
@@ -968,7 +988,7 @@ extern "C" int hvx_index_delete_batch(hvx_index *ix, const uint64_t *node_ids, u
         a.cand = p; p += (size_t)layers * kDelCandCap;
         a.top_cnt = p; p += (size_t)layers * kDelRelCap;
         a.top = p; p += (size_t)layers * kDelRelCap * kDelTop;
-        a.gdm = reinterpret_cast<float *>(p); p += (size_t)layers * (1u + kDelTop) * kDelDm;
+        a.gdm = reinterpret_cast<float *>(p); p += (size_t)layers * std::max<size_t>((size_t)(1u + kDelTop) * kDelDm, fuse_layer_dm<FuseT<true>>());
         a.tick = p; p += (size_t)layers * (1u + kDelTop);
         a.mark = p;
     }
@@ -986,16 +1006,21 @@ extern "C" int hvx_index_delete_batch(hvx_index *ix, const uint64_t *node_ids, u
     const bool steps = ix->opt[HVX_OPT_DELETE_SEQUENTIAL] != 1u;
     // one launch per step while a reciprocal list (row + the source) fits the fused kernel's LDS matrices; HVX_OPT_DELETE_SEQUENTIAL = 2
     // keeps the two-launch steps (A/B, and what wider rows take)
-    const bool fused_steps = steps && ix->opt[HVX_OPT_DELETE_SEQUENTIAL] != 2u && d.s0 + 1u <= kFuseRow && d.su + 1u <= kFuseRow;
+    const bool narrow = d.s0 + 1u <= FuseT<false>::ROWMAX && d.su + 1u <= FuseT<false>::ROWMAX && m0 <= 32u && m <= 32u;
+    const bool fused_steps = steps && (ix->opt[HVX_OPT_DELETE_SEQUENTIAL] != 2u || !narrow); // (rows of up to 64 ids: the wide build of the fused step)
     if (bf16 && !fused_steps)
-        return fail(HVX_ERR_UNSUPPORTED, "a bf16 image relinks by fused steps only (rows of at most %u ids, HVX_OPT_DELETE_SEQUENTIAL unset)", kFuseRow - 1u);
+        return fail(HVX_ERR_UNSUPPORTED, "a bf16 image relinks by fused steps only (HVX_OPT_DELETE_SEQUENTIAL unset)");
+    if (!narrow && !fused_steps)
+        return fail(HVX_ERR_UNSUPPORTED, "rows wider than 34 ids / degree limits above 32 relink by fused steps only (HVX_OPT_DELETE_SEQUENTIAL unset)");
+    const DeleteStepKernel fused_kernel = narrow ? kern.fused : kern.fused_wide;
+    const size_t fused_lds = narrow ? fuse_lds_bytes<FuseT<false>>() : fuse_lds_bytes<FuseT<true>>();
     const uint32_t groups = kDelWaves * 8u;
     if (fused_steps) {
         // workgroups (128 row groups each) of layer 0 / of every upper layer: a typical step has ~8 000 pairs on layer 0 (the source's
-        // <= 2 080 and ~10 reciprocal lists of 561), at most 20 032
-        a.g_own = 96u;
-        a.g_recip = 12u;
-        HIP_TRY(hipFuncSetAttribute((const void *)kern.fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fuse_lds_bytes()));
+        // <= 2 080 and ~10 reciprocal lists of 561), at most 20 032; the wide build: <= 8 256 + 64 x 2 145
+        a.g_own = narrow ? 96u : 192u;
+        a.g_recip = narrow ? 12u : 24u;
+        HIP_TRY(hipFuncSetAttribute((const void *)fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));
     } else {
         // workgroups (32 row groups each) that share one prune's distance matrix: about one pair per row group.  A source's row grows to
         // at most 64 ids (65 x 64 / 2 pairs), a reciprocal row to Mmax + 1
@@ -1042,7 +1067,7 @@ extern "C" int hvx_index_delete_batch(hvx_index *ix, const uint64_t *node_ids, u
         }
         for (uint32_t ri = 0; steps && ri < n_steps; ++ri) { // (a step past a layer's last source returns at once)
             if (fused_steps) {
-                hipLaunchKernelGGL(kern.fused, dim3(a.g_own + (a.layers - 1u) * a.g_recip), dim3(kFuseWaves * 64u), fuse_lds_bytes(), s, a, ri);
+                hipLaunchKernelGGL(fused_kernel, dim3(a.g_own + (a.layers - 1u) * a.g_recip), dim3(kFuseWaves * 64u), fused_lds, s, a, ri);
                 continue;
             }
             hipLaunchKernelGGL(kern.own, dim3(a.layers, a.g_own), dim3(kDelWaves * 64u), step_lds, s, a, ri);

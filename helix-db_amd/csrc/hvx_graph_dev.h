@@ -244,4 +244,106 @@ __device__ __forceinline__ void store_canonical_reg(uint32_t *row, uint32_t stri
     if (lane < ns) st_row(row + rank, mine);
 }
 
+
+// The same replay for prunes of up to 128 ids (degree limits up to 64: the reference's scale fixture runs M 32 / M0 64,
+// scale_contracts.rs:167-173): two candidates per lane (c = lane, lane + 64), 128-bit masks, the matrix rows STREAMED (32 floats at a
+// time: only "closer than the owner" bits are kept), Candidate order and the masks in rank order through LDS.  RW = row width of G in
+// floats, a multiple of 32.  W2: per-wavefront scratch of kWide2Words uint32 (keys [128] u64 | conf [128][4] | ord [128] | kept [64]).
+constexpr uint32_t kWide2Words = 128 * 2 + 128 * 4 + 128 + 64;
+template <int RW>
+__device__ __forceinline__ uint32_t replay_rows2(const float *G, const uint32_t *cur, uint32_t nc, uint32_t maxn, uint32_t lane, uint32_t *W2, bool *bad) {
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(W2);
+    uint32_t *conf = W2 + 256, *ord = W2 + 256 + 512, *kept = W2 + 256 + 512 + 128;
+    float d[2];
+    uint32_t v[2], rank[2];
+    unsigned long long key[2];
+    bool isbad = false;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const uint32_t c = lane + 64u * (uint32_t)s;
+        const bool valid = c < nc;
+        d[s] = valid ? ld_agent(G + (size_t)nc * RW + c) : 0.f;
+        v[s] = valid ? cur[c] : kSentinel;
+        float chk = d[s];
+        isbad |= valid && !score_valid(chk);
+        key[s] = valid ? ((unsigned long long)__float_as_uint(d[s] + 0.0f) << 32) | v[s] : (0xFFFFFFFFull << 32) | c;
+        keys[c] = key[s];
+        rank[s] = 0;
+    }
+    if (__ballot(isbad) != 0ull) *bad = true;
+    lds_order();
+    for (uint32_t t = 0; t < nc; ++t) { // Candidate order: score, then id
+        const unsigned long long kt = keys[t];
+        rank[0] += kt < key[0] ? 1u : 0u;
+        rank[1] += kt < key[1] ? 1u : 0u;
+    }
+    const unsigned long long alo = nc >= 64u ? ~0ull : (1ull << nc) - 1ull;
+    const unsigned long long ahi = nc <= 64u ? 0ull : (nc >= 128u ? ~0ull : (1ull << (nc - 64u)) - 1ull);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const uint32_t c = lane + 64u * (uint32_t)s;
+        if (c >= nc) continue;
+        // bit t of conf(c) <=> candidate t is strictly closer to c than the owner is
+        unsigned long long lo = 0ull, hi = 0ull;
+        const unsigned long long *rp = reinterpret_cast<const unsigned long long *>(G + (size_t)c * RW);
+#pragma unroll
+        for (int ch = 0; ch < RW / 32; ++ch) {
+            unsigned long long x[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) x[u] = ld_agent(rp + ch * 16 + u);
+            unsigned long long bits = 0ull;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const float d0 = __uint_as_float((uint32_t)x[u]), d1 = __uint_as_float((uint32_t)(x[u] >> 32));
+                bits |= (unsigned long long)((d0 < d[s] ? 1u : 0u) | (d1 < d[s] ? 2u : 0u)) << (2 * u);
+            }
+            // 32 columns: ch * 32 ..
+            if (ch == 0) lo |= bits;
+            else if (ch == 1) lo |= bits << 32;
+            else if (ch == 2) hi |= bits;
+            else if (ch == 3) hi |= bits << 32;
+        }
+        lo &= alo; hi &= ahi;
+        if (c < 64u) lo &= ~(1ull << c); else hi &= ~(1ull << (c - 64u));
+        const uint32_t r = rank[s];
+        conf[r * 4u + 0u] = (uint32_t)lo; conf[r * 4u + 1u] = (uint32_t)(lo >> 32);
+        conf[r * 4u + 2u] = (uint32_t)hi; conf[r * 4u + 3u] = (uint32_t)(hi >> 32);
+        ord[r] = c;
+    }
+    lds_order();
+    unsigned long long slo = 0ull, shi = 0ull, rlo = 0ull, rhi = 0ull; // selected by index / by rank
+    uint32_t ns = 0;
+    for (uint32_t r = 0; r < nc && ns < maxn; ++r) {
+        const unsigned long long clo = ((unsigned long long)conf[r * 4u + 1u] << 32) | conf[r * 4u + 0u];
+        const unsigned long long chi = ((unsigned long long)conf[r * 4u + 3u] << 32) | conf[r * 4u + 2u];
+        if ((clo & slo) | (chi & shi)) continue;
+        const uint32_t ci = ord[r];
+        if (ci < 64u) slo |= 1ull << ci; else shi |= 1ull << (ci - 64u);
+        if (r < 64u) rlo |= 1ull << r; else rhi |= 1ull << (r - 64u);
+        ++ns;
+    }
+    // rank r = lane, lane + 64: the selected ones to their slots in selection order, then the backfill: the others, closest first
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t nsel = ns;
+    const unsigned long long flo = ~rlo & alo, fhi = ~rhi & ahi; // (the live ids hold the first nc ranks)
+    const uint32_t nfree = (uint32_t)__builtin_popcountll(flo) + (uint32_t)__builtin_popcountll(fhi);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const uint32_t r = lane + 64u * (uint32_t)s;
+        if (r >= nc) continue;
+        const uint32_t id = cur[ord[r]];
+        const bool sel = s == 0 ? ((rlo >> lane) & 1ull) != 0ull : ((rhi >> lane) & 1ull) != 0ull;
+        if (sel) {
+            const uint32_t slot = s == 0 ? (uint32_t)__builtin_popcountll(rlo & lt) : (uint32_t)__builtin_popcountll(rlo) + (uint32_t)__builtin_popcountll(rhi & lt);
+            kept[slot] = id;
+        } else if (nsel < maxn) {
+            const uint32_t rk = s == 0 ? (uint32_t)__builtin_popcountll(flo & lt) : (uint32_t)__builtin_popcountll(flo) + (uint32_t)__builtin_popcountll(fhi & lt);
+            if (nsel + rk < maxn) kept[nsel + rk] = id;
+        }
+    }
+    if (nsel < maxn) ns = nsel + nfree < maxn ? nsel + nfree : maxn;
+    lds_order();
+    return ns;
+}
+
 } // namespace hvx

@@ -147,7 +147,7 @@ enum hvx_option {
                                         handle runs one query per SIMD (hvx_index_set_occupancy(1): one batch in flight), 1 = never,
                                         2 = always where it is built, 3 = always, with ONE gatherer even where three are built */
     HVX_OPT_DELETE_SEQUENTIAL = 10,  /* 0: one fused launch per relinked row (round 6); 1: every source in the one-wavefront kernel; 2: two launches per row
-                                        (what rows wider than 34 ids take) -- all three produce the reference's rows */
+                                        (rows of at most 34 ids, degree limits <= 32) -- all three produce the reference's rows */
     HVX_OPT_RESTRICTED_DIRECT = 11,  /* restricted exact scans of k <= 64: 0 = the one-launch reference-order kernel (csrc/hvx_restricted_exact.hip) where it is
                                         the cheaper one (b x candidates x dim <= 2^31), 1 = never, 2 = always */
     HVX_OPT_RESTRICTED_EXACT_MIB = 12, /* device plan of HVX_RESTRICTED_AUTO: candidate sets whose rows take at most this many MiB are scanned
@@ -702,7 +702,7 @@ int hvx_index_insert_batch(hvx_index *, const uint64_t *node_ids /*[count]*/, co
  * hvx_index_live_rows does not; hvx_index_export_graph returns empty rows for it.  Same generation rules as
  * hvx_index_insert_batch: owner handle only, visible_seq + 1 per call that deleted something, forks adopt with hvx_index_refresh.
  * Its id comes back through hvx_index_upsert_batch (into the same slot), not through hvx_index_insert_batch (ids ascend).
- * f32 and bf16 images (bf16: rows of at most 34 ids, relinked on the rounded vectors), degree limits <= 32; fp8 images are refused.
+ * f32 and bf16 images (bf16: relinked on the rounded vectors), degree limits <= 64 on rows of at most 64 ids; fp8 images are refused.
  * HVX_ERR_UNSUPPORTED when more than 4 096 rows of one layer hold a node or their joint
  * neighbourhood exceeds 16 384 rows (after such a failure the image is partially relinked: discard the handle).
  */

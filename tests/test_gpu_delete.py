@@ -378,3 +378,42 @@ def test_deletes_on_a_bf16_image_equal_the_oracle_on_the_rounded_rows(orc, hv, n
         gix.upsert_batch(np.asarray(live[:1], np.uint64), data[:1], ef_construction=80)
     assert_same_graph(gix, oix, ids, deleted)
     gix.close()
+
+
+@pytest.mark.parametrize("n,dim,metric,dtype", [(700, 64, 1, "f32"), (600, 128, 0, "f32"), (500, 128, 1, "bf16")])
+def test_deletes_on_an_m32_m0_64_graph_equal_the_oracle(orc, hv, n, dim, metric, dtype):
+    """The reference's scale fixture runs M = 32 / M0 = 64 (scale_contracts.rs:167-173): rows of up to 64 ids, a source's merged row of up
+    to 128, reciprocal lists of 65 -- the WIDE build of the fused step (two candidates per lane, 128-bit masks, matrix rows streamed).
+    Rows, entry point and top layer equal the oracle's sequential deletes after two batches; searches equal the oracle's afterwards."""
+    rng = np.random.default_rng(6400 + dim + metric)
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    rows = fx.round_bf16(data) if dtype == "bf16" else data
+    lv = fx.draw_levels(n, 32, seed=n + 1)
+    ids = np.arange(n, dtype=np.uint64) * 2 + 3
+    oix = orc.Index(dim, metric, kernel=orc.K_AVX_FMA, m=32, m0=64, ef_construction=120)
+    for i in range(n):
+        assert oix.insert(int(ids[i]), rows[i], int(lv[i])) == orc.OK
+    ex = oix.export()
+    assert max(np.diff(ex["l0_offsets"].astype(np.int64))) > 34           # rows the narrow build does not serve
+    ex["vectors"] = data
+    gix = hv.ValidatedVectorReadIndex.from_export(ex, dim=dim, metric=metric, m=32, m0=64, dtype=hv.BF16 if dtype == "bf16" else hv.F32)
+    assert_same_graph(gix, oix, ids, ())
+    perm = rng.permutation(n)
+    deleted = []
+    for bi, b in enumerate([perm[: n // 14], perm[n // 14: n // 6]]):
+        want = [int(x) for x in ids[b] if int(x) not in deleted]
+        ent = oix.entry()[0]
+        if ent not in want and ent not in deleted:
+            want.insert(len(want) // 2, ent)
+        for d in want:
+            assert oix.delete(d) == (orc.OK, True)
+        stb = gix.delete_batch(np.asarray(want, np.uint64))
+        deleted += want
+        assert stb["deleted"] == len(want) and stb["relinked_rows"] > 0
+        assert_same_graph(gix, oix, ids, deleted)
+    q = rng.standard_normal((12, dim)).astype(np.float32)
+    gid, gsc, gcnt, _ = gix.search_batch(q, hv.SearchParams(10).with_ef(64))
+    for qi in range(q.shape[0]):
+        rc, oid, osc = oix.search(q[qi], 10, 64)
+        assert gid[qi, :gcnt[qi]].tolist() == oid.tolist() and bits(gsc[qi, :gcnt[qi]]).tolist() == bits(osc).tolist()
+    gix.close()

@@ -38,6 +38,7 @@
 
 #include "hvx_host.h"
 #include "hvx_graph_dev.h"
+#include "hvx_toplist.h"
 
 using namespace hvx;
 
@@ -54,7 +55,6 @@ constexpr uint32_t kDelRelCap = 4096;   // relink sources per layer (sorted in L
 constexpr uint32_t kDelCandCap = 16384; // candidates per layer (one source's scores live in LDS)
 constexpr uint32_t kDelTop = 64;        // Mmax (round 6: degree limits up to 64 through the wide build of the fused step)
 constexpr uint32_t kDelMinLayers = 16;
-constexpr uint32_t kDelMark = 0xFFFFFFFFu;
 constexpr uint32_t kDelWaves = 4;  // wavefronts of a step workgroup (32 row groups of 8 lanes)
 constexpr uint32_t kDelDm = 65 * 64; // one prune's distance matrix
 
@@ -253,9 +253,8 @@ __device__ __forceinline__ float pair_distance(const DevIndex &ix, uint32_t ni, 
 }
 
 // relink_neighbor's ranking (mutation.rs:1936-1957) for every source of every layer: distances to all candidates, the Mmax smallest
-template <uint32_t METRIC, bool FUSED, bool BF> __global__ __launch_bounds__(256) void delete_rank_kernel(DeleteArgs a) {
+template <uint32_t METRIC, bool FUSED, bool BF> __global__ __launch_bounds__(1024) void delete_rank_kernel(DeleteArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ unsigned long long red[4];
     __shared__ uint32_t s_bad;
     const DevIndex &ix = a.ix;
     const uint32_t L = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -267,75 +266,53 @@ template <uint32_t METRIC, bool FUSED, bool BF> __global__ __launch_bounds__(256
     if (nr == 0u || nc == 0u) return;
     const uint32_t maxn = L == 0u ? a.m0 : a.m;
     float *qv = reinterpret_cast<float *>(smem);
-    uint32_t *sc = reinterpret_cast<uint32_t *>(smem + (((size_t)ix.ld * 4u + 15u) & ~(size_t)15u));
+    // Round 6: sixteen wavefronts; every wavefront keeps the Mmax smallest (score, id) pairs of ITS candidates in a register list
+    // (hvx_toplist.h), the lists meet in LDS and wavefront 0 merges them -- rounds 3-5 kept every score in LDS and ran Mmax block-wide
+    // arg-min reductions per source (59 us per delete)
+    float *m_sc = reinterpret_cast<float *>(smem + (((size_t)ix.ld * 4u + 15u) & ~(size_t)15u));
+    uint32_t *m_id = reinterpret_cast<uint32_t *>(m_sc + 16 * 64);
     const uint32_t *cand = a.cand + (size_t)L * kDelCandCap;
     for (uint32_t ri = blockIdx.x; ri < nr; ri += gridDim.x) {
         const uint32_t r = a.rel[(size_t)L * kDelRelCap + ri];
         __syncthreads();
         if constexpr (BF) { // the source's row as f32, element order
             const uint16_t *rb = ix.vecb + (size_t)r * ix.dim;
-            for (uint32_t t = tid; t < ix.dim; t += 256u) qv[t] = bf16_to_f32(rb[bf16_slot_of(t)]);
+            for (uint32_t t = tid; t < ix.dim; t += 1024u) qv[t] = bf16_to_f32(rb[bf16_slot_of(t)]);
         } else {
             const float *rv = ix.vec + (size_t)r * ix.ld;
-            for (uint32_t t = tid; t < ix.ld; t += 256u) qv[t] = rv[t];
+            for (uint32_t t = tid; t < ix.ld; t += 1024u) qv[t] = rv[t];
         }
         __syncthreads();
         const float rh = ix.hdr[r];
         bool bad = false;
-        for (uint32_t c0 = 0; c0 < nc; c0 += 32u) {
+        TopList l;
+        l.init();
+        for (uint32_t c0 = 0; c0 < nc; c0 += 128u) {
             const uint32_t idx = c0 + wave * 8u + (uint32_t)grp;
             const uint32_t c = cand[idx < nc ? idx : nc - 1u];
             float d;
             if constexpr (BF) d = group_distance_bf16<METRIC == kL1 ? kL2 : METRIC>(ix, qv, rh, c, j);
             else d = group_distance<METRIC, FUSED>(ix, qv, rh, c, j);
-            if (idx < nc && j == 0) {
-                uint32_t bits = kDelMark; // (the source itself is no candidate of its own relink: :1937-1939)
-                if (c != r) {
-                    if (score_valid(d)) bits = __float_as_uint(d);
-                    else bad = true; // Candidate::try_new fails: the reference aborts the delete
-                }
-                sc[idx] = bits;
-            }
+            bool take = idx < nc && j == 0 && c != r; // (the source itself is no candidate of its own relink: :1937-1939)
+            if (take && !score_valid(d)) { bad = true; take = false; } // Candidate::try_new fails: the reference aborts the delete
+            l.offer(take, d, c, maxn, (int)lane);
         }
-        if (bad) s_bad = 1u;
+        if (__ballot(bad) != 0ull && lane == 0) s_bad = 1u;
+        m_sc[wave * 64u + lane] = l.sc;
+        m_id[wave * 64u + lane] = l.id;
         __syncthreads();
-        auto local_best = [&]() -> unsigned long long {
-            unsigned long long best = ~0ull;
-            for (uint32_t i = tid; i < nc; i += 256u) {
-                const uint32_t b = sc[i];
-                if (b == kDelMark) continue;
-                const unsigned long long key = ((unsigned long long)b << 32) | cand[i]; // Candidate order: score, then id (rows ascend with ids)
-                best = key < best ? key : best;
+        if (wave == 0) {
+            TopList m;
+            m.init();
+            for (uint32_t w = 0; w < 16u; ++w) {
+                const uint32_t id = m_id[w * 64u + lane];
+                m.offer(id != kSentinel && lane < maxn, m_sc[w * 64u + lane], id, maxn, (int)lane);
             }
-            return best;
-        };
-        unsigned long long best = local_best();
-        uint32_t got = 0;
-        uint32_t *out = a.top + ((size_t)L * kDelRelCap + ri) * kDelTop;
-        for (uint32_t t = 0; t < maxn; ++t) {
-            unsigned long long w = best;
-#pragma unroll
-            for (int s = 32; s > 0; s >>= 1) {
-                const unsigned long long o = __shfl_xor(w, s, 64);
-                w = o < w ? o : w;
-            }
-            if (lane == 0) red[wave] = w;
-            __syncthreads();
-            unsigned long long win = red[0];
-            win = red[1] < win ? red[1] : win;
-            win = red[2] < win ? red[2] : win;
-            win = red[3] < win ? red[3] : win;
-            if (win == ~0ull) break; // (uniform: every thread reads the same four words)
-            if (tid == 0) out[t] = (uint32_t)win;
-            got = t + 1u;
-            if (best == win) { // this thread's: take it out and look again
-                for (uint32_t i = tid; i < nc; i += 256u)
-                    if (cand[i] == (uint32_t)win) sc[i] = kDelMark;
-                best = local_best();
-            }
-            __syncthreads();
+            const uint32_t got = m.count < maxn ? m.count : maxn;
+            uint32_t *out = a.top + ((size_t)L * kDelRelCap + ri) * kDelTop;
+            if (lane < got) out[lane] = m.id;
+            if (lane == 0) a.top_cnt[(size_t)L * kDelRelCap + ri] = got;
         }
-        if (tid == 0) a.top_cnt[(size_t)L * kDelRelCap + ri] = got;
     }
     __syncthreads();
     if (tid == 0 && s_bad) atomicMax(&a.ctl[0], 4u);
@@ -998,7 +975,7 @@ extern "C" int hvx_index_delete_batch(hvx_index *ix, const uint64_t *node_ids, u
     a.dead = ix->d_dead;
     HIP_TRY(hipMemsetAsync(a.ctl, 0, 16, s));
     const DeleteKernels kern = pick_delete_kernels(d.metric, kernel_fused(d.fkernel), bf16);
-    const size_t rank_lds = (((size_t)d.ld * 4u + 15u) & ~(size_t)15u) + (size_t)kDelCandCap * 4u;
+    const size_t rank_lds = (((size_t)d.ld * 4u + 15u) & ~(size_t)15u) + 16u * 64u * 8u;
     const size_t relink_lds = (((size_t)d.ld * 4u + 15u) & ~(size_t)15u) + 4 * 256 + 256;
     if (rank_lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kern.rank, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_lds));
     if (relink_lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kern.relink, hipFuncAttributeMaxDynamicSharedMemorySize, (int)relink_lds));
@@ -1058,7 +1035,7 @@ extern "C" int hvx_index_delete_batch(hvx_index *ix, const uint64_t *node_ids, u
             if (!ix->del_ev) HIP_TRY(hipEventCreateWithFlags(&ix->del_ev, hipEventDisableTiming));
             HIP_TRY(hipEventRecord(ix->del_ev, s));
         }
-        hipLaunchKernelGGL(kern.rank, dim3(64, a.layers), dim3(256), rank_lds, s, a);
+        hipLaunchKernelGGL(kern.rank, dim3(64, a.layers), dim3(1024), rank_lds, s, a);
         if (steps) {
             HIP_TRY(hipEventSynchronize(ix->del_ev));
             uint32_t most = 0;

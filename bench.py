@@ -57,7 +57,7 @@ def log(*a):
 HEADLINE_KERNEL = "hnsw_wave_kernel<1u, 3, 24, false, false, false, true, 2, false>"
 
 
-def measure_traffic_pass(args, timeout_s=300):
+def measure_traffic_pass(args, timeout_s=150):
     """roofline.traffic of THIS run: a child `rocprofv3 --pmc FETCH_SIZE TCC_EA0_RDREQ_sum --kernel-trace` pass of the headline leg of this
     command (its own pass, counters + kernel trace only -- MI355X_MICROARCH.md, HBM section), FETCH_SIZE KiB x 1024 x 2 (gfx950 reports
     half of a wide coalesced read), mean over the headline kernel's 3 warm-up + 6 timed launches; cross-check TCC_EA0_RDREQ_sum x 128 B.

@@ -239,7 +239,7 @@ constexpr uint32_t kSeqLinkDm = kSeqRS * kSeqRS;
 constexpr uint32_t kSeqLayerDm = kSeqSelDm + 32u * kSeqLinkDm;
 constexpr uint32_t kSeqPairs = 128;              // (row, victim) removals one layer's links can log
 
-template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(256) void build_select_seq_kernel(BuildArgs a) {
+template <uint32_t METRIC, bool FUSED, bool BF> __global__ __launch_bounds__(256) void build_select_seq_kernel(BuildArgs a) {
     __shared__ uint32_t s_cid[64], s_wsc[128], s_last;
     const DevIndex &ix = a.ix;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
@@ -266,7 +266,7 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(256) void bu
             uint32_t i, jj;
             pair_of(q, i, jj); // 0 <= jj < i < hyd
             const uint32_t ni = s_cid[i], nj = s_cid[jj];
-            const float d = group_distance<METRIC, FUSED>(ix, ix.vec + (size_t)ni * ix.ld, ix.hdr[ni], nj, j);
+            const float d = pair_distance<METRIC, FUSED, BF>(ix, ni, nj, j);
             if (j == 0) { st_agent(gl + i * 64u + jj, d); st_agent(gl + jj * 64u + i, d); }
         }
         stores_done(); // the stores have been acknowledged before the ticket is taken
@@ -313,7 +313,7 @@ __device__ __forceinline__ SeqLds carve_seq(char *smem) {
 }
 static size_t seq_lds_bytes() { return (size_t)(2 * 32 * kSeqRS + 5 * 32 + 2 * kSeqPairs + 36 + 16 * 128) * 4; }
 
-template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(1024) void build_link_seq_kernel(BuildArgs a) {
+template <uint32_t METRIC, bool FUSED, bool BF> __global__ __launch_bounds__(1024) void build_link_seq_kernel(BuildArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t s_err, s_last, s_np;
     const DevIndex &ix = a.ix;
@@ -381,7 +381,7 @@ template <uint32_t METRIC, bool FUSED> __global__ __launch_bounds__(1024) void b
             const uint32_t *rc = S.rcur + t * kSeqRS;
             const uint32_t nc = S.rdeg[t];
             const uint32_t node_i = i < nc ? rc[i] : S.to[t], node_j = rc[jj];
-            const float d = group_distance<METRIC, FUSED>(ix, ix.vec + (size_t)node_i * ix.ld, ix.hdr[node_i], node_j, j);
+            const float d = pair_distance<METRIC, FUSED, BF>(ix, node_i, node_j, j);
             if (j == 0) {
                 float *out = gl + (size_t)t * kSeqLinkDm;
                 st_agent(out + i * kSeqRS + jj, d);
@@ -825,12 +825,17 @@ struct BuildKernels {
     BuildKernel select_seq, link_seq;  // one node per step
 };
 template <uint32_t METRIC, bool FUSED> static BuildKernels build_kernels_of() {
-    BuildKernels k{build_select_kernel<METRIC, FUSED>, build_link_kernel<METRIC, FUSED>, nullptr, build_select_seq_kernel<METRIC, FUSED>,
-                   build_link_seq_kernel<METRIC, FUSED>};
+    BuildKernels k{build_select_kernel<METRIC, FUSED>, build_link_kernel<METRIC, FUSED>, nullptr, build_select_seq_kernel<METRIC, FUSED, false>,
+                   build_link_seq_kernel<METRIC, FUSED, false>};
     if constexpr (METRIC != kL1) k.link_wg = build_link_wg_kernel<METRIC, FUSED>;
     return k;
 }
-static BuildKernels pick_build_kernels(uint32_t metric, bool fused) {
+// bf16 images (round 6): one node at a time only -- the many-workgroup select / link steps over the interleaved bf16 rows
+template <uint32_t METRIC> static BuildKernels build_kernels_bf16() {
+    return BuildKernels{nullptr, nullptr, nullptr, build_select_seq_kernel<METRIC, true, true>, build_link_seq_kernel<METRIC, true, true>};
+}
+static BuildKernels pick_build_kernels(uint32_t metric, bool fused, bool bf16 = false) {
+    if (bf16) return metric == kL2 ? build_kernels_bf16<kL2>() : build_kernels_bf16<kCosine>();
     if (metric == kL2) return fused ? build_kernels_of<kL2, true>() : build_kernels_of<kL2, false>();
     if (metric == kCosine) return fused ? build_kernels_of<kCosine, true>() : build_kernels_of<kCosine, false>();
     return fused ? build_kernels_of<kL1, true>() : build_kernels_of<kL1, false>();
@@ -853,7 +858,8 @@ extern "C" void hvx_build_params_default(hvx_build_params *p) {
 // (p * stride) mod `mod` (stride 1: row p).  The handle is private to the caller for the duration (its lock is held or it has not
 // been returned yet).
 static int insert_range(hvx_index *ix, uint64_t first, uint64_t count, const uint16_t *levels_in, uint64_t level_row0, const hvx_build_params *params,
-                        uint32_t stride, uint64_t mod, hvx_build_stats *stats) {
+                        uint32_t stride, uint64_t mod, hvx_build_stats *stats, const float *build_q = nullptr) {
+    // build_q (bf16 images): the nodes' ROUNDED vectors as f32 [count][dim] on the device -- the queries of their build searches
     if (count == 0) return HVX_OK;
     struct LevelOf { // levels_in[0] is the level of row level_row0
         const uint16_t *p;
@@ -957,7 +963,9 @@ static int insert_range(hvx_index *ix, uint64_t first, uint64_t count, const uin
     const uint32_t ldp = link_ck * 32u + 32u;
     const size_t link_lds = link_lds_bytes(ldp, ncmax);
     // serves rows without a scalar tail (dim % 32 == 0, no padding) and <= 33 candidates (561 pairs = 4 wavefronts x 18 steps x 8)
-    const BuildKernels kern = pick_build_kernels(d.metric, fused);
+    const bool bf16 = d.dtype == HVX_BF16;
+    if (bf16 && (!build_q || stride != 1u)) return sbail2(fail(HVX_ERR_INVARIANT, "bf16 rows are linked from their rounded f32 vectors"));
+    const BuildKernels kern = pick_build_kernels(d.metric, fused, bf16);
     const bool link_wg = params->link_mode != 1u && kern.link_wg && !kernel_w4(d.fkernel) /* 32-lane tree only */ && ncmax <= 33u && nk_rows > 0 && d.dim_main == d.dim && d.ld == d.dim &&
                          (size_t)(ncmax + 1u) * link_ck * 8u <= 9u * 256u;
     uint64_t done = first, batches = 0, singles = 0;
@@ -979,7 +987,7 @@ static int insert_range(hvx_index *ix, uint64_t first, uint64_t count, const uin
         uint32_t bsz = 1;
         const uint16_t lv0 = levels ? levels[row_at(done)] : 0;
         const bool promotes = lv0 > d.max_layer;
-        if (!promotes && !params->sequential) {
+        if (!promotes && !params->sequential && !bf16) { // (bf16 images: one node per step)
             uint64_t want = std::min<uint64_t>(std::max<uint64_t>(done / divisor, 1), bmax);
             want = std::min<uint64_t>(want, end - done);
             while (bsz < want && !((levels ? levels[row_at(done + bsz)] : 0) > d.max_layer)) ++bsz;
@@ -1008,6 +1016,7 @@ static int insert_range(hvx_index *ix, uint64_t first, uint64_t count, const uin
         a.out_status = d_status;
         a.tie_flags = ix->d_tie;
         a.build_nodes = d_iota + (done - first);
+        if (bf16) a.queries = build_q + (size_t)(done - first) * d.dim;
         a.occupancy = (bsz > 1024u && params->link_mode != 1u) ? 2 : 1; // more nodes than SIMDs: two searches per SIMD instead of two rounds
         if (launch_hnsw_wave(a, bsz, s) != hipSuccess) return sbail2(fail(HVX_ERR_DEVICE, "build search launch failed: %s", hipGetErrorString(hipGetLastError())));
         if (hipEventRecord(ev_search[pb], s) != hipSuccess || hipStreamWaitEvent(s2, ev_search[pb], 0) != hipSuccess)
@@ -1030,7 +1039,8 @@ static int insert_range(hvx_index *ix, uint64_t first, uint64_t count, const uin
         ba.err = d_err;
         ba.dbg = d_dbg;
         // one node: its select and its links as two many-workgroup steps with every prune's distance matrix evaluated up front
-        const bool seq_step = bsz == 1u && params->link_mode != 1u && d.s0 + 1u <= kSeqRow && d.su + 1u <= kSeqRow;
+        const bool seq_step = bsz == 1u && (params->link_mode != 1u || bf16) && d.s0 + 1u <= kSeqRow && d.su + 1u <= kSeqRow;
+        if (bf16 && !seq_step) return sbail2(fail(HVX_ERR_UNSUPPORTED, "a bf16 image links rows of at most %u ids", kSeqRow - 1u));
         hipError_t e;
         if (seq_step) {
             ba.gdm = d_gdm;
@@ -1275,7 +1285,8 @@ extern "C" int hvx_index_upsert_batch(hvx_index *ix, const uint64_t *node_ids, c
     if (count == 0) return HVX_OK;
     if (ix->is_fork) return fail(HVX_ERR_UNSUPPORTED, "rows are written through the handle that owns the image, not a fork");
     const uint32_t dim = ix->dev.dim, ld = ix->dev.ld;
-    if (ix->dev.dtype != HVX_F32) return fail(HVX_ERR_UNSUPPORTED, "rows are written into f32 images");
+    if (ix->dev.dtype != HVX_F32 && ix->dev.dtype != HVX_BF16) return fail(HVX_ERR_UNSUPPORTED, "rows are written into f32 and bf16 images");
+    const bool bf16 = ix->dev.dtype == HVX_BF16; // (round 6: an id the image holds gets its new vector in its slot; bf16 images have no spare rows to append to)
     // ---- every vector is validated before anything changes (an invalid one fails the call: mutation.rs:660-690) ----
     float *d_tmp = nullptr, *d_tmph = nullptr;
     uint32_t *d_st = nullptr;
@@ -1291,6 +1302,7 @@ extern "C" int hvx_index_upsert_batch(hvx_index *ix, const uint64_t *node_ids, c
         std::vector<uint32_t> st(count);
         hipError_t e = hipMemsetAsync(d_tmp, 0, (size_t)count * ld * 4, s);
         if (e == hipSuccess) e = hipMemcpy2DAsync(d_tmp, (size_t)ld * 4, vectors, (size_t)dim * 4, (size_t)dim * 4, count, hipMemcpyDefault, s);
+        if (e == hipSuccess && bf16) e = launch_round_bf16_inplace(d_tmp, (size_t)count * ld, s); // the index IS the rounded vectors: validation and headers see them
         DevIndex view = ix->dev;
         view.vec = d_tmp;
         if (e == hipSuccess) e = launch_validate_rows(view, count, ix->limit, d_st, d_tmph, s);
@@ -1306,6 +1318,7 @@ extern "C" int hvx_index_upsert_batch(hvx_index *ix, const uint64_t *node_ids, c
         bool any = !ids.empty();
         for (uint32_t i = 0; i < count; ++i) {
             if (ix->find_slot(node_ids[i]) != kSentinel) continue;
+            if (bf16) { (void)hipFree(d_tmp); return fail(HVX_ERR_UNSUPPORTED, "node %llu is not in the bf16 image: bf16 images take new vectors for the ids they hold (no spare rows to append to)", (unsigned long long)node_ids[i]); }
             if (any && node_ids[i] <= last) { (void)hipFree(d_tmp); return fail(HVX_ERR_UNSUPPORTED, "node %llu lies between the ids of the image: it has no row slot (hydrate the image again)", (unsigned long long)node_ids[i]); }
             last = node_ids[i];
             any = true;
@@ -1326,9 +1339,11 @@ extern "C" int hvx_index_upsert_batch(hvx_index *ix, const uint64_t *node_ids, c
             DevIndex &d = ix->dev;
             hipStream_t s = ix->stream;
             const uint32_t row = ix->find_slot(node_ids[i]);
-            float *vdst = const_cast<float *>(d.vec) + (size_t)row * d.ld;
+            float *vsrc = d_tmp + (size_t)i * ld; // the validated (bf16 images: rounded) vector
+            float *vdst = bf16 ? vsrc : const_cast<float *>(d.vec) + (size_t)row * d.ld;
             uint16_t lv = 0;
-            hipError_t e = hipMemcpyAsync(vdst, d_tmp + (size_t)i * ld, (size_t)ld * 4, hipMemcpyDeviceToDevice, s);
+            hipError_t e = bf16 ? launch_pack_bf16(vsrc, const_cast<uint16_t *>(d.vecb) + (size_t)row * d.dim, 1u, d.dim, s)
+                                : hipMemcpyAsync(vdst, vsrc, (size_t)ld * 4, hipMemcpyDeviceToDevice, s);
             uint32_t *d_one = nullptr;
             if (e == hipSuccess) e = hipMalloc((void **)&d_one, 4);
             DevIndex view = d;
@@ -1349,7 +1364,7 @@ extern "C" int hvx_index_upsert_batch(hvx_index *ix, const uint64_t *node_ids, c
             (*flags)[row] = 0;
             ix->dead_p = flags;
             ix->n_dead -= 1;
-            if ((rc = insert_range(ix, row, 1, &lv, row, &seq, 1u, d.n, &one))) return done(rc);
+            if ((rc = insert_range(ix, row, 1, &lv, row, &seq, 1u, d.n, &one, bf16 ? vsrc : nullptr))) return done(rc);
             ix->desc.has_entry = 1;
             ix->desc.entry_point = ix->ids_ref()[d.entry];
             ix->desc.max_layer = d.max_layer;

@@ -751,12 +751,13 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
     // the 256 x 256 filtered contraction (hvx_flat_tile.hip) serves the one-pass attempt of scans with dim % 64 == 0
     // (its query tile is 256 wide: a batch of <= 128 queries wastes less on the 128 x 128 kernel)
     const bool tile_ok = d.dim % 64u == 0u && (b > 128u || ix->opt[HVX_OPT_FLAT_FIRST_CHUNK]) && !ix->opt[HVX_OPT_FLAT_NO_TILE];
-    if (f32 && ix->m_rowterm) { // a vector that changed in place (an upsert into the node's own slot) invalidates the cached norms
+    const bool rows_bf16 = d.dtype == HVX_BF16; // (round 6: bf16 images take upserts too; their norms were computed at import)
+    if ((f32 || rows_bf16) && ix->m_rowterm) { // a vector that changed in place (an upsert into the node's own slot) invalidates the cached norms
         uint64_t epoch;
         { std::lock_guard<std::mutex> g(ix->shared->mu); epoch = ix->shared->vec_epoch; }
         if (epoch != ix->rowterm_epoch) { ix->rowterm_rows = 0; ix->m_xmax2 = 0.f; ix->rowterm_epoch = epoch; }
     }
-    if (f32 && (!ix->m_rowterm || ix->rowterm_rows < d.n)) { // |x|^2 per row and its maximum: on first use, and for rows appended since
+    if ((f32 || rows_bf16) && (!ix->m_rowterm || ix->rowterm_rows < d.n)) { // |x|^2 per row and its maximum: on first use, and for rows appended since
         if (!ix->m_rowterm) {
             if ((rc = ix->dalloc((void **)&ix->m_rowterm, std::max<size_t>(std::max<uint64_t>(ix->cap_rows, d.n), 1) * 4))) return rc;
             ix->rowterm_rows = 0;
@@ -765,7 +766,8 @@ static int flat_mfma_impl(hvx_index *ix, const float *d_queries, uint32_t b, uin
         }
         const uint32_t r0 = ix->rowterm_rows, cnt = d.n - r0;
         std::vector<float> h_n2(cnt);
-        HIP_TRY(launch_f32_row_norm2(d.vec + (size_t)r0 * d.ld, cnt, d.ld, d.dim, ix->m_rowterm + r0, ix->stream));
+        if (rows_bf16) HIP_TRY(launch_bf16_row_norm2(d.vecb + (size_t)r0 * d.dim, cnt, d.dim, ix->m_rowterm + r0, ix->stream));
+        else HIP_TRY(launch_f32_row_norm2(d.vec + (size_t)r0 * d.ld, cnt, d.ld, d.dim, ix->m_rowterm + r0, ix->stream));
         HIP_TRY(hipMemcpyAsync(h_n2.data(), ix->m_rowterm + r0, (size_t)cnt * 4, hipMemcpyDeviceToHost, ix->stream));
         HIP_TRY(hipStreamSynchronize(ix->stream));
         for (float v : h_n2) ix->m_xmax2 = std::max(ix->m_xmax2, v);

@@ -132,6 +132,60 @@ __device__ __forceinline__ uint32_t prune_row_dev(const DevIndex &ix, const Buil
 }
 
 
+// distance between two RESIDENT rows, one 8-lane group, in the reference's summation order.  f32 images: the first row is the "query"
+// of group_distance, read in place.  bf16 images (round 6; dim % 64 == 0, AVX+FMA tree, L2 / cosine -- what the import accepts): both rows
+// are decoded from the interleaved layout piece by piece -- the values are exact f32 numbers and the arithmetic and its order are those
+// of group_distance_bf16 (hvx_device.h), so the distance equals the reference's on the rounded vectors bit for bit.
+template <uint32_t METRIC, bool FUSED, bool BF>
+__device__ __forceinline__ float pair_distance(const DevIndex &ix, uint32_t ni, uint32_t nj, int j) {
+    if constexpr (!BF) {
+        return group_distance<METRIC, FUSED>(ix, ix.vec + (size_t)ni * ix.ld, ix.hdr[ni], nj, j);
+    } else {
+        const int slot = chunk_slot(j);
+        const uint16_t *qb = ix.vecb + (size_t)ni * ix.dim, *rb = ix.vecb + (size_t)nj * ix.dim;
+        const float4 *qp = reinterpret_cast<const float4 *>(qb) + slot; // one 16-byte piece = this lane's virtual lanes of TWO chunks
+        const float4 *rp = reinterpret_cast<const float4 *>(rb) + slot;
+        const uint32_t np = ix.dim >> 6;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto step = [&](const float4 qw, const float4 xw) __attribute__((always_inline)) {
+            const uint32_t q0 = __float_as_uint(qw.x), q1 = __float_as_uint(qw.y), q2 = __float_as_uint(qw.z), q3 = __float_as_uint(qw.w);
+            const uint32_t w0 = __float_as_uint(xw.x), w1 = __float_as_uint(xw.y), w2 = __float_as_uint(xw.z), w3 = __float_as_uint(xw.w);
+            const float qa0 = __uint_as_float(q0 << 16), qa1 = __uint_as_float(q0 & 0xFFFF0000u), qa2 = __uint_as_float(q1 << 16), qa3 = __uint_as_float(q1 & 0xFFFF0000u);
+            const float qb0 = __uint_as_float(q2 << 16), qb1 = __uint_as_float(q2 & 0xFFFF0000u), qb2 = __uint_as_float(q3 << 16), qb3 = __uint_as_float(q3 & 0xFFFF0000u);
+            const float a0 = __uint_as_float(w0 << 16), a1 = __uint_as_float(w0 & 0xFFFF0000u), a2 = __uint_as_float(w1 << 16), a3 = __uint_as_float(w1 & 0xFFFF0000u);
+            const float b0 = __uint_as_float(w2 << 16), b1 = __uint_as_float(w2 & 0xFFFF0000u), b2 = __uint_as_float(w3 << 16), b3 = __uint_as_float(w3 & 0xFFFF0000u);
+            if (METRIC == kL2) {
+                float d0 = qa0 - a0, d1 = qa1 - a1, d2 = qa2 - a2, d3 = qa3 - a3;
+                acc.x = __builtin_fmaf(d0, d0, acc.x); acc.y = __builtin_fmaf(d1, d1, acc.y);
+                acc.z = __builtin_fmaf(d2, d2, acc.z); acc.w = __builtin_fmaf(d3, d3, acc.w);
+                d0 = qb0 - b0; d1 = qb1 - b1; d2 = qb2 - b2; d3 = qb3 - b3;
+                acc.x = __builtin_fmaf(d0, d0, acc.x); acc.y = __builtin_fmaf(d1, d1, acc.y);
+                acc.z = __builtin_fmaf(d2, d2, acc.z); acc.w = __builtin_fmaf(d3, d3, acc.w);
+            } else {
+                acc.x = __builtin_fmaf(qa0, a0, acc.x); acc.y = __builtin_fmaf(qa1, a1, acc.y);
+                acc.z = __builtin_fmaf(qa2, a2, acc.z); acc.w = __builtin_fmaf(qa3, a3, acc.w);
+                acc.x = __builtin_fmaf(qb0, b0, acc.x); acc.y = __builtin_fmaf(qb1, b1, acc.y);
+                acc.z = __builtin_fmaf(qb2, b2, acc.z); acc.w = __builtin_fmaf(qb3, b3, acc.w);
+            }
+        };
+        uint32_t m = 0;
+        for (; m + 6u <= np; m += 6u) { // twelve independent 16-byte loads in flight per lane before the first use
+            float4 q[6], x[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) { q[u] = qp[(size_t)(m + u) * 8]; x[u] = rp[(size_t)(m + u) * 8]; }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) step(q[u], x[u]);
+        }
+        for (; m < np; ++m) step(qp[(size_t)m * 8], rp[(size_t)m * 8]);
+        float r = avx_tree_reduce(acc);
+        if (METRIC == kCosine)
+            r = cosine_finish_fn(r, ix.hdr[ni], ix.hdr[nj], [&]() {
+                return stable_half_cosine_fn(ix.dim, [&](uint32_t i) { return bf16_to_f32(qb[bf16_slot_of(i)]); }, [&](uint32_t i) { return bf16_to_f32(rb[bf16_slot_of(i)]); });
+            });
+        return r;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Eager prunes (round 6): a prune's distance matrix is evaluated up front by many workgroups (one 8-lane group per pair), written to HBM
 // with device-scope stores, and ONE wavefront of the last workgroup to deliver replays select_diverse + backfill from registers.  Shared

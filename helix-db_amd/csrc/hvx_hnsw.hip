@@ -317,6 +317,7 @@ hipError_t launch_hnsw_wave_occ2_bf16(const HnswArgs &a, uint32_t b, const WaveG
 hipError_t launch_hnsw_wave_build(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_build_occ2(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_build_gen(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
+hipError_t launch_hnsw_wave_build_bf16(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s); // one-node inserts into bf16 images
 hipError_t launch_hnsw_wave_gen_cos(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_gen_l2(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
 hipError_t launch_hnsw_wave_gen_l1(const HnswArgs &a, uint32_t b, const WaveGeom &g, hipStream_t s);
@@ -420,6 +421,7 @@ static hipError_t launch_hnsw_wave_once(const HnswArgs &a, uint32_t b, hipStream
     const size_t need = (size_t)4 * g.cap + fixed;
     g.lds = need < budget ? budget : need;
     if (a.build_nodes) {
+        if (a.ix.dtype == HVX_BF16) return (build_generic || g.occ != 1u) ? hipErrorInvalidValue : launch_hnsw_wave_build_bf16(a, b, g, s);
         if (build_generic) return launch_hnsw_wave_build_gen(a, b, g, s);
         return g.occ == 2 ? launch_hnsw_wave_build_occ2(a, b, g, s) : launch_hnsw_wave_build(a, b, g, s);
     }

@@ -546,7 +546,9 @@ __device__ __forceinline__ void hnsw_wave_query(const HnswArgs &a, const uint32_
         return;
     }
     const uint32_t bnode = BUILD ? a.build_nodes[q] : 0u;
-    const float *qglobal = BUILD ? ix.vec + (size_t)bnode * ix.ld : a.queries + (size_t)q * ix.dim;
+    // BUILD over bf16 rows (round 6: one-node inserts / upserts into bf16 images): the node's ROUNDED vector arrives as an f32 query
+    // (a.queries, unused by f32 build searches), its stored row is bf16
+    const float *qglobal = (BUILD && ix.vec) ? ix.vec + (size_t)bnode * ix.ld : a.queries + (size_t)q * ix.dim;
     if (GEN) { // zero padded to ld floats, as group_distance reads it
         for (uint32_t i = (uint32_t)lane; i < ix.ld; i += 64) qs[i] = i < ix.dim ? qglobal[i] : 0.f;
     } else {

@@ -722,6 +722,9 @@ int hvx_index_delete_batch(hvx_index *, const uint64_t *node_ids /*[count]*/, ui
  * used there; a revived node keeps the level of its slot: the reference's level draw is random, any draw is a valid one).  Every
  * vector is validated before anything changes.  HVX_ERR_UNSUPPORTED for an id that lies between the image's ids without a slot.
  * Rows equal the oracle's delete + insert of the same ids (tests/test_gpu_delete.py).
+ * bf16 images (round 6): ids the image holds get their new vector in their slot -- rounded to bf16, validated, linked over the bf16 rows
+ * (== the oracle on the rounded vectors); an id the image does not hold is HVX_ERR_UNSUPPORTED (an imported image has no spare rows).
+ * fp8 images are read-only.
  */
 int hvx_index_upsert_batch(hvx_index *, const uint64_t *node_ids /*[count]*/, const float *vectors /*[count][dim] host or device*/,
                            const uint16_t *levels /*[count] or NULL*/, uint32_t count, const hvx_build_params *params /*nullable*/,

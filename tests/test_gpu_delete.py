@@ -317,7 +317,7 @@ def test_deletes_on_a_bf16_image_equal_the_oracle_on_the_rounded_rows(orc, hv, n
     the resident bf16 rows -- the ranking and every prune's distance matrix in f32 on the rounded values, in the reference's summation
     order -- so rows, entry point and top layer equal the oracle's deletes on the ROUNDED vectors after two batches (scattered ids and
     the entry point); the searches (strict arm + production default), the exact scan and a restricted scan equal the oracle's bit for
-    bit afterwards.  Paths that read f32 rows refuse a bf16 image loudly (one-wavefront relinks, two-launch steps, inserts, upserts)."""
+    bit afterwards.  Paths that read f32 rows refuse a bf16 image loudly (one-wavefront relinks, two-launch steps)."""
     rng = np.random.default_rng(9100 + dim + metric)
     data = rng.standard_normal((n, dim)).astype(np.float32)
     rounded = fx.round_bf16(data)
@@ -374,8 +374,6 @@ def test_deletes_on_a_bf16_image_equal_the_oracle_on_the_rounded_rows(orc, hv, n
             gix.delete_batch(np.asarray(live[:1], np.uint64))
     gix.set_option(hv.OPT_DELETE_SEQUENTIAL, 0)
     assert gix.live_rows() == n - len(deleted)                                 # ... refused before anything changed
-    with pytest.raises(hv.HelixDbError):
-        gix.upsert_batch(np.asarray(live[:1], np.uint64), data[:1], ef_construction=80)
     assert_same_graph(gix, oix, ids, deleted)
     gix.close()
 
@@ -416,4 +414,49 @@ def test_deletes_on_an_m32_m0_64_graph_equal_the_oracle(orc, hv, n, dim, metric,
     for qi in range(q.shape[0]):
         rc, oid, osc = oix.search(q[qi], 10, 64)
         assert gid[qi, :gcnt[qi]].tolist() == oid.tolist() and bits(gsc[qi, :gcnt[qi]]).tolist() == bits(osc).tolist()
+    gix.close()
+
+
+@pytest.mark.parametrize("n,dim,metric", [(1200, 128, 1), (900, 256, 0)])
+def test_upserts_into_a_bf16_image_equal_the_oracle_on_the_rounded_rows(orc, hv, n, dim, metric):
+    """Config #4's storage takes new vectors for the ids it holds (round 6): the vector is rounded to bf16, validated, packed into the
+    node's slot, and linked by the one-node steps over the interleaved bf16 rows with the rounded vector as the f32 query of its build
+    search -- rows, entry point, searches and the exact scan (row norms refreshed) equal the oracle's delete + insert of the ROUNDED
+    vectors.  Live ids (the entry point among them) and an id deleted earlier; an id the image does not hold is refused (no spare rows)."""
+    rng = np.random.default_rng(8800 + dim)
+    efc = 80
+    data = rng.standard_normal((n + 40, dim)).astype(np.float32)
+    rounded = fx.round_bf16(data)
+    lv = fx.draw_levels(n, 16, seed=n + 9)
+    ids = np.arange(n, dtype=np.uint64) * 4 + 10
+    oix = orc.Index(dim, metric, kernel=orc.K_AVX_FMA, m=16, m0=32, ef_construction=efc)
+    for i in range(n):
+        assert oix.insert(int(ids[i]), rounded[i], int(lv[i])) == orc.OK
+    ex = oix.export()
+    ex["vectors"] = data[:n]
+    gix = hv.ValidatedVectorReadIndex.from_export(ex, dim=dim, metric=metric, dtype=hv.BF16, m=16, m0=32)
+    gone = int(ids[77])
+    assert oix.delete(gone) == (orc.OK, True) and gix.delete_batch([gone])["deleted"] == 1
+    with pytest.raises(hv.HelixDbError) as e:                                  # not in the image: a bf16 image has no spare rows
+        gix.upsert_batch([int(ids[-1]) + 4], data[n:n + 1])
+    assert e.value.status == hv.ERR_UNSUPPORTED
+    ent = oix.entry()[0]
+    targets = [int(x) for x in ids[rng.permutation(n)[:20]] if int(x) not in (gone, ent)][:14] + [ent, gone]
+    level_of = {int(ids[i]): int(lv[i]) for i in range(n)}
+    for t, nid in enumerate(targets):
+        if oix.is_live(nid):
+            assert oix.delete(nid) == (orc.OK, True)
+        assert oix.insert(nid, rounded[n + t], level_of[nid]) == orc.OK
+    st = gix.upsert_batch(np.asarray(targets, np.uint64), data[n: n + len(targets)], ef_construction=efc)
+    assert st["nodes"] == len(targets) and gix.live_rows() == n == oix.count
+    assert_same_graph(gix, oix, ids, ())
+    q = np.vstack([rng.standard_normal((10, dim)).astype(np.float32), rounded[n: n + 4]])   # four queries ARE upserted vectors
+    gid, gsc, gcnt, _ = gix.search_batch(q, hv.SearchParams(10).with_ef(64))
+    fid, fsc, fcnt, _ = gix.flat_search_batch(q, 10)
+    for qi in range(q.shape[0]):
+        rc, oid, osc = oix.search(q[qi], 10, 64)
+        assert gid[qi, :gcnt[qi]].tolist() == oid.tolist() and bits(gsc[qi, :gcnt[qi]]).tolist() == bits(osc).tolist()
+        rc, tid, tsc = oix.flat(q[qi], 10)
+        assert fid[qi, :fcnt[qi]].tolist() == tid.tolist() and bits(fsc[qi, :fcnt[qi]]).tolist() == bits(tsc).tolist()
+    assert fid[10, 0] == targets[0]                                              # the new vector answers under the old id
     gix.close()

@@ -290,7 +290,9 @@ def test_batching_operator_for_the_prefiltered_branch(orc, hv):
             got = out[t][i]
             assert [r.entity_id for r in got] == want_ids.tolist() and bits(np.array([r.score for r in got], np.float32)).tolist() == bits(want_sc).tolist()
     st = bt.stats()
-    assert st["queries"] == threads * per and st["batches"] < threads * per  # (coalesced)
+    # (whether blocking Python threads meet in one batch is a matter of timing -- a lane dispatches as soon as it holds as many queries as
+    # its previous batch: in 2 of 9 runs of the whole suite every call went alone; the burst of tickets below MUST coalesce)
+    assert st["queries"] == threads * per and st["batches"] <= threads * per
     assert bt.search(q[0], np.zeros(0, np.uint64)) == []                      # empty set: nothing, no validation
     bad = q[1].copy(); bad[3] = np.inf
     assert bt.search(bad, np.zeros(0, np.uint64)) == []
@@ -301,6 +303,7 @@ def test_batching_operator_for_the_prefiltered_branch(orc, hv):
         bt.search(q[0], np.arange(1501, dtype=np.uint64))                    # beyond max_ids_per_query: refused
     assert e.value.status == hv.ERR_UNSUPPORTED
     tickets = []
+    before = bt.stats()
     for i in range(20):
         tk = bt.submit(q[i], ids[i * 50:(i + 1) * 50 + 500])
         assert tk is not None
@@ -309,6 +312,8 @@ def test_batching_operator_for_the_prefiltered_branch(orc, hv):
         got = bt.wait(tk)
         rc, want_ids, want_sc = oix.flat(q[i], k, allowed=ids[i * 50:(i + 1) * 50 + 500])
         assert [r.entity_id for r in got] == want_ids.tolist()
+    after = bt.stats()
+    assert after["queries"] - before["queries"] == 20 and after["batches"] - before["batches"] < 20   # twenty tickets in a burst: coalesced
     with pytest.raises(hv.HelixDbError):
         hv.Batcher.search(bt, q[0])                                           # the unrestricted entry point refuses this batcher
     with pytest.raises(hv.HelixDbError):                                      # the reference plan walks above 256 ids: not batched per caller

@@ -211,6 +211,13 @@ extern "C" int hvx_index_import(const hvx_index_desc *desc, const uint64_t *node
     return hvx::import_index(desc, node_ids, vectors, l0_offsets, l0_neighbors, level, up_offsets, up_neighbors, 0, 0, out);
 }
 
+extern "C" int hvx_index_import_reserve(const hvx_index_desc *desc, const uint64_t *node_ids, const float *vectors, const uint64_t *l0_offsets,
+                                        const uint64_t *l0_neighbors, const uint16_t *level, const uint64_t *up_offsets, const uint64_t *up_neighbors,
+                                        uint64_t reserve_rows, uint64_t reserve_upper_rows, hvx_index **out) {
+    if (desc && desc->dtype == HVX_FP8_E4M3 && (reserve_rows || reserve_upper_rows)) return fail(HVX_ERR_UNSUPPORTED, "fp8 images are read-only: no spare rows");
+    return hvx::import_index(desc, node_ids, vectors, l0_offsets, l0_neighbors, level, up_offsets, up_neighbors, 0, 0, out, reserve_rows, reserve_upper_rows);
+}
+
 // min_s0 / min_su: lower bounds of the row strides (the device builder imports an empty graph and fills rows of up to
 // m0 / m ids afterwards)
 int hvx::import_index(const hvx_index_desc *desc, const uint64_t *node_ids, const float *vectors, const uint64_t *l0_offsets,
@@ -229,7 +236,7 @@ int hvx::import_index(const hvx_index_desc *desc, const uint64_t *node_ids, cons
     if (desc->float_kernel > HVX_KERNEL_NEON)
         return fail(HVX_ERR_UNSUPPORTED, "float kernel %u is not one of the reference's FloatSimd kernels", desc->float_kernel);
     if (desc->n + reserve_rows >= (1ull << 31)) return fail(HVX_ERR_UNSUPPORTED, "shard too large (n < 2^31)");
-    if ((reserve_rows || reserve_up_rows) && desc->dtype != HVX_F32) return fail(HVX_ERR_UNSUPPORTED, "only f32 images can reserve rows for later inserts");
+    if ((reserve_rows || reserve_up_rows) && desc->dtype == HVX_FP8_E4M3) return fail(HVX_ERR_UNSUPPORTED, "fp8 images are read-only: they cannot reserve rows for later inserts");
     const uint64_t n = desc->n;
     const uint64_t cap = n + reserve_rows; // rows the arrays are allocated for (hvx_index_insert_batch appends into the spare ones)
     if (n && (!node_ids || !vectors || !l0_offsets)) return fail(HVX_ERR_INVARIANT, "null array");
@@ -420,7 +427,7 @@ int hvx::import_index(const hvx_index_desc *desc, const uint64_t *node_ids, cons
     }
     if (bf16) {
         void *pb;
-        if ((rc = ix->dalloc(&pb, (size_t)n * d.dim * 2))) return bail_free(rc);
+        if ((rc = ix->dalloc(&pb, std::max<size_t>((size_t)cap * d.dim * 2, 16)))) return bail_free(rc); // (cap: spare rows of hvx_index_import_reserve)
         hipError_t e = launch_pack_bf16(staging, (uint16_t *)pb, (uint32_t)n, d.dim, ix->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
         (void)hipFree(staging);
@@ -429,7 +436,7 @@ int hvx::import_index(const hvx_index_desc *desc, const uint64_t *node_ids, cons
         d.vecb = (const uint16_t *)pb;
         d.vec = nullptr;
         // |x|^2 per row and its maximum: score term and error bound of the MFMA exact scan
-        if ((rc = ix->dalloc((void **)&ix->m_rowterm, std::max<size_t>(n, 1) * 4))) return bail(rc);
+        if ((rc = ix->dalloc((void **)&ix->m_rowterm, std::max<size_t>(cap, 1) * 4))) return bail(rc);
         if (n) {
             std::vector<float> h_n2(n);
             e = launch_bf16_row_norm2(d.vecb, (uint32_t)n, d.dim, ix->m_rowterm, ix->stream);

@@ -1179,7 +1179,8 @@ extern "C" int hvx_index_insert_batch(hvx_index *ix, const uint64_t *node_ids, c
     std::lock_guard<std::mutex> lock(ix->mu);
     HIP_TRY(hipSetDevice(ix->device));
     DevIndex &d = ix->dev;
-    if (d.dtype != HVX_F32) return fail(HVX_ERR_UNSUPPORTED, "rows are inserted into f32 images (import the grown graph with a reduced-precision dtype afterwards)");
+    if (d.dtype != HVX_F32 && d.dtype != HVX_BF16) return fail(HVX_ERR_UNSUPPORTED, "rows are inserted into f32 and bf16 images (fp8 images are read-only)");
+    const bool bf16 = d.dtype == HVX_BF16; // (round 6: rounded, validated, packed, linked one node at a time over the bf16 rows)
     const uint32_t m = ix->desc.m ? ix->desc.m : 16u;
     const uint32_t m0 = std::max(ix->desc.m0 ? ix->desc.m0 : 2u * m, 2u * m);
     const uint32_t efc = params->ef_construction ? params->ef_construction : 200u;
@@ -1207,13 +1208,25 @@ extern "C" int hvx_index_insert_batch(hvx_index *ix, const uint64_t *node_ids, c
     if (!hnsw_wave_supported(probe) && (d.s0 > 64u || d.su > 64u)) return fail(HVX_ERR_UNSUPPORTED, "device build serves neighbour rows of <= 64 ids");
     hipStream_t s = ix->stream;
     // ---- the rows: upload into the spare capacity, validate, headers (nothing is visible yet: d.n still ends before them) ----
-    float *vdst = const_cast<float *>(d.vec) + (size_t)n0 * d.ld;
+    float *vdst;
+    if (bf16) { // the rounded vectors as f32: validation, headers, SimHash rows and the build searches read them; the image gets the packed rows
+        if ((size_t)count * d.ld * 4 > ix->ins_rows_cap) {
+            ix->ins_rows_cap = 0;
+            int rc0 = ix->regrow((void **)&ix->ins_rows, (size_t)count * d.ld * 4);
+            if (rc0) return rc0;
+            ix->ins_rows_cap = (size_t)count * d.ld * 4;
+        }
+        vdst = ix->ins_rows;
+    } else {
+        vdst = const_cast<float *>(d.vec) + (size_t)n0 * d.ld;
+    }
     if (d.ld == d.dim) {
         HIP_TRY(hipMemcpyAsync(vdst, vectors, (size_t)count * d.dim * 4, hipMemcpyDefault, s));
     } else {
         HIP_TRY(hipMemsetAsync(vdst, 0, (size_t)count * d.ld * 4, s));
         HIP_TRY(hipMemcpy2DAsync(vdst, (size_t)d.ld * 4, vectors, (size_t)d.dim * 4, (size_t)d.dim * 4, count, hipMemcpyDefault, s));
     }
+    if (bf16) HIP_TRY(launch_round_bf16_inplace(vdst, (size_t)count * d.ld, s)); // the index IS the rounded vectors
     uint32_t *d_rowstatus = nullptr;
     HIP_TRY(hipMalloc((void **)&d_rowstatus, (size_t)count * 4));
     {
@@ -1239,6 +1252,7 @@ extern "C" int hvx_index_insert_batch(hvx_index *ix, const uint64_t *node_ids, c
     HIP_TRY(hipMemcpyAsync(const_cast<uint16_t *>(d.level) + n0, h_lv.data(), (size_t)count * 2, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(const_cast<uint32_t *>(d.up_base) + n0, h_base.data(), (size_t)count * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(const_cast<uint64_t *>(d.ids) + n0, node_ids, (size_t)count * 8, hipMemcpyHostToDevice, s));
+    if (bf16) HIP_TRY(launch_pack_bf16(vdst, const_cast<uint16_t *>(d.vecb) + (size_t)n0 * d.dim, count, d.dim, s));
     if (ix->has_simhash) { // SimHash rows of the new nodes (SimHasher::hash at insert time: mutation.rs:700-705)
         HIP_TRY(launch_simhash_rows(ix->d_planes_t, vdst, d.dim, d.ld, count, ix->d_node_hash + n0, s));
     }
@@ -1255,7 +1269,7 @@ extern "C" int hvx_index_insert_batch(hvx_index *ix, const uint64_t *node_ids, c
     ix->desc.n = d.n;
     ix->up_rows_used = r;
     // ---- link them into the graph ----
-    int rc = insert_range(ix, n0, count, h_lv.data(), n0, params, 1u, 0, stats);
+    int rc = insert_range(ix, n0, count, h_lv.data(), n0, params, 1u, 0, stats, bf16 ? vdst : nullptr);
     if (rc) return rc; // (the image is partially linked: the host discards the handle and re-hydrates)
     ix->desc.has_entry = 1;
     ix->desc.entry_point = ix->ids_ref()[d.entry];
@@ -1318,7 +1332,6 @@ extern "C" int hvx_index_upsert_batch(hvx_index *ix, const uint64_t *node_ids, c
         bool any = !ids.empty();
         for (uint32_t i = 0; i < count; ++i) {
             if (ix->find_slot(node_ids[i]) != kSentinel) continue;
-            if (bf16) { (void)hipFree(d_tmp); return fail(HVX_ERR_UNSUPPORTED, "node %llu is not in the bf16 image: bf16 images take new vectors for the ids they hold (no spare rows to append to)", (unsigned long long)node_ids[i]); }
             if (any && node_ids[i] <= last) { (void)hipFree(d_tmp); return fail(HVX_ERR_UNSUPPORTED, "node %llu lies between the ids of the image: it has no row slot (hydrate the image again)", (unsigned long long)node_ids[i]); }
             last = node_ids[i];
             any = true;

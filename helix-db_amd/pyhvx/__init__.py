@@ -226,6 +226,8 @@ def lib():
     L.hvx_version.restype = C.c_char_p
     L.hvx_index_import.restype = C.c_int
     L.hvx_index_import.argtypes = [C.POINTER(_Desc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp)]
+    L.hvx_index_import_reserve.restype = C.c_int
+    L.hvx_index_import_reserve.argtypes = [C.POINTER(_Desc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, C.c_uint64, C.POINTER(_vp)]
     L.hvx_index_free.argtypes = [_vp]
     L.hvx_index_sync.restype = C.c_int
     L.hvx_index_sync.argtypes = [_vp]
@@ -551,7 +553,8 @@ class ValidatedVectorReadIndex:
     @classmethod
     def managed(cls, *, dim, metric, node_ids, vectors, l0_offsets, l0_neighbors, level=None,
                 up_offsets=None, up_neighbors=None, entry_point=None, max_layer=0, m=16, m0=32,
-                float_kernel=KERNEL_AVX_FMA, device=-1, max_batch=1024, dtype=F32):
+                float_kernel=KERNEL_AVX_FMA, device=-1, max_batch=1024, dtype=F32, reserve_rows=0, reserve_upper_rows=0):
+        """hvx_index_import; with reserve_rows / reserve_upper_rows: hvx_index_import_reserve (a hydrated image that can grow)"""
         ids = np.ascontiguousarray(node_ids, dtype=np.uint64)
         dev_rows = hasattr(vectors, "data_ptr")  # a torch tensor already resident on the device
         if dev_rows:
@@ -572,8 +575,12 @@ class ValidatedVectorReadIndex:
                   shard_id_lo=int(ids[0]) if ids.size else 0, shard_id_hi=int(ids[-1]) if ids.size else 0,
                   device=device, max_batch=max_batch)
         h = _vp()
-        _check(lib().hvx_index_import(C.byref(d), _ptr(ids), _vp(vectors.data_ptr()) if dev_rows else _ptr(vec), _ptr(o0), _ptr(n0), _ptr(lv),
-                                      _ptr(uo), _ptr(un), C.byref(h)))
+        vp = _vp(vectors.data_ptr()) if dev_rows else _ptr(vec)
+        if reserve_rows or reserve_upper_rows:
+            _check(lib().hvx_index_import_reserve(C.byref(d), _ptr(ids), vp, _ptr(o0), _ptr(n0), _ptr(lv), _ptr(uo), _ptr(un),
+                                                  C.c_uint64(int(reserve_rows)), C.c_uint64(int(reserve_upper_rows)), C.byref(h)))
+        else:
+            _check(lib().hvx_index_import(C.byref(d), _ptr(ids), vp, _ptr(o0), _ptr(n0), _ptr(lv), _ptr(uo), _ptr(un), C.byref(h)))
         return cls(h, dim, metric, int(ids.size))
 
     @classmethod

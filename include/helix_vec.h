@@ -106,6 +106,13 @@ typedef struct hvx_query_stats {
 int hvx_index_import(const hvx_index_desc *desc, const uint64_t *node_ids, const float *vectors,
                      const uint64_t *l0_offsets, const uint64_t *l0_neighbors, const uint16_t *level,
                      const uint64_t *up_offsets, const uint64_t *up_neighbors, hvx_index **out);
+/* The same import with spare capacity (round 6): room for reserve_rows more nodes and reserve_upper_rows more upper-layer rows, so that
+ * hvx_index_insert_batch / appending upserts can grow a HYDRATED image (f32 or bf16 rows; hvx_index_build takes its reserve from
+ * hvx_build_params).  Declare m / m0 in the descriptor: the neighbour rows are sized for them. */
+int hvx_index_import_reserve(const hvx_index_desc *desc, const uint64_t *node_ids, const float *vectors,
+                             const uint64_t *l0_offsets, const uint64_t *l0_neighbors, const uint16_t *level,
+                             const uint64_t *up_offsets, const uint64_t *up_neighbors, uint64_t reserve_rows, uint64_t reserve_upper_rows,
+                             hvx_index **out);
 void hvx_index_free(hvx_index *);
 int hvx_index_sync(const hvx_index *);
 /* the HIP stream (hipStream_t) search kernels are enqueued on */
@@ -677,7 +684,8 @@ int hvx_index_build(const hvx_index_desc *desc, const uint64_t *node_ids, const 
 /*
  * Incremental insert into a LIVE image (VectorIndex::insert -> insert_hnsw, mutation.rs:642-895): `count` new nodes -- ids ascending
  * and above every id of the image, f32 vectors (host or device memory), levels as hvx_index_build takes them -- are appended to
- * the spare capacity of an image built with hvx_build_params.reserve_rows (HVX_ERR_CANDIDATE_LIMIT when they do not fit),
+ * the spare capacity of an image built with hvx_build_params.reserve_rows or hydrated with hvx_index_import_reserve
+ * (HVX_ERR_CANDIDATE_LIMIT when they do not fit; bf16 images: the vectors are rounded first and linked one node at a time),
  * validated like imported rows (an invalid vector fails the call before anything changes), given headers and -- when SimHash
  * rows are attached -- SimHash rows, and linked into the graph by the loop hvx_index_build runs: params->sequential = 1 is the
  * reference's insertion row for row (tests/test_gpu_build.py), the batched mode trades that for throughput exactly as the build
@@ -722,9 +730,8 @@ int hvx_index_delete_batch(hvx_index *, const uint64_t *node_ids /*[count]*/, ui
  * used there; a revived node keeps the level of its slot: the reference's level draw is random, any draw is a valid one).  Every
  * vector is validated before anything changes.  HVX_ERR_UNSUPPORTED for an id that lies between the image's ids without a slot.
  * Rows equal the oracle's delete + insert of the same ids (tests/test_gpu_delete.py).
- * bf16 images (round 6): ids the image holds get their new vector in their slot -- rounded to bf16, validated, linked over the bf16 rows
- * (== the oracle on the rounded vectors); an id the image does not hold is HVX_ERR_UNSUPPORTED (an imported image has no spare rows).
- * fp8 images are read-only.
+ * bf16 images (round 6): the new vector is rounded to bf16, validated and linked over the bf16 rows (== the oracle on the rounded vectors);
+ * appended ids need spare rows (hvx_index_import_reserve).  fp8 images are read-only.
  */
 int hvx_index_upsert_batch(hvx_index *, const uint64_t *node_ids /*[count]*/, const float *vectors /*[count][dim] host or device*/,
                            const uint16_t *levels /*[count] or NULL*/, uint32_t count, const hvx_build_params *params /*nullable*/,

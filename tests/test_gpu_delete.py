@@ -422,7 +422,7 @@ def test_upserts_into_a_bf16_image_equal_the_oracle_on_the_rounded_rows(orc, hv,
     """Config #4's storage takes new vectors for the ids it holds (round 6): the vector is rounded to bf16, validated, packed into the
     node's slot, and linked by the one-node steps over the interleaved bf16 rows with the rounded vector as the f32 query of its build
     search -- rows, entry point, searches and the exact scan (row norms refreshed) equal the oracle's delete + insert of the ROUNDED
-    vectors.  Live ids (the entry point among them) and an id deleted earlier; an id the image does not hold is refused (no spare rows)."""
+    vectors.  Live ids (the entry point among them) and an id deleted earlier; a new id needs spare rows (hvx_index_import_reserve: next test)."""
     rng = np.random.default_rng(8800 + dim)
     efc = 80
     data = rng.standard_normal((n + 40, dim)).astype(np.float32)
@@ -437,9 +437,9 @@ def test_upserts_into_a_bf16_image_equal_the_oracle_on_the_rounded_rows(orc, hv,
     gix = hv.ValidatedVectorReadIndex.from_export(ex, dim=dim, metric=metric, dtype=hv.BF16, m=16, m0=32)
     gone = int(ids[77])
     assert oix.delete(gone) == (orc.OK, True) and gix.delete_batch([gone])["deleted"] == 1
-    with pytest.raises(hv.HelixDbError) as e:                                  # not in the image: a bf16 image has no spare rows
+    with pytest.raises(hv.HelixDbError):                                       # a new id: this image was imported without spare rows
         gix.upsert_batch([int(ids[-1]) + 4], data[n:n + 1])
-    assert e.value.status == hv.ERR_UNSUPPORTED
+    assert gix.live_rows() == n - 1
     ent = oix.entry()[0]
     targets = [int(x) for x in ids[rng.permutation(n)[:20]] if int(x) not in (gone, ent)][:14] + [ent, gone]
     level_of = {int(ids[i]): int(lv[i]) for i in range(n)}
@@ -459,4 +459,44 @@ def test_upserts_into_a_bf16_image_equal_the_oracle_on_the_rounded_rows(orc, hv,
         rc, tid, tsc = oix.flat(q[qi], 10)
         assert fid[qi, :fcnt[qi]].tolist() == tid.tolist() and bits(fsc[qi, :fcnt[qi]]).tolist() == bits(tsc).tolist()
     assert fid[10, 0] == targets[0]                                              # the new vector answers under the old id
+    gix.close()
+
+
+@pytest.mark.parametrize("n,dim,metric", [(1000, 128, 1), (800, 256, 0)])
+def test_inserts_into_a_bf16_image_with_spare_rows_equal_the_oracle(orc, hv, n, dim, metric):
+    """hvx_index_import_reserve + hvx_index_insert_batch on a bf16 image: the first 60 % of the rows are hydrated (rounded at import), the
+    rest arrive in three insert calls -- rounded to bf16, validated, packed behind the image's rows and linked one node at a time over the
+    bf16 rows -- and an appending upsert; rows, entry point, top layer and searches equal the oracle's insertion of the ROUNDED vectors."""
+    rng = np.random.default_rng(7300 + dim)
+    efc = 80
+    data = rng.standard_normal((n + 1, dim)).astype(np.float32)
+    rounded = fx.round_bf16(data)
+    lv = fx.draw_levels(n + 1, 16, seed=n + 2)
+    ids = np.arange(n + 1, dtype=np.uint64) * 2 + 1
+    n0 = n * 6 // 10
+    oix = orc.Index(dim, metric, kernel=orc.K_AVX_FMA, m=16, m0=32, ef_construction=efc)
+    for i in range(n0):
+        assert oix.insert(int(ids[i]), rounded[i], int(lv[i])) == orc.OK
+    ex = oix.export()
+    ex["vectors"] = data[:n0]
+    gix = hv.ValidatedVectorReadIndex.from_export(ex, dim=dim, metric=metric, dtype=hv.BF16, m=16, m0=32, reserve_rows=n + 1 - n0,
+                                                  reserve_upper_rows=int(lv[n0:].sum()))
+    cuts = [n0, n0 + (n - n0) // 3, n0 + 2 * (n - n0) // 3, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        for i in range(a, b):
+            assert oix.insert(int(ids[i]), rounded[i], int(lv[i])) == orc.OK
+        gix.insert_batch(ids[a:b], data[a:b], lv[a:b], ef_construction=efc)
+        assert gix.live_rows() == b == oix.count
+        assert_same_graph(gix, oix, ids[:b], ())
+    assert oix.insert(int(ids[n]), rounded[n], int(lv[n])) == orc.OK            # a fresh id through the upsert entry point: appended
+    gix.upsert_batch(ids[n:n + 1], data[n:n + 1], lv[n:n + 1], ef_construction=efc)
+    assert_same_graph(gix, oix, ids, ())
+    q = np.vstack([rng.standard_normal((10, dim)).astype(np.float32), rounded[n - 3: n + 1]])
+    gid, gsc, gcnt, _ = gix.search_batch(q, hv.SearchParams(10).with_ef(64))
+    fid, fsc, fcnt, _ = gix.flat_search_batch(q, 10)
+    for qi in range(q.shape[0]):
+        rc, oid, osc = oix.search(q[qi], 10, 64)
+        assert gid[qi, :gcnt[qi]].tolist() == oid.tolist() and bits(gsc[qi, :gcnt[qi]]).tolist() == bits(osc).tolist()
+        rc, tid, tsc = oix.flat(q[qi], 10)
+        assert fid[qi, :fcnt[qi]].tolist() == tid.tolist() and bits(fsc[qi, :fcnt[qi]]).tolist() == bits(tsc).tolist()
     gix.close()

@@ -342,7 +342,9 @@ extern "C" int hvx_hydrator_set_entry(hvx_hydrator *h, uint64_t entry_point, uin
     return HVX_OK;
 }
 
-extern "C" int hvx_hydrator_finish(const hvx_hydrator *h, const hvx_index_desc *tmpl, hvx_index **out) {
+extern "C" int hvx_hydrator_finish(const hvx_hydrator *h, const hvx_index_desc *tmpl, hvx_index **out) { return hvx_hydrator_finish_reserve(h, tmpl, 0, 0, out); }
+
+extern "C" int hvx_hydrator_finish_reserve(const hvx_hydrator *h, const hvx_index_desc *tmpl, uint64_t reserve_rows, uint64_t reserve_upper_rows, hvx_index **out) {
     if (!h || !tmpl || !out) return fail(HVX_ERR_INVARIANT, "null argument");
     // every node must have its canonical vector row; neighbour ids without a vector row are dangling and
     // dropped (the reference skips missing rows silently: search.rs:848-914)
@@ -381,5 +383,7 @@ extern "C" int hvx_hydrator_finish(const hvx_hydrator *h, const hvx_index_desc *
     if (n) { d.shard_id_lo = ids.front(); d.shard_id_hi = ids.back(); }
     if (l0_nb.empty()) l0_nb.push_back(0);
     if (up_nb.empty()) up_nb.push_back(0);
+    if (reserve_rows || reserve_upper_rows)
+        return hvx_index_import_reserve(&d, ids.data(), vecs.data(), l0_off.data(), l0_nb.data(), level.data(), up_off.data(), up_nb.data(), reserve_rows, reserve_upper_rows, out);
     return hvx_index_import(&d, ids.data(), vecs.data(), l0_off.data(), l0_nb.data(), level.data(), up_off.data(), up_nb.data(), out);
 }

@@ -1488,9 +1488,15 @@ class Hydrator:
     def set_entry(self, entry_point, max_layer):
         _check(lib().hvx_hydrator_set_entry(self._h, int(entry_point), int(max_layer)))
 
-    def finish(self, *, m=16, m0=32, float_kernel=KERNEL_AVX_FMA, device=-1, max_batch=1024, dtype=F32):
+    def finish(self, *, m=16, m0=32, float_kernel=KERNEL_AVX_FMA, device=-1, max_batch=1024, dtype=F32, reserve_rows=0, reserve_upper_rows=0):
         d = _Desc(dim=self.dim, metric=self.metric, dtype=dtype, float_kernel=float_kernel, n=0, m=m, m0=m0, has_entry=0,
                   max_layer=0, entry_point=0, shard_id_lo=0, shard_id_hi=0, device=device, max_batch=max_batch)
         h = _vp()
-        _check(lib().hvx_hydrator_finish(self._h, C.byref(d), C.byref(h)))
+        if reserve_rows or reserve_upper_rows:
+            L = lib()
+            L.hvx_hydrator_finish_reserve.restype = C.c_int
+            L.hvx_hydrator_finish_reserve.argtypes = [_vp, C.POINTER(_Desc), C.c_uint64, C.c_uint64, C.POINTER(_vp)]
+            _check(L.hvx_hydrator_finish_reserve(self._h, C.byref(d), int(reserve_rows), int(reserve_upper_rows), C.byref(h)))
+        else:
+            _check(lib().hvx_hydrator_finish(self._h, C.byref(d), C.byref(h)))
         return ValidatedVectorReadIndex(h, self.dim, self.metric, -1)

@@ -643,6 +643,8 @@ int hvx_hydrator_set_entry(hvx_hydrator *, uint64_t entry_point, uint32_t max_la
 int hvx_hydrator_set_metadata(hvx_hydrator *, const uint8_t *value, size_t len);
 /* `tmpl` supplies dtype, float_kernel, m, m0, device, max_batch; the rest comes from the collected rows */
 int hvx_hydrator_finish(const hvx_hydrator *, const hvx_index_desc *tmpl, hvx_index **out);
+/* ... with spare capacity (hvx_index_import_reserve): the image a serving host hydrates at start-up and then feeds its writes to */
+int hvx_hydrator_finish_reserve(const hvx_hydrator *, const hvx_index_desc *tmpl, uint64_t reserve_rows, uint64_t reserve_upper_rows, hvx_index **out);
 
 /*
  * GPU-assisted HNSW build: the reference's insert path (mutation.rs:642-895 insert_with_mutation_cache /

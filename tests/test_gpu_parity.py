@@ -631,6 +631,17 @@ def test_hydration_from_persisted_rows_equals_direct_import(orc, hv):
     gix = hy.finish()
     q = rng.standard_normal((16, dim)).astype(np.float32)
     assert_hnsw_equal(orc, hv, oix, gix, q, 10, 64)
+    # round 6: the same rows hydrated WITH spare capacity (hvx_hydrator_finish_reserve) take the host's later writes: 40 more nodes
+    # inserted in the reference's order -- the grown image searches like the oracle that inserted the same nodes
+    more = rng.standard_normal((40, dim)).astype(np.float32)
+    mlv = fx.draw_levels(40, 16, seed=10)
+    mids = np.arange(40, dtype=np.uint64) + (int(ids[-1]) + 7)
+    gix2 = hy.finish(reserve_rows=40, reserve_upper_rows=int(mlv.sum()))
+    for i in range(40):
+        assert oix.insert(int(mids[i]), more[i], int(mlv[i])) == orc.OK
+    gix2.insert_batch(mids, more, mlv, ef_construction=60, sequential=True)
+    assert gix2.live_rows() == n + 40
+    assert_hnsw_equal(orc, hv, oix, gix2, np.vstack([q, more[:4]]), 10, 64)
 
 
 # ---------------------------------------------------------------------------------------------------------------

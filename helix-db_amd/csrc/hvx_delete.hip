@@ -14,20 +14,25 @@
 // then x's rows, item, SimHash row and entry-candidate rows are deleted and, when x was the entry point, the entry moves to the best
 // remaining entry candidate: highest layer first, then the smallest id (keys/vectors.rs:1097 [inv_layer:2][node_id:8]).
 //
-// Kernels per deleted node (no host synchronisation between them, or between the nodes of a batch):
-//   delete_scan_kernel    grid over every row slot: which rows hold x, per layer            (128-260 MB of rows at 1M nodes: ~50 us)
-//   delete_prep_kernel    one workgroup per layer: dedupe + sort the sources, unlink x, collect C (a bitmap marks membership)
-//   delete_rank_kernel    workgroups x layers: for every source its distances to all of C in the reference's summation order
-//                         (group_distance) and the Mmax smallest in Candidate order (model.rs:55-61) -- independent of the graph, so
-//                         this part, the bulk of the arithmetic, runs in parallel over the sources
-//   delete_relink_kernel  one wavefront per layer: the relinks IN ORDER (a relink reads rows earlier relinks of the same delete changed),
-//                         each a merge + at most one prune of <= 64 ids + the reciprocal rows; then x's own row is emptied and its
-//                         deleted bit set
+// Kernels per deleted node (one host read-back per node: the number of relink steps, behind the prep kernel, while the ranking runs):
+//   delete_scan_kernel        grid over every row slot: which rows hold x, per layer         (128-260 MB of rows at 1M nodes: ~50 us)
+//   delete_prep_kernel        one workgroup per layer: dedupe + sort the sources, unlink x, collect C (a bitmap marks membership)
+//   delete_rank_kernel        workgroups x layers: for every source its distances to all of C in the reference's summation order and
+//                             the Mmax smallest in Candidate order (model.rs:55-61) -- independent of the graph, so this part runs in
+//                             parallel over the sources (sixteen wavefronts per source, register top lists)
+//   delete_step_fused_kernel  ONE launch per relinked row (round 6, below): all prunes' distance matrices evaluated up front over the
+//                             layer's workgroups, the last workgroup replays select_diverse from registers; NARROW (rows <= 34 ids) and
+//                             WIDE (rows <= 64 ids: M 32 / M0 64 graphs) builds, f32 and bf16 rows.  The relinks happen IN ORDER (a relink
+//                             reads rows earlier relinks of the same delete changed): one step after the other on the stream
+//   delete_step_own / _recip  the same step as two launches (HVX_OPT_DELETE_SEQUENTIAL = 2)
+//   delete_relink_kernel      one wavefront per layer: empties x's own rows and sets its deleted bit; with HVX_OPT_DELETE_SEQUENTIAL = 1
+//                             it also runs every relink itself (lazy select_diverse: the round-5 first build, 26.9 ms per delete)
 // A deleted node keeps its row slot: unreachable (nothing links to it, the entry point is repaired), absent from every id -> row
 // lookup (hvx_index::find), from exact scans (they run over the live rows, hvx_index::ensure_live), from the SimHash directory, the
 // prefilter's candidate mapping and the audit.  Sequential semantics: the nodes of a batch are deleted one after the other, and
 // the rows equal the CPU restatement's sequential deletes row for row -- tests/test_gpu_delete.py.
-// Limits (exceeded => HVX_ERR_UNSUPPORTED, loudly): 4 096 rows holding one node per layer, 16 384 candidates per layer.
+// Limits (exceeded => HVX_ERR_UNSUPPORTED, loudly): 4 096 rows holding one node per layer, 16 384 candidates per layer, rows of more than
+// 64 ids, fp8 images.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
